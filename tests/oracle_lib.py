@@ -1,0 +1,122 @@
+"""ctypes binding for the CPU oracle (oracle/libam_oracle.so) -- test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libam_oracle.so")
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "am_oracle.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIB)
+        L.amo_replay.restype = ctypes.c_void_p
+        L.amo_replay.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+        L.amo_patch_json.restype = ctypes.c_void_p
+        L.amo_patch_json.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.c_size_t]
+        L.amo_free.argtypes = [ctypes.c_void_p]
+        L.amo_sha256.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        for name, rt in [("amo_num_changes", ctypes.c_uint32), ("amo_num_applied", ctypes.c_uint32),
+                         ("amo_num_ops", ctypes.c_uint64), ("amo_max_op", ctypes.c_uint64),
+                         ("amo_num_actors", ctypes.c_uint32), ("amo_num_rows", ctypes.c_uint64)]:
+            getattr(L, name).restype = rt
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+        L.amo_change_hashes.restype = ctypes.c_void_p
+        L.amo_change_hashes.argtypes = [ctypes.c_void_p]
+        L.amo_actor.restype = ctypes.c_void_p
+        L.amo_actor.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        L.amo_rows.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 7
+        _lib = L
+    return _lib
+
+
+class OracleError(Exception):
+    pass
+
+
+def sha256(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    buf = ctypes.create_string_buffer(data, len(data))
+    lib().amo_sha256(buf, len(data), out)
+    return out.raw
+
+
+class OracleDoc:
+    """Backend.loadChanges(Backend.init(), changes) as restated by the oracle."""
+
+    def __init__(self, log):
+        L = lib()
+        self._arena = np.ascontiguousarray(log.arena, dtype=np.uint8)
+        self._offsets = np.ascontiguousarray(log.offsets, dtype=np.uint64)
+        err = ctypes.create_string_buffer(512)
+        self._h = L.amo_replay(self._arena.ctypes.data, self._offsets.ctypes.data, len(self._offsets) - 1, err, 512)
+        if not self._h:
+            raise OracleError(err.value.decode())
+
+    def patch_json(self) -> str:
+        L = lib()
+        n = ctypes.c_size_t()
+        err = ctypes.create_string_buffer(512)
+        p = L.amo_patch_json(self._h, ctypes.byref(n), err, 512)
+        if not p:
+            raise OracleError(err.value.decode())
+        return ctypes.string_at(p, n.value).decode("utf-8")
+
+    @property
+    def n_ops(self):
+        return lib().amo_num_ops(self._h)
+
+    @property
+    def n_applied(self):
+        return lib().amo_num_applied(self._h)
+
+    @property
+    def max_op(self):
+        return lib().amo_max_op(self._h)
+
+    def hashes(self):
+        n = lib().amo_num_changes(self._h)
+        p = lib().amo_change_hashes(self._h)
+        return np.frombuffer(ctypes.string_at(p, 32 * n), dtype=np.uint8).reshape(n, 32).copy()
+
+    def actors(self):
+        out = []
+        for i in range(lib().amo_num_actors(self._h)):
+            ln = ctypes.c_uint32()
+            p = lib().amo_actor(self._h, i, ctypes.byref(ln))
+            out.append(ctypes.string_at(p, ln.value))
+        return out
+
+    def rows(self):
+        n = lib().amo_num_rows(self._h)
+        a = dict(id_ctr=np.zeros(n, np.uint64), id_actor=np.zeros(n, np.uint32), obj_ctr=np.zeros(n, np.uint64),
+                 obj_actor=np.zeros(n, np.uint32), insert=np.zeros(n, np.uint8), action=np.zeros(n, np.uint32),
+                 succ_num=np.zeros(n, np.uint32))
+        lib().amo_rows(self._h, *[a[k].ctypes.data for k in
+                                  ("id_ctr", "id_actor", "obj_ctr", "obj_actor", "insert", "action", "succ_num")])
+        return a
+
+    def close(self):
+        if self._h:
+            lib().amo_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
