@@ -1,0 +1,23 @@
+"""Golden fixtures: outputs of the unmodified reference JS backend (see oracle/js/make_golden.js)."""
+import base64
+import glob
+import json
+import os
+
+from automerge_classic_amd.loggen import ChangeLog
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixture_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.json")))
+
+
+def load_fixture(name):
+    with open(os.path.join(GOLDEN_DIR, name + ".json")) as f:
+        fx = json.load(f)
+    changes = [base64.b64decode(c) for c in fx["changes"]]
+    fx["log"] = ChangeLog.from_changes(changes, name=name)
+    # the patch the engine/oracle must reproduce: the stock reference, unless its block-boundary defect fired
+    fx["expected"] = fx["patch"] if fx.get("stock_equals_bigblock", True) else fx["patch_bigblock"]
+    return fx
