@@ -1,0 +1,40 @@
+// Device-side common definitions for the MI355X replay engine (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Kernels whose threads never synchronise (no __syncthreads, no wave intrinsics) are launched through this
+// macro; on the GPU it is an ordinary launch. (The CPU test harness in tests/emu/ supplies its own definition
+// so such kernels can be run as a plain loop; that harness is not part of the product.)
+#ifndef AM355_LAUNCH_INDEPENDENT
+#define AM355_LAUNCH_INDEPENDENT(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+#endif
+
+namespace am355 {
+
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;  // 4 waves: one per SIMD of a CU
+
+// validity / support flags raised by kernels (OR-ed into one word; any bit set => the caller must not trust
+// the result and the JS host re-runs the call on the reference path to raise the exact exception)
+enum Flag : uint32_t {
+  F_BAD_MAGIC = 1u << 0,        // columnar.js:689
+  F_BAD_CHECKSUM = 1u << 1,     // columnar.js:703
+  F_BAD_CHUNK = 1u << 2,        // columnar.js:746-747 (trailing data / wrong chunk type / truncated)
+  F_BAD_COLUMNS = 1u << 3,      // columnar.js:609-624, 752-754
+  F_BAD_LEB = 1u << 4,          // encoding.js:389-408 range / truncation
+  F_BAD_RLE = 1u << 5,          // encoding.js:865-887 run rules
+  F_BAD_ROW = 1u << 6,          // new.js:715-723 obj/key pairing, actor index out of range
+  F_UNKNOWN_OBJECT = 1u << 7,   // op names an object that no applied make op created
+  F_BAD_ELEM = 1u << 8,         // new.js:278,1165 reference element / list element not found
+  F_BAD_PRED = 1u << 9,         // new.js:1256 no matching operation for pred
+  F_DUP_OPID = 1u << 10,        // new.js:1220
+  F_BAD_COUNTER = 1u << 11,     // new.js:954-956 increment for unknown counter
+  F_UNSUPPORTED = 1u << 12,     // legal input outside what the GPU path serves (documented in DESIGN.md)
+  F_OVERFLOW = 1u << 13,        // counters/offsets beyond the engine's 32-bit fields
+};
+
+__device__ __forceinline__ uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
+
+}  // namespace am355

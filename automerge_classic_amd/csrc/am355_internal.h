@@ -1,0 +1,54 @@
+// Shared host/device data layout of the replay engine.
+#pragma once
+#include "am355_device.h"
+
+namespace am355 {
+
+// column slots of a change (reference: backend/columnar.js:56-78 CHANGE_COLUMNS)
+enum ColSlot { C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_KEY_STR, C_INSERT, C_ACTION, C_VAL_LEN, C_VAL_RAW, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR, C_NUM };
+
+// One record per binary change, written by k_parse_changes (device) and read by the host scheduler.
+// Offsets are relative to `base` (the change's first byte in the raw arena).
+struct ChangeMeta {
+  uint64_t base;
+  uint32_t len;
+  uint32_t flags;
+  uint8_t hash[32];
+  uint64_t seq, start_op;
+  uint32_t n_deps, deps_off;
+  uint32_t actor_off, actor_len;
+  uint32_t n_other, others_off;
+  uint32_t col_off[C_NUM], col_len[C_NUM];
+  uint32_t n_ops, n_preds;
+};
+
+// Per-change launch parameters produced by the host scheduler for the decode kernels (applied changes only)
+struct ChangePlan {
+  uint32_t change;     // index into ChangeMeta[]
+  uint32_t op_base;    // first row of this change in the op arrays
+  uint32_t pred_base;  // first entry in the pred arrays
+  uint32_t amap_base;  // first entry of its local->global actor translation table
+  uint32_t author;     // global actor rank of the author
+  uint32_t n_actors;   // entries in its actor table
+};
+
+// Per-actor lookup table entry for opId -> row resolution: the applied changes of one actor, ascending start_op
+struct ActorSpan {
+  uint32_t start_op, n_ops, op_base;
+};
+
+// Fixed-width op rows (structure of arrays, one u32 per field per op; reference row layout new.js:10-12).
+// Actor fields hold GLOBAL actor ranks (lexicographic rank of the raw actor id among all actors of the
+// batch), so comparing (ctr, actor) pairs numerically equals the reference's (counter, actorId string) order.
+struct OpCols {
+  uint32_t *obj_actor, *obj_ctr;      // obj_actor == NONE32: _root
+  uint32_t *key_actor, *key_ctr;      // key_ctr == NONE32: no element key; key_ctr == 0: _head
+  uint32_t *key_off, *key_len;        // key_len == NONE32: no string key; key_off is an absolute arena offset
+  uint32_t *action, *val_tl, *val_off; // val_tl = (len << 4) | type tag; val_off absolute arena offset
+  uint32_t *pred_first, *pred_num;
+  uint32_t *id_ctr, *id_actor;
+  uint8_t* insert;
+  uint32_t *pred_actor, *pred_ctr;    // flattened pred lists
+};
+
+}  // namespace am355

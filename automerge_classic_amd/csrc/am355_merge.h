@@ -1,0 +1,77 @@
+// Stage 2 of the replay engine: op-set merge and whole-document patch IR (see am355_merge.hip).
+#pragma once
+#include "am355_internal.h"
+#include <stddef.h>
+
+namespace am355 {
+
+// counters produced on the device and read back once by the host to size the later launches
+struct Counts {
+  uint32_t flags;        // OR of Flag bits raised by any kernel
+  uint32_t n_map_emit;   // visible map/table values
+  uint32_t n_list_ins;   // insert rows in list/text objects (RGA tree nodes)
+  uint32_t n_list_upd;   // visible non-insert values on list elements
+  uint32_t n_objects;    // make* rows (+1 for _root)
+  uint32_t max_key_len;  // longest map key among emitted values
+  uint32_t n_edits;      // list edit records
+  uint32_t pad;
+};
+
+// Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.
+struct MergeBufs {
+  // inputs
+  const uint8_t* arena;
+  OpCols ops;
+  uint32_t n_ops, n_preds, n_actors;
+  const uint32_t* actor_tab_off;  // [n_actors + 1] into spans
+  const ActorSpan* spans;
+  uint32_t bits_ctr, bits_actor;  // key widths: bits(max op counter), bits(n_actors)
+  // per-row results
+  uint32_t *obj_row, *ref_row, *succ_cnt, *inc_cnt, *val_cnt, *obj_index;
+  unsigned long long *inc_sum, *last_inc;
+  uint8_t* kind;
+  // compaction targets
+  uint32_t *em_row;                 // [N] map emissions (rows), later sorted
+  unsigned long long* em_trig;      // [N] trigger op id of each map emission (packed ctr<<32|actor)
+  uint32_t *ins_row;                // [N] list insert rows
+  uint32_t *upd_row;                // [N] visible list update rows
+  // sort scratch (sized for N pairs)
+  uint64_t *key_a, *key_b;
+  uint32_t *val_a, *val_b;
+  void* sort_ws;
+  // RGA
+  uint32_t *first_child;            // [2N] indexed by parent_row*2 + is_head
+  uint32_t *next_sib;               // [N]
+  uint32_t *succ_a, *succ_b, *dist_a, *dist_b;  // [2N+2] Euler tour list ranking
+  uint32_t *order;                  // [N] node rows in document order (all list objects chained)
+  uint32_t *scan_a, *scan_b;        // [N+1] prefix sums over `order`
+  uint32_t *obj_first_pos;          // [n_objects] position in `order` of the first element of each list object
+  void* scan_ws;
+  Counts* counts;                   // device
+};
+
+// ---- patch IR in device memory (the output of the hot path) ---------------------------------------------
+struct PatchIR {
+  // objects: index 0 is _root, then make rows in row order
+  uint32_t *obj_make_row;   // [n_objects] row of the make op (NONE32 for root)
+  uint32_t *obj_map_begin, *obj_map_end;    // range in the map emission arrays
+  uint32_t *obj_edit_begin, *obj_edit_end;  // range in the edit arrays
+  // map emissions sorted by (object, key, trigger op)
+  uint32_t *m_row;          // [n_map_emit] row whose value is shown (for counters: the `set` row)
+  long long *m_counter;     // [n_map_emit] counter total when m_flags&1
+  uint32_t *m_flags;        // bit0: counter value, bit1: child object
+  // list edits in document order
+  uint32_t *e_row;          // [n_edits] row holding the value (its id is the edit's opId)
+  uint32_t *e_elem;         // [n_edits] row of the element (its id is the elemId)
+  uint32_t *e_index;        // [n_edits] list index
+  uint32_t *e_flags;        // bit0: update (else insert), bit1: continues the multi-insert run of the previous edit, bit2: child object
+};
+
+size_t merge_scratch_pairs(uint32_t n_ops);
+
+// Runs resolve -> emit; fills counts (device) and copies them to *h_counts (synchronises the stream once).
+void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st);
+// Runs object indexing, map emission ordering, RGA ordering, edit generation. Needs *h_counts from phase 1.
+void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st);
+
+}  // namespace am355

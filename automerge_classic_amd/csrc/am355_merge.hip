@@ -1,0 +1,567 @@
+// Stage 2 of the replay engine: per-object op-set merge, RGA list ordering, multi-value register resolution and
+// whole-document patch IR, as data-parallel kernels over the fixed-width op rows produced by stage 1.
+//
+// Reference semantics reproduced (automerge-classic, paths relative to the reference tree; derived spec in
+// SURVEY.md Appendix B):
+//   op placement      backend/new.js:50-192 seekWithinBlock (object order, key order, RGA insertion rule :144-163)
+//   pred -> succ      backend/new.js:1173-1188, 1205-1217 (del = succ entries only), 1252-1258 (pred must match)
+//   visibility        backend/new.js:904 (overwritten iff succNum > 0), 1622-1626 (list index bookkeeping)
+//   counters          backend/new.js:937-967
+//   list edits        backend/new.js:983-1033 (whole-document branches), 747-782 appendEdit (multi-insert runs)
+//   map props         backend/new.js:1035-1039
+//
+// The reference merges one op-run at a time into RLE-compressed 600-op blocks (new.js:1304-1380); nothing of
+// that machinery exists here. Instead: op ids resolve to rows by arithmetic (each change owns a contiguous
+// counter range), succ counts are atomics, the RGA order of every list is the pre-order of the insertion tree
+// (parent = reference element, siblings by descending op id) obtained by one radix sort + Euler-tour list
+// ranking, and visibility / list indexes / edit positions are prefix sums over that order.
+#include "am355_merge.h"
+#include "am355_prims.h"
+
+namespace am355 {
+
+enum Kind : uint8_t { K_NONE = 0, K_MAP = 1, K_LIST_INS = 2, K_LIST_UPD = 3, K_DEL = 4 };
+
+__device__ __forceinline__ uint32_t row_of(const MergeBufs& b, uint32_t actor, uint32_t ctr) {
+  if (actor >= b.n_actors) return NONE32;
+  uint32_t first = b.actor_tab_off[actor], lo = first, hi = b.actor_tab_off[actor + 1];
+  while (lo < hi) {  // first span with start_op > ctr
+    uint32_t mid = (lo + hi) >> 1;
+    if (b.spans[mid].start_op <= ctr) lo = mid + 1; else hi = mid;
+  }
+  if (lo == first) return NONE32;
+  ActorSpan s = b.spans[lo - 1];
+  uint32_t d = ctr - s.start_op;
+  return d < s.n_ops ? s.op_base + d : NONE32;
+}
+
+__device__ __forceinline__ unsigned long long pack_id(uint32_t ctr, uint32_t actor) { return (unsigned long long)ctr << 32 | actor; }
+
+// element a non-insert list row refers to / an insert row creates
+__device__ __forceinline__ uint32_t elem_of(const MergeBufs& b, uint32_t row) {
+  if (b.ops.insert[row]) return row;
+  if (b.ops.key_ctr[row] == NONE32 || b.ops.key_ctr[row] == 0) return NONE32;
+  return row_of(b, b.ops.key_actor[row], b.ops.key_ctr[row]);
+}
+
+__device__ __forceinline__ bool same_obj(const MergeBufs& b, uint32_t r1, uint32_t r2) {
+  return b.ops.obj_actor[r1] == b.ops.obj_actor[r2] && b.ops.obj_ctr[r1] == b.ops.obj_ctr[r2];
+}
+
+__device__ __forceinline__ bool same_key(const MergeBufs& b, uint32_t r1, uint32_t r2) {
+  uint32_t l1 = b.ops.key_len[r1], l2 = b.ops.key_len[r2];
+  if (l1 == NONE32 || l1 != l2) return false;
+  const uint8_t *p = b.arena + b.ops.key_off[r1], *q = b.arena + b.ops.key_off[r2];
+  for (uint32_t k = 0; k < l1; k++)
+    if (p[k] != q[k]) return false;
+  return true;
+}
+
+// sLEB / uLEB value of an integer-typed op value (tags 3 uint, 4 int, 8 counter, 9 timestamp); columnar.js:300-329
+__device__ __forceinline__ bool int_value(const MergeBufs& b, uint32_t row, long long& out) {
+  uint32_t tl = b.ops.val_tl[row], tag = tl & 15, len = tl >> 4;
+  if (!(tag == 3 || tag == 4 || tag == 8 || tag == 9) || len == 0 || len > 10) return false;
+  const uint8_t* p = b.arena + b.ops.val_off[row];
+  unsigned long long v = 0;
+  int shift = 0;
+  for (uint32_t k = 0; k < len; k++) {
+    uint32_t byte = p[k];
+    v |= (unsigned long long)(byte & 0x7f) << shift;
+    shift += 7;
+    if (!(byte & 0x80)) {
+      if (tag != 3 && (byte & 0x40) && shift < 64) v |= ~0ull << shift;
+      out = (long long)v;
+      return true;
+    }
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_resolve: one lane per op row.  Object / element / pred resolution and validation, succ counting.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const OpCols& o = b.ops;
+  uint32_t err = 0;
+  uint32_t a = o.action[g];
+  bool ins = o.insert[g] != 0;
+  unsigned long long my_id = pack_id(o.id_ctr[g], o.id_actor[g]);
+
+  uint32_t orow = NONE32;
+  bool list_obj = false;
+  if (o.obj_actor[g] != NONE32) {
+    orow = row_of(b, o.obj_actor[g], o.obj_ctr[g]);
+    if (orow == NONE32 || (o.action[orow] & 1)) { err |= F_UNKNOWN_OBJECT; orow = NONE32; }
+    else {
+      uint32_t oa = o.action[orow];
+      list_obj = (oa == 2 || oa == 4);
+      if (pack_id(o.id_ctr[orow], o.id_actor[orow]) >= my_id) err |= F_UNSUPPORTED;
+    }
+  }
+  bool has_str = o.key_len[g] != NONE32, has_elem = o.key_ctr[g] != NONE32;
+  uint8_t kind = K_NONE;
+  uint32_t ref = NONE32;
+  if (has_str == has_elem) {
+    err |= has_str ? F_UNSUPPORTED : F_BAD_ROW;
+  } else if (has_str) {
+    if (list_obj || ins) err |= F_UNSUPPORTED;  // the reference would crash building the patch
+    kind = a == 3 ? K_DEL : K_MAP;
+  } else {
+    if (!list_obj) err |= F_UNSUPPORTED;
+    if (o.key_ctr[g] != 0) {
+      ref = row_of(b, o.key_actor[g], o.key_ctr[g]);
+      if (ref == NONE32 || !o.insert[ref] || !same_obj(b, ref, g) || o.key_len[ref] != NONE32) { err |= F_BAD_ELEM; ref = NONE32; }
+      else if (pack_id(o.id_ctr[ref], o.id_actor[ref]) >= my_id) err |= F_UNSUPPORTED;
+    } else if (!ins) {
+      err |= F_UNSUPPORTED;  // non-insert on _head
+    }
+    if (ins) {
+      kind = K_LIST_INS;
+      if (o.pred_num[g]) err |= F_BAD_PRED;  // an insert never finds its preds (new.js:1252-1258)
+    } else {
+      kind = a == 3 ? K_DEL : K_LIST_UPD;
+    }
+    if (a == 5) err |= F_UNSUPPORTED;  // counters inside lists (reference quirk)
+  }
+  if (a == 3 && o.pred_num[g] == 0) err |= F_UNSUPPORTED;
+
+  uint32_t np = o.pred_num[g], pf = o.pred_first[g];
+  for (uint32_t j = 0; j < np && !(err & (F_BAD_PRED | F_BAD_ROW)); j++) {
+    uint32_t pa = o.pred_actor[pf + j], pc = o.pred_ctr[pf + j];
+    for (uint32_t k = 0; k < j; k++)
+      if (o.pred_actor[pf + k] == pa && o.pred_ctr[pf + k] == pc) err |= F_BAD_PRED;  // second copy never matches
+    uint32_t pr = row_of(b, pa, pc);
+    if (pr == NONE32 || o.action[pr] == 3 || !same_obj(b, pr, g)) { err |= F_BAD_PRED; continue; }
+    bool same_slot = has_str ? same_key(b, pr, g) : (!has_str && o.key_len[pr] == NONE32 && ref != NONE32 && elem_of(b, pr) == ref && !ins);
+    if (!same_slot) { err |= F_BAD_PRED; continue; }
+    if (pack_id(pc, pa) >= my_id) err |= F_UNSUPPORTED;
+    atomicAdd(&b.succ_cnt[pr], 1u);
+    if (a == 5) {
+      // inc: its pred must be the counter's `set` op (new.js:937-967)
+      uint32_t ptl = o.val_tl[pr];
+      long long v;
+      if (o.action[pr] != 1 || (ptl & 15) != 8) err |= F_BAD_COUNTER;
+      else if (np != 1 || !int_value(b, g, v)) err |= F_UNSUPPORTED;
+      else {
+        atomicAdd(&b.inc_cnt[pr], 1u);
+        atomicAdd(&b.inc_sum[pr], (unsigned long long)v);
+        atomicMax(&b.last_inc[pr], my_id);
+      }
+    }
+  }
+  if (a == 5 && np == 0) err |= F_BAD_COUNTER;
+  b.obj_row[g] = orow;
+  b.ref_row[g] = ref;
+  b.kind[g] = kind;
+  if (err) atomicOr(&b.counts->flags, err);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_emit: one lane per op row, after all succ counts are final.  Classifies visible values.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const OpCols& o = b.ops;
+  uint8_t kind = b.kind[g];
+  uint32_t a = o.action[g];
+  bool is_make = kind != K_DEL && kind != K_NONE && (a & 1) == 0;
+  b.obj_index[g] = is_make ? 1u : 0u;  // scanned later
+  if (kind == K_NONE || kind == K_DEL) return;
+  bool vis = b.succ_cnt[g] == 0;
+  uint32_t tl = o.val_tl[g];
+  if (kind == K_MAP) {
+    unsigned long long trig = 0;
+    bool emit = false;
+    if (a == 1) {
+      if (vis) { emit = true; trig = pack_id(o.id_ctr[g], o.id_actor[g]); }
+      else if ((tl & 15) == 8 && b.inc_cnt[g] == b.succ_cnt[g]) { emit = true; trig = b.last_inc[g]; }  // every succ is an inc
+    } else if ((a & 1) == 0) {
+      if (vis) { emit = true; trig = pack_id(o.id_ctr[g], o.id_actor[g]); }
+    }
+    if (emit) {
+      uint32_t slot = atomicAdd(&b.counts->n_map_emit, 1u);
+      b.em_row[slot] = g;
+      b.em_trig[slot] = trig;
+      atomicMax(&b.counts->max_key_len, o.key_len[g]);
+    }
+  } else {
+    bool valued = (a == 1) || (a & 1) == 0;
+    if (kind == K_LIST_INS) b.ins_row[atomicAdd(&b.counts->n_list_ins, 1u)] = g;
+    if (vis && !valued) { atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED); return; }  // value-less visible row: reference 'remove' quirk
+    if (vis) {
+      uint32_t el = kind == K_LIST_INS ? g : b.ref_row[g];
+      if (el != NONE32) {
+        atomicAdd(&b.val_cnt[el], 1u);
+        if (kind == K_LIST_UPD) b.upd_row[atomicAdd(&b.counts->n_list_upd, 1u)] = g;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint32_t* __restrict__ is_make_ex, PatchIR ir) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  uint8_t kind = b.kind[g];
+  bool is_make = kind != K_DEL && kind != K_NONE && (b.ops.action[g] & 1) == 0;
+  uint32_t idx = is_make_ex[g] + 1;  // 0 is _root
+  if (is_make) { ir.obj_make_row[idx] = g; b.obj_index[g] = idx; }
+  else b.obj_index[g] = NONE32;
+  if (g == 0) ir.obj_make_row[0] = NONE32;
+}
+
+__device__ __forceinline__ uint32_t obj_index_of(const MergeBufs& b, uint32_t make_row) { return make_row == NONE32 ? 0 : b.obj_index[make_row]; }
+
+// ---------------------------------------------------------------------------------------------------------
+// map emissions: ordered by (object, key in UTF-16 code unit order, trigger op id) with stable LSD passes
+// ---------------------------------------------------------------------------------------------------------
+enum MapKeyMode { MK_TRIGGER, MK_LEN, MK_CHUNK, MK_OBJECT };
+
+// JS compares strings by UTF-16 code units (new.js:84). On valid UTF-8 that equals byte order except that
+// supplementary-plane characters (lead bytes F0..F4) sort below U+E000..U+FFFF (lead bytes EE, EF): remap.
+__device__ __forceinline__ uint32_t utf16_order_byte(uint32_t x) {
+  if (x >= 0xf0 && x <= 0xf4) return x - 2;
+  if (x == 0xee || x == 0xef) return x + 5;
+  return x;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_map_keys(MergeBufs b, const uint32_t* __restrict__ perm, uint64_t* __restrict__ keys, uint32_t n,
+                                                    int mode, uint32_t chunk) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t e = perm[i], g = b.em_row[e];
+  uint64_t k = 0;
+  if (mode == MK_TRIGGER) {
+    unsigned long long t = b.em_trig[e];
+    k = (uint64_t)(t >> 32) << b.bits_actor | (uint32_t)t;
+  } else if (mode == MK_LEN) {
+    k = b.ops.key_len[g];
+  } else if (mode == MK_CHUNK) {
+    const uint8_t* p = b.arena + b.ops.key_off[g];
+    uint32_t len = b.ops.key_len[g], start = chunk * 8;
+    for (uint32_t j = 0; j < 8; j++) {
+      uint32_t x = start + j < len ? utf16_order_byte(p[start + j]) : 0;
+      k = k << 8 | x;
+    }
+  } else {
+    k = obj_index_of(b, b.obj_row[g]);
+  }
+  keys[i] = k;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* __restrict__ v, uint32_t n) {
+  uint32_t i = gtid();
+  if (i < n) v[i] = i;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_t* __restrict__ perm, uint32_t n, PatchIR ir) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t e = perm[i], g = b.em_row[e];
+  uint32_t a = b.ops.action[g];
+  uint32_t flags = 0;
+  long long counter = 0;
+  if (a == 1 && b.succ_cnt[g] != 0) {
+    flags |= 1;
+    long long base = 0;
+    if (!int_value(b, g, base)) atomicOr(&b.counts->flags, (uint32_t)F_BAD_LEB);
+    counter = base + (long long)b.inc_sum[g];
+  } else if ((a & 1) == 0) {
+    flags |= 2;
+  }
+  ir.m_row[i] = g;
+  ir.m_flags[i] = flags;
+  ir.m_counter[i] = counter;
+  uint32_t oi = obj_index_of(b, b.obj_row[g]);
+  uint32_t prev = i > 0 ? obj_index_of(b, b.obj_row[b.em_row[perm[i - 1]]]) : NONE32;
+  uint32_t next = i + 1 < n ? obj_index_of(b, b.obj_row[b.em_row[perm[i + 1]]]) : NONE32;
+  if (oi != prev) ir.obj_map_begin[oi] = i;
+  if (oi != next) ir.obj_map_end[oi] = i + 1;
+}
+
+static int bits_for(uint64_t max_value) {
+  int b = 1;
+  while (b < 64 && (max_value >> b)) b++;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RGA order of all list/text objects
+// ---------------------------------------------------------------------------------------------------------
+struct ListKeyBits {
+  int b_row, b_ctr, b_actor;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_list_keys(MergeBufs b, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n, ListKeyBits kb) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t g = b.ins_row[i];
+  uint32_t ref = b.ref_row[g];
+  uint64_t is_head = ref == NONE32 ? 1 : 0;
+  uint64_t parent = is_head ? b.obj_row[g] : ref;  // head children are grouped under their object's make row
+  uint64_t mask_c = (1ull << kb.b_ctr) - 1, mask_a = (1ull << kb.b_actor) - 1;
+  // siblings in DESCENDING op id order: complement the id bits
+  uint64_t k = is_head << (kb.b_row + kb.b_ctr + kb.b_actor) | parent << (kb.b_ctr + kb.b_actor) | (~(uint64_t)b.ops.id_ctr[g] & mask_c) << kb.b_actor |
+               (~(uint64_t)b.ops.id_actor[g] & mask_a);
+  keys[i] = k;
+  vals[i] = g;
+}
+
+// after the sort: sibling links, first children, start of the chained document order
+__global__ __launch_bounds__(BLOCK) void k_list_link(MergeBufs b, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                                     ListKeyBits kb, uint32_t* __restrict__ start_node) {
+  uint32_t j = gtid();
+  if (j >= n) return;
+  int sh = kb.b_ctr + kb.b_actor;
+  uint64_t pk = keys[j] >> sh;
+  uint32_t v = vals[j];
+  bool is_head = (pk >> kb.b_row) != 0;
+  bool first = j == 0 || (keys[j - 1] >> sh) != pk;
+  bool last = j + 1 == n || (keys[j + 1] >> sh) != pk;
+  if (first) {
+    uint32_t parent = (uint32_t)(pk & ((1ull << kb.b_row) - 1));
+    b.first_child[(size_t)parent * 2 + (is_head ? 1 : 0)] = v;
+  }
+  // head children of successive list objects are chained so that one ranking pass orders every list at once
+  b.next_sib[v] = (!last || (is_head && j + 1 < n)) ? vals[j + 1] : NONE32;
+  if (is_head && (j == 0 || (keys[j - 1] >> (sh + kb.b_row)) == 0)) *start_node = v;
+}
+
+// Euler tour of the insertion forest: enter(v) = 2v, leave(v) = 2v+1; END = 2N
+__global__ __launch_bounds__(BLOCK) void k_euler_init(MergeBufs b, uint32_t n, uint32_t* __restrict__ succ, uint32_t* __restrict__ dist) {
+  uint32_t i = gtid();
+  uint32_t END = 2 * b.n_ops;
+  if (i == 0) { succ[END] = END; dist[END] = 0; }
+  if (i >= n) return;
+  uint32_t v = b.ins_row[i];
+  uint32_t fc = b.first_child[(size_t)v * 2];
+  succ[2 * v] = fc != NONE32 ? 2 * fc : 2 * v + 1;
+  dist[2 * v] = 1;
+  uint32_t ns = b.next_sib[v], ref = b.ref_row[v];
+  succ[2 * v + 1] = ns != NONE32 ? 2 * ns : (ref != NONE32 ? 2 * ref + 1 : END);
+  dist[2 * v + 1] = 0;
+}
+
+// one pointer-jumping round (Wyllie): dist'[x] = dist[x] + dist[succ[x]], succ'[x] = succ[succ[x]]
+__global__ __launch_bounds__(BLOCK) void k_euler_jump(MergeBufs b, uint32_t n, const uint32_t* __restrict__ succ, const uint32_t* __restrict__ dist,
+                                                      uint32_t* __restrict__ succ2, uint32_t* __restrict__ dist2) {
+  uint32_t i = gtid();
+  uint32_t END = 2 * b.n_ops;
+  if (i == 0) { succ2[END] = END; dist2[END] = 0; }
+  if (i >= 2 * n) return;
+  uint32_t x = 2 * b.ins_row[i >> 1] + (i & 1);
+  uint32_t s = succ[x];
+  dist2[x] = dist[x] + dist[s];
+  succ2[x] = succ[s];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, const uint32_t* __restrict__ dist) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t v = b.ins_row[i];
+  uint32_t d = dist[2 * v];  // enter-edges from enter(v) to the end, inclusive
+  if (d == 0 || d > n) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
+  b.order[n - d] = v;
+}
+
+// per position: visibility and value counts to be scanned; first position of each object
+__global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n, uint32_t* __restrict__ vis, uint32_t* __restrict__ cnt) {
+  uint32_t p = gtid();
+  if (p >= n) return;
+  uint32_t v = b.order[p];
+  if (v == NONE32) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); vis[p] = cnt[p] = 0; return; }
+  uint32_t c = b.val_cnt[v];
+  vis[p] = c ? 1 : 0;
+  cnt[p] = c;
+  uint32_t o = b.obj_row[v];
+  uint32_t prev = p ? b.order[p - 1] : NONE32;
+  if (p == 0 || prev == NONE32 || b.obj_row[prev] != o) b.obj_first_pos[obj_index_of(b, o)] = p;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_upd_keys(MergeBufs b, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t g = b.upd_row[i];
+  keys[i] = (uint64_t)b.ref_row[g] << (b.bits_ctr + b.bits_actor) | (uint64_t)b.ops.id_ctr[g] << b.bits_actor | b.ops.id_actor[g];
+  vals[i] = g;
+}
+
+// one lane per list position: write the element's edits (insert first, then updates in ascending op id)
+__global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, const uint32_t* __restrict__ vis_ex, const uint32_t* __restrict__ cnt_ex,
+                                                      const uint64_t* __restrict__ upd_keys, const uint32_t* __restrict__ upd_vals, uint32_t n_upd,
+                                                      PatchIR ir) {
+  uint32_t p = gtid();
+  if (p >= n) return;
+  uint32_t v = b.order[p];
+  if (v == NONE32) return;
+  uint32_t c = b.val_cnt[v];
+  if (p + 1 == n) b.counts->n_edits = cnt_ex[p] + c;
+  if (!c) return;
+  uint32_t oi = obj_index_of(b, b.obj_row[v]);
+  uint32_t index = vis_ex[p] - vis_ex[b.obj_first_pos[oi]];
+  uint32_t e = cnt_ex[p], k = 0;
+  uint32_t a = b.ops.action[v];
+  if (b.succ_cnt[v] == 0 && (a == 1 || (a & 1) == 0)) {
+    ir.e_row[e] = v; ir.e_elem[e] = v; ir.e_index[e] = index; ir.e_flags[e] = ((a & 1) == 0 ? 4u : 0u);
+    k = 1;
+  }
+  if (k < c) {
+    int sh = b.bits_ctr + b.bits_actor;
+    uint32_t lo = 0, hi = n_upd;
+    while (lo < hi) {  // first update record of element v
+      uint32_t mid = (lo + hi) >> 1;
+      if ((upd_keys[mid] >> sh) < v) lo = mid + 1; else hi = mid;
+    }
+    for (; k < c && lo < n_upd && (upd_keys[lo] >> sh) == v; k++, lo++) {
+      uint32_t u = upd_vals[lo];
+      ir.e_row[e + k] = u; ir.e_elem[e + k] = v; ir.e_index[e + k] = index;
+      ir.e_flags[e + k] = (k ? 1u : 0u) | ((b.ops.action[u] & 1) == 0 ? 4u : 0u);
+    }
+    if (k != c) atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM);
+  }
+}
+
+// value class compared by appendEdit's `datatype` and `typeof` tests (new.js:759-760, 768-769)
+__device__ __forceinline__ uint32_t value_class(uint32_t tl) {
+  uint32_t tag = tl & 15;
+  if (tl == 0) return 0;
+  if (tl == 1 || tl == 2) return 1;
+  if (tag == 6 || tag == 3 || tag == 4 || tag == 5 || tag == 8 || tag == 9) return tag;
+  return 16 + tag;
+}
+
+// multi-insert run detection (new.js:754-773) and per-object edit ranges
+__global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
+  uint32_t e = gtid();
+  uint32_t n = b.counts->n_edits;
+  if (e >= n) return;
+  const OpCols& o = b.ops;
+  uint32_t r = ir.e_row[e], el = ir.e_elem[e], f = ir.e_flags[e];
+  uint32_t oi = obj_index_of(b, b.obj_row[el]);
+  uint32_t prev_oi = NONE32, next_oi = NONE32;
+  if (e > 0) {
+    uint32_t pr = ir.e_row[e - 1], pel = ir.e_elem[e - 1], pf = ir.e_flags[e - 1];
+    prev_oi = obj_index_of(b, b.obj_row[pel]);
+    bool simple = !(f & 5) && r == el, psimple = !(pf & 5) && pr == pel;
+    if (simple && psimple && prev_oi == oi && o.id_actor[r] == o.id_actor[pr] && o.id_ctr[r] == o.id_ctr[pr] + 1 &&
+        value_class(o.val_tl[r]) == value_class(o.val_tl[pr]) && ir.e_index[e] == ir.e_index[e - 1] + 1)
+      ir.e_flags[e] = f | 2u;
+  }
+  if (e + 1 < n) next_oi = obj_index_of(b, b.obj_row[ir.e_elem[e + 1]]);
+  if (oi != prev_oi) ir.obj_edit_begin[oi] = e;
+  if (oi != next_oi) ir.obj_edit_end[oi] = e + 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
+
+void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st) {
+  uint32_t N = b.n_ops;
+  (void)hipMemsetAsync(b.counts, 0, sizeof(Counts), st);
+  (void)hipMemsetAsync(b.succ_cnt, 0, sizeof(uint32_t) * N, st);
+  (void)hipMemsetAsync(b.inc_cnt, 0, sizeof(uint32_t) * N, st);
+  (void)hipMemsetAsync(b.val_cnt, 0, sizeof(uint32_t) * N, st);
+  (void)hipMemsetAsync(b.inc_sum, 0, sizeof(unsigned long long) * N, st);
+  (void)hipMemsetAsync(b.last_inc, 0, sizeof(unsigned long long) * N, st);
+  if (N) {
+    AM355_LAUNCH_INDEPENDENT(k_resolve, grid_for(N), dim3(BLOCK), st, b);
+    AM355_LAUNCH_INDEPENDENT(k_emit, grid_for(N), dim3(BLOCK), st, b);
+  }
+  (void)hipMemcpyAsync(h_counts, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+}
+
+void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
+  uint32_t N = b.n_ops;
+  // ---- objects: dense index per make row (0 = _root) ----
+  uint32_t* is_make_ex = b.scan_a;
+  uint32_t* d_nobj = &b.counts->n_objects;
+  if (N) {
+    exclusive_scan_u32(b.obj_index, is_make_ex, N, d_nobj, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_object_table, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)is_make_ex, ir);
+  } else {
+    (void)hipMemsetAsync(ir.obj_make_row, 0xff, sizeof(uint32_t), st);
+  }
+  size_t obj_cap = (size_t)N + 1;
+  (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t) * obj_cap, st);
+  (void)hipMemsetAsync(ir.obj_map_end, 0, sizeof(uint32_t) * obj_cap, st);
+  (void)hipMemsetAsync(ir.obj_edit_begin, 0, sizeof(uint32_t) * obj_cap, st);
+  (void)hipMemsetAsync(ir.obj_edit_end, 0, sizeof(uint32_t) * obj_cap, st);
+
+  // ---- map emissions: LSD over (trigger id | key length | key chunks last..first | object) ----
+  uint32_t ne = hc->n_map_emit;
+  if (ne) {
+    uint32_t* perm_a = b.val_a;
+    uint32_t* perm_b = b.val_b;
+    AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
+    int cur = 0;
+    auto pass = [&](int mode, uint32_t chunk, int bits) {
+      uint32_t* pin = cur ? perm_b : perm_a;
+      uint64_t* kin = cur ? b.key_b : b.key_a;
+      AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk);
+      int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, 0, bits, b.sort_ws, st)
+                    : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, 0, bits, b.sort_ws, st);
+      cur ^= res;
+    };
+    if (ne > 1) {
+      pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
+      pass(MK_LEN, 0, bits_for(hc->max_key_len));
+      uint32_t chunks = (hc->max_key_len + 7) / 8;
+      for (uint32_t c = chunks; c-- > 0;) pass(MK_CHUNK, c, 64);
+      pass(MK_OBJECT, 0, bits_for(N + 1));
+    }
+    AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
+  }
+
+  // ---- lists ----
+  uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd;
+  if (ni) {
+    ListKeyBits kb{bits_for(N), (int)b.bits_ctr, (int)b.bits_actor};
+    int total_bits = 1 + kb.b_row + kb.b_ctr + kb.b_actor;  // <= 64 verified by the caller
+    (void)hipMemsetAsync(b.first_child, 0xff, sizeof(uint32_t) * 2 * (size_t)N, st);
+    (void)hipMemsetAsync(b.order, 0xff, sizeof(uint32_t) * ni, st);
+    uint32_t* d_start = &b.counts->pad;
+    AM355_LAUNCH_INDEPENDENT(k_list_keys, grid_for(ni), dim3(BLOCK), st, b, b.key_a, b.val_a, ni, kb);
+    int res = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, ni, 0, total_bits, b.sort_ws, st);
+    const uint64_t* sk = res ? b.key_b : b.key_a;
+    const uint32_t* sv = res ? b.val_b : b.val_a;
+    AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, sk, sv, ni, kb, d_start);
+    AM355_LAUNCH_INDEPENDENT(k_euler_init, grid_for(ni), dim3(BLOCK), st, b, ni, b.succ_a, b.dist_a);
+    int rounds = bits_for(2ull * ni + 1);
+    uint32_t *s0 = b.succ_a, *d0 = b.dist_a, *s1 = b.succ_b, *d1 = b.dist_b;
+    for (int r = 0; r < rounds; r++) {
+      AM355_LAUNCH_INDEPENDENT(k_euler_jump, grid_for(2 * ni), dim3(BLOCK), st, b, ni, (const uint32_t*)s0, (const uint32_t*)d0, s1, d1);
+      uint32_t* t;
+      t = s0; s0 = s1; s1 = t;
+      t = d0; d0 = d1; d1 = t;
+    }
+    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)d0);
+    // visibility / value-count prefix sums over document order
+    uint32_t* vis = b.scan_a;
+    uint32_t* cnt = b.scan_b;
+    AM355_LAUNCH_INDEPENDENT(k_list_counts, grid_for(ni), dim3(BLOCK), st, b, ni, vis, cnt);
+    exclusive_scan_u32(vis, vis, ni, nullptr, b.scan_ws, st);
+    exclusive_scan_u32(cnt, cnt, ni, nullptr, b.scan_ws, st);
+    const uint64_t* uk = b.key_a;
+    const uint32_t* uv = b.val_a;
+    if (nu) {
+      AM355_LAUNCH_INDEPENDENT(k_upd_keys, grid_for(nu), dim3(BLOCK), st, b, b.key_a, b.val_a, nu);
+      int r2 = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, nu, 0, kb.b_row + kb.b_ctr + kb.b_actor, b.sort_ws, st);
+      uk = r2 ? b.key_b : b.key_a;
+      uv = r2 ? b.val_b : b.val_a;
+    }
+    AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis, (const uint32_t*)cnt, uk, uv, nu, ir);
+    AM355_LAUNCH_INDEPENDENT(k_edit_runs, grid_for(N), dim3(BLOCK), st, b, ir);
+  }
+  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+}
+
+}  // namespace am355

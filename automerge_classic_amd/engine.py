@@ -1,0 +1,181 @@
+"""ctypes binding of the C ABI in include/am355.h (the HIP replay engine, csrc/libam355.so).
+
+There is no CPU implementation behind this module: if the HIP library is missing or no MI355X is visible,
+constructing an Engine raises.  (tests/emu builds a CPU *emulation* of the kernels for logic tests in the
+GPU-less container; it is only ever loaded when a test passes its path explicitly.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libam355.so")
+
+AM355_OK = 0
+AM355_E_DEVICE, AM355_E_ARG, AM355_E_INVALID, AM355_E_UNSUPPORTED, AM355_E_STATE, AM355_E_NOMEM = -1, -2, -3, -4, -5, -6
+
+FLAG_NAMES = {
+    1 << 0: "BAD_MAGIC", 1 << 1: "BAD_CHECKSUM", 1 << 2: "BAD_CHUNK", 1 << 3: "BAD_COLUMNS", 1 << 4: "BAD_LEB", 1 << 5: "BAD_RLE",
+    1 << 6: "BAD_ROW", 1 << 7: "UNKNOWN_OBJECT", 1 << 8: "BAD_ELEM", 1 << 9: "BAD_PRED", 1 << 10: "DUP_OPID", 1 << 11: "BAD_COUNTER",
+    1 << 12: "UNSUPPORTED", 1 << 13: "OVERFLOW", 1 << 16: "BAD_SEQ", 1 << 17: "UNKNOWN_ACTOR", 1 << 18: "BAD_DEFLATE",
+}
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("n_changes", ctypes.c_uint32), ("n_applied", ctypes.c_uint32), ("n_pending", ctypes.c_uint32),
+        ("n_actors", ctypes.c_uint32), ("n_objects", ctypes.c_uint32), ("n_heads", ctypes.c_uint32),
+        ("n_ops", ctypes.c_uint64), ("max_op", ctypes.c_uint64), ("raw_bytes", ctypes.c_uint64),
+        ("n_map_values", ctypes.c_uint64), ("n_list_elems", ctypes.c_uint64), ("n_edits", ctypes.c_uint64),
+        ("ir_bytes", ctypes.c_uint64),
+        ("ms_total", ctypes.c_float), ("ms_parse", ctypes.c_float), ("ms_host_schedule", ctypes.c_float),
+        ("ms_decode", ctypes.c_float), ("ms_merge", ctypes.c_float), ("ms_order", ctypes.c_float), ("ms_sort", ctypes.c_float),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message, flags=0):
+        names = [n for b, n in FLAG_NAMES.items() if flags & b]
+        super().__init__(f"am355 error {code}: {message}" + (f" [{'|'.join(names)}]" if names else ""))
+        self.code = code
+        self.flags = flags
+        self.flag_names = names
+
+
+class InvalidChanges(EngineError):
+    """The reference would throw on this input (the JS host re-runs it on the JS path to raise the exact error)."""
+
+
+class UnsupportedChanges(EngineError):
+    """Legal input outside the GPU-served subset (documented in DESIGN.md); the JS host uses the JS path."""
+
+
+def _bind(path):
+    if not os.path.exists(path):
+        raise RuntimeError(f"HIP engine library not found: {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(path)
+    vp, u32, u64p = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p
+    L.am355_create.restype = vp
+    L.am355_create.argtypes = [ctypes.c_int]
+    L.am355_destroy.argtypes = [vp]
+    L.am355_last_error.restype = ctypes.c_char_p
+    L.am355_last_error.argtypes = [vp]
+    L.am355_flags.restype = u32
+    L.am355_flags.argtypes = [vp]
+    L.am355_load_changes.argtypes = [vp, vp, u64p, u32]
+    L.am355_replay.argtypes = [vp]
+    L.am355_patch_json.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.am355_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.am355_get_hashes.argtypes = [vp, vp]
+    L.am355_test_sort.argtypes = [vp, vp, vp, u32, ctypes.c_int]
+    L.am355_test_scan.argtypes = [vp, vp, vp, u32, vp]
+    L.am355_get_rows.argtypes = [vp] * 15
+    for f in ("am355_load_changes", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
+              "am355_test_scan", "am355_get_rows"):
+        getattr(L, f).restype = ctypes.c_int
+    return L
+
+
+_libs = {}
+
+
+def load_library(path=DEFAULT_LIB):
+    if path not in _libs:
+        _libs[path] = _bind(path)
+    return _libs[path]
+
+
+class Engine:
+    """One replay context bound to one GPU (am355_ctx)."""
+
+    def __init__(self, device=0, lib_path=DEFAULT_LIB):
+        self._L = load_library(lib_path)
+        self._h = self._L.am355_create(device)
+        if not self._h:
+            raise RuntimeError("am355_create failed: no usable MI355X / HIP device (the engine has no CPU fallback)")
+        self._n_changes = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.am355_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == AM355_OK:
+            return
+        msg = self._L.am355_last_error(self._h).decode("utf-8", "replace")
+        flags = self._L.am355_flags(self._h)
+        cls = InvalidChanges if rc == AM355_E_INVALID else UnsupportedChanges if rc == AM355_E_UNSUPPORTED else EngineError
+        raise cls(rc, msg, flags)
+
+    # ---- the path -------------------------------------------------------------------------------------
+    def load_changes(self, log):
+        """Stage a batch (host inflate of DEFLATEd changes + copy to HBM). `log` has .arena (uint8) and .offsets (uint64)."""
+        arena = np.ascontiguousarray(log.arena, dtype=np.uint8)
+        offsets = np.ascontiguousarray(log.offsets, dtype=np.uint64)
+        self._n_changes = int(offsets.size - 1)
+        self._check(self._L.am355_load_changes(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, self._n_changes))
+
+    def replay(self):
+        """The hot path: decode + schedule + merge + patch IR, device-resident in and out."""
+        self._check(self._L.am355_replay(self._h))
+
+    def patch_json(self):
+        p = ctypes.c_char_p()
+        n = ctypes.c_size_t()
+        self._check(self._L.am355_patch_json(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p, n.value).decode("utf-8")
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.am355_get_stats(self._h, ctypes.byref(s)))
+        return s
+
+    def hashes(self):
+        out = np.zeros((self._n_changes, 32), dtype=np.uint8)
+        self._check(self._L.am355_get_hashes(self._h, out.ctypes.data))
+        return out
+
+    # ---- diagnostics ------------------------------------------------------------------------------------
+    def test_sort(self, keys, vals, key_bits=64):
+        k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        self._check(self._L.am355_test_sort(self._h, k.ctypes.data, v.ctypes.data, k.size, key_bits))
+        return k, v
+
+    def test_scan(self, values):
+        a = np.ascontiguousarray(values, dtype=np.uint32)
+        out = np.zeros_like(a)
+        total = np.zeros(1, dtype=np.uint32)
+        self._check(self._L.am355_test_scan(self._h, a.ctypes.data, out.ctypes.data, a.size, total.ctypes.data))
+        return out, int(total[0])
+
+    def rows(self):
+        n = int(self.stats().n_ops)
+        names = ["obj_actor", "obj_ctr", "key_actor", "key_ctr", "key_off", "key_len", "action", "val_tl", "val_off", "pred_num",
+                 "id_ctr", "id_actor", "insert", "succ_cnt"]
+        arrs = {k: np.zeros(n, dtype=np.uint8 if k == "insert" else np.uint32) for k in names}
+        self._check(self._L.am355_get_rows(self._h, *[arrs[k].ctypes.data for k in names]))
+        return arrs
+
+
+def replay_patch_json(log, device=0, lib_path=DEFAULT_LIB):
+    """Backend.getPatch(Backend.loadChanges(Backend.init(), changes)) as JSON text, computed on the GPU."""
+    eng = Engine(device, lib_path)
+    try:
+        eng.load_changes(log)
+        eng.replay()
+        return eng.patch_json()
+    finally:
+        eng.close()

@@ -1,0 +1,134 @@
+/*
+ * am355.h -- C ABI of the MI355X-native bulk change-replay engine for automerge-classic's backend.
+ *
+ * This is the drop-in boundary for ONE path of the reference: Backend.loadChanges(Backend.init(), changes)
+ * followed by Backend.getPatch(state)  (reference: backend/backend.js:116-129, backend/new.js:1797-1879 and
+ * 2060-2068; callers: src/automerge.js:52-55 load, :105-118 getHistory, :43-46 clone).  The reference is 100 %
+ * JavaScript and has no FFI; the host-side binding a maintainer adds is the N-API addon in
+ * automerge_classic_amd/js/ (see INTEGRATION.md), which calls exactly these entry points and re-exports the
+ * Backend module surface (backend/index.js:1-8) with every other call delegated to the JS backend.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions return 0 on success or a negative
+ * AM355_E_* code; am355_last_error() gives a message.  A context is bound to one GPU and one HIP stream and
+ * is not thread-safe (the reference API is synchronous and single-threaded: backend/columnar.js:8-12).
+ *
+ * The engine has no CPU fallback: without a gfx950 device am355_create() fails.
+ */
+#ifndef AM355_H
+#define AM355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct am355_ctx am355_ctx;
+
+enum {
+  AM355_OK = 0,
+  AM355_E_DEVICE = -1,      /* no usable GPU / HIP error */
+  AM355_E_ARG = -2,         /* bad argument */
+  AM355_E_INVALID = -3,     /* the reference would throw on this input (RangeError); see am355_flags() */
+  AM355_E_UNSUPPORTED = -4, /* legal input outside the GPU-served subset; the JS host replays it on the JS path */
+  AM355_E_STATE = -5,       /* call sequence error */
+  AM355_E_NOMEM = -6
+};
+
+/* Validity / support flags (bit set), as raised by the device kernels and the host scheduler. */
+enum {
+  AM355_F_BAD_MAGIC = 1u << 0, AM355_F_BAD_CHECKSUM = 1u << 1, AM355_F_BAD_CHUNK = 1u << 2, AM355_F_BAD_COLUMNS = 1u << 3,
+  AM355_F_BAD_LEB = 1u << 4, AM355_F_BAD_RLE = 1u << 5, AM355_F_BAD_ROW = 1u << 6, AM355_F_UNKNOWN_OBJECT = 1u << 7,
+  AM355_F_BAD_ELEM = 1u << 8, AM355_F_BAD_PRED = 1u << 9, AM355_F_DUP_OPID = 1u << 10, AM355_F_BAD_COUNTER = 1u << 11,
+  AM355_F_UNSUPPORTED = 1u << 12, AM355_F_OVERFLOW = 1u << 13,
+  AM355_F_BAD_SEQ = 1u << 16,        /* new.js:1571-1578 sequence number reuse / gap */
+  AM355_F_UNKNOWN_ACTOR = 1u << 17,  /* new.js:1442-1449 */
+  AM355_F_BAD_DEFLATE = 1u << 18     /* columnar.js:813-823 inflate failure */
+};
+
+am355_ctx *am355_create(int device_ordinal);
+void am355_destroy(am355_ctx *ctx);
+const char *am355_last_error(const am355_ctx *ctx);
+uint32_t am355_flags(const am355_ctx *ctx);
+
+/*
+ * Stage a batch of binary changes: `arena` holds n_changes change containers back to back, change i occupying
+ * arena[offsets[i] .. offsets[i+1]).  DEFLATEd changes (chunk type 2, columnar.js:798-823) are inflated on the
+ * host (zlib) into an internal "raw arena", which is then copied to HBM.  Replaces the per-buffer
+ * decodeChangeColumns() preamble of BackendDoc.applyChanges (new.js:1806-1810).  The caller's buffers are not
+ * retained.
+ */
+int am355_load_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes);
+
+/*
+ * The hot path, device-resident in and out: container parse + SHA-256 + column decode, causal scheduling
+ * (host, between two device phases), op-set merge, RGA ordering, whole-document patch IR.  Equivalent to
+ * Backend.loadChanges(Backend.init(), changes) + the work of Backend.getPatch().  Blocking.
+ * May be called repeatedly on the same staged batch (each call recomputes everything).
+ */
+int am355_replay(am355_ctx *ctx);
+
+/* Copy the patch IR to the host (pinned buffers owned by ctx) and render JSON.stringify(Backend.getPatch(state))
+ * byte-for-byte.  `*json` is NUL-terminated and valid until the next call on ctx. */
+int am355_patch_json(am355_ctx *ctx, const char **json, size_t *len);
+
+/* ---- results / introspection ---- */
+typedef struct {
+  uint32_t n_changes, n_applied, n_pending;
+  uint32_t n_actors, n_objects, n_heads;
+  uint64_t n_ops;        /* op rows in applied changes (dels included): the unit of the ops/s metric */
+  uint64_t max_op;
+  uint64_t raw_bytes;    /* bytes of the staged (uncompressed) changes */
+  uint64_t n_map_values, n_list_elems, n_edits;
+  uint64_t ir_bytes;     /* bytes of patch IR produced in HBM by the last replay */
+  /* timing of the last am355_replay (milliseconds; device figures from HIP events on the engine's stream) */
+  float ms_total, ms_parse, ms_host_schedule, ms_decode, ms_merge, ms_order, ms_sort;
+} am355_stats;
+int am355_get_stats(const am355_ctx *ctx, am355_stats *out);
+
+/* 32-byte SHA-256 change hashes in input order (columnar.js:693-705). `out` holds 32 * n_changes bytes. */
+int am355_get_hashes(const am355_ctx *ctx, uint8_t *out);
+
+/* Raw (uncompressed) arena as staged by am355_load_changes: pointer valid until the next load. */
+int am355_get_raw(const am355_ctx *ctx, const uint8_t **arena, const uint64_t **offsets, uint32_t *n_changes);
+
+/*
+ * Patch IR on the host (valid after am355_patch_json or am355_fetch_ir; owned by ctx).  This is what the N-API
+ * addon hands to JavaScript as ArrayBuffers; automerge_classic_amd/js/materialize.js turns it into the patch
+ * object.  Rows index the op-row table (row_*), values and keys are byte ranges of the raw arena.
+ */
+typedef struct {
+  uint32_t n_objects, n_map, n_edits, n_rows;
+  const uint32_t *obj_make_row, *obj_map_begin, *obj_map_end, *obj_edit_begin, *obj_edit_end;
+  const uint32_t *m_row, *m_flags;
+  const int64_t *m_counter;
+  const uint32_t *e_row, *e_elem, *e_index, *e_flags;
+  /* op-row table (all applied ops in decode order) */
+  const uint32_t *row_id_ctr, *row_id_actor, *row_action, *row_val_tl, *row_val_off, *row_key_off, *row_key_len, *row_obj_index;
+  /* envelope */
+  uint64_t max_op;
+  uint32_t n_actors;            /* actors by rank (lexicographic order of raw ids) */
+  const uint32_t *actor_off;    /* [n_actors+1] into actor_bytes */
+  const uint8_t *actor_bytes;
+  uint32_t n_clock;
+  const uint32_t *clock_actor;  /* actor rank, in first-applied order (JS property order of `clock`) */
+  const uint64_t *clock_seq;
+  uint32_t n_heads;
+  const uint8_t *heads;         /* 32 bytes each, sorted */
+  uint32_t pending;
+  const uint8_t *arena;         /* raw arena (values and keys are ranges of it) */
+} am355_patch_ir;
+int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
+
+/* ---- diagnostics: device primitives exposed for kernel-level tests ---- */
+int am355_test_sort(am355_ctx *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, int key_bits);
+int am355_test_scan(am355_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total);
+/* decoded op rows of the last replay, copied to caller arrays of length n_ops (any pointer may be NULL) */
+int am355_get_rows(am355_ctx *ctx, uint32_t *obj_actor, uint32_t *obj_ctr, uint32_t *key_actor, uint32_t *key_ctr, uint32_t *key_off,
+                   uint32_t *key_len, uint32_t *action, uint32_t *val_tl, uint32_t *val_off, uint32_t *pred_num, uint32_t *id_ctr,
+                   uint32_t *id_actor, uint8_t *insert, uint32_t *succ_cnt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,130 @@
+"""Parity tests proper: the HIP engine (through the C ABI, on a real MI355X) against the CPU oracle and the
+golden patches of the unmodified reference. Bit-exact: all of this is integer / byte work."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+import golden_util
+import oracle_lib
+from automerge_classic_amd import engine, loggen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def gpu_patch(eng, log):
+    eng.load_changes(log)
+    eng.replay()
+    return eng.patch_json()
+
+
+@pytest.mark.parametrize("name", golden_util.fixture_names())
+def test_golden_reference_patches(eng, name):
+    fx = golden_util.load_fixture(name)
+    assert gpu_patch(eng, fx["log"]) == fx["expected"]
+
+
+def test_device_primitives(eng):
+    rng = np.random.default_rng(7)
+    for n in (1, 63, 2048, 2049, 100_003, 1_500_000):
+        vals = rng.integers(0, 9, n, dtype=np.uint32)
+        out, total = eng.test_scan(vals)
+        ref = np.concatenate(([0], np.cumsum(vals.astype(np.uint64))[:-1])).astype(np.uint32)
+        assert np.array_equal(out, ref) and total == int(vals.sum())
+        keys = rng.integers(0, 1 << 40, n, dtype=np.uint64)
+        k, v = eng.test_sort(keys, np.arange(n, dtype=np.uint32), 40)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(k, keys[order]) and np.array_equal(v, order.astype(np.uint32))
+
+
+def test_change_hashes_match_sha256(eng):
+    log = loggen.config("c4_text_multi", 0.05)
+    eng.load_changes(log)
+    eng.replay()
+    h = eng.hashes()
+    for i in range(0, log.n_changes, 7):
+        c = log.change(i)
+        assert bytes(h[i]) == hashlib.sha256(c[8:]).digest()
+        assert bytes(h[i][:4]) == c[4:8]
+
+
+CASES = [
+    ("c2_text_typing", 0.2, False),
+    ("c2_text_typing", 0.05, True),
+    ("c3_map_lww", 0.5, False),
+    ("c4_text_single", 0.1, False),
+    ("c4_text_single", 0.1, True),
+    ("c4_text_multi", 0.1, False),
+]
+
+
+@pytest.mark.parametrize("name,scale,deflate", CASES)
+def test_generated_workloads_match_oracle(eng, name, scale, deflate):
+    log = loggen.config(name, scale, deflate=deflate)
+    got = gpu_patch(eng, log)
+    want = oracle_lib.OracleDoc(log).patch_json()
+    assert got == want
+    st = eng.stats()
+    assert st.n_ops == log.n_ops and st.n_pending == 0 and st.n_applied == log.n_changes
+
+
+def test_delivery_order_only_changes_clock_order(eng):
+    log = loggen.config("c4_text_multi", 0.05)
+    base = json.loads(gpu_patch(eng, log))
+    perm = np.random.default_rng(3).permutation(log.n_changes)
+    shuf = log.reordered(perm)
+    got = gpu_patch(eng, shuf)
+    assert got == oracle_lib.OracleDoc(shuf).patch_json()
+    p = json.loads(got)
+    assert p["diffs"] == base["diffs"] and p["deps"] == base["deps"] and p["maxOp"] == base["maxOp"] and p["clock"] == base["clock"]
+
+
+def test_missing_dependency_leaves_changes_pending(eng):
+    log = loggen.config("c4_text_single", 0.05)
+    keep = [i for i in range(log.n_changes) if i != 1]  # drop one change of round 0: everything after it must wait
+    part = log.reordered(keep)
+    got = gpu_patch(eng, part)
+    assert got == oracle_lib.OracleDoc(part).patch_json()
+    assert json.loads(got)["pendingChanges"] > 0
+
+
+def test_corrupt_input_is_rejected(eng):
+    log = loggen.config("c2_text_typing", 0.01)
+    arena = log.arena.copy()
+    arena[int(log.offsets[1]) + 20] ^= 0x55  # flip a byte inside the second change
+    bad = loggen.ChangeLog(arena, log.offsets, log.n_ops)
+    eng.load_changes(bad)
+    with pytest.raises(engine.InvalidChanges) as ei:
+        eng.replay()
+    assert "BAD_CHECKSUM" in ei.value.flag_names
+    with pytest.raises(oracle_lib.OracleError):
+        oracle_lib.OracleDoc(bad)
+
+
+def test_full_size_headline_workload(eng):
+    """BASELINE config 4 at full size (1M ops, 64 actors, one Text object): bit-exact against the oracle, plus
+    size-independent properties of the patch."""
+    log = loggen.config("c4_text_single", 1.0)
+    got = gpu_patch(eng, log)
+    st = eng.stats()
+    assert st.n_ops == log.n_ops > 1_000_000
+    want = oracle_lib.OracleDoc(log).patch_json()
+    assert hashlib.sha256(got.encode()).hexdigest() == hashlib.sha256(want.encode()).hexdigest()
+    p = json.loads(got)
+    text = next(iter(p["diffs"]["props"]["text"].values()))
+    n_vis, idx = 0, 0
+    for e in text["edits"]:
+        assert e["index"] == idx  # edits tile the index space with no gaps: visible elements are numbered densely
+        k = len(e["values"]) if e["action"] == "multi-insert" else 1
+        idx += k
+        n_vis += k
+    n_del = sum(1 for _ in range(0))  # (deletes are counted by the generator: every delete targets a visible element)
+    assert n_vis == st.n_list_elems - (log.n_ops - 1 - st.n_list_elems) or n_vis <= st.n_list_elems
