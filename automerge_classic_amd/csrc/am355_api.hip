@@ -82,8 +82,10 @@ struct Hash32Hasher {
 
 struct am355_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // decode / merge critical path
+  hipStream_t stream2 = nullptr;  // SHA-256 + dependency resolution, off the critical path
   hipEvent_t ev[8] = {};
+  hipEvent_t ev_parse = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
   std::string err;
   uint32_t flags = 0;
 
@@ -94,6 +96,11 @@ struct am355_ctx {
   bool staged = false, replayed = false, ir_fetched = false;
   DevBuf d_arena, d_offsets, d_metas;
   HostBuf h_metas;
+  // stage-1 side tables (device) and their pinned host mirrors
+  DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1;
+  HostBuf h_slots, h_hashes, h_has_dep, h_words;
+  uint32_t amap_cap = 0, slot_mask = 0, hash_mask = 0;
+  bool used_fast_path = false;
 
   // schedule
   std::vector<ChangePlan> plans;
@@ -149,8 +156,10 @@ extern "C" am355_ctx* am355_create(int device) {
   am355_ctx* c = new am355_ctx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
   return c;
 }
 
@@ -158,6 +167,14 @@ extern "C" void am355_destroy(am355_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream2);
+  for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
+                    &c->d_words, &c->d_slot_rank, &c->d_scan1})
+    b->release();
+  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words}) b->release();
+  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1})
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_spans, &c->d_tab_off, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts})
     b->release();
@@ -254,8 +271,43 @@ static int bits_for64(uint64_t max_value) {
   return b;
 }
 
+// Open-addressing set of 32-byte hashes (keyed by their first 8 bytes, verified by full comparison).
+struct HashSet {
+  std::vector<const uint8_t*> slot;
+  size_t mask = 0;
+  void init(size_t n) {
+    size_t cap = 16;
+    while (cap < n * 2 + 2) cap <<= 1;
+    slot.assign(cap, nullptr);
+    mask = cap - 1;
+  }
+  static uint64_t key(const uint8_t* h) { uint64_t v; memcpy(&v, h, 8); return v * 0x9e3779b97f4a7c15ull; }
+  const uint8_t** find(const uint8_t* h) {
+    size_t i = (size_t)(key(h) >> 20) & mask;
+    while (slot[i]) {
+      if (slot[i] != (const uint8_t*)1 && memcmp(slot[i], h, 32) == 0) return &slot[i];
+      i = (i + 1) & mask;
+    }
+    return nullptr;
+  }
+  bool has(const uint8_t* h) { return find(h) != nullptr; }
+  void add(const uint8_t* h) {
+    size_t i = (size_t)(key(h) >> 20) & mask;
+    while (slot[i] && slot[i] != (const uint8_t*)1) i = (i + 1) & mask;
+    slot[i] = h;
+  }
+  void del(const uint8_t* h) {
+    const uint8_t** p = find(h);
+    if (p) *p = (const uint8_t*)1;  // tombstone
+  }
+};
+
+// General scheduler: exact restatement of the reference's retry loop for any delivery order, duplicates and
+// missing dependencies. Used when the device-side checks cannot prove the in-order fast path.
 static int schedule(am355_ctx* c) {
+  auto T0 = std::chrono::steady_clock::now();
   const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+  const uint8_t* hashes = c->h_hashes.as<uint8_t>();
   uint32_t n = c->n_changes;
   const uint8_t* raw = c->raw.data();
   uint32_t dev_flags = 0;
@@ -265,30 +317,52 @@ static int schedule(am355_ctx* c) {
     return fail(c, (dev_flags & (F_OVERFLOW | F_UNSUPPORTED)) ? AM355_E_UNSUPPORTED : AM355_E_INVALID, "malformed change (flags 0x%x)", dev_flags);
   }
   // ---- actor ids: global table ranked lexicographically (hex-string order == byte order, new.js:65) ----
+  // Changes of one author nearly always carry the same "other actors" table, so each author's last table is
+  // memoised (bytes compared), which turns O(changes x actors) string interning into O(changes) memcmp.
   std::unordered_map<std::string, uint32_t> actor_ix;
   std::vector<std::string> names;
-  std::vector<std::vector<uint32_t>> local(n);  // per change: provisional ids of [author, others...]
+  std::vector<uint32_t> local_off(n + 1, 0), local_ids;
+  local_ids.reserve((size_t)n * 2);
+  struct Memo { const uint8_t* p = nullptr; uint32_t len = 0, n_other = 0, first = 0; };
+  std::vector<Memo> memo;
+  auto intern = [&](const uint8_t* b, size_t len) {
+    std::string s((const char*)b, len);
+    auto it = actor_ix.find(s);
+    if (it != actor_ix.end()) return it->second;
+    uint32_t id = (uint32_t)names.size();
+    actor_ix.emplace(s, id);
+    names.push_back(std::move(s));
+    memo.emplace_back();
+    return id;
+  };
   for (uint32_t i = 0; i < n; i++) {
     const ChangeMeta& m = metas[i];
     const uint8_t* p = raw + m.base;
-    auto intern = [&](const uint8_t* b, size_t len) {
-      std::string s((const char*)b, len);
-      auto it = actor_ix.find(s);
-      if (it != actor_ix.end()) return it->second;
-      uint32_t id = (uint32_t)names.size();
-      actor_ix.emplace(s, id);
-      names.push_back(std::move(s));
-      return id;
-    };
-    local[i].push_back(intern(p + m.actor_off, m.actor_len));
+    uint32_t author = intern(p + m.actor_off, m.actor_len);
+    local_ids.push_back(author);
+    // bytes of the other-actors table: from others_off up to the column directory; its exact end is found by parsing
+    Memo& mm = memo[author];
     size_t off = m.others_off;
-    for (uint32_t k = 0; k < m.n_other; k++) {
-      uint64_t l;
-      read_uleb_host(p, m.len, off, l);
-      local[i].push_back(intern(p + off, (size_t)l));
-      off += (size_t)l;
+    if (mm.p && mm.n_other == m.n_other && m.others_off + mm.len <= m.len && memcmp(mm.p, p + m.others_off, mm.len) == 0) {
+      for (uint32_t k = 0; k < m.n_other; k++) local_ids.push_back(local_ids[mm.first + k]);
+    } else {
+      uint32_t first = (uint32_t)local_ids.size();
+      for (uint32_t k = 0; k < m.n_other; k++) {
+        uint64_t l;
+        read_uleb_host(p, m.len, off, l);
+        uint32_t id = intern(p + off, (size_t)l);
+        local_ids.push_back(id);
+        off += (size_t)l;
+      }
+      Memo& m2 = memo[author];  // (memo may have grown)
+      m2.p = p + m.others_off;
+      m2.len = (uint32_t)(off - m.others_off);
+      m2.n_other = m.n_other;
+      m2.first = first;
     }
+    local_off[i + 1] = (uint32_t)local_ids.size();
   }
+  auto T1 = std::chrono::steady_clock::now();
   uint32_t na = (uint32_t)names.size();
   std::vector<uint32_t> by_rank(na), rank(na);
   for (uint32_t i = 0; i < na; i++) by_rank[i] = i;
@@ -297,50 +371,55 @@ static int schedule(am355_ctx* c) {
   c->actors.resize(na);
   for (uint32_t r = 0; r < na; r++) c->actors[r] = names[by_rank[r]];
 
+  auto T2 = std::chrono::steady_clock::now();
   // ---- causal scheduling (new.js:1550-1597 inside the retry loop of :1822-1841) ----
-  std::unordered_map<Hash32, uint32_t, Hash32Hasher> known;  // applied hashes
-  std::unordered_map<Hash32, bool, Hash32Hasher> heads;
+  HashSet known, heads;
+  known.init(n);
+  heads.init(n);
   std::vector<uint64_t> clock(na, 0);
   std::vector<uint8_t> has_clock(na, 0), actor_read(na, 0);
   c->clock_actor.clear();
-  std::vector<uint32_t> queue(n), next_q, applied_all;
+  std::vector<uint32_t> queue(n), next_q, applied_all, head_list;
   for (uint32_t i = 0; i < n; i++) queue[i] = i;
   uint32_t sched_flags = 0;
   while (!queue.empty()) {
     std::vector<uint32_t> applied;
     next_q.clear();
+    // Memo: a dependency block byte-identical to the one of the previously accepted change is ready again
+    // (the known set only grows) and its hashes have already been taken off the heads.
+    const uint8_t* last_deps = nullptr;
+    uint32_t last_n_deps = 0;
     for (uint32_t ci : queue) {
       const ChangeMeta& m = metas[ci];
-      Hash32 h;
-      memcpy(h.b, m.hash, 32);
-      if (known.count(h)) continue;  // duplicate (new.js:1557)
-      uint32_t author = rank[local[ci][0]];
+      const uint8_t* my_hash = hashes + 32 * (size_t)ci;
+      if (known.has(my_hash)) continue;  // duplicate (new.js:1557)
+      uint32_t author = rank[local_ids[local_off[ci]]];
       uint64_t expected = clock[author] + 1;
+      const uint8_t* deps = raw + m.base + m.deps_off;
+      bool same_as_last = last_deps && m.n_deps == last_n_deps && memcmp(deps, last_deps, (size_t)32 * m.n_deps) == 0;
       bool ready = true;
-      for (uint32_t k = 0; k < m.n_deps; k++) {
-        Hash32 d;
-        memcpy(d.b, raw + m.base + m.deps_off + 32 * k, 32);
-        if (!known.count(d)) ready = false;
-      }
+      if (!same_as_last)
+        for (uint32_t k = 0; k < m.n_deps && ready; k++)
+          if (!known.has(deps + 32 * k)) ready = false;
       if (!ready) { next_q.push_back(ci); continue; }
       if (m.seq != expected) { sched_flags |= AM355_F_BAD_SEQ; break; }
       if (!has_clock[author]) { has_clock[author] = 1; c->clock_actor.push_back(author); }
       clock[author] = m.seq;
-      known.emplace(h, ci);
-      for (uint32_t k = 0; k < m.n_deps; k++) {
-        Hash32 d;
-        memcpy(d.b, raw + m.base + m.deps_off + 32 * k, 32);
-        heads.erase(d);
-      }
-      heads[h] = true;
+      known.add(my_hash);
+      if (!same_as_last)
+        for (uint32_t k = 0; k < m.n_deps; k++) heads.del(deps + 32 * k);
+      heads.add(my_hash);
+      head_list.push_back(ci);
+      last_deps = deps;
+      last_n_deps = m.n_deps;
       applied.push_back(ci);
     }
     if (sched_flags) break;
     // changes are read in applied order; each may only mention actors already in the document (new.js:1442-1449)
     for (uint32_t ci : applied) {
-      actor_read[rank[local[ci][0]]] = 1;
-      for (uint32_t a : local[ci])
-        if (!actor_read[rank[a]]) sched_flags |= AM355_F_UNKNOWN_ACTOR;
+      actor_read[rank[local_ids[local_off[ci]]]] = 1;
+      for (uint32_t k = local_off[ci]; k < local_off[ci + 1]; k++)
+        if (!actor_read[rank[local_ids[k]]]) sched_flags |= AM355_F_UNKNOWN_ACTOR;
       applied_all.push_back(ci);
     }
     queue.swap(next_q);
@@ -355,16 +434,19 @@ static int schedule(am355_ctx* c) {
   c->clock_seq.clear();
   for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
   {
-    std::vector<Hash32> hs;
-    for (auto& kv : heads) hs.push_back(kv.first);
-    std::sort(hs.begin(), hs.end(), [](const Hash32& x, const Hash32& y) { return memcmp(x.b, y.b, 32) < 0; });
+    std::vector<const uint8_t*> hs;
+    for (uint32_t ci : head_list)
+      if (heads.has(hashes + 32 * (size_t)ci)) hs.push_back(hashes + 32 * (size_t)ci);
+    std::sort(hs.begin(), hs.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
     c->heads.resize(hs.size() * 32);
-    for (size_t i = 0; i < hs.size(); i++) memcpy(&c->heads[32 * i], hs[i].b, 32);
+    for (size_t i = 0; i < hs.size(); i++) memcpy(&c->heads[32 * i], hs[i], 32);
   }
 
+  auto T3 = std::chrono::steady_clock::now();
   // ---- launch plan for the decode kernels, op-id -> row tables ----
   c->plans.clear();
   c->amap.clear();
+  c->amap.reserve(local_ids.size());
   uint64_t ops = 0, preds = 0, max_op = 0;
   std::vector<std::vector<ActorSpan>> per_actor(na);
   for (uint32_t ci : applied_all) {
@@ -374,9 +456,9 @@ static int schedule(am355_ctx* c) {
     pl.op_base = (uint32_t)ops;
     pl.pred_base = (uint32_t)preds;
     pl.amap_base = (uint32_t)c->amap.size();
-    pl.author = rank[local[ci][0]];
-    pl.n_actors = (uint32_t)local[ci].size();
-    for (uint32_t a : local[ci]) c->amap.push_back(rank[a]);
+    pl.author = rank[local_ids[local_off[ci]]];
+    pl.n_actors = local_off[ci + 1] - local_off[ci];
+    for (uint32_t k = local_off[ci]; k < local_off[ci + 1]; k++) c->amap.push_back(rank[local_ids[k]]);
     if (m.n_ops) {
       per_actor[pl.author].push_back(ActorSpan{(uint32_t)m.start_op, m.n_ops, pl.op_base});
       max_op = std::max<uint64_t>(max_op, m.start_op + m.n_ops - 1);
@@ -403,6 +485,11 @@ static int schedule(am355_ctx* c) {
     c->spans.insert(c->spans.end(), v.begin(), v.end());
   }
   c->actor_tab_off[na] = (uint32_t)c->spans.size();
+  if (getenv("AM355_DEBUG_TIMING")) {
+    auto T4 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "schedule: actors %.3f rank %.3f causal %.3f plan %.3f ms\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), ms(T3, T4));
+  }
   return AM355_OK;
 }
 
@@ -418,37 +505,105 @@ static T* carve(uint8_t*& p, size_t count) {
 
 static size_t carve_size(size_t count, size_t elem) { return ((count * elem) + 255) & ~(size_t)255; }
 
-extern "C" int am355_replay(am355_ctx* c) {
-  if (!c) return AM355_E_ARG;
-  if (!c->staged) return fail(c, AM355_E_STATE, "am355_load_changes must be called first");
-  (void)hipSetDevice(c->device);
-  c->replayed = c->ir_fetched = false;
-  c->flags = 0;
-  auto t_begin = std::chrono::steady_clock::now();
+static uint32_t pow2_at_least(uint64_t v) {
+  uint32_t p = 64;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// words shared with the device: [0] flags of the critical-path kernels, [1] fast-path word (stream A part),
+// [2] total actor-table entries, [3] flags of the hash stream, [4] fast-path word (stream B part)
+enum { W_FLAGS_A = 0, W_FAST_A = 1, W_TOTAL_ENTRIES = 2, W_FLAGS_B = 3, W_FAST_B = 4, W_NUM = 8 };
+
+static int error_for_flags(am355_ctx* c, uint32_t f, const char* what) {
+  c->flags |= f;
+  uint32_t hard = f & ~(uint32_t)(F_OVERFLOW | F_UNSUPPORTED);
+  return fail(c, hard ? AM355_E_INVALID : AM355_E_UNSUPPORTED, "%s (flags 0x%x)", what, f);
+}
+
+// Host half of the in-order fast path: O(changes + actors log actors). Everything that needs the change hashes
+// (dependency resolution, heads) has been checked on the device and is confirmed when stream B is joined.
+static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
+  const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+  const unsigned long long* slots = c->h_slots.as<unsigned long long>();
+  const uint8_t* raw = c->raw.data();
+  uint32_t n = c->n_changes, n_slots = c->slot_mask + 1;
+  // distinct actor ids -> lexicographic ranks (hex-string order == byte order, new.js:65)
+  struct Ent { uint32_t slot, off, len; };
+  std::vector<Ent> ents;
+  for (uint32_t i = 0; i < n_slots; i++)
+    if (slots[i]) ents.push_back(Ent{i, (uint32_t)((slots[i] >> 16) - 1), (uint32_t)(slots[i] & 0xffff)});
+  std::sort(ents.begin(), ents.end(), [&](const Ent& x, const Ent& y) {
+    uint32_t m = std::min(x.len, y.len);
+    int r = m ? memcmp(raw + x.off, raw + y.off, m) : 0;
+    return r ? r < 0 : x.len < y.len;
+  });
+  uint32_t na = (uint32_t)ents.size();
+  slot_rank.assign(n_slots, 0);
+  c->actors.resize(na);
+  for (uint32_t r = 0; r < na; r++) {
+    slot_rank[ents[r].slot] = r;
+    c->actors[r].assign((const char*)raw + ents[r].off, ents[r].len);
+  }
+  std::vector<uint64_t> clock(na, 0);
+  c->clock_actor.clear();
+  c->plans.clear();
+  c->plans.reserve(n);
+  uint64_t ops = 0, preds = 0, entries = 0, max_op = 0;
+  std::vector<std::vector<ActorSpan>> per_actor(na);
+  for (uint32_t ci = 0; ci < n; ci++) {
+    const ChangeMeta& m = metas[ci];
+    uint32_t author = slot_rank[m.author_slot];
+    if (m.seq != clock[author] + 1) { c->flags |= AM355_F_BAD_SEQ; return fail(c, AM355_E_INVALID, "sequence number %llu out of order", (unsigned long long)m.seq); }
+    if (clock[author] == 0) c->clock_actor.push_back(author);
+    clock[author] = m.seq;
+    if (m.n_ops) {
+      ChangePlan pl{ci, (uint32_t)ops, (uint32_t)preds, (uint32_t)entries, author, m.n_entries};
+      c->plans.push_back(pl);
+      per_actor[author].push_back(ActorSpan{(uint32_t)m.start_op, m.n_ops, pl.op_base});
+      max_op = std::max<uint64_t>(max_op, m.start_op + m.n_ops - 1);
+    }
+    ops += m.n_ops;
+    preds += m.n_preds;
+    entries += m.n_entries;
+    if (ops >= 0x7ffffff0ull || preds >= 0xfffffff0ull) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 ops in one batch"); }
+  }
+  c->n_applied = n;
+  c->n_pending = 0;
+  c->n_ops = ops;
+  c->n_preds = preds;
+  c->max_op = max_op;
+  c->clock_seq.clear();
+  for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
+  c->spans.clear();
+  c->actor_tab_off.assign(na + 1, 0);
+  for (uint32_t a = 0; a < na; a++) {
+    auto& v = per_actor[a];
+    // seq order is start_op order for well-formed histories; sort anyway and verify the ranges are disjoint
+    std::sort(v.begin(), v.end(), [](const ActorSpan& x, const ActorSpan& y) { return x.start_op < y.start_op; });
+    for (size_t k = 1; k < v.size(); k++)
+      if ((uint64_t)v[k - 1].start_op + v[k - 1].n_ops > v[k].start_op) {
+        c->flags |= AM355_F_DUP_OPID;
+        return fail(c, AM355_E_INVALID, "overlapping op id ranges for one actor (duplicate operation ID)");
+      }
+    c->actor_tab_off[a] = (uint32_t)c->spans.size();
+    c->spans.insert(c->spans.end(), v.begin(), v.end());
+  }
+  c->actor_tab_off[na] = (uint32_t)c->spans.size();
+  return AM355_OK;
+}
+
+// Device buffers for N op rows / P preds, decode, merge, patch IR. `slot_rank` != null: actor tables are the
+// device-interned slots (fast path); null: c->amap holds ranks (general path).
+static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   hipStream_t st = c->stream;
-  uint32_t n = c->n_changes;
-
-  // ---- stage 1a: parse + hash + count (device), metas to host ----
-  HIPCHK(c, hipEventRecord(c->ev[0], st));
-  launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), st);
-  HIPCHK(c, hipEventRecord(c->ev[1], st));
-  HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
-
-  // ---- host: causal schedule, actor ranks, launch plan ----
-  auto t_h0 = std::chrono::steady_clock::now();
-  int rc = schedule(c);
-  if (rc) return rc;
-  auto t_h1 = std::chrono::steady_clock::now();
-
   uint32_t N = (uint32_t)c->n_ops, P = (uint32_t)c->n_preds, NA = (uint32_t)c->actors.size();
   int bits_ctr = bits_for64(c->max_op), bits_actor = bits_for64(NA ? NA - 1 : 0), bits_row = bits_for64(N);
   if (1 + bits_row + bits_ctr + bits_actor > 64) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "sort key wider than 64 bits"); }
-
-  // ---- device buffers ----
   size_t np = c->plans.size();
   if (!c->d_plans.ensure(sizeof(ChangePlan) * std::max<size_t>(np, 1)) || !c->d_amap.ensure(4 * std::max<size_t>(c->amap.size(), 1)) ||
-      !c->d_spans.ensure(sizeof(ActorSpan) * std::max<size_t>(c->spans.size(), 1)) || !c->d_tab_off.ensure(4 * (size_t)(NA + 1)))
+      !c->d_spans.ensure(sizeof(ActorSpan) * std::max<size_t>(c->spans.size(), 1)) || !c->d_tab_off.ensure(4 * (size_t)(NA + 1)) ||
+      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
   size_t Nc = (size_t)N + 1;
   {
@@ -487,7 +642,6 @@ extern "C" int am355_replay(am355_ctx* c) {
     b.succ_a = carve<uint32_t>(p, 2 * Nc + 2); b.succ_b = carve<uint32_t>(p, 2 * Nc + 2); b.dist_a = carve<uint32_t>(p, 2 * Nc + 2); b.dist_b = carve<uint32_t>(p, 2 * Nc + 2);
     b.order = carve<uint32_t>(p, Nc + 1); b.scan_a = carve<uint32_t>(p, Nc + 1); b.scan_b = carve<uint32_t>(p, Nc + 1);
     b.scan_ws = p;
-    b.obj_first_pos = nullptr;  // carved from the IR arena below
     uint8_t* s = c->d_sort.as<uint8_t>();
     b.key_a = carve<uint64_t>(s, Nc); b.key_b = carve<uint64_t>(s, Nc); b.val_a = carve<uint32_t>(s, Nc); b.val_b = carve<uint32_t>(s, Nc);
     b.sort_ws = s;
@@ -501,45 +655,161 @@ extern "C" int am355_replay(am355_ctx* c) {
     b.obj_first_pos = b.em_row;  // em_row is dead once the map emissions are ordered (lists run afterwards)
   }
   HIPCHK(c, hipMemcpyAsync(c->d_plans.p, c->plans.data(), sizeof(ChangePlan) * np, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->amap.data(), 4 * c->amap.size(), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->spans.data(), sizeof(ActorSpan) * c->spans.size(), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_tab_off.p, c->actor_tab_off.data(), 4 * c->actor_tab_off.size(), hipMemcpyHostToDevice, st));
+  const uint32_t* d_amap;
+  const uint32_t* d_rank = nullptr;
+  if (slot_rank) {
+    HIPCHK(c, hipMemcpyAsync(c->d_slot_rank.p, slot_rank->data(), 4 * slot_rank->size(), hipMemcpyHostToDevice, st));
+    d_amap = c->d_amap_prov.as<uint32_t>();
+    d_rank = c->d_slot_rank.as<uint32_t>();
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->amap.data(), 4 * c->amap.size(), hipMemcpyHostToDevice, st));
+    d_amap = c->d_amap.as<uint32_t>();
+  }
 
   // ---- stage 1b: column decode ----
   HIPCHK(c, hipEventRecord(c->ev[2], st));
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
-  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), (uint32_t)np, c->d_amap.as<uint32_t>(),
-                        c->cols, &c->d_counts.as<Counts>()->flags, st);
-  HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->d_counts.p, sizeof(Counts), hipMemcpyDeviceToHost, st));
+  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), (uint32_t)np, d_amap, d_rank, c->cols,
+                        &c->d_counts.as<Counts>()->flags, st);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
-  HIPCHK(c, hipStreamSynchronize(st));
-  Counts* hc = c->h_counts.as<Counts>();
-  if (hc->flags) {
-    c->flags |= hc->flags;
-    return fail(c, (hc->flags & (F_OVERFLOW | F_UNSUPPORTED)) ? AM355_E_UNSUPPORTED : AM355_E_INVALID, "malformed columns (flags 0x%x)", hc->flags);
-  }
 
-  // ---- stage 2: merge ----
+  // ---- stage 2: merge (decode flags are read together with the phase-1 counters) ----
+  Counts* hc = c->h_counts.as<Counts>();
+  {
+    // phase 1 resets the counters itself; keep the decode flags by OR-ing them back on the host
+    HIPCHK(c, hipMemcpyAsync(hc, c->d_counts.p, sizeof(Counts), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (hc->flags) return error_for_flags(c, hc->flags, "malformed columns");
+  }
   merge_phase1(c->mb, hc, st);
   HIPCHK(c, hipEventRecord(c->ev[4], st));
-  if (hc->flags) {
-    c->flags |= hc->flags;
-    uint32_t hard = hc->flags & ~(uint32_t)(F_OVERFLOW | F_UNSUPPORTED);
-    return fail(c, hard ? AM355_E_INVALID : AM355_E_UNSUPPORTED, "op set rejected (flags 0x%x)", hc->flags);
-  }
+  if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
   merge_phase2(c->mb, c->ir, hc, st);
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   HIPCHK(c, hipStreamSynchronize(st));
-  if (hc->flags) {
-    c->flags |= hc->flags;
-    uint32_t hard = hc->flags & ~(uint32_t)(F_OVERFLOW | F_UNSUPPORTED);
-    return fail(c, hard ? AM355_E_INVALID : AM355_E_UNSUPPORTED, "op set rejected (flags 0x%x)", hc->flags);
-  }
+  if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
   c->counts = *hc;
   c->counts.n_objects += 1;  // + _root
+  return AM355_OK;
+}
+
+extern "C" int am355_replay(am355_ctx* c) {
+  if (!c) return AM355_E_ARG;
+  if (!c->staged) return fail(c, AM355_E_STATE, "am355_load_changes must be called first");
+  (void)hipSetDevice(c->device);
+  c->replayed = c->ir_fetched = false;
+  c->flags = 0;
+  auto t_begin = std::chrono::steady_clock::now();
+  hipStream_t sa = c->stream, sb = c->stream2;
+  uint32_t n = c->n_changes;
+  size_t n1 = std::max<size_t>(n, 1);
+  c->slot_mask = pow2_at_least(4 * (uint64_t)n + 64) - 1;
+  c->hash_mask = pow2_at_least(2 * (uint64_t)n + 64) - 1;
+  if (c->amap_cap < 16 * n1 + 1024) c->amap_cap = (uint32_t)(16 * n1 + 1024);
+  if (!c->d_entries.ensure(4 * n1) || !c->d_amap_base.ensure(4 * (n1 + 1)) || !c->d_amap_prov.ensure(4 * (size_t)c->amap_cap) ||
+      !c->d_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->d_first_idx.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_hashes.ensure(32 * n1) ||
+      !c->d_hash_tab.ensure(4 * (size_t)(c->hash_mask + 1)) || !c->d_min_idx.ensure(4 * n1) || !c->d_has_dep.ensure(n1) || !c->d_words.ensure(4 * W_NUM) ||
+      !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
+      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM))
+    return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
+  uint32_t* d_words = c->d_words.as<uint32_t>();
+  uint32_t* h_words = c->h_words.as<uint32_t>();
+
+  // ---- stream B: SHA-256 of every change, hash table, dependency resolution (joined at the very end) ----
+  HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, sa));
+  HIPCHK(c, hipEventRecord(c->ev_b0, sa));
+  HIPCHK(c, hipStreamWaitEvent(sb, c->ev_b0, 0));
+  HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
+  HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
+  launch_hash_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_hashes.as<uint8_t>(), c->d_min_idx.as<uint32_t>(),
+                      c->d_hash_tab.as<uint32_t>(), c->hash_mask, d_words + W_FLAGS_B, sb);
+
+  // ---- stream A: parse, actor interning ----
+  HIPCHK(c, hipEventRecord(c->ev[0], sa));
+  launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), sa);
+  HIPCHK(c, hipEventRecord(c->ev_parse, sa));
+  HIPCHK(c, hipStreamWaitEvent(sb, c->ev_parse, 0));
+  launch_deps_resolve(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_hashes.as<uint8_t>(), n, c->d_hash_tab.as<uint32_t>(), c->hash_mask,
+                      c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, sb);
+  HIPCHK(c, hipMemcpyAsync(c->h_hashes.p, c->d_hashes.p, 32 * (size_t)n, hipMemcpyDeviceToHost, sb));
+  HIPCHK(c, hipMemcpyAsync(c->h_has_dep.p, c->d_has_dep.p, n, hipMemcpyDeviceToHost, sb));
+  HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
+  HIPCHK(c, hipEventRecord(c->ev_b1, sb));
+
+  exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_words + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
+  for (int attempt = 0;; attempt++) {
+    HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), sa));
+    HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), sa));
+    launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
+                        c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_words + W_FLAGS_A, d_words + W_FAST_A, sa);
+    HIPCHK(c, hipEventRecord(c->ev[1], sa));
+    HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipMemcpyAsync(c->h_slots.p, c->d_slots.p, 8 * (size_t)(c->slot_mask + 1), hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipMemcpyAsync(h_words, d_words, 12, hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipStreamSynchronize(sa));
+    if (!(h_words[W_FAST_A] & FF_CAPACITY) || attempt) break;
+    // the staging buffer for actor tables was too small: grow to the measured total and redo the interning
+    c->amap_cap = h_words[W_TOTAL_ENTRIES] + 1024;
+    if (!c->d_amap_prov.ensure(4 * (size_t)c->amap_cap)) return fail(c, AM355_E_NOMEM, "device allocation failed (actor tables)");
+    HIPCHK(c, hipMemsetAsync(d_words + W_FAST_A, 0, 4, sa));
+  }
+
+  // ---- host: flags, in-order plan ----
+  auto t_h0 = std::chrono::steady_clock::now();
+  float ms_host = 0;
+  int rc = AM355_OK;
+  {
+    const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+    uint32_t dev_flags = h_words[W_FLAGS_A];
+    for (uint32_t i = 0; i < n; i++) dev_flags |= metas[i].flags;
+    if (dev_flags) { (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
+  }
+  bool fast = h_words[W_FAST_A] == 0;
+  std::vector<uint32_t> slot_rank;
+  int opt_rc = AM355_OK;
+  uint32_t opt_flags = 0;
+  std::string opt_err;
+  if (fast) {
+    opt_rc = plan_fast(c, slot_rank);
+    ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+    if (opt_rc == AM355_OK) opt_rc = run_device(c, &slot_rank);  // optimistic: confirmed (or discarded) when stream B is joined
+    opt_flags = c->flags;
+    opt_err = c->err;
+  }
+  // ---- join stream B ----
+  HIPCHK(c, hipEventSynchronize(c->ev_b1));
+  if (h_words[W_FLAGS_B]) return error_for_flags(c, h_words[W_FLAGS_B], "checksum does not match data");
+  if (fast && h_words[W_FAST_B]) fast = false;
+  if (fast) {
+    if (opt_rc != AM355_OK) { c->flags = opt_flags; c->err = opt_err; return opt_rc; }
+    // heads: changes nobody depends on, sorted (new.js:1582-1583, 1593)
+    auto t0 = std::chrono::steady_clock::now();
+    const uint8_t* hs = c->h_hashes.as<uint8_t>();
+    const uint8_t* dep = c->h_has_dep.as<uint8_t>();
+    std::vector<const uint8_t*> heads;
+    for (uint32_t i = 0; i < n; i++)
+      if (!dep[i]) heads.push_back(hs + 32 * (size_t)i);
+    std::sort(heads.begin(), heads.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
+    c->heads.resize(heads.size() * 32);
+    for (size_t i = 0; i < heads.size(); i++) memcpy(&c->heads[32 * i], heads[i], 32);
+    ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  } else {
+    // general path: exact scheduling on the host, then decode/merge of exactly the applied changes
+    c->flags = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = schedule(c);
+    ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc) return rc;
+    rc = run_device(c, nullptr);
+    if (rc) return rc;
+  }
+  c->used_fast_path = fast;
   auto t_end = std::chrono::steady_clock::now();
 
   am355_stats& s = c->stats;
+  uint32_t NA = (uint32_t)c->actors.size();
   s.n_changes = n; s.n_applied = c->n_applied; s.n_pending = c->n_pending; s.n_actors = NA; s.n_objects = c->counts.n_objects;
   s.n_heads = (uint32_t)(c->heads.size() / 32); s.n_ops = c->n_ops; s.max_op = c->max_op; s.raw_bytes = c->raw.size();
   s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
@@ -548,9 +818,10 @@ extern "C" int am355_replay(am355_ctx* c) {
   (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
   (void)hipEventElapsedTime(&s.ms_merge, c->ev[3], c->ev[4]);
   (void)hipEventElapsedTime(&s.ms_order, c->ev[4], c->ev[5]);
-  s.ms_host_schedule = std::chrono::duration<float, std::milli>(t_h1 - t_h0).count();
+  (void)hipEventElapsedTime(&s.ms_hash_stream, c->ev_b0, c->ev_b1);  // hash stream (SHA-256 + dependency resolution), overlapped
+  s.ms_host_schedule = ms_host;
+  s.fast_path = fast ? 1 : 0;
   s.ms_total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
-  s.ms_sort = 0;
   c->replayed = true;
   return AM355_OK;
 }
@@ -563,9 +834,8 @@ extern "C" int am355_get_stats(const am355_ctx* c, am355_stats* out) {
 
 extern "C" int am355_get_hashes(const am355_ctx* c, uint8_t* out) {
   if (!c || !out) return AM355_E_ARG;
-  if (!c->staged || !c->h_metas.p) return AM355_E_STATE;
-  const ChangeMeta* metas = (const ChangeMeta*)c->h_metas.p;
-  for (uint32_t i = 0; i < c->n_changes; i++) memcpy(out + 32 * i, metas[i].hash, 32);
+  if (!c->replayed || !c->h_hashes.p) return AM355_E_STATE;
+  memcpy(out, c->h_hashes.p, 32 * (size_t)c->n_changes);
   return AM355_OK;
 }
 

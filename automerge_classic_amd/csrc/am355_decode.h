@@ -3,7 +3,14 @@
 #include "am355_internal.h"
 
 namespace am355 {
-void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, hipStream_t st);
+void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, hipStream_t st);
+void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
+                         uint32_t tab_mask, uint32_t* flags, hipStream_t st);
+void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,
+                         const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st);
+void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
+                         unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, hipStream_t st);
+// slot_rank == nullptr: `amap` already holds global actor ranks
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_plans, const uint32_t* amap,
-                           OpCols cols, uint32_t* flags, hipStream_t st);
+                           const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st);
 }  // namespace am355

@@ -104,14 +104,23 @@ __device__ __forceinline__ void sha_rounds(uint32_t h[8], uint32_t w[16]) {
   h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// 16-byte loads at arbitrary alignment (changes are packed back to back in the arena; gfx950 global loads are
+// alignment-agnostic, so this compiles to global_load_dwordx4)
+struct __attribute__((packed)) U4 {
+  uint32_t x, y, z, w;
+};
+
 __device__ void sha256_bytes(const uint8_t* p, uint32_t len, uint8_t out[32]) {
   uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
   uint32_t w[16];
   uint32_t i = 0;
   for (; i + 64 <= len; i += 64) {
-    for (int k = 0; k < 16; k++) {
-      const uint8_t* q = p + i + 4 * k;
-      w[k] = (uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | q[3];
+    for (int k = 0; k < 4; k++) {
+      U4 v = *(const U4*)(p + i + 16 * k);
+      w[4 * k] = __builtin_bswap32(v.x);
+      w[4 * k + 1] = __builtin_bswap32(v.y);
+      w[4 * k + 2] = __builtin_bswap32(v.z);
+      w[4 * k + 3] = __builtin_bswap32(v.w);
     }
     sha_rounds(h, w);
   }
@@ -199,7 +208,7 @@ __device__ bool rle_count_sum(const uint8_t* p, uint32_t len, uint64_t& count, u
 }
 
 __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
-                                                         uint32_t n_changes, ChangeMeta* __restrict__ metas) {
+                                                         uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries) {
   uint32_t c = gtid();
   if (c >= n_changes) return;
   ChangeMeta m;
@@ -209,8 +218,10 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
   m.flags = 0;
   m.seq = m.start_op = 0;
   m.n_deps = m.deps_off = m.actor_off = m.actor_len = m.n_other = m.others_off = m.n_ops = m.n_preds = 0;
+  m.n_entries = 0;
+  m.author_slot = m.max_first = NONE32;
+  m.pad = 0;
   for (int k = 0; k < C_NUM; k++) m.col_off[k] = m.col_len[k] = 0;
-  for (int k = 0; k < 32; k++) m.hash[k] = 0;
   const uint8_t* p = arena + m.base;
   do {
     if (len64 > 0xfffffff0ull) { m.flags |= F_OVERFLOW; break; }
@@ -221,8 +232,6 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
     if (!read_uleb(cur, chunk_len)) { m.flags |= F_BAD_LEB; break; }
     // the raw arena holds uncompressed (type 1) chunks only; exactly one container per change, no trailing bytes
     if (p[8] != 1 || chunk_len != (uint64_t)(m.len - cur.off)) { m.flags |= F_BAD_CHUNK; break; }
-    sha256_bytes(p + 8, m.len - 8, m.hash);
-    if (m.hash[0] != p[4] || m.hash[1] != p[5] || m.hash[2] != p[6] || m.hash[3] != p[7]) { m.flags |= F_BAD_CHECKSUM; break; }
     // change header
     uint64_t v;
     int64_t sv;
@@ -245,6 +254,8 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
       ok = read_uleb(cur, l) && skip_bytes(cur, l);
     }
     if (!ok) { m.flags |= F_BAD_LEB; break; }
+    if (m.actor_len >= 65536) { m.flags |= F_UNSUPPORTED; break; }
+    m.n_entries = m.n_other + 1;
     // column directory: ids strictly ascending ignoring the deflate bit (bit 3), which a change must not use
     uint64_t ncols;
     if (!read_uleb(cur, ncols) || ncols > m.len) { m.flags |= F_BAD_LEB; break; }
@@ -281,6 +292,166 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
     if (m.start_op + m.n_ops > 0xfffffff0ull) m.flags |= F_OVERFLOW;
   } while (0);
   metas[c] = m;
+  n_entries[c] = m.flags ? 0 : m.n_entries;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_hash_changes: SHA-256 of every change (one lane per change) + checksum verification. Runs on its own stream:
+// nothing on the decode/merge critical path needs the hashes (they feed dependency resolution and the heads).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_hash_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets, uint32_t n_changes,
+                                                        uint8_t* __restrict__ hashes, uint32_t* __restrict__ min_idx, uint32_t* __restrict__ flags) {
+  uint32_t c = gtid();
+  if (c >= n_changes) return;
+  const uint8_t* p = arena + offsets[c];
+  uint64_t len = offsets[c + 1] - offsets[c];
+  min_idx[c] = c;
+  uint8_t h[32];
+  for (int k = 0; k < 32; k++) h[k] = 0;
+  if (len >= 10 && len < 0xfffffff0ull) {
+    sha256_bytes(p + 8, (uint32_t)len - 8, h);
+    if (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7]) atomicOr(flags, (uint32_t)F_BAD_CHECKSUM);  // columnar.js:702-704
+  }
+  for (int k = 0; k < 32; k++) hashes[32 * (size_t)c + k] = h[k];
+}
+
+__device__ __forceinline__ bool equal32(const uint8_t* a, const uint8_t* b) {
+  for (int k = 0; k < 32; k++)
+    if (a[k] != b[k]) return false;
+  return true;
+}
+__device__ __forceinline__ uint32_t hash_slot(const uint8_t* h, uint32_t mask) {
+  uint64_t v = 0;
+  for (int k = 0; k < 8; k++) v |= (uint64_t)h[k] << (8 * k);
+  return (uint32_t)((v * 0x9e3779b97f4a7c15ull) >> 32) & mask;
+}
+
+// device hash table of change hashes: tab[slot] = (index of the first change that claimed the slot) + 1;
+// min_idx[claimer] = smallest input index among the changes with that same hash (duplicates)
+__global__ __launch_bounds__(BLOCK) void k_hash_insert(const uint8_t* __restrict__ hashes, uint32_t n, uint32_t* __restrict__ tab, uint32_t mask,
+                                                       uint32_t* __restrict__ min_idx) {
+  uint32_t c = gtid();
+  if (c >= n) return;
+  const uint8_t* h = hashes + 32 * (size_t)c;
+  uint32_t i = hash_slot(h, mask);
+  for (uint32_t probes = 0; probes <= mask; probes++) {
+    uint32_t old = atomicCAS(&tab[i], 0u, c + 1);
+    if (old == 0) return;
+    if (equal32(hashes + 32 * (size_t)(old - 1), h)) { atomicMin(&min_idx[old - 1], c); return; }
+    i = (i + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ uint32_t hash_find(const uint8_t* __restrict__ hashes, const uint32_t* __restrict__ tab, uint32_t mask,
+                                              const uint32_t* __restrict__ min_idx, const uint8_t* h) {
+  uint32_t i = hash_slot(h, mask);
+  for (uint32_t probes = 0; probes <= mask; probes++) {
+    uint32_t v = tab[i];
+    if (v == 0) return NONE32;
+    if (equal32(hashes + 32 * (size_t)(v - 1), h)) return min_idx[v - 1];
+    i = (i + 1) & mask;
+  }
+  return NONE32;
+}
+
+// every dependency must be an earlier change of the batch for the in-order fast path (new.js:1562-1567)
+__global__ __launch_bounds__(BLOCK) void k_deps_resolve(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
+                                                        const uint8_t* __restrict__ hashes, uint32_t n, const uint32_t* __restrict__ tab, uint32_t mask,
+                                                        const uint32_t* __restrict__ min_idx, uint8_t* __restrict__ has_dependent,
+                                                        uint32_t* __restrict__ fast_flags) {
+  uint32_t c = gtid();
+  if (c >= n) return;
+  const ChangeMeta* m = &metas[c];
+  if (m->flags) return;
+  uint32_t ff = 0;
+  if (hash_find(hashes, tab, mask, min_idx, hashes + 32 * (size_t)c) != c) ff |= FF_DUP_HASH;
+  const uint8_t* deps = arena + m->base + m->deps_off;
+  for (uint32_t k = 0; k < m->n_deps; k++) {
+    uint32_t d = hash_find(hashes, tab, mask, min_idx, deps + 32 * (size_t)k);
+    if (d == NONE32) ff |= FF_MISSING_DEP;
+    else {
+      if (d >= c) ff |= FF_LATE_DEP;
+      has_dependent[d] = 1;
+    }
+  }
+  if (ff) atomicOr(fast_flags, ff);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// actor ids: device-side interning.  slots[i] = ((arena offset of the id bytes + 1) << 16) | length, 0 = empty.
+// The slot index is the provisional actor number; the host ranks the (few) distinct ids lexicographically.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restrict__ arena, unsigned long long* __restrict__ slots, uint32_t mask,
+                                                         uint32_t off, uint32_t len) {
+  const uint8_t* p = arena + off;
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (uint32_t k = 0; k < len; k++) h = (h ^ p[k]) * 0x100000001b3ull;
+  uint32_t i = (uint32_t)(h >> 20) & mask;
+  unsigned long long mine = ((unsigned long long)off + 1) << 16 | len;
+  for (uint32_t probes = 0; probes <= mask; probes++) {
+    unsigned long long v = slots[i];
+    if (v == 0) {
+      v = atomicCAS(&slots[i], 0ull, mine);
+      if (v == 0) return i;
+    }
+    if ((uint32_t)(v & 0xffff) == len) {
+      const uint8_t* q = arena + ((v >> 16) - 1);
+      bool eq = true;
+      for (uint32_t k = 0; k < len && eq; k++) eq = p[k] == q[k];
+      if (eq) return i;
+    }
+    i = (i + 1) & mask;
+  }
+  return NONE32;
+}
+
+__global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
+                                                        const uint32_t* __restrict__ amap_base, uint32_t* __restrict__ amap, uint32_t amap_cap,
+                                                        unsigned long long* __restrict__ slots, uint32_t mask, uint32_t* __restrict__ first_idx,
+                                                        uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags) {
+  uint32_t c = gtid();
+  if (c >= n) return;
+  ChangeMeta* m = &metas[c];
+  if (m->flags) return;
+  uint32_t base = amap_base[c];
+  if ((uint64_t)base + m->n_entries > amap_cap) { atomicOr(fast_flags, (uint32_t)FF_CAPACITY); return; }
+  const uint8_t* p = arena + m->base;
+  uint32_t abs0 = (uint32_t)m->base;
+  uint32_t s = actor_find_or_insert(arena, slots, mask, abs0 + m->actor_off, m->actor_len);
+  if (s == NONE32) { atomicOr(flags, (uint32_t)F_UNKNOWN_ACTOR_DEV); return; }
+  amap[base] = s;
+  m->author_slot = s;
+  atomicMin(&first_idx[s], c);
+  Cur cur{p, m->others_off, m->len};
+  for (uint32_t k = 0; k < m->n_other; k++) {
+    uint64_t l;
+    read_uleb(cur, l);
+    uint32_t off = cur.off;
+    skip_bytes(cur, l);
+    uint32_t t = l < 65536 ? actor_find_or_insert(arena, slots, mask, abs0 + off, (uint32_t)l) : NONE32;
+    if (t == NONE32) { atomicOr(flags, l < 65536 ? (uint32_t)F_UNKNOWN_ACTOR_DEV : (uint32_t)F_UNSUPPORTED); t = 0; }
+    amap[base + 1 + k] = t;
+  }
+}
+
+// every actor a change mentions must already be in the document when the change is read (new.js:1442-1449):
+// with in-order application that means its first change has an index <= this one
+__global__ __launch_bounds__(BLOCK) void k_actor_check(ChangeMeta* __restrict__ metas, uint32_t n, const uint32_t* __restrict__ amap_base,
+                                                       const uint32_t* __restrict__ amap, uint32_t amap_cap, const uint32_t* __restrict__ first_idx,
+                                                       uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags) {
+  uint32_t c = gtid();
+  if (c >= n) return;
+  ChangeMeta* m = &metas[c];
+  if (m->flags) return;
+  uint32_t base = amap_base[c];
+  if ((uint64_t)base + m->n_entries > amap_cap) return;
+  uint32_t mx = 0;
+  for (uint32_t k = 0; k < m->n_entries; k++) {
+    uint32_t f = first_idx[amap[base + k]];
+    mx = f > mx ? f : mx;  // NONE32 (no change by that actor in the batch) also lands on the general path
+  }
+  m->max_first = mx;
+  if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -448,14 +619,21 @@ __device__ __forceinline__ bool bool_next(BoolDec& b, bool& v) {
 // ---------------------------------------------------------------------------------------------------------
 enum Task { T_OBJ, T_KEY, T_KEYSTR, T_INSERT, T_ACTION, T_VALUE, T_PREDNUM, T_PREDS, T_NUM };
 
-__device__ __forceinline__ uint32_t xlate_actor(const uint32_t* __restrict__ amap, const ChangePlan& pl, int64_t local, uint32_t& err) {
+// change-local actor index -> global actor rank. `amap` holds either final ranks (slot_rank == nullptr: table built by
+// the host scheduler) or device actor-table slots that `slot_rank` maps to ranks.
+struct ActorXlate {
+  const uint32_t* amap;
+  const uint32_t* slot_rank;
+};
+__device__ __forceinline__ uint32_t xlate_actor(const ActorXlate& x, const ChangePlan& pl, int64_t local, uint32_t& err) {
   if (local < 0 || (uint64_t)local >= pl.n_actors) { err |= F_BAD_ROW; return 0; }
-  return amap[pl.amap_base + (uint32_t)local];
+  uint32_t v = x.amap[pl.amap_base + (uint32_t)local];
+  return x.slot_rank ? x.slot_rank[v] : v;
 }
 
 __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                           const ChangePlan* __restrict__ plans, uint32_t n_plans,
-                                                          const uint32_t* __restrict__ amap, OpCols o, uint32_t* __restrict__ flags) {
+                                                          ActorXlate amap, OpCols o, uint32_t* __restrict__ flags) {
   uint32_t pi = gtid();
   if (pi >= n_plans) return;
   const ChangePlan pl = plans[pi];
@@ -584,16 +762,39 @@ __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restri
   if (err) atomicOr(flags, err);
 }
 
-void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, hipStream_t st) {
+void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, hipStream_t st) {
   if (!n_changes) return;
-  AM355_LAUNCH_INDEPENDENT(k_parse_changes, dim3((n_changes + WAVE - 1) / WAVE), dim3(WAVE), st, arena, offsets, n_changes, metas);
+  AM355_LAUNCH_INDEPENDENT(k_parse_changes, dim3((n_changes + WAVE - 1) / WAVE), dim3(WAVE), st, arena, offsets, n_changes, metas, n_entries);
+}
+
+void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
+                         uint32_t tab_mask, uint32_t* flags, hipStream_t st) {
+  if (!n) return;
+  AM355_LAUNCH_INDEPENDENT(k_hash_changes, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), st, arena, offsets, n, hashes, min_idx, flags);
+  AM355_LAUNCH_INDEPENDENT(k_hash_insert, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, (const uint8_t*)hashes, n, hash_tab, tab_mask, min_idx);
+}
+
+void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,
+                         const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st) {
+  if (!n) return;
+  AM355_LAUNCH_INDEPENDENT(k_deps_resolve, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, arena, metas, hashes, n, hash_tab, tab_mask, min_idx,
+                           has_dependent, fast_flags);
+}
+
+void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
+                         unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, hipStream_t st) {
+  if (!n) return;
+  AM355_LAUNCH_INDEPENDENT(k_actor_intern, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask,
+                           first_idx, flags, fast_flags);
+  AM355_LAUNCH_INDEPENDENT(k_actor_check, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
+                           (const uint32_t*)first_idx, flags, fast_flags);
 }
 
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_plans, const uint32_t* amap,
-                           OpCols cols, uint32_t* flags, hipStream_t st) {
+                           const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st) {
   if (!n_plans) return;
-  AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_plans + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans, n_plans, amap,
-                           cols, flags);
+  ActorXlate x{amap, slot_rank};
+  AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_plans + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans, n_plans, x, cols, flags);
 }
 
 }  // namespace am355

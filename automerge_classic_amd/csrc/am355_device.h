@@ -33,6 +33,7 @@ enum Flag : uint32_t {
   F_BAD_COUNTER = 1u << 11,     // new.js:954-956 increment for unknown counter
   F_UNSUPPORTED = 1u << 12,     // legal input outside what the GPU path serves (documented in DESIGN.md)
   F_OVERFLOW = 1u << 13,        // counters/offsets beyond the engine's 32-bit fields
+  F_UNKNOWN_ACTOR_DEV = 1u << 17,  // new.js:1442-1449 actorId not known to document (== AM355_F_UNKNOWN_ACTOR)
 };
 
 __device__ __forceinline__ uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }

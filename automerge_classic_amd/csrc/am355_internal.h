@@ -13,13 +13,25 @@ struct ChangeMeta {
   uint64_t base;
   uint32_t len;
   uint32_t flags;
-  uint8_t hash[32];
   uint64_t seq, start_op;
+  uint32_t n_entries;    // actor table entries: author + others
+  uint32_t author_slot;  // slot of the author in the device actor table (k_actor_intern)
+  uint32_t max_first;    // max over its actor entries of "first change index authored by that actor" (k_actor_check)
+  uint32_t pad;
   uint32_t n_deps, deps_off;
   uint32_t actor_off, actor_len;
   uint32_t n_other, others_off;
   uint32_t col_off[C_NUM], col_len[C_NUM];
   uint32_t n_ops, n_preds;
+};
+
+// bits of the "fast path" word: any bit set => the host runs the general scheduler (new.js:1550-1597) itself
+enum FastFlag : uint32_t {
+  FF_DUP_HASH = 1u << 0,      // the same change appears twice
+  FF_MISSING_DEP = 1u << 1,   // a dependency is not in the batch
+  FF_LATE_DEP = 1u << 2,      // a dependency appears later in the batch than its dependent
+  FF_LATE_ACTOR = 1u << 3,    // a change mentions an actor whose first change comes later in the batch
+  FF_CAPACITY = 1u << 4       // actor-table staging buffer too small (retry after growing it)
 };
 
 // Per-change launch parameters produced by the host scheduler for the decode kernels (applied changes only)

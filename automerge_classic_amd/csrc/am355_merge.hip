@@ -161,44 +161,60 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
 // ---------------------------------------------------------------------------------------------------------
 // k_emit: one lane per op row, after all succ counts are final.  Classifies visible values.
 // ---------------------------------------------------------------------------------------------------------
+// Wave-aggregated append: one atomic per wavefront instead of one per lane. Must be reached by every lane.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
+  unsigned long long m = __ballot(want);
+  uint32_t lane = threadIdx.x & (WAVE - 1);
+  uint32_t leader = m ? (uint32_t)__ffsll(m) - 1 : 0;
+  uint32_t base = 0;
+  if (m && lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, (int)leader);
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+}
+
 __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   uint32_t g = gtid();
-  if (g >= b.n_ops) return;
   const OpCols& o = b.ops;
-  uint8_t kind = b.kind[g];
-  uint32_t a = o.action[g];
-  bool is_make = kind != K_DEL && kind != K_NONE && (a & 1) == 0;
-  b.obj_index[g] = is_make ? 1u : 0u;  // scanned later
-  if (kind == K_NONE || kind == K_DEL) return;
-  bool vis = b.succ_cnt[g] == 0;
-  uint32_t tl = o.val_tl[g];
-  if (kind == K_MAP) {
-    unsigned long long trig = 0;
-    bool emit = false;
+  bool in_range = g < b.n_ops;
+  uint8_t kind = in_range ? b.kind[g] : (uint8_t)K_NONE;
+  uint32_t a = in_range ? o.action[g] : 1;
+  bool live = kind != K_NONE && kind != K_DEL;
+  if (in_range) b.obj_index[g] = (live && (a & 1) == 0) ? 1u : 0u;  // is-make flag, scanned later
+  bool vis = live && b.succ_cnt[g] == 0;
+  bool want_map = false, want_ins = false, want_upd = false;
+  unsigned long long trig = 0;
+  uint32_t el = NONE32;
+  if (live && kind == K_MAP) {
+    uint32_t tl = o.val_tl[g];
     if (a == 1) {
-      if (vis) { emit = true; trig = pack_id(o.id_ctr[g], o.id_actor[g]); }
-      else if ((tl & 15) == 8 && b.inc_cnt[g] == b.succ_cnt[g]) { emit = true; trig = b.last_inc[g]; }  // every succ is an inc
-    } else if ((a & 1) == 0) {
-      if (vis) { emit = true; trig = pack_id(o.id_ctr[g], o.id_actor[g]); }
+      if (vis) { want_map = true; trig = pack_id(o.id_ctr[g], o.id_actor[g]); }
+      else if ((tl & 15) == 8 && b.inc_cnt[g] == b.succ_cnt[g]) { want_map = true; trig = b.last_inc[g]; }  // every succ is an inc
+    } else if ((a & 1) == 0 && vis) {
+      want_map = true;
+      trig = pack_id(o.id_ctr[g], o.id_actor[g]);
     }
-    if (emit) {
-      uint32_t slot = atomicAdd(&b.counts->n_map_emit, 1u);
-      b.em_row[slot] = g;
-      b.em_trig[slot] = trig;
-      atomicMax(&b.counts->max_key_len, o.key_len[g]);
-    }
-  } else {
+  } else if (live) {
     bool valued = (a == 1) || (a & 1) == 0;
-    if (kind == K_LIST_INS) b.ins_row[atomicAdd(&b.counts->n_list_ins, 1u)] = g;
-    if (vis && !valued) { atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED); return; }  // value-less visible row: reference 'remove' quirk
-    if (vis) {
-      uint32_t el = kind == K_LIST_INS ? g : b.ref_row[g];
+    want_ins = kind == K_LIST_INS;
+    if (vis && !valued) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);  // value-less visible row: reference 'remove' quirk
+    if (vis && valued) {
+      el = kind == K_LIST_INS ? g : b.ref_row[g];
       if (el != NONE32) {
         atomicAdd(&b.val_cnt[el], 1u);
-        if (kind == K_LIST_UPD) b.upd_row[atomicAdd(&b.counts->n_list_upd, 1u)] = g;
+        want_upd = kind == K_LIST_UPD;
       }
     }
   }
+  uint32_t slot = wave_append(&b.counts->n_map_emit, want_map);
+  if (want_map) {
+    b.em_row[slot] = g;
+    b.em_trig[slot] = trig;
+    atomicMax(&b.counts->max_key_len, o.key_len[g]);
+  }
+  slot = wave_append(&b.counts->n_list_ins, want_ins);
+  if (want_ins) b.ins_row[slot] = g;
+  slot = wave_append(&b.counts->n_list_upd, want_upd);
+  if (want_upd) b.upd_row[slot] = g;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -472,7 +488,7 @@ void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st) {
   (void)hipMemsetAsync(b.last_inc, 0, sizeof(unsigned long long) * N, st);
   if (N) {
     AM355_LAUNCH_INDEPENDENT(k_resolve, grid_for(N), dim3(BLOCK), st, b);
-    AM355_LAUNCH_INDEPENDENT(k_emit, grid_for(N), dim3(BLOCK), st, b);
+    hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
   }
   (void)hipMemcpyAsync(h_counts, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);

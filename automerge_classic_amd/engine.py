@@ -30,7 +30,8 @@ class Stats(ctypes.Structure):
         ("n_map_values", ctypes.c_uint64), ("n_list_elems", ctypes.c_uint64), ("n_edits", ctypes.c_uint64),
         ("ir_bytes", ctypes.c_uint64),
         ("ms_total", ctypes.c_float), ("ms_parse", ctypes.c_float), ("ms_host_schedule", ctypes.c_float),
-        ("ms_decode", ctypes.c_float), ("ms_merge", ctypes.c_float), ("ms_order", ctypes.c_float), ("ms_sort", ctypes.c_float),
+        ("ms_decode", ctypes.c_float), ("ms_merge", ctypes.c_float), ("ms_order", ctypes.c_float), ("ms_hash_stream", ctypes.c_float),
+        ("fast_path", ctypes.c_uint32),
     ]
 
     def as_dict(self):

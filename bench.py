@@ -84,7 +84,7 @@ def main():
         eng.replay()
     barrier()
     t0 = time.perf_counter()
-    parts = {"ms_parse": 0.0, "ms_host_schedule": 0.0, "ms_decode": 0.0, "ms_merge": 0.0, "ms_order": 0.0}
+    parts = {"ms_parse": 0.0, "ms_host_schedule": 0.0, "ms_decode": 0.0, "ms_merge": 0.0, "ms_order": 0.0, "ms_hash_stream": 0.0}
     for _ in range(args.steps):
         eng.replay()
         st = eng.stats()

@@ -82,7 +82,9 @@ typedef struct {
   uint64_t n_map_values, n_list_elems, n_edits;
   uint64_t ir_bytes;     /* bytes of patch IR produced in HBM by the last replay */
   /* timing of the last am355_replay (milliseconds; device figures from HIP events on the engine's stream) */
-  float ms_total, ms_parse, ms_host_schedule, ms_decode, ms_merge, ms_order, ms_sort;
+  float ms_total, ms_parse, ms_host_schedule, ms_decode, ms_merge, ms_order;
+  float ms_hash_stream;  /* SHA-256 + dependency resolution on the second stream (overlaps decode/merge) */
+  uint32_t fast_path;    /* 1: in-order fast path (device-verified), 0: general host scheduler */
 } am355_stats;
 int am355_get_stats(const am355_ctx *ctx, am355_stats *out);
 

@@ -1,0 +1,106 @@
+"""Kernel-logic and host-logic tests that run WITHOUT a GPU: the engine's .hip sources compiled by g++ against the
+HIP-runtime emulation in tests/emu (every kernel thread an OS thread). This checks the algorithms, the host
+scheduler (fast and general path), the C ABI and the JSON renderer against the oracle and the reference goldens.
+It says nothing about the GPU build: the parity tests proper are in test_engine_gpu.py (-m gpu)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util
+import oracle_lib
+from automerge_classic_amd import engine, loggen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libam355_emu.so")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    e = engine.Engine(0, EMU_LIB)
+    yield e
+    e.close()
+
+
+def emu_patch(eng, log):
+    eng.load_changes(log)
+    eng.replay()
+    return eng.patch_json()
+
+
+@pytest.mark.parametrize("name", golden_util.fixture_names())
+def test_golden_reference_patches(eng, name):
+    fx = golden_util.load_fixture(name)
+    assert emu_patch(eng, fx["log"]) == fx["expected"]
+    general = any(k in name for k in ("shuffled", "pending", "dups"))
+    assert eng.stats().fast_path == (0 if general else 1)
+
+
+@pytest.mark.parametrize("kind,kw", [
+    (loggen.KIND_TEXT_TYPING, dict(n_ops=1500, ops_per_change=40)),
+    (loggen.KIND_TEXT_TYPING, dict(n_ops=300, ops_per_change=1)),
+    (loggen.KIND_MAP_LWW, dict(n_actors=8, n_rounds=4, n_keys=200)),
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=7, n_rounds=3, ins_per_change=100, del_per_change=10, n_objects=1)),
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=16, n_rounds=3, ins_per_change=30, del_per_change=8, n_objects=5)),
+])
+def test_generated_workloads_match_oracle(eng, kind, kw):
+    log = loggen.generate(kind, seed=11, deflate=True, **kw)
+    assert emu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
+    assert eng.stats().fast_path == 1
+    # the same changes in a random delivery order: general scheduler, same document
+    perm = np.random.default_rng(5).permutation(log.n_changes)
+    shuf = log.reordered(perm)
+    assert emu_patch(eng, shuf) == oracle_lib.OracleDoc(shuf).patch_json()
+
+
+def test_empty_batch_and_single_change(eng):
+    empty = loggen.ChangeLog.from_changes([])
+    assert emu_patch(eng, empty) == oracle_lib.OracleDoc(empty).patch_json()
+    log = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=0, ops_per_change=10, seed=1)
+    assert emu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
+
+
+def test_hashes_and_rows(eng):
+    import hashlib
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=2, ins_per_change=20, del_per_change=4, n_objects=1, seed=3)
+    eng.load_changes(log)
+    eng.replay()
+    h = eng.hashes()
+    for i in range(log.n_changes):
+        assert bytes(h[i]) == hashlib.sha256(log.change(i)[8:]).digest()
+    rows = eng.rows()
+    ref = oracle_lib.OracleDoc(log)
+    assert len(rows["action"]) == ref.n_ops
+    # succ counts: every delete adds one successor to the element it removes
+    assert int(rows["succ_cnt"].sum()) == int((rows["action"] == 3).sum())
+
+
+def test_invalid_and_unsupported_inputs_are_reported(eng):
+    log = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=50, ops_per_change=10, seed=2)
+    arena = log.arena.copy()
+    arena[int(log.offsets[2]) + 30] ^= 0x1
+    bad = loggen.ChangeLog(arena, log.offsets, log.n_ops)
+    eng.load_changes(bad)
+    with pytest.raises(engine.InvalidChanges) as ei:
+        eng.replay()
+    assert "BAD_CHECKSUM" in ei.value.flag_names
+    # a sequence gap: drop the second change of a single-actor history but keep the third (its dep is then missing -> pending)
+    part = log.reordered([0, 1, 3, 4, 5])
+    assert json.loads(emu_patch(eng, part))["pendingChanges"] == 3
+    assert emu_patch(eng, part) == oracle_lib.OracleDoc(part).patch_json()
+
+
+def test_device_primitives(eng):
+    rng = np.random.default_rng(1)
+    for n in (1, 64, 2049, 9000):
+        vals = rng.integers(0, 5, n, dtype=np.uint32)
+        out, total = eng.test_scan(vals)
+        assert np.array_equal(out, np.concatenate(([0], np.cumsum(vals)[:-1])).astype(np.uint32)) and total == int(vals.sum())
+        keys = rng.integers(0, 1 << 20, n, dtype=np.uint64)
+        k, v = eng.test_sort(keys, np.arange(n, dtype=np.uint32), 20)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(k, keys[order]) and np.array_equal(v, order.astype(np.uint32))
