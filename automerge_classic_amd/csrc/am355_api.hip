@@ -633,10 +633,13 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     b.actor_tab_off = c->d_tab_off.as<uint32_t>();
     b.spans = c->d_spans.as<ActorSpan>();
     b.bits_ctr = (uint32_t)bits_ctr; b.bits_actor = (uint32_t)bits_actor;
-    b.obj_row = carve<uint32_t>(p, Nc); b.ref_row = carve<uint32_t>(p, Nc); b.succ_cnt = carve<uint32_t>(p, Nc); b.inc_cnt = carve<uint32_t>(p, Nc);
-    b.val_cnt = carve<uint32_t>(p, Nc); b.obj_index = carve<uint32_t>(p, Nc);
+    b.zero_base = p;
+    b.succ_cnt = carve<uint32_t>(p, Nc); b.inc_cnt = carve<uint32_t>(p, Nc); b.val_cnt = carve<uint32_t>(p, Nc);
+    b.inc_sum = carve<unsigned long long>(p, Nc); b.last_inc = carve<unsigned long long>(p, Nc);
+    b.zero_bytes = (size_t)(p - (uint8_t*)b.zero_base);
+    b.obj_row = carve<uint32_t>(p, Nc); b.ref_row = carve<uint32_t>(p, Nc); b.obj_index = carve<uint32_t>(p, Nc);
     b.em_row = carve<uint32_t>(p, Nc); b.ins_row = carve<uint32_t>(p, Nc); b.upd_row = carve<uint32_t>(p, Nc); b.next_sib = carve<uint32_t>(p, Nc);
-    b.inc_sum = carve<unsigned long long>(p, Nc); b.last_inc = carve<unsigned long long>(p, Nc); b.em_trig = carve<unsigned long long>(p, Nc);
+    b.em_trig = carve<unsigned long long>(p, Nc);
     b.kind = carve<uint8_t>(p, Nc);
     b.first_child = carve<uint32_t>(p, 2 * Nc);
     b.succ_a = carve<uint32_t>(p, 2 * Nc + 2); b.succ_b = carve<uint32_t>(p, 2 * Nc + 2); b.dist_a = carve<uint32_t>(p, 2 * Nc + 2); b.dist_b = carve<uint32_t>(p, 2 * Nc + 2);

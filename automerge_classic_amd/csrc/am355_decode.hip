@@ -19,9 +19,34 @@ namespace am355 {
 // ---------------------------------------------------------------------------------------------------------
 // byte cursor + LEB128
 // ---------------------------------------------------------------------------------------------------------
+// Byte cursor with an 8-byte register window: column streams are consumed a byte at a time by the LEB128 readers,
+// and one 8-byte load (any alignment) per 8 bytes instead of one load per byte cuts the dependent memory round
+// trips that dominate these latency-bound decoders.
+struct __attribute__((packed)) U8B {
+  uint64_t v;
+};
 struct Cur {
   const uint8_t* p;
   uint32_t off, len;
+  uint64_t win;
+  uint32_t win_off;  // window holds bytes [win_off, win_off + 8); WIN_EMPTY makes every offset miss
+  __device__ __forceinline__ Cur() {}
+  static constexpr uint32_t WIN_EMPTY = 0xffffff00u;  // o - WIN_EMPTY = o + 256 >= 8 for every valid offset
+  __device__ __forceinline__ Cur(const uint8_t* p_, uint32_t off_, uint32_t len_) : p(p_), off(off_), len(len_), win(0), win_off(WIN_EMPTY) {}
+  __device__ __forceinline__ uint32_t byte_at(uint32_t o) {
+    uint32_t d = o - win_off;
+    if (d >= 8) {
+      // refill; near the end of the buffer fall back to byte loads so nothing beyond `len` is touched
+      if (o + 8 <= len) win = ((const U8B*)(p + o))->v;
+      else {
+        win = 0;
+        for (uint32_t k = 0; o + k < len && k < 8; k++) win |= (uint64_t)p[o + k] << (8 * k);
+      }
+      win_off = o;
+      d = 0;
+    }
+    return (uint32_t)(win >> (8 * d)) & 0xff;
+  }
 };
 
 constexpr uint64_t MAX_SAFE = 9007199254740991ull;  // 2^53 - 1
@@ -31,7 +56,7 @@ __device__ __forceinline__ bool read_uleb(Cur& c, uint64_t& out) {
   uint64_t v = 0;
   int shift = 0;
   while (c.off < c.len) {
-    uint32_t b = c.p[c.off];
+    uint32_t b = c.byte_at(c.off);
     if (shift == 63 && (b & 0xfe)) return false;
     v |= (uint64_t)(b & 0x7f) << shift;
     shift += 7;
@@ -49,7 +74,7 @@ __device__ __forceinline__ bool read_sleb(Cur& c, int64_t& out) {
   uint64_t v = 0;
   int shift = 0;
   while (c.off < c.len) {
-    uint32_t b = c.p[c.off];
+    uint32_t b = c.byte_at(c.off);
     if (shift == 63 && b != 0 && b != 0x7f) return false;
     v |= (uint64_t)(b & 0x7f) << shift;
     shift += 7;
@@ -177,7 +202,7 @@ __device__ __forceinline__ int col_slot(uint64_t id) {
 // number of values and their sum in an RLE-uint column (run level; validity of individual values is checked
 // again by the decode kernel)
 __device__ bool rle_count_sum(const uint8_t* p, uint32_t len, uint64_t& count, uint64_t& sum) {
-  Cur c{p, 0, len};
+  Cur c(p, 0, len);
   count = 0;
   sum = 0;
   while (c.off < c.len) {
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
     if (len64 > 0xfffffff0ull) { m.flags |= F_OVERFLOW; break; }
     if (m.len < 10) { m.flags |= F_BAD_CHUNK; break; }
     if (p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83) { m.flags |= F_BAD_MAGIC; break; }
-    Cur cur{p, 9, m.len};
+    Cur cur(p, 9, m.len);
     uint64_t chunk_len;
     if (!read_uleb(cur, chunk_len)) { m.flags |= F_BAD_LEB; break; }
     // the raw arena holds uncompressed (type 1) chunks only; exactly one container per change, no trailing bytes
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
     if (m.flags) break;
     if (total > (uint64_t)(m.len - cur.off)) { m.flags |= F_BAD_CHUNK; break; }
     uint32_t data_off = cur.off;
-    Cur dir{p, dir_off, m.len};
+    Cur dir(p, dir_off, m.len);
     for (uint64_t k = 0; k < ncols; k++) {
       uint64_t id, l;
       read_uleb(dir, id);
@@ -316,9 +341,8 @@ __global__ __launch_bounds__(WAVE) void k_hash_changes(const uint8_t* __restrict
 }
 
 __device__ __forceinline__ bool equal32(const uint8_t* a, const uint8_t* b) {
-  for (int k = 0; k < 32; k++)
-    if (a[k] != b[k]) return false;
-  return true;
+  U4 a0 = *(const U4*)a, a1 = *(const U4*)(a + 16), b0 = *(const U4*)b, b1 = *(const U4*)(b + 16);
+  return a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
 }
 __device__ __forceinline__ uint32_t hash_slot(const uint8_t* h, uint32_t mask) {
   uint64_t v = 0;
@@ -354,19 +378,20 @@ __device__ __forceinline__ uint32_t hash_find(const uint8_t* __restrict__ hashes
   return NONE32;
 }
 
-// every dependency must be an earlier change of the batch for the in-order fast path (new.js:1562-1567)
-__global__ __launch_bounds__(BLOCK) void k_deps_resolve(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
-                                                        const uint8_t* __restrict__ hashes, uint32_t n, const uint32_t* __restrict__ tab, uint32_t mask,
-                                                        const uint32_t* __restrict__ min_idx, uint8_t* __restrict__ has_dependent,
-                                                        uint32_t* __restrict__ fast_flags) {
-  uint32_t c = gtid();
+// every dependency must be an earlier change of the batch for the in-order fast path (new.js:1562-1567).
+// One wavefront per change, one lane per dependency hash.
+__global__ __launch_bounds__(WAVE) void k_deps_resolve(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
+                                                       const uint8_t* __restrict__ hashes, uint32_t n, const uint32_t* __restrict__ tab, uint32_t mask,
+                                                       const uint32_t* __restrict__ min_idx, uint8_t* __restrict__ has_dependent,
+                                                       uint32_t* __restrict__ fast_flags) {
+  uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n) return;
   const ChangeMeta* m = &metas[c];
   if (m->flags) return;
   uint32_t ff = 0;
-  if (hash_find(hashes, tab, mask, min_idx, hashes + 32 * (size_t)c) != c) ff |= FF_DUP_HASH;
+  if (lane == 0 && hash_find(hashes, tab, mask, min_idx, hashes + 32 * (size_t)c) != c) ff |= FF_DUP_HASH;
   const uint8_t* deps = arena + m->base + m->deps_off;
-  for (uint32_t k = 0; k < m->n_deps; k++) {
+  for (uint32_t k = lane; k < m->n_deps; k += WAVE) {
     uint32_t d = hash_find(hashes, tab, mask, min_idx, deps + 32 * (size_t)k);
     if (d == NONE32) ff |= FF_MISSING_DEP;
     else {
@@ -405,32 +430,51 @@ __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restri
   return NONE32;
 }
 
+// One wavefront per change: lane 0 walks the length-prefixed table (sequential by nature) 64 entries at a time
+// into LDS, then every lane interns one entry.
 __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
                                                         const uint32_t* __restrict__ amap_base, uint32_t* __restrict__ amap, uint32_t amap_cap,
                                                         unsigned long long* __restrict__ slots, uint32_t mask, uint32_t* __restrict__ first_idx,
                                                         uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags) {
-  uint32_t c = gtid();
+  __shared__ uint32_t s_off[WAVE], s_len[WAVE];
+  uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n) return;
   ChangeMeta* m = &metas[c];
   if (m->flags) return;
   uint32_t base = amap_base[c];
-  if ((uint64_t)base + m->n_entries > amap_cap) { atomicOr(fast_flags, (uint32_t)FF_CAPACITY); return; }
+  if ((uint64_t)base + m->n_entries > amap_cap) {
+    if (lane == 0) atomicOr(fast_flags, (uint32_t)FF_CAPACITY);
+    return;
+  }
   const uint8_t* p = arena + m->base;
   uint32_t abs0 = (uint32_t)m->base;
-  uint32_t s = actor_find_or_insert(arena, slots, mask, abs0 + m->actor_off, m->actor_len);
-  if (s == NONE32) { atomicOr(flags, (uint32_t)F_UNKNOWN_ACTOR_DEV); return; }
-  amap[base] = s;
-  m->author_slot = s;
-  atomicMin(&first_idx[s], c);
-  Cur cur{p, m->others_off, m->len};
-  for (uint32_t k = 0; k < m->n_other; k++) {
-    uint64_t l;
-    read_uleb(cur, l);
-    uint32_t off = cur.off;
-    skip_bytes(cur, l);
-    uint32_t t = l < 65536 ? actor_find_or_insert(arena, slots, mask, abs0 + off, (uint32_t)l) : NONE32;
-    if (t == NONE32) { atomicOr(flags, l < 65536 ? (uint32_t)F_UNKNOWN_ACTOR_DEV : (uint32_t)F_UNSUPPORTED); t = 0; }
-    amap[base + 1 + k] = t;
+  uint32_t n_other = m->n_other;
+  if (lane == 0) {
+    uint32_t s = actor_find_or_insert(arena, slots, mask, abs0 + m->actor_off, m->actor_len);
+    if (s == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); s = 0; }
+    amap[base] = s;
+    m->author_slot = s;
+    atomicMin(&first_idx[s], c);
+  }
+  Cur cur(p, m->others_off, m->len);  // advanced by lane 0 only
+  for (uint32_t k0 = 0; k0 < n_other; k0 += WAVE) {
+    uint32_t cnt = n_other - k0 < WAVE ? n_other - k0 : WAVE;
+    if (lane == 0) {
+      for (uint32_t j = 0; j < cnt; j++) {
+        uint64_t l = 0;
+        read_uleb(cur, l);
+        s_off[j] = abs0 + cur.off;
+        s_len[j] = l < 65536 ? (uint32_t)l : NONE32;
+        skip_bytes(cur, l);
+      }
+    }
+    __syncthreads();
+    if (lane < cnt) {
+      uint32_t t = s_len[lane] != NONE32 ? actor_find_or_insert(arena, slots, mask, s_off[lane], s_len[lane]) : NONE32;
+      if (t == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); t = 0; }
+      amap[base + 1 + k0 + lane] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -467,7 +511,7 @@ struct Rle {
 };
 
 __device__ __forceinline__ void rle_init(Rle& r, const uint8_t* p, uint32_t len) {
-  r.c = Cur{p, 0, len};
+  r.c = Cur(p, 0, len);
   r.state = 0;
   r.count = 0;
   r.have_last = false;
@@ -685,7 +729,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restri
     }
   } else if (task == T_INSERT) {
     BoolDec b;
-    b.c = Cur{p + m->col_off[C_INSERT], 0, m->col_len[C_INSERT]};
+    b.c = Cur(p + m->col_off[C_INSERT], 0, m->col_len[C_INSERT]);
     b.last = true;
     b.first = true;
     b.count = 0;
@@ -777,15 +821,14 @@ void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t
 void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,
                          const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st) {
   if (!n) return;
-  AM355_LAUNCH_INDEPENDENT(k_deps_resolve, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, arena, metas, hashes, n, hash_tab, tab_mask, min_idx,
-                           has_dependent, fast_flags);
+  AM355_LAUNCH_INDEPENDENT(k_deps_resolve, dim3(n), dim3(WAVE), st, arena, metas, hashes, n, hash_tab, tab_mask, min_idx, has_dependent, fast_flags);
 }
 
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, hipStream_t st) {
   if (!n) return;
-  AM355_LAUNCH_INDEPENDENT(k_actor_intern, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask,
-                           first_idx, flags, fast_flags);
+  hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
+                     fast_flags);
   AM355_LAUNCH_INDEPENDENT(k_actor_check, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
                            (const uint32_t*)first_idx, flags, fast_flags);
 }

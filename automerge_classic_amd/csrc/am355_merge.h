@@ -48,6 +48,8 @@ struct MergeBufs {
   uint32_t *obj_first_pos;          // [n_objects] position in `order` of the first element of each list object
   void* scan_ws;
   Counts* counts;                   // device
+  void* zero_base;                  // succ_cnt .. last_inc are contiguous: one memset per replay
+  size_t zero_bytes;
 };
 
 // ---- patch IR in device memory (the output of the hot path) ---------------------------------------------

@@ -211,10 +211,15 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
     b.em_trig[slot] = trig;
     atomicMax(&b.counts->max_key_len, o.key_len[g]);
   }
-  slot = wave_append(&b.counts->n_list_ins, want_ins);
-  if (want_ins) b.ins_row[slot] = g;
+  // list insert rows are most of a text document: compact them with a prefix sum rather than contended atomics
+  if (in_range) b.scan_b[g] = want_ins ? 1u : 0u;
   slot = wave_append(&b.counts->n_list_upd, want_upd);
   if (want_upd) b.upd_row[slot] = g;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_ins_scatter(MergeBufs b, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos) {
+  uint32_t g = gtid();
+  if (g < b.n_ops && flag[g]) b.ins_row[pos[g]] = g;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -226,9 +231,17 @@ __global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint3
   uint8_t kind = b.kind[g];
   bool is_make = kind != K_DEL && kind != K_NONE && (b.ops.action[g] & 1) == 0;
   uint32_t idx = is_make_ex[g] + 1;  // 0 is _root
-  if (is_make) { ir.obj_make_row[idx] = g; b.obj_index[g] = idx; }
-  else b.obj_index[g] = NONE32;
-  if (g == 0) ir.obj_make_row[0] = NONE32;
+  if (is_make) {
+    ir.obj_make_row[idx] = g;
+    b.obj_index[g] = idx;
+    ir.obj_map_begin[idx] = ir.obj_map_end[idx] = ir.obj_edit_begin[idx] = ir.obj_edit_end[idx] = 0;
+  } else {
+    b.obj_index[g] = NONE32;
+  }
+  if (g == 0) {
+    ir.obj_make_row[0] = NONE32;
+    ir.obj_map_begin[0] = ir.obj_map_end[0] = ir.obj_edit_begin[0] = ir.obj_edit_end[0] = 0;
+  }
 }
 
 __device__ __forceinline__ uint32_t obj_index_of(const MergeBufs& b, uint32_t make_row) { return make_row == NONE32 ? 0 : b.obj_index[make_row]; }
@@ -481,14 +494,12 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); 
 void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st) {
   uint32_t N = b.n_ops;
   (void)hipMemsetAsync(b.counts, 0, sizeof(Counts), st);
-  (void)hipMemsetAsync(b.succ_cnt, 0, sizeof(uint32_t) * N, st);
-  (void)hipMemsetAsync(b.inc_cnt, 0, sizeof(uint32_t) * N, st);
-  (void)hipMemsetAsync(b.val_cnt, 0, sizeof(uint32_t) * N, st);
-  (void)hipMemsetAsync(b.inc_sum, 0, sizeof(unsigned long long) * N, st);
-  (void)hipMemsetAsync(b.last_inc, 0, sizeof(unsigned long long) * N, st);
+  (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, st);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
   if (N) {
     AM355_LAUNCH_INDEPENDENT(k_resolve, grid_for(N), dim3(BLOCK), st, b);
     hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
+    exclusive_scan_u32(b.scan_b, b.scan_a, N, &b.counts->n_list_ins, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_ins_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_b, (const uint32_t*)b.scan_a);
   }
   (void)hipMemcpyAsync(h_counts, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
@@ -504,12 +515,11 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
     AM355_LAUNCH_INDEPENDENT(k_object_table, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)is_make_ex, ir);
   } else {
     (void)hipMemsetAsync(ir.obj_make_row, 0xff, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_map_end, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_edit_begin, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_edit_end, 0, sizeof(uint32_t), st);
   }
-  size_t obj_cap = (size_t)N + 1;
-  (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t) * obj_cap, st);
-  (void)hipMemsetAsync(ir.obj_map_end, 0, sizeof(uint32_t) * obj_cap, st);
-  (void)hipMemsetAsync(ir.obj_edit_begin, 0, sizeof(uint32_t) * obj_cap, st);
-  (void)hipMemsetAsync(ir.obj_edit_end, 0, sizeof(uint32_t) * obj_cap, st);
 
   // ---- map emissions: LSD over (trigger id | key length | key chunks last..first | object) ----
   uint32_t ne = hc->n_map_emit;
