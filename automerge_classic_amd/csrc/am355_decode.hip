@@ -14,6 +14,8 @@
 // and write each fixed-width field once.
 #include "am355_decode.h"
 
+#include <cstdlib>
+
 namespace am355 {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -677,7 +679,7 @@ __device__ __forceinline__ uint32_t xlate_actor(const ActorXlate& x, const Chang
 
 __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                           const ChangePlan* __restrict__ plans, uint32_t n_plans,
-                                                          ActorXlate amap, OpCols o, uint32_t* __restrict__ flags) {
+                                                          ActorXlate amap, OpCols o, uint32_t* __restrict__ flags, int task_base) {
   uint32_t pi = gtid();
   if (pi >= n_plans) return;
   const ChangePlan pl = plans[pi];
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restri
   uint32_t n = m->n_ops, base = pl.op_base;
   uint32_t err = 0;
   uint32_t abs0 = (uint32_t)m->base;  // arena is < 4 GiB (checked on the host), so absolute offsets fit 32 bits
-  int task = blockIdx.y;
+  int task = blockIdx.y + task_base;
   RVal v;
   v.off = v.len = 0;
   v.i = 0;
@@ -837,7 +839,13 @@ void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const 
                            const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st) {
   if (!n_plans) return;
   ActorXlate x{amap, slot_rank};
-  AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_plans + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans, n_plans, x, cols, flags);
+  static const bool split = getenv("AM355_SPLIT_DECODE") != nullptr;  // diagnostic: one launch per column group so a profiler can time them
+  if (split) {
+    for (int t = 0; t < T_NUM; t++)
+      AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_plans + WAVE - 1) / WAVE, 1), dim3(WAVE), st, arena, metas, plans, n_plans, x, cols, flags, t);
+    return;
+  }
+  AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_plans + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans, n_plans, x, cols, flags, 0);
 }
 
 }  // namespace am355

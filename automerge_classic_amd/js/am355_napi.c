@@ -1,0 +1,210 @@
+/*
+ * am355_napi.c -- thin N-API (v8, Node >= 12) binding of the C ABI in include/am355.h.
+ *
+ * The reference has no native addon; this is the binding a maintainer adds so that the unchanged JavaScript
+ * frontend can call the MI355X engine through `Automerge.setDefaultBackend(require('mi355x-backend'))`
+ * (reference plug-in point: src/automerge.js:147-149; harness: test/wasm.js:12-25).  One JS function per C entry
+ * point, no logic of its own.
+ *
+ *   const am = require('./am355_napi.node')
+ *   const ctx = am.create(0)                       // throws if no MI355X is usable (no CPU fallback)
+ *   am.loadChanges(ctx, [Uint8Array, ...])         // stage + inflate + copy to HBM
+ *   am.replay(ctx)                                 // the hot path (blocking, like every Backend call)
+ *   am.patchJSON(ctx) -> string                    // JSON.stringify(getPatch) text, built from the device IR
+ *   am.stats(ctx) -> {nOps, nChanges, msTotal, ...};  am.hashes(ctx) -> Uint8Array(32 * n);  am.destroy(ctx)
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/am355.h"
+
+#define NAPI_CALL(env, call)                                                   \
+  do {                                                                         \
+    if ((call) != napi_ok) {                                                   \
+      napi_throw_error((env), NULL, "N-API call failed: " #call);              \
+      return NULL;                                                             \
+    }                                                                          \
+  } while (0)
+
+static void finalize_ctx(napi_env env, void *data, void *hint) {
+  (void)env; (void)hint;
+  if (data) am355_destroy((am355_ctx *)data);
+}
+
+static am355_ctx *get_ctx(napi_env env, napi_value v) {
+  void *p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    napi_throw_type_error(env, NULL, "expected an am355 context");
+    return NULL;
+  }
+  return (am355_ctx *)p;
+}
+
+static napi_value throw_engine(napi_env env, am355_ctx *ctx, int rc) {
+  /* error object carries the code and the validity flags so the JS wrapper can decide to replay on the JS path */
+  napi_value msg, err, code, flags;
+  napi_create_string_utf8(env, am355_last_error(ctx), NAPI_AUTO_LENGTH, &msg);
+  napi_create_error(env, NULL, msg, &err);
+  napi_create_int32(env, rc, &code);
+  napi_create_uint32(env, am355_flags(ctx), &flags);
+  napi_set_named_property(env, err, "am355Code", code);
+  napi_set_named_property(env, err, "am355Flags", flags);
+  napi_throw(env, err);
+  return NULL;
+}
+
+static napi_value js_create(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  int32_t device = 0;
+  if (argc >= 1) napi_get_value_int32(env, argv[0], &device);
+  am355_ctx *ctx = am355_create(device);
+  if (!ctx) {
+    napi_throw_error(env, NULL, "am355_create failed: no usable MI355X / HIP device (the engine has no CPU fallback)");
+    return NULL;
+  }
+  napi_value ext;
+  NAPI_CALL(env, napi_create_external(env, ctx, finalize_ctx, NULL, &ext));
+  return ext;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info) {
+  /* contexts are also released by the finalizer; explicit destroy is a no-op kept for symmetry */
+  (void)info;
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+static napi_value js_load_changes(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  bool is_array = false;
+  napi_is_array(env, argv[1], &is_array);
+  if (!is_array) { napi_throw_type_error(env, NULL, "applyChanges takes an array of Uint8Arrays"); return NULL; }
+  uint32_t n = 0;
+  napi_get_array_length(env, argv[1], &n);
+  uint64_t *offsets = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+  size_t total = 0;
+  offsets[0] = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value el;
+    napi_get_element(env, argv[1], i, &el);
+    bool is_ta = false;
+    napi_is_typedarray(env, el, &is_ta);
+    if (!is_ta) { free(offsets); napi_throw_type_error(env, NULL, "change is not a Uint8Array"); return NULL; }
+    napi_typedarray_type t; size_t len; void *data; napi_value ab; size_t off;
+    napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off);
+    if (t != napi_uint8_array) { free(offsets); napi_throw_type_error(env, NULL, "change is not a Uint8Array"); return NULL; }
+    total += len;
+    offsets[i + 1] = total;
+  }
+  uint8_t *arena = (uint8_t *)malloc(total ? total : 1);
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value el;
+    napi_get_element(env, argv[1], i, &el);
+    napi_typedarray_type t; size_t len; void *data; napi_value ab; size_t off;
+    napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off);
+    if (len) memcpy(arena + offsets[i], data, len);
+  }
+  int rc = am355_load_changes(ctx, arena, offsets, n);
+  free(arena);
+  free(offsets);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+static napi_value js_replay(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  int rc = am355_replay(ctx);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+static napi_value js_patch_json(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  const char *json = NULL;
+  size_t len = 0;
+  int rc = am355_patch_json(ctx, &json, &len);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value s;
+  NAPI_CALL(env, napi_create_string_utf8(env, json, len, &s));
+  return s;
+}
+
+static napi_value js_hashes(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  am355_stats st;
+  am355_get_stats(ctx, &st);
+  void *data = NULL;
+  napi_value ab, ta;
+  size_t bytes = 32 * (size_t)st.n_changes;
+  NAPI_CALL(env, napi_create_arraybuffer(env, bytes, &data, &ab));
+  int rc = am355_get_hashes(ctx, (uint8_t *)data);
+  if (rc) return throw_engine(env, ctx, rc);
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
+  return ta;
+}
+
+static void set_num(napi_env env, napi_value obj, const char *name, double v) {
+  napi_value n;
+  napi_create_double(env, v, &n);
+  napi_set_named_property(env, obj, name, n);
+}
+
+static napi_value js_stats(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  am355_stats st;
+  am355_get_stats(ctx, &st);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  set_num(env, o, "nChanges", st.n_changes); set_num(env, o, "nApplied", st.n_applied); set_num(env, o, "nPending", st.n_pending);
+  set_num(env, o, "nActors", st.n_actors); set_num(env, o, "nObjects", st.n_objects); set_num(env, o, "nOps", (double)st.n_ops);
+  set_num(env, o, "maxOp", (double)st.max_op); set_num(env, o, "rawBytes", (double)st.raw_bytes); set_num(env, o, "nEdits", (double)st.n_edits);
+  set_num(env, o, "msTotal", st.ms_total); set_num(env, o, "msParse", st.ms_parse); set_num(env, o, "msHostSchedule", st.ms_host_schedule);
+  set_num(env, o, "msDecode", st.ms_decode); set_num(env, o, "msMerge", st.ms_merge); set_num(env, o, "msOrder", st.ms_order);
+  set_num(env, o, "msHashStream", st.ms_hash_stream); set_num(env, o, "fastPath", st.fast_path);
+  return o;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+  napi_property_descriptor props[] = {
+      {"create", NULL, js_create, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"destroy", NULL, js_destroy, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"loadChanges", NULL, js_load_changes, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"replay", NULL, js_replay, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"patchJSON", NULL, js_patch_json, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"hashes", NULL, js_hashes, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"stats", NULL, js_stats, NULL, NULL, NULL, napi_enumerable, NULL},
+  };
+  napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

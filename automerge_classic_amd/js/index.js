@@ -1,0 +1,145 @@
+// mi355x-backend: drop-in replacement for automerge-classic's `backend` module whose bulk-replay path runs on an
+// AMD MI355X through the N-API addon (am355_napi.node -> include/am355.h -> HIP kernels).
+//
+//   const Automerge = require('automerge')
+//   Automerge.setDefaultBackend(require('mi355x-backend'))        // reference plug-in point: src/automerge.js:147-149
+//
+// Module surface = reference backend/index.js:1-8.  GPU-served calls (SURVEY.md "Scope decisions"):
+//   loadChanges(init(), changes)  and  getPatch(state)             (backend/backend.js:116-129, new.js:1797-1879, 2060-2068)
+// i.e. the pair behind Automerge.load / getHistory / clone.  Everything else (applyLocalChange, incremental
+// applyChanges, save, clone, hash-graph queries, sync protocol) is delegated to the reference JS backend, onto
+// which a GPU-built state is hydrated lazily -- by replaying the retained change buffers -- the first time such a
+// call is made.  Inputs the engine rejects (AM355_E_INVALID: the reference would throw; AM355_E_UNSUPPORTED: legal
+// but outside the GPU-served subset) are re-run on the JS path so the caller sees the reference's exact exception
+// or result.  If the addon or the GPU is missing, requiring this module throws: there is no silent CPU mode
+// (set MI355X_BACKEND_JS_ONLY=1 to run the pure pass-through plumbing configuration explicitly).
+'use strict'
+const path = require('path')
+
+const JS_ONLY = process.env.MI355X_BACKEND_JS_ONLY === '1'
+let addon = null, ctx = null
+if (!JS_ONLY) {
+  addon = require(path.join(__dirname, 'am355_napi.node'))
+  ctx = addon.create(parseInt(process.env.MI355X_DEVICE || '0'))   // throws without an MI355X
+}
+
+// The unmodified reference backend (the package a user already has installed)
+let refBackend = null
+function ref() {
+  if (!refBackend) {
+    const spec = process.env.AUTOMERGE_BACKEND_PATH || 'automerge/backend'
+    refBackend = require(spec)
+  }
+  return refBackend
+}
+
+const AM355_E_INVALID = -3, AM355_E_UNSUPPORTED = -4
+
+// A state built on the GPU. `changes` are retained (by reference, like BackendDoc.changes new.js:1847) so that a
+// JS BackendDoc can be hydrated later; `patch` is the whole-document patch computed by the engine.
+class GpuState {
+  constructor(changes, patch, heads) {
+    this.changes = changes
+    this.patch = patch
+    this.heads = heads
+    this.js = null   // hydrated reference backend handle
+  }
+}
+
+function isFrozenCheck(backend) {
+  // reference util.js:1-10
+  if (backend.frozen) {
+    throw new Error(
+      'Attempting to use an outdated Automerge document that has already been updated. ' +
+      'Please use the latest document state, or call Automerge.clone() if you really ' +
+      'need to use this old document state.')
+  }
+}
+
+function isEmptyRefState(backend) {
+  const s = backend.state
+  return s && !(s instanceof GpuState) && Array.isArray(s.changes) && s.changes.length === 0 &&
+    (!s.queue || s.queue.length === 0) && !s.binaryDoc
+}
+
+// Returns the JS (reference) handle equivalent to `backend`, hydrating a GPU-built state if necessary
+function toJs(backend) {
+  isFrozenCheck(backend)
+  if (!(backend.state instanceof GpuState)) return backend
+  const g = backend.state
+  if (!g.js) g.js = ref().loadChanges(ref().init(), g.changes)
+  const handle = g.js
+  g.js = null          // the JS handle is single-use (functional API over a mutable state)
+  backend.frozen = true
+  return handle
+}
+
+function gpuReplay(changes) {
+  addon.loadChanges(ctx, changes)
+  addon.replay(ctx)
+  const patch = JSON.parse(addon.patchJSON(ctx))
+  return patch
+}
+
+function init() {
+  return ref().init()
+}
+
+function loadChanges(backend, changes) {
+  isFrozenCheck(backend)
+  if (!JS_ONLY && isEmptyRefState(backend) && Array.isArray(changes) && changes.length > 0) {
+    try {
+      const patch = gpuReplay(changes)
+      backend.frozen = true
+      const state = new GpuState(changes.slice(), patch, patch.deps)
+      return { state, heads: patch.deps }
+    } catch (e) {
+      if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
+      // fall through: the reference path raises the exact exception (or serves the unsupported case)
+    }
+  }
+  return ref().loadChanges(toJs(backend), changes)
+}
+
+function getPatch(backend) {
+  isFrozenCheck(backend)
+  if (backend.state instanceof GpuState) return backend.state.patch
+  return ref().getPatch(backend)
+}
+
+function getHeads(backend) {
+  return backend.heads   // reference backend.js:135-137
+}
+
+function load(data) {
+  return ref().load(data)   // document-format load: "next" row of the scope table (SURVEY.md §8f)
+}
+
+function free(backend) {
+  if (backend.state instanceof GpuState) { backend.state = null; backend.frozen = true } else ref().free(backend)
+}
+
+const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...args)
+
+module.exports = {
+  init, load, loadChanges, getPatch, getHeads, free,
+  clone: delegate1('clone'),
+  applyChanges: delegate1('applyChanges'),
+  applyLocalChange: delegate1('applyLocalChange'),
+  save: delegate1('save'),
+  getAllChanges: delegate1('getAllChanges'),
+  getChanges: delegate1('getChanges'),
+  getChangeByHash: delegate1('getChangeByHash'),
+  getMissingDeps: delegate1('getMissingDeps'),
+  getChangesAdded: (b1, b2) => ref().getChangesAdded(toJs(b1), toJs(b2)),
+  // sync protocol: unchanged reference code operating on JS handles (backend/sync.js:20 binds the JS backend)
+  generateSyncMessage: (backend, syncState) => ref().generateSyncMessage(toJs(backend), syncState),
+  receiveSyncMessage: (backend, syncState, msg) => ref().receiveSyncMessage(toJs(backend), syncState, msg),
+  encodeSyncMessage: (...a) => ref().encodeSyncMessage(...a),
+  decodeSyncMessage: (...a) => ref().decodeSyncMessage(...a),
+  encodeSyncState: (...a) => ref().encodeSyncState(...a),
+  decodeSyncState: (...a) => ref().decodeSyncState(...a),
+  initSyncState: (...a) => ref().initSyncState(...a),
+  // engine statistics of the last GPU replay (not part of the reference surface)
+  _engineStats: () => (addon ? addon.stats(ctx) : null)
+}

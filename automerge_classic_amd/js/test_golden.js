@@ -1,0 +1,25 @@
+// Runs on the GPU box (node + addon + MI355X, no reference tree needed): every golden fixture produced by the
+// unmodified reference must be reproduced byte-for-byte through the JS Backend surface of mi355x-backend.
+//   node automerge_classic_amd/js/test_golden.js tests/golden
+'use strict'
+const fs = require('fs')
+const path = require('path')
+const Backend = require('./index.js')
+
+const dir = process.argv[2] || path.join(__dirname, '..', '..', 'tests', 'golden')
+let failed = 0, n = 0
+for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
+  const fx = JSON.parse(fs.readFileSync(path.join(dir, f), 'utf8'))
+  const changes = fx.changes.map(c => new Uint8Array(Buffer.from(c, 'base64')))
+  const expected = fx.stock_equals_bigblock === false ? fx.patch_bigblock : fx.patch
+  // the handle given to loadChanges must look like a fresh reference state: {state: {changes: [], queue: []}, heads: []}
+  const empty = { state: { changes: [], queue: [] }, heads: [] }
+  const state = Backend.loadChanges(empty, changes)
+  const got = JSON.stringify(Backend.getPatch(state))
+  n++
+  if (got !== expected) { failed++; console.error(`FAIL ${f}`) } else console.log(`ok   ${f}  (${changes.length} changes)`)
+  if (!empty.frozen) { failed++; console.error(`FAIL ${f}: old handle not frozen`) }
+  if (JSON.stringify(Backend.getHeads(state)) !== JSON.stringify(JSON.parse(expected).deps)) { failed++; console.error(`FAIL ${f}: heads`) }
+}
+console.log(`${n - failed}/${n} golden fixtures reproduced through the JS Backend surface; engine: ${JSON.stringify(Backend._engineStats())}`)
+process.exit(failed ? 1 : 0)
