@@ -657,6 +657,19 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     ir.e_row = carve<uint32_t>(r, Nc); ir.e_elem = carve<uint32_t>(r, Nc); ir.e_index = carve<uint32_t>(r, Nc); ir.e_flags = carve<uint32_t>(r, Nc);
     b.obj_first_pos = b.em_row;  // em_row is dead once the map emissions are ordered (lists run afterwards)
   }
+  // wave-decodable changes first, the (rare) ones with an over-long column after them
+  uint32_t n_wave = 0;
+  {
+    const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+    std::vector<ChangePlan> big;
+    size_t w = 0;
+    for (size_t i = 0; i < np; i++) {
+      if (decode_fits_wave(metas[c->plans[i].change])) c->plans[w++] = c->plans[i];
+      else big.push_back(c->plans[i]);
+    }
+    n_wave = (uint32_t)w;
+    for (auto& pl : big) c->plans[w++] = pl;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_plans.p, c->plans.data(), sizeof(ChangePlan) * np, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->spans.data(), sizeof(ActorSpan) * c->spans.size(), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_tab_off.p, c->actor_tab_off.data(), 4 * c->actor_tab_off.size(), hipMemcpyHostToDevice, st));
@@ -674,8 +687,8 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   // ---- stage 1b: column decode ----
   HIPCHK(c, hipEventRecord(c->ev[2], st));
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
-  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), (uint32_t)np, d_amap, d_rank, c->cols,
-                        &c->d_counts.as<Counts>()->flags, st);
+  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n_wave, (uint32_t)np - n_wave, d_amap, d_rank,
+                        c->cols, &c->d_counts.as<Counts>()->flags, st);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
 
   // ---- stage 2: merge (decode flags are read together with the phase-1 counters) ----

@@ -10,7 +10,8 @@ void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const ui
                          const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st);
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, hipStream_t st);
-// slot_rank == nullptr: `amap` already holds global actor ranks
-void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_plans, const uint32_t* amap,
-                           const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st);
+// slot_rank == nullptr: `amap` already holds global actor ranks. plans = [n_wave wave-decodable | n_serial others]
+void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_wave, uint32_t n_serial,
+                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st);
+bool decode_fits_wave(const ChangeMeta& m);  // host: can this change use the wave-per-change decoder?
 }  // namespace am355

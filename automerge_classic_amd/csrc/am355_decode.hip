@@ -808,6 +808,488 @@ __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restri
   if (err) atomicOr(flags, err);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_decode_wave: one wavefront per change, run-level decode.
+//
+// The lane-serial decoder above walks every VALUE of a column; here the sequential part is one step per RECORD.
+// For each column: (1) the bytes are staged in LDS with coalesced loads; (2) LEB128 tokens are found in parallel --
+// a byte with bit 7 clear ends a number, so one ballot per 64 bytes plus popcount/clz gives every token's index
+// and start, and each terminating lane assembles its token; (3) lane 0 walks the records over the token table
+// (a literal of k values is ONE step); (4) all lanes expand runs into rows (binary search in the run table), apply
+// wave prefix sums where the format needs them (delta columns, value offsets, pred list offsets) and store rows
+// with consecutive lanes writing consecutive addresses. Columns longer than WV_COLMAX bytes (rare: the change is
+// then routed to the lane-serial kernel by the host) and the UTF-8 key column (string bytes are not LEB tokens;
+// walked by lane 0) are the exceptions.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t WV_COLMAX = 1024;
+constexpr uint32_t WV_RUNMAX = WV_COLMAX / 2;  // every record is at least two tokens
+constexpr uint32_t WV_ACTMAX = 1024;
+
+struct WaveLds {
+  uint8_t bytes[WV_COLMAX];
+  uint32_t tok_lo[WV_COLMAX], tok_hi[WV_COLMAX];
+  uint8_t tok_len[WV_COLMAX], tok_last[WV_COLMAX];
+  uint32_t run_start[WV_RUNMAX + 1], run_tok[WV_RUNMAX];
+  uint8_t run_kind[WV_RUNMAX];
+  uint32_t n_runs, n_tokens, total_rows, err;
+  uint32_t rank[WV_ACTMAX];
+};
+enum { RK_REP = 1, RK_LIT = 2, RK_NUL = 3 };
+
+__device__ __forceinline__ bool wv_tok_uint(const WaveLds& L, uint32_t t, uint64_t& v) {
+  uint32_t nb = L.tok_len[t];
+  if (nb == 0 || nb > 10 || (nb == 10 && (L.tok_last[t] & 0xfe))) return false;
+  v = (uint64_t)L.tok_hi[t] << 32 | L.tok_lo[t];
+  return v <= MAX_SAFE;
+}
+__device__ __forceinline__ bool wv_tok_sint(const WaveLds& L, uint32_t t, int64_t& out) {
+  uint32_t nb = L.tok_len[t], last = L.tok_last[t];
+  if (nb == 0 || nb > 10 || (nb == 10 && last != 0 && last != 0x7f)) return false;
+  uint64_t v = (uint64_t)L.tok_hi[t] << 32 | L.tok_lo[t];
+  if ((last & 0x40) && 7 * nb < 64) v |= ~0ull << (7 * nb);
+  out = (int64_t)v;
+  return out <= (int64_t)MAX_SAFE && out >= -(int64_t)MAX_SAFE;
+}
+
+// Stage + tokenise + record-walk one RLE column (uint or int values). All lanes must call it.
+__device__ void wv_load_column(WaveLds& L, const uint8_t* __restrict__ col, uint32_t len, uint32_t lane) {
+  __syncthreads();  // previous column's readers are done
+  for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
+  if (lane == 0) L.err = 0;
+  __syncthreads();
+  uint32_t tok_base = 0, carry_start = 0;
+  for (uint32_t chunk = 0; chunk < len; chunk += WAVE) {
+    uint32_t pos = chunk + lane;
+    bool in = pos < len;
+    uint32_t b = in ? L.bytes[pos] : 0x80;
+    bool term = in && !(b & 0x80);
+    unsigned long long mask = __ballot(term);
+    if (term) {
+      unsigned long long below = mask & ((1ull << lane) - 1);
+      uint32_t start = below ? chunk + (63 - (uint32_t)__clzll(below)) + 1 : carry_start;
+      uint32_t nb = pos - start + 1, idx = tok_base + (uint32_t)__popcll(below);
+      uint64_t v = 0;
+      if (nb <= 10)
+        for (uint32_t k = 0; k < nb; k++) v |= (uint64_t)(L.bytes[start + k] & 0x7f) << (7 * k);
+      L.tok_lo[idx] = (uint32_t)v;
+      L.tok_hi[idx] = (uint32_t)(v >> 32);
+      L.tok_len[idx] = nb <= 10 ? (uint8_t)nb : (uint8_t)0xff;
+      L.tok_last[idx] = (uint8_t)b;
+    }
+    if (mask) carry_start = chunk + (63 - (uint32_t)__clzll(mask)) + 1;
+    tok_base += (uint32_t)__popcll(mask);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t e = carry_start != len ? (uint32_t)F_BAD_LEB : 0;  // buffer ended with incomplete number
+    uint32_t t = 0, nr = 0, prev = 0;
+    uint64_t rows = 0;
+    while (t < tok_base && !e) {
+      int64_t cnt;
+      if (!wv_tok_sint(L, t, cnt)) { e = F_BAD_LEB; break; }
+      uint32_t kind, first = t + 1;
+      uint64_t count;
+      if (cnt > 1) {
+        if (t + 1 >= tok_base) { e = F_BAD_LEB; break; }
+        kind = RK_REP; count = (uint64_t)cnt; t += 2;
+      } else if (cnt == 1) {
+        e = F_BAD_RLE; break;  // repetition count of 1
+      } else if (cnt < 0) {
+        if (prev == RK_LIT) { e = F_BAD_RLE; break; }  // successive literals
+        count = (uint64_t)(-cnt);
+        if (count > (uint64_t)(tok_base - t - 1)) { e = F_BAD_LEB; break; }
+        kind = RK_LIT; t += 1 + (uint32_t)count;
+      } else {
+        uint64_t z;
+        if (prev == RK_NUL) { e = F_BAD_RLE; break; }  // successive null runs
+        if (t + 1 >= tok_base || !wv_tok_uint(L, t + 1, z)) { e = F_BAD_LEB; break; }
+        if (z == 0) { e = F_BAD_RLE; break; }
+        kind = RK_NUL; count = z; t += 2;
+      }
+      L.run_start[nr] = (uint32_t)rows;
+      L.run_kind[nr] = (uint8_t)kind;
+      L.run_tok[nr] = first;
+      nr++;
+      rows += count;
+      if (rows > 0xfffffff0ull) { e = F_OVERFLOW; break; }
+      prev = kind;
+    }
+    L.run_start[nr] = (uint32_t)rows;
+    L.n_runs = nr;
+    L.n_tokens = tok_base;
+    L.total_rows = (uint32_t)rows;
+    L.err = e;
+  }
+  __syncthreads();
+}
+
+// value of row i of the loaded column: returns the token index holding it, or NONE32 for null. *boundary is set when
+// row i must differ from row i-1 for the encoding to be legal (different records, or both inside a literal).
+__device__ __forceinline__ uint32_t wv_row_token(const WaveLds& L, uint32_t i, bool* lit_or_first) {
+  if (i >= L.total_rows) { *lit_or_first = false; return NONE32; }  // past the end every value is null (encoding.js:821)
+  uint32_t lo = 0, hi = L.n_runs;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (L.run_start[mid] <= i) lo = mid; else hi = mid;
+  }
+  uint32_t kind = L.run_kind[lo], off = i - L.run_start[lo];
+  *lit_or_first = kind == RK_LIT || off == 0;
+  if (kind == RK_NUL) return NONE32;
+  return kind == RK_REP ? L.run_tok[lo] : L.run_tok[lo] + off;
+}
+
+// decoded value of row i (uint or signed), with the reference's adjacency rule (no equal neighbours across record
+// boundaries or inside literals: encoding.js:826-829, 868-872)
+template <bool SIGNED>
+__device__ __forceinline__ bool wv_row_value(const WaveLds& L, uint32_t i, bool& is_null, int64_t& v, uint32_t& err) {
+  bool edge;
+  uint32_t t = wv_row_token(L, i, &edge);
+  is_null = t == NONE32;
+  v = 0;
+  if (is_null) return true;
+  bool ok;
+  if (SIGNED) ok = wv_tok_sint(L, t, v);
+  else { uint64_t u; ok = wv_tok_uint(L, t, u); v = (int64_t)u; }
+  if (!ok) { err |= F_BAD_LEB; return false; }
+  if (edge && i > 0) {
+    bool e2;
+    uint32_t tp = wv_row_token(L, i - 1, &e2);
+    if (tp != NONE32 && L.tok_lo[tp] == L.tok_lo[t] && L.tok_hi[tp] == L.tok_hi[t] && L.tok_len[tp] == L.tok_len[t]) {
+      // equal payloads of equal length are equal numbers; different-length encodings of one number are compared by value
+      err |= F_BAD_RLE;
+    } else if (tp != NONE32 && L.tok_len[tp] != L.tok_len[t]) {
+      int64_t pv = 0;
+      bool okp;
+      if (SIGNED) okp = wv_tok_sint(L, tp, pv);
+      else { uint64_t u = 0; okp = wv_tok_uint(L, tp, u); pv = (int64_t)u; }
+      if (okp && pv == v) err |= F_BAD_RLE;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t x, uint32_t lane) {
+  for (int d = 1; d < WAVE; d <<= 1) {
+    int64_t y = __shfl_up(x, (unsigned)d);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
+                                                       const ChangePlan* __restrict__ plans, uint32_t n_plans, ActorXlate x, OpCols o,
+                                                       uint32_t* __restrict__ flags) {
+  __shared__ WaveLds L;
+  uint32_t pi = blockIdx.x, lane = threadIdx.x;
+  if (pi >= n_plans) return;
+  const ChangePlan pl = plans[pi];
+  const ChangeMeta* m = &metas[pl.change];
+  const uint8_t* p = arena + m->base;
+  const uint32_t n = m->n_ops, base = pl.op_base, abs0 = (uint32_t)m->base, n_preds_cap = m->n_preds;
+  const uint32_t start_op = (uint32_t)m->start_op;
+  uint32_t col_off[C_NUM], col_len[C_NUM];
+  for (int k = 0; k < C_NUM; k++) { col_off[k] = m->col_off[k]; col_len[k] = m->col_len[k]; }
+  uint32_t err = 0;
+  // change-local actor index -> global rank, staged once per change
+  for (uint32_t k = lane; k < pl.n_actors; k += WAVE) {
+    uint32_t v = x.amap[pl.amap_base + k];
+    L.rank[k] = x.slot_rank ? x.slot_rank[v] : v;
+  }
+
+  // ---- action (+ op ids: op i of a change is (startOp + i, author), new.js:708-709) ----
+  wv_load_column(L, p + col_off[C_ACTION], col_len[C_ACTION], lane);
+  err |= L.err;
+  for (uint32_t i = lane; i < n; i += WAVE) {
+    bool nul; int64_t v;
+    wv_row_value<false>(L, i, nul, v, err);
+    if (nul) err |= F_UNSUPPORTED;
+    if ((uint64_t)v >= NONE32) err |= F_OVERFLOW;
+    o.action[base + i] = (uint32_t)v;
+    o.id_ctr[base + i] = start_op + i;
+    o.id_actor[base + i] = pl.author;
+  }
+  // ---- insert (boolean: alternating run lengths, first run counts false; encoding.js:1171-1183) ----
+  {
+    __syncthreads();
+    uint32_t len = col_len[C_INSERT];
+    const uint8_t* col = p + col_off[C_INSERT];
+    for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
+    __syncthreads();
+    // tokens = run lengths
+    uint32_t tok_base = 0, carry_start = 0;
+    for (uint32_t chunk = 0; chunk < len; chunk += WAVE) {
+      uint32_t pos = chunk + lane;
+      bool in = pos < len;
+      uint32_t b = in ? L.bytes[pos] : 0x80;
+      bool term = in && !(b & 0x80);
+      unsigned long long mask = __ballot(term);
+      if (term) {
+        unsigned long long below = mask & ((1ull << lane) - 1);
+        uint32_t start = below ? chunk + (63 - (uint32_t)__clzll(below)) + 1 : carry_start;
+        uint32_t nb = pos - start + 1, idx = tok_base + (uint32_t)__popcll(below);
+        uint64_t v = 0;
+        if (nb <= 10)
+          for (uint32_t k = 0; k < nb; k++) v |= (uint64_t)(L.bytes[start + k] & 0x7f) << (7 * k);
+        L.tok_lo[idx] = (uint32_t)v; L.tok_hi[idx] = (uint32_t)(v >> 32);
+        L.tok_len[idx] = nb <= 10 ? (uint8_t)nb : (uint8_t)0xff; L.tok_last[idx] = (uint8_t)b;
+      }
+      if (mask) carry_start = chunk + (63 - (uint32_t)__clzll(mask)) + 1;
+      tok_base += (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      uint32_t e = carry_start != len ? (uint32_t)F_BAD_LEB : 0;
+      uint64_t rows = 0;
+      for (uint32_t t = 0; t < tok_base && !e; t++) {
+        uint64_t c;
+        if (!wv_tok_uint(L, t, c)) { e = F_BAD_LEB; break; }
+        if (c == 0 && t > 0) { e = F_BAD_RLE; break; }  // zero-length runs are only legal as the first (false) run
+        L.run_start[t] = (uint32_t)rows;
+        rows += c;
+        if (rows > 0xfffffff0ull) { e = F_OVERFLOW; break; }
+      }
+      L.run_start[tok_base] = (uint32_t)rows;
+      L.n_runs = tok_base;
+      L.total_rows = (uint32_t)rows;
+      L.err = e;
+    }
+    __syncthreads();
+    err |= L.err;
+    for (uint32_t i = lane; i < n; i += WAVE) {
+      uint32_t val = 0;
+      if (i < L.total_rows) {
+        uint32_t lo = 0, hi = L.n_runs;
+        while (hi - lo > 1) {
+          uint32_t mid = (lo + hi) >> 1;
+          if (L.run_start[mid] <= i) lo = mid; else hi = mid;
+        }
+        // several runs may start at the same row when a zero-length first run exists: take the last one covering i
+        val = lo & 1;  // run 0 = false, run 1 = true, ...
+      }
+      o.insert[base + i] = (uint8_t)val;
+    }
+  }
+  // ---- object id ----
+  wv_load_column(L, p + col_off[C_OBJ_ACTOR], col_len[C_OBJ_ACTOR], lane);
+  err |= L.err;
+  for (uint32_t i = lane; i < n; i += WAVE) {
+    bool nul; int64_t v;
+    wv_row_value<false>(L, i, nul, v, err);
+    uint32_t r = NONE32;
+    if (!nul) { if ((uint64_t)v >= pl.n_actors) err |= F_BAD_ROW; else r = L.rank[v]; }
+    o.obj_actor[base + i] = r;
+  }
+  wv_load_column(L, p + col_off[C_OBJ_CTR], col_len[C_OBJ_CTR], lane);
+  err |= L.err;
+  for (uint32_t i = lane; i < n; i += WAVE) {
+    bool nul; int64_t v;
+    wv_row_value<false>(L, i, nul, v, err);
+    if (nul != (o.obj_actor[base + i] == NONE32) && !(err & F_BAD_ROW)) err |= F_BAD_ROW;  // new.js:715-718
+    if (!nul && (uint64_t)v >= NONE32) err |= F_OVERFLOW;
+    o.obj_ctr[base + i] = nul ? 0 : (uint32_t)v;
+  }
+  // ---- key: element id (actor, delta-coded counter) ----
+  wv_load_column(L, p + col_off[C_KEY_ACTOR], col_len[C_KEY_ACTOR], lane);
+  err |= L.err;
+  for (uint32_t i = lane; i < n; i += WAVE) {
+    bool nul; int64_t v;
+    wv_row_value<false>(L, i, nul, v, err);
+    uint32_t r = NONE32;
+    if (!nul) { if ((uint64_t)v >= pl.n_actors) err |= F_BAD_ROW; else r = L.rank[v]; }
+    o.key_actor[base + i] = r;
+  }
+  wv_load_column(L, p + col_off[C_KEY_CTR], col_len[C_KEY_CTR], lane);
+  err |= L.err;
+  {
+    int64_t carry = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += WAVE) {
+      uint32_t i = i0 + lane;
+      bool nul = true; int64_t d = 0;
+      if (i < n) wv_row_value<true>(L, i, nul, d, err);
+      int64_t abs = carry + wave_incl_scan_i64(nul ? 0 : d, lane);  // running value; nulls do not advance it
+      carry = __shfl(abs, WAVE - 1);
+      if (i < n) {
+        bool a_null = o.key_actor[base + i] == NONE32;
+        if (!nul && (abs > (int64_t)MAX_SAFE || abs < -(int64_t)MAX_SAFE)) err |= F_BAD_LEB;
+        // new.js:719-723
+        if ((nul && !a_null) || (!nul && abs == 0 && !a_null) || (!nul && abs > 0 && a_null)) err |= F_BAD_ROW;
+        if (!nul && (abs < 0 || (uint64_t)abs >= NONE32)) err |= F_OVERFLOW;
+        o.key_ctr[base + i] = nul ? NONE32 : (uint32_t)abs;
+      }
+    }
+  }
+  // ---- key: string (UTF-8 RLE column: string bytes are not LEB tokens, so lane 0 walks it -- one step per RECORD, one
+  //      per value only inside literals -- filling the run table in batches that all lanes then expand) ----
+  {
+    __syncthreads();
+    Cur c(p + col_off[C_KEY_STR], 0, col_len[C_KEY_STR]);
+    const uint32_t col_abs = abs0 + col_off[C_KEY_STR];
+    int state = 0;                 // 0 none, 1 repetition, 2 literal, 3 nulls (encoding.js:865-887)
+    bool have_last = false;
+    uint32_t last_off = 0, last_len = 0;
+    int64_t lit_left = 0;          // values still to read from the current literal
+    uint32_t rows_done = 0;        // rows already expanded
+    for (;;) {
+      if (lane == 0) {
+        uint32_t nr = 0, e = 0;
+        uint64_t rows = rows_done;
+        auto same = [&](uint32_t off, uint32_t len) {
+          if (!have_last || last_len != len) return false;
+          for (uint32_t k = 0; k < len; k++)
+            if (c.p[last_off + k] != c.p[off + k]) return false;
+          return true;
+        };
+        while (nr < WV_RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
+          uint32_t kind, off = 0, len = 0;
+          uint64_t count = 1;
+          if (lit_left > 0) {
+            uint64_t l;
+            if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
+            off = c.off; len = (uint32_t)l;
+            if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
+            if (same(off, len)) { e = F_BAD_RLE; break; }  // repetition inside a literal
+            have_last = true; last_off = off; last_len = len;
+            lit_left--;
+            kind = RK_REP;
+          } else {
+            int64_t cnt;
+            if (!read_sleb(c, cnt)) { e = F_BAD_LEB; break; }
+            if (cnt > 1) {
+              uint64_t l;
+              if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
+              off = c.off; len = (uint32_t)l;
+              if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
+              if ((state == 1 || state == 2) && same(off, len)) { e = F_BAD_RLE; break; }
+              state = 1; have_last = true; last_off = off; last_len = len;
+              kind = RK_REP; count = (uint64_t)cnt;
+            } else if (cnt == 1) { e = F_BAD_RLE; break; }
+            else if (cnt < 0) {
+              if (state == 2) { e = F_BAD_RLE; break; }
+              state = 2; lit_left = -cnt;
+              continue;
+            } else {
+              uint64_t z;
+              if (state == 3) { e = F_BAD_RLE; break; }
+              if (!read_uleb(c, z)) { e = F_BAD_LEB; break; }
+              if (z == 0) { e = F_BAD_RLE; break; }
+              state = 3; have_last = false;
+              kind = RK_NUL; count = z;
+            }
+          }
+          L.run_start[nr] = (uint32_t)(rows - rows_done);
+          L.run_kind[nr] = (uint8_t)kind;
+          L.run_tok[nr] = col_abs + off;
+          L.tok_lo[nr] = len;
+          nr++;
+          rows += count;
+          if (rows > n) rows = n;
+        }
+        bool exhausted = !(lit_left > 0 || c.off < c.len);
+        if ((exhausted || e) && rows < n) {  // past the end of the column every value is null
+          if (nr == WV_RUNMAX) nr--, rows = rows_done + L.run_start[nr];  // (cannot happen: loop stops at RUNMAX only with data left)
+          L.run_start[nr] = (uint32_t)(rows - rows_done);
+          L.run_kind[nr] = RK_NUL;
+          L.run_tok[nr] = 0;
+          L.tok_lo[nr] = 0;
+          nr++;
+          rows = n;
+        }
+        L.run_start[nr] = (uint32_t)(rows - rows_done);
+        L.n_runs = nr;
+        L.total_rows = (uint32_t)(rows - rows_done);
+        L.err = e;
+      }
+      __syncthreads();
+      err |= L.err;
+      uint32_t batch = L.total_rows, nr = L.n_runs;
+      for (uint32_t i = lane; i < batch; i += WAVE) {
+        uint32_t lo = 0, hi = nr;
+        while (hi - lo > 1) {
+          uint32_t mid = (lo + hi) >> 1;
+          if (L.run_start[mid] <= i) lo = mid; else hi = mid;
+        }
+        bool nul = L.run_kind[lo] == RK_NUL;
+        o.key_off[base + rows_done + i] = nul ? 0 : L.run_tok[lo];
+        o.key_len[base + rows_done + i] = nul ? NONE32 : L.tok_lo[lo];
+      }
+      rows_done += batch;
+      __syncthreads();
+      if (rows_done >= n || batch == 0) break;
+    }
+  }
+  // ---- value: (len << 4 | tag) per row, offsets into valRaw are an exclusive prefix sum of the lengths ----
+  wv_load_column(L, p + col_off[C_VAL_LEN], col_len[C_VAL_LEN], lane);
+  err |= L.err;
+  {
+    int64_t carry = 0;
+    uint32_t raw_abs = abs0 + col_off[C_VAL_RAW], raw_len = col_len[C_VAL_RAW];
+    for (uint32_t i0 = 0; i0 < n; i0 += WAVE) {
+      uint32_t i = i0 + lane;
+      bool nul = true; int64_t tl = 0;
+      if (i < n) wv_row_value<false>(L, i, nul, tl, err);
+      if (nul) tl = 0;
+      if ((uint64_t)tl >= NONE32) { err |= F_OVERFLOW; tl = 0; }
+      int64_t incl = carry + wave_incl_scan_i64(tl >> 4, lane);
+      carry = __shfl(incl, WAVE - 1);
+      if (i < n) {
+        if ((uint64_t)incl > raw_len) err |= F_BAD_CHUNK;  // readRawBytes past the end of valRaw
+        o.val_tl[base + i] = (uint32_t)tl;
+        o.val_off[base + i] = raw_abs + (uint32_t)(incl - (tl >> 4));
+      }
+    }
+  }
+  // ---- preds: group cardinality, then the two value columns consumed predNum[i] entries per row ----
+  uint32_t total_preds = 0;
+  wv_load_column(L, p + col_off[C_PRED_NUM], col_len[C_PRED_NUM], lane);
+  err |= L.err;
+  {
+    int64_t carry = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += WAVE) {
+      uint32_t i = i0 + lane;
+      bool nul = true; int64_t k = 0;
+      if (i < n) wv_row_value<false>(L, i, nul, k, err);
+      if (nul) k = 0;
+      int64_t incl = carry + wave_incl_scan_i64(k, lane);
+      carry = __shfl(incl, WAVE - 1);
+      if (i < n) {
+        if ((uint64_t)incl > n_preds_cap) { err |= F_BAD_RLE; k = 0; incl = 0; }
+        o.pred_num[base + i] = (uint32_t)k;
+        o.pred_first[base + i] = pl.pred_base + (uint32_t)(incl - k);
+      }
+    }
+    total_preds = (uint64_t)carry > n_preds_cap ? 0 : (uint32_t)carry;
+  }
+  wv_load_column(L, p + col_off[C_PRED_ACTOR], col_len[C_PRED_ACTOR], lane);
+  err |= L.err;
+  for (uint32_t j = lane; j < total_preds; j += WAVE) {
+    bool nul; int64_t v;
+    wv_row_value<false>(L, j, nul, v, err);
+    uint32_t r = 0;
+    if (nul) err |= F_UNSUPPORTED;
+    else if ((uint64_t)v >= pl.n_actors) err |= F_BAD_ROW;
+    else r = L.rank[v];
+    o.pred_actor[pl.pred_base + j] = r;
+  }
+  wv_load_column(L, p + col_off[C_PRED_CTR], col_len[C_PRED_CTR], lane);
+  err |= L.err;
+  {
+    int64_t carry = 0;
+    for (uint32_t j0 = 0; j0 < total_preds; j0 += WAVE) {
+      uint32_t j = j0 + lane;
+      bool nul = true; int64_t d = 0;
+      if (j < total_preds) wv_row_value<true>(L, j, nul, d, err);
+      int64_t abs = carry + wave_incl_scan_i64(nul ? 0 : d, lane);
+      carry = __shfl(abs, WAVE - 1);
+      if (j < total_preds) {
+        if (nul) err |= F_UNSUPPORTED;
+        else if (abs < 0 || (uint64_t)abs >= NONE32) err |= F_OVERFLOW;
+        o.pred_ctr[pl.pred_base + j] = (uint32_t)abs;
+      }
+    }
+  }
+  if (err) atomicOr(flags, err);
+}
+
 void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, hipStream_t st) {
   if (!n_changes) return;
   AM355_LAUNCH_INDEPENDENT(k_parse_changes, dim3((n_changes + WAVE - 1) / WAVE), dim3(WAVE), st, arena, offsets, n_changes, metas, n_entries);
@@ -835,17 +1317,22 @@ void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, co
                            (const uint32_t*)first_idx, flags, fast_flags);
 }
 
-void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_plans, const uint32_t* amap,
-                           const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st) {
-  if (!n_plans) return;
+void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_wave, uint32_t n_serial,
+                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st) {
+  // plans[0 .. n_wave) go to the wave-per-change run-level decoder, plans[n_wave .. n_wave + n_serial) (changes with a
+  // column too long for its LDS staging) to the lane-serial decoder
   ActorXlate x{amap, slot_rank};
-  static const bool split = getenv("AM355_SPLIT_DECODE") != nullptr;  // diagnostic: one launch per column group so a profiler can time them
-  if (split) {
-    for (int t = 0; t < T_NUM; t++)
-      AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_plans + WAVE - 1) / WAVE, 1), dim3(WAVE), st, arena, metas, plans, n_plans, x, cols, flags, t);
-    return;
-  }
-  AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_plans + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans, n_plans, x, cols, flags, 0);
+  if (n_wave) hipLaunchKernelGGL(k_decode_wave, dim3(n_wave), dim3(WAVE), 0, st, arena, metas, plans, n_wave, x, cols, flags);
+  if (n_serial)
+    AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans + n_wave, n_serial, x,
+                             cols, flags, 0);
+}
+
+bool decode_fits_wave(const ChangeMeta& m) {
+  static const int tokenised[] = {C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_INSERT, C_ACTION, C_VAL_LEN, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR};
+  for (int c : tokenised)
+    if (m.col_len[c] > WV_COLMAX) return false;
+  return m.n_entries <= WV_ACTMAX;
 }
 
 }  // namespace am355

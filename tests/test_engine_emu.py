@@ -45,6 +45,8 @@ def test_golden_reference_patches(eng, name):
     (loggen.KIND_TEXT_TYPING, dict(n_ops=300, ops_per_change=1)),
     (loggen.KIND_MAP_LWW, dict(n_actors=8, n_rounds=4, n_keys=200)),
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=7, n_rounds=3, ins_per_change=100, del_per_change=10, n_objects=1)),
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=3, n_rounds=2, ins_per_change=40, del_per_change=700, n_objects=1)),  # columns > 1 KiB: lane-serial decoder
+    (loggen.KIND_MAP_LWW, dict(n_actors=3, n_rounds=3, n_keys=1500)),  # 500 literal keys/values per change
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=16, n_rounds=3, ins_per_change=30, del_per_change=8, n_objects=5)),
 ])
 def test_generated_workloads_match_oracle(eng, kind, kw):

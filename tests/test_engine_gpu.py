@@ -66,6 +66,12 @@ CASES = [
 ]
 
 
+def test_oversized_columns_use_the_serial_decoder(eng):
+    # 2000 deletes per change: pred / key columns exceed the wave decoder's LDS staging and take the lane-serial kernel
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=3, ins_per_change=3000, del_per_change=2000, n_objects=1, seed=9)
+    assert gpu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
+
+
 @pytest.mark.parametrize("name,scale,deflate", CASES)
 def test_generated_workloads_match_oracle(eng, name, scale, deflate):
     log = loggen.config(name, scale, deflate=deflate)
