@@ -620,8 +620,8 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     o.pred_ctr = carve<uint32_t>(q, (size_t)P + 1);
   }
   {
-    size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc, 4) + 4 * carve_size(2 * Nc + 2, 4) +
-                   3 * carve_size(Nc + 1, 4) + scan_workspace_bytes((uint32_t)Nc) + 256;
+    size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc + 2, 4) + 4 * carve_size(2 * Nc + 2, 4) +
+                   3 * carve_size(Nc + 1, 4) + scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 256;
     size_t sort_bytes = 2 * carve_size(Nc, 8) + 2 * carve_size(Nc, 4) + sort_workspace_bytes((uint32_t)Nc) + 256;
     size_t ir_bytes = 5 * carve_size(Nc, 4) + 2 * carve_size(Nc, 4) + carve_size(Nc, 8) + 4 * carve_size(Nc, 4);
     if (!c->d_merge.ensure(bytes) || !c->d_sort.ensure(sort_bytes) || !c->d_ir.ensure(ir_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
@@ -641,7 +641,7 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     b.em_row = carve<uint32_t>(p, Nc); b.ins_row = carve<uint32_t>(p, Nc); b.upd_row = carve<uint32_t>(p, Nc); b.next_sib = carve<uint32_t>(p, Nc);
     b.em_trig = carve<unsigned long long>(p, Nc);
     b.kind = carve<uint8_t>(p, Nc);
-    b.first_child = carve<uint32_t>(p, 2 * Nc);
+    b.first_child = carve<uint32_t>(p, 2 * Nc + 2);
     b.succ_a = carve<uint32_t>(p, 2 * Nc + 2); b.succ_b = carve<uint32_t>(p, 2 * Nc + 2); b.dist_a = carve<uint32_t>(p, 2 * Nc + 2); b.dist_b = carve<uint32_t>(p, 2 * Nc + 2);
     b.order = carve<uint32_t>(p, Nc + 1); b.scan_a = carve<uint32_t>(p, Nc + 1); b.scan_b = carve<uint32_t>(p, Nc + 1);
     b.scan_ws = p;
@@ -702,7 +702,12 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   merge_phase1(c->mb, hc, st);
   HIPCHK(c, hipEventRecord(c->ev[4], st));
   if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
-  merge_phase2(c->mb, c->ir, hc, st);
+  merge_phase2(c->mb, c->ir, hc, st, false);
+  if (hc->pad && !hc->flags) {
+    // some list element has hundreds of children (e.g. everyone inserting at the same spot): redo the ordering with the radix sort
+    HIPCHK(c, hipMemsetAsync(&c->mb.counts->pad, 0, sizeof(uint32_t), st));
+    merge_phase2(c->mb, c->ir, hc, st, true);
+  }
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   HIPCHK(c, hipStreamSynchronize(st));
   if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");

@@ -40,7 +40,7 @@ struct MergeBufs {
   uint32_t *val_a, *val_b;
   void* sort_ws;
   // RGA
-  uint32_t *first_child;            // [2N] indexed by parent_row*2 + is_head
+  uint32_t *first_child;            // [2N+1] indexed by parent slot: element row, or N + make row for a list head
   uint32_t *next_sib;               // [N]
   uint32_t *succ_a, *succ_b, *dist_a, *dist_b;  // [2N+2] Euler tour list ranking
   uint32_t *order;                  // [N] node rows in document order (all list objects chained)
@@ -74,6 +74,8 @@ size_t merge_scratch_pairs(uint32_t n_ops);
 // Runs resolve -> emit; fills counts (device) and copies them to *h_counts (synchronises the stream once).
 void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st);
 // Runs object indexing, map emission ordering, RGA ordering, edit generation. Needs *h_counts from phase 1.
-void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st);
+// force_radix: order list siblings with the radix sort instead of the counting sort (needed when a parent has more
+// than a few hundred children; phase 2 reports that in h_counts->pad and the caller reruns it with force_radix).
+void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, bool force_radix);
 
 }  // namespace am355

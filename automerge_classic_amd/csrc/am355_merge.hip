@@ -354,11 +354,72 @@ __global__ __launch_bounds__(BLOCK) void k_list_link(MergeBufs b, const uint64_t
   bool last = j + 1 == n || (keys[j + 1] >> sh) != pk;
   if (first) {
     uint32_t parent = (uint32_t)(pk & ((1ull << kb.b_row) - 1));
-    b.first_child[(size_t)parent * 2 + (is_head ? 1 : 0)] = v;
+    b.first_child[is_head ? b.n_ops + parent : parent] = v;
   }
   // head children of successive list objects are chained so that one ranking pass orders every list at once
   b.next_sib[v] = (!last || (is_head && j + 1 < n)) ? vals[j + 1] : NONE32;
   if (is_head && (j == 0 || (keys[j - 1] >> (sh + kb.b_row)) == 0)) *start_node = v;
+}
+
+// ---- sibling grouping by counting sort (the common case) ------------------------------------------------------
+// Nearly every element has at most one child (typing runs), so a comparison-free grouping by parent beats a
+// 48-bit radix sort: count children per parent, prefix-sum, scatter, then order the few multi-child groups by
+// descending op id in place. Parent index space: element parents are rows [0, N), "head of object o" is N + make row
+// of o, so head children of successive objects end up contiguous at the tail (they are chained for the ranking).
+// A group larger than SEG_SORT_MAX falls back to the radix path (flag in Counts.pad).
+constexpr uint32_t SEG_SORT_MAX = 256;
+
+__device__ __forceinline__ uint32_t parent_slot(const MergeBufs& b, uint32_t g) {
+  uint32_t ref = b.ref_row[g];
+  return ref == NONE32 ? b.n_ops + b.obj_row[g] : ref;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_child_count(MergeBufs b, uint32_t n, uint32_t* __restrict__ cnt) {
+  uint32_t i = gtid();
+  if (i < n) atomicAdd(&cnt[parent_slot(b, b.ins_row[i])], 1u);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_child_scatter(MergeBufs b, uint32_t n, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                         uint32_t* __restrict__ sorted) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t g = b.ins_row[i], ps = parent_slot(b, g);
+  uint32_t k = atomicSub(&cnt[ps], 1u) - 1;  // any order inside the group: it is sorted next
+  sorted[off[ps] + k] = g;
+}
+
+// one lane per node: the first node of every multi-child group sorts that group (descending op id)
+__global__ __launch_bounds__(BLOCK) void k_child_group_sort(MergeBufs b, uint32_t n, const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
+  uint32_t j = gtid();
+  if (j >= n) return;
+  uint32_t ps = parent_slot(b, sorted[j]);
+  uint32_t lo = off[ps], hi = off[ps + 1];
+  if (j != lo || hi - lo < 2) return;
+  if (hi - lo > SEG_SORT_MAX) { b.counts->pad = 1; return; }
+  const OpCols& o = b.ops;
+  for (uint32_t a = lo + 1; a < hi; a++) {  // insertion sort, keys are unique op ids
+    uint32_t v = sorted[a];
+    unsigned long long kv = pack_id(o.id_ctr[v], o.id_actor[v]);
+    uint32_t c = a;
+    while (c > lo) {
+      uint32_t u = sorted[c - 1];
+      if (pack_id(o.id_ctr[u], o.id_actor[u]) > kv) break;
+      sorted[c] = u;
+      c--;
+    }
+    sorted[c] = v;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_child_link(MergeBufs b, uint32_t n, const uint32_t* __restrict__ off, const uint32_t* __restrict__ sorted) {
+  uint32_t j = gtid();
+  if (j >= n) return;
+  uint32_t v = sorted[j], ps = parent_slot(b, v);
+  bool is_head = ps >= b.n_ops;
+  if (j == off[ps]) b.first_child[ps] = v;
+  bool last = j + 1 == off[ps + 1];
+  // head children of successive list objects are chained so that one ranking pass orders every list at once
+  b.next_sib[v] = (!last || (is_head && j + 1 < n)) ? sorted[j + 1] : NONE32;
 }
 
 // Euler tour of the insertion forest: enter(v) = 2v, leave(v) = 2v+1; END = 2N
@@ -368,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void k_euler_init(MergeBufs b, uint32_t n, u
   if (i == 0) { succ[END] = END; dist[END] = 0; }
   if (i >= n) return;
   uint32_t v = b.ins_row[i];
-  uint32_t fc = b.first_child[(size_t)v * 2];
+  uint32_t fc = b.first_child[v];
   succ[2 * v] = fc != NONE32 ? 2 * fc : 2 * v + 1;
   dist[2 * v] = 1;
   uint32_t ns = b.next_sib[v], ref = b.ref_row[v];
@@ -505,8 +566,9 @@ void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st) {
   (void)hipStreamSynchronize(st);
 }
 
-void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
+void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool force_radix) {
   uint32_t N = b.n_ops;
+  if (!force_radix) {  // (a radix rerun only redoes the list ordering; objects and map values are already in place)
   // ---- objects: dense index per make row (0 = _root) ----
   uint32_t* is_make_ex = b.scan_a;
   uint32_t* d_nobj = &b.counts->n_objects;
@@ -546,6 +608,8 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
     AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
   }
 
+  }
+
   // ---- lists ----
   uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd;
   if (ni) {
@@ -553,12 +617,25 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
     int total_bits = 1 + kb.b_row + kb.b_ctr + kb.b_actor;  // <= 64 verified by the caller
     (void)hipMemsetAsync(b.first_child, 0xff, sizeof(uint32_t) * 2 * (size_t)N, st);
     (void)hipMemsetAsync(b.order, 0xff, sizeof(uint32_t) * ni, st);
-    uint32_t* d_start = &b.counts->pad;
-    AM355_LAUNCH_INDEPENDENT(k_list_keys, grid_for(ni), dim3(BLOCK), st, b, b.key_a, b.val_a, ni, kb);
-    int res = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, ni, 0, total_bits, b.sort_ws, st);
-    const uint64_t* sk = res ? b.key_b : b.key_a;
-    const uint32_t* sv = res ? b.val_b : b.val_a;
-    AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, sk, sv, ni, kb, d_start);
+    if (!force_radix) {
+      // counting-sort grouping (cnt and off live in the Euler scratch, which is initialised afterwards)
+      uint32_t* cnt = b.dist_a;
+      uint32_t* off = b.dist_b;
+      uint32_t* sorted = b.val_a;
+      (void)hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (2 * (size_t)N + 1), st);
+      AM355_LAUNCH_INDEPENDENT(k_child_count, grid_for(ni), dim3(BLOCK), st, b, ni, cnt);
+      exclusive_scan_u32(cnt, off, 2 * N + 1, nullptr, b.scan_ws, st);
+      AM355_LAUNCH_INDEPENDENT(k_child_scatter, grid_for(ni), dim3(BLOCK), st, b, ni, cnt, (const uint32_t*)off, sorted);
+      AM355_LAUNCH_INDEPENDENT(k_child_group_sort, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)off, sorted);
+      AM355_LAUNCH_INDEPENDENT(k_child_link, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)off, (const uint32_t*)sorted);
+    } else {
+      uint32_t* d_start = &b.counts->n_edits;  // scratch word, rewritten by k_list_edits
+      AM355_LAUNCH_INDEPENDENT(k_list_keys, grid_for(ni), dim3(BLOCK), st, b, b.key_a, b.val_a, ni, kb);
+      int res = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, ni, 0, total_bits, b.sort_ws, st);
+      const uint64_t* sk = res ? b.key_b : b.key_a;
+      const uint32_t* sv = res ? b.val_b : b.val_a;
+      AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, sk, sv, ni, kb, d_start);
+    }
     AM355_LAUNCH_INDEPENDENT(k_euler_init, grid_for(ni), dim3(BLOCK), st, b, ni, b.succ_a, b.dist_a);
     int rounds = bits_for(2ull * ni + 1);
     uint32_t *s0 = b.succ_a, *d0 = b.dist_a, *s1 = b.succ_b, *d1 = b.dist_b;

@@ -47,6 +47,7 @@ def test_golden_reference_patches(eng, name):
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=7, n_rounds=3, ins_per_change=100, del_per_change=10, n_objects=1)),
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=3, n_rounds=2, ins_per_change=40, del_per_change=700, n_objects=1)),  # columns > 1 KiB: lane-serial decoder
     (loggen.KIND_MAP_LWW, dict(n_actors=3, n_rounds=3, n_keys=1500)),  # 500 literal keys/values per change
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=300, n_rounds=2, ins_per_change=2, del_per_change=1, n_objects=1)),  # 300 children of _head: radix fallback
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=16, n_rounds=3, ins_per_change=30, del_per_change=8, n_objects=5)),
 ])
 def test_generated_workloads_match_oracle(eng, kind, kw):

@@ -66,6 +66,12 @@ CASES = [
 ]
 
 
+def test_many_children_of_one_element_use_the_radix_path(eng):
+    # 1000 actors all inserting at the head in the same round: one parent with 1000 children
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=1000, n_rounds=2, ins_per_change=3, del_per_change=1, n_objects=1, seed=5)
+    assert gpu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
+
+
 def test_oversized_columns_use_the_serial_decoder(eng):
     # 2000 deletes per change: pred / key columns exceed the wave decoder's LDS staging and take the lane-serial kernel
     log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=3, ins_per_change=3000, del_per_change=2000, n_objects=1, seed=9)
