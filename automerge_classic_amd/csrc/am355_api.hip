@@ -642,7 +642,7 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     b.em_trig = carve<unsigned long long>(p, Nc);
     b.kind = carve<uint8_t>(p, Nc);
     b.first_child = carve<uint32_t>(p, 2 * Nc + 2);
-    b.succ_a = carve<uint32_t>(p, 2 * Nc + 2); b.succ_b = carve<uint32_t>(p, 2 * Nc + 2); b.dist_a = carve<uint32_t>(p, 2 * Nc + 2); b.dist_b = carve<uint32_t>(p, 2 * Nc + 2);
+    b.euler_a = carve<unsigned long long>(p, 2 * Nc + 2); b.euler_b = carve<unsigned long long>(p, 2 * Nc + 2);
     b.order = carve<uint32_t>(p, Nc + 1); b.scan_a = carve<uint32_t>(p, Nc + 1); b.scan_b = carve<uint32_t>(p, Nc + 1);
     b.scan_ws = p;
     uint8_t* s = c->d_sort.as<uint8_t>();
@@ -691,14 +691,8 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
                         c->cols, &c->d_counts.as<Counts>()->flags, st);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
 
-  // ---- stage 2: merge (decode flags are read together with the phase-1 counters) ----
+  // ---- stage 2: merge (the decode flags land in the same counter block and are read with the phase-1 counters) ----
   Counts* hc = c->h_counts.as<Counts>();
-  {
-    // phase 1 resets the counters itself; keep the decode flags by OR-ing them back on the host
-    HIPCHK(c, hipMemcpyAsync(hc, c->d_counts.p, sizeof(Counts), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (hc->flags) return error_for_flags(c, hc->flags, "malformed columns");
-  }
   merge_phase1(c->mb, hc, st);
   HIPCHK(c, hipEventRecord(c->ev[4], st));
   if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");

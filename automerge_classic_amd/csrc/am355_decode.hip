@@ -141,15 +141,24 @@ __device__ void sha256_bytes(const uint8_t* p, uint32_t len, uint8_t out[32]) {
   uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
   uint32_t w[16];
   uint32_t i = 0;
+  // software prefetch: the next 64-byte block is requested before the 64 dependent rounds of the current one, so the
+  // memory round trip hides under ~2000 serial ALU instructions instead of preceding them
+  U4 cur[4], nxt[4];
+  if (len >= 64)
+    for (int k = 0; k < 4; k++) cur[k] = *(const U4*)(p + 16 * k);
   for (; i + 64 <= len; i += 64) {
+    bool more = i + 128 <= len;
+    if (more)
+      for (int k = 0; k < 4; k++) nxt[k] = *(const U4*)(p + i + 64 + 16 * k);
     for (int k = 0; k < 4; k++) {
-      U4 v = *(const U4*)(p + i + 16 * k);
-      w[4 * k] = __builtin_bswap32(v.x);
-      w[4 * k + 1] = __builtin_bswap32(v.y);
-      w[4 * k + 2] = __builtin_bswap32(v.z);
-      w[4 * k + 3] = __builtin_bswap32(v.w);
+      w[4 * k] = __builtin_bswap32(cur[k].x);
+      w[4 * k + 1] = __builtin_bswap32(cur[k].y);
+      w[4 * k + 2] = __builtin_bswap32(cur[k].z);
+      w[4 * k + 3] = __builtin_bswap32(cur[k].w);
     }
     sha_rounds(h, w);
+    if (more)
+      for (int k = 0; k < 4; k++) cur[k] = nxt[k];
   }
   // final one or two padded blocks
   uint32_t rem = len - i;

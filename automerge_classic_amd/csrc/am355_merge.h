@@ -42,7 +42,7 @@ struct MergeBufs {
   // RGA
   uint32_t *first_child;            // [2N+1] indexed by parent slot: element row, or N + make row for a list head
   uint32_t *next_sib;               // [N]
-  uint32_t *succ_a, *succ_b, *dist_a, *dist_b;  // [2N+2] Euler tour list ranking
+  unsigned long long *euler_a, *euler_b;        // [2N+2] Euler tour list ranking: (weight-to-end << 32 | successor)
   uint32_t *order;                  // [N] node rows in document order (all list objects chained)
   uint32_t *scan_a, *scan_b;        // [N+1] prefix sums over `order`
   uint32_t *obj_first_pos;          // [n_objects] position in `order` of the first element of each list object

@@ -388,27 +388,25 @@ __global__ __launch_bounds__(BLOCK) void k_child_scatter(MergeBufs b, uint32_t n
   sorted[off[ps] + k] = g;
 }
 
-// one lane per node: the first node of every multi-child group sorts that group (descending op id)
-__global__ __launch_bounds__(BLOCK) void k_child_group_sort(MergeBufs b, uint32_t n, const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
+// one lane per node: its position inside its sibling group = number of siblings with a greater op id
+// (descending order; op ids are unique). O(k) per node, all nodes of a group in parallel.
+__global__ __launch_bounds__(BLOCK) void k_child_group_sort(MergeBufs b, uint32_t n, const uint32_t* __restrict__ off, const uint32_t* __restrict__ grouped,
+                                                            uint32_t* __restrict__ sorted) {
   uint32_t j = gtid();
   if (j >= n) return;
-  uint32_t ps = parent_slot(b, sorted[j]);
+  uint32_t v = grouped[j];
+  uint32_t ps = parent_slot(b, v);
   uint32_t lo = off[ps], hi = off[ps + 1];
-  if (j != lo || hi - lo < 2) return;
-  if (hi - lo > SEG_SORT_MAX) { b.counts->pad = 1; return; }
+  if (hi - lo == 1) { sorted[j] = v; return; }
+  if (hi - lo > SEG_SORT_MAX) { b.counts->pad = 1; sorted[j] = v; return; }
   const OpCols& o = b.ops;
-  for (uint32_t a = lo + 1; a < hi; a++) {  // insertion sort, keys are unique op ids
-    uint32_t v = sorted[a];
-    unsigned long long kv = pack_id(o.id_ctr[v], o.id_actor[v]);
-    uint32_t c = a;
-    while (c > lo) {
-      uint32_t u = sorted[c - 1];
-      if (pack_id(o.id_ctr[u], o.id_actor[u]) > kv) break;
-      sorted[c] = u;
-      c--;
-    }
-    sorted[c] = v;
+  unsigned long long kv = pack_id(o.id_ctr[v], o.id_actor[v]);
+  uint32_t rank = 0;
+  for (uint32_t a = lo; a < hi; a++) {
+    uint32_t u = grouped[a];
+    rank += pack_id(o.id_ctr[u], o.id_actor[u]) > kv ? 1u : 0u;
   }
+  sorted[lo + rank] = v;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_child_link(MergeBufs b, uint32_t n, const uint32_t* __restrict__ off, const uint32_t* __restrict__ sorted) {
@@ -422,39 +420,47 @@ __global__ __launch_bounds__(BLOCK) void k_child_link(MergeBufs b, uint32_t n, c
   b.next_sib[v] = (!last || (is_head && j + 1 < n)) ? sorted[j + 1] : NONE32;
 }
 
-// Euler tour of the insertion forest: enter(v) = 2v, leave(v) = 2v+1; END = 2N
-__global__ __launch_bounds__(BLOCK) void k_euler_init(MergeBufs b, uint32_t n, uint32_t* __restrict__ succ, uint32_t* __restrict__ dist) {
-  uint32_t i = gtid();
+// Euler tour of the insertion forest: enter(v) = 2v, leave(v) = 2v+1; END = 2N. Each list entry is one 64-bit word
+// (successor in the low half, weight-to-end in the high half) so a pointer-jumping round is one coalesced 8-byte
+// read, one random 8-byte read and one coalesced 8-byte write per entry. Entries of rows that are not list elements
+// point at END and cost only the coalesced traffic.
+__device__ __forceinline__ unsigned long long euler_pack(uint32_t succ, uint32_t dist) { return (unsigned long long)dist << 32 | succ; }
+
+__global__ __launch_bounds__(BLOCK) void k_euler_init(MergeBufs b, unsigned long long* __restrict__ el) {
+  uint32_t v = gtid();
   uint32_t END = 2 * b.n_ops;
-  if (i == 0) { succ[END] = END; dist[END] = 0; }
-  if (i >= n) return;
-  uint32_t v = b.ins_row[i];
+  if (v == 0) el[END] = euler_pack(END, 0);
+  if (v >= b.n_ops) return;
+  if (b.kind[v] != K_LIST_INS) {
+    el[2 * (size_t)v] = euler_pack(END, 0);
+    el[2 * (size_t)v + 1] = euler_pack(END, 0);
+    return;
+  }
   uint32_t fc = b.first_child[v];
-  succ[2 * v] = fc != NONE32 ? 2 * fc : 2 * v + 1;
-  dist[2 * v] = 1;
   uint32_t ns = b.next_sib[v], ref = b.ref_row[v];
-  succ[2 * v + 1] = ns != NONE32 ? 2 * ns : (ref != NONE32 ? 2 * ref + 1 : END);
-  dist[2 * v + 1] = 0;
+  el[2 * (size_t)v] = euler_pack(fc != NONE32 ? 2 * fc : 2 * v + 1, 1);
+  el[2 * (size_t)v + 1] = euler_pack(ns != NONE32 ? 2 * ns : (ref != NONE32 ? 2 * ref + 1 : END), 0);
 }
 
 // one pointer-jumping round (Wyllie): dist'[x] = dist[x] + dist[succ[x]], succ'[x] = succ[succ[x]]
-__global__ __launch_bounds__(BLOCK) void k_euler_jump(MergeBufs b, uint32_t n, const uint32_t* __restrict__ succ, const uint32_t* __restrict__ dist,
-                                                      uint32_t* __restrict__ succ2, uint32_t* __restrict__ dist2) {
-  uint32_t i = gtid();
-  uint32_t END = 2 * b.n_ops;
-  if (i == 0) { succ2[END] = END; dist2[END] = 0; }
-  if (i >= 2 * n) return;
-  uint32_t x = 2 * b.ins_row[i >> 1] + (i & 1);
-  uint32_t s = succ[x];
-  dist2[x] = dist[x] + dist[s];
-  succ2[x] = succ[s];
+__global__ __launch_bounds__(BLOCK) void k_euler_jump(uint32_t n_entries, uint32_t END, const unsigned long long* __restrict__ in,
+                                                      unsigned long long* __restrict__ out) {
+  uint32_t x = gtid();
+  if (x > n_entries) return;  // (x == n_entries is END itself)
+  unsigned long long e = in[x];
+  uint32_t s = (uint32_t)e;
+  if (s != END) {
+    unsigned long long t = in[s];
+    e = euler_pack((uint32_t)t, (uint32_t)(e >> 32) + (uint32_t)(t >> 32));
+  }
+  out[x] = e;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, const uint32_t* __restrict__ dist) {
+__global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, const unsigned long long* __restrict__ el) {
   uint32_t i = gtid();
   if (i >= n) return;
   uint32_t v = b.ins_row[i];
-  uint32_t d = dist[2 * v];  // enter-edges from enter(v) to the end, inclusive
+  uint32_t d = (uint32_t)(el[2 * (size_t)v] >> 32);  // enter-edges from enter(v) to the end, inclusive
   if (d == 0 || d > n) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
   b.order[n - d] = v;
 }
@@ -554,7 +560,7 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); 
 
 void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st) {
   uint32_t N = b.n_ops;
-  (void)hipMemsetAsync(b.counts, 0, sizeof(Counts), st);
+  // (b.counts was cleared before the decode kernels, whose validity flags it already holds)
   (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, st);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
   if (N) {
     AM355_LAUNCH_INDEPENDENT(k_resolve, grid_for(N), dim3(BLOCK), st, b);
@@ -619,14 +625,15 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
     (void)hipMemsetAsync(b.order, 0xff, sizeof(uint32_t) * ni, st);
     if (!force_radix) {
       // counting-sort grouping (cnt and off live in the Euler scratch, which is initialised afterwards)
-      uint32_t* cnt = b.dist_a;
-      uint32_t* off = b.dist_b;
-      uint32_t* sorted = b.val_a;
+      uint32_t* cnt = (uint32_t*)b.euler_b;
+      uint32_t* off = cnt + (2 * (size_t)N + 2);
+      uint32_t* grouped = b.val_a;
+      uint32_t* sorted = b.val_b;
       (void)hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (2 * (size_t)N + 1), st);
       AM355_LAUNCH_INDEPENDENT(k_child_count, grid_for(ni), dim3(BLOCK), st, b, ni, cnt);
       exclusive_scan_u32(cnt, off, 2 * N + 1, nullptr, b.scan_ws, st);
-      AM355_LAUNCH_INDEPENDENT(k_child_scatter, grid_for(ni), dim3(BLOCK), st, b, ni, cnt, (const uint32_t*)off, sorted);
-      AM355_LAUNCH_INDEPENDENT(k_child_group_sort, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)off, sorted);
+      AM355_LAUNCH_INDEPENDENT(k_child_scatter, grid_for(ni), dim3(BLOCK), st, b, ni, cnt, (const uint32_t*)off, grouped);
+      AM355_LAUNCH_INDEPENDENT(k_child_group_sort, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)off, (const uint32_t*)grouped, sorted);
       AM355_LAUNCH_INDEPENDENT(k_child_link, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)off, (const uint32_t*)sorted);
     } else {
       uint32_t* d_start = &b.counts->n_edits;  // scratch word, rewritten by k_list_edits
@@ -636,16 +643,16 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
       const uint32_t* sv = res ? b.val_b : b.val_a;
       AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, sk, sv, ni, kb, d_start);
     }
-    AM355_LAUNCH_INDEPENDENT(k_euler_init, grid_for(ni), dim3(BLOCK), st, b, ni, b.succ_a, b.dist_a);
+    AM355_LAUNCH_INDEPENDENT(k_euler_init, grid_for(N), dim3(BLOCK), st, b, b.euler_a);
     int rounds = bits_for(2ull * ni + 1);
-    uint32_t *s0 = b.succ_a, *d0 = b.dist_a, *s1 = b.succ_b, *d1 = b.dist_b;
+    unsigned long long *e0 = b.euler_a, *e1 = b.euler_b;
     for (int r = 0; r < rounds; r++) {
-      AM355_LAUNCH_INDEPENDENT(k_euler_jump, grid_for(2 * ni), dim3(BLOCK), st, b, ni, (const uint32_t*)s0, (const uint32_t*)d0, s1, d1);
-      uint32_t* t;
-      t = s0; s0 = s1; s1 = t;
-      t = d0; d0 = d1; d1 = t;
+      AM355_LAUNCH_INDEPENDENT(k_euler_jump, grid_for(2 * N + 1), dim3(BLOCK), st, 2 * N, 2 * N, (const unsigned long long*)e0, e1);
+      unsigned long long* t = e0;
+      e0 = e1;
+      e1 = t;
     }
-    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)d0);
+    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const unsigned long long*)e0);
     // visibility / value-count prefix sums over document order
     uint32_t* vis = b.scan_a;
     uint32_t* cnt = b.scan_b;
