@@ -111,22 +111,38 @@ __device__ const uint32_t SHA_K[64] = {
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
+// One 64-byte block. Fully unrolled so that the 16-word message window lives in fixed registers (a rolled loop makes the
+// compiler index the register file dynamically, several times slower) and the a..h rotation is pure renaming.
+#define AM355_SHA_ROUND(a, b, c, d, e, f, g, hh, i)                                                            \
+  {                                                                                                            \
+    uint32_t wi;                                                                                               \
+    if ((i) < 16) {                                                                                            \
+      wi = w[(i)&15];                                                                                          \
+    } else {                                                                                                   \
+      uint32_t w15 = w[((i)-15) & 15], w2 = w[((i)-2) & 15];                                                   \
+      uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);                                             \
+      uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);                                              \
+      wi = w[(i)&15] + s0 + w[((i)-7) & 15] + s1;                                                              \
+      w[(i)&15] = wi;                                                                                          \
+    }                                                                                                          \
+    uint32_t t1 = hh + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + wi;  \
+    uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));              \
+    d += t1;                                                                                                   \
+    hh = t1 + t2;                                                                                              \
+  }
+
 __device__ __forceinline__ void sha_rounds(uint32_t h[8], uint32_t w[16]) {
   uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-  for (int i = 0; i < 64; i++) {
-    uint32_t wi;
-    if (i < 16) {
-      wi = w[i];
-    } else {
-      uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-      uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-      uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
-      wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
-      w[i & 15] = wi;
-    }
-    uint32_t t1 = hh + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + wi;
-    uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+#pragma unroll
+  for (int i = 0; i < 64; i += 8) {
+    AM355_SHA_ROUND(a, b, c, d, e, f, g, hh, i + 0)
+    AM355_SHA_ROUND(hh, a, b, c, d, e, f, g, i + 1)
+    AM355_SHA_ROUND(g, hh, a, b, c, d, e, f, i + 2)
+    AM355_SHA_ROUND(f, g, hh, a, b, c, d, e, i + 3)
+    AM355_SHA_ROUND(e, f, g, hh, a, b, c, d, i + 4)
+    AM355_SHA_ROUND(d, e, f, g, hh, a, b, c, i + 5)
+    AM355_SHA_ROUND(c, d, e, f, g, hh, a, b, i + 6)
+    AM355_SHA_ROUND(b, c, d, e, f, g, hh, a, i + 7)
   }
   h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
