@@ -98,7 +98,7 @@ struct am355_ctx {
   HostBuf h_metas;
   // stage-1 side tables (device) and their pinned host mirrors
   DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1;
-  HostBuf h_slots, h_hashes, h_has_dep, h_words;
+  HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage;
   uint32_t amap_cap = 0, slot_mask = 0, hash_mask = 0;
   bool used_fast_path = false;
 
@@ -155,8 +155,12 @@ extern "C" am355_ctx* am355_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   am355_ctx* c = new am355_ctx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
-  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  // the decode/merge stream outranks the hash stream: their small grids would otherwise share SIMDs and the
+  // ALU-dense SHA-256 waves slow the latency-bound parse/decode waves down
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high) != hipSuccess) { delete c; return nullptr; }
+  if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_low) != hipSuccess) { delete c; return nullptr; }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
@@ -171,7 +175,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
                     &c->d_words, &c->d_slot_rank, &c->d_scan1})
     b->release();
-  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words}) b->release();
+  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage}) b->release();
   for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -670,18 +674,33 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     n_wave = (uint32_t)w;
     for (auto& pl : big) c->plans[w++] = pl;
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_plans.p, c->plans.data(), sizeof(ChangePlan) * np, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_spans.p, c->spans.data(), sizeof(ActorSpan) * c->spans.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_tab_off.p, c->actor_tab_off.data(), 4 * c->actor_tab_off.size(), hipMemcpyHostToDevice, st));
+  // host -> device tables go through one pinned staging buffer (pageable std::vector memory would make every copy a
+  // synchronous bounce through the driver's own staging)
   const uint32_t* d_amap;
   const uint32_t* d_rank = nullptr;
-  if (slot_rank) {
-    HIPCHK(c, hipMemcpyAsync(c->d_slot_rank.p, slot_rank->data(), 4 * slot_rank->size(), hipMemcpyHostToDevice, st));
-    d_amap = c->d_amap_prov.as<uint32_t>();
-    d_rank = c->d_slot_rank.as<uint32_t>();
-  } else {
-    HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->amap.data(), 4 * c->amap.size(), hipMemcpyHostToDevice, st));
-    d_amap = c->d_amap.as<uint32_t>();
+  {
+    size_t b_plans = sizeof(ChangePlan) * np, b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size();
+    size_t b_rank = slot_rank ? 4 * slot_rank->size() : 0, b_amap = slot_rank ? 0 : 4 * c->amap.size();
+    if (!c->h_stage.ensure(b_plans + b_spans + b_tab + b_rank + b_amap + 64)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+    uint8_t* h = c->h_stage.as<uint8_t>();
+    auto push = [&](void* dev, const void* src, size_t bytes) -> hipError_t {
+      if (!bytes) return hipSuccess;
+      memcpy(h, src, bytes);
+      hipError_t e = hipMemcpyAsync(dev, h, bytes, hipMemcpyHostToDevice, st);
+      h += bytes;
+      return e;
+    };
+    HIPCHK(c, push(c->d_plans.p, c->plans.data(), b_plans));
+    HIPCHK(c, push(c->d_spans.p, c->spans.data(), b_spans));
+    HIPCHK(c, push(c->d_tab_off.p, c->actor_tab_off.data(), b_tab));
+    if (slot_rank) {
+      HIPCHK(c, push(c->d_slot_rank.p, slot_rank->data(), b_rank));
+      d_amap = c->d_amap_prov.as<uint32_t>();
+      d_rank = c->d_slot_rank.as<uint32_t>();
+    } else {
+      HIPCHK(c, push(c->d_amap.p, c->amap.data(), b_amap));
+      d_amap = c->d_amap.as<uint32_t>();
+    }
   }
 
   // ---- stage 1b: column decode ----
@@ -732,20 +751,20 @@ extern "C" int am355_replay(am355_ctx* c) {
   uint32_t* d_words = c->d_words.as<uint32_t>();
   uint32_t* h_words = c->h_words.as<uint32_t>();
 
-  // ---- stream B: SHA-256 of every change, hash table, dependency resolution (joined at the very end) ----
+  // ---- stream A: parse ----
   HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, sa));
-  HIPCHK(c, hipEventRecord(c->ev_b0, sa));
-  HIPCHK(c, hipStreamWaitEvent(sb, c->ev_b0, 0));
+  HIPCHK(c, hipEventRecord(c->ev[0], sa));
+  launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), sa);
+  HIPCHK(c, hipEventRecord(c->ev_parse, sa));
+
+  // ---- stream B (after the parse, so the two small grids do not compete): SHA-256 of every change, hash table,
+  //      dependency resolution; joined at the very end ----
+  HIPCHK(c, hipStreamWaitEvent(sb, c->ev_parse, 0));
+  HIPCHK(c, hipEventRecord(c->ev_b0, sb));
   HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
   HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
   launch_hash_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_hashes.as<uint8_t>(), c->d_min_idx.as<uint32_t>(),
                       c->d_hash_tab.as<uint32_t>(), c->hash_mask, d_words + W_FLAGS_B, sb);
-
-  // ---- stream A: parse, actor interning ----
-  HIPCHK(c, hipEventRecord(c->ev[0], sa));
-  launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), sa);
-  HIPCHK(c, hipEventRecord(c->ev_parse, sa));
-  HIPCHK(c, hipStreamWaitEvent(sb, c->ev_parse, 0));
   launch_deps_resolve(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_hashes.as<uint8_t>(), n, c->d_hash_tab.as<uint32_t>(), c->hash_mask,
                       c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, sb);
   HIPCHK(c, hipMemcpyAsync(c->h_hashes.p, c->d_hashes.p, 32 * (size_t)n, hipMemcpyDeviceToHost, sb));
