@@ -98,7 +98,9 @@ struct am355_ctx {
   HostBuf h_metas;
   // stage-1 side tables (device) and their pinned host mirrors
   DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1;
-  HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage;
+  HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_briefs, h_distinct;
+  DevBuf d_briefs, d_distinct;
+  bool have_host_metas = false;
   uint32_t amap_cap = 0, slot_mask = 0, hash_mask = 0;
   bool used_fast_path = false;
 
@@ -175,7 +177,9 @@ extern "C" void am355_destroy(am355_ctx* c) {
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
                     &c->d_words, &c->d_slot_rank, &c->d_scan1})
     b->release();
-  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage}) b->release();
+  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_briefs, &c->h_distinct}) b->release();
+  c->d_briefs.release();
+  c->d_distinct.release();
   for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -525,18 +529,24 @@ static int error_for_flags(am355_ctx* c, uint32_t f, const char* what) {
   return fail(c, hard ? AM355_E_INVALID : AM355_E_UNSUPPORTED, "%s (flags 0x%x)", what, f);
 }
 
-// Host half of the in-order fast path: O(changes + actors log actors). Everything that needs the change hashes
-// (dependency resolution, heads) has been checked on the device and is confirmed when stream B is joined.
+// Host half of the in-order fast path: O(changes + actors log actors), no allocation in steady state. Everything that
+// needs the change hashes (dependency resolution, heads) has been checked on the device and is confirmed when stream
+// B is joined.
 static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
-  const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
-  const unsigned long long* slots = c->h_slots.as<unsigned long long>();
+  const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
+  const uint32_t* distinct = c->h_distinct.as<uint32_t>();
+  const unsigned long long* slots = (const unsigned long long*)(distinct + 2 + distinct_capacity());  // ((offset + 1) << 16) | length
   const uint8_t* raw = c->raw.data();
   uint32_t n = c->n_changes, n_slots = c->slot_mask + 1;
   // distinct actor ids -> lexicographic ranks (hex-string order == byte order, new.js:65)
   struct Ent { uint32_t slot, off, len; };
-  std::vector<Ent> ents;
-  for (uint32_t i = 0; i < n_slots; i++)
-    if (slots[i]) ents.push_back(Ent{i, (uint32_t)((slots[i] >> 16) - 1), (uint32_t)(slots[i] & 0xffff)});
+  static thread_local std::vector<Ent> ents;
+  ents.clear();
+  uint32_t nd = distinct[0];
+  for (uint32_t k = 0; k < nd; k++) {
+    uint32_t i = distinct[1 + k];
+    ents.push_back(Ent{i, (uint32_t)((slots[k] >> 16) - 1), (uint32_t)(slots[k] & 0xffff)});
+  }
   std::sort(ents.begin(), ents.end(), [&](const Ent& x, const Ent& y) {
     uint32_t m = std::min(x.len, y.len);
     int r = m ? memcmp(raw + x.off, raw + y.off, m) : 0;
@@ -549,23 +559,24 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
     slot_rank[ents[r].slot] = r;
     c->actors[r].assign((const char*)raw + ents[r].off, ents[r].len);
   }
-  std::vector<uint64_t> clock(na, 0);
+  static thread_local std::vector<uint64_t> clock;
+  static thread_local std::vector<uint32_t> span_cnt;
+  clock.assign(na, 0);
+  span_cnt.assign(na + 1, 0);
   c->clock_actor.clear();
   c->plans.clear();
   c->plans.reserve(n);
   uint64_t ops = 0, preds = 0, entries = 0, max_op = 0;
-  std::vector<std::vector<ActorSpan>> per_actor(na);
   for (uint32_t ci = 0; ci < n; ci++) {
-    const ChangeMeta& m = metas[ci];
+    const ChangeBrief& m = br[ci];
     uint32_t author = slot_rank[m.author_slot];
     if (m.seq != clock[author] + 1) { c->flags |= AM355_F_BAD_SEQ; return fail(c, AM355_E_INVALID, "sequence number %llu out of order", (unsigned long long)m.seq); }
     if (clock[author] == 0) c->clock_actor.push_back(author);
     clock[author] = m.seq;
     if (m.n_ops) {
-      ChangePlan pl{ci, (uint32_t)ops, (uint32_t)preds, (uint32_t)entries, author, m.n_entries};
-      c->plans.push_back(pl);
-      per_actor[author].push_back(ActorSpan{(uint32_t)m.start_op, m.n_ops, pl.op_base});
-      max_op = std::max<uint64_t>(max_op, m.start_op + m.n_ops - 1);
+      c->plans.push_back(ChangePlan{ci, (uint32_t)ops, (uint32_t)preds, (uint32_t)entries, author, m.n_entries});
+      span_cnt[author]++;
+      max_op = std::max<uint64_t>(max_op, (uint64_t)m.start_op + m.n_ops - 1);
     }
     ops += m.n_ops;
     preds += m.n_preds;
@@ -579,21 +590,24 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
   c->max_op = max_op;
   c->clock_seq.clear();
   for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
-  c->spans.clear();
+  // per-actor tables of (start_op, n_ops, op_base): counting layout, then verify ascending and disjoint
   c->actor_tab_off.assign(na + 1, 0);
+  for (uint32_t a = 0; a < na; a++) c->actor_tab_off[a + 1] = c->actor_tab_off[a] + span_cnt[a];
+  c->spans.resize(c->actor_tab_off[na]);
+  for (uint32_t a = 0; a < na; a++) span_cnt[a] = c->actor_tab_off[a];
+  for (const ChangePlan& pl : c->plans) c->spans[span_cnt[pl.author]++] = ActorSpan{br[pl.change].start_op, br[pl.change].n_ops, pl.op_base};
   for (uint32_t a = 0; a < na; a++) {
-    auto& v = per_actor[a];
-    // seq order is start_op order for well-formed histories; sort anyway and verify the ranges are disjoint
-    std::sort(v.begin(), v.end(), [](const ActorSpan& x, const ActorSpan& y) { return x.start_op < y.start_op; });
-    for (size_t k = 1; k < v.size(); k++)
+    ActorSpan* v = c->spans.data() + c->actor_tab_off[a];
+    size_t k_n = c->actor_tab_off[a + 1] - c->actor_tab_off[a];
+    bool sorted = true;
+    for (size_t k = 1; k < k_n; k++) sorted = sorted && v[k - 1].start_op <= v[k].start_op;
+    if (!sorted) std::sort(v, v + k_n, [](const ActorSpan& x, const ActorSpan& y) { return x.start_op < y.start_op; });
+    for (size_t k = 1; k < k_n; k++)
       if ((uint64_t)v[k - 1].start_op + v[k - 1].n_ops > v[k].start_op) {
         c->flags |= AM355_F_DUP_OPID;
         return fail(c, AM355_E_INVALID, "overlapping op id ranges for one actor (duplicate operation ID)");
       }
-    c->actor_tab_off[a] = (uint32_t)c->spans.size();
-    c->spans.insert(c->spans.end(), v.begin(), v.end());
   }
-  c->actor_tab_off[na] = (uint32_t)c->spans.size();
   return AM355_OK;
 }
 
@@ -664,11 +678,11 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   // wave-decodable changes first, the (rare) ones with an over-long column after them
   uint32_t n_wave = 0;
   {
-    const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+    const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
     std::vector<ChangePlan> big;
     size_t w = 0;
     for (size_t i = 0; i < np; i++) {
-      if (decode_fits_wave(metas[c->plans[i].change])) c->plans[w++] = c->plans[i];
+      if (br[c->plans[i].change].flags_fits & 0x80000000u) c->plans[w++] = c->plans[i];
       else big.push_back(c->plans[i]);
     }
     n_wave = (uint32_t)w;
@@ -746,8 +760,10 @@ extern "C" int am355_replay(am355_ctx* c) {
       !c->d_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->d_first_idx.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_hashes.ensure(32 * n1) ||
       !c->d_hash_tab.ensure(4 * (size_t)(c->hash_mask + 1)) || !c->d_min_idx.ensure(4 * n1) || !c->d_has_dep.ensure(n1) || !c->d_words.ensure(4 * W_NUM) ||
       !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
-      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM))
+      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_briefs.ensure(sizeof(ChangeBrief) * n1) || !c->h_briefs.ensure(sizeof(ChangeBrief) * n1) ||
+      !c->d_distinct.ensure(12 * (size_t)distinct_capacity() + 16) || !c->h_distinct.ensure(12 * (size_t)distinct_capacity() + 16))
     return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
+  c->have_host_metas = false;
   uint32_t* d_words = c->d_words.as<uint32_t>();
   uint32_t* h_words = c->h_words.as<uint32_t>();
 
@@ -757,30 +773,35 @@ extern "C" int am355_replay(am355_ctx* c) {
   launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), sa);
   HIPCHK(c, hipEventRecord(c->ev_parse, sa));
 
-  // ---- stream B (after the parse, so the two small grids do not compete): SHA-256 of every change, hash table,
-  //      dependency resolution; joined at the very end ----
-  HIPCHK(c, hipStreamWaitEvent(sb, c->ev_parse, 0));
-  HIPCHK(c, hipEventRecord(c->ev_b0, sb));
-  HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
-  HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
-  launch_hash_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_hashes.as<uint8_t>(), c->d_min_idx.as<uint32_t>(),
-                      c->d_hash_tab.as<uint32_t>(), c->hash_mask, d_words + W_FLAGS_B, sb);
-  launch_deps_resolve(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_hashes.as<uint8_t>(), n, c->d_hash_tab.as<uint32_t>(), c->hash_mask,
-                      c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, sb);
-  HIPCHK(c, hipMemcpyAsync(c->h_hashes.p, c->d_hashes.p, 32 * (size_t)n, hipMemcpyDeviceToHost, sb));
-  HIPCHK(c, hipMemcpyAsync(c->h_has_dep.p, c->d_has_dep.p, n, hipMemcpyDeviceToHost, sb));
-  HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
-  HIPCHK(c, hipEventRecord(c->ev_b1, sb));
-
   exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_words + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
   for (int attempt = 0;; attempt++) {
     HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), sa));
     HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), sa));
+    HIPCHK(c, hipMemsetAsync(c->d_distinct.p, 0, 4, sa));
     launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
-                        c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_words + W_FLAGS_A, d_words + W_FAST_A, sa);
+                        c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_words + W_FLAGS_A, d_words + W_FAST_A,
+                        c->d_distinct.as<uint32_t>(), c->d_briefs.as<ChangeBrief>(), sa);
     HIPCHK(c, hipEventRecord(c->ev[1], sa));
-    HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, sa));
-    HIPCHK(c, hipMemcpyAsync(c->h_slots.p, c->d_slots.p, 8 * (size_t)(c->slot_mask + 1), hipMemcpyDeviceToHost, sa));
+    if (attempt == 0) {
+      // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. It starts
+      //      after the parse / actor kernels of stream A: those grids are as small as the hash grid (one wave per 64
+      //      changes) and the ALU-dense SHA waves would otherwise share their SIMDs and slow them down ----
+      HIPCHK(c, hipStreamWaitEvent(sb, c->ev[1], 0));
+      HIPCHK(c, hipEventRecord(c->ev_b0, sb));
+      HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
+      HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
+      launch_hash_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_hashes.as<uint8_t>(), c->d_min_idx.as<uint32_t>(),
+                      c->d_hash_tab.as<uint32_t>(), c->hash_mask, d_words + W_FLAGS_B, sb);
+      launch_deps_resolve(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_hashes.as<uint8_t>(), n, c->d_hash_tab.as<uint32_t>(), c->hash_mask,
+                      c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, sb);
+      HIPCHK(c, hipMemcpyAsync(c->h_hashes.p, c->d_hashes.p, 32 * (size_t)n, hipMemcpyDeviceToHost, sb));
+      HIPCHK(c, hipMemcpyAsync(c->h_has_dep.p, c->d_has_dep.p, n, hipMemcpyDeviceToHost, sb));
+      HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
+      HIPCHK(c, hipEventRecord(c->ev_b1, sb));
+    }
+    // the host only needs a 32-byte digest per change and the handful of distinct actor ids
+    HIPCHK(c, hipMemcpyAsync(c->h_briefs.p, c->d_briefs.p, sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipMemcpyAsync(c->h_distinct.p, c->d_distinct.p, 12 * (size_t)distinct_capacity() + 16, hipMemcpyDeviceToHost, sa));
     HIPCHK(c, hipMemcpyAsync(h_words, d_words, 12, hipMemcpyDeviceToHost, sa));
     HIPCHK(c, hipStreamSynchronize(sa));
     if (!(h_words[W_FAST_A] & FF_CAPACITY) || attempt) break;
@@ -795,12 +816,13 @@ extern "C" int am355_replay(am355_ctx* c) {
   float ms_host = 0;
   int rc = AM355_OK;
   {
-    const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+    const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
     uint32_t dev_flags = h_words[W_FLAGS_A];
-    for (uint32_t i = 0; i < n; i++) dev_flags |= metas[i].flags;
+    for (uint32_t i = 0; i < n; i++) dev_flags |= br[i].flags_fits & 0x7fffffffu;
     if (dev_flags) { (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
   }
   bool fast = h_words[W_FAST_A] == 0;
+  if (c->h_distinct.as<uint32_t>()[0] > distinct_capacity()) fast = false;  // thousands of actors: the general path interns them on the host
   std::vector<uint32_t> slot_rank;
   int opt_rc = AM355_OK;
   uint32_t opt_flags = 0;
@@ -832,6 +854,8 @@ extern "C" int am355_replay(am355_ctx* c) {
   } else {
     // general path: exact scheduling on the host, then decode/merge of exactly the applied changes
     c->flags = 0;
+    HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipStreamSynchronize(sa));
     auto t0 = std::chrono::steady_clock::now();
     rc = schedule(c);
     ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -8,8 +8,11 @@ void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t
                          uint32_t tab_mask, uint32_t* flags, hipStream_t st);
 void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,
                          const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st);
+// distinct: [0] count of claimed actor-table slots, [1..] their indexes (capacity distinct_capacity()); briefs: per-change digest for the host
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
-                         unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, hipStream_t st);
+                         unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
+                         ChangeBrief* briefs, hipStream_t st);
+uint32_t distinct_capacity();
 // slot_rank == nullptr: `amap` already holds global actor ranks. plans = [n_wave wave-decodable | n_serial others]
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_wave, uint32_t n_serial,
                            const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st);

@@ -433,8 +433,11 @@ __global__ __launch_bounds__(WAVE) void k_deps_resolve(const uint8_t* __restrict
 // actor ids: device-side interning.  slots[i] = ((arena offset of the id bytes + 1) << 16) | length, 0 = empty.
 // The slot index is the provisional actor number; the host ranks the (few) distinct ids lexicographically.
 // ---------------------------------------------------------------------------------------------------------
+// `distinct`: word 0 = number of claimed slots, words [1, 1+CAP) their slot indexes, then (8-byte aligned at word
+// 2+CAP) CAP 64-bit slot values -- everything the host needs about the actor table in one small copy
+constexpr uint32_t DISTINCT_CAP = 4096;
 __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restrict__ arena, unsigned long long* __restrict__ slots, uint32_t mask,
-                                                         uint32_t off, uint32_t len) {
+                                                         uint32_t off, uint32_t len, uint32_t* __restrict__ distinct) {
   const uint8_t* p = arena + off;
   uint64_t h = 0xcbf29ce484222325ull;
   for (uint32_t k = 0; k < len; k++) h = (h ^ p[k]) * 0x100000001b3ull;
@@ -444,7 +447,14 @@ __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restri
     unsigned long long v = slots[i];
     if (v == 0) {
       v = atomicCAS(&slots[i], 0ull, mine);
-      if (v == 0) return i;
+      if (v == 0) {
+        uint32_t k = atomicAdd(&distinct[0], 1u);
+        if (k < DISTINCT_CAP) {
+          distinct[1 + k] = i;
+          ((unsigned long long*)(distinct + 2 + DISTINCT_CAP))[k] = mine;
+        }
+        return i;
+      }
     }
     if ((uint32_t)(v & 0xffff) == len) {
       const uint8_t* q = arena + ((v >> 16) - 1);
@@ -462,7 +472,7 @@ __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restri
 __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
                                                         const uint32_t* __restrict__ amap_base, uint32_t* __restrict__ amap, uint32_t amap_cap,
                                                         unsigned long long* __restrict__ slots, uint32_t mask, uint32_t* __restrict__ first_idx,
-                                                        uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags) {
+                                                        uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags, uint32_t* __restrict__ distinct) {
   __shared__ uint32_t s_off[WAVE], s_len[WAVE];
   uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n) return;
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
   uint32_t abs0 = (uint32_t)m->base;
   uint32_t n_other = m->n_other;
   if (lane == 0) {
-    uint32_t s = actor_find_or_insert(arena, slots, mask, abs0 + m->actor_off, m->actor_len);
+    uint32_t s = actor_find_or_insert(arena, slots, mask, abs0 + m->actor_off, m->actor_len, distinct);
     if (s == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); s = 0; }
     amap[base] = s;
     m->author_slot = s;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
     }
     __syncthreads();
     if (lane < cnt) {
-      uint32_t t = s_len[lane] != NONE32 ? actor_find_or_insert(arena, slots, mask, s_off[lane], s_len[lane]) : NONE32;
+      uint32_t t = s_len[lane] != NONE32 ? actor_find_or_insert(arena, slots, mask, s_off[lane], s_len[lane], distinct) : NONE32;
       if (t == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); t = 0; }
       amap[base + 1 + k0 + lane] = t;
     }
@@ -507,22 +517,36 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
 
 // every actor a change mentions must already be in the document when the change is read (new.js:1442-1449):
 // with in-order application that means its first change has an index <= this one
+__device__ __forceinline__ bool fits_wave_dev(const ChangeMeta& m);
+
 __global__ __launch_bounds__(BLOCK) void k_actor_check(ChangeMeta* __restrict__ metas, uint32_t n, const uint32_t* __restrict__ amap_base,
                                                        const uint32_t* __restrict__ amap, uint32_t amap_cap, const uint32_t* __restrict__ first_idx,
-                                                       uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags) {
+                                                       uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags, ChangeBrief* __restrict__ briefs) {
   uint32_t c = gtid();
   if (c >= n) return;
   ChangeMeta* m = &metas[c];
-  if (m->flags) return;
-  uint32_t base = amap_base[c];
-  if ((uint64_t)base + m->n_entries > amap_cap) return;
-  uint32_t mx = 0;
-  for (uint32_t k = 0; k < m->n_entries; k++) {
-    uint32_t f = first_idx[amap[base + k]];
-    mx = f > mx ? f : mx;  // NONE32 (no change by that actor in the batch) also lands on the general path
+  ChangeBrief br;
+  br.seq = m->seq;
+  br.start_op = (uint32_t)m->start_op;
+  br.n_ops = m->n_ops;
+  br.n_preds = m->n_preds;
+  br.n_entries = m->n_entries;
+  br.author_slot = m->author_slot;
+  br.flags_fits = m->flags;
+  if (!m->flags) {
+    uint32_t base = amap_base[c];
+    if ((uint64_t)base + m->n_entries <= amap_cap) {
+      uint32_t mx = 0;
+      for (uint32_t k = 0; k < m->n_entries; k++) {
+        uint32_t f = first_idx[amap[base + k]];
+        mx = f > mx ? f : mx;  // NONE32 (no change by that actor in the batch) also lands on the general path
+      }
+      m->max_first = mx;
+      if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
+    }
+    if (fits_wave_dev(*m)) br.flags_fits |= 0x80000000u;
   }
-  m->max_first = mx;
-  if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
+  briefs[c] = br;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -860,6 +884,13 @@ struct WaveLds {
   uint32_t rank[WV_ACTMAX];
 };
 enum { RK_REP = 1, RK_LIT = 2, RK_NUL = 3 };
+
+__device__ __forceinline__ bool fits_wave_dev(const ChangeMeta& m) {
+  const int tokenised[] = {C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_INSERT, C_ACTION, C_VAL_LEN, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR};
+  for (int k = 0; k < 10; k++)
+    if (m.col_len[tokenised[k]] > WV_COLMAX) return false;
+  return m.n_entries <= WV_ACTMAX;
+}
 
 __device__ __forceinline__ bool wv_tok_uint(const WaveLds& L, uint32_t t, uint64_t& v) {
   uint32_t nb = L.tok_len[t];
@@ -1334,13 +1365,16 @@ void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const ui
 }
 
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
-                         unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, hipStream_t st) {
+                         unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
+                         ChangeBrief* briefs, hipStream_t st) {
   if (!n) return;
   hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
-                     fast_flags);
+                     fast_flags, distinct);
   AM355_LAUNCH_INDEPENDENT(k_actor_check, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
-                           (const uint32_t*)first_idx, flags, fast_flags);
+                           (const uint32_t*)first_idx, flags, fast_flags, briefs);
 }
+
+uint32_t distinct_capacity() { return DISTINCT_CAP; }
 
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_wave, uint32_t n_serial,
                            const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st) {

@@ -25,6 +25,13 @@ struct ChangeMeta {
   uint32_t n_ops, n_preds;
 };
 
+// What the host's in-order fast path needs per change (32 B instead of the full ChangeMeta), written by k_actor_check
+struct ChangeBrief {
+  uint64_t seq;
+  uint32_t start_op, n_ops, n_preds, n_entries, author_slot;
+  uint32_t flags_fits;  // validity flags of the change; bit 31: all columns fit the wave-per-change decoder
+};
+
 // bits of the "fast path" word: any bit set => the host runs the general scheduler (new.js:1550-1597) itself
 enum FastFlag : uint32_t {
   FF_DUP_HASH = 1u << 0,      // the same change appears twice

@@ -114,9 +114,9 @@ def main():
         return
     value = total_ops / elapsed
     phases = {k: v / args.steps for k, v in parts.items()}
-    # Roofline of the dominant kernel on the critical path, k_decode_columns: algorithmic bytes per
-    # launch = encoded bytes read once + fixed-width op rows written once (53 B/op); duration from HIP events recorded
-    # on the engine's stream around that launch inside am355_replay (ms_decode).
+    # Roofline of the dominant single kernel on the critical path, k_decode_wave: algorithmic bytes
+    # per launch = encoded bytes read once + fixed-width op rows written once (53 B/op + 8 B/pred); duration from HIP
+    # events recorded on the engine's stream around that launch inside am355_replay (ms_decode).
     rows = eng.rows()
     n_preds = int(rows["pred_num"].sum())
     alg_bytes = st.raw_bytes + 53 * st.n_ops + 8 * n_preds
@@ -137,8 +137,13 @@ def main():
         "algorithmic_bytes_per_op": {"E_encoded": E, "R_op_record": R, "P_patch_ir": P, "A": E + R + P},
         "host_buffers_in_ops_per_s": st.n_ops / t_host_in,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "kernel": "k_decode_columns", "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases["ms_decode"]},
+                     "kernel": "k_decode_wave", "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases["ms_decode"]},
     }
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode_wave.json")
+    if os.path.exists(pmc) and args.workload == "c4_text_single" and args.scale == 1.0:
+        # HBM bytes per launch from rocprofv3 PMC passes of this same command (committed summary; counters cannot be read in-process)
+        with open(pmc) as f:
+            out["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(log)
     print(json.dumps(out))

@@ -121,6 +121,16 @@ def test_corrupt_input_is_rejected(eng):
         oracle_lib.OracleDoc(bad)
 
 
+@pytest.mark.parametrize("name,scale", [("c2_text_typing", 1.0), ("c3_map_lww", 1.0), ("c4_text_multi", 1.0)])
+def test_full_size_other_configs(eng, name, scale):
+    """BASELINE configs 2 and 3 and the shardable variant of config 4 at full size, bit-exact against the oracle."""
+    log = loggen.config(name, scale)
+    got = gpu_patch(eng, log)
+    want = oracle_lib.OracleDoc(log).patch_json()
+    assert hashlib.sha256(got.encode()).hexdigest() == hashlib.sha256(want.encode()).hexdigest()
+    assert eng.stats().n_ops == log.n_ops
+
+
 def test_full_size_headline_workload(eng):
     """BASELINE config 4 at full size (1M ops, 64 actors, one Text object): bit-exact against the oracle, plus
     size-independent properties of the patch."""
