@@ -51,6 +51,24 @@ struct Cur {
   }
 };
 
+// 16-byte loads at arbitrary alignment (changes are packed back to back in the arena; gfx950 global loads are
+// alignment-agnostic, so this compiles to global_load_dwordx4)
+struct __attribute__((packed)) U4 {
+  uint32_t x, y, z, w;
+};
+struct alignas(16) V4 {  // the same 16 bytes at a 16-byte aligned LDS address
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ void stage_to_lds(uint8_t* dst /* 16-byte aligned */, const uint8_t* __restrict__ src, uint32_t total, uint32_t lane) {
+  uint32_t vec = total & ~15u;
+  for (uint32_t i = lane * 16; i < vec; i += WAVE * 16) {
+    U4 v = *(const U4*)(src + i);
+    V4 w{v.x, v.y, v.z, v.w};
+    *(V4*)(dst + i) = w;
+  }
+  for (uint32_t i = vec + lane; i < total; i += WAVE) dst[i] = src[i];
+}
+
 constexpr uint64_t MAX_SAFE = 9007199254740991ull;  // 2^53 - 1
 
 // encoding.js:389-396 + 410-436: at most 10 bytes / 64 bits, result must fit in 53 bits
@@ -146,12 +164,6 @@ __device__ __forceinline__ void sha_rounds(uint32_t h[8], uint32_t w[16]) {
   }
   h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
-
-// 16-byte loads at arbitrary alignment (changes are packed back to back in the arena; gfx950 global loads are
-// alignment-agnostic, so this compiles to global_load_dwordx4)
-struct __attribute__((packed)) U4 {
-  uint32_t x, y, z, w;
-};
 
 __device__ void sha256_bytes(const uint8_t* p, uint32_t len, uint8_t out[32]) {
   uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
@@ -259,10 +271,21 @@ __device__ bool rle_count_sum(const uint8_t* p, uint32_t len, uint64_t& count, u
   return true;
 }
 
+// One wavefront per change: the change is staged into LDS with wide coalesced loads (one memory round trip instead of
+// one per dependent header field), then lane 0 parses it there. Changes larger than the staging buffer are parsed
+// straight from global memory by the same code.
+constexpr uint32_t PARSE_STAGE = 8192;
+
 __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
                                                          uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries) {
-  uint32_t c = gtid();
+  __shared__ alignas(16) uint8_t stage[PARSE_STAGE];
+  uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n_changes) return;
+  uint64_t base64 = offsets[c], total64 = offsets[c + 1] - offsets[c];
+  bool staged = total64 <= PARSE_STAGE;
+  if (staged) stage_to_lds(stage, arena + base64, (uint32_t)total64, lane);
+  __syncthreads();
+  if (lane != 0) return;
   ChangeMeta m;
   m.base = offsets[c];
   uint64_t len64 = offsets[c + 1] - offsets[c];
@@ -274,7 +297,7 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
   m.author_slot = m.max_first = NONE32;
   m.pad = 0;
   for (int k = 0; k < C_NUM; k++) m.col_off[k] = m.col_len[k] = 0;
-  const uint8_t* p = arena + m.base;
+  const uint8_t* p = staged ? (const uint8_t*)stage : arena + m.base;
   do {
     if (len64 > 0xfffffff0ull) { m.flags |= F_OVERFLOW; break; }
     if (m.len < 10) { m.flags |= F_BAD_CHUNK; break; }
@@ -873,8 +896,10 @@ __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restri
 constexpr uint32_t WV_COLMAX = 1024;
 constexpr uint32_t WV_RUNMAX = WV_COLMAX / 2;  // every record is at least two tokens
 constexpr uint32_t WV_ACTMAX = 1024;
+constexpr uint32_t WV_REGION = 4096;  // all columns of a change, staged once when they fit
 
 struct WaveLds {
+  alignas(16) uint8_t region[WV_REGION];
   uint8_t bytes[WV_COLMAX];
   uint32_t tok_lo[WV_COLMAX], tok_hi[WV_COLMAX];
   uint8_t tok_len[WV_COLMAX], tok_last[WV_COLMAX];
@@ -1051,9 +1076,20 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     uint32_t v = x.amap[pl.amap_base + k];
     L.rank[k] = x.slot_rank ? x.slot_rank[v] : v;
   }
+  // the columns of a change are contiguous: when they fit, stage them all with one round of wide loads so the
+  // per-column steps below never wait on global memory again
+  uint32_t reg_lo = 0xffffffffu, reg_hi = 0;
+  for (int k = 0; k < C_NUM; k++)
+    if (col_len[k]) {
+      reg_lo = col_off[k] < reg_lo ? col_off[k] : reg_lo;
+      reg_hi = col_off[k] + col_len[k] > reg_hi ? col_off[k] + col_len[k] : reg_hi;
+    }
+  const bool staged = reg_hi > reg_lo && reg_hi - reg_lo <= WV_REGION;
+  if (staged) stage_to_lds(L.region, p + reg_lo, reg_hi - reg_lo, lane);
+  auto colp = [&](int k) -> const uint8_t* { return staged && col_len[k] ? (const uint8_t*)L.region + (col_off[k] - reg_lo) : p + col_off[k]; };
 
   // ---- action (+ op ids: op i of a change is (startOp + i, author), new.js:708-709) ----
-  wv_load_column(L, p + col_off[C_ACTION], col_len[C_ACTION], lane);
+  wv_load_column(L, colp(C_ACTION), col_len[C_ACTION], lane);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1068,7 +1104,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   {
     __syncthreads();
     uint32_t len = col_len[C_INSERT];
-    const uint8_t* col = p + col_off[C_INSERT];
+    const uint8_t* col = colp(C_INSERT);
     for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
     __syncthreads();
     // tokens = run lengths
@@ -1126,7 +1162,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     }
   }
   // ---- object id ----
-  wv_load_column(L, p + col_off[C_OBJ_ACTOR], col_len[C_OBJ_ACTOR], lane);
+  wv_load_column(L, colp(C_OBJ_ACTOR), col_len[C_OBJ_ACTOR], lane);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1135,7 +1171,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     if (!nul) { if ((uint64_t)v >= pl.n_actors) err |= F_BAD_ROW; else r = L.rank[v]; }
     o.obj_actor[base + i] = r;
   }
-  wv_load_column(L, p + col_off[C_OBJ_CTR], col_len[C_OBJ_CTR], lane);
+  wv_load_column(L, colp(C_OBJ_CTR), col_len[C_OBJ_CTR], lane);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1145,7 +1181,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     o.obj_ctr[base + i] = nul ? 0 : (uint32_t)v;
   }
   // ---- key: element id (actor, delta-coded counter) ----
-  wv_load_column(L, p + col_off[C_KEY_ACTOR], col_len[C_KEY_ACTOR], lane);
+  wv_load_column(L, colp(C_KEY_ACTOR), col_len[C_KEY_ACTOR], lane);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1154,7 +1190,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     if (!nul) { if ((uint64_t)v >= pl.n_actors) err |= F_BAD_ROW; else r = L.rank[v]; }
     o.key_actor[base + i] = r;
   }
-  wv_load_column(L, p + col_off[C_KEY_CTR], col_len[C_KEY_CTR], lane);
+  wv_load_column(L, colp(C_KEY_CTR), col_len[C_KEY_CTR], lane);
   err |= L.err;
   {
     int64_t carry = 0;
@@ -1178,7 +1214,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   //      per value only inside literals -- filling the run table in batches that all lanes then expand) ----
   {
     __syncthreads();
-    Cur c(p + col_off[C_KEY_STR], 0, col_len[C_KEY_STR]);
+    Cur c(colp(C_KEY_STR), 0, col_len[C_KEY_STR]);
     const uint32_t col_abs = abs0 + col_off[C_KEY_STR];
     int state = 0;                 // 0 none, 1 repetition, 2 literal, 3 nulls (encoding.js:865-887)
     bool have_last = false;
@@ -1274,7 +1310,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     }
   }
   // ---- value: (len << 4 | tag) per row, offsets into valRaw are an exclusive prefix sum of the lengths ----
-  wv_load_column(L, p + col_off[C_VAL_LEN], col_len[C_VAL_LEN], lane);
+  wv_load_column(L, colp(C_VAL_LEN), col_len[C_VAL_LEN], lane);
   err |= L.err;
   {
     int64_t carry = 0;
@@ -1296,7 +1332,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   }
   // ---- preds: group cardinality, then the two value columns consumed predNum[i] entries per row ----
   uint32_t total_preds = 0;
-  wv_load_column(L, p + col_off[C_PRED_NUM], col_len[C_PRED_NUM], lane);
+  wv_load_column(L, colp(C_PRED_NUM), col_len[C_PRED_NUM], lane);
   err |= L.err;
   {
     int64_t carry = 0;
@@ -1315,7 +1351,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     }
     total_preds = (uint64_t)carry > n_preds_cap ? 0 : (uint32_t)carry;
   }
-  wv_load_column(L, p + col_off[C_PRED_ACTOR], col_len[C_PRED_ACTOR], lane);
+  wv_load_column(L, colp(C_PRED_ACTOR), col_len[C_PRED_ACTOR], lane);
   err |= L.err;
   for (uint32_t j = lane; j < total_preds; j += WAVE) {
     bool nul; int64_t v;
@@ -1326,7 +1362,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     else r = L.rank[v];
     o.pred_actor[pl.pred_base + j] = r;
   }
-  wv_load_column(L, p + col_off[C_PRED_CTR], col_len[C_PRED_CTR], lane);
+  wv_load_column(L, colp(C_PRED_CTR), col_len[C_PRED_CTR], lane);
   err |= L.err;
   {
     int64_t carry = 0;
@@ -1348,7 +1384,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
 
 void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, hipStream_t st) {
   if (!n_changes) return;
-  AM355_LAUNCH_INDEPENDENT(k_parse_changes, dim3((n_changes + WAVE - 1) / WAVE), dim3(WAVE), st, arena, offsets, n_changes, metas, n_entries);
+  hipLaunchKernelGGL(k_parse_changes, dim3(n_changes), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries);
 }
 
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
