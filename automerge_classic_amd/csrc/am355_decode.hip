@@ -69,6 +69,16 @@ __device__ __forceinline__ void stage_to_lds(uint8_t* dst /* 16-byte aligned */,
   for (uint32_t i = vec + lane; i < total; i += WAVE) dst[i] = src[i];
 }
 
+// byte-string equality, eight bytes per load (`limit` = end of the buffer both ranges live in: no read beyond it)
+__device__ __forceinline__ bool bytes_equal(const uint8_t* p, uint32_t a, uint32_t b, uint32_t len, uint32_t limit) {
+  uint32_t k = 0;
+  for (; k + 8 <= len && a + k + 8 <= limit && b + k + 8 <= limit; k += 8)
+    if (((const U8B*)(p + a + k))->v != ((const U8B*)(p + b + k))->v) return false;
+  for (; k < len; k++)
+    if (p[a + k] != p[b + k]) return false;
+  return true;
+}
+
 constexpr uint64_t MAX_SAFE = 9007199254740991ull;  // 2^53 - 1
 
 // encoding.js:389-396 + 410-436: at most 10 bytes / 64 bits, result must fit in 53 bits
@@ -625,10 +635,7 @@ template <int TYPE>
 __device__ __forceinline__ bool rle_same(const Rle& r, const RVal& v) {
   if (!r.have_last || r.last_null) return false;
   if (TYPE == RT_UTF8) {
-    if (r.last_len != v.len) return false;
-    for (uint32_t k = 0; k < v.len; k++)
-      if (r.c.p[r.last_off + k] != r.c.p[v.off + k]) return false;
-    return true;
+    return r.last_len == v.len && bytes_equal(r.c.p, r.last_off, v.off, v.len, r.c.len);
   }
   return r.last == v.i;
 }
@@ -1214,7 +1221,15 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   //      per value only inside literals -- filling the run table in batches that all lanes then expand) ----
   {
     __syncthreads();
-    Cur c(colp(C_KEY_STR), 0, col_len[C_KEY_STR]);
+    // lane 0 compares neighbouring strings byte by byte: make sure it does so in LDS. If the whole column region did
+    // not fit, the key column alone usually does (`region` is unused in that case: the other columns stage through `bytes`).
+    const uint8_t* keycol = colp(C_KEY_STR);
+    if (!staged && col_len[C_KEY_STR] && col_len[C_KEY_STR] <= WV_REGION) {
+      stage_to_lds(L.region, p + col_off[C_KEY_STR], col_len[C_KEY_STR], lane);
+      keycol = L.region;
+      __syncthreads();
+    }
+    Cur c(keycol, 0, col_len[C_KEY_STR]);
     const uint32_t col_abs = abs0 + col_off[C_KEY_STR];
     int state = 0;                 // 0 none, 1 repetition, 2 literal, 3 nulls (encoding.js:865-887)
     bool have_last = false;
@@ -1226,10 +1241,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
         uint32_t nr = 0, e = 0;
         uint64_t rows = rows_done;
         auto same = [&](uint32_t off, uint32_t len) {
-          if (!have_last || last_len != len) return false;
-          for (uint32_t k = 0; k < len; k++)
-            if (c.p[last_off + k] != c.p[off + k]) return false;
-          return true;
+          return have_last && last_len == len && bytes_equal(c.p, last_off, off, len, c.len);
         };
         while (nr < WV_RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
           uint32_t kind, off = 0, len = 0;
