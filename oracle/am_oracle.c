@@ -710,6 +710,8 @@ struct amo_doc {
   uint8_t *hashes;        /* 32 * n_changes */
   span_t *actors;         /* document actor table, first-applied order (new.js:1434-1441) */
   uint64_t *clock;        /* seq per document actor */
+  uint32_t *clock_order;  /* actors with a clock entry, in JS property order of `clock` (NULL: all actors in table order) */
+  uint32_t n_clock;
   uint32_t n_actors, cap_actors;
   uint8_t *heads;         /* sorted, 32 bytes each */
   uint32_t n_heads;
@@ -1085,6 +1087,7 @@ void amo_free(amo_doc *d) {
   free(d->hashes);
   free(d->actors);
   free(d->clock);
+  free(d->clock_order);
   free(d->json.p);
   pool_free(&d->pool);
   free(d);
@@ -1888,33 +1891,37 @@ const char *amo_patch_json(amo_doc *d, size_t *len, char *errbuf, size_t errcap)
     {
       /* clock keys are hex actor ids in first-applied order, except integer-like keys go first */
       static const char hx[] = "0123456789abcdef";
-      idxkey_t *idx = (idxkey_t *)malloc(sizeof(idxkey_t) * (d->n_actors ? d->n_actors : 1));
-      char **hex = (char **)malloc(sizeof(char *) * (d->n_actors ? d->n_actors : 1));
+      uint32_t nc = d->clock_order ? d->n_clock : d->n_actors;
+      idxkey_t *idx = (idxkey_t *)malloc(sizeof(idxkey_t) * (nc ? nc : 1));
+      char **hex = (char **)malloc(sizeof(char *) * (nc ? nc : 1));
       uint64_t ni = 0;
-      for (uint32_t i = 0; i < d->n_actors; i++) {
-        hex[i] = (char *)malloc(d->actors[i].len * 2 + 1);
-        for (size_t k = 0; k < d->actors[i].len; k++) { hex[i][2 * k] = hx[d->actors[i].p[k] >> 4]; hex[i][2 * k + 1] = hx[d->actors[i].p[k] & 15]; }
-        hex[i][d->actors[i].len * 2] = 0;
+      for (uint32_t k = 0; k < nc; k++) {
+        uint32_t i = d->clock_order ? d->clock_order[k] : k;
+        hex[k] = (char *)malloc(d->actors[i].len * 2 + 1);
+        for (size_t j = 0; j < d->actors[i].len; j++) { hex[k][2 * j] = hx[d->actors[i].p[j] >> 4]; hex[k][2 * j + 1] = hx[d->actors[i].p[j] & 15]; }
+        hex[k][d->actors[i].len * 2] = 0;
         uint64_t v;
-        if (array_index_key((const uint8_t *)hex[i], d->actors[i].len * 2, &v)) { idx[ni].num = v; idx[ni].pos = i; ni++; }
+        if (array_index_key((const uint8_t *)hex[k], d->actors[i].len * 2, &v)) { idx[ni].num = v; idx[ni].pos = k; ni++; }
       }
       qsort(idx, ni, sizeof(idxkey_t), cmp_idxkey);
       int first = 1;
-      for (uint64_t i = 0; i < ni; i++) {
-        snprintf(t, sizeof t, "\":%llu", (unsigned long long)d->clock[idx[i].pos]);
-        if (!first) sb_putc(b, ',');
-        first = 0;
-        sb_putc(b, '"'); sb_puts(b, hex[idx[i].pos]); sb_puts(b, t);
-      }
-      for (uint32_t i = 0; i < d->n_actors; i++) {
-        uint64_t v;
-        if (array_index_key((const uint8_t *)hex[i], d->actors[i].len * 2, &v)) continue;
+      for (uint64_t q = 0; q < ni; q++) {
+        uint32_t k = (uint32_t)idx[q].pos, i = d->clock_order ? d->clock_order[k] : k;
         snprintf(t, sizeof t, "\":%llu", (unsigned long long)d->clock[i]);
         if (!first) sb_putc(b, ',');
         first = 0;
-        sb_putc(b, '"'); sb_puts(b, hex[i]); sb_puts(b, t);
+        sb_putc(b, '"'); sb_puts(b, hex[k]); sb_puts(b, t);
       }
-      for (uint32_t i = 0; i < d->n_actors; i++) free(hex[i]);
+      for (uint32_t k = 0; k < nc; k++) {
+        uint32_t i = d->clock_order ? d->clock_order[k] : k;
+        uint64_t v;
+        if (array_index_key((const uint8_t *)hex[k], d->actors[i].len * 2, &v)) continue;
+        snprintf(t, sizeof t, "\":%llu", (unsigned long long)d->clock[i]);
+        if (!first) sb_putc(b, ',');
+        first = 0;
+        sb_putc(b, '"'); sb_puts(b, hex[k]); sb_puts(b, t);
+      }
+      for (uint32_t k = 0; k < nc; k++) free(hex[k]);
       free(hex);
       free(idx);
     }
@@ -1954,6 +1961,288 @@ const char *amo_patch_json(amo_doc *d, size_t *len, char *errbuf, size_t errcap)
   d->json_done = 1;
   if (len) *len = d->json.len;
   return d->json.p;
+}
+
+/* ===================================================================================================
+ * Document load.  columnar.js:1006-1038 decodeDocumentHeader, 1062-1067 inflateColumn; new.js:1645-1675
+ * readDocumentChanges, 1695-1750 BackendDoc constructor (whole-document patch = documentPatch over the stored
+ * rows, which a saved document holds in canonical order with their succ lists: columnar.js:892, new.js:2047).
+ * =================================================================================================*/
+
+static int inflate_raw(const uint8_t *in, size_t inlen, uint8_t **out, size_t *outlen, err_t *e) {
+  size_t cap = inlen * 4 + 1024;
+  for (;;) {
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { free(buf); return fail(e, "inflate init failed"); }
+    zs.next_in = (Bytef *)in; zs.avail_in = (uInt)inlen;
+    zs.next_out = buf; zs.avail_out = (uInt)cap;
+    int rc = inflate(&zs, Z_FINISH);
+    size_t got = zs.total_out;
+    inflateEnd(&zs);
+    if (rc == Z_STREAM_END) { *out = buf; *outlen = got; return 0; }
+    free(buf);
+    if (rc == Z_BUF_ERROR || rc == Z_OK) { cap *= 4; continue; }
+    return fail(e, "invalid deflate data");
+  }
+}
+
+typedef struct {
+  uint64_t id;
+  span_t data;
+} dcol_t;
+
+static span_t find_col(const dcol_t *cols, uint64_t n, uint64_t id) {
+  span_t none = {NULL, 0};
+  for (uint64_t i = 0; i < n; i++)
+    if (cols[i].id == id) return cols[i].data;
+  return none;
+}
+
+/* read a column directory and return the columns (inflated into pool memory) */
+static int read_doc_columns(pool_t *pool, dec_t *h, dcol_t **out, uint64_t *n_out, uint64_t **lens_out, err_t *e) {
+  uint64_t n;
+  if (read_u53(h, &n, e)) return -1;
+  if (n > h->len) return fail(e, "subarray exceeds buffer size");
+  dcol_t *cols = (dcol_t *)pool_alloc(pool, sizeof(dcol_t) * (n + 1));
+  uint64_t *lens = (uint64_t *)pool_alloc(pool, sizeof(uint64_t) * (n + 1));
+  int64_t last = -1;
+  for (uint64_t i = 0; i < n; i++) {
+    if (read_u53(h, &cols[i].id, e) || read_u53(h, &lens[i], e)) return -1;
+    int64_t masked = (int64_t)(cols[i].id & ~(uint64_t)8);
+    if (masked <= last) return fail(e, "Columns must be in ascending order");
+    last = masked;
+  }
+  *out = cols;
+  *n_out = n;
+  *lens_out = lens;
+  return 0;
+}
+
+static int load_doc_column_data(pool_t *pool, dec_t *h, dcol_t *cols, uint64_t n, const uint64_t *lens, err_t *e) {
+  for (uint64_t i = 0; i < n; i++) {
+    const uint8_t *p;
+    if (read_bytes(h, lens[i], &p, e)) return -1;
+    if (cols[i].id & 8) {
+      uint8_t *buf;
+      size_t blen;
+      if (inflate_raw(p, lens[i], &buf, &blen, e)) return -1;
+      uint8_t *keep = (uint8_t *)pool_alloc(pool, blen ? blen : 1);
+      memcpy(keep, buf, blen);
+      free(buf);
+      cols[i].data.p = keep;
+      cols[i].data.len = blen;
+      cols[i].id ^= 8;
+    } else {
+      cols[i].data.p = p;
+      cols[i].data.len = lens[i];
+    }
+  }
+  return 0;
+}
+
+amo_doc *amo_load_document(const uint8_t *buf, size_t len, char *errbuf, size_t errcap) {
+  err_t e = {{0}, 0};
+  amo_doc *d = (amo_doc *)calloc(1, sizeof *d);
+  d->hashes = (uint8_t *)calloc(1, 32);
+  int rc = 0;
+  uint8_t *copy = (uint8_t *)pool_alloc(&d->pool, len ? len : 1); /* rows keep pointers into the document */
+  memcpy(copy, buf, len);
+  buf = copy;
+  do {
+    dec_t c = {buf, len, 0};
+    const uint8_t *magic, *sum, *typ, *body;
+    uint64_t clen;
+    if ((rc = read_bytes(&c, 4, &magic, &e))) break;
+    if (memcmp(magic, MAGIC, 4) != 0) { rc = fail(&e, "Data does not begin with magic bytes 85 6f 4a 83"); break; }
+    if ((rc = read_bytes(&c, 4, &sum, &e))) break;
+    size_t hash_start = c.off;
+    if ((rc = read_bytes(&c, 1, &typ, &e)) || (rc = read_u53(&c, &clen, &e)) || (rc = read_bytes(&c, clen, &body, &e))) break;
+    uint8_t hash[32];
+    amo_sha256(buf + hash_start, c.off - hash_start, hash);
+    if (memcmp(hash, sum, 4) != 0) { rc = fail(&e, "checksum does not match data"); break; }
+    if (c.off != len) { rc = fail(&e, "Encoded document has trailing data"); break; }
+    if (*typ != 0) { rc = fail(&e, "Unexpected chunk type: %d", *typ); break; }
+
+    dec_t h = {body, clen, 0};
+    uint64_t na, nh;
+    if ((rc = read_u53(&h, &na, &e))) break;
+    if (na > clen || na >= MAX_ACTORS) { rc = fail(&e, "unsupported: too many actors"); break; }
+    d->n_actors = d->cap_actors = (uint32_t)na;
+    d->actors = (span_t *)calloc(na ? na : 1, sizeof(span_t));
+    d->clock = (uint64_t *)calloc(na ? na : 1, 8);
+    d->clock_order = (uint32_t *)calloc(na ? na : 1, 4);
+    for (uint64_t i = 0; i < na && !rc; i++) {
+      uint64_t l;
+      if ((rc = read_u53(&h, &l, &e)) || (rc = read_bytes(&h, l, &d->actors[i].p, &e))) break;
+      d->actors[i].len = l;
+    }
+    if (rc) break;
+    if ((rc = read_u53(&h, &nh, &e))) break;
+    const uint8_t *heads;
+    if ((rc = read_bytes(&h, nh * 32, &heads, &e))) break;
+    d->n_heads = (uint32_t)nh;
+    d->heads = (uint8_t *)pool_alloc(&d->pool, nh ? nh * 32 : 1);
+    memcpy(d->heads, heads, nh * 32);
+    dcol_t *ccols, *ocols;
+    uint64_t ncc, noc, *clens, *olens;
+    if ((rc = read_doc_columns(&d->pool, &h, &ccols, &ncc, &clens, &e)) || (rc = read_doc_columns(&d->pool, &h, &ocols, &noc, &olens, &e))) break;
+    if ((rc = load_doc_column_data(&d->pool, &h, ccols, ncc, clens, &e)) || (rc = load_doc_column_data(&d->pool, &h, ocols, noc, olens, &e))) break;
+    /* headsIndexes and extraBytes follow; neither influences the patch */
+
+    /* ---- readDocumentChanges (new.js:1645-1675): clock in first-appearance order, seq continuity ---- */
+    {
+      span_t ca = find_col(ccols, ncc, 0x01), cs = find_col(ccols, ncc, 0x03);
+      rle_t actorD;
+      delta_t seqD;
+      rle_init(&actorD, 0, ca.p, ca.len);
+      delta_init(&seqD, cs.p, cs.len);
+      while (!rle_done(&actorD) && !rc) {
+        rval_t a, q;
+        if ((rc = rle_read(&actorD, &a, &e)) || (rc = delta_read(&seqD, &q, &e))) break;
+        if (a.is_null || (uint64_t)a.i >= na) { rc = fail(&e, "unsupported: bad actor index in change metadata"); break; }
+        uint64_t seq = q.is_null ? 0 : (uint64_t)q.i;
+        if (seq != 1 && seq != d->clock[a.i] + 1) { rc = fail(&e, "Expected seq %llu, got %llu", (unsigned long long)d->clock[a.i] + 1, (unsigned long long)seq); break; }
+        int seen = 0;
+        for (uint32_t k = 0; k < d->n_clock; k++) seen |= d->clock_order[k] == (uint32_t)a.i;
+        if (!seen) d->clock_order[d->n_clock++] = (uint32_t)a.i;
+        d->clock[a.i] = seq;
+        d->n_changes++;
+      }
+      if (rc) break;
+      d->n_applied = d->n_changes;
+    }
+
+    /* ---- op rows, in file order ---- */
+    rle_t objA, objC, keyA, keyS, idA, act, vlen, snum, sact;
+    delta_t keyC, idC, sctr;
+    bool_t ins;
+#define COL(id) find_col(ocols, noc, id)
+    span_t t;
+    t = COL(0x01); rle_init(&objA, 0, t.p, t.len);
+    t = COL(0x02); rle_init(&objC, 0, t.p, t.len);
+    t = COL(0x11); rle_init(&keyA, 0, t.p, t.len);
+    t = COL(0x13); delta_init(&keyC, t.p, t.len);
+    t = COL(0x15); rle_init(&keyS, 2, t.p, t.len);
+    t = COL(0x21); rle_init(&idA, 0, t.p, t.len);
+    t = COL(0x23); delta_init(&idC, t.p, t.len);
+    t = COL(0x34); bool_init(&ins, t.p, t.len);
+    t = COL(0x42); rle_init(&act, 0, t.p, t.len);
+    t = COL(0x56); rle_init(&vlen, 0, t.p, t.len);
+    t = COL(0x80); rle_init(&snum, 0, t.p, t.len);
+    t = COL(0x81); rle_init(&sact, 0, t.p, t.len);
+    t = COL(0x83); delta_init(&sctr, t.p, t.len);
+    span_t rawc = COL(0x57);
+#undef COL
+    dec_t raw = {rawc.p, rawc.len, 0};
+    obj_t *cur_obj = NULL;
+    opid_t cur_objid = {0, 0};
+    int have_obj = 0;
+    elem_t *tail = NULL;     /* last element of the current list object */
+    slot_t *cur_slot = NULL;
+    row_t *last_row = NULL;  /* last row of the current slot / element */
+    while (!rle_done(&act) && !rc) {
+      rval_t vOA, vOC, vKA, vKC, vKS, vIA, vIC, vAct, vLen, vSN;
+      int b;
+      if ((rc = rle_read(&objA, &vOA, &e)) || (rc = rle_read(&objC, &vOC, &e)) || (rc = rle_read(&keyA, &vKA, &e)) ||
+          (rc = delta_read(&keyC, &vKC, &e)) || (rc = rle_read(&keyS, &vKS, &e)) || (rc = rle_read(&idA, &vIA, &e)) ||
+          (rc = delta_read(&idC, &vIC, &e)) || (rc = bool_read(&ins, &b, &e)) || (rc = rle_read(&act, &vAct, &e)) ||
+          (rc = rle_read(&vlen, &vLen, &e)) || (rc = rle_read(&snum, &vSN, &e)))
+        break;
+      if (vIA.is_null || vIC.is_null || vAct.is_null || (uint64_t)vIA.i >= na || vIC.i <= 0) { rc = fail(&e, "unsupported: document row without a valid id"); break; }
+      if (vOA.is_null != vOC.is_null || (!vOA.is_null && (uint64_t)vOA.i >= na)) { rc = fail(&e, "unsupported: bad object reference in document"); break; }
+      opid_t id = {(uint64_t)vIC.i, (uint32_t)vIA.i};
+      opid_t objid = {0, 0};
+      if (!vOC.is_null) { objid.ctr = (uint64_t)vOC.i; objid.actor = (uint32_t)vOA.i; }
+      if (id.ctr >= ((uint64_t)1 << 44)) { rc = fail(&e, "unsupported: op counter too large"); break; }
+      uint64_t tl = vLen.is_null ? 0 : (uint64_t)vLen.i;
+      const uint8_t *val;
+      if ((rc = read_bytes(&raw, tl >> 4, &val, &e))) break;
+      if (!have_obj || objid.ctr != cur_objid.ctr || objid.actor != cur_objid.actor) {
+        /* object order: _root, then ascending (ctr, actorId) */
+        if (have_obj && !(cur_objid.ctr == 0 ? objid.ctr != 0 : cmp_opid(d, cur_objid, objid) < 0)) { rc = fail(&e, "unsupported: document objects not in canonical order"); break; }
+        if (objid.ctr == 0) cur_obj = &d->root;
+        else {
+          void **sl = tab_slot(&d->objs, idkey(objid), 0);
+          if (!sl) { rc = fail(&e, "unsupported: document row for an unknown object"); break; }
+          cur_obj = (obj_t *)*sl;
+        }
+        cur_objid = objid;
+        have_obj = 1;
+        tail = &cur_obj->head;
+        cur_slot = NULL;
+        last_row = NULL;
+      }
+      row_t *r = (row_t *)pool_alloc(&d->pool, sizeof *r);
+      r->id = id; r->insert = (uint8_t)b; r->action = (uint32_t)vAct.i; r->val_tag_len = tl; r->val = val;
+      uint64_t ns = vSN.is_null ? 0 : (uint64_t)vSN.i;
+      if (ns) {
+        r->succ = (opid_t *)pool_alloc(&d->pool, sizeof(opid_t) * ns);
+        r->cap_succ = r->n_succ = (uint32_t)ns;
+        for (uint64_t k = 0; k < ns && !rc; k++) {
+          rval_t sa, sc;
+          if ((rc = rle_read(&sact, &sa, &e)) || (rc = delta_read(&sctr, &sc, &e))) break;
+          if (sa.is_null || sc.is_null || (uint64_t)sa.i >= na) { rc = fail(&e, "unsupported: bad succ entry"); break; }
+          r->succ[k].ctr = (uint64_t)sc.i;
+          r->succ[k].actor = (uint32_t)sa.i;
+          if ((uint64_t)sc.i > d->max_op) d->max_op = (uint64_t)sc.i; /* new.js:1628-1630 */
+        }
+        if (rc) break;
+      }
+      if (id.ctr > d->max_op) d->max_op = id.ctr; /* new.js:1627 */
+      if (!vKS.is_null) {
+        if (is_list_type(cur_obj->type) || b) { rc = fail(&e, "unsupported: string key used in a list object"); break; }
+        if (!cur_slot || cur_slot->key_len != vKS.slen || memcmp(cur_slot->key, vKS.s, vKS.slen) != 0) {
+          if (cur_slot && cmp_utf16(cur_slot->key, cur_slot->key_len, vKS.s, vKS.slen) >= 0) { rc = fail(&e, "unsupported: document keys not in canonical order"); break; }
+          if (find_slot(d, cur_obj, vKS.s, (uint32_t)vKS.slen, 0)) { rc = fail(&e, "unsupported: document keys not in canonical order"); break; }
+          cur_slot = find_slot(d, cur_obj, vKS.s, (uint32_t)vKS.slen, 1);
+          last_row = NULL;
+        }
+        if (last_row && cmp_opid(d, last_row->id, id) >= 0) { rc = fail(&e, "unsupported: document ops not in ascending order"); break; }
+        if (last_row) last_row->next = r; else cur_slot->rows = r;
+        last_row = r;
+      } else {
+        if (!is_list_type(cur_obj->type)) { rc = fail(&e, "unsupported: list operation on a map object"); break; }
+        if (b) {
+          elem_t *el = (elem_t *)pool_alloc(&d->pool, sizeof *el);
+          el->rows = r;
+          tail->next = el;
+          tail = el;
+          cur_obj->n_elems++;
+          index_elem(d, cur_objid, id, el);
+          last_row = r;
+        } else {
+          if (vKC.is_null || vKA.is_null || vKC.i <= 0 || tail == &cur_obj->head || tail->rows->id.ctr != (uint64_t)vKC.i ||
+              tail->rows->id.actor != (uint32_t)vKA.i) { rc = fail(&e, "unsupported: list update does not follow its element"); break; }
+          if (cmp_opid(d, last_row->id, id) >= 0) { rc = fail(&e, "unsupported: document ops not in ascending order"); break; }
+          last_row->next = r;
+          last_row = r;
+        }
+      }
+      d->n_rows++;
+      d->n_ops++;
+      if ((r->action & 1) == 0) {
+        void **sl = tab_slot(&d->objs, idkey(id), 1);
+        if (*sl) { rc = fail(&e, "duplicate operation ID in document"); break; }
+        obj_t *no = (obj_t *)pool_alloc(&d->pool, sizeof *no);
+        no->id = id;
+        no->type = (int)r->action;
+        *sl = no;
+        if (d->n_objs == d->cap_objs) {
+          d->cap_objs = d->cap_objs ? d->cap_objs * 2 : 64;
+          d->obj_list = (obj_t **)realloc(d->obj_list, d->cap_objs * sizeof(obj_t *));
+        }
+        d->obj_list[d->n_objs++] = no;
+      }
+    }
+  } while (0);
+  if (rc) {
+    if (errbuf && errcap) snprintf(errbuf, errcap, "%s", e.msg);
+    amo_free(d);
+    return NULL;
+  }
+  return d;
 }
 
 /* ===================================================================================================

@@ -33,6 +33,10 @@ void amo_sha256(const uint8_t *data, size_t len, uint8_t out[32]);
  */
 amo_doc *amo_replay(const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes, char *err, size_t errcap);
 
+/* Backend.load(document bytes): columnar.js:1006-1038 + new.js:1645-1675, 1695-1750. The patch of the loaded state is
+ * then amo_patch_json(). Returns NULL and fills err when the reference would throw (or "unsupported:" inputs). */
+amo_doc *amo_load_document(const uint8_t *doc, size_t len, char *err, size_t errcap);
+
 /* JSON.stringify(Backend.getPatch(state)) -- new.js:2060-2068, 1604-1635, 884-1040. NUL-terminated,
  * owned by the doc. Returns NULL (and fills err) if the reference would throw while building the patch. */
 const char *amo_patch_json(amo_doc *doc, size_t *len, char *err, size_t errcap);

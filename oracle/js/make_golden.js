@@ -5,6 +5,7 @@
 //   NODE_PATH=oracle/js_shims/node_modules node oracle/js/make_golden.js tests/golden
 //
 // Each fixture: { name, note, changes: [base64...], patch: <JSON.stringify of the stock reference patch>,
+//                 doc: base64 of Backend.save(state), load_patch: JSON.stringify(getPatch(Backend.load(doc))),
 //                 patch_bigblock: <same with REF_BLOCK_SIZE=1e8, see ref_loader.js>, stock_equals_bigblock }.
 // The big-block variant is computed in a child process so both come from pristine module instances.
 const fs = require('fs')
@@ -195,7 +196,7 @@ function handBuilt() {
       { action: 'makeMap', obj: `19@${A}`, key: 'row1', pred: [] },
       { action: 'set', obj: `20@${A}`, key: 'name', value: 'n', pred: [] }] }
     out.hand_conflicts = [c1, c2, c3, c4].map(encodeChange)
-    out.hand_conflicts_pending = [c1, c4, c3].map(encodeChange) // c4 lacks dep c2 -> stays queued
+    out.hand_conflicts_pending = [c1, c4, c3].map(encodeChange) // c4 lacks dep c2 -> stays queued (no document fixture)
     out.hand_conflicts_shuffled = [c4, c3, c2, c1].map(encodeChange)
   }
   { // integer-like map keys and actor ids (JS property enumeration order), unicode keys beyond the BMP
@@ -220,12 +221,23 @@ function refPatch(changes) {
   return JSON.stringify(Backend.getPatch(state))
 }
 
+// Backend.save() of the replayed state, and getPatch() of Backend.load() of those bytes (SURVEY.md §8 row a21)
+function refSaveLoad(changes) {
+  const state = Backend.loadChanges(Backend.init(), changes)
+  const doc = Backend.save(state)
+  const loaded = Backend.load(doc)
+  return { doc, patch: JSON.stringify(Backend.getPatch(loaded)) }
+}
+
 function main() {
   const outDir = process.argv[2]
   if (process.argv[3] === '--child') {
     // child mode: read changes from a fixture, print the patch of the big-block reference
     const fx = JSON.parse(fs.readFileSync(process.argv[4], 'utf8'))
-    process.stdout.write(refPatch(fx.changes.map(c => new Uint8Array(Buffer.from(c, 'base64')))))
+    const chg = fx.changes.map(c => new Uint8Array(Buffer.from(c, 'base64')))
+    const out = { patch: refPatch(chg) }
+    if (fx.doc) out.load_patch = JSON.stringify(Backend.getPatch(Backend.load(new Uint8Array(Buffer.from(fx.doc, 'base64')))))
+    process.stdout.write(JSON.stringify(out))
     return
   }
   fs.mkdirSync(outDir, { recursive: true })
@@ -235,7 +247,7 @@ function main() {
   scenarios.frontend_text_4actors = { changes: textScenario(303, 4, 6, 24), note: 'real frontend, Text typing bursts + deletes, synced rounds (multi-insert ops)' }
   scenarios.frontend_text_8actors = { changes: textScenario(404, 8, 5, 40), note: 'real frontend, 8 actors, crosses 600-op block boundaries' }
   const hb = handBuilt()
-  for (const k of Object.keys(hb)) scenarios[k] = { changes: hb[k], note: 'hand-built changes via reference encodeChange' }
+  for (const k of Object.keys(hb)) scenarios[k] = { changes: hb[k], note: 'hand-built changes via reference encodeChange', noDoc: k.includes('pending') }
   // delivery-order variants
   {
     const rnd = splitmix(7)
@@ -248,14 +260,20 @@ function main() {
   for (const name of Object.keys(scenarios)) {
     const sc = scenarios[name]
     const fx = { name, note: sc.note, changes: sc.changes.map(b64), patch: refPatch(sc.changes) }
+    if (!sc.noDoc) {
+      // the saved document (only when nothing is pending: save() of a state with queued changes drops them)
+      const sl = refSaveLoad(sc.changes)
+      fx.doc = b64(sl.doc)
+      fx.load_patch = sl.patch
+    }
     const file = path.join(outDir, name + '.json')
     fs.writeFileSync(file, JSON.stringify(fx))
-    const big = execFileSync(process.execPath, [__filename, outDir, '--child', file],
-      { env: Object.assign({}, process.env, { REF_BLOCK_SIZE: '100000000' }), maxBuffer: 1 << 30 }).toString()
-    fx.stock_equals_bigblock = (big === fx.patch)
-    if (!fx.stock_equals_bigblock) fx.patch_bigblock = big
+    const big = JSON.parse(execFileSync(process.execPath, [__filename, outDir, '--child', file],
+      { env: Object.assign({}, process.env, { REF_BLOCK_SIZE: '100000000' }), maxBuffer: 1 << 30 }).toString())
+    fx.stock_equals_bigblock = (big.patch === fx.patch) && (!fx.doc || big.load_patch === fx.load_patch)
+    if (!fx.stock_equals_bigblock) { fx.patch_bigblock = big.patch; fx.load_patch_bigblock = big.load_patch }
     fs.writeFileSync(file, JSON.stringify(fx))
-    console.error(`${name}: ${sc.changes.length} changes, patch ${fx.patch.length} B, stock==bigblock: ${fx.stock_equals_bigblock}`)
+    console.error(`${name}: ${sc.changes.length} changes, patch ${fx.patch.length} B, doc ${fx.doc ? Buffer.from(fx.doc, 'base64').length : 0} B, stock==bigblock: ${fx.stock_equals_bigblock}`)
   }
 }
 main()

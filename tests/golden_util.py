@@ -20,4 +20,7 @@ def load_fixture(name):
     fx["log"] = ChangeLog.from_changes(changes, name=name)
     # the patch the engine/oracle must reproduce: the stock reference, unless its block-boundary defect fired
     fx["expected"] = fx["patch"] if fx.get("stock_equals_bigblock", True) else fx["patch_bigblock"]
+    if "doc" in fx:
+        fx["doc_bytes"] = base64.b64decode(fx["doc"])
+        fx["expected_load"] = fx["load_patch"] if fx.get("stock_equals_bigblock", True) else fx["load_patch_bigblock"]
     return fx

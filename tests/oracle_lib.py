@@ -26,6 +26,8 @@ def lib():
         L = ctypes.CDLL(LIB)
         L.amo_replay.restype = ctypes.c_void_p
         L.amo_replay.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+        L.amo_load_document.restype = ctypes.c_void_p
+        L.amo_load_document.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
         L.amo_patch_json.restype = ctypes.c_void_p
         L.amo_patch_json.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.c_size_t]
         L.amo_free.argtypes = [ctypes.c_void_p]
@@ -66,6 +68,17 @@ class OracleDoc:
         self._h = L.amo_replay(self._arena.ctypes.data, self._offsets.ctypes.data, len(self._offsets) - 1, err, 512)
         if not self._h:
             raise OracleError(err.value.decode())
+
+    @classmethod
+    def load_document(cls, doc_bytes: bytes):
+        """Backend.load(bytes) as restated by the oracle."""
+        self = cls.__new__(cls)
+        self._doc = np.frombuffer(doc_bytes, dtype=np.uint8).copy()
+        err = ctypes.create_string_buffer(512)
+        self._h = lib().amo_load_document(self._doc.ctypes.data, self._doc.size, err, 512)
+        if not self._h:
+            raise OracleError(err.value.decode())
+        return self
 
     def patch_json(self) -> str:
         L = lib()
