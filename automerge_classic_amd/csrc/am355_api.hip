@@ -94,6 +94,9 @@ struct am355_ctx {
   std::vector<uint64_t> raw_off;
   uint32_t n_changes = 0;
   bool staged = false, replayed = false, ir_fetched = false;
+  bool is_document = false;          // staged input is one saved document (am355_load_document) rather than changes
+  ChangeMeta doc_meta{};             // column layout of the staged document inside `raw`
+  std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
   DevBuf d_arena, d_offsets, d_metas;
   HostBuf h_metas;
   // stage-1 side tables (device) and their pinned host mirrors
@@ -215,6 +218,7 @@ extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
   c->staged = c->replayed = c->ir_fetched = false;
+  c->is_document = false;
   c->flags = 0;
   c->raw.clear();
   c->raw_off.assign(1, 0);
@@ -266,6 +270,233 @@ extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint
   c->staged = true;
   c->stats = am355_stats{};
   c->stats.n_changes = n;
+  c->stats.raw_bytes = c->raw.size();
+  return AM355_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// document staging (Backend.load): columnar.js:1006-1038 decodeDocumentHeader, 1062-1067 inflateColumn,
+// new.js:1645-1675 readDocumentChanges.  Host work is the container/header parse, the chunk checksum (one SHA-256
+// over the whole chunk is sequential by construction), zlib inflate of the columns and the scan of the change
+// metadata (clock); the op columns go to HBM for the device decode + patch.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct HostSha256 {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+        0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+        0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void digest(const uint8_t* p, size_t len, uint8_t out[32]) {
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) block(p + i);
+    uint8_t tail[128] = {0};
+    size_t rem = len - i, tl = rem < 56 ? 64 : 128;
+    memcpy(tail, p + i, rem);
+    tail[rem] = 0x80;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    block(tail);
+    if (tl == 128) block(tail + 64);
+    for (int k = 0; k < 8; k++) { out[4 * k] = h[k] >> 24; out[4 * k + 1] = h[k] >> 16; out[4 * k + 2] = h[k] >> 8; out[4 * k + 3] = h[k]; }
+  }
+};
+
+// host-side RLE-uint / delta reader for the (small) change-metadata columns
+struct HostRle {
+  const uint8_t* p; size_t len, off = 0; int64_t count = 0; int state = 0; int64_t last = 0; bool last_null = true; bool is_signed;
+  HostRle(const uint8_t* p_, size_t l, bool sg) : p(p_), len(l), is_signed(sg) {}
+  bool done() const { return count == 0 && off >= len; }
+  bool leb(bool sg, int64_t& out) {
+    uint64_t v = 0; int shift = 0;
+    while (off < len && shift < 64) {
+      uint8_t b = p[off++];
+      v |= (uint64_t)(b & 0x7f) << shift; shift += 7;
+      if (!(b & 0x80)) { if (sg && (b & 0x40) && shift < 64) v |= ~0ull << shift; out = (int64_t)v; return true; }
+    }
+    return false;
+  }
+  bool next(bool& is_null, int64_t& v) {
+    if (done()) { is_null = true; v = 0; return true; }
+    if (count == 0) {
+      int64_t n;
+      if (!leb(true, n)) return false;
+      if (n > 1) { if (!leb(is_signed, last)) return false; last_null = false; state = 1; count = n; }
+      else if (n == 1) return false;
+      else if (n < 0) { state = 2; count = -n; }
+      else { int64_t z; if (!leb(false, z) || z <= 0) return false; state = 3; count = z; last_null = true; }
+    }
+    count--;
+    if (state == 2) { if (!leb(is_signed, last)) return false; last_null = false; }
+    is_null = last_null; v = last;
+    return true;
+  }
+};
+}  // namespace
+
+extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len) {
+  if (!c || !doc) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
+  (void)hipSetDevice(c->device);
+  c->staged = c->replayed = c->ir_fetched = false;
+  c->is_document = true;
+  c->flags = 0;
+  auto bad = [&](uint32_t flag, const char* msg) { c->flags |= flag; return fail(c, AM355_E_INVALID, "%s", msg); };
+  if (len < 10 || doc[0] != 0x85 || doc[1] != 0x6f || doc[2] != 0x4a || doc[3] != 0x83) return bad(AM355_F_BAD_MAGIC, "Data does not begin with magic bytes 85 6f 4a 83");
+  size_t off = 9;
+  uint64_t clen;
+  if (!read_uleb_host(doc, len, off, clen) || clen != len - off) return bad(AM355_F_BAD_CHUNK, "Encoded document has trailing data or is truncated");
+  if (doc[8] != 0) return bad(AM355_F_BAD_CHUNK, "Unexpected chunk type");
+  uint8_t digest[32];
+  HostSha256().digest(doc + 8, len - 8, digest);
+  if (memcmp(digest, doc + 4, 4) != 0) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
+  const uint8_t* h = doc + off;
+  size_t hl = (size_t)clen, ho = 0;
+  uint64_t na, nh;
+  if (!read_uleb_host(h, hl, ho, na) || na > hl) return bad(AM355_F_BAD_LEB, "bad document header");
+  c->actors.clear();
+  for (uint64_t i = 0; i < na; i++) {
+    uint64_t l;
+    if (!read_uleb_host(h, hl, ho, l) || l > hl - ho) return bad(AM355_F_BAD_LEB, "bad document header");
+    c->actors.emplace_back((const char*)h + ho, (size_t)l);
+    ho += (size_t)l;
+  }
+  if (!read_uleb_host(h, hl, ho, nh) || nh * 32 > hl - ho) return bad(AM355_F_BAD_LEB, "bad document header");
+  c->heads.assign(h + ho, h + ho + nh * 32);
+  ho += (size_t)nh * 32;
+  struct Col { uint64_t id, len; std::vector<uint8_t> data; const uint8_t* p = nullptr; size_t n = 0; };
+  auto read_dir = [&](std::vector<Col>& cols) -> bool {
+    uint64_t n;
+    if (!read_uleb_host(h, hl, ho, n) || n > hl) return false;
+    int64_t last = -1;
+    for (uint64_t i = 0; i < n; i++) {
+      Col col;
+      if (!read_uleb_host(h, hl, ho, col.id) || !read_uleb_host(h, hl, ho, col.len)) return false;
+      if ((int64_t)(col.id & ~8ull) <= last) return false;  // Columns must be in ascending order (deflate bit ignored)
+      last = (int64_t)(col.id & ~8ull);
+      cols.push_back(std::move(col));
+    }
+    return true;
+  };
+  std::vector<Col> ccols, ocols;
+  if (!read_dir(ccols) || !read_dir(ocols)) return bad(AM355_F_BAD_COLUMNS, "bad column directory");
+  auto read_data = [&](std::vector<Col>& cols) -> int {
+    for (Col& col : cols) {
+      if (col.len > hl - ho) return 1;
+      const uint8_t* p = h + ho;
+      ho += (size_t)col.len;
+      if (col.id & 8) {
+        std::vector<uint8_t> out(std::max<size_t>(col.len * 4, 1024));
+        for (;;) {
+          z_stream zs;
+          memset(&zs, 0, sizeof zs);
+          if (inflateInit2(&zs, -15) != Z_OK) return 2;
+          zs.next_in = (Bytef*)p; zs.avail_in = (uInt)col.len; zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+          int rc = inflate(&zs, Z_FINISH);
+          size_t got = zs.total_out;
+          inflateEnd(&zs);
+          if (rc == Z_STREAM_END) { out.resize(got); break; }
+          if (rc == Z_BUF_ERROR || rc == Z_OK) { out.resize(out.size() * 4); continue; }
+          return 2;
+        }
+        col.data = std::move(out);
+        col.p = col.data.data();
+        col.n = col.data.size();
+        col.id ^= 8;
+      } else {
+        col.p = p;
+        col.n = (size_t)col.len;
+      }
+    }
+    return 0;
+  };
+  int rd = read_data(ccols);
+  if (!rd) rd = read_data(ocols);
+  if (rd == 1) return bad(AM355_F_BAD_CHUNK, "document columns exceed the chunk");
+  if (rd == 2) return bad(AM355_F_BAD_DEFLATE, "invalid deflate data in a document column");
+  // (headsIndexes and extraBytes follow; neither influences the patch)
+
+  // ---- change metadata: clock in first-appearance order, seq continuity (new.js:1645-1675) ----
+  auto find = [](std::vector<Col>& cols, uint64_t id) -> Col* { for (Col& x : cols) if (x.id == id) return &x; return nullptr; };
+  {
+    Col* ca = find(ccols, 0x01);
+    Col* cs = find(ccols, 0x03);
+    HostRle ra(ca ? ca->p : nullptr, ca ? ca->n : 0, false), rs(cs ? cs->p : nullptr, cs ? cs->n : 0, true);
+    std::vector<uint64_t> clock(na, 0);
+    std::vector<uint8_t> seen(na, 0);
+    c->clock_actor.clear();
+    int64_t seq_abs = 0;
+    uint32_t n_changes = 0;
+    while (!ra.done()) {
+      bool an, sn;
+      int64_t a, dv;
+      if (!ra.next(an, a) || !rs.next(sn, dv)) return bad(AM355_F_BAD_RLE, "malformed change metadata columns");
+      if (an || a < 0 || (uint64_t)a >= na) return bad(AM355_F_BAD_ROW, "bad actor index in change metadata");
+      if (!sn) seq_abs += dv;
+      uint64_t seq = sn ? 0 : (uint64_t)seq_abs;
+      if (seq != 1 && seq != clock[a] + 1) { c->flags |= AM355_F_BAD_SEQ; return fail(c, AM355_E_INVALID, "Expected seq %llu, got %llu", (unsigned long long)clock[a] + 1, (unsigned long long)seq); }
+      if (!seen[a]) { seen[a] = 1; c->clock_actor.push_back((uint32_t)a); }  // document actor index for now, ranks below
+      clock[a] = seq;
+      n_changes++;
+    }
+    c->n_changes = n_changes;
+    c->clock_seq.clear();
+    for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
+  }
+  // ---- actor ranks: op-id comparison on the device is numeric on (ctr, rank) ----
+  {
+    std::vector<uint32_t> order(na);
+    for (uint32_t i = 0; i < na; i++) order[i] = i;
+    std::vector<std::string> names = c->actors;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return names[x] < names[y]; });
+    c->doc_actor_rank.assign(na, 0);
+    for (uint32_t r = 0; r < na; r++) { c->doc_actor_rank[order[r]] = r; c->actors[r] = names[order[r]]; }
+    for (uint32_t& a : c->clock_actor) a = c->doc_actor_rank[a];
+  }
+  // ---- op columns -> one arena; layout recorded like a change's column directory ----
+  c->raw.clear();
+  c->raw_off.assign(1, 0);
+  ChangeMeta& m = c->doc_meta;
+  memset(&m, 0, sizeof m);
+  m.n_entries = (uint32_t)na;
+  auto place = [&](int slot, uint64_t id) {
+    Col* col = find(ocols, id);
+    m.col_off[slot] = (uint32_t)c->raw.size();
+    m.col_len[slot] = col ? (uint32_t)col->n : 0;
+    if (col) c->raw.insert(c->raw.end(), col->p, col->p + col->n);
+  };
+  place(C_OBJ_ACTOR, 0x01); place(C_OBJ_CTR, 0x02); place(C_KEY_ACTOR, 0x11); place(C_KEY_CTR, 0x13); place(C_KEY_STR, 0x15);
+  place(C_ID_ACTOR, 0x21); place(C_ID_CTR, 0x23); place(C_INSERT, 0x34); place(C_ACTION, 0x42); place(C_VAL_LEN, 0x56); place(C_VAL_RAW, 0x57);
+  place(C_PRED_NUM, 0x80); place(C_PRED_ACTOR, 0x81); place(C_PRED_CTR, 0x83);
+  c->raw_off.push_back(c->raw.size());
+  if (c->raw.size() >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "document larger than 4 GiB (32-bit arena offsets)");
+  m.len = (uint32_t)c->raw.size();
+  if (!c->d_arena.ensure(c->raw.size() + 64) || !c->d_metas.ensure(sizeof(ChangeMeta)) || !c->h_metas.ensure(sizeof(ChangeMeta)) ||
+      !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(sizeof(Counts)))
+    return fail(c, AM355_E_NOMEM, "device allocation failed");
+  HIPCHK(c, hipMemcpyAsync(c->d_arena.p, c->raw.data(), c->raw.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->staged = true;
+  c->stats = am355_stats{};
+  c->stats.n_changes = c->n_changes;
   c->stats.raw_bytes = c->raw.size();
   return AM355_OK;
 }
@@ -613,16 +844,11 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
 
 // Device buffers for N op rows / P preds, decode, merge, patch IR. `slot_rank` != null: actor tables are the
 // device-interned slots (fast path); null: c->amap holds ranks (general path).
-static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
-  hipStream_t st = c->stream;
+// Device buffers for N op rows / P preds (op rows, merge scratch, sort scratch, patch IR), carved from a few arenas.
+static int setup_buffers(am355_ctx* c) {
   uint32_t N = (uint32_t)c->n_ops, P = (uint32_t)c->n_preds, NA = (uint32_t)c->actors.size();
   int bits_ctr = bits_for64(c->max_op), bits_actor = bits_for64(NA ? NA - 1 : 0), bits_row = bits_for64(N);
   if (1 + bits_row + bits_ctr + bits_actor > 64) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "sort key wider than 64 bits"); }
-  size_t np = c->plans.size();
-  if (!c->d_plans.ensure(sizeof(ChangePlan) * std::max<size_t>(np, 1)) || !c->d_amap.ensure(4 * std::max<size_t>(c->amap.size(), 1)) ||
-      !c->d_spans.ensure(sizeof(ActorSpan) * std::max<size_t>(c->spans.size(), 1)) || !c->d_tab_off.ensure(4 * (size_t)(NA + 1)) ||
-      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)))
-    return fail(c, AM355_E_NOMEM, "device allocation failed");
   size_t Nc = (size_t)N + 1;
   {
     size_t bytes = 13 * carve_size(Nc, 4) + carve_size(Nc, 1);
@@ -675,6 +901,21 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     ir.e_row = carve<uint32_t>(r, Nc); ir.e_elem = carve<uint32_t>(r, Nc); ir.e_index = carve<uint32_t>(r, Nc); ir.e_flags = carve<uint32_t>(r, Nc);
     b.obj_first_pos = b.em_row;  // em_row is dead once the map emissions are ordered (lists run afterwards)
   }
+  return AM355_OK;
+}
+
+// Decode + merge + patch IR for the planned changes. `slot_rank` != null: actor tables are the device-interned slots
+// (fast path); null: c->amap holds ranks (general path).
+static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
+  hipStream_t st = c->stream;
+  size_t np = c->plans.size();
+  uint32_t NA = (uint32_t)c->actors.size();
+  if (!c->d_plans.ensure(sizeof(ChangePlan) * std::max<size_t>(np, 1)) || !c->d_amap.ensure(4 * std::max<size_t>(c->amap.size(), 1)) ||
+      !c->d_spans.ensure(sizeof(ActorSpan) * std::max<size_t>(c->spans.size(), 1)) || !c->d_tab_off.ensure(4 * (size_t)(NA + 1)) ||
+      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)))
+    return fail(c, AM355_E_NOMEM, "device allocation failed");
+  int rcb = setup_buffers(c);
+  if (rcb) return rcb;
   // wave-decodable changes first, the (rare) ones with an over-long column after them
   uint32_t n_wave = 0;
   {
@@ -743,12 +984,75 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   return AM355_OK;
 }
 
+// Backend.load(bytes) + getPatch: device decode of the document's op columns, then the whole-document patch of the
+// (already canonical) rows. new.js:1695-1750, 1604-1635.
+static int replay_document(am355_ctx* c) {
+  auto t_begin = std::chrono::steady_clock::now();
+  hipStream_t st = c->stream;
+  uint32_t NA = (uint32_t)c->actors.size();
+  HIPCHK(c, hipEventRecord(c->ev[0], st));
+  HIPCHK(c, hipMemcpyAsync(c->d_metas.p, &c->doc_meta, sizeof(ChangeMeta), hipMemcpyHostToDevice, st));
+  launch_doc_count(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), st);
+  HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(c->ev[1], st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const ChangeMeta* hm = c->h_metas.as<ChangeMeta>();
+  if (hm->flags) return error_for_flags(c, hm->flags, "malformed document columns");
+  c->n_ops = hm->n_ops;
+  c->n_preds = hm->n_preds;
+  c->n_applied = c->n_changes;
+  c->n_pending = 0;
+  c->max_op = 0xffffffffu >> 8;  // only sizes sort keys, which the document path never builds
+  if (c->n_ops >= 0x7ffffff0ull) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 rows in one document"); }
+  if (!c->d_plans.ensure(sizeof(ChangePlan)) || !c->d_amap.ensure(4 * (size_t)std::max(NA, 1u)) || !c->d_words.ensure(4 * W_NUM) || !c->h_words.ensure(4 * W_NUM))
+    return fail(c, AM355_E_NOMEM, "device allocation failed");
+  int rc = setup_buffers(c);
+  if (rc) return rc;
+  ChangePlan pl{0, 0, 0, 0, NONE32, NA};  // author NONE32 = document mode: ids come from the idActor / idCtr columns
+  HIPCHK(c, hipMemcpyAsync(c->d_plans.p, &pl, sizeof pl, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
+  HIPCHK(c, hipMemsetAsync(c->d_words.p, 0, 4 * W_NUM, st));
+  HIPCHK(c, hipEventRecord(c->ev[2], st));
+  launch_decode_document(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_amap.as<uint32_t>(), c->cols,
+                         &c->d_counts.as<Counts>()->flags, st);
+  HIPCHK(c, hipEventRecord(c->ev[3], st));
+  // maxOp = max over op ids and succ counters (new.js:1627-1630)
+  uint32_t* d_max = c->d_words.as<uint32_t>();
+  max_u32(c->cols.id_ctr, (uint32_t)c->n_ops, d_max, st);
+  max_u32(c->cols.pred_ctr, (uint32_t)c->n_preds, d_max, st);
+  HIPCHK(c, hipMemcpyAsync(c->h_words.p, d_max, 4, hipMemcpyDeviceToHost, st));
+  Counts* hc = c->h_counts.as<Counts>();
+  doc_patch(c->mb, c->ir, hc, st);
+  HIPCHK(c, hipEventRecord(c->ev[4], st));
+  HIPCHK(c, hipEventRecord(c->ev[5], st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (hc->flags) return error_for_flags(c, hc->flags, "document rejected");
+  c->max_op = c->h_words.as<uint32_t>()[0];
+  c->counts = *hc;
+  c->counts.n_objects += 1;  // + _root
+  auto t_end = std::chrono::steady_clock::now();
+  am355_stats& s = c->stats;
+  s.n_changes = c->n_changes; s.n_applied = c->n_changes; s.n_pending = 0; s.n_actors = NA; s.n_objects = c->counts.n_objects;
+  s.n_heads = (uint32_t)(c->heads.size() / 32); s.n_ops = c->n_ops; s.max_op = c->max_op; s.raw_bytes = c->raw.size();
+  s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
+  s.ir_bytes = (uint64_t)c->counts.n_objects * 20 + (uint64_t)c->counts.n_map_emit * 16 + (uint64_t)c->counts.n_edits * 16;
+  (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&s.ms_merge, c->ev[3], c->ev[4]);
+  s.ms_order = 0; s.ms_hash_stream = 0; s.ms_host_schedule = 0; s.fast_path = 1;
+  s.ms_total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
+  c->replayed = true;
+  return AM355_OK;
+}
+
 extern "C" int am355_replay(am355_ctx* c) {
   if (!c) return AM355_E_ARG;
   if (!c->staged) return fail(c, AM355_E_STATE, "am355_load_changes must be called first");
   (void)hipSetDevice(c->device);
   c->replayed = c->ir_fetched = false;
   c->flags = 0;
+  if (c->is_document) return replay_document(c);
   auto t_begin = std::chrono::steady_clock::now();
   hipStream_t sa = c->stream, sb = c->stream2;
   uint32_t n = c->n_changes;
@@ -892,7 +1196,7 @@ extern "C" int am355_get_stats(const am355_ctx* c, am355_stats* out) {
 
 extern "C" int am355_get_hashes(const am355_ctx* c, uint8_t* out) {
   if (!c || !out) return AM355_E_ARG;
-  if (!c->replayed || !c->h_hashes.p) return AM355_E_STATE;
+  if (!c->replayed || !c->h_hashes.p || c->is_document) return AM355_E_STATE;  // a document stores no per-change hashes
   memcpy(out, c->h_hashes.p, 32 * (size_t)c->n_changes);
   return AM355_OK;
 }

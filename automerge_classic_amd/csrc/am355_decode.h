@@ -16,5 +16,9 @@ uint32_t distinct_capacity();
 // slot_rank == nullptr: `amap` already holds global actor ranks. plans = [n_wave wave-decodable | n_serial others]
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_wave, uint32_t n_serial,
                            const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st);
-bool decode_fits_wave(const ChangeMeta& m);  // host: can this change use the wave-per-change decoder?
+bool decode_fits_wave(const ChangeMeta& m);
+// documents: count rows / succ entries into meta->n_ops / n_preds, then decode all op columns of the one pseudo-change
+void launch_doc_count(const uint8_t* arena, ChangeMeta* meta, hipStream_t st);
+void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const ChangePlan* plan, const uint32_t* actor_rank, OpCols cols,
+                            uint32_t* flags, hipStream_t st);  // host: can this change use the wave-per-change decoder?
 }  // namespace am355

@@ -742,7 +742,7 @@ __device__ __forceinline__ bool bool_next(BoolDec& b, bool& v) {
 // ---------------------------------------------------------------------------------------------------------
 // k_decode_columns: grid.y selects the column group (uniform per wave), one lane per applied change.
 // ---------------------------------------------------------------------------------------------------------
-enum Task { T_OBJ, T_KEY, T_KEYSTR, T_INSERT, T_ACTION, T_VALUE, T_PREDNUM, T_PREDS, T_NUM };
+enum Task { T_OBJ, T_KEY, T_KEYSTR, T_INSERT, T_ACTION, T_VALUE, T_PREDNUM, T_PREDS, T_NUM, T_ID = T_NUM, T_NUM_DOC };  // T_ID: documents only
 
 // change-local actor index -> global actor rank. `amap` holds either final ranks (slot_rank == nullptr: table built by
 // the host scheduler) or device actor-table slots that `slot_rank` maps to ranks.
@@ -827,9 +827,26 @@ __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restri
       if (v.is_null) err |= F_UNSUPPORTED;
       if ((uint64_t)v.i >= NONE32) err |= F_OVERFLOW;
       o.action[base + i] = (uint32_t)v.i;
-      // ops carry no id columns in a change: op i is (startOp + i, author)  (new.js:708-709)
-      o.id_ctr[base + i] = (uint32_t)m->start_op + i;
-      o.id_actor[base + i] = pl.author;
+      if (pl.author != NONE32) {
+        // ops carry no id columns in a change: op i is (startOp + i, author)  (new.js:708-709)
+        o.id_ctr[base + i] = (uint32_t)m->start_op + i;
+        o.id_actor[base + i] = pl.author;
+      }
+    }
+  } else if (task == T_ID) {
+    // documents store the op ids explicitly (idActor / idCtr columns, columnar.js:62-63)
+    Rle a;
+    Delta c;
+    rle_init(a, p + m->col_off[C_ID_ACTOR], m->col_len[C_ID_ACTOR]);
+    rle_init(c.r, p + m->col_off[C_ID_CTR], m->col_len[C_ID_CTR]);
+    c.abs = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      RVal va, vc;
+      if (!rle_next<RT_UINT>(a, va) || !delta_next(c, vc)) { err |= F_BAD_RLE; break; }
+      if (va.is_null || vc.is_null || vc.i <= 0) err |= F_BAD_ROW;
+      if (!vc.is_null && (vc.i < 0 || (uint64_t)vc.i >= NONE32)) err |= F_OVERFLOW;
+      o.id_actor[base + i] = va.is_null ? 0 : xlate_actor(amap, pl, va.i, err);
+      o.id_ctr[base + i] = vc.is_null ? 0 : (uint32_t)vc.i;
     }
   } else if (task == T_VALUE) {
     Rle l;
@@ -1423,6 +1440,29 @@ void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, co
 }
 
 uint32_t distinct_capacity() { return DISTINCT_CAP; }
+
+// rows and succ entries of a document's op columns (lane 0: values in `action`; lane 1: sum of `succNum`)
+__global__ __launch_bounds__(WAVE) void k_doc_count(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ meta) {
+  uint32_t lane = threadIdx.x;
+  if (lane > 1) return;
+  int slot = lane == 0 ? C_ACTION : C_PRED_NUM;
+  uint64_t cnt, sum;
+  bool ok = rle_count_sum(arena + meta->base + meta->col_off[slot], meta->col_len[slot], cnt, sum);
+  if (!ok) { atomicOr(&meta->flags, (uint32_t)F_BAD_RLE); return; }
+  if (lane == 0) meta->n_ops = (uint32_t)cnt; else meta->n_preds = (uint32_t)sum;
+}
+
+void launch_doc_count(const uint8_t* arena, ChangeMeta* meta, hipStream_t st) {
+  AM355_LAUNCH_INDEPENDENT(k_doc_count, dim3(1), dim3(WAVE), st, arena, meta);
+}
+
+// Document op columns -> rows. First version: the lane-serial column decoders, one lane per column group (document
+// columns run to megabytes, far beyond the wave decoder's LDS staging; a parallel big-column decoder is the next step).
+void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const ChangePlan* plan, const uint32_t* actor_rank, OpCols cols,
+                            uint32_t* flags, hipStream_t st) {
+  ActorXlate x{actor_rank, nullptr};
+  AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3(1, T_NUM_DOC), dim3(WAVE), st, arena, meta, plan, 1u, x, cols, flags, 0);
+}
 
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_wave, uint32_t n_serial,
                            const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st) {

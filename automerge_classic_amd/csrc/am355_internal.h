@@ -5,7 +5,10 @@
 namespace am355 {
 
 // column slots of a change (reference: backend/columnar.js:56-78 CHANGE_COLUMNS)
-enum ColSlot { C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_KEY_STR, C_INSERT, C_ACTION, C_VAL_LEN, C_VAL_RAW, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR, C_NUM };
+// (a saved document stores the same columns plus the op ids, and succ lists instead of pred lists -- columnar.js:80-84;
+//  when a document is decoded the three C_PRED_* slots hold its succNum / succActor / succCtr columns)
+enum ColSlot { C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_KEY_STR, C_INSERT, C_ACTION, C_VAL_LEN, C_VAL_RAW, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR,
+               C_ID_ACTOR, C_ID_CTR, C_NUM };
 
 // One record per binary change, written by k_parse_changes (device) and read by the host scheduler.
 // Offsets are relative to `base` (the change's first byte in the raw arena).

@@ -78,4 +78,8 @@ void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st);
 // than a few hundred children; phase 2 reports that in h_counts->pad and the caller reruns it with force_radix).
 void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, bool force_radix);
 
+// Document load: whole-document patch of rows already in canonical order (pred_* arrays = succ lists). `b.counts` must be
+// cleared by the caller before the decode kernels run.
+void doc_patch(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st);
+
 }  // namespace am355

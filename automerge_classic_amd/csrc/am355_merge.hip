@@ -554,6 +554,166 @@ __global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Document load (Backend.load): whole-document patch of rows that are ALREADY in canonical order with their succ
+// lists (a saved document: columnar.js:892, new.js:2047).  No sorting or list ranking is needed -- object groups,
+// map keys and list elements are contiguous in row order -- so the patch is element-wise work plus prefix sums.
+// Reference: new.js:1604-1635 documentPatch, 884-1040 updatePatchProperty.  Rows come from k_decode_columns in
+// document mode (pred_* arrays hold the succ lists).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t doc_hash_slot(unsigned long long key, uint32_t mask) { return (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 40) & mask; }
+
+// per row: kind, succ count, list-insert flag, make flag; make rows enter the id -> row table
+__global__ __launch_bounds__(BLOCK) void k_doc_prepare(MergeBufs b, unsigned long long* __restrict__ tab_key, uint32_t* __restrict__ tab_row, uint32_t mask) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const OpCols& o = b.ops;
+  uint32_t a = o.action[g], err = 0;
+  bool has_str = o.key_len[g] != NONE32, has_elem = o.key_ctr[g] != NONE32, ins = o.insert[g] != 0;
+  uint8_t kind = K_NONE;
+  if (has_str == has_elem) err |= has_str ? F_UNSUPPORTED : F_BAD_ROW;
+  else if (has_str) { kind = K_MAP; if (ins) err |= F_UNSUPPORTED; }
+  else kind = ins ? K_LIST_INS : K_LIST_UPD;
+  if (a == 3) err |= F_UNSUPPORTED;  // a `del` row only exists in documents written from the empty-pred corner case
+  if (kind != K_MAP && a == 5) err |= F_UNSUPPORTED;  // counters inside lists (reference quirk)
+  b.kind[g] = kind;
+  b.succ_cnt[g] = o.pred_num[g];
+  b.scan_b[g] = kind == K_LIST_INS ? 1u : 0u;
+  bool is_make = kind != K_NONE && (a & 1) == 0;
+  b.obj_index[g] = is_make ? 1u : 0u;
+  if (is_make) {
+    unsigned long long key = pack_id(o.id_ctr[g], o.id_actor[g]);
+    uint32_t i = doc_hash_slot(key, mask);
+    for (uint32_t probes = 0; probes <= mask; probes++) {
+      unsigned long long old = atomicCAS(&tab_key[i], 0ull, key);
+      if (old == 0) { tab_row[i] = g; break; }
+      if (old == key) { err |= F_DUP_OPID; break; }
+      i = (i + 1) & mask;
+    }
+  }
+  if (err) atomicOr(&b.counts->flags, err);
+}
+
+__device__ __forceinline__ uint32_t doc_find_make(const unsigned long long* __restrict__ tab_key, const uint32_t* __restrict__ tab_row, uint32_t mask,
+                                                  unsigned long long key) {
+  uint32_t i = doc_hash_slot(key, mask);
+  for (uint32_t probes = 0; probes <= mask; probes++) {
+    unsigned long long k = tab_key[i];
+    if (k == 0) return NONE32;
+    if (k == key) return tab_row[i];
+    i = (i + 1) & mask;
+  }
+  return NONE32;
+}
+
+// per row: object (make row) lookup, element of a list update, counter bookkeeping, first row of every object group
+__global__ __launch_bounds__(BLOCK) void k_doc_resolve(MergeBufs b, const unsigned long long* __restrict__ tab_key, const uint32_t* __restrict__ tab_row,
+                                                       uint32_t mask, const uint32_t* __restrict__ ins_ex, uint32_t* __restrict__ obj_first) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const OpCols& o = b.ops;
+  uint32_t err = 0;
+  uint8_t kind = b.kind[g];
+  uint32_t orow = NONE32;
+  bool list_obj = false;
+  if (o.obj_actor[g] != NONE32) {
+    orow = doc_find_make(tab_key, tab_row, mask, pack_id(o.obj_ctr[g], o.obj_actor[g]));
+    if (orow == NONE32) err |= F_UNKNOWN_OBJECT;
+    else { uint32_t oa = o.action[orow]; list_obj = oa == 2 || oa == 4; }
+  }
+  if (kind == K_MAP && list_obj) err |= F_UNSUPPORTED;
+  if ((kind == K_LIST_INS || kind == K_LIST_UPD) && !list_obj) err |= F_UNSUPPORTED;
+  b.obj_row[g] = orow;
+  bool new_obj = g == 0 || o.obj_actor[g - 1] != o.obj_actor[g] || o.obj_ctr[g - 1] != o.obj_ctr[g];
+  if (new_obj && !(err & F_UNKNOWN_OBJECT)) {
+    uint32_t oi = obj_index_of(b, orow);
+    if (atomicCAS(&obj_first[oi], NONE32, g) != NONE32) err |= F_UNSUPPORTED;  // the rows of one object must be contiguous
+  }
+  uint32_t ref = NONE32;
+  if (kind == K_LIST_UPD) {
+    uint32_t before = ins_ex[g];  // list-insert rows before g: the update belongs to the latest one
+    ref = before ? b.ins_row[before - 1] : NONE32;
+    if (ref == NONE32 || o.id_actor[ref] != o.key_actor[g] || o.id_ctr[ref] != o.key_ctr[g] || !same_obj(b, ref, g)) { err |= F_BAD_ELEM; ref = NONE32; }
+  }
+  b.ref_row[g] = ref;
+  if (kind == K_MAP && o.action[g] == 5) {
+    // inc: the counter it feeds is the latest preceding `set` of a counter, on the same key, that lists this op as a
+    // successor (counterStates[succOp] = counterState, later assignment wins: new.js:944-950)
+    uint32_t my_a = o.id_actor[g], my_c = o.id_ctr[g];
+    uint32_t owner = NONE32;
+    for (uint32_t r = g; r-- > 0 && owner == NONE32;) {
+      if (!same_obj(b, r, g) || !same_key(b, r, g)) break;
+      if (o.action[r] == 1 && (o.val_tl[r] & 15) == 8) {
+        uint32_t f = o.pred_first[r], n = o.pred_num[r];
+        for (uint32_t k = 0; k < n; k++)
+          if (o.pred_actor[f + k] == my_a && o.pred_ctr[f + k] == my_c) owner = r;
+      }
+    }
+    long long v;
+    if (owner == NONE32) err |= F_BAD_COUNTER;  // increment operation for unknown counter (new.js:954-956)
+    else if (!int_value(b, g, v)) err |= F_UNSUPPORTED;
+    else {
+      atomicAdd(&b.inc_cnt[owner], 1u);
+      atomicAdd(&b.inc_sum[owner], (unsigned long long)v);
+      atomicMax(&b.last_inc[owner], (unsigned long long)g);  // row order within a key is op-id order
+    }
+  }
+  if (err) atomicOr(&b.counts->flags, err);
+}
+
+// per row: which rows trigger a map emission / produce a list edit; value counts per list element
+__global__ __launch_bounds__(BLOCK) void k_doc_emit(MergeBufs b, uint32_t* __restrict__ trig_flag, uint32_t* __restrict__ trig_src, uint32_t* __restrict__ edit_flag) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const OpCols& o = b.ops;
+  uint8_t kind = b.kind[g];
+  uint32_t a = o.action[g];
+  bool vis = b.succ_cnt[g] == 0;
+  bool valued = a == 1 || (a & 1) == 0;
+  edit_flag[g] = 0;
+  if (kind == K_MAP) {
+    if (vis && valued) { trig_flag[g] = 1; trig_src[g] = g; }
+    else if (a == 1 && (o.val_tl[g] & 15) == 8 && b.succ_cnt[g] != 0 && b.inc_cnt[g] == b.succ_cnt[g]) {
+      uint32_t t = (uint32_t)b.last_inc[g];  // the row of the last increment completes the counter
+      trig_flag[t] = 1;
+      trig_src[t] = g;
+    }
+  } else if (kind == K_LIST_INS || kind == K_LIST_UPD) {
+    if (vis && !valued) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);  // reference 'remove' quirk
+    if (vis && valued) {
+      uint32_t el = kind == K_LIST_INS ? g : b.ref_row[g];
+      if (el != NONE32) { edit_flag[g] = 1; atomicAdd(&b.val_cnt[el], 1u); }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_doc_visflag(MergeBufs b, uint32_t* __restrict__ flag) {
+  uint32_t g = gtid();
+  if (g < b.n_ops) flag[g] = (b.kind[g] == K_LIST_INS && b.val_cnt[g] > 0) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_doc_scatter(MergeBufs b, const uint32_t* __restrict__ trig_flag, const uint32_t* __restrict__ trig_src,
+                                                       const uint32_t* __restrict__ em_pos, const uint32_t* __restrict__ edit_flag,
+                                                       const uint32_t* __restrict__ ed_pos, const uint32_t* __restrict__ idx_ex,
+                                                       const uint32_t* __restrict__ obj_first, uint32_t* __restrict__ perm, PatchIR ir) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  if (trig_flag[g]) {
+    uint32_t i = em_pos[g];
+    b.em_row[i] = trig_src[g];
+    perm[i] = i;
+  }
+  if (edit_flag[g]) {
+    uint32_t e = ed_pos[g];
+    uint32_t el = b.kind[g] == K_LIST_INS ? g : b.ref_row[g];
+    uint32_t first_row = obj_first[obj_index_of(b, b.obj_row[g])];
+    ir.e_row[e] = g;
+    ir.e_elem[e] = el;
+    ir.e_index[e] = idx_ex[el] - idx_ex[first_row];
+    ir.e_flags[e] = (ed_pos[g] != ed_pos[el] ? 1u : 0u) | ((b.ops.action[g] & 1) == 0 ? 4u : 0u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
@@ -670,6 +830,56 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
     AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis, (const uint32_t*)cnt, uk, uv, nu, ir);
     AM355_LAUNCH_INDEPENDENT(k_edit_runs, grid_for(N), dim3(BLOCK), st, b, ir);
   }
+  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+}
+
+// Whole-document patch of canonical rows (document load). Synchronises the stream twice (counts).
+void doc_patch(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
+  uint32_t N = b.n_ops;
+  uint32_t cap = 1;  // id -> make-row table lives in the Euler scratch (2N+4 slots): largest power of two that fits
+  while ((uint64_t)cap * 2 <= 2ull * N + 4) cap *= 2;
+  uint32_t mask = cap - 1;
+  unsigned long long* tab_key = b.euler_a;
+  uint32_t* tab_row = b.first_child;
+  uint32_t* obj_first = (uint32_t*)b.key_b;     // [N+1]
+  uint32_t* trig_flag = b.order;
+  uint32_t* trig_src = b.upd_row;
+  uint32_t* edit_flag = b.next_sib;
+  uint32_t* idx_ex = (uint32_t*)b.euler_b;      // [N+1]
+  uint32_t* perm = b.val_a;
+  (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, st);
+  (void)hipMemsetAsync(tab_key, 0, sizeof(unsigned long long) * ((size_t)mask + 1), st);
+  (void)hipMemsetAsync(obj_first, 0xff, sizeof(uint32_t) * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(trig_flag, 0, sizeof(uint32_t) * ((size_t)N + 1), st);
+  if (N) {
+    AM355_LAUNCH_INDEPENDENT(k_doc_prepare, grid_for(N), dim3(BLOCK), st, b, tab_key, tab_row, mask);
+    exclusive_scan_u32(b.obj_index, b.scan_a, N, &b.counts->n_objects, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_object_table, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_a, ir);
+    exclusive_scan_u32(b.scan_b, b.scan_a, N, &b.counts->n_list_ins, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_ins_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_b, (const uint32_t*)b.scan_a);
+    AM355_LAUNCH_INDEPENDENT(k_doc_resolve, grid_for(N), dim3(BLOCK), st, b, (const unsigned long long*)tab_key, (const uint32_t*)tab_row, mask,
+                             (const uint32_t*)b.scan_a, obj_first);
+    AM355_LAUNCH_INDEPENDENT(k_doc_emit, grid_for(N), dim3(BLOCK), st, b, trig_flag, trig_src, edit_flag);
+    exclusive_scan_u32(trig_flag, b.scan_a, N, &b.counts->n_map_emit, b.scan_ws, st);
+    exclusive_scan_u32(edit_flag, b.scan_b, N, &b.counts->n_edits, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_doc_visflag, grid_for(N), dim3(BLOCK), st, b, b.ins_row);
+    exclusive_scan_u32(b.ins_row, idx_ex, N, nullptr, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_doc_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)trig_flag, (const uint32_t*)trig_src,
+                             (const uint32_t*)b.scan_a, (const uint32_t*)edit_flag, (const uint32_t*)b.scan_b, (const uint32_t*)idx_ex,
+                             (const uint32_t*)obj_first, perm, ir);
+  } else {
+    (void)hipMemsetAsync(ir.obj_make_row, 0xff, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_map_end, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_edit_begin, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj_edit_end, 0, sizeof(uint32_t), st);
+  }
+  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  if (hc->flags || !N) return;
+  if (hc->n_map_emit) AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(hc->n_map_emit), dim3(BLOCK), st, b, (const uint32_t*)perm, hc->n_map_emit, ir);
+  if (hc->n_edits) AM355_LAUNCH_INDEPENDENT(k_edit_runs, grid_for(hc->n_edits), dim3(BLOCK), st, b, ir);
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
 }

@@ -7,6 +7,8 @@ namespace am355 {
 size_t scan_workspace_bytes(uint32_t n);
 // out[i] = sum(in[0..i)); in == out allowed. *d_total (device, optional) receives the grand total.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total, void* ws, hipStream_t st);
+// *d_out = max(*d_out, max(v[0..n)))
+void max_u32(const uint32_t* v, uint32_t n, uint32_t* d_out, hipStream_t st);
 size_t sort_workspace_bytes(uint32_t n);
 int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n, int begin_bit, int end_bit,
                      void* ws, hipStream_t st);

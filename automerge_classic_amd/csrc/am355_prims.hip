@@ -168,6 +168,25 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(const uint64_t* __restri
   }
 }
 
+// maximum of a uint32 array into *out (which the caller zeroes): block reduction in LDS, one global atomic per workgroup
+__global__ __launch_bounds__(BLOCK) void k_max_u32(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t smax;
+  if (threadIdx.x == 0) smax = 0;
+  __syncthreads();
+  uint32_t m = 0;
+  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) m = v[i] > m ? v[i] : m;
+  atomicMax(&smax, m);
+  __syncthreads();
+  if (threadIdx.x == 0 && smax) atomicMax(out, smax);
+}
+
+void max_u32(const uint32_t* v, uint32_t n, uint32_t* d_out, hipStream_t st) {
+  if (!n) return;
+  uint32_t blocks = (n + BLOCK - 1) / BLOCK;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_max_u32, dim3(blocks), dim3(BLOCK), 0, st, v, n, d_out);
+}
+
 size_t sort_workspace_bytes(uint32_t n) {
   uint32_t n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
   size_t table = (size_t)RADIX * n_tiles;

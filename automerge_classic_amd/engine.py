@@ -69,6 +69,7 @@ def _bind(path):
     L.am355_flags.restype = u32
     L.am355_flags.argtypes = [vp]
     L.am355_load_changes.argtypes = [vp, vp, u64p, u32]
+    L.am355_load_document.argtypes = [vp, vp, ctypes.c_size_t]
     L.am355_replay.argtypes = [vp]
     L.am355_patch_json.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
     L.am355_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
@@ -76,7 +77,7 @@ def _bind(path):
     L.am355_test_sort.argtypes = [vp, vp, vp, u32, ctypes.c_int]
     L.am355_test_scan.argtypes = [vp, vp, vp, u32, vp]
     L.am355_get_rows.argtypes = [vp] * 15
-    for f in ("am355_load_changes", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
+    for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows"):
         getattr(L, f).restype = ctypes.c_int
     return L
@@ -127,6 +128,12 @@ class Engine:
         offsets = np.ascontiguousarray(log.offsets, dtype=np.uint64)
         self._n_changes = int(offsets.size - 1)
         self._check(self._L.am355_load_changes(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, self._n_changes))
+
+    def load_document(self, doc: bytes):
+        """Stage one saved document (Backend.save bytes): host header parse / checksum / inflate, op columns to HBM."""
+        buf = np.frombuffer(bytes(doc), dtype=np.uint8)
+        self._n_changes = 0
+        self._check(self._L.am355_load_document(self._h, buf.ctypes.data, buf.size))
 
     def replay(self):
         """The hot path: decode + schedule + merge + patch IR, device-resident in and out."""

@@ -38,11 +38,12 @@ const AM355_E_INVALID = -3, AM355_E_UNSUPPORTED = -4
 // A state built on the GPU. `changes` are retained (by reference, like BackendDoc.changes new.js:1847) so that a
 // JS BackendDoc can be hydrated later; `patch` is the whole-document patch computed by the engine.
 class GpuState {
-  constructor(changes, patch, heads) {
-    this.changes = changes
+  constructor(changes, patch, heads, doc) {
+    this.changes = changes   // retained change buffers (loadChanges), or null
+    this.doc = doc || null   // retained document bytes (load), or null
     this.patch = patch
     this.heads = heads
-    this.js = null   // hydrated reference backend handle
+    this.js = null           // hydrated reference backend handle
   }
 }
 
@@ -67,7 +68,7 @@ function toJs(backend) {
   isFrozenCheck(backend)
   if (!(backend.state instanceof GpuState)) return backend
   const g = backend.state
-  if (!g.js) g.js = ref().loadChanges(ref().init(), g.changes)
+  if (!g.js) g.js = g.doc ? ref().load(g.doc) : ref().loadChanges(ref().init(), g.changes)
   const handle = g.js
   g.js = null          // the JS handle is single-use (functional API over a mutable state)
   backend.frozen = true
@@ -112,7 +113,19 @@ function getHeads(backend) {
 }
 
 function load(data) {
-  return ref().load(data)   // document-format load: "next" row of the scope table (SURVEY.md §8f)
+  // Backend.load(bytes) (backend.js:104-107, new.js:1695-1750): header / checksum / inflate on the host, op-column decode and
+  // whole-document patch on the GPU
+  if (!JS_ONLY && data instanceof Uint8Array) {
+    try {
+      addon.loadDocument(ctx, data)
+      addon.replay(ctx)
+      const patch = JSON.parse(addon.patchJSON(ctx))
+      return { state: new GpuState(null, patch, patch.deps, data), heads: patch.deps }
+    } catch (e) {
+      if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
+    }
+  }
+  return ref().load(data)
 }
 
 function free(backend) {

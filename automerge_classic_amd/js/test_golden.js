@@ -20,6 +20,13 @@ for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
   if (got !== expected) { failed++; console.error(`FAIL ${f}`) } else console.log(`ok   ${f}  (${changes.length} changes)`)
   if (!empty.frozen) { failed++; console.error(`FAIL ${f}: old handle not frozen`) }
   if (JSON.stringify(Backend.getHeads(state)) !== JSON.stringify(JSON.parse(expected).deps)) { failed++; console.error(`FAIL ${f}: heads`) }
+  if (fx.doc) {
+    // Backend.load(Backend.save(state)) + getPatch
+    const want = fx.stock_equals_bigblock === false ? fx.load_patch_bigblock : fx.load_patch
+    const loaded = Backend.load(new Uint8Array(Buffer.from(fx.doc, 'base64')))
+    n++
+    if (JSON.stringify(Backend.getPatch(loaded)) !== want) { failed++; console.error(`FAIL ${f}: document load`) } else console.log(`ok   ${f}  (document load)`)
+  }
 }
 console.log(`${n - failed}/${n} golden fixtures reproduced through the JS Backend surface; engine: ${JSON.stringify(Backend._engineStats())}`)
 process.exit(failed ? 1 : 0)

@@ -61,6 +61,15 @@ uint32_t am355_flags(const am355_ctx *ctx);
 int am355_load_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes);
 
 /*
+ * Stage one saved document (chunk type 0, as written by Backend.save / Automerge.save): container + header parse, chunk
+ * checksum, zlib inflate of DEFLATEd columns and the change-metadata scan (clock) on the host, op columns to HBM.
+ * Replaces decodeDocumentHeader + readDocumentChanges of `new BackendDoc(buffer)` (columnar.js:1006-1038, new.js:1645-1675,
+ * 1695-1750).  am355_replay then decodes the op columns and builds the whole-document patch on the device, so
+ * am355_load_document + am355_replay + am355_patch_json == JSON.stringify(Backend.getPatch(Backend.load(bytes))).
+ */
+int am355_load_document(am355_ctx *ctx, const uint8_t *doc, size_t len);
+
+/*
  * The hot path, device-resident in and out: container parse + SHA-256 + column decode, causal scheduling
  * (host, between two device phases), op-set merge, RGA ordering, whole-document patch IR.  Equivalent to
  * Backend.loadChanges(Backend.init(), changes) + the work of Backend.getPatch().  Blocking.

@@ -40,6 +40,22 @@ def test_golden_reference_patches(eng, name):
     assert eng.stats().fast_path == (0 if general else 1)
 
 
+@pytest.mark.parametrize("name", golden_util.fixture_names())
+def test_document_load_matches_reference(eng, name):
+    """Backend.load(bytes) + getPatch against the unmodified reference's save()/load()."""
+    fx = golden_util.load_fixture(name)
+    if "doc_bytes" not in fx:
+        pytest.skip("no document fixture")
+    eng.load_document(fx["doc_bytes"])
+    eng.replay()
+    assert eng.patch_json() == fx["expected_load"]
+    # a corrupted byte must be caught by the chunk checksum
+    bad = bytearray(fx["doc_bytes"])
+    bad[len(bad) // 2] ^= 0x40
+    with pytest.raises(engine.InvalidChanges):
+        eng.load_document(bytes(bad))
+
+
 @pytest.mark.parametrize("kind,kw", [
     (loggen.KIND_TEXT_TYPING, dict(n_ops=1500, ops_per_change=40)),
     (loggen.KIND_TEXT_TYPING, dict(n_ops=300, ops_per_change=1)),

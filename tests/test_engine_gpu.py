@@ -32,6 +32,18 @@ def test_golden_reference_patches(eng, name):
     assert gpu_patch(eng, fx["log"]) == fx["expected"]
 
 
+@pytest.mark.parametrize("name", golden_util.fixture_names())
+def test_document_load_matches_reference(eng, name):
+    """Backend.load(bytes) + getPatch against the unmodified reference's save()/load()."""
+    fx = golden_util.load_fixture(name)
+    if "doc_bytes" not in fx:
+        pytest.skip("no document fixture")
+    eng.load_document(fx["doc_bytes"])
+    eng.replay()
+    assert eng.patch_json() == fx["expected_load"]
+    assert oracle_lib.OracleDoc.load_document(fx["doc_bytes"]).patch_json() == fx["expected_load"]
+
+
 def test_device_primitives(eng):
     rng = np.random.default_rng(7)
     for n in (1, 63, 2048, 2049, 100_003, 1_500_000):
