@@ -128,6 +128,8 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
   if (a == 3 && o.pred_num[g] == 0) err |= F_UNSUPPORTED;
 
   uint32_t np = o.pred_num[g], pf = o.pred_first[g];
+  uint32_t counter_row = NONE32;
+  unsigned long long counter_id = 0;
   for (uint32_t j = 0; j < np && !(err & (F_BAD_PRED | F_BAD_ROW)); j++) {
     uint32_t pa = o.pred_actor[pf + j], pc = o.pred_ctr[pf + j];
     for (uint32_t k = 0; k < j; k++)
@@ -138,20 +140,23 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
     if (!same_slot) { err |= F_BAD_PRED; continue; }
     if (pack_id(pc, pa) >= my_id) err |= F_UNSUPPORTED;
     atomicAdd(&b.succ_cnt[pr], 1u);
-    if (a == 5) {
-      // inc: its pred must be the counter's `set` op (new.js:937-967)
-      uint32_t ptl = o.val_tl[pr];
-      long long v;
-      if (o.action[pr] != 1 || (ptl & 15) != 8) err |= F_BAD_COUNTER;
-      else if (np != 1 || !int_value(b, g, v)) err |= F_UNSUPPORTED;
-      else {
-        atomicAdd(&b.inc_cnt[pr], 1u);
-        atomicAdd(&b.inc_sum[pr], (unsigned long long)v);
-        atomicMax(&b.last_inc[pr], my_id);
-      }
+    if (a == 5 && o.action[pr] == 1 && (o.val_tl[pr] & 15) == 8) {
+      // inc: it feeds the counter `set` among its preds; with several (conflicting counters) the one with the greatest
+      // op id takes it -- counterStates[succOp] is overwritten by each later counter row (new.js:944-950)
+      unsigned long long pid = pack_id(pc, pa);
+      if (counter_row == NONE32 || pid > counter_id) { counter_row = pr; counter_id = pid; }
     }
   }
-  if (a == 5 && np == 0) err |= F_BAD_COUNTER;
+  if (a == 5 && !(err & (F_BAD_PRED | F_BAD_ROW))) {
+    long long v;
+    if (counter_row == NONE32) err |= F_BAD_COUNTER;  // increment operation for unknown counter (new.js:954-956)
+    else if (!int_value(b, g, v)) err |= F_UNSUPPORTED;
+    else {
+      atomicAdd(&b.inc_cnt[counter_row], 1u);
+      atomicAdd(&b.inc_sum[counter_row], (unsigned long long)v);
+      atomicMax(&b.last_inc[counter_row], my_id);
+    }
+  }
   b.obj_row[g] = orow;
   b.ref_row[g] = ref;
   b.kind[g] = kind;
