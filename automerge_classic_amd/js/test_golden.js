@@ -10,6 +10,14 @@ const dir = process.argv[2] || path.join(__dirname, '..', '..', 'tests', 'golden
 let failed = 0, n = 0
 for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
   const fx = JSON.parse(fs.readFileSync(path.join(dir, f), 'utf8'))
+  if (!fx.changes) {
+    // document-only fixture: Backend.load + getPatch
+    const want = fx.stock_equals_bigblock === false ? fx.load_patch_bigblock : fx.load_patch
+    const loaded = Backend.load(new Uint8Array(Buffer.from(fx.doc, 'base64')))
+    n++
+    if (JSON.stringify(Backend.getPatch(loaded)) !== want) { failed++; console.error(`FAIL ${f}: document load`) } else console.log(`ok   ${f}  (document load, ${fx.rows} rows)`)
+    continue
+  }
   const changes = fx.changes.map(c => new Uint8Array(Buffer.from(c, 'base64')))
   const expected = fx.stock_equals_bigblock === false ? fx.patch_bigblock : fx.patch
   // the handle given to loadChanges must look like a fresh reference state: {state: {changes: [], queue: []}, heads: []}

@@ -34,6 +34,14 @@ class _Log(ctypes.Structure):
     ]
 
 
+class _DocParams(ctypes.Structure):
+    _fields_ = [
+        ("n_actors", ctypes.c_uint32), ("n_texts", ctypes.c_uint32), ("text_len", ctypes.c_uint32), ("n_maps", ctypes.c_uint32),
+        ("keys_per_map", ctypes.c_uint32), ("n_submaps", ctypes.c_uint32), ("n_lists", ctypes.c_uint32), ("list_len", ctypes.c_uint32),
+        ("deflate", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("seed", ctypes.c_uint64),
+    ]
+
+
 _lib = None
 
 
@@ -46,6 +54,10 @@ def _load():
         _lib.amlog_generate.argtypes = [ctypes.POINTER(_Params), ctypes.POINTER(_Log)]
         _lib.amlog_generate.restype = ctypes.c_int
         _lib.amlog_free.argtypes = [ctypes.POINTER(_Log)]
+        _lib.amlog_generate_document.argtypes = [ctypes.POINTER(_DocParams), ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        _lib.amlog_generate_document.restype = ctypes.c_int
+        _lib.amlog_free_bytes.argtypes = [ctypes.POINTER(ctypes.c_uint8)]
     return _lib
 
 
@@ -131,3 +143,28 @@ def config(name, scale=1.0, deflate=False):
         return generate(KIND_TEXT_CONCURRENT, n_actors=64, n_rounds=max(1, int(64 * scale)), ins_per_change=200,
                         del_per_change=50, n_objects=64, seed=0x5EED0004, deflate=deflate, name=name)
     raise KeyError(name)
+
+
+def generate_document(*, n_actors=16, n_texts=4, text_len=1000, n_maps=4, keys_per_map=200, n_submaps=2, n_lists=2, list_len=300,
+                      deflate=True, seed=0x5EED0005):
+    """A synthetic saved document (Backend.save format) with a mix of Text, nested maps/tables (conflicts, counters) and
+    lists of primitives (BASELINE config 5). Returns (document bytes, number of op rows)."""
+    lib = _load()
+    p = _DocParams(n_actors, n_texts, text_len, n_maps, keys_per_map, n_submaps, n_lists, list_len, 1 if deflate else 0, 0, seed)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_uint64()
+    rows = ctypes.c_uint64()
+    rc = lib.amlog_generate_document(ctypes.byref(p), ctypes.byref(out), ctypes.byref(n), ctypes.byref(rows))
+    if rc != 0:
+        raise RuntimeError(f"amlog_generate_document failed rc={rc}")
+    try:
+        return ctypes.string_at(out, n.value), int(rows.value)
+    finally:
+        lib.amlog_free_bytes(out)
+
+
+def document_config(scale=1.0, deflate=True):
+    """BASELINE config 5 shape: ~40 % text, ~40 % map, ~20 % list rows; scale 1.0 is about 10 M rows."""
+    s = max(scale, 1e-4)
+    return generate_document(n_actors=64, n_texts=256, text_len=max(1, int(13000 * s)), n_maps=100, keys_per_map=max(4, int(22000 * s)),
+                             n_submaps=4, n_lists=64, list_len=max(1, int(26000 * s)), deflate=deflate)

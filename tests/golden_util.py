@@ -9,17 +9,33 @@ from automerge_classic_amd.loggen import ChangeLog
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def fixture_names():
+def _all_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.json")))
+
+
+def fixture_names():
+    """Fixtures holding binary changes and the reference's loadChanges + getPatch result."""
+    return [n for n in _all_names() if not n.startswith("synthetic_doc_")]
+
+
+def doc_fixture_names():
+    """Fixtures holding a saved document and the reference's load + getPatch result."""
+    out = []
+    for n in _all_names():
+        with open(os.path.join(GOLDEN_DIR, n + ".json")) as f:
+            if "doc" in json.load(f):
+                out.append(n)
+    return out
 
 
 def load_fixture(name):
     with open(os.path.join(GOLDEN_DIR, name + ".json")) as f:
         fx = json.load(f)
-    changes = [base64.b64decode(c) for c in fx["changes"]]
-    fx["log"] = ChangeLog.from_changes(changes, name=name)
-    # the patch the engine/oracle must reproduce: the stock reference, unless its block-boundary defect fired
-    fx["expected"] = fx["patch"] if fx.get("stock_equals_bigblock", True) else fx["patch_bigblock"]
+    if "changes" in fx:
+        changes = [base64.b64decode(c) for c in fx["changes"]]
+        fx["log"] = ChangeLog.from_changes(changes, name=name)
+        # the patch the engine/oracle must reproduce: the stock reference, unless its block-boundary defect fired
+        fx["expected"] = fx["patch"] if fx.get("stock_equals_bigblock", True) else fx["patch_bigblock"]
     if "doc" in fx:
         fx["doc_bytes"] = base64.b64decode(fx["doc"])
         fx["expected_load"] = fx["load_patch"] if fx.get("stock_equals_bigblock", True) else fx["load_patch_bigblock"]

@@ -32,7 +32,7 @@ def test_golden_reference_patches(eng, name):
     assert gpu_patch(eng, fx["log"]) == fx["expected"]
 
 
-@pytest.mark.parametrize("name", golden_util.fixture_names())
+@pytest.mark.parametrize("name", golden_util.doc_fixture_names())
 def test_document_load_matches_reference(eng, name):
     """Backend.load(bytes) + getPatch against the unmodified reference's save()/load()."""
     fx = golden_util.load_fixture(name)
