@@ -10,6 +10,7 @@
 #include "../../include/am355.h"
 #include "am355_decode.h"
 #include "am355_merge.h"
+#include "am355_bigcol.h"
 #include "am355_prims.h"
 #include "am355_render.h"
 
@@ -99,6 +100,10 @@ struct am355_ctx {
   std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
   DevBuf d_arena, d_offsets, d_metas;
   HostBuf h_metas;
+  DevBuf d_big, d_bigvals, d_ks;     // document load: token / record index, column values, keyStr run table
+  HostBuf h_biginfo;
+  BigColDesc doc_cols{};
+  bool doc_serial = false;           // AM355_DOC_SERIAL=1: lane-serial column decoders (first version, kept for cross-checks)
   // stage-1 side tables (device) and their pinned host mirrors
   DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1;
   HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_briefs, h_distinct;
@@ -187,9 +192,9 @@ extern "C" void am355_destroy(am355_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_spans, &c->d_tab_off, &c->d_cols, &c->d_pred,
-                    &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts})
+                    &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks})
     b->release();
-  for (HostBuf* b : {&c->h_metas, &c->h_counts, &c->h_ir, &c->h_rows}) b->release();
+  for (HostBuf* b : {&c->h_metas, &c->h_counts, &c->h_ir, &c->h_rows, &c->h_biginfo}) b->release();
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -483,9 +488,25 @@ extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len)
     m.col_len[slot] = col ? (uint32_t)col->n : 0;
     if (col) c->raw.insert(c->raw.end(), col->p, col->p + col->n);
   };
-  place(C_OBJ_ACTOR, 0x01); place(C_OBJ_CTR, 0x02); place(C_KEY_ACTOR, 0x11); place(C_KEY_CTR, 0x13); place(C_KEY_STR, 0x15);
-  place(C_ID_ACTOR, 0x21); place(C_ID_CTR, 0x23); place(C_INSERT, 0x34); place(C_ACTION, 0x42); place(C_VAL_LEN, 0x56); place(C_VAL_RAW, 0x57);
-  place(C_PRED_NUM, 0x80); place(C_PRED_ACTOR, 0x81); place(C_PRED_CTR, 0x83);
+  // the LEB-tokenisable columns first (BigCol order), the two byte-string columns after them
+  static const struct { int slot; uint64_t id; uint32_t kind; } big[BIG_NCOL] = {
+      {C_OBJ_ACTOR, 0x01, BK_UINT}, {C_OBJ_CTR, 0x02, BK_UINT}, {C_KEY_ACTOR, 0x11, BK_UINT}, {C_KEY_CTR, 0x13, BK_DELTA}, {C_ID_ACTOR, 0x21, BK_UINT},
+      {C_ID_CTR, 0x23, BK_DELTA}, {C_INSERT, 0x34, BK_BOOL}, {C_ACTION, 0x42, BK_UINT}, {C_VAL_LEN, 0x56, BK_UINT}, {C_PRED_NUM, 0x80, BK_UINT},
+      {C_PRED_ACTOR, 0x81, BK_UINT}, {C_PRED_CTR, 0x83, BK_DELTA}};
+  for (int k = 0; k < BIG_NCOL; k++) {
+    place(big[k].slot, big[k].id);
+    c->doc_cols.off[k] = m.col_off[big[k].slot];
+    c->doc_cols.len[k] = m.col_len[big[k].slot];
+    c->doc_cols.kind[k] = big[k].kind;
+    // every column must end on the last byte of a number (the device finds numbers by their terminating bytes)
+    if (m.col_len[big[k].slot] && (c->raw.back() & 0x80)) return bad(AM355_F_BAD_LEB, "incomplete number");
+  }
+  c->doc_cols.tok_bytes = (uint32_t)c->raw.size();
+  place(C_KEY_STR, 0x15); place(C_VAL_RAW, 0x57);
+  {
+    const char* e = getenv("AM355_DOC_SERIAL");
+    c->doc_serial = e && *e == '1';
+  }
   c->raw_off.push_back(c->raw.size());
   if (c->raw.size() >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "document larger than 4 GiB (32-bit arena offsets)");
   m.len = (uint32_t)c->raw.size();
@@ -990,32 +1011,85 @@ static int replay_document(am355_ctx* c) {
   auto t_begin = std::chrono::steady_clock::now();
   hipStream_t st = c->stream;
   uint32_t NA = (uint32_t)c->actors.size();
-  HIPCHK(c, hipEventRecord(c->ev[0], st));
-  HIPCHK(c, hipMemcpyAsync(c->d_metas.p, &c->doc_meta, sizeof(ChangeMeta), hipMemcpyHostToDevice, st));
-  launch_doc_count(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), st);
-  HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipEventRecord(c->ev[1], st));
-  HIPCHK(c, hipStreamSynchronize(st));
-  const ChangeMeta* hm = c->h_metas.as<ChangeMeta>();
-  if (hm->flags) return error_for_flags(c, hm->flags, "malformed document columns");
-  c->n_ops = hm->n_ops;
-  c->n_preds = hm->n_preds;
-  c->n_applied = c->n_changes;
-  c->n_pending = 0;
-  c->max_op = 0xffffffffu >> 8;  // only sizes sort keys, which the document path never builds
-  if (c->n_ops >= 0x7ffffff0ull) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 rows in one document"); }
   if (!c->d_plans.ensure(sizeof(ChangePlan)) || !c->d_amap.ensure(4 * (size_t)std::max(NA, 1u)) || !c->d_words.ensure(4 * W_NUM) || !c->h_words.ensure(4 * W_NUM))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
-  int rc = setup_buffers(c);
-  if (rc) return rc;
-  ChangePlan pl{0, 0, 0, 0, NONE32, NA};  // author NONE32 = document mode: ids come from the idActor / idCtr columns
-  HIPCHK(c, hipMemcpyAsync(c->d_plans.p, &pl, sizeof pl, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
-  HIPCHK(c, hipMemsetAsync(c->d_words.p, 0, 4 * W_NUM, st));
-  HIPCHK(c, hipEventRecord(c->ev[2], st));
-  launch_decode_document(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_amap.as<uint32_t>(), c->cols,
-                         &c->d_counts.as<Counts>()->flags, st);
+  HIPCHK(c, hipEventRecord(c->ev[0], st));
+  if (c->doc_serial) {
+    // first version: two lanes count rows / succ entries, then one lane per column group decodes value by value
+    HIPCHK(c, hipMemcpyAsync(c->d_metas.p, &c->doc_meta, sizeof(ChangeMeta), hipMemcpyHostToDevice, st));
+    launch_doc_count(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), st);
+    HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const ChangeMeta* hm = c->h_metas.as<ChangeMeta>();
+    if (hm->flags) return error_for_flags(c, hm->flags, "malformed document columns");
+    c->n_ops = hm->n_ops;
+    c->n_preds = hm->n_preds;
+    c->n_applied = c->n_changes;
+    c->n_pending = 0;
+    c->max_op = 0xffffffffu >> 8;  // only sizes sort keys, which the document path never builds
+    if (c->n_ops >= 0x7ffffff0ull) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 rows in one document"); }
+    int rc = setup_buffers(c);
+    if (rc) return rc;
+    ChangePlan pl{0, 0, 0, 0, NONE32, NA};  // author NONE32 = document mode: ids come from the idActor / idCtr columns
+    HIPCHK(c, hipMemcpyAsync(c->d_plans.p, &pl, sizeof pl, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
+    HIPCHK(c, hipMemsetAsync(c->d_words.p, 0, 4 * W_NUM, st));
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    launch_decode_document(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_amap.as<uint32_t>(), c->cols,
+                           &c->d_counts.as<Counts>()->flags, st);
+  } else {
+    // parallel column decode (am355_bigcol.hip); the keyStr column is walked by one lane on the second stream meanwhile
+    const BigColDesc& d = c->doc_cols;
+    const ChangeMeta& m = c->doc_meta;
+    uint32_t ks_cap = m.col_len[C_KEY_STR] / 2 + 4;
+    if (!c->d_big.ensure(bigcol_work_bytes(d.tok_bytes)) || !c->d_ks.ensure(3 * 4 * (size_t)ks_cap + 64) || !c->h_biginfo.ensure(sizeof(BigColInfo)))
+      return fail(c, AM355_E_NOMEM, "device allocation failed (document index)");
+    BigColWork w;
+    bigcol_carve(w, c->d_big.p, d.tok_bytes);
+    uint32_t* ks_start = c->d_ks.as<uint32_t>();
+    uint32_t *ks_off = ks_start + ks_cap, *ks_len = ks_off + ks_cap;
+    uint32_t* d_words = c->d_words.as<uint32_t>();
+    HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev_b0, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_b0, 0));
+    launch_keystr_runs(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], ks_start, ks_off, ks_len, d_words + W_TOTAL_ENTRIES,
+                       d_words + W_FLAGS_B, c->stream2);
+    HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
+    bigcol_index(c->d_arena.as<uint8_t>(), d, w, st);
+    BigColInfo* hi = c->h_biginfo.as<BigColInfo>();
+    HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (hi->flags) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, hi->flags, "malformed document columns"); }
+    BigColInfo info = *hi;
+    uint32_t N = info.rows[BC_ACTION], Pcap = info.rows[BC_SUCC_ACTOR];
+    if (N >= 0x7ffffff0u) { (void)hipStreamSynchronize(c->stream2); c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 rows in one document"); }
+    if (!c->d_bigvals.ensure(bigcol_vals_bytes(N, Pcap))) { (void)hipStreamSynchronize(c->stream2); return fail(c, AM355_E_NOMEM, "device allocation failed (document columns)"); }
+    BigColVals v;
+    bigcol_carve_vals(v, c->d_bigvals.p, N, Pcap);
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    bigcol_expand(d, w, info, v, N, Pcap, st);
+    HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (hi->flags) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, hi->flags, "malformed document columns"); }
+    if (hi->n_succ > Pcap) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, AM355_F_UNSUPPORTED, "succ columns shorter than succNum announces"); }
+    c->n_ops = N;
+    c->n_preds = hi->n_succ;
+    c->n_applied = c->n_changes;
+    c->n_pending = 0;
+    c->max_op = 0xffffffffu >> 8;  // only sizes sort keys, which the document path never builds
+    int rc = setup_buffers(c);
+    if (rc) { (void)hipStreamSynchronize(c->stream2); return rc; }
+    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
+    uint32_t* flags = &c->d_counts.as<Counts>()->flags;
+    bigcol_assemble(v, N, (uint32_t)c->n_preds, c->d_amap.as<uint32_t>(), NA, m.col_off[C_VAL_RAW], m.col_len[C_VAL_RAW], c->cols, flags, st);
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_b1, 0));
+    launch_keystr_expand(ks_start, ks_off, ks_len, d_words + W_TOTAL_ENTRIES, N, c->cols.key_off, c->cols.key_len, st);
+    HIPCHK(c, hipMemcpyAsync(c->h_words.as<uint32_t>() + W_FLAGS_B, d_words + W_FLAGS_B, 4, hipMemcpyDeviceToHost, st));
+  }
   HIPCHK(c, hipEventRecord(c->ev[3], st));
   // maxOp = max over op ids and succ counters (new.js:1627-1630)
   uint32_t* d_max = c->d_words.as<uint32_t>();
@@ -1027,6 +1101,7 @@ static int replay_document(am355_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[4], st));
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   HIPCHK(c, hipStreamSynchronize(st));
+  if (!c->doc_serial && c->h_words.as<uint32_t>()[W_FLAGS_B]) return error_for_flags(c, c->h_words.as<uint32_t>()[W_FLAGS_B], "malformed key column");
   if (hc->flags) return error_for_flags(c, hc->flags, "document rejected");
   c->max_op = c->h_words.as<uint32_t>()[0];
   c->counts = *hc;

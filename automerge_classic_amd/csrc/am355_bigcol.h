@@ -1,0 +1,56 @@
+// Parallel decode of the multi-megabyte columns of a saved document (see am355_bigcol.hip).
+#pragma once
+#include "am355_internal.h"
+#include <stddef.h>
+
+namespace am355 {
+
+constexpr int BIG_NCOL = 12;
+// order of the tokenisable columns at the front of the document arena
+enum BigCol { BC_OBJ_ACTOR, BC_OBJ_CTR, BC_KEY_ACTOR, BC_KEY_CTR, BC_ID_ACTOR, BC_ID_CTR, BC_INSERT, BC_ACTION, BC_VAL_LEN, BC_SUCC_NUM, BC_SUCC_ACTOR, BC_SUCC_CTR };
+enum BigKind : uint32_t { BK_UINT = 0, BK_DELTA = 1, BK_BOOL = 2 };
+
+struct BigColDesc {
+  uint32_t off[BIG_NCOL], len[BIG_NCOL], kind[BIG_NCOL];
+  uint32_t tok_bytes;  // the columns occupy arena[0, tok_bytes)
+};
+
+// filled on the device, read back once by the host
+struct BigColInfo {
+  uint32_t t0[BIG_NCOL], t1[BIG_NCOL];  // token range of each column
+  uint32_t r0[BIG_NCOL], r1[BIG_NCOL];  // record range
+  uint32_t rows[BIG_NCOL];              // values the column holds
+  uint32_t n_tokens, n_records, flags, n_succ;  // n_succ = sum of succNum over the rows
+};
+
+// all arrays are sized by the byte count of the columns (tokens <= bytes, records <= tokens), so nothing here waits for a
+// device-side count; cap = tok_bytes + 2
+struct BigColWork {
+  uint32_t *term_ex, *tok_end, *tok_lo, *tok_hi, *jump_a, *jump_b, *mark, *rec_ex, *rec_tok, *rec_rows, *rec_start;  // [cap]
+  uint16_t* tok_meta;                                                                                           // [cap] byte count | last byte << 8
+  void* scan_ws;                                                                                                // scan_workspace_bytes(cap)
+  BigColInfo* info;                                                                                             // device
+};
+size_t bigcol_work_bytes(uint32_t tok_bytes);
+void bigcol_carve(BigColWork& w, void* base, uint32_t tok_bytes);
+
+// value arrays: NONE32 = null for the plain columns; delta columns carry a separate null mask
+struct BigColVals {
+  uint32_t* v[BIG_NCOL];       // [rows + 1]
+  uint8_t* key_ctr_null;       // [N + 1]
+  uint32_t *val_off, *succ_first;  // [N + 1] exclusive prefix sums of value lengths / succ counts
+  uint32_t* tmp;               // [max(N, P) + 1]
+  void* scan_ws;               // scan_workspace_bytes(max(N, P) + 1)
+};
+size_t bigcol_vals_bytes(uint32_t n_rows, uint32_t n_succ);
+void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_succ);
+
+// tokens -> records -> row starts; fills *w.info (column ranges, rows per column). One stream, no host round trip inside.
+void bigcol_index(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipStream_t st);
+// values of every row of every column, delta / offset prefix sums; info->n_succ
+void bigcol_expand(const BigColDesc& d, const BigColWork& w, const BigColInfo& h, BigColVals& v, uint32_t n_rows, uint32_t n_succ_cap, hipStream_t st);
+// fixed-width op rows from the value arrays (key strings are filled by launch_keystr_expand)
+void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, const uint32_t* actor_rank, uint32_t n_actors, uint32_t val_raw_abs,
+                     uint32_t val_raw_len, OpCols o, uint32_t* flags, hipStream_t st);
+
+}  // namespace am355

@@ -1,0 +1,368 @@
+// Parallel decode of big RLE / delta / boolean columns (document load, BASELINE config 5).
+//
+// The columns of a saved document run to megabytes, so neither the wave-per-change decoder (LDS staging) nor a lane per
+// column will do. The scheme (reference codecs: backend/encoding.js:789-920 RLE, 1004-1051 delta, 1141-1207 boolean):
+//   A. tokens   every byte with bit 7 clear ends a LEB128 number: flag + prefix sum over the bytes of all columns at once
+//               gives each number's index; one lane per number assembles it.
+//   B. records  seen as a record header, token t names its successor (t+2 for a repetition or null run, t+1+k for a
+//               literal of k values; t+1 in a boolean column). The real headers are the orbit of the column's first
+//               token under that map: marked by pointer doubling, all columns together, log2(tokens) rounds.
+//   C. rows     rows per record -> prefix sum -> row start of every record; every row binary-searches its record and reads
+//               its value (repetition: the record's value token; literal: value token + offset; null run: null; boolean:
+//               record parity). Delta columns, value offsets and succ-list offsets are further prefix sums.
+// All of it is streaming integer work over HBM-resident arrays (prefix sums, gathers); no MFMA.
+#include "am355_bigcol.h"
+#include "am355_prims.h"
+
+namespace am355 {
+
+static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
+constexpr uint64_t MAX_SAFE_BIG = 9007199254740991ull;
+
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t bigcol_work_bytes(uint32_t tok_bytes) {
+  size_t cap = (size_t)tok_bytes + 2;
+  return 11 * al256(4 * cap) + al256(2 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + al256(sizeof(BigColInfo));
+}
+void bigcol_carve(BigColWork& w, void* base, uint32_t tok_bytes) {
+  size_t cap = (size_t)tok_bytes + 2;
+  uint8_t* p = (uint8_t*)base;
+  auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
+  uint32_t** arrs[] = {&w.term_ex, &w.tok_end, &w.tok_lo, &w.tok_hi, &w.jump_a, &w.jump_b, &w.mark, &w.rec_ex, &w.rec_tok, &w.rec_rows, &w.rec_start};
+  for (uint32_t** a : arrs) *a = (uint32_t*)take(4 * cap);
+  w.tok_meta = (uint16_t*)take(2 * cap);
+  w.scan_ws = take(scan_workspace_bytes((uint32_t)cap));
+  w.info = (BigColInfo*)take(sizeof(BigColInfo));
+}
+size_t bigcol_vals_bytes(uint32_t n_rows, uint32_t n_succ) {
+  size_t n = (size_t)n_rows + 1, p = (size_t)n_succ + 1;
+  return 12 * al256(4 * n) + 2 * al256(4 * p) + al256(n) + al256(4 * (n > p ? n : p)) + al256(scan_workspace_bytes((uint32_t)(n > p ? n : p)));
+}
+void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_succ) {
+  size_t n = (size_t)n_rows + 1, pn = (size_t)n_succ + 1;
+  uint8_t* p = (uint8_t*)base;
+  auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
+  for (int c = 0; c < BIG_NCOL; c++) v.v[c] = (uint32_t*)take(4 * (c >= BC_SUCC_ACTOR ? pn : n));
+  v.val_off = (uint32_t*)take(4 * n);
+  v.succ_first = (uint32_t*)take(4 * n);
+  v.key_ctr_null = (uint8_t*)take(n);
+  v.tmp = (uint32_t*)take(4 * (n > pn ? n : pn));
+  v.scan_ws = take(scan_workspace_bytes((uint32_t)(n > pn ? n : pn)));
+}
+
+// ---- tokens -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void kb_term_flags(const uint8_t* __restrict__ arena, uint32_t n, uint32_t* __restrict__ flags) {
+  uint32_t i = gtid();
+  if (i < n) flags[i] = (arena[i] & 0x80) ? 0u : 1u;
+  else if (i == n) flags[n] = 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void kb_token_ends(const uint8_t* __restrict__ arena, uint32_t n, const uint32_t* __restrict__ term_ex,
+                                                       uint32_t* __restrict__ tok_end) {
+  uint32_t i = gtid();
+  if (i < n && !(arena[i] & 0x80)) tok_end[term_ex[i]] = i;
+}
+
+__global__ __launch_bounds__(WAVE) void kb_col_ranges(BigColDesc d, const uint32_t* __restrict__ term_ex, BigColInfo* __restrict__ info) {
+  uint32_t c = threadIdx.x;
+  if (c >= BIG_NCOL) return;
+  info->t0[c] = term_ex[d.off[c]];
+  info->t1[c] = term_ex[d.off[c] + d.len[c]];
+}
+
+__device__ __forceinline__ bool big_tok_sint(uint32_t lo, uint32_t hi, uint32_t meta, int64_t& out) {
+  uint32_t nb = meta & 0xff, last = meta >> 8;
+  if (nb == 0 || nb > 10 || (nb == 10 && last != 0 && last != 0x7f)) return false;
+  uint64_t v = (uint64_t)hi << 32 | lo;
+  if ((last & 0x40) && 7 * nb < 64) v |= ~0ull << (7 * nb);
+  out = (int64_t)v;
+  return out <= (int64_t)MAX_SAFE_BIG && out >= -(int64_t)MAX_SAFE_BIG;
+}
+__device__ __forceinline__ bool big_tok_uint(uint32_t lo, uint32_t hi, uint32_t meta, uint64_t& out) {
+  uint32_t nb = meta & 0xff, last = meta >> 8;
+  if (nb == 0 || nb > 10 || (nb == 10 && (last & 0xfe))) return false;
+  out = (uint64_t)hi << 32 | lo;
+  return out <= MAX_SAFE_BIG;
+}
+__device__ __forceinline__ int big_col_of(const BigColInfo* info, uint32_t t) {
+  int c = 0;
+  for (int k = 0; k < BIG_NCOL; k++)
+    if (t >= info->t0[k] && t < info->t1[k]) c = k;
+  return c;
+}
+
+// one lane per token: assemble its value; as a would-be record header, where does the next header sit?
+__global__ __launch_bounds__(BLOCK) void kb_token_values(const uint8_t* __restrict__ arena, BigColDesc d, uint32_t cap, BigColWork w) {
+  uint32_t t = gtid();
+  if (t >= cap) return;
+  uint32_t n_tokens = w.info->n_tokens;
+  w.rec_rows[t] = 0;
+  if (t >= n_tokens) { w.jump_a[t] = NONE32; w.mark[t] = 0; return; }
+  uint32_t end = w.tok_end[t], start = t ? w.tok_end[t - 1] + 1 : 0;
+  uint32_t nb = end - start + 1;
+  uint64_t v = 0;
+  if (nb <= 10)
+    for (uint32_t k = 0; k < nb; k++) v |= (uint64_t)(arena[start + k] & 0x7f) << (7 * k);
+  uint32_t meta = (nb <= 10 ? nb : 0xffu) | (uint32_t)arena[end] << 8;
+  w.tok_lo[t] = (uint32_t)v;
+  w.tok_hi[t] = (uint32_t)(v >> 32);
+  w.tok_meta[t] = (uint16_t)meta;
+  int c = big_col_of(w.info, t);
+  uint32_t t0 = w.info->t0[c], t1 = w.info->t1[c];
+  uint32_t next;
+  if (d.kind[c] == BK_BOOL) next = t + 1;
+  else {
+    int64_t cnt;
+    if (!big_tok_sint((uint32_t)v, (uint32_t)(v >> 32), meta, cnt)) next = t + 1;  // not a count: never the header of a well-formed column
+    else if (cnt < 0) next = (uint64_t)(-cnt) + 1 > (uint64_t)(t1 - t) ? t1 : t + 1 + (uint32_t)(-cnt);
+    else next = t + 2;
+  }
+  w.jump_a[t] = next >= t1 ? NONE32 : next;
+  w.mark[t] = t == t0 ? 1u : 0u;
+}
+
+// pointer doubling: a marked token marks the header 2^round records ahead. Marks only ever land on true headers, so
+// reading marks written in the same round is harmless.
+__global__ __launch_bounds__(BLOCK) void kb_double(const BigColInfo* __restrict__ info, const uint32_t* __restrict__ jump_in, uint32_t* __restrict__ jump_out,
+                                                   uint32_t* __restrict__ mark) {
+  uint32_t t = gtid();
+  if (t >= info->n_tokens) return;
+  uint32_t j = jump_in[t];
+  if (j != NONE32) {
+    if (mark[t]) mark[j] = 1;
+    j = jump_in[j];
+  }
+  jump_out[t] = j;
+}
+
+// ---- records ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void kb_records(BigColDesc d, uint32_t cap, BigColWork w) {
+  uint32_t t = gtid();
+  if (t < BIG_NCOL) {
+    w.info->r0[t] = w.rec_ex[w.info->t0[t]];
+    w.info->r1[t] = w.rec_ex[w.info->t1[t]];
+  }
+  if (t >= w.info->n_tokens || !w.mark[t]) return;
+  int c = big_col_of(w.info, t);
+  uint32_t t0 = w.info->t0[c], t1 = w.info->t1[c];
+  uint32_t r = w.rec_ex[t], err = 0;
+  uint64_t rows = 0;
+  uint32_t lo = w.tok_lo[t], hi = w.tok_hi[t], meta = w.tok_meta[t];
+  if (d.kind[c] == BK_BOOL) {
+    if (!big_tok_uint(lo, hi, meta, rows)) err |= F_BAD_LEB;
+    if (rows == 0 && t != t0) err |= F_BAD_RLE;  // a zero-length run only as the leading `false` run (encoding.js:1180-1184)
+  } else {
+    int64_t cnt;
+    if (!big_tok_sint(lo, hi, meta, cnt)) err |= F_BAD_LEB;
+    else if (cnt > 1) {
+      rows = (uint64_t)cnt;
+      if (t + 1 >= t1) err |= F_BAD_LEB;
+    } else if (cnt == 1) err |= F_BAD_RLE;
+    else if (cnt < 0) {
+      rows = (uint64_t)(-cnt);
+      if (rows > (uint64_t)(t1 - t - 1)) { err |= F_BAD_LEB; rows = 0; }
+    } else {
+      if (t + 1 >= t1 || !big_tok_uint(w.tok_lo[t + 1], w.tok_hi[t + 1], w.tok_meta[t + 1], rows)) err |= F_BAD_LEB;
+      else if (rows == 0) err |= F_BAD_RLE;
+    }
+    // successive literals / successive null runs are not canonical (encoding.js:870-887)
+    if (!err && t != t0 && cnt <= 0) {
+      // the previous header is not known here; kb_record_pairs checks neighbours once rec_tok is complete
+    }
+  }
+  if (rows > 0x7ffffff0ull) { err |= F_OVERFLOW; rows = 0; }
+  w.rec_tok[r] = t;
+  w.rec_rows[r] = (uint32_t)rows;
+  if (err) atomicOr(&w.info->flags, err);
+}
+
+// neighbouring records of one column: two literals or two null runs in a row are rejected by the reference decoder
+__global__ __launch_bounds__(BLOCK) void kb_record_pairs(BigColDesc d, BigColWork w) {
+  uint32_t r = gtid();
+  if (r == 0 || r >= w.info->n_records) return;
+  uint32_t t = w.rec_tok[r], tp = w.rec_tok[r - 1];
+  int c = big_col_of(w.info, t);
+  if (d.kind[c] == BK_BOOL || tp < w.info->t0[c]) return;
+  int64_t a = 0, b = 0;
+  big_tok_sint(w.tok_lo[tp], w.tok_hi[tp], w.tok_meta[tp], a);
+  big_tok_sint(w.tok_lo[t], w.tok_hi[t], w.tok_meta[t], b);
+  if ((a < 0 && b < 0) || (a == 0 && b == 0)) atomicOr(&w.info->flags, (uint32_t)F_BAD_RLE);
+}
+
+__global__ __launch_bounds__(WAVE) void kb_col_rows(BigColWork w) {
+  uint32_t c = threadIdx.x;
+  if (c >= BIG_NCOL) return;
+  w.info->rows[c] = w.rec_start[w.info->r1[c]] - w.rec_start[w.info->r0[c]];
+}
+
+void bigcol_index(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipStream_t st) {
+  uint32_t L = d.tok_bytes, cap = L + 2;
+  (void)hipMemsetAsync(w.info, 0, sizeof(BigColInfo), st);
+  AM355_LAUNCH_INDEPENDENT(kb_term_flags, grid_for(L + 1), dim3(BLOCK), st, arena, L, w.term_ex);
+  exclusive_scan_u32(w.term_ex, w.term_ex, L + 1, &w.info->n_tokens, w.scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kb_col_ranges, dim3(1), dim3(WAVE), st, d, (const uint32_t*)w.term_ex, w.info);
+  AM355_LAUNCH_INDEPENDENT(kb_token_ends, grid_for(L), dim3(BLOCK), st, arena, L, (const uint32_t*)w.term_ex, w.tok_end);
+  AM355_LAUNCH_INDEPENDENT(kb_token_values, grid_for(cap), dim3(BLOCK), st, arena, d, cap, w);
+  int rounds = 1;
+  while (rounds < 32 && (L >> rounds)) rounds++;
+  uint32_t *j0 = w.jump_a, *j1 = w.jump_b;
+  for (int r = 0; r < rounds; r++) {
+    AM355_LAUNCH_INDEPENDENT(kb_double, grid_for(L + 1), dim3(BLOCK), st, (const BigColInfo*)w.info, (const uint32_t*)j0, j1, w.mark);
+    uint32_t* t = j0;
+    j0 = j1;
+    j1 = t;
+  }
+  exclusive_scan_u32(w.mark, w.rec_ex, cap, &w.info->n_records, w.scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kb_records, grid_for(cap), dim3(BLOCK), st, d, cap, w);
+  AM355_LAUNCH_INDEPENDENT(kb_record_pairs, grid_for(cap), dim3(BLOCK), st, d, w);
+  exclusive_scan_u32(w.rec_rows, w.rec_start, cap, nullptr, w.scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kb_col_rows, dim3(1), dim3(WAVE), st, w);
+}
+
+// ---- rows ---------------------------------------------------------------------------------------------------
+// one lane per row of one column. Delta columns: out = the delta (0 for null) and null_out = 1 for null.
+__global__ __launch_bounds__(BLOCK) void kb_expand(BigColWork w, uint32_t kind, uint32_t r0, uint32_t r1, uint32_t n_rows, uint32_t* __restrict__ out,
+                                                   uint8_t* __restrict__ null_out) {
+  uint32_t row = gtid();
+  if (row >= n_rows) return;
+  uint32_t base = w.rec_start[r0];
+  uint32_t avail = w.rec_start[r1] - base;
+  uint32_t val = kind == BK_DELTA ? 0 : NONE32;
+  bool nul = true;
+  if (row < avail) {
+    uint32_t lo = r0, hi = r1;  // last record whose first row is <= row
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (w.rec_start[mid] - base <= row) lo = mid; else hi = mid;
+    }
+    uint32_t t = w.rec_tok[lo], off = row - (w.rec_start[lo] - base);
+    if (kind == BK_BOOL) { val = (lo - r0) & 1; nul = false; }
+    else {
+      int64_t cnt = 0;
+      big_tok_sint(w.tok_lo[t], w.tok_hi[t], w.tok_meta[t], cnt);
+      if (cnt != 0) {
+        uint32_t vt = cnt > 1 ? t + 1 : t + 1 + off;
+        uint32_t vlo = w.tok_lo[vt], vhi = w.tok_hi[vt], vmeta = w.tok_meta[vt];
+        nul = false;
+        if (kind == BK_DELTA) {
+          int64_t dv = 0;
+          if (!big_tok_sint(vlo, vhi, vmeta, dv)) atomicOr(&w.info->flags, (uint32_t)F_BAD_LEB);
+          if (dv > 0x7fffffffll || dv < -0x7fffffffll) { atomicOr(&w.info->flags, (uint32_t)F_OVERFLOW); dv = 0; }
+          val = (uint32_t)(int32_t)dv;  // summed modulo 2^32; every partial sum is checked to be a 32-bit counter
+        } else {
+          uint64_t uv = 0;
+          if (!big_tok_uint(vlo, vhi, vmeta, uv)) atomicOr(&w.info->flags, (uint32_t)F_BAD_LEB);
+          if (uv >= NONE32) { atomicOr(&w.info->flags, (uint32_t)F_OVERFLOW); uv = 0; }
+          val = (uint32_t)uv;
+        }
+        // a literal never repeats its predecessor, a repetition never continues the previous value (encoding.js:870-887)
+        if (cnt < 0 ? off > 0 : false) {
+          uint32_t pt = vt - 1;
+          if (w.tok_lo[pt] == vlo && w.tok_hi[pt] == vhi && (w.tok_meta[pt] & 0xff) == (vmeta & 0xff)) atomicOr(&w.info->flags, (uint32_t)F_BAD_RLE);
+        }
+      }
+    }
+  }
+  out[row] = val;
+  if (null_out) null_out[row] = nul ? 1 : 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void kb_shift4(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t i = gtid();
+  if (i <= n) out[i] = i < n && in[i] != NONE32 ? in[i] >> 4 : 0;
+}
+__global__ __launch_bounds__(BLOCK) void kb_null_to_zero(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t i = gtid();
+  if (i <= n) out[i] = i < n && in[i] != NONE32 ? in[i] : 0;
+}
+// absolute value of a delta column: exclusive prefix + own delta
+__global__ __launch_bounds__(BLOCK) void kb_delta_abs(const uint32_t* __restrict__ ex, uint32_t n, uint32_t* __restrict__ delta_inout, uint32_t* __restrict__ flags) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t a = ex[i] + delta_inout[i];
+  if (a >= 0x80000000u) atomicOr(flags, (uint32_t)F_OVERFLOW);  // negative or beyond 2^31: not an op counter this engine represents
+  delta_inout[i] = a;
+}
+
+void bigcol_expand(const BigColDesc& d, const BigColWork& w, const BigColInfo& h, BigColVals& v, uint32_t n_rows, uint32_t n_succ_cap, hipStream_t st) {
+  for (int c = 0; c < BIG_NCOL; c++) {
+    uint32_t n = c >= BC_SUCC_ACTOR ? n_succ_cap : n_rows;
+    if (!n) continue;
+    AM355_LAUNCH_INDEPENDENT(kb_expand, grid_for(n), dim3(BLOCK), st, w, d.kind[c], h.r0[c], h.r1[c], n, v.v[c], c == BC_KEY_CTR ? v.key_ctr_null : (uint8_t*)nullptr);
+  }
+  // value offsets, succ list offsets
+  AM355_LAUNCH_INDEPENDENT(kb_shift4, grid_for(n_rows + 1), dim3(BLOCK), st, (const uint32_t*)v.v[BC_VAL_LEN], n_rows, v.val_off);
+  exclusive_scan_u32(v.val_off, v.val_off, n_rows + 1, nullptr, v.scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kb_null_to_zero, grid_for(n_rows + 1), dim3(BLOCK), st, (const uint32_t*)v.v[BC_SUCC_NUM], n_rows, v.succ_first);
+  exclusive_scan_u32(v.succ_first, v.succ_first, n_rows + 1, &w.info->n_succ, v.scan_ws, st);
+  // delta columns -> absolute counters
+  struct { int c; uint32_t n; } deltas[] = {{BC_KEY_CTR, n_rows}, {BC_ID_CTR, n_rows}, {BC_SUCC_CTR, n_succ_cap}};
+  for (auto& dl : deltas) {
+    if (!dl.n) continue;
+    uint32_t* ex = v.tmp;
+    exclusive_scan_u32(v.v[dl.c], ex, dl.n, nullptr, v.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(kb_delta_abs, grid_for(dl.n), dim3(BLOCK), st, (const uint32_t*)ex, dl.n, v.v[dl.c], &w.info->flags);
+  }
+}
+
+// ---- op rows --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t big_rank(const uint32_t* __restrict__ rank, uint32_t n_actors, uint32_t idx, uint32_t& err) {
+  if (idx >= n_actors) { err |= F_BAD_ROW; return 0; }
+  return rank[idx];
+}
+
+// same row checks as the lane-serial decoder (am355_decode.hip k_decode_columns; new.js:715-723)
+__global__ __launch_bounds__(BLOCK) void kb_assemble(BigColVals v, uint32_t n_rows, const uint32_t* __restrict__ rank, uint32_t n_actors, uint32_t val_raw_abs,
+                                                     uint32_t val_raw_len, OpCols o, uint32_t* __restrict__ flags) {
+  uint32_t i = gtid();
+  if (i >= n_rows) return;
+  uint32_t err = 0;
+  uint32_t oa = v.v[BC_OBJ_ACTOR][i], oc = v.v[BC_OBJ_CTR][i];
+  if ((oa == NONE32) != (oc == NONE32)) err |= F_BAD_ROW;
+  o.obj_actor[i] = oa == NONE32 ? NONE32 : big_rank(rank, n_actors, oa, err);
+  o.obj_ctr[i] = oc == NONE32 ? 0 : oc;
+  uint32_t ka = v.v[BC_KEY_ACTOR][i], kc = v.v[BC_KEY_CTR][i];
+  bool kc_null = v.key_ctr_null[i] != 0;
+  if ((kc_null && ka != NONE32) || (!kc_null && kc == 0 && ka != NONE32) || (!kc_null && kc > 0 && ka == NONE32)) err |= F_BAD_ROW;
+  o.key_actor[i] = ka == NONE32 ? NONE32 : big_rank(rank, n_actors, ka, err);
+  o.key_ctr[i] = kc_null ? NONE32 : kc;
+  uint32_t ia = v.v[BC_ID_ACTOR][i], ic = v.v[BC_ID_CTR][i];
+  if (ia == NONE32 || ic == 0) err |= F_BAD_ROW;
+  o.id_actor[i] = ia == NONE32 ? 0 : big_rank(rank, n_actors, ia, err);
+  o.id_ctr[i] = ic;
+  uint32_t ins = v.v[BC_INSERT][i];
+  o.insert[i] = ins == NONE32 ? 0 : (uint8_t)ins;
+  uint32_t act = v.v[BC_ACTION][i];
+  if (act == NONE32) { err |= F_UNSUPPORTED; act = 0; }
+  o.action[i] = act;
+  uint32_t tl = v.v[BC_VAL_LEN][i];
+  if (tl == NONE32) tl = 0;
+  uint32_t used = v.val_off[i];
+  if ((uint64_t)used + (tl >> 4) > val_raw_len) err |= F_BAD_CHUNK;  // readRawBytes past the column
+  o.val_tl[i] = tl;
+  o.val_off[i] = val_raw_abs + used;
+  uint32_t sn = v.v[BC_SUCC_NUM][i];
+  o.pred_num[i] = sn == NONE32 ? 0 : sn;
+  o.pred_first[i] = v.succ_first[i];
+  if (err) atomicOr(flags, err);
+}
+
+__global__ __launch_bounds__(BLOCK) void kb_assemble_succ(BigColVals v, uint32_t n_succ, const uint32_t* __restrict__ rank, uint32_t n_actors, OpCols o,
+                                                          uint32_t* __restrict__ flags) {
+  uint32_t i = gtid();
+  if (i >= n_succ) return;
+  uint32_t err = 0;
+  uint32_t a = v.v[BC_SUCC_ACTOR][i];
+  if (a == NONE32) { err |= F_UNSUPPORTED; a = 0; }
+  o.pred_actor[i] = big_rank(rank, n_actors, a, err);
+  o.pred_ctr[i] = v.v[BC_SUCC_CTR][i];
+  if (err) atomicOr(flags, err);
+}
+
+void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, const uint32_t* actor_rank, uint32_t n_actors, uint32_t val_raw_abs,
+                     uint32_t val_raw_len, OpCols o, uint32_t* flags, hipStream_t st) {
+  if (n_rows) AM355_LAUNCH_INDEPENDENT(kb_assemble, grid_for(n_rows), dim3(BLOCK), st, v, n_rows, actor_rank, n_actors, val_raw_abs, val_raw_len, o, flags);
+  if (n_succ) AM355_LAUNCH_INDEPENDENT(kb_assemble_succ, grid_for(n_succ), dim3(BLOCK), st, v, n_succ, actor_rank, n_actors, o, flags);
+}
+
+}  // namespace am355

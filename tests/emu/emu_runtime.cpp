@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- see tests/emu/include/hip/hip_runtime.h.
 #include <hip/hip_runtime.h>
 
+const char* emu_current_kernel = nullptr;
 thread_local emu_uint3 threadIdx, blockIdx;
 thread_local dim3 blockDim, gridDim;
 

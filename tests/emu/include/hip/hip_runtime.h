@@ -75,6 +75,8 @@ struct emu_uint3 { unsigned x, y, z; };
 extern thread_local emu_uint3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
 
+extern const char* emu_current_kernel;
+
 namespace emu {
 
 class Barrier {  // reusable counting barrier (sense reversal); spins briefly then yields
@@ -87,7 +89,18 @@ class Barrier {  // reusable counting barrier (sense reversal); spins briefly th
       gen_.store(g + 1, std::memory_order_release);
     } else {
       unsigned spins = 0;
-      while (gen_.load(std::memory_order_acquire) == g) { if (++spins > 64) std::this_thread::yield(); }
+      std::chrono::steady_clock::time_point t0;
+      while (gen_.load(std::memory_order_acquire) == g) {
+        if (++spins > 64) std::this_thread::yield();
+        if ((spins & 0xfffff) == 0) {  // watchdog: a barrier that never completes is a bug in a kernel or in this emulation
+          auto now = std::chrono::steady_clock::now();
+          if (t0 == std::chrono::steady_clock::time_point()) t0 = now;
+          else if (now - t0 > std::chrono::seconds(90)) {
+            fprintf(stderr, "emu: barrier stuck for 90 s in kernel %s (arrived %u of %u)\n", emu_current_kernel ? emu_current_kernel : "?", count_.load(), n_);
+            abort();
+          }
+        }
+      }
     }
   }
  private:
@@ -142,7 +155,7 @@ inline void emu_launch(bool coop, K kernel, dim3 grid, dim3 block, A... args) {
   }
 }
 // The engine launches every kernel through one of these two macros (see am355_device.h).
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(true, kernel, dim3(grid), dim3(block), __VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_current_kernel = #kernel, emu_launch(true, kernel, dim3(grid), dim3(block), __VA_ARGS__)
 #define AM355_LAUNCH_INDEPENDENT(kernel, grid, block, stream, ...) emu_launch(false, kernel, dim3(grid), dim3(block), __VA_ARGS__)
 
 inline void emu_require_coop(const char* what) {

@@ -123,3 +123,32 @@ def test_device_primitives(eng):
         k, v = eng.test_sort(keys, np.arange(n, dtype=np.uint32), 20)
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(k, keys[order]) and np.array_equal(v, order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("serial", [False, True])
+@pytest.mark.parametrize("deflate", [False, True])
+def test_generated_document_matches_oracle(eng, serial, deflate, monkeypatch):
+    """Synthetic config-5 shaped document: parallel big-column decoder and the lane-serial one against the oracle."""
+    doc, rows = loggen.generate_document(n_actors=7, n_texts=3, text_len=180, n_maps=3, keys_per_map=40, n_submaps=2, n_lists=2, list_len=90,
+                                         deflate=deflate, seed=0xD0C5)
+    if serial:
+        monkeypatch.setenv("AM355_DOC_SERIAL", "1")
+    else:
+        monkeypatch.delenv("AM355_DOC_SERIAL", raising=False)
+    eng.load_document(doc)
+    eng.replay()
+    assert eng.stats().n_ops == rows
+    assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
+
+
+def test_document_columns_parallel_equals_serial(eng, monkeypatch):
+    doc, rows = loggen.generate_document(n_actors=5, n_texts=2, text_len=700, n_maps=2, keys_per_map=90, n_submaps=3, n_lists=3, list_len=200,
+                                         deflate=False, seed=0xD0C6)
+    got = []
+    for serial in ("0", "1"):
+        monkeypatch.setenv("AM355_DOC_SERIAL", serial)
+        eng.load_document(doc)
+        eng.replay()
+        got.append(eng.rows())
+    for k in got[0]:
+        assert np.array_equal(got[0][k], got[1][k]), k

@@ -162,3 +162,38 @@ def test_full_size_headline_workload(eng):
         n_vis += k
     n_del = sum(1 for _ in range(0))  # (deletes are counted by the generator: every delete targets a visible element)
     assert n_vis == st.n_list_elems - (log.n_ops - 1 - st.n_list_elems) or n_vis <= st.n_list_elems
+
+
+@pytest.mark.parametrize("deflate", [False, True])
+def test_generated_document_matches_oracle(eng, deflate):
+    """Config-5 shaped saved document (text / nested maps / lists), ~120 k rows, against the oracle's Backend.load."""
+    doc, rows = loggen.document_config(0.01, deflate=deflate)
+    eng.load_document(doc)
+    eng.replay()
+    assert eng.stats().n_ops == rows
+    assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
+
+
+def test_document_columns_parallel_equals_serial(eng, monkeypatch):
+    """The parallel big-column decoder and the lane-serial decoders produce identical op rows."""
+    doc, rows = loggen.generate_document(n_actors=9, n_texts=5, text_len=2500, n_maps=4, keys_per_map=400, n_submaps=3, n_lists=5, list_len=1500,
+                                         deflate=False, seed=0xD0C7)
+    got = []
+    for serial in ("0", "1"):
+        monkeypatch.setenv("AM355_DOC_SERIAL", serial)
+        eng.load_document(doc)
+        eng.replay()
+        got.append((eng.rows(), eng.patch_json()))
+    monkeypatch.delenv("AM355_DOC_SERIAL")
+    assert got[0][1] == got[1][1]
+    for k in got[0][0]:
+        assert np.array_equal(got[0][0][k], got[1][0][k]), k
+
+
+def test_full_size_document(eng):
+    """BASELINE config 5 at 1/10 scale (1.2 M rows; the oracle needs the rest of the minute for 10 M)."""
+    doc, rows = loggen.document_config(0.1)
+    eng.load_document(doc)
+    eng.replay()
+    assert eng.stats().n_ops == rows
+    assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
