@@ -1040,23 +1040,21 @@ static int replay_document(am355_ctx* c) {
     launch_decode_document(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_amap.as<uint32_t>(), c->cols,
                            &c->d_counts.as<Counts>()->flags, st);
   } else {
-    // parallel column decode (am355_bigcol.hip); the keyStr column is walked by one lane on the second stream meanwhile
+    // parallel column decode (am355_bigcol.hip); the keyStr column is indexed on the second stream meanwhile
     const BigColDesc& d = c->doc_cols;
     const ChangeMeta& m = c->doc_meta;
-    uint32_t ks_cap = m.col_len[C_KEY_STR] / 2 + 4;
-    if (!c->d_big.ensure(bigcol_work_bytes(d.tok_bytes)) || !c->d_ks.ensure(3 * 4 * (size_t)ks_cap + 64) || !c->h_biginfo.ensure(sizeof(BigColInfo)))
+    if (!c->d_big.ensure(bigcol_work_bytes(d.tok_bytes)) || !c->d_ks.ensure(keystr_work_bytes(m.col_len[C_KEY_STR])) || !c->h_biginfo.ensure(sizeof(BigColInfo)))
       return fail(c, AM355_E_NOMEM, "device allocation failed (document index)");
     BigColWork w;
     bigcol_carve(w, c->d_big.p, d.tok_bytes);
-    uint32_t* ks_start = c->d_ks.as<uint32_t>();
-    uint32_t *ks_off = ks_start + ks_cap, *ks_len = ks_off + ks_cap;
+    uint32_t *ks_start, *ks_off, *ks_len;
     uint32_t* d_words = c->d_words.as<uint32_t>();
     HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, st));
     HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev_b0, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_b0, 0));
-    launch_keystr_runs(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], ks_start, ks_off, ks_len, d_words + W_TOTAL_ENTRIES,
-                       d_words + W_FLAGS_B, c->stream2);
+    keystr_index(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], c->d_ks.p, &ks_start, &ks_off, &ks_len, d_words + W_TOTAL_ENTRIES,
+                 d_words + W_FLAGS_B, c->stream2);
     HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
     bigcol_index(c->d_arena.as<uint8_t>(), d, w, st);
     BigColInfo* hi = c->h_biginfo.as<BigColInfo>();

@@ -53,4 +53,10 @@ void bigcol_expand(const BigColDesc& d, const BigColWork& w, const BigColInfo& h
 void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, const uint32_t* actor_rank, uint32_t n_actors, uint32_t val_raw_abs,
                      uint32_t val_raw_len, OpCols o, uint32_t* flags, hipStream_t st);
 
+// keyStr column -> run table (run_start has n_runs + 1 entries; run_len NONE32 = null run), fully parallel. The three table
+// pointers point into `work` (keystr_work_bytes(col_len) bytes).
+size_t keystr_work_bytes(uint32_t col_len);
+void keystr_index(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len,
+                  uint32_t* n_runs, uint32_t* flags, hipStream_t st);
+
 }  // namespace am355

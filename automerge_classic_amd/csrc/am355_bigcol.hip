@@ -365,4 +365,237 @@ void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, cons
   if (n_succ) AM355_LAUNCH_INDEPENDENT(kb_assemble_succ, grid_for(n_succ), dim3(BLOCK), st, v, n_succ, actor_rank, n_actors, o, flags);
 }
 
+
+// ---- key strings ------------------------------------------------------------------------------------------------
+// The keyStr column (UTF-8 RLE, encoding.js:789-920 with type 'utf8') holds length-prefixed strings between the record
+// headers, so its numbers cannot be found by their terminating bytes. Every byte position is parsed speculatively in both
+// roles instead:
+//   as a string   [len][bytes]          -> vnext[i]: where the next string of a literal would start
+//   as a header   count>1 [len][bytes]  -> hnext[i] = end of the string
+//                 count==0 [n]          -> hnext[i] = after n
+//                 count<0 (k strings)   -> hnext[i] = k-th vnext-successor of the first string
+// 1. k-th successors for all positions at once: pointer doubling over vnext, each position applying round r when bit r of
+//    its k is set (jumps commute, so no per-level tables are kept).
+// 2. true headers = orbit of position 0 under hnext (pointer doubling, as for the token columns).
+// 3. true literal items = vnext-orbits of the first string of every true literal, cut at the next true header.
+// 4. items (repetition / null run / literal value) -> prefix sums -> run table (first row, offset, length).
+// Position L (one past the column) is the regular end of the parse; NONE32 is "ran off the column".
+struct KeyWork {
+  uint32_t *vnext, *hnext, *kk, *ja, *jb, *mark_h, *mark_v, *item_ex, *rows;  // [L + 2]
+  uint32_t *run_start, *run_off, *run_len, *run_kind;                        // [L + 2] (items <= bytes)
+  uint32_t* n_runs;                                                          // device word
+  void* scan_ws;
+};
+
+__device__ __forceinline__ bool key_uleb(const uint8_t* __restrict__ p, uint32_t i, uint32_t L, uint64_t& v, uint32_t& nb) {
+  v = 0;
+  for (nb = 0; nb < 10 && i + nb < L; nb++) {
+    uint32_t b = p[i + nb];
+    if (nb == 9 && (b & 0xfe)) return false;
+    v |= (uint64_t)(b & 0x7f) << (7 * nb);
+    if (!(b & 0x80)) { nb++; return v <= MAX_SAFE_BIG; }
+  }
+  return false;
+}
+__device__ __forceinline__ bool key_sleb(const uint8_t* __restrict__ p, uint32_t i, uint32_t L, int64_t& out, uint32_t& nb) {
+  uint64_t v = 0;
+  for (nb = 0; nb < 10 && i + nb < L; nb++) {
+    uint32_t b = p[i + nb];
+    if (nb == 9 && b != 0 && b != 0x7f) return false;
+    v |= (uint64_t)(b & 0x7f) << (7 * nb);
+    if (!(b & 0x80)) {
+      nb++;
+      if ((b & 0x40) && 7 * nb < 64) v |= ~0ull << (7 * nb);
+      out = (int64_t)v;
+      return out <= (int64_t)MAX_SAFE_BIG && out >= -(int64_t)MAX_SAFE_BIG;
+    }
+  }
+  return false;
+}
+// where the string starting at i ends (NONE32: malformed / beyond the column)
+__device__ __forceinline__ uint32_t key_string_end(const uint8_t* __restrict__ p, uint32_t i, uint32_t L, uint32_t* off, uint32_t* len) {
+  uint64_t v;
+  uint32_t nb;
+  if (i >= L || !key_uleb(p, i, L, v, nb) || v > (uint64_t)(L - i - nb)) return NONE32;
+  if (off) { *off = i + nb; *len = (uint32_t)v; }
+  return i + nb + (uint32_t)v;
+}
+
+__global__ __launch_bounds__(BLOCK) void kk_init(const uint8_t* __restrict__ col, uint32_t L, KeyWork k) {
+  uint32_t i = gtid();
+  if (i > L + 1) return;
+  k.mark_h[i] = (i == 0 && L > 0) ? 1u : 0u;
+  k.mark_v[i] = 0;
+  k.rows[i] = 0;
+  if (i >= L) { k.vnext[i] = NONE32; k.hnext[i] = NONE32; k.kk[i] = 0; k.ja[i] = NONE32; return; }
+  uint32_t vn = key_string_end(col, i, L, nullptr, nullptr);
+  k.vnext[i] = vn;
+  k.ja[i] = vn;
+  int64_t cnt;
+  uint32_t hb;
+  uint32_t hn = NONE32, kc = 0;
+  if (key_sleb(col, i, L, cnt, hb)) {
+    uint32_t q = i + hb;
+    if (cnt > 1) hn = key_string_end(col, q, L, nullptr, nullptr);
+    else if (cnt == 0) {
+      uint64_t n;
+      uint32_t nb;
+      if (key_uleb(col, q, L, n, nb) && n > 0) hn = q + nb;
+    } else if (cnt < 0 && (uint64_t)(-cnt) <= (uint64_t)L && q < L) {
+      hn = q;  // advanced k times by the doubling rounds
+      kc = (uint32_t)(-cnt);
+    }
+  }
+  k.hnext[i] = hn;
+  k.kk[i] = kc;
+}
+
+// round r of the k-th-successor computation; jump tables double each round
+__global__ __launch_bounds__(BLOCK) void kk_kth_round(uint32_t L, int r, KeyWork k, const uint32_t* __restrict__ jin, uint32_t* __restrict__ jout) {
+  uint32_t i = gtid();
+  if (i > L) return;
+  if ((k.kk[i] >> r) & 1) {
+    uint32_t x = k.hnext[i];
+    k.hnext[i] = x == NONE32 ? NONE32 : jin[x];
+  }
+  uint32_t j = jin[i];
+  jout[i] = j == NONE32 ? NONE32 : jin[j];
+}
+
+__global__ __launch_bounds__(BLOCK) void kk_copy(uint32_t n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+  uint32_t i = gtid();
+  if (i < n) out[i] = in[i];
+}
+
+// generic marking round: a marked position marks its jump target (targets >= L are ends, never marked)
+__global__ __launch_bounds__(BLOCK) void kk_mark_round(uint32_t L, const uint32_t* __restrict__ jin, uint32_t* __restrict__ jout, uint32_t* __restrict__ mark) {
+  uint32_t i = gtid();
+  if (i >= L) { if (i <= L + 1) jout[i] = NONE32; return; }
+  uint32_t j = jin[i];
+  if (j < L) {
+    if (mark[i]) mark[j] = 1;
+    j = jin[j];
+  } else j = NONE32;
+  jout[i] = j;
+}
+
+// literal items: start marks on the first string of every true literal; jumps follow vnext but stop at a true header
+__global__ __launch_bounds__(BLOCK) void kk_item_init(const uint8_t* __restrict__ col, uint32_t L, KeyWork k, uint32_t* __restrict__ flags) {
+  uint32_t i = gtid();
+  if (i >= L) { if (i <= L + 1) k.ja[i] = NONE32; return; }
+  uint32_t vn = k.vnext[i];
+  k.ja[i] = (vn < L && !k.mark_h[vn]) ? vn : NONE32;
+  if (k.mark_h[i]) {
+    if (k.hnext[i] == NONE32 || k.hnext[i] > L) atomicOr(flags, (uint32_t)F_BAD_LEB);  // header that is not a well-formed record, or runs off the column
+    if (k.kk[i]) {
+      int64_t cnt;
+      uint32_t hb;
+      key_sleb(col, i, L, cnt, hb);
+      k.mark_v[i + hb] = 2;  // 2 = first value of its literal
+    }
+  }
+}
+
+// 1 for every run of the final table: repetitions and null runs sit on their header, literal values on their string
+__global__ __launch_bounds__(BLOCK) void kk_item_flags(uint32_t L, KeyWork k) {
+  uint32_t i = gtid();
+  if (i > L + 1) return;
+  uint32_t f = 0;
+  if (i < L) f = (k.mark_h[i] && !k.kk[i]) || k.mark_v[i] ? 1u : 0u;
+  k.item_ex[i] = f;
+}
+
+__global__ __launch_bounds__(BLOCK) void kk_items(const uint8_t* __restrict__ col, uint32_t col_abs, uint32_t L, KeyWork k, uint32_t* __restrict__ flags) {
+  uint32_t i = gtid();
+  if (i >= L) return;
+  bool is_h = k.mark_h[i] && !k.kk[i], is_v = k.mark_v[i] != 0;
+  if (!is_h && !is_v) return;
+  uint32_t idx = k.item_ex[i];
+  uint32_t off = 0, len = NONE32, rows = 1;
+  if (is_v) key_string_end(col, i, L, &off, &len);
+  else {
+    int64_t cnt = 0;
+    uint32_t hb = 0;
+    key_sleb(col, i, L, cnt, hb);
+    if (cnt > 1) {
+      key_string_end(col, i + hb, L, &off, &len);
+      rows = cnt > 0x7ffffff0ll ? 0 : (uint32_t)cnt;
+      if (!rows) atomicOr(flags, (uint32_t)F_OVERFLOW);
+    } else {
+      uint64_t n = 0;
+      uint32_t nb;
+      key_uleb(col, i + hb, L, n, nb);
+      rows = n > 0x7ffffff0ull ? 0 : (uint32_t)n;
+      if (!rows) atomicOr(flags, (uint32_t)F_OVERFLOW);
+    }
+  }
+  k.rows[idx] = rows;
+  k.run_off[idx] = len == NONE32 ? 0 : col_abs + off;
+  k.run_len[idx] = len;
+  k.run_kind[idx] = is_v ? k.mark_v[i] : 0;  // 0 record on its own, 1 later literal value, 2 first literal value
+  // canonical form (encoding.js:865-887): no two null runs in a row, no value equal to its predecessor -- checked
+  // between neighbouring runs by kk_run_pairs once the table is complete
+}
+
+__global__ __launch_bounds__(BLOCK) void kk_run_pairs(const uint8_t* __restrict__ arena, KeyWork k, uint32_t* __restrict__ flags) {
+  uint32_t r = gtid();
+  uint32_t n = *k.n_runs;
+  if (r == 0 || r >= n) return;
+  uint32_t la = k.run_len[r - 1], lb = k.run_len[r];
+  if (k.run_kind[r] == 2 && k.run_kind[r - 1] != 0) { atomicOr(flags, (uint32_t)F_BAD_RLE); return; }  // two literals in a row
+  if (la == NONE32 && lb == NONE32) { atomicOr(flags, (uint32_t)F_BAD_RLE); return; }
+  if (la != lb || la == NONE32) return;
+  const uint8_t *a = arena + k.run_off[r - 1], *b = arena + k.run_off[r];
+  for (uint32_t j = 0; j < la; j++)
+    if (a[j] != b[j]) return;
+  atomicOr(flags, (uint32_t)F_BAD_RLE);
+}
+
+size_t keystr_work_bytes(uint32_t col_len) {
+  size_t cap = (size_t)col_len + 2;
+  return 13 * al256(4 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + 256;
+}
+
+void keystr_index(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len,
+                  uint32_t* n_runs, uint32_t* flags, hipStream_t st) {
+  uint32_t L = col_len, cap = L + 2;
+  KeyWork k;
+  uint8_t* p = (uint8_t*)work;
+  auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
+  uint32_t** arrs[] = {&k.vnext, &k.hnext, &k.kk, &k.ja, &k.jb, &k.mark_h, &k.mark_v, &k.item_ex, &k.rows, &k.run_start, &k.run_off, &k.run_len, &k.run_kind};
+  for (uint32_t** a : arrs) *a = (uint32_t*)take(4 * (size_t)cap);
+  k.scan_ws = take(scan_workspace_bytes(cap));
+  k.n_runs = n_runs;
+  *run_start = k.run_start; *run_off = k.run_off; *run_len = k.run_len;
+  const uint8_t* col = arena + col_abs;
+  int rounds = 1;
+  while (rounds < 32 && (L >> rounds)) rounds++;
+  AM355_LAUNCH_INDEPENDENT(kk_init, grid_for(cap), dim3(BLOCK), st, col, L, k);
+  uint32_t *j0 = k.ja, *j1 = k.jb;
+  auto swap = [&]() { uint32_t* t = j0; j0 = j1; j1 = t; };
+  for (int r = 0; r < rounds; r++) {  // 1. k-th successors
+    AM355_LAUNCH_INDEPENDENT(kk_kth_round, grid_for(L + 1), dim3(BLOCK), st, L, r, k, (const uint32_t*)j0, j1);
+    swap();
+  }
+  AM355_LAUNCH_INDEPENDENT(kk_copy, grid_for(cap), dim3(BLOCK), st, cap, (const uint32_t*)k.hnext, j0);
+  for (int r = 0; r < rounds; r++) {  // 2. true headers
+    AM355_LAUNCH_INDEPENDENT(kk_mark_round, grid_for(cap), dim3(BLOCK), st, L, (const uint32_t*)j0, j1, k.mark_h);
+    swap();
+  }
+  {
+    KeyWork k2 = k;
+    k2.ja = j0;  // kk_item_init writes the literal-item jump table into the current buffer
+    AM355_LAUNCH_INDEPENDENT(kk_item_init, grid_for(cap), dim3(BLOCK), st, col, L, k2, flags);
+  }
+  for (int r = 0; r < rounds; r++) {  // 3. literal items
+    AM355_LAUNCH_INDEPENDENT(kk_mark_round, grid_for(cap), dim3(BLOCK), st, L, (const uint32_t*)j0, j1, k.mark_v);
+    swap();
+  }
+  AM355_LAUNCH_INDEPENDENT(kk_item_flags, grid_for(cap), dim3(BLOCK), st, L, k);
+  exclusive_scan_u32(k.item_ex, k.item_ex, cap, k.n_runs, k.scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kk_items, grid_for(L), dim3(BLOCK), st, col, col_abs, L, k, flags);
+  exclusive_scan_u32(k.rows, k.run_start, cap, nullptr, k.scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kk_run_pairs, grid_for(cap), dim3(BLOCK), st, arena, k, flags);
+}
+
 }  // namespace am355

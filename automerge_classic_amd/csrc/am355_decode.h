@@ -21,9 +21,7 @@ bool decode_fits_wave(const ChangeMeta& m);
 void launch_doc_count(const uint8_t* arena, ChangeMeta* meta, hipStream_t st);
 void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const ChangePlan* plan, const uint32_t* actor_rank, OpCols cols,
                             uint32_t* flags, hipStream_t st);  // host: can this change use the wave-per-change decoder?
-// document keyStr column: run table by one lane (one step per record / literal value), then one lane per row
-void launch_keystr_runs(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, uint32_t* run_start, uint32_t* run_off, uint32_t* run_len,
-                        uint32_t* n_runs, uint32_t* flags, hipStream_t st);
+// document keyStr column: key_off / key_len of every row from the run table built by keystr_index (am355_bigcol.hip)
 void launch_keystr_expand(const uint32_t* run_start, const uint32_t* run_off, const uint32_t* run_len, const uint32_t* n_runs, uint32_t n_rows,
                           uint32_t* key_off, uint32_t* key_len, hipStream_t st);
 }  // namespace am355

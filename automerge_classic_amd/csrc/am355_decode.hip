@@ -1456,68 +1456,6 @@ void launch_doc_count(const uint8_t* arena, ChangeMeta* meta, hipStream_t st) {
   AM355_LAUNCH_INDEPENDENT(k_doc_count, dim3(1), dim3(WAVE), st, arena, meta);
 }
 
-// keyStr column of a document -> run table. The string bytes are not LEB tokens, so one lane walks the column: one step
-// per RECORD (a repetition of any length, a null run) or per literal value. run_start has n_runs + 1 entries.
-__global__ __launch_bounds__(WAVE) void k_keystr_runs(const uint8_t* __restrict__ arena, uint32_t col_abs, uint32_t col_len, uint32_t* __restrict__ run_start,
-                                                      uint32_t* __restrict__ run_off, uint32_t* __restrict__ run_len, uint32_t* __restrict__ n_runs_out,
-                                                      uint32_t* __restrict__ flags) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Cur c(arena + col_abs, 0, col_len);
-  int state = 0;  // 0 none, 1 repetition, 2 literal, 3 nulls (encoding.js:865-887)
-  bool have_last = false;
-  uint32_t last_off = 0, last_len = 0, nr = 0, e = 0;
-  int64_t lit_left = 0;
-  uint64_t rows = 0;
-  auto same = [&](uint32_t off, uint32_t len) { return have_last && last_len == len && bytes_equal(c.p, last_off, off, len, c.len); };
-  while (!e && (lit_left > 0 || c.off < c.len)) {
-    uint32_t off = 0, len = 0;
-    uint64_t count = 1;
-    bool nul = false;
-    if (lit_left > 0) {
-      uint64_t l;
-      if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
-      off = c.off; len = (uint32_t)l;
-      if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
-      if (same(off, len)) { e = F_BAD_RLE; break; }
-      have_last = true; last_off = off; last_len = len;
-      lit_left--;
-    } else {
-      int64_t cnt;
-      if (!read_sleb(c, cnt)) { e = F_BAD_LEB; break; }
-      if (cnt > 1) {
-        uint64_t l;
-        if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
-        off = c.off; len = (uint32_t)l;
-        if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
-        if ((state == 1 || state == 2) && same(off, len)) { e = F_BAD_RLE; break; }
-        state = 1; have_last = true; last_off = off; last_len = len;
-        count = (uint64_t)cnt;
-      } else if (cnt == 1) { e = F_BAD_RLE; break; }
-      else if (cnt < 0) {
-        if (state == 2) { e = F_BAD_RLE; break; }
-        state = 2; lit_left = -cnt;
-        continue;
-      } else {
-        uint64_t z;
-        if (state == 3) { e = F_BAD_RLE; break; }
-        if (!read_uleb(c, z)) { e = F_BAD_LEB; break; }
-        if (z == 0) { e = F_BAD_RLE; break; }
-        state = 3; have_last = false;
-        nul = true; count = z;
-      }
-    }
-    if (rows + count > 0xfffffff0ull) { e = F_OVERFLOW; break; }
-    run_start[nr] = (uint32_t)rows;
-    run_off[nr] = nul ? 0 : col_abs + off;
-    run_len[nr] = nul ? NONE32 : len;
-    nr++;
-    rows += count;
-  }
-  run_start[nr] = (uint32_t)rows;
-  *n_runs_out = nr;
-  if (e) atomicOr(flags, e);
-}
-
 // key_off / key_len of every row from the run table (rows past the end of the column are null, encoding.js:821)
 __global__ __launch_bounds__(BLOCK) void k_keystr_expand(const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ run_off,
                                                           const uint32_t* __restrict__ run_len, const uint32_t* __restrict__ n_runs_p, uint32_t n_rows,
@@ -1539,10 +1477,6 @@ __global__ __launch_bounds__(BLOCK) void k_keystr_expand(const uint32_t* __restr
   key_len[row] = len;
 }
 
-void launch_keystr_runs(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, uint32_t* run_start, uint32_t* run_off, uint32_t* run_len,
-                        uint32_t* n_runs, uint32_t* flags, hipStream_t st) {
-  AM355_LAUNCH_INDEPENDENT(k_keystr_runs, dim3(1), dim3(WAVE), st, arena, col_abs, col_len, run_start, run_off, run_len, n_runs, flags);
-}
 void launch_keystr_expand(const uint32_t* run_start, const uint32_t* run_off, const uint32_t* run_len, const uint32_t* n_runs, uint32_t n_rows,
                           uint32_t* key_off, uint32_t* key_len, hipStream_t st) {
   if (!n_rows) return;

@@ -633,6 +633,25 @@ __global__ __launch_bounds__(BLOCK) void k_doc_resolve(MergeBufs b, const unsign
     uint32_t oi = obj_index_of(b, orow);
     if (atomicCAS(&obj_first[oi], NONE32, g) != NONE32) err |= F_UNSUPPORTED;  // the rows of one object must be contiguous
   }
+  // canonical row order (the order save() writes: columnar.js:892, new.js:2047): objects ascending by id with _root
+  // first, map keys ascending in UTF-16 order, the ops of one key / element ascending by id. Anything else is legal
+  // input the reference treats row by row; it is left to the JS path.
+  if (g > 0) {
+    unsigned long long prev_id = pack_id(o.id_ctr[g - 1], o.id_actor[g - 1]), my_id = pack_id(o.id_ctr[g], o.id_actor[g]);
+    if (new_obj) {
+      bool prev_root = o.obj_actor[g - 1] == NONE32, cur_root = o.obj_actor[g] == NONE32;
+      if (cur_root || (!prev_root && pack_id(o.obj_ctr[g - 1], o.obj_actor[g - 1]) >= pack_id(o.obj_ctr[g], o.obj_actor[g]))) err |= F_UNSUPPORTED;
+    } else if (kind == K_MAP && b.kind[g - 1] == K_MAP) {
+      if (o.key_off[g - 1] == o.key_off[g] || same_key(b, g - 1, g)) { if (prev_id >= my_id) err |= F_UNSUPPORTED; }
+      else {
+        const uint8_t *p = b.arena + o.key_off[g - 1], *q = b.arena + o.key_off[g];
+        uint32_t lp = o.key_len[g - 1], lq = o.key_len[g], k = 0;
+        while (k < lp && k < lq && p[k] == q[k]) k++;
+        bool less = k == lp ? k < lq : (k < lq && utf16_order_byte(p[k]) < utf16_order_byte(q[k]));
+        if (!less) err |= F_UNSUPPORTED;
+      }
+    } else if (kind == K_LIST_UPD && prev_id >= my_id) err |= F_UNSUPPORTED;
+  }
   uint32_t ref = NONE32;
   if (kind == K_LIST_UPD) {
     uint32_t before = ins_ex[g];  // list-insert rows before g: the update belongs to the latest one

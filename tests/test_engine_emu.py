@@ -152,3 +152,40 @@ def test_document_columns_parallel_equals_serial(eng, monkeypatch):
         got.append(eng.rows())
     for k in got[0]:
         assert np.array_equal(got[0][k], got[1][k]), k
+
+
+def _mutated_documents(n, seed):
+    """Single-byte mutations in the op columns of an uncompressed document, container checksum repaired."""
+    import hashlib
+    import random
+    doc, _ = loggen.generate_document(n_actors=4, n_texts=2, text_len=60, n_maps=2, keys_per_map=25, n_submaps=2, n_lists=2, list_len=40,
+                                      deflate=False, seed=77)
+    rng = random.Random(seed)
+    for _ in range(n):
+        d = bytearray(doc)
+        pos = rng.randrange(len(d) // 3, len(d))
+        d[pos] = rng.randrange(256)
+        d[4:8] = hashlib.sha256(bytes(d[8:])).digest()[:4]
+        yield pos, bytes(d)
+
+
+def test_mutated_documents_never_disagree_with_the_oracle(eng):
+    """Whatever a damaged document decodes to, the engine either rejects it (the JS host then runs the reference path)
+    or produces exactly the oracle's patch; it never accepts what the oracle rejects."""
+    agree = 0
+    for pos, d in _mutated_documents(200, 5):
+        try:
+            want = oracle_lib.OracleDoc.load_document(d).patch_json()
+        except oracle_lib.OracleError:
+            want = None
+        try:
+            eng.load_document(d)
+            eng.replay()
+            got = eng.patch_json()
+        except engine.EngineError:
+            got = None
+        if got is not None:
+            assert want is not None, f"engine accepted a document the oracle rejects (byte {pos})"
+            assert got == want, f"different patch for mutation at byte {pos}"
+            agree += 1
+    assert agree > 20
