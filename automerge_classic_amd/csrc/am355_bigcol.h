@@ -29,6 +29,7 @@ struct BigColWork {
   uint32_t *term_ex, *tok_end, *tok_lo, *tok_hi, *jump_a, *jump_b, *mark, *rec_ex, *rec_tok, *rec_rows, *rec_start;  // [cap]
   uint16_t* tok_meta;                                                                                           // [cap] byte count | last byte << 8
   void* scan_ws;                                                                                                // scan_workspace_bytes(cap)
+  void* chain_ws;                                                                                               // chain_work_bytes(cap)
   BigColInfo* info;                                                                                             // device
 };
 size_t bigcol_work_bytes(uint32_t tok_bytes);

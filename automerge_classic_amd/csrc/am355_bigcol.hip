@@ -22,7 +22,7 @@ constexpr uint64_t MAX_SAFE_BIG = 9007199254740991ull;
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 size_t bigcol_work_bytes(uint32_t tok_bytes) {
   size_t cap = (size_t)tok_bytes + 2;
-  return 11 * al256(4 * cap) + al256(2 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + al256(sizeof(BigColInfo));
+  return 11 * al256(4 * cap) + al256(2 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + al256(sizeof(BigColInfo)) + al256(chain_work_bytes((uint32_t)cap));
 }
 void bigcol_carve(BigColWork& w, void* base, uint32_t tok_bytes) {
   size_t cap = (size_t)tok_bytes + 2;
@@ -33,6 +33,7 @@ void bigcol_carve(BigColWork& w, void* base, uint32_t tok_bytes) {
   w.tok_meta = (uint16_t*)take(2 * cap);
   w.scan_ws = take(scan_workspace_bytes((uint32_t)cap));
   w.info = (BigColInfo*)take(sizeof(BigColInfo));
+  w.chain_ws = take(chain_work_bytes((uint32_t)cap));
 }
 size_t bigcol_vals_bytes(uint32_t n_rows, uint32_t n_succ) {
   size_t n = (size_t)n_rows + 1, p = (size_t)n_succ + 1;
@@ -121,20 +122,6 @@ __global__ __launch_bounds__(BLOCK) void kb_token_values(const uint8_t* __restri
   w.mark[t] = t == t0 ? 1u : 0u;
 }
 
-// pointer doubling: a marked token marks the header 2^round records ahead. Marks only ever land on true headers, so
-// reading marks written in the same round is harmless.
-__global__ __launch_bounds__(BLOCK) void kb_double(const BigColInfo* __restrict__ info, const uint32_t* __restrict__ jump_in, uint32_t* __restrict__ jump_out,
-                                                   uint32_t* __restrict__ mark) {
-  uint32_t t = gtid();
-  if (t >= info->n_tokens) return;
-  uint32_t j = jump_in[t];
-  if (j != NONE32) {
-    if (mark[t]) mark[j] = 1;
-    j = jump_in[j];
-  }
-  jump_out[t] = j;
-}
-
 // ---- records ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void kb_records(BigColDesc d, uint32_t cap, BigColWork w) {
   uint32_t t = gtid();
@@ -203,15 +190,7 @@ void bigcol_index(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipS
   AM355_LAUNCH_INDEPENDENT(kb_col_ranges, dim3(1), dim3(WAVE), st, d, (const uint32_t*)w.term_ex, w.info);
   AM355_LAUNCH_INDEPENDENT(kb_token_ends, grid_for(L), dim3(BLOCK), st, arena, L, (const uint32_t*)w.term_ex, w.tok_end);
   AM355_LAUNCH_INDEPENDENT(kb_token_values, grid_for(cap), dim3(BLOCK), st, arena, d, cap, w);
-  int rounds = 1;
-  while (rounds < 32 && (L >> rounds)) rounds++;
-  uint32_t *j0 = w.jump_a, *j1 = w.jump_b;
-  for (int r = 0; r < rounds; r++) {
-    AM355_LAUNCH_INDEPENDENT(kb_double, grid_for(L + 1), dim3(BLOCK), st, (const BigColInfo*)w.info, (const uint32_t*)j0, j1, w.mark);
-    uint32_t* t = j0;
-    j0 = j1;
-    j1 = t;
-  }
+  chain_mark(w.jump_a, cap, w.mark, w.chain_ws, st);  // record headers = orbit of each column's first number
   exclusive_scan_u32(w.mark, w.rec_ex, cap, &w.info->n_records, w.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(kb_records, grid_for(cap), dim3(BLOCK), st, d, cap, w);
   AM355_LAUNCH_INDEPENDENT(kb_record_pairs, grid_for(cap), dim3(BLOCK), st, d, w);
@@ -462,23 +441,6 @@ __global__ __launch_bounds__(BLOCK) void kk_kth_round(uint32_t L, int r, KeyWork
   jout[i] = j == NONE32 ? NONE32 : jin[j];
 }
 
-__global__ __launch_bounds__(BLOCK) void kk_copy(uint32_t n, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
-  uint32_t i = gtid();
-  if (i < n) out[i] = in[i];
-}
-
-// generic marking round: a marked position marks its jump target (targets >= L are ends, never marked)
-__global__ __launch_bounds__(BLOCK) void kk_mark_round(uint32_t L, const uint32_t* __restrict__ jin, uint32_t* __restrict__ jout, uint32_t* __restrict__ mark) {
-  uint32_t i = gtid();
-  if (i >= L) { if (i <= L + 1) jout[i] = NONE32; return; }
-  uint32_t j = jin[i];
-  if (j < L) {
-    if (mark[i]) mark[j] = 1;
-    j = jin[j];
-  } else j = NONE32;
-  jout[i] = j;
-}
-
 // literal items: start marks on the first string of every true literal; jumps follow vnext but stop at a true header
 __global__ __launch_bounds__(BLOCK) void kk_item_init(const uint8_t* __restrict__ col, uint32_t L, KeyWork k, uint32_t* __restrict__ flags) {
   uint32_t i = gtid();
@@ -553,7 +515,7 @@ __global__ __launch_bounds__(BLOCK) void kk_run_pairs(const uint8_t* __restrict_
 
 size_t keystr_work_bytes(uint32_t col_len) {
   size_t cap = (size_t)col_len + 2;
-  return 13 * al256(4 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + 256;
+  return 13 * al256(4 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + al256(chain_work_bytes((uint32_t)cap)) + 256;
 }
 
 void keystr_index(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len,
@@ -565,6 +527,7 @@ void keystr_index(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void
   uint32_t** arrs[] = {&k.vnext, &k.hnext, &k.kk, &k.ja, &k.jb, &k.mark_h, &k.mark_v, &k.item_ex, &k.rows, &k.run_start, &k.run_off, &k.run_len, &k.run_kind};
   for (uint32_t** a : arrs) *a = (uint32_t*)take(4 * (size_t)cap);
   k.scan_ws = take(scan_workspace_bytes(cap));
+  void* chain_ws = take(chain_work_bytes(cap));
   k.n_runs = n_runs;
   *run_start = k.run_start; *run_off = k.run_off; *run_len = k.run_len;
   const uint8_t* col = arena + col_abs;
@@ -577,20 +540,9 @@ void keystr_index(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void
     AM355_LAUNCH_INDEPENDENT(kk_kth_round, grid_for(L + 1), dim3(BLOCK), st, L, r, k, (const uint32_t*)j0, j1);
     swap();
   }
-  AM355_LAUNCH_INDEPENDENT(kk_copy, grid_for(cap), dim3(BLOCK), st, cap, (const uint32_t*)k.hnext, j0);
-  for (int r = 0; r < rounds; r++) {  // 2. true headers
-    AM355_LAUNCH_INDEPENDENT(kk_mark_round, grid_for(cap), dim3(BLOCK), st, L, (const uint32_t*)j0, j1, k.mark_h);
-    swap();
-  }
-  {
-    KeyWork k2 = k;
-    k2.ja = j0;  // kk_item_init writes the literal-item jump table into the current buffer
-    AM355_LAUNCH_INDEPENDENT(kk_item_init, grid_for(cap), dim3(BLOCK), st, col, L, k2, flags);
-  }
-  for (int r = 0; r < rounds; r++) {  // 3. literal items
-    AM355_LAUNCH_INDEPENDENT(kk_mark_round, grid_for(cap), dim3(BLOCK), st, L, (const uint32_t*)j0, j1, k.mark_v);
-    swap();
-  }
+  chain_mark(k.hnext, L, k.mark_h, chain_ws, st);  // 2. true headers
+  AM355_LAUNCH_INDEPENDENT(kk_item_init, grid_for(cap), dim3(BLOCK), st, col, L, k, flags);
+  chain_mark(k.ja, L, k.mark_v, chain_ws, st);     // 3. literal items
   AM355_LAUNCH_INDEPENDENT(kk_item_flags, grid_for(cap), dim3(BLOCK), st, L, k);
   exclusive_scan_u32(k.item_ex, k.item_ex, cap, k.n_runs, k.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(kk_items, grid_for(L), dim3(BLOCK), st, col, col_abs, L, k, flags);

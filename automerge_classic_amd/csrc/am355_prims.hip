@@ -216,4 +216,162 @@ int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint3
   return cur;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// forward chain marking. next[i] is a position > i (or >= n / NONE32 = end of chain); mark[] holds start nodes; on
+// return mark[] is nonzero on every node reachable from a start. (Record headers of a column are the orbit of its first
+// number under "skip this record"; document columns: am355_bigcol.hip.)
+//
+// Plain pointer doubling costs log2(n) passes over all n nodes. Chains only move forward, so they are cut into tiles
+// of CH_TILE positions instead:
+//   1. per tile, in LDS: exit[i] = first position outside the tile on i's chain (pointer doubling inside the tile).
+//      The distinct exit targets are few per tile (chains merge within a few hops) -- they are the only positions
+//      through which a chain can enter a later tile.
+//   2. compact the exit targets (flag + prefix sum) into M << n nodes linked by exit[]; mark the ones reachable from
+//      the starts' exits by pointer doubling over M nodes, log2(n / CH_TILE) rounds.
+//   3. per tile, in LDS again: marks spread from the tile's start nodes and marked entry nodes along next[].
+// HBM traffic: a handful of passes over n instead of log2(n).
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t CH_TILE = 4096;
+constexpr uint32_t CH_PER = CH_TILE / BLOCK;
+constexpr int CH_ROUNDS = 12;  // 2^12 = CH_TILE
+
+__global__ __launch_bounds__(BLOCK) void kc_tile_exits(const uint32_t* __restrict__ next, uint32_t n, const uint32_t* __restrict__ mark,
+                                                       uint32_t* __restrict__ exit1, uint32_t* __restrict__ flag, uint32_t* __restrict__ cstart) {
+  __shared__ uint32_t cur[CH_TILE];
+  uint32_t base = blockIdx.x * CH_TILE, t = threadIdx.x;
+  uint32_t end = base + CH_TILE < n ? base + CH_TILE : n;
+  for (uint32_t k = 0; k < CH_PER; k++) {
+    uint32_t l = t + k * BLOCK, g = base + l;
+    uint32_t c = g < n ? next[g] : NONE32;
+    cur[l] = (c >= n || c <= g) ? NONE32 : c;  // a chain that does not move forward ends (callers guarantee next > i)
+  }
+  __syncthreads();
+  // in place: every value is always some node further along the same chain, so stale reads only slow the doubling down
+  for (int r = 0; r < CH_ROUNDS; r++) {
+    for (uint32_t k = 0; k < CH_PER; k++) {
+      uint32_t l = t + k * BLOCK;
+      uint32_t c = cur[l];
+      if (c < end) cur[l] = cur[c - base];
+    }
+    __syncthreads();
+  }
+  for (uint32_t k = 0; k < CH_PER; k++) {
+    uint32_t l = t + k * BLOCK, g = base + l;
+    if (g >= n) continue;
+    uint32_t c = cur[l];
+    exit1[g] = c;
+    if (c < n) {
+      flag[c] = 1;
+      if (mark[g]) cstart[c] = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void kc_compact(uint32_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ ex, const uint32_t* __restrict__ exit1,
+                                                    const uint32_t* __restrict__ cstart, uint32_t* __restrict__ cpos, uint32_t* __restrict__ cnext,
+                                                    uint32_t* __restrict__ cmark) {
+  uint32_t i = gtid();
+  if (i >= n || !flag[i]) return;
+  uint32_t id = ex[i], e = exit1[i];
+  cpos[id] = i;
+  cnext[id] = e < n ? ex[e] : NONE32;
+  cmark[id] = cstart[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void kc_round(const uint32_t* __restrict__ n_nodes, const uint32_t* __restrict__ jin, uint32_t* __restrict__ jout,
+                                                  uint32_t* __restrict__ cmark) {
+  uint32_t m_total = *n_nodes;
+  for (uint32_t m = gtid(); m < m_total; m += gridDim.x * BLOCK) {
+    uint32_t j = jin[m];
+    if (j != NONE32) {
+      if (cmark[m]) cmark[j] = 1;
+      j = jin[j];
+    }
+    jout[m] = j;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void kc_entries(const uint32_t* __restrict__ n_nodes, const uint32_t* __restrict__ cpos, const uint32_t* __restrict__ cmark,
+                                                    uint32_t* __restrict__ mark) {
+  uint32_t m_total = *n_nodes;
+  for (uint32_t m = gtid(); m < m_total; m += gridDim.x * BLOCK)
+    if (cmark[m] && !mark[cpos[m]]) mark[cpos[m]] = 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void kc_tile_marks(const uint32_t* __restrict__ next, uint32_t n, uint32_t* __restrict__ mark) {
+  __shared__ uint16_t ja[CH_TILE], jb[CH_TILE];
+  __shared__ uint8_t mk[CH_TILE];
+  __shared__ uint32_t any;
+  uint32_t base = blockIdx.x * CH_TILE, t = threadIdx.x;
+  uint32_t end = base + CH_TILE < n ? base + CH_TILE : n;
+  if (t == 0) any = 0;
+  __syncthreads();
+  uint32_t have = 0;
+  for (uint32_t k = 0; k < CH_PER; k++) {
+    uint32_t l = t + k * BLOCK, g = base + l;
+    uint32_t c = g < n ? next[g] : NONE32;
+    ja[l] = (c < end && c > g) ? (uint16_t)(c - base) : (uint16_t)0xffff;
+    uint32_t m = g < n ? mark[g] : 0;
+    mk[l] = m ? 1 : 0;
+    have |= m;
+  }
+  if (have) any = 1;
+  __syncthreads();
+  if (!any) return;  // no chain passes through this tile
+  uint16_t *jin = ja, *jout = jb;
+  for (int r = 0; r < CH_ROUNDS; r++) {
+    for (uint32_t k = 0; k < CH_PER; k++) {
+      uint32_t l = t + k * BLOCK;
+      uint32_t j = jin[l];
+      if (j != 0xffff) {
+        if (mk[l]) mk[j] = 1;
+        j = jin[j];
+      }
+      jout[l] = (uint16_t)j;
+    }
+    __syncthreads();
+    uint16_t* s = jin;
+    jin = jout;
+    jout = s;
+  }
+  for (uint32_t k = 0; k < CH_PER; k++) {
+    uint32_t l = t + k * BLOCK, g = base + l;
+    if (g < n && mk[l] && !mark[g]) mark[g] = 1;
+  }
+}
+
+size_t chain_work_bytes(uint32_t n) {
+  size_t cap = ((size_t)n + 2 + 63) & ~(size_t)63;
+  return 8 * 4 * cap + scan_workspace_bytes(n + 2) + 512;
+}
+
+void chain_mark(const uint32_t* next, uint32_t n, uint32_t* mark, void* work, hipStream_t st) {
+  if (!n) return;
+  size_t cap = ((size_t)n + 2 + 63) & ~(size_t)63;
+  uint32_t* p = (uint32_t*)work;
+  uint32_t *exit1 = p, *flag = p + cap, *cstart = p + 2 * cap, *ex = p + 3 * cap, *cpos = p + 4 * cap, *ca = p + 5 * cap, *cb = p + 6 * cap, *cmark = p + 7 * cap;
+  uint32_t* n_nodes = p + 8 * cap;
+  void* scan_ws = (void*)(n_nodes + 64);
+  uint32_t tiles = (n + CH_TILE - 1) / CH_TILE;
+  (void)hipMemsetAsync(flag, 0, 2 * 4 * cap, st);  // flag and cstart
+  hipLaunchKernelGGL(kc_tile_exits, dim3(tiles), dim3(BLOCK), 0, st, next, n, (const uint32_t*)mark, exit1, flag, cstart);
+  exclusive_scan_u32(flag, ex, n + 1, n_nodes, scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kc_compact, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, n, (const uint32_t*)flag, (const uint32_t*)ex, (const uint32_t*)exit1,
+                           (const uint32_t*)cstart, cpos, ca, cmark);
+  // a compact chain visits every tile at most once
+  int rounds = 1;
+  while (rounds < 32 && ((tiles + 1) >> rounds)) rounds++;
+  uint32_t blocks = (n / 8 + BLOCK - 1) / BLOCK;
+  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+  for (int r = 0; r < rounds; r++) {
+    AM355_LAUNCH_INDEPENDENT(kc_round, dim3(blocks), dim3(BLOCK), st, (const uint32_t*)n_nodes, (const uint32_t*)ca, cb, cmark);
+    uint32_t* t = ca;
+    ca = cb;
+    cb = t;
+  }
+  AM355_LAUNCH_INDEPENDENT(kc_entries, dim3(blocks), dim3(BLOCK), st, (const uint32_t*)n_nodes, (const uint32_t*)cpos, (const uint32_t*)cmark, mark);
+  hipLaunchKernelGGL(kc_tile_marks, dim3(tiles), dim3(BLOCK), 0, st, next, n, mark);
+}
+
 }  // namespace am355
