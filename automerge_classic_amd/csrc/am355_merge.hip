@@ -425,33 +425,66 @@ __global__ __launch_bounds__(BLOCK) void k_child_link(MergeBufs b, uint32_t n, c
   b.next_sib[v] = (!last || (is_head && j + 1 < n)) ? sorted[j + 1] : NONE32;
 }
 
-// Euler tour of the insertion forest: enter(v) = 2v, leave(v) = 2v+1; END = 2N. Each list entry is one 64-bit word
-// (successor in the low half, weight-to-end in the high half) so a pointer-jumping round is one coalesced 8-byte
-// read, one random 8-byte read and one coalesced 8-byte write per entry. Entries of rows that are not list elements
-// point at END and cost only the coalesced traffic.
+// Euler tour of the insertion forest over typing runs (below): enter(run k) = 2k, leave(run k) = 2k+1; END = 2 x runs.
+// Each list entry is one 64-bit word (successor in the low half, weight-to-end in the high half) so a pointer-jumping
+// round is one coalesced 8-byte read, one random 8-byte read and one coalesced 8-byte write per entry.
 __device__ __forceinline__ unsigned long long euler_pack(uint32_t succ, uint32_t dist) { return (unsigned long long)dist << 32 | succ; }
 
-__global__ __launch_bounds__(BLOCK) void k_euler_init(MergeBufs b, unsigned long long* __restrict__ el) {
-  uint32_t v = gtid();
-  uint32_t END = 2 * b.n_ops;
-  if (v == 0) el[END] = euler_pack(END, 0);
-  if (v >= b.n_ops) return;
-  if (b.kind[v] != K_LIST_INS) {
-    el[2 * (size_t)v] = euler_pack(END, 0);
-    el[2 * (size_t)v + 1] = euler_pack(END, 0);
-    return;
+// Typing runs. Most elements of a text have exactly one child, inserted right after them (the next character typed):
+// then enter(v) -> enter(child) and leave(child) -> leave(v) are forced links, and a maximal run of such elements can
+// enter the tour as ONE pair of entries whose enter edge weighs the run's length. Runs are consecutive in the insert
+// list (ins_row), so a run is [heads[k], heads[k+1]) there. The tour shrinks from 2 x elements to 2 x runs entries
+// (x100 for typical typing), and the pointer-jumping rounds with it.
+__global__ __launch_bounds__(BLOCK) void k_run_flags(MergeBufs b, uint32_t n, uint32_t* __restrict__ is_head) {
+  uint32_t i = gtid();
+  if (i > n) return;
+  uint32_t head = i < n ? 1u : 0u;
+  if (i > 0 && i < n) {
+    uint32_t v = b.ins_row[i], prev = b.ins_row[i - 1];
+    if (b.ref_row[v] == prev && b.first_child[prev] == v && b.next_sib[v] == NONE32) head = 0;  // v is the only child of its predecessor
   }
-  uint32_t fc = b.first_child[v];
-  uint32_t ns = b.next_sib[v], ref = b.ref_row[v];
-  el[2 * (size_t)v] = euler_pack(fc != NONE32 ? 2 * fc : 2 * v + 1, 1);
-  el[2 * (size_t)v + 1] = euler_pack(ns != NONE32 ? 2 * ns : (ref != NONE32 ? 2 * ref + 1 : END), 0);
+  is_head[i] = head;
 }
 
-// one pointer-jumping round (Wyllie): dist'[x] = dist[x] + dist[succ[x]], succ'[x] = succ[succ[x]]
-__global__ __launch_bounds__(BLOCK) void k_euler_jump(uint32_t n_entries, uint32_t END, const unsigned long long* __restrict__ in,
+// heads[k] = first insert-list index of run k (heads[H] = n); row_run[] = run of a row, kept for run heads and tails
+// only (the rows other runs refer to: a first child and a next sibling are always heads, a parent is always a tail)
+__global__ __launch_bounds__(BLOCK) void k_run_heads(MergeBufs b, uint32_t n, const uint32_t* __restrict__ is_head, const uint32_t* __restrict__ head_ex,
+                                                     uint32_t* __restrict__ heads, uint32_t* __restrict__ row_run) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  if (is_head[i]) {
+    uint32_t k = head_ex[i];
+    heads[k] = i;
+    row_run[b.ins_row[i]] = k;
+    if (i > 0) row_run[b.ins_row[i - 1]] = k - 1;
+  }
+  if (i + 1 == n) {
+    uint32_t H = head_ex[i] + is_head[i];
+    heads[H] = n;
+    row_run[b.ins_row[i]] = H - 1;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_euler_init_runs(MergeBufs b, const uint32_t* __restrict__ n_runs, const uint32_t* __restrict__ heads,
+                                                           const uint32_t* __restrict__ row_run, unsigned long long* __restrict__ el) {
+  uint32_t k = gtid();
+  uint32_t H = *n_runs, END = 2 * H;
+  if (k == 0) el[END] = euler_pack(END, 0);
+  if (k >= H) return;
+  uint32_t i0 = heads[k], i1 = heads[k + 1];
+  uint32_t h = b.ins_row[i0], t = b.ins_row[i1 - 1];
+  uint32_t fc = b.first_child[t], ns = b.next_sib[h], ref = b.ref_row[h];
+  el[2 * (size_t)k] = euler_pack(fc != NONE32 ? 2 * row_run[fc] : 2 * k + 1, i1 - i0);
+  el[2 * (size_t)k + 1] = euler_pack(ns != NONE32 ? 2 * row_run[ns] : (ref != NONE32 ? 2 * row_run[ref] + 1 : END), 0);
+}
+
+// one pointer-jumping round (Wyllie): dist'[x] = dist[x] + dist[succ[x]], succ'[x] = succ[succ[x]]. The launch covers
+// the worst case (every element its own run); lanes beyond the measured tour leave at once.
+__global__ __launch_bounds__(BLOCK) void k_euler_jump(const uint32_t* __restrict__ n_runs, const unsigned long long* __restrict__ in,
                                                       unsigned long long* __restrict__ out) {
   uint32_t x = gtid();
-  if (x > n_entries) return;  // (x == n_entries is END itself)
+  uint32_t END = 2 * *n_runs;
+  if (x > END) return;  // (x == END is the end marker itself)
   unsigned long long e = in[x];
   uint32_t s = (uint32_t)e;
   if (s != END) {
@@ -461,13 +494,15 @@ __global__ __launch_bounds__(BLOCK) void k_euler_jump(uint32_t n_entries, uint32
   out[x] = e;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, const unsigned long long* __restrict__ el) {
+__global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, const uint32_t* __restrict__ is_head, const uint32_t* __restrict__ head_ex,
+                                                      const uint32_t* __restrict__ heads, const unsigned long long* __restrict__ el) {
   uint32_t i = gtid();
   if (i >= n) return;
-  uint32_t v = b.ins_row[i];
-  uint32_t d = (uint32_t)(el[2 * (size_t)v] >> 32);  // enter-edges from enter(v) to the end, inclusive
-  if (d == 0 || d > n) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
-  b.order[n - d] = v;
+  uint32_t k = head_ex[i] + is_head[i] - 1;  // i = 0 is always a head
+  uint32_t d = (uint32_t)(el[2 * (size_t)k] >> 32);  // elements from the run's first one to the end of the tour, inclusive
+  uint32_t within = i - heads[k];
+  if (d == 0 || d > n || within >= d) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
+  b.order[n - d + within] = b.ins_row[i];
 }
 
 // per position: visibility and value counts to be scanned; first position of each object
@@ -827,16 +862,27 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
       const uint32_t* sv = res ? b.val_b : b.val_a;
       AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, sk, sv, ni, kb, d_start);
     }
-    AM355_LAUNCH_INDEPENDENT(k_euler_init, grid_for(N), dim3(BLOCK), st, b, b.euler_a);
+    // typing runs -> contracted Euler tour -> list ranking
+    uint32_t* is_head = b.scan_a;   // [ni + 1]
+    uint32_t* head_ex = b.scan_b;   // [ni + 1]
+    uint32_t* heads = b.val_a;      // [runs + 1]   (the grouping scratch is free again)
+    uint32_t* row_run = b.val_b;    // [N]
+    uint32_t* d_runs = &b.counts->n_edits;  // scratch word until k_list_edits rewrites it
+    AM355_LAUNCH_INDEPENDENT(k_run_flags, grid_for(ni + 1), dim3(BLOCK), st, b, ni, is_head);
+    exclusive_scan_u32(is_head, head_ex, ni + 1, d_runs, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_run_heads, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex, heads, row_run);
+    AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(ni), dim3(BLOCK), st, b, (const uint32_t*)d_runs, (const uint32_t*)heads, (const uint32_t*)row_run,
+                             b.euler_a);
     int rounds = bits_for(2ull * ni + 1);
     unsigned long long *e0 = b.euler_a, *e1 = b.euler_b;
     for (int r = 0; r < rounds; r++) {
-      AM355_LAUNCH_INDEPENDENT(k_euler_jump, grid_for(2 * N + 1), dim3(BLOCK), st, 2 * N, 2 * N, (const unsigned long long*)e0, e1);
+      AM355_LAUNCH_INDEPENDENT(k_euler_jump, grid_for(2 * ni + 1), dim3(BLOCK), st, (const uint32_t*)d_runs, (const unsigned long long*)e0, e1);
       unsigned long long* t = e0;
       e0 = e1;
       e1 = t;
     }
-    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const unsigned long long*)e0);
+    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex, (const uint32_t*)heads,
+                             (const unsigned long long*)e0);
     // visibility / value-count prefix sums over document order
     uint32_t* vis = b.scan_a;
     uint32_t* cnt = b.scan_b;
