@@ -937,18 +937,23 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     return fail(c, AM355_E_NOMEM, "device allocation failed");
   int rcb = setup_buffers(c);
   if (rcb) return rcb;
-  // wave-decodable changes first, the (rare) ones with an over-long column after them
-  uint32_t n_wave = 0;
+  // decoder classes: changes whose columns fit the small LDS footprint first, then the large footprint, then the (rare)
+  // ones with a column too long for LDS staging
+  uint32_t n_small = 0, n_large = 0;
   {
     const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
-    std::vector<ChangePlan> big;
+    std::vector<ChangePlan> large, serial;
     size_t w = 0;
     for (size_t i = 0; i < np; i++) {
-      if (br[c->plans[i].change].flags_fits & 0x80000000u) c->plans[w++] = c->plans[i];
-      else big.push_back(c->plans[i]);
+      uint32_t f = br[c->plans[i].change].flags_fits;
+      if (f & 0x40000000u) c->plans[w++] = c->plans[i];
+      else if (f & 0x80000000u) large.push_back(c->plans[i]);
+      else serial.push_back(c->plans[i]);
     }
-    n_wave = (uint32_t)w;
-    for (auto& pl : big) c->plans[w++] = pl;
+    n_small = (uint32_t)w;
+    n_large = (uint32_t)large.size();
+    for (auto& pl : large) c->plans[w++] = pl;
+    for (auto& pl : serial) c->plans[w++] = pl;
   }
   // host -> device tables go through one pinned staging buffer (pageable std::vector memory would make every copy a
   // synchronous bounce through the driver's own staging)
@@ -982,7 +987,8 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   // ---- stage 1b: column decode ----
   HIPCHK(c, hipEventRecord(c->ev[2], st));
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
-  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n_wave, (uint32_t)np - n_wave, d_amap, d_rank,
+  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n_small, n_large, (uint32_t)np - n_small - n_large, d_amap,
+                        d_rank,
                         c->cols, &c->d_counts.as<Counts>()->flags, st);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
 
@@ -1195,7 +1201,7 @@ extern "C" int am355_replay(am355_ctx* c) {
   {
     const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
     uint32_t dev_flags = h_words[W_FLAGS_A];
-    for (uint32_t i = 0; i < n; i++) dev_flags |= br[i].flags_fits & 0x7fffffffu;
+    for (uint32_t i = 0; i < n; i++) dev_flags |= br[i].flags_fits & 0x3fffffffu;
     if (dev_flags) { (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
   }
   bool fast = h_words[W_FAST_A] == 0;

@@ -550,7 +550,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
 
 // every actor a change mentions must already be in the document when the change is read (new.js:1442-1449):
 // with in-order application that means its first change has an index <= this one
-__device__ __forceinline__ bool fits_wave_dev(const ChangeMeta& m);
+__device__ __forceinline__ int wave_class_of(const ChangeMeta& m);
 
 __global__ __launch_bounds__(BLOCK) void k_actor_check(ChangeMeta* __restrict__ metas, uint32_t n, const uint32_t* __restrict__ amap_base,
                                                        const uint32_t* __restrict__ amap, uint32_t amap_cap, const uint32_t* __restrict__ first_idx,
@@ -577,7 +577,9 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(ChangeMeta* __restrict__ 
       m->max_first = mx;
       if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
     }
-    if (fits_wave_dev(*m)) br.flags_fits |= 0x80000000u;
+    int wc = wave_class_of(*m);
+    if (wc >= 1) br.flags_fits |= 0x80000000u;
+    if (wc == 2) br.flags_fits |= 0x40000000u;
   }
   briefs[c] = br;
 }
@@ -913,41 +915,50 @@ __global__ __launch_bounds__(WAVE) void k_decode_columns(const uint8_t* __restri
 // and start, and each terminating lane assembles its token; (3) lane 0 walks the records over the token table
 // (a literal of k values is ONE step); (4) all lanes expand runs into rows (binary search in the run table), apply
 // wave prefix sums where the format needs them (delta columns, value offsets, pred list offsets) and store rows
-// with consecutive lanes writing consecutive addresses. Columns longer than WV_COLMAX bytes (rare: the change is
+// with consecutive lanes writing consecutive addresses. Columns longer than the large class's COLMAX bytes (rare: the change is
 // then routed to the lane-serial kernel by the host) and the UTF-8 key column (string bytes are not LEB tokens;
 // walked by lane 0) are the exceptions.
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t WV_COLMAX = 1024;
-constexpr uint32_t WV_RUNMAX = WV_COLMAX / 2;  // every record is at least two tokens
-constexpr uint32_t WV_ACTMAX = 1024;
-constexpr uint32_t WV_REGION = 4096;  // all columns of a change, staged once when they fit
-
-struct WaveLds {
-  alignas(16) uint8_t region[WV_REGION];
-  uint8_t bytes[WV_COLMAX];
-  uint32_t tok_lo[WV_COLMAX], tok_hi[WV_COLMAX];
-  uint8_t tok_len[WV_COLMAX], tok_last[WV_COLMAX];
-  uint32_t run_start[WV_RUNMAX + 1], run_tok[WV_RUNMAX];
-  uint8_t run_kind[WV_RUNMAX];
+// LDS working set of one wave, in two sizes: the number of waves a CU can hold is set by this struct (160 KB of LDS per
+// CU), and typical changes (a few hundred ops, columns of ~100 bytes) need a fraction of what the largest
+// wave-decodable ones do. COLMAX = longest tokenised column, REGION = all columns staged at once when they fit,
+// ACTMAX = entries of the change's actor table.
+template <uint32_t COLMAX_, uint32_t REGION_, uint32_t ACTMAX_>
+struct WaveLdsT {
+  static constexpr uint32_t COLMAX = COLMAX_, REGION = REGION_, ACTMAX = ACTMAX_;
+  static constexpr uint32_t RUNMAX = COLMAX_ / 2;  // every record is at least two tokens
+  alignas(16) uint8_t region[REGION_];
+  uint8_t bytes[COLMAX_];
+  uint32_t tok_lo[COLMAX_], tok_hi[COLMAX_];
+  uint8_t tok_len[COLMAX_], tok_last[COLMAX_];
+  uint32_t run_start[COLMAX_ / 2 + 1], run_tok[COLMAX_ / 2];
+  uint8_t run_kind[COLMAX_ / 2];
   uint32_t n_runs, n_tokens, total_rows, err;
-  uint32_t rank[WV_ACTMAX];
+  uint32_t rank[ACTMAX_];
 };
+using WaveLdsSmall = WaveLdsT<256, 1024, 64>;     // ~5.4 KB: 29 waves per CU
+using WaveLdsLarge = WaveLdsT<1024, 4096, 1024>;  // ~24 KB: 6 waves per CU
 enum { RK_REP = 1, RK_LIT = 2, RK_NUL = 3 };
 
-__device__ __forceinline__ bool fits_wave_dev(const ChangeMeta& m) {
+// 2: small wave class, 1: large wave class, 0: lane-serial decoder
+__device__ __forceinline__ int wave_class_of(const ChangeMeta& m) {
   const int tokenised[] = {C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_INSERT, C_ACTION, C_VAL_LEN, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR};
-  for (int k = 0; k < 10; k++)
-    if (m.col_len[tokenised[k]] > WV_COLMAX) return false;
-  return m.n_entries <= WV_ACTMAX;
+  uint32_t longest = 0;
+  for (int k = 0; k < 10; k++) longest = m.col_len[tokenised[k]] > longest ? m.col_len[tokenised[k]] : longest;
+  if (longest <= WaveLdsSmall::COLMAX && m.n_entries <= WaveLdsSmall::ACTMAX) return 2;
+  if (longest <= WaveLdsLarge::COLMAX && m.n_entries <= WaveLdsLarge::ACTMAX) return 1;
+  return 0;
 }
 
-__device__ __forceinline__ bool wv_tok_uint(const WaveLds& L, uint32_t t, uint64_t& v) {
+template <class WL>
+__device__ __forceinline__ bool wv_tok_uint(const WL& L, uint32_t t, uint64_t& v) {
   uint32_t nb = L.tok_len[t];
   if (nb == 0 || nb > 10 || (nb == 10 && (L.tok_last[t] & 0xfe))) return false;
   v = (uint64_t)L.tok_hi[t] << 32 | L.tok_lo[t];
   return v <= MAX_SAFE;
 }
-__device__ __forceinline__ bool wv_tok_sint(const WaveLds& L, uint32_t t, int64_t& out) {
+template <class WL>
+__device__ __forceinline__ bool wv_tok_sint(const WL& L, uint32_t t, int64_t& out) {
   uint32_t nb = L.tok_len[t], last = L.tok_last[t];
   if (nb == 0 || nb > 10 || (nb == 10 && last != 0 && last != 0x7f)) return false;
   uint64_t v = (uint64_t)L.tok_hi[t] << 32 | L.tok_lo[t];
@@ -957,7 +968,8 @@ __device__ __forceinline__ bool wv_tok_sint(const WaveLds& L, uint32_t t, int64_
 }
 
 // Stage + tokenise + record-walk one RLE column (uint or int values). All lanes must call it.
-__device__ void wv_load_column(WaveLds& L, const uint8_t* __restrict__ col, uint32_t len, uint32_t lane) {
+template <class WL>
+__device__ void wv_load_column(WL& L, const uint8_t* __restrict__ col, uint32_t len, uint32_t lane) {
   __syncthreads();  // previous column's readers are done
   for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
   if (lane == 0) L.err = 0;
@@ -1030,7 +1042,8 @@ __device__ void wv_load_column(WaveLds& L, const uint8_t* __restrict__ col, uint
 
 // value of row i of the loaded column: returns the token index holding it, or NONE32 for null. *boundary is set when
 // row i must differ from row i-1 for the encoding to be legal (different records, or both inside a literal).
-__device__ __forceinline__ uint32_t wv_row_token(const WaveLds& L, uint32_t i, bool* lit_or_first) {
+template <class WL>
+__device__ __forceinline__ uint32_t wv_row_token(const WL& L, uint32_t i, bool* lit_or_first) {
   if (i >= L.total_rows) { *lit_or_first = false; return NONE32; }  // past the end every value is null (encoding.js:821)
   uint32_t lo = 0, hi = L.n_runs;
   while (hi - lo > 1) {
@@ -1045,8 +1058,8 @@ __device__ __forceinline__ uint32_t wv_row_token(const WaveLds& L, uint32_t i, b
 
 // decoded value of row i (uint or signed), with the reference's adjacency rule (no equal neighbours across record
 // boundaries or inside literals: encoding.js:826-829, 868-872)
-template <bool SIGNED>
-__device__ __forceinline__ bool wv_row_value(const WaveLds& L, uint32_t i, bool& is_null, int64_t& v, uint32_t& err) {
+template <bool SIGNED, class WL>
+__device__ __forceinline__ bool wv_row_value(const WL& L, uint32_t i, bool& is_null, int64_t& v, uint32_t& err) {
   bool edge;
   uint32_t t = wv_row_token(L, i, &edge);
   is_null = t == NONE32;
@@ -1081,10 +1094,11 @@ __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t x, uint32_t lane) 
   return x;
 }
 
+template <class WL>
 __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                        const ChangePlan* __restrict__ plans, uint32_t n_plans, ActorXlate x, OpCols o,
                                                        uint32_t* __restrict__ flags) {
-  __shared__ WaveLds L;
+  __shared__ WL L;
   uint32_t pi = blockIdx.x, lane = threadIdx.x;
   if (pi >= n_plans) return;
   const ChangePlan pl = plans[pi];
@@ -1108,7 +1122,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
       reg_lo = col_off[k] < reg_lo ? col_off[k] : reg_lo;
       reg_hi = col_off[k] + col_len[k] > reg_hi ? col_off[k] + col_len[k] : reg_hi;
     }
-  const bool staged = reg_hi > reg_lo && reg_hi - reg_lo <= WV_REGION;
+  const bool staged = reg_hi > reg_lo && reg_hi - reg_lo <= WL::REGION;
   if (staged) stage_to_lds(L.region, p + reg_lo, reg_hi - reg_lo, lane);
   auto colp = [&](int k) -> const uint8_t* { return staged && col_len[k] ? (const uint8_t*)L.region + (col_off[k] - reg_lo) : p + col_off[k]; };
 
@@ -1241,7 +1255,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     // lane 0 compares neighbouring strings byte by byte: make sure it does so in LDS. If the whole column region did
     // not fit, the key column alone usually does (`region` is unused in that case: the other columns stage through `bytes`).
     const uint8_t* keycol = colp(C_KEY_STR);
-    if (!staged && col_len[C_KEY_STR] && col_len[C_KEY_STR] <= WV_REGION) {
+    if (!staged && col_len[C_KEY_STR] && col_len[C_KEY_STR] <= WL::REGION) {
       stage_to_lds(L.region, p + col_off[C_KEY_STR], col_len[C_KEY_STR], lane);
       keycol = L.region;
       __syncthreads();
@@ -1260,7 +1274,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
         auto same = [&](uint32_t off, uint32_t len) {
           return have_last && last_len == len && bytes_equal(c.p, last_off, off, len, c.len);
         };
-        while (nr < WV_RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
+        while (nr < WL::RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
           uint32_t kind, off = 0, len = 0;
           uint64_t count = 1;
           if (lit_left > 0) {
@@ -1307,7 +1321,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
         }
         bool exhausted = !(lit_left > 0 || c.off < c.len);
         if ((exhausted || e) && rows < n) {  // past the end of the column every value is null
-          if (nr == WV_RUNMAX) nr--, rows = rows_done + L.run_start[nr];  // (cannot happen: loop stops at RUNMAX only with data left)
+          if (nr == WL::RUNMAX) nr--, rows = rows_done + L.run_start[nr];  // (cannot happen: loop stops at RUNMAX only with data left)
           L.run_start[nr] = (uint32_t)(rows - rows_done);
           L.run_kind[nr] = RK_NUL;
           L.run_tok[nr] = 0;
@@ -1491,22 +1505,16 @@ void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const 
   AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3(1, T_NUM_DOC), dim3(WAVE), st, arena, meta, plan, 1u, x, cols, flags, 0);
 }
 
-void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_wave, uint32_t n_serial,
+void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_small, uint32_t n_large, uint32_t n_serial,
                            const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st) {
-  // plans[0 .. n_wave) go to the wave-per-change run-level decoder, plans[n_wave .. n_wave + n_serial) (changes with a
-  // column too long for its LDS staging) to the lane-serial decoder
+  // plans = [small wave class | large wave class | lane-serial]: the first two go to the wave-per-change run-level decoder
+  // (two LDS footprints, see WaveLdsT), the rest (a column too long for LDS staging) to the lane-serial decoder
   ActorXlate x{amap, slot_rank};
-  if (n_wave) hipLaunchKernelGGL(k_decode_wave, dim3(n_wave), dim3(WAVE), 0, st, arena, metas, plans, n_wave, x, cols, flags);
+  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags);
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, st, arena, metas, plans + n_small, n_large, x, cols, flags);
   if (n_serial)
-    AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans + n_wave, n_serial, x,
-                             cols, flags, 0);
-}
-
-bool decode_fits_wave(const ChangeMeta& m) {
-  static const int tokenised[] = {C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_INSERT, C_ACTION, C_VAL_LEN, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR};
-  for (int c : tokenised)
-    if (m.col_len[c] > WV_COLMAX) return false;
-  return m.n_entries <= WV_ACTMAX;
+    AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), st, arena, metas, plans + n_small + n_large, n_serial,
+                             x, cols, flags, 0);
 }
 
 }  // namespace am355

@@ -32,7 +32,7 @@ struct ChangeMeta {
 struct ChangeBrief {
   uint64_t seq;
   uint32_t start_op, n_ops, n_preds, n_entries, author_slot;
-  uint32_t flags_fits;  // validity flags of the change; bit 31: all columns fit the wave-per-change decoder
+  uint32_t flags_fits;  // validity flags of the change; bit 31: the columns fit the wave-per-change decoder, bit 30: its small LDS class
 };
 
 // bits of the "fast path" word: any bit set => the host runs the general scheduler (new.js:1550-1597) itself
