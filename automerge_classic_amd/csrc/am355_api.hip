@@ -85,6 +85,8 @@ struct am355_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // decode / merge critical path
   hipStream_t stream2 = nullptr;  // SHA-256 + dependency resolution, off the critical path
+  hipStream_t stream3 = nullptr;  // second decoder class, side by side with the first
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[8] = {};
   hipEvent_t ev_parse = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
   std::string err;
@@ -171,6 +173,8 @@ extern "C" am355_ctx* am355_create(int device) {
   (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
   if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high) != hipSuccess) { delete c; return nullptr; }
   if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_low) != hipSuccess) { delete c; return nullptr; }
+  if (hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_high) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev_fork) != hipSuccess || hipEventCreate(&c->ev_join) != hipSuccess) { delete c; return nullptr; }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
@@ -182,6 +186,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream2);
+  (void)hipStreamSynchronize(c->stream3);
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
                     &c->d_words, &c->d_slot_rank, &c->d_scan1})
     b->release();
@@ -191,6 +196,9 @@ extern "C" void am355_destroy(am355_ctx* c) {
   for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  for (hipEvent_t e : {c->ev_fork, c->ev_join})
+    if (e) (void)hipEventDestroy(e);
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_spans, &c->d_tab_off, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks})
     b->release();
@@ -989,7 +997,7 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
   launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n_small, n_large, (uint32_t)np - n_small - n_large, d_amap,
                         d_rank,
-                        c->cols, &c->d_counts.as<Counts>()->flags, st);
+                        c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3, c->ev_fork, c->ev_join);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
 
   // ---- stage 2: merge (the decode flags land in the same counter block and are read with the phase-1 counters) ----
