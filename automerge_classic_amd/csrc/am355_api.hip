@@ -164,6 +164,9 @@ static int fail(am355_ctx* c, int code, const char* fmt, ...) {
 extern "C" am355_ctx* am355_create(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
+  // every replay has a few host round trips of some microseconds each: wait for them actively (refused, harmlessly, when the
+  // host process has already initialised the device with other flags)
+  (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   am355_ctx* c = new am355_ctx();
   c->device = device;

@@ -289,6 +289,7 @@ constexpr uint32_t PARSE_STAGE = 8192;
 __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
                                                          uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries) {
   __shared__ alignas(16) uint8_t stage[PARSE_STAGE];
+  wave_priority_high();
   uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n_changes) return;
   uint64_t base64 = offsets[c], total64 = offsets[c + 1] - offsets[c];
@@ -296,6 +297,8 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
   if (staged) stage_to_lds(stage, arena + base64, (uint32_t)total64, lane);
   __syncthreads();
   if (lane != 0) return;
+  ChangeMeta* out = &metas[c];
+  bool stored = false;
   ChangeMeta m;
   m.base = offsets[c];
   uint64_t len64 = offsets[c + 1] - offsets[c];
@@ -359,24 +362,32 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
     if (total > (uint64_t)(m.len - cur.off)) { m.flags |= F_BAD_CHUNK; break; }
     uint32_t data_off = cur.off;
     Cur dir(p, dir_off, m.len);
+    // the directory entries go straight to the output record: indexing a local copy by the column slot would push the
+    // whole struct into scratch memory
+    *out = m;
+    stored = true;
+    uint32_t act_off = 0, act_len = 0, pn_off = 0, pn_len = 0;
     for (uint64_t k = 0; k < ncols; k++) {
       uint64_t id, l;
       read_uleb(dir, id);
       read_uleb(dir, l);
       int s = col_slot(id);
-      if (s >= 0) { m.col_off[s] = data_off; m.col_len[s] = (uint32_t)l; }
+      if (s >= 0) { out->col_off[s] = data_off; out->col_len[s] = (uint32_t)l; }
+      if (s == C_ACTION) { act_off = data_off; act_len = (uint32_t)l; }
+      if (s == C_PRED_NUM) { pn_off = data_off; pn_len = (uint32_t)l; }
       data_off += (uint32_t)l;
     }
     // whatever follows the columns is `extraBytes` (columnar.js:757-760): preserved by the reference, unused here
     uint64_t cnt, sum;
-    if (!rle_count_sum(p + m.col_off[C_ACTION], m.col_len[C_ACTION], cnt, sum)) { m.flags |= F_BAD_RLE; break; }
+    if (!rle_count_sum(p + act_off, act_len, cnt, sum)) { m.flags |= F_BAD_RLE; break; }
     m.n_ops = (uint32_t)cnt;
-    if (!rle_count_sum(p + m.col_off[C_PRED_NUM], m.col_len[C_PRED_NUM], cnt, sum)) { m.flags |= F_BAD_RLE; break; }
+    if (!rle_count_sum(p + pn_off, pn_len, cnt, sum)) { m.flags |= F_BAD_RLE; break; }
     // only the first n_ops rows of predNum count (a longer column is ignored; a shorter one is padded with nulls)
     m.n_preds = (uint32_t)sum;
     if (m.start_op + m.n_ops > 0xfffffff0ull) m.flags |= F_OVERFLOW;
   } while (0);
-  metas[c] = m;
+  if (!stored) *out = m;
+  else { out->flags = m.flags; out->n_ops = m.n_ops; out->n_preds = m.n_preds; }
   n_entries[c] = m.flags ? 0 : m.n_entries;
 }
 
@@ -507,6 +518,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
                                                         unsigned long long* __restrict__ slots, uint32_t mask, uint32_t* __restrict__ first_idx,
                                                         uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags, uint32_t* __restrict__ distinct) {
   __shared__ uint32_t s_off[WAVE], s_len[WAVE];
+  wave_priority_high();
   uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n) return;
   ChangeMeta* m = &metas[c];
@@ -1099,6 +1111,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
                                                        const ChangePlan* __restrict__ plans, uint32_t n_plans, ActorXlate x, OpCols o,
                                                        uint32_t* __restrict__ flags) {
   __shared__ WL L;
+  wave_priority_high();
   uint32_t pi = blockIdx.x, lane = threadIdx.x;
   if (pi >= n_plans) return;
   const ChangePlan pl = plans[pi];

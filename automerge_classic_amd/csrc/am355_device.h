@@ -36,6 +36,11 @@ enum Flag : uint32_t {
   F_UNKNOWN_ACTOR_DEV = 1u << 17,  // new.js:1442-1449 actorId not known to document (== AM355_F_UNKNOWN_ACTOR)
 };
 
+// Wave issue priority inside a SIMD (s_setprio, 0..3). The latency-bound one-wave-per-change kernels of the critical path raise
+// it so that ALU-dense waves of the hash stream sharing their SIMD do not stretch them (queue priorities alone do not
+// guarantee that on every runtime).
+__device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
+
 __device__ __forceinline__ uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
 
 }  // namespace am355

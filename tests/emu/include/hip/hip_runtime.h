@@ -58,6 +58,8 @@ inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+constexpr unsigned hipDeviceScheduleSpin = 1;
+inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event(); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
@@ -203,6 +205,7 @@ template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
   return __shfl(v, lane + (int)d >= width ? lane : lane + (int)d, width);
 }
 template <class T> inline T __shfl_xor(T v, int m, int width = 64) { return __shfl(v, ((int)emu::cur_lane % width) ^ m, width); }
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_wave_barrier() { if (emu::in_coop) emu::cur_wave->bar.wait(); }
 inline unsigned __lane_id() { return emu::in_coop ? emu::cur_lane : (threadIdx.x & 63); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
