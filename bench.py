@@ -166,7 +166,7 @@ def main():
         "algorithmic_bytes_per_op": {"E_encoded": E, "R_op_record": R, "P_patch_ir": P, "A": E + R + P},
         "host_buffers_in_ops_per_s": st.n_ops / t_host_in,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "kernel": "k_decode_wave", "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases["ms_decode"]},
+                     "kernel": "k_decode_wave<small>", "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases["ms_decode"]},
     }
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode_wave.json")
     if os.path.exists(pmc) and args.workload == "c4_text_single" and args.scale == 1.0:
