@@ -82,4 +82,19 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, b
 // cleared by the caller before the decode kernels run.
 void doc_patch(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st);
 
+// ---- Backend.save after a replay: op rows in saved-document order (am355_merge.hip, "Backend.save") -------------------
+struct SaveBufs {
+  uint32_t *map_flag, *map_ex, *upd_flag, *upd_ex, *upd_cnt, *pos_of, *list_off, *final_pos, *src_of, *map_perm;  // [N + 2]
+  uint32_t *obj_rank, *rank_obj, *base_by_rank;            // [n_objects + 2]
+  uint32_t *map_begin, *map_end, *list_begin, *list_end;   // [n_objects + 1] each, contiguous
+  uint64_t *succ_key_a, *succ_key_b;                       // [P + 1]
+  uint32_t *succ_val_a, *succ_val_b;                       // [P + 1]
+  uint32_t* words;                                         // [8] device: map rows, update rows, longest key
+  OpCols out;                                              // canonical rows (actor fields: document actor index; pred_* = succ lists)
+};
+// counts map rows / list update rows (s.words), compacts them; the caller reads s.words back before phase 2
+void save_phase1(MergeBufs& b, SaveBufs& s, hipStream_t st);
+// n_obj includes _root; doc_actor[rank] = index in the document's actor table (device)
+void save_phase2(MergeBufs& b, PatchIR& ir, SaveBufs& s, const uint32_t* words, uint32_t n_obj, uint32_t n_ins, const uint32_t* doc_actor, hipStream_t st);
+
 }  // namespace am355

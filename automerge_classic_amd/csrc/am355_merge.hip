@@ -265,7 +265,7 @@ __device__ __forceinline__ uint32_t utf16_order_byte(uint32_t x) {
 }
 
 __global__ __launch_bounds__(BLOCK) void k_map_keys(MergeBufs b, const uint32_t* __restrict__ perm, uint64_t* __restrict__ keys, uint32_t n,
-                                                    int mode, uint32_t chunk) {
+                                                    int mode, uint32_t chunk, const uint32_t* __restrict__ obj_rank) {
   uint32_t i = gtid();
   if (i >= n) return;
   uint32_t e = perm[i], g = b.em_row[e];
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(BLOCK) void k_map_keys(MergeBufs b, const uint32_t*
     }
   } else {
     k = obj_index_of(b, b.obj_row[g]);
+    if (obj_rank) k = obj_rank[k];  // save(): objects in ascending id order instead of creation order
   }
   keys[i] = k;
 }
@@ -818,7 +819,7 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
     auto pass = [&](int mode, uint32_t chunk, int bits) {
       uint32_t* pin = cur ? perm_b : perm_a;
       uint64_t* kin = cur ? b.key_b : b.key_a;
-      AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk);
+      AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk, (const uint32_t*)nullptr);
       int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, 0, bits, b.sort_ws, st)
                     : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, 0, bits, b.sort_ws, st);
       cur ^= res;
@@ -952,6 +953,253 @@ void doc_patch(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
   if (hc->n_edits) AM355_LAUNCH_INDEPENDENT(k_edit_runs, grid_for(hc->n_edits), dim3(BLOCK), st, b, ir);
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Backend.save after a replay (new.js:2033-2055, columnar.js:983-1004): the op rows in the order a
+// saved document holds them -- objects ascending by id with _root first, map rows by (key, op id), list rows in RGA
+// order with each element's updates after it -- with their succ lists; `del` ops leave no row, only succ entries
+// (new.js:1205-1217). The replay already knows every ingredient: object of each row, RGA position of each element,
+// succ counts. What is left is sorting (map rows by key, updates by element, objects by id) and prefix sums.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void ks_classify(MergeBufs b, uint32_t* __restrict__ map_flag, uint32_t* __restrict__ upd_flag, uint32_t* __restrict__ upd_cnt,
+                                                     uint32_t* __restrict__ max_key_len) {
+  uint32_t g = gtid();
+  if (g > b.n_ops) return;
+  uint32_t mf = 0, uf = 0;
+  if (g < b.n_ops) {
+    uint8_t kind = b.kind[g];
+    if (kind == K_MAP) { mf = 1; atomicMax(max_key_len, b.ops.key_len[g]); }
+    else if (kind == K_LIST_UPD) { uf = 1; atomicAdd(&upd_cnt[b.ref_row[g]], 1u); }
+  }
+  map_flag[g] = mf;
+  upd_flag[g] = uf;
+}
+
+__global__ __launch_bounds__(BLOCK) void ks_compact(MergeBufs b, const uint32_t* __restrict__ map_flag, const uint32_t* __restrict__ map_ex,
+                                                    const uint32_t* __restrict__ upd_flag, const uint32_t* __restrict__ upd_ex) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  if (map_flag[g]) { b.em_row[map_ex[g]] = g; b.em_trig[map_ex[g]] = pack_id(b.ops.id_ctr[g], b.ops.id_actor[g]); }
+  if (upd_flag[g]) b.upd_row[upd_ex[g]] = g;
+}
+
+__global__ __launch_bounds__(BLOCK) void ks_obj_keys(MergeBufs b, PatchIR ir, uint32_t n_obj, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  uint32_t i = gtid();  // object i + 1
+  if (i + 1 >= n_obj) return;
+  uint32_t row = ir.obj_make_row[i + 1];
+  keys[i] = (uint64_t)b.ops.id_ctr[row] << b.bits_actor | b.ops.id_actor[row];
+  vals[i] = i + 1;
+}
+__global__ __launch_bounds__(BLOCK) void ks_obj_rank(const uint32_t* __restrict__ sorted, uint32_t n_obj, uint32_t* __restrict__ obj_rank, uint32_t* __restrict__ rank_obj) {
+  uint32_t i = gtid();
+  if (i == 0) { obj_rank[0] = 0; rank_obj[0] = 0; }
+  if (i + 1 >= n_obj) return;
+  obj_rank[sorted[i]] = i + 1;
+  rank_obj[i + 1] = sorted[i];
+}
+
+// first / one-past-last sorted map row of every object
+__global__ __launch_bounds__(BLOCK) void ks_map_bounds(MergeBufs b, const uint32_t* __restrict__ perm, uint32_t n, uint32_t* __restrict__ begin, uint32_t* __restrict__ end) {
+  uint32_t m = gtid();
+  if (m >= n) return;
+  uint32_t oi = obj_index_of(b, b.obj_row[b.em_row[perm[m]]]);
+  if (m == 0 || obj_index_of(b, b.obj_row[b.em_row[perm[m - 1]]]) != oi) begin[oi] = m;
+  if (m + 1 == n || obj_index_of(b, b.obj_row[b.em_row[perm[m + 1]]]) != oi) end[oi] = m + 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void ks_list_counts(MergeBufs b, uint32_t n, const uint32_t* __restrict__ upd_cnt, uint32_t* __restrict__ pos_of, uint32_t* __restrict__ cnt) {
+  uint32_t p = gtid();
+  if (p > n) return;
+  if (p == n) { cnt[p] = 0; return; }
+  uint32_t v = b.order[p];
+  pos_of[v] = p;
+  cnt[p] = 1 + upd_cnt[v];
+}
+__global__ __launch_bounds__(BLOCK) void ks_list_bounds(MergeBufs b, uint32_t n, const uint32_t* __restrict__ list_off, uint32_t* __restrict__ begin, uint32_t* __restrict__ end) {
+  uint32_t p = gtid();
+  if (p >= n) return;
+  uint32_t oi = obj_index_of(b, b.obj_row[b.order[p]]);
+  if (p == 0 || obj_index_of(b, b.obj_row[b.order[p - 1]]) != oi) begin[oi] = list_off[p];
+  if (p + 1 == n || obj_index_of(b, b.obj_row[b.order[p + 1]]) != oi) end[oi] = list_off[p + 1];
+}
+__global__ __launch_bounds__(BLOCK) void ks_upd_keys(MergeBufs b, uint32_t n, const uint32_t* __restrict__ pos_of, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t g = b.upd_row[i];
+  keys[i] = (uint64_t)pos_of[b.ref_row[g]] << (b.bits_ctr + b.bits_actor) | (uint64_t)b.ops.id_ctr[g] << b.bits_actor | b.ops.id_actor[g];
+  vals[i] = g;
+}
+// rows of each object, in ascending object id order
+__global__ __launch_bounds__(BLOCK) void ks_obj_counts(uint32_t n_obj, const uint32_t* __restrict__ rank_obj, const uint32_t* __restrict__ map_begin,
+                                                       const uint32_t* __restrict__ map_end, const uint32_t* __restrict__ list_begin, const uint32_t* __restrict__ list_end,
+                                                       uint32_t* __restrict__ cnt_by_rank) {
+  uint32_t r = gtid();
+  if (r > n_obj) return;
+  uint32_t c = 0;
+  if (r < n_obj) { uint32_t oi = rank_obj[r]; c = (map_end[oi] - map_begin[oi]) + (list_end[oi] - list_begin[oi]); }
+  cnt_by_rank[r] = c;
+}
+
+__global__ __launch_bounds__(BLOCK) void ks_place_map(MergeBufs b, const uint32_t* __restrict__ perm, uint32_t n, const uint32_t* __restrict__ obj_rank,
+                                                      const uint32_t* __restrict__ base_by_rank, const uint32_t* __restrict__ map_begin, uint32_t* __restrict__ final_pos,
+                                                      uint32_t* __restrict__ src_of) {
+  uint32_t m = gtid();
+  if (m >= n) return;
+  uint32_t g = b.em_row[perm[m]], oi = obj_index_of(b, b.obj_row[g]);
+  uint32_t f = base_by_rank[obj_rank[oi]] + (m - map_begin[oi]);
+  final_pos[g] = f;
+  src_of[f] = g;
+}
+__global__ __launch_bounds__(BLOCK) void ks_place_ins(MergeBufs b, uint32_t n, const uint32_t* __restrict__ obj_rank, const uint32_t* __restrict__ base_by_rank,
+                                                      const uint32_t* __restrict__ list_begin, const uint32_t* __restrict__ list_off, uint32_t* __restrict__ final_pos,
+                                                      uint32_t* __restrict__ src_of) {
+  uint32_t p = gtid();
+  if (p >= n) return;
+  uint32_t g = b.order[p], oi = obj_index_of(b, b.obj_row[g]);
+  uint32_t f = base_by_rank[obj_rank[oi]] + (list_off[p] - list_begin[oi]);
+  final_pos[g] = f;
+  src_of[f] = g;
+}
+// sorted update j of the element at list position p sits at p + j + 1 of the chained list rows (p elements and j updates precede it)
+__global__ __launch_bounds__(BLOCK) void ks_place_upd(MergeBufs b, const uint32_t* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ pos_of,
+                                                      const uint32_t* __restrict__ obj_rank, const uint32_t* __restrict__ base_by_rank,
+                                                      const uint32_t* __restrict__ list_begin, uint32_t* __restrict__ final_pos, uint32_t* __restrict__ src_of) {
+  uint32_t j = gtid();
+  if (j >= n) return;
+  uint32_t g = sorted[j], oi = obj_index_of(b, b.obj_row[g]);
+  uint32_t f = base_by_rank[obj_rank[oi]] + (pos_of[b.ref_row[g]] + j + 1 - list_begin[oi]);
+  final_pos[g] = f;
+  src_of[f] = g;
+}
+
+// canonical rows: gather + actor rank -> document actor index
+__global__ __launch_bounds__(BLOCK) void ks_gather(MergeBufs b, uint32_t n_doc, const uint32_t* __restrict__ src_of, const uint32_t* __restrict__ doc_actor, OpCols out) {
+  uint32_t f = gtid();
+  if (f > n_doc) return;
+  if (f == n_doc) { out.pred_num[f] = 0; return; }
+  const OpCols& o = b.ops;
+  uint32_t g = src_of[f];
+  bool root = o.obj_actor[g] == NONE32;
+  out.obj_actor[f] = root ? NONE32 : doc_actor[o.obj_actor[g]];
+  out.obj_ctr[f] = root ? NONE32 : o.obj_ctr[g];
+  out.key_actor[f] = o.key_actor[g] == NONE32 ? NONE32 : doc_actor[o.key_actor[g]];
+  out.key_ctr[f] = o.key_ctr[g];
+  out.key_off[f] = o.key_off[g];
+  out.key_len[f] = o.key_len[g];
+  out.id_actor[f] = doc_actor[o.id_actor[g]];
+  out.id_ctr[f] = o.id_ctr[g];
+  out.insert[f] = o.insert[g];
+  out.action[f] = o.action[g];
+  out.val_tl[f] = o.val_tl[g];
+  out.val_off[f] = o.val_off[g];
+  out.pred_num[f] = b.succ_cnt[g];
+}
+
+// one (target position, successor id) pair per pred entry of every op, `del`s included
+__global__ __launch_bounds__(BLOCK) void ks_succ_pairs(MergeBufs b, const uint32_t* __restrict__ final_pos, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const OpCols& o = b.ops;
+  uint32_t np = o.pred_num[g], pf = o.pred_first[g];
+  for (uint32_t k = 0; k < np; k++) {
+    uint32_t t = row_of(b, o.pred_actor[pf + k], o.pred_ctr[pf + k]);
+    uint32_t f = t == NONE32 ? 0 : final_pos[t];
+    keys[pf + k] = (uint64_t)f << (b.bits_ctr + b.bits_actor) | (uint64_t)o.id_ctr[g] << b.bits_actor | o.id_actor[g];
+    vals[pf + k] = g;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void ks_succ_out(MergeBufs b, const uint32_t* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ doc_actor, OpCols out) {
+  uint32_t j = gtid();
+  if (j >= n) return;
+  uint32_t g = sorted[j];
+  out.pred_actor[j] = doc_actor[b.ops.id_actor[g]];
+  out.pred_ctr[j] = b.ops.id_ctr[g];
+}
+
+void save_phase1(MergeBufs& b, SaveBufs& s, hipStream_t st) {
+  uint32_t N = b.n_ops;
+  (void)hipMemsetAsync(s.upd_cnt, 0, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(s.words, 0, 4 * 8, st);
+  AM355_LAUNCH_INDEPENDENT(ks_classify, grid_for(N + 1), dim3(BLOCK), st, b, s.map_flag, s.upd_flag, s.upd_cnt, s.words + 2);
+  exclusive_scan_u32(s.map_flag, s.map_ex, N + 1, s.words + 0, b.scan_ws, st);
+  exclusive_scan_u32(s.upd_flag, s.upd_ex, N + 1, s.words + 1, b.scan_ws, st);
+  if (N) AM355_LAUNCH_INDEPENDENT(ks_compact, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)s.map_flag, (const uint32_t*)s.map_ex, (const uint32_t*)s.upd_flag,
+                                  (const uint32_t*)s.upd_ex);
+}
+
+// words (host copy of s.words): [0] map rows, [1] list update rows, [2] longest map key
+void save_phase2(MergeBufs& b, PatchIR& ir, SaveBufs& s, const uint32_t* words, uint32_t n_obj, uint32_t n_ins, const uint32_t* doc_actor, hipStream_t st) {
+  uint32_t N = b.n_ops, nm = words[0], nu = words[1], max_key = words[2];
+  uint32_t n_doc = nm + nu + n_ins;
+  // objects by id
+  if (n_obj > 1) {
+    AM355_LAUNCH_INDEPENDENT(ks_obj_keys, grid_for(n_obj), dim3(BLOCK), st, b, ir, n_obj, b.key_a, b.val_a);
+    int res = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, n_obj - 1, 0, (int)(b.bits_ctr + b.bits_actor), b.sort_ws, st);
+    AM355_LAUNCH_INDEPENDENT(ks_obj_rank, grid_for(n_obj), dim3(BLOCK), st, (const uint32_t*)(res ? b.val_b : b.val_a), n_obj, s.obj_rank, s.rank_obj);
+  } else {
+    (void)hipMemsetAsync(s.obj_rank, 0, 4, st);
+    (void)hipMemsetAsync(s.rank_obj, 0, 4, st);
+  }
+  (void)hipMemsetAsync(s.map_begin, 0, 4 * 4 * ((size_t)n_obj + 1), st);  // map_begin, map_end, list_begin, list_end are contiguous
+  // map rows by (object id, key, op id)
+  const uint32_t* map_perm = b.val_a;
+  if (nm) {
+    uint32_t *perm_a = b.val_a, *perm_b = b.val_b;
+    AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(nm), dim3(BLOCK), st, perm_a, nm);
+    int cur = 0;
+    auto pass = [&](int mode, uint32_t chunk, int bits) {
+      uint32_t* pin = cur ? perm_b : perm_a;
+      uint64_t* kin = cur ? b.key_b : b.key_a;
+      AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(nm), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, nm, mode, chunk, (const uint32_t*)s.obj_rank);
+      int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, nm, 0, bits, b.sort_ws, st)
+                    : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, nm, 0, bits, b.sort_ws, st);
+      cur ^= res;
+    };
+    if (nm > 1) {
+      pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
+      pass(MK_LEN, 0, bits_for(max_key));
+      uint32_t chunks = (max_key + 7) / 8;
+      for (uint32_t c = chunks; c-- > 0;) pass(MK_CHUNK, c, 64);
+      pass(MK_OBJECT, 0, bits_for(n_obj));
+    }
+    map_perm = cur ? perm_b : perm_a;
+    // the permutation must survive the update sort below, which uses the same scratch: park it
+    (void)hipMemcpyAsync(s.map_perm, map_perm, 4 * (size_t)nm, hipMemcpyDeviceToDevice, st);
+    AM355_LAUNCH_INDEPENDENT(ks_map_bounds, grid_for(nm), dim3(BLOCK), st, b, (const uint32_t*)s.map_perm, nm, s.map_begin, s.map_end);
+  }
+  // list rows: elements in RGA order, each followed by its updates in ascending op id
+  const uint32_t* upd_sorted = b.val_a;
+  if (n_ins) {
+    AM355_LAUNCH_INDEPENDENT(ks_list_counts, grid_for(n_ins + 1), dim3(BLOCK), st, b, n_ins, (const uint32_t*)s.upd_cnt, s.pos_of, s.list_off);
+    exclusive_scan_u32(s.list_off, s.list_off, n_ins + 1, nullptr, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(ks_list_bounds, grid_for(n_ins), dim3(BLOCK), st, b, n_ins, (const uint32_t*)s.list_off, s.list_begin, s.list_end);
+  }
+  if (nu) {
+    AM355_LAUNCH_INDEPENDENT(ks_upd_keys, grid_for(nu), dim3(BLOCK), st, b, nu, (const uint32_t*)s.pos_of, b.key_a, b.val_a);
+    int res = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, nu, 0, bits_for(n_ins) + (int)(b.bits_ctr + b.bits_actor), b.sort_ws, st);
+    upd_sorted = res ? b.val_b : b.val_a;
+  }
+  AM355_LAUNCH_INDEPENDENT(ks_obj_counts, grid_for(n_obj + 1), dim3(BLOCK), st, n_obj, (const uint32_t*)s.rank_obj, (const uint32_t*)s.map_begin, (const uint32_t*)s.map_end,
+                           (const uint32_t*)s.list_begin, (const uint32_t*)s.list_end, s.base_by_rank);
+  exclusive_scan_u32(s.base_by_rank, s.base_by_rank, n_obj + 1, nullptr, b.scan_ws, st);
+  (void)hipMemsetAsync(s.final_pos, 0xff, 4 * ((size_t)N + 1), st);
+  if (nm) AM355_LAUNCH_INDEPENDENT(ks_place_map, grid_for(nm), dim3(BLOCK), st, b, (const uint32_t*)s.map_perm, nm, (const uint32_t*)s.obj_rank, (const uint32_t*)s.base_by_rank,
+                                   (const uint32_t*)s.map_begin, s.final_pos, s.src_of);
+  if (n_ins) AM355_LAUNCH_INDEPENDENT(ks_place_ins, grid_for(n_ins), dim3(BLOCK), st, b, n_ins, (const uint32_t*)s.obj_rank, (const uint32_t*)s.base_by_rank,
+                                      (const uint32_t*)s.list_begin, (const uint32_t*)s.list_off, s.final_pos, s.src_of);
+  if (nu) AM355_LAUNCH_INDEPENDENT(ks_place_upd, grid_for(nu), dim3(BLOCK), st, b, upd_sorted, nu, (const uint32_t*)s.pos_of, (const uint32_t*)s.obj_rank,
+                                   (const uint32_t*)s.base_by_rank, (const uint32_t*)s.list_begin, s.final_pos, s.src_of);
+  AM355_LAUNCH_INDEPENDENT(ks_gather, grid_for(n_doc + 1), dim3(BLOCK), st, b, n_doc, (const uint32_t*)s.src_of, doc_actor, s.out);
+  exclusive_scan_u32(s.out.pred_num, s.out.pred_first, n_doc + 1, nullptr, b.scan_ws, st);
+  // succ lists: every pred entry names (row it overwrites, id of the overwriting op); sorted by canonical position, then id
+  uint32_t P = b.n_preds;
+  if (P) {
+    AM355_LAUNCH_INDEPENDENT(ks_succ_pairs, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)s.final_pos, s.succ_key_a, s.succ_val_a);
+    int res = radix_sort_pairs(s.succ_key_a, s.succ_val_a, s.succ_key_b, s.succ_val_b, P, 0, bits_for(n_doc) + (int)(b.bits_ctr + b.bits_actor), b.sort_ws, st);
+    AM355_LAUNCH_INDEPENDENT(ks_succ_out, grid_for(P), dim3(BLOCK), st, b, (const uint32_t*)(res ? s.succ_val_b : s.succ_val_a), P, doc_actor, s.out);
+  }
 }
 
 }  // namespace am355

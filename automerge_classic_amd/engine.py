@@ -77,8 +77,9 @@ def _bind(path):
     L.am355_test_sort.argtypes = [vp, vp, vp, u32, ctypes.c_int]
     L.am355_test_scan.argtypes = [vp, vp, vp, u32, vp]
     L.am355_get_rows.argtypes = [vp] * 15
+    L.am355_save.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
-              "am355_test_scan", "am355_get_rows"):
+              "am355_test_scan", "am355_get_rows", "am355_save"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -144,6 +145,14 @@ class Engine:
         n = ctypes.c_size_t()
         self._check(self._L.am355_patch_json(self._h, ctypes.byref(p), ctypes.byref(n)))
         return ctypes.string_at(p, n.value).decode("utf-8")
+
+    def save(self, reencode=False):
+        """Backend.save(state): the document as one binary chunk (op columns encoded on the GPU). A loaded document returns
+        the bytes it came from, as the reference does; reencode=True re-encodes its op columns instead (diagnostic)."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        self._check(self._L.am355_save(self._h, 1 if reencode else 0, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p, n.value)
 
     def stats(self):
         s = Stats()

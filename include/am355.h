@@ -101,6 +101,15 @@ int am355_get_stats(const am355_ctx *ctx, am355_stats *out);
 int am355_get_hashes(const am355_ctx *ctx, uint8_t *out);
 
 /* Raw (uncompressed) arena as staged by am355_load_changes: pointer valid until the next load. */
+/* Backend.save(state) (reference: backend/new.js:2033-2055 BackendDoc.save, backend/columnar.js:983-1004
+ * encodeDocumentHeader): the document as one binary chunk -- actor table in order of first appearance, heads, change
+ * metadata columns, all non-`del` op rows in canonical order with their succ lists (columns encoded on the GPU),
+ * columns of >= 256 bytes DEFLATEd. Valid after am355_replay. A state produced by am355_load_document returns the
+ * bytes it was loaded from, as the reference does (new.js:2034); flags bit 0 forces a re-encode of its op columns
+ * (diagnostic for the column encoders). AM355_E_UNSUPPORTED while changes are queued (the JS path saves those).
+ * *bytes is owned by ctx and valid until the next am355_save / am355_destroy. */
+int am355_save(am355_ctx *ctx, uint32_t flags, const uint8_t **bytes, size_t *len);
+
 int am355_get_raw(const am355_ctx *ctx, const uint8_t **arena, const uint64_t **offsets, uint32_t *n_changes);
 
 /*
