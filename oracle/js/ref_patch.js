@@ -2,7 +2,7 @@
 // on a change log and prints/saves its getPatch() result. Only usable inside the build container
 // (the reference tree does not travel to the GPU box); its outputs are committed under tests/golden/.
 //
-//   NODE_PATH=oracle/js_shims/node_modules [REF_BLOCK_SIZE=n] node oracle/js/ref_patch.js <log.bin> [--check-encode] [--out patch.json] [--time N]
+//   NODE_PATH=oracle/js_shims/node_modules [REF_BLOCK_SIZE=n] node oracle/js/ref_patch.js <log.bin> [--check-encode] [--out patch.json] [--save doc.bin] [--time N]
 // (REF_BLOCK_SIZE: see ref_loader.js)
 //
 // Log file layout (little endian): u32 n_changes, u64 n_ops, u64 offsets[n+1], arena.
@@ -60,6 +60,8 @@ let patch
 {
   const t0 = process.hrtime.bigint()
   const state = Backend.loadChanges(Backend.init(), changes)
+  const saveIdx = args.indexOf('--save')
+  if (saveIdx >= 0) fs.writeFileSync(args[saveIdx + 1], Backend.save(state))  // the reference's document bytes, for am355_save parity
   const t1 = process.hrtime.bigint()
   patch = Backend.getPatch(state)
   const t2 = process.hrtime.bigint()

@@ -15,7 +15,13 @@ def _all_names():
 
 def fixture_names():
     """Fixtures holding binary changes and the reference's loadChanges + getPatch result."""
-    return [n for n in _all_names() if not n.startswith("synthetic_doc_")]
+    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n != "save_generated"]
+
+
+def save_digest_cases():
+    """Length + SHA-256 of the reference's Backend.save on deterministic generated logs (oracle/make_save_golden.py)."""
+    with open(os.path.join(GOLDEN_DIR, "save_generated.json")) as f:
+        return json.load(f)["cases"]
 
 
 def doc_fixture_names():

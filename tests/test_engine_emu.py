@@ -189,3 +189,55 @@ def test_mutated_documents_never_disagree_with_the_oracle(eng):
             assert got == want, f"different patch for mutation at byte {pos}"
             agree += 1
     assert agree > 20
+
+
+@pytest.mark.parametrize("name", golden_util.fixture_names())
+def test_save_after_replay_is_byte_identical_to_the_reference(eng, name):
+    """Backend.save(Backend.loadChanges(Backend.init(), changes)) -- the golden holds the unmodified reference's bytes."""
+    fx = golden_util.load_fixture(name)
+    eng.load_changes(fx["log"])
+    eng.replay()
+    if "doc_bytes" not in fx:  # changes left in the queue: that document is saved by the JS path
+        with pytest.raises(engine.UnsupportedChanges):
+            eng.save()
+        return
+    assert eng.save() == fx["doc_bytes"]
+
+
+@pytest.mark.parametrize("name", golden_util.doc_fixture_names())
+def test_reencoding_a_loaded_document_reproduces_it(eng, name):
+    """Column encoders alone: decode the op columns of a reference-written document, encode them again."""
+    fx = golden_util.load_fixture(name)
+    eng.load_document(fx["doc_bytes"])
+    eng.replay()
+    assert eng.save() == fx["doc_bytes"]  # unchanged document: the bytes it was given (new.js:2034)
+    if "nodeflate" not in name:            # (that fixture was written without column compression; save() always compresses)
+        assert eng.save(reencode=True) == fx["doc_bytes"]
+
+
+@pytest.mark.parametrize("workload,scale", [("c2_text_typing", 0.02), ("c3_map_lww", 0.25), ("c4_text_multi", 0.03)])
+def test_saved_document_loads_to_the_same_patch(eng, workload, scale):
+    """save() of a generated log, loaded again (engine and oracle): same document."""
+    log = loggen.config(workload, scale, False)
+    want = emu_patch(eng, log)
+    doc = eng.save()
+    eng.load_document(doc)
+    eng.replay()
+    got = eng.patch_json()
+    oracle = oracle_lib.OracleDoc.load_document(doc).patch_json()
+    assert got == oracle
+    # the loaded document has no pending queue and the same content; `clock` key order is first-appearance in both
+    assert json.loads(got)["diffs"] == json.loads(want)["diffs"]
+    assert json.loads(got)["maxOp"] == json.loads(want)["maxOp"] and json.loads(got)["deps"] == json.loads(want)["deps"]
+
+
+@pytest.mark.parametrize("case", golden_util.save_digest_cases(), ids=lambda c: c["workload"])
+def test_save_of_generated_logs_matches_the_reference_digest(eng, case):
+    """Same bytes as the unmodified reference's Backend.save on the generated workloads (digests: oracle/make_save_golden.py)."""
+    import hashlib
+    log = loggen.config(case["workload"], case["scale"], False)
+    assert log.n_ops == case["n_ops"] and log.n_changes == case["n_changes"]
+    eng.load_changes(log)
+    eng.replay()
+    doc = eng.save()
+    assert len(doc) == case["doc_len"] and hashlib.sha256(doc).hexdigest() == case["doc_sha256"]
