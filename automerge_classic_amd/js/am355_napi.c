@@ -170,6 +170,27 @@ static napi_value js_patch_json(napi_env env, napi_callback_info info) {
   return s;
 }
 
+/* save(ctx, flags) -> Uint8Array: am355_save (Backend.save, new.js:2033-2055); the bytes are copied into a JS-owned buffer */
+static napi_value js_save(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t flags = 0;
+  if (argc > 1) napi_get_value_uint32(env, argv[1], &flags);
+  const uint8_t *bytes = NULL;
+  size_t len = 0;
+  int rc = am355_save(ctx, flags, &bytes, &len);
+  if (rc) return throw_engine(env, ctx, rc);
+  void *data = NULL;
+  napi_value ab, ta;
+  NAPI_CALL(env, napi_create_arraybuffer(env, len, &data, &ab));
+  if (len) memcpy(data, bytes, len);
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, len, ab, 0, &ta));
+  return ta;
+}
+
 static napi_value js_hashes(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -221,6 +242,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"loadDocument", NULL, js_load_document, NULL, NULL, NULL, napi_enumerable, NULL},
       {"replay", NULL, js_replay, NULL, NULL, NULL, napi_enumerable, NULL},
       {"patchJSON", NULL, js_patch_json, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"save", NULL, js_save, NULL, NULL, NULL, napi_enumerable, NULL},
       {"hashes", NULL, js_hashes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"stats", NULL, js_stats, NULL, NULL, NULL, napi_enumerable, NULL},
   };

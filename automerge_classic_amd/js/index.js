@@ -44,8 +44,10 @@ class GpuState {
     this.patch = patch
     this.heads = heads
     this.js = null           // hydrated reference backend handle
+    this.generation = 0      // engine replay this state was built by (the one context is reused by every call)
   }
 }
+let generation = 0           // bumped by every GPU replay
 
 function isFrozenCheck(backend) {
   // reference util.js:1-10
@@ -76,6 +78,7 @@ function toJs(backend) {
 }
 
 function gpuReplay(changes) {
+  generation++
   addon.loadChanges(ctx, changes)
   addon.replay(ctx)
   const patch = JSON.parse(addon.patchJSON(ctx))
@@ -93,6 +96,7 @@ function loadChanges(backend, changes) {
       const patch = gpuReplay(changes)
       backend.frozen = true
       const state = new GpuState(changes.slice(), patch, patch.deps)
+      state.generation = generation
       return { state, heads: patch.deps }
     } catch (e) {
       if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
@@ -117,6 +121,7 @@ function load(data) {
   // whole-document patch on the GPU
   if (!JS_ONLY && data instanceof Uint8Array) {
     try {
+      generation++
       addon.loadDocument(ctx, data)
       addon.replay(ctx)
       const patch = JSON.parse(addon.patchJSON(ctx))
@@ -128,6 +133,24 @@ function load(data) {
   return ref().load(data)
 }
 
+// Backend.save(state) (backend.js:93-95, new.js:2033-2055). A GPU-built state is saved by the engine: canonical row order and
+// column encoding on the GPU, document assembly / DEFLATE / checksum on the host. If the engine context has moved on to
+// another document since, the retained changes are replayed first (still far cheaper than the JS path).
+function save(backend) {
+  isFrozenCheck(backend)
+  const g = backend.state
+  if (!JS_ONLY && g instanceof GpuState && !g.js) {
+    if (g.doc) return g.doc   // unchanged loaded document: the bytes it was loaded from (new.js:2034)
+    try {
+      if (g.generation !== generation) { gpuReplay(g.changes); g.generation = generation }
+      return addon.save(ctx, 0)
+    } catch (e) {
+      if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
+    }
+  }
+  return ref().save(toJs(backend))
+}
+
 function free(backend) {
   if (backend.state instanceof GpuState) { backend.state = null; backend.frozen = true } else ref().free(backend)
 }
@@ -135,11 +158,10 @@ function free(backend) {
 const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...args)
 
 module.exports = {
-  init, load, loadChanges, getPatch, getHeads, free,
+  init, load, loadChanges, getPatch, getHeads, free, save,
   clone: delegate1('clone'),
   applyChanges: delegate1('applyChanges'),
   applyLocalChange: delegate1('applyLocalChange'),
-  save: delegate1('save'),
   getAllChanges: delegate1('getAllChanges'),
   getChanges: delegate1('getChanges'),
   getChangeByHash: delegate1('getChangeByHash'),

@@ -10,6 +10,7 @@ const dir = process.argv[2] || path.join(__dirname, '..', '..', 'tests', 'golden
 let failed = 0, n = 0
 for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
   const fx = JSON.parse(fs.readFileSync(path.join(dir, f), 'utf8'))
+  if (!fx.changes && !fx.doc) continue   // not a patch fixture (e.g. digests of generated workloads)
   if (!fx.changes) {
     // document-only fixture: Backend.load + getPatch
     const want = fx.stock_equals_bigblock === false ? fx.load_patch_bigblock : fx.load_patch
@@ -29,6 +30,10 @@ for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
   if (!empty.frozen) { failed++; console.error(`FAIL ${f}: old handle not frozen`) }
   if (JSON.stringify(Backend.getHeads(state)) !== JSON.stringify(JSON.parse(expected).deps)) { failed++; console.error(`FAIL ${f}: heads`) }
   if (fx.doc) {
+    // Backend.save(state): served by the engine, byte-identical to the reference's document
+    const saved = Buffer.from(Backend.save(state))
+    n++
+    if (!saved.equals(Buffer.from(fx.doc, 'base64'))) { failed++; console.error(`FAIL ${f}: save`) } else console.log(`ok   ${f}  (save, ${saved.length} bytes)`)
     // Backend.load(Backend.save(state)) + getPatch
     const want = fx.stock_equals_bigblock === false ? fx.load_patch_bigblock : fx.load_patch
     const loaded = Backend.load(new Uint8Array(Buffer.from(fx.doc, 'base64')))
