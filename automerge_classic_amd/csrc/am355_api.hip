@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1615,6 +1616,14 @@ extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_byte
   }
   if (c->n_pending) return fail(c, AM355_E_UNSUPPORTED, "changes are queued: the document is saved by the JS path");
   hipStream_t st = c->stream;
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "am355_save: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+    t_start = now;
+  };
   const uint32_t N = (uint32_t)c->n_ops, P = (uint32_t)c->n_preds, NA = (uint32_t)c->actors.size();
   const uint32_t n_obj = c->counts.n_objects, n_ins = c->counts.n_list_ins;
   // ---- actor table of the document: order of first appearance (new.js:1434-1441); documents keep theirs ----
@@ -1713,6 +1722,7 @@ extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_byte
   HIPCHK(c, hipStreamSynchronize(st));
   uint32_t lens[E_NUM];
   memcpy(lens, c->h_words.p, 4 * E_NUM);
+  lap("row order + column encode");
   std::vector<SaveColumn> ops_cols;
   {
     size_t total = 0;
@@ -1731,6 +1741,7 @@ extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_byte
       at += lens[k];
     }
   }
+  lap("columns to host");
   // ---- change metadata columns (columnar.js:86-96, new.js:1680-1692) ----
   std::vector<SaveColumn> chg_cols;
   std::vector<uint8_t> tail;  // headsIndexes (+ extraBytes of a loaded document)
@@ -1801,11 +1812,25 @@ extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_byte
     }
     tail = t;
   }
+  lap("change metadata");
   // ---- document chunk (columnar.js:983-1004): actors, heads, the two column directories, column data, head indexes ----
-  for (auto& col : chg_cols)
-    if (!deflate_column(col)) return fail(c, AM355_E_NOMEM, "deflate failed");
-  for (auto& col : ops_cols)
-    if (!deflate_column(col)) return fail(c, AM355_E_NOMEM, "deflate failed");
+  {
+    // DEFLATE is the one sequential codec the format imposes; columns are independent streams, so the big ones get a host
+    // thread each (output per column is unchanged)
+    std::vector<SaveColumn*> all;
+    for (auto& col : chg_cols) all.push_back(&col);
+    for (auto& col : ops_cols) all.push_back(&col);
+    std::vector<std::thread> workers;
+    std::vector<int> ok(all.size(), 1);
+    for (size_t k = 0; k < all.size(); k++) {
+      if (all[k]->data.size() >= (64u << 10)) workers.emplace_back([&, k]() { ok[k] = deflate_column(*all[k]) ? 1 : 0; });
+      else ok[k] = deflate_column(*all[k]) ? 1 : 0;
+    }
+    for (auto& t : workers) t.join();
+    for (int v : ok)
+      if (!v) return fail(c, AM355_E_NOMEM, "deflate failed");
+  }
+  lap("deflate");
   HostOut body;
   body.uleb(NA);
   for (uint32_t i = 0; i < NA; i++) { const std::string& id = c->actors[actor_by_doc[i]]; body.uleb(id.size()); body.bytes(id.data(), id.size()); }
@@ -1834,6 +1859,7 @@ extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_byte
   c->saved.insert(c->saved.end(), magic, magic + 4);
   c->saved.insert(c->saved.end(), digest, digest + 4);
   c->saved.insert(c->saved.end(), chunk.begin(), chunk.end());
+  lap("assembly + checksum");
   *out_bytes = c->saved.data();
   *out_len = c->saved.size();
   return AM355_OK;
