@@ -27,19 +27,26 @@ namespace am355 {
 struct __attribute__((packed)) U8B {
   uint64_t v;
 };
-struct Cur {
-  const uint8_t* p;
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) { return ((const U8B*)p)->v; }
+#ifdef AM355_LDS_IS_DISTINCT
+__device__ __forceinline__ uint64_t load_u64_unaligned(LdsBytes p) { return ((const __attribute__((address_space(3))) U8B*)p)->v; }
+#endif
+
+// P = `const uint8_t*` (global memory) or LdsBytes
+template <class P>
+struct CurT {
+  P p;
   uint32_t off, len;
   uint64_t win;
   uint32_t win_off;  // window holds bytes [win_off, win_off + 8); WIN_EMPTY makes every offset miss
-  __device__ __forceinline__ Cur() {}
+  __device__ __forceinline__ CurT() {}
   static constexpr uint32_t WIN_EMPTY = 0xffffff00u;  // o - WIN_EMPTY = o + 256 >= 8 for every valid offset
-  __device__ __forceinline__ Cur(const uint8_t* p_, uint32_t off_, uint32_t len_) : p(p_), off(off_), len(len_), win(0), win_off(WIN_EMPTY) {}
+  __device__ __forceinline__ CurT(P p_, uint32_t off_, uint32_t len_) : p(p_), off(off_), len(len_), win(0), win_off(WIN_EMPTY) {}
   __device__ __forceinline__ uint32_t byte_at(uint32_t o) {
     uint32_t d = o - win_off;
     if (d >= 8) {
       // refill; near the end of the buffer fall back to byte loads so nothing beyond `len` is touched
-      if (o + 8 <= len) win = ((const U8B*)(p + o))->v;
+      if (o + 8 <= len) win = load_u64_unaligned(p + o);
       else {
         win = 0;
         for (uint32_t k = 0; o + k < len && k < 8; k++) win |= (uint64_t)p[o + k] << (8 * k);
@@ -50,6 +57,8 @@ struct Cur {
     return (uint32_t)(win >> (8 * d)) & 0xff;
   }
 };
+using Cur = CurT<const uint8_t*>;
+using CurLds = CurT<LdsBytes>;
 
 // 16-byte loads at arbitrary alignment (changes are packed back to back in the arena; gfx950 global loads are
 // alignment-agnostic, so this compiles to global_load_dwordx4)
@@ -70,10 +79,11 @@ __device__ __forceinline__ void stage_to_lds(uint8_t* dst /* 16-byte aligned */,
 }
 
 // byte-string equality, eight bytes per load (`limit` = end of the buffer both ranges live in: no read beyond it)
-__device__ __forceinline__ bool bytes_equal(const uint8_t* p, uint32_t a, uint32_t b, uint32_t len, uint32_t limit) {
+template <class P>
+__device__ __forceinline__ bool bytes_equal(P p, uint32_t a, uint32_t b, uint32_t len, uint32_t limit) {
   uint32_t k = 0;
   for (; k + 8 <= len && a + k + 8 <= limit && b + k + 8 <= limit; k += 8)
-    if (((const U8B*)(p + a + k))->v != ((const U8B*)(p + b + k))->v) return false;
+    if (load_u64_unaligned(p + a + k) != load_u64_unaligned(p + b + k)) return false;
   for (; k < len; k++)
     if (p[a + k] != p[b + k]) return false;
   return true;
@@ -82,7 +92,8 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t* p, uint32_t a, uint32
 constexpr uint64_t MAX_SAFE = 9007199254740991ull;  // 2^53 - 1
 
 // encoding.js:389-396 + 410-436: at most 10 bytes / 64 bits, result must fit in 53 bits
-__device__ __forceinline__ bool read_uleb(Cur& c, uint64_t& out) {
+template <class C>
+__device__ __forceinline__ bool read_uleb(C& c, uint64_t& out) {
   uint64_t v = 0;
   int shift = 0;
   while (c.off < c.len) {
@@ -100,7 +111,8 @@ __device__ __forceinline__ bool read_uleb(Cur& c, uint64_t& out) {
 }
 
 // encoding.js:398-408 + 438-488
-__device__ __forceinline__ bool read_sleb(Cur& c, int64_t& out) {
+template <class C>
+__device__ __forceinline__ bool read_sleb(C& c, int64_t& out) {
   uint64_t v = 0;
   int shift = 0;
   while (c.off < c.len) {
@@ -119,7 +131,8 @@ __device__ __forceinline__ bool read_sleb(Cur& c, int64_t& out) {
   return false;
 }
 
-__device__ __forceinline__ bool skip_bytes(Cur& c, uint64_t n) {
+template <class C>
+__device__ __forceinline__ bool skip_bytes(C& c, uint64_t n) {
   if (n > (uint64_t)(c.len - c.off)) return false;
   c.off += (uint32_t)n;
   return true;
@@ -250,8 +263,9 @@ __device__ __forceinline__ int col_slot(uint64_t id) {
 
 // number of values and their sum in an RLE-uint column (run level; validity of individual values is checked
 // again by the decode kernel)
-__device__ bool rle_count_sum(const uint8_t* p, uint32_t len, uint64_t& count, uint64_t& sum) {
-  Cur c(p, 0, len);
+template <class P>
+__device__ __forceinline__ bool rle_count_sum(P p, uint32_t len, uint64_t& count, uint64_t& sum) {
+  CurT<P> c(p, 0, len);
   count = 0;
   sum = 0;
   while (c.off < c.len) {
@@ -286,22 +300,12 @@ __device__ bool rle_count_sum(const uint8_t* p, uint32_t len, uint64_t& count, u
 // straight from global memory by the same code.
 constexpr uint32_t PARSE_STAGE = 8192;
 
-__global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
-                                                         uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries) {
-  __shared__ alignas(16) uint8_t stage[PARSE_STAGE];
-  wave_priority_high();
-  uint32_t c = blockIdx.x, lane = threadIdx.x;
-  if (c >= n_changes) return;
-  uint64_t base64 = offsets[c], total64 = offsets[c + 1] - offsets[c];
-  bool staged = total64 <= PARSE_STAGE;
-  if (staged) stage_to_lds(stage, arena + base64, (uint32_t)total64, lane);
-  __syncthreads();
-  if (lane != 0) return;
-  ChangeMeta* out = &metas[c];
+// header + column directory of one change, read through `p` (LDS when the change was staged, else global memory)
+template <class P>
+__device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len64, ChangeMeta* out, uint32_t* n_entries_out) {
   bool stored = false;
   ChangeMeta m;
-  m.base = offsets[c];
-  uint64_t len64 = offsets[c + 1] - offsets[c];
+  m.base = base64;
   m.len = (uint32_t)len64;
   m.flags = 0;
   m.seq = m.start_op = 0;
@@ -310,12 +314,11 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
   m.author_slot = m.max_first = NONE32;
   m.pad = 0;
   for (int k = 0; k < C_NUM; k++) m.col_off[k] = m.col_len[k] = 0;
-  const uint8_t* p = staged ? (const uint8_t*)stage : arena + m.base;
   do {
     if (len64 > 0xfffffff0ull) { m.flags |= F_OVERFLOW; break; }
     if (m.len < 10) { m.flags |= F_BAD_CHUNK; break; }
     if (p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83) { m.flags |= F_BAD_MAGIC; break; }
-    Cur cur(p, 9, m.len);
+    CurT<P> cur(p, 9, m.len);
     uint64_t chunk_len;
     if (!read_uleb(cur, chunk_len)) { m.flags |= F_BAD_LEB; break; }
     // the raw arena holds uncompressed (type 1) chunks only; exactly one container per change, no trailing bytes
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
     if (m.flags) break;
     if (total > (uint64_t)(m.len - cur.off)) { m.flags |= F_BAD_CHUNK; break; }
     uint32_t data_off = cur.off;
-    Cur dir(p, dir_off, m.len);
+    CurT<P> dir(p, dir_off, m.len);
     // the directory entries go straight to the output record: indexing a local copy by the column slot would push the
     // whole struct into scratch memory
     *out = m;
@@ -388,7 +391,23 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
   } while (0);
   if (!stored) *out = m;
   else { out->flags = m.flags; out->n_ops = m.n_ops; out->n_preds = m.n_preds; }
-  n_entries[c] = m.flags ? 0 : m.n_entries;
+  *n_entries_out = m.flags ? 0 : m.n_entries;
+}
+
+__global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
+                                                         uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries) {
+  __shared__ alignas(16) uint8_t stage[PARSE_STAGE];
+  wave_priority_high();
+  uint32_t c = blockIdx.x, lane = threadIdx.x;
+  if (c >= n_changes) return;
+  uint64_t base64 = offsets[c], total64 = offsets[c + 1] - offsets[c];
+  bool staged = total64 <= PARSE_STAGE;
+  if (staged) stage_to_lds(stage, arena + base64, (uint32_t)total64, lane);
+  __syncthreads();
+  if (lane != 0) return;
+  // two instantiations so that the staged case reads LDS with ds_read instead of FLAT loads through a generic pointer
+  if (staged) parse_change((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c]);
+  else parse_change(arena + base64, base64, total64, &metas[c], &n_entries[c]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -980,8 +999,8 @@ __device__ __forceinline__ bool wv_tok_sint(const WL& L, uint32_t t, int64_t& ou
 }
 
 // Stage + tokenise + record-walk one RLE column (uint or int values). All lanes must call it.
-template <class WL>
-__device__ void wv_load_column(WL& L, const uint8_t* __restrict__ col, uint32_t len, uint32_t lane) {
+template <class WL, class P>
+__device__ __forceinline__ void wv_load_column(WL& L, P col, uint32_t len, uint32_t lane) {
   __syncthreads();  // previous column's readers are done
   for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
   if (lane == 0) L.err = 0;
@@ -1106,6 +1125,105 @@ __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t x, uint32_t lane) 
   return x;
 }
 
+// key strings of one change (UTF-8 RLE column: string bytes are not LEB tokens, so lane 0 walks it -- one step per RECORD, one
+// per value only inside literals -- filling the run table in batches that all lanes then expand). P: LdsBytes when the
+// column is staged (the usual case), else global memory.
+template <class WL, class P>
+__device__ __forceinline__ uint32_t wv_key_column(WL& L, P keycol, uint32_t key_len, uint32_t col_abs, uint32_t n, uint32_t base, uint32_t lane, OpCols o) {
+CurT<P> c(keycol, 0, key_len);
+uint32_t err = 0;
+  int state = 0;                 // 0 none, 1 repetition, 2 literal, 3 nulls (encoding.js:865-887)
+  bool have_last = false;
+  uint32_t last_off = 0, last_len = 0;
+  int64_t lit_left = 0;          // values still to read from the current literal
+  uint32_t rows_done = 0;        // rows already expanded
+  for (;;) {
+    if (lane == 0) {
+      uint32_t nr = 0, e = 0;
+      uint64_t rows = rows_done;
+      auto same = [&](uint32_t off, uint32_t len) {
+        return have_last && last_len == len && bytes_equal(c.p, last_off, off, len, c.len);
+      };
+      while (nr < WL::RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
+        uint32_t kind, off = 0, len = 0;
+        uint64_t count = 1;
+        if (lit_left > 0) {
+          uint64_t l;
+          if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
+          off = c.off; len = (uint32_t)l;
+          if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
+          if (same(off, len)) { e = F_BAD_RLE; break; }  // repetition inside a literal
+          have_last = true; last_off = off; last_len = len;
+          lit_left--;
+          kind = RK_REP;
+        } else {
+          int64_t cnt;
+          if (!read_sleb(c, cnt)) { e = F_BAD_LEB; break; }
+          if (cnt > 1) {
+            uint64_t l;
+            if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
+            off = c.off; len = (uint32_t)l;
+            if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
+            if ((state == 1 || state == 2) && same(off, len)) { e = F_BAD_RLE; break; }
+            state = 1; have_last = true; last_off = off; last_len = len;
+            kind = RK_REP; count = (uint64_t)cnt;
+          } else if (cnt == 1) { e = F_BAD_RLE; break; }
+          else if (cnt < 0) {
+            if (state == 2) { e = F_BAD_RLE; break; }
+            state = 2; lit_left = -cnt;
+            continue;
+          } else {
+            uint64_t z;
+            if (state == 3) { e = F_BAD_RLE; break; }
+            if (!read_uleb(c, z)) { e = F_BAD_LEB; break; }
+            if (z == 0) { e = F_BAD_RLE; break; }
+            state = 3; have_last = false;
+            kind = RK_NUL; count = z;
+          }
+        }
+        L.run_start[nr] = (uint32_t)(rows - rows_done);
+        L.run_kind[nr] = (uint8_t)kind;
+        L.run_tok[nr] = col_abs + off;
+        L.tok_lo[nr] = len;
+        nr++;
+        rows += count;
+        if (rows > n) rows = n;
+      }
+      bool exhausted = !(lit_left > 0 || c.off < c.len);
+      if ((exhausted || e) && rows < n) {  // past the end of the column every value is null
+        if (nr == WL::RUNMAX) nr--, rows = rows_done + L.run_start[nr];  // (cannot happen: loop stops at RUNMAX only with data left)
+        L.run_start[nr] = (uint32_t)(rows - rows_done);
+        L.run_kind[nr] = RK_NUL;
+        L.run_tok[nr] = 0;
+        L.tok_lo[nr] = 0;
+        nr++;
+        rows = n;
+      }
+      L.run_start[nr] = (uint32_t)(rows - rows_done);
+      L.n_runs = nr;
+      L.total_rows = (uint32_t)(rows - rows_done);
+      L.err = e;
+    }
+    __syncthreads();
+    err |= L.err;
+    uint32_t batch = L.total_rows, nr = L.n_runs;
+    for (uint32_t i = lane; i < batch; i += WAVE) {
+      uint32_t lo = 0, hi = nr;
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (L.run_start[mid] <= i) lo = mid; else hi = mid;
+      }
+      bool nul = L.run_kind[lo] == RK_NUL;
+      o.key_off[base + rows_done + i] = nul ? 0 : L.run_tok[lo];
+      o.key_len[base + rows_done + i] = nul ? NONE32 : L.tok_lo[lo];
+    }
+    rows_done += batch;
+    __syncthreads();
+    if (rows_done >= n || batch == 0) break;
+  }
+  return err;
+}
+
 template <class WL>
 __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                        const ChangePlan* __restrict__ plans, uint32_t n_plans, ActorXlate x, OpCols o,
@@ -1137,10 +1255,15 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     }
   const bool staged = reg_hi > reg_lo && reg_hi - reg_lo <= WL::REGION;
   if (staged) stage_to_lds(L.region, p + reg_lo, reg_hi - reg_lo, lane);
-  auto colp = [&](int k) -> const uint8_t* { return staged && col_len[k] ? (const uint8_t*)L.region + (col_off[k] - reg_lo) : p + col_off[k]; };
+  // columns are read through LDS-typed pointers when staged (ds_read), through global pointers otherwise; a pointer that
+  // could be either would make every access a FLAT load
+  auto load_col = [&](int k) {
+    if (staged && col_len[k]) wv_load_column(L, (LdsBytes)(L.region + (col_off[k] - reg_lo)), col_len[k], lane);
+    else wv_load_column(L, p + col_off[k], col_len[k], lane);
+  };
 
   // ---- action (+ op ids: op i of a change is (startOp + i, author), new.js:708-709) ----
-  wv_load_column(L, colp(C_ACTION), col_len[C_ACTION], lane);
+  load_col(C_ACTION);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1155,8 +1278,13 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   {
     __syncthreads();
     uint32_t len = col_len[C_INSERT];
-    const uint8_t* col = colp(C_INSERT);
-    for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
+    if (staged && len) {
+      LdsBytes col = (LdsBytes)(L.region + (col_off[C_INSERT] - reg_lo));
+      for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
+    } else {
+      const uint8_t* col = p + col_off[C_INSERT];
+      for (uint32_t i = lane; i < len; i += WAVE) L.bytes[i] = col[i];
+    }
     __syncthreads();
     // tokens = run lengths
     uint32_t tok_base = 0, carry_start = 0;
@@ -1213,7 +1341,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     }
   }
   // ---- object id ----
-  wv_load_column(L, colp(C_OBJ_ACTOR), col_len[C_OBJ_ACTOR], lane);
+  load_col(C_OBJ_ACTOR);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1222,7 +1350,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     if (!nul) { if ((uint64_t)v >= pl.n_actors) err |= F_BAD_ROW; else r = L.rank[v]; }
     o.obj_actor[base + i] = r;
   }
-  wv_load_column(L, colp(C_OBJ_CTR), col_len[C_OBJ_CTR], lane);
+  load_col(C_OBJ_CTR);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1232,7 +1360,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     o.obj_ctr[base + i] = nul ? 0 : (uint32_t)v;
   }
   // ---- key: element id (actor, delta-coded counter) ----
-  wv_load_column(L, colp(C_KEY_ACTOR), col_len[C_KEY_ACTOR], lane);
+  load_col(C_KEY_ACTOR);
   err |= L.err;
   for (uint32_t i = lane; i < n; i += WAVE) {
     bool nul; int64_t v;
@@ -1241,7 +1369,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     if (!nul) { if ((uint64_t)v >= pl.n_actors) err |= F_BAD_ROW; else r = L.rank[v]; }
     o.key_actor[base + i] = r;
   }
-  wv_load_column(L, colp(C_KEY_CTR), col_len[C_KEY_CTR], lane);
+  load_col(C_KEY_CTR);
   err |= L.err;
   {
     int64_t carry = 0;
@@ -1261,112 +1389,24 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
       }
     }
   }
-  // ---- key: string (UTF-8 RLE column: string bytes are not LEB tokens, so lane 0 walks it -- one step per RECORD, one
-  //      per value only inside literals -- filling the run table in batches that all lanes then expand) ----
+  // ---- key: string ----
   {
     __syncthreads();
     // lane 0 compares neighbouring strings byte by byte: make sure it does so in LDS. If the whole column region did
     // not fit, the key column alone usually does (`region` is unused in that case: the other columns stage through `bytes`).
-    const uint8_t* keycol = colp(C_KEY_STR);
+    const uint32_t col_abs = abs0 + col_off[C_KEY_STR];
+    uint32_t key_at = staged ? col_off[C_KEY_STR] - reg_lo : 0;
+    bool key_lds = staged && col_len[C_KEY_STR];
     if (!staged && col_len[C_KEY_STR] && col_len[C_KEY_STR] <= WL::REGION) {
       stage_to_lds(L.region, p + col_off[C_KEY_STR], col_len[C_KEY_STR], lane);
-      keycol = L.region;
+      key_lds = true;
       __syncthreads();
     }
-    Cur c(keycol, 0, col_len[C_KEY_STR]);
-    const uint32_t col_abs = abs0 + col_off[C_KEY_STR];
-    int state = 0;                 // 0 none, 1 repetition, 2 literal, 3 nulls (encoding.js:865-887)
-    bool have_last = false;
-    uint32_t last_off = 0, last_len = 0;
-    int64_t lit_left = 0;          // values still to read from the current literal
-    uint32_t rows_done = 0;        // rows already expanded
-    for (;;) {
-      if (lane == 0) {
-        uint32_t nr = 0, e = 0;
-        uint64_t rows = rows_done;
-        auto same = [&](uint32_t off, uint32_t len) {
-          return have_last && last_len == len && bytes_equal(c.p, last_off, off, len, c.len);
-        };
-        while (nr < WL::RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
-          uint32_t kind, off = 0, len = 0;
-          uint64_t count = 1;
-          if (lit_left > 0) {
-            uint64_t l;
-            if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
-            off = c.off; len = (uint32_t)l;
-            if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
-            if (same(off, len)) { e = F_BAD_RLE; break; }  // repetition inside a literal
-            have_last = true; last_off = off; last_len = len;
-            lit_left--;
-            kind = RK_REP;
-          } else {
-            int64_t cnt;
-            if (!read_sleb(c, cnt)) { e = F_BAD_LEB; break; }
-            if (cnt > 1) {
-              uint64_t l;
-              if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
-              off = c.off; len = (uint32_t)l;
-              if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
-              if ((state == 1 || state == 2) && same(off, len)) { e = F_BAD_RLE; break; }
-              state = 1; have_last = true; last_off = off; last_len = len;
-              kind = RK_REP; count = (uint64_t)cnt;
-            } else if (cnt == 1) { e = F_BAD_RLE; break; }
-            else if (cnt < 0) {
-              if (state == 2) { e = F_BAD_RLE; break; }
-              state = 2; lit_left = -cnt;
-              continue;
-            } else {
-              uint64_t z;
-              if (state == 3) { e = F_BAD_RLE; break; }
-              if (!read_uleb(c, z)) { e = F_BAD_LEB; break; }
-              if (z == 0) { e = F_BAD_RLE; break; }
-              state = 3; have_last = false;
-              kind = RK_NUL; count = z;
-            }
-          }
-          L.run_start[nr] = (uint32_t)(rows - rows_done);
-          L.run_kind[nr] = (uint8_t)kind;
-          L.run_tok[nr] = col_abs + off;
-          L.tok_lo[nr] = len;
-          nr++;
-          rows += count;
-          if (rows > n) rows = n;
-        }
-        bool exhausted = !(lit_left > 0 || c.off < c.len);
-        if ((exhausted || e) && rows < n) {  // past the end of the column every value is null
-          if (nr == WL::RUNMAX) nr--, rows = rows_done + L.run_start[nr];  // (cannot happen: loop stops at RUNMAX only with data left)
-          L.run_start[nr] = (uint32_t)(rows - rows_done);
-          L.run_kind[nr] = RK_NUL;
-          L.run_tok[nr] = 0;
-          L.tok_lo[nr] = 0;
-          nr++;
-          rows = n;
-        }
-        L.run_start[nr] = (uint32_t)(rows - rows_done);
-        L.n_runs = nr;
-        L.total_rows = (uint32_t)(rows - rows_done);
-        L.err = e;
-      }
-      __syncthreads();
-      err |= L.err;
-      uint32_t batch = L.total_rows, nr = L.n_runs;
-      for (uint32_t i = lane; i < batch; i += WAVE) {
-        uint32_t lo = 0, hi = nr;
-        while (hi - lo > 1) {
-          uint32_t mid = (lo + hi) >> 1;
-          if (L.run_start[mid] <= i) lo = mid; else hi = mid;
-        }
-        bool nul = L.run_kind[lo] == RK_NUL;
-        o.key_off[base + rows_done + i] = nul ? 0 : L.run_tok[lo];
-        o.key_len[base + rows_done + i] = nul ? NONE32 : L.tok_lo[lo];
-      }
-      rows_done += batch;
-      __syncthreads();
-      if (rows_done >= n || batch == 0) break;
-    }
+    if (key_lds) err |= wv_key_column(L, (LdsBytes)(L.region + key_at), col_len[C_KEY_STR], col_abs, n, base, lane, o);
+    else err |= wv_key_column(L, p + col_off[C_KEY_STR], col_len[C_KEY_STR], col_abs, n, base, lane, o);
   }
   // ---- value: (len << 4 | tag) per row, offsets into valRaw are an exclusive prefix sum of the lengths ----
-  wv_load_column(L, colp(C_VAL_LEN), col_len[C_VAL_LEN], lane);
+  load_col(C_VAL_LEN);
   err |= L.err;
   {
     int64_t carry = 0;
@@ -1388,7 +1428,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   }
   // ---- preds: group cardinality, then the two value columns consumed predNum[i] entries per row ----
   uint32_t total_preds = 0;
-  wv_load_column(L, colp(C_PRED_NUM), col_len[C_PRED_NUM], lane);
+  load_col(C_PRED_NUM);
   err |= L.err;
   {
     int64_t carry = 0;
@@ -1407,7 +1447,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     }
     total_preds = (uint64_t)carry > n_preds_cap ? 0 : (uint32_t)carry;
   }
-  wv_load_column(L, colp(C_PRED_ACTOR), col_len[C_PRED_ACTOR], lane);
+  load_col(C_PRED_ACTOR);
   err |= L.err;
   for (uint32_t j = lane; j < total_preds; j += WAVE) {
     bool nul; int64_t v;
@@ -1418,7 +1458,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     else r = L.rank[v];
     o.pred_actor[pl.pred_base + j] = r;
   }
-  wv_load_column(L, colp(C_PRED_CTR), col_len[C_PRED_CTR], lane);
+  load_col(C_PRED_CTR);
   err |= L.err;
   {
     int64_t carry = 0;

@@ -41,6 +41,14 @@ enum Flag : uint32_t {
 // guarantee that on every runtime).
 __device__ __forceinline__ void wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
 
+// Byte pointer into LDS with its address space in the type. A plain `const uint8_t*` that may point to LDS or to global
+// memory is a generic pointer: every load through it is a FLAT instruction (slow path, both counters), which is what a
+// lane-serial parser staged in LDS must not pay per byte. (The CPU emulation of tests/emu defines it as a plain pointer.)
+#ifndef AM355_LDS_BYTES_DEFINED
+typedef const __attribute__((address_space(3))) uint8_t* LdsBytes;
+#define AM355_LDS_IS_DISTINCT 1
+#endif
+
 __device__ __forceinline__ uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
 
 }  // namespace am355

@@ -74,6 +74,10 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 
 // ---- per-thread coordinates --------------------------------------------------------------------------
 struct emu_uint3 { unsigned x, y, z; };
+// LDS is ordinary memory here
+#define AM355_LDS_BYTES_DEFINED 1
+typedef const uint8_t* LdsBytes;
+
 extern thread_local emu_uint3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
 
