@@ -1133,17 +1133,13 @@ __device__ __forceinline__ uint32_t wv_key_column(WL& L, P keycol, uint32_t key_
 CurT<P> c(keycol, 0, key_len);
 uint32_t err = 0;
   int state = 0;                 // 0 none, 1 repetition, 2 literal, 3 nulls (encoding.js:865-887)
-  bool have_last = false;
-  uint32_t last_off = 0, last_len = 0;
+  uint32_t prev_kind = RK_NUL, prev_off = 0, prev_len = 0;  // last run of the previous batch (lane 0 uses it)
   int64_t lit_left = 0;          // values still to read from the current literal
   uint32_t rows_done = 0;        // rows already expanded
   for (;;) {
     if (lane == 0) {
       uint32_t nr = 0, e = 0;
       uint64_t rows = rows_done;
-      auto same = [&](uint32_t off, uint32_t len) {
-        return have_last && last_len == len && bytes_equal(c.p, last_off, off, len, c.len);
-      };
       while (nr < WL::RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
         uint32_t kind, off = 0, len = 0;
         uint64_t count = 1;
@@ -1152,8 +1148,6 @@ uint32_t err = 0;
           if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
           off = c.off; len = (uint32_t)l;
           if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
-          if (same(off, len)) { e = F_BAD_RLE; break; }  // repetition inside a literal
-          have_last = true; last_off = off; last_len = len;
           lit_left--;
           kind = RK_REP;
         } else {
@@ -1164,8 +1158,7 @@ uint32_t err = 0;
             if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }
             off = c.off; len = (uint32_t)l;
             if (!skip_bytes(c, l)) { e = F_BAD_LEB; break; }
-            if ((state == 1 || state == 2) && same(off, len)) { e = F_BAD_RLE; break; }
-            state = 1; have_last = true; last_off = off; last_len = len;
+            state = 1;
             kind = RK_REP; count = (uint64_t)cnt;
           } else if (cnt == 1) { e = F_BAD_RLE; break; }
           else if (cnt < 0) {
@@ -1177,7 +1170,7 @@ uint32_t err = 0;
             if (state == 3) { e = F_BAD_RLE; break; }
             if (!read_uleb(c, z)) { e = F_BAD_LEB; break; }
             if (z == 0) { e = F_BAD_RLE; break; }
-            state = 3; have_last = false;
+            state = 3;
             kind = RK_NUL; count = z;
           }
         }
@@ -1207,6 +1200,16 @@ uint32_t err = 0;
     __syncthreads();
     err |= L.err;
     uint32_t batch = L.total_rows, nr = L.n_runs;
+    // a value never equals its predecessor (neither inside a literal nor across records, encoding.js:868-872): checked here,
+    // one lane per run, instead of byte by byte inside lane 0's walk
+    for (uint32_t r = lane; r < nr; r += WAVE) {
+      uint32_t k = L.run_kind[r], pk = r ? L.run_kind[r - 1] : prev_kind;
+      if (k == RK_NUL || pk == RK_NUL) continue;
+      uint32_t off = L.run_tok[r] - col_abs, len = L.tok_lo[r];
+      uint32_t poff = r ? L.run_tok[r - 1] - col_abs : prev_off, plen = r ? L.tok_lo[r - 1] : prev_len;
+      if (len == plen && bytes_equal(keycol, poff, off, len, key_len)) err |= F_BAD_RLE;
+    }
+    if (lane == 0 && nr) { prev_kind = L.run_kind[nr - 1]; prev_off = L.run_tok[nr - 1] - col_abs; prev_len = L.tok_lo[nr - 1]; }
     for (uint32_t i = lane; i < batch; i += WAVE) {
       uint32_t lo = 0, hi = nr;
       while (hi - lo > 1) {
