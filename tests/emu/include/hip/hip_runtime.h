@@ -219,6 +219,10 @@ inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 
 // ---- atomics -----------------------------------------------------------------------------------------
+#define __HIP_MEMORY_SCOPE_AGENT 0
+template <class T> inline T __hip_atomic_load(const T* p, int order, int) { return __atomic_load_n(p, order); }
+template <class T> inline void __hip_atomic_store(T* p, T v, int order, int) { __atomic_store_n(p, v, order); }
+inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
 template <class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <class T> inline T atomicSub(T* p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
 template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
