@@ -242,6 +242,14 @@ function main() {
   }
   fs.mkdirSync(outDir, { recursive: true })
   const scenarios = {}
+  if (process.env.CAMPAIGN) {
+    // differential campaign: CAMPAIGN="seed:actors:steps:depth,..." (mixed) or "t:seed:actors:rounds:burst" (text) -> only these
+    for (const spec of process.env.CAMPAIGN.split(',')) {
+      const f = spec.split(':')
+      if (f[0] === 't') scenarios[`campaign_text_${f[1]}`] = { changes: textScenario(+f[1], +f[2], +f[3], +f[4]), note: `campaign text ${spec}` }
+      else scenarios[`campaign_mixed_${f[0]}`] = { changes: frontendScenario(+f[0], +f[1], +f[2], +f[3]), note: `campaign mixed ${spec}` }
+    }
+  } else {
   scenarios.frontend_mixed_3actors = { changes: frontendScenario(101, 3, 120, 2), note: 'real frontend, 3 actors, maps/lists/text/counters/tables, random merges' }
   scenarios.frontend_mixed_6actors = { changes: frontendScenario(202, 6, 260, 3), note: 'real frontend, 6 actors, deeper nesting' }
   scenarios.frontend_text_4actors = { changes: textScenario(303, 4, 6, 24), note: 'real frontend, Text typing bursts + deletes, synced rounds (multi-insert ops)' }
@@ -256,6 +264,7 @@ function main() {
     scenarios.frontend_mixed_3actors_shuffled = { changes: base, note: 'same changes as frontend_mixed_3actors, shuffled delivery' }
     const dup = scenarios.frontend_text_4actors.changes.slice(0, 9)
     scenarios.frontend_text_4actors_dups = { changes: scenarios.frontend_text_4actors.changes.concat(dup), note: 'duplicate changes appended' }
+  }
   }
   for (const name of Object.keys(scenarios)) {
     const sc = scenarios[name]
