@@ -110,8 +110,10 @@ struct am355_ctx {
   bool doc_serial = false;           // AM355_DOC_SERIAL=1: lane-serial column decoders (first version, kept for cross-checks)
   // stage-1 side tables (device) and their pinned host mirrors
   DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1;
-  HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_briefs, h_distinct;
-  DevBuf d_briefs, d_distinct;
+  HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_s1;
+  DevBuf d_s1;                 // stage-1 results read by the host: flag words | distinct actor ids | one ChangeBrief per change
+  ChangeBrief* hp_briefs = nullptr;
+  uint32_t* hp_distinct = nullptr;
   bool have_host_metas = false;
   uint32_t amap_cap = 0, slot_mask = 0, hash_mask = 0;
   bool used_fast_path = false;
@@ -135,7 +137,9 @@ struct am355_ctx {
   std::vector<uint8_t> heads;
   uint32_t n_applied = 0, n_pending = 0;
   uint64_t n_ops = 0, n_preds = 0, max_op = 0;
-  DevBuf d_plans, d_amap, d_spans, d_tab_off;
+  DevBuf d_plans, d_amap, d_tables;   // d_tables: plans | actor spans | span offsets | slot ranks or actor tables (run_device)
+  ActorSpan* p_spans = nullptr;
+  uint32_t* p_tab_off = nullptr;
 
   // op rows + merge buffers (one arena of u32 words per purpose)
   DevBuf d_cols, d_pred, d_merge, d_sort, d_ir, d_counts;
@@ -203,16 +207,15 @@ extern "C" void am355_destroy(am355_ctx* c) {
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
                     &c->d_words, &c->d_slot_rank, &c->d_scan1})
     b->release();
-  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_briefs, &c->h_distinct}) b->release();
-  c->d_briefs.release();
-  c->d_distinct.release();
+  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1}) b->release();
+  c->d_s1.release();
   for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
-  for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_spans, &c->d_tab_off, &c->d_cols, &c->d_pred,
+  for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
   for (HostBuf* b : {&c->h_metas, &c->h_counts, &c->h_ir, &c->h_rows, &c->h_biginfo, &c->h_encout}) b->release();
@@ -817,8 +820,8 @@ static int error_for_flags(am355_ctx* c, uint32_t f, const char* what) {
 // needs the change hashes (dependency resolution, heads) has been checked on the device and is confirmed when stream
 // B is joined.
 static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
-  const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
-  const uint32_t* distinct = c->h_distinct.as<uint32_t>();
+  const ChangeBrief* br = c->hp_briefs;
+  const uint32_t* distinct = c->hp_distinct;
   const unsigned long long* slots = (const unsigned long long*)(distinct + 2 + distinct_capacity());  // ((offset + 1) << 16) | length
   const uint8_t* raw = c->raw.data();
   uint32_t n = c->n_changes, n_slots = c->slot_mask + 1;
@@ -927,8 +930,8 @@ static int setup_buffers(am355_ctx* c) {
     b.arena = c->d_arena.as<uint8_t>();
     b.ops = c->cols;
     b.n_ops = N; b.n_preds = P; b.n_actors = NA;
-    b.actor_tab_off = c->d_tab_off.as<uint32_t>();
-    b.spans = c->d_spans.as<ActorSpan>();
+    b.actor_tab_off = c->p_tab_off;
+    b.spans = c->p_spans;
     b.bits_ctr = (uint32_t)bits_ctr; b.bits_actor = (uint32_t)bits_actor;
     b.zero_base = p;
     b.succ_cnt = carve<uint32_t>(p, Nc); b.inc_cnt = carve<uint32_t>(p, Nc); b.val_cnt = carve<uint32_t>(p, Nc);
@@ -963,10 +966,16 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   hipStream_t st = c->stream;
   size_t np = c->plans.size();
   uint32_t NA = (uint32_t)c->actors.size();
-  if (!c->d_plans.ensure(sizeof(ChangePlan) * std::max<size_t>(np, 1)) || !c->d_amap.ensure(4 * std::max<size_t>(c->amap.size(), 1)) ||
-      !c->d_spans.ensure(sizeof(ActorSpan) * std::max<size_t>(c->spans.size(), 1)) || !c->d_tab_off.ensure(4 * (size_t)(NA + 1)) ||
-      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)))
-    return fail(c, AM355_E_NOMEM, "device allocation failed");
+  // the host-built tables (plans, actor spans, span offsets, slot ranks or actor translation tables) live in one device block so
+  // that they travel in ONE host-to-device copy from the pinned staging buffer
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t b_plans = sizeof(ChangePlan) * np, b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size();
+  size_t b_rank = slot_rank ? 4 * slot_rank->size() : 0, b_amap = slot_rank ? 0 : 4 * c->amap.size();
+  size_t o_spans = al(b_plans + 16), o_tab = o_spans + al(b_spans + 16), o_x = o_tab + al(b_tab + 16), tables_bytes = o_x + al(std::max(b_rank, b_amap) + 16);
+  if (!c->d_tables.ensure(tables_bytes) || !c->h_stage.ensure(tables_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed");
+  uint8_t* d_tables = c->d_tables.as<uint8_t>();
+  c->p_spans = (ActorSpan*)(d_tables + o_spans);
+  c->p_tab_off = (uint32_t*)(d_tables + o_tab);
   int rcb = setup_buffers(c);
   if (rcb) return rcb;
   c->applied_change.resize(np);
@@ -976,7 +985,7 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   // ones with a column too long for LDS staging
   uint32_t n_small = 0, n_large = 0;
   {
-    const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
+    const ChangeBrief* br = c->hp_briefs;
     std::vector<ChangePlan> large, serial;
     size_t w = 0;
     for (size_t i = 0; i < np; i++) {
@@ -990,39 +999,29 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     for (auto& pl : large) c->plans[w++] = pl;
     for (auto& pl : serial) c->plans[w++] = pl;
   }
-  // host -> device tables go through one pinned staging buffer (pageable std::vector memory would make every copy a
-  // synchronous bounce through the driver's own staging)
+  // (pageable std::vector memory would make the copy a synchronous bounce through the driver's own staging)
   const uint32_t* d_amap;
   const uint32_t* d_rank = nullptr;
   {
-    size_t b_plans = sizeof(ChangePlan) * np, b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size();
-    size_t b_rank = slot_rank ? 4 * slot_rank->size() : 0, b_amap = slot_rank ? 0 : 4 * c->amap.size();
-    if (!c->h_stage.ensure(b_plans + b_spans + b_tab + b_rank + b_amap + 64)) return fail(c, AM355_E_NOMEM, "host allocation failed");
     uint8_t* h = c->h_stage.as<uint8_t>();
-    auto push = [&](void* dev, const void* src, size_t bytes) -> hipError_t {
-      if (!bytes) return hipSuccess;
-      memcpy(h, src, bytes);
-      hipError_t e = hipMemcpyAsync(dev, h, bytes, hipMemcpyHostToDevice, st);
-      h += bytes;
-      return e;
-    };
-    HIPCHK(c, push(c->d_plans.p, c->plans.data(), b_plans));
-    HIPCHK(c, push(c->d_spans.p, c->spans.data(), b_spans));
-    HIPCHK(c, push(c->d_tab_off.p, c->actor_tab_off.data(), b_tab));
+    if (b_plans) memcpy(h, c->plans.data(), b_plans);
+    if (b_spans) memcpy(h + o_spans, c->spans.data(), b_spans);
+    if (b_tab) memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
     if (slot_rank) {
-      HIPCHK(c, push(c->d_slot_rank.p, slot_rank->data(), b_rank));
+      if (b_rank) memcpy(h + o_x, slot_rank->data(), b_rank);
       d_amap = c->d_amap_prov.as<uint32_t>();
-      d_rank = c->d_slot_rank.as<uint32_t>();
+      d_rank = (const uint32_t*)(d_tables + o_x);
     } else {
-      HIPCHK(c, push(c->d_amap.p, c->amap.data(), b_amap));
-      d_amap = c->d_amap.as<uint32_t>();
+      if (b_amap) memcpy(h + o_x, c->amap.data(), b_amap);
+      d_amap = (const uint32_t*)(d_tables + o_x);
     }
+    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_x + std::max(b_rank, b_amap), hipMemcpyHostToDevice, st));
   }
 
   // ---- stage 1b: column decode ----
   HIPCHK(c, hipEventRecord(c->ev[2], st));
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
-  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n_small, n_large, (uint32_t)np - n_small - n_large, d_amap,
+  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, (uint32_t)np - n_small - n_large, d_amap,
                         d_rank,
                         c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3, c->ev_fork, c->ev_join);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
@@ -1178,27 +1177,38 @@ extern "C" int am355_replay(am355_ctx* c) {
       !c->d_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->d_first_idx.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_hashes.ensure(32 * n1) ||
       !c->d_hash_tab.ensure(4 * (size_t)(c->hash_mask + 1)) || !c->d_min_idx.ensure(4 * n1) || !c->d_has_dep.ensure(n1) || !c->d_words.ensure(4 * W_NUM) ||
       !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
-      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_briefs.ensure(sizeof(ChangeBrief) * n1) || !c->h_briefs.ensure(sizeof(ChangeBrief) * n1) ||
-      !c->d_distinct.ensure(12 * (size_t)distinct_capacity() + 16) || !c->h_distinct.ensure(12 * (size_t)distinct_capacity() + 16))
+      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM))
     return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
   c->have_host_metas = false;
-  uint32_t* d_words = c->d_words.as<uint32_t>();
+  // what the host reads after stage 1 -- a few flag words, the distinct actor ids, one brief per change -- sits in one device
+  // block: one memset clears the words and the distinct counter, one copy brings everything back
+  const size_t s1_distinct = 64, s1_briefs = s1_distinct + ((12 * (size_t)distinct_capacity() + 16 + 63) & ~(size_t)63);
+  const size_t s1_bytes = s1_briefs + sizeof(ChangeBrief) * n1;
+  if (!c->d_s1.ensure(s1_bytes) || !c->h_s1.ensure(s1_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
+  uint32_t* d_wa = c->d_s1.as<uint32_t>();                        // W_FLAGS_A, W_FAST_A, W_TOTAL_ENTRIES
+  uint32_t* d_distinct = (uint32_t*)(c->d_s1.as<uint8_t>() + s1_distinct);
+  ChangeBrief* d_briefs = (ChangeBrief*)(c->d_s1.as<uint8_t>() + s1_briefs);
+  const uint32_t* h_wa = c->h_s1.as<uint32_t>();
+  c->hp_distinct = (uint32_t*)(c->h_s1.as<uint8_t>() + s1_distinct);
+  c->hp_briefs = (ChangeBrief*)(c->h_s1.as<uint8_t>() + s1_briefs);
+  uint32_t* d_words = c->d_words.as<uint32_t>();  // stream B's words (W_FLAGS_B, W_FAST_B)
   uint32_t* h_words = c->h_words.as<uint32_t>();
 
   // ---- stream A: parse ----
   HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, sa));
+  HIPCHK(c, hipMemsetAsync(d_wa, 0, s1_distinct + 16, sa));
   HIPCHK(c, hipEventRecord(c->ev[0], sa));
   launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), sa);
   HIPCHK(c, hipEventRecord(c->ev_parse, sa));
 
-  exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_words + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
+  exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_wa + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
   for (int attempt = 0;; attempt++) {
     HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), sa));
     HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), sa));
-    HIPCHK(c, hipMemsetAsync(c->d_distinct.p, 0, 4, sa));
+    if (attempt) HIPCHK(c, hipMemsetAsync(d_distinct, 0, 4, sa));
     launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
-                        c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_words + W_FLAGS_A, d_words + W_FAST_A,
-                        c->d_distinct.as<uint32_t>(), c->d_briefs.as<ChangeBrief>(), sa);
+                        c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_wa + W_FLAGS_A, d_wa + W_FAST_A,
+                        d_distinct, d_briefs, sa);
     HIPCHK(c, hipEventRecord(c->ev[1], sa));
     if (attempt == 0) {
       // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. It starts
@@ -1218,15 +1228,13 @@ extern "C" int am355_replay(am355_ctx* c) {
       HIPCHK(c, hipEventRecord(c->ev_b1, sb));
     }
     // the host only needs a 32-byte digest per change and the handful of distinct actor ids
-    HIPCHK(c, hipMemcpyAsync(c->h_briefs.p, c->d_briefs.p, sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
-    HIPCHK(c, hipMemcpyAsync(c->h_distinct.p, c->d_distinct.p, 12 * (size_t)distinct_capacity() + 16, hipMemcpyDeviceToHost, sa));
-    HIPCHK(c, hipMemcpyAsync(h_words, d_words, 12, hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
     HIPCHK(c, hipStreamSynchronize(sa));
-    if (!(h_words[W_FAST_A] & FF_CAPACITY) || attempt) break;
+    if (!(h_wa[W_FAST_A] & FF_CAPACITY) || attempt) break;
     // the staging buffer for actor tables was too small: grow to the measured total and redo the interning
-    c->amap_cap = h_words[W_TOTAL_ENTRIES] + 1024;
+    c->amap_cap = h_wa[W_TOTAL_ENTRIES] + 1024;
     if (!c->d_amap_prov.ensure(4 * (size_t)c->amap_cap)) return fail(c, AM355_E_NOMEM, "device allocation failed (actor tables)");
-    HIPCHK(c, hipMemsetAsync(d_words + W_FAST_A, 0, 4, sa));
+    HIPCHK(c, hipMemsetAsync(d_wa + W_FAST_A, 0, 4, sa));
   }
 
   // ---- host: flags, in-order plan ----
@@ -1234,13 +1242,13 @@ extern "C" int am355_replay(am355_ctx* c) {
   float ms_host = 0;
   int rc = AM355_OK;
   {
-    const ChangeBrief* br = c->h_briefs.as<ChangeBrief>();
-    uint32_t dev_flags = h_words[W_FLAGS_A];
+    const ChangeBrief* br = c->hp_briefs;
+    uint32_t dev_flags = h_wa[W_FLAGS_A];
     for (uint32_t i = 0; i < n; i++) dev_flags |= br[i].flags_fits & 0x3fffffffu;
     if (dev_flags) { (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
   }
-  bool fast = h_words[W_FAST_A] == 0;
-  if (c->h_distinct.as<uint32_t>()[0] > distinct_capacity()) fast = false;  // thousands of actors: the general path interns them on the host
+  bool fast = h_wa[W_FAST_A] == 0;
+  if (c->hp_distinct[0] > distinct_capacity()) fast = false;  // thousands of actors: the general path interns them on the host
   std::vector<uint32_t> slot_rank;
   int opt_rc = AM355_OK;
   uint32_t opt_flags = 0;
