@@ -17,6 +17,7 @@
 const path = require('path')
 
 const JS_ONLY = process.env.MI355X_BACKEND_JS_ONLY === '1'
+const HYDRATE_FROM_DOC = process.env.MI355X_HYDRATE === 'doc'
 let addon = null, ctx = null
 if (!JS_ONLY) {
   addon = require(path.join(__dirname, 'am355_napi.node'))
@@ -70,7 +71,21 @@ function toJs(backend) {
   isFrozenCheck(backend)
   if (!(backend.state instanceof GpuState)) return backend
   const g = backend.state
-  if (!g.js) g.js = g.doc ? ref().load(g.doc) : ref().loadChanges(ref().init(), g.changes)
+  if (!g.js) {
+    if (g.doc) g.js = ref().load(g.doc)
+    else if (HYDRATE_FROM_DOC && !JS_ONLY) {
+      // hydrate the JS BackendDoc from the engine's save() bytes: Backend.load of a document is several times cheaper in JS than
+      // replaying every change (opt-in: MI355X_HYDRATE=doc; the default replays the retained changes, exact by construction)
+      let bytes = null
+      try {
+        if (g.generation !== generation) { gpuReplay(g.changes); g.generation = generation }
+        bytes = addon.save(ctx, 0)
+      } catch (e) {
+        if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
+      }
+      g.js = bytes ? ref().load(bytes) : ref().loadChanges(ref().init(), g.changes)
+    } else g.js = ref().loadChanges(ref().init(), g.changes)
+  }
   const handle = g.js
   g.js = null          // the JS handle is single-use (functional API over a mutable state)
   backend.frozen = true
