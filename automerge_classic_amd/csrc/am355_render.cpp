@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace am355 {
@@ -243,6 +245,85 @@ struct R {
     return true;
   }
 
+  // edits [b, e) of one list object, comma separated; b must be the first edit of a multi-insert run or a single edit
+  bool edits_serial(uint32_t b, uint32_t e) {
+    char t[64];
+    for (uint32_t i = b; i < e;) {
+      uint32_t j = i + 1;
+      while (j < e && (ir.e_flags[j] & 2)) j++;
+      if (i > b) out.push_back(',');
+      uint32_t row = ir.e_row[i], f = ir.e_flags[i];
+      if (j - i >= 2) {
+        snprintf(t, sizeof t, "{\"action\":\"multi-insert\",\"index\":%u,\"elemId\":", ir.e_index[i]);
+        out += t;
+        op_id(ir.e_elem[i]);
+        uint32_t tl = ir.row_val_tl[row];
+        if (has_datatype(tl) && (tl & 15) != 0) { out += ",\"datatype\":"; datatype(tl & 15); }  // only truthy datatypes (new.js:762)
+        out += ",\"values\":[";
+        for (uint32_t k = i; k < j; k++) {
+          if (k > i) out.push_back(',');
+          if (!prim_value(ir.e_row[k])) return false;
+        }
+        out += "]}";
+      } else if (f & 1) {
+        snprintf(t, sizeof t, "{\"action\":\"update\",\"index\":%u,\"opId\":", ir.e_index[i]);
+        out += t;
+        op_id(row);
+        out += ",\"value\":";
+        if (!value_of_row(row, (f & 4) != 0)) return false;
+        out.push_back('}');
+      } else {
+        snprintf(t, sizeof t, "{\"action\":\"insert\",\"index\":%u,\"elemId\":", ir.e_index[i]);
+        out += t;
+        op_id(ir.e_elem[i]);
+        out += ",\"opId\":";
+        op_id(row);
+        out += ",\"value\":";
+        if (!value_of_row(row, (f & 4) != 0)) return false;
+        out.push_back('}');
+      }
+      i = j;
+    }
+    return true;
+  }
+
+  // Long edit lists (a Text object holds one edit per character run) are rendered by several host threads, each into its
+  // own buffer, split where no multi-insert run is cut; the pieces are then joined. Same text as the serial walk.
+  bool edits(uint32_t b, uint32_t e) {
+    // (AM355_RENDER_CHUNK: edits per thread below which the walk stays serial; the tests lower it to exercise the join)
+    const char* env = getenv("AM355_RENDER_CHUNK");
+    const uint32_t kMinPerThread = env && atoi(env) > 0 ? (uint32_t)atoi(env) : 1u << 15;
+    unsigned hw = std::thread::hardware_concurrency();
+    uint32_t want = (e - b) / kMinPerThread;
+    if (want > 16) want = 16;
+    if (hw && want > hw) want = hw;
+    if (want < 2) return edits_serial(b, e);
+    std::vector<uint32_t> cut{b};
+    for (uint32_t k = 1; k < want; k++) {
+      uint32_t c = b + (uint32_t)((uint64_t)(e - b) * k / want);
+      while (c < e && (ir.e_flags[c] & 2)) c++;  // never inside a multi-insert run
+      if (c > cut.back() && c < e) cut.push_back(c);
+    }
+    cut.push_back(e);
+    size_t parts = cut.size() - 1;
+    std::vector<std::string> piece(parts), perr(parts);
+    std::vector<char> ok(parts, 1);
+    std::vector<std::thread> workers;
+    for (size_t k = 0; k < parts; k++)
+      workers.emplace_back([&, k]() {
+        R sub(ir, piece[k]);
+        ok[k] = sub.edits_serial(cut[k], cut[k + 1]) ? 1 : 0;
+        perr[k] = sub.err;
+      });
+    for (auto& w : workers) w.join();
+    for (size_t k = 0; k < parts; k++) {
+      if (!ok[k]) return fail(perr[k].c_str());
+      if (k && !piece[k].empty()) out.push_back(',');
+      out += piece[k];
+    }
+    return true;
+  }
+
   bool object(uint32_t oi) {
     if (oi >= ir.n_objects) return fail("internal: object index out of range");
     if (++depth > 100000) return fail("unsupported: object nesting too deep");
@@ -261,43 +342,7 @@ struct R {
     if (oi != 0 && (type == 2 || type == 4)) {
       out += ",\"edits\":[";
       uint32_t b = ir.obj_edit_begin[oi], e = ir.obj_edit_end[oi];
-      char t[64];
-      for (uint32_t i = b; i < e;) {
-        uint32_t j = i + 1;
-        while (j < e && (ir.e_flags[j] & 2)) j++;
-        if (i > b) out.push_back(',');
-        uint32_t row = ir.e_row[i], f = ir.e_flags[i];
-        if (j - i >= 2) {
-          snprintf(t, sizeof t, "{\"action\":\"multi-insert\",\"index\":%u,\"elemId\":", ir.e_index[i]);
-          out += t;
-          op_id(ir.e_elem[i]);
-          uint32_t tl = ir.row_val_tl[row];
-          if (has_datatype(tl) && (tl & 15) != 0) { out += ",\"datatype\":"; datatype(tl & 15); }  // only truthy datatypes (new.js:762)
-          out += ",\"values\":[";
-          for (uint32_t k = i; k < j; k++) {
-            if (k > i) out.push_back(',');
-            if (!prim_value(ir.e_row[k])) return false;
-          }
-          out += "]}";
-        } else if (f & 1) {
-          snprintf(t, sizeof t, "{\"action\":\"update\",\"index\":%u,\"opId\":", ir.e_index[i]);
-          out += t;
-          op_id(row);
-          out += ",\"value\":";
-          if (!value_of_row(row, (f & 4) != 0)) return false;
-          out.push_back('}');
-        } else {
-          snprintf(t, sizeof t, "{\"action\":\"insert\",\"index\":%u,\"elemId\":", ir.e_index[i]);
-          out += t;
-          op_id(ir.e_elem[i]);
-          out += ",\"opId\":";
-          op_id(row);
-          out += ",\"value\":";
-          if (!value_of_row(row, (f & 4) != 0)) return false;
-          out.push_back('}');
-        }
-        i = j;
-      }
+      if (!edits(b, e)) return false;
       out += "]}";
     } else {
       out += ",\"props\":{";

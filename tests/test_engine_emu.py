@@ -241,3 +241,11 @@ def test_save_of_generated_logs_matches_the_reference_digest(eng, case):
     eng.replay()
     doc = eng.save()
     assert len(doc) == case["doc_len"] and hashlib.sha256(doc).hexdigest() == case["doc_sha256"]
+
+
+@pytest.mark.parametrize("name", ["frontend_text_8actors", "frontend_mixed_6actors", "campaign_text_2003"])
+def test_threaded_rendering_produces_the_same_text(eng, name, monkeypatch):
+    """Long edit lists are rendered by several host threads; with a tiny chunk size the goldens go through that path."""
+    monkeypatch.setenv("AM355_RENDER_CHUNK", "3")
+    fx = golden_util.load_fixture(name)
+    assert emu_patch(eng, fx["log"]) == fx["expected"]
