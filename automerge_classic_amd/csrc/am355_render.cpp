@@ -316,6 +316,9 @@ struct R {
         perr[k] = sub.err;
       });
     for (auto& w : workers) w.join();
+    size_t total = out.size() + parts;
+    for (auto& pc : piece) total += pc.size();
+    out.reserve(total + 64);
     for (size_t k = 0; k < parts; k++) {
       if (!ok[k]) return fail(perr[k].c_str());
       if (k && !piece[k].empty()) out.push_back(',');
