@@ -960,8 +960,8 @@ struct WaveLdsT {
   static constexpr uint32_t RUNMAX = COLMAX_ / 2;  // every record is at least two tokens
   alignas(16) uint8_t region[REGION_];
   uint8_t bytes[COLMAX_];
-  uint32_t tok_lo[COLMAX_], tok_hi[COLMAX_];
-  uint8_t tok_len[COLMAX_], tok_last[COLMAX_];
+  uint64_t tok[COLMAX_];  // one LEB128 number per word: see wv_pack_token
+  uint32_t aux[COLMAX_ / 2 + 1];  // key column: string length of each run
   uint32_t run_start[COLMAX_ / 2 + 1], run_tok[COLMAX_ / 2];
   uint8_t run_kind[COLMAX_ / 2];
   uint32_t n_runs, n_tokens, total_rows, err;
@@ -981,21 +981,32 @@ __device__ __forceinline__ int wave_class_of(const ChangeMeta& m) {
   return 0;
 }
 
+// A LEB128 number as one LDS word, so that reading a value is one ds_read instead of four: bits 0-52 the value (53 bits, JS safe
+// integers; for a negative number the low 53 bits of its two's complement), 53-56 the byte count, 57 the sign bit of the last
+// byte, 58 / 59 "valid as unsigned" / "valid as signed" (encoding.js:389-488: at most 10 bytes, within +-(2^53 - 1)).
+__device__ __forceinline__ uint64_t wv_pack_token(uint64_t raw, uint32_t nb, uint32_t last) {
+  const uint64_t M53 = (1ull << 53) - 1;
+  bool len_ok = nb >= 1 && nb <= 10;
+  bool ok_u = len_ok && !(nb == 10 && (last & 0xfe)) && raw <= MAX_SAFE;
+  uint64_t sv = raw;
+  if ((last & 0x40) && 7 * nb < 64) sv |= ~0ull << (7 * nb);
+  bool ok_s = len_ok && !(nb == 10 && last != 0 && last != 0x7f) && (int64_t)sv <= (int64_t)MAX_SAFE && (int64_t)sv >= -(int64_t)MAX_SAFE;
+  return (sv & M53) | (uint64_t)(nb <= 15 ? nb : 15) << 53 | (uint64_t)((last >> 6) & 1) << 57 | (uint64_t)ok_u << 58 | (uint64_t)ok_s << 59;
+}
 template <class WL>
 __device__ __forceinline__ bool wv_tok_uint(const WL& L, uint32_t t, uint64_t& v) {
-  uint32_t nb = L.tok_len[t];
-  if (nb == 0 || nb > 10 || (nb == 10 && (L.tok_last[t] & 0xfe))) return false;
-  v = (uint64_t)L.tok_hi[t] << 32 | L.tok_lo[t];
-  return v <= MAX_SAFE;
+  uint64_t w = L.tok[t];
+  uint32_t bits = 7 * (uint32_t)((w >> 53) & 15);
+  v = w & ((1ull << (bits < 53 ? bits : 53)) - 1);  // the field is sign-extended from bit 7*nb: the unsigned value is below it
+  return (w >> 58) & 1;
 }
 template <class WL>
 __device__ __forceinline__ bool wv_tok_sint(const WL& L, uint32_t t, int64_t& out) {
-  uint32_t nb = L.tok_len[t], last = L.tok_last[t];
-  if (nb == 0 || nb > 10 || (nb == 10 && last != 0 && last != 0x7f)) return false;
-  uint64_t v = (uint64_t)L.tok_hi[t] << 32 | L.tok_lo[t];
-  if ((last & 0x40) && 7 * nb < 64) v |= ~0ull << (7 * nb);
+  uint64_t w = L.tok[t];
+  uint64_t v = w & ((1ull << 53) - 1);
+  if ((w >> 57) & 1) v |= ~0ull << 53;  // a valid negative number is >= -(2^53 - 1): every higher bit is set
   out = (int64_t)v;
-  return out <= (int64_t)MAX_SAFE && out >= -(int64_t)MAX_SAFE;
+  return (w >> 59) & 1;
 }
 
 // Stage + tokenise + record-walk one RLE column (uint or int values). All lanes must call it.
@@ -1019,10 +1030,7 @@ __device__ __forceinline__ void wv_load_column(WL& L, P col, uint32_t len, uint3
       uint64_t v = 0;
       if (nb <= 10)
         for (uint32_t k = 0; k < nb; k++) v |= (uint64_t)(L.bytes[start + k] & 0x7f) << (7 * k);
-      L.tok_lo[idx] = (uint32_t)v;
-      L.tok_hi[idx] = (uint32_t)(v >> 32);
-      L.tok_len[idx] = nb <= 10 ? (uint8_t)nb : (uint8_t)0xff;
-      L.tok_last[idx] = (uint8_t)b;
+      L.tok[idx] = wv_pack_token(v, nb, b);
     }
     if (mask) carry_start = chunk + (63 - (uint32_t)__clzll(mask)) + 1;
     tok_base += (uint32_t)__popcll(mask);
@@ -1071,28 +1079,37 @@ __device__ __forceinline__ void wv_load_column(WL& L, P col, uint32_t len, uint3
   __syncthreads();
 }
 
-// value of row i of the loaded column: returns the token index holding it, or NONE32 for null. *boundary is set when
-// row i must differ from row i-1 for the encoding to be legal (different records, or both inside a literal).
+// value of row i of the loaded column: returns the token index holding it, or NONE32 for null. *prev receives the token of
+// row i - 1 when row i must differ from it for the encoding to be legal (first row of a record after a non-null record, or
+// inside a literal), else NONE32.
 template <class WL>
-__device__ __forceinline__ uint32_t wv_row_token(const WL& L, uint32_t i, bool* lit_or_first) {
-  if (i >= L.total_rows) { *lit_or_first = false; return NONE32; }  // past the end every value is null (encoding.js:821)
+__device__ __forceinline__ uint32_t wv_row_token(const WL& L, uint32_t i, uint32_t* prev) {
+  *prev = NONE32;
+  if (i >= L.total_rows) return NONE32;  // past the end every value is null (encoding.js:821)
   uint32_t lo = 0, hi = L.n_runs;
   while (hi - lo > 1) {
     uint32_t mid = (lo + hi) >> 1;
     if (L.run_start[mid] <= i) lo = mid; else hi = mid;
   }
-  uint32_t kind = L.run_kind[lo], off = i - L.run_start[lo];
-  *lit_or_first = kind == RK_LIT || off == 0;
+  uint32_t kind = L.run_kind[lo], start = L.run_start[lo], off = i - start;
   if (kind == RK_NUL) return NONE32;
-  return kind == RK_REP ? L.run_tok[lo] : L.run_tok[lo] + off;
+  uint32_t first = L.run_tok[lo];
+  if (off > 0) {
+    if (kind == RK_LIT) *prev = first + off - 1;
+  } else if (lo > 0) {
+    uint32_t pk = L.run_kind[lo - 1];
+    if (pk == RK_REP) *prev = L.run_tok[lo - 1];
+    else if (pk == RK_LIT) *prev = L.run_tok[lo - 1] + (start - L.run_start[lo - 1] - 1);
+  }
+  return kind == RK_REP ? first : first + off;
 }
 
 // decoded value of row i (uint or signed), with the reference's adjacency rule (no equal neighbours across record
 // boundaries or inside literals: encoding.js:826-829, 868-872)
 template <bool SIGNED, class WL>
 __device__ __forceinline__ bool wv_row_value(const WL& L, uint32_t i, bool& is_null, int64_t& v, uint32_t& err) {
-  bool edge;
-  uint32_t t = wv_row_token(L, i, &edge);
+  uint32_t tp;
+  uint32_t t = wv_row_token(L, i, &tp);
   is_null = t == NONE32;
   v = 0;
   if (is_null) return true;
@@ -1100,19 +1117,12 @@ __device__ __forceinline__ bool wv_row_value(const WL& L, uint32_t i, bool& is_n
   if (SIGNED) ok = wv_tok_sint(L, t, v);
   else { uint64_t u; ok = wv_tok_uint(L, t, u); v = (int64_t)u; }
   if (!ok) { err |= F_BAD_LEB; return false; }
-  if (edge && i > 0) {
-    bool e2;
-    uint32_t tp = wv_row_token(L, i - 1, &e2);
-    if (tp != NONE32 && L.tok_lo[tp] == L.tok_lo[t] && L.tok_hi[tp] == L.tok_hi[t] && L.tok_len[tp] == L.tok_len[t]) {
-      // equal payloads of equal length are equal numbers; different-length encodings of one number are compared by value
-      err |= F_BAD_RLE;
-    } else if (tp != NONE32 && L.tok_len[tp] != L.tok_len[t]) {
-      int64_t pv = 0;
-      bool okp;
-      if (SIGNED) okp = wv_tok_sint(L, tp, pv);
-      else { uint64_t u = 0; okp = wv_tok_uint(L, tp, u); pv = (int64_t)u; }
-      if (okp && pv == v) err |= F_BAD_RLE;
-    }
+  if (tp != NONE32) {
+    int64_t pv = 0;
+    bool okp;
+    if (SIGNED) okp = wv_tok_sint(L, tp, pv);
+    else { uint64_t u = 0; okp = wv_tok_uint(L, tp, u); pv = (int64_t)u; }
+    if (okp && pv == v) err |= F_BAD_RLE;  // (an invalid predecessor raises its own flag when its row is decoded)
   }
   return true;
 }
@@ -1177,7 +1187,7 @@ uint32_t err = 0;
         L.run_start[nr] = (uint32_t)(rows - rows_done);
         L.run_kind[nr] = (uint8_t)kind;
         L.run_tok[nr] = col_abs + off;
-        L.tok_lo[nr] = len;
+        L.aux[nr] = len;
         nr++;
         rows += count;
         if (rows > n) rows = n;
@@ -1188,7 +1198,7 @@ uint32_t err = 0;
         L.run_start[nr] = (uint32_t)(rows - rows_done);
         L.run_kind[nr] = RK_NUL;
         L.run_tok[nr] = 0;
-        L.tok_lo[nr] = 0;
+        L.aux[nr] = 0;
         nr++;
         rows = n;
       }
@@ -1205,11 +1215,11 @@ uint32_t err = 0;
     for (uint32_t r = lane; r < nr; r += WAVE) {
       uint32_t k = L.run_kind[r], pk = r ? L.run_kind[r - 1] : prev_kind;
       if (k == RK_NUL || pk == RK_NUL) continue;
-      uint32_t off = L.run_tok[r] - col_abs, len = L.tok_lo[r];
-      uint32_t poff = r ? L.run_tok[r - 1] - col_abs : prev_off, plen = r ? L.tok_lo[r - 1] : prev_len;
+      uint32_t off = L.run_tok[r] - col_abs, len = L.aux[r];
+      uint32_t poff = r ? L.run_tok[r - 1] - col_abs : prev_off, plen = r ? L.aux[r - 1] : prev_len;
       if (len == plen && bytes_equal(keycol, poff, off, len, key_len)) err |= F_BAD_RLE;
     }
-    if (lane == 0 && nr) { prev_kind = L.run_kind[nr - 1]; prev_off = L.run_tok[nr - 1] - col_abs; prev_len = L.tok_lo[nr - 1]; }
+    if (lane == 0 && nr) { prev_kind = L.run_kind[nr - 1]; prev_off = L.run_tok[nr - 1] - col_abs; prev_len = L.aux[nr - 1]; }
     for (uint32_t i = lane; i < batch; i += WAVE) {
       uint32_t lo = 0, hi = nr;
       while (hi - lo > 1) {
@@ -1218,7 +1228,7 @@ uint32_t err = 0;
       }
       bool nul = L.run_kind[lo] == RK_NUL;
       o.key_off[base + rows_done + i] = nul ? 0 : L.run_tok[lo];
-      o.key_len[base + rows_done + i] = nul ? NONE32 : L.tok_lo[lo];
+      o.key_len[base + rows_done + i] = nul ? NONE32 : L.aux[lo];
     }
     rows_done += batch;
     __syncthreads();
@@ -1304,8 +1314,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
         uint64_t v = 0;
         if (nb <= 10)
           for (uint32_t k = 0; k < nb; k++) v |= (uint64_t)(L.bytes[start + k] & 0x7f) << (7 * k);
-        L.tok_lo[idx] = (uint32_t)v; L.tok_hi[idx] = (uint32_t)(v >> 32);
-        L.tok_len[idx] = nb <= 10 ? (uint8_t)nb : (uint8_t)0xff; L.tok_last[idx] = (uint8_t)b;
+        L.tok[idx] = wv_pack_token(v, nb, b);
       }
       if (mask) carry_start = chunk + (63 - (uint32_t)__clzll(mask)) + 1;
       tok_base += (uint32_t)__popcll(mask);
