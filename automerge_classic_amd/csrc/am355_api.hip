@@ -1019,8 +1019,8 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   }
 
   // ---- stage 1b: column decode ----
-  HIPCHK(c, hipEventRecord(c->ev[2], st));
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
+  HIPCHK(c, hipEventRecord(c->ev[2], st));  // brackets the decode launch only (bench.py's roofline.launch_ms)
   launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, (uint32_t)np - n_small - n_large, d_amap,
                         d_rank,
                         c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3, c->ev_fork, c->ev_join);
