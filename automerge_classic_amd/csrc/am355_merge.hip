@@ -289,6 +289,34 @@ __global__ __launch_bounds__(BLOCK) void k_map_keys(MergeBufs b, const uint32_t*
   keys[i] = k;
 }
 
+// The same order for a handful of emissions (a root map with a few keys next to a large Text is the common document):
+// the multi-pass radix sort would spend ~16 passes of 5 launches on them. One workgroup ranks every emission against all
+// others instead. Order: (object, key bytes in UTF-16 order -- a prefix sorts first --, trigger op id).
+constexpr uint32_t MAP_SORT_SMALL = 512;  // n comparisons per lane: beyond a few hundred the radix passes win
+__device__ __forceinline__ bool map_emission_less(const MergeBufs& b, uint32_t ea, uint32_t eb, const uint32_t* __restrict__ obj_rank) {
+  uint32_t ga = b.em_row[ea], gb = b.em_row[eb];
+  uint32_t oa = obj_index_of(b, b.obj_row[ga]), ob = obj_index_of(b, b.obj_row[gb]);
+  if (obj_rank) { oa = obj_rank[oa]; ob = obj_rank[ob]; }
+  if (oa != ob) return oa < ob;
+  const uint8_t *p = b.arena + b.ops.key_off[ga], *q = b.arena + b.ops.key_off[gb];
+  uint32_t la = b.ops.key_len[ga], lb = b.ops.key_len[gb], n = la < lb ? la : lb;
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t x = utf16_order_byte(p[k]), y = utf16_order_byte(q[k]);
+    if (x != y) return x < y;
+  }
+  if (la != lb) return la < lb;
+  unsigned long long ta = b.em_trig[ea], tb = b.em_trig[eb];
+  if (ta != tb) return ta < tb;
+  return ea < eb;
+}
+__global__ __launch_bounds__(BLOCK) void k_map_sort_small(MergeBufs b, uint32_t n, const uint32_t* __restrict__ obj_rank, uint32_t* __restrict__ perm) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < n; j++) rank += map_emission_less(b, j, i, obj_rank) ? 1u : 0u;
+  perm[rank] = i;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* __restrict__ v, uint32_t n) {
   uint32_t i = gtid();
   if (i < n) v[i] = i;
@@ -824,7 +852,10 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
                     : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, 0, bits, b.sort_ws, st);
       cur ^= res;
     };
-    if (ne > 1) {
+    if (ne > 1 && ne <= MAP_SORT_SMALL) {
+      AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(ne), dim3(BLOCK), st, b, ne, (const uint32_t*)nullptr, perm_b);
+      cur = 1;
+    } else if (ne > 1) {
       pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
       pass(MK_LEN, 0, bits_for(hc->max_key_len));
       uint32_t chunks = (hc->max_key_len + 7) / 8;
@@ -1157,7 +1188,10 @@ void save_phase2(MergeBufs& b, PatchIR& ir, SaveBufs& s, const uint32_t* words, 
                     : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, nm, 0, bits, b.sort_ws, st);
       cur ^= res;
     };
-    if (nm > 1) {
+    if (nm > 1 && nm <= MAP_SORT_SMALL) {
+      AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(nm), dim3(BLOCK), st, b, nm, (const uint32_t*)s.obj_rank, perm_b);
+      cur = 1;
+    } else if (nm > 1) {
       pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
       pass(MK_LEN, 0, bits_for(max_key));
       uint32_t chunks = (max_key + 7) / 8;
