@@ -184,7 +184,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   uint8_t kind = in_range ? b.kind[g] : (uint8_t)K_NONE;
   uint32_t a = in_range ? o.action[g] : 1;
   bool live = kind != K_NONE && kind != K_DEL;
-  if (in_range) b.obj_index[g] = (live && (a & 1) == 0) ? 1u : 0u;  // is-make flag, scanned later
+  bool is_make = live && (a & 1) == 0;
+  if (in_range) b.obj_index[g] = is_make ? 1u : 0u;  // is-make flag, scanned later
+  (void)wave_append(&b.counts->n_objects, is_make);  // the count alone is needed early: it sizes the object pass of the map sort
   bool vis = live && b.succ_cnt[g] == 0;
   bool want_map = false, want_ins = false, want_upd = false;
   unsigned long long trig = 0;
@@ -844,12 +846,12 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
     uint32_t* perm_b = b.val_b;
     AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
     int cur = 0;
-    auto pass = [&](int mode, uint32_t chunk, int bits) {
+    auto pass = [&](int mode, uint32_t chunk, int bits, int begin_bit = 0) {
       uint32_t* pin = cur ? perm_b : perm_a;
       uint64_t* kin = cur ? b.key_b : b.key_a;
       AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk, (const uint32_t*)nullptr);
-      int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, 0, bits, b.sort_ws, st)
-                    : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, 0, bits, b.sort_ws, st);
+      int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, begin_bit, bits, b.sort_ws, st)
+                    : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, begin_bit, bits, b.sort_ws, st);
       cur ^= res;
     };
     if (ne > 1 && ne <= MAP_SORT_SMALL) {
@@ -859,8 +861,13 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
       pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
       pass(MK_LEN, 0, bits_for(hc->max_key_len));
       uint32_t chunks = (hc->max_key_len + 7) / 8;
-      for (uint32_t c = chunks; c-- > 0;) pass(MK_CHUNK, c, 64);
-      pass(MK_OBJECT, 0, bits_for(N + 1));
+      for (uint32_t c = chunks; c-- > 0;) {
+        // bytes are packed first-byte-highest: positions past the longest key are zero in every key -- no pass over them
+        uint32_t used = hc->max_key_len - 8 * c < 8 ? hc->max_key_len - 8 * c : 8;
+        pass(MK_CHUNK, c, 64, 64 - 8 * (int)used);
+      }
+      // object index <= number of make rows (0 is _root); a document whose only map is _root needs no object pass at all
+      if (hc->n_objects) pass(MK_OBJECT, 0, bits_for(hc->n_objects));
     }
     AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
   }
