@@ -249,3 +249,37 @@ def test_threaded_rendering_produces_the_same_text(eng, name, monkeypatch):
     monkeypatch.setenv("AM355_RENDER_CHUNK", "3")
     fx = golden_util.load_fixture(name)
     assert emu_patch(eng, fx["log"]) == fx["expected"]
+
+
+def test_mutated_changes_never_disagree_with_the_oracle(eng):
+    """Single-byte damage in the op columns of one change (checksum repaired): the engine may refuse more than the oracle does
+    (the JS host then runs the reference path), but it never accepts what the oracle rejects and never produces another patch."""
+    import base64
+    import hashlib
+    import random
+    with open(os.path.join(golden_util.GOLDEN_DIR, "frontend_mixed_3actors.json")) as f:
+        changes = [base64.b64decode(c) for c in json.load(f)["changes"]]
+    rng = random.Random(11)
+    equal = refused = 0
+    for _ in range(70):
+        ci = rng.randrange(len(changes))
+        ch = bytearray(changes[ci])
+        pos = rng.randrange(9 + int((len(ch) - 9) * 0.4), len(ch))
+        ch[pos] = rng.randrange(256)
+        ch[4:8] = hashlib.sha256(bytes(ch[8:])).digest()[:4]
+        log = loggen.ChangeLog.from_changes(changes[:ci] + [bytes(ch)] + changes[ci + 1:], name="mutated")
+        try:
+            want = oracle_lib.OracleDoc(log).patch_json()
+        except oracle_lib.OracleError:
+            want = None
+        try:
+            got = emu_patch(eng, log)
+        except engine.EngineError:
+            got = None
+        if got is not None:
+            assert want is not None, f"engine accepted a change the oracle rejects (change {ci}, byte {pos})"
+            assert got == want, f"different patch (change {ci}, byte {pos})"
+            equal += 1
+        else:
+            refused += 1
+    assert equal > 3 and refused > 20
