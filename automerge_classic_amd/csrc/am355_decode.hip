@@ -341,6 +341,9 @@ __device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len6
     m.others_off = cur.off;
     if (ok && v > m.len) ok = false;
     for (uint64_t k = 0; ok && k < m.n_other; k++) {
+      // actor ids are 16 bytes in practice: a one-byte length is the fast path of this (serial) walk
+      uint32_t b0 = cur.off < cur.len ? cur.byte_at(cur.off) : 0x80u;
+      if (b0 < 0x80) { cur.off++; ok = skip_bytes(cur, b0); continue; }
       uint64_t l;
       ok = read_uleb(cur, l) && skip_bytes(cur, l);
     }
