@@ -248,3 +248,22 @@ def test_full_size_save_round_trip(eng, workload):
     got = json.loads(got)
     assert got["diffs"] == want["diffs"] and got["maxOp"] == want["maxOp"] and got["deps"] == want["deps"] and got["clock"] == want["clock"]
     assert eng.save(reencode=True) == doc
+
+
+def test_empty_and_tiny_inputs(eng):
+    """No changes at all; one change with a single op: patch against the oracle, save against the reference's bytes."""
+    empty = loggen.ChangeLog.from_changes([])
+    eng.load_changes(empty)
+    eng.replay()
+    assert eng.patch_json() == oracle_lib.OracleDoc(empty).patch_json()
+    doc = eng.save()
+    assert doc.hex() == "856f4a83b81a9544000400000000"  # Backend.save(Backend.init()) of the unmodified reference
+    eng.load_document(doc)
+    eng.replay()
+    assert eng.patch_json() == '{"maxOp":0,"clock":{},"deps":[],"pendingChanges":0,"diffs":{"objectId":"_root","type":"map","props":{}}}'
+    one = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=1, ops_per_change=1, seed=5)
+    eng.load_changes(one)
+    eng.replay()
+    assert eng.patch_json() == oracle_lib.OracleDoc(one).patch_json()
+    want = eng.patch_json()
+    assert oracle_lib.OracleDoc.load_document(eng.save()).patch_json() == want
