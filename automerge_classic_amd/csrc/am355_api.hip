@@ -1093,13 +1093,19 @@ static int replay_document(am355_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev_b0, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_b0, 0));
-    keystr_index(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], c->d_ks.p, &ks_start, &ks_off, &ks_len, d_words + W_TOTAL_ENTRIES,
-                 d_words + W_FLAGS_B, c->stream2);
-    HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
+    KeyStage ks;
+    keystr_index_begin(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], c->d_ks.p, ks, d_words + W_TOTAL_ENTRIES, d_words + W_FAST_B,
+                       c->stream2);
+    HIPCHK(c, hipMemcpyAsync(c->h_words.as<uint32_t>() + W_FAST_B, d_words + W_FAST_B, 4, hipMemcpyDeviceToHost, c->stream2));
     bigcol_index(c->d_arena.as<uint8_t>(), d, w, st);
     BigColInfo* hi = c->h_biginfo.as<BigColInfo>();
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->ev[1], st));
+    // the key stream's one host decision (does the parse reach a literal longer than the first doubling rounds cover?) is
+    // taken while the main stream is busy with the token index
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    keystr_index_finish(ks, c->h_words.as<uint32_t>()[W_FAST_B] != 0, &ks_start, &ks_off, &ks_len, d_words + W_FLAGS_B, c->stream2);
+    HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
     HIPCHK(c, hipStreamSynchronize(st));
     if (hi->flags) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, hi->flags, "malformed document columns"); }
     BigColInfo info = *hi;

@@ -54,10 +54,27 @@ void bigcol_expand(const BigColDesc& d, const BigColWork& w, const BigColInfo& h
 void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, const uint32_t* actor_rank, uint32_t n_actors, uint32_t val_raw_abs,
                      uint32_t val_raw_len, OpCols o, uint32_t* flags, hipStream_t st);
 
-// keyStr column -> run table (run_start has n_runs + 1 entries; run_len NONE32 = null run), fully parallel. The three table
-// pointers point into `work` (keystr_work_bytes(col_len) bytes).
+// keyStr column -> run table (run_start has n_runs + 1 entries; run_len NONE32 = null run), fully parallel; scratch in `work`
+// (keystr_work_bytes(col_len) bytes). Two steps with one host decision in between (see am355_bigcol.hip): `begin` leaves one
+// word at *d_unresolved (zeroed by the caller) telling whether a literal longer than the first doubling rounds cover is on
+// the true parse; `finish` gets that word's value.
+struct KeyWork {
+  uint32_t *vnext, *hnext, *kk, *ja, *jb, *mark_h, *mark_v, *item_ex, *rows;  // [L + 2]
+  uint32_t *run_start, *run_off, *run_len, *run_kind;                        // [L + 2] (items <= bytes)
+  uint32_t* n_runs;                                                          // device word
+  void* scan_ws;
+};
+struct KeyStage {
+  KeyWork k;
+  uint32_t *j0, *j1;
+  void* chain_ws;
+  const uint8_t *col, *arena;
+  uint32_t col_abs, L;
+  int rounds, done;
+};
 size_t keystr_work_bytes(uint32_t col_len);
-void keystr_index(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len,
-                  uint32_t* n_runs, uint32_t* flags, hipStream_t st);
+void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, KeyStage& s, uint32_t* n_runs, uint32_t* d_unresolved,
+                        hipStream_t st);
+void keystr_index_finish(KeyStage& s, bool unresolved, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len, uint32_t* flags, hipStream_t st);
 
 }  // namespace am355

@@ -13,6 +13,7 @@
 // All of it is streaming integer work over HBM-resident arrays (prefix sums, gathers); no MFMA.
 #include "am355_bigcol.h"
 #include "am355_prims.h"
+#include <cstdlib>
 
 namespace am355 {
 
@@ -359,12 +360,6 @@ void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, cons
 // 3. true literal items = vnext-orbits of the first string of every true literal, cut at the next true header.
 // 4. items (repetition / null run / literal value) -> prefix sums -> run table (first row, offset, length).
 // Position L (one past the column) is the regular end of the parse; NONE32 is "ran off the column".
-struct KeyWork {
-  uint32_t *vnext, *hnext, *kk, *ja, *jb, *mark_h, *mark_v, *item_ex, *rows;  // [L + 2]
-  uint32_t *run_start, *run_off, *run_len, *run_kind;                        // [L + 2] (items <= bytes)
-  uint32_t* n_runs;                                                          // device word
-  void* scan_ws;
-};
 
 __device__ __forceinline__ bool key_uleb(const uint8_t* __restrict__ p, uint32_t i, uint32_t L, uint64_t& v, uint32_t& nb) {
   v = 0;
@@ -518,36 +513,82 @@ size_t keystr_work_bytes(uint32_t col_len) {
   return 13 * al256(4 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + al256(chain_work_bytes((uint32_t)cap)) + 256;
 }
 
-void keystr_index(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len,
-                  uint32_t* n_runs, uint32_t* flags, hipStream_t st) {
+// literal headers whose string count needs doubling rounds beyond `r0` are not resolved yet: the header walk stops at them
+__global__ __launch_bounds__(BLOCK) void kk_effective(uint32_t L, int r0, KeyWork k, uint32_t* __restrict__ heff) {
+  uint32_t i = gtid();
+  if (i > L + 1) return;
+  heff[i] = i < L && (k.kk[i] >> r0) == 0 ? k.hnext[i] : NONE32;
+}
+__global__ __launch_bounds__(BLOCK) void kk_check_unresolved(uint32_t L, int r0, KeyWork k, uint32_t* __restrict__ unresolved) {
+  uint32_t i = gtid();
+  if (i < L && k.mark_h[i] && (k.kk[i] >> r0) != 0) *unresolved = 1;
+}
+__global__ __launch_bounds__(BLOCK) void kk_reset_marks(uint32_t L, uint32_t* __restrict__ mark) {
+  uint32_t i = gtid();
+  if (i <= L + 1) mark[i] = (i == 0 && L > 0) ? 1u : 0u;
+}
+
+// Literals of a few thousand strings are the rule, so the k-th-successor doubling first runs KEY_ROUNDS_FIRST rounds only
+// (enough for k < 2^12) and the true headers are walked with longer literals treated as dead ends. Only if the walk actually
+// reaches such a header (one device word, read by the host) do the remaining rounds run and the walk repeat.
+constexpr int KEY_ROUNDS_FIRST = 12;
+
+void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, KeyStage& s, uint32_t* n_runs, uint32_t* d_unresolved,
+                        hipStream_t st) {
   uint32_t L = col_len, cap = L + 2;
-  KeyWork k;
+  KeyWork& k = s.k;
   uint8_t* p = (uint8_t*)work;
   auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
   uint32_t** arrs[] = {&k.vnext, &k.hnext, &k.kk, &k.ja, &k.jb, &k.mark_h, &k.mark_v, &k.item_ex, &k.rows, &k.run_start, &k.run_off, &k.run_len, &k.run_kind};
   for (uint32_t** a : arrs) *a = (uint32_t*)take(4 * (size_t)cap);
   k.scan_ws = take(scan_workspace_bytes(cap));
-  void* chain_ws = take(chain_work_bytes(cap));
+  s.chain_ws = take(chain_work_bytes(cap));
   k.n_runs = n_runs;
-  *run_start = k.run_start; *run_off = k.run_off; *run_len = k.run_len;
-  const uint8_t* col = arena + col_abs;
-  int rounds = 1;
-  while (rounds < 32 && (L >> rounds)) rounds++;
-  AM355_LAUNCH_INDEPENDENT(kk_init, grid_for(cap), dim3(BLOCK), st, col, L, k);
-  uint32_t *j0 = k.ja, *j1 = k.jb;
-  auto swap = [&]() { uint32_t* t = j0; j0 = j1; j1 = t; };
-  for (int r = 0; r < rounds; r++) {  // 1. k-th successors
-    AM355_LAUNCH_INDEPENDENT(kk_kth_round, grid_for(L + 1), dim3(BLOCK), st, L, r, k, (const uint32_t*)j0, j1);
-    swap();
+  s.col = arena + col_abs;
+  s.arena = arena;
+  s.col_abs = col_abs;
+  s.L = L;
+  s.rounds = 1;
+  while (s.rounds < 32 && (L >> s.rounds)) s.rounds++;
+  int first = KEY_ROUNDS_FIRST;
+  if (const char* e = getenv("AM355_KEY_ROUNDS")) first = atoi(e) > 0 ? atoi(e) : first;  // (tests lower it to reach the second stage)
+  s.done = s.rounds < first ? s.rounds : first;
+  AM355_LAUNCH_INDEPENDENT(kk_init, grid_for(cap), dim3(BLOCK), st, s.col, L, k);
+  s.j0 = k.ja;
+  s.j1 = k.jb;
+  for (int r = 0; r < s.done; r++) {  // 1. k-th successors, first rounds
+    AM355_LAUNCH_INDEPENDENT(kk_kth_round, grid_for(L + 1), dim3(BLOCK), st, L, r, k, (const uint32_t*)s.j0, s.j1);
+    uint32_t* t = s.j0; s.j0 = s.j1; s.j1 = t;
   }
-  chain_mark(k.hnext, L, k.mark_h, chain_ws, st);  // 2. true headers
-  AM355_LAUNCH_INDEPENDENT(kk_item_init, grid_for(cap), dim3(BLOCK), st, col, L, k, flags);
-  chain_mark(k.ja, L, k.mark_v, chain_ws, st);     // 3. literal items
+  if (s.done < s.rounds) {
+    uint32_t* heff = k.item_ex;  // (free until the item flags are built)
+    AM355_LAUNCH_INDEPENDENT(kk_effective, grid_for(cap), dim3(BLOCK), st, L, s.done, k, heff);
+    chain_mark(heff, L, k.mark_h, s.chain_ws, st);  // 2. true headers (as far as they are resolved)
+    AM355_LAUNCH_INDEPENDENT(kk_check_unresolved, grid_for(L), dim3(BLOCK), st, L, s.done, k, d_unresolved);
+  } else {
+    chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);
+  }
+}
+
+void keystr_index_finish(KeyStage& s, bool unresolved, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len, uint32_t* flags, hipStream_t st) {
+  KeyWork& k = s.k;
+  uint32_t L = s.L, cap = L + 2;
+  if (unresolved) {
+    for (int r = s.done; r < s.rounds; r++) {  // the remaining rounds, then the walk again
+      AM355_LAUNCH_INDEPENDENT(kk_kth_round, grid_for(L + 1), dim3(BLOCK), st, L, r, k, (const uint32_t*)s.j0, s.j1);
+      uint32_t* t = s.j0; s.j0 = s.j1; s.j1 = t;
+    }
+    AM355_LAUNCH_INDEPENDENT(kk_reset_marks, grid_for(cap), dim3(BLOCK), st, L, k.mark_h);
+    chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);
+  }
+  *run_start = k.run_start; *run_off = k.run_off; *run_len = k.run_len;
+  AM355_LAUNCH_INDEPENDENT(kk_item_init, grid_for(cap), dim3(BLOCK), st, s.col, L, k, flags);
+  chain_mark(k.ja, L, k.mark_v, s.chain_ws, st);     // 3. literal items
   AM355_LAUNCH_INDEPENDENT(kk_item_flags, grid_for(cap), dim3(BLOCK), st, L, k);
   exclusive_scan_u32(k.item_ex, k.item_ex, cap, k.n_runs, k.scan_ws, st);
-  AM355_LAUNCH_INDEPENDENT(kk_items, grid_for(L), dim3(BLOCK), st, col, col_abs, L, k, flags);
+  AM355_LAUNCH_INDEPENDENT(kk_items, grid_for(L), dim3(BLOCK), st, s.col, s.col_abs, L, k, flags);
   exclusive_scan_u32(k.rows, k.run_start, cap, nullptr, k.scan_ws, st);
-  AM355_LAUNCH_INDEPENDENT(kk_run_pairs, grid_for(cap), dim3(BLOCK), st, arena, k, flags);
+  AM355_LAUNCH_INDEPENDENT(kk_run_pairs, grid_for(cap), dim3(BLOCK), st, s.arena, k, flags);
 }
 
 }  // namespace am355

@@ -283,3 +283,19 @@ def test_mutated_changes_never_disagree_with_the_oracle(eng):
         else:
             refused += 1
     assert equal > 3 and refused > 20
+
+
+@pytest.mark.parametrize("first_rounds", ["1", "3"])
+def test_key_column_second_stage(eng, first_rounds, monkeypatch):
+    """The key-string index resolves literals longer than its first doubling rounds cover in a second stage: force it."""
+    monkeypatch.setenv("AM355_KEY_ROUNDS", first_rounds)
+    for name in ("synthetic_doc_medium", "frontend_mixed_6actors", "campaign_mixed_1008"):
+        fx = golden_util.load_fixture(name)
+        eng.load_document(fx["doc_bytes"])
+        eng.replay()
+        assert eng.patch_json() == fx["expected_load"], name
+    doc, rows = loggen.generate_document(n_actors=5, n_texts=2, text_len=300, n_maps=3, keys_per_map=120, n_submaps=2, n_lists=2, list_len=100,
+                                         deflate=False, seed=0xD0C8)
+    eng.load_document(doc)
+    eng.replay()
+    assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
