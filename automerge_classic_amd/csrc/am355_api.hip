@@ -1049,6 +1049,10 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
 // (already canonical) rows. new.js:1695-1750, 1604-1635.
 static int replay_document(am355_ctx* c) {
   auto t_begin = std::chrono::steady_clock::now();
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "replay_document: %-28s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   hipStream_t st = c->stream;
   uint32_t NA = (uint32_t)c->actors.size();
   if (!c->d_plans.ensure(sizeof(ChangePlan)) || !c->d_amap.ensure(4 * (size_t)std::max(NA, 1u)) || !c->d_words.ensure(4 * W_NUM) || !c->h_words.ensure(4 * W_NUM))
@@ -1103,10 +1107,13 @@ static int replay_document(am355_ctx* c) {
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     // the key stream's one host decision (does the parse reach a literal longer than the first doubling rounds cover?) is
     // taken while the main stream is busy with the token index
+    lap("enqueued index");
     HIPCHK(c, hipStreamSynchronize(c->stream2));
+    lap("key stage 1 done");
     keystr_index_finish(ks, c->h_words.as<uint32_t>()[W_FAST_B] != 0, &ks_start, &ks_off, &ks_len, d_words + W_FLAGS_B, c->stream2);
     HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
     HIPCHK(c, hipStreamSynchronize(st));
+    lap("token index done");
     if (hi->flags) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, hi->flags, "malformed document columns"); }
     BigColInfo info = *hi;
     uint32_t N = info.rows[BC_ACTION], Pcap = info.rows[BC_SUCC_ACTOR];
@@ -1118,6 +1125,7 @@ static int replay_document(am355_ctx* c) {
     bigcol_expand(d, w, info, v, N, Pcap, st);
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    lap("expand done");
     if (hi->flags) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, hi->flags, "malformed document columns"); }
     if (hi->n_succ > Pcap) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, AM355_F_UNSUPPORTED, "succ columns shorter than succNum announces"); }
     c->n_ops = N;
@@ -1145,6 +1153,7 @@ static int replay_document(am355_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[4], st));
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   HIPCHK(c, hipStreamSynchronize(st));
+  lap("patch done");
   if (!c->doc_serial && c->h_words.as<uint32_t>()[W_FLAGS_B]) return error_for_flags(c, c->h_words.as<uint32_t>()[W_FLAGS_B], "malformed key column");
   if (hc->flags) return error_for_flags(c, hc->flags, "document rejected");
   c->max_op = c->h_words.as<uint32_t>()[0];
