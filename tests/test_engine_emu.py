@@ -299,3 +299,13 @@ def test_key_column_second_stage(eng, first_rounds, monkeypatch):
     eng.load_document(doc)
     eng.replay()
     assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
+
+
+def test_document_with_a_long_key_literal(eng):
+    """6000 keys written once each: one key-column literal longer than the first stage of the key index resolves."""
+    log = loggen.generate(loggen.KIND_MAP_LWW, n_actors=1, n_rounds=1, n_keys=6000, seed=9)
+    emu_patch(eng, log)
+    doc = eng.save()
+    eng.load_document(doc)
+    eng.replay()
+    assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()

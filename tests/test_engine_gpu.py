@@ -267,3 +267,18 @@ def test_empty_and_tiny_inputs(eng):
     assert eng.patch_json() == oracle_lib.OracleDoc(one).patch_json()
     want = eng.patch_json()
     assert oracle_lib.OracleDoc.load_document(eng.save()).patch_json() == want
+
+
+def test_document_with_a_long_key_literal(eng):
+    """200 k keys written once each: the saved document's key column is one literal of 200 k strings, which the key index
+    resolves in its second stage (more doubling rounds than the first stage runs)."""
+    log = loggen.generate(loggen.KIND_MAP_LWW, n_actors=1, n_rounds=1, n_keys=200_000, seed=9)
+    eng.load_changes(log)
+    eng.replay()
+    want = json.loads(eng.patch_json())
+    doc = eng.save()
+    eng.load_document(doc)
+    eng.replay()
+    got = eng.patch_json()
+    assert got == oracle_lib.OracleDoc.load_document(doc).patch_json()
+    assert json.loads(got)["diffs"] == want["diffs"]
