@@ -1101,8 +1101,11 @@ static int replay_document(am355_ctx* c) {
     keystr_index_begin(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], c->d_ks.p, ks, d_words + W_TOTAL_ENTRIES, d_words + W_FAST_B,
                        c->stream2);
     HIPCHK(c, hipMemcpyAsync(c->h_words.as<uint32_t>() + W_FAST_B, d_words + W_FAST_B, 4, hipMemcpyDeviceToHost, c->stream2));
-    bigcol_index(c->d_arena.as<uint8_t>(), d, w, st);
     BigColInfo* hi = c->h_biginfo.as<BigColInfo>();
+    bigcol_index_tokens(c->d_arena.as<uint8_t>(), d, w, st);
+    HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));  // number count: everything after runs over numbers, not bytes
+    bigcol_index_records(c->d_arena.as<uint8_t>(), d, w, hi->n_tokens, st);
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     // the key stream's one host decision (does the parse reach a literal longer than the first doubling rounds cover?) is

@@ -46,8 +46,10 @@ struct BigColVals {
 size_t bigcol_vals_bytes(uint32_t n_rows, uint32_t n_succ);
 void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_succ);
 
-// tokens -> records -> row starts; fills *w.info (column ranges, rows per column). One stream, no host round trip inside.
-void bigcol_index(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipStream_t st);
+// numbers (info->n_tokens, column token ranges), then -- with n_tokens read back by the caller -- records and row starts
+// (column record ranges, rows per column in *w.info)
+void bigcol_index_tokens(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipStream_t st);
+void bigcol_index_records(const uint8_t* arena, const BigColDesc& d, BigColWork& w, uint32_t n_tokens, hipStream_t st);
 // values of every row of every column, delta / offset prefix sums; info->n_succ
 void bigcol_expand(const BigColDesc& d, const BigColWork& w, const BigColInfo& h, BigColVals& v, uint32_t n_rows, uint32_t n_succ_cap, hipStream_t st);
 // fixed-width op rows from the value arrays (key strings are filled by launch_keystr_expand)

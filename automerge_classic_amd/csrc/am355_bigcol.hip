@@ -6,7 +6,8 @@
 //               gives each number's index; one lane per number assembles it.
 //   B. records  seen as a record header, token t names its successor (t+2 for a repetition or null run, t+1+k for a
 //               literal of k values; t+1 in a boolean column). The real headers are the orbit of the column's first
-//               token under that map: marked by pointer doubling, all columns together, log2(tokens) rounds.
+//               token under that map: marked by chain_mark (am355_prims.hip: tile exits in LDS, compacted entry graph),
+//               all columns together.
 //   C. rows     rows per record -> prefix sum -> row start of every record; every row binary-searches its record and reads
 //               its value (repetition: the record's value token; literal: value token + offset; null run: null; boolean:
 //               record parity). Delta columns, value offsets and succ-list offsets are further prefix sums.
@@ -183,13 +184,20 @@ __global__ __launch_bounds__(WAVE) void kb_col_rows(BigColWork w) {
   w.info->rows[c] = w.rec_start[w.info->r1[c]] - w.rec_start[w.info->r0[c]];
 }
 
-void bigcol_index(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipStream_t st) {
-  uint32_t L = d.tok_bytes, cap = L + 2;
+// Step 1: numbers. Leaves info->n_tokens for the host, so that everything after runs over the numbers (about two thirds of
+// the byte count for these columns) instead of over the bytes.
+void bigcol_index_tokens(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipStream_t st) {
+  uint32_t L = d.tok_bytes;
   (void)hipMemsetAsync(w.info, 0, sizeof(BigColInfo), st);
   AM355_LAUNCH_INDEPENDENT(kb_term_flags, grid_for(L + 1), dim3(BLOCK), st, arena, L, w.term_ex);
   exclusive_scan_u32(w.term_ex, w.term_ex, L + 1, &w.info->n_tokens, w.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(kb_col_ranges, dim3(1), dim3(WAVE), st, d, (const uint32_t*)w.term_ex, w.info);
   AM355_LAUNCH_INDEPENDENT(kb_token_ends, grid_for(L), dim3(BLOCK), st, arena, L, (const uint32_t*)w.term_ex, w.tok_end);
+}
+
+// Step 2: records and row starts, over n_tokens numbers (read back by the caller).
+void bigcol_index_records(const uint8_t* arena, const BigColDesc& d, BigColWork& w, uint32_t n_tokens, hipStream_t st) {
+  uint32_t cap = n_tokens + 2;
   AM355_LAUNCH_INDEPENDENT(kb_token_values, grid_for(cap), dim3(BLOCK), st, arena, d, cap, w);
   chain_mark(w.jump_a, cap, w.mark, w.chain_ws, st);  // record headers = orbit of each column's first number
   exclusive_scan_u32(w.mark, w.rec_ex, cap, &w.info->n_records, w.scan_ws, st);
