@@ -1352,6 +1352,14 @@ extern "C" int am355_get_raw(const am355_ctx* c, const uint8_t** arena, const ui
 // ---------------------------------------------------------------------------------------------------------
 // IR download + JSON
 // ---------------------------------------------------------------------------------------------------------
+extern "C" int am355_get_applied(const am355_ctx* c, uint32_t* out, uint32_t* n_applied) {
+  if (!c || !n_applied) return AM355_E_ARG;
+  if (!c->replayed || c->is_document) return AM355_E_STATE;
+  *n_applied = (uint32_t)c->applied_change.size();
+  if (out) memcpy(out, c->applied_change.data(), 4 * c->applied_change.size());
+  return AM355_OK;
+}
+
 extern "C" int am355_fetch_ir(am355_ctx* c, am355_patch_ir* out) {
   if (!c) return AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");

@@ -191,6 +191,25 @@ static napi_value js_save(napi_env env, napi_callback_info info) {
   return ta;
 }
 
+/* appliedOrder(ctx) -> Uint32Array: input indexes of the applied changes in application order (am355_get_applied) */
+static napi_value js_applied_order(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t n = 0;
+  int rc = am355_get_applied(ctx, NULL, &n);
+  if (rc) return throw_engine(env, ctx, rc);
+  void *data = NULL;
+  napi_value ab, ta;
+  NAPI_CALL(env, napi_create_arraybuffer(env, 4 * (size_t)n, &data, &ab));
+  rc = am355_get_applied(ctx, (uint32_t *)data, &n);
+  if (rc) return throw_engine(env, ctx, rc);
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint32_array, n, ab, 0, &ta));
+  return ta;
+}
+
 static napi_value js_hashes(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -243,6 +262,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"replay", NULL, js_replay, NULL, NULL, NULL, napi_enumerable, NULL},
       {"patchJSON", NULL, js_patch_json, NULL, NULL, NULL, napi_enumerable, NULL},
       {"save", NULL, js_save, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"appliedOrder", NULL, js_applied_order, NULL, NULL, NULL, napi_enumerable, NULL},
       {"hashes", NULL, js_hashes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"stats", NULL, js_stats, NULL, NULL, NULL, napi_enumerable, NULL},
   };

@@ -46,6 +46,10 @@ class GpuState {
     this.heads = heads
     this.js = null           // hydrated reference backend handle
     this.generation = 0      // engine replay this state was built by (the one context is reused by every call)
+    this.applied = null      // input indexes of the applied changes, application order (loadChanges states)
+    this.hashes = null       // 32 bytes per input change
+    this.pending = 0
+    this.byHash = null       // lazily: hex hash -> input index, applied changes only
   }
 }
 let generation = 0           // bumped by every GPU replay
@@ -112,6 +116,9 @@ function loadChanges(backend, changes) {
       backend.frozen = true
       const state = new GpuState(changes.slice(), patch, patch.deps)
       state.generation = generation
+      state.applied = addon.appliedOrder(ctx)
+      state.hashes = addon.hashes(ctx)
+      state.pending = patch.pendingChanges
       return { state, heads: patch.deps }
     } catch (e) {
       if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
@@ -166,6 +173,45 @@ function save(backend) {
   return ref().save(toJs(backend))
 }
 
+// History queries on a state built by loadChanges: the engine knows which changes were applied and in what order, and the
+// change buffers are retained, so these need no JS BackendDoc. (Loaded documents and anything involving queued changes
+// go to the reference path.)
+function gpuHistory(backend) {
+  const g = backend.state
+  return !JS_ONLY && g instanceof GpuState && !g.js && g.changes && g.applied && g.pending === 0 ? g : null
+}
+function hashIndex(g) {
+  if (!g.byHash) {
+    g.byHash = new Map()
+    for (const i of g.applied) g.byHash.set(Buffer.from(g.hashes.buffer, g.hashes.byteOffset + 32 * i, 32).toString('hex'), i)
+  }
+  return g.byHash
+}
+function getAllChanges(backend) {   // new.js:1924-1927: BackendDoc.changes in application order
+  isFrozenCheck(backend)
+  const g = gpuHistory(backend)
+  if (g) return Array.from(g.applied, i => g.changes[i])
+  return ref().getAllChanges(toJs(backend))
+}
+function getChanges(backend, haveDeps) {
+  isFrozenCheck(backend)
+  const g = gpuHistory(backend)
+  if (g && Array.isArray(haveDeps) && haveDeps.length === 0) return Array.from(g.applied, i => g.changes[i])
+  return ref().getChanges(toJs(backend), haveDeps)
+}
+function getChangeByHash(backend, hash) {   // new.js:1999-2002
+  isFrozenCheck(backend)
+  const g = gpuHistory(backend)
+  if (g) { const i = hashIndex(g).get(hash); return i === undefined ? undefined : g.changes[i] }
+  return ref().getChangeByHash(toJs(backend), hash)
+}
+function getMissingDeps(backend, heads = []) {   // new.js:2014-2028 with an empty queue: the given heads we do not have
+  isFrozenCheck(backend)
+  const g = gpuHistory(backend)
+  if (g) { const idx = hashIndex(g); return Array.from(new Set(heads)).filter(h => !idx.has(h)).sort() }
+  return ref().getMissingDeps(toJs(backend), heads)
+}
+
 function free(backend) {
   if (backend.state instanceof GpuState) { backend.state = null; backend.frozen = true } else ref().free(backend)
 }
@@ -173,14 +219,10 @@ function free(backend) {
 const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...args)
 
 module.exports = {
-  init, load, loadChanges, getPatch, getHeads, free, save,
+  init, load, loadChanges, getPatch, getHeads, free, save, getAllChanges, getChanges, getChangeByHash, getMissingDeps,
   clone: delegate1('clone'),
   applyChanges: delegate1('applyChanges'),
   applyLocalChange: delegate1('applyLocalChange'),
-  getAllChanges: delegate1('getAllChanges'),
-  getChanges: delegate1('getChanges'),
-  getChangeByHash: delegate1('getChangeByHash'),
-  getMissingDeps: delegate1('getMissingDeps'),
   getChangesAdded: (b1, b2) => ref().getChangesAdded(toJs(b1), toJs(b2)),
   // sync protocol: unchanged reference code operating on JS handles (backend/sync.js:20 binds the JS backend)
   generateSyncMessage: (backend, syncState) => ref().generateSyncMessage(toJs(backend), syncState),

@@ -29,6 +29,21 @@ for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
   if (got !== expected) { failed++; console.error(`FAIL ${f}`) } else console.log(`ok   ${f}  (${changes.length} changes)`)
   if (!empty.frozen) { failed++; console.error(`FAIL ${f}: old handle not frozen`) }
   if (JSON.stringify(Backend.getHeads(state)) !== JSON.stringify(JSON.parse(expected).deps)) { failed++; console.error(`FAIL ${f}: heads`) }
+  if (JSON.parse(got).pendingChanges === 0) {
+    // history queries served from the engine's application order: every applied change once, each findable by its hash
+    // (with queued changes they go to the reference path, which is not present on the GPU box)
+    const all = Backend.getAllChanges(state)
+    const inputs = new Set(changes.map(c => Buffer.from(c).toString('base64')))
+    const uniq = new Set(all.map(c => Buffer.from(c).toString('base64')))
+    const patch = JSON.parse(got)
+    const applied = Object.values(patch.clock).reduce((a, b) => a + b, 0)
+    n++
+    let ok = all.length === applied && uniq.size === all.length && all.every(c => inputs.has(Buffer.from(c).toString('base64')))
+    for (const h of patch.deps) ok = ok && Backend.getChangeByHash(state, h) !== undefined
+    ok = ok && Backend.getMissingDeps(state, patch.deps.concat(['00'.repeat(32)])).length === 1
+    if (!f.includes('shuffled') && !f.includes('pending')) ok = ok && all.every((c, i) => Buffer.from(c).equals(Buffer.from(changes[i])))
+    if (!ok) { failed++; console.error(`FAIL ${f}: history queries`) } else console.log(`ok   ${f}  (history queries, ${all.length} changes)`)
+  }
   if (fx.doc) {
     // Backend.save(state): served by the engine, byte-identical to the reference's document
     const saved = Buffer.from(Backend.save(state))

@@ -101,6 +101,11 @@ int am355_get_stats(const am355_ctx *ctx, am355_stats *out);
 int am355_get_hashes(const am355_ctx *ctx, uint8_t *out);
 
 /* Raw (uncompressed) arena as staged by am355_load_changes: pointer valid until the next load. */
+/* Input indexes of the applied changes, in application order (what BackendDoc.changes holds, backend/new.js:1847, and
+ * Backend.getAllChanges returns, new.js:1924-1927): duplicates and queued changes do not appear. Valid after am355_replay
+ * of changes. out may be NULL to query the count. */
+int am355_get_applied(const am355_ctx *ctx, uint32_t *out, uint32_t *n_applied);
+
 /* Backend.save(state) (reference: backend/new.js:2033-2055 BackendDoc.save, backend/columnar.js:983-1004
  * encodeDocumentHeader): the document as one binary chunk -- actor table in order of first appearance, heads, change
  * metadata columns, all non-`del` op rows in canonical order with their succ lists (columns encoded on the GPU),
