@@ -78,8 +78,9 @@ def _bind(path):
     L.am355_test_scan.argtypes = [vp, vp, vp, u32, vp]
     L.am355_get_rows.argtypes = [vp] * 15
     L.am355_save.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.am355_get_applied.argtypes = [vp, vp, ctypes.POINTER(u32)]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
-              "am355_test_scan", "am355_get_rows", "am355_save"):
+              "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -153,6 +154,14 @@ class Engine:
         n = ctypes.c_size_t()
         self._check(self._L.am355_save(self._h, 1 if reencode else 0, ctypes.byref(p), ctypes.byref(n)))
         return ctypes.string_at(p, n.value)
+
+    def applied(self):
+        """Input indexes of the applied changes in application order (BackendDoc.changes / getAllChanges order)."""
+        n = ctypes.c_uint32()
+        self._check(self._L.am355_get_applied(self._h, None, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        self._check(self._L.am355_get_applied(self._h, out.ctypes.data if n.value else None, ctypes.byref(n)))
+        return out
 
     def stats(self):
         s = Stats()

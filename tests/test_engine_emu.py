@@ -309,3 +309,22 @@ def test_document_with_a_long_key_literal(eng):
     eng.load_document(doc)
     eng.replay()
     assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
+
+
+def test_applied_order(eng):
+    """am355_get_applied: input order on the fast path, duplicates dropped, queued changes absent."""
+    fx = golden_util.load_fixture("frontend_text_4actors")
+    emu_patch(eng, fx["log"])
+    n = len(fx["log"].offsets) - 1
+    assert list(eng.applied()) == list(range(n))
+    dups = golden_util.load_fixture("frontend_text_4actors_dups")
+    emu_patch(eng, dups["log"])
+    assert list(eng.applied()) == list(range(n))          # the appended copies are not applied again
+    pend = golden_util.load_fixture("hand_conflicts_pending")
+    emu_patch(eng, pend["log"])
+    st = eng.stats()
+    assert len(eng.applied()) == st.n_applied and st.n_pending > 0
+    shuf = golden_util.load_fixture("frontend_mixed_3actors_shuffled")
+    emu_patch(eng, shuf["log"])
+    order = list(eng.applied())
+    assert sorted(order) == list(range(len(shuf["log"].offsets) - 1)) and order != sorted(order)
