@@ -46,7 +46,20 @@ class Rec extends Orig {
       for (const c of changes) this.__inputs.push(c)
       let patch = null
       try { patch = JSON.stringify(this.getPatch()) } catch (e) { patch = null }
-      if (patch) record('changes', this.__inputs, { patch })
+      const extra = { patch }
+      if (patch && this.queue.length === 0) {
+        // digest of the reference's Backend.save(Backend.loadChanges(Backend.init(), changes)): a fresh document fed the same
+        // changes in one batch (the document under test is left untouched)
+        try {
+          const fresh = new Orig()
+          fresh.applyChanges(this.__inputs.slice())
+          if (fresh.queue.length !== 0) throw new Error('queued')
+          const doc = fresh.save()
+          extra.doc_len = doc.byteLength
+          extra.doc_sha256 = crypto.createHash('sha256').update(doc).digest('hex')
+        } catch (e) { /* leave the digest out */ }
+      }
+      if (patch) record('changes', this.__inputs, extra)
     } else this.__inputs = null
     return r
   }

@@ -31,7 +31,7 @@ def main():
                         plist.append(c)
                     idx.append(pool[c])
                 v = {"kind": d["kind"], "changes": idx}
-                for k in ("patch", "error"):
+                for k in ("patch", "error", "doc_len", "doc_sha256"):
                     if k in d:
                         v[k] = d[k]
                 vecs.append(v)

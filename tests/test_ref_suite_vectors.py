@@ -2,9 +2,11 @@
 the patch the unmodified reference then reports (1477 change vectors, 18 saved documents, 4 rejected batches; captured by
 oracle/make_ref_suite_vectors.py from new_backend_test, backend_test, test, text_test, table_test, sync_test, proxies_test,
 frontend_test). The reference applied the changes in several calls, the bulk replay applies them in one: the patch objects are
-compared as objects (`clock` key order is the one thing allowed to differ)."""
+compared as objects (`clock` key order is the one thing allowed to differ). 1471 vectors also carry length + SHA-256 of the
+reference's Backend.save of the same changes applied to a fresh document in one batch: am355_save must produce those bytes."""
 import base64
 import gzip
+import hashlib
 import json
 import os
 import subprocess
@@ -57,6 +59,10 @@ def _run_engine(eng, vectors):
             continue
         assert v["kind"] != "reject", f"vector {i}: the engine accepted a batch the reference rejects ({v['error']})"
         assert got == json.loads(v["patch"]), f"vector {i} ({v['kind']}, {len(blobs)} blobs): patch differs from the reference"
+        if "doc_sha256" in v:
+            # Backend.save(Backend.loadChanges(Backend.init(), changes)) of the reference, by digest
+            doc = eng.save()
+            assert len(doc) == v["doc_len"] and hashlib.sha256(doc).hexdigest() == v["doc_sha256"], f"vector {i}: saved document differs"
         equal += 1
     return equal, refused
 
