@@ -99,6 +99,7 @@ struct am355_ctx {
   std::vector<uint64_t> raw_off;
   uint32_t n_changes = 0;
   bool staged = false, replayed = false, ir_fetched = false;
+  bool has_unknown_cols = false;     // some change carries columns outside the modelled set (kept by the reference's save)
   bool is_document = false;          // staged input is one saved document (am355_load_document) rather than changes
   ChangeMeta doc_meta{};             // column layout of the staged document inside `raw`
   std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
@@ -1262,7 +1263,11 @@ extern "C" int am355_replay(am355_ctx* c) {
   {
     const ChangeBrief* br = c->hp_briefs;
     uint32_t dev_flags = h_wa[W_FLAGS_A];
-    for (uint32_t i = 0; i < n; i++) dev_flags |= br[i].flags_fits & 0x3fffffffu;
+    c->has_unknown_cols = false;
+    for (uint32_t i = 0; i < n; i++) {
+      dev_flags |= br[i].flags_fits & 0x1fffffffu;
+      if (br[i].flags_fits & 0x20000000u) c->has_unknown_cols = true;
+    }
     if (dev_flags) { (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
   }
   bool fast = h_wa[W_FAST_A] == 0;
@@ -1649,6 +1654,7 @@ extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_byte
     return AM355_OK;
   }
   if (c->n_pending) return fail(c, AM355_E_UNSUPPORTED, "changes are queued: the document is saved by the JS path");
+  if (!c->is_document && c->has_unknown_cols) return fail(c, AM355_E_UNSUPPORTED, "a change carries columns this engine does not model: the document is saved by the JS path");
   hipStream_t st = c->stream;
   const bool trace = getenv("AM355_TRACE") != nullptr;
   auto t_start = std::chrono::steady_clock::now();

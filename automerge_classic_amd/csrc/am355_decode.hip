@@ -304,6 +304,7 @@ constexpr uint32_t PARSE_STAGE = 8192;
 template <class P>
 __device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len64, ChangeMeta* out, uint32_t* n_entries_out) {
   bool stored = false;
+  uint32_t unknown_cols = 0;
   ChangeMeta m;
   m.base = base64;
   m.len = (uint32_t)len64;
@@ -379,6 +380,7 @@ __device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len6
       read_uleb(dir, l);
       int s = col_slot(id);
       if (s >= 0) { out->col_off[s] = data_off; out->col_len[s] = (uint32_t)l; }
+      else if (l) unknown_cols = 1;  // preserved by the reference (new.js:1387-1425); irrelevant to the patch, but save() must keep them
       if (s == C_ACTION) { act_off = data_off; act_len = (uint32_t)l; }
       if (s == C_PRED_NUM) { pn_off = data_off; pn_len = (uint32_t)l; }
       data_off += (uint32_t)l;
@@ -393,7 +395,7 @@ __device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len6
     if (m.start_op + m.n_ops > 0xfffffff0ull) m.flags |= F_OVERFLOW;
   } while (0);
   if (!stored) *out = m;
-  else { out->flags = m.flags; out->n_ops = m.n_ops; out->n_preds = m.n_preds; }
+  else { out->flags = m.flags; out->n_ops = m.n_ops; out->n_preds = m.n_preds; out->pad = unknown_cols; }
   *n_entries_out = m.flags ? 0 : m.n_entries;
 }
 
@@ -614,6 +616,7 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(ChangeMeta* __restrict__ 
     int wc = wave_class_of(*m);
     if (wc >= 1) br.flags_fits |= 0x80000000u;
     if (wc == 2) br.flags_fits |= 0x40000000u;
+    if (m->pad & 1) br.flags_fits |= 0x20000000u;  // the change carries columns this engine does not model
   }
   briefs[c] = br;
 }

@@ -20,7 +20,7 @@ struct ChangeMeta {
   uint32_t n_entries;    // actor table entries: author + others
   uint32_t author_slot;  // slot of the author in the device actor table (k_actor_intern)
   uint32_t max_first;    // max over its actor entries of "first change index authored by that actor" (k_actor_check)
-  uint32_t pad;
+  uint32_t pad;  // bit 0: the change has non-empty columns outside the modelled set
   uint32_t n_deps, deps_off;
   uint32_t actor_off, actor_len;
   uint32_t n_other, others_off;
@@ -32,7 +32,7 @@ struct ChangeMeta {
 struct ChangeBrief {
   uint64_t seq;
   uint32_t start_op, n_ops, n_preds, n_entries, author_slot;
-  uint32_t flags_fits;  // validity flags of the change; bit 31: the columns fit the wave-per-change decoder, bit 30: its small LDS class
+  uint32_t flags_fits;  // validity flags of the change; bit 31: the columns fit the wave-per-change decoder, bit 30: its small LDS class, bit 29: unmodelled columns present
 };
 
 // bits of the "fast path" word: any bit set => the host runs the general scheduler (new.js:1550-1597) itself
