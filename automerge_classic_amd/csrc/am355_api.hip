@@ -745,8 +745,12 @@ static int schedule(am355_ctx* c) {
   c->amap.reserve(local_ids.size());
   uint64_t ops = 0, preds = 0, max_op = 0;
   std::vector<std::vector<ActorSpan>> per_actor(na);
+  c->applied_change.clear();
+  c->applied_op_base.clear();
   for (uint32_t ci : applied_all) {
     const ChangeMeta& m = metas[ci];
+    c->applied_change.push_back(ci);  // (changes without ops are applied too: they have no plan, but a place in the history)
+    c->applied_op_base.push_back((uint32_t)ops);
     ChangePlan pl;
     pl.change = ci;
     pl.op_base = (uint32_t)ops;
@@ -854,9 +858,13 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
   c->clock_actor.clear();
   c->plans.clear();
   c->plans.reserve(n);
+  c->applied_change.resize(n);
+  c->applied_op_base.resize(n);
   uint64_t ops = 0, preds = 0, entries = 0, max_op = 0;
   for (uint32_t ci = 0; ci < n; ci++) {
     const ChangeBrief& m = br[ci];
+    c->applied_change[ci] = ci;
+    c->applied_op_base[ci] = (uint32_t)ops;
     uint32_t author = slot_rank[m.author_slot];
     if (m.seq != clock[author] + 1) { c->flags |= AM355_F_BAD_SEQ; return fail(c, AM355_E_INVALID, "sequence number %llu out of order", (unsigned long long)m.seq); }
     if (clock[author] == 0) c->clock_actor.push_back(author);
@@ -979,9 +987,6 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   c->p_tab_off = (uint32_t*)(d_tables + o_tab);
   int rcb = setup_buffers(c);
   if (rcb) return rcb;
-  c->applied_change.resize(np);
-  c->applied_op_base.resize(np);
-  for (size_t i = 0; i < np; i++) { c->applied_change[i] = c->plans[i].change; c->applied_op_base[i] = c->plans[i].op_base; }
   // decoder classes: changes whose columns fit the small LDS footprint first, then the large footprint, then the (rare)
   // ones with a column too long for LDS staging
   uint32_t n_small = 0, n_large = 0;

@@ -328,3 +328,20 @@ def test_applied_order(eng):
     emu_patch(eng, shuf["log"])
     order = list(eng.applied())
     assert sorted(order) == list(range(len(shuf["log"].offsets) - 1)) and order != sorted(order)
+
+
+def test_changes_without_ops_are_part_of_the_history(eng):
+    """A change with no ops is applied like any other (found by the reference-suite vectors): it appears in the application
+    order and in the saved document."""
+    import base64
+    import gzip
+    with open(os.path.join(golden_util.GOLDEN_DIR, "ref_suite_vectors.json.gz"), "rb") as f:
+        d = json.loads(gzip.decompress(f.read()))
+    pool = [base64.b64decode(x) for x in d["pool"]]
+    v = d["vectors"][817]
+    blobs = [pool[k] for k in v["changes"]]
+    log = loggen.ChangeLog.from_changes(blobs)
+    assert json.loads(emu_patch(eng, log)) == json.loads(v["patch"])
+    assert list(eng.applied()) == [0, 1] and eng.stats().n_ops < 2   # at least one of the two changes has no ops
+    import hashlib
+    assert hashlib.sha256(eng.save()).hexdigest() == v["doc_sha256"]
