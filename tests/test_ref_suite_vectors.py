@@ -46,6 +46,7 @@ def test_oracle_reproduces_every_reference_suite_vector():
 def _run_engine(eng, vectors):
     """Returns (equal, refused); raises on a differing patch or on an accepted batch the reference rejects."""
     equal = refused = 0
+    loaded = [0]
     for i, (v, blobs) in enumerate(vectors):
         try:
             if v["kind"] == "doc":
@@ -67,8 +68,18 @@ def _run_engine(eng, vectors):
                 doc = None   # e.g. changes with columns the engine does not model: their document is saved by the JS path
             if doc is not None:
                 assert len(doc) == v["doc_len"] and hashlib.sha256(doc).hexdigest() == v["doc_sha256"], f"vector {i}: saved document differs"
+                # ... and those bytes (= the reference's document) loaded again are the same document
+                try:
+                    eng.load_document(doc)
+                    eng.replay()
+                    again = json.loads(eng.patch_json())
+                except engine.UnsupportedChanges:
+                    again = None
+                if again is not None:
+                    assert again == json.loads(v["patch"]), f"vector {i}: Backend.load of the saved document gives another patch"
+                    loaded[0] += 1
         equal += 1
-    return equal, refused
+    return equal, refused, loaded[0]
 
 
 def test_engine_emulation_on_a_sample_of_reference_suite_vectors():
@@ -78,10 +89,10 @@ def test_engine_emulation_on_a_sample_of_reference_suite_vectors():
     sample = [x for i, x in enumerate(vs) if i % 12 == 0 or x[0]["kind"] != "changes"]
     eng = engine.Engine(0, os.path.join(EMU_DIR, "libam355_emu.so"))
     try:
-        equal, refused = _run_engine(eng, sample)
+        equal, refused, loaded = _run_engine(eng, sample)
     finally:
         eng.close()
-    assert equal >= len(sample) - 8 and refused <= 8
+    assert equal >= len(sample) - 8 and refused <= 8 and loaded >= len(sample) - 40
 
 
 @pytest.mark.gpu
@@ -89,8 +100,8 @@ def test_engine_on_every_reference_suite_vector():
     vs = _vectors()
     eng = engine.Engine(0)
     try:
-        equal, refused = _run_engine(eng, vs)
+        equal, refused, loaded = _run_engine(eng, vs)
     finally:
         eng.close()
     # 4 rejected batches + the couple of legal inputs the engine leaves to the JS path (counters in lists etc.)
-    assert equal >= len(vs) - 10 and refused <= 10
+    assert equal >= len(vs) - 10 and refused <= 10 and loaded >= 1400
