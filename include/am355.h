@@ -3,14 +3,16 @@
  *
  * This is the drop-in boundary for ONE path of the reference: Backend.loadChanges(Backend.init(), changes)
  * followed by Backend.getPatch(state)  (reference: backend/backend.js:116-129, backend/new.js:1797-1879 and
- * 2060-2068; callers: src/automerge.js:52-55 load, :105-118 getHistory, :43-46 clone).  The reference is 100 %
+ * 2060-2068; callers: src/automerge.js:52-55 load, :105-118 getHistory, :43-46 clone) -- plus the two calls on
+ * either side of it: Backend.load(bytes) (am355_load_document) and Backend.save(state) (am355_save).  The reference is 100 %
  * JavaScript and has no FFI; the host-side binding a maintainer adds is the N-API addon in
  * automerge_classic_amd/js/ (see INTEGRATION.md), which calls exactly these entry points and re-exports the
  * Backend module surface (backend/index.js:1-8) with every other call delegated to the JS backend.
  *
  * Plain pointers and sizes only; no C++ or torch types.  All functions return 0 on success or a negative
  * AM355_E_* code; am355_last_error() gives a message.  A context is bound to one GPU and one HIP stream and
- * is not thread-safe (the reference API is synchronous and single-threaded: backend/columnar.js:8-12).
+ * is not thread-safe (the reference API is synchronous and single-threaded: backend/columnar.js:8-12); the engine itself
+ * uses host threads internally (column DEFLATE in am355_save, patch text in am355_patch_json).
  *
  * The engine has no CPU fallback: without a gfx950 device am355_create() fails.
  */
