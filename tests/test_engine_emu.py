@@ -345,3 +345,43 @@ def test_changes_without_ops_are_part_of_the_history(eng):
     assert list(eng.applied()) == [0, 1] and eng.stats().n_ops < 2   # at least one of the two changes has no ops
     import hashlib
     assert hashlib.sha256(eng.save()).hexdigest() == v["doc_sha256"]
+
+
+def test_call_sequence_and_argument_errors():
+    """C-ABI error behaviour (include/am355.h): state errors instead of crashes, results owned by the context."""
+    import ctypes
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    e = engine.Engine(0, EMU_LIB)
+    try:
+        with pytest.raises(engine.EngineError) as ei:
+            e.replay()                      # nothing staged
+        assert ei.value.code == engine.AM355_E_STATE
+        with pytest.raises(engine.EngineError) as ei:
+            e.save()                        # nothing replayed
+        assert ei.value.code == engine.AM355_E_STATE
+        with pytest.raises(engine.EngineError) as ei:
+            e.patch_json()
+        assert ei.value.code == engine.AM355_E_STATE
+        L = e._L
+        assert L.am355_save(e._h, 0, None, None) == engine.AM355_E_ARG
+        assert L.am355_load_document(e._h, None, 0) == engine.AM355_E_ARG
+        n = ctypes.c_uint32()
+        assert L.am355_get_applied(e._h, None, ctypes.byref(n)) == engine.AM355_E_STATE
+        # a rejected batch leaves the context usable
+        fx = golden_util.load_fixture("hand_conflicts")
+        bad = bytearray(fx["log"].arena.tobytes())
+        bad[6] ^= 0xFF                      # checksum byte of the first change
+        log = loggen.ChangeLog.from_changes([bytes(bad[int(fx["log"].offsets[i]):int(fx["log"].offsets[i + 1])]) for i in range(len(fx["log"].offsets) - 1)])
+        with pytest.raises(engine.InvalidChanges):
+            e.load_changes(log)
+            e.replay()
+        assert emu_patch(e, fx["log"]) == fx["expected"]
+        # a document after changes and changes after a document
+        doc = e.save()
+        e.load_document(doc)
+        e.replay()
+        with pytest.raises(engine.EngineError):
+            e.hashes()                      # a loaded document has no per-change hashes
+        assert emu_patch(e, fx["log"]) == fx["expected"]
+    finally:
+        e.close()
