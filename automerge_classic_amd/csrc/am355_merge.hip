@@ -186,7 +186,6 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   bool live = kind != K_NONE && kind != K_DEL;
   bool is_make = live && (a & 1) == 0;
   if (in_range) b.obj_index[g] = is_make ? 1u : 0u;  // is-make flag, scanned later
-  (void)wave_append(&b.counts->n_objects, is_make);  // the count alone is needed early: it sizes the object pass of the map sort
   bool vis = live && b.succ_cnt[g] == 0;
   bool want_map = false, want_ins = false, want_upd = false;
   unsigned long long trig = 0;
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void k_ins_scatter(MergeBufs b, const uint32
 // ---------------------------------------------------------------------------------------------------------
 // objects
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint32_t* __restrict__ is_make_ex, PatchIR ir) {
+__global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint32_t* is_make_ex /* may be b.obj_index itself */, PatchIR ir) {
   uint32_t g = gtid();
   if (g >= b.n_ops) return;
   uint8_t kind = b.kind[g];
@@ -815,7 +814,9 @@ void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st) {
   if (N) {
     AM355_LAUNCH_INDEPENDENT(k_resolve, grid_for(N), dim3(BLOCK), st, b);
     hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
-    exclusive_scan_u32(b.scan_b, b.scan_a, N, &b.counts->n_list_ins, b.scan_ws, st);
+    // insert rows -> dense list positions; make rows -> dense object indexes (is-make flags become their exclusive prefix in place;
+    // k_object_table recomputes the flag)
+    exclusive_scan2_u32(b.scan_b, b.scan_a, &b.counts->n_list_ins, b.obj_index, b.obj_index, &b.counts->n_objects, N, b.scan_ws, st);
     AM355_LAUNCH_INDEPENDENT(k_ins_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_b, (const uint32_t*)b.scan_a);
   }
   (void)hipMemcpyAsync(h_counts, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
@@ -826,11 +827,9 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
   uint32_t N = b.n_ops;
   if (!force_radix) {  // (a radix rerun only redoes the list ordering; objects and map values are already in place)
   // ---- objects: dense index per make row (0 = _root) ----
-  uint32_t* is_make_ex = b.scan_a;
-  uint32_t* d_nobj = &b.counts->n_objects;
+  const uint32_t* is_make_ex = b.obj_index;  // scanned in phase 1
   if (N) {
-    exclusive_scan_u32(b.obj_index, is_make_ex, N, d_nobj, b.scan_ws, st);
-    AM355_LAUNCH_INDEPENDENT(k_object_table, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)is_make_ex, ir);
+    AM355_LAUNCH_INDEPENDENT(k_object_table, grid_for(N), dim3(BLOCK), st, b, is_make_ex, ir);
   } else {
     (void)hipMemsetAsync(ir.obj_make_row, 0xff, sizeof(uint32_t), st);
     (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t), st);
@@ -926,8 +925,7 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
     uint32_t* vis = b.scan_a;
     uint32_t* cnt = b.scan_b;
     AM355_LAUNCH_INDEPENDENT(k_list_counts, grid_for(ni), dim3(BLOCK), st, b, ni, vis, cnt);
-    exclusive_scan_u32(vis, vis, ni, nullptr, b.scan_ws, st);
-    exclusive_scan_u32(cnt, cnt, ni, nullptr, b.scan_ws, st);
+    exclusive_scan2_u32(vis, vis, nullptr, cnt, cnt, nullptr, ni, b.scan_ws, st);
     const uint64_t* uk = b.key_a;
     const uint32_t* uv = b.val_a;
     if (nu) {

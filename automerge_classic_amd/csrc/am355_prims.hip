@@ -78,7 +78,81 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict
   }
 }
 
-size_t scan_workspace_bytes(uint32_t n) { return sizeof(uint32_t) * ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 1); }
+// Two independent scans over the same index range in one pass: the replay runs its scans back to back on arrays that take a few
+// microseconds to stream, so a scan costs its three launches -- two arrays per launch halve that.
+__global__ __launch_bounds__(BLOCK) void k_scan2_tile_sums(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b, uint32_t* __restrict__ sums_a,
+                                                          uint32_t* __restrict__ sums_b, uint32_t n) {
+  __shared__ uint32_t s[BLOCK];
+  uint32_t base = blockIdx.x * SCAN_TILE;
+  uint32_t sa = 0, sb = 0;
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    uint32_t i = base + j * BLOCK + threadIdx.x;
+    if (i < n) { sa += in_a[i]; sb += in_b[i]; }
+  }
+  uint32_t ta, tb;
+  block_exclusive_scan(sa, s, &ta);
+  block_exclusive_scan(sb, s, &tb);
+  if (threadIdx.x == 0) { sums_a[blockIdx.x] = ta; sums_b[blockIdx.x] = tb; }
+}
+__global__ __launch_bounds__(BLOCK) void k_scan2_sums(uint32_t* __restrict__ sums_a, uint32_t* __restrict__ sums_b, uint32_t n_tiles, uint32_t* __restrict__ total_a,
+                                                     uint32_t* __restrict__ total_b) {
+  __shared__ uint32_t s[BLOCK];
+  uint32_t ca = 0, cb = 0;
+  for (uint32_t base = 0; base < n_tiles; base += BLOCK) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t va = i < n_tiles ? sums_a[i] : 0, vb = i < n_tiles ? sums_b[i] : 0;
+    uint32_t ta, tb;
+    uint32_t ea = block_exclusive_scan(va, s, &ta);
+    uint32_t eb = block_exclusive_scan(vb, s, &tb);
+    if (i < n_tiles) { sums_a[i] = ca + ea; sums_b[i] = cb + eb; }
+    ca += ta;
+    cb += tb;
+  }
+  if (threadIdx.x == 0) {
+    if (total_a) *total_a = ca;
+    if (total_b) *total_b = cb;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_scan2_apply(const uint32_t* __restrict__ in_a, uint32_t* __restrict__ out_a, const uint32_t* __restrict__ in_b,
+                                                      uint32_t* __restrict__ out_b, const uint32_t* __restrict__ sums_a, const uint32_t* __restrict__ sums_b, uint32_t n) {
+  __shared__ uint32_t s[BLOCK];
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t va[SCAN_ITEMS], vb[SCAN_ITEMS];
+  uint32_t sa = 0, sb = 0;
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    uint32_t i = base + j;
+    va[j] = i < n ? in_a[i] : 0;
+    vb[j] = i < n ? in_b[i] : 0;
+    sa += va[j];
+    sb += vb[j];
+  }
+  uint32_t ta, tb;
+  uint32_t ea = block_exclusive_scan(sa, s, &ta) + sums_a[blockIdx.x];
+  uint32_t eb = block_exclusive_scan(sb, s, &tb) + sums_b[blockIdx.x];
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    uint32_t i = base + j;
+    if (i < n) { out_a[i] = ea; out_b[i] = eb; }
+    ea += va[j];
+    eb += vb[j];
+  }
+}
+
+void exclusive_scan2_u32(const uint32_t* in_a, uint32_t* out_a, uint32_t* d_total_a, const uint32_t* in_b, uint32_t* out_b, uint32_t* d_total_b, uint32_t n,
+                         void* ws, hipStream_t st) {
+  uint32_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (n_tiles == 0) {
+    if (d_total_a) (void)hipMemsetAsync(d_total_a, 0, sizeof(uint32_t), st);
+    if (d_total_b) (void)hipMemsetAsync(d_total_b, 0, sizeof(uint32_t), st);
+    return;
+  }
+  uint32_t* sums_a = (uint32_t*)ws;
+  uint32_t* sums_b = sums_a + n_tiles + 1;
+  hipLaunchKernelGGL(k_scan2_tile_sums, dim3(n_tiles), dim3(BLOCK), 0, st, in_a, in_b, sums_a, sums_b, n);
+  hipLaunchKernelGGL(k_scan2_sums, dim3(1), dim3(BLOCK), 0, st, sums_a, sums_b, n_tiles, d_total_a, d_total_b);
+  hipLaunchKernelGGL(k_scan2_apply, dim3(n_tiles), dim3(BLOCK), 0, st, in_a, out_a, in_b, out_b, (const uint32_t*)sums_a, (const uint32_t*)sums_b, n);
+}
+
+size_t scan_workspace_bytes(uint32_t n) { return 2 * sizeof(uint32_t) * ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 2); }  // (room for a dual scan)
 
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total, void* ws, hipStream_t st) {
   uint32_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
