@@ -91,6 +91,7 @@ struct am355_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[8] = {};
   hipEvent_t ev_parse = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
+  hipEvent_t ev_counts = nullptr, ev_runs = nullptr;  // merge stage: counter read-backs that do not drain the stream
   std::string err;
   uint32_t flags = 0;
 
@@ -176,6 +177,20 @@ static int fail(am355_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(ctx, AM355_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
+
+// No C++ exception may cross the C ABI (an escaped std::bad_alloc would terminate the host process: untrusted input must end in
+// an error code, as the reference ends in a catchable exception).
+template <class F>
+static int guarded(am355_ctx* c, F body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return c ? fail(c, AM355_E_NOMEM, "out of host memory") : AM355_E_NOMEM;
+  } catch (const std::exception& e) {
+    return c ? fail(c, AM355_E_DEVICE, "internal error: %s", e.what()) : AM355_E_DEVICE;
+  }
+}
+
 extern "C" am355_ctx* am355_create(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return nullptr;
@@ -196,6 +211,7 @@ extern "C" am355_ctx* am355_create(int device) {
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev_counts) != hipSuccess || hipEventCreate(&c->ev_runs) != hipSuccess) { delete c; return nullptr; }
   return c;
 }
 
@@ -210,7 +226,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
     b->release();
   for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1}) b->release();
   c->d_s1.release();
-  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1})
+  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -244,15 +260,57 @@ static bool read_uleb_host(const uint8_t* p, size_t len, size_t& off, uint64_t& 
   return false;
 }
 
-extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
+// Raw DEFLATE of one stream (columnar.js:813-823, 1062-1067; the reference calls pako.inflateRaw). Returns 0 on success, 1 on
+// malformed / truncated data, 2 when the inflated size would pass `cap`, 3 on allocation failure. The output buffer only grows
+// when zlib has actually filled it: Z_BUF_ERROR with input exhausted and output space left is a truncated stream, not "retry
+// with more room" (a truncated stream must end in a catchable error as in the reference, not in an endless reallocation).
+static int inflate_raw(const uint8_t* in, size_t in_len, std::vector<uint8_t>& out, size_t cap) {
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, -15) != Z_OK) return 3;
+  out.resize(std::min<size_t>(std::max<size_t>(in_len * 4, 1024), cap));
+  size_t in_off = 0, produced = 0;
+  int result = 1;
+  for (;;) {
+    if (zs.avail_in == 0 && in_off < in_len) {
+      size_t take = std::min<size_t>(in_len - in_off, 1u << 30);
+      zs.next_in = (Bytef*)(in + in_off);
+      zs.avail_in = (uInt)take;
+      in_off += take;
+    }
+    if (produced == out.size()) {
+      if (out.size() >= cap) { result = 2; break; }
+      out.resize(std::min<size_t>(out.size() * 2, cap));
+    }
+    size_t room = std::min<size_t>(out.size() - produced, 1u << 30);
+    zs.next_out = out.data() + produced;
+    zs.avail_out = (uInt)room;
+    int rc = inflate(&zs, Z_NO_FLUSH);
+    produced += room - zs.avail_out;
+    if (rc == Z_STREAM_END) { result = 0; break; }
+    if (rc == Z_OK) continue;
+    if (rc == Z_BUF_ERROR && zs.avail_out == 0) continue;  // output full: grow and go on
+    result = rc == Z_MEM_ERROR ? 3 : 1;                     // Z_DATA_ERROR, or Z_BUF_ERROR with the input exhausted = truncated
+    break;
+  }
+  inflateEnd(&zs);
+  out.resize(result == 0 ? produced : 0);
+  return result;
+}
+constexpr size_t INFLATE_CAP = 0xfff00000ull;  // one staged batch / document is addressed with 32-bit arena offsets
+
+static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
   c->staged = c->replayed = c->ir_fetched = false;
   c->is_document = false;
   c->flags = 0;
+  for (uint32_t i = 0; i < n; i++)
+    if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
+  if (offsets[n] - offsets[0] >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }
   c->raw.clear();
   c->raw_off.assign(1, 0);
-  c->raw.reserve(offsets[n] + 64);
+  c->raw.reserve((size_t)(offsets[n] - offsets[0]) + 64);
   for (uint32_t i = 0; i < n; i++) {
     const uint8_t* p = arena + offsets[i];
     size_t len = offsets[i + 1] - offsets[i];
@@ -261,24 +319,13 @@ extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint
       size_t off = 9;
       uint64_t clen;
       if (!read_uleb_host(p, len, off, clen) || clen > len - off) { c->flags |= AM355_F_BAD_CHUNK; return fail(c, AM355_E_INVALID, "change %u: bad deflate container", i); }
-      std::vector<uint8_t> out(std::max<size_t>(clen * 4, 1024));
-      size_t outlen = 0;
-      for (;;) {
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) return fail(c, AM355_E_NOMEM, "inflateInit2");
-        zs.next_in = (Bytef*)(p + off);
-        zs.avail_in = (uInt)clen;
-        zs.next_out = out.data();
-        zs.avail_out = (uInt)out.size();
-        int rc = inflate(&zs, Z_FINISH);
-        outlen = zs.total_out;
-        inflateEnd(&zs);
-        if (rc == Z_STREAM_END) break;
-        if (rc == Z_BUF_ERROR || rc == Z_OK) { out.resize(out.size() * 4); continue; }
-        c->flags |= AM355_F_BAD_DEFLATE;
-        return fail(c, AM355_E_INVALID, "change %u: invalid deflate data", i);
-      }
+      std::vector<uint8_t> out;
+      int irc = inflate_raw(p + off, (size_t)clen, out, INFLATE_CAP);
+      if (irc == 3) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
+      if (irc == 2) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "change %u: inflated size beyond the 4 GiB batch limit", i); }
+      if (irc) { c->flags |= AM355_F_BAD_DEFLATE; return fail(c, AM355_E_INVALID, "change %u: invalid or truncated deflate data", i); }
+      size_t outlen = out.size();
+      if (c->raw.size() + outlen >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch inflates beyond the 4 GiB limit"); }
       c->raw.insert(c->raw.end(), p, p + 8);
       c->raw.push_back(1);
       uint64_t v = outlen;
@@ -292,7 +339,7 @@ extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint
   if (c->raw.size() >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)");
   c->n_changes = n;
   if (!c->d_arena.ensure(c->raw.size() + 64) || !c->d_offsets.ensure(sizeof(uint64_t) * (n + 1)) || !c->d_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) ||
-      !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) || !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(sizeof(Counts)))
+      !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) || !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
   HIPCHK(c, hipMemcpyAsync(c->d_arena.p, c->raw.data(), c->raw.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->raw_off.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream));
@@ -383,7 +430,7 @@ struct HostRle {
 };
 }  // namespace
 
-extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len) {
+static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   if (!c || !doc) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
   c->staged = c->replayed = c->ir_fetched = false;
@@ -410,7 +457,7 @@ extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len)
     c->actors.emplace_back((const char*)h + ho, (size_t)l);
     ho += (size_t)l;
   }
-  if (!read_uleb_host(h, hl, ho, nh) || nh * 32 > hl - ho) return bad(AM355_F_BAD_LEB, "bad document header");
+  if (!read_uleb_host(h, hl, ho, nh) || nh > (hl - ho) / 32) return bad(AM355_F_BAD_LEB, "bad document header");
   c->heads.assign(h + ho, h + ho + nh * 32);
   ho += (size_t)nh * 32;
   struct Col { uint64_t id, len; std::vector<uint8_t> data; const uint8_t* p = nullptr; size_t n = 0; };
@@ -435,19 +482,9 @@ extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len)
       const uint8_t* p = h + ho;
       ho += (size_t)col.len;
       if (col.id & 8) {
-        std::vector<uint8_t> out(std::max<size_t>(col.len * 4, 1024));
-        for (;;) {
-          z_stream zs;
-          memset(&zs, 0, sizeof zs);
-          if (inflateInit2(&zs, -15) != Z_OK) return 2;
-          zs.next_in = (Bytef*)p; zs.avail_in = (uInt)col.len; zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
-          int rc = inflate(&zs, Z_FINISH);
-          size_t got = zs.total_out;
-          inflateEnd(&zs);
-          if (rc == Z_STREAM_END) { out.resize(got); break; }
-          if (rc == Z_BUF_ERROR || rc == Z_OK) { out.resize(out.size() * 4); continue; }
-          return 2;
-        }
+        std::vector<uint8_t> out;
+        int irc = inflate_raw(p, (size_t)col.len, out, INFLATE_CAP);
+        if (irc) return irc == 1 ? 2 : irc == 2 ? 3 : 4;
         col.data = std::move(out);
         col.p = col.data.data();
         col.n = col.data.size();
@@ -462,7 +499,9 @@ extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len)
   int rd = read_data(ccols);
   if (!rd) rd = read_data(ocols);
   if (rd == 1) return bad(AM355_F_BAD_CHUNK, "document columns exceed the chunk");
-  if (rd == 2) return bad(AM355_F_BAD_DEFLATE, "invalid deflate data in a document column");
+  if (rd == 2) return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
+  if (rd == 3) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "document column inflates beyond the 4 GiB limit"); }
+  if (rd == 4) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
   // (headsIndexes and extraBytes follow; neither influences the patch: kept for am355_save)
   c->doc_tail.assign(h + ho, h + hl);
   c->doc_chg_cols.clear();
@@ -547,7 +586,7 @@ extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len)
   if (c->raw.size() >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "document larger than 4 GiB (32-bit arena offsets)");
   m.len = (uint32_t)c->raw.size();
   if (!c->d_arena.ensure(c->raw.size() + 64) || !c->d_metas.ensure(sizeof(ChangeMeta)) || !c->h_metas.ensure(sizeof(ChangeMeta)) ||
-      !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(sizeof(Counts)))
+      !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
   HIPCHK(c, hipMemcpyAsync(c->d_arena.p, c->raw.data(), c->raw.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -929,11 +968,14 @@ static int setup_buffers(am355_ctx* c) {
     o.pred_ctr = carve<uint32_t>(q, (size_t)P + 1);
   }
   {
+    size_t cw = carry_words(N);
     size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc + 2, 4) + 4 * carve_size(2 * Nc + 2, 4) +
-                   3 * carve_size(Nc + 1, 4) + scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 256;
+                   3 * carve_size(Nc + 1, 4) + scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 256 +
+                   6 * carve_size(Nc + 3, 4) + 5 * carve_size(cw, 4);
     size_t sort_bytes = 2 * carve_size(Nc, 8) + 2 * carve_size(Nc, 4) + sort_workspace_bytes((uint32_t)Nc) + 256;
     size_t ir_bytes = 5 * carve_size(Nc, 4) + 2 * carve_size(Nc, 4) + carve_size(Nc, 8) + 4 * carve_size(Nc, 4);
-    if (!c->d_merge.ensure(bytes) || !c->d_sort.ensure(sort_bytes) || !c->d_ir.ensure(ir_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
+    if (!c->d_merge.ensure(bytes) || !c->d_sort.ensure(sort_bytes) || !c->d_ir.ensure(ir_bytes) || !c->d_counts.ensure(merge_counts_bytes(N)))
+      return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
     uint8_t* p = c->d_merge.as<uint8_t>();
     MergeBufs& b = c->mb;
     b.arena = c->d_arena.as<uint8_t>();
@@ -954,17 +996,24 @@ static int setup_buffers(am355_ctx* c) {
     b.euler_a = carve<unsigned long long>(p, 2 * Nc + 2); b.euler_b = carve<unsigned long long>(p, 2 * Nc + 2);
     b.order = carve<uint32_t>(p, Nc + 1); b.scan_a = carve<uint32_t>(p, Nc + 1); b.scan_b = carve<uint32_t>(p, Nc + 1);
     b.scan_ws = p;
+    p += (scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 255) & ~(size_t)255;
+    b.run_heads = carve<uint32_t>(p, Nc + 3); b.row_run = carve<uint32_t>(p, Nc + 3); b.obj_n = carve<uint32_t>(p, Nc + 3);
+    b.obj_first_pos = carve<uint32_t>(p, Nc + 3); b.list_vis = carve<uint32_t>(p, Nc + 3); b.list_cnt = carve<uint32_t>(p, Nc + 3);
+    b.cs_ins.wg_sum = carve<uint32_t>(p, cw); b.cs_make.wg_sum = carve<uint32_t>(p, cw); b.cs_runs.wg_sum = carve<uint32_t>(p, cw);
+    b.cs_vis.wg_sum = carve<uint32_t>(p, cw); b.cs_cnt.wg_sum = carve<uint32_t>(p, cw);
+    // unordered child lists (k_child_push) live in the second Euler buffer, which list ranking only uses afterwards
+    b.child_head = (uint32_t*)b.euler_b;
+    b.child_next = b.child_head + (2 * Nc + 2);
     uint8_t* s = c->d_sort.as<uint8_t>();
     b.key_a = carve<uint64_t>(s, Nc); b.key_b = carve<uint64_t>(s, Nc); b.val_a = carve<uint32_t>(s, Nc); b.val_b = carve<uint32_t>(s, Nc);
     b.sort_ws = s;
-    b.counts = c->d_counts.as<Counts>();
+    merge_bind_counts(b, c->d_counts.p);
     uint8_t* r = c->d_ir.as<uint8_t>();
     PatchIR& ir = c->ir;
     ir.obj_make_row = carve<uint32_t>(r, Nc); ir.obj_map_begin = carve<uint32_t>(r, Nc); ir.obj_map_end = carve<uint32_t>(r, Nc);
     ir.obj_edit_begin = carve<uint32_t>(r, Nc); ir.obj_edit_end = carve<uint32_t>(r, Nc);
     ir.m_row = carve<uint32_t>(r, Nc); ir.m_flags = carve<uint32_t>(r, Nc); ir.m_counter = carve<long long>(r, Nc);
     ir.e_row = carve<uint32_t>(r, Nc); ir.e_elem = carve<uint32_t>(r, Nc); ir.e_index = carve<uint32_t>(r, Nc); ir.e_flags = carve<uint32_t>(r, Nc);
-    b.obj_first_pos = b.em_row;  // em_row is dead once the map emissions are ordered (lists run afterwards)
   }
   return AM355_OK;
 }
@@ -1024,27 +1073,22 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
     HIPCHK(c, hipMemcpyAsync(d_tables, h, o_x + std::max(b_rank, b_amap), hipMemcpyHostToDevice, st));
   }
 
-  // ---- stage 1b: column decode ----
-  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
-  HIPCHK(c, hipEventRecord(c->ev[2], st));  // brackets the decode launch only (bench.py's roofline.launch_ms)
+  // ---- stage 1b: column decode; the zero-fills of the merge stage and the second decoder class run beside it on stream3 ----
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+  merge_prepare(c->mb, c->stream3);
+  HIPCHK(c, hipEventRecord(c->ev[2], st));  // brackets the decode launch only
   launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, (uint32_t)np - n_small - n_large, d_amap,
-                        d_rank,
-                        c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3, c->ev_fork, c->ev_join);
+                        d_rank, c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+  HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
 
-  // ---- stage 2: merge (the decode flags land in the same counter block and are read with the phase-1 counters) ----
+  // ---- stage 2: merge (the decode flags land in the same counter block and are read with the first counters) ----
   Counts* hc = c->h_counts.as<Counts>();
-  merge_phase1(c->mb, hc, st);
-  HIPCHK(c, hipEventRecord(c->ev[4], st));
-  if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
-  merge_phase2(c->mb, c->ir, hc, st, false);
-  if (hc->pad && !hc->flags) {
-    // some list element has hundreds of children (e.g. everyone inserting at the same spot): redo the ordering with the radix sort
-    HIPCHK(c, hipMemsetAsync(&c->mb.counts->pad, 0, sizeof(uint32_t), st));
-    merge_phase2(c->mb, c->ir, hc, st, true);
-  }
+  merge_run(c->mb, c->ir, hc, st, c->ev_counts, c->ev_runs);
   HIPCHK(c, hipEventRecord(c->ev[5], st));
-  HIPCHK(c, hipStreamSynchronize(st));
   if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
   c->counts = *hc;
   c->counts.n_objects += 1;  // + _root
@@ -1183,7 +1227,7 @@ static int replay_document(am355_ctx* c) {
   return AM355_OK;
 }
 
-extern "C" int am355_replay(am355_ctx* c) {
+static int replay_impl(am355_ctx* c) {
   if (!c) return AM355_E_ARG;
   if (!c->staged) return fail(c, AM355_E_STATE, "am355_load_changes must be called first");
   (void)hipSetDevice(c->device);
@@ -1328,8 +1372,11 @@ extern "C" int am355_replay(am355_ctx* c) {
   s.ir_bytes = (uint64_t)c->counts.n_objects * 20 + (uint64_t)c->counts.n_map_emit * 16 + (uint64_t)c->counts.n_edits * 16;
   (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
-  (void)hipEventElapsedTime(&s.ms_merge, c->ev[3], c->ev[4]);
-  (void)hipEventElapsedTime(&s.ms_order, c->ev[4], c->ev[5]);
+  s.ms_merge = s.ms_order = 0;
+  if (c->n_ops) {  // (ev_counts: after resolve / emit / compaction, before the ordering kernels)
+    (void)hipEventElapsedTime(&s.ms_merge, c->ev[3], c->ev_counts);
+    (void)hipEventElapsedTime(&s.ms_order, c->ev_counts, c->ev[5]);
+  }
   (void)hipEventElapsedTime(&s.ms_hash_stream, c->ev_b0, c->ev_b1);  // hash stream (SHA-256 + dependency resolution), overlapped
   s.ms_host_schedule = ms_host;
   s.fast_path = fast ? 1 : 0;
@@ -1370,7 +1417,7 @@ extern "C" int am355_get_applied(const am355_ctx* c, uint32_t* out, uint32_t* n_
   return AM355_OK;
 }
 
-extern "C" int am355_fetch_ir(am355_ctx* c, am355_patch_ir* out) {
+static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
   if (!c) return AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");
   (void)hipSetDevice(c->device);
@@ -1432,9 +1479,9 @@ extern "C" int am355_fetch_ir(am355_ctx* c, am355_patch_ir* out) {
   return AM355_OK;
 }
 
-extern "C" int am355_patch_json(am355_ctx* c, const char** json, size_t* len) {
+static int patch_json_impl(am355_ctx* c, const char** json, size_t* len) {
   if (!c) return AM355_E_ARG;
-  int rc = am355_fetch_ir(c, nullptr);
+  int rc = fetch_ir_impl(c, nullptr);
   if (rc) return rc;
   std::string err;
   c->json.clear();
@@ -1649,7 +1696,7 @@ __global__ __launch_bounds__(BLOCK) void k_save_doc_rows(OpCols in, uint32_t n, 
 
 }  // namespace
 
-extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, size_t* out_len) {
+static int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, size_t* out_len) {
   if (!c || !out_bytes || !out_len) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must be called first");
   (void)hipSetDevice(c->device);
@@ -1909,3 +1956,11 @@ extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_byte
   *out_len = c->saved.size();
   return AM355_OK;
 }
+
+// ---- C ABI entry points of the calls that allocate with the input size ----
+extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) { return guarded(c, [&]() { return load_changes_impl(c, arena, offsets, n); }); }
+extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len) { return guarded(c, [&]() { return load_document_impl(c, doc, len); }); }
+extern "C" int am355_replay(am355_ctx* c) { return guarded(c, [&]() { return replay_impl(c); }); }
+extern "C" int am355_fetch_ir(am355_ctx* c, am355_patch_ir* out) { return guarded(c, [&]() { return fetch_ir_impl(c, out); }); }
+extern "C" int am355_patch_json(am355_ctx* c, const char** json, size_t* len) { return guarded(c, [&]() { return patch_json_impl(c, json, len); }); }
+extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, size_t* out_len) { return guarded(c, [&]() { return save_impl(c, flags, out_bytes, out_len); }); }

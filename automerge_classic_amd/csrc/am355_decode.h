@@ -14,10 +14,10 @@ void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, co
                          ChangeBrief* briefs, hipStream_t st);
 uint32_t distinct_capacity();
 // slot_rank == nullptr: `amap` already holds global actor ranks. plans = [n_small | n_large wave-decodable | n_serial others]
-// (ChangeBrief.flags_fits bit 30: small wave class, bit 31: any wave class)
+// (ChangeBrief.flags_fits bit 30: small wave class, bit 31: any wave class). `aux`: a stream the caller forked from `st` and joins
+// afterwards (the second decoder class runs there)
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_small, uint32_t n_large, uint32_t n_serial,
-                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux,
-                           hipEvent_t ev_fork, hipEvent_t ev_join);
+                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux);
 // documents: count rows / succ entries into meta->n_ops / n_preds, then decode all op columns of the one pseudo-change
 void launch_doc_count(const uint8_t* arena, ChangeMeta* meta, hipStream_t st);
 void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const ChangePlan* plan, const uint32_t* actor_rank, OpCols cols,

@@ -1577,29 +1577,20 @@ void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const 
 }
 
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_small, uint32_t n_large, uint32_t n_serial,
-                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux,
-                           hipEvent_t ev_fork, hipEvent_t ev_join) {
+                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux) {
   // plans = [small wave class | large wave class | lane-serial]: the first two go to the wave-per-change run-level decoder
   // (two LDS footprints, see WaveLdsT), the rest (a column too long for LDS staging) to the lane-serial decoder.
   // Every launch is bound by the latency of one change, not by throughput, so the classes run side by side: the large
-  // class on the auxiliary stream. With few changes the LDS footprint does not limit residency: one launch.
+  // class on the auxiliary stream, which the caller has forked from `st` and joins afterwards. With few changes the LDS
+  // footprint does not limit residency: one launch.
   ActorXlate x{amap, slot_rank};
   if (n_large && n_small + n_large <= 1024) { n_large += n_small; n_small = 0; }
-  bool fork = n_small && (n_large || n_serial) && aux;
-  if (fork) {
-    (void)hipEventRecord(ev_fork, st);
-    (void)hipStreamWaitEvent(aux, ev_fork, 0);
-  }
-  hipStream_t s2 = fork ? aux : st;
+  hipStream_t s2 = (n_small && aux) ? aux : st;
   if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags);
   if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags);
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans + n_small + n_large, n_serial,
                              x, cols, flags, 0);
-  if (fork) {
-    (void)hipEventRecord(ev_join, aux);
-    (void)hipStreamWaitEvent(st, ev_join, 0);
-  }
 }
 
 }  // namespace am355

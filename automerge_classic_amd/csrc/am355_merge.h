@@ -1,6 +1,7 @@
 // Stage 2 of the replay engine: op-set merge and whole-document patch IR (see am355_merge.hip).
 #pragma once
 #include "am355_internal.h"
+#include "am355_scan.h"
 #include <stddef.h>
 
 namespace am355 {
@@ -14,7 +15,10 @@ struct Counts {
   uint32_t n_objects;    // make* rows (+1 for _root)
   uint32_t max_key_len;  // longest map key among emitted values
   uint32_t n_edits;      // list edit records
-  uint32_t pad;
+  uint32_t pad;          // a list element has more children than the in-place sibling ordering handles: redo with the radix sort
+  uint32_t n_runs;       // typing runs of the insertion forest (list ranking works on 2 x runs + 1 tour entries)
+  uint32_t euler_done;   // the single-workgroup LDS list ranking handled the tour
+  uint32_t reserved[6];
 };
 
 // Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.
@@ -42,15 +46,27 @@ struct MergeBufs {
   // RGA
   uint32_t *first_child;            // [2N+1] indexed by parent slot: element row, or N + make row for a list head
   uint32_t *next_sib;               // [N]
+  uint32_t *child_head;             // [2N+1] unordered child list per parent slot (atomic push), aliases the Euler scratch
+  uint32_t *child_next;             // [N]
+  uint32_t *obj_n;                  // [n_objects + 1] list elements (insert rows) per object
+  uint32_t *run_heads, *row_run;    // typing runs: first insert-list index of each run; run of a row (run heads and tails only)
+  uint32_t *list_vis, *list_cnt;    // [N] per list position: element visible, number of its edits (scanned into scan_a / scan_b)
+  CarryScan cs_ins, cs_make, cs_runs, cs_vis, cs_cnt;  // carried scans (am355_scan.h); their group sums follow `counts`
   unsigned long long *euler_a, *euler_b;        // [2N+2] Euler tour list ranking: (weight-to-end << 32 | successor)
   uint32_t *order;                  // [N] node rows in document order (all list objects chained)
   uint32_t *scan_a, *scan_b;        // [N+1] prefix sums over `order`
   uint32_t *obj_first_pos;          // [n_objects] position in `order` of the first element of each list object
   void* scan_ws;
-  Counts* counts;                   // device
+  Counts* counts;                   // device; followed by the group sums of the carried scans (cleared with it)
+  size_t counts_bytes;              // Counts + group sums
   void* zero_base;                  // succ_cnt .. last_inc are contiguous: one memset per replay
   size_t zero_bytes;
 };
+
+// bytes of the device block that holds Counts and the carried scans' group sums for N op rows
+size_t merge_counts_bytes(uint32_t n_ops);
+// points b.counts / b.cs_*.group_sum into that block (b.cs_*.wg_sum are carved by the caller: carry_words(N) words each)
+void merge_bind_counts(MergeBufs& b, void* d_counts_block);
 
 // ---- patch IR in device memory (the output of the hot path) ---------------------------------------------
 struct PatchIR {
@@ -71,12 +87,14 @@ struct PatchIR {
 
 size_t merge_scratch_pairs(uint32_t n_ops);
 
-// Runs resolve -> emit; fills counts (device) and copies them to *h_counts (synchronises the stream once).
-void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st);
-// Runs object indexing, map emission ordering, RGA ordering, edit generation. Needs *h_counts from phase 1.
-// force_radix: order list siblings with the radix sort instead of the counting sort (needed when a parent has more
-// than a few hundred children; phase 2 reports that in h_counts->pad and the caller reruns it with force_radix).
-void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, bool force_radix);
+// Zero-fills the merge stage needs (succ / counter accumulators, child lists, list order): independent of the decode kernels,
+// so the caller issues them on a second stream beside the decode and joins before merge_run.
+void merge_prepare(MergeBufs& b, hipStream_t aux);
+// resolve -> emit -> compaction -> object table, map emission order, RGA order (sibling ordering, typing runs, list ranking),
+// edits. `b.counts` (cleared by the caller BEFORE the decode kernels, whose validity flags it already holds) is read back
+// twice without draining the stream (ev_counts, ev_runs: the host sizes the later launches while the device works through
+// the earlier ones) and once at the end (synchronises st). Returns the counters in *h_counts.
+void merge_run(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs);
 
 // Document load: whole-document patch of rows already in canonical order (pred_* arrays = succ lists). `b.counts` must be
 // cleared by the caller before the decode kernels run.

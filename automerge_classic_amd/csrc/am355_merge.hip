@@ -82,27 +82,41 @@ __device__ __forceinline__ bool int_value(const MergeBufs& b, uint32_t row, long
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
   uint32_t g = gtid();
-  if (g >= b.n_ops) return;
+  const bool in_range = g < b.n_ops;
   const OpCols& o = b.ops;
   uint32_t err = 0;
-  uint32_t a = o.action[g];
-  bool ins = o.insert[g] != 0;
-  unsigned long long my_id = pack_id(o.id_ctr[g], o.id_actor[g]);
+  uint32_t a = in_range ? o.action[g] : 1;
+  bool ins = in_range && o.insert[g] != 0;
+  unsigned long long my_id = in_range ? pack_id(o.id_ctr[g], o.id_actor[g]) : 0;
 
+  // object: nearly every row of a wavefront names the same object (a change edits one Text, a whole document may be one
+  // Text), so one lane resolves it for the wave and only rows naming another object search the span table themselves
+  uint32_t oa = in_range ? o.obj_actor[g] : NONE32, oc = in_range ? o.obj_ctr[g] : 0;
+  bool has_obj = oa != NONE32;
   uint32_t orow = NONE32;
+  {
+    unsigned long long m = __ballot(has_obj);
+    uint32_t lane = threadIdx.x & (WAVE - 1);
+    uint32_t leader = m ? (uint32_t)__ffsll(m) - 1 : 0;
+    uint32_t la = __shfl(oa, (int)leader), lc = __shfl(oc, (int)leader);
+    uint32_t lrow = (m && lane == leader) ? row_of(b, oa, oc) : NONE32;
+    lrow = __shfl(lrow, (int)leader);
+    if (has_obj) orow = (oa == la && oc == lc) ? lrow : row_of(b, oa, oc);
+  }
+  if (!in_range) return;
   bool list_obj = false;
-  if (o.obj_actor[g] != NONE32) {
-    orow = row_of(b, o.obj_actor[g], o.obj_ctr[g]);
+  if (has_obj) {
     if (orow == NONE32 || (o.action[orow] & 1)) { err |= F_UNKNOWN_OBJECT; orow = NONE32; }
     else {
-      uint32_t oa = o.action[orow];
-      list_obj = (oa == 2 || oa == 4);
+      uint32_t oact = o.action[orow];
+      list_obj = (oact == 2 || oact == 4);
       if (pack_id(o.id_ctr[orow], o.id_actor[orow]) >= my_id) err |= F_UNSUPPORTED;
     }
   }
   bool has_str = o.key_len[g] != NONE32, has_elem = o.key_ctr[g] != NONE32;
   uint8_t kind = K_NONE;
   uint32_t ref = NONE32;
+  const uint32_t ka = o.key_actor[g], kc = o.key_ctr[g];
   if (has_str == has_elem) {
     err |= has_str ? F_UNSUPPORTED : F_BAD_ROW;
   } else if (has_str) {
@@ -110,8 +124,10 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
     kind = a == 3 ? K_DEL : K_MAP;
   } else {
     if (!list_obj) err |= F_UNSUPPORTED;
-    if (o.key_ctr[g] != 0) {
-      ref = row_of(b, o.key_actor[g], o.key_ctr[g]);
+    if (kc != 0) {
+      // typing: the reference element of an insert is nearly always the op right before it (same change, previous row)
+      if (g > 0 && o.id_ctr[g - 1] == kc && o.id_actor[g - 1] == ka) ref = g - 1;
+      else ref = row_of(b, ka, kc);
       if (ref == NONE32 || !o.insert[ref] || !same_obj(b, ref, g) || o.key_len[ref] != NONE32) { err |= F_BAD_ELEM; ref = NONE32; }
       else if (pack_id(o.id_ctr[ref], o.id_actor[ref]) >= my_id) err |= F_UNSUPPORTED;
     } else if (!ins) {
@@ -134,9 +150,15 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
     uint32_t pa = o.pred_actor[pf + j], pc = o.pred_ctr[pf + j];
     for (uint32_t k = 0; k < j; k++)
       if (o.pred_actor[pf + k] == pa && o.pred_ctr[pf + k] == pc) err |= F_BAD_PRED;  // second copy never matches
-    uint32_t pr = row_of(b, pa, pc);
+    // deleting / overwriting a list element names the element's own insert op as pred: already resolved as `ref`
+    uint32_t pr = (ref != NONE32 && pa == ka && pc == kc) ? ref : row_of(b, pa, pc);
     if (pr == NONE32 || o.action[pr] == 3 || !same_obj(b, pr, g)) { err |= F_BAD_PRED; continue; }
-    bool same_slot = has_str ? same_key(b, pr, g) : (!has_str && o.key_len[pr] == NONE32 && ref != NONE32 && elem_of(b, pr) == ref && !ins);
+    bool same_slot;
+    if (has_str) same_slot = same_key(b, pr, g);
+    else if (o.key_len[pr] != NONE32 || ref == NONE32 || ins) same_slot = false;
+    else if (pr == ref) same_slot = true;
+    else if (!o.insert[pr] && o.key_actor[pr] == ka && o.key_ctr[pr] == kc) same_slot = true;  // an earlier update of the same element
+    else same_slot = elem_of(b, pr) == ref;
     if (!same_slot) { err |= F_BAD_PRED; continue; }
     if (pack_id(pc, pa) >= my_id) err |= F_UNSUPPORTED;
     atomicAdd(&b.succ_cnt[pr], 1u);
@@ -178,6 +200,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 }
 
 __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
+  __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t g = gtid();
   const OpCols& o = b.ops;
   bool in_range = g < b.n_ops;
@@ -185,7 +208,6 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   uint32_t a = in_range ? o.action[g] : 1;
   bool live = kind != K_NONE && kind != K_DEL;
   bool is_make = live && (a & 1) == 0;
-  if (in_range) b.obj_index[g] = is_make ? 1u : 0u;  // is-make flag, scanned later
   bool vis = live && b.succ_cnt[g] == 0;
   bool want_map = false, want_ins = false, want_upd = false;
   unsigned long long trig = 0;
@@ -217,26 +239,25 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
     b.em_trig[slot] = trig;
     atomicMax(&b.counts->max_key_len, o.key_len[g]);
   }
-  // list insert rows are most of a text document: compact them with a prefix sum rather than contended atomics
-  if (in_range) b.scan_b[g] = want_ins ? 1u : 0u;
   slot = wave_append(&b.counts->n_list_upd, want_upd);
   if (want_upd) b.upd_row[slot] = g;
+  // list insert rows are most of a text document, make rows must keep row order: both are compacted by prefix sums, whose
+  // workgroup sums this kernel publishes (k_compact_rows rebuilds the positions: no scan launch in between)
+  uint32_t t_ins = carry_publish(b.cs_ins, want_ins ? 1u : 0u, s_red);
+  uint32_t t_make = carry_publish(b.cs_make, is_make ? 1u : 0u, s_red);
+  if (threadIdx.x == 0) {
+    if (t_ins) atomicAdd(&b.counts->n_list_ins, t_ins);
+    if (t_make) atomicAdd(&b.counts->n_objects, t_make);
+  }
 }
 
+// documents (doc_patch): insert rows to dense positions from a scanned flag array
 __global__ __launch_bounds__(BLOCK) void k_ins_scatter(MergeBufs b, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos) {
   uint32_t g = gtid();
   if (g < b.n_ops && flag[g]) b.ins_row[pos[g]] = g;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// objects
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint32_t* is_make_ex /* may be b.obj_index itself */, PatchIR ir) {
-  uint32_t g = gtid();
-  if (g >= b.n_ops) return;
-  uint8_t kind = b.kind[g];
-  bool is_make = kind != K_DEL && kind != K_NONE && (b.ops.action[g] & 1) == 0;
-  uint32_t idx = is_make_ex[g] + 1;  // 0 is _root
+__device__ __forceinline__ void object_table_entry(const MergeBufs& b, const PatchIR& ir, uint32_t g, bool is_make, uint32_t idx) {
   if (is_make) {
     ir.obj_make_row[idx] = g;
     b.obj_index[g] = idx;
@@ -248,6 +269,32 @@ __global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint3
     ir.obj_make_row[0] = NONE32;
     ir.obj_map_begin[0] = ir.obj_map_end[0] = ir.obj_edit_begin[0] = ir.obj_edit_end[0] = 0;
   }
+}
+
+// consumer of k_emit's carried scans: list insert rows -> dense list (ins_row), make rows -> object table (index 0 = _root)
+__global__ __launch_bounds__(BLOCK) void k_compact_rows(MergeBufs b, PatchIR ir) {
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  uint32_t g = gtid();
+  bool in_range = g < b.n_ops;
+  uint8_t kind = in_range ? b.kind[g] : (uint8_t)K_NONE;
+  bool live = kind != K_NONE && kind != K_DEL;
+  bool is_make = live && (b.ops.action[g] & 1) == 0;
+  bool want_ins = kind == K_LIST_INS;
+  uint32_t pos = carry_prefix(b.cs_ins, want_ins ? 1u : 0u, s_red);
+  uint32_t idx = carry_prefix(b.cs_make, is_make ? 1u : 0u, s_red) + 1;  // 0 is _root
+  if (want_ins) b.ins_row[pos] = g;
+  if (in_range) object_table_entry(b, ir, g, is_make, idx);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint32_t* is_make_ex /* may be b.obj_index itself */, PatchIR ir) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  uint8_t kind = b.kind[g];
+  bool is_make = kind != K_DEL && kind != K_NONE && (b.ops.action[g] & 1) == 0;
+  object_table_entry(b, ir, g, is_make, is_make_ex[g] + 1);  // 0 is _root
 }
 
 __device__ __forceinline__ uint32_t obj_index_of(const MergeBufs& b, uint32_t make_row) { return make_row == NONE32 ? 0 : b.obj_index[make_row]; }
@@ -376,9 +423,10 @@ __global__ __launch_bounds__(BLOCK) void k_list_keys(MergeBufs b, uint64_t* __re
   vals[i] = g;
 }
 
-// after the sort: sibling links, first children, start of the chained document order
+// after the sort (radix path, taken when some element has more children than the in-place ordering handles): sibling links
+// and first children
 __global__ __launch_bounds__(BLOCK) void k_list_link(MergeBufs b, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
-                                                     ListKeyBits kb, uint32_t* __restrict__ start_node) {
+                                                     ListKeyBits kb) {
   uint32_t j = gtid();
   if (j >= n) return;
   int sh = kb.b_ctr + kb.b_actor;
@@ -391,17 +439,16 @@ __global__ __launch_bounds__(BLOCK) void k_list_link(MergeBufs b, const uint64_t
     uint32_t parent = (uint32_t)(pk & ((1ull << kb.b_row) - 1));
     b.first_child[is_head ? b.n_ops + parent : parent] = v;
   }
-  // head children of successive list objects are chained so that one ranking pass orders every list at once
-  b.next_sib[v] = (!last || (is_head && j + 1 < n)) ? vals[j + 1] : NONE32;
-  if (is_head && (j == 0 || (keys[j - 1] >> (sh + kb.b_row)) == 0)) *start_node = v;
+  b.next_sib[v] = last ? NONE32 : vals[j + 1];
 }
 
-// ---- sibling grouping by counting sort (the common case) ------------------------------------------------------
-// Nearly every element has at most one child (typing runs), so a comparison-free grouping by parent beats a
-// 48-bit radix sort: count children per parent, prefix-sum, scatter, then order the few multi-child groups by
-// descending op id in place. Parent index space: element parents are rows [0, N), "head of object o" is N + make row
-// of o, so head children of successive objects end up contiguous at the tail (they are chained for the ranking).
-// A group larger than SEG_SORT_MAX falls back to the radix path (flag in Counts.pad).
+// ---- sibling ordering in place (the common case) -------------------------------------------------------------
+// The RGA order of a list is the pre-order of its insertion forest with siblings in DESCENDING op id. Nearly every element
+// has at most one child (typing), so no sort is run: every insert row pushes itself onto an unordered list of its parent
+// (one atomic exchange), then walks that list once to find its next sibling (the greatest id below its own) and whether it
+// is the first child. O(k) per node for a parent with k children; beyond SEG_SORT_MAX children the walk is abandoned
+// (Counts.pad) and the host redoes the ordering with one radix sort of (parent | ~id) keys.
+// Parent slot space: element parents are rows [0, N), "head of list object o" is N + make row of o.
 constexpr uint32_t SEG_SORT_MAX = 256;
 
 __device__ __forceinline__ uint32_t parent_slot(const MergeBufs& b, uint32_t g) {
@@ -409,96 +456,99 @@ __device__ __forceinline__ uint32_t parent_slot(const MergeBufs& b, uint32_t g) 
   return ref == NONE32 ? b.n_ops + b.obj_row[g] : ref;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_child_count(MergeBufs b, uint32_t n, uint32_t* __restrict__ cnt) {
+__global__ __launch_bounds__(BLOCK) void k_child_push(MergeBufs b) {
   uint32_t i = gtid();
-  if (i < n) atomicAdd(&cnt[parent_slot(b, b.ins_row[i])], 1u);
+  if (i >= b.counts->n_list_ins) return;
+  uint32_t v = b.ins_row[i];
+  b.child_next[v] = atomicExch(&b.child_head[parent_slot(b, v)], v);
 }
-
-__global__ __launch_bounds__(BLOCK) void k_child_scatter(MergeBufs b, uint32_t n, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-                                                         uint32_t* __restrict__ sorted) {
-  uint32_t i = gtid();
-  if (i >= n) return;
-  uint32_t g = b.ins_row[i], ps = parent_slot(b, g);
-  uint32_t k = atomicSub(&cnt[ps], 1u) - 1;  // any order inside the group: it is sorted next
-  sorted[off[ps] + k] = g;
-}
-
-// one lane per node: its position inside its sibling group = number of siblings with a greater op id
-// (descending order; op ids are unique). O(k) per node, all nodes of a group in parallel.
-__global__ __launch_bounds__(BLOCK) void k_child_group_sort(MergeBufs b, uint32_t n, const uint32_t* __restrict__ off, const uint32_t* __restrict__ grouped,
-                                                            uint32_t* __restrict__ sorted) {
-  uint32_t j = gtid();
-  if (j >= n) return;
-  uint32_t v = grouped[j];
-  uint32_t ps = parent_slot(b, v);
-  uint32_t lo = off[ps], hi = off[ps + 1];
-  if (hi - lo == 1) { sorted[j] = v; return; }
-  if (hi - lo > SEG_SORT_MAX) { b.counts->pad = 1; sorted[j] = v; return; }
-  const OpCols& o = b.ops;
-  unsigned long long kv = pack_id(o.id_ctr[v], o.id_actor[v]);
-  uint32_t rank = 0;
-  for (uint32_t a = lo; a < hi; a++) {
-    uint32_t u = grouped[a];
-    rank += pack_id(o.id_ctr[u], o.id_actor[u]) > kv ? 1u : 0u;
-  }
-  sorted[lo + rank] = v;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_child_link(MergeBufs b, uint32_t n, const uint32_t* __restrict__ off, const uint32_t* __restrict__ sorted) {
-  uint32_t j = gtid();
-  if (j >= n) return;
-  uint32_t v = sorted[j], ps = parent_slot(b, v);
-  bool is_head = ps >= b.n_ops;
-  if (j == off[ps]) b.first_child[ps] = v;
-  bool last = j + 1 == off[ps + 1];
-  // head children of successive list objects are chained so that one ranking pass orders every list at once
-  b.next_sib[v] = (!last || (is_head && j + 1 < n)) ? sorted[j + 1] : NONE32;
-}
-
-// Euler tour of the insertion forest over typing runs (below): enter(run k) = 2k, leave(run k) = 2k+1; END = 2 x runs.
-// Each list entry is one 64-bit word (successor in the low half, weight-to-end in the high half) so a pointer-jumping
-// round is one coalesced 8-byte read, one random 8-byte read and one coalesced 8-byte write per entry.
-__device__ __forceinline__ unsigned long long euler_pack(uint32_t succ, uint32_t dist) { return (unsigned long long)dist << 32 | succ; }
 
 // Typing runs. Most elements of a text have exactly one child, inserted right after them (the next character typed):
-// then enter(v) -> enter(child) and leave(child) -> leave(v) are forced links, and a maximal run of such elements can
-// enter the tour as ONE pair of entries whose enter edge weighs the run's length. Runs are consecutive in the insert
-// list (ins_row), so a run is [heads[k], heads[k+1]) there. The tour shrinks from 2 x elements to 2 x runs entries
-// (x100 for typical typing), and the pointer-jumping rounds with it.
-__global__ __launch_bounds__(BLOCK) void k_run_flags(MergeBufs b, uint32_t n, uint32_t* __restrict__ is_head) {
+// then enter(v) -> enter(child) and leave(child) -> leave(v) are forced links of the Euler tour, and a maximal run of such
+// elements enters the tour as ONE pair of entries whose enter edge weighs the run's length. Runs are consecutive in the
+// insert list (ins_row), so run k is [heads[k], heads[k+1]) there. The tour shrinks from 2 x elements to 2 x runs entries
+// (x100 for typical typing) and the list ranking with it.
+// FROM_LINKS: first_child / next_sib were produced by the radix path; only the run flags are computed here.
+template <bool FROM_LINKS>
+__global__ __launch_bounds__(BLOCK) void k_child_order(MergeBufs b, uint32_t* __restrict__ is_head) {
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  const uint32_t ni = b.counts->n_list_ins;
+  if (blockIdx.x * BLOCK >= ni) return;  // (whole workgroup)
   uint32_t i = gtid();
-  if (i > n) return;
-  uint32_t head = i < n ? 1u : 0u;
-  if (i > 0 && i < n) {
-    uint32_t v = b.ins_row[i], prev = b.ins_row[i - 1];
-    if (b.ref_row[v] == prev && b.first_child[prev] == v && b.next_sib[v] == NONE32) head = 0;  // v is the only child of its predecessor
+  uint32_t head = 0;
+  if (i < ni) {
+    const OpCols& o = b.ops;
+    uint32_t v = b.ins_row[i], ps = parent_slot(b, v);
+    bool first, none_after;
+    if (FROM_LINKS) {
+      first = b.first_child[ps] == v;
+      none_after = b.next_sib[v] == NONE32;
+    } else {
+      unsigned long long kv = pack_id(o.id_ctr[v], o.id_actor[v]), best_id = 0;
+      uint32_t greater = 0, best = NONE32, steps = 0;
+      bool abandoned = false;
+      for (uint32_t u = b.child_head[ps]; u != NONE32; u = b.child_next[u]) {
+        if (++steps > SEG_SORT_MAX) { abandoned = true; break; }
+        if (u == v) continue;
+        unsigned long long ku = pack_id(o.id_ctr[u], o.id_actor[u]);
+        if (ku > kv) greater++;
+        else if (best == NONE32 || ku > best_id) { best = u; best_id = ku; }
+      }
+      if (abandoned) {  // consistent placeholder links; the host reruns the ordering through the radix path
+        b.counts->pad = 1;
+        b.next_sib[v] = NONE32;
+        first = false;
+        none_after = false;
+      } else {
+        b.next_sib[v] = best;
+        if (greater == 0) b.first_child[ps] = v;
+        first = greater == 0;
+        none_after = best == NONE32;
+      }
+    }
+    // v continues the run of its predecessor in the insert list iff it is that element's only child
+    head = (i > 0 && ps == b.ins_row[i - 1] && first && none_after) ? 0u : 1u;
+    is_head[i] = head;
   }
-  is_head[i] = head;
+  uint32_t t = carry_publish(b.cs_runs, head, s_red);
+  if (threadIdx.x == 0 && t) atomicAdd(&b.counts->n_runs, t);
 }
 
-// heads[k] = first insert-list index of run k (heads[H] = n); row_run[] = run of a row, kept for run heads and tails
-// only (the rows other runs refer to: a first child and a next sibling are always heads, a parent is always a tail)
-__global__ __launch_bounds__(BLOCK) void k_run_heads(MergeBufs b, uint32_t n, const uint32_t* __restrict__ is_head, const uint32_t* __restrict__ head_ex,
+// heads[k] = first insert-list index of run k (heads[H] = n); head_ex[i] = runs that start before i; row_run[] = run of a
+// row, kept for run heads and tails only (the rows other runs refer to: a first child and a next sibling are always heads,
+// a parent is always a tail)
+__global__ __launch_bounds__(BLOCK) void k_run_heads(MergeBufs b, const uint32_t* __restrict__ is_head, uint32_t* __restrict__ head_ex,
                                                      uint32_t* __restrict__ heads, uint32_t* __restrict__ row_run) {
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  const uint32_t n = b.counts->n_list_ins;
+  if (blockIdx.x * BLOCK >= n) return;
   uint32_t i = gtid();
+  uint32_t flag = i < n ? is_head[i] : 0;
+  uint32_t k = carry_prefix(b.cs_runs, flag, s_red);
   if (i >= n) return;
-  if (is_head[i]) {
-    uint32_t k = head_ex[i];
+  head_ex[i] = k;
+  if (flag) {
     heads[k] = i;
     row_run[b.ins_row[i]] = k;
     if (i > 0) row_run[b.ins_row[i - 1]] = k - 1;
   }
   if (i + 1 == n) {
-    uint32_t H = head_ex[i] + is_head[i];
+    uint32_t H = k + flag;
     heads[H] = n;
     row_run[b.ins_row[i]] = H - 1;
   }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_euler_init_runs(MergeBufs b, const uint32_t* __restrict__ n_runs, const uint32_t* __restrict__ heads,
-                                                           const uint32_t* __restrict__ row_run, unsigned long long* __restrict__ el) {
+// Euler tour of the insertion forest over typing runs: enter(run k) = 2k, leave(run k) = 2k+1; END = 2 x runs. Every list
+// object is its own tree; all of them are ranked in one pass (each tour ends at END) and the objects are laid out one after
+// another afterwards (k_obj_n + prefix sum). One 64-bit word per entry (successor in the low half, weight-to-end in the
+// high half): a pointer-jumping round is one 8-byte read, one dependent 8-byte read and one 8-byte write per entry.
+__device__ __forceinline__ unsigned long long euler_pack(uint32_t succ, uint32_t dist) { return (unsigned long long)dist << 32 | succ; }
+
+__global__ __launch_bounds__(BLOCK) void k_euler_init_runs(MergeBufs b, const uint32_t* __restrict__ heads, const uint32_t* __restrict__ row_run,
+                                                           unsigned long long* __restrict__ el) {
   uint32_t k = gtid();
-  uint32_t H = *n_runs, END = 2 * H;
+  uint32_t H = b.counts->n_runs, END = 2 * H;
   if (k == 0) el[END] = euler_pack(END, 0);
   if (k >= H) return;
   uint32_t i0 = heads[k], i1 = heads[k + 1];
@@ -508,12 +558,51 @@ __global__ __launch_bounds__(BLOCK) void k_euler_init_runs(MergeBufs b, const ui
   el[2 * (size_t)k + 1] = euler_pack(ns != NONE32 ? 2 * row_run[ns] : (ref != NONE32 ? 2 * row_run[ref] + 1 : END), 0);
 }
 
-// one pointer-jumping round (Wyllie): dist'[x] = dist[x] + dist[succ[x]], succ'[x] = succ[succ[x]]. The launch covers
-// the worst case (every element its own run); lanes beyond the measured tour leave at once.
-__global__ __launch_bounds__(BLOCK) void k_euler_jump(const uint32_t* __restrict__ n_runs, const unsigned long long* __restrict__ in,
-                                                      unsigned long long* __restrict__ out) {
+// List ranking (Wyllie pointer jumping: dist'[x] = dist[x] + dist[succ[x]], succ'[x] = succ[succ[x]]) of a tour that fits
+// the LDS of ONE compute unit -- 16 K entries = 8 K typing runs, which covers the headline 1 M-op text (~5 k runs): one
+// launch of one 1024-thread workgroup, log2(entries) rounds in place (every lane keeps its 16 entries in registers across
+// the barrier), instead of log2(entries) launches over an array that small. Longer tours: k_euler_jump rounds in HBM.
+constexpr uint32_t EULER_LDS_ENTRIES = 16384;  // x 8 B = 128 KiB of the CU's 160 KiB
+constexpr uint32_t EULER_LDS_THREADS = 1024;
+__global__ __launch_bounds__(EULER_LDS_THREADS) void k_euler_rank_lds(Counts* __restrict__ counts, unsigned long long* __restrict__ el) {
+  __shared__ unsigned long long L[EULER_LDS_ENTRIES];
+  const uint32_t H = counts->n_runs, END = 2 * H, E = END + 1;
+  if (H == 0 || E > EULER_LDS_ENTRIES) return;
+  const uint32_t t = threadIdx.x;
+  constexpr uint32_t PER = EULER_LDS_ENTRIES / EULER_LDS_THREADS;
+  for (uint32_t x = t; x < E; x += EULER_LDS_THREADS) L[x] = el[x];
+  __syncthreads();
+  int rounds = 1;
+  while ((E >> rounds) != 0) rounds++;
+  for (int r = 0; r < rounds; r++) {
+    unsigned long long nv[PER];
+    for (uint32_t j = 0; j < PER; j++) {
+      uint32_t x = t + j * EULER_LDS_THREADS;
+      if (x < END) {
+        unsigned long long e = L[x];
+        uint32_t s = (uint32_t)e;
+        if (s != END) {
+          unsigned long long f = L[s];
+          e = euler_pack((uint32_t)f, (uint32_t)(e >> 32) + (uint32_t)(f >> 32));
+        }
+        nv[j] = e;
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < PER; j++) {
+      uint32_t x = t + j * EULER_LDS_THREADS;
+      if (x < END) L[x] = nv[j];
+    }
+    __syncthreads();
+  }
+  for (uint32_t x = t; x < END; x += EULER_LDS_THREADS) el[x] = L[x];
+  if (t == 0) counts->euler_done = 1;
+}
+
+// one pointer-jumping round over a tour in HBM (tours beyond the LDS kernel)
+__global__ __launch_bounds__(BLOCK) void k_euler_jump(uint32_t n_runs, const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out) {
   uint32_t x = gtid();
-  uint32_t END = 2 * *n_runs;
+  uint32_t END = 2 * n_runs;
   if (x > END) return;  // (x == END is the end marker itself)
   unsigned long long e = in[x];
   uint32_t s = (uint32_t)e;
@@ -524,29 +613,56 @@ __global__ __launch_bounds__(BLOCK) void k_euler_jump(const uint32_t* __restrict
   out[x] = e;
 }
 
+// elements per list object = weight of the tour from its first head child to the end of its tree; entry n_obj is 0 (prefix sum)
+__global__ __launch_bounds__(BLOCK) void k_obj_n(MergeBufs b, PatchIR ir, uint32_t n_obj, const uint32_t* __restrict__ row_run,
+                                                 const unsigned long long* __restrict__ el) {
+  uint32_t oi = gtid();
+  if (oi > n_obj) return;
+  uint32_t c = 0;
+  if (oi > 0 && oi < n_obj) {
+    uint32_t fc = b.first_child[b.n_ops + ir.obj_make_row[oi]];
+    if (fc != NONE32) c = (uint32_t)(el[2 * (size_t)row_run[fc]] >> 32);
+  }
+  b.obj_n[oi] = c;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, const uint32_t* __restrict__ is_head, const uint32_t* __restrict__ head_ex,
                                                       const uint32_t* __restrict__ heads, const unsigned long long* __restrict__ el) {
   uint32_t i = gtid();
   if (i >= n) return;
   uint32_t k = head_ex[i] + is_head[i] - 1;  // i = 0 is always a head
-  uint32_t d = (uint32_t)(el[2 * (size_t)k] >> 32);  // elements from the run's first one to the end of the tour, inclusive
+  uint32_t d = (uint32_t)(el[2 * (size_t)k] >> 32);  // elements from the run's first one to the end of its object's tour, inclusive
   uint32_t within = i - heads[k];
-  if (d == 0 || d > n || within >= d) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
-  b.order[n - d + within] = b.ins_row[i];
+  uint32_t v = b.ins_row[i], oi = obj_index_of(b, b.obj_row[v]);
+  uint32_t n_o = b.obj_n[oi];
+  uint32_t pos = b.obj_first_pos[oi] + n_o - d + within;
+  if (d == 0 || d > n_o || within >= d || pos >= n) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
+  b.order[pos] = v;
 }
 
-// per position: visibility and value counts to be scanned; first position of each object
-__global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n, uint32_t* __restrict__ vis, uint32_t* __restrict__ cnt) {
+// per list position: visibility and edit counts, scanned by k_list_scan through the carried sums published here
+__global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n) {
+  __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t p = gtid();
-  if (p >= n) return;
-  uint32_t v = b.order[p];
-  if (v == NONE32) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); vis[p] = cnt[p] = 0; return; }
-  uint32_t c = b.val_cnt[v];
-  vis[p] = c ? 1 : 0;
-  cnt[p] = c;
-  uint32_t o = b.obj_row[v];
-  uint32_t prev = p ? b.order[p - 1] : NONE32;
-  if (p == 0 || prev == NONE32 || b.obj_row[prev] != o) b.obj_first_pos[obj_index_of(b, o)] = p;
+  uint32_t c = 0;
+  if (p < n) {
+    uint32_t v = b.order[p];
+    if (v == NONE32) atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM);
+    else c = b.val_cnt[v];
+    b.list_vis[p] = c ? 1 : 0;
+    b.list_cnt[p] = c;
+  }
+  carry_publish(b.cs_vis, c ? 1u : 0u, s_red);
+  carry_publish(b.cs_cnt, c, s_red);
+}
+__global__ __launch_bounds__(BLOCK) void k_list_scan(MergeBufs b, uint32_t n, uint32_t* __restrict__ vis_ex, uint32_t* __restrict__ cnt_ex) {
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  uint32_t p = gtid();
+  uint32_t vis = p < n ? b.list_vis[p] : 0, c = p < n ? b.list_cnt[p] : 0;
+  uint32_t ve = carry_prefix(b.cs_vis, vis, s_red);
+  uint32_t ce = carry_prefix(b.cs_cnt, c, s_red);
+  if (p < n) { vis_ex[p] = ve; cnt_ex[p] = ce; }
+  if (p + 1 == n) b.counts->n_edits = ce + c;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_upd_keys(MergeBufs b, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n) {
@@ -566,7 +682,6 @@ __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, c
   uint32_t v = b.order[p];
   if (v == NONE32) return;
   uint32_t c = b.val_cnt[v];
-  if (p + 1 == n) b.counts->n_edits = cnt_ex[p] + c;
   if (!c) return;
   uint32_t oi = obj_index_of(b, b.obj_row[v]);
   uint32_t index = vis_ex[p] - vis_ex[b.obj_first_pos[oi]];
@@ -807,125 +922,148 @@ __global__ __launch_bounds__(BLOCK) void k_doc_scatter(MergeBufs b, const uint32
 // ---------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
 
-void merge_phase1(MergeBufs& b, Counts* h_counts, hipStream_t st) {
-  uint32_t N = b.n_ops;
-  // (b.counts was cleared before the decode kernels, whose validity flags it already holds)
-  (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, st);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
-  if (N) {
-    AM355_LAUNCH_INDEPENDENT(k_resolve, grid_for(N), dim3(BLOCK), st, b);
-    hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
-    // insert rows -> dense list positions; make rows -> dense object indexes (is-make flags become their exclusive prefix in place;
-    // k_object_table recomputes the flag)
-    exclusive_scan2_u32(b.scan_b, b.scan_a, &b.counts->n_list_ins, b.obj_index, b.obj_index, &b.counts->n_objects, N, b.scan_ws, st);
-    AM355_LAUNCH_INDEPENDENT(k_ins_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_b, (const uint32_t*)b.scan_a);
-  }
-  (void)hipMemcpyAsync(h_counts, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
+size_t merge_counts_bytes(uint32_t n_ops) {
+  size_t groups = ((((size_t)n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2;
+  return ((sizeof(Counts) + 5 * 4 * groups) + 255) & ~(size_t)255;
 }
 
-void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool force_radix) {
+void merge_bind_counts(MergeBufs& b, void* block) {
+  size_t groups = ((((size_t)b.n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2;
+  b.counts = (Counts*)block;
+  b.counts_bytes = merge_counts_bytes(b.n_ops);
+  uint32_t* g = (uint32_t*)((uint8_t*)block + sizeof(Counts));
+  b.cs_ins.group_sum = g;
+  b.cs_make.group_sum = g + groups;
+  b.cs_runs.group_sum = g + 2 * groups;   // runs | vis | cnt are contiguous: cleared together when the list ordering is redone
+  b.cs_vis.group_sum = g + 3 * groups;
+  b.cs_cnt.group_sum = g + 4 * groups;
+}
+
+void merge_prepare(MergeBufs& b, hipStream_t aux) {
   uint32_t N = b.n_ops;
-  if (!force_radix) {  // (a radix rerun only redoes the list ordering; objects and map values are already in place)
-  // ---- objects: dense index per make row (0 = _root) ----
-  const uint32_t* is_make_ex = b.obj_index;  // scanned in phase 1
-  if (N) {
-    AM355_LAUNCH_INDEPENDENT(k_object_table, grid_for(N), dim3(BLOCK), st, b, is_make_ex, ir);
+  (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, aux);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
+  if (!N) return;
+  (void)hipMemsetAsync(b.first_child, 0xff, sizeof(uint32_t) * (2 * (size_t)N + 1), aux);
+  (void)hipMemsetAsync(b.child_head, 0xff, sizeof(uint32_t) * (2 * (size_t)N + 1), aux);
+  (void)hipMemsetAsync(b.order, 0xff, sizeof(uint32_t) * (size_t)N, aux);
+}
+
+// map emissions: LSD over (trigger id | key length | key chunks last..first | object)
+static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hipStream_t st) {
+  uint32_t ne = hc->n_map_emit;
+  if (!ne) return;
+  uint32_t* perm_a = b.val_a;
+  uint32_t* perm_b = b.val_b;
+  int cur = 0;
+  auto pass = [&](int mode, uint32_t chunk, int bits, int begin_bit = 0) {
+    uint32_t* pin = cur ? perm_b : perm_a;
+    uint64_t* kin = cur ? b.key_b : b.key_a;
+    AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk, (const uint32_t*)nullptr);
+    int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, begin_bit, bits, b.sort_ws, st)
+                  : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, begin_bit, bits, b.sort_ws, st);
+    cur ^= res;
+  };
+  if (ne <= MAP_SORT_SMALL) {
+    AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(ne), dim3(BLOCK), st, b, ne, (const uint32_t*)nullptr, perm_b);  // (one emission: rank 0)
+    cur = 1;
   } else {
+    AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
+    pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
+    pass(MK_LEN, 0, bits_for(hc->max_key_len));
+    uint32_t chunks = (hc->max_key_len + 7) / 8;
+    for (uint32_t c = chunks; c-- > 0;) {
+      // bytes are packed first-byte-highest: positions past the longest key are zero in every key -- no pass over them
+      uint32_t used = hc->max_key_len - 8 * c < 8 ? hc->max_key_len - 8 * c : 8;
+      pass(MK_CHUNK, c, 64, 64 - 8 * (int)used);
+    }
+    // object index <= number of make rows (0 is _root); a document whose only map is _root needs no object pass at all
+    if (hc->n_objects) pass(MK_OBJECT, 0, bits_for(hc->n_objects));
+  }
+  AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
+}
+
+void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs) {
+  const uint32_t N = b.n_ops;
+  Counts* hc_runs = hc + 1;  // second read-back (pinned host memory with room for two records)
+  if (!N) {
     (void)hipMemsetAsync(ir.obj_make_row, 0xff, sizeof(uint32_t), st);
     (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t), st);
     (void)hipMemsetAsync(ir.obj_map_end, 0, sizeof(uint32_t), st);
     (void)hipMemsetAsync(ir.obj_edit_begin, 0, sizeof(uint32_t), st);
     (void)hipMemsetAsync(ir.obj_edit_end, 0, sizeof(uint32_t), st);
+    (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    return;
   }
+  uint32_t* is_head = b.scan_a;   // [ni]
+  uint32_t* head_ex = b.scan_b;   // [ni]
+  uint32_t* heads = b.run_heads;  // [runs + 1]
+  uint32_t* row_run = b.row_run;  // [N]
+  // ---- per-row resolution, visibility, compaction (b.counts already holds the decode kernels' validity flags) ----
+  hipLaunchKernelGGL(k_resolve, grid_for(N), dim3(BLOCK), 0, st, b);
+  hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
+  hipLaunchKernelGGL(k_compact_rows, grid_for(N), dim3(BLOCK), 0, st, b, ir);
+  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipEventRecord(ev_counts, st);
+  // ---- lists, first half: launched for the worst case (every row an insert) with the real count read on the device, so the
+  //      host does not have to wait for the counters before the device has more work ----
+  AM355_LAUNCH_INDEPENDENT(k_child_push, grid_for(N), dim3(BLOCK), st, b);
+  hipLaunchKernelGGL(k_child_order<false>, grid_for(N), dim3(BLOCK), 0, st, b, is_head);
+  (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipEventRecord(ev_runs, st);
+  hipLaunchKernelGGL(k_run_heads, grid_for(N), dim3(BLOCK), 0, st, b, (const uint32_t*)is_head, head_ex, heads, row_run);
+  AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)heads, (const uint32_t*)row_run, b.euler_a);
+  hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
 
-  // ---- map emissions: LSD over (trigger id | key length | key chunks last..first | object) ----
-  uint32_t ne = hc->n_map_emit;
-  if (ne) {
-    uint32_t* perm_a = b.val_a;
-    uint32_t* perm_b = b.val_b;
-    AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
-    int cur = 0;
-    auto pass = [&](int mode, uint32_t chunk, int bits, int begin_bit = 0) {
-      uint32_t* pin = cur ? perm_b : perm_a;
-      uint64_t* kin = cur ? b.key_b : b.key_a;
-      AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk, (const uint32_t*)nullptr);
-      int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, begin_bit, bits, b.sort_ws, st)
-                    : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, begin_bit, bits, b.sort_ws, st);
-      cur ^= res;
-    };
-    if (ne > 1 && ne <= MAP_SORT_SMALL) {
-      AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(ne), dim3(BLOCK), st, b, ne, (const uint32_t*)nullptr, perm_b);
-      cur = 1;
-    } else if (ne > 1) {
-      pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
-      pass(MK_LEN, 0, bits_for(hc->max_key_len));
-      uint32_t chunks = (hc->max_key_len + 7) / 8;
-      for (uint32_t c = chunks; c-- > 0;) {
-        // bytes are packed first-byte-highest: positions past the longest key are zero in every key -- no pass over them
-        uint32_t used = hc->max_key_len - 8 * c < 8 ? hc->max_key_len - 8 * c : 8;
-        pass(MK_CHUNK, c, 64, 64 - 8 * (int)used);
-      }
-      // object index <= number of make rows (0 is _root); a document whose only map is _root needs no object pass at all
-      if (hc->n_objects) pass(MK_OBJECT, 0, bits_for(hc->n_objects));
-    }
-    AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
-  }
+  (void)hipEventSynchronize(ev_counts);
+  if (hc->flags) { (void)hipStreamSynchronize(st); return; }
+  order_map_emissions(b, ir, hc, st);
 
-  }
-
-  // ---- lists ----
-  uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd;
+  const uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd, n_obj = hc->n_objects + 1;
   if (ni) {
+    (void)hipEventSynchronize(ev_runs);
+    uint32_t H = hc_runs->n_runs;
     ListKeyBits kb{bits_for(N), (int)b.bits_ctr, (int)b.bits_actor};
-    int total_bits = 1 + kb.b_row + kb.b_ctr + kb.b_actor;  // <= 64 verified by the caller
-    (void)hipMemsetAsync(b.first_child, 0xff, sizeof(uint32_t) * 2 * (size_t)N, st);
-    (void)hipMemsetAsync(b.order, 0xff, sizeof(uint32_t) * ni, st);
-    if (!force_radix) {
-      // counting-sort grouping (cnt and off live in the Euler scratch, which is initialised afterwards)
-      uint32_t* cnt = (uint32_t*)b.euler_b;
-      uint32_t* off = cnt + (2 * (size_t)N + 2);
-      uint32_t* grouped = b.val_a;
-      uint32_t* sorted = b.val_b;
-      (void)hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (2 * (size_t)N + 1), st);
-      AM355_LAUNCH_INDEPENDENT(k_child_count, grid_for(ni), dim3(BLOCK), st, b, ni, cnt);
-      exclusive_scan_u32(cnt, off, 2 * N + 1, nullptr, b.scan_ws, st);
-      AM355_LAUNCH_INDEPENDENT(k_child_scatter, grid_for(ni), dim3(BLOCK), st, b, ni, cnt, (const uint32_t*)off, grouped);
-      AM355_LAUNCH_INDEPENDENT(k_child_group_sort, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)off, (const uint32_t*)grouped, sorted);
-      AM355_LAUNCH_INDEPENDENT(k_child_link, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)off, (const uint32_t*)sorted);
-    } else {
-      uint32_t* d_start = &b.counts->n_edits;  // scratch word, rewritten by k_list_edits
+    if (hc_runs->pad) {
+      // some list element has hundreds of children (e.g. everyone inserting at the same spot): order the siblings with one
+      // radix sort of (is_head | parent | ~id) keys and redo the run detection from those links
+      int total_bits = 1 + kb.b_row + kb.b_ctr + kb.b_actor;  // <= 64 verified by the caller
+      (void)hipMemsetAsync(&b.counts->pad, 0, 3 * sizeof(uint32_t), st);  // pad, n_runs, euler_done
+      (void)hipMemsetAsync(b.cs_runs.group_sum, 0, (size_t)((uint8_t*)b.counts + b.counts_bytes - (uint8_t*)b.cs_runs.group_sum), st);
+      (void)hipMemsetAsync(b.first_child, 0xff, sizeof(uint32_t) * (2 * (size_t)N + 1), st);
       AM355_LAUNCH_INDEPENDENT(k_list_keys, grid_for(ni), dim3(BLOCK), st, b, b.key_a, b.val_a, ni, kb);
       int res = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, ni, 0, total_bits, b.sort_ws, st);
-      const uint64_t* sk = res ? b.key_b : b.key_a;
-      const uint32_t* sv = res ? b.val_b : b.val_a;
-      AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, sk, sv, ni, kb, d_start);
+      AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, (const uint64_t*)(res ? b.key_b : b.key_a), (const uint32_t*)(res ? b.val_b : b.val_a), ni, kb);
+      hipLaunchKernelGGL(k_child_order<true>, grid_for(ni), dim3(BLOCK), 0, st, b, is_head);
+      (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+      hipLaunchKernelGGL(k_run_heads, grid_for(ni), dim3(BLOCK), 0, st, b, (const uint32_t*)is_head, head_ex, heads, row_run);
+      AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(ni), dim3(BLOCK), st, b, (const uint32_t*)heads, (const uint32_t*)row_run, b.euler_a);
+      hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
+      (void)hipStreamSynchronize(st);
+      H = hc_runs->n_runs;
     }
-    // typing runs -> contracted Euler tour -> list ranking
-    uint32_t* is_head = b.scan_a;   // [ni + 1]
-    uint32_t* head_ex = b.scan_b;   // [ni + 1]
-    uint32_t* heads = b.val_a;      // [runs + 1]   (the grouping scratch is free again)
-    uint32_t* row_run = b.val_b;    // [N]
-    uint32_t* d_runs = &b.counts->n_edits;  // scratch word until k_list_edits rewrites it
-    AM355_LAUNCH_INDEPENDENT(k_run_flags, grid_for(ni + 1), dim3(BLOCK), st, b, ni, is_head);
-    exclusive_scan_u32(is_head, head_ex, ni + 1, d_runs, b.scan_ws, st);
-    AM355_LAUNCH_INDEPENDENT(k_run_heads, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex, heads, row_run);
-    AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(ni), dim3(BLOCK), st, b, (const uint32_t*)d_runs, (const uint32_t*)heads, (const uint32_t*)row_run,
-                             b.euler_a);
-    int rounds = bits_for(2ull * ni + 1);
-    unsigned long long *e0 = b.euler_a, *e1 = b.euler_b;
-    for (int r = 0; r < rounds; r++) {
-      AM355_LAUNCH_INDEPENDENT(k_euler_jump, grid_for(2 * ni + 1), dim3(BLOCK), st, (const uint32_t*)d_runs, (const unsigned long long*)e0, e1);
-      unsigned long long* t = e0;
-      e0 = e1;
-      e1 = t;
+    // list ranking: done by the LDS kernel when the tour fits, else pointer-jumping rounds over the tour in HBM
+    const unsigned long long* el = b.euler_a;
+    if (2 * (uint64_t)H + 1 > EULER_LDS_ENTRIES) {
+      int rounds = bits_for(2ull * H + 1);
+      unsigned long long *e0 = b.euler_a, *e1 = b.euler_b;
+      for (int r = 0; r < rounds; r++) {
+        AM355_LAUNCH_INDEPENDENT(k_euler_jump, grid_for(2 * H + 1), dim3(BLOCK), st, H, (const unsigned long long*)e0, e1);
+        unsigned long long* t = e0;
+        e0 = e1;
+        e1 = t;
+      }
+      el = e0;
     }
-    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex, (const uint32_t*)heads,
-                             (const unsigned long long*)e0);
-    // visibility / value-count prefix sums over document order
-    uint32_t* vis = b.scan_a;
-    uint32_t* cnt = b.scan_b;
-    AM355_LAUNCH_INDEPENDENT(k_list_counts, grid_for(ni), dim3(BLOCK), st, b, ni, vis, cnt);
-    exclusive_scan2_u32(vis, vis, nullptr, cnt, cnt, nullptr, ni, b.scan_ws, st);
+    // objects laid out one after another: elements per object from the ranked tour, prefix sum
+    AM355_LAUNCH_INDEPENDENT(k_obj_n, grid_for(n_obj + 1), dim3(BLOCK), st, b, ir, n_obj, (const uint32_t*)row_run, el);
+    exclusive_scan_u32(b.obj_n, b.obj_first_pos, n_obj + 1, nullptr, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex, (const uint32_t*)heads, el);
+    // visibility / edit-count prefix sums over document order
+    uint32_t* vis_ex = b.scan_a;
+    uint32_t* cnt_ex = b.scan_b;
+    hipLaunchKernelGGL(k_list_counts, grid_for(ni), dim3(BLOCK), 0, st, b, ni);
+    hipLaunchKernelGGL(k_list_scan, grid_for(ni), dim3(BLOCK), 0, st, b, ni, vis_ex, cnt_ex);
     const uint64_t* uk = b.key_a;
     const uint32_t* uv = b.val_a;
     if (nu) {
@@ -934,7 +1072,7 @@ void merge_phase2(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, bool fo
       uk = r2 ? b.key_b : b.key_a;
       uv = r2 ? b.val_b : b.val_a;
     }
-    AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis, (const uint32_t*)cnt, uk, uv, nu, ir);
+    AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis_ex, (const uint32_t*)cnt_ex, uk, uv, nu, ir);
     AM355_LAUNCH_INDEPENDENT(k_edit_runs, grid_for(N), dim3(BLOCK), st, b, ir);
   }
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);

@@ -3,63 +3,63 @@
 // ranking, LDS histograms. These are HBM-bound integer kernels (no MFMA): each sort pass reads and writes
 // every pair once (12 B in, 12 B out) plus one histogram read of the keys.
 #include "am355_prims.h"
+#include "am355_scan.h"
 
 namespace am355 {
 
 // ---------------------------------------------------------------------------------------------------------
-// exclusive scan (uint32 -> uint32), n up to 2^32-1.  Three launches: per-tile sums, scan of tile sums, apply.
+// exclusive scan (uint32 -> uint32), n up to 2^32-1.
+//   n <= SCAN_SINGLE          one launch: a single workgroup walks the array with a running carry
+//   n <= SCAN_TILE * 1024     two launches: per-tile sums; apply, where every workgroup first sums the (at most 1024) tile sums
+//                             before its own -- cheaper than a third launch for arrays that stream in a few microseconds
+//   larger                    three launches: per-tile sums, scan of the tile sums by one workgroup, apply
+// The workgroup scan is a wave scan (__shfl_up, log2 64 steps in registers) plus one LDS exchange of the four wave totals.
+// (Standalone scans; producers / consumers that can carry the tile sums themselves use am355_scan.h instead.)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;
-
-// block-wide exclusive scan of one value per thread; returns exclusive prefix, *total gets the block sum
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s /* [BLOCK] LDS */, uint32_t* total) {
-  uint32_t t = threadIdx.x;
-  s[t] = v;
-  __syncthreads();
-  for (uint32_t off = 1; off < BLOCK; off <<= 1) {
-    uint32_t add = t >= off ? s[t - off] : 0;
-    __syncthreads();
-    s[t] += add;
-    __syncthreads();
-  }
-  uint32_t incl = s[t];
-  *total = s[BLOCK - 1];
-  __syncthreads();
-  return incl - v;
-}
+constexpr uint32_t SCAN_SINGLE = 4 * SCAN_TILE;
+constexpr uint32_t SCAN_TWO_LAUNCH_TILES = 1024;
 
 __global__ __launch_bounds__(BLOCK) void k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ tile_sums, uint32_t n) {
-  __shared__ uint32_t s[BLOCK];
+  __shared__ uint32_t s[BLOCK / WAVE];
   uint32_t base = blockIdx.x * SCAN_TILE;
   uint32_t sum = 0;
   for (int j = 0; j < SCAN_ITEMS; j++) {
     uint32_t i = base + j * BLOCK + threadIdx.x;
     if (i < n) sum += in[i];
   }
-  uint32_t total;
-  block_exclusive_scan(sum, s, &total);
+  uint32_t total = block_sum_u32(sum, s);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
 // single workgroup: exclusive scan of the tile sums in place; writes grand total
 __global__ __launch_bounds__(BLOCK) void k_scan_sums(uint32_t* __restrict__ sums, uint32_t n_tiles, uint32_t* __restrict__ grand_total) {
-  __shared__ uint32_t s[BLOCK];
+  __shared__ uint32_t s[BLOCK / WAVE];
   uint32_t carry = 0;
   for (uint32_t base = 0; base < n_tiles; base += BLOCK) {
     uint32_t i = base + threadIdx.x;
     uint32_t v = i < n_tiles ? sums[i] : 0;
     uint32_t total;
-    uint32_t ex = block_exclusive_scan(v, s, &total);
+    uint32_t ex = block_exclusive_scan_u32(v, s, &total);
     if (i < n_tiles) sums[i] = carry + ex;
     carry += total;
   }
   if (threadIdx.x == 0 && grand_total) *grand_total = carry;
 }
 
+// PREFIXED: tile_sums[] already holds exclusive prefixes (three-launch form); else the workgroup sums the tile sums before its own
+template <bool PREFIXED>
 __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                      const uint32_t* __restrict__ tile_sums, uint32_t n) {
-  __shared__ uint32_t s[BLOCK];
+                                                      const uint32_t* __restrict__ tile_sums, uint32_t n, uint32_t* __restrict__ grand_total) {
+  __shared__ uint32_t s[BLOCK / WAVE];
+  uint32_t before;
+  if (PREFIXED) before = tile_sums[blockIdx.x];
+  else {
+    uint32_t part = 0;
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += BLOCK) part += tile_sums[k];
+    before = block_sum_u32(part, s);
+  }
   // thread t owns SCAN_ITEMS consecutive elements so the in-thread prefix is sequential
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict
     sum += v[j];
   }
   uint32_t total;
-  uint32_t ex = block_exclusive_scan(sum, s, &total) + tile_sums[blockIdx.x];
+  uint32_t ex = block_exclusive_scan_u32(sum, s, &total) + before;
+  if (!PREFIXED && grand_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand_total = before + total;
   for (int j = 0; j < SCAN_ITEMS; j++) {
     uint32_t i = base + j;
     if (i < n) out[i] = ex;
@@ -78,32 +79,54 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict
   }
 }
 
-// Two independent scans over the same index range in one pass: the replay runs its scans back to back on arrays that take a few
-// microseconds to stream, so a scan costs its three launches -- two arrays per launch halve that.
+// one workgroup, one launch: tiles in sequence with a running carry
+__global__ __launch_bounds__(BLOCK) void k_scan_single(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ grand_total) {
+  __shared__ uint32_t s[BLOCK / WAVE];
+  uint32_t carry = 0;
+  for (uint32_t tile = 0; tile < n; tile += SCAN_TILE) {
+    uint32_t base = tile + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t sum = 0;
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t i = base + j;
+      v[j] = i < n ? in[i] : 0;
+      sum += v[j];
+    }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan_u32(sum, s, &total) + carry;
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t i = base + j;
+      if (i < n) out[i] = ex;
+      ex += v[j];
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0 && grand_total) *grand_total = carry;
+}
+
+// Two independent scans over the same index range in one pass (same launch structure as the single scan).
 __global__ __launch_bounds__(BLOCK) void k_scan2_tile_sums(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b, uint32_t* __restrict__ sums_a,
                                                           uint32_t* __restrict__ sums_b, uint32_t n) {
-  __shared__ uint32_t s[BLOCK];
+  __shared__ uint32_t s[BLOCK / WAVE];
   uint32_t base = blockIdx.x * SCAN_TILE;
   uint32_t sa = 0, sb = 0;
   for (int j = 0; j < SCAN_ITEMS; j++) {
     uint32_t i = base + j * BLOCK + threadIdx.x;
     if (i < n) { sa += in_a[i]; sb += in_b[i]; }
   }
-  uint32_t ta, tb;
-  block_exclusive_scan(sa, s, &ta);
-  block_exclusive_scan(sb, s, &tb);
+  uint32_t ta = block_sum_u32(sa, s), tb = block_sum_u32(sb, s);
   if (threadIdx.x == 0) { sums_a[blockIdx.x] = ta; sums_b[blockIdx.x] = tb; }
 }
 __global__ __launch_bounds__(BLOCK) void k_scan2_sums(uint32_t* __restrict__ sums_a, uint32_t* __restrict__ sums_b, uint32_t n_tiles, uint32_t* __restrict__ total_a,
                                                      uint32_t* __restrict__ total_b) {
-  __shared__ uint32_t s[BLOCK];
+  __shared__ uint32_t s[BLOCK / WAVE];
   uint32_t ca = 0, cb = 0;
   for (uint32_t base = 0; base < n_tiles; base += BLOCK) {
     uint32_t i = base + threadIdx.x;
     uint32_t va = i < n_tiles ? sums_a[i] : 0, vb = i < n_tiles ? sums_b[i] : 0;
     uint32_t ta, tb;
-    uint32_t ea = block_exclusive_scan(va, s, &ta);
-    uint32_t eb = block_exclusive_scan(vb, s, &tb);
+    uint32_t ea = block_exclusive_scan_u32(va, s, &ta);
+    uint32_t eb = block_exclusive_scan_u32(vb, s, &tb);
     if (i < n_tiles) { sums_a[i] = ca + ea; sums_b[i] = cb + eb; }
     ca += ta;
     cb += tb;
@@ -113,9 +136,19 @@ __global__ __launch_bounds__(BLOCK) void k_scan2_sums(uint32_t* __restrict__ sum
     if (total_b) *total_b = cb;
   }
 }
+template <bool PREFIXED>
 __global__ __launch_bounds__(BLOCK) void k_scan2_apply(const uint32_t* __restrict__ in_a, uint32_t* __restrict__ out_a, const uint32_t* __restrict__ in_b,
-                                                      uint32_t* __restrict__ out_b, const uint32_t* __restrict__ sums_a, const uint32_t* __restrict__ sums_b, uint32_t n) {
-  __shared__ uint32_t s[BLOCK];
+                                                      uint32_t* __restrict__ out_b, const uint32_t* __restrict__ sums_a, const uint32_t* __restrict__ sums_b, uint32_t n,
+                                                      uint32_t* __restrict__ total_a, uint32_t* __restrict__ total_b) {
+  __shared__ uint32_t s[BLOCK / WAVE];
+  uint32_t before_a, before_b;
+  if (PREFIXED) { before_a = sums_a[blockIdx.x]; before_b = sums_b[blockIdx.x]; }
+  else {
+    uint32_t pa = 0, pb = 0;
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += BLOCK) { pa += sums_a[k]; pb += sums_b[k]; }
+    before_a = block_sum_u32(pa, s);
+    before_b = block_sum_u32(pb, s);
+  }
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   uint32_t va[SCAN_ITEMS], vb[SCAN_ITEMS];
   uint32_t sa = 0, sb = 0;
@@ -127,8 +160,12 @@ __global__ __launch_bounds__(BLOCK) void k_scan2_apply(const uint32_t* __restric
     sb += vb[j];
   }
   uint32_t ta, tb;
-  uint32_t ea = block_exclusive_scan(sa, s, &ta) + sums_a[blockIdx.x];
-  uint32_t eb = block_exclusive_scan(sb, s, &tb) + sums_b[blockIdx.x];
+  uint32_t ea = block_exclusive_scan_u32(sa, s, &ta) + before_a;
+  uint32_t eb = block_exclusive_scan_u32(sb, s, &tb) + before_b;
+  if (!PREFIXED && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (total_a) *total_a = before_a + ta;
+    if (total_b) *total_b = before_b + tb;
+  }
   for (int j = 0; j < SCAN_ITEMS; j++) {
     uint32_t i = base + j;
     if (i < n) { out_a[i] = ea; out_b[i] = eb; }
@@ -148,8 +185,14 @@ void exclusive_scan2_u32(const uint32_t* in_a, uint32_t* out_a, uint32_t* d_tota
   uint32_t* sums_a = (uint32_t*)ws;
   uint32_t* sums_b = sums_a + n_tiles + 1;
   hipLaunchKernelGGL(k_scan2_tile_sums, dim3(n_tiles), dim3(BLOCK), 0, st, in_a, in_b, sums_a, sums_b, n);
+  if (n_tiles <= SCAN_TWO_LAUNCH_TILES) {
+    hipLaunchKernelGGL(k_scan2_apply<false>, dim3(n_tiles), dim3(BLOCK), 0, st, in_a, out_a, in_b, out_b, (const uint32_t*)sums_a, (const uint32_t*)sums_b, n, d_total_a,
+                       d_total_b);
+    return;
+  }
   hipLaunchKernelGGL(k_scan2_sums, dim3(1), dim3(BLOCK), 0, st, sums_a, sums_b, n_tiles, d_total_a, d_total_b);
-  hipLaunchKernelGGL(k_scan2_apply, dim3(n_tiles), dim3(BLOCK), 0, st, in_a, out_a, in_b, out_b, (const uint32_t*)sums_a, (const uint32_t*)sums_b, n);
+  hipLaunchKernelGGL(k_scan2_apply<true>, dim3(n_tiles), dim3(BLOCK), 0, st, in_a, out_a, in_b, out_b, (const uint32_t*)sums_a, (const uint32_t*)sums_b, n,
+                     (uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
 size_t scan_workspace_bytes(uint32_t n) { return 2 * sizeof(uint32_t) * ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 2); }  // (room for a dual scan)
@@ -161,9 +204,17 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
     if (d_total) (void)hipMemsetAsync(d_total, 0, sizeof(uint32_t), st);
     return;
   }
+  if (n <= SCAN_SINGLE) {
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(BLOCK), 0, st, in, out, n, d_total);
+    return;
+  }
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(BLOCK), 0, st, in, sums, n);
+  if (n_tiles <= SCAN_TWO_LAUNCH_TILES) {
+    hipLaunchKernelGGL(k_scan_apply<false>, dim3(n_tiles), dim3(BLOCK), 0, st, in, out, (const uint32_t*)sums, n, d_total);
+    return;
+  }
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, st, sums, n_tiles, d_total);
-  hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(BLOCK), 0, st, in, out, sums, n);
+  hipLaunchKernelGGL(k_scan_apply<true>, dim3(n_tiles), dim3(BLOCK), 0, st, in, out, (const uint32_t*)sums, n, (uint32_t*)nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -79,8 +79,9 @@ def _bind(path):
     L.am355_get_rows.argtypes = [vp] * 15
     L.am355_save.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     L.am355_get_applied.argtypes = [vp, vp, ctypes.POINTER(u32)]
+    L.am355_fetch_ir.argtypes = [vp, vp]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
-              "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied"):
+              "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -140,6 +141,10 @@ class Engine:
     def replay(self):
         """The hot path: decode + schedule + merge + patch IR, device-resident in and out."""
         self._check(self._L.am355_replay(self._h))
+
+    def fetch_ir(self):
+        """Patch IR + envelope from HBM into host memory owned by the context (what the JS host materialises the patch from)."""
+        self._check(self._L.am355_fetch_ir(self._h, None))
 
     def patch_json(self):
         p = ctypes.c_char_p()

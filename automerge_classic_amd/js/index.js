@@ -70,8 +70,11 @@ function isEmptyRefState(backend) {
     (!s.queue || s.queue.length === 0) && !s.binaryDoc
 }
 
-// Returns the JS (reference) handle equivalent to `backend`, hydrating a GPU-built state if necessary
-function toJs(backend) {
+// The JS (reference) handle equivalent to `backend`: a GPU-built state is hydrated once and the handle is cached on it.
+// Read-only reference calls (clone, save, getAllChanges, getChanges, getChangesAdded, getChangeByHash, getMissingDeps,
+// generateSyncMessage) use it WITHOUT freezing anything, as the reference never freezes on those (backend.js:12-14, 93-98,
+// 139-196): `Automerge.load(bytes)` -> `getAllChanges(doc)` -> `Automerge.change(doc)` must keep working.
+function hydrate(backend) {
   isFrozenCheck(backend)
   if (!(backend.state instanceof GpuState)) return backend
   const g = backend.state
@@ -90,9 +93,18 @@ function toJs(backend) {
       g.js = bytes ? ref().load(bytes) : ref().loadChanges(ref().init(), g.changes)
     } else g.js = ref().loadChanges(ref().init(), g.changes)
   }
-  const handle = g.js
-  g.js = null          // the JS handle is single-use (functional API over a mutable state)
-  backend.frozen = true
+  return g.js
+}
+
+// Mutating reference calls (applyChanges, applyLocalChange, loadChanges, receiveSyncMessage) TAKE the JS handle: the
+// reference freezes the handle it is given and returns a new one (backend.js:9-31, util.js:1-10), so the wrapper handle is
+// frozen with it.
+function toJs(backend) {
+  const handle = hydrate(backend)
+  if (backend.state instanceof GpuState) {
+    backend.state.js = null
+    backend.frozen = true
+  }
   return handle
 }
 
@@ -161,7 +173,7 @@ function load(data) {
 function save(backend) {
   isFrozenCheck(backend)
   const g = backend.state
-  if (!JS_ONLY && g instanceof GpuState && !g.js) {
+  if (!JS_ONLY && g instanceof GpuState) {
     if (g.doc) return g.doc   // unchanged loaded document: the bytes it was loaded from (new.js:2034)
     try {
       if (g.generation !== generation) { gpuReplay(g.changes); g.generation = generation }
@@ -170,7 +182,7 @@ function save(backend) {
       if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
     }
   }
-  return ref().save(toJs(backend))
+  return ref().save(hydrate(backend))
 }
 
 // History queries on a state built by loadChanges: the engine knows which changes were applied and in what order, and the
@@ -178,7 +190,7 @@ function save(backend) {
 // go to the reference path.)
 function gpuHistory(backend) {
   const g = backend.state
-  return !JS_ONLY && g instanceof GpuState && !g.js && g.changes && g.applied && g.pending === 0 ? g : null
+  return !JS_ONLY && g instanceof GpuState && g.changes && g.applied && g.pending === 0 ? g : null
 }
 function hashIndex(g) {
   if (!g.byHash) {
@@ -191,42 +203,54 @@ function getAllChanges(backend) {   // new.js:1924-1927: BackendDoc.changes in a
   isFrozenCheck(backend)
   const g = gpuHistory(backend)
   if (g) return Array.from(g.applied, i => g.changes[i])
-  return ref().getAllChanges(toJs(backend))
+  return ref().getAllChanges(hydrate(backend))
 }
 function getChanges(backend, haveDeps) {
   isFrozenCheck(backend)
   const g = gpuHistory(backend)
   if (g && Array.isArray(haveDeps) && haveDeps.length === 0) return Array.from(g.applied, i => g.changes[i])
-  return ref().getChanges(toJs(backend), haveDeps)
+  return ref().getChanges(hydrate(backend), haveDeps)
 }
 function getChangeByHash(backend, hash) {   // new.js:1999-2002
   isFrozenCheck(backend)
   const g = gpuHistory(backend)
   if (g) { const i = hashIndex(g).get(hash); return i === undefined ? undefined : g.changes[i] }
-  return ref().getChangeByHash(toJs(backend), hash)
+  return ref().getChangeByHash(hydrate(backend), hash)
 }
 function getMissingDeps(backend, heads = []) {   // new.js:2014-2028 with an empty queue: the given heads we do not have
   isFrozenCheck(backend)
   const g = gpuHistory(backend)
   if (g) { const idx = hashIndex(g); return Array.from(new Set(heads)).filter(h => !idx.has(h)).sort() }
-  return ref().getMissingDeps(toJs(backend), heads)
+  return ref().getMissingDeps(hydrate(backend), heads)
 }
 
 function free(backend) {
   if (backend.state instanceof GpuState) { backend.state = null; backend.frozen = true } else ref().free(backend)
 }
 
+// backend/sync.js:420-473: the handle is only replaced (and the old one frozen) when the message carried changes; a message
+// without changes returns the handle it was given, which the frontend keeps using (src/automerge.js receiveSyncMessage)
+function receiveSyncMessage(backend, syncState, msg) {
+  const handle = hydrate(backend)
+  const result = ref().receiveSyncMessage(handle, syncState, msg)
+  if (backend.state instanceof GpuState) {
+    if (result[0] === handle) result[0] = backend
+    else { backend.state.js = null; backend.frozen = true }
+  }
+  return result
+}
+
 const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...args)
 
 module.exports = {
   init, load, loadChanges, getPatch, getHeads, free, save, getAllChanges, getChanges, getChangeByHash, getMissingDeps,
-  clone: delegate1('clone'),
+  clone: backend => ref().clone(hydrate(backend)),
   applyChanges: delegate1('applyChanges'),
   applyLocalChange: delegate1('applyLocalChange'),
-  getChangesAdded: (b1, b2) => ref().getChangesAdded(toJs(b1), toJs(b2)),
+  getChangesAdded: (b1, b2) => ref().getChangesAdded(hydrate(b1), hydrate(b2)),
   // sync protocol: unchanged reference code operating on JS handles (backend/sync.js:20 binds the JS backend)
-  generateSyncMessage: (backend, syncState) => ref().generateSyncMessage(toJs(backend), syncState),
-  receiveSyncMessage: (backend, syncState, msg) => ref().receiveSyncMessage(toJs(backend), syncState, msg),
+  generateSyncMessage: (backend, syncState) => ref().generateSyncMessage(hydrate(backend), syncState),
+  receiveSyncMessage,
   encodeSyncMessage: (...a) => ref().encodeSyncMessage(...a),
   decodeSyncMessage: (...a) => ref().decodeSyncMessage(...a),
   encodeSyncState: (...a) => ref().encodeSyncState(...a),

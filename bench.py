@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- bulk change-replay throughput of the MI355X engine (BASELINE.json metric).
+"""bench.py -- bulk change-replay throughput of the MI355X engine (BASELINE.json metric, SURVEY.md §8d).
 
-A "step" is one pass of the hot path (container parse + SHA-256 + column decode -> causal schedule -> op-set
-merge -> RGA order -> whole-document patch IR) over one staged batch of synthetic changes, with the (inflated)
-change bytes already resident in HBM when the timed region starts and the patch IR left in HBM when it ends.
+A "step" is one pass of the hot path over one batch of synthetic changes, timed as SURVEY.md §8(d) defines T_replay:
+from "array of binary changes in HOST memory" to "patch IR + envelope in HOST memory" -- host inflate + staging, H2D,
+container parse + SHA-256 + column decode -> causal schedule -> op-set merge -> RGA order -> whole-document patch IR, D2H.
+`value` = ops / T_replay.  The same line also carries
+  t_device_ops_per_s   the replay alone, inputs already resident in HBM and the IR left in HBM (what round 1 reported as `value`),
+  roofline             whole path: N_ops x A / T_device with A = E + R + P algorithmic bytes per op, plus a
+                       per-kernel table (live HIP-event brackets of the phases; rocprofv3 + PMC figures of the top kernels
+                       from the committed summary of this same command, profiles/r02_kernel_table.json),
+  cpu_baseline         the CPU oracle (plain-C port of the reference's algorithm) on the same workload, 1 thread,
+  workloads            sub-lines for c4_text_multi, c3_map_lww, c2_text_typing, the headline log in shuffled delivery order
+                       (general scheduler, fast_path 0) and c5_doc_mixed (Backend.load), N = 1 only.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4_text_single] [--scale 1.0]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4_text_single] [--scale 1.0] [--no-sublines]
 
-For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU. The headline workload is a
-single Text object, which objectId sharding cannot split ("replicas only"): every rank replays its
-own independent document of the same shape (different seed); value = total ops of all ranks / max time over ranks.
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU: every rank replays its own document of
+the same shape (different seed); value = total ops of all ranks / max time over ranks ("weak"). `--shard` selects the
+objectId-sharded mode instead (one document split over the ranks).
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,7 +39,12 @@ WORKLOADS = {
     # BASELINE config 5: Backend.load of a saved document (~10 M rows at scale 1.0: Text / nested maps / lists)
     "c5_doc_mixed": ("doc", dict()),
 }
+SHAPE = {"c2_text_typing": "one Text object, 1 actor", "c3_map_lww": "root map of 10 k keys, multi-value conflicts",
+         "c4_text_single": "one Text object", "c4_text_multi": "64 Text objects at root keys", "c5_doc_mixed": "256 Text + nested maps + lists"}
 BASE_SEED = {"c2_text_typing": 0x5EED0002, "c3_map_lww": 0x5EED0003, "c4_text_single": 0x5EED0004, "c4_text_multi": 0x5EED0004, "c5_doc_mixed": 0x5EED0005}
+PARITY = ("bit-exact getPatch vs the CPU oracle at this size and vs reference goldens (pytest -m gpu); NOTE the STOCK reference is "
+          "delivery-order dependent on this workload (600-op block-boundary defect, tests/golden/defect_block_boundary.json): "
+          "the answer reproduced is the block-size-patched reference's = the documented RGA rule (DESIGN.md §6)")
 
 
 def make_log(name, scale, seed):
@@ -60,7 +75,9 @@ def cpu_baseline(log, budget_s=12.0):
         reps += 1
     return {"value": log.n_ops / best, "unit": "ops/s", "cores": 1, "kind": "port",
             "sample": f"{log.name}: {log.n_ops} ops, {log.n_changes} changes, best of {reps} runs of oracle loadChanges+getPatch "
-                      f"({time.perf_counter() - t_all:.1f} s of CPU work)"}
+                      f"({time.perf_counter() - t_all:.1f} s of CPU work)",
+            "reference_js_note": "the reference itself (JavaScript, node 12, 1 core) cannot run on the GPU box (no reference tree there); in the build "
+                                 "container it replays this workload at ~25-30 k ops/s (BASELINE.md §2, DESIGN.md §7)"}
 
 
 def cpu_baseline_document(doc_bytes, n_rows, budget_s=12.0):
@@ -82,6 +99,119 @@ def cpu_baseline_document(doc_bytes, n_rows, budget_s=12.0):
                       f"({time.perf_counter() - t_all:.1f} s of CPU work)"}
 
 
+PHASES = ("ms_parse", "ms_host_schedule", "ms_decode", "ms_merge", "ms_order", "ms_hash_stream")
+
+
+class Workload:
+    """One staged input (a change log or a saved document) and the two timed regions over it."""
+
+    def __init__(self, eng, name, scale, seed, shuffled=False):
+        from automerge_classic_amd import loggen
+        self.eng, self.name, self.scale = eng, name, scale
+        self.is_doc = WORKLOADS[name][0] == "doc"
+        if self.is_doc:
+            self.doc_bytes, self.doc_rows = loggen.document_config(scale)
+            self.log = None
+        else:
+            self.log = make_log(name, scale, seed)
+            if shuffled:
+                self.log = self.log.reordered(np.random.default_rng(seed & 0xFFFF).permutation(self.log.n_changes))
+                self.log.name = name + "+shuffled"
+
+    def stage(self):
+        if self.is_doc:
+            self.eng.load_document(self.doc_bytes)
+        else:
+            self.eng.load_changes(self.log)
+
+    def step_replay(self):
+        """T_replay: host buffers -> inflate/staging -> H2D -> replay -> patch IR + envelope in host memory."""
+        self.stage()
+        self.eng.replay()
+        self.eng.fetch_ir()
+
+    def step_device(self):
+        """T_device: the replay alone, staged bytes resident in HBM, IR left in HBM."""
+        self.eng.replay()
+
+    def describe(self, st):
+        if self.is_doc:
+            return (f"{self.name} x{self.scale}: Backend.load of a {len(self.doc_bytes)}-byte saved document, {st.n_ops} op rows, {st.n_actors} actors "
+                    f"({st.raw_bytes} bytes of inflated op columns), {SHAPE[self.name]}")
+        return (f"{self.log.name} x{self.scale}: {st.n_ops} ops, {st.n_changes} changes, {st.n_actors} actors, {st.raw_bytes} encoded bytes, "
+                f"{SHAPE[self.name]}")
+
+
+def timed(fn, steps, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return time.perf_counter() - t0
+
+
+def algorithmic_bytes(st):
+    """A = E + R + P bytes per op: encoded input, one fixed-width op record (53 B here), patch IR."""
+    n = max(int(st.n_ops), 1)
+    E, R, P = st.raw_bytes / n, 53.0, st.ir_bytes / n
+    return {"E_encoded": E, "R_op_record": R, "P_patch_ir": P, "A": E + R + P}
+
+
+def phase_table(phases, st, n_preds):
+    """Live HIP-event brackets (recorded on the engine's stream inside am355_replay) priced against their algorithmic bytes."""
+    n, raw = int(st.n_ops), int(st.raw_bytes)
+    rows = [
+        ("parse + actor intern (k_parse_changes, k_actor_intern, k_actor_check)", phases["ms_parse"], raw + 176 * int(st.n_changes)),
+        ("column decode (k_decode_wave<small|large>)", phases["ms_decode"], raw + 53 * n + 8 * n_preds),
+        ("merge: resolve + emit + compaction (k_resolve, k_emit, scans)", phases["ms_merge"], 53 * n + 8 * n_preds + 28 * n),
+        ("order + patch IR (sibling grouping, list ranking, edits)", phases["ms_order"], 30 * int(st.n_list_elems) + int(st.ir_bytes)),
+        ("SHA-256 + dependency resolution (second stream, overlapped)", phases["ms_hash_stream"], raw),
+    ]
+    out = []
+    for name, ms, b in rows:
+        if ms > 0:
+            gbs = b / (ms * 1e-3) / 1e9
+            out.append({"phase": name, "ms": ms, "algorithmic_bytes": b, "GB_per_s": gbs, "frac_of_hbm_peak": gbs / 8000.0})
+    return out
+
+
+def run_workload(w, steps, warmup, sync, want_rows=True):
+    eng = w.eng
+    for _ in range(warmup):
+        w.step_replay()
+    t_replay = timed(w.step_replay, steps, sync)
+    st = eng.stats()
+    # T_device: staged once, replayed K times
+    w.stage()
+    for _ in range(min(warmup, 3)):
+        w.step_device()
+    parts = {k: 0.0 for k in PHASES}
+
+    def dev():
+        eng.replay()
+        s = eng.stats()
+        for k in parts:
+            parts[k] += getattr(s, k)
+    t_device = timed(dev, steps, sync)
+    st = eng.stats()
+    phases = {k: v / steps for k, v in parts.items()}
+    n_preds = int(eng.rows()["pred_num"].sum()) if want_rows else 0
+    return {"t_replay_s": t_replay, "t_device_s": t_device, "stats": st, "phases": phases, "n_preds": n_preds}
+
+
+def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False):
+    w = Workload(eng, name, scale, seed, shuffled=shuffled)
+    r = run_workload(w, steps, warmup, sync, want_rows=False)
+    st = r["stats"]
+    A = algorithmic_bytes(st)
+    whole = st.n_ops * A["A"] / (r["t_device_s"] / steps) / 1e9
+    return {"workload": w.describe(st), "ops_per_s": st.n_ops * steps / r["t_replay_s"], "ms_per_step": r["t_replay_s"] / steps * 1e3,
+            "t_device_ops_per_s": st.n_ops * steps / r["t_device_s"], "t_device_ms": r["t_device_s"] / steps * 1e3, "fast_path": int(st.fast_path),
+            "phases_ms": r["phases"], "algorithmic_bytes_per_op": A,
+            "roofline_whole_path": {"achieved": whole, "unit": "GB/s", "frac": whole / 8000.0}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +220,8 @@ def main():
     ap.add_argument("--workload", default="c4_text_single", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sublines", action="store_true")
+    ap.add_argument("--shard", action="store_true", help="N > 1: ONE document sharded by objectId over the ranks instead of one document per rank")
     args = ap.parse_args()
 
     import torch
@@ -102,17 +234,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.shard:
+        from automerge_classic_amd import shard
+        return shard.bench_main(args, rank, world, local_rank, dist)
 
-    is_doc = WORKLOADS[args.workload][0] == "doc"
     eng = engine.Engine(local_rank)
-    if is_doc:
-        from automerge_classic_amd import loggen
-        doc_bytes, doc_rows = loggen.document_config(args.scale)
-        log = None
-        eng.load_document(doc_bytes)   # host header parse / checksum / inflate + H2D: outside the timed region (inputs resident in HBM)
-    else:
-        log = make_log(args.workload, args.scale, dist_util.rank_seed(BASE_SEED[args.workload], rank))
-        eng.load_changes(log)   # host inflate + H2D: outside the timed region by contract (inputs resident in HBM)
 
     def barrier():
         torch.cuda.synchronize()
@@ -120,78 +246,76 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    w = Workload(eng, args.workload, args.scale, dist_util.rank_seed(BASE_SEED[args.workload], rank))
     for _ in range(args.warmup):
-        eng.replay()
-    barrier()
-    t0 = time.perf_counter()
-    parts = {"ms_parse": 0.0, "ms_host_schedule": 0.0, "ms_decode": 0.0, "ms_merge": 0.0, "ms_order": 0.0, "ms_hash_stream": 0.0}
-    for _ in range(args.steps):
-        eng.replay()
-        st = eng.stats()
-        for k in parts:
-            parts[k] += getattr(st, k)
-    barrier()
-    elapsed = time.perf_counter() - t0
+        w.step_replay()
+    # ---- the timed region of `value`: K steps of T_replay (host buffers in -> patch IR in host memory) ----
+    elapsed = timed(w.step_replay, args.steps, barrier)
     st = eng.stats()
     elapsed, total_ops = dist_util.aggregate(elapsed, float(st.n_ops) * args.steps, dist, torch.device("cuda", local_rank))
+    # ---- T_device (not `value`): the replay alone, inputs resident in HBM ----
+    w.stage()
+    for _ in range(3):
+        w.step_device()
+    parts = {k: 0.0 for k in PHASES}
+
+    def dev():
+        eng.replay()
+        s = eng.stats()
+        for k in parts:
+            parts[k] += getattr(s, k)
+    t_dev = timed(dev, args.steps, barrier)
+    t_dev, _ = dist_util.aggregate(t_dev, 0.0, dist, torch.device("cuda", local_rank))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    value = total_ops / elapsed
+    st = eng.stats()
     phases = {k: v / args.steps for k, v in parts.items()}
-    # Roofline of the dominant single kernel on the critical path, k_decode_wave: algorithmic bytes
-    # per launch = encoded bytes read once + fixed-width op rows written once (53 B/op + 8 B/pred); duration from HIP
-    # events recorded on the engine's stream around that launch inside am355_replay (ms_decode).
-    rows = eng.rows()
-    n_preds = int(rows["pred_num"].sum())
-    alg_bytes = st.raw_bytes + 53 * st.n_ops + 8 * n_preds
-    achieved = alg_bytes / (phases["ms_decode"] * 1e-3) / 1e9
-    E, R, P = st.raw_bytes / st.n_ops, 53.0, st.ir_bytes / st.n_ops
-    # Backend.save of the replayed state: outside the metric, reported next to it
+    value = total_ops / elapsed
+    t_device_ms = t_dev / args.steps * 1e3
+    n_preds = int(eng.rows()["pred_num"].sum())
+    A = algorithmic_bytes(st)
+    whole = st.n_ops * A["A"] / (t_device_ms * 1e-3) / 1e9  # (N_ops x A / T_device), GB/s
+    roofline = {"bound": "hbm", "achieved": whole, "peak": 8000.0, "unit": "GB/s", "frac": whole / 8000.0, "traffic": None,
+                "kernel": "whole path (SURVEY.md §8d): N_ops x (E + R + P) / T_device", "algorithmic_bytes_per_launch": st.n_ops * A["A"],
+                "launch_ms": t_device_ms, "phases": phase_table(phases, st, n_preds)}
+    table = os.path.join(ROOT, "profiles", "r02_kernel_table.json")
+    if os.path.exists(table) and args.workload == "c4_text_single" and args.scale == 1.0:
+        # rocprofv3 kernel-trace + PMC passes of this same command (committed summary; counters cannot be read in-process):
+        # per kernel: calls per replay, average us, algorithmic bytes, PMC HBM bytes, fraction of the 8 TB/s peak
+        with open(table) as f:
+            t = json.load(f)
+        roofline["kernels"] = t.get("kernels")
+        roofline["traffic"] = t.get("traffic_bytes_per_replay")
+        roofline["kernels_source"] = t.get("source")
     save_info = None
-    if not is_doc:
+    if not w.is_doc:
         eng.save()
         t0 = time.perf_counter()
         saved = eng.save()
-        save_info = {"ms": (time.perf_counter() - t0) * 1e3, "doc_bytes": len(saved),
-                     "note": "row order + column encoders on the GPU (~1.2 ms at 1 M ops); the rest is host DEFLATE of the columns, SHA-256, change metadata"}
-    t0 = time.perf_counter()
-    if is_doc:
-        eng.load_document(doc_bytes)
-    else:
-        eng.load_changes(log)
-    eng.replay()
-    t_host_in = time.perf_counter() - t0
+        save_info = {"ms": (time.perf_counter() - t0) * 1e3, "doc_bytes": len(saved)}
     out = {
         "metric": "CRDT ops/sec applied (bulk replay)", "value": value, "unit": "ops/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"{args.workload} x{args.scale}: {st.n_ops} ops, {st.n_changes} changes, {st.n_actors} actors, "
-                               f"{st.raw_bytes} encoded bytes, one Text object; one document per GPU (replicas only, DESIGN.md §8)",
-                   "parity": "bit-exact getPatch vs oracle and reference goldens (pytest -m gpu)", "fast_path": int(st.fast_path)},
-        "phases_ms": phases,
-        "algorithmic_bytes_per_op": {"E_encoded": E, "R_op_record": R, "P_patch_ir": P, "A": E + R + P},
-        "host_buffers_in_ops_per_s": st.n_ops / t_host_in,
-        "save": save_info,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "kernel": "k_decode_wave<small>", "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": phases["ms_decode"]},
+        "config": {"workload": w.describe(st) + "; one document per GPU",
+                   "timed_region": "T_replay (SURVEY.md §8d): binary changes in host memory -> host inflate/staging -> H2D -> replay -> patch IR + envelope in host memory",
+                   "parity": PARITY, "fast_path": int(st.fast_path)},
+        "t_device_ops_per_s": st.n_ops / (t_device_ms * 1e-3), "t_device_ms": t_device_ms,
+        "phases_ms": phases, "algorithmic_bytes_per_op": A, "save": save_info, "roofline": roofline,
     }
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_decode_wave.json")
-    if os.path.exists(pmc) and args.workload == "c4_text_single" and args.scale == 1.0:
-        # HBM bytes per launch from rocprofv3 PMC passes of this same command (committed summary; counters cannot be read in-process)
-        with open(pmc) as f:
-            out["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
-    if is_doc:
-        out["config"]["workload"] = (f"{args.workload} x{args.scale}: Backend.load of a {len(doc_bytes)}-byte saved document, {st.n_ops} op rows, "
-                                     f"{st.n_actors} actors ({st.raw_bytes} bytes of inflated op columns); one document per GPU")
-        # document load: the column decode is a pipeline of streaming kernels (am355_bigcol.hip), priced as one unit
-        ms = phases["ms_parse"] + phases["ms_decode"]
-        ach = alg_bytes / (ms * 1e-3) / 1e9
-        out["roofline"].update({"kernel": "document column decode (am355_bigcol.hip: index + expand + assemble)", "launch_ms": ms, "achieved": ach,
-                                "frac": ach / 8000.0})
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-        out["cpu_baseline"] = cpu_baseline_document(doc_bytes, int(st.n_ops)) if is_doc else cpu_baseline(log)
+        out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops)) if w.is_doc else cpu_baseline(w.log)
+    if not args.no_sublines and world == 1:
+        subs, k, wu = [], max(5, args.steps // 3), 2
+        for name in ("c4_text_multi", "c3_map_lww", "c2_text_typing"):
+            if name != args.workload:
+                subs.append(subline(eng, name, 1.0, BASE_SEED[name], k, wu, barrier))
+        subs.append(subline(eng, "c4_text_single", 1.0, BASE_SEED["c4_text_single"], k, wu, barrier, shuffled=True))
+        if args.workload != "c5_doc_mixed":
+            subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 3, 1, barrier))
+        out["workloads"] = subs
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

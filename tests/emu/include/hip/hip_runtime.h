@@ -3,7 +3,7 @@
 // A tiny stand-in for <hip/hip_runtime.h> that lets g++ compile the engine's .hip sources into a CPU
 // "emulation" library (tests/emu/libam355_emu.so) so that kernel *logic* can be checked against the oracle in
 // the GPU-less build container (`pytest -m "not gpu"`). Every kernel thread becomes an OS thread of a
-// persistent 256-thread pool; blocks run one after another; __syncthreads()/__ballot()/__shfl() are real
+// persistent 1024-thread pool; blocks run one after another; __syncthreads()/__ballot()/__shfl() are real
 // barriers between those threads; wave size is 64. It is slow and it is not a fallback: the product library
 // (automerge_classic_amd/csrc/libam355.so) is built by hipcc for gfx950 only and fails loudly without a GPU.
 #pragma once
@@ -122,7 +122,7 @@ struct Wave {
 };
 
 struct Runtime {
-  static constexpr unsigned MAXT = 256;
+  static constexpr unsigned MAXT = 1024;
   std::vector<std::thread> workers;
   std::function<void()> body;
   unsigned n_threads = 0;      // threads of the current block

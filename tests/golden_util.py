@@ -19,7 +19,7 @@ def fixture_names():
 
 
 def save_digest_cases():
-    """Length + SHA-256 of the reference's Backend.save on deterministic generated logs (oracle/make_save_golden.py)."""
+    """Length + SHA-256 of the block-size-patched reference's Backend.save on deterministic generated logs (oracle/make_save_golden.py)."""
     with open(os.path.join(GOLDEN_DIR, "save_generated.json")) as f:
         return json.load(f)["cases"]
 
@@ -45,4 +45,13 @@ def load_fixture(name):
     if "doc" in fx:
         fx["doc_bytes"] = base64.b64decode(fx["doc"])
         fx["expected_load"] = fx["load_patch"] if fx.get("stock_equals_bigblock", True) else fx["load_patch_bigblock"]
+    return fx
+
+
+def defect_fixture():
+    """tests/golden/defect_block_boundary.json (oracle/make_defect_fixture.py): inputs on which the STOCK reference's
+    block-boundary defect fires -- its answer depends on delivery order -- next to the block-size-patched reference's."""
+    fx = load_fixture("defect_block_boundary")
+    changes = [base64.b64decode(c) for c in fx["changes"]]
+    fx["log_reversed"] = ChangeLog.from_changes([changes[i] for i in fx["order_reversed"]], name="defect_block_boundary+reversed")
     return fx

@@ -40,6 +40,14 @@ def test_golden_reference_patches(eng, name):
     assert eng.stats().fast_path == (0 if general else 1)
 
 
+def test_defect_fixture_both_delivery_orders(eng):
+    """Inputs on which the stock reference diverges with delivery order: the engine gives the block-size-patched
+    reference's document for both orders."""
+    fx = golden_util.defect_fixture()
+    assert emu_patch(eng, fx["log"]) == fx["patch_bigblock"] != fx["patch"]
+    assert emu_patch(eng, fx["log_reversed"]) == fx["patch_bigblock_reversed"]
+
+
 @pytest.mark.parametrize("name", golden_util.doc_fixture_names())
 def test_document_load_matches_reference(eng, name):
     """Backend.load(bytes) + getPatch against the unmodified reference's save()/load()."""
@@ -65,6 +73,7 @@ def test_document_load_matches_reference(eng, name):
     (loggen.KIND_MAP_LWW, dict(n_actors=3, n_rounds=3, n_keys=1500)),  # 500 literal keys/values per change
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=300, n_rounds=2, ins_per_change=2, del_per_change=1, n_objects=1)),  # 300 children of _head: radix fallback
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=16, n_rounds=3, ins_per_change=30, del_per_change=8, n_objects=5)),
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=40, n_rounds=210, ins_per_change=1, del_per_change=0, n_objects=1)),  # 8400 typing runs: tour beyond the LDS list ranking
 ])
 def test_generated_workloads_match_oracle(eng, kind, kw):
     log = loggen.generate(kind, seed=11, deflate=True, **kw)
@@ -113,9 +122,60 @@ def test_invalid_and_unsupported_inputs_are_reported(eng):
     assert emu_patch(eng, part) == oracle_lib.OracleDoc(part).patch_json()
 
 
+def _uleb(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def test_truncated_deflate_streams_are_rejected_not_retried(eng):
+    """A DEFLATE stream cut short must end in AM355_E_INVALID / BAD_DEFLATE (the reference throws a catchable error), for a
+    DEFLATEd change (chunk type 2, columnar.js:813-823) and for a DEFLATEd document column (columnar.js:1062-1067)."""
+    import hashlib
+    import zlib
+    log = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=4000, ops_per_change=2000, seed=4, deflate=True)
+    c = log.change(1)
+    assert c[8] == 2
+    off, clen, shift = 9, 0, 0
+    while True:
+        b = c[off]
+        off += 1
+        clen |= (b & 0x7F) << shift
+        shift += 7
+        if not b & 0x80:
+            break
+    for cut in (1, 5, clen // 2):
+        data = c[off:off + clen - cut]
+        bad = c[:9] + _uleb(len(data)) + data
+        eng.load_changes(loggen.ChangeLog.from_changes([log.change(0)]))  # (context stays usable around a rejected batch)
+        with pytest.raises(engine.InvalidChanges) as ei:
+            eng.load_changes(loggen.ChangeLog.from_changes([log.change(0), bad]))
+        assert "BAD_DEFLATE" in ei.value.flag_names
+    # a document whose one op column is a truncated raw-DEFLATE stream
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    stream = comp.compress(bytes(range(256)) * 40) + comp.flush()
+    for cut in (1, len(stream) // 2):
+        col = stream[:-cut]
+        body = _uleb(0) + _uleb(0) + _uleb(0) + _uleb(1) + _uleb(0x42 | 8) + _uleb(len(col)) + col
+        chunk = bytes([0]) + _uleb(len(body)) + body
+        doc = bytes([0x85, 0x6F, 0x4A, 0x83]) + hashlib.sha256(chunk).digest()[:4] + chunk
+        with pytest.raises(engine.InvalidChanges) as ei:
+            eng.load_document(doc)
+        assert "BAD_DEFLATE" in ei.value.flag_names
+    # offsets that are not ascending are an argument error, not a crash
+    arena = np.zeros(16, dtype=np.uint8)
+    with pytest.raises(engine.EngineError) as ei:
+        eng.load_changes(loggen.ChangeLog(arena, np.array([0, 12, 4], dtype=np.uint64), 0))
+    assert ei.value.code == engine.AM355_E_ARG
+
+
 def test_device_primitives(eng):
     rng = np.random.default_rng(1)
-    for n in (1, 64, 2049, 9000):
+    for n in (1, 64, 2049, 8192, 9000, 70_001):
         vals = rng.integers(0, 5, n, dtype=np.uint32)
         out, total = eng.test_scan(vals)
         assert np.array_equal(out, np.concatenate(([0], np.cumsum(vals)[:-1])).astype(np.uint32)) and total == int(vals.sum())
