@@ -20,7 +20,9 @@
 
 namespace am355 {
 
-enum Kind : uint8_t { K_NONE = 0, K_MAP = 1, K_LIST_INS = 2, K_LIST_UPD = 3, K_DEL = 4 };
+// K_LIST_INS_VIS: an insert row whose own value is visible (set by k_emit: the element's value count is val_cnt + this bit, so the
+// common case -- one visible value per element, its insert -- costs no atomic)
+enum Kind : uint8_t { K_NONE = 0, K_MAP = 1, K_LIST_INS = 2, K_LIST_UPD = 3, K_DEL = 4, K_LIST_INS_VIS = 5 };
 
 __device__ __forceinline__ uint32_t row_of(const MergeBufs& b, uint32_t actor, uint32_t ctr) {
   if (actor >= b.n_actors) return NONE32;
@@ -226,10 +228,13 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
     want_ins = kind == K_LIST_INS;
     if (vis && !valued) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);  // value-less visible row: reference 'remove' quirk
     if (vis && valued) {
-      el = kind == K_LIST_INS ? g : b.ref_row[g];
-      if (el != NONE32) {
-        atomicAdd(&b.val_cnt[el], 1u);
-        want_upd = kind == K_LIST_UPD;
+      if (kind == K_LIST_INS) b.kind[g] = K_LIST_INS_VIS;
+      else {
+        el = b.ref_row[g];
+        if (el != NONE32) {
+          atomicAdd(&b.val_cnt[el], 1u);
+          want_upd = true;
+        }
       }
     }
   }
@@ -237,18 +242,17 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   if (want_map) {
     b.em_row[slot] = g;
     b.em_trig[slot] = trig;
-    atomicMax(&b.counts->max_key_len, o.key_len[g]);
+    // (monotone maximum: the plain read only filters; same-word device atomics cost ~12 ns each, serialised)
+    if (o.key_len[g] > *(volatile uint32_t*)&b.counts->max_key_len) atomicMax(&b.counts->max_key_len, o.key_len[g]);
   }
   slot = wave_append(&b.counts->n_list_upd, want_upd);
   if (want_upd) b.upd_row[slot] = g;
   // list insert rows are most of a text document, make rows must keep row order: both are compacted by prefix sums, whose
   // workgroup sums this kernel publishes (k_compact_rows rebuilds the positions: no scan launch in between)
-  uint32_t t_ins = carry_publish(b.cs_ins, want_ins ? 1u : 0u, s_red);
-  uint32_t t_make = carry_publish(b.cs_make, is_make ? 1u : 0u, s_red);
-  if (threadIdx.x == 0) {
-    if (t_ins) atomicAdd(&b.counts->n_list_ins, t_ins);
-    if (t_make) atomicAdd(&b.counts->n_objects, t_make);
-  }
+  // (the totals -- Counts.n_list_ins, n_objects -- are written by the consumer's last thread: one atomic per workgroup on one
+  // word would serialise 4 k workgroups behind each other)
+  carry_publish(b.cs_ins, want_ins ? 1u : 0u, s_red);
+  carry_publish(b.cs_make, is_make ? 1u : 0u, s_red);
 }
 
 // documents (doc_patch): insert rows to dense positions from a scanned flag array
@@ -279,11 +283,15 @@ __global__ __launch_bounds__(BLOCK) void k_compact_rows(MergeBufs b, PatchIR ir)
   uint8_t kind = in_range ? b.kind[g] : (uint8_t)K_NONE;
   bool live = kind != K_NONE && kind != K_DEL;
   bool is_make = live && (b.ops.action[g] & 1) == 0;
-  bool want_ins = kind == K_LIST_INS;
+  bool want_ins = kind == K_LIST_INS || kind == K_LIST_INS_VIS;
   uint32_t pos = carry_prefix(b.cs_ins, want_ins ? 1u : 0u, s_red);
   uint32_t idx = carry_prefix(b.cs_make, is_make ? 1u : 0u, s_red) + 1;  // 0 is _root
   if (want_ins) b.ins_row[pos] = g;
   if (in_range) object_table_entry(b, ir, g, is_make, idx);
+  if (g + 1 == b.n_ops) {
+    b.counts->n_list_ins = pos + (want_ins ? 1u : 0u);
+    b.counts->n_objects = idx - 1 + (is_make ? 1u : 0u);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -510,8 +518,7 @@ __global__ __launch_bounds__(BLOCK) void k_child_order(MergeBufs b, uint32_t* __
     head = (i > 0 && ps == b.ins_row[i - 1] && first && none_after) ? 0u : 1u;
     is_head[i] = head;
   }
-  uint32_t t = carry_publish(b.cs_runs, head, s_red);
-  if (threadIdx.x == 0 && t) atomicAdd(&b.counts->n_runs, t);
+  carry_publish(b.cs_runs, head, s_red);  // (Counts.n_runs: written by k_run_heads)
 }
 
 // heads[k] = first insert-list index of run k (heads[H] = n); head_ex[i] = runs that start before i; row_run[] = run of a
@@ -536,6 +543,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_heads(MergeBufs b, const uint32_t
     uint32_t H = k + flag;
     heads[H] = n;
     row_run[b.ins_row[i]] = H - 1;
+    b.counts->n_runs = H;
   }
 }
 
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n) 
   if (p < n) {
     uint32_t v = b.order[p];
     if (v == NONE32) atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM);
-    else c = b.val_cnt[v];
+    else c = b.val_cnt[v] + (b.kind[v] == K_LIST_INS_VIS ? 1u : 0u);
     b.list_vis[p] = c ? 1 : 0;
     b.list_cnt[p] = c;
   }
@@ -681,13 +689,14 @@ __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, c
   if (p >= n) return;
   uint32_t v = b.order[p];
   if (v == NONE32) return;
-  uint32_t c = b.val_cnt[v];
+  const bool own = b.kind[v] == K_LIST_INS_VIS;  // the insert's own value is visible
+  uint32_t c = b.val_cnt[v] + (own ? 1u : 0u);
   if (!c) return;
   uint32_t oi = obj_index_of(b, b.obj_row[v]);
   uint32_t index = vis_ex[p] - vis_ex[b.obj_first_pos[oi]];
   uint32_t e = cnt_ex[p], k = 0;
   uint32_t a = b.ops.action[v];
-  if (b.succ_cnt[v] == 0 && (a == 1 || (a & 1) == 0)) {
+  if (own) {
     ir.e_row[e] = v; ir.e_elem[e] = v; ir.e_index[e] = index; ir.e_flags[e] = ((a & 1) == 0 ? 4u : 0u);
     k = 1;
   }
@@ -923,15 +932,15 @@ __global__ __launch_bounds__(BLOCK) void k_doc_scatter(MergeBufs b, const uint32
 static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
 
 size_t merge_counts_bytes(uint32_t n_ops) {
-  size_t groups = ((((size_t)n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2;
-  return ((sizeof(Counts) + 5 * 4 * groups) + 255) & ~(size_t)255;
+  size_t groups = (((((size_t)n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2) * CARRY_GROUP_STRIDE;
+  return ((((sizeof(Counts) + 255) & ~(size_t)255) + 5 * 4 * groups) + 255) & ~(size_t)255;
 }
 
 void merge_bind_counts(MergeBufs& b, void* block) {
-  size_t groups = ((((size_t)b.n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2;
+  size_t groups = (((((size_t)b.n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2) * CARRY_GROUP_STRIDE;
   b.counts = (Counts*)block;
   b.counts_bytes = merge_counts_bytes(b.n_ops);
-  uint32_t* g = (uint32_t*)((uint8_t*)block + sizeof(Counts));
+  uint32_t* g = (uint32_t*)((uint8_t*)block + ((sizeof(Counts) + 255) & ~(size_t)255));
   b.cs_ins.group_sum = g;
   b.cs_make.group_sum = g + groups;
   b.cs_runs.group_sum = g + 2 * groups;   // runs | vis | cnt are contiguous: cleared together when the list ordering is redone
@@ -1009,9 +1018,9 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   //      host does not have to wait for the counters before the device has more work ----
   AM355_LAUNCH_INDEPENDENT(k_child_push, grid_for(N), dim3(BLOCK), st, b);
   hipLaunchKernelGGL(k_child_order<false>, grid_for(N), dim3(BLOCK), 0, st, b, is_head);
+  hipLaunchKernelGGL(k_run_heads, grid_for(N), dim3(BLOCK), 0, st, b, (const uint32_t*)is_head, head_ex, heads, row_run);
   (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipEventRecord(ev_runs, st);
-  hipLaunchKernelGGL(k_run_heads, grid_for(N), dim3(BLOCK), 0, st, b, (const uint32_t*)is_head, head_ex, heads, row_run);
   AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)heads, (const uint32_t*)row_run, b.euler_a);
   hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
 
@@ -1035,8 +1044,8 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
       int res = radix_sort_pairs(b.key_a, b.val_a, b.key_b, b.val_b, ni, 0, total_bits, b.sort_ws, st);
       AM355_LAUNCH_INDEPENDENT(k_list_link, grid_for(ni), dim3(BLOCK), st, b, (const uint64_t*)(res ? b.key_b : b.key_a), (const uint32_t*)(res ? b.val_b : b.val_a), ni, kb);
       hipLaunchKernelGGL(k_child_order<true>, grid_for(ni), dim3(BLOCK), 0, st, b, is_head);
-      (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
       hipLaunchKernelGGL(k_run_heads, grid_for(ni), dim3(BLOCK), 0, st, b, (const uint32_t*)is_head, head_ex, heads, row_run);
+      (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
       AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(ni), dim3(BLOCK), st, b, (const uint32_t*)heads, (const uint32_t*)row_run, b.euler_a);
       hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
       (void)hipStreamSynchronize(st);

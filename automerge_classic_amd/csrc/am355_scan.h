@@ -58,9 +58,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_u32(uint32_t v, uint32_
 
 // ---- carried scan ----
 constexpr uint32_t CARRY_GROUP_SHIFT = 6;  // 64 workgroups (16384 elements) per group sum
+// Every group sum sits in its own 256-byte stretch: device-scope atomics on one word (and on words of one line) execute one after
+// another at ~12 ns each (MI355X_MICROARCH.md, "fanin"), so the sums of different groups must not share a line -- 64 arrivals
+// per word, all groups in parallel.
+constexpr uint32_t CARRY_GROUP_STRIDE = 64;  // words
 struct CarryScan {
   uint32_t* wg_sum;     // [workgroups]
-  uint32_t* group_sum;  // [workgroups >> CARRY_GROUP_SHIFT, + 1], zeroed before the producer runs
+  uint32_t* group_sum;  // [(workgroups >> CARRY_GROUP_SHIFT) + 1] x CARRY_GROUP_STRIDE words, zeroed before the producer runs
 };
 __host__ __device__ __forceinline__ size_t carry_words(uint32_t n_elems) {  // words of one CarryScan over n_elems elements
   size_t wgs = ((size_t)n_elems + BLOCK - 1) / BLOCK + 1;
@@ -71,7 +75,7 @@ __device__ __forceinline__ uint32_t carry_publish(const CarryScan& c, uint32_t v
   uint32_t total = block_sum_u32(v, s);
   if (threadIdx.x == 0) {
     c.wg_sum[blockIdx.x] = total;
-    if (total) atomicAdd(&c.group_sum[blockIdx.x >> CARRY_GROUP_SHIFT], total);
+    if (total) atomicAdd(&c.group_sum[(size_t)(blockIdx.x >> CARRY_GROUP_SHIFT) * CARRY_GROUP_STRIDE], total);
   }
   return total;
 }
@@ -79,7 +83,7 @@ __device__ __forceinline__ uint32_t carry_publish(const CarryScan& c, uint32_t v
 __device__ __forceinline__ uint32_t carry_prefix(const CarryScan& c, uint32_t v, uint32_t* s) {
   uint32_t g = blockIdx.x >> CARRY_GROUP_SHIFT, first = g << CARRY_GROUP_SHIFT;
   uint32_t part = 0;
-  for (uint32_t k = threadIdx.x; k < g; k += BLOCK) part += c.group_sum[k];
+  for (uint32_t k = threadIdx.x; k < g; k += BLOCK) part += c.group_sum[(size_t)k * CARRY_GROUP_STRIDE];
   if (first + threadIdx.x < blockIdx.x) part += c.wg_sum[first + threadIdx.x];  // (at most 63 workgroups before this one in its group)
   uint32_t before = block_sum_u32(part, s);
   uint32_t total;
