@@ -971,9 +971,10 @@ static int setup_buffers(am355_ctx* c) {
     size_t cw = carry_words(N);
     size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc + 2, 4) + 4 * carve_size(2 * Nc + 2, 4) +
                    3 * carve_size(Nc + 1, 4) + scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 256 +
-                   6 * carve_size(Nc + 3, 4) + 5 * carve_size(cw, 4);
+                   6 * carve_size(Nc + 3, 4) + 6 * carve_size(cw, 4);
     size_t sort_bytes = 2 * carve_size(Nc, 8) + 2 * carve_size(Nc, 4) + sort_workspace_bytes((uint32_t)Nc) + 256;
-    size_t ir_bytes = 5 * carve_size(Nc, 4) + 2 * carve_size(Nc, 4) + carve_size(Nc, 8) + 4 * carve_size(Nc, 4);
+    size_t ir_bytes = carve_size(Nc + 1, sizeof(am355_ir_object)) + carve_size(Nc, sizeof(am355_ir_map)) + carve_size(Nc + 1, sizeof(am355_ir_edit)) +
+                      carve_size(Nc, sizeof(am355_ir_value)) + 4 * carve_size(Nc, 4);
     if (!c->d_merge.ensure(bytes) || !c->d_sort.ensure(sort_bytes) || !c->d_ir.ensure(ir_bytes) || !c->d_counts.ensure(merge_counts_bytes(N)))
       return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
     uint8_t* p = c->d_merge.as<uint8_t>();
@@ -1000,7 +1001,7 @@ static int setup_buffers(am355_ctx* c) {
     b.run_heads = carve<uint32_t>(p, Nc + 3); b.row_run = carve<uint32_t>(p, Nc + 3); b.obj_n = carve<uint32_t>(p, Nc + 3);
     b.obj_first_pos = carve<uint32_t>(p, Nc + 3); b.list_vis = carve<uint32_t>(p, Nc + 3); b.list_cnt = carve<uint32_t>(p, Nc + 3);
     b.cs_ins.wg_sum = carve<uint32_t>(p, cw); b.cs_make.wg_sum = carve<uint32_t>(p, cw); b.cs_runs.wg_sum = carve<uint32_t>(p, cw);
-    b.cs_vis.wg_sum = carve<uint32_t>(p, cw); b.cs_cnt.wg_sum = carve<uint32_t>(p, cw);
+    b.cs_vis.wg_sum = carve<uint32_t>(p, cw); b.cs_cnt.wg_sum = carve<uint32_t>(p, cw); b.cs_erec.wg_sum = carve<uint32_t>(p, cw);
     // unordered child lists (k_child_push) live in the second Euler buffer, which list ranking only uses afterwards
     b.child_head = (uint32_t*)b.euler_b;
     b.child_next = b.child_head + (2 * Nc + 2);
@@ -1010,9 +1011,8 @@ static int setup_buffers(am355_ctx* c) {
     merge_bind_counts(b, c->d_counts.p);
     uint8_t* r = c->d_ir.as<uint8_t>();
     PatchIR& ir = c->ir;
-    ir.obj_make_row = carve<uint32_t>(r, Nc); ir.obj_map_begin = carve<uint32_t>(r, Nc); ir.obj_map_end = carve<uint32_t>(r, Nc);
-    ir.obj_edit_begin = carve<uint32_t>(r, Nc); ir.obj_edit_end = carve<uint32_t>(r, Nc);
-    ir.m_row = carve<uint32_t>(r, Nc); ir.m_flags = carve<uint32_t>(r, Nc); ir.m_counter = carve<long long>(r, Nc);
+    ir.obj = carve<am355_ir_object>(r, Nc + 1); ir.map = carve<am355_ir_map>(r, Nc); ir.edit = carve<am355_ir_edit>(r, Nc + 1);
+    ir.val = carve<am355_ir_value>(r, Nc);
     ir.e_row = carve<uint32_t>(r, Nc); ir.e_elem = carve<uint32_t>(r, Nc); ir.e_index = carve<uint32_t>(r, Nc); ir.e_flags = carve<uint32_t>(r, Nc);
   }
   return AM355_OK;
@@ -1128,7 +1128,7 @@ static int replay_document(am355_ctx* c) {
     ChangePlan pl{0, 0, 0, 0, NONE32, NA};  // author NONE32 = document mode: ids come from the idActor / idCtr columns
     HIPCHK(c, hipMemcpyAsync(c->d_plans.p, &pl, sizeof pl, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
+    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
     HIPCHK(c, hipMemsetAsync(c->d_words.p, 0, 4 * W_NUM, st));
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     launch_decode_document(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_amap.as<uint32_t>(), c->cols,
@@ -1188,7 +1188,7 @@ static int replay_document(am355_ctx* c) {
     c->max_op = 0xffffffffu >> 8;  // only sizes sort keys, which the document path never builds
     int rc = setup_buffers(c);
     if (rc) { (void)hipStreamSynchronize(c->stream2); return rc; }
-    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, sizeof(Counts), st));
+    HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
     uint32_t* flags = &c->d_counts.as<Counts>()->flags;
     bigcol_assemble(v, N, (uint32_t)c->n_preds, c->d_amap.as<uint32_t>(), NA, m.col_off[C_VAL_RAW], m.col_len[C_VAL_RAW], c->cols, flags, st);
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_b1, 0));
@@ -1217,7 +1217,8 @@ static int replay_document(am355_ctx* c) {
   s.n_changes = c->n_changes; s.n_applied = c->n_changes; s.n_pending = 0; s.n_actors = NA; s.n_objects = c->counts.n_objects;
   s.n_heads = (uint32_t)(c->heads.size() / 32); s.n_ops = c->n_ops; s.max_op = c->max_op; s.raw_bytes = c->raw.size();
   s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
-  s.ir_bytes = (uint64_t)c->counts.n_objects * 20 + (uint64_t)c->counts.n_map_emit * 16 + (uint64_t)c->counts.n_edits * 16;
+  s.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
+               ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit) + (uint64_t)c->counts.n_edits * sizeof(am355_ir_value);
   (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
   (void)hipEventElapsedTime(&s.ms_merge, c->ev[3], c->ev[4]);
@@ -1369,7 +1370,8 @@ static int replay_impl(am355_ctx* c) {
   s.n_changes = n; s.n_applied = c->n_applied; s.n_pending = c->n_pending; s.n_actors = NA; s.n_objects = c->counts.n_objects;
   s.n_heads = (uint32_t)(c->heads.size() / 32); s.n_ops = c->n_ops; s.max_op = c->max_op; s.raw_bytes = c->raw.size();
   s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
-  s.ir_bytes = (uint64_t)c->counts.n_objects * 20 + (uint64_t)c->counts.n_map_emit * 16 + (uint64_t)c->counts.n_edits * 16;
+  s.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
+               ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit) + (uint64_t)c->counts.n_edits * sizeof(am355_ir_value);
   (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
   s.ms_merge = s.ms_order = 0;
@@ -1423,8 +1425,9 @@ static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
   (void)hipSetDevice(c->device);
   if (!c->ir_fetched) {
     hipStream_t st = c->stream;
-    uint32_t N = (uint32_t)c->n_ops, NO = c->counts.n_objects, NM = c->counts.n_map_emit, NE = c->counts.n_edits;
-    size_t bytes = 5 * carve_size(NO, 4) + 2 * carve_size(NM, 4) + carve_size(NM, 8) + 4 * carve_size(NE, 4) + 8 * carve_size(N, 4) + 4096;
+    uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NR = c->counts.n_erecs, NV = c->counts.n_edits;
+    size_t bytes = carve_size(NO, sizeof(am355_ir_object)) + carve_size(NM, sizeof(am355_ir_map)) + carve_size((size_t)NR + 1, sizeof(am355_ir_edit)) +
+                   carve_size(NV, sizeof(am355_ir_value)) + 4096;
     if (!c->h_ir.ensure(bytes)) return fail(c, AM355_E_NOMEM, "host allocation failed");
     uint8_t* p = c->h_ir.as<uint8_t>();
     am355_patch_ir& h = c->hir;
@@ -1434,27 +1437,11 @@ static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
       if (count) (void)hipMemcpyAsync(dst, dev, count * elem, hipMemcpyDeviceToHost, st);
       return dst;
     };
-    h.n_objects = NO; h.n_map = NM; h.n_edits = NE; h.n_rows = N;
-    h.obj_make_row = (const uint32_t*)pull(c->ir.obj_make_row, NO, 4);
-    h.obj_map_begin = (const uint32_t*)pull(c->ir.obj_map_begin, NO, 4);
-    h.obj_map_end = (const uint32_t*)pull(c->ir.obj_map_end, NO, 4);
-    h.obj_edit_begin = (const uint32_t*)pull(c->ir.obj_edit_begin, NO, 4);
-    h.obj_edit_end = (const uint32_t*)pull(c->ir.obj_edit_end, NO, 4);
-    h.m_row = (const uint32_t*)pull(c->ir.m_row, NM, 4);
-    h.m_flags = (const uint32_t*)pull(c->ir.m_flags, NM, 4);
-    h.m_counter = (const int64_t*)pull(c->ir.m_counter, NM, 8);
-    h.e_row = (const uint32_t*)pull(c->ir.e_row, NE, 4);
-    h.e_elem = (const uint32_t*)pull(c->ir.e_elem, NE, 4);
-    h.e_index = (const uint32_t*)pull(c->ir.e_index, NE, 4);
-    h.e_flags = (const uint32_t*)pull(c->ir.e_flags, NE, 4);
-    h.row_id_ctr = (const uint32_t*)pull(c->cols.id_ctr, N, 4);
-    h.row_id_actor = (const uint32_t*)pull(c->cols.id_actor, N, 4);
-    h.row_action = (const uint32_t*)pull(c->cols.action, N, 4);
-    h.row_val_tl = (const uint32_t*)pull(c->cols.val_tl, N, 4);
-    h.row_val_off = (const uint32_t*)pull(c->cols.val_off, N, 4);
-    h.row_key_off = (const uint32_t*)pull(c->cols.key_off, N, 4);
-    h.row_key_len = (const uint32_t*)pull(c->cols.key_len, N, 4);
-    h.row_obj_index = (const uint32_t*)pull(c->mb.obj_index, N, 4);
+    h.n_objects = NO; h.n_map = NM; h.n_edits = NR; h.n_values = NV;
+    h.objects = (const am355_ir_object*)pull(c->ir.obj, NO, sizeof(am355_ir_object));
+    h.map = (const am355_ir_map*)pull(c->ir.map, NM, sizeof(am355_ir_map));
+    h.edits = (const am355_ir_edit*)pull(c->ir.edit, (size_t)NR + 1, sizeof(am355_ir_edit));
+    h.values = (const am355_ir_value*)pull(c->ir.val, NV, sizeof(am355_ir_value));
     HIPCHK(c, hipStreamSynchronize(st));
     h.max_op = c->max_op;
     h.n_actors = (uint32_t)c->actors.size();
@@ -1473,6 +1460,7 @@ static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
     h.heads = c->heads.data();
     h.pending = c->n_pending;
     h.arena = c->raw.data();
+    h.arena_len = c->raw.size();
     c->ir_fetched = true;
   }
   if (out) *out = c->hir;

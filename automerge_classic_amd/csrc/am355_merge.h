@@ -2,6 +2,7 @@
 #pragma once
 #include "am355_internal.h"
 #include "am355_scan.h"
+#include "../../include/am355.h"
 #include <stddef.h>
 
 namespace am355 {
@@ -18,7 +19,8 @@ struct Counts {
   uint32_t pad;          // a list element has more children than the in-place sibling ordering handles: redo with the radix sort
   uint32_t n_runs;       // typing runs of the insertion forest (list ranking works on 2 x runs + 1 tour entries)
   uint32_t euler_done;   // the single-workgroup LDS list ranking handled the tour
-  uint32_t reserved[6];
+  uint32_t n_erecs;      // edit records (a multi-insert run counts once)
+  uint32_t reserved[5];
 };
 
 // Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.
@@ -51,7 +53,7 @@ struct MergeBufs {
   uint32_t *obj_n;                  // [n_objects + 1] list elements (insert rows) per object
   uint32_t *run_heads, *row_run;    // typing runs: first insert-list index of each run; run of a row (run heads and tails only)
   uint32_t *list_vis, *list_cnt;    // [N] per list position: element visible, number of its edits (scanned into scan_a / scan_b)
-  CarryScan cs_ins, cs_make, cs_runs, cs_vis, cs_cnt;  // carried scans (am355_scan.h); their group sums follow `counts`
+  CarryScan cs_ins, cs_make, cs_runs, cs_vis, cs_cnt, cs_erec;  // carried scans (am355_scan.h); their group sums follow `counts`
   unsigned long long *euler_a, *euler_b;        // [2N+2] Euler tour list ranking: (weight-to-end << 32 | successor)
   uint32_t *order;                  // [N] node rows in document order (all list objects chained)
   uint32_t *scan_a, *scan_b;        // [N+1] prefix sums over `order`
@@ -69,20 +71,19 @@ size_t merge_counts_bytes(uint32_t n_ops);
 void merge_bind_counts(MergeBufs& b, void* d_counts_block);
 
 // ---- patch IR in device memory (the output of the hot path) ---------------------------------------------
+// The four record tables of include/am355.h (objects, map records, edit records, values) are written by the device in their
+// final layout and copied to the host as they are. The per-element arrays e_* are the intermediate the edit records are
+// packed from (one entry per visible list value, in document order).
 struct PatchIR {
-  // objects: index 0 is _root, then make rows in row order
-  uint32_t *obj_make_row;   // [n_objects] row of the make op (NONE32 for root)
-  uint32_t *obj_map_begin, *obj_map_end;    // range in the map emission arrays
-  uint32_t *obj_edit_begin, *obj_edit_end;  // range in the edit arrays
-  // map emissions sorted by (object, key, trigger op)
-  uint32_t *m_row;          // [n_map_emit] row whose value is shown (for counters: the `set` row)
-  long long *m_counter;     // [n_map_emit] counter total when m_flags&1
-  uint32_t *m_flags;        // bit0: counter value, bit1: child object
-  // list edits in document order
+  am355_ir_object* obj;     // [n_objects] index 0 is _root, then make rows in row order (make_row: NONE32 for root)
+  am355_ir_map* map;        // [n_map_emit] sorted by (object, key, trigger op)
+  am355_ir_edit* edit;      // [n_erecs + 1] one record per edit (a multi-insert run is ONE record) + sentinel
+  am355_ir_value* val;      // [n_edits] one per visible list value; edit record k owns [edit[k].first, edit[k+1].first)
   uint32_t *e_row;          // [n_edits] row holding the value (its id is the edit's opId)
   uint32_t *e_elem;         // [n_edits] row of the element (its id is the elemId)
   uint32_t *e_index;        // [n_edits] list index
-  uint32_t *e_flags;        // bit0: update (else insert), bit1: continues the multi-insert run of the previous edit, bit2: child object
+  uint32_t *e_flags;        // bit0: update (else insert), bit1: continues the multi-insert run of the previous edit, bit2: child
+                            // object, bit8 / bit9: first / last edit of its list object
 };
 
 size_t merge_scratch_pairs(uint32_t n_ops);

@@ -263,16 +263,12 @@ __global__ __launch_bounds__(BLOCK) void k_ins_scatter(MergeBufs b, const uint32
 
 __device__ __forceinline__ void object_table_entry(const MergeBufs& b, const PatchIR& ir, uint32_t g, bool is_make, uint32_t idx) {
   if (is_make) {
-    ir.obj_make_row[idx] = g;
+    ir.obj[idx] = am355_ir_object{b.ops.id_ctr[g], b.ops.id_actor[g], b.ops.action[g], 0, 0, 0, 0, g};
     b.obj_index[g] = idx;
-    ir.obj_map_begin[idx] = ir.obj_map_end[idx] = ir.obj_edit_begin[idx] = ir.obj_edit_end[idx] = 0;
   } else {
     b.obj_index[g] = NONE32;
   }
-  if (g == 0) {
-    ir.obj_make_row[0] = NONE32;
-    ir.obj_map_begin[0] = ir.obj_map_end[0] = ir.obj_edit_begin[0] = ir.obj_edit_end[0] = 0;
-  }
+  if (g == 0) ir.obj[0] = am355_ir_object{0, 0, 0, 0, 0, 0, 0, NONE32};
 }
 
 // consumer of k_emit's carried scans: list insert rows -> dense list (ins_row), make rows -> object table (index 0 = _root)
@@ -382,25 +378,25 @@ __global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_
   uint32_t i = gtid();
   if (i >= n) return;
   uint32_t e = perm[i], g = b.em_row[e];
-  uint32_t a = b.ops.action[g];
+  const OpCols& o = b.ops;
+  uint32_t a = o.action[g];
   uint32_t flags = 0;
   long long counter = 0;
   if (a == 1 && b.succ_cnt[g] != 0) {
-    flags |= 1;
+    flags |= AM355_MAP_COUNTER;
     long long base = 0;
     if (!int_value(b, g, base)) atomicOr(&b.counts->flags, (uint32_t)F_BAD_LEB);
     counter = base + (long long)b.inc_sum[g];
   } else if ((a & 1) == 0) {
-    flags |= 2;
+    flags |= AM355_MAP_CHILD;
   }
-  ir.m_row[i] = g;
-  ir.m_flags[i] = flags;
-  ir.m_counter[i] = counter;
+  ir.map[i] = am355_ir_map{o.id_ctr[g], o.id_actor[g], o.key_off[g], o.key_len[g], o.val_tl[g], (flags & AM355_MAP_CHILD) ? b.obj_index[g] : o.val_off[g],
+                           flags, 0, counter};
   uint32_t oi = obj_index_of(b, b.obj_row[g]);
   uint32_t prev = i > 0 ? obj_index_of(b, b.obj_row[b.em_row[perm[i - 1]]]) : NONE32;
   uint32_t next = i + 1 < n ? obj_index_of(b, b.obj_row[b.em_row[perm[i + 1]]]) : NONE32;
-  if (oi != prev) ir.obj_map_begin[oi] = i;
-  if (oi != next) ir.obj_map_end[oi] = i + 1;
+  if (oi != prev) ir.obj[oi].map_begin = i;
+  if (oi != next) ir.obj[oi].map_end = i + 1;
 }
 
 static int bits_for(uint64_t max_value) {
@@ -628,7 +624,7 @@ __global__ __launch_bounds__(BLOCK) void k_obj_n(MergeBufs b, PatchIR ir, uint32
   if (oi > n_obj) return;
   uint32_t c = 0;
   if (oi > 0 && oi < n_obj) {
-    uint32_t fc = b.first_child[b.n_ops + ir.obj_make_row[oi]];
+    uint32_t fc = b.first_child[b.n_ops + ir.obj[oi].make_row];
     if (fc != NONE32) c = (uint32_t)(el[2 * (size_t)row_run[fc]] >> 32);
   }
   b.obj_n[oi] = c;
@@ -725,26 +721,61 @@ __device__ __forceinline__ uint32_t value_class(uint32_t tl) {
   return 16 + tag;
 }
 
-// multi-insert run detection (new.js:754-773) and per-object edit ranges
+// multi-insert run detection (new.js:754-773), first / last edit of every list object; publishes the number of edit RECORDS
+// (an edit that does not continue a multi-insert run starts one) for k_edit_pack's carried scan
 __global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
-  uint32_t e = gtid();
+  __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t n = b.counts->n_edits;
+  if (blockIdx.x * BLOCK >= n && blockIdx.x) return;  // (whole workgroup; workgroup 0 always publishes)
+  uint32_t e = gtid();
+  uint32_t head = 0;
+  if (e < n) {
+    const OpCols& o = b.ops;
+    uint32_t r = ir.e_row[e], el = ir.e_elem[e], f = ir.e_flags[e] & 5u;
+    uint32_t oi = obj_index_of(b, b.obj_row[el]);
+    uint32_t prev_oi = NONE32, next_oi = NONE32;
+    if (e > 0) {
+      uint32_t pr = ir.e_row[e - 1], pel = ir.e_elem[e - 1], pf = ir.e_flags[e - 1];
+      prev_oi = obj_index_of(b, b.obj_row[pel]);
+      bool simple = !(f & 5) && r == el, psimple = !(pf & 5) && pr == pel;
+      if (simple && psimple && prev_oi == oi && o.id_actor[r] == o.id_actor[pr] && o.id_ctr[r] == o.id_ctr[pr] + 1 &&
+          value_class(o.val_tl[r]) == value_class(o.val_tl[pr]) && ir.e_index[e] == ir.e_index[e - 1] + 1)
+        f |= 2u;
+    }
+    if (e + 1 < n) next_oi = obj_index_of(b, b.obj_row[ir.e_elem[e + 1]]);
+    if (oi != prev_oi) f |= 0x100u;
+    if (oi != next_oi) f |= 0x200u;
+    ir.e_flags[e] = f;
+    head = (f & 2u) ? 0u : 1u;
+  }
+  carry_publish(b.cs_erec, head, s_red);
+}
+
+// consumer of k_edit_runs' carried scan (same grid): one value record per element edit, one edit record per run head, the
+// edit ranges of the list objects, the sentinel record and Counts.n_erecs
+__global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  uint32_t n = b.counts->n_edits;
+  if (blockIdx.x * BLOCK >= n && blockIdx.x) return;
+  uint32_t e = gtid();
+  uint32_t f = e < n ? ir.e_flags[e] : 2u;
+  uint32_t head = (f & 2u) ? 0u : 1u;
+  uint32_t k = carry_prefix(b.cs_erec, head, s_red);
+  if (e == 0 && n == 0) { ir.edit[0] = am355_ir_edit{0, 0, 0, 0, 0, 0, 0, 0}; b.counts->n_erecs = 0; }
   if (e >= n) return;
   const OpCols& o = b.ops;
-  uint32_t r = ir.e_row[e], el = ir.e_elem[e], f = ir.e_flags[e];
-  uint32_t oi = obj_index_of(b, b.obj_row[el]);
-  uint32_t prev_oi = NONE32, next_oi = NONE32;
-  if (e > 0) {
-    uint32_t pr = ir.e_row[e - 1], pel = ir.e_elem[e - 1], pf = ir.e_flags[e - 1];
-    prev_oi = obj_index_of(b, b.obj_row[pel]);
-    bool simple = !(f & 5) && r == el, psimple = !(pf & 5) && pr == pel;
-    if (simple && psimple && prev_oi == oi && o.id_actor[r] == o.id_actor[pr] && o.id_ctr[r] == o.id_ctr[pr] + 1 &&
-        value_class(o.val_tl[r]) == value_class(o.val_tl[pr]) && ir.e_index[e] == ir.e_index[e - 1] + 1)
-      ir.e_flags[e] = f | 2u;
+  uint32_t r = ir.e_row[e], el = ir.e_elem[e];
+  ir.val[e] = am355_ir_value{o.val_tl[r], (f & 4u) ? b.obj_index[r] : o.val_off[r]};
+  if (head) ir.edit[k] = am355_ir_edit{f & 5u, ir.e_index[e], o.id_ctr[r], o.id_actor[r], o.id_ctr[el], o.id_actor[el], e, 0};
+  if (f & 0x300u) {
+    uint32_t oi = obj_index_of(b, b.obj_row[el]);
+    if (f & 0x100u) ir.obj[oi].edit_begin = k;         // (the first edit of an object is always a head)
+    if (f & 0x200u) ir.obj[oi].edit_end = k + head;
   }
-  if (e + 1 < n) next_oi = obj_index_of(b, b.obj_row[ir.e_elem[e + 1]]);
-  if (oi != prev_oi) ir.obj_edit_begin[oi] = e;
-  if (oi != next_oi) ir.obj_edit_end[oi] = e + 1;
+  if (e + 1 == n) {
+    ir.edit[k + head] = am355_ir_edit{0, 0, 0, 0, 0, 0, n, 0};
+    b.counts->n_erecs = k + head;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -933,7 +964,7 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); 
 
 size_t merge_counts_bytes(uint32_t n_ops) {
   size_t groups = (((((size_t)n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2) * CARRY_GROUP_STRIDE;
-  return ((((sizeof(Counts) + 255) & ~(size_t)255) + 5 * 4 * groups) + 255) & ~(size_t)255;
+  return ((((sizeof(Counts) + 255) & ~(size_t)255) + 6 * 4 * groups) + 255) & ~(size_t)255;
 }
 
 void merge_bind_counts(MergeBufs& b, void* block) {
@@ -946,6 +977,7 @@ void merge_bind_counts(MergeBufs& b, void* block) {
   b.cs_runs.group_sum = g + 2 * groups;   // runs | vis | cnt are contiguous: cleared together when the list ordering is redone
   b.cs_vis.group_sum = g + 3 * groups;
   b.cs_cnt.group_sum = g + 4 * groups;
+  b.cs_erec.group_sum = g + 5 * groups;
 }
 
 void merge_prepare(MergeBufs& b, hipStream_t aux) {
@@ -995,11 +1027,8 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   const uint32_t N = b.n_ops;
   Counts* hc_runs = hc + 1;  // second read-back (pinned host memory with room for two records)
   if (!N) {
-    (void)hipMemsetAsync(ir.obj_make_row, 0xff, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_map_end, 0, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_edit_begin, 0, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_edit_end, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj, 0, sizeof(am355_ir_object), st);
+    (void)hipMemsetAsync(ir.edit, 0, sizeof(am355_ir_edit), st);
     (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
     return;
@@ -1082,7 +1111,10 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
       uv = r2 ? b.val_b : b.val_a;
     }
     AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis_ex, (const uint32_t*)cnt_ex, uk, uv, nu, ir);
-    AM355_LAUNCH_INDEPENDENT(k_edit_runs, grid_for(N), dim3(BLOCK), st, b, ir);
+    hipLaunchKernelGGL(k_edit_runs, grid_for(N), dim3(BLOCK), 0, st, b, ir);
+    hipLaunchKernelGGL(k_edit_pack, grid_for(N), dim3(BLOCK), 0, st, b, ir);
+  } else {
+    (void)hipMemsetAsync(ir.edit, 0, sizeof(am355_ir_edit), st);
   }
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
@@ -1123,17 +1155,15 @@ void doc_patch(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
                              (const uint32_t*)b.scan_a, (const uint32_t*)edit_flag, (const uint32_t*)b.scan_b, (const uint32_t*)idx_ex,
                              (const uint32_t*)obj_first, perm, ir);
   } else {
-    (void)hipMemsetAsync(ir.obj_make_row, 0xff, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_map_begin, 0, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_map_end, 0, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_edit_begin, 0, sizeof(uint32_t), st);
-    (void)hipMemsetAsync(ir.obj_edit_end, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(ir.obj, 0, sizeof(am355_ir_object), st);
+    (void)hipMemsetAsync(ir.edit, 0, sizeof(am355_ir_edit), st);
   }
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
   if (hc->flags || !N) return;
   if (hc->n_map_emit) AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(hc->n_map_emit), dim3(BLOCK), st, b, (const uint32_t*)perm, hc->n_map_emit, ir);
-  if (hc->n_edits) AM355_LAUNCH_INDEPENDENT(k_edit_runs, grid_for(hc->n_edits), dim3(BLOCK), st, b, ir);
+  hipLaunchKernelGGL(k_edit_runs, grid_for(hc->n_edits ? hc->n_edits : 1), dim3(BLOCK), 0, st, b, ir);
+  hipLaunchKernelGGL(k_edit_pack, grid_for(hc->n_edits ? hc->n_edits : 1), dim3(BLOCK), 0, st, b, ir);
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
 }
@@ -1171,7 +1201,7 @@ __global__ __launch_bounds__(BLOCK) void ks_compact(MergeBufs b, const uint32_t*
 __global__ __launch_bounds__(BLOCK) void ks_obj_keys(MergeBufs b, PatchIR ir, uint32_t n_obj, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   uint32_t i = gtid();  // object i + 1
   if (i + 1 >= n_obj) return;
-  uint32_t row = ir.obj_make_row[i + 1];
+  uint32_t row = ir.obj[i + 1].make_row;
   keys[i] = (uint64_t)b.ops.id_ctr[row] << b.bits_actor | b.ops.id_actor[row];
   vals[i] = i + 1;
 }

@@ -79,13 +79,14 @@ struct R {
     for (size_t i = 0; i < n; i++) { out.push_back(hx[p[i] >> 4]); out.push_back(hx[p[i] & 15]); }
   }
 
-  void op_id(uint32_t row) {
+  bool op_id(uint32_t ctr, uint32_t a) {
+    if (a >= ir.n_actors) return fail("internal: actor rank out of range");
     char t[24];
-    snprintf(t, sizeof t, "\"%u@", ir.row_id_ctr[row]);
+    snprintf(t, sizeof t, "\"%u@", ctr);
     out += t;
-    uint32_t a = ir.row_id_actor[row];
     hex(ir.actor_bytes + ir.actor_off[a], ir.actor_off[a + 1] - ir.actor_off[a]);
     out.push_back('"');
+    return true;
   }
 
   // ECMA-262 Number::toString
@@ -130,9 +131,9 @@ struct R {
     }
   }
 
-  bool leb_value(uint32_t row, int64_t& v) {
-    uint32_t tl = ir.row_val_tl[row], tag = tl & 15, len = tl >> 4;
-    const uint8_t* p = ir.arena + ir.row_val_off[row];
+  bool leb_value(uint32_t tl, uint32_t off, int64_t& v) {
+    uint32_t tag = tl & 15, len = tl >> 4;
+    const uint8_t* p = ir.arena + off;
     uint64_t u = 0;
     int shift = 0;
     for (uint32_t i = 0; i < len; i++) {
@@ -151,9 +152,10 @@ struct R {
     return fail("buffer ended with incomplete number");
   }
 
-  bool prim_value(uint32_t row) {
-    uint32_t tl = ir.row_val_tl[row], tag = tl & 15, len = tl >> 4;
-    const uint8_t* p = ir.arena + ir.row_val_off[row];
+  bool prim_value(uint32_t tl, uint32_t off) {
+    uint32_t tag = tl & 15, len = tl >> 4;
+    if (tl > 2 && (uint64_t)off + len > ir.arena_len) return fail("internal: value outside the arena");
+    const uint8_t* p = ir.arena + off;
     if (tl == 0) { out += "null"; return true; }
     if (tl == 1) { out += "false"; return true; }
     if (tl == 2) { out += "true"; return true; }
@@ -162,7 +164,7 @@ struct R {
       case 6: return json_string(p, len);
       case 3: case 4: case 8: case 9: {
         int64_t v;
-        if (!leb_value(row, v)) return false;
+        if (!leb_value(tl, off, v)) return false;
         snprintf(t, sizeof t, "%lld", (long long)v);
         out += t;
         return true;
@@ -199,11 +201,10 @@ struct R {
     }
   }
 
-  bool value_of_row(uint32_t row, bool child) {
-    if (child) return object(ir.row_obj_index[row]);
-    uint32_t tl = ir.row_val_tl[row];
+  bool value(uint32_t tl, uint32_t off, bool child) {
+    if (child) return object(off);
     out += "{\"type\":\"value\",\"value\":";
-    if (!prim_value(row)) return false;
+    if (!prim_value(tl, off)) return false;
     if (has_datatype(tl)) { out += ",\"datatype\":"; datatype(tl & 15); }
     out.push_back('}');
     return true;
@@ -219,25 +220,24 @@ struct R {
     return v <= 4294967294ull;
   }
 
-  bool same_key(uint32_t r1, uint32_t r2) {
-    uint32_t l = ir.row_key_len[r1];
-    return l == ir.row_key_len[r2] && memcmp(ir.arena + ir.row_key_off[r1], ir.arena + ir.row_key_off[r2], l) == 0;
+  bool same_key(const am355_ir_map& x, const am355_ir_map& y) {
+    return x.key_len == y.key_len && memcmp(ir.arena + x.key_off, ir.arena + y.key_off, x.key_len) == 0;
   }
 
-  bool prop(uint32_t begin, uint32_t end) {  // emissions [begin, end) share one key
-    uint32_t r0 = ir.m_row[begin];
-    if (!json_string(ir.arena + ir.row_key_off[r0], ir.row_key_len[r0])) return false;
+  bool prop(uint32_t begin, uint32_t end) {  // map records [begin, end) share one key
+    const am355_ir_map& m0 = ir.map[begin];
+    if (!json_string(ir.arena + m0.key_off, m0.key_len)) return false;
     out += ":{";
     for (uint32_t i = begin; i < end; i++) {
       if (i > begin) out.push_back(',');
-      uint32_t row = ir.m_row[i], f = ir.m_flags[i];
-      op_id(row);
+      const am355_ir_map& m = ir.map[i];
+      if (!op_id(m.id_ctr, m.id_actor)) return false;
       out.push_back(':');
-      if (f & 1) {
+      if (m.flags & AM355_MAP_COUNTER) {
         char t[80];
-        snprintf(t, sizeof t, "{\"type\":\"value\",\"datatype\":\"counter\",\"value\":%lld}", (long long)ir.m_counter[i]);
+        snprintf(t, sizeof t, "{\"type\":\"value\",\"datatype\":\"counter\",\"value\":%lld}", (long long)m.counter);
         out += t;
-      } else if (!value_of_row(row, (f & 2) != 0)) {
+      } else if (!value(m.val_tl, m.val_off, (m.flags & AM355_MAP_CHILD) != 0)) {
         return false;
       }
     }
@@ -245,50 +245,50 @@ struct R {
     return true;
   }
 
-  // edits [b, e) of one list object, comma separated; b must be the first edit of a multi-insert run or a single edit
+  // edit records [b, e) of one list object, comma separated
   bool edits_serial(uint32_t b, uint32_t e) {
     char t[64];
-    for (uint32_t i = b; i < e;) {
-      uint32_t j = i + 1;
-      while (j < e && (ir.e_flags[j] & 2)) j++;
+    for (uint32_t i = b; i < e; i++) {
+      const am355_ir_edit& ed = ir.edits[i];
+      uint32_t v0 = ed.first, v1 = ir.edits[i + 1].first;
+      if (v1 <= v0 || v1 > ir.n_values) return fail("internal: edit record without values");
       if (i > b) out.push_back(',');
-      uint32_t row = ir.e_row[i], f = ir.e_flags[i];
-      if (j - i >= 2) {
-        snprintf(t, sizeof t, "{\"action\":\"multi-insert\",\"index\":%u,\"elemId\":", ir.e_index[i]);
+      const am355_ir_value& val = ir.values[v0];
+      if (v1 - v0 >= 2) {
+        snprintf(t, sizeof t, "{\"action\":\"multi-insert\",\"index\":%u,\"elemId\":", ed.index);
         out += t;
-        op_id(ir.e_elem[i]);
-        uint32_t tl = ir.row_val_tl[row];
+        if (!op_id(ed.elem_ctr, ed.elem_actor)) return false;
+        uint32_t tl = val.tl;
         if (has_datatype(tl) && (tl & 15) != 0) { out += ",\"datatype\":"; datatype(tl & 15); }  // only truthy datatypes (new.js:762)
         out += ",\"values\":[";
-        for (uint32_t k = i; k < j; k++) {
-          if (k > i) out.push_back(',');
-          if (!prim_value(ir.e_row[k])) return false;
+        for (uint32_t k = v0; k < v1; k++) {
+          if (k > v0) out.push_back(',');
+          if (!prim_value(ir.values[k].tl, ir.values[k].off)) return false;
         }
         out += "]}";
-      } else if (f & 1) {
-        snprintf(t, sizeof t, "{\"action\":\"update\",\"index\":%u,\"opId\":", ir.e_index[i]);
+      } else if (ed.flags & AM355_EDIT_UPDATE) {
+        snprintf(t, sizeof t, "{\"action\":\"update\",\"index\":%u,\"opId\":", ed.index);
         out += t;
-        op_id(row);
+        if (!op_id(ed.id_ctr, ed.id_actor)) return false;
         out += ",\"value\":";
-        if (!value_of_row(row, (f & 4) != 0)) return false;
+        if (!value(val.tl, val.off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
         out.push_back('}');
       } else {
-        snprintf(t, sizeof t, "{\"action\":\"insert\",\"index\":%u,\"elemId\":", ir.e_index[i]);
+        snprintf(t, sizeof t, "{\"action\":\"insert\",\"index\":%u,\"elemId\":", ed.index);
         out += t;
-        op_id(ir.e_elem[i]);
+        if (!op_id(ed.elem_ctr, ed.elem_actor)) return false;
         out += ",\"opId\":";
-        op_id(row);
+        if (!op_id(ed.id_ctr, ed.id_actor)) return false;
         out += ",\"value\":";
-        if (!value_of_row(row, (f & 4) != 0)) return false;
+        if (!value(val.tl, val.off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
         out.push_back('}');
       }
-      i = j;
     }
     return true;
   }
 
   // Long edit lists (a Text object holds one edit per character run) are rendered by several host threads, each into its
-  // own buffer, split where no multi-insert run is cut; the pieces are then joined. Same text as the serial walk.
+  // own buffer (an edit record is a whole edit, so any split point will do); the pieces are then joined. Same text as the serial walk.
   bool edits(uint32_t b, uint32_t e) {
     // (AM355_RENDER_CHUNK: edits per thread below which the walk stays serial; the tests lower it to exercise the join)
     const char* env = getenv("AM355_RENDER_CHUNK");
@@ -301,7 +301,6 @@ struct R {
     std::vector<uint32_t> cut{b};
     for (uint32_t k = 1; k < want; k++) {
       uint32_t c = b + (uint32_t)((uint64_t)(e - b) * k / want);
-      while (c < e && (ir.e_flags[c] & 2)) c++;  // never inside a multi-insert run
       if (c > cut.back() && c < e) cut.push_back(c);
     }
     cut.push_back(e);
@@ -330,10 +329,10 @@ struct R {
   bool object(uint32_t oi) {
     if (oi >= ir.n_objects) return fail("internal: object index out of range");
     if (++depth > 100000) return fail("unsupported: object nesting too deep");
-    uint32_t mk = ir.obj_make_row[oi];
-    uint32_t type = oi == 0 ? 0 : ir.row_action[mk];
+    const am355_ir_object& ob = ir.objects[oi];
+    uint32_t type = oi == 0 ? 0 : ob.type;
     out += "{\"objectId\":";
-    if (oi == 0) out += "\"_root\""; else op_id(mk);
+    if (oi == 0) out += "\"_root\""; else if (!op_id(ob.id_ctr, ob.id_actor)) return false;
     out += ",\"type\":";
     switch (type) {
       case 0: out += "\"map\""; break;
@@ -344,21 +343,22 @@ struct R {
     }
     if (oi != 0 && (type == 2 || type == 4)) {
       out += ",\"edits\":[";
-      uint32_t b = ir.obj_edit_begin[oi], e = ir.obj_edit_end[oi];
+      uint32_t b = ob.edit_begin, e = ob.edit_end;
+      if (b > e || e > ir.n_edits) return fail("internal: edit range out of bounds");
       if (!edits(b, e)) return false;
       out += "]}";
     } else {
       out += ",\"props\":{";
-      uint32_t b = ir.obj_map_begin[oi], e = ir.obj_map_end[oi];
+      uint32_t b = ob.map_begin, e = ob.map_end;
+      if (b > e || e > ir.n_map) return fail("internal: map range out of bounds");
       // group by key; integer-like keys first in numeric order, then the rest in (already sorted) key order
       struct Grp { uint32_t b, e; uint64_t num; bool is_index; };
       std::vector<Grp> groups;
       for (uint32_t i = b; i < e;) {
         uint32_t j = i + 1;
-        while (j < e && same_key(ir.m_row[i], ir.m_row[j])) j++;
+        while (j < e && same_key(ir.map[i], ir.map[j])) j++;
         Grp g{i, j, 0, false};
-        uint32_t r = ir.m_row[i];
-        g.is_index = array_index_key(ir.arena + ir.row_key_off[r], ir.row_key_len[r], g.num);
+        g.is_index = array_index_key(ir.arena + ir.map[i].key_off, ir.map[i].key_len, g.num);
         groups.push_back(g);
         i = j;
       }

@@ -102,7 +102,6 @@ int am355_get_stats(const am355_ctx *ctx, am355_stats *out);
 /* 32-byte SHA-256 change hashes in input order (columnar.js:693-705). `out` holds 32 * n_changes bytes. */
 int am355_get_hashes(const am355_ctx *ctx, uint8_t *out);
 
-/* Raw (uncompressed) arena as staged by am355_load_changes: pointer valid until the next load. */
 /* Input indexes of the applied changes, in application order (what BackendDoc.changes holds, backend/new.js:1847, and
  * Backend.getAllChanges returns, new.js:1924-1927): duplicates and queued changes do not appear. Valid after am355_replay
  * of changes. out may be NULL to query the count. */
@@ -117,21 +116,60 @@ int am355_get_applied(const am355_ctx *ctx, uint32_t *out, uint32_t *n_applied);
  * *bytes is owned by ctx and valid until the next am355_save / am355_destroy. */
 int am355_save(am355_ctx *ctx, uint32_t flags, const uint8_t **bytes, size_t *len);
 
+/* Raw (uncompressed) arena as staged by am355_load_changes: pointers valid until the next load. */
 int am355_get_raw(const am355_ctx *ctx, const uint8_t **arena, const uint64_t **offsets, uint32_t *n_changes);
 
 /*
- * Patch IR on the host (valid after am355_patch_json or am355_fetch_ir; owned by ctx).  This is what the N-API
- * addon hands to JavaScript as ArrayBuffers; automerge_classic_amd/js/materialize.js turns it into the patch
- * object.  Rows index the op-row table (row_*), values and keys are byte ranges of the raw arena.
+ * Patch IR on the host (valid after am355_fetch_ir or am355_patch_json; owned by ctx, pinned memory).  This is the OUTPUT of the
+ * hot path: four record tables written by the device in exactly this layout and copied to the host as they are (four copies).
+ * The N-API addon hands them to JavaScript as external ArrayBuffers and automerge_classic_amd/js/materialize.js builds the patch
+ * object from them; am355_patch_json renders the same tables as JSON text.  Values and map keys are byte ranges of the raw
+ * arena; op ids are (counter, actor rank) with the actor table in the envelope.
+ *
+ *   objects   index 0 is _root, then the make ops in application order.  A map/table object owns the map records
+ *             [map_begin, map_end), a list/text object the edit records [edit_begin, edit_end).
+ *   map       one record per visible value of a map key (conflicts: several records with the same key), sorted by (object, key in
+ *             UTF-16 code unit order, op id)  -- new.js:1035-1039 `props[key][opId] = value`.
+ *   edits     one record per edit of the reference's whole-document patch, in document order: insert, update, or multi-insert
+ *             (new.js:747-782 appendEdit; a record with count >= 2 values is a multi-insert: consecutive op ids of one actor,
+ *             elemId == opId, same value class).  Record k owns the values [first, edits[k+1].first); the table ends with a
+ *             sentinel record whose `first` is n_values.
+ *   values    (type/length word as in the valLen column: len << 4 | type, columnar.js:300-329; offset of the bytes in the arena)
  */
 typedef struct {
-  uint32_t n_objects, n_map, n_edits, n_rows;
-  const uint32_t *obj_make_row, *obj_map_begin, *obj_map_end, *obj_edit_begin, *obj_edit_end;
-  const uint32_t *m_row, *m_flags;
-  const int64_t *m_counter;
-  const uint32_t *e_row, *e_elem, *e_index, *e_flags;
-  /* op-row table (all applied ops in decode order) */
-  const uint32_t *row_id_ctr, *row_id_actor, *row_action, *row_val_tl, *row_val_off, *row_key_off, *row_key_len, *row_obj_index;
+  uint32_t id_ctr, id_actor;      /* objectId = id_ctr@actor (ignored for _root) */
+  uint32_t type;                  /* action of the make op: 0 makeMap, 2 makeList, 4 makeText, 6 makeTable */
+  uint32_t map_begin, map_end;    /* map / table: range of map records */
+  uint32_t edit_begin, edit_end;  /* list / text: range of edit records */
+  uint32_t make_row;              /* (engine-internal: op row of the make op) */
+} am355_ir_object;
+enum { AM355_MAP_COUNTER = 1u, AM355_MAP_CHILD = 2u };
+typedef struct {
+  uint32_t id_ctr, id_actor;      /* opId under which the value is listed */
+  uint32_t key_off, key_len;      /* key bytes (UTF-8) in the arena */
+  uint32_t val_tl, val_off;       /* value; AM355_MAP_CHILD: val_off = object index */
+  uint32_t flags, pad;
+  int64_t counter;                /* AM355_MAP_COUNTER: the counter's total (new.js:937-967) */
+} am355_ir_map;
+enum { AM355_EDIT_UPDATE = 1u, AM355_EDIT_CHILD = 4u };
+typedef struct {
+  uint32_t flags;                 /* AM355_EDIT_UPDATE: `update` edit (else insert / multi-insert); AM355_EDIT_CHILD: the value is an object */
+  uint32_t index;                 /* list index */
+  uint32_t id_ctr, id_actor;      /* opId */
+  uint32_t elem_ctr, elem_actor;  /* elemId */
+  uint32_t first;                 /* first value record of this edit */
+  uint32_t pad;
+} am355_ir_edit;
+typedef struct {
+  uint32_t tl, off;               /* AM355_EDIT_CHILD edits: off = object index */
+} am355_ir_value;
+
+typedef struct {
+  uint32_t n_objects, n_map, n_edits, n_values;
+  const am355_ir_object *objects; /* [n_objects] */
+  const am355_ir_map *map;        /* [n_map] */
+  const am355_ir_edit *edits;     /* [n_edits + 1] (sentinel) */
+  const am355_ir_value *values;   /* [n_values] */
   /* envelope */
   uint64_t max_op;
   uint32_t n_actors;            /* actors by rank (lexicographic order of raw ids) */
@@ -144,6 +182,7 @@ typedef struct {
   const uint8_t *heads;         /* 32 bytes each, sorted */
   uint32_t pending;
   const uint8_t *arena;         /* raw arena (values and keys are ranges of it) */
+  uint64_t arena_len;
 } am355_patch_ir;
 int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
 
