@@ -14,6 +14,7 @@
 #include "am355_encode.h"
 #include "am355_prims.h"
 #include "am355_render.h"
+#include "am355_host.h"
 
 #include <zlib.h>
 
@@ -21,7 +22,11 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -73,6 +78,92 @@ struct HostBuf {
   template <class T> T* as() { return (T*)p; }
 };
 
+// Byte vector in pinned host memory (the raw arena: the H2D copy of pageable memory is a synchronous bounce through the
+// driver's own staging buffer).
+struct PinnedBytes {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  ~PinnedBytes() { if (p) (void)hipHostFree(p); }
+  uint8_t* data() { return p; }
+  const uint8_t* data() const { return p; }
+  size_t size() const { return n; }
+  void clear() { n = 0; }
+  uint8_t& back() { return p[n - 1]; }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    size_t c2 = std::max(want + want / 8 + 4096, cap * 2);
+    void* q = nullptr;
+    if (hipHostMalloc(&q, c2, hipHostMallocDefault) != hipSuccess) throw std::bad_alloc();
+    if (n) memcpy(q, p, n);
+    if (p) (void)hipHostFree(p);
+    p = (uint8_t*)q;
+    cap = c2;
+  }
+  void resize(size_t want) { reserve(want); n = want; }
+  void push_back(uint8_t b) { reserve(n + 1); p[n++] = b; }
+  void append(const uint8_t* a, const uint8_t* b) { size_t k = (size_t)(b - a); reserve(n + k); if (k) memcpy(p + n, a, k); n += k; }
+};
+
+// A few persistent host threads for the byte-shovelling around the device work: gather of the change buffers into the pinned
+// arena (+ the H2D copy of each slice), raw-DEFLATE of compressed changes / document columns, the document checksum.
+// run(k, fn) executes fn(0..k-1), one index per worker at a time, and returns when all are done.
+class HostPool {
+ public:
+  explicit HostPool(unsigned n) {
+    for (unsigned i = 0; i < n; i++) workers_.emplace_back([this]() { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  unsigned size() const { return (unsigned)workers_.size(); }
+  void run(unsigned k, const std::function<void(unsigned)>& fn) {
+    if (k == 0) return;
+    if (k == 1 || workers_.empty()) { for (unsigned i = 0; i < k; i++) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> l(m_);
+      fn_ = &fn; next_ = 0; total_ = k; done_ = 0; gen_++;
+    }
+    cv_.notify_all();
+    // the caller works too
+    for (;;) {
+      unsigned i;
+      { std::lock_guard<std::mutex> l(m_); if (next_ >= total_) break; i = next_++; }
+      fn(i);
+      { std::lock_guard<std::mutex> l(m_); done_++; }
+    }
+    std::unique_lock<std::mutex> l(m_);
+    cv_done_.wait(l, [&]() { return done_ == total_; });
+    fn_ = nullptr;
+  }
+ private:
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> l(m_);
+      cv_.wait(l, [&]() { return stop_ || (gen_ != seen && fn_ && next_ < total_); });
+      if (stop_) return;
+      seen = gen_;
+      while (fn_ && next_ < total_) {
+        unsigned i = next_++;
+        const std::function<void(unsigned)>* f = fn_;
+        l.unlock();
+        (*f)(i);
+        l.lock();
+        if (++done_ == total_) cv_done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, cv_done_;
+  const std::function<void(unsigned)>* fn_ = nullptr;
+  unsigned next_ = 0, total_ = 0, done_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
 struct Hash32 {
   uint8_t b[32];
   bool operator==(const Hash32& o) const { return memcmp(b, o.b, 32) == 0; }
@@ -96,7 +187,8 @@ struct am355_ctx {
   uint32_t flags = 0;
 
   // staged batch
-  std::vector<uint8_t> raw;        // uncompressed changes, host copy (the scheduler reads deps / actor ids here)
+  PinnedBytes raw;                 // uncompressed changes, host copy in pinned memory (the scheduler reads deps / actor ids here)
+  std::unique_ptr<HostPool> pool;  // host worker threads (staging, inflate, checksum)
   std::vector<uint64_t> raw_off;
   uint32_t n_changes = 0;
   bool staged = false, replayed = false, ir_fetched = false;
@@ -105,7 +197,7 @@ struct am355_ctx {
   ChangeMeta doc_meta{};             // column layout of the staged document inside `raw`
   std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
   DevBuf d_arena, d_offsets, d_metas;
-  HostBuf h_metas;
+  HostBuf h_metas, h_offsets;
   DevBuf d_big, d_bigvals, d_ks;     // document load: token / record index, column values, keyStr run table
   HostBuf h_biginfo;
   BigColDesc doc_cols{};
@@ -200,6 +292,12 @@ extern "C" am355_ctx* am355_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   am355_ctx* c = new am355_ctx();
   c->device = device;
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    const char* env = getenv("AM355_HOST_THREADS");
+    unsigned want = env && atoi(env) > 0 ? (unsigned)atoi(env) : std::min(hw ? hw : 4u, 16u);
+    c->pool.reset(new HostPool(want > 1 ? want - 1 : 0));  // (the calling thread works too)
+  }
   // the decode/merge stream outranks the hash stream: their small grids would otherwise share SIMDs and the
   // ALU-dense SHA-256 waves slow the latency-bound parse/decode waves down
   int prio_low = 0, prio_high = 0;
@@ -235,7 +333,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
-  for (HostBuf* b : {&c->h_metas, &c->h_counts, &c->h_ir, &c->h_rows, &c->h_biginfo, &c->h_encout}) b->release();
+  for (HostBuf* b : {&c->h_metas, &c->h_offsets, &c->h_counts, &c->h_ir, &c->h_rows, &c->h_biginfo, &c->h_encout}) b->release();
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -260,43 +358,6 @@ static bool read_uleb_host(const uint8_t* p, size_t len, size_t& off, uint64_t& 
   return false;
 }
 
-// Raw DEFLATE of one stream (columnar.js:813-823, 1062-1067; the reference calls pako.inflateRaw). Returns 0 on success, 1 on
-// malformed / truncated data, 2 when the inflated size would pass `cap`, 3 on allocation failure. The output buffer only grows
-// when zlib has actually filled it: Z_BUF_ERROR with input exhausted and output space left is a truncated stream, not "retry
-// with more room" (a truncated stream must end in a catchable error as in the reference, not in an endless reallocation).
-static int inflate_raw(const uint8_t* in, size_t in_len, std::vector<uint8_t>& out, size_t cap) {
-  z_stream zs;
-  memset(&zs, 0, sizeof zs);
-  if (inflateInit2(&zs, -15) != Z_OK) return 3;
-  out.resize(std::min<size_t>(std::max<size_t>(in_len * 4, 1024), cap));
-  size_t in_off = 0, produced = 0;
-  int result = 1;
-  for (;;) {
-    if (zs.avail_in == 0 && in_off < in_len) {
-      size_t take = std::min<size_t>(in_len - in_off, 1u << 30);
-      zs.next_in = (Bytef*)(in + in_off);
-      zs.avail_in = (uInt)take;
-      in_off += take;
-    }
-    if (produced == out.size()) {
-      if (out.size() >= cap) { result = 2; break; }
-      out.resize(std::min<size_t>(out.size() * 2, cap));
-    }
-    size_t room = std::min<size_t>(out.size() - produced, 1u << 30);
-    zs.next_out = out.data() + produced;
-    zs.avail_out = (uInt)room;
-    int rc = inflate(&zs, Z_NO_FLUSH);
-    produced += room - zs.avail_out;
-    if (rc == Z_STREAM_END) { result = 0; break; }
-    if (rc == Z_OK) continue;
-    if (rc == Z_BUF_ERROR && zs.avail_out == 0) continue;  // output full: grow and go on
-    result = rc == Z_MEM_ERROR ? 3 : 1;                     // Z_DATA_ERROR, or Z_BUF_ERROR with the input exhausted = truncated
-    break;
-  }
-  inflateEnd(&zs);
-  out.resize(result == 0 ? produced : 0);
-  return result;
-}
 constexpr size_t INFLATE_CAP = 0xfff00000ull;  // one staged batch / document is addressed with 32-bit arena offsets
 
 static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
@@ -308,41 +369,100 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   for (uint32_t i = 0; i < n; i++)
     if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
   if (offsets[n] - offsets[0] >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }
-  c->raw.clear();
-  c->raw_off.assign(1, 0);
-  c->raw.reserve((size_t)(offsets[n] - offsets[0]) + 64);
-  for (uint32_t i = 0; i < n; i++) {
-    const uint8_t* p = arena + offsets[i];
-    size_t len = offsets[i + 1] - offsets[i];
-    if (len > 9 && p[8] == 2) {
-      // chunk type 2: rebuild the uncompressed container (columnar.js:813-823); the checksum/hash are over that form
-      size_t off = 9;
-      uint64_t clen;
-      if (!read_uleb_host(p, len, off, clen) || clen > len - off) { c->flags |= AM355_F_BAD_CHUNK; return fail(c, AM355_E_INVALID, "change %u: bad deflate container", i); }
-      std::vector<uint8_t> out;
-      int irc = inflate_raw(p + off, (size_t)clen, out, INFLATE_CAP);
-      if (irc == 3) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
-      if (irc == 2) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "change %u: inflated size beyond the 4 GiB batch limit", i); }
-      if (irc) { c->flags |= AM355_F_BAD_DEFLATE; return fail(c, AM355_E_INVALID, "change %u: invalid or truncated deflate data", i); }
-      size_t outlen = out.size();
-      if (c->raw.size() + outlen >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch inflates beyond the 4 GiB limit"); }
-      c->raw.insert(c->raw.end(), p, p + 8);
-      c->raw.push_back(1);
-      uint64_t v = outlen;
-      do { uint8_t x = v & 0x7f; v >>= 7; if (v) x |= 0x80; c->raw.push_back(x); } while (v);
-      c->raw.insert(c->raw.end(), out.begin(), out.begin() + outlen);
-    } else {
-      c->raw.insert(c->raw.end(), p, p + len);
+  // ---- gather into the pinned raw arena + H2D, in slices handled by the host pool ----
+  // Slice k covers a contiguous run of changes of about equal bytes. Phase A (parallel): changes of chunk type 2 are inflated
+  // and their uncompressed containers rebuilt (columnar.js:813-823; checksum / hash are over that form) into a slice-local
+  // buffer; a slice without compressed changes has nothing to do. Then the slice sizes are summed (host, O(slices)) and
+  // phase B (parallel) copies every slice to its place in the pinned arena, fills its offsets and enqueues its H2D copy, so
+  // that the DMA engine works on early slices while the host threads are still gathering later ones.
+  const size_t in_bytes = (size_t)(offsets[n] - offsets[0]);
+  unsigned n_slices = 1;
+  if (in_bytes >= (1u << 20) && n >= 16) n_slices = (unsigned)std::min<size_t>({(size_t)(c->pool->size() + 1) * 2, in_bytes >> 19, (size_t)n / 8});
+  if (n_slices < 1) n_slices = 1;
+  struct Slice { uint32_t c0 = 0, c1 = 0; size_t out_bytes = 0, base = 0; bool any_deflated = false; int err = 0; uint32_t err_change = 0; std::vector<uint8_t> tmp; std::vector<uint32_t> tmp_len; };
+  std::vector<Slice> slices(n_slices);
+  {
+    uint32_t ci = 0;
+    for (unsigned k = 0; k < n_slices; k++) {
+      slices[k].c0 = ci;
+      uint64_t target = offsets[0] + (uint64_t)in_bytes * (k + 1) / n_slices;
+      while (ci < n && (k + 1 == n_slices || offsets[ci + 1] <= target)) ci++;
+      slices[k].c1 = ci;
     }
-    c->raw_off.push_back(c->raw.size());
+    slices[n_slices - 1].c1 = n;
   }
-  if (c->raw.size() >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)");
+  auto phase_a = [&](unsigned k) {
+    Slice& sl = slices[k];
+    for (uint32_t i = sl.c0; i < sl.c1; i++) {
+      size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+      if (len > 9 && arena[offsets[i] + 8] == 2) { sl.any_deflated = true; break; }
+    }
+    if (!sl.any_deflated) { sl.out_bytes = (size_t)(offsets[sl.c1] - offsets[sl.c0]); return; }
+    sl.tmp_len.resize(sl.c1 - sl.c0);
+    std::vector<uint8_t> out;
+    for (uint32_t i = sl.c0; i < sl.c1 && !sl.err; i++) {
+      const uint8_t* p = arena + offsets[i];
+      size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+      size_t before = sl.tmp.size();
+      if (len > 9 && p[8] == 2) {
+        size_t off = 9;
+        uint64_t clen;
+        if (!read_uleb_host(p, len, off, clen) || clen > len - off) { sl.err = 10; sl.err_change = i; break; }
+        int irc = inflate_raw(p + off, (size_t)clen, out, INFLATE_CAP);
+        if (irc) { sl.err = irc; sl.err_change = i; break; }
+        sl.tmp.insert(sl.tmp.end(), p, p + 8);
+        sl.tmp.push_back(1);
+        uint64_t v = out.size();
+        do { uint8_t x = v & 0x7f; v >>= 7; if (v) x |= 0x80; sl.tmp.push_back(x); } while (v);
+        sl.tmp.insert(sl.tmp.end(), out.begin(), out.end());
+      } else {
+        sl.tmp.insert(sl.tmp.end(), p, p + len);
+      }
+      if (sl.tmp.size() >= INFLATE_CAP) { sl.err = 2; sl.err_change = i; break; }
+      sl.tmp_len[i - sl.c0] = (uint32_t)(sl.tmp.size() - before);
+    }
+    sl.out_bytes = sl.tmp.size();
+  };
+  c->pool->run(n_slices, phase_a);
+  size_t total = 0;
+  for (Slice& sl : slices) {
+    if (sl.err == 10) { c->flags |= AM355_F_BAD_CHUNK; return fail(c, AM355_E_INVALID, "change %u: bad deflate container", sl.err_change); }
+    if (sl.err == 3) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
+    if (sl.err == 2) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "change %u: inflated size beyond the 4 GiB batch limit", sl.err_change); }
+    if (sl.err) { c->flags |= AM355_F_BAD_DEFLATE; return fail(c, AM355_E_INVALID, "change %u: invalid or truncated deflate data", sl.err_change); }
+    sl.base = total;
+    total += sl.out_bytes;
+    if (total >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }
+  }
+  c->raw.resize(total);
+  c->raw_off.resize((size_t)n + 1);
+  c->raw_off[n] = total;
   c->n_changes = n;
-  if (!c->d_arena.ensure(c->raw.size() + 64) || !c->d_offsets.ensure(sizeof(uint64_t) * (n + 1)) || !c->d_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) ||
-      !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) || !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)))
+  if (!c->d_arena.ensure(total + 64) || !c->d_offsets.ensure(sizeof(uint64_t) * (n + 1)) || !c->d_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) ||
+      !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) || !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)) ||
+      !c->h_offsets.ensure(sizeof(uint64_t) * ((size_t)n + 1)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
-  HIPCHK(c, hipMemcpyAsync(c->d_arena.p, c->raw.data(), c->raw.size(), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->raw_off.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, c->stream));
+  uint8_t* raw = c->raw.data();
+  uint64_t* roff = c->raw_off.data();
+  std::vector<hipError_t> h2d(n_slices, hipSuccess);
+  auto phase_b = [&](unsigned k) {
+    Slice& sl = slices[k];
+    (void)hipSetDevice(c->device);
+    if (sl.any_deflated) {
+      if (sl.out_bytes) memcpy(raw + sl.base, sl.tmp.data(), sl.out_bytes);
+      size_t o = sl.base;
+      for (uint32_t i = sl.c0; i < sl.c1; i++) { roff[i] = o; o += sl.tmp_len[i - sl.c0]; }
+    } else {
+      if (sl.out_bytes) memcpy(raw + sl.base, arena + offsets[sl.c0], sl.out_bytes);
+      for (uint32_t i = sl.c0; i < sl.c1; i++) roff[i] = sl.base + (offsets[i] - offsets[sl.c0]);
+    }
+    if (sl.out_bytes) h2d[k] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + sl.base, raw + sl.base, sl.out_bytes, hipMemcpyHostToDevice, c->stream);
+  };
+  c->pool->run(n_slices, phase_b);
+  for (hipError_t e : h2d)
+    if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (arena): %s", hipGetErrorString(e));
+  memcpy(c->h_offsets.p, roff, sizeof(uint64_t) * ((size_t)n + 1));  // (pinned mirror: the copy below must not bounce through the driver)
+  HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->h_offsets.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->staged = true;
   c->stats = am355_stats{};
@@ -358,46 +478,6 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
 // metadata (clock); the op columns go to HBM for the device decode + patch.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
-struct HostSha256 {
-  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-  void block(const uint8_t* p) {
-    static const uint32_t K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
-        0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
-        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
-        0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
-        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
-        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-    uint32_t w[64];
-    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
-    for (int i = 16; i < 64; i++) {
-      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
-      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-    }
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-    for (int i = 0; i < 64; i++) {
-      uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
-      uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-  }
-  void digest(const uint8_t* p, size_t len, uint8_t out[32]) {
-    size_t i = 0;
-    for (; i + 64 <= len; i += 64) block(p + i);
-    uint8_t tail[128] = {0};
-    size_t rem = len - i, tl = rem < 56 ? 64 : 128;
-    memcpy(tail, p + i, rem);
-    tail[rem] = 0x80;
-    uint64_t bits = (uint64_t)len * 8;
-    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
-    block(tail);
-    if (tl == 128) block(tail + 64);
-    for (int k = 0; k < 8; k++) { out[4 * k] = h[k] >> 24; out[4 * k + 1] = h[k] >> 16; out[4 * k + 2] = h[k] >> 8; out[4 * k + 3] = h[k]; }
-  }
-};
-
 // host-side RLE-uint / delta reader for the (small) change-metadata columns
 struct HostRle {
   const uint8_t* p; size_t len, off = 0; int64_t count = 0; int state = 0; int64_t last = 0; bool last_null = true; bool is_signed;
@@ -436,16 +516,28 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   c->staged = c->replayed = c->ir_fetched = false;
   c->is_document = true;
   c->flags = 0;
-  c->doc_bytes.assign(doc, doc + len);
-  auto bad = [&](uint32_t flag, const char* msg) { c->flags |= flag; return fail(c, AM355_E_INVALID, "%s", msg); };
-  if (len < 10 || doc[0] != 0x85 || doc[1] != 0x6f || doc[2] != 0x4a || doc[3] != 0x83) return bad(AM355_F_BAD_MAGIC, "Data does not begin with magic bytes 85 6f 4a 83");
+  auto bad0 = [&](uint32_t flag, const char* msg) { c->flags |= flag; return fail(c, AM355_E_INVALID, "%s", msg); };
+  if (len < 10 || doc[0] != 0x85 || doc[1] != 0x6f || doc[2] != 0x4a || doc[3] != 0x83) return bad0(AM355_F_BAD_MAGIC, "Data does not begin with magic bytes 85 6f 4a 83");
   size_t off = 9;
   uint64_t clen;
-  if (!read_uleb_host(doc, len, off, clen) || clen != len - off) return bad(AM355_F_BAD_CHUNK, "Encoded document has trailing data or is truncated");
-  if (doc[8] != 0) return bad(AM355_F_BAD_CHUNK, "Unexpected chunk type");
-  uint8_t digest[32];
-  HostSha256().digest(doc + 8, len - 8, digest);
-  if (memcmp(digest, doc + 4, 4) != 0) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
+  if (!read_uleb_host(doc, len, off, clen) || clen != len - off) return bad0(AM355_F_BAD_CHUNK, "Encoded document has trailing data or is truncated");
+  if (doc[8] != 0) return bad0(AM355_F_BAD_CHUNK, "Unexpected chunk type");
+  // The chunk checksum (one SHA-256 over the whole chunk: sequential by construction) runs on a pool thread beside the column
+  // inflates below. The reference verifies it before it reads the header (columnar.js:699-705), so a malformed header is only
+  // reported once the checksum is known to match.
+  bool sum_done = false, sum_ok = false;
+  auto check_sum = [&]() {
+    uint8_t digest[32];
+    sha256_digest(doc + 8, len - 8, digest);
+    sum_ok = memcmp(digest, doc + 4, 4) == 0;
+    sum_done = true;
+  };
+  auto bad = [&](uint32_t flag, const char* msg) {
+    if (!sum_done) check_sum();
+    if (!sum_ok) { flag = AM355_F_BAD_CHECKSUM; msg = "checksum does not match data"; }
+    c->flags |= flag;
+    return fail(c, AM355_E_INVALID, "%s", msg);
+  };
   const uint8_t* h = doc + off;
   size_t hl = (size_t)clen, ho = 0;
   uint64_t na, nh;
@@ -476,32 +568,47 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   };
   std::vector<Col> ccols, ocols;
   if (!read_dir(ccols) || !read_dir(ocols)) return bad(AM355_F_BAD_COLUMNS, "bad column directory");
-  auto read_data = [&](std::vector<Col>& cols) -> int {
-    for (Col& col : cols) {
-      if (col.len > hl - ho) return 1;
-      const uint8_t* p = h + ho;
-      ho += (size_t)col.len;
-      if (col.id & 8) {
-        std::vector<uint8_t> out;
-        int irc = inflate_raw(p, (size_t)col.len, out, INFLATE_CAP);
-        if (irc) return irc == 1 ? 2 : irc == 2 ? 3 : 4;
-        col.data = std::move(out);
-        col.p = col.data.data();
-        col.n = col.data.size();
-        col.id ^= 8;
-      } else {
-        col.p = p;
-        col.n = (size_t)col.len;
-      }
+  // column slices, then: checksum | copy of the document bytes (Backend.save of an unchanged document returns them, new.js:2034) |
+  // raw-DEFLATE of every compressed column (columnar.js:1062-1067), all on the host pool, longest columns first
+  std::vector<Col*> all_cols;
+  for (Col& col : ccols) all_cols.push_back(&col);
+  for (Col& col : ocols) all_cols.push_back(&col);
+  for (Col* col : all_cols) {
+    if (col->len > hl - ho) return bad(AM355_F_BAD_CHUNK, "document columns exceed the chunk");
+    col->p = h + ho;
+    col->n = (size_t)col->len;
+    ho += (size_t)col->len;
+  }
+  {
+    std::vector<Col*> deflated;
+    for (Col* col : all_cols)
+      if (col->id & 8) deflated.push_back(col);
+    std::sort(deflated.begin(), deflated.end(), [](const Col* x, const Col* y) { return x->len > y->len; });
+    std::vector<int> irc(deflated.size(), 0);
+    const unsigned n_tasks = (unsigned)deflated.size() + 2;
+    c->pool->run(n_tasks, [&](unsigned t) {
+      // (the two longest columns first, then the checksum, which takes about as long as a mid-sized column)
+      unsigned sum_slot = std::min<unsigned>(2, (unsigned)deflated.size()), copy_slot = sum_slot + 1;
+      if (t == sum_slot) { check_sum(); return; }
+      if (t == copy_slot) { c->doc_bytes.assign(doc, doc + len); return; }
+      size_t k = t < sum_slot ? t : t - 2;
+      Col* col = deflated[k];
+      irc[k] = inflate_raw(col->p, (size_t)col->len, col->data, INFLATE_CAP);
+    });
+    if (!sum_ok) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
+    int rd = 0;
+    for (Col* col : all_cols) {  // (errors in column order, as a sequential reader would meet them)
+      if (!(col->id & 8)) continue;
+      size_t k = (size_t)(std::find(deflated.begin(), deflated.end(), col) - deflated.begin());
+      if (irc[k]) { rd = irc[k] == 1 ? 2 : irc[k] == 2 ? 3 : 4; break; }
+      col->p = col->data.data();
+      col->n = col->data.size();
+      col->id ^= 8;
     }
-    return 0;
-  };
-  int rd = read_data(ccols);
-  if (!rd) rd = read_data(ocols);
-  if (rd == 1) return bad(AM355_F_BAD_CHUNK, "document columns exceed the chunk");
-  if (rd == 2) return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
-  if (rd == 3) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "document column inflates beyond the 4 GiB limit"); }
-  if (rd == 4) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
+    if (rd == 2) return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
+    if (rd == 3) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "document column inflates beyond the 4 GiB limit"); }
+    if (rd == 4) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
+  }
   // (headsIndexes and extraBytes follow; neither influences the patch: kept for am355_save)
   c->doc_tail.assign(h + ho, h + hl);
   c->doc_chg_cols.clear();
@@ -557,11 +664,21 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   ChangeMeta& m = c->doc_meta;
   memset(&m, 0, sizeof m);
   m.n_entries = (uint32_t)na;
+  // (placement first -- offsets only --, the bytes follow in parallel pieces together with their H2D copies)
+  struct Piece { const uint8_t* src; size_t dst, n; };
+  std::vector<Piece> pieces;
+  size_t arena_bytes = 0;
+  uint8_t last_byte = 0;
   auto place = [&](int slot, uint64_t id) {
     Col* col = find(ocols, id);
-    m.col_off[slot] = (uint32_t)c->raw.size();
+    if (col && arena_bytes + col->n >= 0xfff00000ull) { arena_bytes = 0xfff00000ull; return; }
+    m.col_off[slot] = (uint32_t)arena_bytes;
     m.col_len[slot] = col ? (uint32_t)col->n : 0;
-    if (col) c->raw.insert(c->raw.end(), col->p, col->p + col->n);
+    if (col && col->n) {
+      for (size_t o = 0; o < col->n; o += (size_t)4 << 20) pieces.push_back(Piece{col->p + o, arena_bytes + o, std::min<size_t>((size_t)4 << 20, col->n - o)});
+      last_byte = col->p[col->n - 1];
+      arena_bytes += col->n;
+    }
   };
   // the LEB-tokenisable columns first (BigCol order), the two byte-string columns after them
   static const struct { int slot; uint64_t id; uint32_t kind; } big[BIG_NCOL] = {
@@ -574,21 +691,33 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     c->doc_cols.len[k] = m.col_len[big[k].slot];
     c->doc_cols.kind[k] = big[k].kind;
     // every column must end on the last byte of a number (the device finds numbers by their terminating bytes)
-    if (m.col_len[big[k].slot] && (c->raw.back() & 0x80)) return bad(AM355_F_BAD_LEB, "incomplete number");
+    if (m.col_len[big[k].slot] && (last_byte & 0x80)) return bad(AM355_F_BAD_LEB, "incomplete number");
   }
-  c->doc_cols.tok_bytes = (uint32_t)c->raw.size();
+  c->doc_cols.tok_bytes = (uint32_t)arena_bytes;
   place(C_KEY_STR, 0x15); place(C_VAL_RAW, 0x57);
   {
     const char* e = getenv("AM355_DOC_SERIAL");
     c->doc_serial = e && *e == '1';
   }
-  c->raw_off.push_back(c->raw.size());
-  if (c->raw.size() >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "document larger than 4 GiB (32-bit arena offsets)");
-  m.len = (uint32_t)c->raw.size();
-  if (!c->d_arena.ensure(c->raw.size() + 64) || !c->d_metas.ensure(sizeof(ChangeMeta)) || !c->h_metas.ensure(sizeof(ChangeMeta)) ||
+  if (arena_bytes >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "document larger than 4 GiB (32-bit arena offsets)");
+  c->raw.resize(arena_bytes);
+  c->raw_off.push_back(arena_bytes);
+  m.len = (uint32_t)arena_bytes;
+  if (!c->d_arena.ensure(arena_bytes + 64) || !c->d_metas.ensure(sizeof(ChangeMeta)) || !c->h_metas.ensure(sizeof(ChangeMeta)) ||
       !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
-  HIPCHK(c, hipMemcpyAsync(c->d_arena.p, c->raw.data(), c->raw.size(), hipMemcpyHostToDevice, c->stream));
+  {
+    std::vector<hipError_t> h2d(pieces.size(), hipSuccess);
+    uint8_t* raw = c->raw.data();
+    c->pool->run((unsigned)pieces.size(), [&](unsigned k) {
+      (void)hipSetDevice(c->device);
+      const Piece& pc = pieces[k];
+      memcpy(raw + pc.dst, pc.src, pc.n);
+      h2d[k] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + pc.dst, raw + pc.dst, pc.n, hipMemcpyHostToDevice, c->stream);
+    });
+    for (hipError_t e : h2d)
+      if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (document columns): %s", hipGetErrorString(e));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->staged = true;
   c->stats = am355_stats{};
@@ -1933,7 +2062,7 @@ static int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, si
   chunk.uleb(body.size());
   chunk.bytes(body.data(), body.size());
   uint8_t digest[32];
-  HostSha256().digest(chunk.data(), chunk.size(), digest);
+  sha256_digest(chunk.data(), chunk.size(), digest);
   c->saved.clear();
   static const uint8_t magic[4] = {0x85, 0x6f, 0x4a, 0x83};
   c->saved.insert(c->saved.end(), magic, magic + 4);
