@@ -376,8 +376,16 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   // phase B (parallel) copies every slice to its place in the pinned arena, fills its offsets and enqueues its H2D copy, so
   // that the DMA engine works on early slices while the host threads are still gathering later ones.
   const size_t in_bytes = (size_t)(offsets[n] - offsets[0]);
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "load_changes: %-22s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   unsigned n_slices = 1;
-  if (in_bytes >= (1u << 20) && n >= 16) n_slices = (unsigned)std::min<size_t>({(size_t)(c->pool->size() + 1) * 2, in_bytes >> 19, (size_t)n / 8});
+  // (AM355_SLICE_BYTES: bytes per slice, 2 MiB by default -- every H2D copy has a fixed cost of some microseconds --; the tests lower it to exercise the sliced path on small inputs)
+  const char* slice_env = getenv("AM355_SLICE_BYTES");
+  const size_t slice_bytes = slice_env && atol(slice_env) > 0 ? (size_t)atol(slice_env) : (size_t)1 << 21;
+  if (in_bytes >= 2 * slice_bytes && n >= 16) n_slices = (unsigned)std::min<size_t>({(size_t)(c->pool->size() + 1) * 2, in_bytes / slice_bytes, (size_t)n / 8});
   if (n_slices < 1) n_slices = 1;
   struct Slice { uint32_t c0 = 0, c1 = 0; size_t out_bytes = 0, base = 0; bool any_deflated = false; int err = 0; uint32_t err_change = 0; std::vector<uint8_t> tmp; std::vector<uint32_t> tmp_len; };
   std::vector<Slice> slices(n_slices);
@@ -424,6 +432,7 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
     sl.out_bytes = sl.tmp.size();
   };
   c->pool->run(n_slices, phase_a);
+  lap("inflate / sizes");
   size_t total = 0;
   for (Slice& sl : slices) {
     if (sl.err == 10) { c->flags |= AM355_F_BAD_CHUNK; return fail(c, AM355_E_INVALID, "change %u: bad deflate container", sl.err_change); }
@@ -459,11 +468,13 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
     if (sl.out_bytes) h2d[k] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + sl.base, raw + sl.base, sl.out_bytes, hipMemcpyHostToDevice, c->stream);
   };
   c->pool->run(n_slices, phase_b);
+  lap("gathered, H2D enqueued");
   for (hipError_t e : h2d)
     if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (arena): %s", hipGetErrorString(e));
   memcpy(c->h_offsets.p, roff, sizeof(uint64_t) * ((size_t)n + 1));  // (pinned mirror: the copy below must not bounce through the driver)
   HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->h_offsets.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  lap("H2D done");
   c->staged = true;
   c->stats = am355_stats{};
   c->stats.n_changes = n;
@@ -1100,7 +1111,7 @@ static int setup_buffers(am355_ctx* c) {
     size_t cw = carry_words(N);
     size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc + 2, 4) + 4 * carve_size(2 * Nc + 2, 4) +
                    3 * carve_size(Nc + 1, 4) + scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 256 +
-                   6 * carve_size(Nc + 3, 4) + 6 * carve_size(cw, 4);
+                   6 * carve_size(Nc + 3, 4) + 6 * carve_size(cw, 4) + carve_size(2048, 4);
     size_t sort_bytes = 2 * carve_size(Nc, 8) + 2 * carve_size(Nc, 4) + sort_workspace_bytes((uint32_t)Nc) + 256;
     size_t ir_bytes = carve_size(Nc + 1, sizeof(am355_ir_object)) + carve_size(Nc, sizeof(am355_ir_map)) + carve_size(Nc + 1, sizeof(am355_ir_edit)) +
                       carve_size(Nc, sizeof(am355_ir_value)) + 4 * carve_size(Nc, 4);
@@ -1122,18 +1133,23 @@ static int setup_buffers(am355_ctx* c) {
     b.em_row = carve<uint32_t>(p, Nc); b.ins_row = carve<uint32_t>(p, Nc); b.upd_row = carve<uint32_t>(p, Nc); b.next_sib = carve<uint32_t>(p, Nc);
     b.em_trig = carve<unsigned long long>(p, Nc);
     b.kind = carve<uint8_t>(p, Nc);
+    // order | first_child | child_head (start of euler_b) are contiguous: one 0xff fill per replay (merge_prepare)
+    b.order = carve<uint32_t>(p, Nc + 1);
     b.first_child = carve<uint32_t>(p, 2 * Nc + 2);
-    b.euler_a = carve<unsigned long long>(p, 2 * Nc + 2); b.euler_b = carve<unsigned long long>(p, 2 * Nc + 2);
-    b.order = carve<uint32_t>(p, Nc + 1); b.scan_a = carve<uint32_t>(p, Nc + 1); b.scan_b = carve<uint32_t>(p, Nc + 1);
+    b.euler_b = carve<unsigned long long>(p, 2 * Nc + 2); b.euler_a = carve<unsigned long long>(p, 2 * Nc + 2);
+    b.scan_a = carve<uint32_t>(p, Nc + 1); b.scan_b = carve<uint32_t>(p, Nc + 1);
     b.scan_ws = p;
     p += (scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 255) & ~(size_t)255;
     b.run_heads = carve<uint32_t>(p, Nc + 3); b.row_run = carve<uint32_t>(p, Nc + 3); b.obj_n = carve<uint32_t>(p, Nc + 3);
     b.obj_first_pos = carve<uint32_t>(p, Nc + 3); b.list_vis = carve<uint32_t>(p, Nc + 3); b.list_cnt = carve<uint32_t>(p, Nc + 3);
     b.cs_ins.wg_sum = carve<uint32_t>(p, cw); b.cs_make.wg_sum = carve<uint32_t>(p, cw); b.cs_runs.wg_sum = carve<uint32_t>(p, cw);
     b.cs_vis.wg_sum = carve<uint32_t>(p, cw); b.cs_cnt.wg_sum = carve<uint32_t>(p, cw); b.cs_erec.wg_sum = carve<uint32_t>(p, cw);
+    b.head_child = carve<uint32_t>(p, 2048);
     // unordered child lists (k_child_push) live in the second Euler buffer, which list ranking only uses afterwards
     b.child_head = (uint32_t*)b.euler_b;
     b.child_next = b.child_head + (2 * Nc + 2);
+    b.fill_base = b.order;
+    b.fill_bytes = (size_t)((uint8_t*)(b.child_head + 2 * Nc + 1) - (uint8_t*)b.order);
     uint8_t* s = c->d_sort.as<uint8_t>();
     b.key_a = carve<uint64_t>(s, Nc); b.key_b = carve<uint64_t>(s, Nc); b.val_a = carve<uint32_t>(s, Nc); b.val_b = carve<uint32_t>(s, Nc);
     b.sort_ws = s;
@@ -1365,6 +1381,10 @@ static int replay_impl(am355_ctx* c) {
   c->flags = 0;
   if (c->is_document) return replay_document(c);
   auto t_begin = std::chrono::steady_clock::now();
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "replay: %-28s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   hipStream_t sa = c->stream, sb = c->stream2;
   uint32_t n = c->n_changes;
   size_t n1 = std::max<size_t>(n, 1);
@@ -1427,7 +1447,9 @@ static int replay_impl(am355_ctx* c) {
     }
     // the host only needs a 32-byte digest per change and the handful of distinct actor ids
     HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
+    lap("stage 1 enqueued");
     HIPCHK(c, hipStreamSynchronize(sa));
+    lap("stage 1 done");
     if (!(h_wa[W_FAST_A] & FF_CAPACITY) || attempt) break;
     // the staging buffer for actor tables was too small: grow to the measured total and redo the interning
     c->amap_cap = h_wa[W_TOTAL_ENTRIES] + 1024;
@@ -1458,12 +1480,15 @@ static int replay_impl(am355_ctx* c) {
   if (fast) {
     opt_rc = plan_fast(c, slot_rank);
     ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+    lap("plan_fast done");
     if (opt_rc == AM355_OK) opt_rc = run_device(c, &slot_rank);  // optimistic: confirmed (or discarded) when stream B is joined
+    lap("run_device done");
     opt_flags = c->flags;
     opt_err = c->err;
   }
   // ---- join stream B ----
   HIPCHK(c, hipEventSynchronize(c->ev_b1));
+  lap("hash stream joined");
   if (h_words[W_FLAGS_B]) return error_for_flags(c, h_words[W_FLAGS_B], "checksum does not match data");
   if (fast && h_words[W_FAST_B]) fast = false;
   if (fast) {
@@ -1492,6 +1517,7 @@ static int replay_impl(am355_ctx* c) {
     if (rc) return rc;
   }
   c->used_fast_path = fast;
+  lap("end");
   auto t_end = std::chrono::steady_clock::now();
 
   am355_stats& s = c->stats;

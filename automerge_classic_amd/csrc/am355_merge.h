@@ -20,7 +20,8 @@ struct Counts {
   uint32_t n_runs;       // typing runs of the insertion forest (list ranking works on 2 x runs + 1 tour entries)
   uint32_t euler_done;   // the single-workgroup LDS list ranking handled the tour
   uint32_t n_erecs;      // edit records (a multi-insert run counts once)
-  uint32_t reserved[5];
+  uint32_t n_head_children;  // insert rows whose reference element is _head (all list objects)
+  uint32_t reserved[4];
 };
 
 // Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.
@@ -50,6 +51,7 @@ struct MergeBufs {
   uint32_t *next_sib;               // [N]
   uint32_t *child_head;             // [2N+1] unordered child list per parent slot (atomic push), aliases the Euler scratch
   uint32_t *child_next;             // [N]
+  uint32_t *head_child;             // [HEAD_CHILD_MAX] children of list heads (ordered by one workgroup from LDS)
   uint32_t *obj_n;                  // [n_objects + 1] list elements (insert rows) per object
   uint32_t *run_heads, *row_run;    // typing runs: first insert-list index of each run; run of a row (run heads and tails only)
   uint32_t *list_vis, *list_cnt;    // [N] per list position: element visible, number of its edits (scanned into scan_a / scan_b)
@@ -63,6 +65,8 @@ struct MergeBufs {
   size_t counts_bytes;              // Counts + group sums
   void* zero_base;                  // succ_cnt .. last_inc are contiguous: one memset per replay
   size_t zero_bytes;
+  void* fill_base;                  // order | first_child | child_head are contiguous: one 0xff fill per replay
+  size_t fill_bytes;
 };
 
 // bytes of the device block that holds Counts and the carried scans' group sums for N op rows

@@ -18,6 +18,10 @@
 #include "am355_merge.h"
 #include "am355_prims.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace am355 {
 
 // K_LIST_INS_VIS: an insert row whose own value is visible (set by k_emit: the element's value count is val_cnt + this bit, so the
@@ -460,11 +464,51 @@ __device__ __forceinline__ uint32_t parent_slot(const MergeBufs& b, uint32_t g) 
   return ref == NONE32 ? b.n_ops + b.obj_row[g] : ref;
 }
 
+// Children of a list HEAD are the one long sibling list of ordinary documents (everybody's first insert into an empty text,
+// every insert at position 0): walking it costs every one of its k children k dependent loads. They are therefore ALSO
+// collected in an array (up to HEAD_CHILD_MAX of them in the whole batch) which one workgroup orders from LDS
+// (k_head_children); beyond that the linked lists serve as for any other parent.
+constexpr uint32_t HEAD_CHILD_MAX = 2048;
+constexpr uint32_t HEAD_CHILD_THREADS = 1024;
+
 __global__ __launch_bounds__(BLOCK) void k_child_push(MergeBufs b) {
   uint32_t i = gtid();
-  if (i >= b.counts->n_list_ins) return;
-  uint32_t v = b.ins_row[i];
-  b.child_next[v] = atomicExch(&b.child_head[parent_slot(b, v)], v);
+  bool in_range = i < b.counts->n_list_ins;
+  uint32_t v = in_range ? b.ins_row[i] : 0;
+  bool head_child = in_range && b.ref_row[v] == NONE32;
+  if (in_range) b.child_next[v] = atomicExch(&b.child_head[parent_slot(b, v)], v);
+  uint32_t slot = wave_append(&b.counts->n_head_children, head_child);
+  if (head_child && slot < HEAD_CHILD_MAX) b.head_child[slot] = v;
+}
+
+// one workgroup: sibling links of all head children (siblings in DESCENDING op id, per list object)
+__global__ __launch_bounds__(HEAD_CHILD_THREADS) void k_head_children(MergeBufs b) {
+  __shared__ unsigned long long s_id[HEAD_CHILD_MAX];
+  __shared__ uint32_t s_obj[HEAD_CHILD_MAX], s_row[HEAD_CHILD_MAX];
+  const uint32_t n = b.counts->n_head_children;
+  if (n == 0 || n > HEAD_CHILD_MAX) return;
+  for (uint32_t k = threadIdx.x; k < n; k += HEAD_CHILD_THREADS) {
+    uint32_t v = b.head_child[k];
+    s_row[k] = v;
+    s_obj[k] = b.obj_row[v];
+    s_id[k] = pack_id(b.ops.id_ctr[v], b.ops.id_actor[v]);
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += HEAD_CHILD_THREADS) {
+    const uint32_t obj = s_obj[k];
+    const unsigned long long kv = s_id[k];
+    unsigned long long best_id = 0;
+    uint32_t greater = 0, best = NONE32;
+    for (uint32_t j = 0; j < n; j++) {
+      if (s_obj[j] != obj || j == k) continue;
+      unsigned long long ku = s_id[j];
+      if (ku > kv) greater++;
+      else if (best == NONE32 || ku > best_id) { best = s_row[j]; best_id = ku; }
+    }
+    uint32_t v = s_row[k];
+    b.next_sib[v] = best;
+    if (greater == 0) b.first_child[b.n_ops + obj] = v;
+  }
 }
 
 // Typing runs. Most elements of a text have exactly one child, inserted right after them (the next character typed):
@@ -487,6 +531,8 @@ __global__ __launch_bounds__(BLOCK) void k_child_order(MergeBufs b, uint32_t* __
     if (FROM_LINKS) {
       first = b.first_child[ps] == v;
       none_after = b.next_sib[v] == NONE32;
+    } else if (ps >= b.n_ops && b.counts->n_head_children <= HEAD_CHILD_MAX) {
+      first = none_after = false;  // a head child (linked by k_head_children) always starts a run: its parent is no element
     } else {
       unsigned long long kv = pack_id(o.id_ctr[v], o.id_actor[v]), best_id = 0;
       uint32_t greater = 0, best = NONE32, steps = 0;
@@ -984,9 +1030,7 @@ void merge_prepare(MergeBufs& b, hipStream_t aux) {
   uint32_t N = b.n_ops;
   (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, aux);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
   if (!N) return;
-  (void)hipMemsetAsync(b.first_child, 0xff, sizeof(uint32_t) * (2 * (size_t)N + 1), aux);
-  (void)hipMemsetAsync(b.child_head, 0xff, sizeof(uint32_t) * (2 * (size_t)N + 1), aux);
-  (void)hipMemsetAsync(b.order, 0xff, sizeof(uint32_t) * (size_t)N, aux);
+  (void)hipMemsetAsync(b.fill_base, 0xff, b.fill_bytes, aux);  // order, first_child, child_head
 }
 
 // map emissions: LSD over (trigger id | key length | key chunks last..first | object)
@@ -1025,6 +1069,11 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
 
 void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs) {
   const uint32_t N = b.n_ops;
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "  merge_run: %-24s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   Counts* hc_runs = hc + 1;  // second read-back (pinned host memory with room for two records)
   if (!N) {
     (void)hipMemsetAsync(ir.obj, 0, sizeof(am355_ir_object), st);
@@ -1045,7 +1094,8 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   (void)hipEventRecord(ev_counts, st);
   // ---- lists, first half: launched for the worst case (every row an insert) with the real count read on the device, so the
   //      host does not have to wait for the counters before the device has more work ----
-  AM355_LAUNCH_INDEPENDENT(k_child_push, grid_for(N), dim3(BLOCK), st, b);
+  hipLaunchKernelGGL(k_child_push, grid_for(N), dim3(BLOCK), 0, st, b);
+  hipLaunchKernelGGL(k_head_children, dim3(1), dim3(HEAD_CHILD_THREADS), 0, st, b);
   hipLaunchKernelGGL(k_child_order<false>, grid_for(N), dim3(BLOCK), 0, st, b, is_head);
   hipLaunchKernelGGL(k_run_heads, grid_for(N), dim3(BLOCK), 0, st, b, (const uint32_t*)is_head, head_ex, heads, row_run);
   (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
@@ -1053,13 +1103,16 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)heads, (const uint32_t*)row_run, b.euler_a);
   hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
 
+  lap("first half enqueued");
   (void)hipEventSynchronize(ev_counts);
+  lap("counts read");
   if (hc->flags) { (void)hipStreamSynchronize(st); return; }
   order_map_emissions(b, ir, hc, st);
 
   const uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd, n_obj = hc->n_objects + 1;
   if (ni) {
     (void)hipEventSynchronize(ev_runs);
+    lap("runs read");
     uint32_t H = hc_runs->n_runs;
     ListKeyBits kb{bits_for(N), (int)b.bits_ctr, (int)b.bits_actor};
     if (hc_runs->pad) {
@@ -1117,7 +1170,9 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
     (void)hipMemsetAsync(ir.edit, 0, sizeof(am355_ir_edit), st);
   }
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  lap("all enqueued");
   (void)hipStreamSynchronize(st);
+  lap("done");
 }
 
 // Whole-document patch of canonical rows (document load). Synchronises the stream twice (counts).

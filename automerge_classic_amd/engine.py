@@ -80,8 +80,9 @@ def _bind(path):
     L.am355_save.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     L.am355_get_applied.argtypes = [vp, vp, ctypes.POINTER(u32)]
     L.am355_fetch_ir.argtypes = [vp, vp]
+    L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
-              "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir"):
+              "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -172,6 +173,15 @@ class Engine:
         s = Stats()
         self._check(self._L.am355_get_stats(self._h, ctypes.byref(s)))
         return s
+
+    def raw(self):
+        """(arena, offsets) as staged: the uncompressed change containers back to back (copies)."""
+        a, o, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
+        self._check(self._L.am355_get_raw(self._h, ctypes.byref(a), ctypes.byref(o), ctypes.byref(n)))
+        offs = np.ctypeslib.as_array(ctypes.cast(o, ctypes.POINTER(ctypes.c_uint64)), shape=(n.value + 1,)).copy()
+        size = int(offs[-1])
+        arena = np.ctypeslib.as_array(ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)), shape=(size,)).copy() if size else np.zeros(0, dtype=np.uint8)
+        return arena, offs
 
     def hashes(self):
         out = np.zeros((self._n_changes, 32), dtype=np.uint8)

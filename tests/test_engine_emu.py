@@ -173,6 +173,22 @@ def test_truncated_deflate_streams_are_rejected_not_retried(eng):
     assert ei.value.code == engine.AM355_E_ARG
 
 
+@pytest.mark.parametrize("deflate", [False, True])
+def test_sliced_staging_gathers_the_same_arena(eng, monkeypatch, deflate):
+    """am355_load_changes gathers large batches in slices on host threads (gather / inflate + H2D per slice): with the slice
+    size lowered the sliced path runs on a small log; the staged raw arena, offsets and the patch equal the one-slice result."""
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, seed=5, n_actors=8, n_rounds=6, ins_per_change=60, del_per_change=15, n_objects=2, deflate=deflate)
+    eng.load_changes(log)
+    eng.replay()
+    want_raw, want_patch = eng.raw(), eng.patch_json()
+    monkeypatch.setenv("AM355_SLICE_BYTES", "600")
+    eng.load_changes(log)
+    eng.replay()
+    got_raw = eng.raw()
+    assert np.array_equal(got_raw[0], want_raw[0]) and np.array_equal(got_raw[1], want_raw[1])
+    assert eng.patch_json() == want_patch == oracle_lib.OracleDoc(log).patch_json()
+
+
 def test_device_primitives(eng):
     rng = np.random.default_rng(1)
     for n in (1, 64, 2049, 8192, 9000, 70_001):
