@@ -24,12 +24,19 @@ struct Counts {
   uint32_t reserved[4];
 };
 
+// Owner of an object's rows: _root on rank 0, every other object by its id (ordering and pred / succ resolution
+// never cross objects, new.js:1141-1145, 1173-1176; the one cross-object link, make row -> child object, is the object index).
+__host__ __device__ __forceinline__ uint32_t shard_owner(uint32_t obj_actor, uint32_t obj_ctr, uint32_t world) {
+  return obj_actor == NONE32 ? 0u : (obj_ctr + obj_actor) % world;
+}
+
 // Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.
 struct MergeBufs {
   // inputs
   const uint8_t* arena;
   OpCols ops;
   uint32_t n_ops, n_preds, n_actors;
+  uint32_t shard_rank, shard_world;  // objectId sharding: this rank merges the objects it owns (shard_owner); world 1 = everything
   const uint32_t* actor_tab_off;  // [n_actors + 1] into spans
   const ActorSpan* spans;
   uint32_t bits_ctr, bits_actor;  // key widths: bits(max op counter), bits(n_actors)

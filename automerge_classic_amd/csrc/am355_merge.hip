@@ -26,7 +26,11 @@ namespace am355 {
 
 // K_LIST_INS_VIS: an insert row whose own value is visible (set by k_emit: the element's value count is val_cnt + this bit, so the
 // common case -- one visible value per element, its insert -- costs no atomic)
-enum Kind : uint8_t { K_NONE = 0, K_MAP = 1, K_LIST_INS = 2, K_LIST_UPD = 3, K_DEL = 4, K_LIST_INS_VIS = 5 };
+// K_FOREIGN: objectId sharding (MergeBufs.shard_world > 1) -- the row belongs to an object another rank owns. It takes no part in
+// this rank's merge (no validation, no succ counting, no emission) except that a make row still enters the object table, so
+// that object indexes are the same on every rank (the fragments of the patch IR are stitched by object index).
+enum Kind : uint8_t { K_NONE = 0, K_MAP = 1, K_LIST_INS = 2, K_LIST_UPD = 3, K_DEL = 4, K_LIST_INS_VIS = 5, K_FOREIGN = 6 };
+
 
 __device__ __forceinline__ uint32_t row_of(const MergeBufs& b, uint32_t actor, uint32_t ctr) {
   if (actor >= b.n_actors) return NONE32;
@@ -110,6 +114,12 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
     if (has_obj) orow = (oa == la && oc == lc) ? lrow : row_of(b, oa, oc);
   }
   if (!in_range) return;
+  if (b.shard_world > 1 && shard_owner(oa, oc, b.shard_world) != b.shard_rank) {
+    b.obj_row[g] = NONE32;
+    b.ref_row[g] = NONE32;
+    b.kind[g] = K_FOREIGN;
+    return;
+  }
   bool list_obj = false;
   if (has_obj) {
     if (orow == NONE32 || (o.action[orow] & 1)) { err |= F_UNKNOWN_OBJECT; orow = NONE32; }
@@ -213,7 +223,8 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   uint8_t kind = in_range ? b.kind[g] : (uint8_t)K_NONE;
   uint32_t a = in_range ? o.action[g] : 1;
   bool live = kind != K_NONE && kind != K_DEL;
-  bool is_make = live && (a & 1) == 0;
+  bool is_make = live && (a & 1) == 0;  // (a foreign make row too: the object table is the same on every rank)
+  if (kind == K_FOREIGN) live = false;
   bool vis = live && b.succ_cnt[g] == 0;
   bool want_map = false, want_ins = false, want_upd = false;
   unsigned long long trig = 0;

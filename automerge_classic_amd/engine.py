@@ -80,9 +80,14 @@ def _bind(path):
     L.am355_save.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     L.am355_get_applied.argtypes = [vp, vp, ctypes.POINTER(u32)]
     L.am355_fetch_ir.argtypes = [vp, vp]
+    L.am355_set_shard.argtypes = [vp, u32, u32]
+    L.am355_fragment_size.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+    L.am355_export_fragment.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+    L.am355_import_fragments.argtypes = [vp, vp, vp, u32]
     L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
-              "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw"):
+              "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
+              "am355_import_fragments"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -173,6 +178,27 @@ class Engine:
         s = Stats()
         self._check(self._L.am355_get_stats(self._h, ctypes.byref(s)))
         return s
+
+    # ---- objectId sharding (one Engine per GPU / process) ---------------------------------------------------
+    def set_shard(self, rank, world):
+        self._check(self._L.am355_set_shard(self._h, rank, world))
+
+    def fragment_size(self):
+        n = ctypes.c_size_t()
+        self._check(self._L.am355_fragment_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def export_fragment(self, ptr, capacity, device):
+        """This rank's record tables into caller memory at `ptr` (device or host); returns the bytes written."""
+        n = ctypes.c_size_t()
+        self._check(self._L.am355_export_fragment(self._h, ctypes.c_void_p(ptr), capacity, 1 if device else 0, ctypes.byref(n)))
+        return n.value
+
+    def import_fragments(self, frags, offsets):
+        """frags: uint8 host array holding the fragments of all ranks, offsets: uint64[world + 1]."""
+        f = np.ascontiguousarray(frags, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self._L.am355_import_fragments(self._h, f.ctypes.data, o.ctypes.data, o.size - 1))
 
     def raw(self):
         """(arena, offsets) as staged: the uncompressed change containers back to back (copies)."""

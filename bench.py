@@ -16,8 +16,11 @@ container parse + SHA-256 + column decode -> causal schedule -> op-set merge -> 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4_text_single] [--scale 1.0] [--no-sublines]
 
 For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU: every rank replays its own document of
-the same shape (different seed); value = total ops of all ranks / max time over ranks ("weak"). `--shard` selects the
-objectId-sharded mode instead (one document split over the ranks).
+the same shape (different seed); value = total ops of all ranks / max time over ranks ("weak": one document needs one GPU for
+0.6 ms, a node serves many documents). The same line then carries `sharded`: ONE document (c4_text_multi, 64 Text objects) split
+by objectId over the N ranks (automerge_classic_amd/shard.py) -- every rank decodes the batch and merges the
+objects it owns, the patch-IR fragments are all-gathered over RCCL and stitched on rank 0 -- as strong-scaling figures next to
+the single-GPU time of the same log measured in the same run.
 """
 import argparse
 import json
@@ -212,6 +215,50 @@ def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False):
             "roofline_whole_path": {"achieved": whole, "unit": "GB/s", "frac": whole / 8000.0}}
 
 
+def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier):
+    """ONE document (c4_text_multi: 64 Text objects) sharded by objectId over the ranks: T_replay-style region (host buffers on
+    every rank -> stitched patch IR on rank 0's host), max over ranks; beside it the same log unsharded on rank 0 alone."""
+    import hashlib
+    import torch
+    from automerge_classic_amd import shard
+    name = "c4_text_multi"
+    log = make_log(name, 1.0, BASE_SEED[name])  # (the same log on every rank)
+    # parity first, outside the timed region: stitched patch == unsharded patch
+    eng.set_shard(0, 1)
+    eng.load_changes(log)
+    eng.replay()
+    want = hashlib.sha256(eng.patch_json().encode()).hexdigest() if rank == 0 else None
+    sr = shard.ShardedReplay(eng, dist, device)
+    have = sr.step(lambda: eng.load_changes(log))
+    same = (hashlib.sha256(eng.patch_json().encode()).hexdigest() == want) if have else True
+    eng.set_shard(0, 1)
+    dt, info = shard.bench_sharded(eng, log, dist, device, steps, warmup, barrier)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
+    # the same log on one GPU (rank 0; the other ranks wait at the barrier)
+    t_single = 0.0
+    if rank == 0:
+        def one():
+            eng.load_changes(log)
+            eng.replay()
+            eng.fetch_ir()
+        for _ in range(warmup):
+            one()
+        t_single = timed(one, steps, torch.cuda.synchronize)
+    barrier()
+    if rank != 0:
+        return None
+    n_ops = int(log.n_ops)
+    return {"workload": f"{name} x1.0: {n_ops} ops, {log.n_changes} changes, 64 Text objects, ONE document over {world} GPUs (objectId sharding: owner = "
+                        "(object counter + actor rank) mod N, _root on rank 0; every rank decodes the batch, merges its objects, all_gather of the "
+                        "patch-IR fragments over RCCL, stitch on rank 0)",
+            "scaling": "strong", "n_gpus": world, "steps": steps, "ops_per_s": n_ops * steps / dt, "ms_per_step": dt / steps * 1e3,
+            "single_gpu_ops_per_s": n_ops * steps / t_single, "single_gpu_ms_per_step": t_single / steps * 1e3,
+            "speedup_vs_single_gpu": t_single / dt, "fragment_bytes": info.get("fragment_bytes"),
+            "parity": "stitched patch == unsharded patch (sha256 of the patch text)" if same else "MISMATCH"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,7 +268,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sublines", action="store_true")
-    ap.add_argument("--shard", action="store_true", help="N > 1: ONE document sharded by objectId over the ranks instead of one document per rank")
+    ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the objectId-sharded measurement that follows the replica measurement")
     args = ap.parse_args()
 
     import torch
@@ -234,10 +281,6 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.shard:
-        from automerge_classic_amd import shard
-        return shard.bench_main(args, rank, world, local_rank, dist)
-
     eng = engine.Engine(local_rank)
 
     def barrier():
@@ -266,6 +309,9 @@ def main():
             parts[k] += getattr(s, k)
     t_dev = timed(dev, args.steps, barrier)
     t_dev, _ = dist_util.aggregate(t_dev, 0.0, dist, torch.device("cuda", local_rank))
+    sharded = None
+    if world > 1 and not args.no_shard:
+        sharded = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), max(5, args.steps // 2), 3, barrier)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -305,6 +351,8 @@ def main():
         "t_device_ops_per_s": st.n_ops / (t_device_ms * 1e-3), "t_device_ms": t_device_ms,
         "phases_ms": phases, "algorithmic_bytes_per_op": A, "save": save_info, "roofline": roofline,
     }
+    if sharded is not None:
+        out["sharded"] = sharded
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops)) if w.is_doc else cpu_baseline(w.log)
     if not args.no_sublines and world == 1:

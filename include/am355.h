@@ -186,6 +186,23 @@ typedef struct {
 } am355_patch_ir;
 int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
 
+/*
+ * objectId sharding over several GPUs (one context per GPU, one process per GPU).  Ordering and pred / succ
+ * resolution never cross objects (new.js:1141-1145, 1173-1176), so after am355_set_shard(ctx, rank, world) a replay merges
+ * only the objects rank `rank` owns (_root: rank 0; any other object: (counter + actor rank) mod world) -- every rank still
+ * stages and decodes the whole batch, which keeps op id -> row arithmetic and the object table identical everywhere; the one
+ * cross-object link (make op -> child object, new.js:894-897, 973-976) is the object index.  The OUTPUT is what is exchanged:
+ * am355_export_fragment writes this rank's record tables as one contiguous block into caller memory (device memory for an
+ * RCCL all_gather over xGMI, or host memory), and am355_import_fragments stitches the blocks of all ranks into the patch IR
+ * of the whole document, which am355_patch_json / am355_fetch_ir of that context then return.  world == 1 restores the
+ * unsharded engine.  am355_save is not available on a sharded context.
+ */
+int am355_set_shard(am355_ctx *ctx, uint32_t rank, uint32_t world);
+int am355_fragment_size(am355_ctx *ctx, size_t *bytes);
+int am355_export_fragment(am355_ctx *ctx, void *dst, size_t capacity, int dst_is_device, size_t *len);
+/* fragments of ranks 0..world-1 back to back in host memory, fragment r = frags[offsets[r] .. offsets[r+1]) */
+int am355_import_fragments(am355_ctx *ctx, const uint8_t *frags, const uint64_t *offsets, uint32_t world);
+
 /* ---- diagnostics: device primitives exposed for kernel-level tests ---- */
 int am355_test_sort(am355_ctx *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, int key_bits);
 int am355_test_scan(am355_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total);

@@ -41,3 +41,65 @@ def test_two_rank_replicas_over_gloo(tmp_path):
                           "--master-port", "29533", str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "rank0ok" in out.stdout and "rank1ok" in out.stdout
+
+
+SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+from automerge_classic_amd import engine, loggen, shard
+import oracle_lib
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 2
+EMU = os.path.join(ROOT, "tests", "emu", "libam355_emu.so")
+eng = engine.Engine(0, EMU)
+cases = [
+    loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=3, ins_per_change=25, del_per_change=6, n_objects=7, seed=41),   # 7 Text objects over 2 ranks
+    loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=5, n_rounds=2, ins_per_change=30, del_per_change=5, n_objects=1, seed=42),   # one Text: one rank owns it all
+    loggen.generate(loggen.KIND_MAP_LWW, n_actors=4, n_rounds=3, n_keys=120, seed=43),                                                 # only _root: rank 0 owns everything
+]
+import golden_util
+for name in golden_util.fixture_names():   # real-frontend documents: nested maps / lists / text / tables / counters
+    fx = golden_util.load_fixture(name)
+    if "campaign" in name or "mixed" in name or "conflicts" in name:
+        cases.append(fx["log"])
+sr = shard.ShardedReplay(eng, dist, torch.device("cpu"), stitch_on_all_ranks=True)
+single = engine.Engine(0, EMU)
+for log in cases:
+    try:
+        single.load_changes(log); single.replay(); want = single.patch_json()
+    except engine.EngineError:
+        continue   # (inputs the engine leaves to the JS path)
+    assert sr.step(lambda: eng.load_changes(log))
+    got = eng.patch_json()
+    assert got == want, (log.name, rank)
+    assert want == oracle_lib.OracleDoc(log).patch_json()
+    if rank == 0:
+        sys.stdout.write("case ok %d ops, fragments %s\\n" % (single.stats().n_ops, sr.last["fragment_bytes"]))
+# a batch one rank rejects is rejected on every rank (no rank is left waiting in a collective)
+bad = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=3, n_rounds=2, ins_per_change=10, del_per_change=2, n_objects=2, seed=44)
+arena = bad.arena.copy(); arena[int(bad.offsets[1]) + 20] ^= 0x55
+broken = loggen.ChangeLog(arena, bad.offsets, bad.n_ops)
+try:
+    sr.step(lambda: eng.load_changes(broken))
+    raise SystemExit("corrupt batch was accepted")
+except (engine.EngineError, RuntimeError):
+    pass
+dist.barrier()
+dist.destroy_process_group()
+sys.stdout.write("rank%dok\\n" % rank); sys.stdout.flush()
+'''
+
+
+def test_two_rank_objectid_sharding_over_gloo(tmp_path):
+    """objectId sharding (SURVEY.md §8e): two ranks each merge the objects they own, all_gather their patch-IR fragments and
+    stitch them; the stitched patch equals the single-rank patch (and the oracle's) byte for byte."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    script = tmp_path / "shard_worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\n" + SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29534", str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "rank0ok" in out.stdout and "rank1ok" in out.stdout and out.stdout.count("case ok") >= 3
