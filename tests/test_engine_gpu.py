@@ -352,26 +352,32 @@ def test_objectid_shards_stitch_to_the_unsharded_patch(eng, world):
             e.close()
 
 
-def test_sharded_replay_through_rccl_world_1(eng):
+RCCL_WORKER = r'''
+import hashlib, os, sys
+sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist   # (torch first: its bundled HIP runtime then serves the engine too, as in bench.py)
+from automerge_classic_amd import engine, loggen, shard
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+log = loggen.config("c4_text_multi", 0.1)
+e = engine.Engine(0)
+e.load_changes(log); e.replay()
+want = e.patch_json()
+sr = shard.ShardedReplay(e, dist, torch.device("cuda", 0))
+assert sr.step(lambda: e.load_changes(log))
+assert e.patch_json() == want
+dist.destroy_process_group()
+print("rccl-ok", hashlib.sha256(want.encode()).hexdigest())
+'''
+
+
+def test_sharded_replay_through_rccl_world_1(tmp_path):
     """The host binding of the sharded path (automerge_classic_amd/shard.py) with the RCCL backend on the one GPU of the test box:
     fragment exported into a device tensor, all_gather_into_tensor, stitch. (World sizes > 1 over RCCL need more GPUs: the
     driver's multi-GPU bench; the stitching itself is covered for 2, 3 and 8 shards above and over gloo on CPU.)"""
-    import torch
-    import torch.distributed as dist
-    from automerge_classic_amd import shard
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        log = loggen.config("c4_text_multi", 0.1)
-        want = gpu_patch(eng, log)
-        e = engine.Engine(0)
-        sr = shard.ShardedReplay(e, dist, torch.device("cuda", 0))
-        assert sr.step(lambda: e.load_changes(log))
-        assert e.patch_json() == want
-        e.close()
-    finally:
-        if created:
-            dist.destroy_process_group()
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(f"ROOT = {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}\n" + RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "rccl-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
