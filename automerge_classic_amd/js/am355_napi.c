@@ -12,6 +12,7 @@
  *   am.loadDocument(ctx, Uint8Array)               // stage one saved document (Backend.save bytes)
  *   am.replay(ctx)                                 // the hot path (blocking, like every Backend call)
  *   am.patchJSON(ctx) -> string                    // JSON.stringify(getPatch) text, built from the device IR
+ *   am.fetchIR(ctx) -> {objects, map, edits, values, arena, ...}   // the record tables; materialize.js builds the patch object
  *   am.stats(ctx) -> {nOps, nChanges, msTotal, ...};  am.hashes(ctx) -> Uint8Array(32 * n);  am.destroy(ctx)
  */
 #include <node_api.h>
@@ -29,18 +30,24 @@
     }                                                                          \
   } while (0)
 
+/* the external wraps a small box so that an explicit destroy() and the finalizer cannot both release the context */
+typedef struct { am355_ctx *ctx; } ctx_box;
+
 static void finalize_ctx(napi_env env, void *data, void *hint) {
   (void)env; (void)hint;
-  if (data) am355_destroy((am355_ctx *)data);
+  ctx_box *box = (ctx_box *)data;
+  if (!box) return;
+  if (box->ctx) am355_destroy(box->ctx);
+  free(box);
 }
 
 static am355_ctx *get_ctx(napi_env env, napi_value v) {
   void *p = NULL;
-  if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
-    napi_throw_type_error(env, NULL, "expected an am355 context");
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((ctx_box *)p)->ctx) {
+    napi_throw_type_error(env, NULL, "expected a live am355 context");
     return NULL;
   }
-  return (am355_ctx *)p;
+  return ((ctx_box *)p)->ctx;
 }
 
 static napi_value throw_engine(napi_env env, am355_ctx *ctx, int rc) {
@@ -67,14 +74,24 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
     napi_throw_error(env, NULL, "am355_create failed: no usable MI355X / HIP device (the engine has no CPU fallback)");
     return NULL;
   }
+  ctx_box *box = (ctx_box *)malloc(sizeof(ctx_box));
+  if (!box) { am355_destroy(ctx); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  box->ctx = ctx;
   napi_value ext;
-  NAPI_CALL(env, napi_create_external(env, ctx, finalize_ctx, NULL, &ext));
+  NAPI_CALL(env, napi_create_external(env, box, finalize_ctx, NULL, &ext));
   return ext;
 }
 
 static napi_value js_destroy(napi_env env, napi_callback_info info) {
-  /* contexts are also released by the finalizer; explicit destroy is a no-op kept for symmetry */
-  (void)info;
+  /* releases the engine context now; the finalizer of the external then finds an empty box */
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  void *p = NULL;
+  if (argc >= 1 && napi_get_value_external(env, argv[0], &p) == napi_ok && p && ((ctx_box *)p)->ctx) {
+    am355_destroy(((ctx_box *)p)->ctx);
+    ((ctx_box *)p)->ctx = NULL;
+  }
   napi_value u;
   napi_get_undefined(env, &u);
   return u;
@@ -234,6 +251,59 @@ static void set_num(napi_env env, napi_value obj, const char *name, double v) {
   napi_set_named_property(env, obj, name, n);
 }
 
+
+/* copy `len` bytes into a JS-owned ArrayBuffer (the engine's pinned buffers are reused by the next call on the context) */
+static napi_value copy_to_arraybuffer(napi_env env, const void *src, size_t len) {
+  void *data = NULL;
+  napi_value ab;
+  if (napi_create_arraybuffer(env, len, &data, &ab) != napi_ok) return NULL;
+  if (len && src) memcpy(data, src, len);
+  return ab;
+}
+
+/* fetchIR(ctx) -> {objects, map, edits, values, arena: ArrayBuffer, nObjects, nMap, nEdits, nValues, maxOp, pending,
+ *                  actorOff: ArrayBuffer(u32), actorBytes: ArrayBuffer, clockActor: ArrayBuffer(u32), clockSeq: ArrayBuffer(f64), heads: ArrayBuffer}
+ * am355_fetch_ir: the record tables of include/am355.h as the device wrote them; materialize.js builds the patch object. */
+static napi_value js_fetch_ir(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  am355_patch_ir ir;
+  int rc = am355_fetch_ir(ctx, &ir);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value o;
+  NAPI_CALL(env, napi_create_object(env, &o));
+#define PUT_AB(name, ptr, bytes)                                                        \
+  do {                                                                                  \
+    napi_value ab_ = copy_to_arraybuffer(env, (ptr), (bytes));                          \
+    if (!ab_) { napi_throw_error(env, NULL, "out of memory (patch IR)"); return NULL; } \
+    napi_set_named_property(env, o, name, ab_);                                         \
+  } while (0)
+  PUT_AB("objects", ir.objects, (size_t)ir.n_objects * sizeof(am355_ir_object));
+  PUT_AB("map", ir.map, (size_t)ir.n_map * sizeof(am355_ir_map));
+  PUT_AB("edits", ir.edits, ((size_t)ir.n_edits + 1) * sizeof(am355_ir_edit));
+  PUT_AB("values", ir.values, (size_t)ir.n_values * sizeof(am355_ir_value));
+  PUT_AB("arena", ir.arena, (size_t)ir.arena_len);
+  PUT_AB("actorOff", ir.actor_off, ((size_t)ir.n_actors + 1) * sizeof(uint32_t));
+  PUT_AB("actorBytes", ir.actor_bytes, ir.n_actors ? (size_t)ir.actor_off[ir.n_actors] : 0);
+  PUT_AB("clockActor", ir.clock_actor, (size_t)ir.n_clock * sizeof(uint32_t));
+  PUT_AB("heads", ir.heads, (size_t)ir.n_heads * 32);
+  {
+    void *data = NULL;
+    napi_value ab;
+    NAPI_CALL(env, napi_create_arraybuffer(env, (size_t)ir.n_clock * sizeof(double), &data, &ab));
+    for (uint32_t i = 0; i < ir.n_clock; i++) ((double *)data)[i] = (double)ir.clock_seq[i];
+    napi_set_named_property(env, o, "clockSeq", ab);
+  }
+#undef PUT_AB
+  set_num(env, o, "nObjects", ir.n_objects); set_num(env, o, "nMap", ir.n_map); set_num(env, o, "nEdits", ir.n_edits);
+  set_num(env, o, "nValues", ir.n_values); set_num(env, o, "nActors", ir.n_actors); set_num(env, o, "maxOp", (double)ir.max_op);
+  set_num(env, o, "pending", ir.pending);
+  return o;
+}
+
 static napi_value js_stats(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -265,6 +335,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"appliedOrder", NULL, js_applied_order, NULL, NULL, NULL, napi_enumerable, NULL},
       {"hashes", NULL, js_hashes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"stats", NULL, js_stats, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"fetchIR", NULL, js_fetch_ir, NULL, NULL, NULL, napi_enumerable, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

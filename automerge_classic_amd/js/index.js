@@ -18,6 +18,8 @@ const path = require('path')
 
 const JS_ONLY = process.env.MI355X_BACKEND_JS_ONLY === '1'
 const HYDRATE_FROM_DOC = process.env.MI355X_HYDRATE === 'doc'
+const PATCH_VIA_JSON = process.env.MI355X_PATCH_VIA_JSON === '1'   // A/B: JSON text rendered by the engine + JSON.parse
+const { materialize } = require('./materialize.js')
 let addon = null, ctx = null
 if (!JS_ONLY) {
   addon = require(path.join(__dirname, 'am355_napi.node'))
@@ -53,6 +55,7 @@ class GpuState {
   }
 }
 let generation = 0           // bumped by every GPU replay
+const counters = { gpuLoadChanges: 0, gpuLoad: 0, gpuSave: 0, fallbackToJs: 0, hydrations: 0 }   // (diagnostics: which path served the calls)
 
 function isFrozenCheck(backend) {
   // reference util.js:1-10
@@ -79,6 +82,7 @@ function hydrate(backend) {
   if (!(backend.state instanceof GpuState)) return backend
   const g = backend.state
   if (!g.js) {
+    counters.hydrations++
     if (g.doc) g.js = ref().load(g.doc)
     else if (HYDRATE_FROM_DOC && !JS_ONLY) {
       // hydrate the JS BackendDoc from the engine's save() bytes: Backend.load of a document is several times cheaper in JS than
@@ -108,12 +112,17 @@ function toJs(backend) {
   return handle
 }
 
+// the patch object of the last replay: built from the record tables the device wrote (materialize.js) -- real JS values, no
+// JSON text in between
+function gpuPatch() {
+  return PATCH_VIA_JSON ? JSON.parse(addon.patchJSON(ctx)) : materialize(addon.fetchIR(ctx))
+}
+
 function gpuReplay(changes) {
   generation++
   addon.loadChanges(ctx, changes)
   addon.replay(ctx)
-  const patch = JSON.parse(addon.patchJSON(ctx))
-  return patch
+  return gpuPatch()
 }
 
 function init() {
@@ -125,6 +134,7 @@ function loadChanges(backend, changes) {
   if (!JS_ONLY && isEmptyRefState(backend) && Array.isArray(changes) && changes.length > 0) {
     try {
       const patch = gpuReplay(changes)
+      counters.gpuLoadChanges++
       backend.frozen = true
       const state = new GpuState(changes.slice(), patch, patch.deps)
       state.generation = generation
@@ -134,6 +144,7 @@ function loadChanges(backend, changes) {
       return { state, heads: patch.deps }
     } catch (e) {
       if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
+      counters.fallbackToJs++
       // fall through: the reference path raises the exact exception (or serves the unsupported case)
     }
   }
@@ -158,10 +169,12 @@ function load(data) {
       generation++
       addon.loadDocument(ctx, data)
       addon.replay(ctx)
-      const patch = JSON.parse(addon.patchJSON(ctx))
+      const patch = gpuPatch()
+      counters.gpuLoad++
       return { state: new GpuState(null, patch, patch.deps, data), heads: patch.deps }
     } catch (e) {
       if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
+      counters.fallbackToJs++
     }
   }
   return ref().load(data)
@@ -177,7 +190,9 @@ function save(backend) {
     if (g.doc) return g.doc   // unchanged loaded document: the bytes it was loaded from (new.js:2034)
     try {
       if (g.generation !== generation) { gpuReplay(g.changes); g.generation = generation }
-      return addon.save(ctx, 0)
+      const bytes = addon.save(ctx, 0)
+      counters.gpuSave++
+      return bytes
     } catch (e) {
       if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
     }
@@ -257,5 +272,6 @@ module.exports = {
   decodeSyncState: (...a) => ref().decodeSyncState(...a),
   initSyncState: (...a) => ref().initSyncState(...a),
   // engine statistics of the last GPU replay (not part of the reference surface)
-  _engineStats: () => (addon ? addon.stats(ctx) : null)
+  _engineStats: () => (addon ? addon.stats(ctx) : null),
+  _counters: counters
 }

@@ -1,0 +1,187 @@
+// Patch IR (the record tables of include/am355.h, as written by the device) -> the patch object the frontend consumes.
+//
+// This is presentation of results computed on the GPU; the shapes and key orders are the reference's, so that
+// JSON.stringify(materialize(ir)) === JSON.stringify(Backend.getPatch(state)) and assert.deepStrictEqual holds:
+//   envelope                       backend/new.js:2064-2067   {maxOp, clock, deps, pendingChanges, diffs}
+//   object patch                   backend/new.js:726-732     {objectId, type, props} | {objectId, type, edits}
+//   map props                      backend/new.js:1035-1039   props[key][opId] = valueDiff
+//   list edits                     backend/new.js:747-782     insert / multi-insert / update (appendEdit)
+//   values                         backend/columnar.js:300-329 decodeValue, new.js:963 (counter), :971 ({type: 'value', ...})
+// Values are real JS values (float64 NaN / Infinity stay what they are, byte arrays are Uint8Arrays): nothing goes through JSON text.
+'use strict'
+
+const OBJ_WORDS = 8, MAP_WORDS = 10, EDIT_WORDS = 8, VAL_WORDS = 2
+const MAP_COUNTER = 1, MAP_CHILD = 2, EDIT_UPDATE = 1, EDIT_CHILD = 4
+const TYPE_NAME = { 0: 'map', 2: 'list', 4: 'text', 6: 'table' }
+const HEX = []
+for (let i = 0; i < 256; i++) HEX.push((i < 16 ? '0' : '') + i.toString(16))
+const MAX_SAFE = Number.MAX_SAFE_INTEGER
+
+function unsupported(msg) {
+  // inputs the reference itself would throw on (number out of range, bad float length): the caller replays them on the JS path
+  const e = new RangeError(msg)
+  e.am355Code = -4
+  return e
+}
+
+function hexOf(bytes, start, end) {
+  let s = ''
+  for (let i = start; i < end; i++) s += HEX[bytes[i]]
+  return s
+}
+
+class Materializer {
+  constructor(ir) {
+    this.ir = ir
+    this.obj = new Uint32Array(ir.objects)
+    this.map = new Uint32Array(ir.map)
+    this.mapCounter = ir.map.byteLength ? new DataView(ir.map) : null
+    this.edit = new Uint32Array(ir.edits)
+    this.val = new Uint32Array(ir.values)
+    this.arena = new Uint8Array(ir.arena)
+    this.arenaBuf = Buffer.from(ir.arena)
+    this.decoder = new TextDecoder('utf-8')
+    const actorOff = new Uint32Array(ir.actorOff), actorBytes = new Uint8Array(ir.actorBytes)
+    this.actors = []
+    for (let a = 0; a < ir.nActors; a++) this.actors.push('@' + hexOf(actorBytes, actorOff[a], actorOff[a + 1]))
+    this.depth = 0
+  }
+
+  opId(ctr, actor) { return ctr + this.actors[actor] }
+
+  str(off, len) {
+    const a = this.arena
+    if (len === 1 && a[off] < 0x80) return String.fromCharCode(a[off])
+    let ascii = true
+    for (let i = off, e = off + len; i < e; i++) if (a[i] >= 0x80) { ascii = false; break }
+    if (ascii) return this.arenaBuf.latin1Slice(off, off + len)
+    return this.decoder.decode(a.subarray(off, off + len))   // utf8ToString of the reference (encoding.js): replacement on malformed input
+  }
+
+  // LEB128 as Decoder.readUint53 / readInt53 (encoding.js:341-488): value with the 53-bit range check
+  leb(off, len, signed) {
+    const a = this.arena
+    let result = 0, mul = 1
+    for (let i = 0; i < len; i++) {
+      const b = a[off + i]
+      if (!(b & 0x80)) {
+        if (signed && (b & 0x40)) result += ((b & 0x7f) - 0x80) * mul
+        else result += (b & 0x7f) * mul
+        if (result > MAX_SAFE || result < -MAX_SAFE || i > 9) throw unsupported('number out of range')
+        return result
+      }
+      result += (b & 0x7f) * mul
+      mul *= 128
+      if (i >= 9) throw unsupported('number out of range')
+    }
+    throw unsupported('buffer ended with incomplete number')
+  }
+
+  // {value, datatype?} exactly as decodeValue (key order: value, then datatype)
+  decode(tl, off) {
+    if (tl === 0) return { value: null }
+    if (tl === 1) return { value: false }
+    if (tl === 2) return { value: true }
+    const tag = tl & 15, len = tl >>> 4
+    switch (tag) {
+      case 6: return { value: this.str(off, len) }
+      case 3: return { value: this.leb(off, len, false), datatype: 'uint' }
+      case 4: return { value: this.leb(off, len, true), datatype: 'int' }
+      case 5:
+        if (len !== 8) throw unsupported(`Invalid length for floating point number: ${len}`)
+        return { value: new DataView(this.ir.arena, off, 8).getFloat64(0, true), datatype: 'float64' }
+      case 8: return { value: this.leb(off, len, true), datatype: 'counter' }
+      case 9: return { value: this.leb(off, len, true), datatype: 'timestamp' }
+      default: return { value: this.arena.slice(off, off + len), datatype: tag }
+    }
+  }
+
+  valueDiff(tl, off, child) {
+    if (child) return this.object(off)
+    const v = this.decode(tl, off)
+    return v.datatype === undefined ? { type: 'value', value: v.value } : { type: 'value', value: v.value, datatype: v.datatype }
+  }
+
+  sameKey(i, j) {
+    const m = this.map, a = this.arena
+    const len = m[i * MAP_WORDS + 3]
+    if (len !== m[j * MAP_WORDS + 3]) return false
+    const p = m[i * MAP_WORDS + 2], q = m[j * MAP_WORDS + 2]
+    if (p === q) return true
+    for (let k = 0; k < len; k++) if (a[p + k] !== a[q + k]) return false
+    return true
+  }
+
+  props(begin, end) {
+    const m = this.map, props = {}
+    for (let i = begin; i < end;) {
+      let j = i + 1
+      while (j < end && this.sameKey(i, j)) j++
+      const values = {}
+      for (let k = i; k < j; k++) {
+        const w = k * MAP_WORDS, flags = m[w + 6]
+        const id = this.opId(m[w], m[w + 1])
+        if (flags & MAP_COUNTER) {
+          const lo = this.mapCounter.getUint32(k * 40 + 32, true), hi = this.mapCounter.getInt32(k * 40 + 36, true)
+          values[id] = { type: 'value', datatype: 'counter', value: hi * 4294967296 + lo }
+        } else {
+          values[id] = this.valueDiff(m[w + 4], m[w + 5], (flags & MAP_CHILD) !== 0)
+        }
+      }
+      props[this.str(m[i * MAP_WORDS + 2], m[i * MAP_WORDS + 3])] = values   // (integer-like keys take their JS property order by themselves)
+      i = j
+    }
+    return props
+  }
+
+  edits(begin, end) {
+    const e = this.edit, v = this.val, out = new Array(end - begin)
+    for (let k = begin; k < end; k++) {
+      const w = k * EDIT_WORDS, flags = e[w], index = e[w + 1]
+      const first = e[w + 6], next = e[w + EDIT_WORDS + 6]
+      const tl = v[first * VAL_WORDS], off = v[first * VAL_WORDS + 1]
+      if (next - first >= 2) {
+        const values = new Array(next - first)
+        for (let i = first; i < next; i++) values[i - first] = this.decode(v[i * VAL_WORDS], v[i * VAL_WORDS + 1]).value
+        const head = this.decode(tl, off)
+        const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
+        if (head.datatype) edit.datatype = head.datatype   // only truthy datatypes (new.js:762)
+        edit.values = values
+        out[k - begin] = edit
+      } else if (flags & EDIT_UPDATE) {
+        out[k - begin] = { action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) }
+      } else {
+        out[k - begin] = { action: 'insert', index, elemId: this.opId(e[w + 4], e[w + 5]), opId: this.opId(e[w + 2], e[w + 3]),
+                           value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) }
+      }
+    }
+    return out
+  }
+
+  object(oi) {
+    if (oi >= this.ir.nObjects) throw new Error('patch IR: object index out of range')
+    if (++this.depth > 10000) throw unsupported('object nesting too deep')
+    const o = this.obj, w = oi * OBJ_WORDS
+    const type = oi === 0 ? 0 : o[w + 2]
+    const res = { objectId: oi === 0 ? '_root' : this.opId(o[w], o[w + 1]), type: TYPE_NAME[type] === undefined ? null : TYPE_NAME[type] }
+    if (oi !== 0 && (type === 2 || type === 4)) res.edits = this.edits(o[w + 5], o[w + 6])
+    else res.props = this.props(o[w + 3], o[w + 4])
+    this.depth--
+    return res
+  }
+
+  patch() {
+    const ir = this.ir, clock = {}
+    const clockActor = new Uint32Array(ir.clockActor), clockSeq = new Float64Array(ir.clockSeq)
+    for (let i = 0; i < clockActor.length; i++) clock[this.actors[clockActor[i]].slice(1)] = clockSeq[i]
+    const heads = new Uint8Array(ir.heads), deps = []
+    for (let i = 0; i + 32 <= heads.length; i += 32) deps.push(hexOf(heads, i, i + 32))
+    return { maxOp: ir.maxOp, clock, deps, pendingChanges: ir.pending, diffs: this.object(0) }
+  }
+}
+
+function materialize(ir) {
+  return new Materializer(ir).patch()
+}
+
+module.exports = { materialize }

@@ -38,4 +38,5 @@ function run(suite, prefix, bes, aes) {
 for (const f of process.argv.slice(2)) require(path.join(REF, 'test', f))
 run(stack[0], '', [], [])
 console.log(`${passed} passed, ${failed} failed (reference suites ${process.argv.slice(2).join(', ')} against mi355x-backend${process.env.MI355X_BACKEND_JS_ONLY === '1' ? ' in JS-only plumbing mode' : ''})`)
+if (Backend._counters) console.log('served by: ' + JSON.stringify(Backend._counters))
 process.exit(failed ? 1 : 0)

@@ -1,4 +1,5 @@
 """The JavaScript host side (north_star: host code stays JavaScript, calling HIP through an N-API addon)."""
+import json
 import os
 import shutil
 import subprocess
@@ -34,6 +35,59 @@ def test_js_backend_plumbing_runs_reference_suites():
                          capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert " 0 failed" in out.stdout
+
+
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libam355_emu.so")
+
+
+def _emu_env(**extra):
+    """node with the CPU emulation build of the engine preloaded: the addon's am355_* calls resolve to it (test infrastructure;
+    the product addon links automerge_classic_amd/csrc/libam355.so, which needs the GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    if not os.path.exists(os.path.join(JS, "am355_napi.node")):
+        import __graft_entry__ as g
+        g.build_js_addon()
+    return dict(os.environ, LD_PRELOAD=EMU_LIB, **extra)
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_host_materialises_reference_patches_emulated():
+    """node -> index.js -> addon -> (emulated) engine -> patch IR -> materialize.js: every golden fixture through the JS Backend surface
+    and a slice of the vectors captured from the reference's suites, JSON.stringify-exact against the reference's patches."""
+    env = _emu_env()
+    out = subprocess.run([NODE, os.path.join(JS, "test_golden.js"), os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "golden fixtures reproduced" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    out = subprocess.run([NODE, os.path.join(JS, "test_vectors.js"), os.path.join(ROOT, "tests", "golden", "ref_suite_vectors.json.gz"), "12", "5"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and '"failed":0' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.skipif(NODE is None or not os.path.isdir("/root/reference"), reason="needs node and the reference tree (build container only)")
+def test_reference_suites_and_frontend_flows_over_the_engine_enabled_wrapper_emulated():
+    """The reference's own suites and frontend flows (load -> getAllChanges -> change, merge of loaded documents, clone, sync, history
+    snapshots) against mi355x-backend WITH the engine serving Backend.load / loadChanges (emulated kernels): GpuState handles,
+    freezing and lazy hydration behave like reference handles."""
+    env = _emu_env(NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"), AUTOMERGE_BACKEND_PATH="/root/reference/backend")
+    out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "wrapper_flows.js")], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "wrapper flows ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "run_ref_tests.js"), "test.js", "text_test.js", "sync_test.js", "backend_test.js"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and " 0 failed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    served = json.loads(out.stdout.split("served by: ")[1].splitlines()[0])
+    assert served["gpuLoad"] >= 10 and served["fallbackToJs"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_host_reproduces_all_reference_suite_vectors_on_gpu():
+    """All 1499 vectors captured from the reference's suites through node -> addon -> MI355X -> materialize.js."""
+    if not os.path.exists(os.path.join(JS, "am355_napi.node")):
+        import __graft_entry__ as g
+        g.build_js_addon()
+    out = subprocess.run([NODE, os.path.join(JS, "test_vectors.js")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["vectors"] >= 1499 and res["equal"] >= 1490 and res["rejected"] == [14, 16, 25, 33] and res["unsupported"] == [56, 911]
 
 
 @pytest.mark.skipif(NODE is None, reason="node not installed")
