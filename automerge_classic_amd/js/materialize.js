@@ -16,6 +16,8 @@ const TYPE_NAME = { 0: 'map', 2: 'list', 4: 'text', 6: 'table' }
 const HEX = []
 for (let i = 0; i < 256; i++) HEX.push((i < 16 ? '0' : '') + i.toString(16))
 const MAX_SAFE = Number.MAX_SAFE_INTEGER
+const ASCII = []
+for (let i = 0; i < 128; i++) ASCII.push(String.fromCharCode(i))
 
 function unsupported(msg) {
   // inputs the reference itself would throw on (number out of range, bad float length): the caller replays them on the JS path
@@ -51,7 +53,7 @@ class Materializer {
 
   str(off, len) {
     const a = this.arena
-    if (len === 1 && a[off] < 0x80) return String.fromCharCode(a[off])
+    if (len === 1 && a[off] < 0x80) return ASCII[a[off]]
     let ascii = true
     for (let i = off, e = off + len; i < e; i++) if (a[i] >= 0x80) { ascii = false; break }
     if (ascii) return this.arenaBuf.latin1Slice(off, off + len)
@@ -98,6 +100,7 @@ class Materializer {
 
   valueDiff(tl, off, child) {
     if (child) return this.object(off)
+    if ((tl & 15) === 6) return { type: 'value', value: this.str(off, tl >>> 4) }   // (the common case without the intermediate object)
     const v = this.decode(tl, off)
     return v.datatype === undefined ? { type: 'value', value: v.value } : { type: 'value', value: v.value, datatype: v.datatype }
   }
@@ -142,12 +145,17 @@ class Materializer {
       const tl = v[first * VAL_WORDS], off = v[first * VAL_WORDS + 1]
       if (next - first >= 2) {
         const values = new Array(next - first)
-        for (let i = first; i < next; i++) values[i - first] = this.decode(v[i * VAL_WORDS], v[i * VAL_WORDS + 1]).value
-        const head = this.decode(tl, off)
-        const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
-        if (head.datatype) edit.datatype = head.datatype   // only truthy datatypes (new.js:762)
-        edit.values = values
-        out[k - begin] = edit
+        if ((tl & 15) === 6) {   // strings: a run of typed characters
+          for (let i = first; i < next; i++) { const t = v[i * VAL_WORDS]; values[i - first] = this.str(v[i * VAL_WORDS + 1], t >>> 4) }
+          out[k - begin] = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]), values }
+        } else {
+          for (let i = first; i < next; i++) values[i - first] = this.decode(v[i * VAL_WORDS], v[i * VAL_WORDS + 1]).value
+          const head = this.decode(tl, off)
+          const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
+          if (head.datatype) edit.datatype = head.datatype   // only truthy datatypes (new.js:762)
+          edit.values = values
+          out[k - begin] = edit
+        }
       } else if (flags & EDIT_UPDATE) {
         out[k - begin] = { action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) }
       } else {
