@@ -1093,8 +1093,8 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
 // Device buffers for N op rows / P preds, decode, merge, patch IR. `slot_rank` != null: actor tables are the
 // device-interned slots (fast path); null: c->amap holds ranks (general path).
 // Device buffers for N op rows / P preds (op rows, merge scratch, sort scratch, patch IR), carved from a few arenas.
-static int setup_buffers(am355_ctx* c) {
-  uint32_t N = (uint32_t)c->n_ops, P = (uint32_t)c->n_preds, NA = (uint32_t)c->actors.size();
+static int setup_buffers(am355_ctx* c, uint32_t NA) {
+  uint32_t N = (uint32_t)c->n_ops, P = (uint32_t)c->n_preds;
   int bits_ctr = bits_for64(c->max_op), bits_actor = bits_for64(NA ? NA - 1 : 0), bits_row = bits_for64(N);
   if (1 + bits_row + bits_ctr + bits_actor > 64) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "sort key wider than 64 bits"); }
   size_t Nc = (size_t)N + 1;
@@ -1184,7 +1184,7 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   uint8_t* d_tables = c->d_tables.as<uint8_t>();
   c->p_spans = (ActorSpan*)(d_tables + o_spans);
   c->p_tab_off = (uint32_t*)(d_tables + o_tab);
-  int rcb = setup_buffers(c);
+  int rcb = setup_buffers(c, (uint32_t)c->actors.size());
   if (rcb) return rcb;
   // decoder classes: changes whose columns fit the small LDS footprint first, then the large footprint, then the (rare)
   // ones with a column too long for LDS staging
@@ -1245,6 +1245,58 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   return AM355_OK;
 }
 
+// In-order fast path with the device-side plan (k_plan): the decode kernels are launched from the device-built plans as soon as
+// the host knows the totals; the host's own planning (sequence numbers, clock, per-actor span tables: plan_fast) runs while the
+// decode kernels do, and its tables reach the device before k_resolve needs them.
+static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_distinct, float* ms_host_plan) {
+  hipStream_t st = c->stream;
+  uint32_t n = c->n_changes;
+  c->n_ops = tot.n_ops;
+  c->n_preds = tot.n_preds;
+  c->max_op = tot.max_op;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // device block for the host-built tables: actor spans (at most one per change) | span offsets (one per actor + 1)
+  size_t o_tab = al(sizeof(ActorSpan) * (size_t)n + 16), tables_bytes = o_tab + al(4 * ((size_t)n_distinct + 1) + 16);
+  if (!c->d_tables.ensure(tables_bytes) || !c->h_stage.ensure(tables_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed");
+  uint8_t* d_tables = c->d_tables.as<uint8_t>();
+  c->p_spans = (ActorSpan*)d_tables;
+  c->p_tab_off = (uint32_t*)(d_tables + o_tab);
+  int rcb = setup_buffers(c, n_distinct);
+  if (rcb) return rcb;
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+  merge_prepare(c->mb, c->stream3);
+  HIPCHK(c, hipEventRecord(c->ev[2], st));
+  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), tot.n_small, tot.n_large, tot.n_serial,
+                        c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3);
+  HIPCHK(c, hipEventRecord(c->ev[3], st));
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+  HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+  // ---- host half of the plan, beside the decode kernels ----
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<uint32_t> slot_rank;
+  int rc = plan_fast(c, slot_rank);
+  *ms_host_plan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (rc == AM355_OK && (c->n_ops != tot.n_ops || c->n_preds != tot.n_preds || c->max_op != tot.max_op || c->actors.size() != n_distinct))
+    rc = fail(c, AM355_E_DEVICE, "internal: device and host plans disagree (%llu / %u ops)", (unsigned long long)c->n_ops, tot.n_ops);
+  if (rc) { (void)hipStreamSynchronize(st); return rc; }
+  {
+    uint8_t* h = c->h_stage.as<uint8_t>();
+    size_t b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size();
+    if (b_spans) memcpy(h, c->spans.data(), b_spans);
+    memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
+    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_tab + b_tab, hipMemcpyHostToDevice, st));
+  }
+  Counts* hc = c->h_counts.as<Counts>();
+  merge_run(c->mb, c->ir, hc, st, c->ev_counts, c->ev_runs);
+  HIPCHK(c, hipEventRecord(c->ev[5], st));
+  if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
+  c->counts = *hc;
+  c->counts.n_objects += 1;  // + _root
+  return AM355_OK;
+}
+
 // Backend.load(bytes) + getPatch: device decode of the document's op columns, then the whole-document patch of the
 // (already canonical) rows. new.js:1695-1750, 1604-1635.
 static int replay_document(am355_ctx* c) {
@@ -1273,7 +1325,7 @@ static int replay_document(am355_ctx* c) {
     c->n_pending = 0;
     c->max_op = 0xffffffffu >> 8;  // only sizes sort keys, which the document path never builds
     if (c->n_ops >= 0x7ffffff0ull) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 rows in one document"); }
-    int rc = setup_buffers(c);
+    int rc = setup_buffers(c, NA);
     if (rc) return rc;
     ChangePlan pl{0, 0, 0, 0, NONE32, NA};  // author NONE32 = document mode: ids come from the idActor / idCtr columns
     HIPCHK(c, hipMemcpyAsync(c->d_plans.p, &pl, sizeof pl, hipMemcpyHostToDevice, st));
@@ -1336,7 +1388,7 @@ static int replay_document(am355_ctx* c) {
     c->n_applied = c->n_changes;
     c->n_pending = 0;
     c->max_op = 0xffffffffu >> 8;  // only sizes sort keys, which the document path never builds
-    int rc = setup_buffers(c);
+    int rc = setup_buffers(c, NA);
     if (rc) { (void)hipStreamSynchronize(c->stream2); return rc; }
     HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
     uint32_t* flags = &c->d_counts.as<Counts>()->flags;
@@ -1400,11 +1452,13 @@ static int replay_impl(am355_ctx* c) {
       !c->d_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->d_first_idx.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_hashes.ensure(32 * n1) ||
       !c->d_hash_tab.ensure(4 * (size_t)(c->hash_mask + 1)) || !c->d_min_idx.ensure(4 * n1) || !c->d_has_dep.ensure(n1) || !c->d_words.ensure(4 * W_NUM) ||
       !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
-      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM))
+      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_plans.ensure(sizeof(ChangePlan) * n1) ||
+      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)))
     return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
   c->have_host_metas = false;
   // what the host reads after stage 1 -- a few flag words, the distinct actor ids, one brief per change -- sits in one device
   // block: one memset clears the words and the distinct counter, one copy brings everything back
+  // (words 0..7: flag words; words 8..15: PlanTotals of k_plan)
   const size_t s1_distinct = 64, s1_briefs = s1_distinct + ((12 * (size_t)distinct_capacity() + 16 + 63) & ~(size_t)63);
   const size_t s1_bytes = s1_briefs + sizeof(ChangeBrief) * n1;
   if (!c->d_s1.ensure(s1_bytes) || !c->h_s1.ensure(s1_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
@@ -1450,6 +1504,8 @@ static int replay_impl(am355_ctx* c) {
       HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
       HIPCHK(c, hipEventRecord(c->ev_b1, sb));
     }
+    // device half of the in-order plan (actor ranks, per-change bases, decoder classes): the decode kernels start from it
+    launch_plan(c->d_arena.as<uint8_t>(), d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plans.as<ChangePlan>(), (PlanTotals*)(d_wa + 8), sa);
     // the host only needs a 32-byte digest per change and the handful of distinct actor ids
     HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
     lap("stage 1 enqueued");
@@ -1466,6 +1522,7 @@ static int replay_impl(am355_ctx* c) {
   auto t_h0 = std::chrono::steady_clock::now();
   float ms_host = 0;
   int rc = AM355_OK;
+  uint64_t sum_ops = 0, sum_preds = 0, sum_entries = 0;
   {
     const ChangeBrief* br = c->hp_briefs;
     uint32_t dev_flags = h_wa[W_FLAGS_A];
@@ -1473,16 +1530,30 @@ static int replay_impl(am355_ctx* c) {
     for (uint32_t i = 0; i < n; i++) {
       dev_flags |= br[i].flags_fits & 0x1fffffffu;
       if (br[i].flags_fits & 0x20000000u) c->has_unknown_cols = true;
+      sum_ops += br[i].n_ops; sum_preds += br[i].n_preds; sum_entries += br[i].n_entries;
     }
     if (dev_flags) { (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
   }
+  // the device-built plan is used when its packed 32-bit sums cannot have wrapped and the device ranked the actors itself
+  PlanTotals tot;
+  memcpy(&tot, h_wa + 8, sizeof tot);
+  const bool planned = !tot.fallback && sum_ops < 0x7ffffff0ull && sum_preds < 0xfffffff0ull && sum_entries < 0xfffffff0ull && tot.n_ops == sum_ops &&
+                       tot.n_preds == sum_preds && tot.n_entries == sum_entries && !getenv("AM355_HOST_PLAN");
   bool fast = h_wa[W_FAST_A] == 0;
   if (c->hp_distinct[0] > distinct_capacity()) fast = false;  // thousands of actors: the general path interns them on the host
   std::vector<uint32_t> slot_rank;
   int opt_rc = AM355_OK;
   uint32_t opt_flags = 0;
   std::string opt_err;
-  if (fast) {
+  if (fast && planned) {
+    ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+    float ms_plan = 0;
+    opt_rc = run_device_planned(c, tot, c->hp_distinct[0], &ms_plan);  // optimistic: confirmed (or discarded) when stream B is joined
+    ms_host += ms_plan;  // (host planning time; it runs beside the decode kernels)
+    lap("run_device (device plan) done");
+    opt_flags = c->flags;
+    opt_err = c->err;
+  } else if (fast) {
     opt_rc = plan_fast(c, slot_rank);
     ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
     lap("plan_fast done");

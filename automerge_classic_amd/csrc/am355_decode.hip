@@ -1524,6 +1524,141 @@ void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, co
                            (const uint32_t*)first_idx, flags, fast_flags, briefs);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_plan: one workgroup. (new.js:1434-1451 actor table, :708-709 op id ranges -- the arithmetic the host's plan_fast does too)
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t PLAN_THREADS = 1024;
+constexpr uint32_t PLAN_RANK_MAX = 1024;   // distinct actors ranked on the device (LDS: 40 bytes each)
+constexpr uint32_t PLAN_ID_MAX = 32;       // bytes of an actor id the device ranking handles (ids are 16 bytes in practice)
+
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long x, uint32_t lane) {
+  for (int d = 1; d < WAVE; d <<= 1) {
+    unsigned long long y = __shfl_up(x, (unsigned)d);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  return x;
+}
+// exclusive prefix over the 1024-thread workgroup of three packed 64-bit counters at once; totals returned through t[]
+__device__ __forceinline__ void plan_scan3(unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long (*s)[3], unsigned long long ex[3],
+                                           unsigned long long t[3]) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  unsigned long long ia = wave_incl_scan_u64(a, lane), ib = wave_incl_scan_u64(b, lane), ic = wave_incl_scan_u64(c, lane);
+  if (lane == WAVE - 1) { s[w][0] = ia; s[w][1] = ib; s[w][2] = ic; }
+  __syncthreads();
+  unsigned long long ba = 0, bb = 0, bc = 0, ta = 0, tb = 0, tc = 0;
+  for (uint32_t k = 0; k < PLAN_THREADS / WAVE; k++) {
+    unsigned long long xa = s[k][0], xb = s[k][1], xc = s[k][2];
+    if (k < w) { ba += xa; bb += xb; bc += xc; }
+    ta += xa; tb += xb; tc += xc;
+  }
+  __syncthreads();
+  ex[0] = ba + ia - a; ex[1] = bb + ib - b; ex[2] = bc + ic - c;
+  t[0] = ta; t[1] = tb; t[2] = tc;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict__ arena, const ChangeBrief* __restrict__ briefs, uint32_t n,
+                                                       const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank, uint32_t slot_mask,
+                                                       ChangePlan* __restrict__ plans, PlanTotals* __restrict__ totals) {
+  __shared__ unsigned long long s_id[PLAN_RANK_MAX][PLAN_ID_MAX / 8];  // big-endian words, zero padded
+  __shared__ uint32_t s_len[PLAN_RANK_MAX];
+  __shared__ unsigned long long s_scan[PLAN_THREADS / WAVE][3];
+  __shared__ uint32_t s_fallback, s_max;
+  const uint32_t t = threadIdx.x;
+  const uint32_t nd = distinct[0];
+  if (t == 0) { s_fallback = nd > PLAN_RANK_MAX ? 1u : 0u; s_max = 0; }
+  __syncthreads();
+  // ---- actor ranks: lexicographic order of the id bytes (a proper prefix sorts first) = order of the hex strings (new.js:65) ----
+  if (nd <= PLAN_RANK_MAX) {
+    const unsigned long long* slot_val = (const unsigned long long*)(distinct + 2 + DISTINCT_CAP);
+    if (t < nd) {
+      unsigned long long v = slot_val[t];
+      uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
+      s_len[t] = len;
+      if (len > PLAN_ID_MAX) s_fallback = 1;
+      else {
+        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
+          unsigned long long x = 0;
+          for (uint32_t k = 0; k < 8; k++) x = x << 8 | (wd * 8 + k < len ? arena[off + wd * 8 + k] : 0u);
+          s_id[t][wd] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const bool fallback = s_fallback != 0;
+  if (!fallback && t < nd) {
+    uint32_t rank = 0;
+    const uint32_t my_len = s_len[t];
+    unsigned long long mine[PLAN_ID_MAX / 8];
+    for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) mine[wd] = s_id[t][wd];
+    for (uint32_t j = 0; j < nd; j++) {
+      bool less = false, decided = false;
+      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8 && !decided; wd++) {
+        unsigned long long x = s_id[j][wd];
+        if (x != mine[wd]) { less = x < mine[wd]; decided = true; }
+      }
+      if (!decided) less = s_len[j] < my_len;  // equal up to the padding: the shorter id first (distinct ids differ somewhere)
+      rank += less ? 1u : 0u;
+    }
+    slot_rank[distinct[1 + t]] = rank;
+  }
+  __syncthreads();
+  if (fallback) {
+    if (t == 0) { PlanTotals z{}; z.fallback = 1; *totals = z; }
+    return;
+  }
+  // ---- pass 1: plans per decoder class ----
+  uint32_t c_small = 0, c_large = 0, c_serial = 0, mx = 0;
+  for (uint32_t i = t; i < n; i += PLAN_THREADS) {
+    const ChangeBrief br = briefs[i];
+    if (!br.n_ops || (br.flags_fits & 0x1fffffffu)) continue;  // (a malformed change: the host rejects the batch as soon as it sees the flags)
+    if (br.flags_fits & 0x40000000u) c_small++;
+    else if (br.flags_fits & 0x80000000u) c_large++;
+    else c_serial++;
+    uint32_t last = br.start_op + br.n_ops - 1;
+    mx = last > mx ? last : mx;
+  }
+  unsigned long long ex[3], tot[3];
+  plan_scan3(c_small, c_large, c_serial, s_scan, ex, tot);
+  const uint32_t n_small = (uint32_t)tot[0], n_large = (uint32_t)tot[1], n_serial = (uint32_t)tot[2];
+  atomicMax(&s_max, mx);
+  // ---- pass 2: prefix sums in input order, tile by tile with running carries ----
+  unsigned long long carry_rows = 0;     // ops << 32 | preds   (both < 2^32, checked by the host)
+  unsigned long long carry_ent_small = 0;  // entries | small plans << 32
+  unsigned long long carry_lg_ser = 0;     // large plans | serial plans << 32
+  for (uint32_t base = 0; base < n; base += PLAN_THREADS) {
+    const uint32_t i = base + t;
+    ChangeBrief br{};
+    if (i < n) br = briefs[i];
+    const bool has = i < n && br.n_ops != 0 && !(br.flags_fits & 0x1fffffffu);
+    const bool small = has && (br.flags_fits & 0x40000000u), large = has && !small && (br.flags_fits & 0x80000000u), serial = has && !small && !large;
+    const bool valid = !(br.flags_fits & 0x1fffffffu);
+    unsigned long long a = valid ? (unsigned long long)br.n_ops << 32 | br.n_preds : 0ull;
+    unsigned long long b = (unsigned long long)(valid ? br.n_entries : 0u) | (unsigned long long)(small ? 1u : 0u) << 32;
+    unsigned long long cc = (unsigned long long)(large ? 1u : 0u) | (unsigned long long)(serial ? 1u : 0u) << 32;
+    plan_scan3(a, b, cc, s_scan, ex, tot);
+    if (has) {
+      unsigned long long rows = carry_rows + ex[0], es = carry_ent_small + ex[1], ls = carry_lg_ser + ex[2];
+      uint32_t pos = small ? (uint32_t)(es >> 32) : large ? n_small + (uint32_t)ls : n_small + n_large + (uint32_t)(ls >> 32);
+      // (author_slot is only meaningful once k_actor_intern has run for the change: a capacity retry leaves it unset in the first attempt)
+      plans[pos] = ChangePlan{i, (uint32_t)(rows >> 32), (uint32_t)rows, (uint32_t)es, br.author_slot <= slot_mask ? slot_rank[br.author_slot] : 0u, br.n_entries};
+    }
+    carry_rows += tot[0]; carry_ent_small += tot[1]; carry_lg_ser += tot[2];
+  }
+  __syncthreads();
+  if (t == 0) {
+    PlanTotals z{};
+    z.n_ops = (uint32_t)(carry_rows >> 32); z.n_preds = (uint32_t)carry_rows; z.n_entries = (uint32_t)carry_ent_small;
+    z.n_small = n_small; z.n_large = n_large; z.n_serial = n_serial; z.max_op = s_max; z.fallback = 0;
+    *totals = z;
+  }
+}
+
+void launch_plan(const uint8_t* arena, const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, uint32_t* slot_rank, uint32_t slot_mask,
+                 ChangePlan* plans, PlanTotals* totals, hipStream_t st) {
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, arena, briefs, n, distinct, slot_rank, slot_mask, plans, totals);
+}
+
 uint32_t distinct_capacity() { return DISTINCT_CAP; }
 
 // rows and succ entries of a document's op columns (lane 0: values in `action`; lane 1: sum of `succNum`)

@@ -54,6 +54,15 @@ struct ChangePlan {
   uint32_t n_actors;   // entries in its actor table
 };
 
+// What k_plan reports to the host: the host sizes buffers and launch grids with it while it is still checking sequence numbers and
+// building the per-actor tables itself
+struct PlanTotals {
+  uint32_t n_ops, n_preds, n_entries;
+  uint32_t n_small, n_large, n_serial;  // plans per decoder class (changes without ops have no plan)
+  uint32_t max_op;
+  uint32_t fallback;                    // 1: more distinct actors or longer actor ids than the device ranking handles -- the host plans
+};
+
 // Per-actor lookup table entry for opId -> row resolution: the applied changes of one actor, ascending start_op
 struct ActorSpan {
   uint32_t start_op, n_ops, op_base;
