@@ -1268,8 +1268,9 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
   merge_prepare(c->mb, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev[2], st));
-  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), tot.n_small, tot.n_large, tot.n_serial,
-                        c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3);
+  launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n,
+                        tot.n_small, tot.n_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
+                        &c->d_counts.as<Counts>()->flags, st, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -1452,7 +1453,7 @@ static int replay_impl(am355_ctx* c) {
       !c->d_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->d_first_idx.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_hashes.ensure(32 * n1) ||
       !c->d_hash_tab.ensure(4 * (size_t)(c->hash_mask + 1)) || !c->d_min_idx.ensure(4 * n1) || !c->d_has_dep.ensure(n1) || !c->d_words.ensure(4 * W_NUM) ||
       !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
-      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_plans.ensure(sizeof(ChangePlan) * n1) ||
+      !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_plans.ensure(2 * sizeof(ChangePlan) * n1) ||
       !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)))
     return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
   c->have_host_metas = false;
@@ -1486,6 +1487,11 @@ static int replay_impl(am355_ctx* c) {
     launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
                         c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_wa + W_FLAGS_A, d_wa + W_FAST_A,
                         d_distinct, d_briefs, sa);
+    // device half of the in-order plan (actor ranks, per-change bases, decoder classes): the decode kernels start from it
+    launch_plan(c->d_arena.as<uint8_t>(), d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plans.as<ChangePlan>(),
+                c->d_plans.as<ChangePlan>() + n1, (PlanTotals*)(d_wa + 8), sa);
+    // the host only needs a 32-byte digest per change and the handful of distinct actor ids
+    HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
     HIPCHK(c, hipEventRecord(c->ev[1], sa));
     if (attempt == 0) {
       // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. It starts
@@ -1504,10 +1510,6 @@ static int replay_impl(am355_ctx* c) {
       HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
       HIPCHK(c, hipEventRecord(c->ev_b1, sb));
     }
-    // device half of the in-order plan (actor ranks, per-change bases, decoder classes): the decode kernels start from it
-    launch_plan(c->d_arena.as<uint8_t>(), d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plans.as<ChangePlan>(), (PlanTotals*)(d_wa + 8), sa);
-    // the host only needs a 32-byte digest per change and the handful of distinct actor ids
-    HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
     lap("stage 1 enqueued");
     HIPCHK(c, hipStreamSynchronize(sa));
     lap("stage 1 done");

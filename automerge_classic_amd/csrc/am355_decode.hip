@@ -1556,9 +1556,13 @@ __device__ __forceinline__ void plan_scan3(unsigned long long a, unsigned long l
   t[0] = ta; t[1] = tb; t[2] = tc;
 }
 
+constexpr uint32_t PLAN_ITEMS = 4;  // consecutive changes per thread and tile
+
+// plans: [n] -- the small class fills it from the front, the large class from the back (a plan's place inside its class does not
+// matter: every plan is an independent unit of decode work); plans_serial: [n] the changes left to the lane-serial decoder.
 __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict__ arena, const ChangeBrief* __restrict__ briefs, uint32_t n,
                                                        const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank, uint32_t slot_mask,
-                                                       ChangePlan* __restrict__ plans, PlanTotals* __restrict__ totals) {
+                                                       ChangePlan* __restrict__ plans, ChangePlan* __restrict__ plans_serial, PlanTotals* __restrict__ totals) {
   __shared__ unsigned long long s_id[PLAN_RANK_MAX][PLAN_ID_MAX / 8];  // big-endian words, zero padded
   __shared__ uint32_t s_len[PLAN_RANK_MAX];
   __shared__ unsigned long long s_scan[PLAN_THREADS / WAVE][3];
@@ -1568,19 +1572,22 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict
   if (t == 0) { s_fallback = nd > PLAN_RANK_MAX ? 1u : 0u; s_max = 0; }
   __syncthreads();
   // ---- actor ranks: lexicographic order of the id bytes (a proper prefix sorts first) = order of the hex strings (new.js:65) ----
-  if (nd <= PLAN_RANK_MAX) {
+  if (nd <= PLAN_RANK_MAX && t < nd) {
     const unsigned long long* slot_val = (const unsigned long long*)(distinct + 2 + DISTINCT_CAP);
-    if (t < nd) {
-      unsigned long long v = slot_val[t];
-      uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
-      s_len[t] = len;
-      if (len > PLAN_ID_MAX) s_fallback = 1;
-      else {
-        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
-          unsigned long long x = 0;
-          for (uint32_t k = 0; k < 8; k++) x = x << 8 | (wd * 8 + k < len ? arena[off + wd * 8 + k] : 0u);
-          s_id[t][wd] = x;
-        }
+    unsigned long long v = slot_val[t];
+    uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
+    s_len[t] = len;
+    if (len > PLAN_ID_MAX) s_fallback = 1;
+    else {
+      uint8_t bytes[PLAN_ID_MAX];  // (all loads issued before the first use: one memory round trip, not one per byte)
+#pragma unroll
+      for (uint32_t k = 0; k < PLAN_ID_MAX; k++) bytes[k] = k < len ? arena[off + k] : (uint8_t)0;
+#pragma unroll
+      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
+        unsigned long long x = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) x = x << 8 | bytes[wd * 8 + k];
+        s_id[t][wd] = x;
       }
     }
   }
@@ -1607,56 +1614,63 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict
     if (t == 0) { PlanTotals z{}; z.fallback = 1; *totals = z; }
     return;
   }
-  // ---- pass 1: plans per decoder class ----
-  uint32_t c_small = 0, c_large = 0, c_serial = 0, mx = 0;
-  for (uint32_t i = t; i < n; i += PLAN_THREADS) {
-    const ChangeBrief br = briefs[i];
-    if (!br.n_ops || (br.flags_fits & 0x1fffffffu)) continue;  // (a malformed change: the host rejects the batch as soon as it sees the flags)
-    if (br.flags_fits & 0x40000000u) c_small++;
-    else if (br.flags_fits & 0x80000000u) c_large++;
-    else c_serial++;
-    uint32_t last = br.start_op + br.n_ops - 1;
-    mx = last > mx ? last : mx;
-  }
-  unsigned long long ex[3], tot[3];
-  plan_scan3(c_small, c_large, c_serial, s_scan, ex, tot);
-  const uint32_t n_small = (uint32_t)tot[0], n_large = (uint32_t)tot[1], n_serial = (uint32_t)tot[2];
-  atomicMax(&s_max, mx);
-  // ---- pass 2: prefix sums in input order, tile by tile with running carries ----
-  unsigned long long carry_rows = 0;     // ops << 32 | preds   (both < 2^32, checked by the host)
+  // ---- prefix sums in input order: PLAN_ITEMS consecutive changes per thread, tile by tile with running carries ----
+  unsigned long long carry_rows = 0;       // ops << 32 | preds   (both < 2^32: the host checks the sums before it uses the plan)
   unsigned long long carry_ent_small = 0;  // entries | small plans << 32
   unsigned long long carry_lg_ser = 0;     // large plans | serial plans << 32
-  for (uint32_t base = 0; base < n; base += PLAN_THREADS) {
-    const uint32_t i = base + t;
-    ChangeBrief br{};
-    if (i < n) br = briefs[i];
-    const bool has = i < n && br.n_ops != 0 && !(br.flags_fits & 0x1fffffffu);
-    const bool small = has && (br.flags_fits & 0x40000000u), large = has && !small && (br.flags_fits & 0x80000000u), serial = has && !small && !large;
-    const bool valid = !(br.flags_fits & 0x1fffffffu);
-    unsigned long long a = valid ? (unsigned long long)br.n_ops << 32 | br.n_preds : 0ull;
-    unsigned long long b = (unsigned long long)(valid ? br.n_entries : 0u) | (unsigned long long)(small ? 1u : 0u) << 32;
-    unsigned long long cc = (unsigned long long)(large ? 1u : 0u) | (unsigned long long)(serial ? 1u : 0u) << 32;
-    plan_scan3(a, b, cc, s_scan, ex, tot);
-    if (has) {
-      unsigned long long rows = carry_rows + ex[0], es = carry_ent_small + ex[1], ls = carry_lg_ser + ex[2];
-      uint32_t pos = small ? (uint32_t)(es >> 32) : large ? n_small + (uint32_t)ls : n_small + n_large + (uint32_t)(ls >> 32);
-      // (author_slot is only meaningful once k_actor_intern has run for the change: a capacity retry leaves it unset in the first attempt)
-      plans[pos] = ChangePlan{i, (uint32_t)(rows >> 32), (uint32_t)rows, (uint32_t)es, br.author_slot <= slot_mask ? slot_rank[br.author_slot] : 0u, br.n_entries};
+  uint32_t mx = 0;
+  for (uint32_t base = 0; base < n; base += PLAN_THREADS * PLAN_ITEMS) {
+    ChangeBrief br[PLAN_ITEMS];
+    unsigned long long a[PLAN_ITEMS], b[PLAN_ITEMS], cc[PLAN_ITEMS], sa = 0, sb = 0, sc = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PLAN_ITEMS; k++) {
+      const uint32_t i = base + t * PLAN_ITEMS + k;
+      br[k] = ChangeBrief{};
+      if (i < n) br[k] = briefs[i];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PLAN_ITEMS; k++) {
+      const bool valid = !(br[k].flags_fits & 0x1fffffffu);  // (a malformed change: the host rejects the batch as soon as it sees the flags)
+      const bool has = valid && br[k].n_ops != 0;
+      const bool small = has && (br[k].flags_fits & 0x40000000u), large = has && !small && (br[k].flags_fits & 0x80000000u), serial = has && !small && !large;
+      a[k] = valid ? (unsigned long long)br[k].n_ops << 32 | br[k].n_preds : 0ull;
+      b[k] = (unsigned long long)(valid ? br[k].n_entries : 0u) | (unsigned long long)(small ? 1u : 0u) << 32;
+      cc[k] = (unsigned long long)(large ? 1u : 0u) | (unsigned long long)(serial ? 1u : 0u) << 32;
+      sa += a[k]; sb += b[k]; sc += cc[k];
+      if (has) { uint32_t last = br[k].start_op + br[k].n_ops - 1; mx = last > mx ? last : mx; }
+    }
+    unsigned long long ex[3], tot[3];
+    plan_scan3(sa, sb, sc, s_scan, ex, tot);
+    unsigned long long rows = carry_rows + ex[0], es = carry_ent_small + ex[1], ls = carry_lg_ser + ex[2];
+#pragma unroll
+    for (uint32_t k = 0; k < PLAN_ITEMS; k++) {
+      const uint32_t i = base + t * PLAN_ITEMS + k;
+      const bool small = (b[k] >> 32) != 0, large = (uint32_t)cc[k] != 0, serial = (cc[k] >> 32) != 0;
+      if (small || large || serial) {
+        // (author_slot is only meaningful once k_actor_intern has run for the change: a capacity retry leaves it unset in the first attempt)
+        ChangePlan pl{i, (uint32_t)(rows >> 32), (uint32_t)rows, (uint32_t)es, br[k].author_slot <= slot_mask ? slot_rank[br[k].author_slot] : 0u, br[k].n_entries};
+        if (small) plans[(uint32_t)(es >> 32)] = pl;
+        else if (large) plans[n - 1 - (uint32_t)ls] = pl;
+        else plans_serial[(uint32_t)(ls >> 32)] = pl;
+      }
+      rows += a[k]; es += b[k]; ls += cc[k];
     }
     carry_rows += tot[0]; carry_ent_small += tot[1]; carry_lg_ser += tot[2];
   }
+  atomicMax(&s_max, mx);
   __syncthreads();
   if (t == 0) {
     PlanTotals z{};
     z.n_ops = (uint32_t)(carry_rows >> 32); z.n_preds = (uint32_t)carry_rows; z.n_entries = (uint32_t)carry_ent_small;
-    z.n_small = n_small; z.n_large = n_large; z.n_serial = n_serial; z.max_op = s_max; z.fallback = 0;
+    z.n_small = (uint32_t)(carry_ent_small >> 32); z.n_large = (uint32_t)carry_lg_ser; z.n_serial = (uint32_t)(carry_lg_ser >> 32);
+    z.max_op = s_max; z.fallback = 0;
     *totals = z;
   }
 }
 
 void launch_plan(const uint8_t* arena, const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, uint32_t* slot_rank, uint32_t slot_mask,
-                 ChangePlan* plans, PlanTotals* totals, hipStream_t st) {
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, arena, briefs, n, distinct, slot_rank, slot_mask, plans, totals);
+                 ChangePlan* plans, ChangePlan* plans_serial, PlanTotals* totals, hipStream_t st) {
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, arena, briefs, n, distinct, slot_rank, slot_mask, plans, plans_serial, totals);
 }
 
 uint32_t distinct_capacity() { return DISTINCT_CAP; }
@@ -1726,6 +1740,18 @@ void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const 
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans + n_small + n_large, n_serial,
                              x, cols, flags, 0);
+}
+
+// the same three launches from the device-built plans (k_plan): small class at the front of `plans`, large class at its back
+void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, const ChangePlan* plans_serial, uint32_t n_changes,
+                           uint32_t n_small, uint32_t n_large, uint32_t n_serial, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags,
+                           hipStream_t st, hipStream_t aux) {
+  ActorXlate x{amap, slot_rank};
+  hipStream_t s2 = (n_small && aux) ? aux : st;
+  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags);
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags);
+  if (n_serial)
+    AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans_serial, n_serial, x, cols, flags, 0);
 }
 
 }  // namespace am355
