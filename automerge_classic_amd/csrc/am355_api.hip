@@ -1263,15 +1263,19 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   c->p_tab_off = (uint32_t*)(d_tables + o_tab);
   int rcb = setup_buffers(c, n_distinct);
   if (rcb) return rcb;
+  // the decode launch first (every HIP call before it is device idle time); the merge stage's fills follow on stream3 -- they depend
+  // on nothing of this replay -- and stream3 only waits for the counter reset when a second decoder class runs there
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
-  HIPCHK(c, hipEventRecord(c->ev_fork, st));
-  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-  merge_prepare(c->mb, c->stream3);
+  if (tot.n_small && (tot.n_large || tot.n_serial)) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+  }
   HIPCHK(c, hipEventRecord(c->ev[2], st));
   launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n,
                         tot.n_small, tot.n_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
                         &c->d_counts.as<Counts>()->flags, st, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
+  merge_prepare(c->mb, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   // ---- host half of the plan, beside the decode kernels ----

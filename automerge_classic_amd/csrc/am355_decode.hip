@@ -1527,7 +1527,7 @@ void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, co
 // ---------------------------------------------------------------------------------------------------------
 // k_plan: one workgroup. (new.js:1434-1451 actor table, :708-709 op id ranges -- the arithmetic the host's plan_fast does too)
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t PLAN_THREADS = 1024;
+constexpr uint32_t PLAN_THREADS = 512;    // (8 waves: 256 VGPRs per lane -- at 1024 threads the kernel spilled to scratch)
 constexpr uint32_t PLAN_RANK_MAX = 1024;   // distinct actors ranked on the device (LDS: 40 bytes each)
 constexpr uint32_t PLAN_ID_MAX = 32;       // bytes of an actor id the device ranking handles (ids are 16 bytes in practice)
 
@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void plan_scan3(unsigned long long a, unsigned long l
   t[0] = ta; t[1] = tb; t[2] = tc;
 }
 
-constexpr uint32_t PLAN_ITEMS = 4;  // consecutive changes per thread and tile
+constexpr uint32_t PLAN_ITEMS = 8;  // consecutive changes per thread and tile (4096 changes per tile)
 
 // plans: [n] -- the small class fills it from the front, the large class from the back (a plan's place inside its class does not
 // matter: every plan is an independent unit of decode work); plans_serial: [n] the changes left to the lane-serial decoder.
@@ -1572,42 +1572,46 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict
   if (t == 0) { s_fallback = nd > PLAN_RANK_MAX ? 1u : 0u; s_max = 0; }
   __syncthreads();
   // ---- actor ranks: lexicographic order of the id bytes (a proper prefix sorts first) = order of the hex strings (new.js:65) ----
-  if (nd <= PLAN_RANK_MAX && t < nd) {
+  if (nd <= PLAN_RANK_MAX) {
     const unsigned long long* slot_val = (const unsigned long long*)(distinct + 2 + DISTINCT_CAP);
-    unsigned long long v = slot_val[t];
-    uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
-    s_len[t] = len;
-    if (len > PLAN_ID_MAX) s_fallback = 1;
-    else {
-      uint8_t bytes[PLAN_ID_MAX];  // (all loads issued before the first use: one memory round trip, not one per byte)
+    for (uint32_t a = t; a < nd; a += PLAN_THREADS) {
+      unsigned long long v = slot_val[a];
+      uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
+      s_len[a] = len;
+      if (len > PLAN_ID_MAX) s_fallback = 1;
+      else {
+        uint8_t bytes[PLAN_ID_MAX];  // (all loads issued before the first use: one memory round trip, not one per byte)
 #pragma unroll
-      for (uint32_t k = 0; k < PLAN_ID_MAX; k++) bytes[k] = k < len ? arena[off + k] : (uint8_t)0;
+        for (uint32_t k = 0; k < PLAN_ID_MAX; k++) bytes[k] = k < len ? arena[off + k] : (uint8_t)0;
 #pragma unroll
-      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
-        unsigned long long x = 0;
+        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
+          unsigned long long x = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) x = x << 8 | bytes[wd * 8 + k];
-        s_id[t][wd] = x;
+          for (uint32_t k = 0; k < 8; k++) x = x << 8 | bytes[wd * 8 + k];
+          s_id[a][wd] = x;
+        }
       }
     }
   }
   __syncthreads();
   const bool fallback = s_fallback != 0;
-  if (!fallback && t < nd) {
-    uint32_t rank = 0;
-    const uint32_t my_len = s_len[t];
-    unsigned long long mine[PLAN_ID_MAX / 8];
-    for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) mine[wd] = s_id[t][wd];
-    for (uint32_t j = 0; j < nd; j++) {
-      bool less = false, decided = false;
-      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8 && !decided; wd++) {
-        unsigned long long x = s_id[j][wd];
-        if (x != mine[wd]) { less = x < mine[wd]; decided = true; }
+  if (!fallback) {
+    for (uint32_t a = t; a < nd; a += PLAN_THREADS) {
+      uint32_t rank = 0;
+      const uint32_t my_len = s_len[a];
+      unsigned long long mine[PLAN_ID_MAX / 8];
+      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) mine[wd] = s_id[a][wd];
+      for (uint32_t j = 0; j < nd; j++) {
+        bool less = false, decided = false;
+        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8 && !decided; wd++) {
+          unsigned long long x = s_id[j][wd];
+          if (x != mine[wd]) { less = x < mine[wd]; decided = true; }
+        }
+        if (!decided) less = s_len[j] < my_len;  // equal up to the padding: the shorter id first (distinct ids differ somewhere)
+        rank += less ? 1u : 0u;
       }
-      if (!decided) less = s_len[j] < my_len;  // equal up to the padding: the shorter id first (distinct ids differ somewhere)
-      rank += less ? 1u : 0u;
+      slot_rank[distinct[1 + a]] = rank;
     }
-    slot_rank[distinct[1 + t]] = rank;
   }
   __syncthreads();
   if (fallback) {
