@@ -197,7 +197,9 @@ struct am355_ctx {
   ChangeMeta doc_meta{};             // column layout of the staged document inside `raw`
   std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
   DevBuf d_arena, d_offsets, d_metas;
-  HostBuf h_metas, h_offsets;
+  HostBuf h_metas, h_offsets, h_sig;   // h_sig: HostSignals (device -> host result words without a copy)
+  uint32_t sig_seq = 0;
+  hipEvent_t ev_s1 = nullptr;          // the per-change digests (briefs) have arrived on the host
   DevBuf d_big, d_bigvals, d_ks;     // document load: token / record index, column values, keyStr run table
   HostBuf h_biginfo;
   BigColDesc doc_cols{};
@@ -313,7 +315,9 @@ extern "C" am355_ctx* am355_create(int device) {
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
-  if (hipEventCreate(&c->ev_counts) != hipSuccess || hipEventCreate(&c->ev_runs) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev_counts) != hipSuccess || hipEventCreate(&c->ev_runs) != hipSuccess || hipEventCreate(&c->ev_s1) != hipSuccess) { delete c; return nullptr; }
+  if (!c->h_sig.ensure(sizeof(HostSignals))) { delete c; return nullptr; }
+  memset(c->h_sig.p, 0, sizeof(HostSignals));
   return c;
 }
 
@@ -328,7 +332,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
     b->release();
   for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1}) b->release();
   c->d_s1.release();
-  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs})
+  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -337,7 +341,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
-  for (HostBuf* b : {&c->h_metas, &c->h_offsets, &c->h_counts, &c->h_ir, &c->h_rows, &c->h_biginfo, &c->h_encout}) b->release();
+  for (HostBuf* b : {&c->h_metas, &c->h_offsets, &c->h_sig, &c->h_counts, &c->h_ir, &c->h_rows, &c->h_biginfo, &c->h_encout}) b->release();
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1127,6 +1131,7 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
     b.ops = c->cols;
     b.n_ops = N; b.n_preds = P; b.n_actors = NA;
     b.shard_rank = c->shard_rank; b.shard_world = c->shard_world;
+    b.sig = c->h_sig.as<HostSignals>(); b.sig_seq = c->sig_seq;
     b.actor_tab_off = c->p_tab_off;
     b.spans = c->p_spans;
     b.bits_ctr = (uint32_t)bits_ctr; b.bits_actor = (uint32_t)bits_actor;
@@ -1250,6 +1255,11 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
 // decode kernels do, and its tables reach the device before k_resolve needs them.
 static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_distinct, float* ms_host_plan) {
   hipStream_t st = c->stream;
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "  planned: %-26s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   uint32_t n = c->n_changes;
   c->n_ops = tot.n_ops;
   c->n_preds = tot.n_preds;
@@ -1263,6 +1273,7 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   c->p_tab_off = (uint32_t*)(d_tables + o_tab);
   int rcb = setup_buffers(c, n_distinct);
   if (rcb) return rcb;
+  lap("buffers carved");
   // the decode launch first (every HIP call before it is device idle time); the merge stage's fills follow on stream3 -- they depend
   // on nothing of this replay -- and stream3 only waits for the counter reset when a second decoder class runs there
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
@@ -1274,15 +1285,19 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n,
                         tot.n_small, tot.n_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
                         &c->d_counts.as<Counts>()->flags, st, c->stream3);
+  lap("decode launched");
   HIPCHK(c, hipEventRecord(c->ev[3], st));
   merge_prepare(c->mb, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-  // ---- host half of the plan, beside the decode kernels ----
+  lap("fills enqueued");
+  // ---- host half of the plan, beside the decode kernels (the digests were copied right behind k_plan) ----
+  HIPCHK(c, hipEventSynchronize(c->ev_s1));
   auto t0 = std::chrono::steady_clock::now();
   std::vector<uint32_t> slot_rank;
   int rc = plan_fast(c, slot_rank);
   *ms_host_plan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  lap("plan_fast done");
   if (rc == AM355_OK && (c->n_ops != tot.n_ops || c->n_preds != tot.n_preds || c->max_op != tot.max_op || c->actors.size() != n_distinct))
     rc = fail(c, AM355_E_DEVICE, "internal: device and host plans disagree (%llu / %u ops)", (unsigned long long)c->n_ops, tot.n_ops);
   if (rc) { (void)hipStreamSynchronize(st); return rc; }
@@ -1293,6 +1308,7 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
     memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
     HIPCHK(c, hipMemcpyAsync(d_tables, h, o_tab + b_tab, hipMemcpyHostToDevice, st));
   }
+  lap("tables enqueued");
   Counts* hc = c->h_counts.as<Counts>();
   merge_run(c->mb, c->ir, hc, st, c->ev_counts, c->ev_runs);
   HIPCHK(c, hipEventRecord(c->ev[5], st));
@@ -1463,7 +1479,6 @@ static int replay_impl(am355_ctx* c) {
   c->have_host_metas = false;
   // what the host reads after stage 1 -- a few flag words, the distinct actor ids, one brief per change -- sits in one device
   // block: one memset clears the words and the distinct counter, one copy brings everything back
-  // (words 0..7: flag words; words 8..15: PlanTotals of k_plan)
   const size_t s1_distinct = 64, s1_briefs = s1_distinct + ((12 * (size_t)distinct_capacity() + 16 + 63) & ~(size_t)63);
   const size_t s1_bytes = s1_briefs + sizeof(ChangeBrief) * n1;
   if (!c->d_s1.ensure(s1_bytes) || !c->h_s1.ensure(s1_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
@@ -1475,6 +1490,8 @@ static int replay_impl(am355_ctx* c) {
   c->hp_briefs = (ChangeBrief*)(c->h_s1.as<uint8_t>() + s1_briefs);
   uint32_t* d_words = c->d_words.as<uint32_t>();  // stream B's words (W_FLAGS_B, W_FAST_B)
   uint32_t* h_words = c->h_words.as<uint32_t>();
+  HostSignals* sig = c->h_sig.as<HostSignals>();
+  PlanTotals tot{};
 
   // ---- stream A: parse ----
   HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, sa));
@@ -1492,10 +1509,13 @@ static int replay_impl(am355_ctx* c) {
                         c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_wa + W_FLAGS_A, d_wa + W_FAST_A,
                         d_distinct, d_briefs, sa);
     // device half of the in-order plan (actor ranks, per-change bases, decoder classes): the decode kernels start from it
+    // (its totals, and the stage-1 words the host decides on, reach the host through HostSignals: no copy, no blocking wait)
+    c->sig_seq++;
     launch_plan(c->d_arena.as<uint8_t>(), d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plans.as<ChangePlan>(),
-                c->d_plans.as<ChangePlan>() + n1, (PlanTotals*)(d_wa + 8), sa);
-    // the host only needs a 32-byte digest per change and the handful of distinct actor ids
+                c->d_plans.as<ChangePlan>() + n1, d_wa, sig, c->sig_seq, sa);
+    // the host's own half of the plan needs a 32-byte digest per change and the handful of distinct actor ids: they follow
     HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipEventRecord(c->ev_s1, sa));
     HIPCHK(c, hipEventRecord(c->ev[1], sa));
     if (attempt == 0) {
       // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. It starts
@@ -1515,11 +1535,12 @@ static int replay_impl(am355_ctx* c) {
       HIPCHK(c, hipEventRecord(c->ev_b1, sb));
     }
     lap("stage 1 enqueued");
-    HIPCHK(c, hipStreamSynchronize(sa));
-    lap("stage 1 done");
-    if (!(h_wa[W_FAST_A] & FF_CAPACITY) || attempt) break;
+    wait_host_signal(&sig->plan_seq, c->sig_seq, sa);
+    memcpy(&tot, (const void*)&sig->plan, sizeof tot);
+    lap("stage 1 totals read");
+    if (!(tot.fast_a & FF_CAPACITY) || attempt) break;
     // the staging buffer for actor tables was too small: grow to the measured total and redo the interning
-    c->amap_cap = h_wa[W_TOTAL_ENTRIES] + 1024;
+    c->amap_cap = tot.total_entries + 1024;
     if (!c->d_amap_prov.ensure(4 * (size_t)c->amap_cap)) return fail(c, AM355_E_NOMEM, "device allocation failed (actor tables)");
     HIPCHK(c, hipMemsetAsync(d_wa + W_FAST_A, 0, 4, sa));
   }
@@ -1528,45 +1549,44 @@ static int replay_impl(am355_ctx* c) {
   auto t_h0 = std::chrono::steady_clock::now();
   float ms_host = 0;
   int rc = AM355_OK;
-  uint64_t sum_ops = 0, sum_preds = 0, sum_entries = 0;
-  {
-    const ChangeBrief* br = c->hp_briefs;
-    uint32_t dev_flags = h_wa[W_FLAGS_A];
-    c->has_unknown_cols = false;
-    for (uint32_t i = 0; i < n; i++) {
-      dev_flags |= br[i].flags_fits & 0x1fffffffu;
-      if (br[i].flags_fits & 0x20000000u) c->has_unknown_cols = true;
-      sum_ops += br[i].n_ops; sum_preds += br[i].n_preds; sum_entries += br[i].n_entries;
-    }
-    if (dev_flags) { (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
-  }
-  // the device-built plan is used when its packed 32-bit sums cannot have wrapped and the device ranked the actors itself
-  PlanTotals tot;
-  memcpy(&tot, h_wa + 8, sizeof tot);
-  const bool planned = !tot.fallback && sum_ops < 0x7ffffff0ull && sum_preds < 0xfffffff0ull && sum_entries < 0xfffffff0ull && tot.n_ops == sum_ops &&
-                       tot.n_preds == sum_preds && tot.n_entries == sum_entries && !getenv("AM355_HOST_PLAN");
-  bool fast = h_wa[W_FAST_A] == 0;
-  if (c->hp_distinct[0] > distinct_capacity()) fast = false;  // thousands of actors: the general path interns them on the host
+  // (tot.flags_a: validity flags of the stage-1 kernels OR'ed with those of every change; k_plan saw all the digests)
+  if (tot.flags_a) { (void)hipStreamSynchronize(sa); (void)hipStreamSynchronize(sb); return error_for_flags(c, tot.flags_a, "malformed change"); }
+  c->has_unknown_cols = tot.reserved[0] != 0;
+  bool fast = tot.fast_a == 0;
+  if (tot.n_distinct > distinct_capacity()) fast = false;  // thousands of actors: the general path interns them on the host
+  const bool planned = !tot.fallback && !getenv("AM355_HOST_PLAN");
   std::vector<uint32_t> slot_rank;
   int opt_rc = AM355_OK;
   uint32_t opt_flags = 0;
   std::string opt_err;
   if (fast && planned) {
-    ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
     float ms_plan = 0;
-    opt_rc = run_device_planned(c, tot, c->hp_distinct[0], &ms_plan);  // optimistic: confirmed (or discarded) when stream B is joined
+    opt_rc = run_device_planned(c, tot, tot.n_distinct, &ms_plan);  // optimistic: confirmed (or discarded) when stream B is joined
     ms_host += ms_plan;  // (host planning time; it runs beside the decode kernels)
     lap("run_device (device plan) done");
     opt_flags = c->flags;
     opt_err = c->err;
-  } else if (fast) {
-    opt_rc = plan_fast(c, slot_rank);
-    ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
-    lap("plan_fast done");
-    if (opt_rc == AM355_OK) opt_rc = run_device(c, &slot_rank);  // optimistic: confirmed (or discarded) when stream B is joined
-    lap("run_device done");
-    opt_flags = c->flags;
-    opt_err = c->err;
+  } else {
+    HIPCHK(c, hipEventSynchronize(c->ev_s1));  // the digests
+    if (tot.fallback) {  // (k_plan stopped before it looked at the changes: their flags come from the digests)
+      const ChangeBrief* br = c->hp_briefs;
+      uint32_t dev_flags = 0;
+      c->has_unknown_cols = false;
+      for (uint32_t i = 0; i < n; i++) {
+        dev_flags |= br[i].flags_fits & 0x1fffffffu;
+        if (br[i].flags_fits & 0x20000000u) c->has_unknown_cols = true;
+      }
+      if (dev_flags) { (void)hipStreamSynchronize(sa); (void)hipStreamSynchronize(sb); return error_for_flags(c, dev_flags, "malformed change"); }
+    }
+    if (fast) {
+      opt_rc = plan_fast(c, slot_rank);
+      ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_h0).count();
+      lap("plan_fast done");
+      if (opt_rc == AM355_OK) opt_rc = run_device(c, &slot_rank);  // optimistic: confirmed (or discarded) when stream B is joined
+      lap("run_device done");
+      opt_flags = c->flags;
+      opt_err = c->err;
+    }
   }
   // ---- join stream B ----
   HIPCHK(c, hipEventSynchronize(c->ev_b1));
@@ -1609,6 +1629,8 @@ static int replay_impl(am355_ctx* c) {
   s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
   s.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
                ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit) + (uint64_t)c->counts.n_edits * sizeof(am355_ir_value);
+  // (the last kernel has signalled its counters; its remaining workgroups retire within microseconds: poll, do not block)
+  while (hipEventQuery(c->ev[5]) == hipErrorNotReady) {}
   (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
   s.ms_merge = s.ms_order = 0;

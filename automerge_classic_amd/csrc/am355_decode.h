@@ -16,9 +16,9 @@ uint32_t distinct_capacity();
 // In-order fast path, device half of the plan: lexicographic ranks of the distinct actor ids (slot_rank[slot]), and for every
 // change with ops its ChangePlan (row / pred / actor-table bases by prefix sums in input order, author rank) by decoder class
 // (`plans`: small class from the front, large class from the back; `plans_serial`: the rest) -- what the decode kernels need, so that they can start while the host is still validating
-// sequence numbers and building the per-actor span tables. `totals` (device) is read back by the host.
+// sequence numbers and building the per-actor span tables. The totals go to the host through `sig` (HostSignals.plan).
 void launch_plan(const uint8_t* arena, const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, uint32_t* slot_rank, uint32_t slot_mask,
-                 ChangePlan* plans, ChangePlan* plans_serial, PlanTotals* totals, hipStream_t st);
+                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, HostSignals* sig, uint32_t seq, hipStream_t st);
 void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, const ChangePlan* plans_serial, uint32_t n_changes,
                            uint32_t n_small, uint32_t n_large, uint32_t n_serial, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags,
                            hipStream_t st, hipStream_t aux);

@@ -1562,7 +1562,8 @@ constexpr uint32_t PLAN_ITEMS = 8;  // consecutive changes per thread and tile (
 // matter: every plan is an independent unit of decode work); plans_serial: [n] the changes left to the lane-serial decoder.
 __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict__ arena, const ChangeBrief* __restrict__ briefs, uint32_t n,
                                                        const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank, uint32_t slot_mask,
-                                                       ChangePlan* __restrict__ plans, ChangePlan* __restrict__ plans_serial, PlanTotals* __restrict__ totals) {
+                                                       ChangePlan* __restrict__ plans, ChangePlan* __restrict__ plans_serial,
+                                                       const uint32_t* __restrict__ words, HostSignals* sig, uint32_t seq) {
   __shared__ unsigned long long s_id[PLAN_RANK_MAX][PLAN_ID_MAX / 8];  // big-endian words, zero padded
   __shared__ uint32_t s_len[PLAN_RANK_MAX];
   __shared__ unsigned long long s_scan[PLAN_THREADS / WAVE][3];
@@ -1614,10 +1615,22 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict
     }
   }
   __syncthreads();
+  // (words: [0] validity flags of stage 1, [1] fast-path word, [2] actor-table entries -- final, the kernels that raise them ran before)
   if (fallback) {
-    if (t == 0) { PlanTotals z{}; z.fallback = 1; *totals = z; }
+    if (t == 0) {
+      PlanTotals z{};
+      z.fallback = 1; z.flags_a = words[0]; z.fast_a = words[1]; z.total_entries = words[2]; z.n_distinct = nd;
+      signal_host((uint32_t*)&sig->plan, (const uint32_t*)&z, sizeof(PlanTotals) / 4, &sig->plan_seq, seq);
+    }
     return;
   }
+  __shared__ uint32_t s_bad, s_unknown;
+  if (t == 0) { s_bad = 0; s_unknown = 0; }
+  uint32_t bad = 0, unknown = 0;
+  __shared__ unsigned long long s_sum[3];  // full-width sums of ops / preds / entries: the packed 32-bit halves must not have wrapped
+  if (t < 3) s_sum[t] = 0;
+  __syncthreads();
+  unsigned long long w_ops = 0, w_preds = 0, w_ent = 0;
   // ---- prefix sums in input order: PLAN_ITEMS consecutive changes per thread, tile by tile with running carries ----
   unsigned long long carry_rows = 0;       // ops << 32 | preds   (both < 2^32: the host checks the sums before it uses the plan)
   unsigned long long carry_ent_small = 0;  // entries | small plans << 32
@@ -1635,12 +1648,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict
 #pragma unroll
     for (uint32_t k = 0; k < PLAN_ITEMS; k++) {
       const bool valid = !(br[k].flags_fits & 0x1fffffffu);  // (a malformed change: the host rejects the batch as soon as it sees the flags)
+      bad |= br[k].flags_fits & 0x1fffffffu;
+      unknown |= br[k].flags_fits & 0x20000000u;
       const bool has = valid && br[k].n_ops != 0;
       const bool small = has && (br[k].flags_fits & 0x40000000u), large = has && !small && (br[k].flags_fits & 0x80000000u), serial = has && !small && !large;
       a[k] = valid ? (unsigned long long)br[k].n_ops << 32 | br[k].n_preds : 0ull;
       b[k] = (unsigned long long)(valid ? br[k].n_entries : 0u) | (unsigned long long)(small ? 1u : 0u) << 32;
       cc[k] = (unsigned long long)(large ? 1u : 0u) | (unsigned long long)(serial ? 1u : 0u) << 32;
       sa += a[k]; sb += b[k]; sc += cc[k];
+      if (valid) { w_ops += br[k].n_ops; w_preds += br[k].n_preds; w_ent += br[k].n_entries; }
       if (has) { uint32_t last = br[k].start_op + br[k].n_ops - 1; mx = last > mx ? last : mx; }
     }
     unsigned long long ex[3], tot[3];
@@ -1662,19 +1678,25 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict
     carry_rows += tot[0]; carry_ent_small += tot[1]; carry_lg_ser += tot[2];
   }
   atomicMax(&s_max, mx);
+  atomicAdd(&s_sum[0], w_ops); atomicAdd(&s_sum[1], w_preds); atomicAdd(&s_sum[2], w_ent);
+  if (bad) atomicOr(&s_bad, bad);
+  if (unknown) atomicOr(&s_unknown, 1u);
   __syncthreads();
   if (t == 0) {
     PlanTotals z{};
     z.n_ops = (uint32_t)(carry_rows >> 32); z.n_preds = (uint32_t)carry_rows; z.n_entries = (uint32_t)carry_ent_small;
     z.n_small = (uint32_t)(carry_ent_small >> 32); z.n_large = (uint32_t)carry_lg_ser; z.n_serial = (uint32_t)(carry_lg_ser >> 32);
-    z.max_op = s_max; z.fallback = 0;
-    *totals = z;
+    z.max_op = s_max;
+    z.fallback = (s_sum[0] >= 0x7ffffff0ull || s_sum[1] >= 0xfffffff0ull || s_sum[2] >= 0xfffffff0ull) ? 1u : 0u;
+    z.flags_a = words[0] | s_bad; z.fast_a = words[1]; z.total_entries = words[2]; z.n_distinct = nd;
+    z.reserved[0] = s_unknown;  // some change carries columns this engine does not model (the reference's save keeps them)
+    signal_host((uint32_t*)&sig->plan, (const uint32_t*)&z, sizeof(PlanTotals) / 4, &sig->plan_seq, seq);
   }
 }
 
 void launch_plan(const uint8_t* arena, const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, uint32_t* slot_rank, uint32_t slot_mask,
-                 ChangePlan* plans, ChangePlan* plans_serial, PlanTotals* totals, hipStream_t st) {
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, arena, briefs, n, distinct, slot_rank, slot_mask, plans, plans_serial, totals);
+                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, HostSignals* sig, uint32_t seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, arena, briefs, n, distinct, slot_rank, slot_mask, plans, plans_serial, words, sig, seq);
 }
 
 uint32_t distinct_capacity() { return DISTINCT_CAP; }

@@ -51,4 +51,12 @@ typedef const __attribute__((address_space(3))) uint8_t* LdsBytes;
 
 __device__ __forceinline__ uint32_t gtid() { return blockIdx.x * blockDim.x + threadIdx.x; }
 
+// Publishes `n_words` result words and then the sequence number into pinned host memory (HostSignals, am355_internal.h): called by
+// ONE thread, after everything the words summarise has been written by this or an earlier kernel.
+__device__ __forceinline__ void signal_host(uint32_t* host_words, const uint32_t* values, uint32_t n_words, volatile uint32_t* host_seq, uint32_t seq) {
+  for (uint32_t k = 0; k < n_words; k++) host_words[k] = values[k];
+  __threadfence_system();
+  *host_seq = seq;
+}
+
 }  // namespace am355

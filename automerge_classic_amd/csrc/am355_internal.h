@@ -60,7 +60,24 @@ struct PlanTotals {
   uint32_t n_ops, n_preds, n_entries;
   uint32_t n_small, n_large, n_serial;  // plans per decoder class (changes without ops have no plan)
   uint32_t max_op;
-  uint32_t fallback;                    // 1: more distinct actors or longer actor ids than the device ranking handles -- the host plans
+  uint32_t fallback;                    // 1: more distinct actors / longer actor ids than the device ranking handles, or sums beyond 32 bits -- the host plans
+  uint32_t flags_a, fast_a, total_entries, n_distinct;  // the stage-1 words the host decides on (validity flags, fast-path word, actor-table entries, distinct actors)
+  uint32_t reserved[4];
+};
+
+// Device -> host signalling without a copy and without a blocking wait: the LAST kernel of a phase writes its few result words
+// straight into pinned host memory (fine-grained, device-visible), fences at system scope and then publishes the sequence number
+// of the replay; the host spins on that word. A D2H copy + hipStreamSynchronize costs a copy dispatch (~15 us until it runs, ~5 us
+// on the stream) and an interrupt wake-up (~30 us) on a path whose kernels take 5-60 us each.
+struct HostSignals {
+  volatile uint32_t plan_seq;    uint32_t pad0[15];
+  PlanTotals plan;
+  volatile uint32_t counts_seq;  uint32_t pad1[15];
+  uint32_t counts[16];           // Counts after k_compact_rows
+  volatile uint32_t runs_seq;    uint32_t pad2[15];
+  uint32_t runs[16];             // Counts after k_run_heads
+  volatile uint32_t final_seq;   uint32_t pad3[15];
+  uint32_t final_counts[16];     // Counts after k_edit_pack
 };
 
 // Per-actor lookup table entry for opId -> row resolution: the applied changes of one actor, ascending start_op

@@ -72,6 +72,8 @@ struct MergeBufs {
   size_t counts_bytes;              // Counts + group sums
   void* zero_base;                  // succ_cnt .. last_inc are contiguous: one memset per replay
   size_t zero_bytes;
+  HostSignals* sig;                 // pinned host memory the last kernels of each phase write their counters to (may be null: documents)
+  uint32_t sig_seq;                 // sequence number of this replay
   void* fill_base;                  // order | first_child | child_head are contiguous: one 0xff fill per replay
   size_t fill_bytes;
 };
@@ -98,6 +100,9 @@ struct PatchIR {
 };
 
 size_t merge_scratch_pairs(uint32_t n_ops);
+
+// host side of the device -> host signalling (HostSignals): spins until *seq_word == seq
+void wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st);
 
 // Zero-fills the merge stage needs (succ / counter accumulators, child lists, list order): independent of the decode kernels,
 // so the caller issues them on a second stream beside the decode and joins before merge_run.

@@ -18,9 +18,11 @@
 #include "am355_merge.h"
 #include "am355_prims.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace am355 {
 
@@ -302,6 +304,8 @@ __global__ __launch_bounds__(BLOCK) void k_compact_rows(MergeBufs b, PatchIR ir)
   if (g + 1 == b.n_ops) {
     b.counts->n_list_ins = pos + (want_ins ? 1u : 0u);
     b.counts->n_objects = idx - 1 + (is_make ? 1u : 0u);
+    // (everything else in Counts up to here was written by k_resolve / k_emit, which have completed)
+    if (b.sig) signal_host(b.sig->counts, (const uint32_t*)b.counts, 16, &b.sig->counts_seq, b.sig_seq);
   }
 }
 
@@ -597,6 +601,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_heads(MergeBufs b, const uint32_t
     heads[H] = n;
     row_run[b.ins_row[i]] = H - 1;
     b.counts->n_runs = H;
+    if (b.sig) signal_host(b.sig->runs, (const uint32_t*)b.counts, 16, &b.sig->runs_seq, b.sig_seq);  // (pad: k_child_order, completed)
   }
 }
 
@@ -818,7 +823,11 @@ __global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
   uint32_t f = e < n ? ir.e_flags[e] : 2u;
   uint32_t head = (f & 2u) ? 0u : 1u;
   uint32_t k = carry_prefix(b.cs_erec, head, s_red);
-  if (e == 0 && n == 0) { ir.edit[0] = am355_ir_edit{0, 0, 0, 0, 0, 0, 0, 0}; b.counts->n_erecs = 0; }
+  if (e == 0 && n == 0) {
+    ir.edit[0] = am355_ir_edit{0, 0, 0, 0, 0, 0, 0, 0};
+    b.counts->n_erecs = 0;
+    if (b.sig) signal_host(b.sig->final_counts, (const uint32_t*)b.counts, 16, &b.sig->final_seq, b.sig_seq);
+  }
   if (e >= n) return;
   const OpCols& o = b.ops;
   uint32_t r = ir.e_row[e], el = ir.e_elem[e];
@@ -832,6 +841,9 @@ __global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
   if (e + 1 == n) {
     ir.edit[k + head] = am355_ir_edit{0, 0, 0, 0, 0, 0, n, 0};
     b.counts->n_erecs = k + head;
+    // the counters are final (this kernel raises no flags); other workgroups may still be writing their records, which the host
+    // only reads through later operations on this stream
+    if (b.sig) signal_host(b.sig->final_counts, (const uint32_t*)b.counts, 16, &b.sig->final_seq, b.sig_seq);
   }
 }
 
@@ -1019,6 +1031,20 @@ __global__ __launch_bounds__(BLOCK) void k_doc_scatter(MergeBufs b, const uint32
 // ---------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
 
+// Host side of signal_host (am355_device.h): spin on the sequence word in pinned memory. If the word does not arrive within a
+// generous bound (a device fault, a kernel that was never launched) the stream is drained instead: the caller then reads whatever
+// the device left, and the error surfaces through the HIP status of the next call.
+void wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spins = 0; *seq_word != seq; spins++) {
+    if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { (void)hipStreamSynchronize(st); return; }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+}
+
 size_t merge_counts_bytes(uint32_t n_ops) {
   size_t groups = (((((size_t)n_ops + BLOCK - 1) / BLOCK + 1) >> CARRY_GROUP_SHIFT) + 2) * CARRY_GROUP_STRIDE;
   return ((((sizeof(Counts) + 255) & ~(size_t)255) + 6 * 4 * groups) + 255) & ~(size_t)255;
@@ -1101,28 +1127,32 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   hipLaunchKernelGGL(k_resolve, grid_for(N), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_compact_rows, grid_for(N), dim3(BLOCK), 0, st, b, ir);
-  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
-  (void)hipEventRecord(ev_counts, st);
+  if (!b.sig) (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipEventRecord(ev_counts, st);  // (also the boundary between the merge and the order phase in the statistics)
   // ---- lists, first half: launched for the worst case (every row an insert) with the real count read on the device, so the
   //      host does not have to wait for the counters before the device has more work ----
   hipLaunchKernelGGL(k_child_push, grid_for(N), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_head_children, dim3(1), dim3(HEAD_CHILD_THREADS), 0, st, b);
   hipLaunchKernelGGL(k_child_order<false>, grid_for(N), dim3(BLOCK), 0, st, b, is_head);
   hipLaunchKernelGGL(k_run_heads, grid_for(N), dim3(BLOCK), 0, st, b, (const uint32_t*)is_head, head_ex, heads, row_run);
-  (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
-  (void)hipEventRecord(ev_runs, st);
+  if (!b.sig) {
+    (void)hipMemcpyAsync(hc_runs, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+    (void)hipEventRecord(ev_runs, st);
+  }
   AM355_LAUNCH_INDEPENDENT(k_euler_init_runs, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)heads, (const uint32_t*)row_run, b.euler_a);
   hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
 
   lap("first half enqueued");
-  (void)hipEventSynchronize(ev_counts);
+  if (b.sig) { wait_host_signal(&b.sig->counts_seq, b.sig_seq, st); memcpy(hc, (const void*)b.sig->counts, sizeof(Counts)); }
+  else (void)hipEventSynchronize(ev_counts);
   lap("counts read");
   if (hc->flags) { (void)hipStreamSynchronize(st); return; }
   order_map_emissions(b, ir, hc, st);
 
   const uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd, n_obj = hc->n_objects + 1;
   if (ni) {
-    (void)hipEventSynchronize(ev_runs);
+    if (b.sig) { wait_host_signal(&b.sig->runs_seq, b.sig_seq, st); memcpy(hc_runs, (const void*)b.sig->runs, sizeof(Counts)); }
+    else (void)hipEventSynchronize(ev_runs);
     lap("runs read");
     uint32_t H = hc_runs->n_runs;
     ListKeyBits kb{bits_for(N), (int)b.bits_ctr, (int)b.bits_actor};
@@ -1180,9 +1210,14 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   } else {
     (void)hipMemsetAsync(ir.edit, 0, sizeof(am355_ir_edit), st);
   }
-  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   lap("all enqueued");
-  (void)hipStreamSynchronize(st);
+  if (b.sig && ni) {
+    wait_host_signal(&b.sig->final_seq, b.sig_seq, st);
+    memcpy(hc, (const void*)b.sig->final_counts, sizeof(Counts));
+  } else {
+    (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+  }
   lap("done");
 }
 

@@ -34,7 +34,7 @@ struct dim3 {
 };
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorNotReady = 600 };
 typedef struct emu_stream* hipStream_t;
 typedef struct emu_event* hipEvent_t;
 struct emu_event { std::chrono::steady_clock::time_point t; };
@@ -64,6 +64,7 @@ inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event(); return h
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
@@ -170,6 +171,7 @@ inline void emu_require_coop(const char* what) {
 inline void __syncthreads() { emu_require_coop("__syncthreads"); emu::rt().block_bar.wait(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 inline void __threadfence_block() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+inline void __threadfence_system() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 inline unsigned long long __ballot(int pred) {
   emu_require_coop("__ballot");
