@@ -309,7 +309,24 @@ extern "C" am355_ctx* am355_create(int device) {
   int prio_low = 0, prio_high = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
   if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high) != hipSuccess) { delete c; return nullptr; }
-  if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_low) != hipSuccess) { delete c; return nullptr; }
+  {
+    // The hash stream (one lane per change: ~65 waves of dependent SHA-256 rounds for 4 k changes) gets its own few compute
+    // units when AM355_HASH_CUS=n asks for it (hipExtStreamCreateWithCUMask: its waves then never share a SIMD with the
+    // latency-bound kernels of the critical path); by default it is an ordinary low-priority stream.
+    const char* env = getenv("AM355_HASH_CUS");
+    int want = env ? atoi(env) : 0;
+    bool made = false;
+    if (want > 0) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > want) {
+        int n_cu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+        for (int k = 0; k < want; k++) { int cu = n_cu - 1 - k; mask[(size_t)cu / 32] |= 1u << (cu % 32); }
+        made = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+      }
+    }
+    if (!made && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_low) != hipSuccess) { delete c; return nullptr; }
+  }
   if (hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_high) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_fork) != hipSuccess || hipEventCreate(&c->ev_join) != hipSuccess) { delete c; return nullptr; }
   for (auto& e : c->ev)
@@ -1492,6 +1509,7 @@ static int replay_impl(am355_ctx* c) {
   uint32_t* h_words = c->h_words.as<uint32_t>();
   HostSignals* sig = c->h_sig.as<HostSignals>();
   PlanTotals tot{};
+  static const bool hash_after_parse = []() { const char* e = getenv("AM355_HASH_START"); return !(e && !strcmp(e, "intern")); }();
 
   // ---- stream A: parse ----
   HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, sa));
@@ -1521,7 +1539,7 @@ static int replay_impl(am355_ctx* c) {
       // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. It starts
       //      after the parse / actor kernels of stream A: those grids are as small as the hash grid (one wave per 64
       //      changes) and the ALU-dense SHA waves would otherwise share their SIMDs and slow them down ----
-      HIPCHK(c, hipStreamWaitEvent(sb, c->ev[1], 0));
+      HIPCHK(c, hipStreamWaitEvent(sb, hash_after_parse ? c->ev_parse : c->ev[1], 0));
       HIPCHK(c, hipEventRecord(c->ev_b0, sb));
       HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
       HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
