@@ -50,10 +50,10 @@ PARITY = ("bit-exact getPatch vs the CPU oracle at this size and vs reference go
           "the answer reproduced is the block-size-patched reference's = the documented RGA rule (DESIGN.md §6)")
 
 
-def make_log(name, scale, seed):
+def make_log(name, scale, seed, deflate=False):
     from automerge_classic_amd import loggen
     kind, kw = WORKLOADS[name]
-    kw = dict(kw)
+    kw = dict(kw, deflate=deflate)
     if kind == "typing":
         kw["n_ops"] = max(1, int(kw["n_ops"] * scale))
         return loggen.generate(loggen.KIND_TEXT_TYPING, seed=seed, name=name, **kw)
@@ -108,7 +108,7 @@ PHASES = ("ms_parse", "ms_host_schedule", "ms_decode", "ms_merge", "ms_order", "
 class Workload:
     """One staged input (a change log or a saved document) and the two timed regions over it."""
 
-    def __init__(self, eng, name, scale, seed, shuffled=False):
+    def __init__(self, eng, name, scale, seed, shuffled=False, deflate=False):
         from automerge_classic_amd import loggen
         self.eng, self.name, self.scale = eng, name, scale
         self.is_doc = WORKLOADS[name][0] == "doc"
@@ -116,7 +116,9 @@ class Workload:
             self.doc_bytes, self.doc_rows = loggen.document_config(scale)
             self.log = None
         else:
-            self.log = make_log(name, scale, seed)
+            self.log = make_log(name, scale, seed, deflate)
+            if deflate:
+                self.log.name = name + "+deflate"
             if shuffled:
                 self.log = self.log.reordered(np.random.default_rng(seed & 0xFFFF).permutation(self.log.n_changes))
                 self.log.name = name + "+shuffled"
@@ -203,8 +205,8 @@ def run_workload(w, steps, warmup, sync, want_rows=True):
     return {"t_replay_s": t_replay, "t_device_s": t_device, "stats": st, "phases": phases, "n_preds": n_preds}
 
 
-def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False):
-    w = Workload(eng, name, scale, seed, shuffled=shuffled)
+def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False, deflate=False):
+    w = Workload(eng, name, scale, seed, shuffled=shuffled, deflate=deflate)
     r = run_workload(w, steps, warmup, sync, want_rows=False)
     st = r["stats"]
     A = algorithmic_bytes(st)
@@ -325,7 +327,7 @@ def main():
     whole = st.n_ops * A["A"] / (t_device_ms * 1e-3) / 1e9  # (N_ops x A / T_device), GB/s
     roofline = {"bound": "hbm", "achieved": whole, "peak": 8000.0, "unit": "GB/s", "frac": whole / 8000.0, "traffic": None,
                 "kernel": "whole path (SURVEY.md §8d): N_ops x (E + R + P) / T_device", "algorithmic_bytes_per_launch": st.n_ops * A["A"],
-                "launch_ms": t_device_ms, "phases": phase_table(phases, st, n_preds)}
+                "launch_ms": t_device_ms, "n_preds": n_preds, "phases": phase_table(phases, st, n_preds)}
     table = os.path.join(ROOT, "profiles", "r02_kernel_table.json")
     if os.path.exists(table) and args.workload == "c4_text_single" and args.scale == 1.0:
         # rocprofv3 kernel-trace + PMC passes of this same command (committed summary; counters cannot be read in-process):
@@ -349,7 +351,7 @@ def main():
                    "timed_region": "T_replay (SURVEY.md §8d): binary changes in host memory -> host inflate/staging -> H2D -> replay -> patch IR + envelope in host memory",
                    "parity": PARITY, "fast_path": int(st.fast_path)},
         "t_device_ops_per_s": st.n_ops / (t_device_ms * 1e-3), "t_device_ms": t_device_ms,
-        "phases_ms": phases, "algorithmic_bytes_per_op": A, "save": save_info, "roofline": roofline,
+        "phases_ms": phases, "algorithmic_bytes_per_op": A, "n_list_elems": int(st.n_list_elems), "save": save_info, "roofline": roofline,
     }
     if sharded is not None:
         out["sharded"] = sharded
@@ -361,6 +363,9 @@ def main():
             if name != args.workload:
                 subs.append(subline(eng, name, 1.0, BASE_SEED[name], k, wu, barrier))
         subs.append(subline(eng, "c4_text_single", 1.0, BASE_SEED["c4_text_single"], k, wu, barrier, shuffled=True))
+        # the same log with every change DEFLATEd as the reference's encodeChange does for changes >= 256 bytes (columnar.js:798-811):
+        # T_replay then includes the host inflate (zlib, on the engine's host threads)
+        subs.append(subline(eng, "c4_text_single", 1.0, BASE_SEED["c4_text_single"], k, wu, barrier, deflate=True))
         if args.workload != "c5_doc_mixed":
             subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 3, 1, barrier))
         out["workloads"] = subs
