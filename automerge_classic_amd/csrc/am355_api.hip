@@ -301,7 +301,7 @@ extern "C" am355_ctx* am355_create(int device) {
   {
     unsigned hw = std::thread::hardware_concurrency();
     const char* env = getenv("AM355_HOST_THREADS");
-    unsigned want = env && atoi(env) > 0 ? (unsigned)atoi(env) : std::min(hw ? hw : 4u, 16u);
+    unsigned want = env && atoi(env) > 0 ? (unsigned)atoi(env) : std::min(hw ? hw : 4u, 32u);
     c->pool.reset(new HostPool(want > 1 ? want - 1 : 0));  // (the calling thread works too)
   }
   // the decode/merge stream outranks the hash stream: their small grids would otherwise share SIMDs and the
@@ -410,7 +410,12 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   // (AM355_SLICE_BYTES: bytes per slice, 2 MiB by default -- every H2D copy has a fixed cost of some microseconds --; the tests lower it to exercise the sliced path on small inputs)
   const char* slice_env = getenv("AM355_SLICE_BYTES");
   const size_t slice_bytes = slice_env && atol(slice_env) > 0 ? (size_t)atol(slice_env) : (size_t)1 << 21;
-  if (in_bytes >= 2 * slice_bytes && n >= 16) n_slices = (unsigned)std::min<size_t>({(size_t)(c->pool->size() + 1) * 2, in_bytes / slice_bytes, (size_t)n / 8});
+  // compressed changes (chunk type 2; the first and the middle change are taken as representative) are inflated slice by slice on
+  // the host threads: many small slices keep all of them busy (zlib runs at a few hundred MB/s per thread)
+  const bool deflated = n && ((offsets[1] - offsets[0] > 9 && arena[offsets[0] + 8] == 2) || (offsets[n / 2 + 1] - offsets[n / 2] > 9 && arena[offsets[n / 2] + 8] == 2));
+  const size_t per_slice = deflated && !slice_env ? (size_t)64 << 10 : slice_bytes;
+  if (in_bytes >= 2 * per_slice && n >= 16)
+    n_slices = (unsigned)std::min<size_t>({(size_t)(c->pool->size() + 1) * (deflated ? 8 : 2), in_bytes / per_slice, (size_t)n / 8});
   if (n_slices < 1) n_slices = 1;
   struct Slice { uint32_t c0 = 0, c1 = 0; size_t out_bytes = 0, base = 0; bool any_deflated = false; int err = 0; uint32_t err_change = 0; std::vector<uint8_t> tmp; std::vector<uint32_t> tmp_len; };
   std::vector<Slice> slices(n_slices);
