@@ -146,8 +146,11 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
       // typing: the reference element of an insert is nearly always the op right before it (same change, previous row)
       if (g > 0 && o.id_ctr[g - 1] == kc && o.id_actor[g - 1] == ka) ref = g - 1;
       else ref = row_of(b, ka, kc);
-      if (ref == NONE32 || !o.insert[ref] || !same_obj(b, ref, g) || o.key_len[ref] != NONE32) { err |= F_BAD_ELEM; ref = NONE32; }
-      else if (pack_id(o.id_ctr[ref], o.id_actor[ref]) >= my_id) err |= F_UNSUPPORTED;
+      // Every field read of the reference row is a random 64-byte line (the rows of a deleted element are anywhere): only
+      // `insert` and the object are looked at. Its id IS (kc, ka) -- that is how the row was found -- and an insert row with a
+      // string key is flagged by its own lane (F_UNSUPPORTED above), so neither needs loading here.
+      if (ref == NONE32 || !o.insert[ref] || !same_obj(b, ref, g)) { err |= F_BAD_ELEM; ref = NONE32; }
+      else if (pack_id(kc, ka) >= my_id) err |= F_UNSUPPORTED;
     } else if (!ins) {
       err |= F_UNSUPPORTED;  // non-insert on _head
     }
@@ -169,10 +172,14 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
     for (uint32_t k = 0; k < j; k++)
       if (o.pred_actor[pf + k] == pa && o.pred_ctr[pf + k] == pc) err |= F_BAD_PRED;  // second copy never matches
     // deleting / overwriting a list element names the element's own insert op as pred: already resolved as `ref`
-    uint32_t pr = (ref != NONE32 && pa == ka && pc == kc) ? ref : row_of(b, pa, pc);
-    if (pr == NONE32 || o.action[pr] == 3 || !same_obj(b, pr, g)) { err |= F_BAD_PRED; continue; }
+    const bool pred_is_ref = ref != NONE32 && pa == ka && pc == kc;
+    uint32_t pr = pred_is_ref ? ref : row_of(b, pa, pc);
+    // (pred == the element's own insert row: its object was compared above, and an insert row whose action is `del` is flagged by its
+    // own lane -- BAD_PRED or UNSUPPORTED -- so its action needs no load)
+    if (pr == NONE32 || (!pred_is_ref && (o.action[pr] == 3 || !same_obj(b, pr, g)))) { err |= F_BAD_PRED; continue; }
     bool same_slot;
     if (has_str) same_slot = same_key(b, pr, g);
+    else if (pred_is_ref) same_slot = !ins;
     else if (o.key_len[pr] != NONE32 || ref == NONE32 || ins) same_slot = false;
     else if (pr == ref) same_slot = true;
     else if (!o.insert[pr] && o.key_actor[pr] == ka && o.key_ctr[pr] == kc) same_slot = true;  // an earlier update of the same element
