@@ -21,9 +21,16 @@ const HYDRATE_FROM_DOC = process.env.MI355X_HYDRATE === 'doc'
 const PATCH_VIA_JSON = process.env.MI355X_PATCH_VIA_JSON === '1'   // A/B: JSON text rendered by the engine + JSON.parse
 const { materialize } = require('./materialize.js')
 let addon = null, ctx = null
+// A few engine contexts, used least-recently-used first: a GPU-built state remembers which replay (generation) made it, and as
+// long as that replay still sits in one of the contexts, Backend.save of the state is served from it instead of replaying the
+// retained changes again (MI355X_CONTEXTS, default 4; every context owns its device buffers).
+const MAX_CONTEXTS = Math.max(1, parseInt(process.env.MI355X_CONTEXTS || '4'))
+const contexts = []
+let tick = 0
 if (!JS_ONLY) {
   addon = require(path.join(__dirname, 'am355_napi.node'))
   ctx = addon.create(parseInt(process.env.MI355X_DEVICE || '0'))   // throws without an MI355X
+  contexts.push({ ctx, generation: 0, used: 0 })
 }
 
 // The unmodified reference backend (the package a user already has installed)
@@ -47,7 +54,7 @@ class GpuState {
     this.patch = patch
     this.heads = heads
     this.js = null           // hydrated reference backend handle
-    this.generation = 0      // engine replay this state was built by (the one context is reused by every call)
+    this.generation = 0      // engine replay this state was built by (it may still sit in one of the contexts)
     this.applied = null      // input indexes of the applied changes, application order (loadChanges states)
     this.hashes = null       // 32 bytes per input change
     this.pending = 0
@@ -55,7 +62,28 @@ class GpuState {
   }
 }
 let generation = 0           // bumped by every GPU replay
-const counters = { gpuLoadChanges: 0, gpuLoad: 0, gpuSave: 0, fallbackToJs: 0, hydrations: 0 }   // (diagnostics: which path served the calls)
+
+// the context the next replay runs in (the least recently used one), stamped with a new generation
+function acquireContext() {
+  let e
+  if (contexts.length < MAX_CONTEXTS && contexts.every(x => x.generation !== 0)) {
+    e = { ctx: addon.create(parseInt(process.env.MI355X_DEVICE || '0')), generation: 0, used: 0 }
+    contexts.push(e)
+  } else {
+    e = contexts.reduce((a, b) => (b.used < a.used ? b : a))
+  }
+  e.generation = ++generation
+  e.used = ++tick
+  ctx = e.ctx
+  return e
+}
+// the context that still holds the replay of `gen`, if any
+function contextOf(gen) {
+  const e = contexts.find(x => x.generation === gen && gen !== 0)
+  if (e) { e.used = ++tick; ctx = e.ctx }
+  return e || null
+}
+const counters = { gpuLoadChanges: 0, gpuLoad: 0, gpuSave: 0, saveReplays: 0, fallbackToJs: 0, hydrations: 0 }   // (diagnostics: which path served the calls)
 
 function isFrozenCheck(backend) {
   // reference util.js:1-10
@@ -89,7 +117,7 @@ function hydrate(backend) {
       // replaying every change (opt-in: MI355X_HYDRATE=doc; the default replays the retained changes, exact by construction)
       let bytes = null
       try {
-        if (g.generation !== generation) { gpuReplay(g.changes); g.generation = generation }
+        if (!contextOf(g.generation)) { gpuReplay(g.changes); g.generation = generation }
         bytes = addon.save(ctx, 0)
       } catch (e) {
         if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
@@ -119,7 +147,7 @@ function gpuPatch() {
 }
 
 function gpuReplay(changes) {
-  generation++
+  acquireContext()
   addon.loadChanges(ctx, changes)
   addon.replay(ctx)
   return gpuPatch()
@@ -166,7 +194,7 @@ function load(data) {
   // whole-document patch on the GPU
   if (!JS_ONLY && data instanceof Uint8Array) {
     try {
-      generation++
+      acquireContext()
       addon.loadDocument(ctx, data)
       addon.replay(ctx)
       const patch = gpuPatch()
@@ -189,7 +217,7 @@ function save(backend) {
   if (!JS_ONLY && g instanceof GpuState) {
     if (g.doc) return g.doc   // unchanged loaded document: the bytes it was loaded from (new.js:2034)
     try {
-      if (g.generation !== generation) { gpuReplay(g.changes); g.generation = generation }
+      if (!contextOf(g.generation)) { counters.saveReplays++; gpuReplay(g.changes); g.generation = generation }
       const bytes = addon.save(ctx, 0)
       counters.gpuSave++
       return bytes

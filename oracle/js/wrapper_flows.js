@@ -79,3 +79,18 @@ const served = {}
 for (const k of Object.keys(Backend._counters)) served[k] = Backend._counters[k] - before[k]
 assert.ok(served.gpuLoad >= 7 && served.gpuLoadChanges >= 1, 'Backend.load must be served by the engine: ' + JSON.stringify(served))
 console.log('wrapper flows ok; served by ' + JSON.stringify(served))
+
+// several GPU-built states alive at once: Backend.save of an older one is served from the context that still holds its replay
+{
+  const c0 = Object.assign({}, Backend._counters)
+  const empty = () => ({ state: { changes: [], queue: [] }, heads: [] })
+  const s1 = Backend.loadChanges(empty(), Automerge.getAllChanges(ra))
+  const s2 = Backend.loadChanges(empty(), Automerge.getAllChanges(rb))
+  const b1 = Backend.save(s1), b2 = Backend.save(s2), b1again = Backend.save(s1)
+  assert.deepStrictEqual(Buffer.from(b1), Buffer.from(RefBackend.save(RefBackend.loadChanges(RefBackend.init(), Automerge.getAllChanges(ra)))))
+  assert.deepStrictEqual(Buffer.from(b2), Buffer.from(RefBackend.save(RefBackend.loadChanges(RefBackend.init(), Automerge.getAllChanges(rb)))))
+  assert.deepStrictEqual(Buffer.from(b1again), Buffer.from(b1))
+  assert.strictEqual(Backend._counters.gpuSave - c0.gpuSave, 3)
+  assert.strictEqual(Backend._counters.saveReplays - c0.saveReplays, 0, 'no silent re-replay while the context pool still holds the state')
+  console.log('context pool ok')
+}
