@@ -1677,10 +1677,24 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict
     }
     carry_rows += tot[0]; carry_ent_small += tot[1]; carry_lg_ser += tot[2];
   }
-  atomicMax(&s_max, mx);
-  atomicAdd(&s_sum[0], w_ops); atomicAdd(&s_sum[1], w_preds); atomicAdd(&s_sum[2], w_ent);
-  if (bad) atomicOr(&s_bad, bad);
-  if (unknown) atomicOr(&s_unknown, 1u);
+  // (workgroup-wide sums / maximum through the scan helper and wave shuffles: 512 lanes adding into one LDS word would run one
+  // after another)
+  {
+    unsigned long long ex3[3], tot3[3];
+    plan_scan3(w_ops, w_preds, w_ent, s_scan, ex3, tot3);
+    if (t == 0) { s_sum[0] = tot3[0]; s_sum[1] = tot3[1]; s_sum[2] = tot3[2]; }
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+      uint32_t o = __shfl_xor(mx, d), ob = __shfl_xor(bad, d), ou = __shfl_xor(unknown, d);
+      mx = o > mx ? o : mx;
+      bad |= ob;
+      unknown |= ou;
+    }
+    if ((t & (WAVE - 1)) == 0) {
+      atomicMax(&s_max, mx);
+      if (bad) atomicOr(&s_bad, bad);
+      if (unknown) atomicOr(&s_unknown, 1u);
+    }
+  }
   __syncthreads();
   if (t == 0) {
     PlanTotals z{};
