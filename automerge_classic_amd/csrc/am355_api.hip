@@ -19,6 +19,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -484,20 +485,49 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   uint8_t* raw = c->raw.data();
   uint64_t* roff = c->raw_off.data();
   std::vector<hipError_t> h2d(n_slices, hipSuccess);
-  auto phase_b = [&](unsigned k) {
-    Slice& sl = slices[k];
-    (void)hipSetDevice(c->device);
-    if (sl.any_deflated) {
-      if (sl.out_bytes) memcpy(raw + sl.base, sl.tmp.data(), sl.out_bytes);
-      size_t o = sl.base;
-      for (uint32_t i = sl.c0; i < sl.c1; i++) { roff[i] = o; o += sl.tmp_len[i - sl.c0]; }
-    } else {
-      if (sl.out_bytes) memcpy(raw + sl.base, arena + offsets[sl.c0], sl.out_bytes);
-      for (uint32_t i = sl.c0; i < sl.c1; i++) roff[i] = sl.base + (offsets[i] - offsets[sl.c0]);
-    }
-    if (sl.out_bytes) h2d[k] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + sl.base, raw + sl.base, sl.out_bytes, hipMemcpyHostToDevice, c->stream);
-  };
-  c->pool->run(n_slices, phase_b);
+  bool any_deflated = false;
+  for (const Slice& sl : slices) any_deflated = any_deflated || sl.any_deflated;
+  const char* gather_env = getenv("AM355_GATHER_UNIT");  // (tests: bytes per copy unit, lowered to run the grouped gather on small inputs)
+  if (!any_deflated && (total >= ((size_t)4 << 20) || (gather_env && total > 0))) {
+    // Plain changes: the arena is one contiguous copy of the input. Every H2D command costs tens of microseconds whatever its
+    // size, and one thread copies only ~15 GB/s, so: the host threads copy 256 KiB units, and whoever finishes the last unit of a
+    // ~4 MiB group enqueues that group's H2D copy -- few DMA commands, the first one a few tens of microseconds after the start.
+    const size_t unit = gather_env && atol(gather_env) > 0 ? (size_t)atol(gather_env) : (size_t)256 << 10;
+    const size_t n_units = (total + unit - 1) / unit;
+    const size_t units_per_group = 16;
+    const size_t n_groups = (n_units + units_per_group - 1) / units_per_group;
+    std::vector<std::atomic<uint32_t>> left(n_groups);
+    for (size_t g = 0; g < n_groups; g++) left[g].store((uint32_t)std::min(units_per_group, n_units - g * units_per_group));
+    h2d.assign(n_groups, hipSuccess);
+    const uint8_t* src = arena + offsets[0];
+    const uint64_t off0 = offsets[0];
+    c->pool->run((unsigned)n_units, [&](unsigned u) {
+      size_t b = (size_t)u * unit, e = std::min(total, b + unit);
+      memcpy(raw + b, src + b, e - b);
+      size_t g = u / units_per_group;
+      if (left[g].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        (void)hipSetDevice(c->device);
+        size_t gb = g * units_per_group * unit, ge = std::min(total, gb + units_per_group * unit);
+        h2d[g] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
+      }
+    });
+    for (uint32_t i = 0; i < n; i++) roff[i] = offsets[i] - off0;
+  } else {
+    auto phase_b = [&](unsigned k) {
+      Slice& sl = slices[k];
+      (void)hipSetDevice(c->device);
+      if (sl.any_deflated) {
+        if (sl.out_bytes) memcpy(raw + sl.base, sl.tmp.data(), sl.out_bytes);
+        size_t o = sl.base;
+        for (uint32_t i = sl.c0; i < sl.c1; i++) { roff[i] = o; o += sl.tmp_len[i - sl.c0]; }
+      } else {
+        if (sl.out_bytes) memcpy(raw + sl.base, arena + offsets[sl.c0], sl.out_bytes);
+        for (uint32_t i = sl.c0; i < sl.c1; i++) roff[i] = sl.base + (offsets[i] - offsets[sl.c0]);
+      }
+      if (sl.out_bytes) h2d[k] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + sl.base, raw + sl.base, sl.out_bytes, hipMemcpyHostToDevice, c->stream);
+    };
+    c->pool->run(n_slices, phase_b);
+  }
   lap("gathered, H2D enqueued");
   for (hipError_t e : h2d)
     if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (arena): %s", hipGetErrorString(e));

@@ -187,6 +187,15 @@ def test_sliced_staging_gathers_the_same_arena(eng, monkeypatch, deflate):
     got_raw = eng.raw()
     assert np.array_equal(got_raw[0], want_raw[0]) and np.array_equal(got_raw[1], want_raw[1])
     assert eng.patch_json() == want_patch == oracle_lib.OracleDoc(log).patch_json()
+    if not deflate:
+        # plain changes of a large batch are gathered in small units, the H2D copies enqueued per group of units
+        monkeypatch.delenv("AM355_SLICE_BYTES")
+        monkeypatch.setenv("AM355_GATHER_UNIT", "97")
+        eng.load_changes(log)
+        eng.replay()
+        got_raw = eng.raw()
+        assert np.array_equal(got_raw[0], want_raw[0]) and np.array_equal(got_raw[1], want_raw[1])
+        assert eng.patch_json() == want_patch
 
 
 def test_device_primitives(eng):
