@@ -1223,7 +1223,7 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
                    6 * carve_size(Nc + 3, 4) + 6 * carve_size(cw, 4) + carve_size(2048, 4);
     size_t sort_bytes = 2 * carve_size(Nc, 8) + 2 * carve_size(Nc, 4) + sort_workspace_bytes((uint32_t)Nc) + 256;
     size_t ir_bytes = carve_size(Nc + 1, sizeof(am355_ir_object)) + carve_size(Nc, sizeof(am355_ir_map)) + carve_size(Nc + 1, sizeof(am355_ir_edit)) +
-                      carve_size(Nc, sizeof(am355_ir_value)) + 4 * carve_size(Nc, 4);
+                      4 * carve_size(Nc, 4);
     if (!c->d_merge.ensure(bytes) || !c->d_sort.ensure(sort_bytes) || !c->d_ir.ensure(ir_bytes) || !c->d_counts.ensure(merge_counts_bytes(N)))
       return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
     uint8_t* p = c->d_merge.as<uint8_t>();
@@ -1268,7 +1268,6 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
     uint8_t* r = c->d_ir.as<uint8_t>();
     PatchIR& ir = c->ir;
     ir.obj = carve<am355_ir_object>(r, Nc + 1); ir.map = carve<am355_ir_map>(r, Nc); ir.edit = carve<am355_ir_edit>(r, Nc + 1);
-    ir.val = carve<am355_ir_value>(r, Nc);
     ir.e_row = carve<uint32_t>(r, Nc); ir.e_elem = carve<uint32_t>(r, Nc); ir.e_index = carve<uint32_t>(r, Nc); ir.e_flags = carve<uint32_t>(r, Nc);
   }
   return AM355_OK;
@@ -1542,7 +1541,7 @@ static int replay_document(am355_ctx* c) {
   s.n_heads = (uint32_t)(c->heads.size() / 32); s.n_ops = c->n_ops; s.max_op = c->max_op; s.raw_bytes = c->raw.size();
   s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
   s.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
-               ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit) + (uint64_t)c->counts.n_edits * sizeof(am355_ir_value);
+               ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit);
   (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
   (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
   (void)hipEventElapsedTime(&s.ms_merge, c->ev[3], c->ev[4]);
@@ -1730,7 +1729,7 @@ static int replay_impl(am355_ctx* c) {
   s.n_heads = (uint32_t)(c->heads.size() / 32); s.n_ops = c->n_ops; s.max_op = c->max_op; s.raw_bytes = c->raw.size();
   s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
   s.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
-               ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit) + (uint64_t)c->counts.n_edits * sizeof(am355_ir_value);
+               ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit);
   // (the last kernel has signalled its counters; its remaining workgroups retire within microseconds: poll, do not block)
   while (hipEventQuery(c->ev[5]) == hipErrorNotReady) {}
   (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
@@ -1787,8 +1786,7 @@ static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
   if (!c->ir_fetched) {
     hipStream_t st = c->stream;
     uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NR = c->counts.n_erecs, NV = c->counts.n_edits;
-    size_t bytes = carve_size(NO, sizeof(am355_ir_object)) + carve_size(NM, sizeof(am355_ir_map)) + carve_size((size_t)NR + 1, sizeof(am355_ir_edit)) +
-                   carve_size(NV, sizeof(am355_ir_value)) + 4096;
+    size_t bytes = carve_size(NO, sizeof(am355_ir_object)) + carve_size(NM, sizeof(am355_ir_map)) + carve_size((size_t)NR + 1, sizeof(am355_ir_edit)) + 4096;
     if (!c->h_ir.ensure(bytes)) return fail(c, AM355_E_NOMEM, "host allocation failed");
     uint8_t* p = c->h_ir.as<uint8_t>();
     am355_patch_ir& h = c->hir;
@@ -1802,7 +1800,6 @@ static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
     h.objects = (const am355_ir_object*)pull(c->ir.obj, NO, sizeof(am355_ir_object));
     h.map = (const am355_ir_map*)pull(c->ir.map, NM, sizeof(am355_ir_map));
     h.edits = (const am355_ir_edit*)pull(c->ir.edit, (size_t)NR + 1, sizeof(am355_ir_edit));
-    h.values = (const am355_ir_value*)pull(c->ir.val, NV, sizeof(am355_ir_value));
     HIPCHK(c, hipStreamSynchronize(st));
     h.max_op = c->max_op;
     h.n_actors = (uint32_t)c->actors.size();
@@ -2315,7 +2312,7 @@ static int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, si
 namespace {
 struct FragmentHeader {
   uint32_t magic, world, rank, n_objects, n_map, n_erecs, n_values, reserved;
-  uint64_t off_objects, off_map, off_edits, off_values, total;
+  uint64_t off_objects, off_map, off_edits, total;
 };
 constexpr uint32_t FRAGMENT_MAGIC = 0x46333535;  // "553F"
 inline size_t frag_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -2326,8 +2323,7 @@ FragmentHeader fragment_layout(uint32_t world, uint32_t rank, const Counts& k) {
   h.off_objects = frag_align(sizeof(FragmentHeader));
   h.off_map = h.off_objects + frag_align((size_t)h.n_objects * sizeof(am355_ir_object));
   h.off_edits = h.off_map + frag_align((size_t)h.n_map * sizeof(am355_ir_map));
-  h.off_values = h.off_edits + frag_align(((size_t)h.n_erecs + 1) * sizeof(am355_ir_edit));
-  h.total = h.off_values + frag_align((size_t)h.n_values * sizeof(am355_ir_value));
+  h.total = h.off_edits + frag_align(((size_t)h.n_erecs + 1) * sizeof(am355_ir_edit));
   return h;
 }
 }  // namespace
@@ -2363,7 +2359,6 @@ extern "C" int am355_export_fragment(am355_ctx* c, void* dst, size_t cap, int ds
   if (h.n_objects) HIPCHK(c, hipMemcpyAsync(d + h.off_objects, c->ir.obj, (size_t)h.n_objects * sizeof(am355_ir_object), from_dev, st));
   if (h.n_map) HIPCHK(c, hipMemcpyAsync(d + h.off_map, c->ir.map, (size_t)h.n_map * sizeof(am355_ir_map), from_dev, st));
   HIPCHK(c, hipMemcpyAsync(d + h.off_edits, c->ir.edit, ((size_t)h.n_erecs + 1) * sizeof(am355_ir_edit), from_dev, st));
-  if (h.n_values) HIPCHK(c, hipMemcpyAsync(d + h.off_values, c->ir.val, (size_t)h.n_values * sizeof(am355_ir_value), from_dev, st));
   HIPCHK(c, hipStreamSynchronize(st));
   *len = (size_t)h.total;
   return AM355_OK;
@@ -2392,14 +2387,13 @@ static int import_fragments_impl(am355_ctx* c, const uint8_t* frags, const uint6
   if (n_map >= 0xfffffff0ull || n_erecs >= 0xfffffff0ull || n_values >= 0xfffffff0ull) return fail(c, AM355_E_UNSUPPORTED, "stitched patch too large");
   const uint32_t NO = hs[0].n_objects;
   size_t o_obj = 0, o_map = o_obj + frag_align((size_t)NO * sizeof(am355_ir_object)), o_edit = o_map + frag_align(n_map * sizeof(am355_ir_map)),
-         o_val = o_edit + frag_align(n_erecs * sizeof(am355_ir_edit)), total = o_val + frag_align(n_values * sizeof(am355_ir_value));
+         total = o_edit + frag_align(n_erecs * sizeof(am355_ir_edit));
   c->stitched.assign(total + 64, 0);
   uint8_t* base = c->stitched.data();
   base += (64 - ((uintptr_t)base & 63)) & 63;
   am355_ir_object* obj = (am355_ir_object*)(base + o_obj);
   am355_ir_map* map = (am355_ir_map*)(base + o_map);
   am355_ir_edit* edit = (am355_ir_edit*)(base + o_edit);
-  am355_ir_value* val = (am355_ir_value*)(base + o_val);
   std::vector<uint32_t> map_base(world), edit_base(world), val_base(world);
   uint32_t mb = 0, eb = 0, vb = 0;
   for (uint32_t r = 0; r < world; r++) {
@@ -2408,7 +2402,6 @@ static int import_fragments_impl(am355_ctx* c, const uint8_t* frags, const uint6
     map_base[r] = mb; edit_base[r] = eb; val_base[r] = vb;
     if (h.n_map) memcpy(map + mb, f + h.off_map, (size_t)h.n_map * sizeof(am355_ir_map));
     memcpy(edit + eb, f + h.off_edits, ((size_t)h.n_erecs + 1) * sizeof(am355_ir_edit));
-    if (h.n_values) memcpy(val + vb, f + h.off_values, (size_t)h.n_values * sizeof(am355_ir_value));
     for (uint32_t k = 0; k <= h.n_erecs; k++) edit[eb + k].first += vb;  // (the sentinel of rank r then points at rank r+1's first value)
     mb += h.n_map; eb += h.n_erecs + 1; vb += h.n_values;
   }
@@ -2427,7 +2420,7 @@ static int import_fragments_impl(am355_ctx* c, const uint8_t* frags, const uint6
   if (rc) return rc;
   am355_patch_ir& h = c->hir;
   h.n_objects = NO; h.n_map = mb; h.n_edits = eb; h.n_values = vb;
-  h.objects = obj; h.map = map; h.edits = edit; h.values = val;
+  h.objects = obj; h.map = map; h.edits = edit;
   // (edit record eb is never read: the last fragment's own sentinel is record eb - 1)
   return AM355_OK;
 }

@@ -90,13 +90,13 @@ void merge_bind_counts(MergeBufs& b, void* d_counts_block);
 struct PatchIR {
   am355_ir_object* obj;     // [n_objects] index 0 is _root, then make rows in row order (make_row: NONE32 for root)
   am355_ir_map* map;        // [n_map_emit] sorted by (object, key, trigger op)
-  am355_ir_edit* edit;      // [n_erecs + 1] one record per edit (a multi-insert run is ONE record) + sentinel
-  am355_ir_value* val;      // [n_edits] one per visible list value; edit record k owns [edit[k].first, edit[k+1].first)
+  am355_ir_edit* edit;      // [n_erecs + 1] one record per edit -- per uniform stretch of a multi-insert run -- + sentinel
   uint32_t *e_row;          // [n_edits] row holding the value (its id is the edit's opId)
   uint32_t *e_elem;         // [n_edits] row of the element (its id is the elemId)
   uint32_t *e_index;        // [n_edits] list index
   uint32_t *e_flags;        // bit0: update (else insert), bit1: continues the multi-insert run of the previous edit, bit2: child
-                            // object, bit8 / bit9: first / last edit of its list object
+                            // object, bit8 / bit9: first / last edit of its list object, bit10: its value does not follow the
+                            // previous one in the arena with the same type/length word (starts a new record of the same run)
 };
 
 size_t merge_scratch_pairs(uint32_t n_ops);

@@ -808,45 +808,50 @@ __global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
       prev_oi = obj_index_of(b, b.obj_row[pel]);
       bool simple = !(f & 5) && r == el, psimple = !(pf & 5) && pr == pel;
       if (simple && psimple && prev_oi == oi && o.id_actor[r] == o.id_actor[pr] && o.id_ctr[r] == o.id_ctr[pr] + 1 &&
-          value_class(o.val_tl[r]) == value_class(o.val_tl[pr]) && ir.e_index[e] == ir.e_index[e - 1] + 1)
+          value_class(o.val_tl[r]) == value_class(o.val_tl[pr]) && ir.e_index[e] == ir.e_index[e - 1] + 1) {
         f |= 2u;
+        // a record holds values with one type/length word, back to back in the arena (consecutive ops of a change: consecutive
+        // bytes of its valRaw column); anything else starts a new record of the same multi-insert
+        uint32_t tl = o.val_tl[r], ptl = o.val_tl[pr];
+        if (tl != ptl || o.val_off[r] != o.val_off[pr] + (ptl >> 4)) f |= 0x400u;
+      }
     }
     if (e + 1 < n) next_oi = obj_index_of(b, b.obj_row[ir.e_elem[e + 1]]);
     if (oi != prev_oi) f |= 0x100u;
     if (oi != next_oi) f |= 0x200u;
     ir.e_flags[e] = f;
-    head = (f & 2u) ? 0u : 1u;
+    head = (!(f & 2u) || (f & 0x400u)) ? 1u : 0u;
   }
   carry_publish(b.cs_erec, head, s_red);
 }
 
-// consumer of k_edit_runs' carried scan (same grid): one value record per element edit, one edit record per run head, the
-// edit ranges of the list objects, the sentinel record and Counts.n_erecs
+// consumer of k_edit_runs' carried scan (same grid): one edit record per head (start of an edit, or of a new uniform stretch of a
+// multi-insert), the edit ranges of the list objects, the sentinel record and Counts.n_erecs
 __global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t n = b.counts->n_edits;
   if (blockIdx.x * BLOCK >= n && blockIdx.x) return;
   uint32_t e = gtid();
   uint32_t f = e < n ? ir.e_flags[e] : 2u;
-  uint32_t head = (f & 2u) ? 0u : 1u;
+  uint32_t head = (!(f & 2u) || (f & 0x400u)) ? 1u : 0u;
   uint32_t k = carry_prefix(b.cs_erec, head, s_red);
   if (e == 0 && n == 0) {
-    ir.edit[0] = am355_ir_edit{0, 0, 0, 0, 0, 0, 0, 0};
+    ir.edit[0] = am355_ir_edit{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     b.counts->n_erecs = 0;
     if (b.sig) signal_host(b.sig->final_counts, (const uint32_t*)b.counts, 16, &b.sig->final_seq, b.sig_seq);
   }
   if (e >= n) return;
   const OpCols& o = b.ops;
   uint32_t r = ir.e_row[e], el = ir.e_elem[e];
-  ir.val[e] = am355_ir_value{o.val_tl[r], (f & 4u) ? b.obj_index[r] : o.val_off[r]};
-  if (head) ir.edit[k] = am355_ir_edit{f & 5u, ir.e_index[e], o.id_ctr[r], o.id_actor[r], o.id_ctr[el], o.id_actor[el], e, 0};
+  if (head) ir.edit[k] = am355_ir_edit{f & 7u, ir.e_index[e], o.id_ctr[r], o.id_actor[r], o.id_ctr[el], o.id_actor[el], e, o.val_tl[r],
+                                       (f & 4u) ? b.obj_index[r] : o.val_off[r], 0};
   if (f & 0x300u) {
     uint32_t oi = obj_index_of(b, b.obj_row[el]);
     if (f & 0x100u) ir.obj[oi].edit_begin = k;         // (the first edit of an object is always a head)
     if (f & 0x200u) ir.obj[oi].edit_end = k + head;
   }
   if (e + 1 == n) {
-    ir.edit[k + head] = am355_ir_edit{0, 0, 0, 0, 0, 0, n, 0};
+    ir.edit[k + head] = am355_ir_edit{0, 0, 0, 0, 0, 0, n, 0, 0, 0};
     b.counts->n_erecs = k + head;
     // the counters are final (this kernel raises no flags); other workgroups may still be writing their records, which the host
     // only reads through later operations on this stream

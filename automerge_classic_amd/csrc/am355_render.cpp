@@ -245,25 +245,36 @@ struct R {
     return true;
   }
 
-  // edit records [b, e) of one list object, comma separated
+  // one record's values (all with the type/length word val_tl, back to back in the arena), comma separated
+  bool record_values(const am355_ir_edit& ed, uint32_t count) {
+    uint32_t len = ed.val_tl >> 4;
+    for (uint32_t k = 0; k < count; k++) {
+      if (k) out.push_back(',');
+      if (!prim_value(ed.val_tl, ed.val_off + k * len)) return false;
+    }
+    return true;
+  }
+
+  // edit records [b, e) of one list object, comma separated; b is not a continuation record
   bool edits_serial(uint32_t b, uint32_t e) {
     char t[64];
-    for (uint32_t i = b; i < e; i++) {
+    for (uint32_t i = b; i < e;) {
       const am355_ir_edit& ed = ir.edits[i];
-      uint32_t v0 = ed.first, v1 = ir.edits[i + 1].first;
-      if (v1 <= v0 || v1 > ir.n_values) return fail("internal: edit record without values");
+      uint32_t count = ir.edits[i + 1].first - ed.first;
+      uint32_t j = i + 1;
+      while (j < e && (ir.edits[j].flags & AM355_EDIT_CONT)) j++;  // further records of the same multi-insert
+      if (ir.edits[i + 1].first <= ed.first || ir.edits[j].first > ir.n_values) return fail("internal: edit record without values");
       if (i > b) out.push_back(',');
-      const am355_ir_value& val = ir.values[v0];
-      if (v1 - v0 >= 2) {
+      if (count >= 2 || j > i + 1) {
         snprintf(t, sizeof t, "{\"action\":\"multi-insert\",\"index\":%u,\"elemId\":", ed.index);
         out += t;
         if (!op_id(ed.elem_ctr, ed.elem_actor)) return false;
-        uint32_t tl = val.tl;
+        uint32_t tl = ed.val_tl;
         if (has_datatype(tl) && (tl & 15) != 0) { out += ",\"datatype\":"; datatype(tl & 15); }  // only truthy datatypes (new.js:762)
         out += ",\"values\":[";
-        for (uint32_t k = v0; k < v1; k++) {
-          if (k > v0) out.push_back(',');
-          if (!prim_value(ir.values[k].tl, ir.values[k].off)) return false;
+        for (uint32_t r = i; r < j; r++) {
+          if (r > i) out.push_back(',');
+          if (!record_values(ir.edits[r], ir.edits[r + 1].first - ir.edits[r].first)) return false;
         }
         out += "]}";
       } else if (ed.flags & AM355_EDIT_UPDATE) {
@@ -271,7 +282,7 @@ struct R {
         out += t;
         if (!op_id(ed.id_ctr, ed.id_actor)) return false;
         out += ",\"value\":";
-        if (!value(val.tl, val.off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
+        if (!value(ed.val_tl, ed.val_off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
         out.push_back('}');
       } else {
         snprintf(t, sizeof t, "{\"action\":\"insert\",\"index\":%u,\"elemId\":", ed.index);
@@ -280,15 +291,16 @@ struct R {
         out += ",\"opId\":";
         if (!op_id(ed.id_ctr, ed.id_actor)) return false;
         out += ",\"value\":";
-        if (!value(val.tl, val.off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
+        if (!value(ed.val_tl, ed.val_off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
         out.push_back('}');
       }
+      i = j;
     }
     return true;
   }
 
   // Long edit lists (a Text object holds one edit per character run) are rendered by several host threads, each into its
-  // own buffer (an edit record is a whole edit, so any split point will do); the pieces are then joined. Same text as the serial walk.
+  // own buffer, split where no multi-insert is cut; the pieces are then joined. Same text as the serial walk.
   bool edits(uint32_t b, uint32_t e) {
     // (AM355_RENDER_CHUNK: edits per thread below which the walk stays serial; the tests lower it to exercise the join)
     const char* env = getenv("AM355_RENDER_CHUNK");
@@ -301,6 +313,7 @@ struct R {
     std::vector<uint32_t> cut{b};
     for (uint32_t k = 1; k < want; k++) {
       uint32_t c = b + (uint32_t)((uint64_t)(e - b) * k / want);
+      while (c < e && (ir.edits[c].flags & AM355_EDIT_CONT)) c++;  // never between the records of one multi-insert
       if (c > cut.back() && c < e) cut.push_back(c);
     }
     cut.push_back(e);

@@ -261,7 +261,7 @@ static napi_value copy_to_arraybuffer(napi_env env, const void *src, size_t len)
   return ab;
 }
 
-/* fetchIR(ctx) -> {objects, map, edits, values, arena: ArrayBuffer, nObjects, nMap, nEdits, nValues, maxOp, pending,
+/* fetchIR(ctx) -> {objects, map, edits, arena: ArrayBuffer, nObjects, nMap, nEdits, nValues, maxOp, pending,
  *                  actorOff: ArrayBuffer(u32), actorBytes: ArrayBuffer, clockActor: ArrayBuffer(u32), clockSeq: ArrayBuffer(f64), heads: ArrayBuffer}
  * am355_fetch_ir: the record tables of include/am355.h as the device wrote them; materialize.js builds the patch object. */
 static napi_value js_fetch_ir(napi_env env, napi_callback_info info) {
@@ -284,7 +284,6 @@ static napi_value js_fetch_ir(napi_env env, napi_callback_info info) {
   PUT_AB("objects", ir.objects, (size_t)ir.n_objects * sizeof(am355_ir_object));
   PUT_AB("map", ir.map, (size_t)ir.n_map * sizeof(am355_ir_map));
   PUT_AB("edits", ir.edits, ((size_t)ir.n_edits + 1) * sizeof(am355_ir_edit));
-  PUT_AB("values", ir.values, (size_t)ir.n_values * sizeof(am355_ir_value));
   PUT_AB("arena", ir.arena, (size_t)ir.arena_len);
   PUT_AB("actorOff", ir.actor_off, ((size_t)ir.n_actors + 1) * sizeof(uint32_t));
   PUT_AB("actorBytes", ir.actor_bytes, ir.n_actors ? (size_t)ir.actor_off[ir.n_actors] : 0);

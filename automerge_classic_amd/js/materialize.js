@@ -10,8 +10,8 @@
 // Values are real JS values (float64 NaN / Infinity stay what they are, byte arrays are Uint8Arrays): nothing goes through JSON text.
 'use strict'
 
-const OBJ_WORDS = 8, MAP_WORDS = 10, EDIT_WORDS = 8, VAL_WORDS = 2
-const MAP_COUNTER = 1, MAP_CHILD = 2, EDIT_UPDATE = 1, EDIT_CHILD = 4
+const OBJ_WORDS = 8, MAP_WORDS = 10, EDIT_WORDS = 10
+const MAP_COUNTER = 1, MAP_CHILD = 2, EDIT_UPDATE = 1, EDIT_CONT = 2, EDIT_CHILD = 4
 const TYPE_NAME = { 0: 'map', 2: 'list', 4: 'text', 6: 'table' }
 const HEX = []
 for (let i = 0; i < 256; i++) HEX.push((i < 16 ? '0' : '') + i.toString(16))
@@ -39,7 +39,6 @@ class Materializer {
     this.map = new Uint32Array(ir.map)
     this.mapCounter = ir.map.byteLength ? new DataView(ir.map) : null
     this.edit = new Uint32Array(ir.edits)
-    this.val = new Uint32Array(ir.values)
     this.arena = new Uint8Array(ir.arena)
     this.arenaBuf = Buffer.from(ir.arena)
     this.decoder = new TextDecoder('utf-8')
@@ -138,30 +137,37 @@ class Materializer {
   }
 
   edits(begin, end) {
-    const e = this.edit, v = this.val, out = new Array(end - begin)
-    for (let k = begin; k < end; k++) {
+    const e = this.edit, out = []
+    for (let k = begin; k < end;) {
       const w = k * EDIT_WORDS, flags = e[w], index = e[w + 1]
-      const first = e[w + 6], next = e[w + EDIT_WORDS + 6]
-      const tl = v[first * VAL_WORDS], off = v[first * VAL_WORDS + 1]
-      if (next - first >= 2) {
-        const values = new Array(next - first)
-        if ((tl & 15) === 6) {   // strings: a run of typed characters
-          for (let i = first; i < next; i++) { const t = v[i * VAL_WORDS]; values[i - first] = this.str(v[i * VAL_WORDS + 1], t >>> 4) }
-          out[k - begin] = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]), values }
-        } else {
-          for (let i = first; i < next; i++) values[i - first] = this.decode(v[i * VAL_WORDS], v[i * VAL_WORDS + 1]).value
-          const head = this.decode(tl, off)
-          const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
-          if (head.datatype) edit.datatype = head.datatype   // only truthy datatypes (new.js:762)
-          edit.values = values
-          out[k - begin] = edit
+      const first = e[w + 6], tl = e[w + 7], off = e[w + 8]
+      let count = e[w + EDIT_WORDS + 6] - first
+      let j = k + 1
+      while (j < end && (e[j * EDIT_WORDS] & EDIT_CONT)) j++   // further records of the same multi-insert (its values change length)
+      if (count >= 2 || j > k + 1) {
+        const values = []
+        for (let r = k; r < j; r++) {
+          const rw = r * EDIT_WORDS, rtl = e[rw + 7], len = rtl >>> 4
+          let roff = e[rw + 8]
+          const rcount = e[rw + EDIT_WORDS + 6] - e[rw + 6]
+          if ((rtl & 15) === 6) {   // strings: a run of typed characters, back to back in the arena
+            if (len === 1) { const a = this.arena; for (let i = 0; i < rcount; i++, roff++) values.push(a[roff] < 0x80 ? ASCII[a[roff]] : this.str(roff, 1)) }
+            else for (let i = 0; i < rcount; i++, roff += len) values.push(this.str(roff, len))
+          } else {
+            for (let i = 0; i < rcount; i++, roff += len) values.push(this.decode(rtl, roff).value)
+          }
         }
+        const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
+        if ((tl & 15) !== 6) { const head = this.decode(tl, off); if (head.datatype) edit.datatype = head.datatype }   // only truthy datatypes (new.js:762)
+        edit.values = values
+        out.push(edit)
       } else if (flags & EDIT_UPDATE) {
-        out[k - begin] = { action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) }
+        out.push({ action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) })
       } else {
-        out[k - begin] = { action: 'insert', index, elemId: this.opId(e[w + 4], e[w + 5]), opId: this.opId(e[w + 2], e[w + 3]),
-                           value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) }
+        out.push({ action: 'insert', index, elemId: this.opId(e[w + 4], e[w + 5]), opId: this.opId(e[w + 2], e[w + 3]),
+                   value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) })
       }
+      k = j
     }
     return out
   }

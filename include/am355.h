@@ -121,7 +121,7 @@ int am355_get_raw(const am355_ctx *ctx, const uint8_t **arena, const uint64_t **
 
 /*
  * Patch IR on the host (valid after am355_fetch_ir or am355_patch_json; owned by ctx, pinned memory).  This is the OUTPUT of the
- * hot path: four record tables written by the device in exactly this layout and copied to the host as they are (four copies).
+ * hot path: three record tables written by the device in exactly this layout and copied to the host as they are (three copies).
  * The N-API addon hands them to JavaScript as external ArrayBuffers and automerge_classic_amd/js/materialize.js builds the patch
  * object from them; am355_patch_json renders the same tables as JSON text.  Values and map keys are byte ranges of the raw
  * arena; op ids are (counter, actor rank) with the actor table in the envelope.
@@ -130,11 +130,14 @@ int am355_get_raw(const am355_ctx *ctx, const uint8_t **arena, const uint64_t **
  *             [map_begin, map_end), a list/text object the edit records [edit_begin, edit_end).
  *   map       one record per visible value of a map key (conflicts: several records with the same key), sorted by (object, key in
  *             UTF-16 code unit order, op id)  -- new.js:1035-1039 `props[key][opId] = value`.
- *   edits     one record per edit of the reference's whole-document patch, in document order: insert, update, or multi-insert
- *             (new.js:747-782 appendEdit; a record with count >= 2 values is a multi-insert: consecutive op ids of one actor,
- *             elemId == opId, same value class).  Record k owns the values [first, edits[k+1].first); the table ends with a
- *             sentinel record whose `first` is n_values.
- *   values    (type/length word as in the valLen column: len << 4 | type, columnar.js:300-329; offset of the bytes in the arena)
+ *   edits     the edits of the reference's whole-document patch, in document order: insert, update, or multi-insert (new.js:747-782
+ *             appendEdit: consecutive op ids of one actor, elemId == opId, same value class).  A record carries
+ *             count = edits[k+1].first - first values (the table ends with a sentinel record whose `first` is n_values), all with
+ *             the SAME type/length word, their bytes back to back in the arena from val_off on -- consecutive ops of one change
+ *             have consecutive values in its valRaw column, so a typed run is one record and needs no per-value table.  A
+ *             multi-insert whose values change length (mixed-width UTF-8) continues in the next record (AM355_EDIT_CONT): the
+ *             host appends that record's values to the same edit.  count >= 2 or a following CONT record = multi-insert.
+ *             (type/length word as in the valLen column: len << 4 | type, columnar.js:300-329.)
  */
 typedef struct {
   uint32_t id_ctr, id_actor;      /* objectId = id_ctr@actor (ignored for _root) */
@@ -151,25 +154,24 @@ typedef struct {
   uint32_t flags, pad;
   int64_t counter;                /* AM355_MAP_COUNTER: the counter's total (new.js:937-967) */
 } am355_ir_map;
-enum { AM355_EDIT_UPDATE = 1u, AM355_EDIT_CHILD = 4u };
+enum { AM355_EDIT_UPDATE = 1u, AM355_EDIT_CONT = 2u, AM355_EDIT_CHILD = 4u };
 typedef struct {
-  uint32_t flags;                 /* AM355_EDIT_UPDATE: `update` edit (else insert / multi-insert); AM355_EDIT_CHILD: the value is an object */
-  uint32_t index;                 /* list index */
-  uint32_t id_ctr, id_actor;      /* opId */
+  uint32_t flags;                 /* AM355_EDIT_UPDATE: `update` edit (else insert / multi-insert); AM355_EDIT_CHILD: the value is an object;
+                                     AM355_EDIT_CONT: more values of the previous record's multi-insert */
+  uint32_t index;                 /* list index (of the record's first value) */
+  uint32_t id_ctr, id_actor;      /* opId (of the record's first value) */
   uint32_t elem_ctr, elem_actor;  /* elemId */
-  uint32_t first;                 /* first value record of this edit */
+  uint32_t first;                 /* ordinal of the record's first value among all list values; count = next record's first - first */
+  uint32_t val_tl;                /* type/length word of every value of the record */
+  uint32_t val_off;               /* arena offset of the first value (value i at val_off + i * (val_tl >> 4)); AM355_EDIT_CHILD: object index */
   uint32_t pad;
 } am355_ir_edit;
-typedef struct {
-  uint32_t tl, off;               /* AM355_EDIT_CHILD edits: off = object index */
-} am355_ir_value;
 
 typedef struct {
-  uint32_t n_objects, n_map, n_edits, n_values;
+  uint32_t n_objects, n_map, n_edits, n_values;   /* n_values: visible list values (sum of the records' counts) */
   const am355_ir_object *objects; /* [n_objects] */
   const am355_ir_map *map;        /* [n_map] */
   const am355_ir_edit *edits;     /* [n_edits + 1] (sentinel) */
-  const am355_ir_value *values;   /* [n_values] */
   /* envelope */
   uint64_t max_op;
   uint32_t n_actors;            /* actors by rank (lexicographic order of raw ids) */

@@ -159,6 +159,24 @@ function textScenario(seed, nActors, rounds, burst) {
 }
 
 // Hand-built changes (the style of the reference's own backend tests) for cases the frontend cannot produce
+// Multi-inserts whose values change byte length: mixed-width UTF-8 text typed in one change, lists of numbers pushed in one go
+// (consecutive ops of one change, values of different LEB128 lengths / float64), plus concurrent edits and deletions.
+function multibyteScenario() {
+  const ids = ['aa11', 'bb22']
+  let a = Automerge.from({ text: new Automerge.Text(), nums: [], mixed: [] }, ids[0])
+  a = Automerge.change(a, d => {
+    d.text.insertAt(0, ...'aé€😀bcßπ∑xyz日本語ok')
+    d.nums.push(1, 2, 300, 70000, 5, -1, -200, 3.5, 2.25, 1e100, 7, 8)
+    d.mixed.push('x', 'yy', 'é', 1, 2, true, false, null, 'z', new Date(86400000), new Date(1), new Automerge.Counter(3), 4)
+  })
+  let b = Automerge.merge(Automerge.init(ids[1]), a)
+  a = Automerge.change(a, d => { d.text.insertAt(3, ...'ÄÖ12'); d.text.deleteAt(1); d.nums.insertAt(2, 128, 127, 16384) })
+  b = Automerge.change(b, d => { d.text.insertAt(5, ...'→←ab'); d.text.deleteAt(9); d.nums.deleteAt(0); d.mixed.insertAt(1, 'é', 'è', 'ee') })
+  a = Automerge.merge(a, b)
+  a = Automerge.change(a, d => { d.text.insertAt(d.text.length, ...'end…') })
+  return Automerge.getAllChanges(a)
+}
+
 function handBuilt() {
   const A = '01234567', B = '89abcdef', C = 'fedcba98'
   const hash = c => columnar.decodeChange(encodeChange(c)).hash
@@ -242,7 +260,9 @@ function main() {
   }
   fs.mkdirSync(outDir, { recursive: true })
   const scenarios = {}
-  if (process.env.CAMPAIGN) {
+  if (process.env.EXTRA === 'multibyte') {
+    scenarios.frontend_multibyte_runs = { changes: multibyteScenario(), note: 'real frontend: multi-inserts whose values change byte length (mixed-width UTF-8 text, numbers of different widths, floats, mixed lists)' }
+  } else if (process.env.CAMPAIGN) {
     // differential campaign: CAMPAIGN="seed:actors:steps:depth,..." (mixed) or "t:seed:actors:rounds:burst" (text) -> only these
     for (const spec of process.env.CAMPAIGN.split(',')) {
       const f = spec.split(':')
