@@ -141,20 +141,24 @@ class Materializer {
     for (let k = begin; k < end;) {
       const w = k * EDIT_WORDS, flags = e[w], index = e[w + 1]
       const first = e[w + 6], tl = e[w + 7], off = e[w + 8]
-      let count = e[w + EDIT_WORDS + 6] - first
+      const count = e[w + EDIT_WORDS + 6] - first
       let j = k + 1
       while (j < end && (e[j * EDIT_WORDS] & EDIT_CONT)) j++   // further records of the same multi-insert (its values change length)
       if (count >= 2 || j > k + 1) {
-        const values = []
-        for (let r = k; r < j; r++) {
-          const rw = r * EDIT_WORDS, rtl = e[rw + 7], len = rtl >>> 4
-          let roff = e[rw + 8]
-          const rcount = e[rw + EDIT_WORDS + 6] - e[rw + 6]
-          if ((rtl & 15) === 6) {   // strings: a run of typed characters, back to back in the arena
-            if (len === 1) { const a = this.arena; for (let i = 0; i < rcount; i++, roff++) values.push(a[roff] < 0x80 ? ASCII[a[roff]] : this.str(roff, 1)) }
-            else for (let i = 0; i < rcount; i++, roff += len) values.push(this.str(roff, len))
-          } else {
-            for (let i = 0; i < rcount; i++, roff += len) values.push(this.decode(rtl, roff).value)
+        let values
+        if (j === k + 1 && (tl & 15) === 6 && (tl >>> 4) === 1) {
+          // the common record: a run of typed single-byte characters, back to back in the arena
+          const a = this.arena
+          values = new Array(count)
+          for (let i = 0, o = off; i < count; i++, o++) values[i] = a[o] < 0x80 ? ASCII[a[o]] : this.str(o, 1)
+        } else {
+          values = []
+          for (let r = k; r < j; r++) {
+            const rw = r * EDIT_WORDS, rtl = e[rw + 7], len = rtl >>> 4
+            let roff = e[rw + 8]
+            const rcount = e[rw + EDIT_WORDS + 6] - e[rw + 6]
+            if ((rtl & 15) === 6) for (let i = 0; i < rcount; i++, roff += len) values.push(this.str(roff, len))
+            else for (let i = 0; i < rcount; i++, roff += len) values.push(this.decode(rtl, roff).value)
           }
         }
         const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
