@@ -1594,18 +1594,25 @@ static int replay_impl(am355_ctx* c) {
   PlanTotals tot{};
   static const bool hash_after_parse = []() { const char* e = getenv("AM355_HASH_START"); return !(e && !strcmp(e, "intern")); }();
 
-  // ---- stream A: parse ----
-  HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, sa));
-  HIPCHK(c, hipMemsetAsync(d_wa, 0, s1_distinct + 16, sa));
+  // ---- stream A: parse. The fills of stage 1 (flag words, actor hash table) depend on nothing of this replay: they run on stream3
+  //      beside the parse kernel instead of in front of the kernels that need them ----
   HIPCHK(c, hipEventRecord(c->ev[0], sa));
   launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), sa);
   HIPCHK(c, hipEventRecord(c->ev_parse, sa));
+  HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, c->stream3));
+  HIPCHK(c, hipMemsetAsync(d_wa, 0, s1_distinct + 16, c->stream3));
+  HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), c->stream3));
+  HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), c->stream3));
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+  HIPCHK(c, hipStreamWaitEvent(sa, c->ev_join, 0));
 
   exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_wa + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
   for (int attempt = 0;; attempt++) {
-    HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), sa));
-    HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), sa));
-    if (attempt) HIPCHK(c, hipMemsetAsync(d_distinct, 0, 4, sa));
+    if (attempt) {
+      HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), sa));
+      HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), sa));
+      HIPCHK(c, hipMemsetAsync(d_distinct, 0, 4, sa));
+    }
     launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
                         c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_wa + W_FLAGS_A, d_wa + W_FAST_A,
                         d_distinct, d_briefs, sa);
@@ -1623,6 +1630,7 @@ static int replay_impl(am355_ctx* c) {
       //      after the parse / actor kernels of stream A: those grids are as small as the hash grid (one wave per 64
       //      changes) and the ALU-dense SHA waves would otherwise share their SIMDs and slow them down ----
       HIPCHK(c, hipStreamWaitEvent(sb, hash_after_parse ? c->ev_parse : c->ev[1], 0));
+      HIPCHK(c, hipStreamWaitEvent(sb, c->ev_join, 0));  // (its flag words are cleared on stream3)
       HIPCHK(c, hipEventRecord(c->ev_b0, sb));
       HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
       HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
