@@ -239,7 +239,7 @@ struct am355_ctx {
   BigColDesc doc_cols{};
   bool doc_serial = false;           // AM355_DOC_SERIAL=1: lane-serial column decoders (first version, kept for cross-checks)
   // stage-1 side tables (device) and their pinned host mirrors
-  DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1;
+  DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1, d_plan_sums;
   HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_s1;
   DevBuf d_s1;                 // stage-1 results read by the host: flag words | distinct actor ids | one ChangeBrief per change
   ChangeBrief* hp_briefs = nullptr;
@@ -379,7 +379,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   (void)hipStreamSynchronize(c->stream2);
   (void)hipStreamSynchronize(c->stream3);
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
-                    &c->d_words, &c->d_slot_rank, &c->d_scan1})
+                    &c->d_words, &c->d_slot_rank, &c->d_scan1, &c->d_plan_sums})
     b->release();
   for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1}) b->release();
   c->d_s1.release();
@@ -1574,7 +1574,7 @@ static int replay_impl(am355_ctx* c) {
       !c->d_hash_tab.ensure(4 * (size_t)(c->hash_mask + 1)) || !c->d_min_idx.ensure(4 * n1) || !c->d_has_dep.ensure(n1) || !c->d_words.ensure(4 * W_NUM) ||
       !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
       !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_plans.ensure(2 * sizeof(ChangePlan) * n1) ||
-      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)))
+      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_plan_sums.ensure(plan_block_sums_bytes(n)))
     return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
   c->have_host_metas = false;
   // what the host reads after stage 1 -- a few flag words, the distinct actor ids, one brief per change -- sits in one device
@@ -1615,12 +1615,12 @@ static int replay_impl(am355_ctx* c) {
     }
     launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
                         c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_wa + W_FLAGS_A, d_wa + W_FAST_A,
-                        d_distinct, d_briefs, sa);
+                        d_distinct, d_briefs, c->d_slot_rank.as<uint32_t>(), c->d_plan_sums.as<unsigned long long>(), d_wa + 8, sa);
     // device half of the in-order plan (actor ranks, per-change bases, decoder classes): the decode kernels start from it
     // (its totals, and the stage-1 words the host decides on, reach the host through HostSignals: no copy, no blocking wait)
     c->sig_seq++;
-    launch_plan(c->d_arena.as<uint8_t>(), d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plans.as<ChangePlan>(),
-                c->d_plans.as<ChangePlan>() + n1, d_wa, sig, c->sig_seq, sa);
+    launch_plan(d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plan_sums.as<unsigned long long>(), c->d_plans.as<ChangePlan>(),
+                c->d_plans.as<ChangePlan>() + n1, d_wa, d_wa + 8, sig, c->sig_seq, sa);
     // the host's own half of the plan needs a 32-byte digest per change and the handful of distinct actor ids: they follow
     HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
     HIPCHK(c, hipEventRecord(c->ev_s1, sa));
@@ -1652,6 +1652,7 @@ static int replay_impl(am355_ctx* c) {
     c->amap_cap = tot.total_entries + 1024;
     if (!c->d_amap_prov.ensure(4 * (size_t)c->amap_cap)) return fail(c, AM355_E_NOMEM, "device allocation failed (actor tables)");
     HIPCHK(c, hipMemsetAsync(d_wa + W_FAST_A, 0, 4, sa));
+    HIPCHK(c, hipMemsetAsync(d_wa + 8, 0, 32, sa));  // (plan words)
   }
 
   // ---- host: flags, in-order plan ----

@@ -8,17 +8,21 @@ void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t
                          uint32_t tab_mask, uint32_t* flags, hipStream_t st);
 void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,
                          const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st);
-// distinct: [0] count of claimed actor-table slots, [1..] their indexes (capacity distinct_capacity()); briefs: per-change digest for the host
+// distinct: [0] count of claimed actor-table slots, [1..] their indexes (capacity distinct_capacity()); briefs: per-change digest for the host.
+// k_actor_check also starts the device half of the in-order plan: per-workgroup sums of ops / preds / actor entries / plans per decoder
+// class (block_sums, plan_block_sums_bytes(n) bytes), lexicographic ranks of the distinct actor ids (slot_rank[slot]) and plan_words
+// ([0] fallback, [1] max op, [2] OR of change flags, [3] unknown columns; cleared by the caller).
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
-                         ChangeBrief* briefs, hipStream_t st);
+                         ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st);
+size_t plan_block_sums_bytes(uint32_t n);
 uint32_t distinct_capacity();
-// In-order fast path, device half of the plan: lexicographic ranks of the distinct actor ids (slot_rank[slot]), and for every
-// change with ops its ChangePlan (row / pred / actor-table bases by prefix sums in input order, author rank) by decoder class
-// (`plans`: small class from the front, large class from the back; `plans_serial`: the rest) -- what the decode kernels need, so that they can start while the host is still validating
-// sequence numbers and building the per-actor span tables. The totals go to the host through `sig` (HostSignals.plan).
-void launch_plan(const uint8_t* arena, const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, uint32_t* slot_rank, uint32_t slot_mask,
-                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, HostSignals* sig, uint32_t seq, hipStream_t st);
+// ... and k_plan_apply finishes it: for every change with ops its ChangePlan (row / pred / actor-table bases by prefix sums in input order,
+// author rank) by decoder class (`plans`: small class from the front, large class from the back; `plans_serial`: the rest) -- what the
+// decode kernels need, so that they can start while the host is still validating sequence numbers and building the per-actor span
+// tables. The totals go to the host through `sig` (HostSignals.plan).
+void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, const uint32_t* slot_rank, uint32_t slot_mask, const unsigned long long* block_sums,
+                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st);
 void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, const ChangePlan* plans_serial, uint32_t n_changes,
                            uint32_t n_small, uint32_t n_large, uint32_t n_serial, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags,
                            hipStream_t st, hipStream_t aux);

@@ -588,37 +588,203 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
 // with in-order application that means its first change has an index <= this one
 __device__ __forceinline__ int wave_class_of(const ChangeMeta& m);
 
-__global__ __launch_bounds__(BLOCK) void k_actor_check(ChangeMeta* __restrict__ metas, uint32_t n, const uint32_t* __restrict__ amap_base,
-                                                       const uint32_t* __restrict__ amap, uint32_t amap_cap, const uint32_t* __restrict__ first_idx,
-                                                       uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags, ChangeBrief* __restrict__ briefs) {
-  uint32_t c = gtid();
-  if (c >= n) return;
-  ChangeMeta* m = &metas[c];
-  ChangeBrief br;
-  br.seq = m->seq;
-  br.start_op = (uint32_t)m->start_op;
-  br.n_ops = m->n_ops;
-  br.n_preds = m->n_preds;
-  br.n_entries = m->n_entries;
-  br.author_slot = m->author_slot;
-  br.flags_fits = m->flags;
-  if (!m->flags) {
-    uint32_t base = amap_base[c];
-    if ((uint64_t)base + m->n_entries <= amap_cap) {
-      uint32_t mx = 0;
-      for (uint32_t k = 0; k < m->n_entries; k++) {
-        uint32_t f = first_idx[amap[base + k]];
-        mx = f > mx ? f : mx;  // NONE32 (no change by that actor in the batch) also lands on the general path
-      }
-      m->max_first = mx;
-      if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
-    }
-    int wc = wave_class_of(*m);
-    if (wc >= 1) br.flags_fits |= 0x80000000u;
-    if (wc == 2) br.flags_fits |= 0x40000000u;
-    if (m->pad & 1) br.flags_fits |= 0x20000000u;  // the change carries columns this engine does not model
+// Device half of the in-order plan, part 1 (with k_plan_apply below): while it writes the digests, every workgroup also publishes the
+// sums of its 256 changes (ops, preds, actor entries, plans per decoder class), and one EXTRA workgroup (blockIdx == gridDim - 1)
+// ranks the distinct actor ids lexicographically from LDS. plan_words: [0] fallback, [1] max op id, [2] OR of the changes' validity
+// flags, [3] unknown columns seen (cleared by the caller).
+constexpr uint32_t PLAN_RANK_MAX = 1024;   // distinct actors ranked on the device (LDS: 40 bytes each)
+constexpr uint32_t PLAN_ID_MAX = 32;       // bytes of an actor id the device ranking handles (ids are 16 bytes in practice)
+constexpr uint32_t PLAN_SUMS = 8;          // words per workgroup in block_sums: ops, preds, entries, small, large, serial plans
+
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long x, uint32_t lane) {
+  for (int d = 1; d < WAVE; d <<= 1) {
+    unsigned long long y = __shfl_up(x, (unsigned)d);
+    if (lane >= (uint32_t)d) x += y;
   }
-  briefs[c] = br;
+  return x;
+}
+// exclusive prefix over a BLOCK-thread workgroup of three 64-bit counters at once; totals returned through t[]
+__device__ __forceinline__ void block_scan3(unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long (*s)[3], unsigned long long ex[3],
+                                            unsigned long long t[3]) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+  unsigned long long ia = wave_incl_scan_u64(a, lane), ib = wave_incl_scan_u64(b, lane), ic = wave_incl_scan_u64(c, lane);
+  if (lane == WAVE - 1) { s[w][0] = ia; s[w][1] = ib; s[w][2] = ic; }
+  __syncthreads();
+  unsigned long long ba = 0, bb = 0, bc = 0, ta = 0, tb = 0, tc = 0;
+  for (uint32_t k = 0; k < BLOCK / WAVE; k++) {
+    unsigned long long xa = s[k][0], xb = s[k][1], xc = s[k][2];
+    if (k < w) { ba += xa; bb += xb; bc += xc; }
+    ta += xa; tb += xb; tc += xc;
+  }
+  __syncthreads();
+  ex[0] = ba + ia - a; ex[1] = bb + ib - b; ex[2] = bc + ic - c;
+  t[0] = ta; t[1] = tb; t[2] = tc;
+}
+
+// lexicographic ranks of the distinct actor ids (a proper prefix sorts first) = order of the hex strings (new.js:65); one workgroup
+__device__ void rank_actors(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
+                            uint32_t* __restrict__ plan_words) {
+  __shared__ unsigned long long s_id[PLAN_RANK_MAX][PLAN_ID_MAX / 8];  // big-endian words, zero padded
+  __shared__ uint32_t s_len[PLAN_RANK_MAX];
+  __shared__ uint32_t s_fallback;
+  const uint32_t t = threadIdx.x, nd = distinct[0];
+  if (t == 0) s_fallback = nd > PLAN_RANK_MAX ? 1u : 0u;
+  __syncthreads();
+  if (nd <= PLAN_RANK_MAX) {
+    const unsigned long long* slot_val = (const unsigned long long*)(distinct + 2 + DISTINCT_CAP);
+    for (uint32_t a = t; a < nd; a += BLOCK) {
+      unsigned long long v = slot_val[a];
+      uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
+      s_len[a] = len;
+      if (len > PLAN_ID_MAX) s_fallback = 1;
+      else {
+        uint8_t bytes[PLAN_ID_MAX];  // (all loads issued before the first use: one memory round trip, not one per byte)
+#pragma unroll
+        for (uint32_t k = 0; k < PLAN_ID_MAX; k++) bytes[k] = k < len ? arena[off + k] : (uint8_t)0;
+#pragma unroll
+        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
+          unsigned long long x = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < 8; k++) x = x << 8 | bytes[wd * 8 + k];
+          s_id[a][wd] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (s_fallback) { if (t == 0) plan_words[0] = 1; return; }
+  for (uint32_t a = t; a < nd; a += BLOCK) {
+    uint32_t rank = 0;
+    const uint32_t my_len = s_len[a];
+    unsigned long long mine[PLAN_ID_MAX / 8];
+    for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) mine[wd] = s_id[a][wd];
+    for (uint32_t j = 0; j < nd; j++) {
+      bool less = false, decided = false;
+      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8 && !decided; wd++) {
+        unsigned long long x = s_id[j][wd];
+        if (x != mine[wd]) { less = x < mine[wd]; decided = true; }
+      }
+      if (!decided) less = s_len[j] < my_len;  // equal up to the padding: the shorter id first (distinct ids differ somewhere)
+      rank += less ? 1u : 0u;
+    }
+    slot_rank[distinct[1 + a]] = rank;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
+                                                       const uint32_t* __restrict__ amap_base, const uint32_t* __restrict__ amap, uint32_t amap_cap,
+                                                       const uint32_t* __restrict__ first_idx, uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags,
+                                                       ChangeBrief* __restrict__ briefs, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
+                                                       unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words) {
+  __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
+  if (blockIdx.x + 1 == gridDim.x) { rank_actors(arena, distinct, slot_rank, plan_words); return; }
+  uint32_t c = gtid();
+  const bool in_range = c < n;
+  ChangeBrief br{};
+  if (in_range) {
+    ChangeMeta* m = &metas[c];
+    br.seq = m->seq;
+    br.start_op = (uint32_t)m->start_op;
+    br.n_ops = m->n_ops;
+    br.n_preds = m->n_preds;
+    br.n_entries = m->n_entries;
+    br.author_slot = m->author_slot;
+    br.flags_fits = m->flags;
+    if (!m->flags) {
+      uint32_t base = amap_base[c];
+      if ((uint64_t)base + m->n_entries <= amap_cap) {
+        uint32_t mx = 0;
+        for (uint32_t k = 0; k < m->n_entries; k++) {
+          uint32_t f = first_idx[amap[base + k]];
+          mx = f > mx ? f : mx;  // NONE32 (no change by that actor in the batch) also lands on the general path
+        }
+        m->max_first = mx;
+        if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
+      }
+      int wc = wave_class_of(*m);
+      if (wc >= 1) br.flags_fits |= 0x80000000u;
+      if (wc == 2) br.flags_fits |= 0x40000000u;
+      if (m->pad & 1) br.flags_fits |= 0x20000000u;  // the change carries columns this engine does not model
+    }
+    briefs[c] = br;
+  }
+  // ---- sums of this workgroup's changes for k_plan_apply (a malformed change counts nothing: the host rejects the batch on its flags) ----
+  const bool valid = in_range && !(br.flags_fits & 0x1fffffffu);
+  const bool has = valid && br.n_ops != 0;
+  const bool small = has && (br.flags_fits & 0x40000000u), large = has && !small && (br.flags_fits & 0x80000000u), serial = has && !small && !large;
+  unsigned long long ex[3], t1[3], t2[3];
+  block_scan3(valid ? br.n_ops : 0u, valid ? br.n_preds : 0u, valid ? br.n_entries : 0u, s_scan, ex, t1);
+  block_scan3(small ? 1u : 0u, large ? 1u : 0u, serial ? 1u : 0u, s_scan, ex, t2);
+  uint32_t mx_op = has ? br.start_op + br.n_ops - 1 : 0u, bad = in_range ? (br.flags_fits & 0x1fffffffu) : 0u, unknown = in_range ? (br.flags_fits & 0x20000000u) : 0u;
+  for (int d = WAVE / 2; d >= 1; d >>= 1) {
+    uint32_t o = __shfl_xor(mx_op, d), ob = __shfl_xor(bad, d), ou = __shfl_xor(unknown, d);
+    mx_op = o > mx_op ? o : mx_op;
+    bad |= ob;
+    unknown |= ou;
+  }
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    if (mx_op) atomicMax(&plan_words[1], mx_op);
+    if (bad) atomicOr(&plan_words[2], bad);
+    if (unknown) atomicOr(&plan_words[3], 1u);
+  }
+  if (threadIdx.x == 0) {
+    unsigned long long* out = block_sums + (size_t)blockIdx.x * PLAN_SUMS;
+    out[0] = t1[0]; out[1] = t1[1]; out[2] = t1[2]; out[3] = t2[0]; out[4] = t2[1]; out[5] = t2[2];
+  }
+}
+
+// part 2 (same grid without the extra workgroup): prefix sums in input order -> the ChangePlan of every change with ops. plans: [n] -- the
+// small class fills it from the front, the large class from the back (a plan's place inside its class does not matter: every plan is
+// an independent unit of decode work); plans_serial: [n] the changes left to the lane-serial decoder. The last workgroup reports the
+// totals (and the stage-1 words the host decides on) through HostSignals.
+__global__ __launch_bounds__(BLOCK) void k_plan_apply(const ChangeBrief* __restrict__ briefs, uint32_t n, const uint32_t* __restrict__ slot_rank, uint32_t slot_mask,
+                                                      const unsigned long long* __restrict__ block_sums, ChangePlan* __restrict__ plans,
+                                                      ChangePlan* __restrict__ plans_serial, const uint32_t* __restrict__ words, const uint32_t* __restrict__ plan_words,
+                                                      const uint32_t* __restrict__ distinct, HostSignals* sig, uint32_t seq) {
+  __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
+  __shared__ unsigned long long s_base[6];
+  // sums of the workgroups before this one (L2 hits: a few words per workgroup)
+  {
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += BLOCK) {
+      const unsigned long long* q = block_sums + (size_t)j * PLAN_SUMS;
+      p0 += q[0]; p1 += q[1]; p2 += q[2]; p3 += q[3]; p4 += q[4]; p5 += q[5];
+    }
+    unsigned long long ex[3], t1[3], t2[3];
+    block_scan3(p0, p1, p2, s_scan, ex, t1);
+    block_scan3(p3, p4, p5, s_scan, ex, t2);
+    if (threadIdx.x == 0) { s_base[0] = t1[0]; s_base[1] = t1[1]; s_base[2] = t1[2]; s_base[3] = t2[0]; s_base[4] = t2[1]; s_base[5] = t2[2]; }
+    __syncthreads();
+  }
+  const uint32_t c = gtid();
+  const bool in_range = c < n;
+  ChangeBrief br{};
+  if (in_range) br = briefs[c];
+  const bool valid = in_range && !(br.flags_fits & 0x1fffffffu);
+  const bool has = valid && br.n_ops != 0;
+  const bool small = has && (br.flags_fits & 0x40000000u), large = has && !small && (br.flags_fits & 0x80000000u), serial = has && !small && !large;
+  unsigned long long e1[3], e2[3], t1[3], t2[3];
+  block_scan3(valid ? br.n_ops : 0u, valid ? br.n_preds : 0u, valid ? br.n_entries : 0u, s_scan, e1, t1);
+  block_scan3(small ? 1u : 0u, large ? 1u : 0u, serial ? 1u : 0u, s_scan, e2, t2);
+  if (has) {
+    // (author_slot is only meaningful once k_actor_intern has run for the change: a capacity retry leaves it unset in the first attempt)
+    ChangePlan pl{c, (uint32_t)(s_base[0] + e1[0]), (uint32_t)(s_base[1] + e1[1]), (uint32_t)(s_base[2] + e1[2]),
+                  br.author_slot <= slot_mask ? slot_rank[br.author_slot] : 0u, br.n_entries};
+    if (small) plans[(uint32_t)(s_base[3] + e2[0])] = pl;
+    else if (large) plans[n - 1 - (uint32_t)(s_base[4] + e2[1])] = pl;
+    else plans_serial[(uint32_t)(s_base[5] + e2[2])] = pl;
+  }
+  if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {
+    unsigned long long ops = s_base[0] + t1[0], preds = s_base[1] + t1[1], ent = s_base[2] + t1[2];
+    PlanTotals z{};
+    z.n_ops = (uint32_t)ops; z.n_preds = (uint32_t)preds; z.n_entries = (uint32_t)ent;
+    z.n_small = (uint32_t)(s_base[3] + t2[0]); z.n_large = (uint32_t)(s_base[4] + t2[1]); z.n_serial = (uint32_t)(s_base[5] + t2[2]);
+    z.max_op = plan_words[1];
+    z.fallback = (plan_words[0] || ops >= 0x7ffffff0ull || preds >= 0xfffffff0ull || ent >= 0xfffffff0ull) ? 1u : 0u;
+    z.flags_a = words[0] | plan_words[2]; z.fast_a = words[1]; z.total_entries = words[2]; z.n_distinct = distinct[0];
+    z.reserved[0] = plan_words[3];  // some change carries columns this engine does not model (the reference's save keeps them)
+    signal_host((uint32_t*)&sig->plan, (const uint32_t*)&z, sizeof(PlanTotals) / 4, &sig->plan_seq, seq);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1516,201 +1682,22 @@ void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const ui
 
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
-                         ChangeBrief* briefs, hipStream_t st) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
-                     fast_flags, distinct);
-  AM355_LAUNCH_INDEPENDENT(k_actor_check, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
-                           (const uint32_t*)first_idx, flags, fast_flags, briefs);
+                         ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st) {
+  if (n)
+    hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
+                       fast_flags, distinct);
+  // (+ 1: the workgroup that ranks the distinct actor ids)
+  hipLaunchKernelGGL(k_actor_check, dim3((n + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), 0, st, arena, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
+                     (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, slot_rank, block_sums, plan_words);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k_plan: one workgroup. (new.js:1434-1451 actor table, :708-709 op id ranges -- the arithmetic the host's plan_fast does too)
-// ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t PLAN_THREADS = 512;    // (8 waves: 256 VGPRs per lane -- at 1024 threads the kernel spilled to scratch)
-constexpr uint32_t PLAN_RANK_MAX = 1024;   // distinct actors ranked on the device (LDS: 40 bytes each)
-constexpr uint32_t PLAN_ID_MAX = 32;       // bytes of an actor id the device ranking handles (ids are 16 bytes in practice)
+size_t plan_block_sums_bytes(uint32_t n) { return sizeof(unsigned long long) * PLAN_SUMS * ((size_t)(n + BLOCK - 1) / BLOCK + 1); }
 
-__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long x, uint32_t lane) {
-  for (int d = 1; d < WAVE; d <<= 1) {
-    unsigned long long y = __shfl_up(x, (unsigned)d);
-    if (lane >= (uint32_t)d) x += y;
-  }
-  return x;
-}
-// exclusive prefix over the 1024-thread workgroup of three packed 64-bit counters at once; totals returned through t[]
-__device__ __forceinline__ void plan_scan3(unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long (*s)[3], unsigned long long ex[3],
-                                           unsigned long long t[3]) {
-  const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-  unsigned long long ia = wave_incl_scan_u64(a, lane), ib = wave_incl_scan_u64(b, lane), ic = wave_incl_scan_u64(c, lane);
-  if (lane == WAVE - 1) { s[w][0] = ia; s[w][1] = ib; s[w][2] = ic; }
-  __syncthreads();
-  unsigned long long ba = 0, bb = 0, bc = 0, ta = 0, tb = 0, tc = 0;
-  for (uint32_t k = 0; k < PLAN_THREADS / WAVE; k++) {
-    unsigned long long xa = s[k][0], xb = s[k][1], xc = s[k][2];
-    if (k < w) { ba += xa; bb += xb; bc += xc; }
-    ta += xa; tb += xb; tc += xc;
-  }
-  __syncthreads();
-  ex[0] = ba + ia - a; ex[1] = bb + ib - b; ex[2] = bc + ic - c;
-  t[0] = ta; t[1] = tb; t[2] = tc;
-}
-
-constexpr uint32_t PLAN_ITEMS = 8;  // consecutive changes per thread and tile (4096 changes per tile)
-
-// plans: [n] -- the small class fills it from the front, the large class from the back (a plan's place inside its class does not
-// matter: every plan is an independent unit of decode work); plans_serial: [n] the changes left to the lane-serial decoder.
-__global__ __launch_bounds__(PLAN_THREADS) void k_plan(const uint8_t* __restrict__ arena, const ChangeBrief* __restrict__ briefs, uint32_t n,
-                                                       const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank, uint32_t slot_mask,
-                                                       ChangePlan* __restrict__ plans, ChangePlan* __restrict__ plans_serial,
-                                                       const uint32_t* __restrict__ words, HostSignals* sig, uint32_t seq) {
-  __shared__ unsigned long long s_id[PLAN_RANK_MAX][PLAN_ID_MAX / 8];  // big-endian words, zero padded
-  __shared__ uint32_t s_len[PLAN_RANK_MAX];
-  __shared__ unsigned long long s_scan[PLAN_THREADS / WAVE][3];
-  __shared__ uint32_t s_fallback, s_max;
-  const uint32_t t = threadIdx.x;
-  const uint32_t nd = distinct[0];
-  if (t == 0) { s_fallback = nd > PLAN_RANK_MAX ? 1u : 0u; s_max = 0; }
-  __syncthreads();
-  // ---- actor ranks: lexicographic order of the id bytes (a proper prefix sorts first) = order of the hex strings (new.js:65) ----
-  if (nd <= PLAN_RANK_MAX) {
-    const unsigned long long* slot_val = (const unsigned long long*)(distinct + 2 + DISTINCT_CAP);
-    for (uint32_t a = t; a < nd; a += PLAN_THREADS) {
-      unsigned long long v = slot_val[a];
-      uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
-      s_len[a] = len;
-      if (len > PLAN_ID_MAX) s_fallback = 1;
-      else {
-        uint8_t bytes[PLAN_ID_MAX];  // (all loads issued before the first use: one memory round trip, not one per byte)
-#pragma unroll
-        for (uint32_t k = 0; k < PLAN_ID_MAX; k++) bytes[k] = k < len ? arena[off + k] : (uint8_t)0;
-#pragma unroll
-        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
-          unsigned long long x = 0;
-#pragma unroll
-          for (uint32_t k = 0; k < 8; k++) x = x << 8 | bytes[wd * 8 + k];
-          s_id[a][wd] = x;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const bool fallback = s_fallback != 0;
-  if (!fallback) {
-    for (uint32_t a = t; a < nd; a += PLAN_THREADS) {
-      uint32_t rank = 0;
-      const uint32_t my_len = s_len[a];
-      unsigned long long mine[PLAN_ID_MAX / 8];
-      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) mine[wd] = s_id[a][wd];
-      for (uint32_t j = 0; j < nd; j++) {
-        bool less = false, decided = false;
-        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8 && !decided; wd++) {
-          unsigned long long x = s_id[j][wd];
-          if (x != mine[wd]) { less = x < mine[wd]; decided = true; }
-        }
-        if (!decided) less = s_len[j] < my_len;  // equal up to the padding: the shorter id first (distinct ids differ somewhere)
-        rank += less ? 1u : 0u;
-      }
-      slot_rank[distinct[1 + a]] = rank;
-    }
-  }
-  __syncthreads();
-  // (words: [0] validity flags of stage 1, [1] fast-path word, [2] actor-table entries -- final, the kernels that raise them ran before)
-  if (fallback) {
-    if (t == 0) {
-      PlanTotals z{};
-      z.fallback = 1; z.flags_a = words[0]; z.fast_a = words[1]; z.total_entries = words[2]; z.n_distinct = nd;
-      signal_host((uint32_t*)&sig->plan, (const uint32_t*)&z, sizeof(PlanTotals) / 4, &sig->plan_seq, seq);
-    }
-    return;
-  }
-  __shared__ uint32_t s_bad, s_unknown;
-  if (t == 0) { s_bad = 0; s_unknown = 0; }
-  uint32_t bad = 0, unknown = 0;
-  __shared__ unsigned long long s_sum[3];  // full-width sums of ops / preds / entries: the packed 32-bit halves must not have wrapped
-  if (t < 3) s_sum[t] = 0;
-  __syncthreads();
-  unsigned long long w_ops = 0, w_preds = 0, w_ent = 0;
-  // ---- prefix sums in input order: PLAN_ITEMS consecutive changes per thread, tile by tile with running carries ----
-  unsigned long long carry_rows = 0;       // ops << 32 | preds   (both < 2^32: the host checks the sums before it uses the plan)
-  unsigned long long carry_ent_small = 0;  // entries | small plans << 32
-  unsigned long long carry_lg_ser = 0;     // large plans | serial plans << 32
-  uint32_t mx = 0;
-  for (uint32_t base = 0; base < n; base += PLAN_THREADS * PLAN_ITEMS) {
-    ChangeBrief br[PLAN_ITEMS];
-    unsigned long long a[PLAN_ITEMS], b[PLAN_ITEMS], cc[PLAN_ITEMS], sa = 0, sb = 0, sc = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PLAN_ITEMS; k++) {
-      const uint32_t i = base + t * PLAN_ITEMS + k;
-      br[k] = ChangeBrief{};
-      if (i < n) br[k] = briefs[i];
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < PLAN_ITEMS; k++) {
-      const bool valid = !(br[k].flags_fits & 0x1fffffffu);  // (a malformed change: the host rejects the batch as soon as it sees the flags)
-      bad |= br[k].flags_fits & 0x1fffffffu;
-      unknown |= br[k].flags_fits & 0x20000000u;
-      const bool has = valid && br[k].n_ops != 0;
-      const bool small = has && (br[k].flags_fits & 0x40000000u), large = has && !small && (br[k].flags_fits & 0x80000000u), serial = has && !small && !large;
-      a[k] = valid ? (unsigned long long)br[k].n_ops << 32 | br[k].n_preds : 0ull;
-      b[k] = (unsigned long long)(valid ? br[k].n_entries : 0u) | (unsigned long long)(small ? 1u : 0u) << 32;
-      cc[k] = (unsigned long long)(large ? 1u : 0u) | (unsigned long long)(serial ? 1u : 0u) << 32;
-      sa += a[k]; sb += b[k]; sc += cc[k];
-      if (valid) { w_ops += br[k].n_ops; w_preds += br[k].n_preds; w_ent += br[k].n_entries; }
-      if (has) { uint32_t last = br[k].start_op + br[k].n_ops - 1; mx = last > mx ? last : mx; }
-    }
-    unsigned long long ex[3], tot[3];
-    plan_scan3(sa, sb, sc, s_scan, ex, tot);
-    unsigned long long rows = carry_rows + ex[0], es = carry_ent_small + ex[1], ls = carry_lg_ser + ex[2];
-#pragma unroll
-    for (uint32_t k = 0; k < PLAN_ITEMS; k++) {
-      const uint32_t i = base + t * PLAN_ITEMS + k;
-      const bool small = (b[k] >> 32) != 0, large = (uint32_t)cc[k] != 0, serial = (cc[k] >> 32) != 0;
-      if (small || large || serial) {
-        // (author_slot is only meaningful once k_actor_intern has run for the change: a capacity retry leaves it unset in the first attempt)
-        ChangePlan pl{i, (uint32_t)(rows >> 32), (uint32_t)rows, (uint32_t)es, br[k].author_slot <= slot_mask ? slot_rank[br[k].author_slot] : 0u, br[k].n_entries};
-        if (small) plans[(uint32_t)(es >> 32)] = pl;
-        else if (large) plans[n - 1 - (uint32_t)ls] = pl;
-        else plans_serial[(uint32_t)(ls >> 32)] = pl;
-      }
-      rows += a[k]; es += b[k]; ls += cc[k];
-    }
-    carry_rows += tot[0]; carry_ent_small += tot[1]; carry_lg_ser += tot[2];
-  }
-  // (workgroup-wide sums / maximum through the scan helper and wave shuffles: 512 lanes adding into one LDS word would run one
-  // after another)
-  {
-    unsigned long long ex3[3], tot3[3];
-    plan_scan3(w_ops, w_preds, w_ent, s_scan, ex3, tot3);
-    if (t == 0) { s_sum[0] = tot3[0]; s_sum[1] = tot3[1]; s_sum[2] = tot3[2]; }
-    for (int d = WAVE / 2; d >= 1; d >>= 1) {
-      uint32_t o = __shfl_xor(mx, d), ob = __shfl_xor(bad, d), ou = __shfl_xor(unknown, d);
-      mx = o > mx ? o : mx;
-      bad |= ob;
-      unknown |= ou;
-    }
-    if ((t & (WAVE - 1)) == 0) {
-      atomicMax(&s_max, mx);
-      if (bad) atomicOr(&s_bad, bad);
-      if (unknown) atomicOr(&s_unknown, 1u);
-    }
-  }
-  __syncthreads();
-  if (t == 0) {
-    PlanTotals z{};
-    z.n_ops = (uint32_t)(carry_rows >> 32); z.n_preds = (uint32_t)carry_rows; z.n_entries = (uint32_t)carry_ent_small;
-    z.n_small = (uint32_t)(carry_ent_small >> 32); z.n_large = (uint32_t)carry_lg_ser; z.n_serial = (uint32_t)(carry_lg_ser >> 32);
-    z.max_op = s_max;
-    z.fallback = (s_sum[0] >= 0x7ffffff0ull || s_sum[1] >= 0xfffffff0ull || s_sum[2] >= 0xfffffff0ull) ? 1u : 0u;
-    z.flags_a = words[0] | s_bad; z.fast_a = words[1]; z.total_entries = words[2]; z.n_distinct = nd;
-    z.reserved[0] = s_unknown;  // some change carries columns this engine does not model (the reference's save keeps them)
-    signal_host((uint32_t*)&sig->plan, (const uint32_t*)&z, sizeof(PlanTotals) / 4, &sig->plan_seq, seq);
-  }
-}
-
-void launch_plan(const uint8_t* arena, const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, uint32_t* slot_rank, uint32_t slot_mask,
-                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, HostSignals* sig, uint32_t seq, hipStream_t st) {
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, st, arena, briefs, n, distinct, slot_rank, slot_mask, plans, plans_serial, words, sig, seq);
+void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, const uint32_t* slot_rank, uint32_t slot_mask, const unsigned long long* block_sums,
+                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st) {
+  uint32_t nb = (n + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL(k_plan_apply, dim3(nb ? nb : 1), dim3(BLOCK), 0, st, briefs, n, slot_rank, slot_mask, block_sums, plans, plans_serial, words, plan_words,
+                     distinct, sig, seq);
 }
 
 uint32_t distinct_capacity() { return DISTINCT_CAP; }
