@@ -8,7 +8,8 @@ if "torch" in sys.argv:
 from automerge_classic_amd import engine, loggen  # noqa: E402
 n = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 6
 quiet = "quiet" in sys.argv
-log = loggen.config("c4_text_single", 1.0, False)
+name = next((a for a in sys.argv[1:] if a.startswith("c")), "c4_text_single")
+log = loggen.config(name, 1.0, False)
 eng = engine.Engine(0)
 eng.load_changes(log)
 print("staged", file=sys.stderr, flush=True)
