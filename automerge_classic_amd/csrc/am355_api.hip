@@ -123,10 +123,10 @@ class HostPool {
   // Wakes the workers ahead of a run(): for the next `us` microseconds they poll for work instead of sleeping on the condition
   // variable (waking 31 sleeping threads costs ~100 us -- longer than copying 13 MB with them). Called at the start of a C-ABI
   // call whose serial preamble gives them time to arrive.
-  void prewake(unsigned us = 300) {
+  void prewake(unsigned n_workers, unsigned us = 300) {
     if (workers_.empty()) return;
     hot_until_.store(now_us() + us, std::memory_order_release);
-    cv_.notify_all();
+    wake(n_workers);
   }
   void run(unsigned k, const std::function<void(unsigned)>& fn) {
     if (k == 0) return;
@@ -138,13 +138,17 @@ class HostPool {
       next_.store(g << 32, std::memory_order_relaxed);  // (generation | next index: a worker that arrives late must not draw an index of a later run)
       gen_.store(g, std::memory_order_release);
     }
-    cv_.notify_all();
+    wake(k - 1);  // (only as many workers as there is work: waking all of them costs more than a short job takes)
     work(fn, k, gen_.load(std::memory_order_relaxed));  // the caller works too
     std::unique_lock<std::mutex> l(m_);
     cv_done_.wait(l, [&]() { return done_ == total_; });
     fn_ = nullptr;
   }
  private:
+  void wake(unsigned n) {
+    if (n >= workers_.size()) cv_.notify_all();
+    else for (unsigned i = 0; i < n; i++) cv_.notify_one();
+  }
   static uint64_t now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   void work(const std::function<void(unsigned)>& fn, unsigned total, uint64_t gen) {
     unsigned mine = 0;
@@ -425,7 +429,8 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   c->staged = c->replayed = c->ir_fetched = false;
   c->is_document = false;
   c->flags = 0;
-  if (n && offsets[n] - offsets[0] >= ((uint64_t)1 << 20)) c->pool->prewake();
+  if (n && offsets[n] - offsets[0] >= ((uint64_t)1 << 20))
+    c->pool->prewake(offsets[1] - offsets[0] > 9 && arena[offsets[0] + 8] == 2 ? c->pool->size() : 4);  // (compressed changes: every thread inflates)
   for (uint32_t i = 0; i < n; i++)
     if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
   if (offsets[n] - offsets[0] >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }

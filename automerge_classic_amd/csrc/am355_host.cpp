@@ -112,10 +112,26 @@ void sha256_digest(const uint8_t* p, size_t len, uint8_t out[32]) {
   for (int k = 0; k < 8; k++) { out[4 * k] = h[k] >> 24; out[4 * k + 1] = h[k] >> 16; out[4 * k + 2] = h[k] >> 8; out[4 * k + 3] = h[k]; }
 }
 
-int inflate_raw(const uint8_t* in, size_t in_len, std::vector<uint8_t>& out, size_t cap) {
+// (one z_stream per host thread, re-armed with inflateReset: inflateInit2 allocates and clears ~40 KB of state, which for a batch of
+// thousands of 3 KB changes cost three times the decoding itself)
+namespace {
+struct ThreadInflater {
   z_stream zs;
-  memset(&zs, 0, sizeof zs);
-  if (inflateInit2(&zs, -15) != Z_OK) return 3;
+  bool live = false;
+  ~ThreadInflater() { if (live) inflateEnd(&zs); }
+  bool arm() {
+    if (live) return inflateReset2(&zs, -15) == Z_OK;
+    memset(&zs, 0, sizeof zs);
+    live = inflateInit2(&zs, -15) == Z_OK;
+    return live;
+  }
+};
+}  // namespace
+
+int inflate_raw(const uint8_t* in, size_t in_len, std::vector<uint8_t>& out, size_t cap) {
+  static thread_local ThreadInflater ti;
+  if (!ti.arm()) return 3;
+  z_stream& zs = ti.zs;
   out.resize(std::min<size_t>(std::max<size_t>(in_len * 4, 1024), cap));
   size_t in_off = 0, produced = 0;
   int result = 1;
@@ -141,7 +157,6 @@ int inflate_raw(const uint8_t* in, size_t in_len, std::vector<uint8_t>& out, siz
     result = rc == Z_MEM_ERROR ? 3 : 1;                     // Z_DATA_ERROR, or Z_BUF_ERROR with the input exhausted = truncated
     break;
   }
-  inflateEnd(&zs);
   out.resize(result == 0 ? produced : 0);
   return result;
 }
