@@ -130,7 +130,8 @@ class HostPool {
   }
   void run(unsigned k, const std::function<void(unsigned)>& fn) {
     if (k == 0) return;
-    if (k == 1 || workers_.empty()) { for (unsigned i = 0; i < k; i++) fn(i); return; }
+    // (without workers: highest index first -- task 0 of the staging jobs waits for the others)
+    if (k == 1 || workers_.empty()) { for (unsigned i = k; i-- > 0;) fn(i); return; }
     {
       std::lock_guard<std::mutex> l(m_);
       fn_ = &fn; total_ = k; done_ = 0;
@@ -567,9 +568,39 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
     });
     for (uint32_t i = 0; i < n; i++) roff[i] = offsets[i] - off0;
   } else {
-    auto phase_b = [&](unsigned k) {
-      Slice& sl = slices[k];
-      (void)hipSetDevice(c->device);
+    // slices (inflated or plain) to their place in the arena in parallel; the H2D copies go out in few large commands: consecutive
+    // slices are grouped to >= 2 MiB and one thread (task 0) enqueues a group as soon as its slices have landed
+    std::vector<uint32_t> group_of(n_slices);
+    std::vector<size_t> group_begin{0};
+    {
+      size_t acc = 0;
+      for (unsigned k = 0; k < n_slices; k++) {
+        group_of[k] = (uint32_t)group_begin.size() - 1;
+        acc += slices[k].out_bytes;
+        if (acc >= ((size_t)2 << 20) && k + 1 < n_slices) { group_begin.push_back(slices[k + 1].base); acc = 0; }
+      }
+      group_begin.push_back(total);
+    }
+    const size_t n_groups = group_begin.size() - 1;
+    std::vector<std::atomic<uint32_t>> left(n_groups);
+    for (auto& x : left) x.store(0);
+    for (unsigned k = 0; k < n_slices; k++) left[group_of[k]].fetch_add(1);
+    h2d.assign(n_groups, hipSuccess);
+    c->pool->run(n_slices + 1, [&](unsigned task) {
+      if (task == 0) {
+        (void)hipSetDevice(c->device);
+        for (size_t g = 0; g < n_groups; g++) {
+          while (left[g].load(std::memory_order_acquire) != 0) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+          }
+          size_t gb = group_begin[g], ge = group_begin[g + 1];
+          if (ge > gb) h2d[g] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
+        }
+        return;
+      }
+      Slice& sl = slices[task - 1];
       if (sl.any_deflated) {
         if (sl.out_bytes) memcpy(raw + sl.base, sl.tmp.data(), sl.out_bytes);
         size_t o = sl.base;
@@ -578,9 +609,8 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
         if (sl.out_bytes) memcpy(raw + sl.base, arena + offsets[sl.c0], sl.out_bytes);
         for (uint32_t i = sl.c0; i < sl.c1; i++) roff[i] = sl.base + (offsets[i] - offsets[sl.c0]);
       }
-      if (sl.out_bytes) h2d[k] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + sl.base, raw + sl.base, sl.out_bytes, hipMemcpyHostToDevice, c->stream);
-    };
-    c->pool->run(n_slices, phase_b);
+      left[group_of[task - 1]].fetch_sub(1, std::memory_order_acq_rel);
+    });
   }
   lap("gathered, H2D enqueued");
   for (hipError_t e : h2d)
