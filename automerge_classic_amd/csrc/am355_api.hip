@@ -244,7 +244,8 @@ struct am355_ctx {
   BigColDesc doc_cols{};
   bool doc_serial = false;           // AM355_DOC_SERIAL=1: lane-serial column decoders (first version, kept for cross-checks)
   // stage-1 side tables (device) and their pinned host mirrors
-  DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1, d_plan_sums;
+  DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1, d_plan_sums, d_dep_idx, d_self_idx;
+  HostBuf h_dep_idx, h_self_idx;   // general scheduler: dependency / duplicate indexes resolved on the device
   HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_s1;
   DevBuf d_s1;                 // stage-1 results read by the host: flag words | distinct actor ids | one ChangeBrief per change
   ChangeBrief* hp_briefs = nullptr;
@@ -384,9 +385,9 @@ extern "C" void am355_destroy(am355_ctx* c) {
   (void)hipStreamSynchronize(c->stream2);
   (void)hipStreamSynchronize(c->stream3);
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
-                    &c->d_words, &c->d_slot_rank, &c->d_scan1, &c->d_plan_sums})
+                    &c->d_words, &c->d_slot_rank, &c->d_scan1, &c->d_plan_sums, &c->d_dep_idx, &c->d_self_idx})
     b->release();
-  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1}) b->release();
+  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1, &c->h_dep_idx, &c->h_self_idx}) b->release();
   c->d_s1.release();
   for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1})
     if (e) (void)hipEventDestroy(e);
@@ -992,45 +993,42 @@ static int schedule(am355_ctx* c) {
 
   auto T2 = std::chrono::steady_clock::now();
   // ---- causal scheduling (new.js:1550-1597 inside the retry loop of :1822-1841) ----
-  HashSet known, heads;
-  known.init(n);
-  heads.init(n);
+  // The device has resolved every hash to an index (k_deps_resolve): self[ci] = first change of the batch with ci's hash (ci itself
+  // unless it is a duplicate), dep(ci, k) = first change with that dependency's hash or NONE32. "hash known" is then applied[index],
+  // and the retry loop of the reference runs on integers.
+  const uint32_t* self = c->h_self_idx.as<uint32_t>();
+  const uint32_t* dep_idx = c->h_dep_idx.as<uint32_t>();
+  std::vector<uint8_t> applied_flag(n, 0), is_head(n, 0);
   std::vector<uint64_t> clock(na, 0);
   std::vector<uint8_t> has_clock(na, 0), actor_read(na, 0);
   c->clock_actor.clear();
-  std::vector<uint32_t> queue(n), next_q, applied_all, head_list;
+  std::vector<uint32_t> queue(n), next_q, applied_all;
   for (uint32_t i = 0; i < n; i++) queue[i] = i;
   uint32_t sched_flags = 0;
   while (!queue.empty()) {
     std::vector<uint32_t> applied;
     next_q.clear();
-    // Memo: a dependency block byte-identical to the one of the previously accepted change is ready again
-    // (the known set only grows) and its hashes have already been taken off the heads.
-    const uint8_t* last_deps = nullptr;
-    uint32_t last_n_deps = 0;
     for (uint32_t ci : queue) {
       const ChangeMeta& m = metas[ci];
-      const uint8_t* my_hash = hashes + 32 * (size_t)ci;
-      if (known.has(my_hash)) continue;  // duplicate (new.js:1557)
+      uint32_t first = self[ci] < n ? self[ci] : ci;
+      if (applied_flag[first]) continue;  // duplicate of an applied change (new.js:1557)
       uint32_t author = rank[local_ids[local_off[ci]]];
       uint64_t expected = clock[author] + 1;
-      const uint8_t* deps = raw + m.base + m.deps_off;
-      bool same_as_last = last_deps && m.n_deps == last_n_deps && memcmp(deps, last_deps, (size_t)32 * m.n_deps) == 0;
+      const uint32_t* deps = dep_idx + ((m.base + m.deps_off) >> 5);
       bool ready = true;
-      if (!same_as_last)
-        for (uint32_t k = 0; k < m.n_deps && ready; k++)
-          if (!known.has(deps + 32 * k)) ready = false;
+      for (uint32_t k = 0; k < m.n_deps && ready; k++) {
+        uint32_t d = dep_idx[(m.base + m.deps_off + 32ull * k) >> 5];
+        if (d >= n || !applied_flag[d]) ready = false;
+      }
+      (void)deps;
       if (!ready) { next_q.push_back(ci); continue; }
       if (m.seq != expected) { sched_flags |= AM355_F_BAD_SEQ; break; }
       if (!has_clock[author]) { has_clock[author] = 1; c->clock_actor.push_back(author); }
       clock[author] = m.seq;
-      known.add(my_hash);
-      if (!same_as_last)
-        for (uint32_t k = 0; k < m.n_deps; k++) heads.del(deps + 32 * k);
-      heads.add(my_hash);
-      head_list.push_back(ci);
-      last_deps = deps;
-      last_n_deps = m.n_deps;
+      applied_flag[first] = 1;
+      applied_flag[ci] = 1;
+      for (uint32_t k = 0; k < m.n_deps; k++) is_head[dep_idx[(m.base + m.deps_off + 32ull * k) >> 5]] = 0;
+      is_head[ci] = 1;
       applied.push_back(ci);
     }
     if (sched_flags) break;
@@ -1054,8 +1052,8 @@ static int schedule(am355_ctx* c) {
   for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
   {
     std::vector<const uint8_t*> hs;
-    for (uint32_t ci : head_list)
-      if (heads.has(hashes + 32 * (size_t)ci)) hs.push_back(hashes + 32 * (size_t)ci);
+    for (uint32_t ci : applied_all)
+      if (is_head[ci]) hs.push_back(hashes + 32 * (size_t)ci);
     std::sort(hs.begin(), hs.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
     c->heads.resize(hs.size() * 32);
     for (size_t i = 0; i < hs.size(); i++) memcpy(&c->heads[32 * i], hs[i], 32);
@@ -1609,7 +1607,8 @@ static int replay_impl(am355_ctx* c) {
       !c->d_hash_tab.ensure(4 * (size_t)(c->hash_mask + 1)) || !c->d_min_idx.ensure(4 * n1) || !c->d_has_dep.ensure(n1) || !c->d_words.ensure(4 * W_NUM) ||
       !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
       !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_plans.ensure(2 * sizeof(ChangePlan) * n1) ||
-      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_plan_sums.ensure(plan_block_sums_bytes(n)))
+      !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_plan_sums.ensure(plan_block_sums_bytes(n)) ||
+      !c->d_dep_idx.ensure(4 * (c->raw.size() / 32 + 2)) || !c->d_self_idx.ensure(4 * n1))
     return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
   c->have_host_metas = false;
   // what the host reads after stage 1 -- a few flag words, the distinct actor ids, one brief per change -- sits in one device
@@ -1672,7 +1671,7 @@ static int replay_impl(am355_ctx* c) {
       launch_hash_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_hashes.as<uint8_t>(), c->d_min_idx.as<uint32_t>(),
                       c->d_hash_tab.as<uint32_t>(), c->hash_mask, d_words + W_FLAGS_B, sb);
       launch_deps_resolve(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_hashes.as<uint8_t>(), n, c->d_hash_tab.as<uint32_t>(), c->hash_mask,
-                      c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, sb);
+                      c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, c->d_dep_idx.as<uint32_t>(), c->d_self_idx.as<uint32_t>(), sb);
       HIPCHK(c, hipMemcpyAsync(c->h_hashes.p, c->d_hashes.p, 32 * (size_t)n, hipMemcpyDeviceToHost, sb));
       HIPCHK(c, hipMemcpyAsync(c->h_has_dep.p, c->d_has_dep.p, n, hipMemcpyDeviceToHost, sb));
       HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
@@ -1754,7 +1753,11 @@ static int replay_impl(am355_ctx* c) {
   } else {
     // general path: exact scheduling on the host, then decode/merge of exactly the applied changes
     c->flags = 0;
+    size_t dep_words = c->raw.size() / 32 + 2;
+    if (!c->h_dep_idx.ensure(4 * dep_words) || !c->h_self_idx.ensure(4 * n1)) return fail(c, AM355_E_NOMEM, "host allocation failed");
     HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, sa));
+    HIPCHK(c, hipMemcpyAsync(c->h_dep_idx.p, c->d_dep_idx.p, 4 * dep_words, hipMemcpyDeviceToHost, sa));  // (stream B has been joined)
+    HIPCHK(c, hipMemcpyAsync(c->h_self_idx.p, c->d_self_idx.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sa));
     HIPCHK(c, hipStreamSynchronize(sa));
     auto t0 = std::chrono::steady_clock::now();
     rc = schedule(c);

@@ -7,7 +7,9 @@ void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
                          uint32_t tab_mask, uint32_t* flags, hipStream_t st);
 void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,
-                         const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st);
+                         const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, uint32_t* dep_idx, uint32_t* self_idx, hipStream_t st);
+// (dep_idx[(arena offset of a dependency hash) / 32] = index of the first change of the batch with that hash, NONE32 if none;
+//  self_idx[c] = first change with c's own hash: what the host's general scheduler works on instead of hash lookups)
 // distinct: [0] count of claimed actor-table slots, [1..] their indexes (capacity distinct_capacity()); briefs: per-change digest for the host.
 // k_actor_check also starts the device half of the in-order plan: per-workgroup sums of ops / preds / actor entries / plans per decoder
 // class (block_sums, plan_block_sums_bytes(n) bytes), lexicographic ranks of the distinct actor ids (slot_rank[slot]) and plan_words

@@ -478,16 +478,23 @@ __device__ __forceinline__ uint32_t hash_find(const uint8_t* __restrict__ hashes
 __global__ __launch_bounds__(WAVE) void k_deps_resolve(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                        const uint8_t* __restrict__ hashes, uint32_t n, const uint32_t* __restrict__ tab, uint32_t mask,
                                                        const uint32_t* __restrict__ min_idx, uint8_t* __restrict__ has_dependent,
-                                                       uint32_t* __restrict__ fast_flags) {
+                                                       uint32_t* __restrict__ fast_flags, uint32_t* __restrict__ dep_idx, uint32_t* __restrict__ self_idx) {
   uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n) return;
   const ChangeMeta* m = &metas[c];
   if (m->flags) return;
   uint32_t ff = 0;
-  if (lane == 0 && hash_find(hashes, tab, mask, min_idx, hashes + 32 * (size_t)c) != c) ff |= FF_DUP_HASH;
+  if (lane == 0) {
+    uint32_t first = hash_find(hashes, tab, mask, min_idx, hashes + 32 * (size_t)c);  // first change of the batch with this hash
+    if (first != c) ff |= FF_DUP_HASH;
+    self_idx[c] = first;
+  }
   const uint8_t* deps = arena + m->base + m->deps_off;
   for (uint32_t k = lane; k < m->n_deps; k += WAVE) {
     uint32_t d = hash_find(hashes, tab, mask, min_idx, deps + 32 * (size_t)k);
+    // for the host's general scheduler: dependency -> index of the change it names (NONE32: not in the batch), addressed by the
+    // dependency's place in the arena (32-byte hashes never overlap, so byte offset / 32 is a unique slot)
+    dep_idx[(m->base + m->deps_off + 32 * (uint64_t)k) >> 5] = d;
     if (d == NONE32) ff |= FF_MISSING_DEP;
     else {
       if (d >= c) ff |= FF_LATE_DEP;
@@ -1675,9 +1682,10 @@ void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t
 }
 
 void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,
-                         const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, hipStream_t st) {
+                         const uint32_t* min_idx, uint8_t* has_dependent, uint32_t* fast_flags, uint32_t* dep_idx, uint32_t* self_idx, hipStream_t st) {
   if (!n) return;
-  AM355_LAUNCH_INDEPENDENT(k_deps_resolve, dim3(n), dim3(WAVE), st, arena, metas, hashes, n, hash_tab, tab_mask, min_idx, has_dependent, fast_flags);
+  AM355_LAUNCH_INDEPENDENT(k_deps_resolve, dim3(n), dim3(WAVE), st, arena, metas, hashes, n, hash_tab, tab_mask, min_idx, has_dependent, fast_flags, dep_idx,
+                           self_idx);
 }
 
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,

@@ -132,6 +132,10 @@ int inflate_raw(const uint8_t* in, size_t in_len, std::vector<uint8_t>& out, siz
   static thread_local ThreadInflater ti;
   if (!ti.arm()) return 3;
   z_stream& zs = ti.zs;
+  zs.next_in = nullptr;  // (inflateReset keeps the caller's buffer fields: a previous stream may have ended with input left over)
+  zs.avail_in = 0;
+  zs.next_out = nullptr;
+  zs.avail_out = 0;
   out.resize(std::min<size_t>(std::max<size_t>(in_len * 4, 1024), cap));
   size_t in_off = 0, produced = 0;
   int result = 1;
