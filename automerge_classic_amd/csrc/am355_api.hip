@@ -245,7 +245,7 @@ struct am355_ctx {
   bool doc_serial = false;           // AM355_DOC_SERIAL=1: lane-serial column decoders (first version, kept for cross-checks)
   // stage-1 side tables (device) and their pinned host mirrors
   DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1, d_plan_sums, d_dep_idx, d_self_idx;
-  HostBuf h_dep_idx, h_self_idx;   // general scheduler: dependency / duplicate indexes resolved on the device
+  HostBuf h_dep_idx, h_self_idx, h_amap, h_amap_base;   // general scheduler: dependency / duplicate indexes and actor tables resolved on the device
   HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_s1;
   DevBuf d_s1;                 // stage-1 results read by the host: flag words | distinct actor ids | one ChangeBrief per change
   ChangeBrief* hp_briefs = nullptr;
@@ -387,7 +387,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
                     &c->d_words, &c->d_slot_rank, &c->d_scan1, &c->d_plan_sums, &c->d_dep_idx, &c->d_self_idx})
     b->release();
-  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1, &c->h_dep_idx, &c->h_self_idx}) b->release();
+  for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1, &c->h_dep_idx, &c->h_self_idx, &c->h_amap, &c->h_amap_base}) b->release();
   c->d_s1.release();
   for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1})
     if (e) (void)hipEventDestroy(e);
@@ -924,7 +924,9 @@ struct HashSet {
 
 // General scheduler: exact restatement of the reference's retry loop for any delivery order, duplicates and
 // missing dependencies. Used when the device-side checks cannot prove the in-order fast path.
-static int schedule(am355_ctx* c) {
+static uint32_t rank_device_actors(am355_ctx* c, std::vector<uint32_t>& slot_rank);
+// dev_amap / dev_amap_base: host copies of the device's actor tables (slot numbers) or null
+static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_amap_base) {
   auto T0 = std::chrono::steady_clock::now();
   const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
   const uint8_t* hashes = c->h_hashes.as<uint8_t>();
@@ -937,12 +939,22 @@ static int schedule(am355_ctx* c) {
     return fail(c, (dev_flags & (F_OVERFLOW | F_UNSUPPORTED)) ? AM355_E_UNSUPPORTED : AM355_E_INVALID, "malformed change (flags 0x%x)", dev_flags);
   }
   // ---- actor ids: global table ranked lexicographically (hex-string order == byte order, new.js:65) ----
-  // Changes of one author nearly always carry the same "other actors" table, so each author's last table is
+  // dev_amap != null: the device has interned every actor-table entry (k_actor_intern): per change its entries are slot numbers at
+  // dev_amap[dev_amap_base[i] ..], the distinct ids are ranked from the device's list. Otherwise (more distinct actors than that list
+  // holds) the host interns: changes of one author nearly always carry the same "other actors" table, so each author's last table is
   // memoised (bytes compared), which turns O(changes x actors) string interning into O(changes) memcmp.
+  std::vector<uint32_t> local_off_v, local_ids_v, rank;
+  const uint32_t *local_off, *local_ids;
+  uint32_t na;
+  if (dev_amap) {
+    na = rank_device_actors(c, rank);
+    local_off = dev_amap_base;
+    local_ids = dev_amap;
+  } else {
   std::unordered_map<std::string, uint32_t> actor_ix;
   std::vector<std::string> names;
-  std::vector<uint32_t> local_off(n + 1, 0), local_ids;
-  local_ids.reserve((size_t)n * 2);
+  local_off_v.assign(n + 1, 0);
+  local_ids_v.reserve((size_t)n * 2);
   struct Memo { const uint8_t* p = nullptr; uint32_t len = 0, n_other = 0, first = 0; };
   std::vector<Memo> memo;
   auto intern = [&](const uint8_t* b, size_t len) {
@@ -959,19 +971,19 @@ static int schedule(am355_ctx* c) {
     const ChangeMeta& m = metas[i];
     const uint8_t* p = raw + m.base;
     uint32_t author = intern(p + m.actor_off, m.actor_len);
-    local_ids.push_back(author);
+    local_ids_v.push_back(author);
     // bytes of the other-actors table: from others_off up to the column directory; its exact end is found by parsing
     Memo& mm = memo[author];
     size_t off = m.others_off;
     if (mm.p && mm.n_other == m.n_other && m.others_off + mm.len <= m.len && memcmp(mm.p, p + m.others_off, mm.len) == 0) {
-      for (uint32_t k = 0; k < m.n_other; k++) local_ids.push_back(local_ids[mm.first + k]);
+      for (uint32_t k = 0; k < m.n_other; k++) local_ids_v.push_back(local_ids_v[mm.first + k]);
     } else {
-      uint32_t first = (uint32_t)local_ids.size();
+      uint32_t first = (uint32_t)local_ids_v.size();
       for (uint32_t k = 0; k < m.n_other; k++) {
         uint64_t l;
         read_uleb_host(p, m.len, off, l);
         uint32_t id = intern(p + off, (size_t)l);
-        local_ids.push_back(id);
+        local_ids_v.push_back(id);
         off += (size_t)l;
       }
       Memo& m2 = memo[author];  // (memo may have grown)
@@ -980,16 +992,20 @@ static int schedule(am355_ctx* c) {
       m2.n_other = m.n_other;
       m2.first = first;
     }
-    local_off[i + 1] = (uint32_t)local_ids.size();
+    local_off_v[i + 1] = (uint32_t)local_ids_v.size();
   }
-  auto T1 = std::chrono::steady_clock::now();
-  uint32_t na = (uint32_t)names.size();
-  std::vector<uint32_t> by_rank(na), rank(na);
+  na = (uint32_t)names.size();
+  std::vector<uint32_t> by_rank(na);
+  rank.assign(na, 0);
   for (uint32_t i = 0; i < na; i++) by_rank[i] = i;
   std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t x, uint32_t y) { return names[x] < names[y]; });  // std::string compares bytes as unsigned char
   for (uint32_t r = 0; r < na; r++) rank[by_rank[r]] = r;
   c->actors.resize(na);
   for (uint32_t r = 0; r < na; r++) c->actors[r] = names[by_rank[r]];
+  local_off = local_off_v.data();
+  local_ids = local_ids_v.data();
+  }
+  auto T1 = std::chrono::steady_clock::now();
 
   auto T2 = std::chrono::steady_clock::now();
   // ---- causal scheduling (new.js:1550-1597 inside the retry loop of :1822-1841) ----
@@ -1063,7 +1079,7 @@ static int schedule(am355_ctx* c) {
   // ---- launch plan for the decode kernels, op-id -> row tables ----
   c->plans.clear();
   c->amap.clear();
-  c->amap.reserve(local_ids.size());
+  c->amap.reserve(local_off[n]);
   uint64_t ops = 0, preds = 0, max_op = 0;
   std::vector<std::vector<ActorSpan>> per_actor(na);
   c->applied_change.clear();
@@ -1142,16 +1158,13 @@ static int error_for_flags(am355_ctx* c, uint32_t f, const char* what) {
   return fail(c, hard ? AM355_E_INVALID : AM355_E_UNSUPPORTED, "%s (flags 0x%x)", what, f);
 }
 
-// Host half of the in-order fast path: O(changes + actors log actors), no allocation in steady state. Everything that
-// needs the change hashes (dependency resolution, heads) has been checked on the device and is confirmed when stream
-// B is joined.
-static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
-  const ChangeBrief* br = c->hp_briefs;
+// distinct actor ids as interned by the device (k_actor_intern) -> lexicographic ranks (hex-string order == byte order, new.js:65):
+// fills slot_rank[slot] and c->actors (by rank). Returns the number of actors.
+static uint32_t rank_device_actors(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
   const uint32_t* distinct = c->hp_distinct;
   const unsigned long long* slots = (const unsigned long long*)(distinct + 2 + distinct_capacity());  // ((offset + 1) << 16) | length
   const uint8_t* raw = c->raw.data();
-  uint32_t n = c->n_changes, n_slots = c->slot_mask + 1;
-  // distinct actor ids -> lexicographic ranks (hex-string order == byte order, new.js:65)
+  uint32_t n_slots = c->slot_mask + 1;
   struct Ent { uint32_t slot, off, len; };
   static thread_local std::vector<Ent> ents;
   ents.clear();
@@ -1172,6 +1185,16 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
     slot_rank[ents[r].slot] = r;
     c->actors[r].assign((const char*)raw + ents[r].off, ents[r].len);
   }
+  return na;
+}
+
+// Host half of the in-order fast path: O(changes + actors log actors), no allocation in steady state. Everything that
+// needs the change hashes (dependency resolution, heads) has been checked on the device and is confirmed when stream
+// B is joined.
+static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
+  const ChangeBrief* br = c->hp_briefs;
+  uint32_t n = c->n_changes;
+  uint32_t na = rank_device_actors(c, slot_rank);
   static thread_local std::vector<uint64_t> clock;
   static thread_local std::vector<uint32_t> span_cnt;
   clock.assign(na, 0);
@@ -1758,9 +1781,18 @@ static int replay_impl(am355_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, sa));
     HIPCHK(c, hipMemcpyAsync(c->h_dep_idx.p, c->d_dep_idx.p, 4 * dep_words, hipMemcpyDeviceToHost, sa));  // (stream B has been joined)
     HIPCHK(c, hipMemcpyAsync(c->h_self_idx.p, c->d_self_idx.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sa));
+    // the device's actor tables, when its list of distinct ids holds them all (else the host interns)
+    const bool dev_actors = tot.n_distinct <= distinct_capacity() && !(tot.fast_a & FF_CAPACITY) && tot.total_entries <= c->amap_cap;
+    if (dev_actors) {
+      if (!c->h_amap.ensure(4 * ((size_t)tot.total_entries + 1)) || !c->h_amap_base.ensure(4 * (n1 + 1))) return fail(c, AM355_E_NOMEM, "host allocation failed");
+      HIPCHK(c, hipMemcpyAsync(c->h_amap.p, c->d_amap_prov.p, 4 * (size_t)tot.total_entries, hipMemcpyDeviceToHost, sa));
+      HIPCHK(c, hipMemcpyAsync(c->h_amap_base.p, c->d_amap_base.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sa));
+    }
     HIPCHK(c, hipStreamSynchronize(sa));
+    if (dev_actors) c->h_amap_base.as<uint32_t>()[n] = tot.total_entries;
+    HIPCHK(c, hipEventSynchronize(c->ev_s1));  // (the distinct-actor list rides with the digests)
     auto t0 = std::chrono::steady_clock::now();
-    rc = schedule(c);
+    rc = schedule(c, dev_actors ? c->h_amap.as<uint32_t>() : nullptr, dev_actors ? c->h_amap_base.as<uint32_t>() : nullptr);
     ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc) return rc;
     rc = run_device(c, nullptr);
