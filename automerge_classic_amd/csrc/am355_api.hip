@@ -1014,56 +1014,98 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
   // and the retry loop of the reference runs on integers.
   const uint32_t* self = c->h_self_idx.as<uint32_t>();
   const uint32_t* dep_idx = c->h_dep_idx.as<uint32_t>();
-  std::vector<uint8_t> applied_flag(n, 0), is_head(n, 0);
+  std::vector<uint8_t> is_head(n, 0);
   std::vector<uint64_t> clock(na, 0);
   std::vector<uint8_t> has_clock(na, 0), actor_read(na, 0);
   c->clock_actor.clear();
-  std::vector<uint32_t> queue(n), next_q, applied_all;
-  for (uint32_t i = 0; i < n; i++) queue[i] = i;
-  uint32_t sched_flags = 0;
-  while (!queue.empty()) {
-    std::vector<uint32_t> applied;
-    next_q.clear();
-    for (uint32_t ci : queue) {
-      const ChangeMeta& m = metas[ci];
-      uint32_t first = self[ci] < n ? self[ci] : ci;
-      if (applied_flag[first]) continue;  // duplicate of an applied change (new.js:1557)
-      uint32_t author = rank[local_ids[local_off[ci]]];
-      uint64_t expected = clock[author] + 1;
-      const uint32_t* deps = dep_idx + ((m.base + m.deps_off) >> 5);
-      bool ready = true;
-      for (uint32_t k = 0; k < m.n_deps && ready; k++) {
-        uint32_t d = dep_idx[(m.base + m.deps_off + 32ull * k) >> 5];
-        if (d >= n || !applied_flag[d]) ready = false;
+  // The retry loop applies, pass after pass, every queued change whose dependencies were applied earlier -- in an earlier pass or
+  // earlier in the same pass (the queue keeps its order). So the pass a change is applied in is
+  //     pass(c) = max over its dependencies d of  pass(d) + (d sits after c in the queue ? 1 : 0)        (0 without dependencies),
+  // infinite if a dependency is not in the batch or is itself never applied; the application order is (pass, position). Later copies
+  // of a change are dropped once the first copy is applied. One memoised walk over the dependency edges instead of one scan of the
+  // queue per pass (64 synced rounds delivered in random order need dozens of passes).
+  std::vector<uint32_t> applied_all;
+  uint32_t sched_flags = 0, n_pending = 0;
+  {
+    constexpr uint32_t UNSET = 0xffffffffu, NEVER = 0xfffffffeu, BUSY = 0xfffffffdu;
+    std::vector<uint32_t> pass(n, UNSET), stack;
+    auto dep_of = [&](uint32_t ci, uint32_t k) { const ChangeMeta& m = metas[ci]; return dep_idx[(m.base + m.deps_off + 32ull * k) >> 5]; };
+    for (uint32_t root = 0; root < n; root++) {
+      if (pass[root] != UNSET) continue;
+      stack.push_back(root);
+      while (!stack.empty()) {
+        uint32_t ci = stack.back();
+        if (pass[ci] != UNSET && pass[ci] != BUSY) { stack.pop_back(); continue; }
+        uint32_t first = self[ci] < n ? self[ci] : ci;
+        if (first != ci) { pass[ci] = NEVER; stack.pop_back(); continue; }  // a later copy: never applied itself
+        const uint32_t nd = metas[ci].n_deps;
+        bool pushed = false;
+        uint32_t p = 0;
+        for (uint32_t k = 0; k < nd; k++) {
+          uint32_t d = dep_of(ci, k);
+          if (d >= n) { p = NEVER; break; }
+          if (pass[d] == UNSET) { if (!pushed) pass[ci] = BUSY; stack.push_back(d); pushed = true; continue; }
+          if (pass[d] == BUSY) { p = NEVER; break; }  // (a dependency cycle would need a hash collision: never applied)
+          if (pass[d] == NEVER) { p = NEVER; break; }
+          uint32_t q = pass[d] + (d > ci ? 1u : 0u);
+          p = q > p ? q : p;
+        }
+        if (p == NEVER) { pass[ci] = NEVER; stack.pop_back(); continue; }
+        if (pushed) continue;  // come back when the dependencies are known
+        pass[ci] = p;
+        stack.pop_back();
       }
-      (void)deps;
-      if (!ready) { next_q.push_back(ci); continue; }
-      if (m.seq != expected) { sched_flags |= AM355_F_BAD_SEQ; break; }
+    }
+    // application order: by (pass, position) -- a counting sort over the passes
+    uint32_t max_pass = 0;
+    for (uint32_t ci = 0; ci < n; ci++)
+      if (pass[ci] < BUSY && pass[ci] > max_pass) max_pass = pass[ci];
+    std::vector<uint32_t> start(max_pass + 2, 0);
+    for (uint32_t ci = 0; ci < n; ci++)
+      if (pass[ci] < BUSY) start[pass[ci] + 1]++;
+    for (uint32_t p = 0; p <= max_pass; p++) start[p + 1] += start[p];
+    applied_all.resize(start[max_pass + 1]);
+    for (uint32_t ci = 0; ci < n; ci++)
+      if (pass[ci] < BUSY) applied_all[start[pass[ci]]++] = ci;
+    // what stays queued: changes never applied whose first copy is never applied either
+    for (uint32_t ci = 0; ci < n; ci++) {
+      uint32_t first = self[ci] < n ? self[ci] : ci;
+      if (pass[first] >= BUSY) n_pending++;
+    }
+    // sequence numbers, clock, heads and the actor rule in application order (new.js:1571-1578, 1582-1583, 1442-1449)
+    for (uint32_t ci : applied_all) {
+      const ChangeMeta& m = metas[ci];
+      uint32_t author = rank[local_ids[local_off[ci]]];
+      if (m.seq != clock[author] + 1) { sched_flags |= AM355_F_BAD_SEQ; break; }
       if (!has_clock[author]) { has_clock[author] = 1; c->clock_actor.push_back(author); }
       clock[author] = m.seq;
-      applied_flag[first] = 1;
-      applied_flag[ci] = 1;
-      for (uint32_t k = 0; k < m.n_deps; k++) is_head[dep_idx[(m.base + m.deps_off + 32ull * k) >> 5]] = 0;
+      for (uint32_t k = 0; k < m.n_deps; k++) is_head[dep_of(ci, k)] = 0;
       is_head[ci] = 1;
-      applied.push_back(ci);
     }
-    if (sched_flags) break;
-    // changes are read in applied order; each may only mention actors already in the document (new.js:1442-1449)
-    for (uint32_t ci : applied) {
-      actor_read[rank[local_ids[local_off[ci]]]] = 1;
-      for (uint32_t k = local_off[ci]; k < local_off[ci + 1]; k++)
-        if (!actor_read[rank[local_ids[k]]]) sched_flags |= AM355_F_UNKNOWN_ACTOR;
-      applied_all.push_back(ci);
+    // each change may only mention actors already in the document when it is read: the reference reads the changes of a pass
+    // after the whole pass has been scheduled
+    if (!sched_flags) {
+      size_t i = 0;
+      while (i < applied_all.size()) {
+        size_t j = i;
+        uint32_t p = pass[applied_all[i]];
+        while (j < applied_all.size() && pass[applied_all[j]] == p) j++;
+        for (size_t t = i; t < j; t++) {
+          uint32_t ci = applied_all[t];
+          actor_read[rank[local_ids[local_off[ci]]]] = 1;
+          for (uint32_t k = local_off[ci]; k < local_off[ci + 1]; k++)
+            if (!actor_read[rank[local_ids[k]]]) sched_flags |= AM355_F_UNKNOWN_ACTOR;
+        }
+        i = j;
+      }
     }
-    queue.swap(next_q);
-    if (applied.empty()) break;
   }
   if (sched_flags) {
     c->flags |= sched_flags;
     return fail(c, AM355_E_INVALID, "change schedule rejected (flags 0x%x)", sched_flags);
   }
   c->n_applied = (uint32_t)applied_all.size();
-  c->n_pending = (uint32_t)queue.size();
+  c->n_pending = n_pending;
   c->clock_seq.clear();
   for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
   {
