@@ -15,6 +15,7 @@
 #include "am355_prims.h"
 #include "am355_render.h"
 #include "am355_host.h"
+#include "am355_history.h"
 
 #include <zlib.h>
 
@@ -259,6 +260,8 @@ struct am355_ctx {
   std::vector<uint32_t> applied_change, applied_op_base;  // applied changes in application order (plans get regrouped by decoder class)
   std::vector<uint8_t> doc_bytes;                          // the loaded document as given (Backend.save of an unchanged document returns it)
   std::vector<uint8_t> saved;                              // result of am355_save
+  HistoryOutput history;                                   // result of am355_doc_changes
+  bool history_ok = false; uint32_t history_flags = 0;
   std::vector<std::pair<uint32_t, std::vector<uint8_t>>> doc_chg_cols;  // loaded document: change-metadata columns, inflated
   std::vector<uint8_t> doc_tail;                           // loaded document: headsIndexes + extraBytes
   bool doc_other_ops_cols = false;                         // loaded document has non-empty op columns outside the modelled set
@@ -670,6 +673,7 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   if (!c || !doc) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
   c->staged = c->replayed = c->ir_fetched = false;
+  c->history_ok = false;
   c->is_document = true;
   c->flags = 0;
   auto bad0 = [&](uint32_t flag, const char* msg) { c->flags |= flag; return fail(c, AM355_E_INVALID, "%s", msg); };
@@ -2547,10 +2551,75 @@ static int import_fragments_impl(am355_ctx* c, const uint8_t* frags, const uint6
 }
 
 // ---- C ABI entry points of the calls that allocate with the input size ----
+// ---------------------------------------------------------------------------------------------------------
+// history of a loaded document (am355_history.cpp does the host work; the rows come from the device decode)
+// ---------------------------------------------------------------------------------------------------------
+static int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const uint64_t** offsets, uint32_t* n_changes, const uint8_t** hashes) {
+  if (!c || !arena || !offsets || !n_changes || !hashes) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
+  if (!c->replayed || !c->is_document) return fail(c, AM355_E_STATE, "am355_load_document and am355_replay must be called first");
+  (void)hipSetDevice(c->device);
+  if (!(c->history_ok && c->history_flags == (flags & 1))) {
+    if (c->doc_other_ops_cols) return fail(c, AM355_E_UNSUPPORTED, "document has op columns this engine does not model (child / link / unknown): history comes from the JS path");
+    const bool trace = getenv("AM355_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!trace) return;
+      auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "am355_doc_changes: %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+      t0 = now;
+    };
+    const uint32_t N = (uint32_t)c->n_ops, P = (uint32_t)c->n_preds;
+    const size_t n4 = ((size_t)N * 4 + 255) & ~(size_t)255, p4 = ((size_t)P * 4 + 255) & ~(size_t)255, n1 = ((size_t)N + 255) & ~(size_t)255;
+    if (!c->h_rows.ensure(13 * n4 + n1 + 2 * p4 + 256)) return fail(c, AM355_E_NOMEM, "host allocation failed (rows)");
+    uint8_t* h = c->h_rows.as<uint8_t>();
+    const OpCols& d = c->cols;
+    const uint32_t* src[13] = {d.obj_actor, d.obj_ctr, d.key_actor, d.key_ctr, d.key_off, d.key_len, d.action, d.val_tl, d.val_off, d.pred_first, d.pred_num, d.id_ctr, d.id_actor};
+    const uint32_t* dst[13];
+    for (int k = 0; k < 13; k++) {
+      dst[k] = (const uint32_t*)(h + (size_t)k * n4);
+      if (N) HIPCHK(c, hipMemcpyAsync(h + (size_t)k * n4, src[k], (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    uint8_t* h_insert = h + 13 * n4;
+    uint32_t* h_sa = (uint32_t*)(h_insert + n1);
+    uint32_t* h_sc = (uint32_t*)(h_insert + n1 + p4);
+    if (N) HIPCHK(c, hipMemcpyAsync(h_insert, d.insert, N, hipMemcpyDeviceToHost, c->stream));
+    if (P) {
+      HIPCHK(c, hipMemcpyAsync(h_sa, d.pred_actor, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(h_sc, d.pred_ctr, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap("rows to host");
+    HistoryInput in;
+    in.n_rows = N; in.n_succ = P;
+    in.obj_actor = dst[0]; in.obj_ctr = dst[1]; in.key_actor = dst[2]; in.key_ctr = dst[3]; in.key_off = dst[4]; in.key_len = dst[5];
+    in.action = dst[6]; in.val_tl = dst[7]; in.val_off = dst[8]; in.succ_first = dst[9]; in.succ_num = dst[10]; in.id_ctr = dst[11]; in.id_actor = dst[12];
+    in.insert = h_insert; in.succ_actor = h_sa; in.succ_ctr = h_sc;
+    in.arena = c->raw.data(); in.arena_len = c->raw.size();
+    in.actors = &c->actors;
+    in.change_columns = &c->doc_chg_cols;
+    in.doc_actor_rank = &c->doc_actor_rank;
+    in.heads = c->heads.data(); in.n_heads = (uint32_t)(c->heads.size() / 32);
+    std::string err;
+    c->history = HistoryOutput{};
+    int rc = reconstruct_history(in, (flags & 1) != 0, [&](unsigned k, const std::function<void(unsigned)>& fn) { c->pool->run(k, fn); }, c->history, err);
+    lap("regroup + encode + hash");
+    if (rc == HISTORY_INVALID) return fail(c, AM355_E_INVALID, "%s", err.c_str());
+    if (rc) return fail(c, AM355_E_UNSUPPORTED, "%s", err.c_str());
+    c->history_ok = true;
+    c->history_flags = flags & 1;
+  }
+  *arena = c->history.arena.data();
+  *offsets = c->history.offsets.data();
+  *n_changes = (uint32_t)(c->history.offsets.size() - 1);
+  *hashes = c->history.hashes.data();
+  return AM355_OK;
+}
+
 extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) { return guarded(c, [&]() { return load_changes_impl(c, arena, offsets, n); }); }
 extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len) { return guarded(c, [&]() { return load_document_impl(c, doc, len); }); }
 extern "C" int am355_replay(am355_ctx* c) { return guarded(c, [&]() { return replay_impl(c); }); }
 extern "C" int am355_fetch_ir(am355_ctx* c, am355_patch_ir* out) { return guarded(c, [&]() { return fetch_ir_impl(c, out); }); }
 extern "C" int am355_patch_json(am355_ctx* c, const char** json, size_t* len) { return guarded(c, [&]() { return patch_json_impl(c, json, len); }); }
 extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, size_t* out_len) { return guarded(c, [&]() { return save_impl(c, flags, out_bytes, out_len); }); }
+extern "C" int am355_doc_changes(am355_ctx* c, uint32_t flags, const uint8_t** arena, const uint64_t** offsets, uint32_t* n, const uint8_t** hashes) { return guarded(c, [&]() { return doc_changes_impl(c, flags, arena, offsets, n, hashes); }); }
 extern "C" int am355_import_fragments(am355_ctx* c, const uint8_t* frags, const uint64_t* offsets, uint32_t world) { return guarded(c, [&]() { return import_fragments_impl(c, frags, offsets, world); }); }

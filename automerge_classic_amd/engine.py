@@ -85,9 +85,10 @@ def _bind(path):
     L.am355_export_fragment.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
     L.am355_import_fragments.argtypes = [vp, vp, vp, u32]
     L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
+    L.am355_doc_changes.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_void_p)]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
-              "am355_import_fragments"):
+              "am355_import_fragments", "am355_doc_changes"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -208,6 +209,17 @@ class Engine:
         size = int(offs[-1])
         arena = np.ctypeslib.as_array(ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)), shape=(size,)).copy() if size else np.zeros(0, dtype=np.uint8)
         return arena, offs
+
+    def doc_changes(self, deflate=True):
+        """History of a loaded document: (arena, offsets, hashes) = the binary changes Backend.getAllChanges(Backend.load(doc)) returns,
+        back to back in document order, and their 32-byte hashes (reference new.js:1887-1912, columnar.js:876-981). Copies."""
+        a, o, n, h = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32(), ctypes.c_void_p()
+        self._check(self._L.am355_doc_changes(self._h, 1 if deflate else 0, ctypes.byref(a), ctypes.byref(o), ctypes.byref(n), ctypes.byref(h)))
+        offs = np.ctypeslib.as_array(ctypes.cast(o, ctypes.POINTER(ctypes.c_uint64)), shape=(n.value + 1,)).copy()
+        size = int(offs[-1])
+        arena = np.ctypeslib.as_array(ctypes.cast(a, ctypes.POINTER(ctypes.c_uint8)), shape=(size,)).copy() if size else np.zeros(0, dtype=np.uint8)
+        hashes = np.ctypeslib.as_array(ctypes.cast(h, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value, 32)).copy() if n.value else np.zeros((0, 32), dtype=np.uint8)
+        return arena, offs, hashes
 
     def hashes(self):
         out = np.zeros((self._n_changes, 32), dtype=np.uint8)

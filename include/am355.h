@@ -116,6 +116,19 @@ int am355_get_applied(const am355_ctx *ctx, uint32_t *out, uint32_t *n_applied);
  * *bytes is owned by ctx and valid until the next am355_save / am355_destroy. */
 int am355_save(am355_ctx *ctx, uint32_t flags, const uint8_t **bytes, size_t *len);
 
+/* History of a loaded document (reference: backend/new.js:1887-1912 BackendDoc.computeHashGraph ->
+ * backend/columnar.js:1040-1047 decodeDocument, :876-943 groupChangeOps, :945-981 decodeDocumentChanges, :710-739 encodeChange):
+ * the binary changes the document was made of, in document order -- what Backend.getAllChanges(Backend.load(bytes)) returns --
+ * and their 32-byte hashes.  The op columns come from the GPU decode of am355_replay; regrouping rows into changes
+ * (`del` ops rebuilt from succ lists, preds = inverse of succ), re-encoding each change and chaining the hashes runs on the
+ * engine's host threads.  flags bit 0: DEFLATE changes of >= 256 bytes as encodeChange does (columnar.js:738).
+ * Valid after am355_load_document + am355_replay.  AM355_E_INVALID when the document's heads do not match the rebuilt hash graph
+ * or its rows / change metadata contradict each other (the reference throws); AM355_E_UNSUPPORTED for documents holding what this
+ * path does not rebuild byte for byte (child / link columns, byte-array or unknown-typed values, non-minimal numbers, columns
+ * outside the modelled set): the JS path serves those.  Pointers are owned by ctx and valid until the next load / destroy. */
+int am355_doc_changes(am355_ctx *ctx, uint32_t flags, const uint8_t **arena, const uint64_t **offsets, uint32_t *n_changes,
+                      const uint8_t **hashes);
+
 /* Raw (uncompressed) arena as staged by am355_load_changes: pointers valid until the next load. */
 int am355_get_raw(const am355_ctx *ctx, const uint8_t **arena, const uint64_t **offsets, uint32_t *n_changes);
 

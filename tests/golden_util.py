@@ -15,13 +15,33 @@ def _all_names():
 
 def fixture_names():
     """Fixtures holding binary changes and the reference's loadChanges + getPatch result."""
-    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n != "save_generated"]
+    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n not in ("save_generated", "doc_history")]
 
 
 def save_digest_cases():
     """Length + SHA-256 of the block-size-patched reference's Backend.save on deterministic generated logs (oracle/make_save_golden.py)."""
     with open(os.path.join(GOLDEN_DIR, "save_generated.json")) as f:
         return json.load(f)["cases"]
+
+
+def history_golden():
+    """Backend.getAllChanges(Backend.load(doc)) of the unmodified reference per document (oracle/make_history_golden.py): digests, or
+    the error it throws."""
+    with open(os.path.join(GOLDEN_DIR, "doc_history.json")) as f:
+        return json.load(f)
+
+
+def history_digests(arena, offsets, hashes):
+    """The two digests of doc_history.json over an engine result (arena, offsets, hashes)."""
+    import hashlib
+    import struct
+    a = bytes(bytearray(arena))
+    h = hashlib.sha256()
+    for i in range(len(offsets) - 1):
+        lo, hi = int(offsets[i]), int(offsets[i + 1])
+        h.update(struct.pack("<I", hi - lo))
+        h.update(a[lo:hi])
+    return h.hexdigest(), hashlib.sha256(bytes(bytearray(hashes))).hexdigest()
 
 
 def doc_fixture_names():
