@@ -262,6 +262,7 @@ struct am355_ctx {
   std::vector<uint8_t> saved;                              // result of am355_save
   HistoryOutput history;                                   // result of am355_doc_changes
   bool history_ok = false; uint32_t history_flags = 0;
+  std::vector<uint32_t> doc_col_rows;                      // loaded document: values per op column (BigCol order), parallel decode only
   std::vector<std::pair<uint32_t, std::vector<uint8_t>>> doc_chg_cols;  // loaded document: change-metadata columns, inflated
   std::vector<uint8_t> doc_tail;                           // loaded document: headsIndexes + extraBytes
   bool doc_other_ops_cols = false;                         // loaded document has non-empty op columns outside the modelled set
@@ -769,7 +770,15 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     if (rd == 3) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "document column inflates beyond the 4 GiB limit"); }
     if (rd == 4) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
   }
-  // (headsIndexes and extraBytes follow; neither influences the patch: kept for am355_save)
+  // (headsIndexes and extraBytes follow; neither influences the patch: kept for am355_save. The reference reads one index per
+  // head when anything follows the columns, columnar.js:1032-1034)
+  if (ho < hl) {
+    size_t to = ho;
+    for (uint64_t i = 0; i < nh; i++) {
+      uint64_t ix;
+      if (!read_uleb_host(h, hl, to, ix) || ix >= (1ull << 53)) return bad(AM355_F_BAD_LEB, "bad head index after the columns");
+    }
+  }
   c->doc_tail.assign(h + ho, h + hl);
   c->doc_chg_cols.clear();
   for (Col& col : ccols) c->doc_chg_cols.emplace_back((uint32_t)col.id, std::vector<uint8_t>(col.p, col.p + col.n));
@@ -803,6 +812,7 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
       if (!seen[a]) { seen[a] = 1; c->clock_actor.push_back((uint32_t)a); }  // document actor index for now, ranks below
       clock[a] = seq;
       n_changes++;
+      if (n_changes > (1u << 26)) return fail(c, AM355_E_UNSUPPORTED, "more than 2^26 changes in one document");  // (a run length can claim any count)
     }
     c->n_changes = n_changes;
     c->clock_seq.clear();
@@ -1533,6 +1543,7 @@ static int replay_document(am355_ctx* c) {
   if (!c->d_plans.ensure(sizeof(ChangePlan)) || !c->d_amap.ensure(4 * (size_t)std::max(NA, 1u)) || !c->d_words.ensure(4 * W_NUM) || !c->h_words.ensure(4 * W_NUM))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
   HIPCHK(c, hipEventRecord(c->ev[0], st));
+  c->doc_col_rows.clear();
   if (c->doc_serial) {
     // first version: two lanes count rows / succ entries, then one lane per column group decodes value by value
     HIPCHK(c, hipMemcpyAsync(c->d_metas.p, &c->doc_meta, sizeof(ChangeMeta), hipMemcpyHostToDevice, st));
@@ -1594,6 +1605,7 @@ static int replay_document(am355_ctx* c) {
     lap("token index done");
     if (hi->flags) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, hi->flags, "malformed document columns"); }
     BigColInfo info = *hi;
+    c->doc_col_rows.assign(info.rows, info.rows + BIG_NCOL);
     uint32_t N = info.rows[BC_ACTION], Pcap = info.rows[BC_SUCC_ACTOR];
     if (N >= 0x7ffffff0u) { (void)hipStreamSynchronize(c->stream2); c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 rows in one document"); }
     if (!c->d_bigvals.ensure(bigcol_vals_bytes(N, Pcap))) { (void)hipStreamSynchronize(c->stream2); return fail(c, AM355_E_NOMEM, "device allocation failed (document columns)"); }
@@ -2560,6 +2572,7 @@ static int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena,
   (void)hipSetDevice(c->device);
   if (!(c->history_ok && c->history_flags == (flags & 1))) {
     if (c->doc_other_ops_cols) return fail(c, AM355_E_UNSUPPORTED, "document has op columns this engine does not model (child / link / unknown): history comes from the JS path");
+    if (c->doc_col_rows.size() != BIG_NCOL) return fail(c, AM355_E_UNSUPPORTED, "history needs the parallel column decode (AM355_DOC_SERIAL is set)");
     const bool trace = getenv("AM355_TRACE") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -2599,6 +2612,17 @@ static int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena,
     in.change_columns = &c->doc_chg_cols;
     in.doc_actor_rank = &c->doc_actor_rank;
     in.heads = c->heads.data(); in.n_heads = (uint32_t)(c->heads.size() / 32);
+    {
+      // the reference reads rows until EVERY column is exhausted (columnar.js:577-590 decodeColumns): a column holding more values
+      // than the action column makes extra, empty rows there. The per-row columns must hold N values or none.
+      static const int per_row[] = {BC_OBJ_ACTOR, BC_OBJ_CTR, BC_KEY_ACTOR, BC_KEY_CTR, BC_ID_ACTOR, BC_ID_CTR, BC_INSERT, BC_ACTION, BC_VAL_LEN, BC_SUCC_NUM};
+      for (int k : per_row)
+        if (c->doc_col_rows[k] != N && c->doc_col_rows[k] != 0) return fail(c, AM355_E_UNSUPPORTED, "op columns of unequal length: the JS path decides");
+      if (c->doc_col_rows[BC_SUCC_ACTOR] != P || c->doc_col_rows[BC_SUCC_CTR] != P) return fail(c, AM355_E_UNSUPPORTED, "succ columns do not match succNum: the JS path decides");
+      in.key_column = c->raw.data() + c->doc_meta.col_off[C_KEY_STR];
+      in.key_column_len = c->doc_meta.col_len[C_KEY_STR];
+      in.val_raw_len = c->doc_meta.col_len[C_VAL_RAW];
+    }
     std::string err;
     c->history = HistoryOutput{};
     int rc = reconstruct_history(in, (flags & 1) != 0, [&](unsigned k, const std::function<void(unsigned)>& fn) { c->pool->run(k, fn); }, c->history, err);

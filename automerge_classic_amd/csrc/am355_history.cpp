@@ -86,6 +86,21 @@ struct RleReader {
     v = (int64_t)u;
     return true;
   }
+  // consumes one run without materialising its values; adds its length to n
+  bool skip_run(uint64_t& n) {
+    int64_t c;
+    if (!r.sleb(c)) return false;
+    int64_t v;
+    std::string s;
+    if (c > 1) { if (!raw(v, s)) return false; n += (uint64_t)c; }
+    else if (c == 1) return false;
+    else if (c < 0) {
+      if (c == INT64_MIN) return false;
+      for (int64_t i = 0; i < -c; i++) if (!raw(v, s)) return false;
+      n += (uint64_t)-c;
+    } else { uint64_t z; if (!r.uleb(z) || z == 0) return false; n += z; }
+    return true;
+  }
   // a column that has run out yields nulls (encoding.js:639-642)
   bool next(bool& is_null, int64_t& v, std::string& s) {
     if (done()) { is_null = true; return true; }
@@ -185,6 +200,21 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
   const std::vector<std::string>& actors = *in.actors;
   const uint32_t NA = (uint32_t)actors.size(), N = in.n_rows, P = in.n_succ;
 
+  // the reference reads rows until every column is exhausted (columnar.js:577-590): the key column must hold N values or none,
+  // and the value bytes must be consumed exactly (a longer valRaw column makes extra rows there too)
+  {
+    RleReader keys(nullptr, 2);
+    keys.r.p = in.key_column; keys.r.len = in.key_column_len;
+    uint64_t n_keys = 0;
+    while (!keys.done()) {
+      if (!keys.skip_run(n_keys)) return bad(HISTORY_INVALID, "malformed key column");
+      if (n_keys > (uint64_t)N) break;
+    }
+    if (n_keys != 0 && n_keys != N) return bad(HISTORY_UNSUPPORTED, "key column and action column differ in length: the JS path decides");
+    uint64_t val_bytes = 0;
+    for (uint32_t r = 0; r < N; r++) val_bytes += in.val_tl[r] >> 4;
+    if (val_bytes != in.val_raw_len) return bad(HISTORY_UNSUPPORTED, "value bytes do not cover the valRaw column: the JS path decides");
+  }
   // ---- 1. change metadata ----
   std::vector<ChangeRec> chg;
   std::vector<uint32_t> dep_index;

@@ -31,6 +31,9 @@ struct HistoryInput {
   // change metadata columns of the document, inflated: (column id, bytes); actor indexes in them are DOCUMENT actor indexes
   const std::vector<std::pair<uint32_t, std::vector<uint8_t>>>* change_columns = nullptr;
   const std::vector<uint32_t>* doc_actor_rank = nullptr;  // document actor index -> rank
+  const uint8_t* key_column = nullptr;  // the keyStr column as stored (its value count must equal n_rows, or be zero)
+  size_t key_column_len = 0;
+  size_t val_raw_len = 0;               // length of the valRaw column (the values of the rows must cover it exactly)
   const uint8_t* heads = nullptr;  // the document's heads, 32 bytes each, sorted
   uint32_t n_heads = 0;
 };

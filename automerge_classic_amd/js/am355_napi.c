@@ -303,6 +303,42 @@ static napi_value js_fetch_ir(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* docChanges(ctx, flags) -> { changes: Uint8Array[], hashes: Uint8Array }: am355_doc_changes -- the history of a loaded document
+ * (Backend.getAllChanges(Backend.load(bytes)), new.js:1887-1927). The changes are views into ONE JS-owned ArrayBuffer (the
+ * reference's change buffers are views too: encoding.js Encoder.buffer), hashes holds 32 bytes per change. */
+static napi_value js_doc_changes(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t flags = 1;
+  if (argc > 1) napi_get_value_uint32(env, argv[1], &flags);
+  const uint8_t *arena = NULL, *hashes = NULL;
+  const uint64_t *offsets = NULL;
+  uint32_t n = 0;
+  int rc = am355_doc_changes(ctx, flags, &arena, &offsets, &n, &hashes);
+  if (rc) return throw_engine(env, ctx, rc);
+  size_t total = (size_t)offsets[n];
+  void *data = NULL;
+  napi_value ab, list, out, hab, hta;
+  NAPI_CALL(env, napi_create_arraybuffer(env, total, &data, &ab));
+  if (total) memcpy(data, arena, total);
+  NAPI_CALL(env, napi_create_array_with_length(env, n, &list));
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value ta;
+    NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, (size_t)(offsets[i + 1] - offsets[i]), ab, (size_t)offsets[i], &ta));
+    NAPI_CALL(env, napi_set_element(env, list, i, ta));
+  }
+  hab = copy_to_arraybuffer(env, hashes, 32 * (size_t)n);
+  if (!hab) return NULL;
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, 32 * (size_t)n, hab, 0, &hta));
+  NAPI_CALL(env, napi_create_object(env, &out));
+  NAPI_CALL(env, napi_set_named_property(env, out, "changes", list));
+  NAPI_CALL(env, napi_set_named_property(env, out, "hashes", hta));
+  return out;
+}
+
 static napi_value js_stats(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -334,6 +370,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"appliedOrder", NULL, js_applied_order, NULL, NULL, NULL, napi_enumerable, NULL},
       {"hashes", NULL, js_hashes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"stats", NULL, js_stats, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"docChanges", NULL, js_doc_changes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"fetchIR", NULL, js_fetch_ir, NULL, NULL, NULL, napi_enumerable, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);

@@ -83,7 +83,7 @@ function contextOf(gen) {
   if (e) { e.used = ++tick; ctx = e.ctx }
   return e || null
 }
-const counters = { gpuLoadChanges: 0, gpuLoad: 0, gpuSave: 0, saveReplays: 0, fallbackToJs: 0, hydrations: 0 }   // (diagnostics: which path served the calls)
+const counters = { gpuLoadChanges: 0, gpuLoad: 0, gpuSave: 0, gpuHistory: 0, saveReplays: 0, fallbackToJs: 0, hydrations: 0 }   // (diagnostics: which path served the calls)
 
 function isFrozenCheck(backend) {
   // reference util.js:1-10
@@ -199,7 +199,9 @@ function load(data) {
       addon.replay(ctx)
       const patch = gpuPatch()
       counters.gpuLoad++
-      return { state: new GpuState(null, patch, patch.deps, data), heads: patch.deps }
+      const state = new GpuState(null, patch, patch.deps, data)
+      state.generation = generation
+      return { state, heads: patch.deps }
     } catch (e) {
       if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
       counters.fallbackToJs++
@@ -233,7 +235,32 @@ function save(backend) {
 // go to the reference path.)
 function gpuHistory(backend) {
   const g = backend.state
-  return !JS_ONLY && g instanceof GpuState && g.changes && g.applied && g.pending === 0 ? g : null
+  if (JS_ONLY || !(g instanceof GpuState)) return null
+  if (g.doc && !g.changes && !g.noHistory) loadedHistory(g)
+  return g.changes && g.applied && g.pending === 0 ? g : null
+}
+// History of a LOADED document (new.js:1887-1912 computeHashGraph, columnar.js:876-981): the engine rebuilds the binary changes
+// and their hashes from the rows it decoded (am355_doc_changes) -- once, on the first history query, as the reference defers it.
+// Documents it does not rebuild (or whose heads do not match) go to the reference path, which serves them or throws its error.
+function loadedHistory(g) {
+  try {
+    if (!contextOf(g.generation)) {
+      acquireContext()
+      addon.loadDocument(ctx, g.doc)
+      addon.replay(ctx)
+      g.generation = generation
+    }
+    const h = addon.docChanges(ctx, 1)
+    g.changes = h.changes
+    g.hashes = h.hashes
+    g.applied = Uint32Array.from(h.changes, (_, i) => i)
+    g.pending = 0
+    counters.gpuHistory++
+  } catch (e) {
+    if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
+    g.noHistory = true
+    counters.fallbackToJs++
+  }
 }
 function hashIndex(g) {
   if (!g.byHash) {

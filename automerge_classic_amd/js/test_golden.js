@@ -8,6 +8,25 @@ const Backend = require('./index.js')
 
 const dir = process.argv[2] || path.join(__dirname, '..', '..', 'tests', 'golden')
 let failed = 0, n = 0
+const crypto = require('crypto')
+const historyGolden = JSON.parse(fs.readFileSync(path.join(dir, 'doc_history.json'), 'utf8')).fixtures
+
+// Backend.getAllChanges(Backend.load(doc)) against the unmodified reference's result (digests, oracle/make_history_golden.py);
+// documents on which the reference throws are left to the reference path, which is not present on the GPU box
+function checkHistory(f, loaded) {
+  const want = historyGolden[f.replace(/\.json$/, '')]
+  if (!want || want.error) return
+  n++
+  const before = Backend._counters.gpuHistory
+  const all = Backend.getAllChanges(loaded)
+  const sum = crypto.createHash('sha256')
+  for (const c of all) { const len = Buffer.alloc(4); len.writeUInt32LE(c.byteLength); sum.update(len); sum.update(c) }
+  let ok = all.length === want.n_changes && sum.digest('hex') === want.changes_sha256 && Backend._counters.gpuHistory === before + 1
+  for (const h of want.heads) ok = ok && Backend.getChangeByHash(loaded, h) !== undefined
+  ok = ok && Backend.getMissingDeps(loaded, want.heads.concat(['00'.repeat(32)])).length === 1
+  ok = ok && Backend.getChanges(loaded, []).length === want.n_changes
+  if (!ok) { failed++; console.error(`FAIL ${f}: history of the loaded document`) } else console.log(`ok   ${f}  (history of the loaded document, ${all.length} changes)`)
+}
 for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
   const fx = JSON.parse(fs.readFileSync(path.join(dir, f), 'utf8'))
   if (!fx.changes && !fx.doc) continue   // not a patch fixture (e.g. digests of generated workloads)
@@ -54,6 +73,7 @@ for (const f of fs.readdirSync(dir).filter(f => f.endsWith('.json')).sort()) {
     const loaded = Backend.load(new Uint8Array(Buffer.from(fx.doc, 'base64')))
     n++
     if (JSON.stringify(Backend.getPatch(loaded)) !== want) { failed++; console.error(`FAIL ${f}: document load`) } else console.log(`ok   ${f}  (document load)`)
+    checkHistory(f, loaded)
   }
 }
 console.log(`${n - failed}/${n} golden fixtures reproduced through the JS Backend surface; engine: ${JSON.stringify(Backend._engineStats())}`)

@@ -2089,7 +2089,11 @@ amo_doc *amo_load_document(const uint8_t *buf, size_t len, char *errbuf, size_t 
     uint64_t ncc, noc, *clens, *olens;
     if ((rc = read_doc_columns(&d->pool, &h, &ccols, &ncc, &clens, &e)) || (rc = read_doc_columns(&d->pool, &h, &ocols, &noc, &olens, &e))) break;
     if ((rc = load_doc_column_data(&d->pool, &h, ccols, ncc, clens, &e)) || (rc = load_doc_column_data(&d->pool, &h, ocols, noc, olens, &e))) break;
-    /* headsIndexes and extraBytes follow; neither influences the patch */
+    /* headsIndexes and extraBytes follow (columnar.js:1032-1036); neither influences the patch, but the head indexes are read */
+    if (h.off < h.len) {
+      for (uint64_t i = 0; i < nh && !rc; i++) { uint64_t ix; rc = read_u53(&h, &ix, &e); }
+      if (rc) break;
+    }
 
     /* ---- readDocumentChanges (new.js:1645-1675): clock in first-appearance order, seq continuity ---- */
     {

@@ -32,6 +32,17 @@ assert.strictEqual(f.after, true)
 assert.ok(Number.isNaN(f.n) && f.inf === Infinity, 'non-finite float64 values survive the GPU load path')
 assert.deepStrictEqual(Object.assign({}, f.bytes), { 0: 1, 1: 2, 2: 255 })   // (the frontend stores a Uint8Array as a map object)
 
+// history of a loaded document, rebuilt by the engine (am355_doc_changes): the reference's own bytes, change by change
+{
+  const mine = Automerge.getAllChanges(Automerge.load(bytesB))
+  Automerge.setDefaultBackend(RefBackend)
+  const theirs = Automerge.getAllChanges(Automerge.load(bytesB))
+  Automerge.setDefaultBackend(Backend)
+  assert.strictEqual(mine.length, theirs.length)
+  for (let i = 0; i < mine.length; i++) assert.ok(Buffer.from(mine[i]).equals(Buffer.from(theirs[i])), `change ${i} of the rebuilt history`)
+  assert.ok(Backend._counters.gpuHistory - before.gpuHistory >= 2, 'history of loaded documents must be served by the engine')
+}
+
 // merge of two loaded documents (getChangesAdded on both, applyChanges on one)
 let g1 = Automerge.load(bytesA), g2 = Automerge.load(bytesB)
 const merged = Automerge.merge(g1, g2)
