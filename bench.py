@@ -369,6 +369,21 @@ def main():
         if args.workload != "c5_doc_mixed":
             subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 3, 1, barrier))
         out["workloads"] = subs
+        if save_info is not None:
+            # the history of the saved headline document after Backend.load (binary changes + hashes rebuilt:
+            # op columns decoded on the GPU, regroup / re-encode / hash chain on the host threads); not part of `value`
+            eng.load_document(saved)
+            eng.replay()
+            t0 = time.perf_counter()
+            _, h_off, _ = eng.doc_changes(deflate=False)
+            ms_plain = (time.perf_counter() - t0) * 1e3
+            eng.load_document(saved)
+            eng.replay()
+            t0 = time.perf_counter()
+            eng.doc_changes(deflate=True)
+            ms_deflate = (time.perf_counter() - t0) * 1e3
+            out["history_after_load"] = {"n_changes": int(len(h_off) - 1), "change_bytes": int(h_off[-1]), "ms": ms_plain, "ms_with_deflate": ms_deflate,
+                                         "ops_per_s": st.n_ops / (ms_plain * 1e-3)}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

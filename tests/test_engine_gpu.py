@@ -283,6 +283,67 @@ def test_full_size_save_round_trip(eng, workload):
     assert eng.save(reencode=True) == doc
 
 
+@pytest.mark.parametrize("name", sorted(golden_util.history_golden()["fixtures"]))
+def test_history_of_a_loaded_document_matches_the_reference(eng, name):
+    """Backend.getAllChanges(Backend.load(doc)) against the unmodified reference: binary changes and hashes byte for
+    byte; where the reference throws, the engine refuses (the JS path then raises the reference's error)."""
+    want = golden_util.history_golden()["fixtures"][name]
+    fx = golden_util.load_fixture(name)
+    eng.load_document(fx["doc_bytes"])
+    eng.replay()
+    if "error" in want:
+        with pytest.raises((engine.InvalidChanges, engine.UnsupportedChanges)):
+            eng.doc_changes()
+        return
+    arena, offsets, hashes = eng.doc_changes()
+    assert len(offsets) - 1 == want["n_changes"] and int(offsets[-1]) == want["bytes"]
+    assert golden_util.history_digests(arena, offsets, hashes) == (want["changes_sha256"], want["hashes_sha256"])
+    assert eng.patch_json() == fx["expected_load"]
+
+
+@pytest.mark.parametrize("case", golden_util.history_golden()["generated"], ids=lambda c: "%s-%s-%s" % (c["workload"], c["scale"], c["deflate"]))
+def test_history_after_save_and_load_of_generated_logs(eng, case):
+    log = loggen.config(case["workload"], case["scale"], case["deflate"])
+    eng.load_changes(log)
+    eng.replay()
+    in_hashes = eng.hashes()[eng.applied()]
+    doc = eng.save()
+    eng.load_document(doc)
+    eng.replay()
+    arena, offsets, hashes = eng.doc_changes()
+    assert golden_util.history_digests(arena, offsets, hashes) == (case["changes_sha256"], case["hashes_sha256"])
+    assert (hashes == in_hashes).all()
+
+
+@pytest.mark.parametrize("workload", ["c2_text_typing", "c3_map_lww", "c4_text_multi"])
+def test_full_size_history_round_trip(eng, workload):
+    """Full-size logs: replay -> save -> load -> history gives back the very containers that went in (uncompressed form, byte for
+    byte, in application order) with their hashes; replaying that history saves to the same document."""
+    import time
+    log = loggen.config(workload, 1.0, False)
+    eng.load_changes(log)
+    eng.replay()
+    order = eng.applied()
+    in_hashes = eng.hashes()[order]
+    doc = eng.save()
+    eng.load_document(doc)
+    eng.replay()
+    t0 = time.perf_counter()
+    arena, offsets, hashes = eng.doc_changes(deflate=False)
+    dt = time.perf_counter() - t0
+    print(f"\n{workload}: history of {len(offsets) - 1} changes / {log.n_ops} ops rebuilt in {dt * 1e3:.1f} ms")
+    assert (hashes == in_hashes).all()
+    la, lo = np.asarray(log.arena), np.asarray(log.offsets)
+    if (order == np.arange(len(order))).all():
+        assert int(offsets[-1]) == int(lo[-1]) and (arena == la[:int(lo[-1])]).all()
+    else:
+        assert bytes(arena) == b"".join(bytes(la[int(lo[i]):int(lo[i + 1])]) for i in order)
+    again = loggen.ChangeLog.from_changes([bytes(arena[int(offsets[i]):int(offsets[i + 1])]) for i in range(len(offsets) - 1)], name="history")
+    eng.load_changes(again)
+    eng.replay()
+    assert eng.save() == doc
+
+
 def test_empty_and_tiny_inputs(eng):
     """No changes at all; one change with a single op: patch against the oracle, save against the reference's bytes."""
     empty = loggen.ChangeLog.from_changes([])
