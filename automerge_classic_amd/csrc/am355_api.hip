@@ -233,6 +233,7 @@ struct am355_ctx {
   uint32_t n_changes = 0;
   bool staged = false, replayed = false, ir_fetched = false;
   bool has_unknown_cols = false;     // some change carries columns outside the modelled set (kept by the reference's save)
+  bool staging_in_flight = false;    // am355_load_changes returned with its H2D copies still running on `stream`
   bool is_document = false;          // staged input is one saved document (am355_load_document) rather than changes
   ChangeMeta doc_meta{};             // column layout of the staged document inside `raw`
   std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
@@ -432,6 +433,7 @@ constexpr size_t INFLATE_CAP = 0xfff00000ull;  // one staged batch / document is
 static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
+  if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
   c->staged = c->replayed = c->ir_fetched = false;
   c->is_document = false;
   c->flags = 0;
@@ -534,41 +536,58 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   for (const Slice& sl : slices) any_deflated = any_deflated || sl.any_deflated;
   const char* gather_env = getenv("AM355_GATHER_UNIT");  // (tests: bytes per copy unit, lowered to run the grouped gather on small inputs)
   if (!any_deflated && (total >= ((size_t)4 << 20) || (gather_env && total > 0))) {
-    // Plain changes: the arena is one contiguous copy of the input. Every H2D command costs tens of microseconds whatever its
-    // size, and one thread copies only ~15 GB/s, so: the host threads copy 256 KiB units, and whoever finishes the last unit of a
-    // ~4 MiB group enqueues that group's H2D copy -- few DMA commands, the first one a few tens of microseconds after the start.
-    // (measured on the EPYC 9575F host: ONE thread copies 16 MiB into pinned memory in 0.27 ms, eight threads in 0.23 ms -- the
-    // copy is bound by the memory system, not by cores -- and a 16 MiB H2D copy takes 0.30 ms. So: four copier threads, 1 MiB
-    // units handed out in order, one H2D command per 2 MiB group enqueued by the calling thread as soon as the group is complete.)
-    const size_t unit = gather_env && atol(gather_env) > 0 ? (size_t)atol(gather_env) : (size_t)1 << 20;
+    // Plain changes: the arena is one contiguous copy of the input, pageable -> pinned by host threads, pinned -> HBM by the DMA
+    // engine, pipelined. Measured on the EPYC 9575F host (tools/micro/pinned_memcpy.cpp, profiles/r02_ab_staging_*): one thread
+    // copies 16 MiB into pinned memory in 0.27 ms, one 16 MiB H2D command takes 0.30 ms (56 GB/s: the link), every H2D command
+    // costs ~10 us whatever its size, and a sleeping pool thread needs ~0.1 ms to start working. So: the CALLING thread starts
+    // copying at once and is the one that enqueues; units of 256 KiB are drawn from a shared counter by the caller and four pool
+    // threads (a thread's FIRST unit runs at a fraction of the later rate: cold source lines); the first DMA command goes out
+    // after one unit, every following one covers twice as much, up to 8 MiB -- few commands, none waiting for its bytes.
+    const size_t unit = gather_env && atol(gather_env) > 0 ? (size_t)atol(gather_env) : (size_t)256 << 10;
     const size_t n_units = (total + unit - 1) / unit;
-    const size_t units_per_group = 2;
-    const size_t n_groups = (n_units + units_per_group - 1) / units_per_group;
+    std::vector<uint32_t> group_of(n_units);
+    std::vector<size_t> group_first;  // first unit of each group (+ end)
+    for (size_t u = 0, span = 1; u < n_units; span = std::min<size_t>(span * 2, 64)) {
+      group_first.push_back(u);
+      for (size_t k = 0; k < span && u < n_units; k++, u++) group_of[u] = (uint32_t)group_first.size() - 1;
+    }
+    const size_t n_groups = group_first.size();
+    group_first.push_back(n_units);
     std::vector<std::atomic<uint32_t>> left(n_groups);
-    for (size_t g = 0; g < n_groups; g++) left[g].store((uint32_t)std::min(units_per_group, n_units - g * units_per_group));
+    for (size_t g = 0; g < n_groups; g++) left[g].store((uint32_t)(group_first[g + 1] - group_first[g]));
     h2d.assign(n_groups, hipSuccess);
     const uint8_t* src = arena + offsets[0];
     const uint64_t off0 = offsets[0];
-    const unsigned n_copiers = (unsigned)std::min<size_t>(4, std::max<size_t>(1, std::min<size_t>(n_units, c->pool->size())));
-    c->pool->run(n_copiers + 1, [&](unsigned task) {
-      if (task == 0) {  // the issuer (normally the calling thread: it draws the first index)
-        (void)hipSetDevice(c->device);
-        for (size_t g = 0; g < n_groups; g++) {
-          while (left[g].load(std::memory_order_acquire) != 0) {
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-          }
-          size_t gb = g * units_per_group * unit, ge = std::min(total, gb + units_per_group * unit);
-          h2d[g] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
-          if (trace) fprintf(stderr, "load_changes:   group %zu enqueued      +%8.3f ms\n", g, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    std::atomic<size_t> next_unit{0};
+    const unsigned n_helpers = (unsigned)std::min<size_t>(4, std::min<size_t>(n_units > 1 ? n_units - 1 : 0, c->pool->size()));
+    lap("  buffers ready");
+    c->pool->run(n_helpers + 1, [&](unsigned task) {
+      const bool issuer = task == 0;  // (the calling thread: it draws the first index)
+      size_t next_group = 0;
+      auto issue_ready = [&]() {
+        while (next_group < n_groups && left[next_group].load(std::memory_order_acquire) == 0) {
+          size_t gb = group_first[next_group] * unit, ge = std::min(total, group_first[next_group + 1] * unit);
+          h2d[next_group] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
+          if (trace) fprintf(stderr, "load_changes:   group %zu (%zu KiB) enqueued +%8.3f ms\n", next_group, (ge - gb) >> 10, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+          next_group++;
         }
-        return;
-      }
-      for (size_t u = task - 1; u < n_units; u += n_copiers) {
+      };
+      if (issuer) (void)hipSetDevice(c->device);
+      for (;;) {
+        size_t u = next_unit.fetch_add(1, std::memory_order_relaxed);
+        if (u >= n_units) break;
         size_t b = u * unit, e = std::min(total, b + unit);
         memcpy(raw + b, src + b, e - b);
-        left[u / units_per_group].fetch_sub(1, std::memory_order_acq_rel);
+        left[group_of[u]].fetch_sub(1, std::memory_order_acq_rel);
+        if (issuer) issue_ready();
+      }
+      if (issuer) {
+        while (next_group < n_groups) {
+          issue_ready();
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
       }
     });
     for (uint32_t i = 0; i < n; i++) roff[i] = offsets[i] - off0;
@@ -622,8 +641,10 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
     if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (arena): %s", hipGetErrorString(e));
   memcpy(c->h_offsets.p, roff, sizeof(uint64_t) * ((size_t)n + 1));  // (pinned mirror: the copy below must not bounce through the driver)
   HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->h_offsets.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  lap("H2D done");
+  // No wait here: am355_replay enqueues behind these copies on the same stream, so its host-side set-up runs beside the tail of
+  // the DMA instead of after a wake-up. The pinned arena is only rewritten by the next load, which waits first.
+  c->staging_in_flight = true;
+  if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); lap("H2D done"); }
   c->staged = true;
   c->stats = am355_stats{};
   c->stats.n_changes = n;
@@ -673,6 +694,7 @@ struct HostRle {
 static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   if (!c || !doc) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
+  if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }
   c->staged = c->replayed = c->ir_fetched = false;
   c->history_ok = false;
   c->is_document = true;
