@@ -644,7 +644,8 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   // No wait here: am355_replay enqueues behind these copies on the same stream, so its host-side set-up runs beside the tail of
   // the DMA instead of after a wake-up. The pinned arena is only rewritten by the next load, which waits first.
   c->staging_in_flight = true;
-  if (trace) { HIPCHK(c, hipStreamSynchronize(c->stream)); lap("H2D done"); }
+  static const bool stage_sync = getenv("AM355_STAGE_SYNC") != nullptr;  // (diagnostic: wait for the copies here, as round 1 did)
+  if (trace || stage_sync) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); lap("H2D done"); }
   c->staged = true;
   c->stats = am355_stats{};
   c->stats.n_changes = n;

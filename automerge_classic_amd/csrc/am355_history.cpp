@@ -15,6 +15,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../loggen/wire.hpp"
 #include "am355_host.h"
@@ -197,6 +200,14 @@ struct Built {      // one change after step 5
 
 int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor& par, HistoryOutput& out, std::string& err) {
   auto bad = [&](int rc, const char* msg) { err = msg; return rc; };
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_lap = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "  history: %-26s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+    t_lap = now;
+  };
   const std::vector<std::string>& actors = *in.actors;
   const uint32_t NA = (uint32_t)actors.size(), N = in.n_rows, P = in.n_succ;
 
@@ -215,6 +226,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
     for (uint32_t r = 0; r < N; r++) val_bytes += in.val_tl[r] >> 4;
     if (val_bytes != in.val_raw_len) return bad(HISTORY_UNSUPPORTED, "value bytes do not cover the valRaw column: the JS path decides");
   }
+  lap("column lengths");
   // ---- 1. change metadata ----
   std::vector<ChangeRec> chg;
   std::vector<uint32_t> dep_index;
@@ -284,6 +296,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
       if (chg.size() > 0x7ffffff0u) return bad(HISTORY_UNSUPPORTED, "too many changes");
     }
     if (!r_didx.done()) return bad(HISTORY_INVALID, "dependency index column has trailing values");
+    lap("change metadata");
     // ---- 2. slots: one bit per (actor, counter) up to the actor's last maxOp ----
     std::vector<uint64_t> act_max(NA, 0);
     for (uint32_t a = 0; a < NA; a++) act_max[a] = last_of[a] == NONE ? 0 : chg[last_of[a]].max_op;
@@ -326,6 +339,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
       if (acc >= 0xfffffff0ull) return bad(HISTORY_UNSUPPORTED, "more than 2^32 operations");
       word_rank[W] = (uint32_t)acc;
     }
+    lap("id bitmaps + rank directory");
     const uint32_t M = word_rank[W];
     // number of ids of actor a with counter < ctr, plus the actor's slot base = the slot of (a, ctr) when that id exists
     auto slot_of = [&](uint32_t a, uint64_t ctr) -> uint32_t {
@@ -362,6 +376,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
         }
       }
     });
+    lap("rows and preds by slot");
     // ---- 4. changes -> slot ranges ----
     for (ChangeRec& c : chg) {
       uint64_t prev_max = c.prev_same_actor == NONE ? 0 : chg[c.prev_same_actor].max_op;
@@ -487,6 +502,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
         for (uint32_t a : touched) local[a] = NONE;
       }
     });
+    lap("encode changes");
     {  // the first failure in document order is the one a sequential reader meets
       for (uint32_t k = 0; k < NC; k++) if (built[k].rc == HISTORY_INVALID) return bad(HISTORY_INVALID, built[k].why);
       for (uint32_t k = 0; k < NC; k++) if (built[k].rc) return bad(built[k].rc, built[k].why);
@@ -531,6 +547,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
       for (size_t i = 0; same && i < heads.size(); i++) same = memcmp(heads[i], in.heads + 32 * i, 32) == 0;
       if (!same) return bad(HISTORY_INVALID, "Mismatched heads hashes");
     }
+    lap("hash chain + heads");
     // ---- containers (+ DEFLATE of the chunk data of changes of >= 256 bytes), in parallel ----
     std::vector<Bytes> packed(NC);
     std::vector<int> pack_rc(NC, 0);
@@ -565,6 +582,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
         Bytes().swap(plain[k]);
       }
     });
+    lap("containers");
     for (int rc : pack_rc) if (rc) return bad(HISTORY_UNSUPPORTED, "deflate failed");
     out.offsets.assign((size_t)NC + 1, 0);
     for (uint32_t k = 0; k < NC; k++) out.offsets[k + 1] = out.offsets[k] + packed[k].size();
@@ -573,6 +591,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
       for (uint32_t k = t; k < NC; k += TE) if (!packed[k].empty()) memcpy(&out.arena[out.offsets[k]], packed[k].data(), packed[k].size());
     });
   }
+  lap("concatenate");
   return HISTORY_OK;
 }
 

@@ -1049,7 +1049,13 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); 
 void wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st) {
   auto t0 = std::chrono::steady_clock::now();
   for (uint32_t spins = 0; *seq_word != seq; spins++) {
-    if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { (void)hipStreamSynchronize(st); return; }
+    if ((spins & 0x3ff) == 0x3ff) {
+      auto waited = std::chrono::steady_clock::now() - t0;
+      if (waited > std::chrono::seconds(5)) { (void)hipStreamSynchronize(st); return; }
+      // Long past the time the phase takes: nudge the runtime (commands it still holds back are submitted by a query; seen under
+      // rocprofv3 with copies enqueued and no host wait before the kernels) and notice a stream that ran dry without the signal.
+      if (waited > std::chrono::microseconds(400) && hipStreamQuery(st) == hipSuccess && *seq_word != seq) return;
+    }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
