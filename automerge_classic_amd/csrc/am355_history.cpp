@@ -512,17 +512,33 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
     std::vector<Bytes> plain(NC);  // [chunk type 1][LEB length][dependency count][hashes][rest]: what the hash covers
     std::vector<uint8_t> is_dep(NC, 0);
     {
-      std::vector<const uint8_t*> deps;
-      Bytes dp;
+      // a change can be hashed once its dependencies are: level = 1 + the highest level among them; the changes of one level are
+      // independent (64 per level in a 64-actor round structure, one in a single-author history, which then runs inline)
+      std::vector<uint32_t> level(NC, 0), level_first(2, 0), by_level(NC);
+      uint32_t n_levels = NC ? 1 : 0;
       for (uint32_t k = 0; k < NC; k++) {
         const ChangeRec& c = chg[k];
-        deps.clear();
+        uint32_t l = 0;
         for (uint32_t d = 0; d < c.dep_num; d++) {
           uint32_t j = dep_index[c.dep_first + d];
           if (j >= k) return bad(HISTORY_INVALID, "dependency on a later change");
-          deps.push_back(&out.hashes[(size_t)j * 32]);
+          l = std::max(l, level[j] + 1);
           is_dep[j] = 1;
         }
+        level[k] = l;
+        n_levels = std::max(n_levels, l + 1);
+      }
+      level_first.assign((size_t)n_levels + 1, 0);
+      for (uint32_t k = 0; k < NC; k++) level_first[level[k] + 1]++;
+      for (uint32_t l = 0; l < n_levels; l++) level_first[l + 1] += level_first[l];
+      {
+        std::vector<uint32_t> at(level_first.begin(), level_first.end() - 1);
+        for (uint32_t k = 0; k < NC; k++) by_level[at[level[k]]++] = k;
+      }
+      auto hash_change = [&](uint32_t k, std::vector<const uint8_t*>& deps, Bytes& dp) {
+        const ChangeRec& c = chg[k];
+        deps.clear();
+        for (uint32_t d = 0; d < c.dep_num; d++) deps.push_back(&out.hashes[(size_t)dep_index[c.dep_first + d] * 32]);
         std::sort(deps.begin(), deps.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
         dp.clear();
         put_uleb(dp, deps.size());
@@ -536,6 +552,21 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
         full.insert(full.end(), rest.begin(), rest.end());
         Bytes().swap(rest);
         sha256_digest(full.data(), full.size(), &out.hashes[(size_t)k * 32]);
+      };
+      std::vector<const uint8_t*> deps0;
+      Bytes dp0;
+      for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t lo = level_first[l], hi = level_first[l + 1], cnt = hi - lo;
+        if (cnt < 8) {
+          for (uint32_t i = lo; i < hi; i++) hash_change(by_level[i], deps0, dp0);
+        } else {
+          const unsigned tasks = std::min<uint32_t>(cnt, 32);
+          par(tasks, [&](unsigned t) {
+            std::vector<const uint8_t*> deps;
+            Bytes dp;
+            for (uint32_t i = lo + t; i < hi; i += tasks) hash_change(by_level[i], deps, dp);
+          });
+        }
       }
     }
     {
