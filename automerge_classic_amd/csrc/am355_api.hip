@@ -219,6 +219,7 @@ struct am355_ctx {
   hipStream_t stream = nullptr;   // decode / merge critical path
   hipStream_t stream2 = nullptr;  // SHA-256 + dependency resolution, off the critical path
   hipStream_t stream3 = nullptr;  // second decoder class, side by side with the first
+  hipStream_t stream4 = nullptr;  // small copies that must not queue behind kernels or fills (digests to the host, host-built tables to HBM)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[8] = {};
   hipEvent_t ev_parse = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
@@ -241,6 +242,8 @@ struct am355_ctx {
   HostBuf h_metas, h_offsets, h_sig;   // h_sig: HostSignals (device -> host result words without a copy)
   uint32_t sig_seq = 0;
   hipEvent_t ev_s1 = nullptr;          // the per-change digests (briefs) have arrived on the host
+  hipEvent_t ev_plan = nullptr, ev_tables = nullptr;  // k_plan_apply done (stream4 copies the digests behind it) | host-built tables in HBM
+  void* counts_zeroed_at = nullptr; size_t counts_zeroed = 0;  // the counter block was cleared beside stage 1 (address, bytes)
   DevBuf d_big, d_bigvals, d_ks;     // document load: token / record index, column values, keyStr run table
   HostBuf h_biginfo;
   BigColDesc doc_cols{};
@@ -373,11 +376,13 @@ extern "C" am355_ctx* am355_create(int device) {
     if (!made && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_low) != hipSuccess) { delete c; return nullptr; }
   }
   if (hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_high) != hipSuccess) { delete c; return nullptr; }
+  if (hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_high) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_fork) != hipSuccess || hipEventCreate(&c->ev_join) != hipSuccess) { delete c; return nullptr; }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_counts) != hipSuccess || hipEventCreate(&c->ev_runs) != hipSuccess || hipEventCreate(&c->ev_s1) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev_plan) != hipSuccess || hipEventCreate(&c->ev_tables) != hipSuccess) { delete c; return nullptr; }
   if (!c->h_sig.ensure(sizeof(HostSignals))) { delete c; return nullptr; }
   memset(c->h_sig.p, 0, sizeof(HostSignals));
   return c;
@@ -389,15 +394,17 @@ extern "C" void am355_destroy(am355_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->stream2);
   (void)hipStreamSynchronize(c->stream3);
+  if (c->stream4) (void)hipStreamSynchronize(c->stream4);
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
                     &c->d_words, &c->d_slot_rank, &c->d_scan1, &c->d_plan_sums, &c->d_dep_idx, &c->d_self_idx})
     b->release();
   for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1, &c->h_dep_idx, &c->h_self_idx, &c->h_amap, &c->h_amap_base}) b->release();
   c->d_s1.release();
-  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1})
+  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1, c->ev_plan, c->ev_tables})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
@@ -1511,7 +1518,8 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   lap("buffers carved");
   // the decode launch first (every HIP call before it is device idle time); the merge stage's fills follow on stream3 -- they depend
   // on nothing of this replay -- and stream3 only waits for the counter reset when a second decoder class runs there
-  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
+  if (!(c->counts_zeroed_at == c->d_counts.p && c->mb.counts_bytes <= c->counts_zeroed)) HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
+  c->counts_zeroed_at = nullptr;  // (one replay's worth: the merge kernels are about to write it)
   if (tot.n_small && (tot.n_large || tot.n_serial)) {
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
@@ -1541,7 +1549,11 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
     size_t b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size();
     if (b_spans) memcpy(h, c->spans.data(), b_spans);
     memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
-    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_tab + b_tab, hipMemcpyHostToDevice, st));
+    // on stream4, beside the decode kernels: in the main stream the copy would start when the decode kernels end (and on
+    // stream3 when the merge fills end) and k_resolve would wait for it
+    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_tab + b_tab, hipMemcpyHostToDevice, c->stream4));
+    HIPCHK(c, hipEventRecord(c->ev_tables, c->stream4));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_tables, 0));
   }
   lap("tables enqueued");
   Counts* hc = c->h_counts.as<Counts>();
@@ -1741,6 +1753,17 @@ static int replay_impl(am355_ctx* c) {
   HIPCHK(c, hipMemsetAsync(d_wa, 0, s1_distinct + 16, c->stream3));
   HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), c->stream3));
   HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), c->stream3));
+  {
+    // the merge stage's counter block too: its size follows from the op count, which is at most one op per encoded byte for any
+    // batch worth hurrying (a run length may claim more: the planned path then clears it in front of the decode as before)
+    size_t cb = merge_counts_bytes((uint32_t)std::min<size_t>(c->raw.size(), 0x7ffffff0u));
+    c->counts_zeroed_at = nullptr;
+    if (c->d_counts.ensure(cb)) {
+      HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, cb, c->stream3));
+      c->counts_zeroed_at = c->d_counts.p;
+      c->counts_zeroed = cb;
+    }
+  }
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(sa, c->ev_join, 0));
 
@@ -1760,8 +1783,11 @@ static int replay_impl(am355_ctx* c) {
     launch_plan(d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plan_sums.as<unsigned long long>(), c->d_plans.as<ChangePlan>(),
                 c->d_plans.as<ChangePlan>() + n1, d_wa, d_wa + 8, sig, c->sig_seq, sa);
     // the host's own half of the plan needs a 32-byte digest per change and the handful of distinct actor ids: they follow
-    HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, sa));
-    HIPCHK(c, hipEventRecord(c->ev_s1, sa));
+    // -- on stream4, behind the plan kernel: in stream A the copy (and its dispatch gap) would sit in front of the decode kernels
+    HIPCHK(c, hipEventRecord(c->ev_plan, sa));
+    HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_plan, 0));
+    HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, c->stream4));
+    HIPCHK(c, hipEventRecord(c->ev_s1, c->stream4));
     HIPCHK(c, hipEventRecord(c->ev[1], sa));
     if (attempt == 0) {
       // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. It starts

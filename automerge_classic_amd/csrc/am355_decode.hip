@@ -399,29 +399,22 @@ __device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len6
   *n_entries_out = m.flags ? 0 : m.n_entries;
 }
 
-// PARSE_GROUP changes per wavefront: the parse of one change is a serial chain run by ONE lane, and a wave64 VALU instruction
-// occupies its SIMD for four cycles however many lanes are active -- with one change per wave and 16 waves per CU the kernel was
-// bound by instruction issue (51 us for 4 k changes). Four lanes of a wave parse four staged changes in lockstep (changes of a
-// batch have the same shape, so the lanes rarely diverge): a quarter of the instructions per SIMD.
-constexpr uint32_t PARSE_GROUP = 4;
+// (Four changes per wavefront -- four lanes parsing four staged changes in lockstep -- was measured and dropped: the kernel is bound
+// by the dependent chain of one change, not by instruction issue (57 us either way on the 1 M-op log), and changes of different
+// shape make the lanes diverge, which cost the map workload (few, fat changes with different keys) 0.12 ms per replay.)
 __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
                                                          uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries) {
-  __shared__ alignas(16) uint8_t stage[PARSE_GROUP * PARSE_STAGE];
+  __shared__ alignas(16) uint8_t stage[PARSE_STAGE];
   wave_priority_high();
-  const uint32_t c0 = blockIdx.x * PARSE_GROUP, lane = threadIdx.x;
-#pragma unroll
-  for (uint32_t g = 0; g < PARSE_GROUP; g++) {
-    uint32_t c = c0 + g;
-    if (c >= n_changes) break;
-    uint64_t base64 = offsets[c], total64 = offsets[c + 1] - offsets[c];
-    if (total64 <= PARSE_STAGE) stage_to_lds(stage + g * PARSE_STAGE, arena + base64, (uint32_t)total64, lane);
-  }
-  __syncthreads();
-  const uint32_t c = c0 + lane;
-  if (lane >= PARSE_GROUP || c >= n_changes) return;
+  uint32_t c = blockIdx.x, lane = threadIdx.x;
+  if (c >= n_changes) return;
   uint64_t base64 = offsets[c], total64 = offsets[c + 1] - offsets[c];
+  bool staged = total64 <= PARSE_STAGE;
+  if (staged) stage_to_lds(stage, arena + base64, (uint32_t)total64, lane);
+  __syncthreads();
+  if (lane != 0) return;
   // two instantiations so that the staged case reads LDS with ds_read instead of FLAT loads through a generic pointer
-  if (total64 <= PARSE_STAGE) parse_change((LdsBytes)(stage + lane * PARSE_STAGE), base64, total64, &metas[c], &n_entries[c]);
+  if (staged) parse_change((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c]);
   else parse_change(arena + base64, base64, total64, &metas[c], &n_entries[c]);
 }
 
@@ -1681,7 +1674,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
 
 void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, hipStream_t st) {
   if (!n_changes) return;
-  hipLaunchKernelGGL(k_parse_changes, dim3((n_changes + PARSE_GROUP - 1) / PARSE_GROUP), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries);
+  hipLaunchKernelGGL(k_parse_changes, dim3(n_changes), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries);
 }
 
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
