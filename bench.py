@@ -264,8 +264,8 @@ def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c4_text_single", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -358,7 +358,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops)) if w.is_doc else cpu_baseline(w.log)
     if not args.no_sublines and world == 1:
-        subs, k, wu = [], max(5, args.steps // 3), 2
+        subs, k, wu = [], max(5, min(args.steps // 3, 30)), 3
         for name in ("c4_text_multi", "c3_map_lww", "c2_text_typing"):
             if name != args.workload:
                 subs.append(subline(eng, name, 1.0, BASE_SEED[name], k, wu, barrier))

@@ -8,7 +8,7 @@ OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 B="python bench.py --steps 10 --warmup 3 --no-sublines --no-cpu-baseline"
-timeout -k 5 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
+timeout -k 5 400 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 # (every profiler pass under a hard limit: a pass that stalls must not eat the GPU budget; if the first one stalls, the passes are
 # repeated with AM355_STAGE_SYNC=1 = am355_load_changes waits for its copies, and the note is written next to the results)
 timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run -- $B > $OUT/bench_under_trace.json 2> $OUT/kt.err
