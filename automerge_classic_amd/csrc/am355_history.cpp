@@ -303,7 +303,7 @@ int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor&
     std::vector<uint64_t> word_base(NA + 1, 0);
     for (uint32_t a = 0; a < NA; a++) word_base[a + 1] = word_base[a] + (act_max[a] + 2 + 63) / 64;  // bits 0 .. max + 1
     const uint64_t W = word_base[NA];
-    if (W > (1ull << 27)) return bad(HISTORY_UNSUPPORTED, "actors x operation counters beyond the id index (1 GiB)");
+    if (W > (1ull << 26)) return bad(HISTORY_UNSUPPORTED, "actors x operation counters beyond the id index (2^32 ids)");
     std::vector<uint64_t> all_bits((size_t)W + 1, 0), row_bits((size_t)W + 1, 0);
     const unsigned T = 256;
     std::vector<int> task_rc(T, 0);

@@ -217,14 +217,16 @@ def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False, deflate
             "roofline_whole_path": {"achieved": whole, "unit": "GB/s", "frac": whole / 8000.0}}
 
 
-def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier):
+def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier, scale=1.0, sync=None):
     """ONE document (c4_text_multi: 64 Text objects) sharded by objectId over the ranks: T_replay-style region (host buffers on
     every rank -> stitched patch IR on rank 0's host), max over ranks; beside it the same log unsharded on rank 0 alone."""
     import hashlib
     import torch
     from automerge_classic_amd import shard
     name = "c4_text_multi"
-    log = make_log(name, 1.0, BASE_SEED[name])  # (the same log on every rank)
+    log = make_log(name, scale, BASE_SEED[name])  # (the same log on every rank)
+    if sync is None:
+        sync = torch.cuda.synchronize
     # parity first, outside the timed region: stitched patch == unsharded patch
     eng.set_shard(0, 1)
     eng.load_changes(log)
@@ -247,12 +249,12 @@ def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier):
             eng.fetch_ir()
         for _ in range(warmup):
             one()
-        t_single = timed(one, steps, torch.cuda.synchronize)
+        t_single = timed(one, steps, sync)
     barrier()
     if rank != 0:
         return None
     n_ops = int(log.n_ops)
-    return {"workload": f"{name} x1.0: {n_ops} ops, {log.n_changes} changes, 64 Text objects, ONE document over {world} GPUs (objectId sharding: owner = "
+    return {"workload": f"{name} x{scale}: {n_ops} ops, {log.n_changes} changes, 64 Text objects, ONE document over {world} GPUs (objectId sharding: owner = "
                         "(object counter + actor rank) mod N, _root on rank 0; every rank decodes the batch, merges its objects, all_gather of the "
                         "patch-IR fragments over RCCL, stitch on rank 0)",
             "scaling": "strong", "n_gpus": world, "steps": steps, "ops_per_s": n_ops * steps / dt, "ms_per_step": dt / steps * 1e3,
@@ -313,7 +315,7 @@ def main():
     t_dev, _ = dist_util.aggregate(t_dev, 0.0, dist, torch.device("cuda", local_rank))
     sharded = None
     if world > 1 and not args.no_shard:
-        sharded = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), max(5, args.steps // 2), 3, barrier)
+        sharded = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), max(5, min(args.steps // 2, 30)), 3, barrier)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -366,6 +368,8 @@ def main():
         # the same log with every change DEFLATEd as the reference's encodeChange does for changes >= 256 bytes (columnar.js:798-811):
         # T_replay then includes the host inflate (zlib, on the engine's host threads)
         subs.append(subline(eng, "c4_text_single", 1.0, BASE_SEED["c4_text_single"], k, wu, barrier, deflate=True))
+        # a larger batch of the headline shape (4 x: 4.1 M ops, 54 MB of changes): the same kernels with more work per launch
+        subs.append(subline(eng, "c4_text_single", 4.0, BASE_SEED["c4_text_single"], 8, 2, barrier))
         if args.workload != "c5_doc_mixed":
             subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 3, 1, barrier))
         out["workloads"] = subs

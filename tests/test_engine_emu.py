@@ -5,6 +5,7 @@ It says nothing about the GPU build: the parity tests proper are in test_engine_
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -376,6 +377,58 @@ def test_history_after_save_and_load_of_generated_logs(eng, case):
     eng.load_changes(again)
     eng.replay()
     assert eng.save() == doc
+
+
+def test_history_call_sequence_and_refusals(eng, monkeypatch):
+    """am355_doc_changes: only after load_document + replay; the serial document decoder (diagnostic) does not feed it; the result is
+    cached per flag and dropped by the next load."""
+    fx = golden_util.load_fixture("frontend_text_4actors")
+    eng.load_changes(fx["log"])
+    eng.replay()
+    with pytest.raises(engine.EngineError):   # a replayed change log is not a loaded document
+        eng.doc_changes()
+    eng.load_document(fx["doc_bytes"])
+    with pytest.raises(engine.EngineError):   # not replayed yet
+        eng.doc_changes()
+    eng.replay()
+    a1, o1, h1 = eng.doc_changes()
+    a2, o2, h2 = eng.doc_changes()            # served from the context
+    assert bytes(a1) == bytes(a2) and (o1 == o2).all() and (h1 == h2).all()
+    a3, o3, h3 = eng.doc_changes(deflate=False)
+    assert (h3 == h1).all() and len(o3) == len(o1)   # (same changes; compression may even enlarge small ones)
+    monkeypatch.setenv("AM355_DOC_SERIAL", "1")
+    eng.load_document(fx["doc_bytes"])
+    eng.replay()
+    with pytest.raises(engine.UnsupportedChanges):
+        eng.doc_changes()
+    monkeypatch.delenv("AM355_DOC_SERIAL")
+    eng.load_document(fx["doc_bytes"])
+    eng.replay()
+    assert bytes(eng.doc_changes()[0]) == bytes(a1)
+
+
+def test_inflate_without_libdeflate_gives_the_same_result(tmp_path):
+    """The host inflate goes through libdeflate when the system has it; AM355_NO_LIBDEFLATE=1 (read once per process) forces zlib."""
+    script = tmp_path / "w.py"
+    script.write_text(f"""
+import sys, hashlib
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, "tests")!r})
+from automerge_classic_amd import engine, loggen
+eng = engine.Engine(0, {EMU_LIB!r})
+log = loggen.config("c4_text_multi", 0.03, True)
+eng.load_changes(log); eng.replay()
+h = hashlib.sha256(eng.patch_json().encode())
+doc, rows = loggen.generate_document(n_actors=6, n_texts=3, text_len=900, n_maps=2, keys_per_map=300, n_submaps=2, n_lists=2, list_len=300, deflate=True, seed=5)
+eng.load_document(doc); eng.replay()
+h.update(eng.patch_json().encode())
+print(h.hexdigest())
+""")
+    outs = []
+    for env in ({}, {"AM355_NO_LIBDEFLATE": "1"}):
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 64
 
 
 @pytest.mark.parametrize("name", ["frontend_text_8actors", "frontend_mixed_6actors", "campaign_text_2003"])

@@ -86,6 +86,14 @@ try:
     raise SystemExit("corrupt batch was accepted")
 except (engine.EngineError, RuntimeError):
     pass
+# the bench's own N > 1 section (bench.py sharded_measurement), at a small scale over gloo
+import bench
+r = bench.sharded_measurement(eng, rank, world, dist, torch.device("cpu"), 2, 1, dist.barrier, scale=0.02, sync=lambda: None)
+if rank == 0:
+    assert r["parity"].startswith("stitched patch == unsharded patch") and r["n_gpus"] == 2 and r["ops_per_s"] > 0 and len(r["fragment_bytes"]) == 2, r
+    sys.stdout.write("bench section ok\\n")
+else:
+    assert r is None
 dist.barrier()
 dist.destroy_process_group()
 sys.stdout.write("rank%dok\\n" % rank); sys.stdout.flush()
@@ -102,4 +110,4 @@ def test_two_rank_objectid_sharding_over_gloo(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29534", str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-    assert "rank0ok" in out.stdout and "rank1ok" in out.stdout and out.stdout.count("case ok") >= 3
+    assert "rank0ok" in out.stdout and "rank1ok" in out.stdout and out.stdout.count("case ok") >= 3 and "bench section ok" in out.stdout
