@@ -56,9 +56,10 @@ uint32_t am355_flags(const am355_ctx *ctx);
 /*
  * Stage a batch of binary changes: `arena` holds n_changes change containers back to back, change i occupying
  * arena[offsets[i] .. offsets[i+1]).  DEFLATEd changes (chunk type 2, columnar.js:798-823) are inflated on the
- * host (zlib) into an internal "raw arena", which is then copied to HBM.  Replaces the per-buffer
- * decodeChangeColumns() preamble of BackendDoc.applyChanges (new.js:1806-1810).  The caller's buffers are not
- * retained.
+ * host (libdeflate when the system has it, else zlib) into an internal pinned "raw arena", which is copied to HBM.  Replaces
+ * the per-buffer decodeChangeColumns() preamble of BackendDoc.applyChanges (new.js:1806-1810).  The caller's buffers are not
+ * retained: when the call returns every byte is in the engine's arena -- the copies to HBM may still be running; am355_replay
+ * is ordered behind them on the context's stream (the next load waits for them before it rewrites the arena).
  */
 int am355_load_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes);
 
