@@ -266,6 +266,7 @@ struct am355_ctx {
   std::vector<uint8_t> saved;                              // result of am355_save
   HistoryOutput history;                                   // result of am355_doc_changes
   bool history_ok = false; uint32_t history_flags = 0;
+  std::vector<std::vector<uint8_t>> inflate_scratch;       // am355_load_document: inflated columns, longest first (capacity kept between loads)
   std::vector<uint32_t> doc_col_rows;                      // loaded document: values per op column (BigCol order), parallel decode only
   std::vector<std::pair<uint32_t, std::vector<uint8_t>>> doc_chg_cols;  // loaded document: change-metadata columns, inflated
   std::vector<uint8_t> doc_tail;                           // loaded document: headsIndexes + extraBytes
@@ -707,6 +708,11 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   c->history_ok = false;
   c->is_document = true;
   c->flags = 0;
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "load_document: %-30s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   auto bad0 = [&](uint32_t flag, const char* msg) { c->flags |= flag; return fail(c, AM355_E_INVALID, "%s", msg); };
   if (len < 10 || doc[0] != 0x85 || doc[1] != 0x6f || doc[2] != 0x4a || doc[3] != 0x83) return bad0(AM355_F_BAD_MAGIC, "Data does not begin with magic bytes 85 6f 4a 83");
   size_t off = 9;
@@ -743,7 +749,7 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   if (!read_uleb_host(h, hl, ho, nh) || nh > (hl - ho) / 32) return bad(AM355_F_BAD_LEB, "bad document header");
   c->heads.assign(h + ho, h + ho + nh * 32);
   ho += (size_t)nh * 32;
-  struct Col { uint64_t id, len; std::vector<uint8_t> data; const uint8_t* p = nullptr; size_t n = 0; };
+  struct Col { uint64_t id, len; std::vector<uint8_t>* data = nullptr; const uint8_t* p = nullptr; size_t n = 0; };  // data: inflated bytes (a scratch vector of the context)
   auto read_dir = [&](std::vector<Col>& cols) -> bool {
     uint64_t n;
     if (!read_uleb_host(h, hl, ho, n) || n > hl) return false;
@@ -776,6 +782,10 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
       if (col->id & 8) deflated.push_back(col);
     std::sort(deflated.begin(), deflated.end(), [](const Col* x, const Col* y) { return x->len > y->len; });
     std::vector<int> irc(deflated.size(), 0);
+    // (inflate buffers live in the context: the k-th longest column of the next document finds its pages already mapped -- a fresh
+    // 34 MB vector costs ~10 ms of page faults on the thread that is the critical path of this call)
+    if (c->inflate_scratch.size() < deflated.size()) c->inflate_scratch.resize(deflated.size());
+    for (size_t k = 0; k < deflated.size(); k++) deflated[k]->data = &c->inflate_scratch[k];
     const unsigned n_tasks = (unsigned)deflated.size() + 2;
     c->pool->run(n_tasks, [&](unsigned t) {
       // (the two longest columns first, then the checksum, which takes about as long as a mid-sized column)
@@ -784,16 +794,17 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
       if (t == copy_slot) { c->doc_bytes.assign(doc, doc + len); return; }
       size_t k = t < sum_slot ? t : t - 2;
       Col* col = deflated[k];
-      irc[k] = inflate_raw(col->p, (size_t)col->len, col->data, INFLATE_CAP);
+      irc[k] = inflate_raw(col->p, (size_t)col->len, *col->data, INFLATE_CAP);
     });
+    lap("inflate | checksum | copy");
     if (!sum_ok) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
     int rd = 0;
     for (Col* col : all_cols) {  // (errors in column order, as a sequential reader would meet them)
       if (!(col->id & 8)) continue;
       size_t k = (size_t)(std::find(deflated.begin(), deflated.end(), col) - deflated.begin());
       if (irc[k]) { rd = irc[k] == 1 ? 2 : irc[k] == 2 ? 3 : 4; break; }
-      col->p = col->data.data();
-      col->n = col->data.size();
+      col->p = col->data->data();
+      col->n = col->data->size();
       col->id ^= 8;
     }
     if (rd == 2) return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
@@ -848,6 +859,7 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     c->clock_seq.clear();
     for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
   }
+  lap("change metadata");
   // ---- actor ranks: op-id comparison on the device is numeric on (ctr, rank) ----
   {
     std::vector<uint32_t> order(na);
@@ -900,6 +912,7 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     c->doc_serial = e && *e == '1';
   }
   if (arena_bytes >= 0xfff00000ull) return fail(c, AM355_E_UNSUPPORTED, "document larger than 4 GiB (32-bit arena offsets)");
+  lap("columns placed");
   c->raw.resize(arena_bytes);
   c->raw_off.push_back(arena_bytes);
   m.len = (uint32_t)arena_bytes;
@@ -918,7 +931,9 @@ static int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     for (hipError_t e : h2d)
       if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (document columns): %s", hipGetErrorString(e));
   }
+  lap("gathered, H2D enqueued");
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  lap("H2D done");
   c->staged = true;
   c->stats = am355_stats{};
   c->stats.n_changes = c->n_changes;
