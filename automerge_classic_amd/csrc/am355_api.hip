@@ -1823,7 +1823,11 @@ static int replay_impl(am355_ctx* c) {
       HIPCHK(c, hipEventRecord(c->ev_b1, sb));
     }
     lap("stage 1 enqueued");
-    wait_host_signal(&sig->plan_seq, c->sig_seq, sa);
+    if (!wait_host_signal(&sig->plan_seq, c->sig_seq, sa)) {
+      (void)hipStreamSynchronize(sb);
+      (void)hipStreamSynchronize(c->stream3);
+      return fail(c, AM355_E_DEVICE, "the device did not report the plan of this replay (%s)", hipGetErrorString(hipGetLastError()));
+    }
     memcpy(&tot, (const void*)&sig->plan, sizeof tot);
     lap("stage 1 totals read");
     if (!(tot.fast_a & FF_CAPACITY) || attempt) break;

@@ -102,7 +102,7 @@ struct PatchIR {
 size_t merge_scratch_pairs(uint32_t n_ops);
 
 // host side of the device -> host signalling (HostSignals): spins until *seq_word == seq
-void wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st);
+bool wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st);  // false: no signal (stream drained instead)
 
 // Zero-fills the merge stage needs (succ / counter accumulators, child lists, list order): independent of the decode kernels,
 // so the caller issues them on a second stream beside the decode and joins before merge_run.

@@ -1046,21 +1046,31 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); 
 // Host side of signal_host (am355_device.h): spin on the sequence word in pinned memory. If the word does not arrive within a
 // generous bound (a device fault, a kernel that was never launched) the stream is drained instead: the caller then reads whatever
 // the device left, and the error surfaces through the HIP status of the next call.
-void wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st) {
+bool wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st) {
   auto t0 = std::chrono::steady_clock::now();
   for (uint32_t spins = 0; *seq_word != seq; spins++) {
     if ((spins & 0x3ff) == 0x3ff) {
       auto waited = std::chrono::steady_clock::now() - t0;
-      if (waited > std::chrono::seconds(5)) { (void)hipStreamSynchronize(st); return; }
       // Long past the time the phase takes: nudge the runtime (commands it still holds back are submitted by a query; seen under
-      // rocprofv3 with copies enqueued and no host wait before the kernels) and notice a stream that ran dry without the signal.
-      if (waited > std::chrono::microseconds(400) && hipStreamQuery(st) == hipSuccess && *seq_word != seq) return;
+      // rocprofv3 with copies enqueued and no host wait before the kernels); a stream that ran dry, or five seconds, end the wait.
+      if (waited > std::chrono::seconds(5) || (waited > std::chrono::microseconds(400) && hipStreamQuery(st) == hipSuccess)) {
+        (void)hipStreamSynchronize(st);
+        break;
+      }
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
   }
   std::atomic_thread_fence(std::memory_order_acquire);
+  return *seq_word == seq;  // false: the words behind the signal are NOT this replay's -- the caller reads the device's copy
+}
+
+// the counters of a phase: from the pinned words the phase's last kernel signalled, or -- no signal -- from the device after a drain
+static void read_phase_counts(MergeBufs& b, volatile uint32_t* seq_word, const uint32_t* words, Counts* dst, hipStream_t st) {
+  if (wait_host_signal(seq_word, b.sig_seq, st)) { memcpy(dst, (const void*)words, sizeof(Counts)); return; }
+  (void)hipMemcpyAsync(dst, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
 }
 
 size_t merge_counts_bytes(uint32_t n_ops) {
@@ -1161,7 +1171,7 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
 
   lap("first half enqueued");
-  if (b.sig) { wait_host_signal(&b.sig->counts_seq, b.sig_seq, st); memcpy(hc, (const void*)b.sig->counts, sizeof(Counts)); }
+  if (b.sig) read_phase_counts(b, &b.sig->counts_seq, b.sig->counts, hc, st);
   else (void)hipEventSynchronize(ev_counts);
   lap("counts read");
   if (hc->flags) { (void)hipStreamSynchronize(st); return; }
@@ -1169,7 +1179,7 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
 
   const uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd, n_obj = hc->n_objects + 1;
   if (ni) {
-    if (b.sig) { wait_host_signal(&b.sig->runs_seq, b.sig_seq, st); memcpy(hc_runs, (const void*)b.sig->runs, sizeof(Counts)); }
+    if (b.sig) read_phase_counts(b, &b.sig->runs_seq, b.sig->runs, hc_runs, st);
     else (void)hipEventSynchronize(ev_runs);
     lap("runs read");
     uint32_t H = hc_runs->n_runs;
@@ -1230,8 +1240,7 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   }
   lap("all enqueued");
   if (b.sig && ni) {
-    wait_host_signal(&b.sig->final_seq, b.sig_seq, st);
-    memcpy(hc, (const void*)b.sig->final_counts, sizeof(Counts));
+    read_phase_counts(b, &b.sig->final_seq, b.sig->final_counts, hc, st);
   } else {
     (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
