@@ -141,7 +141,9 @@ inline void atomic_min(uint32_t* p, uint32_t v) {
   while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 
+// valid UTF-8 that TextDecoder -> TextEncoder reproduces (a leading U+FEFF is dropped by the decoder, encoding.js:9-17)
 bool valid_utf8(const uint8_t* s, size_t n) {
+  if (n >= 3 && s[0] == 0xef && s[1] == 0xbb && s[2] == 0xbf) return false;
   size_t i = 0;
   while (i < n) {
     uint8_t c = s[i];

@@ -1631,7 +1631,9 @@ static int json_prim_value(pctx_t *c, sbuf_t *b, const pval_t *v) {
   switch (t & 15) {
     case 6:
       if (!utf8_valid(v->bytes, n)) return fail(c->e, "unsupported: malformed UTF-8 in string value");
-      json_string(b, v->bytes, n);
+      /* utf8ToString = TextDecoder('utf-8').decode (encoding.js:9-17): a leading U+FEFF is dropped */
+      if (n >= 3 && v->bytes[0] == 0xef && v->bytes[1] == 0xbb && v->bytes[2] == 0xbf) json_string(b, v->bytes + 3, n - 3);
+      else json_string(b, v->bytes, n);
       return 0;
     case 3: case 4: case 8: case 9: {
       int64_t x;
@@ -1728,6 +1730,9 @@ static int cmp_idxkey(const void *a, const void *b) {
 
 static int json_prop(pctx_t *c, sbuf_t *b, pprop_t *pp) {
   if (!utf8_valid(pp->key, pp->key_len)) return fail(c->e, "unsupported: malformed UTF-8 in key");
+  /* a key that starts with U+FEFF loses it in utf8ToString and then collides with / repeats other keys (the reference's own
+   * RLE decoder throws on the repeated literal): left to the JS path */
+  if (pp->key_len >= 3 && pp->key[0] == 0xef && pp->key[1] == 0xbb && pp->key[2] == 0xbf) return fail(c->e, "unsupported: map key starts with a byte order mark");
   json_string(b, pp->key, pp->key_len);
   sb_puts(b, ":{");
   for (uint32_t i = 0; i < pp->n; i++) {

@@ -379,6 +379,21 @@ def test_history_after_save_and_load_of_generated_logs(eng, case):
     assert eng.save() == doc
 
 
+def test_map_key_with_a_byte_order_mark_goes_to_the_js_path(eng):
+    """The reference decodes strings with TextDecoder, which drops a leading U+FEFF (encoding.js:9-17): values are rendered without
+    it (golden hand_bom_values); a KEY that loses its first character can collide with another key -- the reference's own decoder
+    throws on such documents -- so the engine leaves those to the JS path."""
+    import base64
+    change = base64.b64decode("hW9Kgw1pqGMBPwACqqoBAeXyxtUGDkluaXRpYWxpemF0aW9uAAYVDjQBQgJWAlcCcAJ+Bu+7v2tleQVvdGhlcgICAQIWdncCAA==")
+    log = loggen.ChangeLog.from_changes([change], name="bom key")
+    eng.load_changes(log)
+    eng.replay()
+    with pytest.raises(engine.UnsupportedChanges):
+        eng.patch_json()
+    with pytest.raises(oracle_lib.OracleError):
+        oracle_lib.OracleDoc(log).patch_json()
+
+
 def test_history_call_sequence_and_refusals(eng, monkeypatch):
     """am355_doc_changes: only after load_document + replay; the serial document decoder (diagnostic) does not feed it; the result is
     cached per flag and dropped by the next load."""
