@@ -2385,6 +2385,36 @@ static int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, si
     }
   }
   lap("columns to host");
+  {
+    // A key that starts with U+FEFF: the reference decodes keys on their way into a document (TextDecoder drops a leading byte
+    // order mark, encoding.js:9-17) and writes the shortened key; such documents are saved by the JS path. (Walk of the encoded key
+    // column: one step per run or literal.)
+    const std::vector<uint8_t>& kc = ops_cols[E_KEY_STR].data;
+    size_t o = 0;
+    auto uleb = [&](uint64_t& v) { return read_uleb_host(kc.data(), kc.size(), o, v); };
+    auto sleb = [&](int64_t& v) {
+      uint64_t u = 0; int shift = 0;
+      while (o < kc.size() && shift < 64) {
+        uint8_t b = kc[o++];
+        u |= (uint64_t)(b & 0x7f) << shift; shift += 7;
+        if (!(b & 0x80)) { if ((b & 0x40) && shift < 64) u |= ~0ull << shift; v = (int64_t)u; return true; }
+      }
+      return false;
+    };
+    bool bom = false, ok = true;
+    while (ok && o < kc.size() && !bom) {
+      int64_t n;
+      if (!(ok = sleb(n))) break;
+      uint64_t strings = n > 0 ? 1 : n < 0 ? (uint64_t)-n : 0, l;
+      if (n == 0) { ok = uleb(l); continue; }
+      for (uint64_t k = 0; ok && k < strings; k++) {
+        ok = uleb(l) && l <= kc.size() - o;
+        if (ok) { bom = bom || (l >= 3 && kc[o] == 0xef && kc[o + 1] == 0xbb && kc[o + 2] == 0xbf); o += (size_t)l; }
+      }
+    }
+    if (!ok) return fail(c, AM355_E_DEVICE, "internal: encoded key column does not parse");
+    if (bom) return fail(c, AM355_E_UNSUPPORTED, "a map key starts with a byte order mark: the document is saved by the JS path");
+  }
   // ---- change metadata columns (columnar.js:86-96, new.js:1680-1692) ----
   std::vector<SaveColumn> chg_cols;
   std::vector<uint8_t> tail;  // headsIndexes (+ extraBytes of a loaded document)

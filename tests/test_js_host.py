@@ -77,6 +77,17 @@ def test_reference_suites_and_frontend_flows_over_the_engine_enabled_wrapper_emu
     assert served["gpuLoad"] >= 10 and served["fallbackToJs"] == 0
 
 
+@pytest.mark.skipif(NODE is None or not os.path.isdir("/root/reference"), reason="needs node and the reference tree (build container only)")
+def test_differential_campaigns_against_the_live_reference_emulated():
+    """Engine (emulated kernels, addon called directly: no JS fallback in between) against the live reference: unusual values / keys
+    (patch text, materialised patch, save, load) and the history of damaged documents. The engine may refuse; it must never differ."""
+    env = _emu_env(NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"))
+    out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "values_campaign.js")], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "DISAGREE 0" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "history_campaign.js"), "12", "3"], capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0 and "DISAGREE 0" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_js_host_reproduces_all_reference_suite_vectors_on_gpu():
