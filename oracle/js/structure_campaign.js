@@ -111,6 +111,19 @@ for (let k = 0; k < nScenarios; k++) {
   } catch (e) {
     if (soft(e)) { refused++; console.log(`(engine refuses ${name}: ${e.message.slice(0, 120)})`) } else throw e
   }
+  // the same changes in a random delivery order, with duplicates; and with some changes missing (their dependents stay queued)
+  const rnd = rng(seed0 * 7919 + k)
+  const shuffled = changes.slice().sort(() => rnd() - 0.5)
+  shuffled.push(changes[Math.floor(rnd() * changes.length)])
+  const holes = changes.filter(() => rnd() > 0.15).sort(() => rnd() - 0.5)
+  for (const [what, batch] of [['patch (shuffled delivery + a duplicate)', shuffled], ['patch (changes missing)', holes]]) {
+    let want
+    try { want = JSON.stringify(Backend.getPatch(Backend.loadChanges(Backend.init(), batch))) } catch (e) { console.log(`(reference throws on ${what} of ${name}: ${e.message})`); continue }
+    try {
+      addon.loadChanges(ctx, batch); addon.replay(ctx)
+      check(what, name, JSON.stringify(materialize(addon.fetchIR(ctx))), want)
+    } catch (e) { if (!soft(e)) throw e; refused++; console.log(`(engine refuses ${what} of ${name}: ${e.message.slice(0, 100)})`) }
+  }
 }
 console.log(`${nScenarios} scenarios: ${same} results identical, ${refused} refusals, DISAGREE ${bad}`)
 process.exit(bad ? 1 : 0)

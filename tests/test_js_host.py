@@ -88,7 +88,7 @@ def test_differential_campaigns_against_the_live_reference_emulated():
     assert out.returncode == 0 and "DISAGREE 0" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
     # tables, bulk list operations (multi-insert / multi-delete ops), lists of lists, containers replaced by scalars: 5 results per scenario
     out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "structure_campaign.js"), "12", "9"], capture_output=True, text=True, env=env, timeout=1500)
-    assert out.returncode == 0 and "DISAGREE 0" in out.stdout and "60 results identical" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.returncode == 0 and "DISAGREE 0" in out.stdout and "84 results identical" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 @pytest.mark.gpu
