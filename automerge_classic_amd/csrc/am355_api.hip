@@ -1088,7 +1088,11 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
   {
     constexpr uint32_t UNSET = 0xffffffffu, NEVER = 0xfffffffeu, BUSY = 0xfffffffdu;
     std::vector<uint32_t> pass(n, UNSET), stack;
-    auto dep_of = [&](uint32_t ci, uint32_t k) { const ChangeMeta& m = metas[ci]; return dep_idx[(m.base + m.deps_off + 32ull * k) >> 5]; };
+    // (dependency list of a change as a compact (first, count) pair: the walk below visits every edge twice and the change records
+    // are 176 bytes apart)
+    std::vector<uint32_t> dep_first(n), dep_count(n);
+    for (uint32_t ci = 0; ci < n; ci++) { const ChangeMeta& m = metas[ci]; dep_first[ci] = (uint32_t)((m.base + m.deps_off) >> 5); dep_count[ci] = m.n_deps; }
+    auto dep_of = [&](uint32_t ci, uint32_t k) { return dep_idx[dep_first[ci] + k]; };
     for (uint32_t root = 0; root < n; root++) {
       if (pass[root] != UNSET) continue;
       stack.push_back(root);
@@ -1097,7 +1101,7 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
         if (pass[ci] != UNSET && pass[ci] != BUSY) { stack.pop_back(); continue; }
         uint32_t first = self[ci] < n ? self[ci] : ci;
         if (first != ci) { pass[ci] = NEVER; stack.pop_back(); continue; }  // a later copy: never applied itself
-        const uint32_t nd = metas[ci].n_deps;
+        const uint32_t nd = dep_count[ci];
         bool pushed = false;
         uint32_t p = 0;
         for (uint32_t k = 0; k < nd; k++) {
@@ -1138,7 +1142,7 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
       if (m.seq != clock[author] + 1) { sched_flags |= AM355_F_BAD_SEQ; break; }
       if (!has_clock[author]) { has_clock[author] = 1; c->clock_actor.push_back(author); }
       clock[author] = m.seq;
-      for (uint32_t k = 0; k < m.n_deps; k++) is_head[dep_of(ci, k)] = 0;
+      for (uint32_t k = 0, nd = dep_count[ci]; k < nd; k++) is_head[dep_of(ci, k)] = 0;
       is_head[ci] = 1;
     }
     // each change may only mention actors already in the document when it is read: the reference reads the changes of a pass
