@@ -650,6 +650,7 @@ typedef struct slot {
   struct slot *hnext;
 } slot_t;
 
+struct chkey;
 typedef struct obj {
   opid_t id;      /* ctr 0 = _root */
   int type;       /* action code of the make op; 0 for root (map) */
@@ -657,6 +658,16 @@ typedef struct obj {
   slot_t **slots; /* hash buckets */
   uint32_t n_slots, n_buckets;
   uint64_t n_elems;
+  /* ---- session documents only (amo_apply_changes, am_oracle_apply.c) ---- */
+  int has_meta;                 /* docState.objectMeta[objectId] exists (new.js:894-897) */
+  struct obj *parent;           /* objectMeta.parentObj (NULL: _root) */
+  opid_t parent_elem;           /* objectMeta.parentKey when the parent is a list / text object ... */
+  const uint8_t *parent_key;    /* ... or a string key */
+  uint32_t parent_key_len;
+  struct chkey *children;       /* objectMeta.children: key / elemId -> { opId: value } */
+  slot_t **sorted;              /* map keys in document order (UTF-16 code unit order, new.js:84) */
+  uint32_t n_sorted, cap_sorted;
+  uint32_t touch_epoch;         /* member of the `objectIds` set of the running applyChanges call */
 } obj_t;
 
 /* generic open-addressing table: 64-bit key -> pointer */
@@ -723,6 +734,14 @@ struct amo_doc {
   uint64_t n_objs, cap_objs;
   sbuf_t json;
   int json_done;
+  /* ---- session documents (amo_init / amo_apply_changes): what a BackendDoc keeps between calls ---- */
+  int session, loaded, meta_built;
+  tab_t known;            /* changeIndexByHash: hashes of the applied changes */
+  struct qchange *queue;  /* this.queue: changes waiting for a dependency */
+  uint32_t n_queue;
+  uint32_t actors_read;   /* actors whose first change has been read (getActorTable, new.js:1434-1451) */
+  uint32_t epoch;
+  sbuf_t apply_json;
 };
 
 /* actor order = order of the hex strings = bytewise order, shorter prefix first (new.js:65,1180,1198) */
@@ -1077,8 +1096,10 @@ amo_doc *amo_replay(const uint8_t *arena, const uint64_t *offsets, uint32_t n, c
   return d;
 }
 
+static void session_free(amo_doc *d);
 void amo_free(amo_doc *d) {
   if (!d) return;
+  session_free(d);
   for (uint64_t i = 0; i < d->n_objs; i++) free(d->obj_list[i]->slots);
   free(d->root.slots);
   free(d->obj_list);
@@ -1842,6 +1863,61 @@ static int json_pobj(pctx_t *c, sbuf_t *b, pobj_t *p) {
   return 0;
 }
 
+/* {"maxOp":..,"clock":{..},"deps":[..],"pendingChanges":n,"diffs":  -- new.js:1870-1873, 2064-2067 */
+static void json_envelope(amo_doc *d, sbuf_t *b) {
+  char t[64];
+  /* envelope key order: maxOp, clock, deps, pendingChanges, diffs (new.js:2064-2067) */
+  snprintf(t, sizeof t, "{\"maxOp\":%llu,\"clock\":{", (unsigned long long)d->max_op);
+  sb_puts(b, t);
+  {
+    /* clock keys are hex actor ids in first-applied order, except integer-like keys go first */
+    static const char hx[] = "0123456789abcdef";
+    uint32_t nc = d->clock_order ? d->n_clock : d->n_actors;
+    idxkey_t *idx = (idxkey_t *)malloc(sizeof(idxkey_t) * (nc ? nc : 1));
+    char **hex = (char **)malloc(sizeof(char *) * (nc ? nc : 1));
+    uint64_t ni = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+      uint32_t i = d->clock_order ? d->clock_order[k] : k;
+      hex[k] = (char *)malloc(d->actors[i].len * 2 + 1);
+      for (size_t j = 0; j < d->actors[i].len; j++) { hex[k][2 * j] = hx[d->actors[i].p[j] >> 4]; hex[k][2 * j + 1] = hx[d->actors[i].p[j] & 15]; }
+      hex[k][d->actors[i].len * 2] = 0;
+      uint64_t v;
+      if (array_index_key((const uint8_t *)hex[k], d->actors[i].len * 2, &v)) { idx[ni].num = v; idx[ni].pos = k; ni++; }
+    }
+    qsort(idx, ni, sizeof(idxkey_t), cmp_idxkey);
+    int first = 1;
+    for (uint64_t q = 0; q < ni; q++) {
+      uint32_t k = (uint32_t)idx[q].pos, i = d->clock_order ? d->clock_order[k] : k;
+      snprintf(t, sizeof t, "\":%llu", (unsigned long long)d->clock[i]);
+      if (!first) sb_putc(b, ',');
+      first = 0;
+      sb_putc(b, '"'); sb_puts(b, hex[k]); sb_puts(b, t);
+    }
+    for (uint32_t k = 0; k < nc; k++) {
+      uint32_t i = d->clock_order ? d->clock_order[k] : k;
+      uint64_t v;
+      if (array_index_key((const uint8_t *)hex[k], d->actors[i].len * 2, &v)) continue;
+      snprintf(t, sizeof t, "\":%llu", (unsigned long long)d->clock[i]);
+      if (!first) sb_putc(b, ',');
+      first = 0;
+      sb_putc(b, '"'); sb_puts(b, hex[k]); sb_puts(b, t);
+    }
+    for (uint32_t k = 0; k < nc; k++) free(hex[k]);
+    free(hex);
+    free(idx);
+  }
+  sb_puts(b, "},\"deps\":[");
+  for (uint32_t i = 0; i < d->n_heads; i++) {
+    static const char hx[] = "0123456789abcdef";
+    if (i) sb_putc(b, ',');
+    sb_putc(b, '"');
+    for (int k = 0; k < 32; k++) { sb_putc(b, hx[d->heads[32 * i + k] >> 4]); sb_putc(b, hx[d->heads[32 * i + k] & 15]); }
+    sb_putc(b, '"');
+  }
+  snprintf(t, sizeof t, "],\"pendingChanges\":%u,\"diffs\":", d->n_pending);
+  sb_puts(b, t);
+}
+
 const char *amo_patch_json(amo_doc *d, size_t *len, char *errbuf, size_t errcap) {
   if (d->json_done) { if (len) *len = d->json.len; return d->json.p; }
   err_t e = {{0}, 0};
@@ -1889,57 +1965,7 @@ const char *amo_patch_json(amo_doc *d, size_t *len, char *errbuf, size_t errcap)
 
   if (!rc) {
     sbuf_t *b = &d->json;
-    char t[64];
-    /* envelope key order: maxOp, clock, deps, pendingChanges, diffs (new.js:2064-2067) */
-    snprintf(t, sizeof t, "{\"maxOp\":%llu,\"clock\":{", (unsigned long long)d->max_op);
-    sb_puts(b, t);
-    {
-      /* clock keys are hex actor ids in first-applied order, except integer-like keys go first */
-      static const char hx[] = "0123456789abcdef";
-      uint32_t nc = d->clock_order ? d->n_clock : d->n_actors;
-      idxkey_t *idx = (idxkey_t *)malloc(sizeof(idxkey_t) * (nc ? nc : 1));
-      char **hex = (char **)malloc(sizeof(char *) * (nc ? nc : 1));
-      uint64_t ni = 0;
-      for (uint32_t k = 0; k < nc; k++) {
-        uint32_t i = d->clock_order ? d->clock_order[k] : k;
-        hex[k] = (char *)malloc(d->actors[i].len * 2 + 1);
-        for (size_t j = 0; j < d->actors[i].len; j++) { hex[k][2 * j] = hx[d->actors[i].p[j] >> 4]; hex[k][2 * j + 1] = hx[d->actors[i].p[j] & 15]; }
-        hex[k][d->actors[i].len * 2] = 0;
-        uint64_t v;
-        if (array_index_key((const uint8_t *)hex[k], d->actors[i].len * 2, &v)) { idx[ni].num = v; idx[ni].pos = k; ni++; }
-      }
-      qsort(idx, ni, sizeof(idxkey_t), cmp_idxkey);
-      int first = 1;
-      for (uint64_t q = 0; q < ni; q++) {
-        uint32_t k = (uint32_t)idx[q].pos, i = d->clock_order ? d->clock_order[k] : k;
-        snprintf(t, sizeof t, "\":%llu", (unsigned long long)d->clock[i]);
-        if (!first) sb_putc(b, ',');
-        first = 0;
-        sb_putc(b, '"'); sb_puts(b, hex[k]); sb_puts(b, t);
-      }
-      for (uint32_t k = 0; k < nc; k++) {
-        uint32_t i = d->clock_order ? d->clock_order[k] : k;
-        uint64_t v;
-        if (array_index_key((const uint8_t *)hex[k], d->actors[i].len * 2, &v)) continue;
-        snprintf(t, sizeof t, "\":%llu", (unsigned long long)d->clock[i]);
-        if (!first) sb_putc(b, ',');
-        first = 0;
-        sb_putc(b, '"'); sb_puts(b, hex[k]); sb_puts(b, t);
-      }
-      for (uint32_t k = 0; k < nc; k++) free(hex[k]);
-      free(hex);
-      free(idx);
-    }
-    sb_puts(b, "},\"deps\":[");
-    for (uint32_t i = 0; i < d->n_heads; i++) {
-      static const char hx[] = "0123456789abcdef";
-      if (i) sb_putc(b, ',');
-      sb_putc(b, '"');
-      for (int k = 0; k < 32; k++) { sb_putc(b, hx[d->heads[32 * i + k] >> 4]); sb_putc(b, hx[d->heads[32 * i + k] & 15]); }
-      sb_putc(b, '"');
-    }
-    snprintf(t, sizeof t, "],\"pendingChanges\":%u,\"diffs\":", d->n_pending);
-    sb_puts(b, t);
+    json_envelope(d, b);
     rc = json_pobj(&c, b, &root);
     if (!rc) sb_putc(b, '}');
   }
@@ -2304,3 +2330,5 @@ void amo_decoded_free(amo_decoded_t *o) {
   free(o->pred_actor); free(o->raw);
   free(o);
 }
+
+#include "am_oracle_apply.c"

@@ -43,6 +43,20 @@ const char *amo_patch_json(amo_doc *doc, size_t *len, char *err, size_t errcap);
 
 void amo_free(amo_doc *doc);
 
+/*
+ * Backend.applyChanges(state, changes) with the INCREMENTAL patch it returns (am_oracle_apply.c restates
+ * new.js:1797-1879, 1550-1597, 1052-1290 mergeDocChangeOps line by line, 884-1040 updatePatchProperty in its incremental mode,
+ * 747-869, 1461-1528 setupPatches).  A session document starts with amo_init() (Backend.init()) or amo_load_document() and is
+ * advanced call by call, as the reference was called.  Returns JSON.stringify(patch) (owned by the doc, valid until the next
+ * call) or NULL with `err` filled when the reference would throw ("unsupported:" for what this restatement refuses); after an
+ * error the document is unusable (the reference leaves it unchanged: rebuild it).  is_local: the call came from
+ * applyLocalChange (the patch of a single change then carries `actor` and `seq`, new.js:1874-1877).
+ * amo_patch_json(doc) afterwards gives Backend.getPatch of the same state.
+ */
+amo_doc *amo_init(void);
+const char *amo_apply_changes(amo_doc *doc, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes, int is_local,
+                              size_t *len, char *err, size_t errcap);
+
 /* ---- introspection used by stage-level parity tests ---- */
 uint32_t amo_num_changes(const amo_doc *doc);          /* changes given */
 uint32_t amo_num_applied(const amo_doc *doc);          /* changes applied (rest are pending) */

@@ -11,8 +11,8 @@ LIB = os.path.join(ORACLE_DIR, "libam_oracle.so")
 
 
 def build():
-    src = os.path.join(ORACLE_DIR, "am_oracle.c")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("am_oracle.c", "am_oracle_apply.c", "am_oracle.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(src) for src in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
 
 
@@ -31,6 +31,11 @@ def lib():
         L.amo_patch_json.restype = ctypes.c_void_p
         L.amo_patch_json.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.c_size_t]
         L.amo_free.argtypes = [ctypes.c_void_p]
+        L.amo_init.restype = ctypes.c_void_p
+        L.amo_init.argtypes = []
+        L.amo_apply_changes.restype = ctypes.c_void_p
+        L.amo_apply_changes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.c_size_t]
         L.amo_sha256.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         for name, rt in [("amo_num_changes", ctypes.c_uint32), ("amo_num_applied", ctypes.c_uint32),
                          ("amo_num_ops", ctypes.c_uint64), ("amo_max_op", ctypes.c_uint64),
@@ -122,6 +127,59 @@ class OracleDoc:
         lib().amo_rows(self._h, *[a[k].ctypes.data for k in
                                   ("id_ctr", "id_actor", "obj_ctr", "obj_actor", "insert", "action", "succ_num")])
         return a
+
+    def close(self):
+        if self._h:
+            lib().amo_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OracleSession:
+    """A BackendDoc advanced call by call: Backend.init() (or Backend.load(doc)) followed by Backend.applyChanges calls, each
+    returning the incremental patch of that call as the oracle restates it (am_oracle_apply.c)."""
+
+    def __init__(self, doc_bytes: bytes = None):
+        L = lib()
+        self._keep = []
+        if doc_bytes is None:
+            self._h = L.amo_init()
+        else:
+            buf = np.frombuffer(doc_bytes, dtype=np.uint8).copy()
+            err = ctypes.create_string_buffer(512)
+            self._h = L.amo_load_document(buf.ctypes.data, buf.size, err, 512)
+            if not self._h:
+                raise OracleError(err.value.decode())
+
+    def apply(self, changes, local=False) -> str:
+        """changes: list of bytes. Returns JSON.stringify(patch); raises OracleError (the session is then dead)."""
+        if self._h is None:
+            raise OracleError("session is dead")
+        arena = np.frombuffer(b"".join(changes), dtype=np.uint8).copy() if changes else np.zeros(1, np.uint8)
+        offsets = np.zeros(len(changes) + 1, np.uint64)
+        np.cumsum([len(c) for c in changes], out=offsets[1:])
+        n = ctypes.c_size_t()
+        err = ctypes.create_string_buffer(512)
+        p = lib().amo_apply_changes(self._h, arena.ctypes.data, offsets.ctypes.data, len(changes), 1 if local else 0, ctypes.byref(n), err, 512)
+        if not p:
+            lib().amo_free(self._h)
+            self._h = None
+            raise OracleError(err.value.decode())
+        return ctypes.string_at(p, n.value).decode("utf-8")
+
+    def patch_json(self) -> str:
+        """Backend.getPatch of the current state."""
+        n = ctypes.c_size_t()
+        err = ctypes.create_string_buffer(512)
+        p = lib().amo_patch_json(self._h, ctypes.byref(n), err, 512)
+        if not p:
+            raise OracleError(err.value.decode())
+        return ctypes.string_at(p, n.value).decode("utf-8")
 
     def close(self):
         if self._h:
