@@ -16,6 +16,8 @@
 #include "am355_render.h"
 #include "am355_host.h"
 #include "am355_history.h"
+#include "am355_delta.h"
+#include "am355_apply.h"
 
 #include <zlib.h>
 
@@ -303,6 +305,16 @@ struct am355_ctx {
 
   am355_stats stats{};
 
+  // incremental applyChanges (am355_apply_changes)
+  std::vector<uint32_t> pending_change;   // queued changes (input indexes, queue order) after the last replay
+  std::vector<uint32_t> pass_first_row;   // first op row of every scheduling pass after the first (general scheduler)
+  DevBuf d_delta, d_pass;
+  HostBuf h_delta;
+  DeltaBufs delta{};
+  ApplyPatch apply;
+  bool apply_ready = false;
+  std::string apply_json;
+
   // objectId sharding (am355_set_shard): this context merges the objects rank `shard_rank` of `shard_world` owns
   uint32_t shard_rank = 0, shard_world = 1;
   std::vector<uint8_t> stitched;  // am355_import_fragments: the combined record tables
@@ -408,6 +420,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
+  c->d_delta.release(); c->d_pass.release(); c->h_delta.release();
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
@@ -443,6 +456,7 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   (void)hipSetDevice(c->device);
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
   c->staged = c->replayed = c->ir_fetched = false;
+  c->apply_ready = false;
   c->is_document = false;
   c->flags = 0;
   if (n && offsets[n] - offsets[0] >= ((uint64_t)1 << 20))
@@ -1083,7 +1097,7 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
   // infinite if a dependency is not in the batch or is itself never applied; the application order is (pass, position). Later copies
   // of a change are dropped once the first copy is applied. One memoised walk over the dependency edges instead of one scan of the
   // queue per pass (64 synced rounds delivered in random order need dozens of passes).
-  std::vector<uint32_t> applied_all;
+  std::vector<uint32_t> applied_all, applied_pass;
   uint32_t sched_flags = 0, n_pending = 0;
   {
     constexpr uint32_t UNSET = 0xffffffffu, NEVER = 0xfffffffeu, BUSY = 0xfffffffdu;
@@ -1131,10 +1145,13 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
     for (uint32_t ci = 0; ci < n; ci++)
       if (pass[ci] < BUSY) applied_all[start[pass[ci]]++] = ci;
     // what stays queued: changes never applied whose first copy is never applied either
+    c->pending_change.clear();
     for (uint32_t ci = 0; ci < n; ci++) {
       uint32_t first = self[ci] < n ? self[ci] : ci;
-      if (pass[first] >= BUSY) n_pending++;
+      if (pass[first] >= BUSY) { n_pending++; c->pending_change.push_back(ci); }
     }
+    applied_pass.resize(applied_all.size());
+    for (size_t t = 0; t < applied_all.size(); t++) applied_pass[t] = pass[applied_all[t]];
     // sequence numbers, clock, heads and the actor rule in application order (new.js:1571-1578, 1582-1583, 1442-1449)
     for (uint32_t ci : applied_all) {
       const ChangeMeta& m = metas[ci];
@@ -1189,8 +1206,11 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
   std::vector<std::vector<ActorSpan>> per_actor(na);
   c->applied_change.clear();
   c->applied_op_base.clear();
-  for (uint32_t ci : applied_all) {
+  c->pass_first_row.clear();
+  for (size_t t = 0; t < applied_all.size(); t++) {
+    uint32_t ci = applied_all[t];
     const ChangeMeta& m = metas[ci];
+    if (t > 0 && applied_pass[t] != applied_pass[t - 1]) c->pass_first_row.push_back((uint32_t)ops);  // (am355_apply_changes: a merge call never spans two passes)
     c->applied_change.push_back(ci);  // (changes without ops are applied too: they have no plan, but a place in the history)
     c->applied_op_base.push_back((uint32_t)ops);
     ChangePlan pl;
@@ -1330,6 +1350,8 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
   }
   c->n_applied = n;
   c->n_pending = 0;
+  c->pending_change.clear();
+  c->pass_first_row.clear();
   c->n_ops = ops;
   c->n_preds = preds;
   c->max_op = max_op;
@@ -2046,6 +2068,116 @@ static int patch_json_impl(am355_ctx* c, const char** json, size_t* len) {
   return AM355_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Backend.applyChanges with its incremental patch (include/am355.h am355_apply_changes)
+// ---------------------------------------------------------------------------------------------------------
+static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
+  if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
+  (void)hipSetDevice(c->device);
+  c->apply_ready = false;
+  if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_apply_changes on a sharded context");
+  const bool have_state = c->staged;
+  if (have_state && c->is_document) return fail(c, AM355_E_UNSUPPORTED, "the state was made by am355_load_document: applyChanges onto it is served by the JS path");
+  if (have_state && !c->replayed) return fail(c, AM355_E_STATE, "the context holds no replayed state (the last replay failed?)");
+  for (uint32_t i = 0; i < n; i++)
+    if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
+  // ---- the queue of the call: changes applied so far (application order) | the batch | changes still queued (new.js:1822) ----
+  const uint32_t n_old_applied = have_state ? (uint32_t)c->applied_change.size() : 0;
+  const uint64_t old_ops = have_state ? c->n_ops : 0;
+  std::vector<uint8_t> comb;
+  std::vector<uint64_t> off;
+  {
+    size_t bytes = (size_t)(offsets[n] - offsets[0]);
+    if (have_state) bytes += c->raw.size();
+    comb.reserve(bytes + 64);
+    off.reserve((size_t)n_old_applied + n + c->pending_change.size() + 1);
+    off.push_back(0);
+    auto put_old = [&](uint32_t ci) {
+      const uint8_t* p = c->raw.data() + c->raw_off[ci];
+      comb.insert(comb.end(), p, p + (c->raw_off[ci + 1] - c->raw_off[ci]));
+      off.push_back(comb.size());
+    };
+    if (have_state) for (uint32_t ci : c->applied_change) put_old(ci);
+    for (uint32_t i = 0; i < n; i++) {
+      comb.insert(comb.end(), arena + offsets[i], arena + offsets[i + 1]);
+      off.push_back(comb.size());
+    }
+    if (have_state) for (uint32_t ci : c->pending_change) put_old(ci);
+  }
+  const uint32_t total_n = (uint32_t)off.size() - 1;
+  int rc = load_changes_impl(c, comb.data(), off.data(), total_n);
+  if (rc) { c->staged = false; return rc; }
+  rc = replay_impl(c);
+  if (rc) { c->staged = false; return rc; }
+  // the earlier changes must have been applied again, first and in their order: rows [0, old_ops) are the state before the call
+  bool prefix_ok = c->applied_change.size() >= n_old_applied && c->n_ops >= old_ops;
+  for (uint32_t i = 0; prefix_ok && i < n_old_applied; i++) prefix_ok = c->applied_change[i] == i;
+  if (prefix_ok && n_old_applied < c->applied_change.size()) prefix_ok = c->applied_op_base[n_old_applied] == old_ops;
+  if (!prefix_ok) { c->staged = false; return fail(c, AM355_E_DEVICE, "internal: the earlier changes were not re-applied first"); }
+
+  // ---- delta stage on the device ----
+  hipStream_t st = c->stream;
+  const uint32_t N = (uint32_t)c->n_ops, T0 = (uint32_t)old_ops, NN = N - T0;
+  const uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NL = c->counts.n_list_ins;
+  if (c->pass_first_row.size() > 4096) return fail(c, AM355_E_UNSUPPORTED, "more scheduling passes than the incremental patch stage handles");
+  if (!c->d_delta.ensure(delta_bytes(N, NN, NM, NO, NL)) || !c->d_pass.ensure(4 * (c->pass_first_row.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
+  DeltaBufs& d = c->delta;
+  delta_bind(d, c->d_delta.p, N, NN, NM, NO, NL);
+  d.T0 = T0; d.n_new = NN; d.n_obj = NO; d.n_map = NM; d.n_list = NL;
+  d.bits_new = (uint32_t)bits_for64(NN ? NN - 1 : 0);
+  std::vector<uint32_t> pass_rows;
+  for (uint32_t r : c->pass_first_row) if (r > T0) pass_rows.push_back(r);
+  d.n_pass = (uint32_t)pass_rows.size();
+  d.pass_rows = c->d_pass.as<uint32_t>();
+  if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
+  DeltaCounts hc{};
+  if (d.n_pass) HIPCHK(c, hipStreamSynchronize(st));  // (pass_rows is pageable memory)
+  delta_run(c->mb, c->ir, d, &hc, st);
+  HIPCHK(c, hipGetLastError());
+  if (hc.flags) return error_for_flags(c, hc.flags, "incremental patch not served");
+
+  // ---- tables to the host, setupPatches, assembly ----
+  rc = fetch_ir_impl(c, nullptr);
+  if (rc) return rc;
+  const uint32_t n_dmap = hc.n_kept + hc.n_place, n_dedits = hc.n_erecs;
+  size_t b_link = carve_size(NO, sizeof(ObjLink)), b_map = carve_size(n_dmap, sizeof(am355_ir_map)), b_edit = carve_size((size_t)n_dedits + 1, sizeof(am355_ir_edit));
+  if (!c->h_delta.ensure(b_link + b_map + b_edit + 256)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+  uint8_t* hp = c->h_delta.as<uint8_t>();
+  ObjLink* h_link = (ObjLink*)hp;
+  am355_ir_map* h_map = (am355_ir_map*)(hp + b_link);
+  am355_ir_edit* h_edit = (am355_ir_edit*)(hp + b_link + b_map);
+  HIPCHK(c, hipMemcpyAsync(h_link, d.link, sizeof(ObjLink) * (size_t)NO, hipMemcpyDeviceToHost, st));
+  if (n_dmap) HIPCHK(c, hipMemcpyAsync(h_map, d.map, sizeof(am355_ir_map) * (size_t)n_dmap, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(h_edit, d.edit, sizeof(am355_ir_edit) * ((size_t)n_dedits + 1), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  std::string err;
+  rc = assemble_apply_patch(c->hir, h_link, h_map, n_dmap, h_edit, n_dedits, c->apply, err);
+  if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; return fail(c, rc, "%s", err.c_str()); }
+  c->apply_ready = true;
+  c->apply_json.clear();
+  return AM355_OK;
+}
+
+static int apply_patch_json_impl(am355_ctx* c, const char** json, size_t* len) {
+  if (!c) return AM355_E_ARG;
+  if (!c->apply_ready) return fail(c, AM355_E_STATE, "am355_apply_changes must succeed first");
+  if (c->apply_json.empty()) {
+    std::string err;
+    if (!am355::render_patch_json(c->apply.ir, c->apply_json, err)) { c->apply_json.clear(); return fail(c, AM355_E_UNSUPPORTED, "%s", err.c_str()); }
+  }
+  if (json) *json = c->apply_json.c_str();
+  if (len) *len = c->apply_json.size();
+  return AM355_OK;
+}
+
+extern "C" int am355_fetch_apply_ir(am355_ctx* c, am355_patch_ir* out) {
+  if (!c) return AM355_E_ARG;
+  if (!c->apply_ready) return fail(c, AM355_E_STATE, "am355_apply_changes must succeed first");
+  if (out) *out = c->apply.ir;
+  return AM355_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // diagnostics
 // ---------------------------------------------------------------------------------------------------------
@@ -2749,3 +2881,5 @@ extern "C" int am355_patch_json(am355_ctx* c, const char** json, size_t* len) { 
 extern "C" int am355_save(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, size_t* out_len) { return guarded(c, [&]() { return save_impl(c, flags, out_bytes, out_len); }); }
 extern "C" int am355_doc_changes(am355_ctx* c, uint32_t flags, const uint8_t** arena, const uint64_t** offsets, uint32_t* n, const uint8_t** hashes) { return guarded(c, [&]() { return doc_changes_impl(c, flags, arena, offsets, n, hashes); }); }
 extern "C" int am355_import_fragments(am355_ctx* c, const uint8_t* frags, const uint64_t* offsets, uint32_t world) { return guarded(c, [&]() { return import_fragments_impl(c, frags, offsets, world); }); }
+extern "C" int am355_apply_changes(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) { return guarded(c, [&]() { return apply_changes_impl(c, arena, offsets, n); }); }
+extern "C" int am355_apply_patch_json(am355_ctx* c, const char** json, size_t* len) { return guarded(c, [&]() { return apply_patch_json_impl(c, json, len); }); }

@@ -1,0 +1,78 @@
+// Incremental patch of Backend.applyChanges: device stage that runs after a replay of (earlier changes + the new
+// batch) and derives, from the merged state and from which rows are new, what the reference's sequential patch state machine
+// reports for the batch (see am355_delta.hip).
+#pragma once
+#include "am355_merge.h"
+
+namespace am355 {
+
+// per object (index as in PatchIR.obj): where it hangs in its parent, whether this call touched it, its ranges in the delta tables
+struct ObjLink {
+  uint32_t parent;                // object index of the parent (NONE32: _root)
+  uint32_t flags;                 // OL_* bits
+  uint32_t key_off, key_len;      // map / table parent: key of the make op (arena bytes)
+  uint32_t elem_ctr, elem_actor;  // list / text parent: id of the element that holds the object
+  uint32_t touch;                 // first new row (counted from the first new row) that names this object, NONE32: untouched
+  uint32_t map_begin, map_end;    // its records in the delta map table
+  uint32_t edit_begin, edit_end;  // its records in the delta edit table
+  uint32_t pad;
+};
+enum : uint32_t {
+  OL_LIST_PARENT = 1u,  // the parent is a list / text object
+  OL_VISIBLE = 2u,      // the make op has no successor (the object is a visible value of its parent's property)
+  OL_ELEM_NEW = 4u      // list parent: the element was inserted by this call
+};
+
+struct DeltaCounts {
+  uint32_t flags;      // Flag bits (F_UNSUPPORTED: outside the subset served here)
+  uint32_t n_items;    // list edit items (inserts of new elements + first deletions of visible elements)
+  uint32_t n_kept;     // visible values of touched map keys
+  uint32_t n_place;    // touched map keys left without a visible value
+  uint32_t n_erecs;    // delta edit records
+  uint32_t n_slots;    // touched map keys
+  uint32_t pad[2];
+};
+
+// Device memory of the delta stage, carved by the caller (delta_bytes / delta_bind). N = op rows, NN = new rows, NM = map records
+// of the whole-document IR, NO = objects.
+struct DeltaBufs {
+  uint32_t T0;            // first new row
+  uint32_t n_new;         // N - T0
+  uint32_t n_obj;         // objects including _root
+  uint32_t n_map;         // records of ir.map
+  uint32_t n_list;        // list elements (positions of MergeBufs.order)
+  uint32_t bits_new;      // bits of a row number counted from T0
+  uint32_t n_pass;        // scheduling passes after the first that begin inside the new rows
+  const uint32_t* pass_rows;  // [n_pass] first row of each such pass
+  DeltaCounts* counts;
+  ObjLink* link;          // [NO]
+  // rows
+  uint32_t *first_del, *new_succ, *has_upd, *pos_of;  // [N]
+  // list positions
+  uint32_t *v0, *icnt, *v0_ex, *item_ex;              // [n_list + 1]
+  // items (ping-pong), [NN + 1]
+  uint32_t *tk[2], *elem[2], *acc[2], *lo[2], *hi[2];
+  uint32_t *zf, *zw, *zf_ex, *zw_ex;                  // [NN + 2]
+  uint32_t *e_index, *e_flags, *e_head, *e_head_ex;   // [NN + 1]
+  am355_ir_edit* edit;                                // [NN + 2]
+  // touched map keys: open-addressing table of cap slots (power of two)
+  uint32_t key_mask;
+  uint32_t *slot_rep, *slot_first, *slot_last, *slot_cont, *slot_cnt, *slot_child, *slot_drop, *place, *place_ex;  // [cap + 1]
+  unsigned long long* slot_L;                         // [cap]
+  // map records
+  uint32_t *keep, *keep_ex, *rec_slot;                // [NM + 1]
+  uint64_t *pair_key[2];                              // [NM + cap + 1]
+  uint32_t *pair_val[2];
+  am355_ir_map* map;                                  // [NM + cap + 1]
+  void* scan_ws;
+  void* sort_ws;
+};
+
+size_t delta_bytes(uint32_t n_ops, uint32_t n_new, uint32_t n_map, uint32_t n_obj, uint32_t n_list);
+void delta_bind(DeltaBufs& d, void* block, uint32_t n_ops, uint32_t n_new, uint32_t n_map, uint32_t n_obj, uint32_t n_list);
+
+// Runs the stage on `st` and synchronises it. On return *hc holds the counters (hc->flags != 0: refused / invalid), the delta tables
+// d.edit [n_erecs + 1], d.map [n_kept + n_place] and d.link [n_obj] are complete in device memory.
+void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st);
+
+}  // namespace am355

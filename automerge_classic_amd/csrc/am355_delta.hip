@@ -1,0 +1,503 @@
+// Incremental patch of Backend.applyChanges(state, changes) as data-parallel kernels.
+//
+// The reference builds that patch op by op while it merges the batch into its document (backend/new.js:1052-1290
+// mergeDocChangeOps calling :884-1040 updatePatchProperty in its incremental mode, :747-782 appendEdit, :1461-1528 setupPatches):
+// list edits carry the index the element had AT THE MOMENT the op was applied, map properties list what is visible after the last
+// op of the batch that touched the key.  Here the whole log (earlier changes + the batch) has just been replayed, so the final
+// state is known -- every element's position in its list (MergeBufs.order), every row's successor count -- and rows are numbered in
+// application order, which makes "time" a row number: rows >= T0 are the batch.  The patch follows from the final state and time:
+//
+//   list object   insert edit for every new element e at time t(e) = its row; remove edit for every element that was visible and
+//                 whose first deletion d is a new row, at time t(d).  index(x, t) = visible elements in front of x at time t
+//                   = V0(x)                                  elements in front that were visible before the batch (prefix sum)
+//                   + #{new elements in front of x inserted before t} - #{elements in front of x removed before t}
+//                 -- a dominance count over (position, time), done for all edits at once by stable binary partitions on the bits of
+//                 the time (most significant first) of the edits laid out in position order: at every level an edit whose bit is 1
+//                 adds the (signed) number of edits of its group with bit 0 in front of it.  The partitions END with the edits of
+//                 each object in time order, which is the order of the reference's `edits` array; runs of consecutive inserts
+//                 become multi-insert records and runs of removes at one index one record (appendEdit, new.js:754-777).
+//   map object    for every key a new row names: its visible values in op id order (`props[key] = {}` when none is left).  The one
+//                 order-dependent rule of the merge loop that shows in a patch is reproduced: when the call that handled the
+//                 key's last op went on to a greater key of the same object (new.js:1125-1129), the document ops of the key with
+//                 a greater id than that last op are never looked at (new.js:1140-1149 keeps the stale `changeOp`), and their
+//                 values are missing from the patch.
+//   object links  am355_api.hip (host): setupPatches over the object table, from ObjLink.
+//
+// Served subset (anything else raises F_UNSUPPORTED and the call is served by the JS path): list elements named by the batch hold
+// exactly one row, their insert -- i.e. the batch inserts and deletes list elements but assigns to none, and deletes no element that
+// holds conflicting values; no objectId sharding.  (Assignments to list elements run into order-dependent edit rewriting --
+// appendUpdate popping earlier edits, an index that lags when the previous element of the same call stays visible, new.js:1203
+// before :1236-1239 -- which the sequential oracle restates and this stage does not.)
+#include "am355_delta.h"
+#include "am355_prims.h"
+#include "am355_rows.h"
+
+namespace am355 {
+
+static inline dim3 dgrid(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static uint32_t key_table_cap(uint32_t n_new) {
+  uint32_t cap = 64;
+  while (cap < 2 * (uint64_t)n_new + 16) cap <<= 1;
+  return cap;
+}
+
+size_t delta_bytes(uint32_t N, uint32_t NN, uint32_t NM, uint32_t NO, uint32_t NL) {
+  size_t cap = key_table_cap(NN);
+  size_t b = al256(sizeof(DeltaCounts)) + al256(sizeof(ObjLink) * ((size_t)NO + 1));
+  b += 4 * al256(4 * ((size_t)N + 1));
+  b += 4 * al256(4 * ((size_t)NL + 2));
+  b += 10 * al256(4 * ((size_t)NN + 2)) + 4 * al256(4 * ((size_t)NN + 3)) + 4 * al256(4 * ((size_t)NN + 2)) + al256(sizeof(am355_ir_edit) * ((size_t)NN + 2));
+  b += 9 * al256(4 * (cap + 1)) + al256(8 * cap);
+  b += 3 * al256(4 * ((size_t)NM + 1)) + 2 * al256(8 * ((size_t)NM + cap + 1)) + 2 * al256(4 * ((size_t)NM + cap + 1)) + al256(sizeof(am355_ir_map) * ((size_t)NM + cap + 1));
+  size_t biggest = std::max<size_t>({(size_t)N + 2, (size_t)NM + cap + 2, (size_t)NN + 4});
+  b += al256(scan_workspace_bytes((uint32_t)biggest)) + al256(sort_workspace_bytes((uint32_t)((size_t)NM + cap + 1)));
+  return b + 4096;
+}
+
+template <class T>
+static T* dcarve(uint8_t*& p, size_t count) {
+  T* r = (T*)p;
+  p += al256(count * sizeof(T));
+  return r;
+}
+
+void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM, uint32_t NO, uint32_t NL) {
+  uint8_t* p = (uint8_t*)block;
+  size_t cap = key_table_cap(NN);
+  d.key_mask = (uint32_t)cap - 1;
+  d.counts = dcarve<DeltaCounts>(p, 1);
+  d.link = dcarve<ObjLink>(p, (size_t)NO + 1);
+  d.first_del = dcarve<uint32_t>(p, (size_t)N + 1); d.new_succ = dcarve<uint32_t>(p, (size_t)N + 1);
+  d.has_upd = dcarve<uint32_t>(p, (size_t)N + 1); d.pos_of = dcarve<uint32_t>(p, (size_t)N + 1);
+  d.v0 = dcarve<uint32_t>(p, (size_t)NL + 2); d.icnt = dcarve<uint32_t>(p, (size_t)NL + 2);
+  d.v0_ex = dcarve<uint32_t>(p, (size_t)NL + 2); d.item_ex = dcarve<uint32_t>(p, (size_t)NL + 2);
+  for (int k = 0; k < 2; k++) {
+    d.tk[k] = dcarve<uint32_t>(p, (size_t)NN + 2); d.elem[k] = dcarve<uint32_t>(p, (size_t)NN + 2); d.acc[k] = dcarve<uint32_t>(p, (size_t)NN + 2);
+    d.lo[k] = dcarve<uint32_t>(p, (size_t)NN + 2); d.hi[k] = dcarve<uint32_t>(p, (size_t)NN + 2);
+  }
+  d.zf = dcarve<uint32_t>(p, (size_t)NN + 3); d.zw = dcarve<uint32_t>(p, (size_t)NN + 3);
+  d.zf_ex = dcarve<uint32_t>(p, (size_t)NN + 3); d.zw_ex = dcarve<uint32_t>(p, (size_t)NN + 3);
+  d.e_index = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_flags = dcarve<uint32_t>(p, (size_t)NN + 2);
+  d.e_head = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_head_ex = dcarve<uint32_t>(p, (size_t)NN + 2);
+  d.edit = dcarve<am355_ir_edit>(p, (size_t)NN + 2);
+  d.slot_rep = dcarve<uint32_t>(p, cap + 1); d.slot_first = dcarve<uint32_t>(p, cap + 1); d.slot_last = dcarve<uint32_t>(p, cap + 1);
+  d.slot_cont = dcarve<uint32_t>(p, cap + 1); d.slot_cnt = dcarve<uint32_t>(p, cap + 1); d.slot_child = dcarve<uint32_t>(p, cap + 1);
+  d.slot_drop = dcarve<uint32_t>(p, cap + 1); d.place = dcarve<uint32_t>(p, cap + 1); d.place_ex = dcarve<uint32_t>(p, cap + 1);
+  d.slot_L = dcarve<unsigned long long>(p, cap);
+  d.keep = dcarve<uint32_t>(p, (size_t)NM + 1); d.keep_ex = dcarve<uint32_t>(p, (size_t)NM + 1); d.rec_slot = dcarve<uint32_t>(p, (size_t)NM + 1);
+  for (int k = 0; k < 2; k++) { d.pair_key[k] = dcarve<uint64_t>(p, (size_t)NM + cap + 1); d.pair_val[k] = dcarve<uint32_t>(p, (size_t)NM + cap + 1); }
+  d.map = dcarve<am355_ir_map>(p, (size_t)NM + cap + 1);
+  size_t biggest = std::max<size_t>({(size_t)N + 2, (size_t)NM + cap + 2, (size_t)NN + 4});
+  d.scan_ws = p;
+  p += al256(scan_workspace_bytes((uint32_t)biggest));
+  d.sort_ws = p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// objects: parent link of every object (setupPatches walks them on the host, new.js:1461-1528)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void kd_objects(MergeBufs b, PatchIR ir, DeltaBufs d) {
+  uint32_t oi = gtid();
+  if (oi >= d.n_obj) return;
+  ObjLink L{NONE32, 0, 0, 0, 0, 0, NONE32, 0, 0, 0, 0, 0};
+  if (oi > 0) {
+    const OpCols& o = b.ops;
+    uint32_t m = ir.obj[oi].make_row;
+    L.parent = obj_index_of(b, b.obj_row[m]);
+    if (b.succ_cnt[m] == 0) L.flags |= OL_VISIBLE;
+    if (o.key_len[m] != NONE32) { L.key_off = o.key_off[m]; L.key_len = o.key_len[m]; }
+    else {
+      uint32_t el = o.insert[m] ? m : b.ref_row[m];
+      L.flags |= OL_LIST_PARENT;
+      if (el != NONE32) { L.elem_ctr = o.id_ctr[el]; L.elem_actor = o.id_actor[el]; if (el >= d.T0) L.flags |= OL_ELEM_NEW; }
+    }
+  }
+  d.link[oi] = L;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rows: which elements hold assignments; per new row: the object it touches, the map key it touches, the element it deletes
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t key_hash(const MergeBufs& b, uint32_t g) {
+  const uint8_t* p = b.arena + b.ops.key_off[g];
+  uint32_t len = b.ops.key_len[g];
+  unsigned long long h = 0xcbf29ce484222325ull ^ b.obj_row[g];
+  for (uint32_t k = 0; k < len; k++) h = (h ^ p[k]) * 0x100000001b3ull;
+  return (uint32_t)(h >> 24);
+}
+
+__device__ __forceinline__ uint32_t key_slot(const MergeBufs& b, const DeltaBufs& d, uint32_t g, bool insert) {
+  uint32_t i = key_hash(b, g) & d.key_mask;
+  for (uint32_t probes = 0; probes <= d.key_mask; probes++) {
+    uint32_t v = d.slot_rep[i];
+    if (v == 0) {
+      if (!insert) return NONE32;
+      v = atomicCAS(&d.slot_rep[i], 0u, g + 1);
+      if (v == 0) return i;
+    }
+    uint32_t r = v - 1;
+    if (b.obj_row[r] == b.obj_row[g] && same_key(b, r, g)) return i;
+    i = (i + 1) & d.key_mask;
+  }
+  return NONE32;
+}
+
+__global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  uint8_t kind = b.kind[g];
+  if (kind == K_LIST_UPD) {
+    uint32_t el = b.ref_row[g];
+    if (el != NONE32) d.has_upd[el] = 1;
+  }
+  if (g < d.T0) return;
+  uint32_t err = 0;
+  if (kind == K_FOREIGN) err |= F_UNSUPPORTED;
+  if (kind != K_NONE && kind != K_FOREIGN) {
+    atomicMin(&d.link[obj_index_of(b, b.obj_row[g])].touch, g - d.T0);
+    if (kind == K_MAP || (kind == K_DEL && b.ops.key_len[g] != NONE32)) {
+      uint32_t s = key_slot(b, d, g, true);
+      if (s == NONE32) err |= F_UNSUPPORTED;
+      else { atomicMin(&d.slot_first[s], g); atomicMax(&d.slot_last[s], g); }
+    } else if (kind == K_DEL) {
+      uint32_t el = b.ref_row[g];
+      if (el == NONE32) err |= F_BAD_ELEM;
+      else { atomicAdd(&d.new_succ[el], 1u); atomicMin(&d.first_del[el], g); }
+    } else if (kind == K_LIST_UPD) {
+      err |= F_UNSUPPORTED;  // an assignment to a list element (see the head of this file)
+    }
+  }
+  if (err) atomicOr(&d.counts->flags, err);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lists
+// ---------------------------------------------------------------------------------------------------------
+// per list position: was the element visible before the batch, how many edit items it gives rise to
+__global__ __launch_bounds__(BLOCK) void kd_positions(MergeBufs b, DeltaBufs d) {
+  uint32_t p = gtid();
+  if (p > d.n_list) return;
+  uint32_t v0 = 0, c = 0;
+  if (p < d.n_list) {
+    uint32_t e = b.order[p];
+    d.pos_of[e] = p;
+    bool fin_vis = b.val_cnt[e] + (b.kind[e] == K_LIST_INS_VIS ? 1u : 0u) > 0;
+    uint32_t ns = d.new_succ[e];
+    bool is_new = e >= d.T0;
+    bool eff_del = ns > 0 && b.succ_cnt[e] == ns;  // visible until a row of the batch deleted it
+    if ((is_new || ns > 0) && d.has_upd[e]) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
+    v0 = (!is_new && (fin_vis || eff_del)) ? 1u : 0u;
+    c = (is_new ? 1u : 0u) + (eff_del ? 1u : 0u);
+  }
+  d.v0[p] = v0;
+  d.icnt[p] = c;
+}
+
+// items in position order: (time << 1 | is_remove), element, group = the items of its list object
+__global__ __launch_bounds__(BLOCK) void kd_items(MergeBufs b, DeltaBufs d) {
+  uint32_t p = gtid();
+  if (p >= d.n_list) return;
+  uint32_t c = d.icnt[p];
+  if (!c) return;
+  uint32_t e = b.order[p], base = d.item_ex[p];
+  uint32_t oi = obj_index_of(b, b.obj_row[e]);
+  uint32_t fp = b.obj_first_pos[oi];
+  uint32_t lo = d.item_ex[fp], hi = d.item_ex[fp + b.obj_n[oi]];
+  uint32_t k = 0;
+  if (e >= d.T0) {
+    d.tk[0][base] = (e - d.T0) << 1; d.elem[0][base] = e; d.acc[0][base] = 0; d.lo[0][base] = lo; d.hi[0][base] = hi;
+    k = 1;
+  }
+  if (k < c) {
+    d.tk[0][base + k] = (d.first_del[e] - d.T0) << 1 | 1u; d.elem[0][base + k] = e; d.acc[0][base + k] = 0; d.lo[0][base + k] = lo; d.hi[0][base + k] = hi;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void kd_bit_flags(DeltaBufs d, int src, uint32_t m, uint32_t bit) {
+  uint32_t i = gtid();
+  if (i > m) return;
+  uint32_t z = 0, w = 0;
+  if (i < m) {
+    uint32_t tk = d.tk[src][i];
+    z = (((tk >> 1) >> bit) & 1u) ? 0u : 1u;
+    w = z ? ((tk & 1u) ? 0xffffffffu : 1u) : 0u;  // +1 insert, -1 remove
+  }
+  d.zf[i] = z;
+  d.zw[i] = w;
+}
+
+// one stable partition of every group by the bit: zeros first. An item whose bit is set has every zero of its group in front of
+// it (in position order) earlier in time: it adds their weights.
+__global__ __launch_bounds__(BLOCK) void kd_partition(DeltaBufs d, int src, uint32_t m, uint32_t bit) {
+  uint32_t i = gtid();
+  if (i >= m) return;
+  int dst = src ^ 1;
+  uint32_t tk = d.tk[src][i], lo = d.lo[src][i], hi = d.hi[src][i], acc = d.acc[src][i];
+  uint32_t zl = d.zf_ex[lo], zi = d.zf_ex[i], nz = d.zf_ex[hi] - zl;
+  uint32_t to, nlo, nhi;
+  if (((tk >> 1) >> bit) & 1u) {
+    acc += d.zw_ex[i] - d.zw_ex[lo];
+    to = lo + nz + ((i - lo) - (zi - zl));
+    nlo = lo + nz; nhi = hi;
+  } else {
+    to = lo + (zi - zl);
+    nlo = lo; nhi = lo + nz;
+  }
+  d.tk[dst][to] = tk; d.elem[dst][to] = d.elem[src][i]; d.acc[dst][to] = acc; d.lo[dst][to] = nlo; d.hi[dst][to] = nhi;
+}
+
+// items are now in (object, time) order: index of each edit, run detection (new.js:754-777)
+__global__ __launch_bounds__(BLOCK) void kd_edit_index(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
+  uint32_t i = gtid();
+  if (i >= m) return;
+  uint32_t tk = d.tk[src][i], e = d.elem[src][i];
+  uint32_t oi = obj_index_of(b, b.obj_row[e]);
+  uint32_t base = d.v0_ex[d.pos_of[e]] - d.v0_ex[b.obj_first_pos[oi]];
+  uint32_t idx = base + d.acc[src][i];
+  if ((tk & 1u) && e >= d.T0) idx -= 1;  // its own insertion sits at the same position and is not "in front"
+  d.e_index[i] = idx;
+}
+
+__global__ __launch_bounds__(BLOCK) void kd_edit_runs(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
+  uint32_t i = gtid();
+  if (i > m) return;
+  if (i == m) { d.e_head[i] = 0; return; }
+  const OpCols& o = b.ops;
+  uint32_t tk = d.tk[src][i], e = d.elem[src][i];
+  uint32_t oi = obj_index_of(b, b.obj_row[e]);
+  bool rem = tk & 1u, child = !rem && (o.action[e] & 1) == 0;
+  uint32_t f = rem ? (uint32_t)AM355_EDIT_REMOVE : (child ? (uint32_t)AM355_EDIT_CHILD : 0u);
+  uint32_t prev_oi = NONE32, next_oi = NONE32;
+  if (i > 0) {
+    uint32_t ptk = d.tk[src][i - 1], pe = d.elem[src][i - 1];
+    prev_oi = obj_index_of(b, b.obj_row[pe]);
+    bool prem = ptk & 1u, pchild = !prem && (o.action[pe] & 1) == 0;
+    if (prev_oi == oi) {
+      if (rem && prem && d.e_index[i] == d.e_index[i - 1]) f |= 2u;
+      else if (!rem && !prem && !child && !pchild && o.id_actor[e] == o.id_actor[pe] && o.id_ctr[e] == o.id_ctr[pe] + 1 &&
+               value_class(o.val_tl[e]) == value_class(o.val_tl[pe]) && d.e_index[i] == d.e_index[i - 1] + 1) {
+        f |= 2u;
+        uint32_t tl = o.val_tl[e], ptl = o.val_tl[pe];
+        if (tl != ptl || o.val_off[e] != o.val_off[pe] + (ptl >> 4)) f |= 0x400u;  // a new record of the same multi-insert
+      }
+    }
+  }
+  if (i + 1 < m) next_oi = obj_index_of(b, b.obj_row[d.elem[src][i + 1]]);
+  if (oi != prev_oi) f |= 0x100u;
+  if (oi != next_oi) f |= 0x200u;
+  d.e_flags[i] = f;
+  d.e_head[i] = (!(f & 2u) || (f & 0x400u)) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
+  uint32_t i = gtid();
+  if (i > m) return;
+  if (i == m) {
+    uint32_t n = d.e_head_ex[m];
+    d.edit[n] = am355_ir_edit{0, 0, 0, 0, 0, 0, m, 0, 0, 0};
+    d.counts->n_erecs = n;
+    return;
+  }
+  uint32_t f = d.e_flags[i], k = d.e_head_ex[i], e = d.elem[src][i];
+  const OpCols& o = b.ops;
+  bool head = d.e_head[i] != 0;
+  if (head) {
+    uint32_t rf = f & (AM355_EDIT_REMOVE | AM355_EDIT_CHILD);
+    if ((f & 2u) && (f & 0x400u)) rf |= AM355_EDIT_CONT;
+    if (f & AM355_EDIT_REMOVE) d.edit[k] = am355_ir_edit{rf, d.e_index[i], 0, 0, 0, 0, i, 0, 0, 0};
+    else d.edit[k] = am355_ir_edit{rf, d.e_index[i], o.id_ctr[e], o.id_actor[e], o.id_ctr[e], o.id_actor[e], i, o.val_tl[e], (f & AM355_EDIT_CHILD) ? b.obj_index[e] : o.val_off[e], 0};
+  }
+  if (f & 0x300u) {
+    uint32_t oi = obj_index_of(b, b.obj_row[e]);
+    if (f & 0x100u) d.link[oi].edit_begin = k;
+    if (f & 0x200u) d.link[oi].edit_end = k + (head ? 1u : 0u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// maps
+// ---------------------------------------------------------------------------------------------------------
+// first key < second key in UTF-16 code unit order (new.js:1126 compares JS strings)
+__device__ __forceinline__ bool key_less_utf16(const MergeBufs& b, uint32_t ra, uint32_t rb) {
+  const uint8_t *p = b.arena + b.ops.key_off[ra], *q = b.arena + b.ops.key_off[rb];
+  uint32_t la = b.ops.key_len[ra], lb = b.ops.key_len[rb], n = la < lb ? la : lb;
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t x = utf16_order_byte(p[k]), y = utf16_order_byte(q[k]);
+    if (x != y) return x < y;
+  }
+  return la < lb;
+}
+
+// per touched key: id of the batch's last op on it, and whether the merge call that handled that op went on to another key
+__global__ __launch_bounds__(BLOCK) void kd_slots(MergeBufs b, DeltaBufs d) {
+  uint32_t s = gtid();
+  if (s > d.key_mask) return;
+  if (!d.slot_rep[s]) return;
+  const OpCols& o = b.ops;
+  uint32_t j = d.slot_last[s];
+  unsigned long long L = pack_id(o.id_ctr[j], o.id_actor[j]);
+  bool ambiguous = false;
+  if (b.kind[j] == K_DEL) {
+    // a deletion leaves the merge loop's work list as soon as the document op of its last pred has been taken (new.js:1207-1216):
+    // from there on -- not from the deletion's own id -- the remaining document ops of the key are at the mercy of the next op
+    L = 0;
+    for (uint32_t k = 0; k < o.pred_num[j]; k++) {
+      unsigned long long pid = pack_id(o.pred_ctr[o.pred_first[j] + k], o.pred_actor[o.pred_first[j] + k]);
+      L = pid > L ? pid : L;
+    }
+    // ... unless an earlier op on the same key travels in the same work list (new.js:1111-1113): not modelled
+    if (j > d.T0) {
+      uint32_t pj = j - 1;
+      uint8_t kp = b.kind[pj];
+      ambiguous = (kp == K_MAP || kp == K_DEL) && o.key_len[pj] != NONE32 && o.id_actor[pj] == o.id_actor[j] && same_obj(b, pj, j) && same_key(b, pj, j);
+    }
+  }
+  d.slot_L[s] = L;
+  uint32_t cont = 0, nx = j + 1;
+  if (nx < b.n_ops) {
+    bool new_pass = false;
+    for (uint32_t k = 0; k < d.n_pass; k++) new_pass = new_pass || d.pass_rows[k] == nx;
+    uint8_t kn = b.kind[nx];
+    if (!new_pass && (kn == K_MAP || kn == K_DEL) && o.key_len[nx] != NONE32 && !o.insert[nx] && o.id_actor[nx] == o.id_actor[j] && same_obj(b, nx, j) &&
+        key_less_utf16(b, j, nx))
+      cont = 1;
+  }
+  if (cont && ambiguous) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
+  d.slot_cont[s] = cont;
+}
+
+// per map record of the whole-document patch: does the batch touch its key, does the patch list it
+__global__ __launch_bounds__(BLOCK) void kd_map_records(MergeBufs b, PatchIR ir, DeltaBufs d) {
+  uint32_t i = gtid();
+  if (i > d.n_map) return;
+  uint32_t keep = 0;
+  if (i < d.n_map) {
+    const am355_ir_map rec = ir.map[i];
+    uint32_t g = row_of(b, rec.id_actor, rec.id_ctr);
+    uint32_t s = g == NONE32 ? NONE32 : key_slot(b, d, g, false);
+    d.rec_slot[i] = s;
+    if (s != NONE32) {
+      unsigned long long trig = (rec.flags & AM355_MAP_COUNTER) ? b.last_inc[g] : pack_id(rec.id_ctr, rec.id_actor);
+      bool drop = d.slot_cont[s] && trig > d.slot_L[s];
+      if (rec.flags & AM355_MAP_CHILD) d.slot_child[s] = 1;
+      if (drop) d.slot_drop[s] = 1;
+      else { keep = 1; atomicAdd(&d.slot_cnt[s], 1u); }
+    }
+  }
+  d.keep[i] = keep;
+}
+
+__global__ __launch_bounds__(BLOCK) void kd_placeholders(DeltaBufs d) {
+  uint32_t s = gtid();
+  if (s > d.key_mask + 1) return;
+  uint32_t pl = 0;
+  if (s <= d.key_mask && d.slot_rep[s]) {
+    pl = d.slot_cnt[s] == 0 ? 1u : 0u;
+    // values were skipped on a key that holds a child object: objectMeta.children of the reference now lacks them, which later
+    // patches would show (new.js:916-931) -- a state this engine does not carry
+    if (d.slot_child[s] && d.slot_drop[s]) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
+  }
+  d.place[s] = pl;
+}
+
+// sort keys: (object | first row that touched the key); records of one key keep their op id order (stable sort)
+__global__ __launch_bounds__(BLOCK) void kd_map_pairs(MergeBufs b, DeltaBufs d) {
+  uint32_t i = gtid();
+  const uint32_t n_kept = d.counts->n_kept;
+  if (i < d.n_map && d.keep[i]) {
+    uint32_t s = d.rec_slot[i], rep = d.slot_rep[s] - 1;
+    uint32_t pos = d.keep_ex[i];
+    d.pair_key[0][pos] = (uint64_t)obj_index_of(b, b.obj_row[rep]) << d.bits_new | (d.slot_first[s] - d.T0);
+    d.pair_val[0][pos] = i;
+  }
+  if (i <= d.key_mask && d.place[i]) {
+    uint32_t rep = d.slot_rep[i] - 1;
+    uint32_t pos = n_kept + d.place_ex[i];
+    d.pair_key[0][pos] = (uint64_t)obj_index_of(b, b.obj_row[rep]) << d.bits_new | (d.slot_first[i] - d.T0);
+    d.pair_val[0][pos] = d.n_map + i;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void kd_map_out(MergeBufs b, PatchIR ir, DeltaBufs d, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  uint32_t v = vals[i];
+  if (v < d.n_map) d.map[i] = ir.map[v];
+  else {
+    uint32_t rep = d.slot_rep[v - d.n_map] - 1;
+    d.map[i] = am355_ir_map{0, 0, b.ops.key_off[rep], b.ops.key_len[rep], 0, 0, AM355_MAP_EMPTY, 0, 0};
+  }
+  uint32_t oi = (uint32_t)(keys[i] >> d.bits_new);
+  uint32_t prev = i > 0 ? (uint32_t)(keys[i - 1] >> d.bits_new) : NONE32, next = i + 1 < n ? (uint32_t)(keys[i + 1] >> d.bits_new) : NONE32;
+  if (oi != prev) d.link[oi].map_begin = i;
+  if (oi != next) d.link[oi].map_end = i + 1;
+}
+
+static int dbits_for(uint64_t max_value) {
+  int b = 1;
+  while (b < 64 && (max_value >> b)) b++;
+  return b;
+}
+
+void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st) {
+  const uint32_t N = b.n_ops, cap = d.key_mask + 1;
+  (void)hipMemsetAsync(d.counts, 0, sizeof(DeltaCounts), st);
+  (void)hipMemsetAsync(d.first_del, 0xff, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(d.new_succ, 0, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(d.has_upd, 0, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(d.slot_rep, 0, 4 * ((size_t)cap + 1), st);
+  (void)hipMemsetAsync(d.slot_first, 0xff, 4 * ((size_t)cap + 1), st);
+  (void)hipMemsetAsync(d.slot_last, 0, 4 * ((size_t)cap + 1), st);
+  (void)hipMemsetAsync(d.slot_cnt, 0, 4 * ((size_t)cap + 1), st);
+  (void)hipMemsetAsync(d.slot_child, 0, 4 * ((size_t)cap + 1), st);
+  (void)hipMemsetAsync(d.slot_drop, 0, 4 * ((size_t)cap + 1), st);
+  AM355_LAUNCH_INDEPENDENT(kd_objects, dgrid(d.n_obj), dim3(BLOCK), st, b, ir, d);
+  if (N) AM355_LAUNCH_INDEPENDENT(kd_rows, dgrid(N), dim3(BLOCK), st, b, d);
+  // ---- lists: items in position order ----
+  AM355_LAUNCH_INDEPENDENT(kd_positions, dgrid(d.n_list + 1), dim3(BLOCK), st, b, d);
+  exclusive_scan2_u32(d.v0, d.v0_ex, nullptr, d.icnt, d.item_ex, nullptr, d.n_list + 1, d.scan_ws, st);
+  if (d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items, dgrid(d.n_list), dim3(BLOCK), st, b, d);
+  // ---- maps: touched keys, kept records, placeholders ----
+  AM355_LAUNCH_INDEPENDENT(kd_slots, dgrid(cap), dim3(BLOCK), st, b, d);
+  AM355_LAUNCH_INDEPENDENT(kd_map_records, dgrid(d.n_map + 1), dim3(BLOCK), st, b, ir, d);
+  AM355_LAUNCH_INDEPENDENT(kd_placeholders, dgrid(cap + 1), dim3(BLOCK), st, d);
+  exclusive_scan_u32(d.keep, d.keep_ex, d.n_map + 1, nullptr, d.scan_ws, st);
+  exclusive_scan_u32(d.place, d.place_ex, cap + 1, nullptr, d.scan_ws, st);
+  (void)hipMemcpyAsync(&d.counts->n_items, d.item_ex + d.n_list, 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(&d.counts->n_kept, d.keep_ex + d.n_map, 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(&d.counts->n_place, d.place_ex + cap, 4, hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  if (hc->flags) return;
+
+  // ---- list edits: dominance counts by binary partitions on the time bits, most significant first ----
+  const uint32_t m = hc->n_items;
+  int cur = 0;
+  if (m) {
+    for (int bit = (int)d.bits_new - 1; bit >= 0; bit--) {
+      AM355_LAUNCH_INDEPENDENT(kd_bit_flags, dgrid(m + 1), dim3(BLOCK), st, d, cur, m, (uint32_t)bit);
+      exclusive_scan2_u32(d.zf, d.zf_ex, nullptr, d.zw, d.zw_ex, nullptr, m + 1, d.scan_ws, st);
+      AM355_LAUNCH_INDEPENDENT(kd_partition, dgrid(m), dim3(BLOCK), st, d, cur, m, (uint32_t)bit);
+      cur ^= 1;
+    }
+    AM355_LAUNCH_INDEPENDENT(kd_edit_index, dgrid(m), dim3(BLOCK), st, b, d, cur, m);
+  }
+  AM355_LAUNCH_INDEPENDENT(kd_edit_runs, dgrid(m + 1), dim3(BLOCK), st, b, d, cur, m);
+  exclusive_scan_u32(d.e_head, d.e_head_ex, m + 1, nullptr, d.scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kd_edit_pack, dgrid(m + 1), dim3(BLOCK), st, b, d, cur, m);
+
+  // ---- map records in patch order ----
+  const uint32_t nm = hc->n_kept + hc->n_place;
+  if (nm) {
+    AM355_LAUNCH_INDEPENDENT(kd_map_pairs, dgrid(std::max(d.n_map, cap)), dim3(BLOCK), st, b, d);
+    int res = radix_sort_pairs(d.pair_key[0], d.pair_val[0], d.pair_key[1], d.pair_val[1], nm, 0, (int)d.bits_new + dbits_for(d.n_obj), d.sort_ws, st);
+    AM355_LAUNCH_INDEPENDENT(kd_map_out, dgrid(nm), dim3(BLOCK), st, b, ir, d, (const uint64_t*)d.pair_key[res], (const uint32_t*)d.pair_val[res], nm);
+  }
+  (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  hc->n_items = m;
+}
+
+}  // namespace am355

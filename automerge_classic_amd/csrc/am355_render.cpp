@@ -235,8 +235,9 @@ struct R {
     if (!json_string(ir.arena + m0.key_off, m0.key_len)) return false;
     out += ":{";
     for (uint32_t i = begin; i < end; i++) {
-      if (i > begin) out.push_back(',');
       const am355_ir_map& m = ir.map[i];
+      if (m.flags & AM355_MAP_EMPTY) continue;  // incremental patch: `props[key] = {}` (new.js:1037)
+      if (i > begin) out.push_back(',');
       if (!op_id(m.id_ctr, m.id_actor)) return false;
       out.push_back(':');
       if (m.flags & AM355_MAP_COUNTER) {
@@ -271,7 +272,10 @@ struct R {
       while (j < e && (ir.edits[j].flags & AM355_EDIT_CONT)) j++;  // further records of the same multi-insert
       if (ir.edits[i + 1].first <= ed.first || ir.edits[j].first > ir.n_values) return fail("internal: edit record without values");
       if (i > b) out.push_back(',');
-      if (count >= 2 || j > i + 1) {
+      if (ed.flags & AM355_EDIT_REMOVE) {  // incremental patch (new.js:1029, 775-777)
+        snprintf(t, sizeof t, "{\"action\":\"remove\",\"index\":%u,\"count\":%u}", ed.index, count);
+        out += t;
+      } else if (count >= 2 || j > i + 1) {
         snprintf(t, sizeof t, "{\"action\":\"multi-insert\",\"index\":%u,\"elemId\":", ed.index);
         out += t;
         if (!op_id(ed.elem_ctr, ed.elem_actor)) return false;

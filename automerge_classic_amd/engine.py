@@ -86,9 +86,12 @@ def _bind(path):
     L.am355_import_fragments.argtypes = [vp, vp, vp, u32]
     L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
     L.am355_doc_changes.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_void_p)]
+    L.am355_apply_changes.argtypes = [vp, vp, u64p, u32]
+    L.am355_apply_patch_json.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.am355_fetch_apply_ir.argtypes = [vp, vp]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
-              "am355_import_fragments", "am355_doc_changes"):
+              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -148,6 +151,21 @@ class Engine:
     def replay(self):
         """The hot path: decode + schedule + merge + patch IR, device-resident in and out."""
         self._check(self._L.am355_replay(self._h))
+
+    def apply_changes(self, log):
+        """Backend.applyChanges(state, changes): the state is what the context holds (earlier load_changes + replay or apply_changes
+        calls, or nothing = Backend.init()). Replays everything, derives the incremental patch of the batch on the device."""
+        arena = np.ascontiguousarray(log.arena, dtype=np.uint8)
+        offsets = np.ascontiguousarray(log.offsets, dtype=np.uint64)
+        self._check(self._L.am355_apply_changes(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, int(offsets.size - 1)))
+        self._n_changes = int(self.stats().n_changes)
+
+    def apply_patch_json(self):
+        """JSON.stringify of the patch the last apply_changes returned (the reference's incremental patch)."""
+        p = ctypes.c_char_p()
+        n = ctypes.c_size_t()
+        self._check(self._L.am355_apply_patch_json(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p, n.value).decode("utf-8")
 
     def fetch_ir(self):
         """Patch IR + envelope from HBM into host memory owned by the context (what the JS host materialises the patch from)."""

@@ -160,7 +160,8 @@ typedef struct {
   uint32_t edit_begin, edit_end;  /* list / text: range of edit records */
   uint32_t make_row;              /* (engine-internal: op row of the make op) */
 } am355_ir_object;
-enum { AM355_MAP_COUNTER = 1u, AM355_MAP_CHILD = 2u };
+enum { AM355_MAP_COUNTER = 1u, AM355_MAP_CHILD = 2u,
+       AM355_MAP_EMPTY = 4u   /* incremental patches only: the key is left without a value (`props[key] = {}`, new.js:1037) */ };
 typedef struct {
   uint32_t id_ctr, id_actor;      /* opId under which the value is listed */
   uint32_t key_off, key_len;      /* key bytes (UTF-8) in the arena */
@@ -168,7 +169,8 @@ typedef struct {
   uint32_t flags, pad;
   int64_t counter;                /* AM355_MAP_COUNTER: the counter's total (new.js:937-967) */
 } am355_ir_map;
-enum { AM355_EDIT_UPDATE = 1u, AM355_EDIT_CONT = 2u, AM355_EDIT_CHILD = 4u };
+enum { AM355_EDIT_UPDATE = 1u, AM355_EDIT_CONT = 2u, AM355_EDIT_CHILD = 4u,
+       AM355_EDIT_REMOVE = 8u  /* incremental patches only: `remove` edit of count = next record's first - first elements (new.js:775-777, 1029) */ };
 typedef struct {
   uint32_t flags;                 /* AM355_EDIT_UPDATE: `update` edit (else insert / multi-insert); AM355_EDIT_CHILD: the value is an object;
                                      AM355_EDIT_CONT: more values of the previous record's multi-insert */
@@ -201,6 +203,29 @@ typedef struct {
   uint64_t arena_len;
 } am355_patch_ir;
 int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
+
+/*
+ * Backend.applyChanges(state, changes) with the INCREMENTAL patch it returns (reference: backend/backend.js:27-31,
+ * backend/new.js:1797-1879 BackendDoc.applyChanges, :1052-1290 mergeDocChangeOps, :884-1040 updatePatchProperty in its incremental
+ * mode, :747-782 appendEdit, :1461-1528 setupPatches).  `state` is what the context holds: the changes of an earlier
+ * am355_load_changes + am355_replay or of earlier am355_apply_changes calls (applied and queued ones), or nothing -- then the call
+ * is Backend.applyChanges(Backend.init(), changes).  The engine replays the earlier changes and the batch together (the queue
+ * semantics of new.js:1822-1841 included) and derives the patch of the batch from the merged state and from which op rows are new
+ * (automerge_classic_amd/csrc/am355_delta.hip): list edits with the index they had when the op was applied, the visible values of every map key
+ * the batch touched, and the links from the touched objects up to _root.  Afterwards am355_apply_patch_json / am355_fetch_apply_ir
+ * give that patch, and am355_patch_json / am355_fetch_ir / am355_save / am355_get_applied ... describe the new state as after
+ * am355_replay.
+ * AM355_E_INVALID: the reference throws on this batch.  AM355_E_UNSUPPORTED: legal, but outside the subset served here (an
+ * assignment to a list element or a deletion of one that holds several values, an edit inside an object that is no longer reachable,
+ * a state made by am355_load_document): the host serves the call on the JS path.  After either the context no longer holds a
+ * state (load again).
+ */
+int am355_apply_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes);
+/* JSON.stringify of the patch Backend.applyChanges returned -- byte for byte; valid until the next call on ctx */
+int am355_apply_patch_json(am355_ctx *ctx, const char **json, size_t *len);
+/* The same patch as record tables (layout above; records may carry AM355_EDIT_REMOVE / AM355_MAP_EMPTY, map records of one object
+ * come in the order the reference inserted the keys, objects the patch does not reach have empty ranges). */
+int am355_fetch_apply_ir(am355_ctx *ctx, am355_patch_ir *out);
 
 /*
  * objectId sharding over several GPUs (one context per GPU, one process per GPU).  Ordering and pred / succ

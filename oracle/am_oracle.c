@@ -641,6 +641,11 @@ typedef struct row {
 typedef struct elem {
   row_t *rows; /* first row is the insert op that created the element */
   struct elem *next;
+  /* session documents (am_oracle_apply.c): node of the list's order-statistic tree -- the elements in list order, every subtree
+   * knowing how many visible elements it holds, so that "visible elements in front of this one" (the visibleCount of seekToOp,
+   * new.js:111-115) costs O(log n) instead of a walk from the head */
+  struct elem *t_left, *t_right, *t_parent;
+  uint32_t t_prio, t_vis, t_sum;
 } elem_t;
 
 typedef struct slot {
@@ -665,6 +670,8 @@ typedef struct obj {
   const uint8_t *parent_key;    /* ... or a string key */
   uint32_t parent_key_len;
   struct chkey *children;       /* objectMeta.children: key / elemId -> { opId: value } */
+  elem_t *t_root;               /* order-statistic tree over the elements (NULL until the first seek builds it) */
+  int t_built;
   slot_t **sorted;              /* map keys in document order (UTF-16 code unit order, new.js:84) */
   uint32_t n_sorted, cap_sorted;
   uint32_t touch_epoch;         /* member of the `objectIds` set of the running applyChanges call */

@@ -153,10 +153,68 @@ static int elem_visible(const elem_t *el) {
     if (r->n_succ == 0) return 1;
   return 0;
 }
+
+/* ---- order-statistic tree over the elements of one list (a treap in list order, subtree sums of visible elements) ---- */
+static uint32_t t_rand(void) {
+  static uint64_t s = 0x9e3779b97f4a7c15ull;
+  s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+  return (uint32_t)(s >> 32);
+}
+static uint32_t t_sum(const elem_t *n) { return n ? n->t_sum : 0; }
+static void t_pull(elem_t *n) { n->t_sum = t_sum(n->t_left) + t_sum(n->t_right) + n->t_vis; }
+static void t_rotate_up(obj_t *o, elem_t *n) {  /* n moves above its parent */
+  elem_t *p = n->t_parent, *g = p->t_parent;
+  if (p->t_left == n) { p->t_left = n->t_right; if (n->t_right) n->t_right->t_parent = p; n->t_right = p; }
+  else { p->t_right = n->t_left; if (n->t_left) n->t_left->t_parent = p; n->t_left = p; }
+  p->t_parent = n;
+  n->t_parent = g;
+  if (!g) o->t_root = n;
+  else if (g->t_left == p) g->t_left = n; else g->t_right = n;
+  t_pull(p);
+  t_pull(n);
+}
+/* `n` becomes the in-order successor of `prev` (NULL: the first element) */
+static void t_insert_after(obj_t *o, elem_t *prev, elem_t *n) {
+  n->t_left = n->t_right = n->t_parent = NULL;
+  n->t_prio = t_rand();
+  n->t_vis = (uint32_t)elem_visible(n);
+  n->t_sum = n->t_vis;
+  if (!o->t_root) { o->t_root = n; return; }
+  if (!prev) {
+    elem_t *x = o->t_root;
+    while (x->t_left) x = x->t_left;
+    x->t_left = n; n->t_parent = x;
+  } else if (!prev->t_right) { prev->t_right = n; n->t_parent = prev; }
+  else {
+    elem_t *x = prev->t_right;
+    while (x->t_left) x = x->t_left;
+    x->t_left = n; n->t_parent = x;
+  }
+  for (elem_t *x = n->t_parent; x; x = x->t_parent) t_pull(x);
+  while (n->t_parent && n->t_parent->t_prio < n->t_prio) t_rotate_up(o, n);
+}
+static void t_build(obj_t *o) {
+  if (o->t_built) return;
+  o->t_built = 1;
+  o->t_root = NULL;
+  elem_t *prev = NULL;
+  for (elem_t *x = o->head.next; x; x = x->next) { t_insert_after(o, prev, x); prev = x; }
+}
+/* the element's visibility changed (a row gained a successor, or a visible row was added) */
+static void t_refresh(obj_t *o, elem_t *el) {
+  if (!o->t_built) return;
+  uint32_t v = (uint32_t)elem_visible(el);
+  if (v == el->t_vis) return;
+  el->t_vis = v;
+  for (elem_t *x = el; x; x = x->t_parent) t_pull(x);
+}
 /* number of visible elements in front of `el` (NULL: of the whole list) -- the visibleCount of seekToOp, new.js:111-115, 148-152, 170-173 */
-static uint64_t vis_before(const obj_t *o, const elem_t *el) {
-  uint64_t n = 0;
-  for (const elem_t *x = o->head.next; x && x != el; x = x->next) n += elem_visible(x);
+static uint64_t vis_before(obj_t *o, const elem_t *el) {
+  t_build(o);
+  if (!el) return t_sum(o->t_root);
+  uint64_t n = t_sum(el->t_left);
+  for (const elem_t *x = el; x->t_parent; x = x->t_parent)
+    if (x->t_parent->t_right == x) n += t_sum(x->t_parent->t_left) + x->t_parent->t_vis;
   return n;
 }
 
@@ -228,11 +286,26 @@ static void prop_state_reset(ictx_t *x) {
   x->n_props = 0;
 }
 
+/* index of the patches' properties: (patch object, key) -> position in patch->props */
+typedef struct pidx {
+  const pobj_t *patch;
+  const uint8_t *key;
+  uint32_t key_len;
+  uint64_t pos;
+  struct pidx *next;
+} pidx_t;
+static tab_t g_pidx;       /* (single-threaded test tool: one applyChanges call at a time) */
+static pool_t g_pidx_pool;
+static uint64_t pidx_key(const pobj_t *patch, const uint8_t *key, uint32_t len) { return mix64((uint64_t)(uintptr_t)patch) ^ ((uint64_t)hash_bytes(key, len) * 0x9e3779b97f4a7c15ull); }
+
 /* patch.props[key], insertion-ordered; `reset`: `patch.props[key] = {}` (an existing key keeps its place among the keys) */
 static pprop_t *patch_prop(pobj_t *patch, const uint8_t *key, uint32_t len, int create, int reset) {
   pprop_t *pp = NULL;
-  for (uint64_t i = patch->n_props; i-- > 0;)
-    if (patch->props[i].key_len == len && memcmp(patch->props[i].key, key, len) == 0) { pp = &patch->props[i]; break; }
+  uint64_t hk = pidx_key(patch, key, len);
+  void **slot = tab_slot(&g_pidx, hk, 0);
+  if (slot)
+    for (pidx_t *n = (pidx_t *)*slot; n; n = n->next)
+      if (n->patch == patch && n->key_len == len && memcmp(n->key, key, len) == 0) { pp = &patch->props[n->pos]; break; }
   if (!pp) {
     if (!create) return NULL;
     if (patch->n_props == patch->cap_props) {
@@ -243,6 +316,10 @@ static pprop_t *patch_prop(pobj_t *patch, const uint8_t *key, uint32_t len, int 
     memset(pp, 0, sizeof *pp);
     pp->key = key;
     pp->key_len = len;
+    slot = tab_slot(&g_pidx, hk, 1);
+    pidx_t *n = (pidx_t *)pool_alloc(&g_pidx_pool, sizeof *n);
+    n->patch = patch; n->key = key; n->key_len = len; n->pos = patch->n_props - 1; n->next = (pidx_t *)*slot;
+    *slot = n;
   } else if (reset) pp->n = 0;
   return pp;
 }
@@ -475,6 +552,7 @@ static row_t *place_row(ictx_t *x, cur_t *c, const cop_t *op, pkey_t *k_out) {
       el->rows = r;
       el->next = c->el;
       c->prev_el->next = el;
+      if (o->t_built) t_insert_after(o, c->prev_el == &o->head ? NULL : c->prev_el, el);
       c->prev_el = el;
       o->n_elems++;
       index_elem(d, o->id, op->id, el);
@@ -494,6 +572,7 @@ static row_t *place_row(ictx_t *x, cur_t *c, const cop_t *op, pkey_t *k_out) {
         while (p->next) p = p->next;
         p->next = r;
       }
+      t_refresh(o, el);
       k_out->is_elem = 1; k_out->elem = op->key; k_out->key = NULL; k_out->key_len = 0;
     }
   } else {
@@ -656,6 +735,7 @@ static int merge_call(ictx_t *x, const cop_t *ops, uint64_t n_ops, uint64_t *pos
         for (uint32_t p = 0; p < op->pred_num; p++)
           if (same_id(op->preds[p], doc->id)) {
             add_succ(d, doc, op->id);
+            if (is_list) t_refresh(o, c.el);
             ch[q].seen[p] = 1;
             break;
           }
@@ -684,7 +764,20 @@ static int merge_call(ictx_t *x, const cop_t *ops, uint64_t n_ops, uint64_t *pos
         rc = fail(e, "duplicate operation ID: %s", buf);
         goto done;
       } else take_ch = 1;
-    } else take_doc = 1;
+    } else {
+      take_doc = 1;
+      if (!is_list && n_ch > 0 && change_op->key_str) {
+        /* the document ops in front of the change op's key go by without a word (new.js:1226-1229): step over them in one go
+         * (the reference decodes them one by one; nothing but the position changes) */
+        uint32_t at = sorted_lower_bound(o, change_op->key_str, change_op->key_len);
+        if (at > c.si) {
+          c.si = at;
+          c.row = c.si < o->n_sorted ? o->sorted[c.si]->rows : NULL;
+          if (c.row) doc_old_succ = c.row->n_succ;
+          continue;
+        }
+      }
+    }
 
     if (take_doc) {
       if (doc->insert && elem_vis) { elem_vis = 0; list_index++; }
@@ -870,6 +963,8 @@ static void release_patches(ictx_t *x) {
   free(c->root->props);
   tab_free(&c->patches);
   pool_free(&c->pool);
+  tab_free(&g_pidx);
+  pool_free(&g_pidx_pool);
   prop_state_reset(x);
   free(x->props);
   free(x->touched);
@@ -971,7 +1066,7 @@ const char *amo_apply_changes(amo_doc *d, const uint8_t *arena, const uint64_t *
         int h = head_find(heads, n_heads, c->deps + 32 * k);
         if (h >= 0) heads[h] = NULL;
       }
-      if (head_find(heads, n_heads, c->hash) < 0) heads[n_heads++] = c->hash;
+      if (head_find(heads, n_heads, c->hash) < 0) heads[n_heads++] = hcopy;
       applied[na++] = c;
     }
     if (rc) break;

@@ -1,0 +1,125 @@
+// TEST INFRASTRUCTURE (build container only). Differential campaign for the INCREMENTAL patches of Backend.applyChanges
+// (SURVEY.md 8f-2): random multi-actor documents made with the real frontend (the generators of make_golden.js), delivered to a
+// fresh reference backend in random batches -- in causal order, or shuffled so that changes wait in the queue -- and every
+// call's patch recorded.  One JSON line per session: {name, calls: [[base64 change...]...], patches: [JSON text | {error}]}.
+//
+//   NODE_PATH=oracle/js_shims/node_modules [REF_BLOCK_SIZE=100000000] node oracle/js/apply_campaign.js out.jsonl SPEC...
+//   SPEC = seed:actors:steps:depth (mixed document) | t:seed:actors:rounds:burst (text) | m:seed:actors:steps:depth (see servedScenario);
+//   every SPEC yields 3 sessions
+const fs = require('fs')
+const { splitmix, frontendScenario, textScenario, Backend } = require('./make_golden.js')
+const out = process.argv[2]
+const Automerge = require('./make_golden.js').Automerge
+
+// "m:" scenarios: what the engine's incremental-patch stage serves (automerge_classic_amd/csrc/am355_delta.hip) -- nested maps and
+// tables with conflicting assignments, deletions and counters, lists and texts that grow and shrink by insertion and deletion
+// (objects as list elements included) but whose elements are never assigned to -- edited by several actors that merge at random.
+function servedScenario(seed, nActors, steps, depthLimit) {
+  const rnd = splitmix(seed)
+  const pick = arr => arr[Math.floor(rnd() * arr.length)]
+  const KEYS = ['alpha', 'beta', 'gamma', 'x', 'y', 'k1', 'k2', '10', '9', '007', 'Ünï', '日本', '😀smile', '￮z', 'quote"q']
+  const ids = []
+  for (let i = 0; i < nActors; i++) { let a = 'abcdef'[Math.floor(rnd() * 6)]; while (a.length < 32) a += '0123456789abcdef'[Math.floor(rnd() * 16)]; ids.push(a) }
+  let docs = ids.map(id => Automerge.init(id))
+  docs[0] = Automerge.change(docs[0], d => { d.title = 'start'; d.items = ['a', 'b']; d.text = new Automerge.Text('hello'); d.n = new Automerge.Counter(1); d.cfg = { deep: { er: 1 } }; d.rows = new Automerge.Table() })
+  for (let i = 1; i < nActors; i++) docs[i] = Automerge.merge(docs[i], docs[0])
+  const scalar = () => {
+    const r = rnd()
+    if (r < 0.3) return Math.floor(rnd() * 2000) - 1000
+    if (r < 0.4) return rnd() * 1e3
+    if (r < 0.5) return pick([true, false, null])
+    if (r < 0.55) return new Date(1600000000000 + Math.floor(rnd() * 1e9))
+    if (r < 0.65) return new Automerge.Counter(Math.floor(rnd() * 10))
+    return pick(KEYS) + Math.floor(rnd() * 10)
+  }
+  const plain = v => (v instanceof Automerge.Counter ? 7 : v)   // no counters inside lists
+  const value = depth => {
+    const r = rnd()
+    if (depth < depthLimit && r < 0.15) return { [pick(KEYS)]: scalar(), n: scalar() }
+    if (depth < depthLimit && r < 0.25) return [plain(scalar()), plain(scalar())]
+    if (depth < depthLimit && r < 0.32) return new Automerge.Text(pick(KEYS) + 'txt')
+    return scalar()
+  }
+  const walk = (obj, depth) => {
+    const isList = Array.isArray(obj) || obj instanceof Automerge.Text
+    const keys = isList ? [...Array(obj.length).keys()] : (obj instanceof Automerge.Table ? obj.ids : Object.keys(obj))
+    const get = k => (obj instanceof Automerge.Text ? obj.get(k) : obj instanceof Automerge.Table ? obj.byId(k) : obj[k])
+    const containers = keys.filter(k => { let v; try { v = get(k) } catch (e) { return false }; return v && typeof v === 'object' && !(v instanceof Date) && !(v instanceof Automerge.Counter) })
+    if (containers.length > 0 && rnd() < 0.6 && depth < 4) return walk(get(pick(containers)), depth + 1)
+    return [obj, depth]
+  }
+  for (let s = 0; s < steps; s++) {
+    const a = Math.floor(rnd() * nActors)
+    try {
+      docs[a] = Automerge.change(docs[a], d => {
+        const nOps = 1 + Math.floor(rnd() * 4)
+        for (let i = 0; i < nOps; i++) {
+          const [obj, depth] = walk(d, 0)
+          if (obj instanceof Automerge.Text) {
+            if (obj.length > 0 && rnd() < 0.35) obj.deleteAt(Math.floor(rnd() * obj.length), 1 + Math.floor(rnd() * Math.min(3, obj.length)))
+            else obj.insertAt(Math.floor(rnd() * (obj.length + 1)), ...(pick(KEYS) + 'ab').split(''))
+          } else if (Array.isArray(obj)) {
+            if (obj.length > 0 && rnd() < 0.35) obj.splice(Math.floor(rnd() * obj.length), 1)
+            else obj.splice(Math.floor(rnd() * (obj.length + 1)), 0, plain(value(depth + 1)))
+          } else if (obj instanceof Automerge.Table) {
+            if (obj.count > 0 && rnd() < 0.3) obj.remove(pick(obj.ids))
+            else obj.add({ name: pick(KEYS), v: Math.floor(rnd() * 100) })
+          } else {
+            const keys = Object.keys(obj).filter(k => k !== 'id')
+            const r = rnd()
+            if (keys.length > 0 && r < 0.15) delete obj[pick(keys)]
+            else if (keys.length > 0 && r < 0.45) {
+              const k = pick(keys)
+              if (obj[k] instanceof Automerge.Counter) { if (rnd() < 0.6) obj[k].increment(1 + Math.floor(rnd() * 5)); else obj[k].decrement(1) }
+              else obj[k] = value(depth + 1)
+            } else obj[pick(KEYS)] = value(depth + 1)
+          }
+        }
+      })
+    } catch (e) { /* the frontend refused this edit */ }
+    if (rnd() < 0.35) { const b = Math.floor(rnd() * nActors); if (b !== a) docs[b] = Automerge.merge(docs[b], docs[a]) }
+  }
+  let all = Automerge.init()
+  for (let i = 0; i < nActors; i++) all = Automerge.merge(all, docs[i])
+  return Automerge.getAllChanges(all)
+}
+const b64 = u8 => Buffer.from(u8.buffer, u8.byteOffset, u8.byteLength).toString('base64')
+const lines = []
+for (const spec of process.argv.slice(3)) {
+  const f = spec.split(':')
+  const changes = f[0] === 't' ? textScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'm' ? servedScenario(+f[1], +f[2], +f[3], +f[4]) : frontendScenario(+f[0], +f[1], +f[2], +f[3])
+  const rnd = splitmix(0xABCD + (f[0] === 't' || f[0] === 'm' ? +f[1] : +f[0]))
+  for (let variant = 0; variant < 3; variant++) {
+    let order = changes.slice()
+    if (variant === 2) {
+      // local shuffles: a change may arrive before its dependencies and wait in the queue
+      for (let i = 0; i + 1 < order.length; i++) {
+        if (rnd() < 0.3) { const j = Math.min(order.length - 1, i + 1 + Math.floor(rnd() * 4)); [order[i], order[j]] = [order[j], order[i]] }
+      }
+    }
+    const calls = []
+    let i = 0
+    while (i < order.length) {
+      const r = rnd()
+      let n = variant === 0 ? 1 + Math.floor(rnd() * 3) : (r < 0.3 ? 1 : r < 0.8 ? 2 + Math.floor(rnd() * 8) : 10 + Math.floor(rnd() * 60))
+      if (variant === 1 && calls.length === 0) n = Math.floor(order.length / 2)   // a big first batch, then small ones
+      calls.push(order.slice(i, i + n))
+      i += n
+    }
+    let backend = Backend.init()
+    const patches = []
+    for (const batch of calls) {
+      try {
+        const [b2, patch] = Backend.applyChanges(backend, batch)
+        backend = b2
+        patches.push(JSON.stringify(patch))
+      } catch (e) {
+        patches.push({ error: String(e.message).split('\n')[0] })
+        break
+      }
+    }
+    lines.push(JSON.stringify({ name: `${spec}#${variant}`, calls: calls.slice(0, patches.length).map(c => c.map(b64)), patches }))
+  }
+  console.error(`${spec}: ${changes.length} changes`)
+}
+fs.writeFileSync(out, lines.join('\n') + '\n')

@@ -305,4 +305,5 @@ function main() {
     console.error(`${name}: ${sc.changes.length} changes, patch ${fx.patch.length} B, doc ${fx.doc ? Buffer.from(fx.doc, 'base64').length : 0} B, stock==bigblock: ${fx.stock_equals_bigblock}`)
   }
 }
-main()
+if (require.main === module) main()
+else module.exports = { splitmix, frontendScenario, textScenario, Automerge, Backend }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE (build container only). Sessions of Backend.applyChanges calls on random multi-actor documents made with the
+real frontend (oracle/js/apply_campaign.js), every call with the patch the unmodified reference returned -- the incremental
+patches of SURVEY.md 8f-2 on documents larger and more concurrent than the reference's own test suites hold.
+-> tests/golden/apply_campaign.json.gz: {"pool": [base64 change...], "sessions": [{"name", "calls": [[pool index...]...],
+"patches": [JSON text | {"error": message}]}]}
+
+  python oracle/make_apply_campaign.py
+"""
+import gzip
+import json
+import os
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPECS = ["m:11:3:120:2", "m:12:4:160:3", "m:15:2:100:3", "m:16:6:140:2", "t:13:4:4:16", "t:14:6:3:24", "t:17:3:8:10", "21:3:70:2"]
+
+
+def main():
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"))
+    env.pop("REF_BLOCK_SIZE", None)
+    with tempfile.TemporaryDirectory() as tmp:
+        raw = os.path.join(tmp, "c.jsonl")
+        subprocess.check_call(["node", os.path.join(ROOT, "oracle", "js", "apply_campaign.js"), raw] + SPECS, env=env)
+        pool, plist, sessions = {}, [], []
+        for line in open(raw):
+            d = json.loads(line)
+            calls = []
+            for call in d["calls"]:
+                idx = []
+                for c in call:
+                    if c not in pool:
+                        pool[c] = len(plist)
+                        plist.append(c)
+                    idx.append(pool[c])
+                calls.append(idx)
+            sessions.append({"name": d["name"], "calls": calls, "patches": d["patches"]})
+    blob = json.dumps({"made_by": "oracle/make_apply_campaign.py: oracle/js/apply_campaign.js " + " ".join(SPECS) + " on the unmodified reference",
+                       "pool": plist, "sessions": sessions}).encode()
+    out = os.path.join(ROOT, "tests", "golden", "apply_campaign.json.gz")
+    with open(out, "wb") as f:
+        f.write(gzip.compress(blob, 9, mtime=0))
+    print(f"{len(sessions)} sessions, {sum(len(s['calls']) for s in sessions)} calls, {len(plist)} changes -> {out} ({os.path.getsize(out)} bytes)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,263 @@
+"""Backend.applyChanges with its incremental patch on the engine (include/am355.h am355_apply_changes).
+
+Checkers: the patches the unmodified reference returned (tests/golden/ref_apply_vectors.json.gz: every applyChanges call of the
+reference's own suites; tests/golden/apply_campaign.json.gz: sessions on random multi-actor documents made with the real
+frontend) and the sequential oracle (oracle/am_oracle_apply.c) on generated logs split into batches.  The engine must return the
+reference's patch text (JS property order included; `clock` may order its keys differently) or refuse the call
+(AM355_E_UNSUPPORTED: the JS path serves it) -- never a different patch, and it must reject what the reference rejects.
+
+CPU suite (`-m "not gpu"`): the kernels under the HIP-runtime emulation of tests/emu on a slice of the vectors.  GPU suite
+(`-m gpu`): everything, full-size logs included."""
+import base64
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from automerge_classic_amd import engine, loggen
+from automerge_classic_amd.loggen import ChangeLog
+from test_apply_vectors import chains, load_vectors, same_patch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libam355_emu.so")
+
+
+def _ordered(text):
+    return json.loads(text, object_pairs_hook=lambda pairs: tuple(pairs))
+
+
+def _same(got, want, local=False):
+    if not local:
+        return same_patch(got, want)
+    g, w = dict(_ordered(got)), dict((k, v) for k, v in _ordered(want) if k not in ("actor", "seq"))
+    return list(g) == list(w) and all(dict(g[k]) == dict(w[k]) if k == "clock" else g[k] == w[k] for k in g)
+
+
+def run_vector_chains(make_engine, max_chain, max_chains=None):
+    """Every call of every chain (sessions that start from an empty document) through a fresh engine context.
+    Returns (equal, refused ids, rejected-like-the-reference)."""
+    vectors, pool = load_vectors()
+    checked, refused = set(), set()
+    equal = rejected = 0
+    done = 0
+    for chain in chains(vectors):
+        if "doc" in vectors[chain[0]] or len(chain) > max_chain:
+            continue
+        if max_chains is not None and done >= max_chains:
+            break
+        done += 1
+        eng = make_engine()
+        try:
+            for j in chain:
+                v = vectors[j]
+                try:
+                    eng.apply_changes(ChangeLog.from_changes([pool[k] for k in v["changes"]]))
+                    got = eng.apply_patch_json()
+                except engine.UnsupportedChanges:
+                    if j not in checked:
+                        checked.add(j)
+                        refused.add(j)
+                    break
+                except engine.InvalidChanges:
+                    if j not in checked:
+                        checked.add(j)
+                        assert "error" in v, f"vector {j}: the engine rejects what the reference accepts"
+                        rejected += 1
+                    break
+                if j in checked:
+                    continue
+                checked.add(j)
+                assert "patch" in v, f"vector {j}: the engine accepts what the reference rejects ({v.get('error')})"
+                assert _same(got, v["patch"], v["local"]), f"vector {j}:\n{got}\n{v['patch']}"
+                equal += 1
+        finally:
+            eng.close()
+    return equal, refused, rejected
+
+
+def load_campaign():
+    with open(os.path.join(HERE, "golden", "apply_campaign.json.gz"), "rb") as f:
+        d = json.loads(gzip.decompress(f.read()))
+    return d["sessions"], [base64.b64decode(x) for x in d["pool"]]
+
+
+def run_campaign(make_engine, names=None):
+    sessions, pool = load_campaign()
+    equal = refused = 0
+    for s in sessions:
+        if names is not None and s["name"] not in names:
+            continue
+        eng = make_engine()
+        try:
+            for ci, (call, want) in enumerate(zip(s["calls"], s["patches"])):
+                try:
+                    eng.apply_changes(ChangeLog.from_changes([pool[k] for k in call]))
+                    got = eng.apply_patch_json()
+                except engine.UnsupportedChanges:
+                    refused += 1
+                    break
+                assert not isinstance(want, dict), f"{s['name']} call {ci}: the reference rejects this batch"
+                assert same_patch(got, want), f"{s['name']} call {ci}:\n{got}\n{want}"
+                equal += 1
+        finally:
+            eng.close()
+    return equal, refused
+
+
+def split_log(log, n_batches):
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    changes = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    per = (len(changes) + n_batches - 1) // n_batches
+    return [changes[i:i + per] for i in range(0, len(changes), per)]
+
+
+def check_against_oracle_session(eng, batches):
+    """The engine's patch of every batch == the oracle's, and the state afterwards == the bulk replay."""
+    session = oracle_lib.OracleSession()
+    for k, batch in enumerate(batches):
+        want = session.apply(batch)
+        eng.apply_changes(ChangeLog.from_changes(batch))
+        got = eng.apply_patch_json()
+        assert same_patch(got, want), f"batch {k}:\n{got[:3000]}\n{want[:3000]}"
+    assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"]
+
+
+def interpret_edits(patch_text, texts):
+    """Applies the list edits of an incremental patch to `texts` ({objectId: list}) like the frontend does (apply_patch.js)."""
+    def visit(node):
+        if "edits" in node:
+            cur = texts.setdefault(node["objectId"], [])
+            for e in node["edits"]:
+                if e["action"] == "insert":
+                    cur.insert(e["index"], e["value"].get("value"))
+                elif e["action"] == "multi-insert":
+                    cur[e["index"]:e["index"]] = e["values"]
+                elif e["action"] == "remove":
+                    del cur[e["index"]:e["index"] + e["count"]]
+                elif e["action"] == "update":
+                    cur[e["index"]] = e["value"].get("value")
+        for vals in node.get("props", {}).values():
+            for v in vals.values():
+                if isinstance(v, dict) and "objectId" in v:
+                    visit(v)
+    visit(json.loads(patch_text)["diffs"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU: kernels under emulation
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    return EMU_LIB
+
+
+def test_reference_suite_calls_emulated(emu_lib):
+    equal, refused, rejected = run_vector_chains(lambda: engine.Engine(0, emu_lib), max_chain=4, max_chains=220)
+    assert equal >= 180
+    assert len(refused) <= equal // 8
+
+
+def test_campaign_sessions_emulated(emu_lib):
+    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), names={"t:13:4:4:16#0", "t:13:4:4:16#2", "m:15:2:100:3#1", "m:11:3:120:2#2"})
+    assert equal >= 20
+
+
+@pytest.mark.parametrize("kind,kw,n_batches", [
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=6, n_rounds=4, ins_per_change=30, del_per_change=9, n_objects=1), 3),
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=5, n_rounds=3, ins_per_change=12, del_per_change=5, n_objects=4), 5),
+    (loggen.KIND_MAP_LWW, dict(n_actors=6, n_rounds=3, n_keys=60), 4),
+    (loggen.KIND_TEXT_TYPING, dict(n_ops=500, ops_per_change=20), 6),
+])
+def test_generated_logs_in_batches_match_the_oracle_emulated(emu_lib, kind, kw, n_batches):
+    log = loggen.generate(kind, seed=23, **kw)
+    eng = engine.Engine(0, emu_lib)
+    try:
+        check_against_oracle_session(eng, split_log(log, n_batches))
+    finally:
+        eng.close()
+
+
+def test_apply_after_load_changes_and_queue_emulated(emu_lib):
+    """loadChanges + replay, then applyChanges on top; a batch delivered out of order waits in the queue (new.js:1822-1841)."""
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=4, ins_per_change=10, del_per_change=3, n_objects=1, seed=5)
+    batches = split_log(log, 4)
+    eng = engine.Engine(0, emu_lib)
+    session = oracle_lib.OracleSession()
+    try:
+        eng.load_changes(ChangeLog.from_changes(batches[0]))
+        eng.replay()
+        session.apply(batches[0])
+        # batch 2 arrives before batch 1: everything in it waits; batch 1 then releases it
+        for batch in (batches[2], batches[1], batches[3]):
+            want = session.apply(batch)
+            eng.apply_changes(ChangeLog.from_changes(batch))
+            assert same_patch(eng.apply_patch_json(), want)
+        assert json.loads(eng.apply_patch_json())["pendingChanges"] == 0
+    finally:
+        eng.close()
+
+
+def test_assignment_to_a_list_element_is_refused_emulated(emu_lib):
+    sessions, pool = load_campaign()
+    s = next(x for x in sessions if x["name"].startswith("21:"))
+    eng = engine.Engine(0, emu_lib)
+    try:
+        with pytest.raises(engine.UnsupportedChanges):
+            for call in s["calls"]:
+                eng.apply_changes(ChangeLog.from_changes([pool[k] for k in call]))
+    finally:
+        eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_reference_suite_calls_gpu():
+    equal, refused, rejected = run_vector_chains(lambda: engine.Engine(0), max_chain=40)
+    assert equal >= 800 and rejected >= 3
+    assert len(refused) <= equal // 10
+
+
+@pytest.mark.gpu
+def test_campaign_sessions_gpu():
+    equal, refused = run_campaign(lambda: engine.Engine(0))
+    assert equal >= 250
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,scale,n_batches", [
+    ("c4_text_single", 0.1, 5), ("c4_text_multi", 0.1, 3), ("c3_map_lww", 1.0, 4), ("c2_text_typing", 1.0, 7), ("c4_text_single", 1.0, 4),
+])
+def test_bench_workloads_in_batches_match_the_oracle_gpu(name, scale, n_batches):
+    log = loggen.config(name, scale)
+    eng = engine.Engine(0)
+    try:
+        check_against_oracle_session(eng, split_log(log, n_batches))
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_full_size_edits_rebuild_the_text_gpu():
+    """Size-independent property: the edits of the incremental patches, applied one batch after the other like the frontend applies
+    them, build the text the whole-document patch of the final state holds (1 M-op headline log in 8 batches)."""
+    log = loggen.config("c4_text_single", 1.0)
+    eng = engine.Engine(0)
+    try:
+        texts = {}
+        for batch in split_log(log, 8):
+            eng.apply_changes(ChangeLog.from_changes(batch))
+            interpret_edits(eng.apply_patch_json(), texts)
+        final = {}
+        interpret_edits(eng.patch_json(), final)
+        assert texts == final and sum(len(v) for v in final.values()) > 500_000
+    finally:
+        eng.close()
