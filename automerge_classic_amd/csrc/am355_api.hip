@@ -313,6 +313,7 @@ struct am355_ctx {
   DeltaBufs delta{};
   ApplyPatch apply;
   bool apply_ready = false;
+  bool state_checked = false;  // the state was built by am355_apply_changes calls (each checked for what later patches depend on) or is empty
   std::string apply_json;
 
   // objectId sharding (am355_set_shard): this context merges the objects rank `shard_rank` of `shard_world` owns
@@ -457,6 +458,7 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
   c->staged = c->replayed = c->ir_fetched = false;
   c->apply_ready = false;
+  c->state_checked = false;
   c->is_document = false;
   c->flags = 0;
   if (n && offsets[n] - offsets[0] >= ((uint64_t)1 << 20))
@@ -1472,6 +1474,10 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   uint8_t* d_tables = c->d_tables.as<uint8_t>();
   c->p_spans = (ActorSpan*)(d_tables + o_spans);
   c->p_tab_off = (uint32_t*)(d_tables + o_tab);
+  // every merge run signals under its own sequence number: when the optimistic in-order run of this replay is discarded (the hash
+  // stream found a late or missing dependency) the general path merges again, and must not take the first run's counters -- already
+  // signalled under the replay's number -- for its own
+  c->sig_seq++;
   int rcb = setup_buffers(c, (uint32_t)c->actors.size());
   if (rcb) return rcb;
   // decoder classes: changes whose columns fit the small LDS footprint first, then the large footprint, then the (rare)
@@ -1554,6 +1560,7 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   uint8_t* d_tables = c->d_tables.as<uint8_t>();
   c->p_spans = (ActorSpan*)d_tables;
   c->p_tab_off = (uint32_t*)(d_tables + o_tab);
+  c->sig_seq++;  // (see run_device)
   int rcb = setup_buffers(c, n_distinct);
   if (rcb) return rcb;
   lap("buffers carved");
@@ -2072,6 +2079,31 @@ static int patch_json_impl(am355_ctx* c, const char** json, size_t* len) {
 // ---------------------------------------------------------------------------------------------------------
 // Backend.applyChanges with its incremental patch (include/am355.h am355_apply_changes)
 // ---------------------------------------------------------------------------------------------------------
+
+// the device stage of am355_apply_changes over the replayed state of the context: rows >= T0 are the batch
+static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool check_only) {
+  hipStream_t st = c->stream;
+  const uint32_t N = (uint32_t)c->n_ops, NN = N - T0;
+  const uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NL = c->counts.n_list_ins;
+  if (c->pass_first_row.size() > 4096) return fail(c, AM355_E_UNSUPPORTED, "more scheduling passes than the incremental patch stage handles");
+  if (!c->d_delta.ensure(delta_bytes(N, NN, NM, NO, NL)) || !c->d_pass.ensure(4 * (c->pass_first_row.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
+  DeltaBufs& d = c->delta;
+  delta_bind(d, c->d_delta.p, N, NN, NM, NO, NL);
+  d.T0 = T0; d.n_new = NN; d.n_obj = NO; d.n_map = NM; d.n_list = NL;
+  d.bits_new = (uint32_t)bits_for64(NN ? NN - 1 : 0);
+  std::vector<uint32_t> pass_rows;
+  for (uint32_t r : c->pass_first_row) if (r > T0) pass_rows.push_back(r);
+  d.n_pass = (uint32_t)pass_rows.size();
+  d.pass_rows = c->d_pass.as<uint32_t>();
+  if (d.n_pass) {
+    HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));  // (pass_rows is pageable memory)
+  }
+  delta_run(c->mb, c->ir, d, hc, st, check_only);
+  HIPCHK(c, hipGetLastError());
+  return AM355_OK;
+}
+
 static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
@@ -2082,6 +2114,17 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   if (have_state && !c->replayed) return fail(c, AM355_E_STATE, "the context holds no replayed state (the last replay failed?)");
   for (uint32_t i = 0; i < n; i++)
     if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
+  if (have_state && !c->state_checked) {
+    // The state came from ONE am355_load_changes + am355_replay (Backend.loadChanges: one call of the reference). The patches of later
+    // calls lean on objectMeta.children of the reference being the visible values of every property that holds a visible child
+    // object (am355_apply.cpp) -- true unless the merge loop of that one call skipped values of such a property: checked now, with
+    // every row of the state taken as the batch.
+    DeltaCounts pre{};
+    int prc = run_delta_stage(c, 0, &pre, true);
+    if (prc) return prc;
+    if (pre.hazard) { c->flags |= AM355_F_UNSUPPORTED; return fail(c, AM355_E_UNSUPPORTED, "the state holds a property whose child-object bookkeeping depends on how the reference merged it (JS path)"); }
+    c->state_checked = true;
+  }
   // ---- the queue of the call: changes applied so far (application order) | the batch | changes still queued (new.js:1822) ----
   const uint32_t n_old_applied = have_state ? (uint32_t)c->applied_change.size() : 0;
   const uint64_t old_ops = have_state ? c->n_ops : 0;
@@ -2118,24 +2161,13 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
 
   // ---- delta stage on the device ----
   hipStream_t st = c->stream;
-  const uint32_t N = (uint32_t)c->n_ops, T0 = (uint32_t)old_ops, NN = N - T0;
-  const uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NL = c->counts.n_list_ins;
-  if (c->pass_first_row.size() > 4096) return fail(c, AM355_E_UNSUPPORTED, "more scheduling passes than the incremental patch stage handles");
-  if (!c->d_delta.ensure(delta_bytes(N, NN, NM, NO, NL)) || !c->d_pass.ensure(4 * (c->pass_first_row.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
+  const uint32_t NO = c->counts.n_objects;
   DeltaBufs& d = c->delta;
-  delta_bind(d, c->d_delta.p, N, NN, NM, NO, NL);
-  d.T0 = T0; d.n_new = NN; d.n_obj = NO; d.n_map = NM; d.n_list = NL;
-  d.bits_new = (uint32_t)bits_for64(NN ? NN - 1 : 0);
-  std::vector<uint32_t> pass_rows;
-  for (uint32_t r : c->pass_first_row) if (r > T0) pass_rows.push_back(r);
-  d.n_pass = (uint32_t)pass_rows.size();
-  d.pass_rows = c->d_pass.as<uint32_t>();
-  if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
   DeltaCounts hc{};
-  if (d.n_pass) HIPCHK(c, hipStreamSynchronize(st));  // (pass_rows is pageable memory)
-  delta_run(c->mb, c->ir, d, &hc, st);
-  HIPCHK(c, hipGetLastError());
-  if (hc.flags) return error_for_flags(c, hc.flags, "incremental patch not served");
+  rc = run_delta_stage(c, (uint32_t)old_ops, &hc, false);
+  if (rc) return rc;
+  c->state_checked = true;  // (a call the engine served: checked; a refused call leaves the state to the JS path)
+  if (hc.flags) { c->state_checked = false; return error_for_flags(c, hc.flags, "incremental patch not served"); }
 
   // ---- tables to the host, setupPatches, assembly ----
   rc = fetch_ir_impl(c, nullptr);
@@ -2156,6 +2188,28 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; return fail(c, rc, "%s", err.c_str()); }
   c->apply_ready = true;
   c->apply_json.clear();
+  return AM355_OK;
+}
+
+extern "C" int am355_reset(am355_ctx* c) {
+  if (!c) return AM355_E_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->staging_in_flight) { c->staging_in_flight = false; (void)hipStreamSynchronize(c->stream); }
+  c->staged = c->replayed = c->ir_fetched = c->apply_ready = false;
+  c->state_checked = true;
+  c->is_document = false;
+  c->flags = 0;
+  c->n_changes = 0;
+  c->applied_change.clear();
+  c->pending_change.clear();
+  return AM355_OK;
+}
+
+extern "C" int am355_get_pending(const am355_ctx* c, uint32_t* out, uint32_t* n_pending) {
+  if (!c || !n_pending) return AM355_E_ARG;
+  if (!c->replayed || c->is_document) return AM355_E_STATE;
+  *n_pending = (uint32_t)c->pending_change.size();
+  if (out && !c->pending_change.empty()) memcpy(out, c->pending_change.data(), 4 * c->pending_change.size());
   return AM355_OK;
 }
 

@@ -30,7 +30,8 @@ struct DeltaCounts {
   uint32_t n_place;    // touched map keys left without a visible value
   uint32_t n_erecs;    // delta edit records
   uint32_t n_slots;    // touched map keys
-  uint32_t pad[2];
+  uint32_t hazard;     // a key that holds a visible child object lost values to the merge loop's skipping rule (see kd_placeholders)
+  uint32_t pad;
 };
 
 // Device memory of the delta stage, carved by the caller (delta_bytes / delta_bind). N = op rows, NN = new rows, NM = map records
@@ -73,6 +74,8 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t n_ops, uint32_t n_new, uint3
 
 // Runs the stage on `st` and synchronises it. On return *hc holds the counters (hc->flags != 0: refused / invalid), the delta tables
 // d.edit [n_erecs + 1], d.map [n_kept + n_place] and d.link [n_obj] are complete in device memory.
-void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st);
+// check_only: stop after the checks over the touched map keys (hc->hazard / hc->flags); no tables are produced. Used on a state
+// that one am355_load_changes + am355_replay built (T0 = 0: every row is "new"), before the first am355_apply_changes onto it.
+void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only = false);
 
 }  // namespace am355

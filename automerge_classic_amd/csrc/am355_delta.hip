@@ -32,6 +32,11 @@
 #include "am355_prims.h"
 #include "am355_rows.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 namespace am355 {
 
 static inline dim3 dgrid(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void kd_placeholders(DeltaBufs d) {
     pl = d.slot_cnt[s] == 0 ? 1u : 0u;
     // values were skipped on a key that holds a child object: objectMeta.children of the reference now lacks them, which later
     // patches would show (new.js:916-931) -- a state this engine does not carry
-    if (d.slot_child[s] && d.slot_drop[s]) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
+    if (d.slot_child[s] && d.slot_drop[s]) { d.counts->hazard = 1; atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED); }
   }
   d.place[s] = pl;
 }
@@ -441,8 +446,14 @@ static int dbits_for(uint64_t max_value) {
   return b;
 }
 
-void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st) {
+void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only) {
   const uint32_t N = b.n_ops, cap = d.key_mask + 1;
+  static const bool debug = getenv("AM355_DELTA_DEBUG") != nullptr;  // (diagnostic: drain the stream after every step and say which)
+  auto step = [&](const char* what) {
+    if (!debug) return;
+    hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, "delta_run: %-18s %s (N %u T0 %u new %u obj %u map %u list %u cap %u)\n", what, hipGetErrorString(e), N, d.T0, d.n_new, d.n_obj, d.n_map, d.n_list, cap);
+  };
   (void)hipMemsetAsync(d.counts, 0, sizeof(DeltaCounts), st);
   (void)hipMemsetAsync(d.first_del, 0xff, 4 * ((size_t)N + 1), st);
   (void)hipMemsetAsync(d.new_succ, 0, 4 * ((size_t)N + 1), st);
@@ -454,23 +465,45 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   (void)hipMemsetAsync(d.slot_child, 0, 4 * ((size_t)cap + 1), st);
   (void)hipMemsetAsync(d.slot_drop, 0, 4 * ((size_t)cap + 1), st);
   AM355_LAUNCH_INDEPENDENT(kd_objects, dgrid(d.n_obj), dim3(BLOCK), st, b, ir, d);
+  step("objects");
   if (N) AM355_LAUNCH_INDEPENDENT(kd_rows, dgrid(N), dim3(BLOCK), st, b, d);
+  step("rows");
+  if (debug) {
+    std::vector<uint32_t> ord(d.n_list + 1);
+    (void)hipMemcpy(ord.data(), b.order, 4 * (size_t)d.n_list, hipMemcpyDeviceToHost);
+    uint32_t bad = 0;
+    for (uint32_t k = 0; k < d.n_list; k++) if (ord[k] >= N) { bad++; fprintf(stderr, "delta_run:   order[%u] = 0x%x\n", k, ord[k]); }
+    {
+      std::vector<uint32_t> fp(d.n_obj + 2), on(d.n_obj + 2);
+      (void)hipMemcpy(fp.data(), b.obj_first_pos, 4 * (size_t)(d.n_obj + 1), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(on.data(), b.obj_n, 4 * (size_t)(d.n_obj + 1), hipMemcpyDeviceToHost);
+      for (uint32_t k = 0; k <= d.n_obj; k++) fprintf(stderr, "delta_run:   object %u first_pos %u n %u\n", k, fp[k], on[k]);
+    }
+    fprintf(stderr, "delta_run: order[0..%u): %u entries out of range; first %u %u %u\n", d.n_list, bad, d.n_list ? ord[0] : 0, d.n_list > 1 ? ord[1] : 0, d.n_list > 2 ? ord[2] : 0);
+  }
   // ---- lists: items in position order ----
   AM355_LAUNCH_INDEPENDENT(kd_positions, dgrid(d.n_list + 1), dim3(BLOCK), st, b, d);
+  step("positions");
   exclusive_scan2_u32(d.v0, d.v0_ex, nullptr, d.icnt, d.item_ex, nullptr, d.n_list + 1, d.scan_ws, st);
+  step("scan positions");
   if (d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items, dgrid(d.n_list), dim3(BLOCK), st, b, d);
+  step("items");
   // ---- maps: touched keys, kept records, placeholders ----
   AM355_LAUNCH_INDEPENDENT(kd_slots, dgrid(cap), dim3(BLOCK), st, b, d);
+  step("slots");
   AM355_LAUNCH_INDEPENDENT(kd_map_records, dgrid(d.n_map + 1), dim3(BLOCK), st, b, ir, d);
+  step("map records");
   AM355_LAUNCH_INDEPENDENT(kd_placeholders, dgrid(cap + 1), dim3(BLOCK), st, d);
+  step("placeholders");
   exclusive_scan_u32(d.keep, d.keep_ex, d.n_map + 1, nullptr, d.scan_ws, st);
   exclusive_scan_u32(d.place, d.place_ex, cap + 1, nullptr, d.scan_ws, st);
+  step("scans");
   (void)hipMemcpyAsync(&d.counts->n_items, d.item_ex + d.n_list, 4, hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(&d.counts->n_kept, d.keep_ex + d.n_map, 4, hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(&d.counts->n_place, d.place_ex + cap, 4, hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
-  if (hc->flags) return;
+  if (hc->flags || check_only) return;
 
   // ---- list edits: dominance counts by binary partitions on the time bits, most significant first ----
   const uint32_t m = hc->n_items;

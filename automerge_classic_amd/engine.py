@@ -89,9 +89,11 @@ def _bind(path):
     L.am355_apply_changes.argtypes = [vp, vp, u64p, u32]
     L.am355_apply_patch_json.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
     L.am355_fetch_apply_ir.argtypes = [vp, vp]
+    L.am355_reset.argtypes = [vp]
+    L.am355_get_pending.argtypes = [vp, vp, ctypes.POINTER(u32)]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
-              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir"):
+              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -159,6 +161,20 @@ class Engine:
         offsets = np.ascontiguousarray(log.offsets, dtype=np.uint64)
         self._check(self._L.am355_apply_changes(self._h, arena.ctypes.data if arena.size else None, offsets.ctypes.data, int(offsets.size - 1)))
         self._n_changes = int(self.stats().n_changes)
+
+    def reset(self):
+        """Forget the state: the next apply_changes starts from Backend.init()."""
+        self._check(self._L.am355_reset(self._h))
+        self._n_changes = 0
+
+    def pending(self):
+        """Indexes (into the engine's list of changes) of the changes still queued for a missing dependency."""
+        n = ctypes.c_uint32()
+        self._check(self._L.am355_get_pending(self._h, None, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            self._check(self._L.am355_get_pending(self._h, out.ctypes.data, ctypes.byref(n)))
+        return out
 
     def apply_patch_json(self):
         """JSON.stringify of the patch the last apply_changes returned (the reference's incremental patch)."""

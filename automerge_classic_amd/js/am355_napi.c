@@ -97,7 +97,9 @@ static napi_value js_destroy(napi_env env, napi_callback_info info) {
   return u;
 }
 
-static napi_value js_load_changes(napi_env env, napi_callback_info info) {
+/* loadChanges(ctx, changes) = am355_load_changes; applyChanges(ctx, changes) = am355_apply_changes (Backend.applyChanges onto the
+ * state the context holds: the incremental patch is then read with fetchApplyIR / applyPatchJSON) */
+static napi_value stage_changes(napi_env env, napi_callback_info info, int apply) {
   size_t argc = 2;
   napi_value argv[2];
   NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -131,7 +133,7 @@ static napi_value js_load_changes(napi_env env, napi_callback_info info) {
     napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off);
     if (len) memcpy(arena + offsets[i], data, len);
   }
-  int rc = am355_load_changes(ctx, arena, offsets, n);
+  int rc = apply ? am355_apply_changes(ctx, arena, offsets, n) : am355_load_changes(ctx, arena, offsets, n);
   free(arena);
   free(offsets);
   if (rc) return throw_engine(env, ctx, rc);
@@ -139,6 +141,8 @@ static napi_value js_load_changes(napi_env env, napi_callback_info info) {
   napi_get_undefined(env, &u);
   return u;
 }
+static napi_value js_load_changes(napi_env env, napi_callback_info info) { return stage_changes(env, info, 0); }
+static napi_value js_apply_changes(napi_env env, napi_callback_info info) { return stage_changes(env, info, 1); }
 
 static napi_value js_load_document(napi_env env, napi_callback_info info) {
   size_t argc = 2;
@@ -227,6 +231,37 @@ static napi_value js_applied_order(napi_env env, napi_callback_info info) {
   return ta;
 }
 
+/* pendingOrder(ctx) -> Uint32Array: am355_get_pending (the changes still queued, as indexes into the engine's list of changes) */
+static napi_value js_pending_order(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t n = 0;
+  int rc = am355_get_pending(ctx, NULL, &n);
+  if (rc) return throw_engine(env, ctx, rc);
+  void *data = NULL;
+  napi_value ab, ta;
+  NAPI_CALL(env, napi_create_arraybuffer(env, (size_t)n * 4, &data, &ab));
+  if (n) am355_get_pending(ctx, (uint32_t *)data, &n);
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint32_array, n, ab, 0, &ta));
+  return ta;
+}
+
+static napi_value js_reset(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  int rc = am355_reset(ctx);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
 static napi_value js_hashes(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -264,14 +299,14 @@ static napi_value copy_to_arraybuffer(napi_env env, const void *src, size_t len)
 /* fetchIR(ctx) -> {objects, map, edits, arena: ArrayBuffer, nObjects, nMap, nEdits, nValues, maxOp, pending,
  *                  actorOff: ArrayBuffer(u32), actorBytes: ArrayBuffer, clockActor: ArrayBuffer(u32), clockSeq: ArrayBuffer(f64), heads: ArrayBuffer}
  * am355_fetch_ir: the record tables of include/am355.h as the device wrote them; materialize.js builds the patch object. */
-static napi_value js_fetch_ir(napi_env env, napi_callback_info info) {
+static napi_value fetch_ir_common(napi_env env, napi_callback_info info, int apply) {
   size_t argc = 1;
   napi_value argv[1];
   NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   am355_ctx *ctx = get_ctx(env, argv[0]);
   if (!ctx) return NULL;
   am355_patch_ir ir;
-  int rc = am355_fetch_ir(ctx, &ir);
+  int rc = apply ? am355_fetch_apply_ir(ctx, &ir) : am355_fetch_ir(ctx, &ir);
   if (rc) return throw_engine(env, ctx, rc);
   napi_value o;
   NAPI_CALL(env, napi_create_object(env, &o));
@@ -302,6 +337,9 @@ static napi_value js_fetch_ir(napi_env env, napi_callback_info info) {
   set_num(env, o, "pending", ir.pending);
   return o;
 }
+static napi_value js_fetch_ir(napi_env env, napi_callback_info info) { return fetch_ir_common(env, info, 0); }
+/* fetchApplyIR(ctx): the patch of the last applyChanges as record tables (am355_fetch_apply_ir) */
+static napi_value js_fetch_apply_ir(napi_env env, napi_callback_info info) { return fetch_ir_common(env, info, 1); }
 
 /* docChanges(ctx, flags) -> { changes: Uint8Array[], hashes: Uint8Array }: am355_doc_changes -- the history of a loaded document
  * (Backend.getAllChanges(Backend.load(bytes)), new.js:1887-1927). The changes are views into ONE JS-owned ArrayBuffer (the
@@ -372,6 +410,10 @@ static napi_value init(napi_env env, napi_value exports) {
       {"stats", NULL, js_stats, NULL, NULL, NULL, napi_enumerable, NULL},
       {"docChanges", NULL, js_doc_changes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"fetchIR", NULL, js_fetch_ir, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"applyChanges", NULL, js_apply_changes, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"pendingOrder", NULL, js_pending_order, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"reset", NULL, js_reset, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"fetchApplyIR", NULL, js_fetch_apply_ir, NULL, NULL, NULL, napi_enumerable, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

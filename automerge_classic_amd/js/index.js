@@ -6,8 +6,10 @@
 //
 // Module surface = reference backend/index.js:1-8.  GPU-served calls (SURVEY.md "Scope decisions"):
 //   loadChanges(init(), changes)  and  getPatch(state)             (backend/backend.js:116-129, new.js:1797-1879, 2060-2068)
-// i.e. the pair behind Automerge.load / getHistory / clone.  Everything else (applyLocalChange, incremental
-// applyChanges, save, clone, hash-graph queries, sync protocol) is delegated to the reference JS backend, onto
+//   applyChanges(state, changes) with its incremental patch        (backend/backend.js:27-31; SURVEY.md 8f-2) when `state` is empty
+//                                                                  or was built by the engine
+//   load / save / getAllChanges after load                         (SURVEY.md a21, 8f-1, 8f-3)
+// Everything else (applyLocalChange, clone, hash-graph queries with dependencies) is delegated to the reference JS backend, onto
 // which a GPU-built state is hydrated lazily -- by replaying the retained change buffers -- the first time such a
 // call is made.  Inputs the engine rejects (AM355_E_INVALID: the reference would throw; AM355_E_UNSUPPORTED: legal
 // but outside the GPU-served subset) are re-run on the JS path so the caller sees the reference's exact exception
@@ -59,6 +61,7 @@ class GpuState {
     this.hashes = null       // 32 bytes per input change
     this.pending = 0
     this.byHash = null       // lazily: hex hash -> input index, applied changes only
+    this.pendingIdx = null   // input indexes of the changes still queued (loadChanges / applyChanges states)
   }
 }
 let generation = 0           // bumped by every GPU replay
@@ -83,7 +86,7 @@ function contextOf(gen) {
   if (e) { e.used = ++tick; ctx = e.ctx }
   return e || null
 }
-const counters = { gpuLoadChanges: 0, gpuLoad: 0, gpuSave: 0, gpuHistory: 0, saveReplays: 0, fallbackToJs: 0, hydrations: 0 }   // (diagnostics: which path served the calls)
+const counters = { gpuLoadChanges: 0, gpuLoad: 0, gpuSave: 0, gpuHistory: 0, gpuApplyChanges: 0, saveReplays: 0, fallbackToJs: 0, hydrations: 0 }   // (diagnostics: which path served the calls)
 
 function isFrozenCheck(backend) {
   // reference util.js:1-10
@@ -167,6 +170,7 @@ function loadChanges(backend, changes) {
       const state = new GpuState(changes.slice(), patch, patch.deps)
       state.generation = generation
       state.applied = addon.appliedOrder(ctx)
+      state.pendingIdx = addon.pendingOrder(ctx)
       state.hashes = addon.hashes(ctx)
       state.pending = patch.pendingChanges
       return { state, heads: patch.deps }
@@ -181,7 +185,16 @@ function loadChanges(backend, changes) {
 
 function getPatch(backend) {
   isFrozenCheck(backend)
-  if (backend.state instanceof GpuState) return backend.state.patch
+  if (backend.state instanceof GpuState) {
+    const g = backend.state
+    if (!g.patch) {
+      // a state made by applyChanges: the whole-document patch is built when somebody asks for it (the engine context that
+      // replayed the state still holds its record tables, else the retained changes are replayed)
+      if (contextOf(g.generation)) g.patch = gpuPatch()
+      else { g.patch = gpuReplay(g.changes); g.generation = generation }
+    }
+    return g.patch
+  }
   return ref().getPatch(backend)
 }
 
@@ -294,6 +307,62 @@ function getMissingDeps(backend, heads = []) {   // new.js:2014-2028 with an emp
   return ref().getMissingDeps(hydrate(backend), heads)
 }
 
+// Backend.applyChanges(backend, changes) -> [backend', patch] (backend.js:27-31, new.js:1797-1879) on the engine: the state is empty
+// (applyChanges(init(), changes): everything arrives in one batch) or was built by the engine, whose context then replays the
+// earlier changes and the batch together and derives the incremental patch on the device (am355_apply_changes). What the engine
+// refuses (an assignment to a list element, an edit inside an object the document no longer reaches ...) or rejects is served by
+// the reference path, which returns the reference's patch or throws its exception.
+function gpuApplyChanges(backend, changes) {
+  const g = backend.state instanceof GpuState ? backend.state : null
+  if (g && g.doc && !g.changes) {
+    loadedHistory(g)   // a loaded document: its changes, rebuilt by the engine (am355_doc_changes)
+    if (!g.changes) return null
+  }
+  if (g && !g.changes) return null
+  let entry
+  if (g) {
+    if (g.doc || !(entry = contextOf(g.generation))) { gpuReplay(g.changes); g.generation = generation; entry = contextOf(generation) }
+    if (!g.applied || !g.pendingIdx) { g.applied = addon.appliedOrder(ctx); g.pendingIdx = addon.pendingOrder(ctx) }
+  } else {
+    entry = acquireContext()
+    addon.reset(ctx)
+  }
+  try {
+    addon.applyChanges(ctx, changes)
+  } catch (e) {
+    entry.generation = 0   // (whatever the context holds now is nobody's state)
+    throw e
+  }
+  const patch = materialize(addon.fetchApplyIR(ctx))
+  // the engine's list of changes: those applied so far in application order, the batch, those that were queued
+  const list = g ? Array.from(g.applied, i => g.changes[i]).concat(changes, Array.from(g.pendingIdx, i => g.changes[i])) : changes.slice()
+  const state = new GpuState(list, null, patch.deps)
+  entry.generation = ++generation
+  state.generation = generation
+  state.applied = addon.appliedOrder(ctx)
+  state.pendingIdx = addon.pendingOrder(ctx)
+  state.hashes = addon.hashes(ctx)
+  state.pending = patch.pendingChanges
+  counters.gpuApplyChanges++
+  return [{ state, heads: patch.deps }, patch]
+}
+
+function applyChanges(backend, changes) {
+  isFrozenCheck(backend)
+  const served = !JS_ONLY && Array.isArray(changes) && changes.length > 0 && changes.every(c => c instanceof Uint8Array) &&
+    ((backend.state instanceof GpuState && !backend.state.js) || isEmptyRefState(backend))
+  if (served) {
+    try {
+      const result = gpuApplyChanges(backend, changes)
+      if (result) { backend.frozen = true; return result }
+    } catch (e) {
+      if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED && !(e instanceof TypeError)) throw e
+      counters.fallbackToJs++
+    }
+  }
+  return ref().applyChanges(toJs(backend), changes)
+}
+
 function free(backend) {
   if (backend.state instanceof GpuState) { backend.state = null; backend.frozen = true } else ref().free(backend)
 }
@@ -315,7 +384,7 @@ const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...ar
 module.exports = {
   init, load, loadChanges, getPatch, getHeads, free, save, getAllChanges, getChanges, getChangeByHash, getMissingDeps,
   clone: backend => ref().clone(hydrate(backend)),
-  applyChanges: delegate1('applyChanges'),
+  applyChanges,
   applyLocalChange: delegate1('applyLocalChange'),
   getChangesAdded: (b1, b2) => ref().getChangesAdded(hydrate(b1), hydrate(b2)),
   // sync protocol: unchanged reference code operating on JS handles (backend/sync.js:20 binds the JS backend)

@@ -5,13 +5,13 @@
 //   envelope                       backend/new.js:2064-2067   {maxOp, clock, deps, pendingChanges, diffs}
 //   object patch                   backend/new.js:726-732     {objectId, type, props} | {objectId, type, edits}
 //   map props                      backend/new.js:1035-1039   props[key][opId] = valueDiff
-//   list edits                     backend/new.js:747-782     insert / multi-insert / update (appendEdit)
+//   list edits                     backend/new.js:747-782     insert / multi-insert / update (appendEdit); remove in the patches of applyChanges
 //   values                         backend/columnar.js:300-329 decodeValue, new.js:963 (counter), :971 ({type: 'value', ...})
 // Values are real JS values (float64 NaN / Infinity stay what they are, byte arrays are Uint8Arrays): nothing goes through JSON text.
 'use strict'
 
 const OBJ_WORDS = 8, MAP_WORDS = 10, EDIT_WORDS = 10
-const MAP_COUNTER = 1, MAP_CHILD = 2, EDIT_UPDATE = 1, EDIT_CONT = 2, EDIT_CHILD = 4
+const MAP_COUNTER = 1, MAP_CHILD = 2, MAP_EMPTY = 4, EDIT_UPDATE = 1, EDIT_CONT = 2, EDIT_CHILD = 4, EDIT_REMOVE = 8
 const TYPE_NAME = { 0: 'map', 2: 'list', 4: 'text', 6: 'table' }
 const HEX = []
 for (let i = 0; i < 256; i++) HEX.push((i < 16 ? '0' : '') + i.toString(16))
@@ -122,6 +122,7 @@ class Materializer {
       const values = {}
       for (let k = i; k < j; k++) {
         const w = k * MAP_WORDS, flags = m[w + 6]
+        if (flags & MAP_EMPTY) continue   // incremental patch: the key is left without a value, `props[key] = {}` (new.js:1037)
         const id = this.opId(m[w], m[w + 1])
         if (flags & MAP_COUNTER) {
           const lo = this.mapCounter.getUint32(k * 40 + 32, true), hi = this.mapCounter.getInt32(k * 40 + 36, true)
@@ -147,7 +148,9 @@ class Materializer {
       const count = e[w + EDIT_WORDS + 6] - first
       let j = k + 1
       while (j < end && (e[j * EDIT_WORDS] & EDIT_CONT)) j++   // further records of the same multi-insert (its values change length)
-      if (count >= 2 || j > k + 1) {
+      if (flags & EDIT_REMOVE) {
+        out.push({ action: 'remove', index, count })   // incremental patch (new.js:1029, 775-777)
+      } else if (count >= 2 || j > k + 1) {
         let values
         if (j === k + 1 && (tl & 15) === 6 && (tl >>> 4) === 1) {
           // the common record: a run of typed single-byte characters, back to back in the arena

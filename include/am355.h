@@ -221,6 +221,12 @@ int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
  * state (load again).
  */
 int am355_apply_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes);
+/* Forget the state the context holds: the next am355_apply_changes is Backend.applyChanges(Backend.init(), changes). */
+int am355_reset(am355_ctx *ctx);
+/* Input indexes of the changes still queued for a missing dependency (BackendDoc.queue, new.js:1866), in queue order. The engine's
+ * own list of changes after am355_apply_changes is: the changes applied before the call in application order, the batch, the
+ * changes queued before the call -- am355_get_applied / am355_get_pending / am355_get_hashes index that list. out may be NULL. */
+int am355_get_pending(const am355_ctx *ctx, uint32_t *out, uint32_t *n_pending);
 /* JSON.stringify of the patch Backend.applyChanges returned -- byte for byte; valid until the next call on ctx */
 int am355_apply_patch_json(am355_ctx *ctx, const char **json, size_t *len);
 /* The same patch as record tables (layout above; records may carry AM355_EDIT_REMOVE / AM355_MAP_EMPTY, map records of one object

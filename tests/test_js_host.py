@@ -74,7 +74,9 @@ def test_reference_suites_and_frontend_flows_over_the_engine_enabled_wrapper_emu
                          capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and " 0 failed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     served = json.loads(out.stdout.split("served by: ")[1].splitlines()[0])
-    assert served["gpuLoad"] >= 10 and served["fallbackToJs"] == 0
+    # Backend.applyChanges goes to the engine too (am355_apply_changes); the few calls it refuses (assignments to list elements ...)
+    # are the only ones the reference path serves
+    assert served["gpuLoad"] >= 10 and served["gpuApplyChanges"] >= 100 and served["fallbackToJs"] <= served["gpuApplyChanges"] // 10
 
 
 @pytest.mark.skipif(NODE is None or not os.path.isdir("/root/reference"), reason="needs node and the reference tree (build container only)")
@@ -89,6 +91,30 @@ def test_differential_campaigns_against_the_live_reference_emulated():
     # tables, bulk list operations (multi-insert / multi-delete ops), lists of lists, containers replaced by scalars: 5 results per scenario
     out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "structure_campaign.js"), "12", "9"], capture_output=True, text=True, env=env, timeout=1500)
     assert out.returncode == 0 and "DISAGREE 0" in out.stdout and "84 results identical" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_host_materialises_incremental_patches_emulated():
+    """Backend.applyChanges calls of the reference's suites: node -> addon -> (emulated) am355_apply_changes -> record tables ->
+    materialize.js, JSON.stringify-exact against the patch the reference returned (a slice; the GPU suite runs all of them)."""
+    env = _emu_env()
+    out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js"), os.path.join(ROOT, "tests", "golden", "ref_apply_vectors.json.gz"), "4", "120"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["equal"] >= 100
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_host_reproduces_the_incremental_patches_of_the_reference_suites_on_gpu():
+    if not os.path.exists(os.path.join(JS, "am355_napi.node")):
+        import __graft_entry__ as g
+        g.build_js_addon()
+    out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["equal"] >= 800 and res["rejected"] >= 3
 
 
 @pytest.mark.gpu
