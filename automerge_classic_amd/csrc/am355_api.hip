@@ -2108,6 +2108,11 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
   c->apply_ready = false;
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "apply_changes: %-26s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_apply_changes on a sharded context");
   const bool have_state = c->staged;
   if (have_state && c->is_document) return fail(c, AM355_E_UNSUPPORTED, "the state was made by am355_load_document: applyChanges onto it is served by the JS path");
@@ -2149,10 +2154,13 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
     if (have_state) for (uint32_t ci : c->pending_change) put_old(ci);
   }
   const uint32_t total_n = (uint32_t)off.size() - 1;
+  lap("queue assembled");
   int rc = load_changes_impl(c, comb.data(), off.data(), total_n);
   if (rc) { c->staged = false; return rc; }
+  lap("staged");
   rc = replay_impl(c);
   if (rc) { c->staged = false; return rc; }
+  lap("replayed");
   // the earlier changes must have been applied again, first and in their order: rows [0, old_ops) are the state before the call
   bool prefix_ok = c->applied_change.size() >= n_old_applied && c->n_ops >= old_ops;
   for (uint32_t i = 0; prefix_ok && i < n_old_applied; i++) prefix_ok = c->applied_change[i] == i;
@@ -2166,12 +2174,14 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   DeltaCounts hc{};
   rc = run_delta_stage(c, (uint32_t)old_ops, &hc, false);
   if (rc) return rc;
+  lap("delta stage");
   c->state_checked = true;  // (a call the engine served: checked; a refused call leaves the state to the JS path)
   if (hc.flags) { c->state_checked = false; return error_for_flags(c, hc.flags, "incremental patch not served"); }
 
   // ---- tables to the host, setupPatches, assembly ----
   rc = fetch_ir_impl(c, nullptr);
   if (rc) return rc;
+  lap("document tables on the host");
   const uint32_t n_dmap = hc.n_kept + hc.n_place, n_dedits = hc.n_erecs;
   size_t b_link = carve_size(NO, sizeof(ObjLink)), b_map = carve_size(n_dmap, sizeof(am355_ir_map)), b_edit = carve_size((size_t)n_dedits + 1, sizeof(am355_ir_edit));
   if (!c->h_delta.ensure(b_link + b_map + b_edit + 256)) return fail(c, AM355_E_NOMEM, "host allocation failed");
@@ -2188,6 +2198,7 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; return fail(c, rc, "%s", err.c_str()); }
   c->apply_ready = true;
   c->apply_json.clear();
+  lap("patch assembled");
   return AM355_OK;
 }
 

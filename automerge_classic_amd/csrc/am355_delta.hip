@@ -149,6 +149,26 @@ __device__ __forceinline__ uint32_t key_slot(const MergeBufs& b, const DeltaBufs
   return NONE32;
 }
 
+// first new row that names each object. A batch names few objects -- often ONE, and a million atomics on one word execute one
+// after another (~12 ns each: 12 ms for the headline log). The lanes of a wavefront that name the same object as its first live lane
+// share one atomic (the lowest row of a wavefront is its lowest lane), and a wavefront whose rows come after the recorded minimum
+// issues none.  (Its own kernel: folded into kd_rows, the compiler -- ROCm 7.2 -- left the row number of the map-key lanes in
+// an undefined register pair.)
+__global__ __launch_bounds__(BLOCK) void kd_touch(MergeBufs b, DeltaBufs d) {
+  uint32_t g = d.T0 + gtid();
+  uint8_t kind = g < b.n_ops ? b.kind[g] : (uint8_t)K_NONE;
+  const bool live = kind != K_NONE && kind != K_FOREIGN;
+  uint32_t oi = live ? obj_index_of(b, b.obj_row[g]) : NONE32;
+  unsigned long long m = __ballot(live);
+  uint32_t lane = threadIdx.x & (WAVE - 1);
+  uint32_t leader = m ? (uint32_t)__ffsll(m) - 1 : 0;
+  uint32_t loi = __shfl(oi, (int)leader);
+  if (live && (lane == leader || oi != loi)) {
+    uint32_t t = g - d.T0;
+    if (d.link[oi].touch > t) atomicMin(&d.link[oi].touch, t);
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
   uint32_t g = gtid();
   if (g >= b.n_ops) return;
@@ -161,7 +181,6 @@ __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
   uint32_t err = 0;
   if (kind == K_FOREIGN) err |= F_UNSUPPORTED;
   if (kind != K_NONE && kind != K_FOREIGN) {
-    atomicMin(&d.link[obj_index_of(b, b.obj_row[g])].touch, g - d.T0);
     if (kind == K_MAP || (kind == K_DEL && b.ops.key_len[g] != NONE32)) {
       uint32_t s = key_slot(b, d, g, true);
       if (s == NONE32) err |= F_UNSUPPORTED;
@@ -467,6 +486,7 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   AM355_LAUNCH_INDEPENDENT(kd_objects, dgrid(d.n_obj), dim3(BLOCK), st, b, ir, d);
   step("objects");
   if (N) AM355_LAUNCH_INDEPENDENT(kd_rows, dgrid(N), dim3(BLOCK), st, b, d);
+  if (d.n_new) hipLaunchKernelGGL(kd_touch, dgrid(d.n_new), dim3(BLOCK), 0, st, b, d);
   step("rows");
   if (debug) {
     std::vector<uint32_t> ord(d.n_list + 1);
