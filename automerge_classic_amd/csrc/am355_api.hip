@@ -18,6 +18,7 @@
 #include "am355_history.h"
 #include "am355_delta.h"
 #include "am355_apply.h"
+#include "am355_sync.h"
 
 #include <zlib.h>
 
@@ -313,6 +314,9 @@ struct am355_ctx {
   DeltaBufs delta{};
   ApplyPatch apply;
   bool apply_ready = false;
+  std::vector<uint32_t> dep_first, dep_index;   // am355_get_dep_graph
+  bool dep_graph_ready = false;
+  DevBuf d_sync;                                // am355_sync_bloom_*: index list, filter bits, flags
   bool state_checked = false;  // the state was built by am355_apply_changes calls (each checked for what later patches depend on) or is empty
   std::string apply_json;
 
@@ -421,7 +425,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
-  c->d_delta.release(); c->d_pass.release(); c->h_delta.release();
+  c->d_delta.release(); c->d_pass.release(); c->h_delta.release(); c->d_sync.release();
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
@@ -1753,6 +1757,7 @@ static int replay_impl(am355_ctx* c) {
   if (!c->staged) return fail(c, AM355_E_STATE, "am355_load_changes must be called first");
   (void)hipSetDevice(c->device);
   c->replayed = c->ir_fetched = false;
+  c->dep_graph_ready = false;
   c->flags = 0;
   if (c->is_document) return replay_document(c);
   auto t_begin = std::chrono::steady_clock::now();
@@ -2240,6 +2245,71 @@ extern "C" int am355_fetch_apply_ir(am355_ctx* c, am355_patch_ir* out) {
   if (!c) return AM355_E_ARG;
   if (!c->apply_ready) return fail(c, AM355_E_STATE, "am355_apply_changes must succeed first");
   if (out) *out = c->apply.ir;
+  return AM355_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// sync protocol, bulk side (include/am355.h)
+// ---------------------------------------------------------------------------------------------------------
+static int get_dep_graph_impl(am355_ctx* c, const uint32_t** dep_first, const uint32_t** dep_index, uint32_t* n_changes) {
+  if (!c) return AM355_E_ARG;
+  if (!c->replayed || c->is_document) return fail(c, AM355_E_STATE, "a replayed state of changes is needed");
+  (void)hipSetDevice(c->device);
+  if (!c->dep_graph_ready) {
+    const uint32_t n = c->n_changes;
+    const size_t dep_words = c->raw.size() / 32 + 2;
+    // the device resolved every dependency hash to the index of the change that carries it (k_deps_resolve), addressed by the
+    // dependency's place in the arena; the change headers say where those places are
+    if (!c->h_dep_idx.ensure(4 * dep_words) || !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u))) return fail(c, AM355_E_NOMEM, "host allocation failed");
+    HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_dep_idx.p, c->d_dep_idx.p, 4 * dep_words, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+    const uint32_t* di = c->h_dep_idx.as<uint32_t>();
+    c->dep_first.assign((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) c->dep_first[i + 1] = c->dep_first[i] + metas[i].n_deps;
+    c->dep_index.resize(c->dep_first[n]);
+    for (uint32_t i = 0; i < n; i++) {
+      const size_t first = (size_t)((metas[i].base + metas[i].deps_off) >> 5);
+      for (uint32_t k = 0; k < metas[i].n_deps; k++) c->dep_index[c->dep_first[i] + k] = di[first + k];
+    }
+    c->dep_graph_ready = true;
+  }
+  if (dep_first) *dep_first = c->dep_first.data();
+  if (dep_index) *dep_index = c->dep_index.data();
+  if (n_changes) *n_changes = c->n_changes;
+  return AM355_OK;
+}
+
+static int sync_bloom_impl(am355_ctx* c, const uint32_t* idx, uint32_t n, uint32_t num_entries, uint32_t bits_per_entry, uint32_t num_probes, const uint8_t* probe_bits,
+                           size_t probe_bytes, uint8_t* out, size_t out_cap, bool build) {
+  if (!c || (n && !idx) || !out) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
+  if (!c->replayed || c->is_document || !c->d_hashes.p) return fail(c, AM355_E_STATE, "a replayed state of changes is needed");
+  (void)hipSetDevice(c->device);
+  for (uint32_t k = 0; k < n; k++)
+    if (idx[k] >= c->n_changes) return fail(c, AM355_E_ARG, "change index %u out of range", idx[k]);
+  hipStream_t st = c->stream;
+  const uint64_t n_bits64 = build ? 8 * (((uint64_t)n * 10 + 7) / 8) : 8 * (uint64_t)probe_bytes;
+  if (n_bits64 > 0xfffffff0ull) return fail(c, AM355_E_UNSUPPORTED, "Bloom filter beyond 2^32 bits");
+  const uint32_t n_bits = (uint32_t)n_bits64;
+  const size_t filter_bytes = n_bits / 8;
+  if (build && out_cap < filter_bytes) return fail(c, AM355_E_ARG, "filter needs %zu bytes", filter_bytes);
+  if (!build && (uint64_t)probe_bytes < ((uint64_t)num_entries * bits_per_entry + 7) / 8) return fail(c, AM355_E_ARG, "filter shorter than its header says");
+  size_t o_bits = ((4 * (size_t)n + 255) & ~(size_t)255), o_flags = o_bits + ((filter_bytes + 8 + 255) & ~(size_t)255);
+  if (!c->d_sync.ensure(o_flags + n + 256)) return fail(c, AM355_E_NOMEM, "device allocation failed");
+  uint8_t* d = c->d_sync.as<uint8_t>();
+  if (n) HIPCHK(c, hipMemcpyAsync(d, idx, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  if (build) {
+    launch_bloom_build(c->d_hashes.as<uint8_t>(), (const uint32_t*)d, n, (uint32_t*)(d + o_bits), n_bits, 7, st);
+    if (filter_bytes) HIPCHK(c, hipMemcpyAsync(out, d + o_bits, filter_bytes, hipMemcpyDeviceToHost, st));
+  } else {
+    if (filter_bytes) HIPCHK(c, hipMemcpyAsync(d + o_bits, probe_bits, filter_bytes, hipMemcpyHostToDevice, st));
+    // (an empty filter -- numEntries 0 -- contains nothing: sync.js:120)
+    launch_bloom_probe(c->d_hashes.as<uint8_t>(), (const uint32_t*)d, n, d + o_bits, num_entries ? n_bits : 0, num_probes, d + o_flags, st);
+    if (n) HIPCHK(c, hipMemcpyAsync(out, d + o_flags, n, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(c, hipStreamSynchronize(st));
   return AM355_OK;
 }
 
@@ -2948,3 +3018,11 @@ extern "C" int am355_doc_changes(am355_ctx* c, uint32_t flags, const uint8_t** a
 extern "C" int am355_import_fragments(am355_ctx* c, const uint8_t* frags, const uint64_t* offsets, uint32_t world) { return guarded(c, [&]() { return import_fragments_impl(c, frags, offsets, world); }); }
 extern "C" int am355_apply_changes(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) { return guarded(c, [&]() { return apply_changes_impl(c, arena, offsets, n); }); }
 extern "C" int am355_apply_patch_json(am355_ctx* c, const char** json, size_t* len) { return guarded(c, [&]() { return apply_patch_json_impl(c, json, len); }); }
+extern "C" int am355_get_dep_graph(am355_ctx* c, const uint32_t** dep_first, const uint32_t** dep_index, uint32_t* n) { return guarded(c, [&]() { return get_dep_graph_impl(c, dep_first, dep_index, n); }); }
+extern "C" int am355_sync_bloom_build(am355_ctx* c, const uint32_t* idx, uint32_t n, uint8_t* bits, size_t cap) {
+  return guarded(c, [&]() { return sync_bloom_impl(c, idx, n, n, 10, 7, nullptr, 0, bits, cap, true); });
+}
+extern "C" int am355_sync_bloom_probe(am355_ctx* c, const uint32_t* idx, uint32_t n, uint32_t num_entries, uint32_t bits_per_entry, uint32_t num_probes, const uint8_t* bits,
+                                      size_t n_bytes, uint8_t* contains) {
+  return guarded(c, [&]() { return sync_bloom_impl(c, idx, n, num_entries, bits_per_entry, num_probes, bits, n_bytes, contains, n, false); });
+}

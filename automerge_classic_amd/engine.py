@@ -90,10 +90,13 @@ def _bind(path):
     L.am355_apply_patch_json.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
     L.am355_fetch_apply_ir.argtypes = [vp, vp]
     L.am355_reset.argtypes = [vp]
+    L.am355_get_dep_graph.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
+    L.am355_sync_bloom_build.argtypes = [vp, vp, u32, vp, ctypes.c_size_t]
+    L.am355_sync_bloom_probe.argtypes = [vp, vp, u32, u32, u32, u32, vp, ctypes.c_size_t, vp]
     L.am355_get_pending.argtypes = [vp, vp, ctypes.POINTER(u32)]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
-              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending"):
+              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -175,6 +178,33 @@ class Engine:
         if n.value:
             self._check(self._L.am355_get_pending(self._h, out.ctypes.data, ctypes.byref(n)))
         return out
+
+    # ---- sync protocol, bulk side ----------------------------------------------------------
+    def dep_graph(self):
+        """(dep_first[n + 1], dep_index[]) over the context's list of changes: change i depends on dep_index[dep_first[i]:dep_first[i + 1]]
+        (0xffffffff: a change the context does not hold)."""
+        f, x, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
+        self._check(self._L.am355_get_dep_graph(self._h, ctypes.byref(f), ctypes.byref(x), ctypes.byref(n)))
+        first = np.ctypeslib.as_array(ctypes.cast(f, ctypes.POINTER(ctypes.c_uint32)), shape=(n.value + 1,)).copy()
+        m = int(first[-1])
+        index = np.ctypeslib.as_array(ctypes.cast(x, ctypes.POINTER(ctypes.c_uint32)), shape=(m,)).copy() if m else np.zeros(0, np.uint32)
+        return first, index
+
+    def bloom_build(self, idx):
+        """`bits` of the sync protocol's Bloom filter (sync.js:38-128) over the hashes of the changes idx[], built on the device."""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        out = np.zeros((idx.size * 10 + 7) // 8, dtype=np.uint8)
+        self._check(self._L.am355_sync_bloom_build(self._h, idx.ctypes.data if idx.size else None, idx.size, out.ctypes.data, out.size))
+        return out
+
+    def bloom_probe(self, idx, num_entries, bits_per_entry, num_probes, bits):
+        """contains[k] for the hashes of the changes idx[] in a filter received from a peer."""
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        out = np.zeros(max(idx.size, 1), dtype=np.uint8)
+        self._check(self._L.am355_sync_bloom_probe(self._h, idx.ctypes.data if idx.size else None, idx.size, num_entries, bits_per_entry, num_probes,
+                                                   bits.ctypes.data if bits.size else None, bits.size, out.ctypes.data))
+        return out[:idx.size]
 
     def apply_patch_json(self):
         """JSON.stringify of the patch the last apply_changes returned (the reference's incremental patch)."""

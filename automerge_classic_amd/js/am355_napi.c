@@ -249,6 +249,89 @@ static napi_value js_pending_order(napi_env env, napi_callback_info info) {
   return ta;
 }
 
+static napi_value copy_to_arraybuffer(napi_env env, const void *src, size_t len);
+
+static int get_u32_array(napi_env env, napi_value v, uint32_t **data, size_t *n) {
+  bool is_ta = false;
+  napi_is_typedarray(env, v, &is_ta);
+  if (!is_ta) return 0;
+  napi_typedarray_type t; size_t len; void *d; napi_value ab; size_t off;
+  napi_get_typedarray_info(env, v, &t, &len, &d, &ab, &off);
+  if (t != napi_uint32_array) return 0;
+  *data = (uint32_t *)d;
+  *n = len;
+  return 1;
+}
+
+/* depGraph(ctx) -> { depFirst: Uint32Array[n + 1], depIndex: Uint32Array }: am355_get_dep_graph (copies) */
+static napi_value js_dep_graph(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  const uint32_t *first = NULL, *index = NULL;
+  uint32_t n = 0;
+  int rc = am355_get_dep_graph(ctx, &first, &index, &n);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value o, ab, ta;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  ab = copy_to_arraybuffer(env, first, 4 * ((size_t)n + 1));
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint32_array, (size_t)n + 1, ab, 0, &ta));
+  napi_set_named_property(env, o, "depFirst", ta);
+  ab = copy_to_arraybuffer(env, index, 4 * (size_t)first[n]);
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint32_array, first[n], ab, 0, &ta));
+  napi_set_named_property(env, o, "depIndex", ta);
+  return o;
+}
+
+/* bloomBuild(ctx, Uint32Array idx) -> Uint8Array: am355_sync_bloom_build (the `bits` of the filter over those changes' hashes) */
+static napi_value js_bloom_build(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t *idx = NULL;
+  size_t n = 0;
+  if (!get_u32_array(env, argv[1], &idx, &n)) { napi_throw_type_error(env, NULL, "bloomBuild takes a Uint32Array of change indexes"); return NULL; }
+  size_t bytes = (n * 10 + 7) / 8;
+  void *data = NULL;
+  napi_value ab, ta;
+  NAPI_CALL(env, napi_create_arraybuffer(env, bytes, &data, &ab));
+  int rc = am355_sync_bloom_build(ctx, idx, (uint32_t)n, (uint8_t *)data, bytes);
+  if (rc) return throw_engine(env, ctx, rc);
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
+  return ta;
+}
+
+/* bloomProbe(ctx, Uint32Array idx, numEntries, numBitsPerEntry, numProbes, Uint8Array bits) -> Uint8Array flags: am355_sync_bloom_probe */
+static napi_value js_bloom_probe(napi_env env, napi_callback_info info) {
+  size_t argc = 6;
+  napi_value argv[6];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t *idx = NULL;
+  size_t n = 0;
+  if (!get_u32_array(env, argv[1], &idx, &n)) { napi_throw_type_error(env, NULL, "bloomProbe takes a Uint32Array of change indexes"); return NULL; }
+  uint32_t ne = 0, nb = 0, np = 0;
+  napi_get_value_uint32(env, argv[2], &ne); napi_get_value_uint32(env, argv[3], &nb); napi_get_value_uint32(env, argv[4], &np);
+  bool is_ta = false;
+  napi_is_typedarray(env, argv[5], &is_ta);
+  if (!is_ta) { napi_throw_type_error(env, NULL, "filter bits must be a Uint8Array"); return NULL; }
+  napi_typedarray_type t; size_t blen; void *bdata; napi_value bab; size_t boff;
+  napi_get_typedarray_info(env, argv[5], &t, &blen, &bdata, &bab, &boff);
+  if (t != napi_uint8_array) { napi_throw_type_error(env, NULL, "filter bits must be a Uint8Array"); return NULL; }
+  void *data = NULL;
+  napi_value ab, ta;
+  NAPI_CALL(env, napi_create_arraybuffer(env, n ? n : 1, &data, &ab));
+  int rc = am355_sync_bloom_probe(ctx, idx, (uint32_t)n, ne, nb, np, (const uint8_t *)bdata, blen, (uint8_t *)data);
+  if (rc) return throw_engine(env, ctx, rc);
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta));
+  return ta;
+}
+
 static napi_value js_reset(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -413,6 +496,9 @@ static napi_value init(napi_env env, napi_value exports) {
       {"applyChanges", NULL, js_apply_changes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"pendingOrder", NULL, js_pending_order, NULL, NULL, NULL, napi_enumerable, NULL},
       {"reset", NULL, js_reset, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"depGraph", NULL, js_dep_graph, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"bloomBuild", NULL, js_bloom_build, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"bloomProbe", NULL, js_bloom_probe, NULL, NULL, NULL, napi_enumerable, NULL},
       {"fetchApplyIR", NULL, js_fetch_apply_ir, NULL, NULL, NULL, napi_enumerable, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);

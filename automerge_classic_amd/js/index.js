@@ -246,11 +246,11 @@ function save(backend) {
 // History queries on a state built by loadChanges: the engine knows which changes were applied and in what order, and the
 // change buffers are retained, so these need no JS BackendDoc. (Loaded documents and anything involving queued changes
 // go to the reference path.)
-function gpuHistory(backend) {
+function gpuHistory(backend, withQueue) {
   const g = backend.state
-  if (JS_ONLY || !(g instanceof GpuState)) return null
+  if (JS_ONLY || !(g instanceof GpuState) || g.js) return null
   if (g.doc && !g.changes && !g.noHistory) loadedHistory(g)
-  return g.changes && g.applied && g.pending === 0 ? g : null
+  return g.changes && g.applied && (g.pending === 0 || withQueue) ? g : null
 }
 // History of a LOADED document (new.js:1887-1912 computeHashGraph, columnar.js:876-981): the engine rebuilds the binary changes
 // and their hashes from the rows it decoded (am355_doc_changes) -- once, on the first history query, as the reference defers it.
@@ -267,6 +267,7 @@ function loadedHistory(g) {
     g.changes = h.changes
     g.hashes = h.hashes
     g.applied = Uint32Array.from(h.changes, (_, i) => i)
+    g.pendingIdx = new Uint32Array(0)
     g.pending = 0
     counters.gpuHistory++
   } catch (e) {
@@ -282,28 +283,29 @@ function hashIndex(g) {
   }
   return g.byHash
 }
-function getAllChanges(backend) {   // new.js:1924-1927: BackendDoc.changes in application order
+function getAllChanges(backend) {   // new.js:1924-1927: BackendDoc.changes in application order (queued changes are not among them)
   isFrozenCheck(backend)
-  const g = gpuHistory(backend)
+  const g = gpuHistory(backend, true)
   if (g) return Array.from(g.applied, i => g.changes[i])
   return ref().getAllChanges(hydrate(backend))
 }
-function getChanges(backend, haveDeps) {
+function getChanges(backend, haveDeps) {   // backend.js:152-157, new.js:1921-1976
   isFrozenCheck(backend)
-  const g = gpuHistory(backend)
-  if (g && Array.isArray(haveDeps) && haveDeps.length === 0) return Array.from(g.applied, i => g.changes[i])
+  if (!Array.isArray(haveDeps)) throw new TypeError('Pass an array of hashes to Backend.getChanges()')
+  const g = gpuHistory(backend, true)
+  if (g) return changesSince(g, haveDeps).map(i => g.changes[i])
   return ref().getChanges(hydrate(backend), haveDeps)
 }
-function getChangeByHash(backend, hash) {   // new.js:1999-2002
+function getChangeByHash(backend, hash) {   // new.js:1999-2002 (applied changes only: queued ones have no index)
   isFrozenCheck(backend)
-  const g = gpuHistory(backend)
+  const g = gpuHistory(backend, true)
   if (g) { const i = hashIndex(g).get(hash); return i === undefined ? undefined : g.changes[i] }
   return ref().getChangeByHash(hydrate(backend), hash)
 }
-function getMissingDeps(backend, heads = []) {   // new.js:2014-2028 with an empty queue: the given heads we do not have
+function getMissingDeps(backend, heads = []) {   // new.js:2014-2028
   isFrozenCheck(backend)
-  const g = gpuHistory(backend)
-  if (g) { const idx = hashIndex(g); return Array.from(new Set(heads)).filter(h => !idx.has(h)).sort() }
+  const g = gpuHistory(backend, true)
+  if (g && g.pendingIdx) return missingDeps(g, heads)
   return ref().getMissingDeps(hydrate(backend), heads)
 }
 
@@ -321,7 +323,7 @@ function gpuApplyChanges(backend, changes) {
   if (g && !g.changes) return null
   let entry
   if (g) {
-    if (g.doc || !(entry = contextOf(g.generation))) { gpuReplay(g.changes); g.generation = generation; entry = contextOf(generation) }
+    if ((g.doc && !g.fromChanges) || !(entry = contextOf(g.generation))) { gpuReplay(g.changes); g.generation = generation; g.fromChanges = true; entry = contextOf(generation) }
     if (!g.applied || !g.pendingIdx) { g.applied = addon.appliedOrder(ctx); g.pendingIdx = addon.pendingOrder(ctx) }
   } else {
     entry = acquireContext()
@@ -367,16 +369,245 @@ function free(backend) {
   if (backend.state instanceof GpuState) { backend.state = null; backend.frozen = true } else ref().free(backend)
 }
 
-// backend/sync.js:420-473: the handle is only replaced (and the old one frozen) when the message carried changes; a message
-// without changes returns the handle it was given, which the frontend keeps using (src/automerge.js receiveSyncMessage)
-function receiveSyncMessage(backend, syncState, msg) {
-  const handle = hydrate(backend)
-  const result = ref().receiveSyncMessage(handle, syncState, msg)
-  if (backend.state instanceof GpuState) {
-    if (result[0] === handle) result[0] = backend
-    else { backend.state.js = null; backend.frozen = true }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Sync protocol (SURVEY.md 8f-4; reference backend/sync.js).  A message that carries changes is applied by applyChanges above --
+// the bulk receive runs on the engine --, and what generateSyncMessage computes over the hash graph of an engine-built state is
+// served from the engine too: the dependency graph by index (resolved on the device while the changes were hashed), the Bloom
+// filter over the hashes of the changes since the last sync built on the device, filters received from the peer probed there.
+// The protocol logic itself is restated from sync.js (it is host code in the reference as well); the wire encoding is the
+// reference's own encodeSyncMessage / decodeSyncMessage.
+// ---------------------------------------------------------------------------------------------------------------------------
+function hexOfHash(g, i) { return Buffer.from(g.hashes.buffer, g.hashes.byteOffset + 32 * i, 32).toString('hex') }
+
+// the engine context that holds the replay of `g` (replayed again from the retained changes when it has moved on)
+function ensureContext(g) {
+  // (a loaded document sits in its context as a document: the hash graph needs the replay of its rebuilt changes)
+  if ((g.doc && !g.fromChanges) || !contextOf(g.generation)) { gpuReplay(g.changes); g.generation = generation; g.fromChanges = true; contextOf(generation) }
+}
+
+// hash graph of an engine-built state, by index into g.changes: dependencies as resolved on the device, dependents in the order the
+// reference pushes them (new.js:1853-1856: in application order, every change onto the lists of its dependencies)
+function graphOf(g) {
+  if (!g.graph) {
+    ensureContext(g)
+    const { depFirst, depIndex } = addon.depGraph(ctx)
+    const applied = new Uint8Array(g.changes.length)
+    for (const i of g.applied) applied[i] = 1
+    const dependents = new Map()
+    for (const i of g.applied) {
+      if (!dependents.has(i)) dependents.set(i, [])
+      for (let k = depFirst[i]; k < depFirst[i + 1]; k++) {
+        const d = depIndex[k]
+        if (!dependents.has(d)) dependents.set(d, [])
+        dependents.get(d).push(i)
+      }
+    }
+    g.graph = { depFirst, depIndex, applied, dependents }
   }
-  return result
+  return g.graph
+}
+
+// BackendDoc.getChanges(haveDeps) (new.js:1921-1976) as a list of indexes, in the order the reference returns the changes
+function changesSince(g, haveDeps) {
+  if (haveDeps.length === 0) return Array.from(g.applied)
+  const idx = hashIndex(g), { depFirst, depIndex, dependents } = graphOf(g)
+  let stack = [], seen = new Set(), toReturn = []
+  for (const hash of haveDeps) {
+    const i = idx.get(hash)
+    if (i === undefined) throw new RangeError(`hash not found: ${hash}`)
+    seen.add(i)
+    stack.push(...dependents.get(i))
+  }
+  const depsSeen = i => { for (let k = depFirst[i]; k < depFirst[i + 1]; k++) if (!seen.has(depIndex[k])) return false; return true }
+  while (stack.length > 0) {
+    const i = stack.pop()
+    seen.add(i)
+    toReturn.push(i)
+    if (!depsSeen(i)) break
+    stack.push(...dependents.get(i))
+  }
+  const heads = g.heads.map(h => idx.get(h))
+  if (stack.length === 0 && heads.every(h => seen.has(h))) return toReturn
+  stack = haveDeps.map(h => idx.get(h))
+  seen = new Set()
+  while (stack.length > 0) {
+    const i = stack.pop()
+    if (!seen.has(i)) {
+      for (let k = depFirst[i]; k < depFirst[i + 1]; k++) stack.push(depIndex[k])
+      seen.add(i)
+    }
+  }
+  return Array.from(g.applied).filter(i => !seen.has(i))
+}
+
+let refColumnar = null
+function columnar() {
+  if (!refColumnar) refColumnar = require(path.join(process.env.AUTOMERGE_BACKEND_PATH || 'automerge/backend', 'columnar'))
+  return refColumnar
+}
+
+// BackendDoc.getMissingDeps(heads) (new.js:2014-2028) with a queue: the dependencies of the queued changes and the given heads that
+// are neither applied nor queued
+function missingDeps(g, heads) {
+  const idx = hashIndex(g), allDeps = new Set(heads), inQueue = new Set()
+  for (const i of g.pendingIdx) {
+    inQueue.add(hexOfHash(g, i))
+    for (const dep of columnar().decodeChangeMeta(g.changes[i], false).deps) allDeps.add(dep)
+  }
+  const missing = []
+  for (const hash of allDeps) if (!idx.has(hash) && !inQueue.has(hash)) missing.push(hash)
+  return missing.sort()
+}
+
+function leb32(out, v) { do { let b = v & 0x7f; v >>>= 7; if (v) b |= 0x80; out.push(b) } while (v) }
+function readLeb32(bytes, pos) {
+  let v = 0, shift = 0
+  for (;;) {
+    if (pos.i >= bytes.length) throw new RangeError('buffer ended with incomplete number')
+    const b = bytes[pos.i++]
+    v += (b & 0x7f) * Math.pow(2, shift)
+    shift += 7
+    if (!(b & 0x80)) break
+    if (shift > 35) throw new RangeError('number out of range')
+  }
+  if (v > 0xffffffff) throw new RangeError('number out of range')
+  return v
+}
+
+// makeBloomFilter (sync.js:234-238): the filter over the changes applied since `lastSync`, its bits set on the device
+function makeBloomFilterGpu(g, lastSync) {
+  const list = changesSince(g, lastSync)
+  if (list.length === 0) return { lastSync, bloom: new Uint8Array(0) }
+  ensureContext(g)
+  const bits = addon.bloomBuild(ctx, Uint32Array.from(list))
+  const head = []
+  leb32(head, list.length); leb32(head, 10); leb32(head, 7)   // numEntries, BITS_PER_ENTRY, NUM_PROBES (sync.js:31, 66-74)
+  const bloom = new Uint8Array(head.length + bits.length)
+  bloom.set(head)
+  bloom.set(bits, head.length)
+  return { lastSync, bloom }
+}
+
+// getChangesToSend (sync.js:246-306) over indexes; the peer's filters are probed on the device
+function changesToSendGpu(backend, g, have, need) {
+  if (have.length === 0) return need.map(hash => getChangeByHash(backend, hash)).filter(change => change !== undefined)
+  const lastSyncHashes = {}, filters = []
+  for (const h of have) {
+    for (const hash of h.lastSync) lastSyncHashes[hash] = true
+    if (!(h.bloom instanceof Uint8Array)) throw new TypeError('invalid argument')
+    if (h.bloom.byteLength === 0) filters.push({ numEntries: 0, numBitsPerEntry: 0, numProbes: 0, bits: h.bloom })
+    else {
+      const pos = { i: 0 }
+      const numEntries = readLeb32(h.bloom, pos), numBitsPerEntry = readLeb32(h.bloom, pos), numProbes = readLeb32(h.bloom, pos)
+      const n = Math.ceil(numEntries * numBitsPerEntry / 8)
+      if (pos.i + n > h.bloom.length) throw new RangeError('subarray exceeds buffer size')
+      filters.push({ numEntries, numBitsPerEntry, numProbes, bits: h.bloom.subarray(pos.i, pos.i + n) })
+    }
+  }
+  const list = changesSince(g, Object.keys(lastSyncHashes)), { depFirst, depIndex } = graphOf(g)
+  ensureContext(g)
+  const listArr = Uint32Array.from(list)
+  const inSome = new Uint8Array(list.length)
+  for (const f of filters) {
+    if (f.numEntries === 0) continue
+    const flags = addon.bloomProbe(ctx, listArr, f.numEntries, f.numBitsPerEntry, f.numProbes, f.bits)
+    for (let k = 0; k < list.length; k++) inSome[k] |= flags[k]
+  }
+  const inList = new Set(list), dependents = new Map(), toSend = new Set()
+  list.forEach((i, k) => {
+    for (let q = depFirst[i]; q < depFirst[i + 1]; q++) {
+      const d = depIndex[q]
+      if (!dependents.has(d)) dependents.set(d, [])
+      dependents.get(d).push(i)
+    }
+    if (!inSome[k]) toSend.add(i)
+  })
+  const stack = Array.from(toSend)
+  while (stack.length > 0) {
+    const i = stack.pop()
+    for (const d of dependents.get(i) || []) if (!toSend.has(d)) { toSend.add(d); stack.push(d) }
+  }
+  const idx = hashIndex(g), out = []
+  for (const hash of need) {
+    const i = idx.get(hash)
+    if (i !== undefined) toSend.add(i)
+    if (i === undefined || !inList.has(i)) { const change = getChangeByHash(backend, hash); if (change) out.push(change) }
+  }
+  for (const i of list) if (toSend.has(i)) out.push(g.changes[i])
+  return out
+}
+
+const compareArrays = (a, b) => (a.length === b.length) && a.every((v, i) => v === b[i])
+
+// generateSyncMessage (sync.js:320-392)
+function generateSyncMessage(backend, syncState) {
+  if (!backend) throw new Error('generateSyncMessage called with no Automerge document')
+  if (!syncState) throw new Error('generateSyncMessage requires a syncState, which can be created with initSyncState()')
+  const g = gpuHistory(backend, true)
+  if (!g || !g.pendingIdx) return ref().generateSyncMessage(hydrate(backend), syncState)
+  let { sharedHeads, lastSentHeads, theirHeads, theirNeed, theirHave, sentHashes } = syncState
+  const ourHeads = backend.heads
+  const ourNeed = missingDeps(g, theirHeads || [])
+  let ourHave = []
+  if (!theirHeads || ourNeed.every(hash => theirHeads.includes(hash))) ourHave = [makeBloomFilterGpu(g, sharedHeads)]
+  if (theirHave && theirHave.length > 0) {
+    const lastSync = theirHave[0].lastSync
+    if (!lastSync.every(hash => getChangeByHash(backend, hash))) {
+      const resetMsg = { heads: ourHeads, need: [], have: [{ lastSync: [], bloom: new Uint8Array(0) }], changes: [] }
+      return [syncState, ref().encodeSyncMessage(resetMsg)]
+    }
+  }
+  let changesToSend = Array.isArray(theirHave) && Array.isArray(theirNeed) ? changesToSendGpu(backend, g, theirHave, theirNeed) : []
+  const headsUnchanged = Array.isArray(lastSentHeads) && compareArrays(ourHeads, lastSentHeads)
+  const headsEqual = Array.isArray(theirHeads) && compareArrays(ourHeads, theirHeads)
+  if (headsUnchanged && headsEqual && changesToSend.length === 0) return [syncState, null]
+  const hashOfChange = new Map()
+  g.applied.forEach(i => hashOfChange.set(g.changes[i], i))
+  const hashHex = change => { const i = hashOfChange.get(change); return i === undefined ? columnar().decodeChangeMeta(change, true).hash : hexOfHash(g, i) }
+  changesToSend = changesToSend.filter(change => !sentHashes[hashHex(change)])
+  const syncMessage = { heads: ourHeads, have: ourHave, need: ourNeed, changes: changesToSend }
+  if (changesToSend.length > 0) {
+    sentHashes = Object.assign({}, sentHashes)
+    for (const change of changesToSend) sentHashes[hashHex(change)] = true
+  }
+  syncState = Object.assign({}, syncState, { lastSentHeads: ourHeads, sentHashes })
+  return [syncState, ref().encodeSyncMessage(syncMessage)]
+}
+
+// advanceHeads (sync.js:406-411)
+function advanceHeads(myOldHeads, myNewHeads, ourOldSharedHeads) {
+  const newHeads = myNewHeads.filter(head => !myOldHeads.includes(head))
+  const commonHeads = ourOldSharedHeads.filter(head => myNewHeads.includes(head))
+  return [...new Set([...newHeads, ...commonHeads])].sort()
+}
+
+// receiveSyncMessage (sync.js:420-473): the changes of the message go through applyChanges above -- on the engine when the state is
+// the engine's -- and the bookkeeping about the peer follows the reference line by line. As there, the handle is only replaced
+// (and the old one frozen) when the message carried changes.
+function receiveSyncMessage(backend, oldSyncState, binaryMessage) {
+  if (!backend) throw new Error('generateSyncMessage called with no Automerge document')
+  if (!oldSyncState) throw new Error('generateSyncMessage requires a syncState, which can be created with initSyncState()')
+  if (JS_ONLY || !(backend.state instanceof GpuState || isEmptyRefState(backend))) {
+    const handle = hydrate(backend)
+    return ref().receiveSyncMessage(handle, oldSyncState, binaryMessage)
+  }
+  let { sharedHeads, lastSentHeads, sentHashes } = oldSyncState, patch = null
+  const message = ref().decodeSyncMessage(binaryMessage)
+  const beforeHeads = getHeads(backend)
+  if (message.changes.length > 0) {
+    [backend, patch] = applyChanges(backend, message.changes)
+    sharedHeads = advanceHeads(beforeHeads, getHeads(backend), sharedHeads)
+  }
+  if (message.changes.length === 0 && compareArrays(message.heads, beforeHeads)) lastSentHeads = message.heads
+  const knownHeads = message.heads.filter(head => getChangeByHash(backend, head))
+  if (knownHeads.length === message.heads.length) {
+    sharedHeads = message.heads
+    if (message.heads.length === 0) { lastSentHeads = []; sentHashes = [] }
+  } else {
+    sharedHeads = [...new Set(knownHeads.concat(sharedHeads))].sort()
+  }
+  const syncState = { sharedHeads, lastSentHeads, theirHave: message.have, theirHeads: message.heads, theirNeed: message.need, sentHashes }
+  return [backend, syncState, patch]
 }
 
 const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...args)
@@ -388,7 +619,7 @@ module.exports = {
   applyLocalChange: delegate1('applyLocalChange'),
   getChangesAdded: (b1, b2) => ref().getChangesAdded(hydrate(b1), hydrate(b2)),
   // sync protocol: unchanged reference code operating on JS handles (backend/sync.js:20 binds the JS backend)
-  generateSyncMessage: (backend, syncState) => ref().generateSyncMessage(hydrate(backend), syncState),
+  generateSyncMessage,
   receiveSyncMessage,
   encodeSyncMessage: (...a) => ref().encodeSyncMessage(...a),
   decodeSyncMessage: (...a) => ref().decodeSyncMessage(...a),

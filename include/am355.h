@@ -234,6 +234,25 @@ int am355_apply_patch_json(am355_ctx *ctx, const char **json, size_t *len);
 int am355_fetch_apply_ir(am355_ctx *ctx, am355_patch_ir *out);
 
 /*
+ * Sync protocol, bulk side (reference backend/sync.js).  A sync message that carries changes is served by
+ * am355_apply_changes; what the protocol computes around it over the hashes of a replayed state:
+ *   am355_get_dep_graph     the dependency graph of the context's list of changes by index (change i depends on
+ *                           dep_index[dep_first[i] .. dep_first[i + 1]); UINT32_MAX: a change the context does not hold) -- what
+ *                           BackendDoc.getChanges / getMissingDeps walk (new.js:1921-1976, 2014-2028), resolved on the device while
+ *                           the changes were hashed; the pointers are owned by ctx and valid until the next replay
+ *   am355_sync_bloom_build  the Bloom filter over the hashes of the changes idx[0 .. n) (sync.js:38-128 BloomFilter of makeBloomFilter,
+ *                           :240-244: 10 bits per entry, 7 probes, triple hashing over the first 12 bytes), built on the device from the
+ *                           resident hashes; bits receives ceil(n * 10 / 8) bytes (the `bits` field of the filter)
+ *   am355_sync_bloom_probe  for a filter received from a peer: contains[k] = 1 iff the hash of change idx[k] is in it
+ *                           (BloomFilter.containsHash of getChangesToSend, sync.js:262-283)
+ * Valid after am355_replay / am355_apply_changes of changes.
+ */
+int am355_get_dep_graph(am355_ctx *ctx, const uint32_t **dep_first, const uint32_t **dep_index, uint32_t *n_changes);
+int am355_sync_bloom_build(am355_ctx *ctx, const uint32_t *idx, uint32_t n, uint8_t *bits, size_t capacity);
+int am355_sync_bloom_probe(am355_ctx *ctx, const uint32_t *idx, uint32_t n, uint32_t num_entries, uint32_t bits_per_entry, uint32_t num_probes,
+                           const uint8_t *bits, size_t n_bytes, uint8_t *contains);
+
+/*
  * objectId sharding over several GPUs (one context per GPU, one process per GPU).  Ordering and pred / succ
  * resolution never cross objects (new.js:1141-1145, 1173-1176), so after am355_set_shard(ctx, rank, world) a replay merges
  * only the objects rank `rank` owns (_root: rank 0; any other object: (counter + actor rank) mod world) -- every rank still

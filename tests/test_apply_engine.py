@@ -266,3 +266,90 @@ def test_full_size_edits_rebuild_the_text_gpu():
         assert texts == final and sum(len(v) for v in final.values()) > 500_000
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# sync protocol, bulk side: dependency graph and Bloom filters over the resident hashes
+# ---------------------------------------------------------------------------------------------------------------------------
+def _bloom_probes(h, n_bits, num_probes):
+    """BloomFilter.getProbes (backend/sync.js:85-100) restated."""
+    x = int.from_bytes(h[0:4], "little") % n_bits
+    y = int.from_bytes(h[4:8], "little") % n_bits
+    z = int.from_bytes(h[8:12], "little") % n_bits
+    probes = [x]
+    for _ in range(1, num_probes):
+        x = (x + y) % n_bits
+        y = (y + z) % n_bits
+        probes.append(x)
+    return probes
+
+
+def _bloom_bits(hashes):
+    """`new BloomFilter(hashes).bits` (sync.js:41-47, 105-109)."""
+    n_bytes = (len(hashes) * 10 + 7) // 8
+    bits = bytearray(n_bytes)
+    for h in hashes:
+        for p in _bloom_probes(h, 8 * n_bytes, 7):
+            bits[p >> 3] |= 1 << (p & 7)
+    return bytes(bits)
+
+
+def _parse_deps(change):
+    """Dependency hashes of an uncompressed binary change (columnar.js:635-640)."""
+    off, length, shift = 9, 0, 0
+    while True:
+        b = change[off]
+        off += 1
+        length |= (b & 0x7f) << shift
+        shift += 7
+        if not b & 0x80:
+            break
+    n = change[off]   # (fewer than 128 dependencies in these logs: one LEB128 byte)
+    assert n < 0x80
+    off += 1
+    return [bytes(change[off + 32 * k: off + 32 * k + 32]) for k in range(n)]
+
+
+def check_sync_pieces(eng):
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=9, n_rounds=5, ins_per_change=6, del_per_change=2, n_objects=2, seed=77)
+    eng.load_changes(log)
+    eng.replay()
+    hashes = [bytes(h) for h in eng.hashes()]
+    arena, offs = eng.raw()
+    arena = bytes(arena)
+    n = len(offs) - 1
+    first, index = eng.dep_graph()
+    by_hash = {}
+    for i, h in enumerate(hashes):
+        by_hash.setdefault(h, i)
+    for i in range(n):
+        deps = _parse_deps(arena[int(offs[i]):int(offs[i + 1])])
+        assert [by_hash.get(d, 0xffffffff) for d in deps] == [int(x) for x in index[first[i]:first[i + 1]]]
+    rng = np.random.default_rng(5)
+    for size in (0, 1, 7, n // 2, n):
+        idx = rng.choice(n, size=size, replace=False).astype(np.uint32) if size else np.zeros(0, np.uint32)
+        bits = eng.bloom_build(idx)
+        assert bytes(bits) == _bloom_bits([hashes[i] for i in idx])
+        if size:
+            everything = np.arange(n, dtype=np.uint32)
+            got = eng.bloom_probe(everything, size, 10, 7, bits)
+            want = [int(all((bits[p >> 3] >> (p & 7)) & 1 for p in _bloom_probes(hashes[i], 8 * len(bits), 7))) for i in range(n)]
+            assert [int(x) for x in got] == want and all(got[i] for i in idx)
+    assert not eng.bloom_probe(np.arange(n, dtype=np.uint32), 0, 0, 0, np.zeros(0, np.uint8)).any()   # an empty filter contains nothing
+
+
+def test_sync_dep_graph_and_bloom_filters_emulated(emu_lib):
+    eng = engine.Engine(0, emu_lib)
+    try:
+        check_sync_pieces(eng)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_sync_dep_graph_and_bloom_filters_gpu():
+    eng = engine.Engine(0)
+    try:
+        check_sync_pieces(eng)
+    finally:
+        eng.close()

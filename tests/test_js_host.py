@@ -93,6 +93,18 @@ def test_differential_campaigns_against_the_live_reference_emulated():
     assert out.returncode == 0 and "DISAGREE 0" in out.stdout and "84 results identical" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+@pytest.mark.skipif(NODE is None or not os.path.isdir("/root/reference"), reason="needs node and the reference tree (build container only)")
+def test_sync_protocol_over_the_engine_against_the_live_reference_emulated():
+    """two peers with diverged histories sync until they agree -- reference on both sides, then the engine-enabled
+    wrapper on the receiving side, on the sending side and on both: every message byte-identical, every patch equal, nothing served
+    by the JS fallback (the bulk receive is am355_apply_changes, the Bloom filters are built and probed on the device)."""
+    env = _emu_env(NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"), AUTOMERGE_BACKEND_PATH="/root/reference/backend")
+    out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "sync_campaign.js"), "6"], capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0 and "DISAGREE 0" in out.stdout and "18 runs identical" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    served = json.loads(out.stdout.split("served by: ")[1].splitlines()[0])
+    assert served["gpuApplyChanges"] >= 12 and served["fallbackToJs"] == 0 and served["hydrations"] == 0
+
+
 @pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_js_host_materialises_incremental_patches_emulated():
     """Backend.applyChanges calls of the reference's suites: node -> addon -> (emulated) am355_apply_changes -> record tables ->
