@@ -1,0 +1,16 @@
+#!/bin/bash
+# same-box A/B of library variants: _ab/run.sh <rounds> <variant>...   (variant = lib[:ENV=VAL])
+rounds=$1; shift
+L=automerge_classic_amd/csrc/libam355.so
+cp $L /tmp/lib_orig.so
+for r in $(seq $rounds); do for v in "$@"; do
+  lib=${v%%:*}; envs=""; [ "$v" != "$lib" ] && envs=${v#*:}
+  cp _ab/lib_$lib.so $L
+  env $envs timeout -k 5 100 python bench.py --steps 60 --warmup 10 --no-sublines --no-cpu-baseline > /tmp/ab.json 2>/dev/null
+  python - "$v" <<PY
+import json,sys
+p=json.loads(open("/tmp/ab.json").read().strip().splitlines()[-1])
+print("%-28s value %.0f ms %.4f t_device_ms %.4f"%(sys.argv[1],p["value"]/1e6,p["ms_per_step"],p["t_device_ms"]),{k[3:]:round(v,3) for k,v in p["phases_ms"].items()})
+PY
+done; done
+cp /tmp/lib_orig.so $L

@@ -54,6 +54,18 @@ struct DevBuf {
     cap = want;
     return true;
   }
+  // grows like ensure() but carries the first `keep` bytes over (device-to-device copy, synchronous)
+  bool ensure_keep(size_t bytes, size_t keep) {
+    if (bytes <= cap) return true;
+    size_t want = bytes + bytes / 2 + 256;
+    void* q = nullptr;
+    if (hipMalloc(&q, want) != hipSuccess) return false;
+    if (p && keep && hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(q); return false; }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = want;
+    return true;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -456,9 +468,13 @@ static bool read_uleb_host(const uint8_t* p, size_t len, size_t& off, uint64_t& 
 
 constexpr size_t INFLATE_CAP = 0xfff00000ull;  // one staged batch / document is addressed with 32-bit arena offsets
 
-static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
+// keep_staged: the changes staged so far stay where they are -- in the pinned arena and in HBM -- and the batch goes behind them
+// (am355_apply_changes onto a state whose changes were all applied in the order they are staged: only the batch crosses the link)
+static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n, bool keep_staged = false) {
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
+  const uint32_t k0 = keep_staged ? c->n_changes : 0;  // changes and bytes kept in front of the batch
+  const size_t b0 = keep_staged ? c->raw.size() : 0;
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
   c->staged = c->replayed = c->ir_fetched = false;
   c->apply_ready = false;
@@ -469,7 +485,7 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
     c->pool->prewake(offsets[1] - offsets[0] > 9 && arena[offsets[0] + 8] == 2 ? c->pool->size() : 4);  // (compressed changes: every thread inflates)
   for (uint32_t i = 0; i < n; i++)
     if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
-  if (offsets[n] - offsets[0] >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }
+  if (offsets[n] - offsets[0] + b0 >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }
   // ---- gather into the pinned raw arena + H2D, in slices handled by the host pool ----
   // Slice k covers a contiguous run of changes of about equal bytes. Phase A (parallel): changes of chunk type 2 are inflated
   // and their uncompressed containers rebuilt (columnar.js:813-823; checksum / hash are over that form) into a slice-local
@@ -547,18 +563,21 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
     if (sl.err) { c->flags |= AM355_F_BAD_DEFLATE; return fail(c, AM355_E_INVALID, "change %u: invalid or truncated deflate data", sl.err_change); }
     sl.base = total;
     total += sl.out_bytes;
-    if (total >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }
+    if (total + b0 >= INFLATE_CAP) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "batch larger than 4 GiB (32-bit arena offsets)"); }
   }
-  c->raw.resize(total);
-  c->raw_off.resize((size_t)n + 1);
-  c->raw_off[n] = total;
-  c->n_changes = n;
-  if (!c->d_arena.ensure(total + 64) || !c->d_offsets.ensure(sizeof(uint64_t) * (n + 1)) || !c->d_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) ||
-      !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u)) || !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)) ||
-      !c->h_offsets.ensure(sizeof(uint64_t) * ((size_t)n + 1)))
+  const uint32_t n_all = k0 + n;
+  c->raw.resize(b0 + total);
+  c->raw_off.resize((size_t)n_all + 1);
+  c->raw_off[n_all] = b0 + total;
+  c->n_changes = n_all;
+  if (!(keep_staged ? c->d_arena.ensure_keep(b0 + total + 64, b0) : c->d_arena.ensure(total + 64)) || !c->d_offsets.ensure(sizeof(uint64_t) * ((size_t)n_all + 1)) ||
+      !c->d_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n_all, 1u)) || !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n_all, 1u)) ||
+      !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)) || !c->h_offsets.ensure(sizeof(uint64_t) * ((size_t)n_all + 1)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
-  uint8_t* raw = c->raw.data();
-  uint64_t* roff = c->raw_off.data();
+  // (from here on `raw`, `d_raw` and `roff` address the batch's part: byte b0 of the arena, entry k0 of the offsets)
+  uint8_t* raw = c->raw.data() + b0;
+  uint8_t* d_raw = c->d_arena.as<uint8_t>() + b0;
+  uint64_t* roff = c->raw_off.data() + k0;
   std::vector<hipError_t> h2d(n_slices, hipSuccess);
   bool any_deflated = false;
   for (const Slice& sl : slices) any_deflated = any_deflated || sl.any_deflated;
@@ -595,7 +614,7 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
       auto issue_ready = [&]() {
         while (next_group < n_groups && left[next_group].load(std::memory_order_acquire) == 0) {
           size_t gb = group_first[next_group] * unit, ge = std::min(total, group_first[next_group + 1] * unit);
-          h2d[next_group] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
+          h2d[next_group] = hipMemcpyAsync(d_raw + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
           if (trace) fprintf(stderr, "load_changes:   group %zu (%zu KiB) enqueued +%8.3f ms\n", next_group, (ge - gb) >> 10, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
           next_group++;
         }
@@ -618,7 +637,7 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
         }
       }
     });
-    for (uint32_t i = 0; i < n; i++) roff[i] = offsets[i] - off0;
+    for (uint32_t i = 0; i < n; i++) roff[i] = b0 + (offsets[i] - off0);
   } else {
     // slices (inflated or plain) to their place in the arena in parallel; the H2D copies go out in few large commands: consecutive
     // slices are grouped to >= 2 MiB and one thread (task 0) enqueues a group as soon as its slices have landed
@@ -648,18 +667,18 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
 #endif
           }
           size_t gb = group_begin[g], ge = group_begin[g + 1];
-          if (ge > gb) h2d[g] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
+          if (ge > gb) h2d[g] = hipMemcpyAsync(d_raw + gb, raw + gb, ge - gb, hipMemcpyHostToDevice, c->stream);
         }
         return;
       }
       Slice& sl = slices[task - 1];
       if (sl.any_deflated) {
         if (sl.out_bytes) memcpy(raw + sl.base, sl.tmp.data(), sl.out_bytes);
-        size_t o = sl.base;
+        size_t o = b0 + sl.base;
         for (uint32_t i = sl.c0; i < sl.c1; i++) { roff[i] = o; o += sl.tmp_len[i - sl.c0]; }
       } else {
         if (sl.out_bytes) memcpy(raw + sl.base, arena + offsets[sl.c0], sl.out_bytes);
-        for (uint32_t i = sl.c0; i < sl.c1; i++) roff[i] = sl.base + (offsets[i] - offsets[sl.c0]);
+        for (uint32_t i = sl.c0; i < sl.c1; i++) roff[i] = b0 + sl.base + (offsets[i] - offsets[sl.c0]);
       }
       left[group_of[task - 1]].fetch_sub(1, std::memory_order_acq_rel);
     });
@@ -667,8 +686,8 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   lap("gathered, H2D enqueued");
   for (hipError_t e : h2d)
     if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (arena): %s", hipGetErrorString(e));
-  memcpy(c->h_offsets.p, roff, sizeof(uint64_t) * ((size_t)n + 1));  // (pinned mirror: the copy below must not bounce through the driver)
-  HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->h_offsets.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+  memcpy(c->h_offsets.p, c->raw_off.data(), sizeof(uint64_t) * ((size_t)n_all + 1));  // (pinned mirror: the copy below must not bounce through the driver)
+  HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->h_offsets.p, sizeof(uint64_t) * ((size_t)n_all + 1), hipMemcpyHostToDevice, c->stream));
   // No wait here: am355_replay enqueues behind these copies on the same stream, so its host-side set-up runs beside the tail of
   // the DMA instead of after a wake-up. The pinned arena is only rewritten by the next load, which waits first.
   c->staging_in_flight = true;
@@ -676,7 +695,7 @@ static int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t*
   if (trace || stage_sync) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); lap("H2D done"); }
   c->staged = true;
   c->stats = am355_stats{};
-  c->stats.n_changes = n;
+  c->stats.n_changes = n_all;
   c->stats.raw_bytes = c->raw.size();
   return AM355_OK;
 }
@@ -1820,6 +1839,30 @@ static int replay_impl(am355_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(sa, c->ev_join, 0));
 
+  // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. Its commands are enqueued
+  //      behind the stage-1 kernels of stream A. AM355_HASH_ENQUEUE=early enqueues them right behind the parse launch, which starts
+  //      the SHA kernel ~35 us sooner; measured on the same box (profiles/r03_ab_hash_enqueue.txt) that costs the replay 0.14 ms:
+  //      the kernels between decode and the compaction take 0.25 instead of 0.10 ms with stream B's commands queued first ----
+  auto enqueue_stream_b = [&]() -> int {
+    // (it starts after the parse kernel -- AM355_HASH_START=intern: after the actor kernels --: those grids are as small as the hash
+    // grid, one wave per 64 changes, and the ALU-dense SHA waves would otherwise share their SIMDs and slow them down)
+    HIPCHK(c, hipStreamWaitEvent(sb, hash_after_parse ? c->ev_parse : c->ev[1], 0));
+    HIPCHK(c, hipStreamWaitEvent(sb, c->ev_join, 0));  // (its flag words are cleared on stream3)
+    HIPCHK(c, hipEventRecord(c->ev_b0, sb));
+    HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
+    HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
+    launch_hash_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_hashes.as<uint8_t>(), c->d_min_idx.as<uint32_t>(),
+                    c->d_hash_tab.as<uint32_t>(), c->hash_mask, d_words + W_FLAGS_B, sb);
+    launch_deps_resolve(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_hashes.as<uint8_t>(), n, c->d_hash_tab.as<uint32_t>(), c->hash_mask,
+                    c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, c->d_dep_idx.as<uint32_t>(), c->d_self_idx.as<uint32_t>(), sb);
+    HIPCHK(c, hipMemcpyAsync(c->h_hashes.p, c->d_hashes.p, 32 * (size_t)n, hipMemcpyDeviceToHost, sb));
+    HIPCHK(c, hipMemcpyAsync(c->h_has_dep.p, c->d_has_dep.p, n, hipMemcpyDeviceToHost, sb));
+    HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
+    HIPCHK(c, hipEventRecord(c->ev_b1, sb));
+    return AM355_OK;
+  };
+  static const bool enqueue_early = []() { const char* e = getenv("AM355_HASH_ENQUEUE"); return e && !strcmp(e, "early"); }();
+  if (hash_after_parse && enqueue_early) { int rb = enqueue_stream_b(); if (rb) return rb; }
   exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_wa + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
   for (int attempt = 0;; attempt++) {
     if (attempt) {
@@ -1842,24 +1885,7 @@ static int replay_impl(am355_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, c->stream4));
     HIPCHK(c, hipEventRecord(c->ev_s1, c->stream4));
     HIPCHK(c, hipEventRecord(c->ev[1], sa));
-    if (attempt == 0) {
-      // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. It starts
-      //      after the parse / actor kernels of stream A: those grids are as small as the hash grid (one wave per 64
-      //      changes) and the ALU-dense SHA waves would otherwise share their SIMDs and slow them down ----
-      HIPCHK(c, hipStreamWaitEvent(sb, hash_after_parse ? c->ev_parse : c->ev[1], 0));
-      HIPCHK(c, hipStreamWaitEvent(sb, c->ev_join, 0));  // (its flag words are cleared on stream3)
-      HIPCHK(c, hipEventRecord(c->ev_b0, sb));
-      HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
-      HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
-      launch_hash_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_hashes.as<uint8_t>(), c->d_min_idx.as<uint32_t>(),
-                      c->d_hash_tab.as<uint32_t>(), c->hash_mask, d_words + W_FLAGS_B, sb);
-      launch_deps_resolve(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_hashes.as<uint8_t>(), n, c->d_hash_tab.as<uint32_t>(), c->hash_mask,
-                      c->d_min_idx.as<uint32_t>(), c->d_has_dep.as<uint8_t>(), d_words + W_FAST_B, c->d_dep_idx.as<uint32_t>(), c->d_self_idx.as<uint32_t>(), sb);
-      HIPCHK(c, hipMemcpyAsync(c->h_hashes.p, c->d_hashes.p, 32 * (size_t)n, hipMemcpyDeviceToHost, sb));
-      HIPCHK(c, hipMemcpyAsync(c->h_has_dep.p, c->d_has_dep.p, n, hipMemcpyDeviceToHost, sb));
-      HIPCHK(c, hipMemcpyAsync(h_words + W_FLAGS_B, d_words + W_FLAGS_B, 8, hipMemcpyDeviceToHost, sb));
-      HIPCHK(c, hipEventRecord(c->ev_b1, sb));
-    }
+    if (attempt == 0 && !(hash_after_parse && enqueue_early)) { int rb = enqueue_stream_b(); if (rb) return rb; }
     lap("stage 1 enqueued");
     if (!wait_host_signal(&sig->plan_seq, c->sig_seq, sa)) {
       (void)hipStreamSynchronize(sb);
@@ -2138,9 +2164,17 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   // ---- the queue of the call: changes applied so far (application order) | the batch | changes still queued (new.js:1822) ----
   const uint32_t n_old_applied = have_state ? (uint32_t)c->applied_change.size() : 0;
   const uint64_t old_ops = have_state ? c->n_ops : 0;
-  std::vector<uint8_t> comb;
-  std::vector<uint64_t> off;
-  {
+  // When every staged change was applied, in the order it is staged, and nothing is queued -- the usual case -- the staged bytes are
+  // already that queue's front, in the pinned arena and in HBM: only the batch is gathered and copied behind them.
+  bool append = have_state && c->pending_change.empty() && n_old_applied == c->n_changes && !getenv("AM355_APPLY_RESTAGE");
+  for (uint32_t i = 0; append && i < n_old_applied; i++) append = c->applied_change[i] == i;
+  int rc;
+  if (append) {
+    lap("queue = staged changes + batch");
+    rc = load_changes_impl(c, arena, offsets, n, true);
+  } else {
+    std::vector<uint8_t> comb;
+    std::vector<uint64_t> off;
     size_t bytes = (size_t)(offsets[n] - offsets[0]);
     if (have_state) bytes += c->raw.size();
     comb.reserve(bytes + 64);
@@ -2157,10 +2191,9 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
       off.push_back(comb.size());
     }
     if (have_state) for (uint32_t ci : c->pending_change) put_old(ci);
+    lap("queue assembled");
+    rc = load_changes_impl(c, comb.data(), off.data(), (uint32_t)off.size() - 1);
   }
-  const uint32_t total_n = (uint32_t)off.size() - 1;
-  lap("queue assembled");
-  int rc = load_changes_impl(c, comb.data(), off.data(), total_n);
   if (rc) { c->staged = false; return rc; }
   lap("staged");
   rc = replay_impl(c);

@@ -517,8 +517,19 @@ constexpr uint32_t DISTINCT_CAP = 4096;
 __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restrict__ arena, unsigned long long* __restrict__ slots, uint32_t mask,
                                                          uint32_t off, uint32_t len, uint32_t* __restrict__ distinct) {
   const uint8_t* p = arena + off;
-  uint64_t h = 0xcbf29ce484222325ull;
-  for (uint32_t k = 0; k < len; k++) h = (h ^ p[k]) * 0x100000001b3ull;
+  // actor ids are 16 bytes in practice: two 8-byte loads (any alignment) instead of a dependent chain of sixteen byte loads for the
+  // hash, and again for every comparison (each load of such a chain is a round trip to L2: this kernel is bound by them)
+  const bool wide = len == 16;
+  uint64_t p0 = 0, p1 = 0, h = 0xcbf29ce484222325ull;
+  if (wide) {
+    p0 = load_u64_unaligned(p);
+    p1 = load_u64_unaligned(p + 8);
+    h = (p0 ^ (p1 * 0x9e3779b97f4a7c15ull)) * 0xff51afd7ed558ccdull;
+    h ^= h >> 29;
+  } else {
+    for (uint32_t k = 0; k < len; k++) h = (h ^ p[k]) * 0x100000001b3ull;
+    h = (h ^ h >> 33) * 0xff51afd7ed558ccdull;  // (FNV-1a keeps the last bytes in the low bits: spread them before the slot is cut out)
+  }
   uint32_t i = (uint32_t)(h >> 20) & mask;
   unsigned long long mine = ((unsigned long long)off + 1) << 16 | len;
   for (uint32_t probes = 0; probes <= mask; probes++) {
@@ -537,7 +548,8 @@ __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restri
     if ((uint32_t)(v & 0xffff) == len) {
       const uint8_t* q = arena + ((v >> 16) - 1);
       bool eq = true;
-      for (uint32_t k = 0; k < len && eq; k++) eq = p[k] == q[k];
+      if (wide) eq = load_u64_unaligned(q) == p0 && load_u64_unaligned(q + 8) == p1;
+      else for (uint32_t k = 0; k < len && eq; k++) eq = p[k] == q[k];
       if (eq) return i;
     }
     i = (i + 1) & mask;
@@ -571,6 +583,21 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
     amap[base] = s;
     m->author_slot = s;
     atomicMin(&first_idx[s], c);
+  }
+  // The table of the other actors is length-prefixed, so finding entry k means walking entries 0 .. k-1 -- unless every entry has the
+  // same one-byte length (ids of 16 bytes: the ordinary case), which all lanes check at once: entry k then sits at a fixed stride.
+  if (n_other && n_other <= WAVE) {
+    const uint32_t l0 = p[m->others_off], stride = l0 + 1;
+    bool fits = l0 < 0x80 && (uint64_t)m->others_off + (uint64_t)stride * n_other <= m->len;
+    bool mine_ok = !fits || lane >= n_other || p[m->others_off + stride * lane] == l0;
+    if (fits && __ballot(!mine_ok) == 0) {
+      if (lane < n_other) {
+        uint32_t t = actor_find_or_insert(arena, slots, mask, abs0 + m->others_off + stride * lane + 1, l0, distinct);
+        if (t == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); t = 0; }
+        amap[base + 1 + lane] = t;
+      }
+      return;
+    }
   }
   Cur cur(p, m->others_off, m->len);  // advanced by lane 0 only
   for (uint32_t k0 = 0; k0 < n_other; k0 += WAVE) {
@@ -666,19 +693,48 @@ __device__ void rank_actors(const uint8_t* __restrict__ arena, const uint32_t* _
   for (uint32_t a = t; a < nd; a += BLOCK) {
     uint32_t rank = 0;
     const uint32_t my_len = s_len[a];
-    unsigned long long mine[PLAN_ID_MAX / 8];
-    for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) mine[wd] = s_id[a][wd];
+    static_assert(PLAN_ID_MAX == 32, "rank_actors compares four 64-bit words");
+    const unsigned long long m0 = s_id[a][0], m1 = s_id[a][1], m2 = s_id[a][2], m3 = s_id[a][3];
     for (uint32_t j = 0; j < nd; j++) {
-      bool less = false, decided = false;
-      for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8 && !decided; wd++) {
-        unsigned long long x = s_id[j][wd];
-        if (x != mine[wd]) { less = x < mine[wd]; decided = true; }
-      }
-      if (!decided) less = s_len[j] < my_len;  // equal up to the padding: the shorter id first (distinct ids differ somewhere)
+      const unsigned long long x0 = s_id[j][0], x1 = s_id[j][1], x2 = s_id[j][2], x3 = s_id[j][3];
+      // equal up to the padding: the shorter id first (distinct ids differ somewhere)
+      const bool less = x0 != m0 ? x0 < m0 : x1 != m1 ? x1 < m1 : x2 != m2 ? x2 < m2 : x3 != m3 ? x3 < m3 : s_len[j] < my_len;
       rank += less ? 1u : 0u;
     }
     slot_rank[distinct[1 + a]] = rank;
   }
+}
+
+// every actor a change mentions must already have a change in the document when the change is read: one wavefront per change, one
+// lane per entry of its actor table (a lane per change walking its 64 entries was 64 pairs of dependent loads: most of k_actor_check)
+__global__ __launch_bounds__(WAVE) void k_actor_first(ChangeMeta* __restrict__ metas, uint32_t n, const uint32_t* __restrict__ amap_base,
+                                                       const uint32_t* __restrict__ amap, uint32_t amap_cap, const uint32_t* __restrict__ first_idx,
+                                                       uint32_t* __restrict__ fast_flags) {
+  uint32_t c = blockIdx.x, lane = threadIdx.x;
+  if (c >= n) return;
+  ChangeMeta* m = &metas[c];
+  if (m->flags) return;
+  uint32_t base = amap_base[c], ne = m->n_entries;
+  if ((uint64_t)base + ne > amap_cap) return;
+  uint32_t mx = 0;
+  for (uint32_t k = lane; k < ne; k += WAVE) {
+    uint32_t f = first_idx[amap[base + k]];
+    mx = f > mx ? f : mx;  // NONE32 (no change by that actor in the batch) also lands on the general path
+  }
+  for (int d = WAVE / 2; d >= 1; d >>= 1) {
+    uint32_t o = __shfl_xor(mx, d);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) {
+    m->max_first = mx;
+    if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
+  }
+}
+
+// one workgroup: lexicographic ranks of the distinct actor ids
+__global__ __launch_bounds__(BLOCK) void k_rank_actors(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
+                                                       uint32_t* __restrict__ plan_words) {
+  rank_actors(arena, distinct, slot_rank, plan_words);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
@@ -687,7 +743,6 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
                                                        ChangeBrief* __restrict__ briefs, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
                                                        unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words) {
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
-  if (blockIdx.x + 1 == gridDim.x) { rank_actors(arena, distinct, slot_rank, plan_words); return; }
   uint32_t c = gtid();
   const bool in_range = c < n;
   ChangeBrief br{};
@@ -701,16 +756,6 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
     br.author_slot = m->author_slot;
     br.flags_fits = m->flags;
     if (!m->flags) {
-      uint32_t base = amap_base[c];
-      if ((uint64_t)base + m->n_entries <= amap_cap) {
-        uint32_t mx = 0;
-        for (uint32_t k = 0; k < m->n_entries; k++) {
-          uint32_t f = first_idx[amap[base + k]];
-          mx = f > mx ? f : mx;  // NONE32 (no change by that actor in the batch) also lands on the general path
-        }
-        m->max_first = mx;
-        if (mx > c) atomicOr(fast_flags, (uint32_t)FF_LATE_ACTOR);
-      }
       int wc = wave_class_of(*m);
       if (wc >= 1) br.flags_fits |= 0x80000000u;
       if (wc == 2) br.flags_fits |= 0x40000000u;
@@ -1697,9 +1742,11 @@ void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, co
   if (n)
     hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
                        fast_flags, distinct);
-  // (+ 1: the workgroup that ranks the distinct actor ids)
-  hipLaunchKernelGGL(k_actor_check, dim3((n + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), 0, st, arena, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
-                     (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, slot_rank, block_sums, plan_words);
+  if (n) hipLaunchKernelGGL(k_actor_first, dim3(n), dim3(WAVE), 0, st, metas, n, amap_base, (const uint32_t*)amap, amap_cap, (const uint32_t*)first_idx, fast_flags);
+  hipLaunchKernelGGL(k_rank_actors, dim3(1), dim3(BLOCK), 0, st, arena, (const uint32_t*)distinct, slot_rank, plan_words);
+  if (n)
+    hipLaunchKernelGGL(k_actor_check, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, arena, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
+                       (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, slot_rank, block_sums, plan_words);
 }
 
 size_t plan_block_sums_bytes(uint32_t n) { return sizeof(unsigned long long) * PLAN_SUMS * ((size_t)(n + BLOCK - 1) / BLOCK + 1); }

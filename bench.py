@@ -217,6 +217,45 @@ def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False, deflate
             "roofline_whole_path": {"achieved": whole, "unit": "GB/s", "frac": whole / 8000.0}}
 
 
+def apply_changes_section(eng, log, sync, reps=7):
+    """SURVEY.md §8f-2 / 8f-4 (not part of `value`): Backend.applyChanges with its incremental patch on the engine -- binary changes in
+    host memory -> am355_apply_changes (replay of the earlier changes + the batch, delta stage, setupPatches) -> patch record tables in
+    host memory -- for the whole headline log onto an empty document and for batches onto the document the rest of the log made; and
+    the sync protocol's Bloom filter over all its change hashes, built on the device."""
+    from automerge_classic_amd.loggen import ChangeLog
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    changes = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    n = len(changes)
+    rows = []
+    for k in (n, max(1, n // 10), max(1, n // 100)):
+        base = ChangeLog.from_changes(changes[:n - k]) if n > k else None
+        batch = ChangeLog.from_changes(changes[n - k:])
+        best, ops_before = None, 0
+        for _ in range(reps):
+            eng.reset()
+            if base is not None:
+                eng.apply_changes(base)
+                ops_before = int(eng.stats().n_ops)
+            sync()
+            t0 = time.perf_counter()
+            eng.apply_changes(batch)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        st = eng.stats()
+        batch_ops = int(st.n_ops) - ops_before
+        rows.append({"batch_changes": k, "batch_ops": batch_ops, "document_ops_before": ops_before, "ms": best * 1e3, "batch_ops_per_s": batch_ops / best,
+                     "patch_bytes": len(eng.apply_patch_json())})
+    idx = np.arange(n, dtype=np.uint32)
+    eng.bloom_build(idx)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bits = eng.bloom_build(idx)
+    bloom_ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"timed_region": "host change buffers -> am355_apply_changes -> incremental patch record tables in host memory (best of %d)" % reps,
+            "parity": "patch text == oracle session == reference on the captured applyChanges calls (tests/test_apply_engine.py)",
+            "batches": rows, "sync_bloom_filter": {"hashes": n, "filter_bytes": int(bits.size), "ms": bloom_ms}}
+
+
 def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier, scale=1.0, sync=None):
     """ONE document (c4_text_multi: 64 Text objects) sharded by objectId over the ranks: T_replay-style region (host buffers on
     every rank -> stitched patch IR on rank 0's host), max over ranks; beside it the same log unsharded on rank 0 alone."""
@@ -399,6 +438,8 @@ def main():
             ms_deflate = (time.perf_counter() - t0) * 1e3
             out["history_after_load"] = {"n_changes": int(len(h_off) - 1), "change_bytes": int(h_off[-1]), "ms": ms_plain, "ms_with_deflate": ms_deflate,
                                          "ops_per_s": st.n_ops / (ms_plain * 1e-3)}
+        if not w.is_doc:
+            out["apply_changes"] = apply_changes_section(eng, w.log, barrier)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

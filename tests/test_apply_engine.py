@@ -189,6 +189,26 @@ def test_generated_logs_in_batches_match_the_oracle_emulated(emu_lib, kind, kw, 
         eng.close()
 
 
+def test_batches_behind_the_staged_changes_or_restaged_emulated(emu_lib, monkeypatch):
+    """A batch onto a state whose changes are all applied is staged behind them (only the batch is copied); AM355_APPLY_RESTAGE=1
+    rebuilds the whole queue instead, as a call with queued changes does. Same patches either way, deflated batches included."""
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=5, n_rounds=4, ins_per_change=14, del_per_change=4, n_objects=2, seed=41)
+    zlog = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=5, n_rounds=4, ins_per_change=14, del_per_change=4, n_objects=2, seed=41, deflate=True)
+    plain, packed = split_log(log, 5), split_log(zlog, 5)
+    batches = [packed[k] if k % 2 else plain[k] for k in range(len(plain))]
+    texts = []
+    for restage in (False, True):
+        if restage:
+            monkeypatch.setenv("AM355_APPLY_RESTAGE", "1")
+        eng = engine.Engine(0, emu_lib)
+        try:
+            check_against_oracle_session(eng, batches)
+            texts.append(eng.patch_json())
+        finally:
+            eng.close()
+    assert texts[0] == texts[1]
+
+
 def test_apply_after_load_changes_and_queue_emulated(emu_lib):
     """loadChanges + replay, then applyChanges on top; a batch delivered out of order waits in the queue (new.js:1822-1841)."""
     log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=4, ins_per_change=10, del_per_change=3, n_objects=1, seed=5)
