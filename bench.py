@@ -8,7 +8,7 @@ container parse + SHA-256 + column decode -> causal schedule -> op-set merge -> 
   t_device_ops_per_s   the replay alone, inputs already resident in HBM and the IR left in HBM (what round 1 reported as `value`),
   roofline             whole path: N_ops x A / T_device with A = E + R + P algorithmic bytes per op, plus a
                        per-kernel table (live HIP-event brackets of the phases; rocprofv3 + PMC figures of the top kernels
-                       from the committed summary of this same command, profiles/r02_kernel_table.json),
+                       from the committed summary of this same command, profiles/rNN_kernel_table.json of the latest round),
   cpu_baseline         the CPU oracle (plain-C port of the reference's algorithm) on the same workload, 1 thread,
   workloads            sub-lines for c4_text_multi, c3_map_lww, c2_text_typing, the headline log in shuffled delivery order
                        (general scheduler, fast_path 0) and c5_doc_mixed (Backend.load), N = 1 only.
@@ -380,7 +380,9 @@ def main():
     roofline = {"bound": "hbm", "achieved": whole, "peak": 8000.0, "unit": "GB/s", "frac": whole / 8000.0, "traffic": None,
                 "kernel": "whole path (SURVEY.md §8d): N_ops x (E + R + P) / T_device", "algorithmic_bytes_per_launch": st.n_ops * A["A"],
                 "launch_ms": t_device_ms, "n_preds": n_preds, "phases": phase_table(phases, st, n_preds)}
-    table = os.path.join(ROOT, "profiles", "r02_kernel_table.json")
+    import glob
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_table.json")))  # (the latest round's summary)
+    table = tables[-1] if tables else os.path.join(ROOT, "profiles", "r02_kernel_table.json")
     if os.path.exists(table) and args.workload == "c4_text_single" and args.scale == 1.0:
         # rocprofv3 kernel-trace + PMC passes of this same command (committed summary; counters cannot be read in-process):
         # per kernel: calls per replay, average us, algorithmic bytes, PMC HBM bytes, fraction of the 8 TB/s peak

@@ -1,5 +1,6 @@
 #!/bin/bash
-# same-box A/B of library variants: _ab/run.sh <rounds> <variant>...   (variant = lib[:ENV=VAL])
+# same-box A/B of library variants: tools/ab_libs.sh <rounds> <variant>...   (variant = lib[:ENV=VAL])
+# (build each variant to _ab/lib_<name>.so: the directory is git-ignored but travels with the gpurun snapshot)
 rounds=$1; shift
 L=automerge_classic_amd/csrc/libam355.so
 cp $L /tmp/lib_orig.so

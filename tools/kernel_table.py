@@ -65,6 +65,8 @@ def main():
         "k_parse_changes": (RAW + 176 * C, "change bytes read once + one 176-byte ChangeMeta per change"),
         "k_hash_changes": (RAW + 32 * C, "change bytes read once + 32-byte digest per change"),
         "k_actor_intern": (17 * 65 * C, "one actor-table entry (16-byte id + length) per (change, actor)"),
+        "k_actor_first": (4 * 65 * C + 8 * C, "one provisional actor number per (change, actor) read, the change's latest first-use written"),
+        "k_rank_actors": (0, "the distinct actor ids (a few hundred bytes): latency of three dependent loads"),
         "k_actor_check": (176 * C + 32 * C, "ChangeMeta read + 32-byte brief written per change"),
         "k_plan": (32 * C + 24 * C, "brief read + plan written per change"),
         "k_decode_wave<small>": (RAW + 53 * N + 8 * P, "encoded bytes read once + 53-byte op row + 8 bytes per pred written once"),
