@@ -2126,10 +2126,8 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   for (uint32_t r : c->pass_first_row) if (r > T0) pass_rows.push_back(r);
   d.n_pass = (uint32_t)pass_rows.size();
   d.pass_rows = c->d_pass.as<uint32_t>();
-  if (d.n_pass) {
-    HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));  // (pass_rows is pageable memory)
-  }
+  if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));  // (pageable sources)
   delta_run(c->mb, c->ir, d, hc, st, check_only);
   HIPCHK(c, hipGetLastError());
   return AM355_OK;

@@ -25,7 +25,7 @@ enum : uint32_t {
 
 struct DeltaCounts {
   uint32_t flags;      // Flag bits (F_UNSUPPORTED: outside the subset served here)
-  uint32_t n_items;    // list edit items (inserts of new elements + first deletions of visible elements)
+  uint32_t n_items;    // list edit items (inserts of new elements + events: an element removed, assigned to, or brought back)
   uint32_t n_kept;     // visible values of touched map keys
   uint32_t n_place;    // touched map keys left without a visible value
   uint32_t n_erecs;    // delta edit records
@@ -47,14 +47,20 @@ struct DeltaBufs {
   const uint32_t* pass_rows;  // [n_pass] first row of each such pass
   DeltaCounts* counts;
   ObjLink* link;          // [NO]
-  // rows
-  uint32_t *first_del, *new_succ, *has_upd, *pos_of;  // [N]
+  // rows: first_del / new_succ per VALUE row (first row of the batch that overwrites or deletes it, how many do); upd_*: the
+  // assignment rows (K_LIST_UPD) of every list element, grouped by element
+  uint32_t *first_del, *new_succ, *upd_n, *pos_of;    // [N + 1]
+  uint32_t *upd_off, *upd_cur, *upd_rows;             // [N + 2]
+  // per new row that deletes from or assigns to a list element: what the patch shows for it (EV_*), was the element visible before
+  // it, how many values it shows afterwards
+  uint32_t *ev_kind, *ev_before, *ev_nafter;          // [NN + 1]
   // list positions
-  uint32_t *v0, *icnt, *v0_ex, *item_ex;              // [n_list + 1]
+  uint32_t *v0, *icnt, *v0_ex, *item_ex, *icur;       // [n_list + 2]
   // items (ping-pong), [NN + 1]
   uint32_t *tk[2], *elem[2], *acc[2], *lo[2], *hi[2];
   uint32_t *zf, *zw, *zf_ex, *zw_ex;                  // [NN + 2]
-  uint32_t *e_index, *e_flags, *e_head, *e_head_ex;   // [NN + 1]
+  uint32_t *e_index, *e_flags, *e_head, *e_head_ex;   // [NN + 2] (e_head: records of the item)
+  uint32_t *e_val, *e_val_ex;                         // [NN + 2] values of the item (count of a remove)
   am355_ir_edit* edit;                                // [NN + 2]
   // touched map keys: open-addressing table of cap slots (power of two)
   uint32_t key_mask;
@@ -68,6 +74,8 @@ struct DeltaBufs {
   void* scan_ws;
   void* sort_ws;
 };
+
+enum : uint32_t { EV_NONE = 0, EV_INSERT = 1, EV_REMOVE = 2, EV_UPDATE = 3 };
 
 size_t delta_bytes(uint32_t n_ops, uint32_t n_new, uint32_t n_map, uint32_t n_obj, uint32_t n_list);
 void delta_bind(DeltaBufs& d, void* block, uint32_t n_ops, uint32_t n_new, uint32_t n_map, uint32_t n_obj, uint32_t n_list);

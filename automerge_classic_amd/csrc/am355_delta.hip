@@ -7,8 +7,9 @@
 // state is known -- every element's position in its list (MergeBufs.order), every row's successor count -- and rows are numbered in
 // application order, which makes "time" a row number: rows >= T0 are the batch.  The patch follows from the final state and time:
 //
-//   list object   insert edit for every new element e at time t(e) = its row; remove edit for every element that was visible and
-//                 whose first deletion d is a new row, at time t(d).  index(x, t) = visible elements in front of x at time t
+//   list object   insert edit for every new element e at time t(e) = its row; for every new row that deletes from or assigns to an
+//                 element an edit at its time: remove (the element was visible and is not any more), insert (the other way round),
+//                 update (it stays visible; weight 0).  index(x, t) = visible elements in front of x at time t
 //                   = V0(x)                                  elements in front that were visible before the batch (prefix sum)
 //                   + #{new elements in front of x inserted before t} - #{elements in front of x removed before t}
 //                 -- a dominance count over (position, time), done for all edits at once by stable binary partitions on the bits of
@@ -23,11 +24,10 @@
 //                 values are missing from the patch.
 //   object links  am355_api.hip (host): setupPatches over the object table, from ObjLink.
 //
-// Served subset (anything else raises F_UNSUPPORTED and the call is served by the JS path): list elements named by the batch hold
-// exactly one row, their insert -- i.e. the batch inserts and deletes list elements but assigns to none, and deletes no element that
-// holds conflicting values; no objectId sharding.  (Assignments to list elements run into order-dependent edit rewriting --
-// appendUpdate popping earlier edits, an index that lags when the previous element of the same call stays visible, new.js:1203
-// before :1236-1239 -- which the sequential oracle restates and this stage does not.)
+// Served subset (anything else raises F_UNSUPPORTED and the call is served by the JS path): list elements hold plain values -- inserted,
+// deleted and assigned to (`list[i] = v`: kd_events; the edit rewriting of appendUpdate and the index lag inside one merge call are
+// restated in kd_edit_runs / kd_events) --; elements that hold child objects or counters are inserted and deleted but not assigned to;
+// no objectId sharding.
 #include "am355_delta.h"
 #include "am355_prims.h"
 #include "am355_rows.h"
@@ -51,9 +51,10 @@ static uint32_t key_table_cap(uint32_t n_new) {
 size_t delta_bytes(uint32_t N, uint32_t NN, uint32_t NM, uint32_t NO, uint32_t NL) {
   size_t cap = key_table_cap(NN);
   size_t b = al256(sizeof(DeltaCounts)) + al256(sizeof(ObjLink) * ((size_t)NO + 1));
-  b += 4 * al256(4 * ((size_t)N + 1));
-  b += 4 * al256(4 * ((size_t)NL + 2));
-  b += 10 * al256(4 * ((size_t)NN + 2)) + 4 * al256(4 * ((size_t)NN + 3)) + 4 * al256(4 * ((size_t)NN + 2)) + al256(sizeof(am355_ir_edit) * ((size_t)NN + 2));
+  b += 4 * al256(4 * ((size_t)N + 1)) + 3 * al256(4 * ((size_t)N + 2));
+  b += 5 * al256(4 * ((size_t)NL + 2));
+  b += 3 * al256(4 * ((size_t)NN + 1));
+  b += 10 * al256(4 * ((size_t)NN + 2)) + 4 * al256(4 * ((size_t)NN + 3)) + 6 * al256(4 * ((size_t)NN + 2)) + al256(sizeof(am355_ir_edit) * ((size_t)NN + 2));
   b += 9 * al256(4 * (cap + 1)) + al256(8 * cap);
   b += 3 * al256(4 * ((size_t)NM + 1)) + 2 * al256(8 * ((size_t)NM + cap + 1)) + 2 * al256(4 * ((size_t)NM + cap + 1)) + al256(sizeof(am355_ir_map) * ((size_t)NM + cap + 1));
   size_t biggest = std::max<size_t>({(size_t)N + 2, (size_t)NM + cap + 2, (size_t)NN + 4});
@@ -75,9 +76,11 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   d.counts = dcarve<DeltaCounts>(p, 1);
   d.link = dcarve<ObjLink>(p, (size_t)NO + 1);
   d.first_del = dcarve<uint32_t>(p, (size_t)N + 1); d.new_succ = dcarve<uint32_t>(p, (size_t)N + 1);
-  d.has_upd = dcarve<uint32_t>(p, (size_t)N + 1); d.pos_of = dcarve<uint32_t>(p, (size_t)N + 1);
+  d.upd_n = dcarve<uint32_t>(p, (size_t)N + 1); d.pos_of = dcarve<uint32_t>(p, (size_t)N + 1);
+  d.upd_off = dcarve<uint32_t>(p, (size_t)N + 2); d.upd_cur = dcarve<uint32_t>(p, (size_t)N + 2); d.upd_rows = dcarve<uint32_t>(p, (size_t)N + 2);
+  d.ev_kind = dcarve<uint32_t>(p, (size_t)NN + 1); d.ev_before = dcarve<uint32_t>(p, (size_t)NN + 1); d.ev_nafter = dcarve<uint32_t>(p, (size_t)NN + 1);
   d.v0 = dcarve<uint32_t>(p, (size_t)NL + 2); d.icnt = dcarve<uint32_t>(p, (size_t)NL + 2);
-  d.v0_ex = dcarve<uint32_t>(p, (size_t)NL + 2); d.item_ex = dcarve<uint32_t>(p, (size_t)NL + 2);
+  d.v0_ex = dcarve<uint32_t>(p, (size_t)NL + 2); d.item_ex = dcarve<uint32_t>(p, (size_t)NL + 2); d.icur = dcarve<uint32_t>(p, (size_t)NL + 2);
   for (int k = 0; k < 2; k++) {
     d.tk[k] = dcarve<uint32_t>(p, (size_t)NN + 2); d.elem[k] = dcarve<uint32_t>(p, (size_t)NN + 2); d.acc[k] = dcarve<uint32_t>(p, (size_t)NN + 2);
     d.lo[k] = dcarve<uint32_t>(p, (size_t)NN + 2); d.hi[k] = dcarve<uint32_t>(p, (size_t)NN + 2);
@@ -86,6 +89,7 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   d.zf_ex = dcarve<uint32_t>(p, (size_t)NN + 3); d.zw_ex = dcarve<uint32_t>(p, (size_t)NN + 3);
   d.e_index = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_flags = dcarve<uint32_t>(p, (size_t)NN + 2);
   d.e_head = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_head_ex = dcarve<uint32_t>(p, (size_t)NN + 2);
+  d.e_val = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_val_ex = dcarve<uint32_t>(p, (size_t)NN + 2);
   d.edit = dcarve<am355_ir_edit>(p, (size_t)NN + 2);
   d.slot_rep = dcarve<uint32_t>(p, cap + 1); d.slot_first = dcarve<uint32_t>(p, cap + 1); d.slot_last = dcarve<uint32_t>(p, cap + 1);
   d.slot_cont = dcarve<uint32_t>(p, cap + 1); d.slot_cnt = dcarve<uint32_t>(p, cap + 1); d.slot_child = dcarve<uint32_t>(p, cap + 1);
@@ -180,31 +184,62 @@ __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
   uint8_t kind = b.kind[g];
   if (kind == K_LIST_UPD) {
     uint32_t el = b.ref_row[g];
-    if (el != NONE32) d.has_upd[el] = 1;
+    if (el != NONE32) atomicAdd(&d.upd_n[el], 1u);
   }
   if (g < d.T0) return;
+  const OpCols& o = b.ops;
   uint32_t err = 0;
   if (kind == K_FOREIGN) err |= F_UNSUPPORTED;
   if (kind != K_NONE && kind != K_FOREIGN) {
-    if (kind == K_MAP || (kind == K_DEL && b.ops.key_len[g] != NONE32)) {
+    if (kind == K_MAP || (kind == K_DEL && o.key_len[g] != NONE32)) {
       uint32_t s = key_slot(b, d, g, true);
       if (s == NONE32) err |= F_UNSUPPORTED;
       else { atomicMin(&d.slot_first[s], g); atomicMax(&d.slot_last[s], g); }
-    } else if (kind == K_DEL) {
-      uint32_t el = b.ref_row[g];
-      if (el == NONE32) err |= F_BAD_ELEM;
-      else { atomicAdd(&d.new_succ[el], 1u); atomicMin(&d.first_del[el], g); }
-    } else if (kind == K_LIST_UPD) {
-      err |= F_UNSUPPORTED;  // an assignment to a list element (see the head of this file)
+    } else if (kind == K_DEL || kind == K_LIST_UPD) {
+      // every value row this op overwrites or deletes: how many rows of the batch do so, and which is the first
+      if (b.ref_row[g] == NONE32) err |= F_BAD_ELEM;
+      for (uint32_t k = 0; k < o.pred_num[g]; k++) {
+        uint32_t r = row_of(b, o.pred_actor[o.pred_first[g] + k], o.pred_ctr[o.pred_first[g] + k]);
+        if (r == NONE32 || r >= g) { err |= F_BAD_ELEM; continue; }
+        atomicAdd(&d.new_succ[r], 1u);
+        atomicMin(&d.first_del[r], g);
+      }
     }
   }
   if (err) atomicOr(&d.counts->flags, err);
 }
 
+__global__ __launch_bounds__(BLOCK) void kd_upd_scatter(MergeBufs b, DeltaBufs d) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops || b.kind[g] != K_LIST_UPD) return;
+  uint32_t el = b.ref_row[g];
+  if (el != NONE32) d.upd_rows[d.upd_off[el] + atomicAdd(&d.upd_cur[el], 1u)] = g;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // lists
 // ---------------------------------------------------------------------------------------------------------
-// per list position: was the element visible before the batch, how many edit items it gives rise to
+// A list element shows the values of its insert row and of the rows that assign to it (K_LIST_UPD), as far as they have no
+// successor. With rows numbered in application order that is a question of time: a value row r exists from time r on, and is
+// overwritten at the time of its first successor -- before the batch if it has successors among the earlier rows, else at
+// first_del[r].
+__device__ __forceinline__ bool alive_at_T0(const MergeBufs& b, const DeltaBufs& d, uint32_t r) { return r >= d.T0 || b.succ_cnt[r] == d.new_succ[r]; }
+constexpr uint32_t ELEM_ROWS_MAX = 32;  // value rows of one element this stage walks (more: refused)
+
+// the element's value rows visible just before / just after row g was applied
+__device__ __forceinline__ void elem_state(const MergeBufs& b, const DeltaBufs& d, uint32_t e, uint32_t g, uint32_t& before, uint32_t& after) {
+  before = after = 0;
+  const uint32_t nu = d.upd_n[e], base = d.upd_off[e];
+  for (uint32_t k = 0; k <= nu; k++) {
+    uint32_t r = k == 0 ? e : d.upd_rows[base + k - 1];
+    if (r > g || !alive_at_T0(b, d, r)) continue;
+    uint32_t dies = d.first_del[r];
+    if (r < g && dies >= g) before++;
+    if (dies > g) after++;
+  }
+}
+
+// per list position: was the element visible before the batch; one edit item for a new element
 __global__ __launch_bounds__(BLOCK) void kd_positions(MergeBufs b, DeltaBufs d) {
   uint32_t p = gtid();
   if (p > d.n_list) return;
@@ -212,35 +247,126 @@ __global__ __launch_bounds__(BLOCK) void kd_positions(MergeBufs b, DeltaBufs d) 
   if (p < d.n_list) {
     uint32_t e = b.order[p];
     d.pos_of[e] = p;
-    bool fin_vis = b.val_cnt[e] + (b.kind[e] == K_LIST_INS_VIS ? 1u : 0u) > 0;
-    uint32_t ns = d.new_succ[e];
     bool is_new = e >= d.T0;
-    bool eff_del = ns > 0 && b.succ_cnt[e] == ns;  // visible until a row of the batch deleted it
-    if ((is_new || ns > 0) && d.has_upd[e]) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
-    v0 = (!is_new && (fin_vis || eff_del)) ? 1u : 0u;
-    c = (is_new ? 1u : 0u) + (eff_del ? 1u : 0u);
+    if (!is_new) {
+      const uint32_t nu = d.upd_n[e], base = d.upd_off[e];
+      bool vis = alive_at_T0(b, d, e);
+      for (uint32_t k = 0; k < nu && !vis; k++) {
+        uint32_t r = d.upd_rows[base + k];
+        vis = r < d.T0 && alive_at_T0(b, d, r);
+      }
+      v0 = vis ? 1u : 0u;
+    }
+    c = is_new ? 1u : 0u;
   }
   d.v0[p] = v0;
   d.icnt[p] = c;
 }
 
-// items in position order: (time << 1 | is_remove), element, group = the items of its list object
-__global__ __launch_bounds__(BLOCK) void kd_items(MergeBufs b, DeltaBufs d) {
-  uint32_t p = gtid();
-  if (p >= d.n_list) return;
-  uint32_t c = d.icnt[p];
-  if (!c) return;
-  uint32_t e = b.order[p], base = d.item_ex[p];
+__device__ __forceinline__ bool list_elem_op(const MergeBufs& b, uint32_t g) {
+  uint8_t k = b.kind[g];
+  return k == K_LIST_UPD || (k == K_DEL && b.ops.key_len[g] == NONE32);
+}
+
+// per new row that deletes from or assigns to a list element: the edit it gives rise to (new.js:984-1033 taken over all the
+// rows of the element the merge call visits: insert when nothing was visible and something is, remove the other way round, update
+// when the element stays visible). Served: elements whose rows are plain `set`s.
+//
+// The index lag of the reference: a merge call takes the following ops of the pass -- the ops of all changes one scheduling pass
+// applies are one stream -- while they are by the same actor and continue on the NEXT element of the document (new.js:1111-1123),
+// and it reports the insert row of such a next element at an index that does not yet count the previous element
+// (updatePatchProperty at new.js:1203 runs before the increment at :1236-1239). It shows when the previous element is visible after
+// its op and the insert row of this one held a visible value: `list[1] = x` followed by the same actor's deletion of element 2
+// gives update@1, remove@1. Reproduced for removes (ev_lag); an update whose first value would sit at the lagging index and the
+// others not is refused.
+constexpr uint32_t GAP_WALK_MAX = 64;  // later insertions between two elements this stage walks over to decide whether they were neighbours
+
+__global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
+  uint32_t t = gtid();
+  if (t >= d.n_new) return;
+  uint32_t g = d.T0 + t;
+  uint32_t ev = EV_NONE, before = 0, after = 0, err = 0, lag = 0;
+  if (list_elem_op(b, g) && b.ref_row[g] != NONE32) {
+    const OpCols& o = b.ops;
+    uint32_t e = b.ref_row[g];
+    const uint32_t nu = d.upd_n[e];
+    if (nu > ELEM_ROWS_MAX) err |= F_UNSUPPORTED;
+    else {
+      elem_state(b, d, e, g, before, after);
+      ev = before ? (after ? EV_UPDATE : EV_REMOVE) : (after ? EV_INSERT : EV_NONE);
+      if (nu > 0) {  // (the element holds assignment rows, old or new)
+        bool plain = o.action[e] == 1;
+        for (uint32_t k = 0; k < nu; k++) plain = plain && o.action[d.upd_rows[d.upd_off[e] + k]] == 1;
+        if (!plain) err |= F_UNSUPPORTED;  // child objects / counters among the values: objectMeta bookkeeping, counter states
+      }
+      // ---- does the op continue the merge call of the previous op of the stream? ----
+      bool first_of_pass = g == d.T0;
+      for (uint32_t k = 0; k < d.n_pass; k++) first_of_pass = first_of_pass || d.pass_rows[k] == g;
+      if (!first_of_pass && list_elem_op(b, g - 1) && o.id_actor[g - 1] == o.id_actor[g] && same_obj(b, g - 1, g) && b.ref_row[g - 1] != NONE32) {
+        uint32_t a = b.ref_row[g - 1];
+        if (a == e) {
+          // several ops on one element share a call unless the later one overwrites the earlier (new.js:1118-1121): not restated
+          bool overwrites = false;
+          for (uint32_t k = 0; k < o.pred_num[g]; k++)
+            overwrites = overwrites || (o.pred_ctr[o.pred_first[g] + k] == o.id_ctr[g - 1] && o.pred_actor[o.pred_first[g] + k] == o.id_actor[g - 1]);
+          if (!overwrites) err |= F_UNSUPPORTED;
+        } else if (d.upd_n[a] <= ELEM_ROWS_MAX) {
+          uint32_t a_before, a_after;
+          elem_state(b, d, a, g - 1, a_before, a_after);
+          const bool ins_row_visible = e < g && alive_at_T0(b, d, e) && d.first_del[e] >= g;  // the insert row held a visible value
+          if (a_after > 0 && ins_row_visible) {
+            // was e the element right behind a when the op was applied? (elements inserted later may stand between them now)
+            uint32_t pa = d.pos_of[a], pe = d.pos_of[e];
+            bool neighbours = pe > pa;
+            if (neighbours && pe - pa - 1 > GAP_WALK_MAX) { neighbours = false; err |= F_UNSUPPORTED; }
+            for (uint32_t q = pa + 1; neighbours && q < pe; q++) neighbours = b.order[q] > g;
+            if (neighbours) {
+              if (ev == EV_REMOVE) lag = 1;
+              else if (d.first_del[e] > g) err |= F_UNSUPPORTED;  // the insert row's value stays: its update edit alone would lag
+            }
+          }
+        } else err |= F_UNSUPPORTED;
+      }
+      if (ev != EV_NONE) atomicAdd(&d.icnt[d.pos_of[e]], 1u);
+    }
+  }
+  d.ev_kind[t] = ev;
+  d.ev_before[t] = (before ? 1u : 0u) | lag << 1;
+  d.ev_nafter[t] = after;
+  if (err) atomicOr(&d.counts->flags, err);
+}
+
+// items: tk = time << 2 | kind (0 insert: +1 visible element, 1 remove: -1, 2 update: 0), element, group = the items of its list object
+__device__ __forceinline__ void put_item(const MergeBufs& b, DeltaBufs& d, uint32_t e, uint32_t tk) {
+  uint32_t p = d.pos_of[e];
   uint32_t oi = obj_index_of(b, b.obj_row[e]);
   uint32_t fp = b.obj_first_pos[oi];
   uint32_t lo = d.item_ex[fp], hi = d.item_ex[fp + b.obj_n[oi]];
-  uint32_t k = 0;
-  if (e >= d.T0) {
-    d.tk[0][base] = (e - d.T0) << 1; d.elem[0][base] = e; d.acc[0][base] = 0; d.lo[0][base] = lo; d.hi[0][base] = hi;
-    k = 1;
-  }
-  if (k < c) {
-    d.tk[0][base + k] = (d.first_del[e] - d.T0) << 1 | 1u; d.elem[0][base + k] = e; d.acc[0][base + k] = 0; d.lo[0][base + k] = lo; d.hi[0][base + k] = hi;
+  uint32_t at = d.item_ex[p] + atomicAdd(&d.icur[p], 1u);
+  d.tk[0][at] = tk; d.elem[0][at] = e; d.acc[0][at] = 0; d.lo[0][at] = lo; d.hi[0][at] = hi;
+}
+
+__global__ __launch_bounds__(BLOCK) void kd_items(MergeBufs b, DeltaBufs d) {
+  uint32_t t = gtid();
+  if (t >= d.n_new) return;
+  uint32_t g = d.T0 + t;
+  uint8_t kind = b.kind[g];
+  if (kind == K_LIST_INS || kind == K_LIST_INS_VIS) put_item(b, d, g, t << 2);
+  uint32_t ev = d.ev_kind[t];
+  if (ev != EV_NONE) put_item(b, d, b.ref_row[g], t << 2 | (ev == EV_INSERT ? 0u : ev == EV_REMOVE ? 1u : 2u));
+}
+
+// the items of one element in time order: an item counts the earlier items IN FRONT of it, and those of its own element are
+// then all counted (kd_edit_index takes them out again)
+__global__ __launch_bounds__(BLOCK) void kd_items_sort(DeltaBufs d) {
+  uint32_t p = gtid();
+  if (p >= d.n_list) return;
+  uint32_t base = d.item_ex[p], c = d.item_ex[p + 1] - base;
+  for (uint32_t i = 1; i < c; i++) {
+    uint32_t tk = d.tk[0][base + i];
+    uint32_t j = i;
+    for (; j > 0 && d.tk[0][base + j - 1] > tk; j--) d.tk[0][base + j] = d.tk[0][base + j - 1];
+    d.tk[0][base + j] = tk;
   }
 }
 
@@ -250,8 +376,8 @@ __global__ __launch_bounds__(BLOCK) void kd_bit_flags(DeltaBufs d, int src, uint
   uint32_t z = 0, w = 0;
   if (i < m) {
     uint32_t tk = d.tk[src][i];
-    z = (((tk >> 1) >> bit) & 1u) ? 0u : 1u;
-    w = z ? ((tk & 1u) ? 0xffffffffu : 1u) : 0u;  // +1 insert, -1 remove
+    z = (((tk >> 2) >> bit) & 1u) ? 0u : 1u;
+    w = z ? ((tk & 3u) == 1u ? 0xffffffffu : (tk & 3u) == 0u ? 1u : 0u) : 0u;  // +1 insert, -1 remove, 0 update
   }
   d.zf[i] = z;
   d.zw[i] = w;
@@ -266,7 +392,7 @@ __global__ __launch_bounds__(BLOCK) void kd_partition(DeltaBufs d, int src, uint
   uint32_t tk = d.tk[src][i], lo = d.lo[src][i], hi = d.hi[src][i], acc = d.acc[src][i];
   uint32_t zl = d.zf_ex[lo], zi = d.zf_ex[i], nz = d.zf_ex[hi] - zl;
   uint32_t to, nlo, nhi;
-  if (((tk >> 1) >> bit) & 1u) {
+  if (((tk >> 2) >> bit) & 1u) {
     acc += d.zw_ex[i] - d.zw_ex[lo];
     to = lo + nz + ((i - lo) - (zi - zl));
     nlo = lo + nz; nhi = hi;
@@ -277,47 +403,119 @@ __global__ __launch_bounds__(BLOCK) void kd_partition(DeltaBufs d, int src, uint
   d.tk[dst][to] = tk; d.elem[dst][to] = d.elem[src][i]; d.acc[dst][to] = acc; d.lo[dst][to] = nlo; d.hi[dst][to] = nhi;
 }
 
-// items are now in (object, time) order: index of each edit, run detection (new.js:754-777)
+// items are now in (object, time) order: index of each edit
 __global__ __launch_bounds__(BLOCK) void kd_edit_index(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
   uint32_t i = gtid();
   if (i >= m) return;
   uint32_t tk = d.tk[src][i], e = d.elem[src][i];
+  uint32_t t = tk >> 2, g = d.T0 + t;
   uint32_t oi = obj_index_of(b, b.obj_row[e]);
-  uint32_t base = d.v0_ex[d.pos_of[e]] - d.v0_ex[b.obj_first_pos[oi]];
-  uint32_t idx = base + d.acc[src][i];
-  if ((tk & 1u) && e >= d.T0) idx -= 1;  // its own insertion sits at the same position and is not "in front"
+  uint32_t p = d.pos_of[e];
+  uint32_t idx = d.v0_ex[p] - d.v0_ex[b.obj_first_pos[oi]] + d.acc[src][i];
+  // the earlier items of its own element sit at the same position and are not "in front": together they moved the element from
+  // its visibility before the batch to its visibility just before this item
+  if (g != e) idx -= (d.ev_before[t] & 1u) - d.v0[p] + (d.ev_before[t] >> 1);  // (bit 1: the reference's index lag, kd_events)
   d.e_index[i] = idx;
 }
+
+// ---- the edits array (new.js:747-869), item by item -------------------------------------------------------------------------
+struct ItemView {
+  uint32_t k, e, g, t, oi, idx;
+  bool own_insert;  // the insert row of a new element (elemId == opId: the only items appendEdit can chain into a multi-insert)
+};
+__device__ __forceinline__ ItemView item_view(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t i) {
+  ItemView v;
+  uint32_t tk = d.tk[src][i];
+  v.k = tk & 3u; v.t = tk >> 2; v.e = d.elem[src][i]; v.g = d.T0 + v.t;
+  v.oi = obj_index_of(b, b.obj_row[v.e]);
+  v.idx = d.e_index[i];
+  v.own_insert = v.k == 0 && v.g == v.e;
+  return v;
+}
+// appendUpdate(firstUpdate) of a later call pops what the edits array ends with at the same index (new.js:800-818): an item is
+// taken away again when the next item of its object is an update at its index and it is itself an insert or an update
+__device__ __forceinline__ bool item_popped(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t i, uint32_t m, const ItemView& v) {
+  if (v.k == 1 || i + 1 >= m) return false;
+  ItemView nx = item_view(b, d, src, i + 1);
+  return nx.oi == v.oi && nx.k == 2 && nx.idx == v.idx;
+}
+// does own-insert item i continue the multi-insert of item i - 1 (appendEdit, new.js:754-772)? bit 0: yes, bit 1: as a new record
+__device__ __forceinline__ uint32_t continues_multi_insert(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t i, const ItemView& v) {
+  if (!v.own_insert || i == 0) return 0;
+  const OpCols& o = b.ops;
+  ItemView pv = item_view(b, d, src, i - 1);
+  if (!pv.own_insert || pv.oi != v.oi) return 0;
+  uint32_t e = v.e, pe = pv.e;
+  bool child = (o.action[e] & 1) == 0, pchild = (o.action[pe] & 1) == 0;
+  if (child || pchild || o.id_actor[e] != o.id_actor[pe] || o.id_ctr[e] != o.id_ctr[pe] + 1 || value_class(o.val_tl[e]) != value_class(o.val_tl[pe]) ||
+      v.idx != pv.idx + 1)
+    return 0;
+  uint32_t tl = o.val_tl[e], ptl = o.val_tl[pe];
+  return (tl != ptl || o.val_off[e] != o.val_off[pe] + (ptl >> 4)) ? 3u : 1u;
+}
+
+constexpr uint32_t POP_WALK_MAX = 64;  // update items at one index in a row this stage walks back over (more: refused)
 
 __global__ __launch_bounds__(BLOCK) void kd_edit_runs(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
   uint32_t i = gtid();
   if (i > m) return;
-  if (i == m) { d.e_head[i] = 0; return; }
+  if (i == m) { d.e_head[i] = 0; d.e_val[i] = 0; return; }
   const OpCols& o = b.ops;
-  uint32_t tk = d.tk[src][i], e = d.elem[src][i];
-  uint32_t oi = obj_index_of(b, b.obj_row[e]);
-  bool rem = tk & 1u, child = !rem && (o.action[e] & 1) == 0;
-  uint32_t f = rem ? (uint32_t)AM355_EDIT_REMOVE : (child ? (uint32_t)AM355_EDIT_CHILD : 0u);
-  uint32_t prev_oi = NONE32, next_oi = NONE32;
-  if (i > 0) {
-    uint32_t ptk = d.tk[src][i - 1], pe = d.elem[src][i - 1];
-    prev_oi = obj_index_of(b, b.obj_row[pe]);
-    bool prem = ptk & 1u, pchild = !prem && (o.action[pe] & 1) == 0;
-    if (prev_oi == oi) {
-      if (rem && prem && d.e_index[i] == d.e_index[i - 1]) f |= 2u;
-      else if (!rem && !prem && !child && !pchild && o.id_actor[e] == o.id_actor[pe] && o.id_ctr[e] == o.id_ctr[pe] + 1 &&
-               value_class(o.val_tl[e]) == value_class(o.val_tl[pe]) && d.e_index[i] == d.e_index[i - 1] + 1) {
-        f |= 2u;
-        uint32_t tl = o.val_tl[e], ptl = o.val_tl[pe];
-        if (tl != ptl || o.val_off[e] != o.val_off[pe] + (ptl >> 4)) f |= 0x400u;  // a new record of the same multi-insert
+  ItemView v = item_view(b, d, src, i);
+  uint32_t f = 0, recs = 0, vals = 0;
+  uint32_t prev_oi = i > 0 ? item_view(b, d, src, i - 1).oi : NONE32;
+  uint32_t next_oi = i + 1 < m ? item_view(b, d, src, i + 1).oi : NONE32;
+  const bool popped = item_popped(b, d, src, i, m, v);
+  if (v.k == 1) {
+    f = AM355_EDIT_REMOVE;
+    bool joins = false;
+    if (i > 0) {
+      ItemView pv = item_view(b, d, src, i - 1);
+      joins = pv.oi == v.oi && pv.k == 1 && pv.idx == v.idx;  // (a popped item is followed by an update, never by a remove)
+    }
+    if (joins) f |= 2u;
+    recs = joins ? 0u : 1u;
+    vals = 1;
+  } else if (v.own_insert) {
+    if ((o.action[v.e] & 1) == 0) f |= AM355_EDIT_CHILD;
+    uint32_t c = continues_multi_insert(b, d, src, i, v);
+    if (c & 1u) f |= 2u;
+    if (c & 2u) f |= 0x400u;
+    if (popped) f |= 0x800u;
+    else {
+      recs = (!(c & 1u) || (c & 2u)) ? 1u : 0u;
+      vals = 1;
+      // the head of a two-value multi-insert whose second value a later update popped stays a multi-insert (new.js:812-814)
+      if (!(c & 1u) && i + 1 < m) {
+        ItemView nx = item_view(b, d, src, i + 1);
+        if (nx.oi == v.oi && (continues_multi_insert(b, d, src, i + 1, nx) & 1u) && item_popped(b, d, src, i + 1, m, nx)) f |= AM355_EDIT_MULTI;
       }
     }
+  } else {
+    // an update, or an element that comes back (insert with opId != elemId): one record per visible value
+    if (popped) f |= 0x800u;
+    else {
+      recs = vals = d.ev_nafter[v.t];
+      bool as_insert = v.k == 0;
+      if (v.k == 2) {
+        // what did the first appendUpdate of this call pop? every update item in front at this index, then at most one insert
+        uint32_t j = i, steps = 0;
+        while (j > 0 && steps <= POP_WALK_MAX) {
+          ItemView pv = item_view(b, d, src, j - 1);
+          if (pv.oi != v.oi || pv.idx != v.idx || pv.k == 1) break;
+          if (pv.k == 0) { as_insert = true; break; }
+          j--; steps++;
+        }
+        if (steps > POP_WALK_MAX) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
+      }
+      if (as_insert) f |= 0x1000u;
+    }
   }
-  if (i + 1 < m) next_oi = obj_index_of(b, b.obj_row[d.elem[src][i + 1]]);
-  if (oi != prev_oi) f |= 0x100u;
-  if (oi != next_oi) f |= 0x200u;
+  if (v.oi != prev_oi) f |= 0x100u;
+  if (v.oi != next_oi) f |= 0x200u;
   d.e_flags[i] = f;
-  d.e_head[i] = (!(f & 2u) || (f & 0x400u)) ? 1u : 0u;
+  d.e_head[i] = recs;
+  d.e_val[i] = vals;
 }
 
 __global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
@@ -325,24 +523,42 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, 
   if (i > m) return;
   if (i == m) {
     uint32_t n = d.e_head_ex[m];
-    d.edit[n] = am355_ir_edit{0, 0, 0, 0, 0, 0, m, 0, 0, 0};
+    d.edit[n] = am355_ir_edit{0, 0, 0, 0, 0, 0, d.e_val_ex[m], 0, 0, 0};
     d.counts->n_erecs = n;
     return;
   }
-  uint32_t f = d.e_flags[i], k = d.e_head_ex[i], e = d.elem[src][i];
   const OpCols& o = b.ops;
-  bool head = d.e_head[i] != 0;
-  if (head) {
-    uint32_t rf = f & (AM355_EDIT_REMOVE | AM355_EDIT_CHILD);
-    if ((f & 2u) && (f & 0x400u)) rf |= AM355_EDIT_CONT;
-    if (f & AM355_EDIT_REMOVE) d.edit[k] = am355_ir_edit{rf, d.e_index[i], 0, 0, 0, 0, i, 0, 0, 0};
-    else d.edit[k] = am355_ir_edit{rf, d.e_index[i], o.id_ctr[e], o.id_actor[e], o.id_ctr[e], o.id_actor[e], i, o.val_tl[e], (f & AM355_EDIT_CHILD) ? b.obj_index[e] : o.val_off[e], 0};
+  ItemView v = item_view(b, d, src, i);
+  uint32_t f = d.e_flags[i], k = d.e_head_ex[i], first = d.e_val_ex[i], recs = d.e_head[i];
+  uint32_t e = v.e;
+  if (recs) {
+    if (f & AM355_EDIT_REMOVE) d.edit[k] = am355_ir_edit{AM355_EDIT_REMOVE, v.idx, 0, 0, 0, 0, first, 0, 0, 0};
+    else if (v.own_insert) {
+      uint32_t rf = f & (AM355_EDIT_CHILD | AM355_EDIT_MULTI);
+      if ((f & 2u) && (f & 0x400u)) rf |= AM355_EDIT_CONT;
+      d.edit[k] = am355_ir_edit{rf, v.idx, o.id_ctr[e], o.id_actor[e], o.id_ctr[e], o.id_actor[e], first, o.val_tl[e], (f & AM355_EDIT_CHILD) ? b.obj_index[e] : o.val_off[e], 0};
+    } else {
+      // the element's visible values after row g, ascending by op id
+      const uint32_t nu = d.upd_n[e], base = d.upd_off[e];
+      unsigned long long last = 0;
+      for (uint32_t j = 0; j < recs; j++) {
+        unsigned long long best = ~0ull;
+        uint32_t best_r = NONE32;
+        for (uint32_t q = 0; q <= nu; q++) {
+          uint32_t r = q == 0 ? e : d.upd_rows[base + q - 1];
+          if (r > v.g || !alive_at_T0(b, d, r) || d.first_del[r] <= v.g) continue;
+          unsigned long long id = pack_id(o.id_ctr[r], o.id_actor[r]);
+          if (id > last && id < best) { best = id; best_r = r; }
+        }
+        if (best_r == NONE32) { atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED); break; }
+        last = best;
+        uint32_t rf = (j == 0 && (f & 0x1000u)) ? 0u : (uint32_t)AM355_EDIT_UPDATE;
+        d.edit[k + j] = am355_ir_edit{rf, v.idx, o.id_ctr[best_r], o.id_actor[best_r], o.id_ctr[e], o.id_actor[e], first + j, o.val_tl[best_r], o.val_off[best_r], 0};
+      }
+    }
   }
-  if (f & 0x300u) {
-    uint32_t oi = obj_index_of(b, b.obj_row[e]);
-    if (f & 0x100u) d.link[oi].edit_begin = k;
-    if (f & 0x200u) d.link[oi].edit_end = k + (head ? 1u : 0u);
-  }
+  if (f & 0x100u) d.link[v.oi].edit_begin = k;
+  if (f & 0x200u) d.link[v.oi].edit_end = d.e_head_ex[i + 1];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -481,7 +697,9 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   (void)hipMemsetAsync(d.counts, 0, sizeof(DeltaCounts), st);
   (void)hipMemsetAsync(d.first_del, 0xff, 4 * ((size_t)N + 1), st);
   (void)hipMemsetAsync(d.new_succ, 0, 4 * ((size_t)N + 1), st);
-  (void)hipMemsetAsync(d.has_upd, 0, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(d.upd_n, 0, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(d.upd_cur, 0, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(d.icur, 0, 4 * ((size_t)d.n_list + 2), st);
   (void)hipMemsetAsync(d.slot_rep, 0, 4 * ((size_t)cap + 1), st);
   (void)hipMemsetAsync(d.slot_first, 0xff, 4 * ((size_t)cap + 1), st);
   (void)hipMemsetAsync(d.slot_last, 0, 4 * ((size_t)cap + 1), st);
@@ -506,12 +724,17 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     }
     fprintf(stderr, "delta_run: order[0..%u): %u entries out of range; first %u %u %u\n", d.n_list, bad, d.n_list ? ord[0] : 0, d.n_list > 1 ? ord[1] : 0, d.n_list > 2 ? ord[2] : 0);
   }
-  // ---- lists: items in position order ----
+  // ---- lists: the assignment rows of every element; items in position order ----
+  exclusive_scan_u32(d.upd_n, d.upd_off, N + 1, nullptr, d.scan_ws, st);
+  if (N) AM355_LAUNCH_INDEPENDENT(kd_upd_scatter, dgrid(N), dim3(BLOCK), st, b, d);
   AM355_LAUNCH_INDEPENDENT(kd_positions, dgrid(d.n_list + 1), dim3(BLOCK), st, b, d);
   step("positions");
+  if (d.n_new) AM355_LAUNCH_INDEPENDENT(kd_events, dgrid(d.n_new), dim3(BLOCK), st, b, d);
+  step("events");
   exclusive_scan2_u32(d.v0, d.v0_ex, nullptr, d.icnt, d.item_ex, nullptr, d.n_list + 1, d.scan_ws, st);
   step("scan positions");
-  if (d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items, dgrid(d.n_list), dim3(BLOCK), st, b, d);
+  if (d.n_new && d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items, dgrid(d.n_new), dim3(BLOCK), st, b, d);
+  if (d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items_sort, dgrid(d.n_list), dim3(BLOCK), st, d);
   step("items");
   // ---- maps: touched keys, kept records, placeholders ----
   AM355_LAUNCH_INDEPENDENT(kd_slots, dgrid(cap), dim3(BLOCK), st, b, d);
@@ -543,7 +766,7 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     AM355_LAUNCH_INDEPENDENT(kd_edit_index, dgrid(m), dim3(BLOCK), st, b, d, cur, m);
   }
   AM355_LAUNCH_INDEPENDENT(kd_edit_runs, dgrid(m + 1), dim3(BLOCK), st, b, d, cur, m);
-  exclusive_scan_u32(d.e_head, d.e_head_ex, m + 1, nullptr, d.scan_ws, st);
+  exclusive_scan2_u32(d.e_head, d.e_head_ex, nullptr, d.e_val, d.e_val_ex, nullptr, m + 1, d.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(kd_edit_pack, dgrid(m + 1), dim3(BLOCK), st, b, d, cur, m);
 
   // ---- map records in patch order ----

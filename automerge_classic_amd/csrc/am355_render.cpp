@@ -275,7 +275,7 @@ struct R {
       if (ed.flags & AM355_EDIT_REMOVE) {  // incremental patch (new.js:1029, 775-777)
         snprintf(t, sizeof t, "{\"action\":\"remove\",\"index\":%u,\"count\":%u}", ed.index, count);
         out += t;
-      } else if (count >= 2 || j > i + 1) {
+      } else if (count >= 2 || j > i + 1 || (ed.flags & AM355_EDIT_MULTI)) {
         snprintf(t, sizeof t, "{\"action\":\"multi-insert\",\"index\":%u,\"elemId\":", ed.index);
         out += t;
         if (!op_id(ed.elem_ctr, ed.elem_actor)) return false;

@@ -11,7 +11,7 @@
 'use strict'
 
 const OBJ_WORDS = 8, MAP_WORDS = 10, EDIT_WORDS = 10
-const MAP_COUNTER = 1, MAP_CHILD = 2, MAP_EMPTY = 4, EDIT_UPDATE = 1, EDIT_CONT = 2, EDIT_CHILD = 4, EDIT_REMOVE = 8
+const MAP_COUNTER = 1, MAP_CHILD = 2, MAP_EMPTY = 4, EDIT_UPDATE = 1, EDIT_CONT = 2, EDIT_CHILD = 4, EDIT_REMOVE = 8, EDIT_MULTI = 16
 const TYPE_NAME = { 0: 'map', 2: 'list', 4: 'text', 6: 'table' }
 const HEX = []
 for (let i = 0; i < 256; i++) HEX.push((i < 16 ? '0' : '') + i.toString(16))
@@ -150,7 +150,7 @@ class Materializer {
       while (j < end && (e[j * EDIT_WORDS] & EDIT_CONT)) j++   // further records of the same multi-insert (its values change length)
       if (flags & EDIT_REMOVE) {
         out.push({ action: 'remove', index, count })   // incremental patch (new.js:1029, 775-777)
-      } else if (count >= 2 || j > k + 1) {
+      } else if (count >= 2 || j > k + 1 || (flags & EDIT_MULTI)) {   // (EDIT_MULTI: a multi-insert that lost its second value, new.js:812-814)
         let values
         if (j === k + 1 && (tl & 15) === 6 && (tl >>> 4) === 1) {
           // the common record: a run of typed single-byte characters, back to back in the arena

@@ -16,7 +16,7 @@ const file = process.argv[2] || path.join(__dirname, '..', '..', 'tests', 'golde
 const maxChain = parseInt(process.argv[3] || '40'), maxSessions = parseInt(process.argv[4] || '1000000')
 const d = JSON.parse(zlib.gunzipSync(fs.readFileSync(file)).toString('utf8'))
 const pool = d.pool.map(x => new Uint8Array(Buffer.from(x, 'base64')))
-const V = d.vectors
+const V = d.vectors || []
 const ctx = addon.create(parseInt(process.env.MI355X_DEVICE || '0'))
 
 function samePatch(got, want) {
@@ -31,9 +31,36 @@ function samePatch(got, want) {
   return true
 }
 
-const hasChild = new Set(V.map(v => v.parent))
 let equal = 0, refused = 0, rejected = 0, failed = 0, sessions = 0
 const checked = new Set()
+if (d.sessions) {
+  // campaign files (oracle/make_apply_campaign.py): {pool, sessions: [{name, calls: [[pool index...]...], patches: [JSON text | {error}]}]}
+  for (const s of d.sessions) {
+    if (sessions >= maxSessions) break
+    sessions++
+    addon.reset(ctx)
+    for (let ci = 0; ci < s.calls.length && ci < s.patches.length; ci++) {
+      const id = s.name + '/' + ci
+      checked.add(id)
+      let patch
+      try {
+        addon.applyChanges(ctx, s.calls[ci].map(k => pool[k]))
+        patch = materialize(addon.fetchApplyIR(ctx))
+      } catch (e) {
+        if (e.am355Code === -4) { refused++; break }
+        if (e.am355Code === -3) { if (typeof s.patches[ci] === 'string') { failed++; console.error(`FAIL ${id}: rejected a batch the reference accepts: ${e.message}`) } else rejected++; break }
+        throw e
+      }
+      if (typeof s.patches[ci] !== 'string') { failed++; console.error(`FAIL ${id}: accepted a batch the reference rejects`); break }
+      if (!samePatch(patch, JSON.parse(s.patches[ci]))) { failed++; console.error(`FAIL ${id}: patch differs`); break }
+      equal++
+    }
+  }
+  addon.destroy(ctx)
+  console.log(JSON.stringify({ sessions, calls: checked.size, equal, refused, rejected, failed }))
+  process.exit(failed ? 1 : 0)
+}
+const hasChild = new Set(V.map(v => v.parent))
 for (let leaf = 0; leaf < V.length && sessions < maxSessions; leaf++) {
   if (hasChild.has(leaf)) continue
   const chain = []

@@ -170,7 +170,9 @@ typedef struct {
   int64_t counter;                /* AM355_MAP_COUNTER: the counter's total (new.js:937-967) */
 } am355_ir_map;
 enum { AM355_EDIT_UPDATE = 1u, AM355_EDIT_CONT = 2u, AM355_EDIT_CHILD = 4u,
-       AM355_EDIT_REMOVE = 8u  /* incremental patches only: `remove` edit of count = next record's first - first elements (new.js:775-777, 1029) */ };
+       AM355_EDIT_REMOVE = 8u, /* incremental patches only: `remove` edit of count = next record's first - first elements (new.js:775-777, 1029) */
+       AM355_EDIT_MULTI = 16u  /* incremental patches only: a `multi-insert` edit even with one value left (appendUpdate took the last
+                                  value of a two-value multi-insert away, new.js:812-814; the reference keeps the edit's action) */ };
 typedef struct {
   uint32_t flags;                 /* AM355_EDIT_UPDATE: `update` edit (else insert / multi-insert); AM355_EDIT_CHILD: the value is an object;
                                      AM355_EDIT_CONT: more values of the previous record's multi-insert */

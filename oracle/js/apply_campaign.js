@@ -4,7 +4,8 @@
 // call's patch recorded.  One JSON line per session: {name, calls: [[base64 change...]...], patches: [JSON text | {error}]}.
 //
 //   NODE_PATH=oracle/js_shims/node_modules [REF_BLOCK_SIZE=100000000] node oracle/js/apply_campaign.js out.jsonl SPEC...
-//   SPEC = seed:actors:steps:depth (mixed document) | t:seed:actors:rounds:burst (text) | m:seed:actors:steps:depth (see servedScenario);
+//   SPEC = seed:actors:steps:depth (mixed document) | t:seed:actors:rounds:burst (text) | m:seed:actors:steps:depth (see servedScenario)
+//        | l:seed:actors:steps:p2 (see listScenario);
 //   every SPEC yields 3 sessions
 const fs = require('fs')
 const { splitmix, frontendScenario, textScenario, Backend } = require('./make_golden.js')
@@ -83,12 +84,45 @@ function servedScenario(seed, nActors, steps, depthLimit) {
   for (let i = 0; i < nActors; i++) all = Automerge.merge(all, docs[i])
   return Automerge.getAllChanges(all)
 }
+// "l:" scenarios: lists of plain values whose ELEMENTS ARE ASSIGNED TO (`list[i] = v`) besides growing and shrinking, by several
+// actors that merge at random: concurrent assignments (several visible values per element), assignment against deletion (the element
+// comes back), assignments to elements inserted by the same batch. Most changes hold one op (p2 = probability of a second op).
+function listScenario(seed, nActors, steps, p2pct) {
+  const rnd = splitmix(seed)
+  const pick = arr => arr[Math.floor(rnd() * arr.length)]
+  const ids = []
+  for (let i = 0; i < nActors; i++) { let a = 'abcdef'[Math.floor(rnd() * 6)]; while (a.length < 32) a += '0123456789abcdef'[Math.floor(rnd() * 16)]; ids.push(a) }
+  let docs = ids.map(id => Automerge.init(id))
+  docs[0] = Automerge.change(docs[0], d => { d.list = ['a', 'b', 'c', 'd']; d.nums = [1, 2, 3]; d.text = new Automerge.Text('hey'); d.k = 0 })
+  for (let i = 1; i < nActors; i++) docs[i] = Automerge.merge(docs[i], docs[0])
+  const scalar = () => { const r = rnd(); return r < 0.4 ? Math.floor(rnd() * 100) : r < 0.5 ? pick([true, null]) : r < 0.6 ? rnd() * 10 : 'v' + Math.floor(rnd() * 1000) }
+  const oneOp = d => {
+    const r0 = rnd()
+    if (r0 < 0.08) { d.k = Math.floor(rnd() * 50); return }
+    if (r0 < 0.2) { const t = d.text; if (t.length > 0 && rnd() < 0.4) t.deleteAt(Math.floor(rnd() * t.length)); else t.insertAt(Math.floor(rnd() * (t.length + 1)), pick(['x', 'y', 'z'])); return }
+    const l = rnd() < 0.7 ? d.list : d.nums
+    const r = rnd()
+    if (l.length > 0 && r < 0.45) l[Math.floor(rnd() * l.length)] = scalar()
+    else if (l.length > 0 && r < 0.65) l.splice(Math.floor(rnd() * l.length), 1 + (rnd() < 0.2 && l.length > 2 ? 1 : 0))
+    else l.splice(Math.floor(rnd() * (l.length + 1)), 0, ...(rnd() < 0.3 ? [scalar(), scalar()] : [scalar()]))
+  }
+  for (let s = 0; s < steps; s++) {
+    const a = Math.floor(rnd() * nActors)
+    try {
+      docs[a] = Automerge.change(docs[a], d => { oneOp(d); if (rnd() * 100 < p2pct) oneOp(d) })
+    } catch (e) { /* the frontend refused this edit */ }
+    if (rnd() < 0.3) { const b = Math.floor(rnd() * nActors); if (b !== a) docs[b] = Automerge.merge(docs[b], docs[a]) }
+  }
+  let all = Automerge.init()
+  for (let i = 0; i < nActors; i++) all = Automerge.merge(all, docs[i])
+  return Automerge.getAllChanges(all)
+}
 const b64 = u8 => Buffer.from(u8.buffer, u8.byteOffset, u8.byteLength).toString('base64')
 const lines = []
 for (const spec of process.argv.slice(3)) {
   const f = spec.split(':')
-  const changes = f[0] === 't' ? textScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'm' ? servedScenario(+f[1], +f[2], +f[3], +f[4]) : frontendScenario(+f[0], +f[1], +f[2], +f[3])
-  const rnd = splitmix(0xABCD + (f[0] === 't' || f[0] === 'm' ? +f[1] : +f[0]))
+  const changes = f[0] === 't' ? textScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'm' ? servedScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'l' ? listScenario(+f[1], +f[2], +f[3], +f[4]) : frontendScenario(+f[0], +f[1], +f[2], +f[3])
+  const rnd = splitmix(0xABCD + (f[0] === 't' || f[0] === 'm' || f[0] === 'l' ? +f[1] : +f[0]))
   for (let variant = 0; variant < 3; variant++) {
     let order = changes.slice()
     if (variant === 2) {

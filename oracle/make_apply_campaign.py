@@ -15,14 +15,16 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SPECS = ["m:11:3:120:2", "m:12:4:160:3", "m:15:2:100:3", "m:16:6:140:2", "t:13:4:4:16", "t:14:6:3:24", "t:17:3:8:10", "21:3:70:2"]
+# lists whose elements are assigned to (apply_campaign.js listScenario) -> tests/golden/apply_campaign_lists.json.gz
+LIST_SPECS = ["l:31:2:60:0", "l:32:3:90:0", "l:33:4:120:0", "l:34:3:100:10", "l:35:5:150:0", "l:36:2:80:25"]
 
 
-def main():
+def main(specs=SPECS, name="apply_campaign.json.gz"):
     env = dict(os.environ, NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"))
     env.pop("REF_BLOCK_SIZE", None)
     with tempfile.TemporaryDirectory() as tmp:
         raw = os.path.join(tmp, "c.jsonl")
-        subprocess.check_call(["node", os.path.join(ROOT, "oracle", "js", "apply_campaign.js"), raw] + SPECS, env=env)
+        subprocess.check_call(["node", os.path.join(ROOT, "oracle", "js", "apply_campaign.js"), raw] + specs, env=env)
         pool, plist, sessions = {}, [], []
         for line in open(raw):
             d = json.loads(line)
@@ -36,9 +38,9 @@ def main():
                     idx.append(pool[c])
                 calls.append(idx)
             sessions.append({"name": d["name"], "calls": calls, "patches": d["patches"]})
-    blob = json.dumps({"made_by": "oracle/make_apply_campaign.py: oracle/js/apply_campaign.js " + " ".join(SPECS) + " on the unmodified reference",
+    blob = json.dumps({"made_by": "oracle/make_apply_campaign.py: oracle/js/apply_campaign.js " + " ".join(specs) + " on the unmodified reference",
                        "pool": plist, "sessions": sessions}).encode()
-    out = os.path.join(ROOT, "tests", "golden", "apply_campaign.json.gz")
+    out = os.path.join(ROOT, "tests", "golden", name)
     with open(out, "wb") as f:
         f.write(gzip.compress(blob, 9, mtime=0))
     print(f"{len(sessions)} sessions, {sum(len(s['calls']) for s in sessions)} calls, {len(plist)} changes -> {out} ({os.path.getsize(out)} bytes)")
@@ -46,3 +48,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main(LIST_SPECS, "apply_campaign_lists.json.gz")

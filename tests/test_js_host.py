@@ -115,6 +115,12 @@ def test_js_host_materialises_incremental_patches_emulated():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["failed"] == 0 and res["equal"] >= 100
+    # lists whose elements are assigned to (update edits, re-insertions, the multi-insert that keeps one value): six sessions
+    out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js"), os.path.join(ROOT, "tests", "golden", "apply_campaign_lists.json.gz"), "0", "6"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["refused"] == 0 and res["equal"] >= 60
 
 
 @pytest.mark.gpu
@@ -127,6 +133,11 @@ def test_js_host_reproduces_the_incremental_patches_of_the_reference_suites_on_g
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["failed"] == 0 and res["equal"] >= 800 and res["rejected"] >= 3
+    out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js"), os.path.join(ROOT, "tests", "golden", "apply_campaign_lists.json.gz")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["refused"] == 0 and res["equal"] == 412
 
 
 @pytest.mark.gpu
