@@ -2212,7 +2212,14 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   if (rc) return rc;
   lap("delta stage");
   c->state_checked = true;  // (a call the engine served: checked; a refused call leaves the state to the JS path)
-  if (hc.flags) { c->state_checked = false; return error_for_flags(c, hc.flags, "incremental patch not served"); }
+  if (hc.flags) {
+    c->state_checked = false;
+    if ((hc.flags & AM355_F_UNSUPPORTED) && hc.reason != NONE32) {
+      c->flags |= hc.flags;
+      return fail(c, AM355_E_UNSUPPORTED, "incremental patch not served: %s (JS path)", delta_reason_text(hc.reason));
+    }
+    return error_for_flags(c, hc.flags, "incremental patch not served");
+  }
 
   // ---- tables to the host, setupPatches, assembly ----
   rc = fetch_ir_impl(c, nullptr);

@@ -31,8 +31,22 @@ struct DeltaCounts {
   uint32_t n_erecs;    // delta edit records
   uint32_t n_slots;    // touched map keys
   uint32_t hazard;     // a key that holds a visible child object lost values to the merge loop's skipping rule (see kd_placeholders)
-  uint32_t pad;
+  uint32_t reason;     // DR_*: why the call is refused (the smallest code raised), NONE32: not refused by this stage
 };
+enum : uint32_t {
+  DR_FOREIGN_ROW = 1,     // a row of an object another shard owns
+  DR_KEY_TABLE,           // touched-key table full
+  DR_ELEM_ROWS,           // more value rows on a touched list element than the stage walks
+  DR_ELEM_NOT_PLAIN,      // an assigned list element holds child objects or counters
+  DR_SAME_ELEM_CALL,      // two ops on one element in one merge call
+  DR_GAP_WALK,            // too many later insertions between two elements of one merge call
+  DR_LAGGING_UPDATE,      // the first update edit of a conflict would sit at the reference's lagging index
+  DR_POP_WALK,            // too many update edits at one index in a row
+  DR_AMBIGUOUS_DEL,       // a deletion whose place in the merge loop's work list is ambiguous
+  DR_CHILD_HAZARD,        // values skipped on a key that holds a child object
+  DR_INTERNAL
+};
+const char* delta_reason_text(uint32_t reason);
 
 // Device memory of the delta stage, carved by the caller (delta_bytes / delta_bind). N = op rows, NN = new rows, NM = map records
 // of the whole-document IR, NO = objects.

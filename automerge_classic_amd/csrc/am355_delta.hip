@@ -39,6 +39,12 @@
 
 namespace am355 {
 
+// why a call is refused (DeltaCounts.reason keeps the smallest code raised: the host names it in the error text)
+__device__ __forceinline__ uint32_t refuse(const DeltaBufs& d, uint32_t reason) {
+  atomicMin(&d.counts->reason, reason);
+  return (uint32_t)F_UNSUPPORTED;
+}
+
 static inline dim3 dgrid(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -189,11 +195,11 @@ __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
   if (g < d.T0) return;
   const OpCols& o = b.ops;
   uint32_t err = 0;
-  if (kind == K_FOREIGN) err |= F_UNSUPPORTED;
+  if (kind == K_FOREIGN) err |= refuse(d, DR_FOREIGN_ROW);
   if (kind != K_NONE && kind != K_FOREIGN) {
     if (kind == K_MAP || (kind == K_DEL && o.key_len[g] != NONE32)) {
       uint32_t s = key_slot(b, d, g, true);
-      if (s == NONE32) err |= F_UNSUPPORTED;
+      if (s == NONE32) err |= refuse(d, DR_KEY_TABLE);
       else { atomicMin(&d.slot_first[s], g); atomicMax(&d.slot_last[s], g); }
     } else if (kind == K_DEL || kind == K_LIST_UPD) {
       // every value row this op overwrites or deletes: how many rows of the batch do so, and which is the first
@@ -290,14 +296,14 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
     const OpCols& o = b.ops;
     uint32_t e = b.ref_row[g];
     const uint32_t nu = d.upd_n[e];
-    if (nu > ELEM_ROWS_MAX) err |= F_UNSUPPORTED;
+    if (nu > ELEM_ROWS_MAX) err |= refuse(d, DR_ELEM_ROWS);
     else {
       elem_state(b, d, e, g, before, after);
       ev = before ? (after ? EV_UPDATE : EV_REMOVE) : (after ? EV_INSERT : EV_NONE);
       if (nu > 0) {  // (the element holds assignment rows, old or new)
         bool plain = o.action[e] == 1;
         for (uint32_t k = 0; k < nu; k++) plain = plain && o.action[d.upd_rows[d.upd_off[e] + k]] == 1;
-        if (!plain) err |= F_UNSUPPORTED;  // child objects / counters among the values: objectMeta bookkeeping, counter states
+        if (!plain) err |= refuse(d, DR_ELEM_NOT_PLAIN);  // child objects / counters among the values: objectMeta bookkeeping, counter states
       }
       // ---- does the op continue the merge call of the previous op of the stream? ----
       bool first_of_pass = g == d.T0;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
           bool overwrites = false;
           for (uint32_t k = 0; k < o.pred_num[g]; k++)
             overwrites = overwrites || (o.pred_ctr[o.pred_first[g] + k] == o.id_ctr[g - 1] && o.pred_actor[o.pred_first[g] + k] == o.id_actor[g - 1]);
-          if (!overwrites) err |= F_UNSUPPORTED;
+          if (!overwrites) err |= refuse(d, DR_SAME_ELEM_CALL);
         } else if (d.upd_n[a] <= ELEM_ROWS_MAX) {
           uint32_t a_before, a_after;
           elem_state(b, d, a, g - 1, a_before, a_after);
@@ -318,14 +324,14 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
             // was e the element right behind a when the op was applied? (elements inserted later may stand between them now)
             uint32_t pa = d.pos_of[a], pe = d.pos_of[e];
             bool neighbours = pe > pa;
-            if (neighbours && pe - pa - 1 > GAP_WALK_MAX) { neighbours = false; err |= F_UNSUPPORTED; }
+            if (neighbours && pe - pa - 1 > GAP_WALK_MAX) { neighbours = false; err |= refuse(d, DR_GAP_WALK); }
             for (uint32_t q = pa + 1; neighbours && q < pe; q++) neighbours = b.order[q] > g;
             if (neighbours) {
               if (ev == EV_REMOVE) lag = 1;
-              else if (d.first_del[e] > g) err |= F_UNSUPPORTED;  // the insert row's value stays: its update edit alone would lag
+              else if (d.first_del[e] > g) err |= refuse(d, DR_LAGGING_UPDATE);  // the insert row's value stays: its update edit alone would lag
             }
           }
-        } else err |= F_UNSUPPORTED;
+        } else err |= refuse(d, DR_ELEM_ROWS);
       }
       if (ev != EV_NONE) atomicAdd(&d.icnt[d.pos_of[e]], 1u);
     }
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_runs(MergeBufs b, DeltaBufs d, 
           if (pv.k == 0) { as_insert = true; break; }
           j--; steps++;
         }
-        if (steps > POP_WALK_MAX) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
+        if (steps > POP_WALK_MAX) atomicOr(&d.counts->flags, refuse(d, DR_POP_WALK));
       }
       if (as_insert) f |= 0x1000u;
     }
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, 
           unsigned long long id = pack_id(o.id_ctr[r], o.id_actor[r]);
           if (id > last && id < best) { best = id; best_r = r; }
         }
-        if (best_r == NONE32) { atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED); break; }
+        if (best_r == NONE32) { atomicOr(&d.counts->flags, refuse(d, DR_INTERNAL)); break; }
         last = best;
         uint32_t rf = (j == 0 && (f & 0x1000u)) ? 0u : (uint32_t)AM355_EDIT_UPDATE;
         d.edit[k + j] = am355_ir_edit{rf, v.idx, o.id_ctr[best_r], o.id_actor[best_r], o.id_ctr[e], o.id_actor[e], first + j, o.val_tl[best_r], o.val_off[best_r], 0};
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(BLOCK) void kd_slots(MergeBufs b, DeltaBufs d) {
         key_less_utf16(b, j, nx))
       cont = 1;
   }
-  if (cont && ambiguous) atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED);
+  if (cont && ambiguous) atomicOr(&d.counts->flags, refuse(d, DR_AMBIGUOUS_DEL));
   d.slot_cont[s] = cont;
 }
 
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(BLOCK) void kd_placeholders(DeltaBufs d) {
     pl = d.slot_cnt[s] == 0 ? 1u : 0u;
     // values were skipped on a key that holds a child object: objectMeta.children of the reference now lacks them, which later
     // patches would show (new.js:916-931) -- a state this engine does not carry
-    if (d.slot_child[s] && d.slot_drop[s]) { d.counts->hazard = 1; atomicOr(&d.counts->flags, (uint32_t)F_UNSUPPORTED); }
+    if (d.slot_child[s] && d.slot_drop[s]) { d.counts->hazard = 1; atomicOr(&d.counts->flags, refuse(d, DR_CHILD_HAZARD)); }
   }
   d.place[s] = pl;
 }
@@ -680,6 +686,23 @@ __global__ __launch_bounds__(BLOCK) void kd_map_out(MergeBufs b, PatchIR ir, Del
   if (oi != next) d.link[oi].map_end = i + 1;
 }
 
+const char* delta_reason_text(uint32_t reason) {
+  switch (reason) {
+    case DR_FOREIGN_ROW: return "rows of objects another shard owns";
+    case DR_KEY_TABLE: return "touched-key table full";
+    case DR_ELEM_ROWS: return "a touched list element holds more value rows than the stage walks";
+    case DR_ELEM_NOT_PLAIN: return "an assigned list element holds child objects or counters";
+    case DR_SAME_ELEM_CALL: return "two ops on one list element in one merge call";
+    case DR_GAP_WALK: return "too many later insertions between two elements of one merge call";
+    case DR_LAGGING_UPDATE: return "the first update edit of a conflict would sit at the reference's lagging list index";
+    case DR_POP_WALK: return "too many update edits at one list index in a row";
+    case DR_AMBIGUOUS_DEL: return "a deletion whose place in the merge loop's work list is ambiguous";
+    case DR_CHILD_HAZARD: return "values skipped on a key that holds a child object";
+    case DR_INTERNAL: return "internal: visible values of an element not found";
+    default: return "outside the served subset";
+  }
+}
+
 static int dbits_for(uint64_t max_value) {
   int b = 1;
   while (b < 64 && (max_value >> b)) b++;
@@ -695,6 +718,7 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     fprintf(stderr, "delta_run: %-18s %s (N %u T0 %u new %u obj %u map %u list %u cap %u)\n", what, hipGetErrorString(e), N, d.T0, d.n_new, d.n_obj, d.n_map, d.n_list, cap);
   };
   (void)hipMemsetAsync(d.counts, 0, sizeof(DeltaCounts), st);
+  (void)hipMemsetAsync(&d.counts->reason, 0xff, 4, st);
   (void)hipMemsetAsync(d.first_del, 0xff, 4 * ((size_t)N + 1), st);
   (void)hipMemsetAsync(d.new_succ, 0, 4 * ((size_t)N + 1), st);
   (void)hipMemsetAsync(d.upd_n, 0, 4 * ((size_t)N + 1), st);
