@@ -2237,7 +2237,18 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   HIPCHK(c, hipMemcpyAsync(h_edit, d.edit, sizeof(am355_ir_edit) * ((size_t)n_dedits + 1), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   std::string err;
-  rc = assemble_apply_patch(c->hir, h_link, h_map, n_dmap, h_edit, n_dedits, c->apply, err);
+  std::unordered_map<uint32_t, uint8_t> known;
+  std::vector<uint32_t> need;
+  for (int round = 0;; round++) {
+    rc = assemble_apply_patch(c->hir, h_link, h_map, n_dmap, h_edit, n_dedits, known, need, c->apply, err);
+    if (rc != AM355_E_UNSUPPORTED || need.empty() || round == 16 || need.size() > 256) break;
+    // the walk met objects that are no longer visible: what the reference's objectMeta lists for their property follows from the
+    // history of the rows on it (am355_delta.hip, delta_key_history)
+    std::vector<uint8_t> st_of(need.size());
+    if (delta_key_history(c->mb, c->ir, d, need.data(), (uint32_t)need.size(), st_of.data(), st) != 0) return fail(c, AM355_E_DEVICE, "key history: %s", hipGetErrorString(hipGetLastError()));
+    for (size_t i = 0; i < need.size(); i++) known[need[i]] = st_of[i];
+    lap("property histories");
+  }
   if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; return fail(c, rc, "%s", err.c_str()); }
   c->apply_ready = true;
   c->apply_json.clear();

@@ -50,7 +50,8 @@ struct KeyRefHash {
 }  // namespace
 
 int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const am355_ir_map* d_map, uint32_t n_dmap, const am355_ir_edit* d_edits,
-                         uint32_t n_dedits, ApplyPatch& out, std::string& err) {
+                         uint32_t n_dedits, const std::unordered_map<uint32_t, uint8_t>& known, std::vector<uint32_t>& need, ApplyPatch& out, std::string& err) {
+  need.clear();
   const uint32_t NO = whole.n_objects;
   const uint8_t* arena = whole.arena;
   // ---- objectIds: the objects the batch touched, in the order it first touched them ----
@@ -77,7 +78,17 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
         // A property the batch itself touched is already in the patch with everything that is visible, and children[key] was
         // refreshed by that visit (or is empty): setupPatches adds nothing and stops here whatever became of the child. Otherwise
         // children[key] is what an earlier call left, which is the visible set only while the child is visible.
-        auto stale = [&]() {
+        // children[key] of a property that holds plain values only is what the last visit left: those values, or nothing for good
+        // (new.js:916-931) -- the device tells which from the rows on the property (delta_key_history). 0: go on, `dead` says how.
+        auto stale = [&](bool& dead) {
+          auto it = known.find(child);
+          if (it == known.end()) { need.push_back(child); dead = true; return AM355_OK; }  // (asked for; this pass goes on as if nothing were listed)
+          if (it->second == KH_DEAD) { dead = true; return AM355_OK; }
+          if (it->second == KH_LIVE) { dead = false; return AM355_OK; }
+          err = "unsupported: the batch edits an object that is no longer a visible value of its parent (objectMeta history)";
+          return AM355_E_UNSUPPORTED;
+        };
+        auto refuse_history = [&]() {
           err = "unsupported: the batch edits an object that is no longer a visible value of its parent (objectMeta history)";
           return AM355_E_UNSUPPORTED;
         };
@@ -123,9 +134,9 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
                 uint32_t count = whole.edits[r + 1].first - ed.first;
                 if (!(ed.flags & (AM355_EDIT_UPDATE | AM355_EDIT_CHILD)) && ed.elem_actor == L.elem_actor && L.elem_ctr >= ed.elem_ctr && L.elem_ctr - ed.elem_ctr < count + 0u) in_run = true;
               }
-              if (in_run) return stale();
+              if (in_run) return refuse_history();
               none_visible = true;
-            } else if (!any_child) return stale();
+            } else if (!any_child) { int rc = stale(none_visible); if (rc) return rc; }
             if (!none_visible) {
               auto& dst = extra_edits[o];
               dst.insert(dst.end(), vals.begin(), vals.end());
@@ -162,7 +173,7 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
             if (L.flags & OL_VISIBLE) {
               if (vals.empty()) { err = "internal: key of a visible child object not found in the document patch"; return AM355_E_DEVICE; }
             } else if (!any_value) none_visible = true;   // children[key] is empty whatever happened before
-            else if (!any_child) return stale();          // plain values only: children[key] lists them, or went empty once and stayed so
+            else if (!any_child) { int rc = stale(none_visible); if (rc) return rc; }  // plain values only: children[key] lists them, or went empty once and stayed so
             if (!none_visible) {
               auto& dst = extra_map[o];
               dst.insert(dst.end(), vals.begin(), vals.end());
@@ -180,6 +191,12 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
     }
   }
 
+  if (!need.empty()) {
+    std::sort(need.begin(), need.end());
+    need.erase(std::unique(need.begin(), need.end()), need.end());
+    err = "unsupported: the batch edits an object that is no longer a visible value of its parent (objectMeta history)";
+    return AM355_E_UNSUPPORTED;
+  }
   // ---- the record tables of the patch ----
   out.objects.assign(whole.objects, whole.objects + NO);
   out.map.clear();

@@ -100,4 +100,13 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t n_ops, uint32_t n_new, uint3
 // that one am355_load_changes + am355_replay built (T0 = 0: every row is "new"), before the first am355_apply_changes onto it.
 void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only = false);
 
+// What the reference's objectMeta holds in `children[key]` for the property (map key or list element) that holds -- or held -- each
+// of the given objects: the visible values, or nothing (KH_DEAD). It is refreshed only while it is non-empty or a child object is
+// visible (new.js:916-931), row by row of every merge call that visits the property: once a visit leaves it empty, later plain values
+// do not bring it back. One thread replays the visits of a property from the rows on it (their row numbers are the times). `objects`
+// (host, object indexes) -> `state` (host): KH_LIVE / KH_DEAD / KH_UNKNOWN (more rows than the walk takes, or a visit the walk does
+// not model). Synchronises `st`.
+enum : uint8_t { KH_UNKNOWN = 0, KH_LIVE = 1, KH_DEAD = 2 };
+int delta_key_history(MergeBufs& b, PatchIR& ir, DeltaBufs& d, const uint32_t* objects, uint32_t n, uint8_t* state, hipStream_t st);
+
 }  // namespace am355

@@ -805,4 +805,134 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   hc->n_items = m;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// objectMeta.children of a property, from the history of the rows on it (see am355_delta.h)
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t KH_ROWS_MAX = 96;
+
+// the property that holds object t: rows on the same map key of the same object, or on the same list element
+__global__ __launch_bounds__(BLOCK) void kh_collect(MergeBufs b, PatchIR ir, const uint32_t* __restrict__ targets, uint32_t n, uint32_t* __restrict__ lists,
+                                                    uint32_t* __restrict__ counts) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const OpCols& o = b.ops;
+  uint8_t kind = b.kind[g];
+  if (kind == K_NONE || kind == K_FOREIGN) return;
+  const bool map_op = kind == K_MAP || (kind == K_DEL && o.key_len[g] != NONE32);
+  for (uint32_t t = 0; t < n; t++) {
+    uint32_t m = ir.obj[targets[t]].make_row;
+    bool hit;
+    if (o.key_len[m] != NONE32) hit = map_op && b.obj_row[g] == b.obj_row[m] && same_key(b, g, m);
+    else {
+      uint32_t el = o.insert[m] ? m : b.ref_row[m];
+      hit = el != NONE32 && (g == el || (!map_op && !o.insert[g] && b.ref_row[g] == el));
+    }
+    if (hit) {
+      uint32_t k = atomicAdd(&counts[t], 1u);
+      if (k < KH_ROWS_MAX) lists[t * KH_ROWS_MAX + k] = g;
+    }
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, DeltaBufs d, const uint32_t* __restrict__ targets, uint32_t n,
+                                                    const uint32_t* __restrict__ lists, const uint32_t* __restrict__ counts, uint32_t* __restrict__ state) {
+  uint32_t t = gtid();
+  if (t >= n) return;
+  const OpCols& o = b.ops;
+  const uint32_t c = counts[t];
+  if (c > KH_ROWS_MAX) { state[t] = KH_UNKNOWN; return; }
+  const bool map_prop = o.key_len[ir.obj[targets[t]].make_row] != NONE32;
+  uint32_t rows[KH_ROWS_MAX], death[KH_ROWS_MAX], by_id[KH_ROWS_MAX];
+  for (uint32_t i = 0; i < c; i++) {  // ascending row number = time
+    uint32_t r = lists[t * KH_ROWS_MAX + i], j = i;
+    for (; j > 0 && rows[j - 1] > r; j--) rows[j] = rows[j - 1];
+    rows[j] = r;
+  }
+  for (uint32_t i = 0; i < c; i++) {  // ascending op id
+    unsigned long long id = pack_id(o.id_ctr[rows[i]], o.id_actor[rows[i]]);
+    uint32_t j = i;
+    for (; j > 0 && pack_id(o.id_ctr[rows[by_id[j - 1]]], o.id_actor[rows[by_id[j - 1]]]) > id; j--) by_id[j] = by_id[j - 1];
+    by_id[j] = i;
+    death[i] = NONE32;
+  }
+  for (uint32_t j = 0; j < c; j++) {  // first successor of every row
+    uint32_t g = rows[j];
+    for (uint32_t k = 0; k < o.pred_num[g]; k++) {
+      uint32_t pc = o.pred_ctr[o.pred_first[g] + k], pa = o.pred_actor[o.pred_first[g] + k];
+      for (uint32_t i = 0; i < j; i++)
+        if (o.id_ctr[rows[i]] == pc && o.id_actor[rows[i]] == pa && death[i] > g) death[i] = g;
+    }
+  }
+  bool empty = true, unknown = false;
+  for (uint32_t j = 0; j < c && !unknown; j++) {
+    const uint32_t g = rows[j];
+    const bool is_del = b.kind[g] == K_DEL;
+    if (!map_prop && o.insert[g] && j > 0) { unknown = true; break; }
+    // two ops of one actor on the property in a row share a merge call unless the second overwrites the first (new.js:1114-1121)
+    if (j + 1 < c && rows[j + 1] == g + 1 && o.id_actor[g + 1] == o.id_actor[g]) {
+      bool overwrites = false;
+      for (uint32_t k = 0; k < o.pred_num[g + 1]; k++)
+        overwrites = overwrites || (o.pred_ctr[o.pred_first[g + 1] + k] == o.id_ctr[g] && o.pred_actor[o.pred_first[g + 1] + k] == o.id_actor[g]);
+      if (!overwrites || is_del) { unknown = true; break; }
+    }
+    // a call that goes on to a greater key of the object leaves the rows above a threshold unvisited (see kd_slots)
+    bool cont = false;
+    unsigned long long thr = pack_id(o.id_ctr[g], o.id_actor[g]);
+    if (map_prop && g + 1 < b.n_ops) {
+      uint32_t nx = g + 1;
+      bool new_pass = false;
+      for (uint32_t k = 0; k < d.n_pass; k++) new_pass = new_pass || d.pass_rows[k] == nx;
+      uint8_t kn = b.kind[nx];
+      cont = !new_pass && (kn == K_MAP || kn == K_DEL) && o.key_len[nx] != NONE32 && !o.insert[nx] && o.id_actor[nx] == o.id_actor[g] && same_obj(b, nx, g) &&
+             key_less_utf16(b, g, nx);
+      if (cont && is_del) {
+        thr = 0;
+        for (uint32_t k = 0; k < o.pred_num[g]; k++) {
+          unsigned long long pid = pack_id(o.pred_ctr[o.pred_first[g] + k], o.pred_actor[o.pred_first[g] + k]);
+          thr = pid > thr ? pid : thr;
+        }
+      }
+    }
+    uint32_t nvals = 0;
+    bool has_child = false;
+    for (uint32_t q = 0; q < c; q++) {
+      const uint32_t i = by_id[q], r = rows[i];
+      if (r > g || b.kind[r] == K_DEL) continue;  // not there yet / a deletion leaves no row
+      if (cont && r != g && pack_id(o.id_ctr[r], o.id_actor[r]) > thr) {
+        // (whether an EARLIER call went on to the next row is not known -- a call of applyChanges or a scheduling pass may have ended
+        // between them --: it only matters when a row it would have skipped is visible)
+        if (g + 1 < d.T0 && death[i] > g) unknown = true;
+        continue;
+      }
+      if (r == g || death[i] > g) {
+        uint32_t a = o.action[r];
+        if ((a & 1u) == 0) has_child = true;
+        if (a == 1 || (a & 1u) == 0) nvals++;
+      }
+      if (has_child || !empty) empty = nvals == 0;
+    }
+  }
+  state[t] = unknown ? (uint32_t)KH_UNKNOWN : empty ? (uint32_t)KH_DEAD : (uint32_t)KH_LIVE;
+}
+
+int delta_key_history(MergeBufs& b, PatchIR& ir, DeltaBufs& d, const uint32_t* objects, uint32_t n, uint8_t* state, hipStream_t st) {
+  if (!n) return 0;
+  uint32_t* dev = nullptr;
+  const size_t words = (size_t)n * (KH_ROWS_MAX + 3);
+  if (hipMalloc((void**)&dev, 4 * words) != hipSuccess) return -1;
+  uint32_t *targets = dev, *counts = dev + n, *out = dev + 2 * (size_t)n, *lists = dev + 3 * (size_t)n;
+  (void)hipMemsetAsync(dev, 0, 4 * words, st);
+  (void)hipMemcpyAsync(targets, objects, 4 * (size_t)n, hipMemcpyHostToDevice, st);
+  (void)hipStreamSynchronize(st);  // (pageable source)
+  if (b.n_ops) AM355_LAUNCH_INDEPENDENT(kh_collect, dgrid(b.n_ops), dim3(BLOCK), st, b, ir, (const uint32_t*)targets, n, lists, counts);
+  AM355_LAUNCH_INDEPENDENT(kh_simulate, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), st, b, ir, d, (const uint32_t*)targets, n, (const uint32_t*)lists, (const uint32_t*)counts, out);
+  std::vector<uint32_t> h(n);
+  (void)hipMemcpyAsync(h.data(), out, 4 * (size_t)n, hipMemcpyDeviceToHost, st);
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return -1;
+  for (uint32_t i = 0; i < n; i++) state[i] = (uint8_t)h[i];
+  return 0;
+}
+
 }  // namespace am355

@@ -230,16 +230,25 @@ def test_apply_after_load_changes_and_queue_emulated(emu_lib):
 
 
 def test_unserved_batch_is_refused_emulated(emu_lib):
-    """A session of the mixed campaign (objects as list elements that are assigned to, counters in lists) ends in a refusal, not in a patch."""
+    """A batch outside the served subset (here: a deletion whose place in the merge loop's work list is ambiguous) ends in a refusal
+    that names the reason, not in a patch."""
     sessions, pool = load_campaign()
-    s = next(x for x in sessions if x["name"].startswith("21:"))
+    s = next(x for x in sessions if x["name"] == "m:16:6:140:2#1")
     eng = engine.Engine(0, emu_lib)
     try:
-        with pytest.raises(engine.UnsupportedChanges):
+        with pytest.raises(engine.UnsupportedChanges, match="work list is ambiguous"):
             for call in s["calls"]:
                 eng.apply_changes(ChangeLog.from_changes([pool[k] for k in call]))
     finally:
         eng.close()
+
+
+def test_edits_inside_objects_that_are_no_longer_visible_emulated(emu_lib):
+    """Nested documents whose objects are overwritten and deleted while other actors still edit them: setupPatches needs what the
+    reference's objectMeta.children holds for the parent property, which the device replays from the history of the rows on it
+    (delta_key_history). Three sessions of the campaign that this decides, served to the end."""
+    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), names={"m:11:3:120:2#0", "m:11:3:120:2#2", "21:3:70:2#0"})
+    assert equal == 54 + 14 + 37 and refused == 0
 
 
 def test_list_assignment_sessions_emulated(emu_lib):
@@ -263,7 +272,7 @@ def test_reference_suite_calls_gpu():
 @pytest.mark.gpu
 def test_campaign_sessions_gpu():
     equal, refused = run_campaign(lambda: engine.Engine(0))
-    assert equal >= 120
+    assert equal >= 300
 
 
 @pytest.mark.gpu
