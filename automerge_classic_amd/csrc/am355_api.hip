@@ -329,6 +329,13 @@ struct am355_ctx {
   std::vector<uint32_t> dep_first, dep_index;   // am355_get_dep_graph
   bool dep_graph_ready = false;
   DevBuf d_sync;                                // am355_sync_bloom_*: index list, filter bits, flags
+  // am355_apply_changes: where the op streams of the calls so far began (a call of applyChanges, a scheduling pass of one) -- the
+  // reference's merge calls never cross them --, whether that record is complete, and whether some call skipped values of a property
+  // that holds a child object (then objectMeta.children of the reference differs from the visible values: delta_key_history)
+  std::vector<uint32_t> stream_breaks;
+  bool breaks_exact = true, children_hazard = false, in_apply = false;
+  bool no_history = false;  // the staged changes are the rebuilt history of a LOADED document: the reference's objectMeta came from one pass over the document
+  DevBuf d_breaks;
   bool state_checked = false;  // the state was built by am355_apply_changes calls (each checked for what later patches depend on) or is empty
   std::string apply_json;
 
@@ -437,7 +444,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
-  c->d_delta.release(); c->d_pass.release(); c->h_delta.release(); c->d_sync.release();
+  c->d_delta.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta.release(); c->d_sync.release();
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
@@ -2013,6 +2020,12 @@ static int replay_impl(am355_ctx* c) {
   s.fast_path = fast ? 1 : 0;
   s.ms_total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
   c->replayed = true;
+  if (!c->in_apply) {  // (one call of Backend.loadChanges: its scheduling passes are the op streams)
+    c->stream_breaks = c->pass_first_row;
+    c->breaks_exact = true;
+    c->children_hazard = false;
+    c->no_history = false;
+  }
   return AM355_OK;
 }
 
@@ -2126,6 +2139,16 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   for (uint32_t r : c->pass_first_row) if (r > T0) pass_rows.push_back(r);
   d.n_pass = (uint32_t)pass_rows.size();
   d.pass_rows = c->d_pass.as<uint32_t>();
+  // every row at which an op stream began: those of the earlier calls, this call's first row, its later passes
+  std::vector<uint32_t> breaks;
+  for (uint32_t r : c->stream_breaks) if (r < T0) breaks.push_back(r);
+  if (T0) breaks.push_back(T0);
+  breaks.insert(breaks.end(), pass_rows.begin(), pass_rows.end());
+  if (!c->d_breaks.ensure(4 * (breaks.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
+  d.n_breaks = (uint32_t)breaks.size();
+  d.breaks = c->d_breaks.as<uint32_t>();
+  d.breaks_exact = c->breaks_exact ? 1u : 0u;
+  if (!breaks.empty()) HIPCHK(c, hipMemcpyAsync(c->d_breaks.p, breaks.data(), 4 * breaks.size(), hipMemcpyHostToDevice, st));
   if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));  // (pageable sources)
   delta_run(c->mb, c->ir, d, hc, st, check_only);
@@ -2156,7 +2179,7 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
     DeltaCounts pre{};
     int prc = run_delta_stage(c, 0, &pre, true);
     if (prc) return prc;
-    if (pre.hazard) { c->flags |= AM355_F_UNSUPPORTED; return fail(c, AM355_E_UNSUPPORTED, "the state holds a property whose child-object bookkeeping depends on how the reference merged it (JS path)"); }
+    if (pre.hazard) c->children_hazard = true;  // (from here on no property is taken to list its visible values without asking)
     c->state_checked = true;
   }
   // ---- the queue of the call: changes applied so far (application order) | the batch | changes still queued (new.js:1822) ----
@@ -2194,7 +2217,10 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   }
   if (rc) { c->staged = false; return rc; }
   lap("staged");
+  if (!have_state) { c->stream_breaks.clear(); c->breaks_exact = true; c->children_hazard = false; c->no_history = false; }
+  c->in_apply = true;
   rc = replay_impl(c);
+  c->in_apply = false;
   if (rc) { c->staged = false; return rc; }
   lap("replayed");
   // the earlier changes must have been applied again, first and in their order: rows [0, old_ops) are the state before the call
@@ -2237,19 +2263,24 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   HIPCHK(c, hipMemcpyAsync(h_edit, d.edit, sizeof(am355_ir_edit) * ((size_t)n_dedits + 1), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   std::string err;
-  std::unordered_map<uint32_t, uint8_t> known;
+  std::unordered_map<uint32_t, KeyHistory> known;
   std::vector<uint32_t> need;
+  const bool ask_always = c->children_hazard;
+  if (hc.hazard) c->children_hazard = true;  // (this call skipped values of a property with a child object: later calls ask)
   for (int round = 0;; round++) {
-    rc = assemble_apply_patch(c->hir, h_link, h_map, n_dmap, h_edit, n_dedits, known, need, c->apply, err);
-    if (rc != AM355_E_UNSUPPORTED || need.empty() || round == 16 || need.size() > 256) break;
+    rc = assemble_apply_patch(c->hir, h_link, h_map, n_dmap, h_edit, n_dedits, known, ask_always, need, c->apply, err);
+    if (rc != AM355_E_UNSUPPORTED || need.empty() || round == 16 || need.size() > 256 || c->no_history) break;
     // the walk met objects that are no longer visible: what the reference's objectMeta lists for their property follows from the
     // history of the rows on it (am355_delta.hip, delta_key_history)
-    std::vector<uint8_t> st_of(need.size());
+    std::vector<KeyHistory> st_of(need.size());
     if (delta_key_history(c->mb, c->ir, d, need.data(), (uint32_t)need.size(), st_of.data(), st) != 0) return fail(c, AM355_E_DEVICE, "key history: %s", hipGetErrorString(hipGetLastError()));
     for (size_t i = 0; i < need.size(); i++) known[need[i]] = st_of[i];
     lap("property histories");
   }
   if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; return fail(c, rc, "%s", err.c_str()); }
+  // the op streams of this call (this engine re-applies the earlier changes in front of them: their rows keep their numbers)
+  if (old_ops) c->stream_breaks.push_back((uint32_t)old_ops);
+  for (uint32_t r : c->pass_first_row) if (r > old_ops) c->stream_breaks.push_back(r);
   c->apply_ready = true;
   c->apply_json.clear();
   lap("patch assembled");
@@ -2262,11 +2293,22 @@ extern "C" int am355_reset(am355_ctx* c) {
   if (c->staging_in_flight) { c->staging_in_flight = false; (void)hipStreamSynchronize(c->stream); }
   c->staged = c->replayed = c->ir_fetched = c->apply_ready = false;
   c->state_checked = true;
+  c->stream_breaks.clear();
+  c->breaks_exact = true;
+  c->children_hazard = false;
+  c->no_history = false;
   c->is_document = false;
   c->flags = 0;
   c->n_changes = 0;
   c->applied_change.clear();
   c->pending_change.clear();
+  return AM355_OK;
+}
+
+extern "C" int am355_forget_call_history(am355_ctx* c, int from_document) {
+  if (!c) return AM355_E_ARG;
+  c->breaks_exact = false;
+  if (from_document) c->no_history = true;
   return AM355_OK;
 }
 

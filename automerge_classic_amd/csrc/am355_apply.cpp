@@ -50,7 +50,8 @@ struct KeyRefHash {
 }  // namespace
 
 int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const am355_ir_map* d_map, uint32_t n_dmap, const am355_ir_edit* d_edits,
-                         uint32_t n_dedits, const std::unordered_map<uint32_t, uint8_t>& known, std::vector<uint32_t>& need, ApplyPatch& out, std::string& err) {
+                         uint32_t n_dedits, const std::unordered_map<uint32_t, KeyHistory>& known, bool ask_always, std::vector<uint32_t>& need, ApplyPatch& out,
+                         std::string& err) {
   need.clear();
   const uint32_t NO = whole.n_objects;
   const uint8_t* arena = whole.arena;
@@ -80,13 +81,21 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
         // children[key] is what an earlier call left, which is the visible set only while the child is visible.
         // children[key] of a property that holds plain values only is what the last visit left: those values, or nothing for good
         // (new.js:916-931) -- the device tells which from the rows on the property (delta_key_history). 0: go on, `dead` says how.
+        // `listed`: the op ids children[key] lists (KH_LIVE)
+        const KeyHistory* listed = nullptr;
         auto stale = [&](bool& dead) {
           auto it = known.find(child);
           if (it == known.end()) { need.push_back(child); dead = true; return AM355_OK; }  // (asked for; this pass goes on as if nothing were listed)
-          if (it->second == KH_DEAD) { dead = true; return AM355_OK; }
-          if (it->second == KH_LIVE) { dead = false; return AM355_OK; }
+          if (it->second.state == KH_DEAD) { dead = true; return AM355_OK; }
+          if (it->second.state == KH_LIVE) { dead = false; listed = &it->second; return AM355_OK; }
           err = "unsupported: the batch edits an object that is no longer a visible value of its parent (objectMeta history)";
           return AM355_E_UNSUPPORTED;
+        };
+        auto is_listed = [&](uint32_t ctr, uint32_t actor) {
+          if (!listed) return true;
+          for (uint32_t k = 0; k < listed->n; k++)
+            if (listed->ctr[k] == ctr && listed->actor[k] == actor) return true;
+          return false;
         };
         auto refuse_history = [&]() {
           err = "unsupported: the batch edits an object that is no longer a visible value of its parent (objectMeta history)";
@@ -137,6 +146,12 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
               if (in_run) return refuse_history();
               none_visible = true;
             } else if (!any_child) { int rc = stale(none_visible); if (rc) return rc; }
+            if (!none_visible && listed) {
+              std::vector<am355_ir_edit> kept;
+              for (const am355_ir_edit& u : vals) if (is_listed(u.id_ctr, u.id_actor)) kept.push_back(u);
+              if (kept.size() != listed->n) { err = "unsupported: objectMeta lists values of a list element that the document patch does not show"; return AM355_E_UNSUPPORTED; }
+              vals.swap(kept);
+            }
             if (!none_visible) {
               auto& dst = extra_edits[o];
               dst.insert(dst.end(), vals.begin(), vals.end());
@@ -170,10 +185,17 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
               any_child = any_child || (m.flags & AM355_MAP_CHILD);
               vals.push_back(m);
             }
-            if (L.flags & OL_VISIBLE) {
+            if (ask_always && any_value) { int rc = stale(none_visible); if (rc) return rc; }  // (a call may have skipped values of the property)
+            else if (L.flags & OL_VISIBLE) {
               if (vals.empty()) { err = "internal: key of a visible child object not found in the document patch"; return AM355_E_DEVICE; }
             } else if (!any_value) none_visible = true;   // children[key] is empty whatever happened before
             else if (!any_child) { int rc = stale(none_visible); if (rc) return rc; }  // plain values only: children[key] lists them, or went empty once and stayed so
+            if (!none_visible && listed) {
+              std::vector<am355_ir_map> kept;
+              for (const am355_ir_map& m : vals) if (is_listed(m.id_ctr, m.id_actor)) kept.push_back(m);
+              if (kept.size() != listed->n) { err = "unsupported: objectMeta lists values of a property that the document patch does not show"; return AM355_E_UNSUPPORTED; }
+              vals.swap(kept);
+            }
             if (!none_visible) {
               auto& dst = extra_map[o];
               dst.insert(dst.end(), vals.begin(), vals.end());

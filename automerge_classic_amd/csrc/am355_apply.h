@@ -20,10 +20,12 @@ struct ApplyPatch {
 // whole: the whole-document IR of the new state (host).  link / d_map / d_edits: the delta tables copied from the device.
 // Returns 0, or AM355_E_UNSUPPORTED with *err set (an edit inside an object the document no longer reaches, where what the children
 // tables of the reference's objectMeta hold could not be told).
-// known: what objectMeta.children holds for the property of some objects (object index -> KH_*, am355_delta.h), found by the device
-// from the history of the rows on it; need: filled with the objects whose property the walk had to know about and did not (the caller
-// asks the device and calls again). With need empty on return the result is final.
+// known: what objectMeta.children holds for the property of some objects (object index -> KeyHistory, am355_delta.h), found by the
+// device from the history of the rows on it; need: filled with the objects whose property the walk had to know about and did not (the
+// caller asks the device and calls again). With need empty on return the result is final. ask_always: the state has seen a merge call
+// that skipped values of a property with a child object -- no property is taken to list its visible values without asking.
 int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const am355_ir_map* d_map, uint32_t n_dmap, const am355_ir_edit* d_edits,
-                         uint32_t n_dedits, const std::unordered_map<uint32_t, uint8_t>& known, std::vector<uint32_t>& need, ApplyPatch& out, std::string& err);
+                         uint32_t n_dedits, const std::unordered_map<uint32_t, KeyHistory>& known, bool ask_always, std::vector<uint32_t>& need, ApplyPatch& out,
+                         std::string& err);
 
 }  // namespace am355

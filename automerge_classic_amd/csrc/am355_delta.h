@@ -59,6 +59,9 @@ struct DeltaBufs {
   uint32_t bits_new;      // bits of a row number counted from T0
   uint32_t n_pass;        // scheduling passes after the first that begin inside the new rows
   const uint32_t* pass_rows;  // [n_pass] first row of each such pass
+  uint32_t n_breaks;          // rows at which an op stream began: a call of applyChanges or a scheduling pass of one (all calls so far)
+  const uint32_t* breaks;     // [n_breaks] ascending
+  uint32_t breaks_exact;      // 0: where EARLIER calls ended is not known (the staged changes were replayed in one go)
   DeltaCounts* counts;
   ObjLink* link;          // [NO]
   // rows: first_del / new_succ per VALUE row (first row of the batch that overwrites or deletes it, how many do); upd_*: the
@@ -103,10 +106,17 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
 // What the reference's objectMeta holds in `children[key]` for the property (map key or list element) that holds -- or held -- each
 // of the given objects: the visible values, or nothing (KH_DEAD). It is refreshed only while it is non-empty or a child object is
 // visible (new.js:916-931), row by row of every merge call that visits the property: once a visit leaves it empty, later plain values
-// do not bring it back. One thread replays the visits of a property from the rows on it (their row numbers are the times). `objects`
-// (host, object indexes) -> `state` (host): KH_LIVE / KH_DEAD / KH_UNKNOWN (more rows than the walk takes, or a visit the walk does
-// not model). Synchronises `st`.
+// do not bring it back; and it lists the values the LAST visit saw, which a call that went on to a greater key did not all look at
+// (kd_slots). One thread replays the visits of a property from the rows on it (their row numbers are the times). `objects` (host,
+// object indexes) -> `out` (host): KH_LIVE with the listed values / KH_DEAD / KH_UNKNOWN (more rows than the walk takes, or a visit
+// the walk does not model). Synchronises `st`.
 enum : uint8_t { KH_UNKNOWN = 0, KH_LIVE = 1, KH_DEAD = 2 };
-int delta_key_history(MergeBufs& b, PatchIR& ir, DeltaBufs& d, const uint32_t* objects, uint32_t n, uint8_t* state, hipStream_t st);
+constexpr uint32_t KH_VALUES_MAX = 16;  // values of one property the walk reports (more: KH_UNKNOWN)
+struct KeyHistory {
+  uint8_t state = KH_UNKNOWN;
+  uint32_t n = 0;                         // KH_LIVE: the op ids of the listed values, ascending
+  uint32_t ctr[KH_VALUES_MAX], actor[KH_VALUES_MAX];
+};
+int delta_key_history(MergeBufs& b, PatchIR& ir, DeltaBufs& d, const uint32_t* objects, uint32_t n, KeyHistory* out, hipStream_t st);
 
 }  // namespace am355

@@ -603,6 +603,9 @@ __global__ __launch_bounds__(BLOCK) void kd_slots(MergeBufs b, DeltaBufs d) {
       uint32_t pj = j - 1;
       uint8_t kp = b.kind[pj];
       ambiguous = (kp == K_MAP || kp == K_DEL) && o.key_len[pj] != NONE32 && o.id_actor[pj] == o.id_actor[j] && same_obj(b, pj, j) && same_key(b, pj, j);
+      // (a deletion OF that earlier op starts a merge call of its own, new.js:1114-1121: nothing travels with it)
+      for (uint32_t k = 0; k < o.pred_num[j]; k++)
+        if (o.pred_ctr[o.pred_first[j] + k] == o.id_ctr[pj] && o.pred_actor[o.pred_first[j] + k] == o.id_actor[pj]) ambiguous = false;
     }
   }
   d.slot_L[s] = L;
@@ -647,8 +650,9 @@ __global__ __launch_bounds__(BLOCK) void kd_placeholders(DeltaBufs d) {
   if (s <= d.key_mask && d.slot_rep[s]) {
     pl = d.slot_cnt[s] == 0 ? 1u : 0u;
     // values were skipped on a key that holds a child object: objectMeta.children of the reference now lacks them, which later
-    // patches would show (new.js:916-931) -- a state this engine does not carry
-    if (d.slot_child[s] && d.slot_drop[s]) { d.counts->hazard = 1; atomicOr(&d.counts->flags, refuse(d, DR_CHILD_HAZARD)); }
+    // patches show (new.js:916-931) -- from here on the host asks delta_key_history what a property lists instead of taking its
+    // visible values
+    if (d.slot_child[s] && d.slot_drop[s]) d.counts->hazard = 1;
   }
   d.place[s] = pl;
 }
@@ -835,12 +839,15 @@ __global__ __launch_bounds__(BLOCK) void kh_collect(MergeBufs b, PatchIR ir, con
 }
 
 __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, DeltaBufs d, const uint32_t* __restrict__ targets, uint32_t n,
-                                                    const uint32_t* __restrict__ lists, const uint32_t* __restrict__ counts, uint32_t* __restrict__ state) {
+                                                    const uint32_t* __restrict__ lists, const uint32_t* __restrict__ counts, uint32_t* __restrict__ state,
+                                                    uint32_t* __restrict__ values) {
   uint32_t t = gtid();
   if (t >= n) return;
   const OpCols& o = b.ops;
   const uint32_t c = counts[t];
-  if (c > KH_ROWS_MAX) { state[t] = KH_UNKNOWN; return; }
+  state[2 * t] = KH_UNKNOWN;
+  state[2 * t + 1] = 0;
+  if (c > KH_ROWS_MAX) return;
   const bool map_prop = o.key_len[ir.obj[targets[t]].make_row] != NONE32;
   uint32_t rows[KH_ROWS_MAX], death[KH_ROWS_MAX], by_id[KH_ROWS_MAX];
   for (uint32_t i = 0; i < c; i++) {  // ascending row number = time
@@ -863,7 +870,9 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
         if (o.id_ctr[rows[i]] == pc && o.id_actor[rows[i]] == pa && death[i] > g) death[i] = g;
     }
   }
-  bool empty = true, unknown = false;
+  bool unknown = false;
+  uint32_t listed[(KH_ROWS_MAX + 31) / 32] = {};  // children[key]: bit q = the row by_id[q] is listed
+  auto none_listed = [&]() { uint32_t any = 0; for (uint32_t w = 0; w < (KH_ROWS_MAX + 31) / 32; w++) any |= listed[w]; return any == 0; };
   for (uint32_t j = 0; j < c && !unknown; j++) {
     const uint32_t g = rows[j];
     const bool is_del = b.kind[g] == K_DEL;
@@ -880,8 +889,10 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
     unsigned long long thr = pack_id(o.id_ctr[g], o.id_actor[g]);
     if (map_prop && g + 1 < b.n_ops) {
       uint32_t nx = g + 1;
-      bool new_pass = false;
-      for (uint32_t k = 0; k < d.n_pass; k++) new_pass = new_pass || d.pass_rows[k] == nx;
+      // (an op stream ends with the scheduling pass, and with the call of applyChanges)
+      uint32_t lo = 0, hi = d.n_breaks;
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.breaks[mid] < nx) lo = mid + 1; else hi = mid; }
+      const bool new_pass = lo < d.n_breaks && d.breaks[lo] == nx;
       uint8_t kn = b.kind[nx];
       cont = !new_pass && (kn == K_MAP || kn == K_DEL) && o.key_len[nx] != NONE32 && !o.insert[nx] && o.id_actor[nx] == o.id_actor[g] && same_obj(b, nx, g) &&
              key_less_utf16(b, g, nx);
@@ -893,45 +904,65 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
         }
       }
     }
-    uint32_t nvals = 0;
+    uint32_t seen[(KH_ROWS_MAX + 31) / 32] = {};  // visible values among the rows visited so far
     bool has_child = false;
     for (uint32_t q = 0; q < c; q++) {
       const uint32_t i = by_id[q], r = rows[i];
       if (r > g || b.kind[r] == K_DEL) continue;  // not there yet / a deletion leaves no row
       if (cont && r != g && pack_id(o.id_ctr[r], o.id_actor[r]) > thr) {
-        // (whether an EARLIER call went on to the next row is not known -- a call of applyChanges or a scheduling pass may have ended
-        // between them --: it only matters when a row it would have skipped is visible)
-        if (g + 1 < d.T0 && death[i] > g) unknown = true;
+        // (when the staged changes were replayed in one go, whether an EARLIER call went on to the next row is not known -- a call of
+        // applyChanges or a scheduling pass may have ended between them --: it only matters when a row it would have skipped is visible)
+        if (!d.breaks_exact && g + 1 < d.T0 && death[i] > g) unknown = true;
         continue;
       }
       if (r == g || death[i] > g) {
         uint32_t a = o.action[r];
         if ((a & 1u) == 0) has_child = true;
-        if (a == 1 || (a & 1u) == 0) nvals++;
+        if (a == 1 || (a & 1u) == 0) seen[q >> 5] |= 1u << (q & 31);
       }
-      if (has_child || !empty) empty = nvals == 0;
+      if (has_child || !none_listed())
+        for (uint32_t w = 0; w < (KH_ROWS_MAX + 31) / 32; w++) listed[w] = seen[w];
     }
   }
-  state[t] = unknown ? (uint32_t)KH_UNKNOWN : empty ? (uint32_t)KH_DEAD : (uint32_t)KH_LIVE;
+  if (unknown) return;
+  uint32_t nl = 0;
+  for (uint32_t q = 0; q < c; q++)
+    if (listed[q >> 5] >> (q & 31) & 1u) {
+      if (nl == KH_VALUES_MAX) return;  // (KH_UNKNOWN)
+      uint32_t r = rows[by_id[q]];
+      values[(size_t)t * 2 * KH_VALUES_MAX + 2 * nl] = o.id_ctr[r];
+      values[(size_t)t * 2 * KH_VALUES_MAX + 2 * nl + 1] = o.id_actor[r];
+      nl++;
+    }
+  state[2 * t] = nl ? (uint32_t)KH_LIVE : (uint32_t)KH_DEAD;
+  state[2 * t + 1] = nl;
 }
 
-int delta_key_history(MergeBufs& b, PatchIR& ir, DeltaBufs& d, const uint32_t* objects, uint32_t n, uint8_t* state, hipStream_t st) {
+int delta_key_history(MergeBufs& b, PatchIR& ir, DeltaBufs& d, const uint32_t* objects, uint32_t n, KeyHistory* out, hipStream_t st) {
   if (!n) return 0;
   uint32_t* dev = nullptr;
-  const size_t words = (size_t)n * (KH_ROWS_MAX + 3);
+  const size_t words = (size_t)n * (KH_ROWS_MAX + 4 + 2 * KH_VALUES_MAX);
   if (hipMalloc((void**)&dev, 4 * words) != hipSuccess) return -1;
-  uint32_t *targets = dev, *counts = dev + n, *out = dev + 2 * (size_t)n, *lists = dev + 3 * (size_t)n;
+  uint32_t *targets = dev, *counts = dev + n, *state = dev + 2 * (size_t)n, *values = dev + 4 * (size_t)n, *lists = values + (size_t)n * 2 * KH_VALUES_MAX;
   (void)hipMemsetAsync(dev, 0, 4 * words, st);
   (void)hipMemcpyAsync(targets, objects, 4 * (size_t)n, hipMemcpyHostToDevice, st);
   (void)hipStreamSynchronize(st);  // (pageable source)
   if (b.n_ops) AM355_LAUNCH_INDEPENDENT(kh_collect, dgrid(b.n_ops), dim3(BLOCK), st, b, ir, (const uint32_t*)targets, n, lists, counts);
-  AM355_LAUNCH_INDEPENDENT(kh_simulate, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), st, b, ir, d, (const uint32_t*)targets, n, (const uint32_t*)lists, (const uint32_t*)counts, out);
-  std::vector<uint32_t> h(n);
-  (void)hipMemcpyAsync(h.data(), out, 4 * (size_t)n, hipMemcpyDeviceToHost, st);
+  AM355_LAUNCH_INDEPENDENT(kh_simulate, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), st, b, ir, d, (const uint32_t*)targets, n, (const uint32_t*)lists, (const uint32_t*)counts, state,
+                           values);
+  std::vector<uint32_t> h((size_t)n * (2 + 2 * KH_VALUES_MAX));
+  (void)hipMemcpyAsync(h.data(), state, 4 * h.size(), hipMemcpyDeviceToHost, st);  // (state | values: contiguous)
   hipError_t e = hipStreamSynchronize(st);
   (void)hipFree(dev);
   if (e != hipSuccess) return -1;
-  for (uint32_t i = 0; i < n; i++) state[i] = (uint8_t)h[i];
+  for (uint32_t i = 0; i < n; i++) {
+    out[i].state = (uint8_t)h[2 * (size_t)i];
+    out[i].n = h[2 * (size_t)i + 1];
+    for (uint32_t k = 0; k < out[i].n && k < KH_VALUES_MAX; k++) {
+      out[i].ctr[k] = h[2 * (size_t)n + (size_t)i * 2 * KH_VALUES_MAX + 2 * k];
+      out[i].actor[k] = h[2 * (size_t)n + (size_t)i * 2 * KH_VALUES_MAX + 2 * k + 1];
+    }
+  }
   return 0;
 }
 

@@ -94,9 +94,10 @@ def _bind(path):
     L.am355_sync_bloom_build.argtypes = [vp, vp, u32, vp, ctypes.c_size_t]
     L.am355_sync_bloom_probe.argtypes = [vp, vp, u32, u32, u32, u32, vp, ctypes.c_size_t, vp]
     L.am355_get_pending.argtypes = [vp, vp, ctypes.POINTER(u32)]
+    L.am355_forget_call_history.argtypes = [vp, ctypes.c_int]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
-              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
+              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_forget_call_history", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -169,6 +170,10 @@ class Engine:
         """Forget the state: the next apply_changes starts from Backend.init()."""
         self._check(self._L.am355_reset(self._h))
         self._n_changes = 0
+
+    def forget_call_history(self, from_document=False):
+        """The staged changes were replayed in one go, not by the Backend.applyChanges calls that built the state (include/am355.h)."""
+        self._check(self._L.am355_forget_call_history(self._h, 1 if from_document else 0))
 
     def pending(self):
         """Indexes (into the engine's list of changes) of the changes still queued for a missing dependency."""

@@ -62,6 +62,8 @@ class GpuState {
     this.pending = 0
     this.byHash = null       // lazily: hex hash -> input index, applied changes only
     this.pendingIdx = null   // input indexes of the changes still queued (loadChanges / applyChanges states)
+    this.calls = 1           // backend calls that built the state (1: one loadChanges / applyChanges onto an empty document)
+    this.fromDocument = false // the lineage began with load(bytes): the reference's objectMeta came from the document, not from changes
   }
 }
 let generation = 0           // bumped by every GPU replay
@@ -154,6 +156,16 @@ function gpuReplay(changes) {
   addon.loadChanges(ctx, changes)
   addon.replay(ctx)
   return gpuPatch()
+}
+
+// The retained changes of `g` replayed into a fresh context, in one go. When that is not how the state came to be -- several calls
+// built it, or it was loaded from a document -- the engine is told: the few patches of later applyChanges calls that depend on where
+// the reference's calls ended, or on an objectMeta made from a document, are then refused instead of guessed (am355_forget_call_history)
+function replayRetained(g) {
+  gpuReplay(g.changes)
+  g.generation = generation
+  g.fromChanges = true
+  if (g.calls > 1 || g.fromDocument || g.doc) addon.forgetCallHistory(ctx, !!(g.fromDocument || g.doc))
 }
 
 function init() {
@@ -323,7 +335,7 @@ function gpuApplyChanges(backend, changes) {
   if (g && !g.changes) return null
   let entry
   if (g) {
-    if ((g.doc && !g.fromChanges) || !(entry = contextOf(g.generation))) { gpuReplay(g.changes); g.generation = generation; g.fromChanges = true; entry = contextOf(generation) }
+    if ((g.doc && !g.fromChanges) || !(entry = contextOf(g.generation))) { replayRetained(g); entry = contextOf(generation) }
     if (!g.applied || !g.pendingIdx) { g.applied = addon.appliedOrder(ctx); g.pendingIdx = addon.pendingOrder(ctx) }
   } else {
     entry = acquireContext()
@@ -345,6 +357,8 @@ function gpuApplyChanges(backend, changes) {
   state.pendingIdx = addon.pendingOrder(ctx)
   state.hashes = addon.hashes(ctx)
   state.pending = patch.pendingChanges
+  state.calls = g ? g.calls + 1 : 1
+  state.fromDocument = !!(g && (g.fromDocument || g.doc))
   counters.gpuApplyChanges++
   return [{ state, heads: patch.deps }, patch]
 }
@@ -382,7 +396,7 @@ function hexOfHash(g, i) { return Buffer.from(g.hashes.buffer, g.hashes.byteOffs
 // the engine context that holds the replay of `g` (replayed again from the retained changes when it has moved on)
 function ensureContext(g) {
   // (a loaded document sits in its context as a document: the hash graph needs the replay of its rebuilt changes)
-  if ((g.doc && !g.fromChanges) || !contextOf(g.generation)) { gpuReplay(g.changes); g.generation = generation; g.fromChanges = true; contextOf(generation) }
+  if ((g.doc && !g.fromChanges) || !contextOf(g.generation)) { replayRetained(g); contextOf(generation) }
 }
 
 // hash graph of an engine-built state, by index into g.changes: dependencies as resolved on the device, dependents in the order the

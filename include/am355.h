@@ -225,6 +225,16 @@ int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
 int am355_apply_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes);
 /* Forget the state the context holds: the next am355_apply_changes is Backend.applyChanges(Backend.init(), changes). */
 int am355_reset(am355_ctx *ctx);
+/* The staged changes were NOT applied by the one am355_load_changes + am355_replay that built the state: the host replayed the
+ * retained changes of a state that several Backend.applyChanges calls had built (automerge_classic_amd/js/index.js does so when the
+ * context of a state has moved on). Where those calls ended is then not known to the engine -- the reference's merge calls never
+ * cross a call (new.js:1052-1290 runs per applyChanges), and what its objectMeta.children lists depends on them (new.js:916-931,
+ * 1125-1149) --: am355_apply_changes then refuses the few patches that depend on it instead of assuming one call.
+ * from_document != 0: the staged changes are the REBUILT history of a document that the reference loaded (Backend.load): its objectMeta
+ * came from one pass over the document's rows (new.js:1695-1750), not from that history; patches that need what objectMeta lists for a
+ * property whose child object is no longer visible are refused. Holds until am355_reset / the next am355_load_changes. */
+int am355_forget_call_history(am355_ctx *ctx, int from_document);
+
 /* Input indexes of the changes still queued for a missing dependency (BackendDoc.queue, new.js:1866), in queue order. The engine's
  * own list of changes after am355_apply_changes is: the changes applied before the call in application order, the batch, the
  * changes queued before the call -- am355_get_applied / am355_get_pending / am355_get_hashes index that list. out may be NULL. */

@@ -230,15 +230,13 @@ def test_apply_after_load_changes_and_queue_emulated(emu_lib):
 
 
 def test_unserved_batch_is_refused_emulated(emu_lib):
-    """A batch outside the served subset (here: a deletion whose place in the merge loop's work list is ambiguous) ends in a refusal
-    that names the reason, not in a patch."""
-    sessions, pool = load_campaign()
-    s = next(x for x in sessions if x["name"] == "m:16:6:140:2#1")
+    """A batch outside the served subset (vector 15 of the reference's suites: two assignments to one list element in one change) ends
+    in a refusal that names the reason, not in a patch."""
+    vectors, pool = load_vectors()
     eng = engine.Engine(0, emu_lib)
     try:
-        with pytest.raises(engine.UnsupportedChanges, match="work list is ambiguous"):
-            for call in s["calls"]:
-                eng.apply_changes(ChangeLog.from_changes([pool[k] for k in call]))
+        with pytest.raises(engine.UnsupportedChanges, match="two ops on one list element"):
+            eng.apply_changes(ChangeLog.from_changes([pool[k] for k in vectors[15]["changes"]]))
     finally:
         eng.close()
 
@@ -247,8 +245,45 @@ def test_edits_inside_objects_that_are_no_longer_visible_emulated(emu_lib):
     """Nested documents whose objects are overwritten and deleted while other actors still edit them: setupPatches needs what the
     reference's objectMeta.children holds for the parent property, which the device replays from the history of the rows on it
     (delta_key_history). Three sessions of the campaign that this decides, served to the end."""
-    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), names={"m:11:3:120:2#0", "m:11:3:120:2#2", "21:3:70:2#0"})
-    assert equal == 54 + 14 + 37 and refused == 0
+    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), names={"m:11:3:120:2#0", "m:12:4:160:3#1", "m:16:6:140:2#2", "21:3:70:2#0"})
+    assert equal == 54 + 10 + 16 + 37 and refused == 0
+
+
+def test_state_replayed_in_one_go_is_served_or_refused_emulated(emu_lib):
+    """The JS host replays the retained changes of a state into a fresh context when the old one has moved on: one call where the
+    reference had many. The engine is told (am355_forget_call_history) and must then still return the reference's patch -- or refuse
+    the call where the patch depends on where the reference's calls ended -- never a different one."""
+    sessions, pool = load_campaign()
+    equal = refused = 0
+    for name in ("m:12:4:160:3#0", "m:16:6:140:2#2", "21:3:70:2#0"):
+        s = next(x for x in sessions if x["name"] == name)
+        given = []
+        eng = None
+        try:
+            for ci, (call, want) in enumerate(zip(s["calls"], s["patches"])):
+                batch = [pool[k] for k in call]
+                if ci % 7 == 3:  # the context "moved on": everything given so far again, in one go
+                    if eng is not None:
+                        eng.close()
+                    eng = engine.Engine(0, emu_lib)
+                    eng.load_changes(ChangeLog.from_changes(given))
+                    eng.replay()
+                    eng.forget_call_history()
+                elif eng is None:
+                    eng = engine.Engine(0, emu_lib)
+                given += batch
+                try:
+                    eng.apply_changes(ChangeLog.from_changes(batch))
+                    got = eng.apply_patch_json()
+                except engine.UnsupportedChanges:
+                    refused += 1
+                    break
+                assert same_patch(got, want), f"{name} call {ci}:\n{got}\n{want}"
+                equal += 1
+        finally:
+            if eng is not None:
+                eng.close()
+    assert equal >= 60
 
 
 def test_list_assignment_sessions_emulated(emu_lib):
@@ -272,7 +307,7 @@ def test_reference_suite_calls_gpu():
 @pytest.mark.gpu
 def test_campaign_sessions_gpu():
     equal, refused = run_campaign(lambda: engine.Engine(0))
-    assert equal >= 300
+    assert equal == 447 and refused == 0
 
 
 @pytest.mark.gpu
