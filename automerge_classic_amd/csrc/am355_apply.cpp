@@ -68,6 +68,20 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
   std::unordered_set<uint64_t> appended_elems;           // (parent, element id) that received update edits -- key below
   std::unordered_map<uint32_t, std::unordered_map<uint64_t, uint32_t>> elem_index;  // list parent -> element id -> first whole-document record
   auto elem_key = [](uint32_t ctr, uint32_t actor) { return (uint64_t)ctr << 32 | actor; };
+  // list parent -> op ids of the batch's own edits that carry one (insert / update: new.js:1477-1481 looks for them)
+  std::unordered_map<uint32_t, std::unordered_set<uint64_t>> edit_ops;
+  auto batch_edit_ops = [&](uint32_t o) -> const std::unordered_set<uint64_t>& {
+    auto it = edit_ops.find(o);
+    if (it != edit_ops.end()) return it->second;
+    auto& set = edit_ops[o];
+    for (uint32_t r = link[o].edit_begin; r < link[o].edit_end && r < n_dedits; r++) {
+      const am355_ir_edit& ed = d_edits[r];
+      if (ed.flags & (AM355_EDIT_REMOVE | AM355_EDIT_CONT | AM355_EDIT_MULTI)) continue;
+      if (d_edits[r + 1].first - ed.first != 1 || (r + 1 < link[o].edit_end && (d_edits[r + 1].flags & AM355_EDIT_CONT))) continue;  // multi-insert: no opId
+      set.insert(elem_key(ed.id_ctr, ed.id_actor));
+    }
+    return set;
+  };
 
   for (uint32_t start : touched) {
     uint32_t o = start, child = NONE32;
@@ -153,6 +167,12 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
               vals.swap(kept);
             }
             if (!none_visible) {
+              // an edit of the batch already shows one of the listed values: the child is linked through it (new.js:1477-1481)
+              const auto& ops = batch_edit_ops(o);
+              for (const am355_ir_edit& u : vals)
+                if (ops.count(elem_key(u.id_ctr, u.id_actor))) exists = true;
+            }
+            if (!none_visible && !exists) {
               auto& dst = extra_edits[o];
               dst.insert(dst.end(), vals.begin(), vals.end());
               appended_elems.insert(pk);

@@ -37,7 +37,7 @@ enum : uint32_t {
   DR_FOREIGN_ROW = 1,     // a row of an object another shard owns
   DR_KEY_TABLE,           // touched-key table full
   DR_ELEM_ROWS,           // more value rows on a touched list element than the stage walks
-  DR_ELEM_NOT_PLAIN,      // an assigned list element holds child objects or counters
+  DR_ELEM_NOT_PLAIN,      // an assigned list element holds something that is neither a value nor a child object (inc, link)
   DR_SAME_ELEM_CALL,      // two ops on one element in one merge call
   DR_GAP_WALK,            // too many later insertions between two elements of one merge call
   DR_LAGGING_UPDATE,      // the first update edit of a conflict would sit at the reference's lagging index

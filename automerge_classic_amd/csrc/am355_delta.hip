@@ -301,8 +301,10 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
       elem_state(b, d, e, g, before, after);
       ev = before ? (after ? EV_UPDATE : EV_REMOVE) : (after ? EV_INSERT : EV_NONE);
       if (nu > 0) {  // (the element holds assignment rows, old or new)
-        bool plain = o.action[e] == 1;
-        for (uint32_t k = 0; k < nu; k++) plain = plain && o.action[d.upd_rows[d.upd_off[e] + k]] == 1;
+        // values are `set` rows and make rows (child objects); anything else (inc, link, unknown actions) is not restated
+        auto is_value = [&](uint32_t r) { uint32_t a = o.action[r]; return a == 1 || ((a & 1u) == 0 && a < 7); };
+        bool plain = is_value(e);
+        for (uint32_t k = 0; k < nu; k++) plain = plain && is_value(d.upd_rows[d.upd_off[e] + k]);
         if (!plain) err |= refuse(d, DR_ELEM_NOT_PLAIN);  // child objects / counters among the values: objectMeta bookkeeping, counter states
       }
       // ---- does the op continue the merge call of the previous op of the stream? ----
@@ -559,7 +561,10 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, 
         if (best_r == NONE32) { atomicOr(&d.counts->flags, refuse(d, DR_INTERNAL)); break; }
         last = best;
         uint32_t rf = (j == 0 && (f & 0x1000u)) ? 0u : (uint32_t)AM355_EDIT_UPDATE;
-        d.edit[k + j] = am355_ir_edit{rf, v.idx, o.id_ctr[best_r], o.id_actor[best_r], o.id_ctr[e], o.id_actor[e], first + j, o.val_tl[best_r], o.val_off[best_r], 0};
+        const bool child = (o.action[best_r] & 1u) == 0;
+        if (child) rf |= AM355_EDIT_CHILD;
+        d.edit[k + j] = am355_ir_edit{rf, v.idx, o.id_ctr[best_r], o.id_actor[best_r], o.id_ctr[e], o.id_actor[e], first + j, o.val_tl[best_r],
+                                      child ? b.obj_index[best_r] : o.val_off[best_r], 0};
       }
     }
   }
@@ -695,7 +700,7 @@ const char* delta_reason_text(uint32_t reason) {
     case DR_FOREIGN_ROW: return "rows of objects another shard owns";
     case DR_KEY_TABLE: return "touched-key table full";
     case DR_ELEM_ROWS: return "a touched list element holds more value rows than the stage walks";
-    case DR_ELEM_NOT_PLAIN: return "an assigned list element holds child objects or counters";
+    case DR_ELEM_NOT_PLAIN: return "an assigned list element holds an op that is neither a value nor a child object";
     case DR_SAME_ELEM_CALL: return "two ops on one list element in one merge call";
     case DR_GAP_WALK: return "too many later insertions between two elements of one merge call";
     case DR_LAGGING_UPDATE: return "the first update edit of a conflict would sit at the reference's lagging list index";
