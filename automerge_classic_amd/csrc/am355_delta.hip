@@ -31,6 +31,7 @@
 #include "am355_delta.h"
 #include "am355_prims.h"
 #include "am355_rows.h"
+#include "am355_scan.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void kd_bit_flags(DeltaBufs d, int src, uint
   if (i < m) {
     uint32_t tk = d.tk[src][i];
     z = (((tk >> 2) >> bit) & 1u) ? 0u : 1u;
-    w = z ? ((tk & 3u) == 1u ? 0xffffffffu : (tk & 3u) == 0u ? 1u : 0u) : 0u;  // +1 insert, -1 remove, 0 update
+    w = z ? ((tk & 3u) == 1u ? 0xffffffffu : (tk & 3u) == 0u ? 1u : 0u) : 0u;  // +1 insert, -1 remove, 0 update (item_weight)
   }
   d.zf[i] = z;
   d.zw[i] = w;
@@ -393,6 +394,9 @@ __global__ __launch_bounds__(BLOCK) void kd_bit_flags(DeltaBufs d, int src, uint
 
 // one stable partition of every group by the bit: zeros first. An item whose bit is set has every zero of its group in front of
 // it (in position order) earlier in time: it adds their weights.
+__device__ __forceinline__ uint32_t item_weight(uint32_t tk) { return (tk & 3u) == 1u ? 0xffffffffu : (tk & 3u) == 0u ? 1u : 0u; }  // +1 insert, -1 remove, 0 update
+
+// (it also leaves the flags of the NEXT level at the item's new place: one launch less per level)
 __global__ __launch_bounds__(BLOCK) void kd_partition(DeltaBufs d, int src, uint32_t m, uint32_t bit) {
   uint32_t i = gtid();
   if (i >= m) return;
@@ -409,6 +413,70 @@ __global__ __launch_bounds__(BLOCK) void kd_partition(DeltaBufs d, int src, uint
     nlo = lo; nhi = lo + nz;
   }
   d.tk[dst][to] = tk; d.elem[dst][to] = d.elem[src][i]; d.acc[dst][to] = acc; d.lo[dst][to] = nlo; d.hi[dst][to] = nhi;
+  if (bit > 0) {
+    uint32_t z = (((tk >> 2) >> (bit - 1)) & 1u) ? 0u : 1u;
+    d.zf[to] = z;
+    d.zw[to] = z ? item_weight(tk) : 0u;
+  }
+}
+
+// All levels in one workgroup with the items in LDS: a batch of a few changes has a few hundred items and would otherwise spend two
+// launches per level of a dozen levels on them.
+constexpr uint32_t PART_LDS_MAX = 1024;  // items (4 per thread)
+__global__ __launch_bounds__(BLOCK) void kd_partition_lds(DeltaBufs d, uint32_t m, uint32_t bits) {
+  __shared__ uint32_t s_tk[2][PART_LDS_MAX], s_el[2][PART_LDS_MAX], s_acc[2][PART_LDS_MAX], s_lh[2][PART_LDS_MAX];  // lo | hi << 16
+  __shared__ uint32_t s_zf[PART_LDS_MAX + 1], s_zw[PART_LDS_MAX + 1], s_scan[BLOCK / WAVE];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t i = t; i < m; i += BLOCK) {
+    s_tk[0][i] = d.tk[0][i]; s_el[0][i] = d.elem[0][i]; s_acc[0][i] = 0; s_lh[0][i] = d.lo[0][i] | d.hi[0][i] << 16;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int bit = (int)bits - 1; bit >= 0; bit--) {
+    // exclusive prefixes of the zero flags and of their weights over all items (4 consecutive items per thread)
+    uint32_t z[4], w[4], zs = 0, ws = 0;
+    for (uint32_t k = 0; k < 4; k++) {
+      uint32_t i = 4 * t + k;
+      z[k] = w[k] = 0;
+      if (i < m) {
+        uint32_t tk = s_tk[cur][i];
+        z[k] = (((tk >> 2) >> bit) & 1u) ? 0u : 1u;
+        w[k] = z[k] ? item_weight(tk) : 0u;
+      }
+      zs += z[k]; ws += w[k];
+    }
+    uint32_t zt, wt;
+    uint32_t zb = block_exclusive_scan_u32(zs, s_scan, &zt), wb = block_exclusive_scan_u32(ws, s_scan, &wt);
+    for (uint32_t k = 0; k < 4; k++) {
+      uint32_t i = 4 * t + k;
+      if (i <= m) { s_zf[i] = zb; s_zw[i] = wb; }
+      zb += z[k]; wb += w[k];
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < 4; k++) {
+      uint32_t i = 4 * t + k;
+      if (i >= m) continue;
+      uint32_t tk = s_tk[cur][i], lh = s_lh[cur][i], lo = lh & 0xffffu, hi = lh >> 16, acc = s_acc[cur][i];
+      uint32_t zl = s_zf[lo], zi = s_zf[i], nz = s_zf[hi] - zl;
+      uint32_t to, nlo, nhi;
+      if (((tk >> 2) >> bit) & 1u) {
+        acc += s_zw[i] - s_zw[lo];
+        to = lo + nz + ((i - lo) - (zi - zl));
+        nlo = lo + nz; nhi = hi;
+      } else {
+        to = lo + (zi - zl);
+        nlo = lo; nhi = lo + nz;
+      }
+      s_tk[cur ^ 1][to] = tk; s_el[cur ^ 1][to] = s_el[cur][i]; s_acc[cur ^ 1][to] = acc; s_lh[cur ^ 1][to] = nlo | nhi << 16;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int out = (int)(bits & 1u);  // (where the level-by-level version leaves them)
+  for (uint32_t i = t; i < m; i += BLOCK) {
+    d.tk[out][i] = s_tk[cur][i]; d.elem[out][i] = s_el[cur][i]; d.acc[out][i] = s_acc[cur][i];
+    d.lo[out][i] = s_lh[cur][i] & 0xffffu; d.hi[out][i] = s_lh[cur][i] >> 16;
+  }
 }
 
 // items are now in (object, time) order: index of each edit
@@ -790,11 +858,17 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   const uint32_t m = hc->n_items;
   int cur = 0;
   if (m) {
-    for (int bit = (int)d.bits_new - 1; bit >= 0; bit--) {
-      AM355_LAUNCH_INDEPENDENT(kd_bit_flags, dgrid(m + 1), dim3(BLOCK), st, d, cur, m, (uint32_t)bit);
-      exclusive_scan2_u32(d.zf, d.zf_ex, nullptr, d.zw, d.zw_ex, nullptr, m + 1, d.scan_ws, st);
-      AM355_LAUNCH_INDEPENDENT(kd_partition, dgrid(m), dim3(BLOCK), st, d, cur, m, (uint32_t)bit);
-      cur ^= 1;
+    static const bool no_lds = getenv("AM355_DELTA_NO_LDS") != nullptr;  // (tests: the level-by-level version on small batches too)
+    if (m <= PART_LDS_MAX && !no_lds) {
+      hipLaunchKernelGGL(kd_partition_lds, dim3(1), dim3(BLOCK), 0, st, d, m, d.bits_new);
+      cur = (int)(d.bits_new & 1u);
+    } else {
+      if (d.bits_new) AM355_LAUNCH_INDEPENDENT(kd_bit_flags, dgrid(m + 1), dim3(BLOCK), st, d, cur, m, d.bits_new - 1);
+      for (int bit = (int)d.bits_new - 1; bit >= 0; bit--) {
+        exclusive_scan2_u32(d.zf, d.zf_ex, nullptr, d.zw, d.zw_ex, nullptr, m + 1, d.scan_ws, st);
+        AM355_LAUNCH_INDEPENDENT(kd_partition, dgrid(m), dim3(BLOCK), st, d, cur, m, (uint32_t)bit);
+        cur ^= 1;
+      }
     }
     AM355_LAUNCH_INDEPENDENT(kd_edit_index, dgrid(m), dim3(BLOCK), st, b, d, cur, m);
   }

@@ -179,6 +179,7 @@ def test_campaign_sessions_emulated(emu_lib):
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=5, n_rounds=3, ins_per_change=12, del_per_change=5, n_objects=4), 5),
     (loggen.KIND_MAP_LWW, dict(n_actors=6, n_rounds=3, n_keys=60), 4),
     (loggen.KIND_TEXT_TYPING, dict(n_ops=500, ops_per_change=20), 6),
+    (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=8, n_rounds=4, ins_per_change=60, del_per_change=15, n_objects=2), 2),  # > 1024 edit items per batch: level-by-level partitions
 ])
 def test_generated_logs_in_batches_match_the_oracle_emulated(emu_lib, kind, kw, n_batches):
     log = loggen.generate(kind, seed=23, **kw)
