@@ -2061,7 +2061,9 @@ extern "C" int am355_get_applied(const am355_ctx* c, uint32_t* out, uint32_t* n_
   return AM355_OK;
 }
 
-static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
+// with_edits = false (am355_apply_changes): the object and map tables only -- the edit records of a text document are megabytes and
+// setupPatches looks at them only when a touched object hangs in a list (c->hir.edits stays null; a later full fetch copies all three)
+static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out, bool with_edits = true) {
   if (!c) return AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");
   (void)hipSetDevice(c->device);
@@ -2081,7 +2083,7 @@ static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
     h.n_objects = NO; h.n_map = NM; h.n_edits = NR; h.n_values = NV;
     h.objects = (const am355_ir_object*)pull(c->ir.obj, NO, sizeof(am355_ir_object));
     h.map = (const am355_ir_map*)pull(c->ir.map, NM, sizeof(am355_ir_map));
-    h.edits = (const am355_ir_edit*)pull(c->ir.edit, (size_t)NR + 1, sizeof(am355_ir_edit));
+    h.edits = with_edits ? (const am355_ir_edit*)pull(c->ir.edit, (size_t)NR + 1, sizeof(am355_ir_edit)) : nullptr;
     HIPCHK(c, hipStreamSynchronize(st));
     h.max_op = c->max_op;
     h.n_actors = (uint32_t)c->actors.size();
@@ -2101,7 +2103,7 @@ static int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out) {
     h.pending = c->n_pending;
     h.arena = c->raw.data();
     h.arena_len = c->raw.size();
-    c->ir_fetched = true;
+    c->ir_fetched = with_edits;
   }
   if (out) *out = c->hir;
   return AM355_OK;
@@ -2248,7 +2250,7 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   }
 
   // ---- tables to the host, setupPatches, assembly ----
-  rc = fetch_ir_impl(c, nullptr);
+  rc = fetch_ir_impl(c, nullptr, false);
   if (rc) return rc;
   lap("document tables on the host");
   const uint32_t n_dmap = hc.n_kept + hc.n_place, n_dedits = hc.n_erecs;
@@ -2269,6 +2271,13 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   if (hc.hazard) c->children_hazard = true;  // (this call skipped values of a property with a child object: later calls ask)
   for (int round = 0;; round++) {
     rc = assemble_apply_patch(c->hir, h_link, h_map, n_dmap, h_edit, n_dedits, known, ask_always, need, c->apply, err);
+    if (rc == AM355_E_UNSUPPORTED && need.empty() && !c->hir.edits && err == "edit records needed") {
+      // a touched object hangs in a list: setupPatches needs the whole-document edit records of that list
+      int frc = fetch_ir_impl(c, nullptr, true);
+      if (frc) return frc;
+      lap("document edit records on the host");
+      continue;
+    }
     if (rc != AM355_E_UNSUPPORTED || need.empty() || round == 16 || need.size() > 256 || c->no_history) break;
     // the walk met objects that are no longer visible: what the reference's objectMeta lists for their property follows from the
     // history of the rows on it (am355_delta.hip, delta_key_history)

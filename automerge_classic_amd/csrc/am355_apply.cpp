@@ -122,6 +122,7 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
           bool exists = (L.flags & OL_ELEM_NEW) != 0 || appended_elems.count(pk) != 0;
           bool none_visible = false;
           if (!exists) {
+            if (!whole.edits) { need.clear(); err = "edit records needed"; return AM355_E_UNSUPPORTED; }  // (the caller fetches them and calls again)
             auto it = elem_index.find(o);
             if (it == elem_index.end()) {
               auto& m = elem_index[o];

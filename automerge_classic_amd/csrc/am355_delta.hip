@@ -231,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void kd_upd_scatter(MergeBufs b, DeltaBufs d
 // overwritten at the time of its first successor -- before the batch if it has successors among the earlier rows, else at
 // first_del[r].
 __device__ __forceinline__ bool alive_at_T0(const MergeBufs& b, const DeltaBufs& d, uint32_t r) { return r >= d.T0 || b.succ_cnt[r] == d.new_succ[r]; }
-constexpr uint32_t ELEM_ROWS_MAX = 32;  // value rows of one element this stage walks (more: refused)
+constexpr uint32_t ELEM_ROWS_MAX = 1u << 16;  // value rows of one element this stage walks, one thread per op on it (more: refused)
 
 // the element's value rows visible just before / just after row g was applied
 __device__ __forceinline__ void elem_state(const MergeBufs& b, const DeltaBufs& d, uint32_t e, uint32_t g, uint32_t& before, uint32_t& after) {
@@ -286,7 +286,7 @@ __device__ __forceinline__ bool list_elem_op(const MergeBufs& b, uint32_t g) {
 // its op and the insert row of this one held a visible value: `list[1] = x` followed by the same actor's deletion of element 2
 // gives update@1, remove@1. Reproduced for removes (ev_lag); an update whose first value would sit at the lagging index and the
 // others not is refused.
-constexpr uint32_t GAP_WALK_MAX = 64;  // later insertions between two elements this stage walks over to decide whether they were neighbours
+constexpr uint32_t GAP_WALK_MAX = 4096;  // later insertions between two elements this stage walks over to decide whether they were neighbours
 
 __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
   uint32_t t = gtid();
@@ -530,7 +530,7 @@ __device__ __forceinline__ uint32_t continues_multi_insert(const MergeBufs& b, c
   return (tl != ptl || o.val_off[e] != o.val_off[pe] + (ptl >> 4)) ? 3u : 1u;
 }
 
-constexpr uint32_t POP_WALK_MAX = 64;  // update items at one index in a row this stage walks back over (more: refused)
+constexpr uint32_t POP_WALK_MAX = 1u << 16;  // update items at one index in a row the LAST of them walks back over (more: refused)
 
 __global__ __launch_bounds__(BLOCK) void kd_edit_runs(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
   uint32_t i = gtid();
