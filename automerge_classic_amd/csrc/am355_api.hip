@@ -259,6 +259,10 @@ struct am355_ctx {
   hipEvent_t ev_s1 = nullptr;          // the per-change digests (briefs) have arrived on the host
   hipEvent_t ev_plan = nullptr, ev_tables = nullptr;  // k_plan_apply done (stream4 copies the digests behind it) | host-built tables in HBM
   void* counts_zeroed_at = nullptr; size_t counts_zeroed = 0;  // the counter block was cleared beside stage 1 (address, bytes)
+  // AM355_PHASE_EVENTS=1: HIP events between the phases of a change replay (am355_stats.ms_parse / ms_decode / ms_merge / ms_order). Off by
+  // default: every event record between two kernels of the main stream is a packet of its own in front of the next dispatch.
+  bool phase_events = false;
+  bool inline_fills = true;  // AM355_STAGE1_FILLS=stream: the fills of stage 1 as memsets on stream3 (round-2 form) instead of inside k_parse_changes
   DevBuf d_big, d_bigvals, d_ks;     // document load: token / record index, column values, keyStr run table
   HostBuf h_biginfo;
   BigColDesc doc_cols{};
@@ -422,6 +426,8 @@ extern "C" am355_ctx* am355_create(int device) {
   if (hipEventCreate(&c->ev_plan) != hipSuccess || hipEventCreate(&c->ev_tables) != hipSuccess) { delete c; return nullptr; }
   if (!c->h_sig.ensure(sizeof(HostSignals))) { delete c; return nullptr; }
   memset(c->h_sig.p, 0, sizeof(HostSignals));
+  if (const char* e = getenv("AM355_PHASE_EVENTS")) c->phase_events = strcmp(e, "0") != 0;
+  if (const char* e = getenv("AM355_STAGE1_FILLS")) c->inline_fills = strcmp(e, "stream") != 0;
   return c;
 }
 
@@ -1561,7 +1567,7 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
 
   // ---- stage 2: merge (the decode flags land in the same counter block and are read with the first counters) ----
   Counts* hc = c->h_counts.as<Counts>();
-  merge_run(c->mb, c->ir, hc, st, c->ev_counts, c->ev_runs);
+  merge_run(c->mb, c->ir, hc, st, (c->phase_events || !c->mb.sig) ? c->ev_counts : nullptr, c->ev_runs);
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
   c->counts = *hc;
@@ -1602,12 +1608,12 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
     HIPCHK(c, hipEventRecord(c->ev_fork, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
   }
-  HIPCHK(c, hipEventRecord(c->ev[2], st));
+  if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[2], st));
   launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n,
                         tot.n_small, tot.n_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
                         &c->d_counts.as<Counts>()->flags, st, c->stream3);
   lap("decode launched");
-  HIPCHK(c, hipEventRecord(c->ev[3], st));
+  if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
   merge_prepare(c->mb, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -1635,7 +1641,7 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   }
   lap("tables enqueued");
   Counts* hc = c->h_counts.as<Counts>();
-  merge_run(c->mb, c->ir, hc, st, c->ev_counts, c->ev_runs);
+  merge_run(c->mb, c->ir, hc, st, (c->phase_events || !c->mb.sig) ? c->ev_counts : nullptr, c->ev_runs);
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
   c->counts = *hc;
@@ -1826,25 +1832,37 @@ static int replay_impl(am355_ctx* c) {
   // ---- stream A: parse. The fills of stage 1 (flag words, actor hash table) depend on nothing of this replay: they run on stream3
   //      beside the parse kernel instead of in front of the kernels that need them ----
   HIPCHK(c, hipEventRecord(c->ev[0], sa));
-  launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), sa);
-  HIPCHK(c, hipEventRecord(c->ev_parse, sa));
-  HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, c->stream3));
-  HIPCHK(c, hipMemsetAsync(d_wa, 0, s1_distinct + 16, c->stream3));
-  HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), c->stream3));
-  HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), c->stream3));
-  {
-    // the merge stage's counter block too: its size follows from the op count, which is at most one op per encoded byte for any
-    // batch worth hurrying (a run length may claim more: the planned path then clears it in front of the decode as before)
-    size_t cb = merge_counts_bytes((uint32_t)std::min<size_t>(c->raw.size(), 0x7ffffff0u));
-    c->counts_zeroed_at = nullptr;
-    if (c->d_counts.ensure(cb)) {
-      HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, cb, c->stream3));
-      c->counts_zeroed_at = c->d_counts.p;
-      c->counts_zeroed = cb;
-    }
+  // the merge stage's counter block too: its size follows from the op count, which is at most one op per encoded byte for any
+  // batch worth hurrying (a run length may claim more: the planned path then clears it in front of the decode as before)
+  const size_t cb = merge_counts_bytes((uint32_t)std::min<size_t>(c->raw.size(), 0x7ffffff0u));
+  c->counts_zeroed_at = nullptr;
+  const bool counts_too = c->d_counts.ensure(cb);
+  if (c->inline_fills) {
+    // (cleared by the parse kernel's workgroups on their way in: no second stream, no event wait in front of the next kernel)
+    ParseFills f{};
+    auto add = [&](void* q, size_t bytes, uint32_t v) { f.p[f.n] = (uint32_t*)q; f.n_words[f.n] = (bytes + 3) / 4; f.value[f.n] = v; f.n++; };
+    add(d_words, 4 * W_NUM, 0);
+    add(d_wa, s1_distinct + 16, 0);
+    add(c->d_slots.p, 8 * (size_t)(c->slot_mask + 1), 0);
+    add(c->d_first_idx.p, 4 * (size_t)(c->slot_mask + 1), 0xffffffffu);
+    if (counts_too) add(c->d_counts.p, cb, 0);
+    launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), f, sa);
+    HIPCHK(c, hipEventRecord(c->ev_parse, sa));
+  } else {
+    launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), ParseFills{}, sa);
+    HIPCHK(c, hipEventRecord(c->ev_parse, sa));
+    HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, c->stream3));
+    HIPCHK(c, hipMemsetAsync(d_wa, 0, s1_distinct + 16, c->stream3));
+    HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), c->stream3));
+    HIPCHK(c, hipMemsetAsync(c->d_first_idx.p, 0xff, 4 * (size_t)(c->slot_mask + 1), c->stream3));
+    if (counts_too) HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, cb, c->stream3));
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+    HIPCHK(c, hipStreamWaitEvent(sa, c->ev_join, 0));
   }
-  HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
-  HIPCHK(c, hipStreamWaitEvent(sa, c->ev_join, 0));
+  if (counts_too) {
+    c->counts_zeroed_at = c->d_counts.p;
+    c->counts_zeroed = cb;
+  }
 
   // ---- stream B: SHA-256 of every change, hash table, dependency resolution; joined at the very end. Its commands are enqueued
   //      behind the stage-1 kernels of stream A. AM355_HASH_ENQUEUE=early enqueues them right behind the parse launch, which starts
@@ -1854,7 +1872,7 @@ static int replay_impl(am355_ctx* c) {
     // (it starts after the parse kernel -- AM355_HASH_START=intern: after the actor kernels --: those grids are as small as the hash
     // grid, one wave per 64 changes, and the ALU-dense SHA waves would otherwise share their SIMDs and slow them down)
     HIPCHK(c, hipStreamWaitEvent(sb, hash_after_parse ? c->ev_parse : c->ev[1], 0));
-    HIPCHK(c, hipStreamWaitEvent(sb, c->ev_join, 0));  // (its flag words are cleared on stream3)
+    if (!c->inline_fills) HIPCHK(c, hipStreamWaitEvent(sb, c->ev_join, 0));  // (its flag words are cleared on stream3)
     HIPCHK(c, hipEventRecord(c->ev_b0, sb));
     HIPCHK(c, hipMemsetAsync(c->d_hash_tab.p, 0, 4 * (size_t)(c->hash_mask + 1), sb));
     HIPCHK(c, hipMemsetAsync(c->d_has_dep.p, 0, n1, sb));
@@ -1891,7 +1909,7 @@ static int replay_impl(am355_ctx* c) {
     HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_plan, 0));
     HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, c->stream4));
     HIPCHK(c, hipEventRecord(c->ev_s1, c->stream4));
-    HIPCHK(c, hipEventRecord(c->ev[1], sa));
+    if (c->phase_events || !hash_after_parse) HIPCHK(c, hipEventRecord(c->ev[1], sa));
     if (attempt == 0 && !(hash_after_parse && enqueue_early)) { int rb = enqueue_stream_b(); if (rb) return rb; }
     lap("stage 1 enqueued");
     if (!wait_host_signal(&sig->plan_seq, c->sig_seq, sa)) {
@@ -2008,10 +2026,12 @@ static int replay_impl(am355_ctx* c) {
                ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit);
   // (the last kernel has signalled its counters; its remaining workgroups retire within microseconds: poll, do not block)
   while (hipEventQuery(c->ev[5]) == hipErrorNotReady) {}
-  (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
-  s.ms_merge = s.ms_order = 0;
-  if (c->n_ops) {  // (ev_counts: after resolve / emit / compaction, before the ordering kernels)
+  s.ms_parse = s.ms_decode = s.ms_merge = s.ms_order = 0;
+  if (c->phase_events) {
+    (void)hipEventElapsedTime(&s.ms_parse, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&s.ms_decode, c->ev[2], c->ev[3]);
+  }
+  if (c->n_ops && c->phase_events) {  // (ev_counts: after resolve / emit / compaction, before the ordering kernels)
     (void)hipEventElapsedTime(&s.ms_merge, c->ev[3], c->ev_counts);
     (void)hipEventElapsedTime(&s.ms_order, c->ev_counts, c->ev[5]);
   }
@@ -2026,6 +2046,12 @@ static int replay_impl(am355_ctx* c) {
     c->children_hazard = false;
     c->no_history = false;
   }
+  return AM355_OK;
+}
+
+extern "C" int am355_set_phase_events(am355_ctx* c, int on) {
+  if (!c) return AM355_E_ARG;
+  c->phase_events = on != 0;
   return AM355_OK;
 }
 

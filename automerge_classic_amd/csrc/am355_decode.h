@@ -3,7 +3,15 @@
 #include "am355_internal.h"
 
 namespace am355 {
-void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, hipStream_t st);
+// word ranges k_parse_changes clears on its way in (value per range); n = 0: none
+struct ParseFills {
+  uint32_t* p[5];
+  uint64_t n_words[5];
+  uint32_t value[5];
+  uint32_t n;
+};
+void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, const ParseFills& fills,
+                          hipStream_t st);
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
                          uint32_t tab_mask, uint32_t* flags, hipStream_t st);
 void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,

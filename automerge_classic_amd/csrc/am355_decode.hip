@@ -13,6 +13,7 @@
 // execute the same decoder. All arithmetic is integer/byte work; the kernels stream the encoded bytes once
 // and write each fixed-width field once.
 #include "am355_decode.h"
+#include "am355_scan.h"
 
 #include <cstdlib>
 
@@ -399,19 +400,186 @@ __device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len6
   *n_entries_out = m.flags ? 0 : m.n_entries;
 }
 
-// (Four changes per wavefront -- four lanes parsing four staged changes in lockstep -- was measured and dropped: the kernel is bound
-// by the dependent chain of one change, not by instruction issue (57 us either way on the 1 M-op log), and changes of different
-// shape make the lanes diverge, which cost the map workload (few, fat changes with different keys) 0.12 ms per replay.)
+// ---- the header of a staged change by the whole wavefront --------------------------------------------------------------------
+// The lane-serial parse above is ~150 dependent LDS reads behind ~4500 instructions of one lane, and a wavefront costs its SIMD the
+// same four cycles per instruction whatever the number of active lanes: 4 k changes x 4500 instructions were the 50 us of this
+// kernel. Here the 64 lanes look at a 64-byte window at once: the terminator bytes (< 0x80) of the LEB128 numbers come from one
+// ballot, the lane that holds the terminator of token r decodes it (encoding.js:389-408, same range rules) and leaves value, end and
+// validity in LDS for everybody. The header is five such windows (chunk length + dependency count | actor length | seq, startOp,
+// time, message length | number of other actors | column directory), the other-actor table is checked for the uniform 16-byte ids
+// in one step, and the two run-level column walks (row and pred counts) run on two lanes side by side.
+// ANY irregularity -- a malformed or oversized number, actor ids of another length, a directory that does not fit one window, a
+// rule violation -- makes this return false and lane 0 parse the change with parse_change(), which alone decides the flags.
+struct TokScratch {
+  uint64_t v[WAVE];
+  uint8_t end[WAVE];  // bytes of the window consumed up to and including the token
+  uint8_t ok[WAVE];
+  uint32_t col_off[C_NUM], col_len[C_NUM];
+  uint32_t unknown;
+};
+
+template <class P>
+__device__ __forceinline__ uint32_t wave_tokenize(P p, uint32_t off, uint32_t len, uint32_t lane, uint64_t signed_mask, TokScratch& S) {
+  __syncthreads();  // (one wavefront per workgroup: orders the previous window's reads before this one's writes)
+  uint32_t pos = off + lane;
+  uint32_t b = pos < len ? (uint32_t)p[pos] : 0x80u;
+  uint64_t term = __ballot(b < 0x80);
+  if (b < 0x80) {
+    uint64_t below = term & ((1ull << lane) - 1);
+    uint32_t r = (uint32_t)__popcll(below);
+    uint32_t start = below ? 64u - (uint32_t)__clzll(below) : 0u;
+    bool sg = (signed_mask >> r) & 1, ok = true;
+    uint64_t v = 0;
+    int shift = 0;
+    uint32_t bb = 0;
+    for (uint32_t k = start; k <= lane; k++) {
+      bb = p[off + k];
+      if (shift == 63 && (sg ? (bb != 0 && bb != 0x7f) : (bb & 0xfe) != 0)) { ok = false; break; }
+      v |= (uint64_t)(bb & 0x7f) << shift;
+      shift += 7;
+    }
+    if (ok) {
+      if (sg) {
+        if ((bb & 0x40) && shift < 64) v |= ~0ull << shift;
+        int64_t s = (int64_t)v;
+        ok = s <= (int64_t)MAX_SAFE && s >= -(int64_t)MAX_SAFE;
+      } else ok = v <= MAX_SAFE;
+    }
+    S.v[r] = v;
+    S.end[r] = (uint8_t)(lane + 1);
+    S.ok[r] = ok;
+  }
+  __syncthreads();
+  return (uint32_t)__popcll(term);
+}
+
+template <class P>
+__device__ __forceinline__ bool parse_change_wave(P p, uint64_t base64, uint64_t len64, ChangeMeta* out, uint32_t* n_entries_out, uint32_t lane,
+                                                  TokScratch& S) {
+  if (len64 > 0xfffffff0ull || len64 < 10) return false;
+  const uint32_t len = (uint32_t)len64;
+  if (p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83 || p[8] != 1) return false;
+  // window 1: chunk length, number of dependencies
+  uint32_t off = 9;
+  uint32_t n = wave_tokenize(p, off, len, lane, 0, S);
+  if (n < 2 || !S.ok[0] || !S.ok[1]) return false;
+  if (S.v[0] != (uint64_t)(len - (off + S.end[0]))) return false;
+  uint64_t n_deps = S.v[1];
+  off += S.end[1];
+  const uint32_t deps_off = off;
+  if (n_deps > (uint64_t)(len - off) / 32) return false;
+  off += (uint32_t)n_deps * 32;
+  // window 2: length of the author's id
+  n = wave_tokenize(p, off, len, lane, 0, S);
+  if (n < 1 || !S.ok[0]) return false;
+  uint64_t actor_len = S.v[0];
+  off += S.end[0];
+  const uint32_t actor_off = off;
+  if (actor_len > (uint64_t)(len - off) || actor_len >= 65536) return false;
+  off += (uint32_t)actor_len;
+  // window 3: seq, startOp, time (signed), message length
+  n = wave_tokenize(p, off, len, lane, 1ull << 2, S);
+  if (n < 4 || !S.ok[0] || !S.ok[1] || !S.ok[2] || !S.ok[3]) return false;
+  const uint64_t seq = S.v[0], start_op = S.v[1], msg_len = S.v[3];
+  off += S.end[3];
+  if (msg_len > (uint64_t)(len - off)) return false;
+  off += (uint32_t)msg_len;
+  // window 4: number of other actors, then their table
+  n = wave_tokenize(p, off, len, lane, 0, S);
+  if (n < 1 || !S.ok[0]) return false;
+  uint64_t n_other = S.v[0];
+  off += S.end[0];
+  const uint32_t others_off = off;
+  if (n_other > (uint64_t)(len - off) / 17) return false;  // (ids of other lengths: serial walk)
+  bool uniform = true;
+  for (uint32_t k = lane; k < (uint32_t)n_other; k += WAVE) uniform = uniform && p[off + 17 * k] == 16;
+  if (__ballot(!uniform)) return false;
+  off += 17 * (uint32_t)n_other;
+  // window 5: number of columns and the (id, length) directory
+  n = wave_tokenize(p, off, len, lane, 0, S);
+  if (n < 1 || !S.ok[0]) return false;
+  const uint64_t ncols = S.v[0];
+  if (ncols > 31 || n < 1 + 2 * (uint32_t)ncols) return false;
+  const uint32_t nc = (uint32_t)ncols;
+  const uint32_t dir_end = off + S.end[2 * nc];
+  bool good = true;
+  uint64_t id = 0, l = 0;
+  if (lane < nc) {
+    id = S.v[1 + 2 * lane];
+    l = S.v[2 + 2 * lane];
+    good = S.ok[1 + 2 * lane] && S.ok[2 + 2 * lane] && !(id & 8) && l <= (uint64_t)len;
+    if (lane > 0 && S.v[2 * lane - 1] >= id) good = false;  // ids strictly ascending (no deflate bit on either: plain comparison)
+  }
+  if (__ballot(!good)) return false;
+  uint32_t incl = wave_incl_scan_u32((uint32_t)l, lane);  // (l <= len < 2^32 each, at most 31 of them: the sum is checked in 64 bits below)
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nc; k++) total += S.v[2 + 2 * k];
+  if (total > (uint64_t)(len - dir_end)) return false;
+  __syncthreads();
+  if (lane < C_NUM) S.col_off[lane] = S.col_len[lane] = 0;
+  if (lane == 0) S.unknown = 0;
+  __syncthreads();
+  if (lane < nc) {
+    int s = col_slot(id);
+    if (s >= 0) { S.col_off[s] = dir_end + incl - (uint32_t)l; S.col_len[s] = (uint32_t)l; }
+    else if (l) S.unknown = 1;
+  }
+  __syncthreads();
+  // rows = values of the action column, preds = sum of the predNum column: two lanes, one column each
+  uint64_t cnt = 0, sum = 0;
+  bool rle_ok = true;
+  if (lane < 2) {
+    int s = lane == 0 ? C_ACTION : C_PRED_NUM;
+    rle_ok = rle_count_sum(p + S.col_off[s], S.col_len[s], cnt, sum);
+  }
+  if (__ballot(!rle_ok)) return false;
+  const uint64_t n_ops = __shfl(cnt, 0), n_preds = __shfl(sum, 1);
+  if (start_op + n_ops > 0xfffffff0ull) return false;
+  if (lane < C_NUM) { out->col_off[lane] = S.col_off[lane]; out->col_len[lane] = S.col_len[lane]; }
+  if (lane == 0) {
+    out->base = base64;
+    out->len = len;
+    out->flags = 0;
+    out->seq = seq;
+    out->start_op = start_op;
+    out->n_entries = (uint32_t)n_other + 1;
+    out->author_slot = out->max_first = NONE32;
+    out->pad = S.unknown;
+    out->n_deps = (uint32_t)n_deps;
+    out->deps_off = deps_off;
+    out->actor_off = actor_off;
+    out->actor_len = (uint32_t)actor_len;
+    out->n_other = (uint32_t)n_other;
+    out->others_off = others_off;
+    out->n_ops = (uint32_t)n_ops;
+    out->n_preds = (uint32_t)n_preds;
+    *n_entries_out = (uint32_t)n_other + 1;
+  }
+  return true;
+}
+
+// (Four changes per wavefront -- four lanes parsing four staged changes in lockstep -- was measured and dropped in round 2: changes of
+// different shape make the lanes diverge, which cost the map workload (few, fat changes with different keys) 0.12 ms per replay.)
+// `fills`: word ranges the kernels behind this one expect cleared (flag words, the actor hash table, the merge stage's counter block).
+// They depend on nothing of the replay; as fills on a stream of their own they cost the main stream an event wait in front of the
+// next kernel -- here every workgroup clears a slice on its way in (a few hundred bytes each).
 __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
-                                                         uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries) {
+                                                         uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries, ParseFills fills) {
   __shared__ alignas(16) uint8_t stage[PARSE_STAGE];
+  __shared__ TokScratch scratch;
   wave_priority_high();
   uint32_t c = blockIdx.x, lane = threadIdx.x;
+  for (uint32_t r = 0; r < fills.n; r++) {
+    uint32_t* __restrict__ q = fills.p[r];
+    const uint32_t v = fills.value[r];
+    for (uint64_t w = (uint64_t)c * WAVE + lane; w < fills.n_words[r]; w += (uint64_t)gridDim.x * WAVE) q[w] = v;
+  }
   if (c >= n_changes) return;
   uint64_t base64 = offsets[c], total64 = offsets[c + 1] - offsets[c];
   bool staged = total64 <= PARSE_STAGE;
   if (staged) stage_to_lds(stage, arena + base64, (uint32_t)total64, lane);
   __syncthreads();
+  if (staged && parse_change_wave((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c], lane, scratch)) return;
   if (lane != 0) return;
   // two instantiations so that the staged case reads LDS with ds_read instead of FLAT loads through a generic pointer
   if (staged) parse_change((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c]);
@@ -1717,9 +1885,10 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   if (err) atomicOr(flags, err);
 }
 
-void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, hipStream_t st) {
-  if (!n_changes) return;
-  hipLaunchKernelGGL(k_parse_changes, dim3(n_changes), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries);
+void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, const ParseFills& fills,
+                          hipStream_t st) {
+  if (!n_changes && !fills.n) return;
+  hipLaunchKernelGGL(k_parse_changes, dim3(n_changes ? n_changes : 64), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries, fills);
 }
 
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,

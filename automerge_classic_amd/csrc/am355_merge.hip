@@ -349,10 +349,9 @@ __global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* __restrict__ v, uint32
   if (i < n) v[i] = i;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_t* __restrict__ perm, uint32_t n, PatchIR ir) {
-  uint32_t i = gtid();
-  if (i >= n) return;
-  uint32_t e = perm[i], g = b.em_row[e];
+// one map emission: its record at output position i (e = emission at i, e_prev / e_next = its neighbours in output order, NONE32 at the ends)
+__device__ __forceinline__ void map_finish_one(const MergeBufs& b, const PatchIR& ir, uint32_t i, uint32_t e, uint32_t e_prev, uint32_t e_next) {
+  uint32_t g = b.em_row[e];
   const OpCols& o = b.ops;
   uint32_t a = o.action[g];
   uint32_t flags = 0;
@@ -368,10 +367,29 @@ __global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_
   ir.map[i] = am355_ir_map{o.id_ctr[g], o.id_actor[g], o.key_off[g], o.key_len[g], o.val_tl[g], (flags & AM355_MAP_CHILD) ? b.obj_index[g] : o.val_off[g],
                            flags, 0, counter};
   uint32_t oi = obj_index_of(b, b.obj_row[g]);
-  uint32_t prev = i > 0 ? obj_index_of(b, b.obj_row[b.em_row[perm[i - 1]]]) : NONE32;
-  uint32_t next = i + 1 < n ? obj_index_of(b, b.obj_row[b.em_row[perm[i + 1]]]) : NONE32;
+  uint32_t prev = e_prev != NONE32 ? obj_index_of(b, b.obj_row[b.em_row[e_prev]]) : NONE32;
+  uint32_t next = e_next != NONE32 ? obj_index_of(b, b.obj_row[b.em_row[e_next]]) : NONE32;
   if (oi != prev) ir.obj[oi].map_begin = i;
   if (oi != next) ir.obj[oi].map_end = i + 1;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_t* __restrict__ perm, uint32_t n, PatchIR ir) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  map_finish_one(b, ir, i, perm[i], i > 0 ? perm[i - 1] : NONE32, i + 1 < n ? perm[i + 1] : NONE32);
+}
+
+// up to BLOCK emissions (a text document's root map: one): ranks by comparison and the records, one workgroup, one launch
+__global__ __launch_bounds__(BLOCK) void k_map_small_finish(MergeBufs b, uint32_t n, PatchIR ir) {
+  __shared__ uint32_t s_perm[BLOCK];
+  uint32_t i = threadIdx.x;
+  if (i < n) {
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) rank += map_emission_less(b, j, i, nullptr) ? 1u : 0u;
+    s_perm[rank] = i;
+  }
+  __syncthreads();
+  if (i < n) map_finish_one(b, ir, i, s_perm[i], i > 0 ? s_perm[i - 1] : NONE32, i + 1 < n ? s_perm[i + 1] : NONE32);
 }
 
 static int bits_for(uint64_t max_value) {
@@ -621,6 +639,10 @@ __global__ __launch_bounds__(EULER_LDS_THREADS) void k_euler_rank_lds(Counts* __
   if (t == 0) counts->euler_done = 1;
 }
 
+// (Round 3 tried ranking by splitters instead -- one entry in eight walks to the next splitter, the splitters are ranked by pointer
+// jumping, the stretches are walked again: a third of the LDS traffic, and SLOWER on the headline tour of 16 k entries, 40.7 us against
+// 36.2 us (profiles/r03_ab_euler_rank.txt): the walks of a wavefront last as long as its longest one (62 steps where the average is 8)
+// and sixteen wavefronts of such lane-divergent loops are bound by instruction issue, not by LDS bandwidth.)
 // one pointer-jumping round over a tour in HBM (tours beyond the LDS kernel)
 __global__ __launch_bounds__(BLOCK) void k_euler_jump(uint32_t n_runs, const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out) {
   uint32_t x = gtid();
@@ -636,30 +658,69 @@ __global__ __launch_bounds__(BLOCK) void k_euler_jump(uint32_t n_runs, const uns
 }
 
 // elements per list object = weight of the tour from its first head child to the end of its tree; entry n_obj is 0 (prefix sum)
-__global__ __launch_bounds__(BLOCK) void k_obj_n(MergeBufs b, PatchIR ir, uint32_t n_obj, const uint32_t* __restrict__ row_run,
-                                                 const unsigned long long* __restrict__ el) {
-  uint32_t oi = gtid();
-  if (oi > n_obj) return;
+__device__ __forceinline__ uint32_t obj_elems(const MergeBufs& b, const PatchIR& ir, uint32_t n_obj, const uint32_t* __restrict__ row_run,
+                                              const unsigned long long* __restrict__ el, uint32_t oi) {
   uint32_t c = 0;
   if (oi > 0 && oi < n_obj) {
     uint32_t fc = b.first_child[b.n_ops + ir.obj[oi].make_row];
     if (fc != NONE32) c = (uint32_t)(el[2 * (size_t)row_run[fc]] >> 32);
   }
-  b.obj_n[oi] = c;
+  return c;
+}
+__global__ __launch_bounds__(BLOCK) void k_obj_n(MergeBufs b, PatchIR ir, uint32_t n_obj, const uint32_t* __restrict__ row_run,
+                                                 const unsigned long long* __restrict__ el) {
+  uint32_t oi = gtid();
+  if (oi > n_obj) return;
+  b.obj_n[oi] = obj_elems(b, ir, n_obj, row_run, el, oi);
 }
 
+// element i of the compacted insert list -> its place in document order (n_o / first: element count and first position of its object)
+__device__ __forceinline__ void list_order_one(const MergeBufs& b, uint32_t n, uint32_t i, uint32_t k, uint32_t head_i, uint32_t d, uint32_t n_o, uint32_t first) {
+  uint32_t within = i - head_i;
+  uint32_t pos = first + n_o - d + within;
+  if (d == 0 || d > n_o || within >= d || pos >= n) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
+  b.order[pos] = b.ins_row[i];
+}
 __global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, const uint32_t* __restrict__ is_head, const uint32_t* __restrict__ head_ex,
                                                       const uint32_t* __restrict__ heads, const unsigned long long* __restrict__ el) {
   uint32_t i = gtid();
   if (i >= n) return;
   uint32_t k = head_ex[i] + is_head[i] - 1;  // i = 0 is always a head
   uint32_t d = (uint32_t)(el[2 * (size_t)k] >> 32);  // elements from the run's first one to the end of its object's tour, inclusive
-  uint32_t within = i - heads[k];
-  uint32_t v = b.ins_row[i], oi = obj_index_of(b, b.obj_row[v]);
-  uint32_t n_o = b.obj_n[oi];
-  uint32_t pos = b.obj_first_pos[oi] + n_o - d + within;
-  if (d == 0 || d > n_o || within >= d || pos >= n) { atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM); return; }
-  b.order[pos] = v;
+  uint32_t oi = obj_index_of(b, b.obj_row[b.ins_row[i]]);
+  list_order_one(b, n, i, k, heads[k], d, b.obj_n[oi], b.obj_first_pos[oi]);
+}
+
+// k_obj_n + the prefix sum over the objects + k_list_order in one launch, for documents of up to OBJ_LDS_MAX objects: every workgroup
+// works the (few) object counts and their prefix sum out for itself in LDS -- three dependent loads per object -- instead of two more
+// launches in front of it; workgroup 0 leaves obj_n / obj_first_pos in HBM for the kernels behind.
+constexpr uint32_t OBJ_LDS_MAX = 1023;
+__global__ __launch_bounds__(BLOCK) void k_list_order_objs(MergeBufs b, PatchIR ir, uint32_t n_obj, uint32_t n, const uint32_t* __restrict__ is_head,
+                                                           const uint32_t* __restrict__ head_ex, const uint32_t* __restrict__ heads,
+                                                           const uint32_t* __restrict__ row_run, const unsigned long long* __restrict__ el) {
+  __shared__ uint32_t s_n[OBJ_LDS_MAX + 1], s_first[OBJ_LDS_MAX + 1], s_red[BLOCK / WAVE];
+  // (the element's own loads first: they are in flight while the object table is worked out)
+  uint32_t i = gtid();
+  uint32_t k = 0, d = 0, oi = 0, head_i = 0;
+  if (i < n) {
+    k = head_ex[i] + is_head[i] - 1;
+    d = (uint32_t)(el[2 * (size_t)k] >> 32);
+    head_i = heads[k];
+    oi = obj_index_of(b, b.obj_row[b.ins_row[i]]);
+  }
+  for (uint32_t o = threadIdx.x; o <= n_obj; o += BLOCK) s_n[o] = obj_elems(b, ir, n_obj, row_run, el, o);
+  __syncthreads();
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base <= n_obj; base += BLOCK) {
+    uint32_t o = base + threadIdx.x, total;
+    uint32_t ex = block_exclusive_scan_u32(o <= n_obj ? s_n[o] : 0u, s_red, &total);
+    if (o <= n_obj) s_first[o] = carry + ex;
+    carry += total;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (uint32_t o = threadIdx.x; o <= n_obj; o += BLOCK) { b.obj_n[o] = s_n[o]; b.obj_first_pos[o] = s_first[o]; }
+  if (i < n) list_order_one(b, n, i, k, head_i, d, s_n[oi], s_first[oi]);
 }
 
 // per list position: visibility and edit counts, scanned by k_list_scan through the carried sums published here
@@ -1053,6 +1114,10 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
                   : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, begin_bit, bits, b.sort_ws, st);
     cur ^= res;
   };
+  if (ne <= BLOCK) {
+    hipLaunchKernelGGL(k_map_small_finish, dim3(1), dim3(BLOCK), 0, st, b, ne, ir);
+    return;
+  }
   if (ne <= MAP_SORT_SMALL) {
     AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(ne), dim3(BLOCK), st, b, ne, (const uint32_t*)nullptr, perm_b);  // (one emission: rank 0)
     cur = 1;
@@ -1096,7 +1161,7 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_compact_rows, grid_for(N), dim3(BLOCK), 0, st, b, ir);
   if (!b.sig) (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
-  (void)hipEventRecord(ev_counts, st);  // (also the boundary between the merge and the order phase in the statistics)
+  if (ev_counts) (void)hipEventRecord(ev_counts, st);  // (also the boundary between the merge and the order phase in the statistics; null: not wanted)
   // ---- lists, first half: launched for the worst case (every row an insert) with the real count read on the device, so the
   //      host does not have to wait for the counters before the device has more work ----
   hipLaunchKernelGGL(k_child_push, grid_for(N), dim3(BLOCK), 0, st, b);
@@ -1156,9 +1221,14 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
       el = e0;
     }
     // objects laid out one after another: elements per object from the ranked tour, prefix sum
-    AM355_LAUNCH_INDEPENDENT(k_obj_n, grid_for(n_obj + 1), dim3(BLOCK), st, b, ir, n_obj, (const uint32_t*)row_run, el);
-    exclusive_scan_u32(b.obj_n, b.obj_first_pos, n_obj + 1, nullptr, b.scan_ws, st);
-    AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex, (const uint32_t*)heads, el);
+    if (n_obj <= OBJ_LDS_MAX) {
+      hipLaunchKernelGGL(k_list_order_objs, grid_for(ni), dim3(BLOCK), 0, st, b, ir, n_obj, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex,
+                         (const uint32_t*)heads, (const uint32_t*)row_run, el);
+    } else {
+      AM355_LAUNCH_INDEPENDENT(k_obj_n, grid_for(n_obj + 1), dim3(BLOCK), st, b, ir, n_obj, (const uint32_t*)row_run, el);
+      exclusive_scan_u32(b.obj_n, b.obj_first_pos, n_obj + 1, nullptr, b.scan_ws, st);
+      AM355_LAUNCH_INDEPENDENT(k_list_order, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex, (const uint32_t*)heads, el);
+    }
     // visibility / edit-count prefix sums over document order
     uint32_t* vis_ex = b.scan_a;
     uint32_t* cnt_ex = b.scan_b;

@@ -95,9 +95,10 @@ def _bind(path):
     L.am355_sync_bloom_probe.argtypes = [vp, vp, u32, u32, u32, u32, vp, ctypes.c_size_t, vp]
     L.am355_get_pending.argtypes = [vp, vp, ctypes.POINTER(u32)]
     L.am355_forget_call_history.argtypes = [vp, ctypes.c_int]
+    L.am355_set_phase_events.argtypes = [vp, ctypes.c_int]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
-              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_forget_call_history", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
+              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_forget_call_history", "am355_set_phase_events", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -116,10 +117,16 @@ class Engine:
 
     def __init__(self, device=0, lib_path=DEFAULT_LIB):
         self._L = load_library(lib_path)
+        self.device = device
+        self.lib_path = lib_path
         self._h = self._L.am355_create(device)
         if not self._h:
             raise RuntimeError("am355_create failed: no usable MI355X / HIP device (the engine has no CPU fallback)")
         self._n_changes = 0
+
+    def set_phase_events(self, on):
+        """Measurement switch (am355_set_phase_events): HIP events between the phases of the following replays."""
+        self._check(self._L.am355_set_phase_events(self._h, 1 if on else 0))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -181,6 +181,29 @@ def phase_table(phases, st, n_preds):
     return out
 
 
+def measure_phases(w, steps, sync):
+    """Per-phase device times (am355_stats.ms_*): a few replays of the staged input with the HIP events between the phases switched on
+    (am355_set_phase_events). They are packets of their own in front of the next kernel, so the timed regions run without them."""
+    eng = w.eng
+    eng.set_phase_events(True)
+    try:
+        w.stage()
+        for _ in range(3):
+            eng.replay()
+        steps = max(1, min(steps, 30))
+        parts = {k: 0.0 for k in PHASES}
+        sync()
+        for _ in range(steps):
+            eng.replay()
+            s = eng.stats()
+            for k in parts:
+                parts[k] += getattr(s, k)
+        sync()
+    finally:
+        eng.set_phase_events(False)
+    return {k: v / steps for k, v in parts.items()}
+
+
 def run_workload(w, steps, warmup, sync, want_rows=True):
     eng = w.eng
     for _ in range(warmup):
@@ -191,16 +214,9 @@ def run_workload(w, steps, warmup, sync, want_rows=True):
     w.stage()
     for _ in range(min(warmup, 3)):
         w.step_device()
-    parts = {k: 0.0 for k in PHASES}
-
-    def dev():
-        eng.replay()
-        s = eng.stats()
-        for k in parts:
-            parts[k] += getattr(s, k)
-    t_device = timed(dev, steps, sync)
+    t_device = timed(eng.replay, steps, sync)
     st = eng.stats()
-    phases = {k: v / steps for k, v in parts.items()}
+    phases = measure_phases(w, steps, sync)
     n_preds = int(eng.rows()["pred_num"].sum()) if want_rows else 0
     return {"t_replay_s": t_replay, "t_device_s": t_device, "stats": st, "phases": phases, "n_preds": n_preds}
 
@@ -354,15 +370,9 @@ def main():
     w.stage()
     for _ in range(3):
         w.step_device()
-    parts = {k: 0.0 for k in PHASES}
-
-    def dev():
-        eng.replay()
-        s = eng.stats()
-        for k in parts:
-            parts[k] += getattr(s, k)
-    t_dev = timed(dev, args.steps, barrier)
+    t_dev = timed(eng.replay, args.steps, barrier)
     t_dev, _ = dist_util.aggregate(t_dev, 0.0, dist, torch.device("cuda", local_rank))
+    phases = measure_phases(w, args.steps, lambda: torch.cuda.synchronize())  # (its own context, HIP events between the phases: not timed)
     sharded = None
     if world > 1 and not args.no_shard:
         sharded = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), max(5, min(args.steps // 2, 30)), 3, barrier)
@@ -371,7 +381,6 @@ def main():
             dist.destroy_process_group()
         return
     st = eng.stats()
-    phases = {k: v / args.steps for k, v in parts.items()}
     value = total_ops / elapsed
     t_device_ms = t_dev / args.steps * 1e3
     n_preds = int(eng.rows()["pred_num"].sum())

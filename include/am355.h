@@ -93,12 +93,18 @@ typedef struct {
   uint64_t raw_bytes;    /* bytes of the staged (uncompressed) changes */
   uint64_t n_map_values, n_list_elems, n_edits;
   uint64_t ir_bytes;     /* bytes of patch IR produced in HBM by the last replay */
-  /* timing of the last am355_replay (milliseconds; device figures from HIP events on the engine's stream) */
+  /* timing of the last am355_replay (milliseconds; device figures from HIP events on the engine's stream). ms_parse / ms_decode /
+     ms_merge / ms_order are measured only by a context created with AM355_PHASE_EVENTS=1 in the environment (else 0): an event
+     record between two kernels is a packet of its own in front of the next dispatch, i.e. microseconds of the replay itself. */
   float ms_total, ms_parse, ms_host_schedule, ms_decode, ms_merge, ms_order;
   float ms_hash_stream;  /* SHA-256 + dependency resolution on the second stream (overlaps decode/merge) */
   uint32_t fast_path;    /* 1: in-order fast path (device-verified), 0: general host scheduler */
 } am355_stats;
 int am355_get_stats(const am355_ctx *ctx, am355_stats *out);
+/* Measurement switch: on != 0 makes the following replays record HIP events between their phases (ms_parse / ms_decode / ms_merge /
+ * ms_order of am355_stats); 0 (the default, unless AM355_PHASE_EVENTS=1 is in the environment at am355_create) leaves them out of the
+ * stream and reports those four as 0. No counterpart in the reference. */
+int am355_set_phase_events(am355_ctx *ctx, int on);
 
 /* 32-byte SHA-256 change hashes in input order (columnar.js:693-705). `out` holds 32 * n_changes bytes. */
 int am355_get_hashes(const am355_ctx *ctx, uint8_t *out);
