@@ -878,6 +878,7 @@ __device__ void rank_actors(const uint8_t* __restrict__ arena, const uint32_t* _
 __global__ __launch_bounds__(WAVE) void k_actor_first(ChangeMeta* __restrict__ metas, uint32_t n, const uint32_t* __restrict__ amap_base,
                                                        const uint32_t* __restrict__ amap, uint32_t amap_cap, const uint32_t* __restrict__ first_idx,
                                                        uint32_t* __restrict__ fast_flags) {
+  wave_priority_high();
   uint32_t c = blockIdx.x, lane = threadIdx.x;
   if (c >= n) return;
   ChangeMeta* m = &metas[c];
@@ -902,6 +903,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_first(ChangeMeta* __restrict__ m
 // one workgroup: lexicographic ranks of the distinct actor ids
 __global__ __launch_bounds__(BLOCK) void k_rank_actors(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
                                                        uint32_t* __restrict__ plan_words) {
+  wave_priority_high();
   rank_actors(arena, distinct, slot_rank, plan_words);
 }
 
@@ -910,6 +912,7 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
                                                        const uint32_t* __restrict__ first_idx, uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags,
                                                        ChangeBrief* __restrict__ briefs, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
                                                        unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words) {
+  wave_priority_high();
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
   uint32_t c = gtid();
   const bool in_range = c < n;
@@ -964,6 +967,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_apply(const ChangeBrief* __restr
                                                       const unsigned long long* __restrict__ block_sums, ChangePlan* __restrict__ plans,
                                                       ChangePlan* __restrict__ plans_serial, const uint32_t* __restrict__ words, const uint32_t* __restrict__ plan_words,
                                                       const uint32_t* __restrict__ distinct, HostSignals* sig, uint32_t seq) {
+  wave_priority_high();
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
   __shared__ unsigned long long s_base[6];
   // sums of the workgroups before this one (L2 hits: a few words per workgroup)

@@ -51,6 +51,7 @@ __device__ __forceinline__ bool int_value(const MergeBufs& b, uint32_t row, long
 // k_resolve: one lane per op row.  Object / element / pred resolution and validation, succ counting.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
+  wave_priority_high();
   uint32_t g = gtid();
   const bool in_range = g < b.n_ops;
   const OpCols& o = b.ops;
@@ -183,6 +184,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 }
 
 __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t g = gtid();
   const OpCols& o = b.ops;
@@ -255,6 +257,7 @@ __device__ __forceinline__ void object_table_entry(const MergeBufs& b, const Pat
 
 // consumer of k_emit's carried scans: list insert rows -> dense list (ins_row), make rows -> object table (index 0 = _root)
 __global__ __launch_bounds__(BLOCK) void k_compact_rows(MergeBufs b, PatchIR ir) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t g = gtid();
   bool in_range = g < b.n_ops;
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_
 
 // up to BLOCK emissions (a text document's root map: one): ranks by comparison and the records, one workgroup, one launch
 __global__ __launch_bounds__(BLOCK) void k_map_small_finish(MergeBufs b, uint32_t n, PatchIR ir) {
+  wave_priority_high();
   __shared__ uint32_t s_perm[BLOCK];
   uint32_t i = threadIdx.x;
   if (i < n) {
@@ -461,6 +465,7 @@ constexpr uint32_t HEAD_CHILD_MAX = 2048;
 constexpr uint32_t HEAD_CHILD_THREADS = 1024;
 
 __global__ __launch_bounds__(BLOCK) void k_child_push(MergeBufs b) {
+  wave_priority_high();
   uint32_t i = gtid();
   bool in_range = i < b.counts->n_list_ins;
   uint32_t v = in_range ? b.ins_row[i] : 0;
@@ -472,6 +477,7 @@ __global__ __launch_bounds__(BLOCK) void k_child_push(MergeBufs b) {
 
 // one workgroup: sibling links of all head children (siblings in DESCENDING op id, per list object)
 __global__ __launch_bounds__(HEAD_CHILD_THREADS) void k_head_children(MergeBufs b) {
+  wave_priority_high();
   __shared__ unsigned long long s_id[HEAD_CHILD_MAX];
   __shared__ uint32_t s_obj[HEAD_CHILD_MAX], s_row[HEAD_CHILD_MAX];
   const uint32_t n = b.counts->n_head_children;
@@ -508,6 +514,7 @@ __global__ __launch_bounds__(HEAD_CHILD_THREADS) void k_head_children(MergeBufs 
 // FROM_LINKS: first_child / next_sib were produced by the radix path; only the run flags are computed here.
 template <bool FROM_LINKS>
 __global__ __launch_bounds__(BLOCK) void k_child_order(MergeBufs b, uint32_t* __restrict__ is_head) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   const uint32_t ni = b.counts->n_list_ins;
   if (blockIdx.x * BLOCK >= ni) return;  // (whole workgroup)
@@ -557,6 +564,7 @@ __global__ __launch_bounds__(BLOCK) void k_child_order(MergeBufs b, uint32_t* __
 // a parent is always a tail)
 __global__ __launch_bounds__(BLOCK) void k_run_heads(MergeBufs b, const uint32_t* __restrict__ is_head, uint32_t* __restrict__ head_ex,
                                                      uint32_t* __restrict__ heads, uint32_t* __restrict__ row_run) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   const uint32_t n = b.counts->n_list_ins;
   if (blockIdx.x * BLOCK >= n) return;
@@ -587,6 +595,7 @@ __device__ __forceinline__ unsigned long long euler_pack(uint32_t succ, uint32_t
 
 __global__ __launch_bounds__(BLOCK) void k_euler_init_runs(MergeBufs b, const uint32_t* __restrict__ heads, const uint32_t* __restrict__ row_run,
                                                            unsigned long long* __restrict__ el) {
+  wave_priority_high();
   uint32_t k = gtid();
   uint32_t H = b.counts->n_runs, END = 2 * H;
   if (k == 0) el[END] = euler_pack(END, 0);
@@ -605,6 +614,7 @@ __global__ __launch_bounds__(BLOCK) void k_euler_init_runs(MergeBufs b, const ui
 constexpr uint32_t EULER_LDS_ENTRIES = 16384;  // x 8 B = 128 KiB of the CU's 160 KiB
 constexpr uint32_t EULER_LDS_THREADS = 1024;
 __global__ __launch_bounds__(EULER_LDS_THREADS) void k_euler_rank_lds(Counts* __restrict__ counts, unsigned long long* __restrict__ el) {
+  wave_priority_high();
   __shared__ unsigned long long L[EULER_LDS_ENTRIES];
   const uint32_t H = counts->n_runs, END = 2 * H, E = END + 1;
   if (H == 0 || E > EULER_LDS_ENTRIES) return;
@@ -698,6 +708,7 @@ constexpr uint32_t OBJ_LDS_MAX = 1023;
 __global__ __launch_bounds__(BLOCK) void k_list_order_objs(MergeBufs b, PatchIR ir, uint32_t n_obj, uint32_t n, const uint32_t* __restrict__ is_head,
                                                            const uint32_t* __restrict__ head_ex, const uint32_t* __restrict__ heads,
                                                            const uint32_t* __restrict__ row_run, const unsigned long long* __restrict__ el) {
+  wave_priority_high();
   __shared__ uint32_t s_n[OBJ_LDS_MAX + 1], s_first[OBJ_LDS_MAX + 1], s_red[BLOCK / WAVE];
   // (the element's own loads first: they are in flight while the object table is worked out)
   uint32_t i = gtid();
@@ -725,6 +736,7 @@ __global__ __launch_bounds__(BLOCK) void k_list_order_objs(MergeBufs b, PatchIR 
 
 // per list position: visibility and edit counts, scanned by k_list_scan through the carried sums published here
 __global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t p = gtid();
   uint32_t c = 0;
@@ -739,6 +751,7 @@ __global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n) 
   carry_publish(b.cs_cnt, c, s_red);
 }
 __global__ __launch_bounds__(BLOCK) void k_list_scan(MergeBufs b, uint32_t n, uint32_t* __restrict__ vis_ex, uint32_t* __restrict__ cnt_ex) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t p = gtid();
   uint32_t vis = p < n ? b.list_vis[p] : 0, c = p < n ? b.list_cnt[p] : 0;
@@ -760,6 +773,7 @@ __global__ __launch_bounds__(BLOCK) void k_upd_keys(MergeBufs b, uint64_t* __res
 __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, const uint32_t* __restrict__ vis_ex, const uint32_t* __restrict__ cnt_ex,
                                                       const uint64_t* __restrict__ upd_keys, const uint32_t* __restrict__ upd_vals, uint32_t n_upd,
                                                       PatchIR ir) {
+  wave_priority_high();
   uint32_t p = gtid();
   if (p >= n) return;
   uint32_t v = b.order[p];
@@ -794,6 +808,7 @@ __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, c
 // multi-insert run detection (new.js:754-773), first / last edit of every list object; publishes the number of edit RECORDS
 // (an edit that does not continue a multi-insert run starts one) for k_edit_pack's carried scan
 __global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t n = b.counts->n_edits;
   if (blockIdx.x * BLOCK >= n && blockIdx.x) return;  // (whole workgroup; workgroup 0 always publishes)
@@ -829,6 +844,7 @@ __global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
 // consumer of k_edit_runs' carried scan (same grid): one edit record per head (start of an edit, or of a new uniform stretch of a
 // multi-insert), the edit ranges of the list objects, the sentinel record and Counts.n_erecs
 __global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
+  wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t n = b.counts->n_edits;
   if (blockIdx.x * BLOCK >= n && blockIdx.x) return;

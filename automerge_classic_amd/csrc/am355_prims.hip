@@ -81,6 +81,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict
 
 // one workgroup, one launch: tiles in sequence with a running carry
 __global__ __launch_bounds__(BLOCK) void k_scan_single(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ grand_total) {
+  wave_priority_high();
   __shared__ uint32_t s[BLOCK / WAVE];
   uint32_t carry = 0;
   for (uint32_t tile = 0; tile < n; tile += SCAN_TILE) {
