@@ -2,9 +2,10 @@
 //
 // A tiny stand-in for <hip/hip_runtime.h> that lets g++ compile the engine's .hip sources into a CPU
 // "emulation" library (tests/emu/libam355_emu.so) so that kernel *logic* can be checked against the oracle in
-// the GPU-less build container (`pytest -m "not gpu"`). Every kernel thread becomes an OS thread of a
-// persistent 1024-thread pool; blocks run one after another; __syncthreads()/__ballot()/__shfl() are real
-// barriers between those threads; wave size is 64. It is slow and it is not a fallback: the product library
+// the GPU-less build container (`pytest -m "not gpu"`). Every kernel thread of a block becomes a fiber (ucontext) of
+// the launching OS thread; blocks run one after another; __syncthreads()/__ballot()/__shfl() are barriers at which a
+// fiber hands over to the next one (round robin); wave size is 64. (Until round 3 the threads were OS threads of a
+// 1024-thread pool spinning on sched_yield: the same semantics at ten times the cost.) It is not a fallback: the product library
 // (automerge_classic_amd/csrc/libam355.so) is built by hipcc for gfx950 only and fails loudly without a GPU.
 #pragma once
 #include <atomic>
@@ -90,55 +91,41 @@ extern const char* emu_current_kernel;
 
 namespace emu {
 
-class Barrier {  // reusable counting barrier (sense reversal); spins briefly then yields
+void yield();  // hand over to the next fiber of the block (cooperative launches only)
+void stuck(const char* what, unsigned arrived, unsigned n);
+
+class Barrier {  // reusable counting barrier between the fibers of a block (all on one OS thread: plain counters)
  public:
-  void reset(unsigned n) { n_ = n; count_.store(0); }  // gen_ keeps counting: late spinners still see it change
+  void reset(unsigned n) { n_ = n; count_ = 0; }
   void wait() {
-    unsigned g = gen_.load(std::memory_order_acquire);
-    if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
-      count_.store(0, std::memory_order_relaxed);
-      gen_.store(g + 1, std::memory_order_release);
+    unsigned g = gen_;
+    if (++count_ == n_) {
+      count_ = 0;
+      gen_ = g + 1;
     } else {
-      unsigned spins = 0;
-      std::chrono::steady_clock::time_point t0;
-      while (gen_.load(std::memory_order_acquire) == g) {
-        if (++spins > 64) std::this_thread::yield();
-        if ((spins & 0xfffff) == 0) {  // watchdog: a barrier that never completes is a bug in a kernel or in this emulation
-          auto now = std::chrono::steady_clock::now();
-          if (t0 == std::chrono::steady_clock::time_point()) t0 = now;
-          else if (now - t0 > std::chrono::seconds(90)) {
-            fprintf(stderr, "emu: barrier stuck for 90 s in kernel %s (arrived %u of %u)\n", emu_current_kernel ? emu_current_kernel : "?", count_.load(), n_);
-            abort();
-          }
-        }
+      unsigned long long spins = 0;
+      while (gen_ == g) {
+        yield();
+        if (++spins > 50000000ull) stuck("barrier", count_, n_);  // a barrier that never completes is a bug in a kernel or in this emulation
       }
     }
   }
  private:
   unsigned n_ = 1;
-  std::atomic<unsigned> count_{0}, gen_{0};
+  volatile unsigned count_ = 0, gen_ = 0;
 };
 
 struct Wave {
   Barrier bar;
-  std::atomic<unsigned long long> mask{0};
+  unsigned long long mask = 0;
   unsigned long long shfl[64];
   unsigned lanes = 64;
 };
 
 struct Runtime {
   static constexpr unsigned MAXT = 1024;
-  std::vector<std::thread> workers;
-  std::function<void()> body;
-  unsigned n_threads = 0;      // threads of the current block
-  dim3 grid, block;
-  unsigned cur_block = 0;
-  Barrier start, finish, block_bar;
+  Barrier block_bar;
   Wave waves[MAXT / 64];
-  bool stop = false;
-  Runtime();
-  ~Runtime();
-  void worker(unsigned tid);
   void run(dim3 grid, dim3 block, const std::function<void()>& fn);
 };
 Runtime& rt();
@@ -180,11 +167,11 @@ inline void __threadfence_system() { std::atomic_thread_fence(std::memory_order_
 inline unsigned long long __ballot(int pred) {
   emu_require_coop("__ballot");
   emu::Wave* w = emu::cur_wave;
-  if (emu::cur_lane == 0) w->mask.store(0);
+  if (emu::cur_lane == 0) w->mask = 0;
   w->bar.wait();
-  if (pred) w->mask.fetch_or(1ull << emu::cur_lane);
+  if (pred) w->mask |= 1ull << emu::cur_lane;
   w->bar.wait();
-  unsigned long long m = w->mask.load();
+  unsigned long long m = w->mask;
   w->bar.wait();
   return m;
 }
@@ -228,7 +215,7 @@ inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 #define __HIP_MEMORY_SCOPE_AGENT 0
 template <class T> inline T __hip_atomic_load(const T* p, int order, int) { return __atomic_load_n(p, order); }
 template <class T> inline void __hip_atomic_store(T* p, T v, int order, int) { __atomic_store_n(p, v, order); }
-inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+inline void __builtin_amdgcn_s_sleep(int) { if (emu::in_coop) emu::yield(); else std::this_thread::yield(); }
 template <class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <class T> inline T atomicSub(T* p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
 template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
