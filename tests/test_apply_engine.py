@@ -164,14 +164,23 @@ def emu_lib():
 
 
 def test_reference_suite_calls_emulated(emu_lib):
-    equal, refused, rejected = run_vector_chains(lambda: engine.Engine(0, emu_lib), max_chain=4, max_chains=220)
-    assert equal >= 180
-    assert len(refused) <= equal // 8
+    """The same chains and the same bar as test_reference_suite_calls_gpu, through the CPU emulation of the kernels."""
+    equal, refused, rejected = run_vector_chains(lambda: engine.Engine(0, emu_lib), max_chain=40)
+    assert equal >= 800 and rejected >= 3
+    assert len(refused) <= equal // 40
 
 
 def test_campaign_sessions_emulated(emu_lib):
-    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), names={"t:13:4:4:16#0", "t:13:4:4:16#2", "m:15:2:100:3#1", "m:11:3:120:2#2"})
-    assert equal >= 20
+    """All sessions / 447 calls of tests/golden/apply_campaign.json.gz through the CPU emulation of the kernels: every call served, every
+    patch the live reference's (the same assertion as the GPU test below)."""
+    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib))
+    assert equal == 447 and refused == 0
+
+
+def test_all_list_assignment_sessions_emulated(emu_lib):
+    """All 18 sessions / 412 calls of tests/golden/apply_campaign_lists.json.gz through the CPU emulation."""
+    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), fixture="apply_campaign_lists.json.gz")
+    assert equal == 412 and refused == 0
 
 
 @pytest.mark.parametrize("kind,kw,n_batches", [
