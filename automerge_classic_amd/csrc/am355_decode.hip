@@ -900,13 +900,9 @@ __global__ __launch_bounds__(WAVE) void k_actor_first(ChangeMeta* __restrict__ m
   }
 }
 
-// one workgroup: lexicographic ranks of the distinct actor ids
-__global__ __launch_bounds__(BLOCK) void k_rank_actors(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
-                                                       uint32_t* __restrict__ plan_words) {
-  wave_priority_high();
-  rank_actors(arena, distinct, slot_rank, plan_words);
-}
-
+// (The ranking of the distinct actor ids -- one workgroup, ~20 us of dependent loads: count -> slot -> id bytes -- rides as the LAST
+// workgroup of k_actor_check: both only need what k_actor_intern left, and the consumer of the ranks is the kernel behind. As a
+// kernel of its own in front of k_actor_check it was 20 us of the critical path for one workgroup's worth of work.)
 __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
                                                        const uint32_t* __restrict__ amap_base, const uint32_t* __restrict__ amap, uint32_t amap_cap,
                                                        const uint32_t* __restrict__ first_idx, uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags,
@@ -914,6 +910,10 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
                                                        unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words) {
   wave_priority_high();
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
+  if (blockIdx.x + 1 == gridDim.x) {  // the extra workgroup
+    rank_actors(arena, distinct, slot_rank, plan_words);
+    return;
+  }
   uint32_t c = gtid();
   const bool in_range = c < n;
   ChangeBrief br{};
@@ -1916,10 +1916,8 @@ void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, co
     hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
                        fast_flags, distinct);
   if (n) hipLaunchKernelGGL(k_actor_first, dim3(n), dim3(WAVE), 0, st, metas, n, amap_base, (const uint32_t*)amap, amap_cap, (const uint32_t*)first_idx, fast_flags);
-  hipLaunchKernelGGL(k_rank_actors, dim3(1), dim3(BLOCK), 0, st, arena, (const uint32_t*)distinct, slot_rank, plan_words);
-  if (n)
-    hipLaunchKernelGGL(k_actor_check, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, arena, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
-                       (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, slot_rank, block_sums, plan_words);
+  hipLaunchKernelGGL(k_actor_check, dim3((n + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), 0, st, arena, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
+                     (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, slot_rank, block_sums, plan_words);
 }
 
 size_t plan_block_sums_bytes(uint32_t n) { return sizeof(unsigned long long) * PLAN_SUMS * ((size_t)(n + BLOCK - 1) / BLOCK + 1); }
