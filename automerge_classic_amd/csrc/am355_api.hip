@@ -268,7 +268,7 @@ struct am355_ctx {
   BigColDesc doc_cols{};
   bool doc_serial = false;           // AM355_DOC_SERIAL=1: lane-serial column decoders (first version, kept for cross-checks)
   // stage-1 side tables (device) and their pinned host mirrors
-  DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1, d_plan_sums, d_dep_idx, d_self_idx;
+  DevBuf d_entries, d_amap_base, d_amap_prov, d_slots, d_first_idx, d_hashes, d_hash_tab, d_min_idx, d_has_dep, d_words, d_slot_rank, d_scan1, d_plan_sums, d_dep_idx, d_self_idx, d_rank_ids;
   HostBuf h_dep_idx, h_self_idx, h_amap, h_amap_base;   // general scheduler: dependency / duplicate indexes and actor tables resolved on the device
   HostBuf h_slots, h_hashes, h_has_dep, h_words, h_stage, h_s1;
   DevBuf d_s1;                 // stage-1 results read by the host: flag words | distinct actor ids | one ChangeBrief per change
@@ -439,7 +439,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   (void)hipStreamSynchronize(c->stream3);
   if (c->stream4) (void)hipStreamSynchronize(c->stream4);
   for (DevBuf* b : {&c->d_entries, &c->d_amap_base, &c->d_amap_prov, &c->d_slots, &c->d_first_idx, &c->d_hashes, &c->d_hash_tab, &c->d_min_idx, &c->d_has_dep,
-                    &c->d_words, &c->d_slot_rank, &c->d_scan1, &c->d_plan_sums, &c->d_dep_idx, &c->d_self_idx})
+                    &c->d_words, &c->d_slot_rank, &c->d_scan1, &c->d_plan_sums, &c->d_dep_idx, &c->d_self_idx, &c->d_rank_ids})
     b->release();
   for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1, &c->h_dep_idx, &c->h_self_idx, &c->h_amap, &c->h_amap_base}) b->release();
   c->d_s1.release();
@@ -1809,7 +1809,7 @@ static int replay_impl(am355_ctx* c) {
       !c->d_scan1.ensure(scan_workspace_bytes((uint32_t)n1)) || !c->h_slots.ensure(8 * (size_t)(c->slot_mask + 1)) || !c->h_hashes.ensure(32 * n1) ||
       !c->h_has_dep.ensure(n1) || !c->h_words.ensure(4 * W_NUM) || !c->d_plans.ensure(2 * sizeof(ChangePlan) * n1) ||
       !c->d_slot_rank.ensure(4 * (size_t)(c->slot_mask + 1)) || !c->d_plan_sums.ensure(plan_block_sums_bytes(n)) ||
-      !c->d_dep_idx.ensure(4 * (c->raw.size() / 32 + 2)) || !c->d_self_idx.ensure(4 * n1))
+      !c->d_dep_idx.ensure(4 * (c->raw.size() / 32 + 2)) || !c->d_self_idx.ensure(4 * n1) || !c->d_rank_ids.ensure(rank_ids_bytes()))
     return fail(c, AM355_E_NOMEM, "device allocation failed (stage 1)");
   c->have_host_metas = false;
   // what the host reads after stage 1 -- a few flag words, the distinct actor ids, one brief per change -- sits in one device
@@ -1897,7 +1897,7 @@ static int replay_impl(am355_ctx* c) {
     }
     launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
                         c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_wa + W_FLAGS_A, d_wa + W_FAST_A,
-                        d_distinct, d_briefs, c->d_slot_rank.as<uint32_t>(), c->d_plan_sums.as<unsigned long long>(), d_wa + 8, sa);
+                        d_distinct, c->d_rank_ids.p, d_briefs, c->d_slot_rank.as<uint32_t>(), c->d_plan_sums.as<unsigned long long>(), d_wa + 8, sa);
     // device half of the in-order plan (actor ranks, per-change bases, decoder classes): the decode kernels start from it
     // (its totals, and the stage-1 words the host decides on, reach the host through HostSignals: no copy, no blocking wait)
     c->sig_seq++;

@@ -22,9 +22,11 @@ void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const ui
 // k_actor_check also starts the device half of the in-order plan: per-workgroup sums of ops / preds / actor entries / plans per decoder
 // class (block_sums, plan_block_sums_bytes(n) bytes), lexicographic ranks of the distinct actor ids (slot_rank[slot]) and plan_words
 // ([0] fallback, [1] max op, [2] OR of change flags, [3] unknown columns; cleared by the caller).
+// rank_ids: rank_ids_bytes() bytes of device memory (the ids of the distinct actors as the ranking workgroup reads them; needs no clearing)
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
-                         ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st);
+                         void* rank_ids, ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st);
+size_t rank_ids_bytes();
 size_t plan_block_sums_bytes(uint32_t n);
 uint32_t distinct_capacity();
 // ... and k_plan_apply finishes it: for every change with ops its ChangePlan (row / pred / actor-table bases by prefix sums in input order,

@@ -682,8 +682,17 @@ __global__ __launch_bounds__(WAVE) void k_deps_resolve(const uint8_t* __restrict
 // `distinct`: word 0 = number of claimed slots, words [1, 1+CAP) their slot indexes, then (8-byte aligned at word
 // 2+CAP) CAP 64-bit slot values -- everything the host needs about the actor table in one small copy
 constexpr uint32_t DISTINCT_CAP = 4096;
+constexpr uint32_t PLAN_RANK_MAX = 1024;   // distinct actors ranked on the device (LDS: 40 bytes each)
+constexpr uint32_t PLAN_ID_MAX = 32;       // bytes of an actor id the device ranking handles (ids are 16 bytes in practice)
+// `rank_ids`: what the ranking workgroup (rank_actors) needs about distinct actor k, left by the lane that claimed its slot -- the id as
+// four big-endian words, zero padded, and its length -- so that the ranking is ONE memory round trip (count and records side by side)
+// instead of count -> slot value -> id bytes in the arena.
+struct RankId {
+  unsigned long long w[PLAN_ID_MAX / 8];
+  uint32_t len, pad;
+};
 __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restrict__ arena, unsigned long long* __restrict__ slots, uint32_t mask,
-                                                         uint32_t off, uint32_t len, uint32_t* __restrict__ distinct) {
+                                                         uint32_t off, uint32_t len, uint32_t* __restrict__ distinct, RankId* __restrict__ rank_ids) {
   const uint8_t* p = arena + off;
   // actor ids are 16 bytes in practice: two 8-byte loads (any alignment) instead of a dependent chain of sixteen byte loads for the
   // hash, and again for every comparison (each load of such a chain is a round trip to L2: this kernel is bound by them)
@@ -710,6 +719,19 @@ __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restri
           distinct[1 + k] = i;
           ((unsigned long long*)(distinct + 2 + DISTINCT_CAP))[k] = mine;
         }
+        if (k < PLAN_RANK_MAX) {
+          RankId r;
+          for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) r.w[wd] = 0;
+          r.len = len;
+          r.pad = 0;
+          if (wide) {
+            r.w[0] = __builtin_bswap64(p0);
+            r.w[1] = __builtin_bswap64(p1);
+          } else if (len <= PLAN_ID_MAX) {
+            for (uint32_t b = 0; b < len; b++) r.w[b >> 3] |= (unsigned long long)p[b] << (56 - 8 * (b & 7));
+          }
+          rank_ids[k] = r;
+        }
         return i;
       }
     }
@@ -730,7 +752,8 @@ __device__ __forceinline__ uint32_t actor_find_or_insert(const uint8_t* __restri
 __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
                                                         const uint32_t* __restrict__ amap_base, uint32_t* __restrict__ amap, uint32_t amap_cap,
                                                         unsigned long long* __restrict__ slots, uint32_t mask, uint32_t* __restrict__ first_idx,
-                                                        uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags, uint32_t* __restrict__ distinct) {
+                                                        uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags, uint32_t* __restrict__ distinct,
+                                                        RankId* __restrict__ rank_ids) {
   __shared__ uint32_t s_off[WAVE], s_len[WAVE];
   wave_priority_high();
   uint32_t c = blockIdx.x, lane = threadIdx.x;
@@ -746,7 +769,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
   uint32_t abs0 = (uint32_t)m->base;
   uint32_t n_other = m->n_other;
   if (lane == 0) {
-    uint32_t s = actor_find_or_insert(arena, slots, mask, abs0 + m->actor_off, m->actor_len, distinct);
+    uint32_t s = actor_find_or_insert(arena, slots, mask, abs0 + m->actor_off, m->actor_len, distinct, rank_ids);
     if (s == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); s = 0; }
     amap[base] = s;
     m->author_slot = s;
@@ -760,7 +783,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
     bool mine_ok = !fits || lane >= n_other || p[m->others_off + stride * lane] == l0;
     if (fits && __ballot(!mine_ok) == 0) {
       if (lane < n_other) {
-        uint32_t t = actor_find_or_insert(arena, slots, mask, abs0 + m->others_off + stride * lane + 1, l0, distinct);
+        uint32_t t = actor_find_or_insert(arena, slots, mask, abs0 + m->others_off + stride * lane + 1, l0, distinct, rank_ids);
         if (t == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); t = 0; }
         amap[base + 1 + lane] = t;
       }
@@ -781,7 +804,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
     }
     __syncthreads();
     if (lane < cnt) {
-      uint32_t t = s_len[lane] != NONE32 ? actor_find_or_insert(arena, slots, mask, s_off[lane], s_len[lane], distinct) : NONE32;
+      uint32_t t = s_len[lane] != NONE32 ? actor_find_or_insert(arena, slots, mask, s_off[lane], s_len[lane], distinct, rank_ids) : NONE32;
       if (t == NONE32) { atomicOr(flags, (uint32_t)F_UNSUPPORTED); t = 0; }
       amap[base + 1 + k0 + lane] = t;
     }
@@ -797,8 +820,6 @@ __device__ __forceinline__ int wave_class_of(const ChangeMeta& m);
 // sums of its 256 changes (ops, preds, actor entries, plans per decoder class), and one EXTRA workgroup (blockIdx == gridDim - 1)
 // ranks the distinct actor ids lexicographically from LDS. plan_words: [0] fallback, [1] max op id, [2] OR of the changes' validity
 // flags, [3] unknown columns seen (cleared by the caller).
-constexpr uint32_t PLAN_RANK_MAX = 1024;   // distinct actors ranked on the device (LDS: 40 bytes each)
-constexpr uint32_t PLAN_ID_MAX = 32;       // bytes of an actor id the device ranking handles (ids are 16 bytes in practice)
 constexpr uint32_t PLAN_SUMS = 8;          // words per workgroup in block_sums: ops, preds, entries, small, large, serial plans
 
 __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long x, uint32_t lane) {
@@ -827,49 +848,54 @@ __device__ __forceinline__ void block_scan3(unsigned long long a, unsigned long 
 }
 
 // lexicographic ranks of the distinct actor ids (a proper prefix sorts first) = order of the hex strings (new.js:65); one workgroup
-__device__ void rank_actors(const uint8_t* __restrict__ arena, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
+__device__ void rank_actors(const uint32_t* __restrict__ distinct, const RankId* __restrict__ rank_ids, uint32_t* __restrict__ slot_rank,
                             uint32_t* __restrict__ plan_words) {
   __shared__ unsigned long long s_id[PLAN_RANK_MAX][PLAN_ID_MAX / 8];  // big-endian words, zero padded
   __shared__ uint32_t s_len[PLAN_RANK_MAX];
   __shared__ uint32_t s_fallback;
-  const uint32_t t = threadIdx.x, nd = distinct[0];
+  static_assert(PLAN_RANK_MAX % BLOCK == 0 && PLAN_RANK_MAX <= DISTINCT_CAP, "rank_actors: records per thread");
+  constexpr uint32_t PER = PLAN_RANK_MAX / BLOCK;
+  const uint32_t t = threadIdx.x;
+  // the records and the slot indexes of this thread's actors are requested before the count is known (the tables are allocated in
+  // full; entries beyond the count hold leftovers and are not looked at): one round trip for everything
+  RankId rec[PER];
+  uint32_t slot_of[PER];
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    rec[k] = rank_ids[t + k * BLOCK];
+    slot_of[k] = distinct[1 + t + k * BLOCK];
+  }
+  const uint32_t nd = distinct[0];
   if (t == 0) s_fallback = nd > PLAN_RANK_MAX ? 1u : 0u;
   __syncthreads();
   if (nd <= PLAN_RANK_MAX) {
-    const unsigned long long* slot_val = (const unsigned long long*)(distinct + 2 + DISTINCT_CAP);
-    for (uint32_t a = t; a < nd; a += BLOCK) {
-      unsigned long long v = slot_val[a];
-      uint32_t off = (uint32_t)((v >> 16) - 1), len = (uint32_t)(v & 0xffff);
-      s_len[a] = len;
-      if (len > PLAN_ID_MAX) s_fallback = 1;
-      else {
-        uint8_t bytes[PLAN_ID_MAX];  // (all loads issued before the first use: one memory round trip, not one per byte)
 #pragma unroll
-        for (uint32_t k = 0; k < PLAN_ID_MAX; k++) bytes[k] = k < len ? arena[off + k] : (uint8_t)0;
-#pragma unroll
-        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) {
-          unsigned long long x = 0;
-#pragma unroll
-          for (uint32_t k = 0; k < 8; k++) x = x << 8 | bytes[wd * 8 + k];
-          s_id[a][wd] = x;
-        }
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t a = t + k * BLOCK;
+      if (a < nd) {
+        s_len[a] = rec[k].len;
+        if (rec[k].len > PLAN_ID_MAX) s_fallback = 1;
+        for (uint32_t wd = 0; wd < PLAN_ID_MAX / 8; wd++) s_id[a][wd] = rec[k].w[wd];
       }
     }
   }
   __syncthreads();
   if (s_fallback) { if (t == 0) plan_words[0] = 1; return; }
-  for (uint32_t a = t; a < nd; a += BLOCK) {
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t a = t + k * BLOCK;
+    if (a >= nd) break;
     uint32_t rank = 0;
-    const uint32_t my_len = s_len[a];
+    const uint32_t my_len = rec[k].len;
     static_assert(PLAN_ID_MAX == 32, "rank_actors compares four 64-bit words");
-    const unsigned long long m0 = s_id[a][0], m1 = s_id[a][1], m2 = s_id[a][2], m3 = s_id[a][3];
+    const unsigned long long m0 = rec[k].w[0], m1 = rec[k].w[1], m2 = rec[k].w[2], m3 = rec[k].w[3];
     for (uint32_t j = 0; j < nd; j++) {
       const unsigned long long x0 = s_id[j][0], x1 = s_id[j][1], x2 = s_id[j][2], x3 = s_id[j][3];
       // equal up to the padding: the shorter id first (distinct ids differ somewhere)
       const bool less = x0 != m0 ? x0 < m0 : x1 != m1 ? x1 < m1 : x2 != m2 ? x2 < m2 : x3 != m3 ? x3 < m3 : s_len[j] < my_len;
       rank += less ? 1u : 0u;
     }
-    slot_rank[distinct[1 + a]] = rank;
+    slot_rank[slot_of[k]] = rank;
   }
 }
 
@@ -906,12 +932,12 @@ __global__ __launch_bounds__(WAVE) void k_actor_first(ChangeMeta* __restrict__ m
 __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict__ arena, ChangeMeta* __restrict__ metas, uint32_t n,
                                                        const uint32_t* __restrict__ amap_base, const uint32_t* __restrict__ amap, uint32_t amap_cap,
                                                        const uint32_t* __restrict__ first_idx, uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags,
-                                                       ChangeBrief* __restrict__ briefs, const uint32_t* __restrict__ distinct, uint32_t* __restrict__ slot_rank,
-                                                       unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words) {
+                                                       ChangeBrief* __restrict__ briefs, const uint32_t* __restrict__ distinct, const RankId* __restrict__ rank_ids,
+                                                       uint32_t* __restrict__ slot_rank, unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words) {
   wave_priority_high();
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
   if (blockIdx.x + 1 == gridDim.x) {  // the extra workgroup
-    rank_actors(arena, distinct, slot_rank, plan_words);
+    rank_actors(distinct, rank_ids, slot_rank, plan_words);
     return;
   }
   uint32_t c = gtid();
@@ -1911,14 +1937,16 @@ void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const ui
 
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
-                         ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st) {
+                         void* rank_ids, ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st) {
   if (n)
     hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
-                       fast_flags, distinct);
+                       fast_flags, distinct, (RankId*)rank_ids);
   if (n) hipLaunchKernelGGL(k_actor_first, dim3(n), dim3(WAVE), 0, st, metas, n, amap_base, (const uint32_t*)amap, amap_cap, (const uint32_t*)first_idx, fast_flags);
   hipLaunchKernelGGL(k_actor_check, dim3((n + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), 0, st, arena, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
-                     (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, slot_rank, block_sums, plan_words);
+                     (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, (const RankId*)rank_ids, slot_rank, block_sums, plan_words);
 }
+
+size_t rank_ids_bytes() { return sizeof(RankId) * PLAN_RANK_MAX; }
 
 size_t plan_block_sums_bytes(uint32_t n) { return sizeof(unsigned long long) * PLAN_SUMS * ((size_t)(n + BLOCK - 1) / BLOCK + 1); }
 
