@@ -383,8 +383,7 @@ __global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_
 }
 
 // up to BLOCK emissions (a text document's root map: one): ranks by comparison and the records, one workgroup, one launch
-__global__ __launch_bounds__(BLOCK) void k_map_small_finish(MergeBufs b, uint32_t n, PatchIR ir) {
-  wave_priority_high();
+__device__ __forceinline__ void map_small_finish(const MergeBufs& b, uint32_t n, const PatchIR& ir) {
   __shared__ uint32_t s_perm[BLOCK];
   uint32_t i = threadIdx.x;
   if (i < n) {
@@ -394,6 +393,10 @@ __global__ __launch_bounds__(BLOCK) void k_map_small_finish(MergeBufs b, uint32_
   }
   __syncthreads();
   if (i < n) map_finish_one(b, ir, i, s_perm[i], i > 0 ? s_perm[i - 1] : NONE32, i + 1 < n ? s_perm[i + 1] : NONE32);
+}
+__global__ __launch_bounds__(BLOCK) void k_map_small_finish(MergeBufs b, uint32_t n, PatchIR ir) {
+  wave_priority_high();
+  map_small_finish(b, n, ir);
 }
 
 static int bits_for(uint64_t max_value) {
@@ -705,11 +708,17 @@ __global__ __launch_bounds__(BLOCK) void k_list_order(MergeBufs b, uint32_t n, c
 // works the (few) object counts and their prefix sum out for itself in LDS -- three dependent loads per object -- instead of two more
 // launches in front of it; workgroup 0 leaves obj_n / obj_first_pos in HBM for the kernels behind.
 constexpr uint32_t OBJ_LDS_MAX = 1023;
+// n_map_small != 0: one EXTRA workgroup (the last) orders and writes that many map emissions (map_small_finish): the root map of a text
+// document is one emission, not worth a launch of its own in a chain of launches.
 __global__ __launch_bounds__(BLOCK) void k_list_order_objs(MergeBufs b, PatchIR ir, uint32_t n_obj, uint32_t n, const uint32_t* __restrict__ is_head,
                                                            const uint32_t* __restrict__ head_ex, const uint32_t* __restrict__ heads,
-                                                           const uint32_t* __restrict__ row_run, const unsigned long long* __restrict__ el) {
+                                                           const uint32_t* __restrict__ row_run, const unsigned long long* __restrict__ el, uint32_t n_map_small) {
   wave_priority_high();
   __shared__ uint32_t s_n[OBJ_LDS_MAX + 1], s_first[OBJ_LDS_MAX + 1], s_red[BLOCK / WAVE];
+  if (n_map_small && blockIdx.x + 1 == gridDim.x) {
+    map_small_finish(b, n_map_small, ir);
+    return;
+  }
   // (the element's own loads first: they are in flight while the object table is worked out)
   uint32_t i = gtid();
   uint32_t k = 0, d = 0, oi = 0, head_i = 0;
@@ -1116,7 +1125,7 @@ void merge_prepare(MergeBufs& b, hipStream_t aux) {
 }
 
 // map emissions: LSD over (trigger id | key length | key chunks last..first | object)
-static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hipStream_t st) {
+static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hipStream_t st, uint32_t* ride_with_list_order = nullptr) {
   uint32_t ne = hc->n_map_emit;
   if (!ne) return;
   uint32_t* perm_a = b.val_a;
@@ -1131,7 +1140,8 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
     cur ^= res;
   };
   if (ne <= BLOCK) {
-    hipLaunchKernelGGL(k_map_small_finish, dim3(1), dim3(BLOCK), 0, st, b, ne, ir);
+    if (ride_with_list_order) *ride_with_list_order = ne;  // (an extra workgroup of k_list_order_objs: merge_run)
+    else hipLaunchKernelGGL(k_map_small_finish, dim3(1), dim3(BLOCK), 0, st, b, ne, ir);
     return;
   }
   if (ne <= MAP_SORT_SMALL) {
@@ -1196,9 +1206,10 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   else (void)hipEventSynchronize(ev_counts);
   lap("counts read");
   if (hc->flags) { (void)hipStreamSynchronize(st); return; }
-  order_map_emissions(b, ir, hc, st);
-
   const uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd, n_obj = hc->n_objects + 1;
+  uint32_t map_small = 0;  // a few map emissions: they ride with k_list_order_objs when that kernel is going to run
+  order_map_emissions(b, ir, hc, st, ni && n_obj <= OBJ_LDS_MAX ? &map_small : nullptr);
+
   if (ni) {
     if (b.sig) read_phase_counts(b, &b.sig->runs_seq, b.sig->runs, hc_runs, st);
     else (void)hipEventSynchronize(ev_runs);
@@ -1238,8 +1249,8 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
     }
     // objects laid out one after another: elements per object from the ranked tour, prefix sum
     if (n_obj <= OBJ_LDS_MAX) {
-      hipLaunchKernelGGL(k_list_order_objs, grid_for(ni), dim3(BLOCK), 0, st, b, ir, n_obj, ni, (const uint32_t*)is_head, (const uint32_t*)head_ex,
-                         (const uint32_t*)heads, (const uint32_t*)row_run, el);
+      hipLaunchKernelGGL(k_list_order_objs, dim3(grid_for(ni).x + (map_small ? 1u : 0u)), dim3(BLOCK), 0, st, b, ir, n_obj, ni, (const uint32_t*)is_head,
+                         (const uint32_t*)head_ex, (const uint32_t*)heads, (const uint32_t*)row_run, el, map_small);
     } else {
       AM355_LAUNCH_INDEPENDENT(k_obj_n, grid_for(n_obj + 1), dim3(BLOCK), st, b, ir, n_obj, (const uint32_t*)row_run, el);
       exclusive_scan_u32(b.obj_n, b.obj_first_pos, n_obj + 1, nullptr, b.scan_ws, st);
