@@ -611,39 +611,124 @@ __global__ __launch_bounds__(BLOCK) void k_euler_init_runs(MergeBufs b, const ui
 }
 
 // List ranking (Wyllie pointer jumping: dist'[x] = dist[x] + dist[succ[x]], succ'[x] = succ[succ[x]]) of a tour that fits
-// the LDS of ONE compute unit -- 16 K entries = 8 K typing runs, which covers the headline 1 M-op text (~5 k runs): one
+// the LDS of ONE compute unit -- 16 K entries = 8 K typing runs, which covers the headline 1 M-op text (8082 runs): one
 // launch of one 1024-thread workgroup, log2(entries) rounds in place (every lane keeps its 16 entries in registers across
 // the barrier), instead of log2(entries) launches over an array that small. Longer tours: k_euler_jump rounds in HBM.
+//
+// The rounds are bound by LDS bandwidth (per round and entry two random 8-byte reads and an 8-byte write: 36 us for 14 rounds over
+// 16 k entries). A tour that is ONE path -- a document with one list object, the ordinary text document -- is ranked in half the
+// bytes: the rounds jump over 32-bit entries (successor << 16 | hops to the end, both < 2^14), which gives every entry its POSITION in
+// the tour; the run lengths are then scattered to their positions, one prefix sum over the positions gives the weight from every
+// position to the end, and every entry picks up its own. Several list objects are several paths ending at the same END (equal hop
+// counts on different paths): those tours keep the 64-bit rounds.
 constexpr uint32_t EULER_LDS_ENTRIES = 16384;  // x 8 B = 128 KiB of the CU's 160 KiB
 constexpr uint32_t EULER_LDS_THREADS = 1024;
 __global__ __launch_bounds__(EULER_LDS_THREADS) void k_euler_rank_lds(Counts* __restrict__ counts, unsigned long long* __restrict__ el) {
   wave_priority_high();
   __shared__ unsigned long long L[EULER_LDS_ENTRIES];
+  __shared__ uint32_t s_wave[EULER_LDS_THREADS / WAVE];
   const uint32_t H = counts->n_runs, END = 2 * H, E = END + 1;
   if (H == 0 || E > EULER_LDS_ENTRIES) return;
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x, lane = t & (WAVE - 1), wv = t / WAVE;
   constexpr uint32_t PER = EULER_LDS_ENTRIES / EULER_LDS_THREADS;
-  for (uint32_t x = t; x < E; x += EULER_LDS_THREADS) L[x] = el[x];
-  __syncthreads();
   int rounds = 1;
   while ((E >> rounds) != 0) rounds++;
-  for (int r = 0; r < rounds; r++) {
-    unsigned long long nv[PER];
+  unsigned long long e[PER];
+  uint32_t ends = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; j++) {
+    const uint32_t x = t + j * EULER_LDS_THREADS;
+    e[j] = x < E ? el[x] : 0ull;
+    ends += (x < END && (uint32_t)e[j] == END) ? 1u : 0u;
+  }
+  ends = wave_sum_u32(ends);
+  if (lane == 0) s_wave[wv] = ends;
+  __syncthreads();
+  uint32_t paths = 0;
+  for (uint32_t k = 0; k < EULER_LDS_THREADS / WAVE; k++) paths += s_wave[k];
+  __syncthreads();
+  if (paths == 1) {
+    uint32_t* P = (uint32_t*)L;                 // successor << 16 | hops to the end
+    uint32_t* Wt = P + EULER_LDS_ENTRIES;       // run length by tour position (0 = the entry in front of END), then its prefix sums
+#pragma unroll
     for (uint32_t j = 0; j < PER; j++) {
-      uint32_t x = t + j * EULER_LDS_THREADS;
-      if (x < END) {
-        unsigned long long e = L[x];
-        uint32_t s = (uint32_t)e;
-        if (s != END) {
-          unsigned long long f = L[s];
-          e = euler_pack((uint32_t)f, (uint32_t)(e >> 32) + (uint32_t)(f >> 32));
-        }
-        nv[j] = e;
-      }
+      const uint32_t x = t + j * EULER_LDS_THREADS;
+      if (x < E) P[x] = (uint32_t)e[j] << 16 | (x < END ? 1u : 0u);
+      Wt[x] = 0;
     }
     __syncthreads();
+      // (every round: the sixteen dependent reads of a thread are requested together -- END is a fixed point with zero hops, so they need
+    // no branch; with a branch around each the compiler waited for every read in turn: 2.3 us a round. Now 1.6 us: 16 k random 4-byte LDS
+    // reads at ~5 cycles per wavefront for their bank conflicts, which is what is left of this kernel: rounds 22 of its 32 us)
+    uint32_t pv[PER];
+#pragma unroll
     for (uint32_t j = 0; j < PER; j++) {
-      uint32_t x = t + j * EULER_LDS_THREADS;
+      const uint32_t x = t + j * EULER_LDS_THREADS;
+      pv[j] = x < END ? (uint32_t)e[j] << 16 | 1u : END << 16;  // (what P[x] holds; a thread keeps its own entries in registers between the rounds)
+    }
+    for (int r = 0; r < rounds; r++) {
+      uint32_t qv[PER];
+#pragma unroll
+      for (uint32_t j = 0; j < PER; j++) qv[j] = P[pv[j] >> 16];
+#pragma unroll
+      for (uint32_t j = 0; j < PER; j++) pv[j] = (qv[j] & 0xffff0000u) | ((pv[j] + qv[j]) & 0xffffu);
+      __syncthreads();
+#pragma unroll
+      for (uint32_t j = 0; j < PER; j++) {
+        const uint32_t x = t + j * EULER_LDS_THREADS;
+        if (x < END) P[x] = pv[j];
+      }
+      __syncthreads();
+    }
+    // run lengths to their tour positions
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+      const uint32_t x = t + j * EULER_LDS_THREADS;
+      pv[j] = (pv[j] & 0xffffu) - 1;  // hops - 1 (an entry that never reaches END -- not in a well-formed tour -- lands out of range)
+      if (x < END && pv[j] < END) Wt[pv[j]] = (uint32_t)(e[j] >> 32);
+    }
+    __syncthreads();
+    // inclusive prefix sums over the positions: PER consecutive positions per thread, one scan over the threads' totals
+    uint32_t loc[PER], run = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) { run += Wt[t * PER + k]; loc[k] = run; }
+    const uint32_t incl = wave_incl_scan_u32(run, lane);
+    if (lane == WAVE - 1) s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (uint32_t k = 0; k < wv; k++) base += s_wave[k];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) Wt[t * PER + k] = base + loc[k];
+    __syncthreads();
+  #pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+      const uint32_t x = t + j * EULER_LDS_THREADS;
+      if (x < END) el[x] = euler_pack(END, pv[j] < END ? Wt[pv[j]] : 0u);
+    }
+    if (t == 0) counts->euler_done = 1;
+      return;
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < PER; j++) {
+    const uint32_t x = t + j * EULER_LDS_THREADS;
+    if (x < E) L[x] = e[j];
+  }
+  __syncthreads();
+  for (int r = 0; r < rounds; r++) {
+    unsigned long long nv[PER], fv[PER];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+      const uint32_t x = t + j * EULER_LDS_THREADS;
+      nv[j] = L[x < END ? x : END];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) fv[j] = L[(uint32_t)nv[j]];  // (L[END] = (END, 0): a fixed point, no branch)
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) nv[j] = euler_pack((uint32_t)fv[j], (uint32_t)(nv[j] >> 32) + (uint32_t)(fv[j] >> 32));
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+      const uint32_t x = t + j * EULER_LDS_THREADS;
       if (x < END) L[x] = nv[j];
     }
     __syncthreads();

@@ -514,6 +514,15 @@ def test_document_with_a_long_key_literal(eng):
     assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
 
 
+def test_full_size_headline_workload_emulated(eng):
+    """BASELINE.json's headline configuration at FULL size (1,020,801 ops, 4097 changes, 64 actors, one Text: a tour of 16 k entries, the
+    single-path list ranking, the wave-per-change decoder on every change) through the CPU emulation of the kernels, against the oracle."""
+    log = loggen.config("c4_text_single", 1.0, False)
+    assert emu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
+    st = eng.stats()
+    assert st.n_ops == 1020801 and st.n_changes == 4097 and st.fast_path == 1
+
+
 def test_applied_order(eng):
     """am355_get_applied: input order on the fast path, duplicates dropped, queued changes absent."""
     fx = golden_util.load_fixture("frontend_text_4actors")
