@@ -257,6 +257,7 @@ struct am355_ctx {
   HostBuf h_metas, h_offsets, h_sig;   // h_sig: HostSignals (device -> host result words without a copy)
   uint32_t sig_seq = 0;
   hipEvent_t ev_s1 = nullptr;          // the per-change digests (briefs) have arrived on the host
+  hipEvent_t ev_fills = nullptr;       // merge fills done (when they run on stream4)
   hipEvent_t ev_plan = nullptr, ev_tables = nullptr;  // k_plan_apply done (stream4 copies the digests behind it) | host-built tables in HBM
   void* counts_zeroed_at = nullptr; size_t counts_zeroed = 0;  // the counter block was cleared beside stage 1 (address, bytes)
   // AM355_PHASE_EVENTS=1: HIP events between the phases of a change replay (am355_stats.ms_parse / ms_decode / ms_merge / ms_order). Off by
@@ -423,7 +424,7 @@ extern "C" am355_ctx* am355_create(int device) {
     if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_counts) != hipSuccess || hipEventCreate(&c->ev_runs) != hipSuccess || hipEventCreate(&c->ev_s1) != hipSuccess) { delete c; return nullptr; }
-  if (hipEventCreate(&c->ev_plan) != hipSuccess || hipEventCreate(&c->ev_tables) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev_plan) != hipSuccess || hipEventCreate(&c->ev_tables) != hipSuccess || hipEventCreate(&c->ev_fills) != hipSuccess) { delete c; return nullptr; }
   if (!c->h_sig.ensure(sizeof(HostSignals))) { delete c; return nullptr; }
   memset(c->h_sig.p, 0, sizeof(HostSignals));
   if (const char* e = getenv("AM355_PHASE_EVENTS")) c->phase_events = strcmp(e, "0") != 0;
@@ -443,7 +444,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
     b->release();
   for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1, &c->h_dep_idx, &c->h_self_idx, &c->h_amap, &c->h_amap_base}) b->release();
   c->d_s1.release();
-  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1, c->ev_plan, c->ev_tables})
+  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1, c->ev_plan, c->ev_tables, c->ev_fills})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -1614,7 +1615,15 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
                         &c->d_counts.as<Counts>()->flags, st, c->stream3);
   lap("decode launched");
   if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
-  merge_prepare(c->mb, c->stream3);
+  if (tot.n_small && (tot.n_large || tot.n_serial)) {
+    // (stream3 carries the second decoder class -- 0.27 ms for a batch of fat changes --: the fills, which depend on nothing, would
+    // start behind it and k_resolve would wait for them; they go to the copy stream, which is idle now)
+    merge_prepare(c->mb, c->stream4);
+    HIPCHK(c, hipEventRecord(c->ev_fills, c->stream4));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_fills, 0));
+  } else {
+    merge_prepare(c->mb, c->stream3);
+  }
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   lap("fills enqueued");

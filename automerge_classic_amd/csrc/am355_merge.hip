@@ -294,11 +294,8 @@ __global__ __launch_bounds__(BLOCK) void k_object_table(MergeBufs b, const uint3
 // ---------------------------------------------------------------------------------------------------------
 enum MapKeyMode { MK_TRIGGER, MK_LEN, MK_CHUNK, MK_OBJECT };
 
-__global__ __launch_bounds__(BLOCK) void k_map_keys(MergeBufs b, const uint32_t* __restrict__ perm, uint64_t* __restrict__ keys, uint32_t n,
-                                                    int mode, uint32_t chunk, const uint32_t* __restrict__ obj_rank) {
-  uint32_t i = gtid();
-  if (i >= n) return;
-  uint32_t e = perm[i], g = b.em_row[e];
+__device__ __forceinline__ uint64_t map_key_of(const MergeBufs& b, uint32_t e, int mode, uint32_t chunk, const uint32_t* __restrict__ obj_rank) {
+  uint32_t g = b.em_row[e];
   uint64_t k = 0;
   if (mode == MK_TRIGGER) {
     unsigned long long t = b.em_trig[e];
@@ -316,7 +313,32 @@ __global__ __launch_bounds__(BLOCK) void k_map_keys(MergeBufs b, const uint32_t*
     k = obj_index_of(b, b.obj_row[g]);
     if (obj_rank) k = obj_rank[k];  // save(): objects in ascending id order instead of creation order
   }
-  keys[i] = k;
+  return k;
+}
+__global__ __launch_bounds__(BLOCK) void k_map_keys(MergeBufs b, const uint32_t* __restrict__ perm, uint64_t* __restrict__ keys, uint32_t n,
+                                                    int mode, uint32_t chunk, const uint32_t* __restrict__ obj_rank) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  keys[i] = map_key_of(b, perm[i], mode, chunk, obj_rank);
+}
+// the same + the histogram of the first digit the sort behind it looks at (radix_sort_pairs, first_hist_done): one launch less per field
+__global__ __launch_bounds__(BLOCK) void k_map_keys_hist(MergeBufs b, const uint32_t* __restrict__ perm, uint64_t* __restrict__ keys, uint32_t n,
+                                                         int mode, uint32_t chunk, const uint32_t* __restrict__ obj_rank, int shift,
+                                                         uint32_t* __restrict__ table, uint32_t n_tiles) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * SORT_TILE_ELEMS;
+  for (uint32_t j = 0; j < SORT_TILE_ELEMS / BLOCK; j++) {
+    const uint32_t i = base + j * BLOCK + threadIdx.x;
+    if (i < n) {
+      const uint64_t k = map_key_of(b, perm[i], mode, chunk, obj_rank);
+      keys[i] = k;
+      atomicAdd(&hist[(uint32_t)(k >> shift) & 0xff], 1u);
+    }
+  }
+  __syncthreads();
+  table[threadIdx.x * n_tiles + blockIdx.x] = hist[threadIdx.x];
 }
 
 // The same order for a handful of emissions (a root map with a few keys next to a large Text is the common document):
@@ -1219,9 +1241,14 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
   auto pass = [&](int mode, uint32_t chunk, int bits, int begin_bit = 0) {
     uint32_t* pin = cur ? perm_b : perm_a;
     uint64_t* kin = cur ? b.key_b : b.key_a;
-    AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk, (const uint32_t*)nullptr);
-    int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, begin_bit, bits, b.sort_ws, st)
-                  : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, begin_bit, bits, b.sort_ws, st);
+    const bool fused = sort_is_fused(ne) && bits > begin_bit;
+    if (fused)
+      hipLaunchKernelGGL(k_map_keys_hist, dim3(sort_tiles(ne)), dim3(BLOCK), 0, st, b, (const uint32_t*)pin, kin, ne, mode, chunk, (const uint32_t*)nullptr, begin_bit,
+                         sort_first_table(b.sort_ws), sort_tiles(ne));
+    else
+      AM355_LAUNCH_INDEPENDENT(k_map_keys, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)pin, kin, ne, mode, chunk, (const uint32_t*)nullptr);
+    int res = cur ? radix_sort_pairs(b.key_b, perm_b, b.key_a, perm_a, ne, begin_bit, bits, b.sort_ws, st, fused)
+                  : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, begin_bit, bits, b.sort_ws, st, fused);
     cur ^= res;
   };
   if (ne <= BLOCK) {

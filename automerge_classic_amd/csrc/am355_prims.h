@@ -13,8 +13,15 @@ void exclusive_scan2_u32(const uint32_t* in_a, uint32_t* out_a, uint32_t* d_tota
 // *d_out = max(*d_out, max(v[0..n)))
 void max_u32(const uint32_t* v, uint32_t n, uint32_t* d_out, hipStream_t st);
 size_t sort_workspace_bytes(uint32_t n);
+// first_hist_done: the caller's own kernel (the one that produced keys_a) has already left the histogram of the FIRST digit (bits
+// [begin_bit, begin_bit + 8)) in sort_first_table(ws), laid out [digit x sort_tiles(n) + tile] over tiles of SORT_TILE_ELEMS elements --
+// only for sorts with sort_is_fused(n)
 int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n, int begin_bit, int end_bit,
-                     void* ws, hipStream_t st);
+                     void* ws, hipStream_t st, bool first_hist_done = false);
+constexpr uint32_t SORT_TILE_ELEMS = 2048;
+uint32_t sort_tiles(uint32_t n);
+bool sort_is_fused(uint32_t n);
+uint32_t* sort_first_table(void* ws);
 // Forward chain marking: next[i] > i, or >= n (NONE32) at the end of a chain. mark[] holds the start nodes on entry and
 // is nonzero on every node reachable from a start on return (values already nonzero are kept). `work` needs
 // chain_work_bytes(n) bytes.

@@ -227,6 +227,7 @@ constexpr int SORT_ITEMS = 8;
 constexpr int SORT_WAVE_SPAN = WAVE * SORT_ITEMS;          // 512 elements per wave
 constexpr int SORT_TILE = (BLOCK / WAVE) * SORT_WAVE_SPAN;  // 2048 elements per workgroup
 constexpr int RADIX = 256;
+constexpr uint32_t SORT_FUSED_TILES = 64;
 
 __global__ __launch_bounds__(BLOCK) void k_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
                                                       uint32_t* __restrict__ table, uint32_t n_tiles) {
@@ -242,10 +243,15 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(const uint64_t* __restrict_
   table[threadIdx.x * n_tiles + blockIdx.x] = hist[threadIdx.x];  // digit-major so one scan gives global offsets
 }
 
+// RAW_TABLE: `table` holds the histograms as k_sort_hist left them (no scan launch in between): thread t = digit t adds up its row -- the
+// digit's count over all tiles, and over the tiles in front of this one -- and one workgroup scan over the rows gives the digit's base.
+// For sorts of up to SORT_FUSED_TILES tiles (131 k elements): a pass is two launches instead of three.
+template <bool RAW_TABLE>
 __global__ __launch_bounds__(BLOCK) void k_sort_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                          int shift, const uint32_t* __restrict__ table, uint32_t n_tiles) {
   __shared__ uint32_t wave_cnt[BLOCK / WAVE][RADIX];
+  __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t t = threadIdx.x, w = t / WAVE, lane = t % WAVE;
   for (int k = 0; k < BLOCK / WAVE; k++) wave_cnt[k][t] = 0;
   __syncthreads();
@@ -275,7 +281,19 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(const uint64_t* __restri
   __syncthreads();
   // thread t now plays digit t: turn per-wave counts into global start offsets per (wave, digit)
   {
-    uint32_t run = table[t * n_tiles + blockIdx.x];
+    uint32_t run;
+    if (RAW_TABLE) {
+      uint32_t row = 0, part = 0;
+      for (uint32_t k = 0; k < n_tiles; k++) {
+        uint32_t c = table[t * n_tiles + k];
+        row += c;
+        part += k < blockIdx.x ? c : 0u;
+      }
+      uint32_t total;
+      run = block_exclusive_scan_u32(row, s_red, &total) + part;
+    } else {
+      run = table[t * n_tiles + blockIdx.x];
+    }
     for (int k = 0; k < BLOCK / WAVE; k++) {
       uint32_t c = wave_cnt[k][t];
       wave_cnt[k][t] = run;
@@ -321,8 +339,12 @@ size_t sort_workspace_bytes(uint32_t n) {
 
 // Sorts ascending by bits [begin_bit, end_bit) of the key. Buffers ping-pong; returns 0 if the result is in
 // (keys_a, vals_a), 1 if in (keys_b, vals_b).
+uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+bool sort_is_fused(uint32_t n) { return sort_tiles(n) <= SORT_FUSED_TILES; }
+uint32_t* sort_first_table(void* ws) { return (uint32_t*)ws; }
+
 int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t n, int begin_bit, int end_bit,
-                     void* ws, hipStream_t st) {
+                     void* ws, hipStream_t st, bool first_hist_done) {
   if (n == 0) return 0;
   uint32_t n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
   uint32_t* table = (uint32_t*)ws;
@@ -334,9 +356,13 @@ int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint3
     uint32_t* vi = cur ? vals_b : vals_a;
     uint64_t* ko = cur ? keys_a : keys_b;
     uint32_t* vo = cur ? vals_a : vals_b;
-    hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(BLOCK), 0, st, ki, n, shift, table, n_tiles);
-    exclusive_scan_u32(table, table, (uint32_t)table_n, nullptr, scan_ws, st);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, table, n_tiles);
+    if (!(first_hist_done && shift == begin_bit)) hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(BLOCK), 0, st, ki, n, shift, table, n_tiles);
+    if (n_tiles <= SORT_FUSED_TILES) {
+      hipLaunchKernelGGL(k_sort_scatter<true>, dim3(n_tiles), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, table, n_tiles);
+    } else {
+      exclusive_scan_u32(table, table, (uint32_t)table_n, nullptr, scan_ws, st);
+      hipLaunchKernelGGL(k_sort_scatter<false>, dim3(n_tiles), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, table, n_tiles);
+    }
     cur ^= 1;
   }
   return cur;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of library variants: tools/ab_libs.sh <rounds> <variant>...   (variant = lib[:ENV=VAL])
+# same-box A/B of library variants: [AB_ARGS="--workload c3_map_lww"] tools/ab_libs.sh <rounds> <variant>...   (variant = lib[:ENV=VAL])
 # (build each variant to _ab/lib_<name>.so: the directory is git-ignored but travels with the gpurun snapshot)
 rounds=$1; shift
 L=automerge_classic_amd/csrc/libam355.so
@@ -7,7 +7,7 @@ cp $L /tmp/lib_orig.so
 for r in $(seq $rounds); do for v in "$@"; do
   lib=${v%%:*}; envs=""; [ "$v" != "$lib" ] && envs=${v#*:}
   cp _ab/lib_$lib.so $L
-  env $envs timeout -k 5 100 python bench.py --steps 60 --warmup 10 --no-sublines --no-cpu-baseline > /tmp/ab.json 2>/dev/null
+  env $envs timeout -k 5 100 python bench.py --steps 60 --warmup 10 --no-sublines --no-cpu-baseline $AB_ARGS > /tmp/ab.json 2>/dev/null
   python - "$v" <<PY
 import json,sys
 p=json.loads(open("/tmp/ab.json").read().strip().splitlines()[-1])
