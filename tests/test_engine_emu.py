@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import golden_util
+import mutation_util
 import oracle_lib
 from automerge_classic_amd import engine, loggen
 
@@ -457,35 +458,17 @@ def test_threaded_rendering_produces_the_same_text(eng, name, monkeypatch):
 def test_mutated_changes_never_disagree_with_the_oracle(eng):
     """Single-byte damage in the op columns of one change (checksum repaired): the engine may refuse more than the oracle does
     (the JS host then runs the reference path), but it never accepts what the oracle rejects and never produces another patch."""
-    import base64
-    import hashlib
-    import random
-    with open(os.path.join(golden_util.GOLDEN_DIR, "frontend_mixed_3actors.json")) as f:
-        changes = [base64.b64decode(c) for c in json.load(f)["changes"]]
-    rng = random.Random(11)
-    equal = refused = 0
-    for _ in range(70):
-        ci = rng.randrange(len(changes))
-        ch = bytearray(changes[ci])
-        pos = rng.randrange(9 + int((len(ch) - 9) * 0.4), len(ch))
-        ch[pos] = rng.randrange(256)
-        ch[4:8] = hashlib.sha256(bytes(ch[8:])).digest()[:4]
-        log = loggen.ChangeLog.from_changes(changes[:ci] + [bytes(ch)] + changes[ci + 1:], name="mutated")
-        try:
-            want = oracle_lib.OracleDoc(log).patch_json()
-        except oracle_lib.OracleError:
-            want = None
-        try:
-            got = emu_patch(eng, log)
-        except engine.EngineError:
-            got = None
-        if got is not None:
-            assert want is not None, f"engine accepted a change the oracle rejects (change {ci}, byte {pos})"
-            assert got == want, f"different patch (change {ci}, byte {pos})"
-            equal += 1
-        else:
-            refused += 1
+    equal, refused = mutation_util.column_mutations(lambda log: emu_patch(eng, log))
     assert equal > 3 and refused > 20
+
+
+def test_mutated_change_headers_never_disagree_with_the_oracle(eng):
+    """The same for the HEADER of a change -- dependency count and hashes, actor, seq, startOp, time, message, the table of other actors,
+    the column directory -- which k_parse_changes reads by the whole wavefront (five ballot-tokenised windows) and hands to the
+    lane-serial parser whenever anything is irregular: single-byte damage (checksum repaired) must be accepted with the oracle's patch
+    or refused, over several fixtures (short and long actor tables, one and many dependencies)."""
+    equal, refused = mutation_util.header_mutations(lambda log: emu_patch(eng, log))
+    assert equal > 10 and refused > 20, (equal, refused)
 
 
 @pytest.mark.parametrize("first_rounds", ["1", "3"])

@@ -442,3 +442,14 @@ def test_sharded_replay_through_rccl_world_1(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and "rccl-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_mutated_changes_and_headers_never_disagree_with_the_oracle(eng):
+    """tests/mutation_util.py on the GPU: single-byte damage in the op columns and in the header of a change (checksum repaired) is refused
+    or gives the oracle's patch -- the wave-parallel header parse of k_parse_changes and its fallback to the lane-serial parser included."""
+    import mutation_util
+    equal, refused = mutation_util.column_mutations(lambda log: gpu_patch(eng, log))
+    assert equal > 3 and refused > 20
+    equal, refused = mutation_util.header_mutations(lambda log: gpu_patch(eng, log))
+    assert equal > 10 and refused > 20, (equal, refused)
+
