@@ -497,6 +497,14 @@ def test_document_with_a_long_key_literal(eng):
     assert eng.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
 
 
+def test_more_list_objects_than_the_fused_list_order_holds(eng):
+    """1100 Text objects: beyond the 1023 whose element counts k_list_order_objs works out in LDS, so the three-launch form (k_obj_n,
+    prefix sum, k_list_order) and the standalone map kernels run; several paths in one tour (64-bit list ranking)."""
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=4, ins_per_change=12, del_per_change=3, n_objects=1100, seed=77)
+    assert emu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
+    assert eng.stats().n_objects == 1101
+
+
 def test_full_size_headline_workload_emulated(eng):
     """BASELINE.json's headline configuration at FULL size (1,020,801 ops, 4097 changes, 64 actors, one Text: a tour of 16 k entries, the
     single-path list ranking, the wave-per-change decoder on every change) through the CPU emulation of the kernels, against the oracle."""

@@ -453,3 +453,9 @@ def test_mutated_changes_and_headers_never_disagree_with_the_oracle(eng):
     equal, refused = mutation_util.header_mutations(lambda log: gpu_patch(eng, log))
     assert equal > 10 and refused > 20, (equal, refused)
 
+
+def test_more_list_objects_than_the_fused_list_order_holds(eng):
+    """1100 Text objects: the three-launch form of the list order (k_obj_n, prefix sum, k_list_order) instead of k_list_order_objs."""
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=4, ins_per_change=12, del_per_change=3, n_objects=1100, seed=77)
+    assert gpu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
+
