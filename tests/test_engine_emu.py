@@ -202,7 +202,7 @@ def test_sliced_staging_gathers_the_same_arena(eng, monkeypatch, deflate):
 
 def test_device_primitives(eng):
     rng = np.random.default_rng(1)
-    for n in (1, 64, 2049, 8192, 9000, 70_001):
+    for n in (1, 64, 2049, 8192, 9000, 70_001, 135_001):  # (the last: more than 64 sort tiles -- the scan of the histogram table as its own launch)
         vals = rng.integers(0, 5, n, dtype=np.uint32)
         out, total = eng.test_scan(vals)
         assert np.array_equal(out, np.concatenate(([0], np.cumsum(vals)[:-1])).astype(np.uint32)) and total == int(vals.sum())
