@@ -80,6 +80,7 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 
 // ---- per-thread coordinates --------------------------------------------------------------------------
 struct emu_uint3 { unsigned x, y, z; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 // LDS is ordinary memory here
 #define AM355_LDS_BYTES_DEFINED 1
 typedef const uint8_t* LdsBytes;

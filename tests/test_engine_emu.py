@@ -210,6 +210,11 @@ def test_device_primitives(eng):
         k, v = eng.test_sort(keys, np.arange(n, dtype=np.uint32), 20)
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(k, keys[order]) and np.array_equal(v, order.astype(np.uint32))
+    # three-launch scan (more than 1024 tiles: k_scan_sums between the tile sums and the apply kernel), aligned and unaligned length
+    for n in (2_200_003, 2_300_000):
+        vals = rng.integers(0, 3, n, dtype=np.uint32)
+        out, total = eng.test_scan(vals)
+        assert np.array_equal(out, np.concatenate(([0], np.cumsum(vals)[:-1])).astype(np.uint32)) and total == int(vals.sum())
 
 
 @pytest.mark.parametrize("serial", [False, True])
