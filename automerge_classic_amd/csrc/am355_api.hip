@@ -19,6 +19,7 @@
 #include "am355_delta.h"
 #include "am355_apply.h"
 #include "am355_sync.h"
+#include "am355_canary.h"
 
 #include <zlib.h>
 
@@ -46,10 +47,11 @@ struct DevBuf {
   size_t cap = 0;
   bool ensure(size_t bytes) {
     if (bytes <= cap) return true;
+    canary_forget(p, cap);
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
+    size_t want = bytes + bytes / 8 + 256 + (canary_on() ? (128u << 10) : 0u);
     if (hipMalloc(&p, want) != hipSuccess) return false;
     cap = want;
     return true;
@@ -61,12 +63,14 @@ struct DevBuf {
     void* q = nullptr;
     if (hipMalloc(&q, want) != hipSuccess) return false;
     if (p && keep && hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(q); return false; }
+    canary_forget(p, cap);
     if (p) (void)hipFree(p);
     p = q;
     cap = want;
     return true;
   }
   void release() {
+    canary_forget(p, cap);
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -326,7 +330,7 @@ struct am355_ctx {
   // incremental applyChanges (am355_apply_changes)
   std::vector<uint32_t> pending_change;   // queued changes (input indexes, queue order) after the last replay
   std::vector<uint32_t> pass_first_row;   // first op row of every scheduling pass after the first (general scheduler)
-  DevBuf d_delta, d_pass;
+  DevBuf d_delta, d_pass, d_delta_edit;
   HostBuf h_delta;
   DeltaBufs delta{};
   ApplyPatch apply;
@@ -371,7 +375,12 @@ static int fail(am355_ctx* c, int code, const char* fmt, ...) {
 template <class F>
 static int guarded(am355_ctx* c, F body) {
   try {
-    return body();
+    int rc = body();
+    if (canary_on() && c) {  // AM355_CANARY=1 (am355_canary.h): did a kernel of this call write past one of its arrays?
+      char msg[320];
+      if (!canary_check(msg, sizeof msg)) return fail(c, AM355_E_DEVICE, "%s", msg);
+    }
+    return rc;
   } catch (const std::bad_alloc&) {
     return c ? fail(c, AM355_E_NOMEM, "out of host memory") : AM355_E_NOMEM;
   } catch (const std::exception& e) {
@@ -451,7 +460,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
-  c->d_delta.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta.release(); c->d_sync.release();
+  c->d_delta.release(); c->d_delta_edit.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta.release(); c->d_sync.release();
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
@@ -1300,11 +1309,12 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
 template <class T>
 static T* carve(uint8_t*& p, size_t count) {
   T* r = (T*)p;
-  p += ((count * sizeof(T)) + 255) & ~(size_t)255;
+  canary_note(p, count * sizeof(T));
+  p += carve_round(count * sizeof(T));
   return r;
 }
 
-static size_t carve_size(size_t count, size_t elem) { return ((count * elem) + 255) & ~(size_t)255; }
+static size_t carve_size(size_t count, size_t elem) { return carve_round(count * elem); }
 
 static uint32_t pow2_at_least(uint64_t v) {
   uint32_t p = 64;
@@ -1425,9 +1435,11 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
   int bits_ctr = bits_for64(c->max_op), bits_actor = bits_for64(NA ? NA - 1 : 0), bits_row = bits_for64(N);
   if (1 + bits_row + bits_ctr + bits_actor > 64) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "sort key wider than 64 bits"); }
   size_t Nc = (size_t)N + 1;
+  canary_scope("replay buffers (setup_buffers: op rows, preds, merge scratch, sort scratch, patch IR)");
   {
     size_t bytes = 13 * carve_size(Nc, 4) + carve_size(Nc, 1);
     if (!c->d_cols.ensure(bytes) || !c->d_pred.ensure(2 * carve_size((size_t)P + 1, 4))) return fail(c, AM355_E_NOMEM, "device allocation failed (op rows)");
+    canary_forget(c->d_cols.p, c->d_cols.cap); canary_forget(c->d_pred.p, c->d_pred.cap);
     uint8_t* p = c->d_cols.as<uint8_t>();
     OpCols& o = c->cols;
     o.obj_actor = carve<uint32_t>(p, Nc); o.obj_ctr = carve<uint32_t>(p, Nc); o.key_actor = carve<uint32_t>(p, Nc); o.key_ctr = carve<uint32_t>(p, Nc);
@@ -1448,6 +1460,7 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
                       4 * carve_size(Nc, 4);
     if (!c->d_merge.ensure(bytes) || !c->d_sort.ensure(sort_bytes) || !c->d_ir.ensure(ir_bytes) || !c->d_counts.ensure(merge_counts_bytes(N)))
       return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
+    canary_forget(c->d_merge.p, c->d_merge.cap); canary_forget(c->d_sort.p, c->d_sort.cap); canary_forget(c->d_ir.p, c->d_ir.cap);
     uint8_t* p = c->d_merge.as<uint8_t>();
     MergeBufs& b = c->mb;
     b.arena = c->d_arena.as<uint8_t>();
@@ -1461,7 +1474,8 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
     b.zero_base = p;
     b.succ_cnt = carve<uint32_t>(p, Nc); b.inc_cnt = carve<uint32_t>(p, Nc); b.val_cnt = carve<uint32_t>(p, Nc);
     b.inc_sum = carve<unsigned long long>(p, Nc); b.last_inc = carve<unsigned long long>(p, Nc);
-    b.zero_bytes = (size_t)(p - (uint8_t*)b.zero_base);
+    b.zero_bytes = (size_t)(p - (uint8_t*)b.zero_base) - (canary_on() ? 256 : 0);
+    canary_allow(b.zero_base, b.zero_bytes);
     b.obj_row = carve<uint32_t>(p, Nc); b.ref_row = carve<uint32_t>(p, Nc); b.obj_index = carve<uint32_t>(p, Nc);
     b.em_row = carve<uint32_t>(p, Nc); b.ins_row = carve<uint32_t>(p, Nc); b.upd_row = carve<uint32_t>(p, Nc); b.next_sib = carve<uint32_t>(p, Nc);
     b.em_trig = carve<unsigned long long>(p, Nc);
@@ -1472,7 +1486,8 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
     b.euler_b = carve<unsigned long long>(p, 2 * Nc + 2); b.euler_a = carve<unsigned long long>(p, 2 * Nc + 2);
     b.scan_a = carve<uint32_t>(p, Nc + 1); b.scan_b = carve<uint32_t>(p, Nc + 1);
     b.scan_ws = p;
-    p += (scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 255) & ~(size_t)255;
+    canary_note(p, scan_workspace_bytes((uint32_t)(2 * Nc + 2)));
+    p += carve_round(scan_workspace_bytes((uint32_t)(2 * Nc + 2)));
     b.run_heads = carve<uint32_t>(p, Nc + 3); b.row_run = carve<uint32_t>(p, Nc + 3); b.obj_n = carve<uint32_t>(p, Nc + 3);
     b.obj_first_pos = carve<uint32_t>(p, Nc + 3); b.list_vis = carve<uint32_t>(p, Nc + 3); b.list_cnt = carve<uint32_t>(p, Nc + 3);
     b.cs_ins.wg_sum = carve<uint32_t>(p, cw); b.cs_make.wg_sum = carve<uint32_t>(p, cw); b.cs_runs.wg_sum = carve<uint32_t>(p, cw);
@@ -1483,6 +1498,7 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
     b.child_next = b.child_head + (2 * Nc + 2);
     b.fill_base = b.order;
     b.fill_bytes = (size_t)((uint8_t*)(b.child_head + 2 * Nc + 1) - (uint8_t*)b.order);
+    canary_allow(b.fill_base, b.fill_bytes);
     uint8_t* s = c->d_sort.as<uint8_t>();
     b.key_a = carve<uint64_t>(s, Nc); b.key_b = carve<uint64_t>(s, Nc); b.val_a = carve<uint32_t>(s, Nc); b.val_b = carve<uint32_t>(s, Nc);
     b.sort_ws = s;
@@ -1492,6 +1508,7 @@ static int setup_buffers(am355_ctx* c, uint32_t NA) {
     ir.obj = carve<am355_ir_object>(r, Nc + 1); ir.map = carve<am355_ir_map>(r, Nc); ir.edit = carve<am355_ir_edit>(r, Nc + 1);
     ir.e_row = carve<uint32_t>(r, Nc); ir.e_elem = carve<uint32_t>(r, Nc); ir.e_index = carve<uint32_t>(r, Nc); ir.e_flags = carve<uint32_t>(r, Nc);
   }
+  canary_arm();
   return AM355_OK;
 }
 
@@ -1704,7 +1721,9 @@ static int replay_document(am355_ctx* c) {
     if (!c->d_big.ensure(bigcol_work_bytes(d.tok_bytes)) || !c->d_ks.ensure(keystr_work_bytes(m.col_len[C_KEY_STR])) || !c->h_biginfo.ensure(sizeof(BigColInfo)))
       return fail(c, AM355_E_NOMEM, "device allocation failed (document index)");
     BigColWork w;
+    canary_forget(c->d_big.p, c->d_big.cap);
     bigcol_carve(w, c->d_big.p, d.tok_bytes);
+    canary_arm();
     uint32_t *ks_start, *ks_off, *ks_len;
     uint32_t* d_words = c->d_words.as<uint32_t>();
     HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, st));
@@ -1712,6 +1731,7 @@ static int replay_document(am355_ctx* c) {
     HIPCHK(c, hipEventRecord(c->ev_b0, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_b0, 0));
     KeyStage ks;
+    canary_forget(c->d_ks.p, c->d_ks.cap);
     keystr_index_begin(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], c->d_ks.p, ks, d_words + W_TOTAL_ENTRIES, d_words + W_FAST_B,
                        c->stream2);
     HIPCHK(c, hipMemcpyAsync(c->h_words.as<uint32_t>() + W_FAST_B, d_words + W_FAST_B, 4, hipMemcpyDeviceToHost, c->stream2));
@@ -1738,7 +1758,9 @@ static int replay_document(am355_ctx* c) {
     if (N >= 0x7ffffff0u) { (void)hipStreamSynchronize(c->stream2); c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "more than 2^31 rows in one document"); }
     if (!c->d_bigvals.ensure(bigcol_vals_bytes(N, Pcap))) { (void)hipStreamSynchronize(c->stream2); return fail(c, AM355_E_NOMEM, "device allocation failed (document columns)"); }
     BigColVals v;
+    canary_forget(c->d_bigvals.p, c->d_bigvals.cap);
     bigcol_carve_vals(v, c->d_bigvals.p, N, Pcap);
+    canary_arm();
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     bigcol_expand(d, w, info, v, N, Pcap, st);
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
@@ -2175,6 +2197,7 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   if (!c->d_delta.ensure(delta_bytes(N, NN, NM, NO, NL)) || !c->d_pass.ensure(4 * (c->pass_first_row.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
   DeltaBufs& d = c->delta;
   delta_bind(d, c->d_delta.p, N, NN, NM, NO, NL);
+  canary_arm();
   d.T0 = T0; d.n_new = NN; d.n_obj = NO; d.n_map = NM; d.n_list = NL;
   d.bits_new = (uint32_t)bits_for64(NN ? NN - 1 : 0);
   std::vector<uint32_t> pass_rows;
@@ -2193,7 +2216,11 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   if (!breaks.empty()) HIPCHK(c, hipMemcpyAsync(c->d_breaks.p, breaks.data(), 4 * breaks.size(), hipMemcpyHostToDevice, st));
   if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));  // (pageable sources)
-  delta_run(c->mb, c->ir, d, hc, st, check_only);
+  auto grow = [](void* user, size_t records) -> am355_ir_edit* {
+    am355_ctx* cx = (am355_ctx*)user;
+    return cx->d_delta_edit.ensure(sizeof(am355_ir_edit) * records) ? cx->d_delta_edit.as<am355_ir_edit>() : nullptr;
+  };
+  delta_run(c->mb, c->ir, d, hc, st, check_only, grow, c);
   HIPCHK(c, hipGetLastError());
   return AM355_OK;
 }
@@ -2276,12 +2303,16 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
   const uint32_t NO = c->counts.n_objects;
   DeltaBufs& d = c->delta;
   DeltaCounts hc{};
+  // A call refused from here on leaves the context WITHOUT a state (include/am355.h): the replay above merged the batch, and a later
+  // call must not get patches relative to a state that silently holds a batch whose call boundary nobody recorded.
+  auto drop_state = [&](int code) { c->staged = c->replayed = c->ir_fetched = false; return code; };
   rc = run_delta_stage(c, (uint32_t)old_ops, &hc, false);
-  if (rc) return rc;
+  if (rc) return drop_state(rc);
   lap("delta stage");
   c->state_checked = true;  // (a call the engine served: checked; a refused call leaves the state to the JS path)
   if (hc.flags) {
     c->state_checked = false;
+    drop_state(0);
     if ((hc.flags & AM355_F_UNSUPPORTED) && hc.reason != NONE32) {
       c->flags |= hc.flags;
       return fail(c, AM355_E_UNSUPPORTED, "incremental patch not served: %s (JS path)", delta_reason_text(hc.reason));
@@ -2291,7 +2322,7 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
 
   // ---- tables to the host, setupPatches, assembly ----
   rc = fetch_ir_impl(c, nullptr, false);
-  if (rc) return rc;
+  if (rc) return drop_state(rc);
   lap("document tables on the host");
   const uint32_t n_dmap = hc.n_kept + hc.n_place, n_dedits = hc.n_erecs;
   size_t b_link = carve_size(NO, sizeof(ObjLink)), b_map = carve_size(n_dmap, sizeof(am355_ir_map)), b_edit = carve_size((size_t)n_dedits + 1, sizeof(am355_ir_edit));
@@ -2314,7 +2345,7 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
     if (rc == AM355_E_UNSUPPORTED && need.empty() && !c->hir.edits && err == "edit records needed") {
       // a touched object hangs in a list: setupPatches needs the whole-document edit records of that list
       int frc = fetch_ir_impl(c, nullptr, true);
-      if (frc) return frc;
+      if (frc) return drop_state(frc);
       lap("document edit records on the host");
       continue;
     }
@@ -2322,11 +2353,11 @@ static int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t
     // the walk met objects that are no longer visible: what the reference's objectMeta lists for their property follows from the
     // history of the rows on it (am355_delta.hip, delta_key_history)
     std::vector<KeyHistory> st_of(need.size());
-    if (delta_key_history(c->mb, c->ir, d, need.data(), (uint32_t)need.size(), st_of.data(), st) != 0) return fail(c, AM355_E_DEVICE, "key history: %s", hipGetErrorString(hipGetLastError()));
+    if (delta_key_history(c->mb, c->ir, d, need.data(), (uint32_t)need.size(), st_of.data(), st) != 0) return drop_state(0), fail(c, AM355_E_DEVICE, "key history: %s", hipGetErrorString(hipGetLastError()));
     for (size_t i = 0; i < need.size(); i++) known[need[i]] = st_of[i];
     lap("property histories");
   }
-  if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; return fail(c, rc, "%s", err.c_str()); }
+  if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; drop_state(0); return fail(c, rc, "%s", err.c_str()); }
   // the op streams of this call (this engine re-applies the earlier changes in front of them: their rows keep their numbers)
   if (old_ops) c->stream_breaks.push_back((uint32_t)old_ops);
   for (uint32_t r : c->pass_first_row) if (r > old_ops) c->stream_breaks.push_back(r);
@@ -2691,14 +2722,16 @@ static int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, si
   }
   // ---- device buffers ----
   size_t n1 = (size_t)N + 2, p1 = (size_t)P + 2, o1 = (size_t)n_obj + 2;
-  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  auto al = [](size_t b) { return carve_round(b); };
   size_t save_bytes = 10 * al(4 * n1) + 3 * al(4 * o1) + al(16 * o1) + 2 * al(8 * p1) + 2 * al(4 * p1) + al(64) + 13 * al(4 * n1) + al(n1) + 2 * al(4 * p1) + al(4 * (size_t)std::max(NA, 1u));
   if (!c->d_save.ensure(save_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed (save)");
   SaveBufs s;
   uint32_t* d_doc_actor;
   {
     uint8_t* p = c->d_save.as<uint8_t>();
-    auto take = [&](size_t bytes) { void* r = p; p += al(bytes); return r; };
+    canary_scope("save buffers (d_save)");
+    canary_forget(c->d_save.p, c->d_save.cap);
+    auto take = [&](size_t bytes) { void* r = p; canary_note(p, bytes); p += al(bytes); return r; };
     uint32_t** a10[] = {&s.map_flag, &s.map_ex, &s.upd_flag, &s.upd_ex, &s.upd_cnt, &s.pos_of, &s.list_off, &s.final_pos, &s.src_of, &s.map_perm};
     for (uint32_t** a : a10) *a = (uint32_t*)take(4 * n1);
     s.obj_rank = (uint32_t*)take(4 * o1); s.rank_obj = (uint32_t*)take(4 * o1); s.base_by_rank = (uint32_t*)take(4 * o1);
@@ -2713,6 +2746,7 @@ static int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, si
     o.insert = (uint8_t*)take(n1);
     o.pred_actor = (uint32_t*)take(4 * p1); o.pred_ctr = (uint32_t*)take(4 * p1);
     d_doc_actor = (uint32_t*)take(4 * (size_t)std::max(NA, 1u));
+    canary_arm();
   }
   HIPCHK(c, hipMemcpyAsync(d_doc_actor, doc_actor.data(), 4 * (size_t)std::max(NA, 1u), hipMemcpyHostToDevice, st));
   // ---- rows in saved-document order ----
@@ -2744,7 +2778,9 @@ static int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, si
   size_t enc_bytes = al(enc_work_bytes(nmax)) + al(4 * ((size_t)nmax + 2)) + al((size_t)nmax + 2) + al(4 * E_NUM);
   if (!c->d_enc.ensure(enc_bytes) || !c->d_encout.ensure(out_total + 256) || !c->h_words.ensure(256)) return fail(c, AM355_E_NOMEM, "device allocation failed (save columns)");
   EncWork w;
+  canary_forget(c->d_enc.p, c->d_enc.cap);
   enc_carve(w, c->d_enc.p, nmax);
+  canary_arm();
   uint32_t* deltas = (uint32_t*)(c->d_enc.as<uint8_t>() + al(enc_work_bytes(nmax)));
   uint8_t* nullmask = (uint8_t*)deltas + al(4 * ((size_t)nmax + 2));
   uint32_t* d_lens = (uint32_t*)(nullmask + al((size_t)nmax + 2));

@@ -21,15 +21,16 @@ namespace am355 {
 static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
 constexpr uint64_t MAX_SAFE_BIG = 9007199254740991ull;
 
-static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+static size_t al256(size_t b) { return carve_round(b); }
 size_t bigcol_work_bytes(uint32_t tok_bytes) {
   size_t cap = (size_t)tok_bytes + 2;
   return 11 * al256(4 * cap) + al256(2 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + al256(sizeof(BigColInfo)) + al256(chain_work_bytes((uint32_t)cap));
 }
 void bigcol_carve(BigColWork& w, void* base, uint32_t tok_bytes) {
+  canary_scope("document token work (bigcol_carve)");
   size_t cap = (size_t)tok_bytes + 2;
   uint8_t* p = (uint8_t*)base;
-  auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
+  auto take = [&](size_t bytes) { void* r = p; canary_note(p, bytes); p += al256(bytes); return r; };
   uint32_t** arrs[] = {&w.term_ex, &w.tok_end, &w.tok_lo, &w.tok_hi, &w.jump_a, &w.jump_b, &w.mark, &w.rec_ex, &w.rec_tok, &w.rec_rows, &w.rec_start};
   for (uint32_t** a : arrs) *a = (uint32_t*)take(4 * cap);
   w.tok_meta = (uint16_t*)take(2 * cap);
@@ -42,9 +43,10 @@ size_t bigcol_vals_bytes(uint32_t n_rows, uint32_t n_succ) {
   return 12 * al256(4 * n) + 2 * al256(4 * p) + al256(n) + al256(4 * (n > p ? n : p)) + al256(scan_workspace_bytes((uint32_t)(n > p ? n : p)));
 }
 void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_succ) {
+  canary_scope("document column values (bigcol_carve_vals)");
   size_t n = (size_t)n_rows + 1, pn = (size_t)n_succ + 1;
   uint8_t* p = (uint8_t*)base;
-  auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
+  auto take = [&](size_t bytes) { void* r = p; canary_note(p, bytes); p += al256(bytes); return r; };
   for (int c = 0; c < BIG_NCOL; c++) v.v[c] = (uint32_t*)take(4 * (c >= BC_SUCC_ACTOR ? pn : n));
   v.val_off = (uint32_t*)take(4 * n);
   v.succ_first = (uint32_t*)take(4 * n);
@@ -546,11 +548,13 @@ void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len
   uint32_t L = col_len, cap = L + 2;
   KeyWork& k = s.k;
   uint8_t* p = (uint8_t*)work;
-  auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
+  canary_scope("document key strings (keystr_index_begin)");
+  auto take = [&](size_t bytes) { void* r = p; canary_note(p, bytes); p += al256(bytes); return r; };
   uint32_t** arrs[] = {&k.vnext, &k.hnext, &k.kk, &k.ja, &k.jb, &k.mark_h, &k.mark_v, &k.item_ex, &k.rows, &k.run_start, &k.run_off, &k.run_len, &k.run_kind};
   for (uint32_t** a : arrs) *a = (uint32_t*)take(4 * (size_t)cap);
   k.scan_ws = take(scan_workspace_bytes(cap));
   s.chain_ws = take(chain_work_bytes(cap));
+  canary_arm();
   k.n_runs = n_runs;
   s.col = arena + col_abs;
   s.arena = arena;

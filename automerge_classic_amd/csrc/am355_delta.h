@@ -32,6 +32,8 @@ struct DeltaCounts {
   uint32_t n_slots;    // touched map keys
   uint32_t hazard;     // a key that holds a visible child object lost values to the merge loop's skipping rule (see kd_placeholders)
   uint32_t reason;     // DR_*: why the call is refused (the smallest code raised), NONE32: not refused by this stage
+  uint32_t rec_extra;  // edit records beyond one per item: an update / re-insert item writes one record per visible value (kd_events)
+  uint32_t pad;
 };
 enum : uint32_t {
   DR_FOREIGN_ROW = 1,     // a row of an object another shard owns
@@ -44,6 +46,7 @@ enum : uint32_t {
   DR_POP_WALK,            // too many update edits at one index in a row
   DR_AMBIGUOUS_DEL,       // a deletion whose place in the merge loop's work list is ambiguous
   DR_CHILD_HAZARD,        // values skipped on a key that holds a child object
+  DR_EDIT_TABLE,          // more edit records than the edit table holds and no memory to grow it
   DR_INTERNAL
 };
 const char* delta_reason_text(uint32_t reason);
@@ -78,7 +81,8 @@ struct DeltaBufs {
   uint32_t *zf, *zw, *zf_ex, *zw_ex;                  // [NN + 2]
   uint32_t *e_index, *e_flags, *e_head, *e_head_ex;   // [NN + 2] (e_head: records of the item)
   uint32_t *e_val, *e_val_ex;                         // [NN + 2] values of the item (count of a remove)
-  am355_ir_edit* edit;                                // [NN + 2]
+  am355_ir_edit* edit;                                // [edit_cap] (NN + 2 from the block; delta_run moves it when the records need more)
+  uint32_t edit_cap;
   // touched map keys: open-addressing table of cap slots (power of two)
   uint32_t key_mask;
   uint32_t *slot_rep, *slot_first, *slot_last, *slot_cont, *slot_cnt, *slot_child, *slot_drop, *place, *place_ex;  // [cap + 1]
@@ -101,7 +105,11 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t n_ops, uint32_t n_new, uint3
 // d.edit [n_erecs + 1], d.map [n_kept + n_place] and d.link [n_obj] are complete in device memory.
 // check_only: stop after the checks over the touched map keys (hc->hazard / hc->flags); no tables are produced. Used on a state
 // that one am355_load_changes + am355_replay built (T0 = 0: every row is "new"), before the first am355_apply_changes onto it.
-void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only = false);
+// grow_edit(records): device memory for that many edit records (the caller owns it), nullptr = out of memory. An item of a conflicted
+// list element writes one record per visible value, so the records can outnumber the new rows the block was carved for.
+typedef am355_ir_edit* (*DeltaGrowEdit)(void* user, size_t records);
+void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only = false, DeltaGrowEdit grow_edit = nullptr,
+               void* grow_user = nullptr);
 
 // What the reference's objectMeta holds in `children[key]` for the property (map key or list element) that holds -- or held -- each
 // of the given objects: the visible values, or nothing (KH_DEAD). It is refreshed only while it is non-empty or a child object is

@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t refuse(const DeltaBufs& d, uint32_t reason) 
 }
 
 static inline dim3 dgrid(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
-static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+static size_t al256(size_t b) { return carve_round(b); }
 
 static uint32_t key_table_cap(uint32_t n_new) {
   uint32_t cap = 64;
@@ -72,11 +72,14 @@ size_t delta_bytes(uint32_t N, uint32_t NN, uint32_t NM, uint32_t NO, uint32_t N
 template <class T>
 static T* dcarve(uint8_t*& p, size_t count) {
   T* r = (T*)p;
+  canary_note(p, count * sizeof(T));
   p += al256(count * sizeof(T));
   return r;
 }
 
 void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM, uint32_t NO, uint32_t NL) {
+  canary_scope("delta stage (delta_bind)");
+  canary_forget(block, delta_bytes(N, NN, NM, NO, NL));  // (the layout moves with the sizes: zones of the last call lie inside this call's arrays)
   uint8_t* p = (uint8_t*)block;
   size_t cap = key_table_cap(NN);
   d.key_mask = (uint32_t)cap - 1;
@@ -98,6 +101,7 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   d.e_head = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_head_ex = dcarve<uint32_t>(p, (size_t)NN + 2);
   d.e_val = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_val_ex = dcarve<uint32_t>(p, (size_t)NN + 2);
   d.edit = dcarve<am355_ir_edit>(p, (size_t)NN + 2);
+  d.edit_cap = NN + 2;
   d.slot_rep = dcarve<uint32_t>(p, cap + 1); d.slot_first = dcarve<uint32_t>(p, cap + 1); d.slot_last = dcarve<uint32_t>(p, cap + 1);
   d.slot_cont = dcarve<uint32_t>(p, cap + 1); d.slot_cnt = dcarve<uint32_t>(p, cap + 1); d.slot_child = dcarve<uint32_t>(p, cap + 1);
   d.slot_drop = dcarve<uint32_t>(p, cap + 1); d.place = dcarve<uint32_t>(p, cap + 1); d.place_ex = dcarve<uint32_t>(p, cap + 1);
@@ -107,8 +111,10 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   d.map = dcarve<am355_ir_map>(p, (size_t)NM + cap + 1);
   size_t biggest = std::max<size_t>({(size_t)N + 2, (size_t)NM + cap + 2, (size_t)NN + 4});
   d.scan_ws = p;
+  canary_note(p, scan_workspace_bytes((uint32_t)biggest));
   p += al256(scan_workspace_bytes((uint32_t)biggest));
   d.sort_ws = p;
+  canary_note(p, sort_workspace_bytes((uint32_t)((size_t)NM + cap + 1)));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -342,6 +348,8 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
   d.ev_kind[t] = ev;
   d.ev_before[t] = (before ? 1u : 0u) | lag << 1;
   d.ev_nafter[t] = after;
+  // an update (or an element that comes back) writes one edit record per visible value: the records beyond one per item (rare: conflicts)
+  if (after > 1 && (ev == EV_UPDATE || ev == EV_INSERT)) atomicAdd(&d.counts->rec_extra, after - 1);
   if (err) atomicOr(&d.counts->flags, err);
 }
 
@@ -775,6 +783,7 @@ const char* delta_reason_text(uint32_t reason) {
     case DR_POP_WALK: return "too many update edits at one list index in a row";
     case DR_AMBIGUOUS_DEL: return "a deletion whose place in the merge loop's work list is ambiguous";
     case DR_CHILD_HAZARD: return "values skipped on a key that holds a child object";
+    case DR_EDIT_TABLE: return "more edit records than the edit table holds";
     case DR_INTERNAL: return "internal: visible values of an element not found";
     default: return "outside the served subset";
   }
@@ -786,10 +795,14 @@ static int dbits_for(uint64_t max_value) {
   return b;
 }
 
-void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only) {
+void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only, DeltaGrowEdit grow_edit, void* grow_user) {
   const uint32_t N = b.n_ops, cap = d.key_mask + 1;
   static const bool debug = getenv("AM355_DELTA_DEBUG") != nullptr;  // (diagnostic: drain the stream after every step and say which)
   auto step = [&](const char* what) {
+    if (canary_on()) {  // AM355_CANARY=1: which step of the stage wrote past an array?
+      char msg[320];
+      if (!canary_check(msg, sizeof msg)) fprintf(stderr, "delta_run: after '%s': %s\n", what, msg);
+    }
     if (!debug) return;
     hipError_t e = hipStreamSynchronize(st);
     fprintf(stderr, "delta_run: %-18s %s (N %u T0 %u new %u obj %u map %u list %u cap %u)\n", what, hipGetErrorString(e), N, d.T0, d.n_new, d.n_obj, d.n_map, d.n_list, cap);
@@ -856,6 +869,15 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
 
   // ---- list edits: dominance counts by binary partitions on the time bits, most significant first ----
   const uint32_t m = hc->n_items;
+  // edit records <= one per item + the extra values of conflicted elements + the sentinel: the table must hold them BEFORE kd_edit_pack
+  // writes (the block has room for one record per new row only)
+  const size_t rec_bound = (size_t)m + hc->rec_extra + 2;
+  if (rec_bound > d.edit_cap) {
+    am355_ir_edit* big = grow_edit ? grow_edit(grow_user, rec_bound) : nullptr;
+    if (!big) { hc->flags |= AM355_F_UNSUPPORTED; hc->reason = DR_EDIT_TABLE; return; }
+    d.edit = big;
+    d.edit_cap = (uint32_t)std::min<size_t>(rec_bound, 0xffffffffu);
+  }
   int cur = 0;
   if (m) {
     static const bool no_lds = getenv("AM355_DELTA_NO_LDS") != nullptr;  // (tests: the level-by-level version on small batches too)
@@ -872,16 +894,21 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     }
     AM355_LAUNCH_INDEPENDENT(kd_edit_index, dgrid(m), dim3(BLOCK), st, b, d, cur, m);
   }
+  step("edit index");
   AM355_LAUNCH_INDEPENDENT(kd_edit_runs, dgrid(m + 1), dim3(BLOCK), st, b, d, cur, m);
   exclusive_scan2_u32(d.e_head, d.e_head_ex, nullptr, d.e_val, d.e_val_ex, nullptr, m + 1, d.scan_ws, st);
+  step("edit runs");
   AM355_LAUNCH_INDEPENDENT(kd_edit_pack, dgrid(m + 1), dim3(BLOCK), st, b, d, cur, m);
+  step("edit pack");
 
   // ---- map records in patch order ----
   const uint32_t nm = hc->n_kept + hc->n_place;
   if (nm) {
     AM355_LAUNCH_INDEPENDENT(kd_map_pairs, dgrid(std::max(d.n_map, cap)), dim3(BLOCK), st, b, d);
+    step("map pairs");
     int res = radix_sort_pairs(d.pair_key[0], d.pair_val[0], d.pair_key[1], d.pair_val[1], nm, 0, (int)d.bits_new + dbits_for(d.n_obj), d.sort_ws, st);
     AM355_LAUNCH_INDEPENDENT(kd_map_out, dgrid(nm), dim3(BLOCK), st, b, ir, d, (const uint64_t*)d.pair_key[res], (const uint32_t*)d.pair_val[res], nm);
+    step("map out");
   }
   (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);

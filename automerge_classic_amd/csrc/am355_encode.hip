@@ -12,12 +12,13 @@
 namespace am355 {
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
-static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+static size_t al256(size_t b) { return carve_round(b); }
 
 size_t enc_work_bytes(uint32_t n) { return 8 * al256(4 * ((size_t)n + 2)) + al256(scan_workspace_bytes(n + 2)); }
 void enc_carve(EncWork& w, void* base, uint32_t n) {
+  canary_scope("column encoder work (enc_carve)");
   uint8_t* p = (uint8_t*)base;
-  auto take = [&](size_t bytes) { void* r = p; p += al256(bytes); return r; };
+  auto take = [&](size_t bytes) { void* r = p; canary_note(p, bytes); p += al256(bytes); return r; };
   uint32_t** arrs[] = {&w.flag, &w.run_ex, &w.run_first, &w.grp_flag, &w.grp_ex, &w.grp_first, &w.size, &w.off_ex};
   for (uint32_t** a : arrs) *a = (uint32_t*)take(4 * ((size_t)n + 2));
   w.scan_ws = take(scan_workspace_bytes(n + 2));

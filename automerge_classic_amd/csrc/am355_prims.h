@@ -1,6 +1,7 @@
 // Device-wide primitives (see am355_prims.hip).
 #pragma once
 #include "am355_device.h"
+#include "am355_canary.h"
 #include <stddef.h>
 
 namespace am355 {

@@ -4,6 +4,10 @@
 // every pair once (12 B in, 12 B out) plus one histogram read of the keys.
 #include "am355_prims.h"
 #include "am355_scan.h"
+#include "am355_canary.h"
+#include <mutex>
+#include <string>
+#include <vector>
 
 namespace am355 {
 
@@ -524,6 +528,159 @@ void chain_mark(const uint32_t* next, uint32_t n, uint32_t* mark, void* work, hi
   }
   AM355_LAUNCH_INDEPENDENT(kc_entries, dim3(blocks), dim3(BLOCK), st, (const uint32_t*)n_nodes, (const uint32_t*)cpos, (const uint32_t*)cmark, mark);
   hipLaunchKernelGGL(kc_tile_marks, dim3(tiles), dim3(BLOCK), 0, st, next, n, mark);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AM355_CANARY=1: red zones behind every carve-out (am355_canary.h)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct CanaryZone { unsigned long long addr; uint32_t len, tag; };
+struct CanaryEntry { CanaryZone z; int device; std::string block; uint32_t index; bool armed; };
+std::mutex g_canary_mu;
+std::vector<CanaryEntry> g_canary;
+std::string g_canary_block = "?";
+uint32_t g_canary_index = 0;
+constexpr uint8_t CANARY_BYTE = 0xC5;
+}  // namespace
+
+bool canary_on() {
+  static const bool on = [] { const char* e = getenv("AM355_CANARY"); return e && *e && *e != '0'; }();
+  return on;
+}
+
+void canary_scope(const char* block) {
+  if (!canary_on()) return;
+  std::lock_guard<std::mutex> g(g_canary_mu);
+  g_canary_block = block;
+  g_canary_index = 0;
+}
+
+static void canary_forget_locked(unsigned long long lo, unsigned long long hi, int device) {
+  size_t k = 0;
+  for (size_t i = 0; i < g_canary.size(); i++) {
+    const CanaryEntry& e = g_canary[i];
+    bool overlap = e.device == device && e.z.addr < hi && e.z.addr + e.z.len > lo;
+    if (!overlap) { if (k != i) g_canary[k] = g_canary[i]; k++; }
+  }
+  g_canary.resize(k);
+}
+
+void canary_note(const void* base, size_t used) {
+  if (!canary_on()) return;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> g(g_canary_mu);
+  const uint32_t index = g_canary_index++;
+  const unsigned long long lo = (unsigned long long)(uintptr_t)base, z0 = lo + used, z1 = lo + carve_round(used);
+  for (CanaryEntry& e : g_canary)
+    if (e.device == device && e.z.addr == z0 && e.z.addr + e.z.len == z1) {  // the same carve-out as last time: its zone stands (and was verified)
+      e.block = g_canary_block; e.index = index;
+      return;
+    }
+  canary_forget_locked(lo, z1, device);
+  g_canary.push_back(CanaryEntry{CanaryZone{z0, (uint32_t)(z1 - z0), 0}, device, g_canary_block, index, false});
+}
+
+void canary_forget(const void* base, size_t bytes) {
+  if (!canary_on() || !base) return;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> g(g_canary_mu);
+  canary_forget_locked((unsigned long long)(uintptr_t)base, (unsigned long long)(uintptr_t)base + bytes, device);
+}
+
+void canary_allow(const void* base, size_t bytes) {
+  if (!canary_on() || !base || !bytes) return;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> g(g_canary_mu);
+  const unsigned long long lo = (unsigned long long)(uintptr_t)base, hi = lo + bytes;
+  size_t k = 0;
+  for (size_t i = 0; i < g_canary.size(); i++) {
+    CanaryEntry e = g_canary[i];
+    if (e.device == device && e.z.addr < hi && e.z.addr + e.z.len > lo) {
+      const unsigned long long end = e.z.addr + e.z.len;
+      if (end <= hi || e.z.addr < lo) continue;  // inside the range (or around its start: the carve-out in front is part of the fill)
+      e.z.len = (uint32_t)(end - hi);              // straddles the end: keep what lies behind it
+      e.z.addr = hi;
+      e.armed = false;
+    }
+    g_canary[k++] = e;
+  }
+  g_canary.resize(k);
+}
+
+// one workgroup per zone. fill: writes the pattern; check: the first damaged zone (smallest table index) and the offset of its first
+// damaged byte go to result[0..1]
+__global__ __launch_bounds__(BLOCK) void k_canary(const CanaryZone* __restrict__ zones, uint32_t n, int fill, uint32_t* __restrict__ result) {
+  const CanaryZone z = zones[blockIdx.x];
+  uint8_t* p = (uint8_t*)(uintptr_t)z.addr;
+  for (uint32_t i = threadIdx.x; i < z.len; i += BLOCK) {
+    if (fill) p[i] = CANARY_BYTE;
+    else if (p[i] != CANARY_BYTE) {
+      uint32_t prev = atomicMin(&result[0], blockIdx.x);
+      if (prev >= blockIdx.x) atomicMin(&result[2 + (blockIdx.x & 1023u)], i);
+    }
+  }
+}
+
+static bool canary_run(std::vector<CanaryZone>& zones, int fill, uint32_t* out_first, uint32_t* out_off) {
+  if (zones.empty()) return true;
+  CanaryZone* dz = nullptr;
+  uint32_t* dres = nullptr;
+  std::vector<uint32_t> res(2 + 1024, 0xffffffffu);
+  bool ok = hipMalloc((void**)&dz, sizeof(CanaryZone) * zones.size()) == hipSuccess && hipMalloc((void**)&dres, 4 * res.size()) == hipSuccess &&
+            hipMemcpy(dz, zones.data(), sizeof(CanaryZone) * zones.size(), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(dres, res.data(), 4 * res.size(), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_canary, dim3((uint32_t)zones.size()), dim3(BLOCK), 0, (hipStream_t)0, (const CanaryZone*)dz, (uint32_t)zones.size(), fill, dres);
+    ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(res.data(), dres, 4 * res.size(), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (dz) (void)hipFree(dz);
+  if (dres) (void)hipFree(dres);
+  if (!ok) { *out_first = 0xfffffffeu; return false; }
+  *out_first = res[0];
+  *out_off = res[0] != 0xffffffffu ? res[2 + (res[0] & 1023u)] : 0;
+  return res[0] == 0xffffffffu;
+}
+
+void canary_arm() {
+  if (!canary_on()) return;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::vector<CanaryZone> zones;
+  {
+    std::lock_guard<std::mutex> g(g_canary_mu);
+    for (CanaryEntry& e : g_canary)
+      if (e.device == device && !e.armed) { zones.push_back(e.z); e.armed = true; }
+  }
+  if (zones.empty()) return;
+  (void)hipDeviceSynchronize();  // (kernels of an earlier layout may still be writing where the new zones lie)
+  uint32_t a = 0, b = 0;
+  (void)canary_run(zones, 1, &a, &b);
+}
+
+bool canary_check(char* msg, size_t msg_len) {
+  if (!canary_on()) return true;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::vector<CanaryZone> zones;
+  std::vector<size_t> which;
+  {
+    std::lock_guard<std::mutex> g(g_canary_mu);
+    for (size_t i = 0; i < g_canary.size(); i++)
+      if (g_canary[i].device == device && g_canary[i].armed) { zones.push_back(g_canary[i].z); which.push_back(i); }
+  }
+  (void)hipDeviceSynchronize();
+  uint32_t first = 0, off = 0;
+  if (canary_run(zones, 0, &first, &off)) return true;
+  std::lock_guard<std::mutex> g(g_canary_mu);
+  if (first < which.size() && which[first] < g_canary.size()) {
+    CanaryEntry& e = g_canary[which[first]];
+    snprintf(msg, msg_len, "AM355_CANARY: carve-out #%u of block '%s' was overrun (red zone of %u bytes damaged from byte +%u on)", e.index, e.block.c_str(), e.z.len, off);
+    e.armed = false;  // (filled again by the next canary_arm: one report per overrun)
+  } else snprintf(msg, msg_len, "AM355_CANARY: the check itself failed (%s)", hipGetErrorString(hipGetLastError()));
+  return false;
 }
 
 }  // namespace am355

@@ -64,6 +64,12 @@ class GpuState {
     this.pendingIdx = null   // input indexes of the changes still queued (loadChanges / applyChanges states)
     this.calls = 1           // backend calls that built the state (1: one loadChanges / applyChanges onto an empty document)
     this.fromDocument = false // the lineage began with load(bytes): the reference's objectMeta came from the document, not from changes
+    // How the reference would have come to this state, call by call: the document the lineage began with (or null) and the batch of
+    // every loadChanges / applyChanges call since. hydrate() replays exactly these calls: what the reference's objectMeta.children
+    // holds depends on where its calls ended (new.js:916-931), and a call the engine refused is re-run on a state that must be the
+    // reference's own (ADVICE r3).
+    this.baseDoc = null
+    this.batches = null
   }
 }
 let generation = 0           // bumped by every GPU replay
@@ -128,6 +134,10 @@ function hydrate(backend) {
         if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
       }
       g.js = bytes ? ref().load(bytes) : ref().loadChanges(ref().init(), g.changes)
+    } else if (g.batches) {
+      let handle = g.baseDoc ? ref().load(g.baseDoc) : ref().init()
+      for (const batch of g.batches) handle = ref().loadChanges(handle, batch)
+      g.js = handle
     } else g.js = ref().loadChanges(ref().init(), g.changes)
   }
   return g.js
@@ -180,6 +190,7 @@ function loadChanges(backend, changes) {
       counters.gpuLoadChanges++
       backend.frozen = true
       const state = new GpuState(changes.slice(), patch, patch.deps)
+      state.batches = [state.changes]
       state.generation = generation
       state.applied = addon.appliedOrder(ctx)
       state.pendingIdx = addon.pendingOrder(ctx)
@@ -359,6 +370,8 @@ function gpuApplyChanges(backend, changes) {
   state.pending = patch.pendingChanges
   state.calls = g ? g.calls + 1 : 1
   state.fromDocument = !!(g && (g.fromDocument || g.doc))
+  state.baseDoc = g ? (g.baseDoc || g.doc || null) : null
+  state.batches = (g && g.batches ? g.batches : []).concat([changes.slice()])
   counters.gpuApplyChanges++
   return [{ state, heads: patch.deps }, patch]
 }
@@ -388,8 +401,8 @@ function free(backend) {
 // the bulk receive runs on the engine --, and what generateSyncMessage computes over the hash graph of an engine-built state is
 // served from the engine too: the dependency graph by index (resolved on the device while the changes were hashed), the Bloom
 // filter over the hashes of the changes since the last sync built on the device, filters received from the peer probed there.
-// The protocol logic itself is restated from sync.js (it is host code in the reference as well); the wire encoding is the
-// reference's own encodeSyncMessage / decodeSyncMessage.
+// The protocol logic itself (what to send when, the bookkeeping about the peer, the wire encoding) is the reference's own sync.js,
+// bound to this module by boundSync() below.
 // ---------------------------------------------------------------------------------------------------------------------------
 function hexOfHash(g, i) { return Buffer.from(g.hashes.buffer, g.hashes.byteOffset + 32 * i, 32).toString('hex') }
 
@@ -547,82 +560,60 @@ function changesToSendGpu(backend, g, have, need) {
     if (i !== undefined) toSend.add(i)
     if (i === undefined || !inList.has(i)) { const change = getChangeByHash(backend, hash); if (change) out.push(change) }
   }
-  for (const i of list) if (toSend.has(i)) out.push(g.changes[i])
+  for (const i of list) if (toSend.has(i)) { engineHashOf.set(g.changes[i], hexOfHash(g, i)); out.push(g.changes[i]) }
   return out
 }
 
-const compareArrays = (a, b) => (a.length === b.length) && a.every((v, i) => v === b[i])
-
-// generateSyncMessage (sync.js:320-392)
-function generateSyncMessage(backend, syncState) {
-  if (!backend) throw new Error('generateSyncMessage called with no Automerge document')
-  if (!syncState) throw new Error('generateSyncMessage requires a syncState, which can be created with initSyncState()')
-  const g = gpuHistory(backend, true)
-  if (!g || !g.pendingIdx) return ref().generateSyncMessage(hydrate(backend), syncState)
-  let { sharedHeads, lastSentHeads, theirHeads, theirNeed, theirHave, sentHashes } = syncState
-  const ourHeads = backend.heads
-  const ourNeed = missingDeps(g, theirHeads || [])
-  let ourHave = []
-  if (!theirHeads || ourNeed.every(hash => theirHeads.includes(hash))) ourHave = [makeBloomFilterGpu(g, sharedHeads)]
-  if (theirHave && theirHave.length > 0) {
-    const lastSync = theirHave[0].lastSync
-    if (!lastSync.every(hash => getChangeByHash(backend, hash))) {
-      const resetMsg = { heads: ourHeads, need: [], have: [{ lastSync: [], bloom: new Uint8Array(0) }], changes: [] }
-      return [syncState, ref().encodeSyncMessage(resetMsg)]
+// The protocol logic is the REFERENCE'S OWN backend/sync.js, not a restatement of it: a private instance of that file is compiled
+// with THIS module as its './backend' (so its Backend.getHeads / getMissingDeps / getChangeByHash / getChanges / applyChanges calls
+// land on the functions above -- the bulk receive runs am355_apply_changes) and with two of its module-local functions rebound:
+// makeBloomFilter (sync.js:234-238) and getChangesToSend (sync.js:246-306) go to the device paths above when the state is the
+// engine's. Its './columnar' is the reference's own with one shortcut: decodeChangeMeta(change, true) of a change the engine
+// hashed takes the hash from the engine instead of running SHA-256 in JS again (the reference's own TODO, sync.js:375-377).
+// Nothing is written to disk and the instance does not enter require.cache: the installed package keeps its own sync.js.
+let boundSyncModule = null
+const engineHashOf = new WeakMap()   // change buffer (as retained by a GpuState) -> hex hash the device computed
+function boundSync() {
+  if (boundSyncModule) return boundSyncModule
+  const Module = require('module'), fs = require('fs')
+  const dir = path.dirname(require.resolve(process.env.AUTOMERGE_BACKEND_PATH || 'automerge/backend'))
+  const file = path.join(dir, 'sync.js')
+  const rebind = '\n;module.exports.__rebind = h => { makeBloomFilter = h.makeBloomFilter(makeBloomFilter); getChangesToSend = h.getChangesToSend(getChangesToSend) }\n'
+  const realColumnar = columnar()
+  const columnarForSync = Object.assign(Object.create(realColumnar), {
+    decodeChangeMeta(change, computeHash) {
+      const known = computeHash ? engineHashOf.get(change) : undefined
+      if (known === undefined) return realColumnar.decodeChangeMeta(change, computeHash)
+      const meta = realColumnar.decodeChangeMeta(change, false)
+      meta.hash = known
+      return meta
     }
+  })
+  const m = new Module(file, module)
+  m.filename = file
+  m.paths = Module._nodeModulePaths(dir)
+  m.require = function (id) {
+    if (id === './backend') return module.exports
+    if (id === './columnar') return columnarForSync
+    return Module.prototype.require.call(this, id)
   }
-  let changesToSend = Array.isArray(theirHave) && Array.isArray(theirNeed) ? changesToSendGpu(backend, g, theirHave, theirNeed) : []
-  const headsUnchanged = Array.isArray(lastSentHeads) && compareArrays(ourHeads, lastSentHeads)
-  const headsEqual = Array.isArray(theirHeads) && compareArrays(ourHeads, theirHeads)
-  if (headsUnchanged && headsEqual && changesToSend.length === 0) return [syncState, null]
-  const hashOfChange = new Map()
-  g.applied.forEach(i => hashOfChange.set(g.changes[i], i))
-  const hashHex = change => { const i = hashOfChange.get(change); return i === undefined ? columnar().decodeChangeMeta(change, true).hash : hexOfHash(g, i) }
-  changesToSend = changesToSend.filter(change => !sentHashes[hashHex(change)])
-  const syncMessage = { heads: ourHeads, have: ourHave, need: ourNeed, changes: changesToSend }
-  if (changesToSend.length > 0) {
-    sentHashes = Object.assign({}, sentHashes)
-    for (const change of changesToSend) sentHashes[hashHex(change)] = true
-  }
-  syncState = Object.assign({}, syncState, { lastSentHeads: ourHeads, sentHashes })
-  return [syncState, ref().encodeSyncMessage(syncMessage)]
+  m._compile(fs.readFileSync(file, 'utf8') + rebind, file)
+  m.loaded = true
+  const engineState = backend => { const g = gpuHistory(backend, true); return g && g.pendingIdx ? g : null }
+  m.exports.__rebind({
+    makeBloomFilter: original => (backend, lastSync) => {
+      const g = engineState(backend)
+      return g ? makeBloomFilterGpu(g, lastSync) : original(backend, lastSync)
+    },
+    getChangesToSend: original => (backend, have, need) => {
+      const g = engineState(backend)
+      return g ? changesToSendGpu(backend, g, have, need) : original(backend, have, need)
+    }
+  })
+  boundSyncModule = m.exports
+  return boundSyncModule
 }
-
-// advanceHeads (sync.js:406-411)
-function advanceHeads(myOldHeads, myNewHeads, ourOldSharedHeads) {
-  const newHeads = myNewHeads.filter(head => !myOldHeads.includes(head))
-  const commonHeads = ourOldSharedHeads.filter(head => myNewHeads.includes(head))
-  return [...new Set([...newHeads, ...commonHeads])].sort()
-}
-
-// receiveSyncMessage (sync.js:420-473): the changes of the message go through applyChanges above -- on the engine when the state is
-// the engine's -- and the bookkeeping about the peer follows the reference line by line. As there, the handle is only replaced
-// (and the old one frozen) when the message carried changes.
-function receiveSyncMessage(backend, oldSyncState, binaryMessage) {
-  if (!backend) throw new Error('generateSyncMessage called with no Automerge document')
-  if (!oldSyncState) throw new Error('generateSyncMessage requires a syncState, which can be created with initSyncState()')
-  if (JS_ONLY || !(backend.state instanceof GpuState || isEmptyRefState(backend))) {
-    const handle = hydrate(backend)
-    return ref().receiveSyncMessage(handle, oldSyncState, binaryMessage)
-  }
-  let { sharedHeads, lastSentHeads, sentHashes } = oldSyncState, patch = null
-  const message = ref().decodeSyncMessage(binaryMessage)
-  const beforeHeads = getHeads(backend)
-  if (message.changes.length > 0) {
-    [backend, patch] = applyChanges(backend, message.changes)
-    sharedHeads = advanceHeads(beforeHeads, getHeads(backend), sharedHeads)
-  }
-  if (message.changes.length === 0 && compareArrays(message.heads, beforeHeads)) lastSentHeads = message.heads
-  const knownHeads = message.heads.filter(head => getChangeByHash(backend, head))
-  if (knownHeads.length === message.heads.length) {
-    sharedHeads = message.heads
-    if (message.heads.length === 0) { lastSentHeads = []; sentHashes = [] }
-  } else {
-    sharedHeads = [...new Set(knownHeads.concat(sharedHeads))].sort()
-  }
-  const syncState = { sharedHeads, lastSentHeads, theirHave: message.have, theirHeads: message.heads, theirNeed: message.need, sentHashes }
-  return [backend, syncState, patch]
-}
+const syncModule = () => (JS_ONLY ? ref() : boundSync())
 
 const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...args)
 
@@ -632,14 +623,14 @@ module.exports = {
   applyChanges,
   applyLocalChange: delegate1('applyLocalChange'),
   getChangesAdded: (b1, b2) => ref().getChangesAdded(hydrate(b1), hydrate(b2)),
-  // sync protocol: unchanged reference code operating on JS handles (backend/sync.js:20 binds the JS backend)
-  generateSyncMessage,
-  receiveSyncMessage,
-  encodeSyncMessage: (...a) => ref().encodeSyncMessage(...a),
-  decodeSyncMessage: (...a) => ref().decodeSyncMessage(...a),
-  encodeSyncState: (...a) => ref().encodeSyncState(...a),
-  decodeSyncState: (...a) => ref().decodeSyncState(...a),
-  initSyncState: (...a) => ref().initSyncState(...a),
+  // sync protocol: the reference's own backend/sync.js bound to this module (boundSync above)
+  generateSyncMessage: (...a) => syncModule().generateSyncMessage(...a),
+  receiveSyncMessage: (...a) => syncModule().receiveSyncMessage(...a),
+  encodeSyncMessage: (...a) => syncModule().encodeSyncMessage(...a),
+  decodeSyncMessage: (...a) => syncModule().decodeSyncMessage(...a),
+  encodeSyncState: (...a) => syncModule().encodeSyncState(...a),
+  decodeSyncState: (...a) => syncModule().decodeSyncState(...a),
+  initSyncState: (...a) => syncModule().initSyncState(...a),
   // engine statistics of the last GPU replay (not part of the reference surface)
   _engineStats: () => (addon ? addon.stats(ctx) : null),
   _counters: counters

@@ -223,10 +223,13 @@ int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
  * the batch touched, and the links from the touched objects up to _root.  Afterwards am355_apply_patch_json / am355_fetch_apply_ir
  * give that patch, and am355_patch_json / am355_fetch_ir / am355_save / am355_get_applied ... describe the new state as after
  * am355_replay.
- * AM355_E_INVALID: the reference throws on this batch.  AM355_E_UNSUPPORTED: legal, but outside the subset served here (an
- * assignment to a list element or a deletion of one that holds several values, an edit inside an object that is no longer reachable,
- * a state made by am355_load_document): the host serves the call on the JS path.  After either the context no longer holds a
- * state (load again).
+ * AM355_E_INVALID: the reference throws on this batch.  AM355_E_UNSUPPORTED: legal, but outside the subset served here -- the error
+ * text names the reason (DR_* in csrc/am355_delta.h): two ops of one merge call on one list element, a list element that holds an
+ * `inc` / `link` op or more than 32 value rows, a deletion whose place in the merge loop's work list is ambiguous, a property history
+ * the device cannot replay (too long, or dependent on call boundaries the host did not keep), a sharded context, a state made by
+ * am355_load_document.  Assignments to list elements, conflicting ones included (several values per element: one edit record per
+ * visible value), are served.  The host serves a refused call on the JS path.  After either error the context no longer holds a
+ * state (every refusal path drops it: load again).
  */
 int am355_apply_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes);
 /* Forget the state the context holds: the next am355_apply_changes is Backend.applyChanges(Backend.init(), changes). */

@@ -5,8 +5,8 @@
 //
 //   NODE_PATH=oracle/js_shims/node_modules [REF_BLOCK_SIZE=100000000] node oracle/js/apply_campaign.js out.jsonl SPEC...
 //   SPEC = seed:actors:steps:depth (mixed document) | t:seed:actors:rounds:burst (text) | m:seed:actors:steps:depth (see servedScenario)
-//        | l:seed:actors:steps:p2 (see listScenario);
-//   every SPEC yields 3 sessions
+//        | l:seed:actors:steps:p2 (see listScenario) | c:seed:actors:elements:keys (see conflictScenario: its own call plan);
+//   every other SPEC yields 3 sessions
 const fs = require('fs')
 const { splitmix, frontendScenario, textScenario, Backend } = require('./make_golden.js')
 const out = process.argv[2]
@@ -14,7 +14,8 @@ const Automerge = require('./make_golden.js').Automerge
 
 // "m:" scenarios: what the engine's incremental-patch stage serves (automerge_classic_amd/csrc/am355_delta.hip) -- nested maps and
 // tables with conflicting assignments, deletions and counters, lists and texts that grow and shrink by insertion and deletion
-// (objects as list elements included) but whose elements are never assigned to -- edited by several actors that merge at random.
+// (objects as list elements included) -- edited by several actors that merge at random. (THIS generator never assigns to list
+// elements; the "l:" and "c:" generators below do.)
 function servedScenario(seed, nActors, steps, depthLimit) {
   const rnd = splitmix(seed)
   const pick = arr => arr[Math.floor(rnd() * arr.length)]
@@ -117,10 +118,58 @@ function listScenario(seed, nActors, steps, p2pct) {
   for (let i = 0; i < nActors; i++) all = Automerge.merge(all, docs[i])
   return Automerge.getAllChanges(all)
 }
+// "c:" scenarios: WIDE conflicts -- every actor assigns (or deletes) the same `nElems` list elements and sets `nKeys` map keys in ONE
+// change each, concurrently; the changes are then delivered one call per actor. Every element of the later calls yields an update
+// edit with one record PER VISIBLE VALUE, so the edit records of a call outnumber its op rows (2-way: 2 per row, 3-way: 3 per row):
+// the shape that overflowed the engine's edit table (ADVICE r3). Returns {changes, calls} (its own call plan).
+function conflictScenario(seed, nActors, nElems, nKeys) {
+  const rnd = splitmix(seed)
+  const ids = []
+  for (let i = 0; i < nActors; i++) { let a = 'abcdef'[i % 6]; while (a.length < 32) a += '0123456789abcdef'[Math.floor(rnd() * 16)]; ids.push(a) }
+  let base = Automerge.init(ids[0])
+  base = Automerge.change(base, d => { d.l = []; for (let i = 0; i < nElems; i++) d.l.push('e' + i); d.m = {}; d.t = new Automerge.Text('abc') })
+  const baseChanges = Automerge.getAllChanges(base)
+  const docs = ids.map((id, i) => (i === 0 ? base : Automerge.merge(Automerge.init(id), base)))
+  for (let a = 0; a < nActors; a++) {
+    docs[a] = Automerge.change(docs[a], d => {
+      for (let i = 0; i < nElems; i++) {
+        if (a > 0 && seed % 3 === 0 && i % 7 === 3) continue            // (holes: not every element is touched by everyone)
+        d.l[i] = 'a' + a + '_' + i
+      }
+      for (let k = 0; k < nKeys; k++) d.m['k' + String(k).padStart(3, '0')] = a * 1000 + k
+      if (seed % 2 === 1) d.t.insertAt(1, 'x', 'y')
+    })
+    if (seed % 5 === 2 && a === nActors - 1) {
+      // a last actor that had seen nothing deletes a stretch while the others assign to it: those elements come back
+      docs[a] = Automerge.change(docs[a], d => { d.l.splice(2, Math.min(5, d.l.length - 2)) })
+    }
+  }
+  const per = docs.map(d => Automerge.getAllChanges(d).slice(baseChanges.length))
+  const calls = [baseChanges.concat(per[0])]
+  for (let a = 1; a < nActors; a++) calls.push(per[a])
+  return { calls }
+}
 const b64 = u8 => Buffer.from(u8.buffer, u8.byteOffset, u8.byteLength).toString('base64')
 const lines = []
 for (const spec of process.argv.slice(3)) {
   const f = spec.split(':')
+  if (f[0] === 'c') {
+    const { calls } = conflictScenario(+f[1], +f[2], +f[3], +f[4])
+    for (let variant = 0; variant < 2; variant++) {
+      // variant 1: the later actors' changes in ONE call (one scheduling pass, several merge calls)
+      const plan = variant === 0 ? calls : [calls[0], [].concat(...calls.slice(1))]
+      let backend = Backend.init()
+      const patches = []
+      for (const batch of plan) {
+        const [b2, patch] = Backend.applyChanges(backend, batch)
+        backend = b2
+        patches.push(JSON.stringify(patch))
+      }
+      lines.push(JSON.stringify({ name: `${spec}#${variant}`, calls: plan.map(c => c.map(b64)), patches }))
+    }
+    console.error(`${spec}: ${calls.reduce((n, c) => n + c.length, 0)} changes`)
+    continue
+  }
   const changes = f[0] === 't' ? textScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'm' ? servedScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'l' ? listScenario(+f[1], +f[2], +f[3], +f[4]) : frontendScenario(+f[0], +f[1], +f[2], +f[3])
   const rnd = splitmix(0xABCD + (f[0] === 't' || f[0] === 'm' || f[0] === 'l' ? +f[1] : +f[0]))
   for (let variant = 0; variant < 3; variant++) {

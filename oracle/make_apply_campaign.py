@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SPECS = ["m:11:3:120:2", "m:12:4:160:3", "m:15:2:100:3", "m:16:6:140:2", "t:13:4:4:16", "t:14:6:3:24", "t:17:3:8:10", "21:3:70:2"]
 # lists whose elements are assigned to (apply_campaign.js listScenario) -> tests/golden/apply_campaign_lists.json.gz
 LIST_SPECS = ["l:31:2:60:0", "l:32:3:90:0", "l:33:4:120:0", "l:34:3:100:10", "l:35:5:150:0", "l:36:2:80:25"]
+# wide conflicts: every actor assigns the same list elements in one change (apply_campaign.js conflictScenario): more edit records than
+# op rows per call -> tests/golden/apply_campaign_conflicts.json.gz
+CONFLICT_SPECS = ["c:41:2:60:40", "c:42:3:30:10", "c:43:3:200:0", "c:44:4:64:5", "c:45:2:300:100", "c:47:5:40:3", "c:48:2:5:0"]
 
 
 def main(specs=SPECS, name="apply_campaign.json.gz"):
@@ -49,3 +52,4 @@ def main(specs=SPECS, name="apply_campaign.json.gz"):
 if __name__ == "__main__":
     main()
     main(LIST_SPECS, "apply_campaign_lists.json.gz")
+    main(CONFLICT_SPECS, "apply_campaign_conflicts.json.gz")

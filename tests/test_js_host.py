@@ -105,6 +105,19 @@ def test_sync_protocol_over_the_engine_against_the_live_reference_emulated():
     assert served["gpuApplyChanges"] >= 12 and served["fallbackToJs"] == 0 and served["hydrations"] == 0
 
 
+@pytest.mark.skipif(NODE is None or not os.path.isdir("/root/reference"), reason="needs node and the reference tree (build container only)")
+def test_states_built_by_several_engine_calls_hydrate_to_the_reference_state_emulated():
+    """every call the engine refuses, applyLocalChange and clone run on the HYDRATED reference handle, whose objectMeta depends
+    on where the calls that built the state ended: hydrate() replays the recorded calls one by one. Sessions of the applyChanges
+    campaigns through the engine, and after every second call the NEXT call through the reference on the clone of the engine's state:
+    the patch must be the one the reference recorded."""
+    env = _emu_env(NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"), AUTOMERGE_BACKEND_PATH="/root/reference/backend")
+    out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "hydrate_check.js"), "apply_campaign.json.gz", "apply_campaign_conflicts.json.gz"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "DIFFERENT 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert int(out.stdout.split("hydrate check: ")[1].split()[0]) >= 200
+
+
 @pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_js_host_materialises_incremental_patches_emulated():
     """Backend.applyChanges calls of the reference's suites: node -> addon -> (emulated) am355_apply_changes -> record tables ->
