@@ -464,12 +464,23 @@ __global__ __launch_bounds__(BLOCK) void kk_item_init(const uint8_t* __restrict_
 }
 
 // 1 for every run of the final table: repetitions and null runs sit on their header, literal values on their string
+// (four positions per thread, as 16-byte loads and one 16-byte store where a whole stretch lies inside the column: one position per
+// thread was half a million wavefronts of three loads each for a 34 MB column -- 1.6 ms, bound by launching them)
 __global__ __launch_bounds__(BLOCK) void kk_item_flags(uint32_t L, KeyWork k) {
-  uint32_t i = gtid();
-  if (i > L + 1) return;
-  uint32_t f = 0;
-  if (i < L) f = (k.mark_h[i] && !k.kk[i]) || k.mark_v[i] ? 1u : 0u;
-  k.item_ex[i] = f;
+  const uint32_t i0 = gtid() * 4;
+  if (i0 > L + 1) return;
+  const bool wide = i0 + 4 <= L && ((((uintptr_t)k.mark_h | (uintptr_t)k.kk | (uintptr_t)k.mark_v | (uintptr_t)k.item_ex) & 15) == 0);
+  if (wide) {
+    const uint4 h = *(const uint4*)(k.mark_h + i0), q = *(const uint4*)(k.kk + i0), v = *(const uint4*)(k.mark_v + i0);
+    *(uint4*)(k.item_ex + i0) = uint4{(h.x && !q.x) || v.x ? 1u : 0u, (h.y && !q.y) || v.y ? 1u : 0u, (h.z && !q.z) || v.z ? 1u : 0u,
+                                      (h.w && !q.w) || v.w ? 1u : 0u};
+    return;
+  }
+  for (uint32_t i = i0; i < i0 + 4 && i <= L + 1; i++) {
+    uint32_t f = 0;
+    if (i < L) f = (k.mark_h[i] && !k.kk[i]) || k.mark_v[i] ? 1u : 0u;
+    k.item_ex[i] = f;
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void kk_items(const uint8_t* __restrict__ col, uint32_t col_abs, uint32_t L, KeyWork k, uint32_t* __restrict__ flags) {
@@ -596,7 +607,7 @@ void keystr_index_finish(KeyStage& s, bool unresolved, uint32_t** run_start, uin
   *run_start = k.run_start; *run_off = k.run_off; *run_len = k.run_len;
   AM355_LAUNCH_INDEPENDENT(kk_item_init, grid_for(cap), dim3(BLOCK), st, s.col, L, k, flags);
   chain_mark(k.ja, L, k.mark_v, s.chain_ws, st);     // 3. literal items
-  AM355_LAUNCH_INDEPENDENT(kk_item_flags, grid_for(cap), dim3(BLOCK), st, L, k);
+  AM355_LAUNCH_INDEPENDENT(kk_item_flags, grid_for((cap + 3) / 4), dim3(BLOCK), st, L, k);
   exclusive_scan_u32(k.item_ex, k.item_ex, cap, k.n_runs, k.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(kk_items, grid_for(L), dim3(BLOCK), st, s.col, s.col_abs, L, k, flags);
   exclusive_scan_u32(k.rows, k.run_start, cap, nullptr, k.scan_ws, st);

@@ -28,11 +28,15 @@ constexpr uint32_t SCAN_TWO_LAUNCH_TILES = 1024;
 __global__ __launch_bounds__(BLOCK) void k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t* __restrict__ tile_sums, uint32_t n) {
   __shared__ uint32_t s[BLOCK / WAVE];
   uint32_t base = blockIdx.x * SCAN_TILE;
-  uint32_t sum = 0;
+  uint32_t v[SCAN_ITEMS];  // (all loads requested before the first is used: a branch around each made them one round trip apiece)
+#pragma unroll
   for (int j = 0; j < SCAN_ITEMS; j++) {
     uint32_t i = base + j * BLOCK + threadIdx.x;
-    if (i < n) sum += in[i];
+    v[j] = i < n ? in[i] : 0u;
   }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) sum += v[j];
   uint32_t total = block_sum_u32(sum, s);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
@@ -41,12 +45,24 @@ __global__ __launch_bounds__(BLOCK) void k_scan_tile_sums(const uint32_t* __rest
 __global__ __launch_bounds__(BLOCK) void k_scan_sums(uint32_t* __restrict__ sums, uint32_t n_tiles, uint32_t* __restrict__ grand_total) {
   __shared__ uint32_t s[BLOCK / WAVE];
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < n_tiles; base += BLOCK) {
-    uint32_t i = base + threadIdx.x;
-    uint32_t v = i < n_tiles ? sums[i] : 0;
+  // every thread takes SUMS_PER consecutive sums per round (all loaded before any is used): a quarter of the rounds -- each a load, a
+  // workgroup scan with two barriers and a store -- of one sum per thread
+  constexpr uint32_t SUMS_PER = 4;
+  for (uint32_t base = 0; base < n_tiles; base += BLOCK * SUMS_PER) {
+    const uint32_t i0 = base + threadIdx.x * SUMS_PER;
+    uint32_t v[SUMS_PER], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SUMS_PER; k++) {
+      v[k] = i0 + k < n_tiles ? sums[i0 + k] : 0u;
+      mine += v[k];
+    }
     uint32_t total;
-    uint32_t ex = block_exclusive_scan_u32(v, s, &total);
-    if (i < n_tiles) sums[i] = carry + ex;
+    uint32_t ex = block_exclusive_scan_u32(mine, s, &total) + carry;
+#pragma unroll
+    for (uint32_t k = 0; k < SUMS_PER; k++) {
+      if (i0 + k < n_tiles) sums[i0 + k] = ex;
+      ex += v[k];
+    }
     carry += total;
   }
   if (threadIdx.x == 0 && grand_total) *grand_total = carry;
@@ -64,22 +80,43 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict
     for (uint32_t k = threadIdx.x; k < blockIdx.x; k += BLOCK) part += tile_sums[k];
     before = block_sum_u32(part, s);
   }
-  // thread t owns SCAN_ITEMS consecutive elements so the in-thread prefix is sequential
+  // thread t owns SCAN_ITEMS consecutive elements so the in-thread prefix is sequential; full stretches of 16-byte aligned arrays
+  // move as two 16-byte loads and two 16-byte stores per thread instead of eight 4-byte ones at a 32-byte stride
+  static_assert(SCAN_ITEMS == 8, "k_scan_apply moves a thread's stretch as two uint4");
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  const bool wide = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) && base + SCAN_ITEMS <= n;
   uint32_t v[SCAN_ITEMS];
-  uint32_t sum = 0;
-  for (int j = 0; j < SCAN_ITEMS; j++) {
-    uint32_t i = base + j;
-    v[j] = i < n ? in[i] : 0;
-    sum += v[j];
+  if (wide) {
+    const uint4 a = *(const uint4*)(in + base), b4 = *(const uint4*)(in + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t i = base + j;
+      v[j] = i < n ? in[i] : 0;
+    }
   }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) sum += v[j];
   uint32_t total;
   uint32_t ex = block_exclusive_scan_u32(sum, s, &total) + before;
   if (!PREFIXED && grand_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand_total = before + total;
+  uint32_t o[SCAN_ITEMS];
+#pragma unroll
   for (int j = 0; j < SCAN_ITEMS; j++) {
-    uint32_t i = base + j;
-    if (i < n) out[i] = ex;
+    o[j] = ex;
     ex += v[j];
+  }
+  if (wide) {
+    *(uint4*)(out + base) = uint4{o[0], o[1], o[2], o[3]};
+    *(uint4*)(out + base + 4) = uint4{o[4], o[5], o[6], o[7]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t i = base + j;
+      if (i < n) out[i] = o[j];
+    }
   }
 }
 
