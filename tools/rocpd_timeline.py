@@ -2,7 +2,7 @@
 """Timeline of ONE replay out of a rocprofv3 --kernel-trace rocpd database: every dispatch between the n-th and the (n+1)-th
 k_parse_changes launch, with its start offset, duration, queue and the idle gap since the previous dispatch ended on that queue.
 
-  python tools/rocpd_timeline.py gpurun_out/prof/run_results.db [which=-2] > profiles/<name>.txt
+  python tools/rocpd_timeline.py gpurun_out/prof/run_results.db [which=-2] [anchor kernel=k_parse_changes] > profiles/<name>.txt
 """
 import sqlite3
 import sys
@@ -19,7 +19,8 @@ def main():
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     q = f"select s.display_name, d.start, d.end, {('d.' + qcol) if qcol else '0'} from {disp} d join {sym} s on d.kernel_id=s.id order by d.start"
     rows = list(cur.execute(q))
-    marks = [i for i, r in enumerate(rows) if "k_parse_changes" in r[0]]
+    anchor = sys.argv[3] if len(sys.argv) > 3 else "k_parse_changes"   # (document loads: kb_term_flags)
+    marks = [i for i, r in enumerate(rows) if anchor in r[0]]
     a = marks[which]
     b = marks[which + 1] if which + 1 < 0 or which + 1 < len(marks) and which >= 0 else len(rows)
     if which == -1:
@@ -27,7 +28,7 @@ def main():
     t0 = rows[a][1]
     last_end = {}
     busy = 0.0
-    print(f"# replay #{which}: dispatches {a}..{b - 1}; times in us relative to the k_parse_changes launch")
+    print(f"# replay #{which}: dispatches {a}..{b - 1}; times in us relative to the {anchor} launch")
     print(f"{'start':>9s} {'dur':>8s} {'gap':>7s} {'q':>3s}  kernel")
     for name, s, e, qid in rows[a:b]:
         gap = (s - last_end[qid]) / 1000.0 if qid in last_end else 0.0
