@@ -19,6 +19,7 @@
 #include "am355_delta.h"
 #include "am355_apply.h"
 #include "am355_sync.h"
+#include "am355_sched.h"
 #include "am355_canary.h"
 
 #include <zlib.h>
@@ -262,6 +263,7 @@ struct am355_ctx {
   uint32_t sig_seq = 0;
   hipEvent_t ev_s1 = nullptr;          // the per-change digests (briefs) have arrived on the host
   hipEvent_t ev_fills = nullptr;       // merge fills done (when they run on stream4)
+  hipEvent_t ev_sched = nullptr;   // host copies of the device scheduler's order / pass numbers complete (stream4)
   hipEvent_t ev_plan = nullptr, ev_tables = nullptr;  // k_plan_apply done (stream4 copies the digests behind it) | host-built tables in HBM
   void* counts_zeroed_at = nullptr; size_t counts_zeroed = 0;  // the counter block was cleared beside stage 1 (address, bytes)
   // AM355_PHASE_EVENTS=1: HIP events between the phases of a change replay (am355_stats.ms_parse / ms_decode / ms_merge / ms_order). Off by
@@ -330,7 +332,9 @@ struct am355_ctx {
   // incremental applyChanges (am355_apply_changes)
   std::vector<uint32_t> pending_change;   // queued changes (input indexes, queue order) after the last replay
   std::vector<uint32_t> pass_first_row;   // first op row of every scheduling pass after the first (general scheduler)
-  DevBuf d_delta, d_pass, d_delta_edit;
+  DevBuf d_delta, d_pass, d_delta_edit, d_sched;
+  HostBuf h_sched;
+  bool device_scheduled = false;   // the last general-path replay was scheduled by the device (am355_sched.hip)
   HostBuf h_delta;
   DeltaBufs delta{};
   ApplyPatch apply;
@@ -434,6 +438,7 @@ extern "C" am355_ctx* am355_create(int device) {
   if (hipEventCreate(&c->ev_parse) != hipSuccess || hipEventCreate(&c->ev_b0) != hipSuccess || hipEventCreate(&c->ev_b1) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_counts) != hipSuccess || hipEventCreate(&c->ev_runs) != hipSuccess || hipEventCreate(&c->ev_s1) != hipSuccess) { delete c; return nullptr; }
   if (hipEventCreate(&c->ev_plan) != hipSuccess || hipEventCreate(&c->ev_tables) != hipSuccess || hipEventCreate(&c->ev_fills) != hipSuccess) { delete c; return nullptr; }
+  if (hipEventCreate(&c->ev_sched) != hipSuccess) { delete c; return nullptr; }
   if (!c->h_sig.ensure(sizeof(HostSignals))) { delete c; return nullptr; }
   memset(c->h_sig.p, 0, sizeof(HostSignals));
   if (const char* e = getenv("AM355_PHASE_EVENTS")) c->phase_events = strcmp(e, "0") != 0;
@@ -453,14 +458,14 @@ extern "C" void am355_destroy(am355_ctx* c) {
     b->release();
   for (HostBuf* b : {&c->h_slots, &c->h_hashes, &c->h_has_dep, &c->h_words, &c->h_stage, &c->h_s1, &c->h_dep_idx, &c->h_self_idx, &c->h_amap, &c->h_amap_base}) b->release();
   c->d_s1.release();
-  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1, c->ev_plan, c->ev_tables, c->ev_fills})
+  for (hipEvent_t e : {c->ev_parse, c->ev_b0, c->ev_b1, c->ev_counts, c->ev_runs, c->ev_s1, c->ev_plan, c->ev_tables, c->ev_fills, c->ev_sched})
     if (e) (void)hipEventDestroy(e);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
-  c->d_delta.release(); c->d_delta_edit.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta.release(); c->d_sync.release();
+  c->d_delta.release(); c->d_delta_edit.release(); c->d_sched.release(); c->h_sched.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta.release(); c->d_sync.release();
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
@@ -1149,35 +1154,49 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
   uint32_t sched_flags = 0, n_pending = 0;
   {
     constexpr uint32_t UNSET = 0xffffffffu, NEVER = 0xfffffffeu, BUSY = 0xfffffffdu;
-    std::vector<uint32_t> pass(n, UNSET), stack;
+    // Copies of one change (the same hash several times in the queue) form a group named by its first copy (self[]): every copy is
+    // ready as soon as ITS position allows -- a copy standing behind the dependencies its first copy stands in front of is ready a
+    // pass earlier -- and the reference applies whichever copy becomes ready first, (pass, position) minimal, dropping the others as
+    // duplicates from then on (new.js:1566). gpass[F] / gpos[F]: pass and position at which group F is applied. (Round 3 applied
+    // the FIRST copy only: wrong application order -- visible in the order of the `clock` keys -- whenever a later copy was ready
+    // sooner; found by the device scheduler's tests against the oracle, which has it right.)
+    std::vector<uint32_t> gpass(n, UNSET), gpos(n, 0), pass(n, NEVER), stack;
+    std::vector<uint32_t> copy_next(n, UNSET), copy_tail(n, UNSET);   // the copies of a group, ascending
+    for (uint32_t ci = 0; ci < n; ci++) {
+      uint32_t F = self[ci] < n ? self[ci] : ci;
+      if (F != ci) { uint32_t tail = copy_tail[F] == UNSET ? F : copy_tail[F]; copy_next[tail] = ci; copy_tail[F] = ci; }
+    }
     // (dependency list of a change as a compact (first, count) pair: the walk below visits every edge twice and the change records
     // are 176 bytes apart)
     std::vector<uint32_t> dep_first(n), dep_count(n);
     for (uint32_t ci = 0; ci < n; ci++) { const ChangeMeta& m = metas[ci]; dep_first[ci] = (uint32_t)((m.base + m.deps_off) >> 5); dep_count[ci] = m.n_deps; }
     auto dep_of = [&](uint32_t ci, uint32_t k) { return dep_idx[dep_first[ci] + k]; };
     for (uint32_t root = 0; root < n; root++) {
-      if (pass[root] != UNSET) continue;
+      if ((self[root] < n ? self[root] : root) != root || gpass[root] != UNSET) continue;
       stack.push_back(root);
       while (!stack.empty()) {
-        uint32_t ci = stack.back();
-        if (pass[ci] != UNSET && pass[ci] != BUSY) { stack.pop_back(); continue; }
-        uint32_t first = self[ci] < n ? self[ci] : ci;
-        if (first != ci) { pass[ci] = NEVER; stack.pop_back(); continue; }  // a later copy: never applied itself
-        const uint32_t nd = dep_count[ci];
+        const uint32_t F = stack.back();
+        if (gpass[F] != UNSET && gpass[F] != BUSY) { stack.pop_back(); continue; }
+        // every copy of the group from the groups of its dependencies
         bool pushed = false;
-        uint32_t p = 0;
-        for (uint32_t k = 0; k < nd; k++) {
-          uint32_t d = dep_of(ci, k);
-          if (d >= n) { p = NEVER; break; }
-          if (pass[d] == UNSET) { if (!pushed) pass[ci] = BUSY; stack.push_back(d); pushed = true; continue; }
-          if (pass[d] == BUSY) { p = NEVER; break; }  // (a dependency cycle would need a hash collision: never applied)
-          if (pass[d] == NEVER) { p = NEVER; break; }
-          uint32_t q = pass[d] + (d > ci ? 1u : 0u);
-          p = q > p ? q : p;
+        uint32_t best_p = NEVER, best_pos = 0;
+        for (uint32_t ci = F; ci != UNSET && !pushed; ci = copy_next[ci]) {
+          uint32_t p = 0;
+          for (uint32_t k = 0, nd = dep_count[ci]; k < nd; k++) {
+            const uint32_t d = dep_of(ci, k);
+            if (d >= n) { p = NEVER; break; }
+            if (gpass[d] == UNSET) { gpass[F] = BUSY; stack.push_back(d); pushed = true; break; }
+            if (gpass[d] == BUSY || gpass[d] == NEVER) { p = NEVER; break; }  // (a dependency cycle would need a hash collision: never applied)
+            const uint32_t q = gpass[d] + (gpos[d] > ci ? 1u : 0u);
+            p = q > p ? q : p;
+          }
+          if (pushed) break;
+          if (p != NEVER && (best_p == NEVER || p < best_p)) { best_p = p; best_pos = ci; }  // (copies ascend: the first of the earliest pass)
         }
-        if (p == NEVER) { pass[ci] = NEVER; stack.pop_back(); continue; }
         if (pushed) continue;  // come back when the dependencies are known
-        pass[ci] = p;
+        gpass[F] = best_p;
+        gpos[F] = best_pos;
+        if (best_p != NEVER) pass[best_pos] = best_p;
         stack.pop_back();
       }
     }
@@ -1192,11 +1211,11 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
     applied_all.resize(start[max_pass + 1]);
     for (uint32_t ci = 0; ci < n; ci++)
       if (pass[ci] < BUSY) applied_all[start[pass[ci]]++] = ci;
-    // what stays queued: changes never applied whose first copy is never applied either
+    // what stays queued: the changes of which no copy is ever applied
     c->pending_change.clear();
     for (uint32_t ci = 0; ci < n; ci++) {
       uint32_t first = self[ci] < n ? self[ci] : ci;
-      if (pass[first] >= BUSY) { n_pending++; c->pending_change.push_back(ci); }
+      if (gpass[first] >= BUSY) { n_pending++; c->pending_change.push_back(ci); }
     }
     applied_pass.resize(applied_all.size());
     for (size_t t = 0; t < applied_all.size(); t++) applied_pass[t] = pass[applied_all[t]];
@@ -1207,7 +1226,7 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
       if (m.seq != clock[author] + 1) { sched_flags |= AM355_F_BAD_SEQ; break; }
       if (!has_clock[author]) { has_clock[author] = 1; c->clock_actor.push_back(author); }
       clock[author] = m.seq;
-      for (uint32_t k = 0, nd = dep_count[ci]; k < nd; k++) is_head[dep_of(ci, k)] = 0;
+      for (uint32_t k = 0, nd = dep_count[ci]; k < nd; k++) is_head[gpos[dep_of(ci, k)]] = 0;  // (the copy of the dependency that was applied)
       is_head[ci] = 1;
     }
     // each change may only mention actors already in the document when it is read: the reference reads the changes of a pass
@@ -1365,9 +1384,11 @@ static uint32_t rank_device_actors(am355_ctx* c, std::vector<uint32_t>& slot_ran
 // Host half of the in-order fast path: O(changes + actors log actors), no allocation in steady state. Everything that
 // needs the change hashes (dependency resolution, heads) has been checked on the device and is confirmed when stream
 // B is joined.
-static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
+// `order` (general path, device scheduler am355_sched.hip): the applied changes in application order (n_applied of them) with the
+// scheduling pass of every change in `pass`; null: every change is applied, in input order (in-order fast path).
+static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank, const uint32_t* order = nullptr, uint32_t n_applied = 0, const uint32_t* pass = nullptr) {
   const ChangeBrief* br = c->hp_briefs;
-  uint32_t n = c->n_changes;
+  uint32_t n = order ? n_applied : c->n_changes;
   uint32_t na = rank_device_actors(c, slot_rank);
   static thread_local std::vector<uint64_t> clock;
   static thread_local std::vector<uint32_t> span_cnt;
@@ -1378,11 +1399,14 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
   c->plans.reserve(n);
   c->applied_change.resize(n);
   c->applied_op_base.resize(n);
+  c->pass_first_row.clear();
   uint64_t ops = 0, preds = 0, entries = 0, max_op = 0;
-  for (uint32_t ci = 0; ci < n; ci++) {
+  for (uint32_t t = 0; t < n; t++) {
+    const uint32_t ci = order ? order[t] : t;
     const ChangeBrief& m = br[ci];
-    c->applied_change[ci] = ci;
-    c->applied_op_base[ci] = (uint32_t)ops;
+    if (order && t > 0 && pass[ci] != pass[order[t - 1]]) c->pass_first_row.push_back((uint32_t)ops);  // (am355_apply_changes: a merge call never spans two passes)
+    c->applied_change[t] = ci;
+    c->applied_op_base[t] = (uint32_t)ops;
     uint32_t author = slot_rank[m.author_slot];
     if (m.seq != clock[author] + 1) { c->flags |= AM355_F_BAD_SEQ; return fail(c, AM355_E_INVALID, "sequence number %llu out of order", (unsigned long long)m.seq); }
     if (clock[author] == 0) c->clock_actor.push_back(author);
@@ -1400,7 +1424,6 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank) {
   c->n_applied = n;
   c->n_pending = 0;
   c->pending_change.clear();
-  c->pass_first_row.clear();
   c->n_ops = ops;
   c->n_preds = preds;
   c->max_op = max_op;
@@ -1596,7 +1619,10 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
 // In-order fast path with the device-side plan (k_plan): the decode kernels are launched from the device-built plans as soon as
 // the host knows the totals; the host's own planning (sequence numbers, clock, per-actor span tables: plan_fast) runs while the
 // decode kernels do, and its tables reach the device before k_resolve needs them.
-static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_distinct, float* ms_host_plan) {
+// `go` != null (general path): the plans in d_plans are in the application order the device scheduler found (am355_sched.hip); the
+// host's half runs over that order (go->order / go->pass, host copies complete at go->ready).
+struct GeneralOrder { const uint32_t* order; const uint32_t* pass; uint32_t n_applied; hipEvent_t ready; };
+static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_distinct, float* ms_host_plan, const GeneralOrder* go = nullptr) {
   hipStream_t st = c->stream;
   const bool trace = getenv("AM355_TRACE") != nullptr;
   auto t_begin = std::chrono::steady_clock::now();
@@ -1646,9 +1672,10 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   lap("fills enqueued");
   // ---- host half of the plan, beside the decode kernels (the digests were copied right behind k_plan) ----
   HIPCHK(c, hipEventSynchronize(c->ev_s1));
+  if (go) HIPCHK(c, hipEventSynchronize(go->ready));
   auto t0 = std::chrono::steady_clock::now();
   std::vector<uint32_t> slot_rank;
-  int rc = plan_fast(c, slot_rank);
+  int rc = go ? plan_fast(c, slot_rank, go->order, go->n_applied, go->pass) : plan_fast(c, slot_rank);
   *ms_host_plan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   lap("plan_fast done");
   if (rc == AM355_OK && (c->n_ops != tot.n_ops || c->n_preds != tot.n_preds || c->max_op != tot.max_op || c->actors.size() != n_distinct))
@@ -2020,29 +2047,99 @@ static int replay_impl(am355_ctx* c) {
     for (size_t i = 0; i < heads.size(); i++) memcpy(&c->heads[32 * i], heads[i], 32);
     ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   } else {
-    // general path: exact scheduling on the host, then decode/merge of exactly the applied changes
+    // ---- general path (any delivery order, duplicates, missing dependencies) ----
     c->flags = 0;
-    size_t dep_words = c->raw.size() / 32 + 2;
-    if (!c->h_dep_idx.ensure(4 * dep_words) || !c->h_self_idx.ensure(4 * n1)) return fail(c, AM355_E_NOMEM, "host allocation failed");
-    HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, sa));
-    HIPCHK(c, hipMemcpyAsync(c->h_dep_idx.p, c->d_dep_idx.p, 4 * dep_words, hipMemcpyDeviceToHost, sa));  // (stream B has been joined)
-    HIPCHK(c, hipMemcpyAsync(c->h_self_idx.p, c->d_self_idx.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sa));
     // the device's actor tables, when its list of distinct ids holds them all (else the host interns)
     const bool dev_actors = tot.n_distinct <= distinct_capacity() && !(tot.fast_a & FF_CAPACITY) && tot.total_entries <= c->amap_cap;
-    if (dev_actors) {
-      if (!c->h_amap.ensure(4 * ((size_t)tot.total_entries + 1)) || !c->h_amap_base.ensure(4 * (n1 + 1))) return fail(c, AM355_E_NOMEM, "host allocation failed");
-      HIPCHK(c, hipMemcpyAsync(c->h_amap.p, c->d_amap_prov.p, 4 * (size_t)tot.total_entries, hipMemcpyDeviceToHost, sa));
-      HIPCHK(c, hipMemcpyAsync(c->h_amap_base.p, c->d_amap_base.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sa));
+    bool served = false;
+    const bool host_schedule = getenv("AM355_HOST_SCHEDULE") != nullptr;  // (A/B and tests: the host's scheduler for every batch)
+    if (dev_actors && planned && !host_schedule && n > 0) {
+      // The scheduler runs on the device (am355_sched.hip): pass numbers by relaxation over the dependency indexes stream B resolved,
+      // application order by a stable sort, the decode plans in that order. The host reads the totals from the pinned words, launches
+      // the decode kernels from the device-built plans and does its own half (sequence numbers, clock, span tables) beside them, as
+      // on the in-order path.
+      if (!c->d_sched.ensure(sched_bytes(n, c->slot_mask)) || !c->h_sched.ensure(13 * (size_t)n1 + 64)) return fail(c, AM355_E_NOMEM, "device allocation failed (scheduler)");
+      SchedBufs sbuf;
+      sched_bind(sbuf, c->d_sched.p, n, c->slot_mask);
+      canary_arm();
+      c->sig_seq++;
+      uint32_t* d_order = nullptr;
+      launch_sched_general(c->d_metas.as<ChangeMeta>(), d_briefs, n, c->d_dep_idx.as<uint32_t>(), c->d_self_idx.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(),
+                           c->d_amap_base.as<uint32_t>(), c->amap_cap, c->d_slot_rank.as<uint32_t>(), c->slot_mask, sbuf, &d_order, c->d_plans.as<ChangePlan>(),
+                           c->d_plans.as<ChangePlan>() + n1, d_wa, d_distinct, sig, c->sig_seq, sa);
+      // what the host's half needs: order | pass | first copies | head marks -- on the copy stream, behind the scheduler
+      uint32_t* h_order = c->h_sched.as<uint32_t>();
+      uint32_t *h_pass = h_order + n1, *h_self = h_pass + n1;
+      uint8_t* h_is_head = (uint8_t*)(h_self + n1);
+      HIPCHK(c, hipEventRecord(c->ev_plan, sa));
+      HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_plan, 0));
+      HIPCHK(c, hipMemcpyAsync(h_order, d_order, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream4));
+      HIPCHK(c, hipMemcpyAsync(h_pass, sbuf.pass, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream4));
+      HIPCHK(c, hipMemcpyAsync(h_self, c->d_self_idx.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream4));
+      HIPCHK(c, hipMemcpyAsync(h_is_head, sbuf.is_head, (size_t)n, hipMemcpyDeviceToHost, c->stream4));
+      HIPCHK(c, hipEventRecord(c->ev_sched, c->stream4));
+      if (!wait_host_signal(&sig->plan_seq, c->sig_seq, sa)) {
+        (void)hipStreamSynchronize(c->stream4);
+        return fail(c, AM355_E_DEVICE, "the device did not report the schedule of this replay (%s)", hipGetErrorString(hipGetLastError()));
+      }
+      PlanTotals gen{};
+      memcpy(&gen, (const void*)&sig->plan, sizeof gen);
+      lap("device schedule read");
+      // the relaxation ran out of sweeps, sums beyond 32 bits, or an actor named before its first change: the host's scheduler decides
+      // (and raises the exact flags of an invalid batch)
+      if (!gen.reserved[3] && !gen.flags_a && !gen.fallback) {
+        GeneralOrder go{h_order, h_pass, gen.reserved[1], c->ev_sched};
+        float ms_plan = 0;
+        rc = run_device_planned(c, gen, tot.n_distinct, &ms_plan, &go);
+        ms_host += ms_plan;
+        if (rc) return rc;
+        auto t0 = std::chrono::steady_clock::now();
+        // what stays queued: the changes of which no copy is ever applied (new.js:1566, 1866)
+        // (copies of one change: whichever copy became ready first was applied, the others were dropped as duplicates then)
+        c->pending_change.clear();
+        std::vector<uint8_t> group_applied(n, 0);
+        for (uint32_t ci = 0; ci < n; ci++)
+          if (h_pass[ci] != SCHED_NEVER) group_applied[h_self[ci] < n ? h_self[ci] : ci] = 1;
+        for (uint32_t ci = 0; ci < n; ci++)
+          if (!group_applied[h_self[ci] < n ? h_self[ci] : ci]) c->pending_change.push_back(ci);
+        c->n_pending = (uint32_t)c->pending_change.size();
+        const uint8_t* hs = c->h_hashes.as<uint8_t>();
+        std::vector<const uint8_t*> heads;
+        for (uint32_t i = 0; i < n; i++)
+          if (h_is_head[i]) heads.push_back(hs + 32 * (size_t)i);
+        std::sort(heads.begin(), heads.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
+        c->heads.resize(heads.size() * 32);
+        for (size_t i = 0; i < heads.size(); i++) memcpy(&c->heads[32 * i], heads[i], 32);
+        ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        served = true;
+      } else {
+        (void)hipStreamSynchronize(c->stream4);
+      }
     }
-    HIPCHK(c, hipStreamSynchronize(sa));
-    if (dev_actors) c->h_amap_base.as<uint32_t>()[n] = tot.total_entries;
-    HIPCHK(c, hipEventSynchronize(c->ev_s1));  // (the distinct-actor list rides with the digests)
-    auto t0 = std::chrono::steady_clock::now();
-    rc = schedule(c, dev_actors ? c->h_amap.as<uint32_t>() : nullptr, dev_actors ? c->h_amap_base.as<uint32_t>() : nullptr);
-    ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (rc) return rc;
-    rc = run_device(c, nullptr);
-    if (rc) return rc;
+    if (!served) {
+      // exact scheduling on the host (thousands of actors, pathological dependency chains, and every batch the reference rejects:
+      // the flags it raises are the host's), then decode / merge of exactly the applied changes
+      size_t dep_words = c->raw.size() / 32 + 2;
+      if (!c->h_dep_idx.ensure(4 * dep_words) || !c->h_self_idx.ensure(4 * n1)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+      HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * n, hipMemcpyDeviceToHost, sa));
+      HIPCHK(c, hipMemcpyAsync(c->h_dep_idx.p, c->d_dep_idx.p, 4 * dep_words, hipMemcpyDeviceToHost, sa));  // (stream B has been joined)
+      HIPCHK(c, hipMemcpyAsync(c->h_self_idx.p, c->d_self_idx.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sa));
+      if (dev_actors) {
+        if (!c->h_amap.ensure(4 * ((size_t)tot.total_entries + 1)) || !c->h_amap_base.ensure(4 * (n1 + 1))) return fail(c, AM355_E_NOMEM, "host allocation failed");
+        HIPCHK(c, hipMemcpyAsync(c->h_amap.p, c->d_amap_prov.p, 4 * (size_t)tot.total_entries, hipMemcpyDeviceToHost, sa));
+        HIPCHK(c, hipMemcpyAsync(c->h_amap_base.p, c->d_amap_base.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sa));
+      }
+      HIPCHK(c, hipStreamSynchronize(sa));
+      if (dev_actors) c->h_amap_base.as<uint32_t>()[n] = tot.total_entries;
+      HIPCHK(c, hipEventSynchronize(c->ev_s1));  // (the distinct-actor list rides with the digests)
+      auto t0 = std::chrono::steady_clock::now();
+      rc = schedule(c, dev_actors ? c->h_amap.as<uint32_t>() : nullptr, dev_actors ? c->h_amap_base.as<uint32_t>() : nullptr);
+      ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (rc) return rc;
+      rc = run_device(c, nullptr);
+      if (rc) return rc;
+    }
+    c->device_scheduled = served;
   }
   c->used_fast_path = fast;
   lap("end");
@@ -2068,7 +2165,7 @@ static int replay_impl(am355_ctx* c) {
   }
   (void)hipEventElapsedTime(&s.ms_hash_stream, c->ev_b0, c->ev_b1);  // hash stream (SHA-256 + dependency resolution), overlapped
   s.ms_host_schedule = ms_host;
-  s.fast_path = fast ? 1 : 0;
+  s.fast_path = fast ? 1 : (c->device_scheduled ? 2 : 0);
   s.ms_total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
   c->replayed = true;
   if (!c->in_apply) {  // (one call of Backend.loadChanges: its scheduling passes are the op streams)

@@ -98,7 +98,8 @@ typedef struct {
      record between two kernels is a packet of its own in front of the next dispatch, i.e. microseconds of the replay itself. */
   float ms_total, ms_parse, ms_host_schedule, ms_decode, ms_merge, ms_order;
   float ms_hash_stream;  /* SHA-256 + dependency resolution on the second stream (overlaps decode/merge) */
-  uint32_t fast_path;    /* 1: in-order fast path (device-verified), 0: general host scheduler */
+  uint32_t fast_path;    /* 1: in-order fast path (device-verified); 2: general path, scheduled on the device (csrc/am355_sched.hip);
+                            0: general path, scheduled by the host (thousands of actors, pathological dependency chains) */
 } am355_stats;
 int am355_get_stats(const am355_ctx *ctx, am355_stats *out);
 /* Measurement switch: on != 0 makes the following replays record HIP events between their phases (ms_parse / ms_decode / ms_merge /

@@ -127,6 +127,33 @@ def test_delivery_order_only_changes_clock_order(eng):
     assert p["diffs"] == base["diffs"] and p["deps"] == base["deps"] and p["maxOp"] == base["maxOp"] and p["clock"] == base["clock"]
 
 
+def _scheduler_cases():
+    from test_engine_emu import scheduler_cases
+    return list(scheduler_cases())
+
+
+@pytest.mark.parametrize("name,log", _scheduler_cases(), ids=[n for n, _ in _scheduler_cases()])
+def test_general_scheduler_on_the_device_equals_host_and_oracle(eng, name, log):
+    """SURVEY 8 row a12 on the GPU: ks_pass (register / LDS form and global-memory form), the host's restatement and the oracle agree on
+    shuffled, reversed, duplicated and incomplete deliveries; two sweeps are not enough for reversed chains and the host takes over."""
+    from test_engine_emu import check_scheduler_variants
+    seen = check_scheduler_variants(eng, name, log)
+    if name in ("reversed", "chain_reversed"):
+        assert seen["device_out_of_sweeps"][0] == 0
+
+
+def test_full_size_headline_log_in_shuffled_delivery(eng):
+    """The 1,020,801-op headline log delivered in random order: scheduled on the device (fast_path 2), same patch as the oracle, same
+    document as the in-order delivery."""
+    log = loggen.config("c4_text_single", 1.0)
+    shuf = log.reordered(np.random.default_rng(4).permutation(log.n_changes))
+    got = gpu_patch(eng, shuf)
+    st = eng.stats()
+    assert st.fast_path == 2 and st.n_pending == 0 and st.n_applied == log.n_changes
+    assert got == oracle_lib.OracleDoc(shuf).patch_json()
+    assert json.loads(got)["diffs"] == json.loads(gpu_patch(eng, log))["diffs"]
+
+
 def test_missing_dependency_leaves_changes_pending(eng):
     log = loggen.config("c4_text_single", 0.05)
     keep = [i for i in range(log.n_changes) if i != 1]  # drop one change of round 0: everything after it must wait
