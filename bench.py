@@ -83,6 +83,66 @@ def cpu_baseline(log, budget_s=12.0):
                                  "container it replays this workload at ~25-30 k ops/s (BASELINE.md §2, DESIGN.md §7)"}
 
 
+def reference_js_baseline(name, scale_full, seed):
+    """The UNMODIFIED reference JS backend (north_star: "next to the reference JS backend timed on the box's own host cores in the same
+    run"): `Backend.loadChanges(Backend.init(), changes)` + `Backend.getPatch` under node, 1 core, on a BOUNDED sample of the same
+    workload (the reference replays ~25-30 k ops/s: the full 1 M-op log would take ~40 s per run) -- oracle/js/ref_patch.js --time.
+    Needs node and the reference tree (AUTOMERGE_REF, default /root/reference): present in the build container, absent on the GPU box
+    (nothing there may read it), where the caller reports the C port instead and says so. Returns None when it cannot run."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref = os.environ.get("AUTOMERGE_REF", "/root/reference")
+    node = shutil.which("node")
+    if node is None or not os.path.isdir(os.path.join(ref, "backend")):
+        return None
+    scale = min(scale_full, 0.125 if name.startswith("c4") else 0.5 if name == "c3_map_lww" else 1.0)   # ~100-130 k ops: 10-30 s of CPU work
+    log = make_log(name, scale, seed)
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"), AUTOMERGE_REF=ref)
+    env.pop("REF_BLOCK_SIZE", None)   # (the stock reference: this leg is about time, not about the patch)
+    t_all = time.perf_counter()
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "log.bin")
+            log.save(path)
+            out = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "ref_patch.js"), path, "--time", "3", "--out", os.path.join(tmp, "patch.json")],
+                                 env=env, capture_output=True, text=True, timeout=240)
+        line = [l for l in out.stderr.splitlines() if l.startswith("reference median of")]
+        if out.returncode != 0 or not line:
+            return None
+        ops_per_s = float(line[-1].split("=")[1].split("ops/s")[0])
+    except Exception:  # (a baseline that cannot run must not cost the bench line)
+        return None
+    ver = subprocess.run([node, "--version"], capture_output=True, text=True).stdout.strip()
+    return {"value": ops_per_s, "unit": "ops/s", "cores": 1, "kind": "reference",
+            "sample": f"{name} x{scale}: {log.n_ops} ops, {log.n_changes} changes (the shape of the timed workload at reduced size), median of 3 runs after 1 warm-up of "
+                      f"the unmodified reference's Backend.loadChanges + getPatch under node {ver}, 1 core of {os.cpu_count()} ({time.perf_counter() - t_all:.1f} s of CPU work)"}
+
+
+def js_end_to_end(log):
+    """T_e2e: node -> N-API addon -> GPU -> record tables -> js/materialize.js = the patch OBJECT the frontend consumes,
+    through automerge_classic_amd/js/bench_e2e.js on the same log. None when node or the addon is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    js = os.path.join(ROOT, "automerge_classic_amd", "js")
+    if node is None or not os.path.exists(os.path.join(js, "am355_napi.node")):
+        return None
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "log.bin")
+            log.save(path)
+            out = subprocess.run([node, os.path.join(js, "bench_e2e.js"), path, "7"], capture_output=True, text=True, timeout=240)
+        if out.returncode != 0:
+            return {"error": (out.stderr or out.stdout)[-300:]}
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": str(e)[:300]}
+    return {"t_e2e_ms": d["T_e2e_ms"], "t_e2e_ops_per_s": d["T_e2e_ops_per_s"], "t_replay_ms_through_node": d["T_replay_ms"], "ms": d["ms"],
+            "timed_region": "change Uint8Arrays in node -> addon.loadChanges -> addon.replay -> addon.fetchIR -> materialize.js (the JS patch object); median of 7"}
+
+
 def cpu_baseline_document(doc_bytes, n_rows, budget_s=12.0):
     """The CPU oracle's Backend.load + getPatch on the same saved document (1 thread)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -419,7 +479,24 @@ def main():
     if sharded is not None:
         out["sharded"] = sharded
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-        out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops)) if w.is_doc else cpu_baseline(w.log)
+        if w.is_doc:
+            out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops))
+        else:
+            port = cpu_baseline(w.log)
+            ref_js = reference_js_baseline(args.workload, args.scale, BASE_SEED[args.workload])
+            if ref_js is not None:   # the reference itself ran beside the engine in this run: that is the baseline; the C port rides along
+                ref_js["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}
+                ref_js["leg"] = "reference JS backend (AUTOMERGE_REF resolved)"
+                out["cpu_baseline"] = ref_js
+            else:
+                port["leg"] = "C port of the reference's algorithm (oracle/): node or the reference tree is not on this box"
+                out["cpu_baseline"] = port
+    if world == 1 and not w.is_doc and not args.no_sublines:
+        e2e = js_end_to_end(w.log)
+        if e2e is not None:
+            out["js_end_to_end"] = e2e
+            if "t_e2e_ms" in e2e:
+                out["t_e2e_ms"] = e2e["t_e2e_ms"]
     if not args.no_sublines and world == 1:
         subs, k, wu = [], max(5, min(args.steps // 3, 30)), 3
         for name in ("c4_text_multi", "c3_map_lww", "c2_text_typing"):
