@@ -21,7 +21,7 @@ enum SchedWord : uint32_t {
 struct SchedBufs {
   uint32_t n;
   uint32_t* pass;        // [n] scheduling pass of every change, SCHED_NEVER: never applied
-  uint32_t *cursor, *curmax, *dfirst, *dcnt;  // [n] relaxation state (batches beyond the register-resident size)
+  uint32_t *cursor, *curmax, *dfirst, *dcnt;  // [n] global-memory form of ks_pass (batches beyond its LDS size): wait-on / work list / dependency ranges
   uint32_t *apos, *left;      // [n] per group of copies of one change (at its first copy): position of the copy that is applied | undecided copies
   unsigned long long* best;   // [n] min over a group's decided copies of (pass << 32 | position)
   uint64_t *key_a, *key_b;    // [n] sort keys (pass; n for changes never applied)
