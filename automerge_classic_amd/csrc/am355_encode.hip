@@ -49,10 +49,16 @@ __device__ __forceinline__ uint8_t* put_sleb(uint8_t* p, int64_t v) {
 }
 
 // value sources -------------------------------------------------------------------------------------------------
+// `seg` (all sources; may be null = one segment): seg[i] = index of the first value of the segment value i belongs to. The history
+// reconstruction (am355_hist.hip) encodes the columns of ALL changes of a document in one go: a segment is one change, and what
+// the reference's encoder emits for a change is what it emits for the change's values alone -- runs, literal stretches, null runs
+// and delta chains end at a segment's end.
 struct NumSrc {
   const uint32_t* vals;
   const uint8_t* mask;
   bool is_signed;
+  const uint32_t* seg;
+  __device__ __forceinline__ bool seg_start(uint32_t i) const { return i == 0 || (seg && seg[i] == i); }
   __device__ __forceinline__ bool is_null(uint32_t i) const { return mask ? mask[i] != 0 : vals[i] == NONE32; }
   __device__ __forceinline__ bool equal(uint32_t i, uint32_t j) const {
     bool ni = is_null(i), nj = is_null(j);
@@ -64,6 +70,8 @@ struct NumSrc {
 struct StrSrc {
   const uint8_t* arena;
   const uint32_t *off, *len;
+  const uint32_t* seg;
+  __device__ __forceinline__ bool seg_start(uint32_t i) const { return i == 0 || (seg && seg[i] == i); }
   __device__ __forceinline__ bool is_null(uint32_t i) const { return len[i] == NONE32; }
   __device__ __forceinline__ bool equal(uint32_t i, uint32_t j) const {
     uint32_t li = len[i], lj = len[j];
@@ -88,7 +96,7 @@ template <class Src>
 __global__ __launch_bounds__(BLOCK) void ke_run_flags(Src s, uint32_t n, uint32_t* __restrict__ flag) {
   uint32_t i = gtid();
   if (i > n) return;
-  flag[i] = i < n && (i == 0 || !s.equal(i, i - 1)) ? 1u : 0u;
+  flag[i] = i < n && (s.seg_start(i) || !s.equal(i, i - 1)) ? 1u : 0u;
 }
 
 // run_first[r] = first value of run r; run_first[R] = n
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void ke_group_flags(Src s, uint32_t n, const
     uint32_t a = run_first[r];
     bool lone = run_first[r + 1] - a == 1 && !s.is_null(a);
     bool prev_lone = false;
-    if (r > 0) { uint32_t b = run_first[r - 1]; prev_lone = a - b == 1 && !s.is_null(b); }
+    if (r > 0 && !s.seg_start(a)) { uint32_t b = run_first[r - 1]; prev_lone = a - b == 1 && !s.is_null(b); }
     f = (!lone || !prev_lone) ? 1u : 0u;
   }
   grp_flag[r] = f;
@@ -137,7 +145,9 @@ __global__ __launch_bounds__(BLOCK) void ke_run_sizes(Src s, uint32_t n, const u
   uint32_t sz = 0;
   if (r < R) {
     uint32_t a = run_first[r], len = run_first[r + 1] - a;
-    if (s.is_null(a)) sz = (R == 1) ? 0 : 1 + uleb_size(len);  // a column of nothing but nulls is empty
+    // a column (segment) of nothing but nulls is empty
+    const bool whole = s.seg ? (s.seg_start(a) && (a + len == n || s.seg_start(a + len))) : R == 1;
+    if (s.is_null(a)) sz = whole ? 0 : 1 + uleb_size(len);
     else if (len >= 2) sz = sleb_size((int64_t)len) + s.vsize(a);
     else {
       sz = s.vsize(a);
@@ -158,7 +168,8 @@ __global__ __launch_bounds__(BLOCK) void ke_run_write(Src s, uint32_t n, const u
   uint32_t a = run_first[r], len = run_first[r + 1] - a;
   uint8_t* p = out + off_ex[r];
   if (s.is_null(a)) {
-    if (R == 1) return;
+    const bool whole = s.seg ? (s.seg_start(a) && (a + len == n || s.seg_start(a + len))) : R == 1;
+    if (whole) return;
     *p++ = 0;
     put_uleb(p, len);
   } else if (len >= 2) {
@@ -187,11 +198,34 @@ static void enc_rle(Src s, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len
                            (const uint32_t*)w.grp_flag, (const uint32_t*)w.grp_ex, (const uint32_t*)w.grp_first, (const uint32_t*)w.off_ex, out);
 }
 
-void enc_rle_numbers(const uint32_t* vals, const uint8_t* nullmask, uint32_t n, bool is_signed, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st) {
-  enc_rle(NumSrc{vals, nullmask, is_signed}, n, w, out, d_len, st);
+void enc_rle_numbers(const uint32_t* vals, const uint8_t* nullmask, uint32_t n, bool is_signed, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st,
+                     const uint32_t* seg) {
+  enc_rle(NumSrc{vals, nullmask, is_signed, seg}, n, w, out, d_len, st);
 }
-void enc_rle_strings(const uint8_t* arena, const uint32_t* off, const uint32_t* len, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st) {
-  enc_rle(StrSrc{arena, off, len}, n, w, out, d_len, st);
+void enc_rle_strings(const uint8_t* arena, const uint32_t* off, const uint32_t* len, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st,
+                     const uint32_t* seg) {
+  enc_rle(StrSrc{arena, off, len, seg}, n, w, out, d_len, st);
+}
+
+// byte offset at which every segment's bytes begin in the output of the LAST run-length encode done with `w` (seg_base[k] = index of
+// segment k's first value, seg_base[n_seg] = n): seg_off[k], k = 0 .. n_seg
+__global__ __launch_bounds__(BLOCK) void ke_seg_offsets(const uint32_t* __restrict__ seg_base, uint32_t n_seg, const uint32_t* __restrict__ run_ex,
+                                                        const uint32_t* __restrict__ off_ex, uint32_t* __restrict__ seg_off) {
+  uint32_t k = gtid();
+  if (k > n_seg) return;
+  seg_off[k] = off_ex[run_ex[seg_base[k]]];
+}
+void enc_segment_offsets(const uint32_t* seg_base, uint32_t n_seg, const EncWork& w, uint32_t* seg_off, hipStream_t st) {
+  AM355_LAUNCH_INDEPENDENT(ke_seg_offsets, grid_for(n_seg + 1), dim3(BLOCK), st, seg_base, n_seg, (const uint32_t*)w.run_ex, (const uint32_t*)w.off_ex, seg_off);
+}
+__global__ __launch_bounds__(BLOCK) void ke_seg_offsets_raw(const uint32_t* __restrict__ seg_base, uint32_t n_seg, const uint32_t* __restrict__ off_ex,
+                                                            uint32_t* __restrict__ seg_off) {
+  uint32_t k = gtid();
+  if (k > n_seg) return;
+  seg_off[k] = off_ex[seg_base[k]];
+}
+void enc_segment_offsets_raw(const uint32_t* seg_base, uint32_t n_seg, const EncWork& w, uint32_t* seg_off, hipStream_t st) {
+  AM355_LAUNCH_INDEPENDENT(ke_seg_offsets_raw, grid_for(n_seg + 1), dim3(BLOCK), st, seg_base, n_seg, (const uint32_t*)w.off_ex, seg_off);
 }
 
 // delta ------------------------------------------------------------------------------------------------------------
@@ -205,56 +239,60 @@ __global__ __launch_bounds__(BLOCK) void ke_compact(const uint32_t* __restrict__
   if (i < n && vals[i] != NONE32) packed[ex[i]] = vals[i];
 }
 __global__ __launch_bounds__(BLOCK) void ke_deltas(const uint32_t* __restrict__ vals, uint32_t n, const uint32_t* __restrict__ ex, const uint32_t* __restrict__ packed,
-                                                   uint32_t* __restrict__ deltas, uint8_t* __restrict__ nullmask) {
+                                                   uint32_t* __restrict__ deltas, uint8_t* __restrict__ nullmask, const uint32_t* __restrict__ seg) {
   uint32_t i = gtid();
   if (i >= n) return;
   uint32_t v = vals[i];
   if (v == NONE32) { deltas[i] = 0; nullmask[i] = 1; return; }
   uint32_t k = ex[i];
-  deltas[i] = v - (k ? packed[k - 1] : 0u);  // modulo 2^32: the counters are below 2^31, so the difference is an exact int32
+  const uint32_t k0 = seg ? ex[seg[i]] : 0u;   // non-null values in front of the segment: the running value starts at 0 in every segment
+  deltas[i] = v - (k > k0 ? packed[k - 1] : 0u);  // modulo 2^32: the counters are below 2^31, so the difference is an exact int32
   nullmask[i] = 0;
 }
-void enc_delta_prepare(const uint32_t* vals, uint32_t n, uint32_t* deltas, uint8_t* nullmask, EncWork& w, hipStream_t st) {
+void enc_delta_prepare(const uint32_t* vals, uint32_t n, uint32_t* deltas, uint8_t* nullmask, EncWork& w, hipStream_t st, const uint32_t* seg) {
   if (!n) return;
   AM355_LAUNCH_INDEPENDENT(ke_nonnull_flags, grid_for(n + 1), dim3(BLOCK), st, vals, n, w.flag);
   exclusive_scan_u32(w.flag, w.run_ex, n + 1, nullptr, w.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(ke_compact, grid_for(n), dim3(BLOCK), st, vals, n, (const uint32_t*)w.run_ex, w.run_first);
-  AM355_LAUNCH_INDEPENDENT(ke_deltas, grid_for(n), dim3(BLOCK), st, vals, n, (const uint32_t*)w.run_ex, (const uint32_t*)w.run_first, deltas, nullmask);
+  AM355_LAUNCH_INDEPENDENT(ke_deltas, grid_for(n), dim3(BLOCK), st, vals, n, (const uint32_t*)w.run_ex, (const uint32_t*)w.run_first, deltas, nullmask, seg);
 }
 
 // boolean ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void ke_bool_flags(const uint8_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ flag) {
+__global__ __launch_bounds__(BLOCK) void ke_bool_flags(const uint8_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ flag, const uint32_t* __restrict__ seg) {
   uint32_t i = gtid();
   if (i > n) return;
-  flag[i] = i < n && (i == 0 || (v[i] != 0) != (v[i - 1] != 0)) ? 1u : 0u;
+  flag[i] = i < n && (i == 0 || (seg && seg[i] == i) || (v[i] != 0) != (v[i - 1] != 0)) ? 1u : 0u;
 }
 __global__ __launch_bounds__(BLOCK) void ke_bool_sizes(const uint8_t* __restrict__ v, uint32_t n, const uint32_t* __restrict__ run_ex,
-                                                       const uint32_t* __restrict__ run_first, uint32_t* __restrict__ size) {
+                                                       const uint32_t* __restrict__ run_first, uint32_t* __restrict__ size, const uint32_t* __restrict__ seg) {
   uint32_t r = gtid();
   if (r > n) return;
   uint32_t R = run_ex[n], sz = 0;
   if (r < R) {
-    sz = uleb_size(run_first[r + 1] - run_first[r]);
-    if (r == 0 && v[0]) sz += 1;  // the first run counts `false`: empty when the column starts with `true`
+    const uint32_t a = run_first[r];
+    sz = uleb_size(run_first[r + 1] - a);
+    if ((a == 0 || (seg && seg[a] == a)) && v[a]) sz += 1;  // the first run counts `false`: empty when the column (segment) starts with `true`
   }
   size[r] = sz;
 }
 __global__ __launch_bounds__(BLOCK) void ke_bool_write(const uint8_t* __restrict__ v, uint32_t n, const uint32_t* __restrict__ run_ex,
-                                                       const uint32_t* __restrict__ run_first, const uint32_t* __restrict__ off_ex, uint8_t* __restrict__ out) {
+                                                       const uint32_t* __restrict__ run_first, const uint32_t* __restrict__ off_ex, uint8_t* __restrict__ out,
+                                                       const uint32_t* __restrict__ seg) {
   uint32_t r = gtid();
   if (r >= n || r >= run_ex[n]) return;
   uint8_t* p = out + off_ex[r];
-  if (r == 0 && v[0]) *p++ = 0;
-  put_uleb(p, run_first[r + 1] - run_first[r]);
+  const uint32_t a = run_first[r];
+  if ((a == 0 || (seg && seg[a] == a)) && v[a]) *p++ = 0;
+  put_uleb(p, run_first[r + 1] - a);
 }
-void enc_boolean(const uint8_t* vals, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st) {
+void enc_boolean(const uint8_t* vals, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st, const uint32_t* seg) {
   if (!n) { (void)hipMemsetAsync(d_len, 0, 4, st); return; }
-  AM355_LAUNCH_INDEPENDENT(ke_bool_flags, grid_for(n + 1), dim3(BLOCK), st, vals, n, w.flag);
+  AM355_LAUNCH_INDEPENDENT(ke_bool_flags, grid_for(n + 1), dim3(BLOCK), st, vals, n, w.flag, seg);
   exclusive_scan_u32(w.flag, w.run_ex, n + 1, nullptr, w.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(ke_run_first, grid_for(n + 1), dim3(BLOCK), st, (const uint32_t*)w.flag, (const uint32_t*)w.run_ex, n, w.run_first);
-  AM355_LAUNCH_INDEPENDENT(ke_bool_sizes, grid_for(n + 1), dim3(BLOCK), st, vals, n, (const uint32_t*)w.run_ex, (const uint32_t*)w.run_first, w.size);
+  AM355_LAUNCH_INDEPENDENT(ke_bool_sizes, grid_for(n + 1), dim3(BLOCK), st, vals, n, (const uint32_t*)w.run_ex, (const uint32_t*)w.run_first, w.size, seg);
   exclusive_scan_u32(w.size, w.off_ex, n + 1, d_len, w.scan_ws, st);
-  AM355_LAUNCH_INDEPENDENT(ke_bool_write, grid_for(n), dim3(BLOCK), st, vals, n, (const uint32_t*)w.run_ex, (const uint32_t*)w.run_first, (const uint32_t*)w.off_ex, out);
+  AM355_LAUNCH_INDEPENDENT(ke_bool_write, grid_for(n), dim3(BLOCK), st, vals, n, (const uint32_t*)w.run_ex, (const uint32_t*)w.run_first, (const uint32_t*)w.off_ex, out, seg);
 }
 
 // raw values -------------------------------------------------------------------------------------------------------

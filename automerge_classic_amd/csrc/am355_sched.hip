@@ -165,41 +165,56 @@ __global__ __launch_bounds__(SP_THREADS) void ks_pass(const ChangeMeta* __restri
     // ---- resolve: a wavefront per listed copy, a lane per dependency (the loads of a wavefront's next copy are under way while it
     //      works on this one: the index loads are what a sweep waits for) ----
     uint32_t progress = 0;
-    for (uint32_t w = wave; w < n_list; w += N_WAVES) {
-      const uint32_t ci = st_list[w], first = st_first[ci], cnt = st_cnt[ci];
-      uint32_t mx = 0, waits = NONE32;
-      bool never = false;
-      for (uint32_t k0 = 0; k0 < cnt && waits == NONE32 && !never; k0 += WAVE) {
-        const uint32_t k = k0 + lane;
-        uint32_t q = 0;
-        bool unset = false, nev = false;
-        uint32_t d = NONE32;
-        if (k < cnt) {
-          d = dep_idx[first + k];
-          if (d >= n) nev = true;   // a dependency outside the queue
-          else {
-            const uint32_t p = g.G[d];
-            if (p == SCHED_UNSET) unset = true;
-            else if (p == SCHED_NEVER) nev = true;
-            else q = p + (g.A[d] > ci ? 1u : 0u);   // applied behind this copy: the next pass at the earliest
+    constexpr uint32_t RES = 4;   // copies a wavefront has in flight: the index loads of four copies are one round trip, not four
+    for (uint32_t w0 = wave; w0 < n_list; w0 += N_WAVES * RES) {
+      uint32_t ci_[RES], first_[RES], cnt_[RES], d0_[RES];
+#pragma unroll
+      for (uint32_t j = 0; j < RES; j++) {
+        const uint32_t w = w0 + j * N_WAVES;
+        ci_[j] = w < n_list ? st_list[w] : NONE32;
+        first_[j] = ci_[j] != NONE32 ? st_first[ci_[j]] : 0u;
+        cnt_[j] = ci_[j] != NONE32 ? st_cnt[ci_[j]] : 0u;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < RES; j++) d0_[j] = lane < cnt_[j] ? dep_idx[first_[j] + lane] : NONE32;
+#pragma unroll
+      for (uint32_t j = 0; j < RES; j++) {
+        const uint32_t ci = ci_[j], first = first_[j], cnt = cnt_[j];
+        if (ci == NONE32) continue;
+        uint32_t mx = 0, waits = NONE32;
+        bool never = false;
+        for (uint32_t k0 = 0; k0 < cnt && waits == NONE32 && !never; k0 += WAVE) {
+          const uint32_t k = k0 + lane;
+          uint32_t q = 0;
+          bool unset = false, nev = false;
+          uint32_t d = NONE32;
+          if (k < cnt) {
+            d = k0 == 0 ? d0_[j] : dep_idx[first + k];
+            if (d >= n) nev = true;   // a dependency outside the queue
+            else {
+              const uint32_t p = g.G[d];
+              if (p == SCHED_UNSET) unset = true;
+              else if (p == SCHED_NEVER) nev = true;
+              else q = p + (g.A[d] > ci ? 1u : 0u);   // applied behind this copy: the next pass at the earliest
+            }
           }
+          if (__ballot(nev)) never = true;
+          const unsigned long long mu = __ballot(unset);
+          if (mu && !never) waits = __shfl(d, (int)__ffsll(mu) - 1);
+          for (int o = WAVE / 2; o >= 1; o >>= 1) {
+            const uint32_t x = __shfl_xor(q, o);
+            q = x > q ? x : q;
+          }
+          mx = q > mx ? q : mx;
         }
-        if (__ballot(nev)) never = true;
-        const unsigned long long mu = __ballot(unset);
-        if (mu && !never) waits = __shfl(d, (int)__ffsll(mu) - 1);
-        for (int o = WAVE / 2; o >= 1; o >>= 1) {
-          const uint32_t x = __shfl_xor(q, o);
-          q = x > q ? x : q;
+        if (lane == 0) {
+          if (never || waits == NONE32) {
+            sched_decide(g, ci, self_idx[ci] < n ? self_idx[ci] : ci, never ? SCHED_NEVER : mx);
+            st_wait[ci] = NONE32;
+          } else st_wait[ci] = waits;
         }
-        mx = q > mx ? q : mx;
+        progress = 1;   // (decided, or waiting on another dependency now: either way something moved)
       }
-      if (lane == 0) {
-        if (never || waits == NONE32) {
-          sched_decide(g, ci, self_idx[ci] < n ? self_idx[ci] : ci, never ? SCHED_NEVER : mx);
-          st_wait[ci] = NONE32;
-        } else st_wait[ci] = waits;
-      }
-      progress = 1;   // (decided, or waiting on another dependency now: either way something moved)
     }
     if (progress && lane == 0) s_progress = 1;
     if (!SMALL) __threadfence();
