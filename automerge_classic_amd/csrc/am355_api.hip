@@ -20,6 +20,7 @@
 #include "am355_apply.h"
 #include "am355_sync.h"
 #include "am355_sched.h"
+#include "am355_hist.h"
 #include "am355_canary.h"
 
 #include <zlib.h>
@@ -332,7 +333,7 @@ struct am355_ctx {
   // incremental applyChanges (am355_apply_changes)
   std::vector<uint32_t> pending_change;   // queued changes (input indexes, queue order) after the last replay
   std::vector<uint32_t> pass_first_row;   // first op row of every scheduling pass after the first (general scheduler)
-  DevBuf d_delta, d_pass, d_delta_edit, d_sched;
+  DevBuf d_delta, d_pass, d_delta_edit, d_sched, d_hist;
   HostBuf h_sched;
   bool device_scheduled = false;   // the last general-path replay was scheduled by the device (am355_sched.hip)
   HostBuf h_delta;
@@ -465,7 +466,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
   if (c->stream4) (void)hipStreamDestroy(c->stream4);
   for (hipEvent_t e : {c->ev_fork, c->ev_join})
     if (e) (void)hipEventDestroy(e);
-  c->d_delta.release(); c->d_delta_edit.release(); c->d_sched.release(); c->h_sched.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta.release(); c->d_sync.release();
+  c->d_delta.release(); c->d_delta_edit.release(); c->d_sched.release(); c->h_sched.release(); c->d_hist.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta.release(); c->d_sync.release();
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();
@@ -3224,32 +3225,9 @@ static int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena,
       t0 = now;
     };
     const uint32_t N = (uint32_t)c->n_ops, P = (uint32_t)c->n_preds;
-    const size_t n4 = ((size_t)N * 4 + 255) & ~(size_t)255, p4 = ((size_t)P * 4 + 255) & ~(size_t)255, n1 = ((size_t)N + 255) & ~(size_t)255;
-    if (!c->h_rows.ensure(13 * n4 + n1 + 2 * p4 + 256)) return fail(c, AM355_E_NOMEM, "host allocation failed (rows)");
-    uint8_t* h = c->h_rows.as<uint8_t>();
-    const OpCols& d = c->cols;
-    const uint32_t* src[13] = {d.obj_actor, d.obj_ctr, d.key_actor, d.key_ctr, d.key_off, d.key_len, d.action, d.val_tl, d.val_off, d.pred_first, d.pred_num, d.id_ctr, d.id_actor};
-    const uint32_t* dst[13];
-    for (int k = 0; k < 13; k++) {
-      dst[k] = (const uint32_t*)(h + (size_t)k * n4);
-      if (N) HIPCHK(c, hipMemcpyAsync(h + (size_t)k * n4, src[k], (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    uint8_t* h_insert = h + 13 * n4;
-    uint32_t* h_sa = (uint32_t*)(h_insert + n1);
-    uint32_t* h_sc = (uint32_t*)(h_insert + n1 + p4);
-    if (N) HIPCHK(c, hipMemcpyAsync(h_insert, d.insert, N, hipMemcpyDeviceToHost, c->stream));
-    if (P) {
-      HIPCHK(c, hipMemcpyAsync(h_sa, d.pred_actor, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(h_sc, d.pred_ctr, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    lap("rows to host");
+    hipStream_t st = c->stream;
     HistoryInput in;
     in.n_rows = N; in.n_succ = P;
-    in.obj_actor = dst[0]; in.obj_ctr = dst[1]; in.key_actor = dst[2]; in.key_ctr = dst[3]; in.key_off = dst[4]; in.key_len = dst[5];
-    in.action = dst[6]; in.val_tl = dst[7]; in.val_off = dst[8]; in.succ_first = dst[9]; in.succ_num = dst[10]; in.id_ctr = dst[11]; in.id_actor = dst[12];
-    in.insert = h_insert; in.succ_actor = h_sa; in.succ_ctr = h_sc;
-    in.arena = c->raw.data(); in.arena_len = c->raw.size();
     in.actors = &c->actors;
     in.change_columns = &c->doc_chg_cols;
     in.doc_actor_rank = &c->doc_actor_rank;
@@ -3265,10 +3243,105 @@ static int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena,
       in.key_column_len = c->doc_meta.col_len[C_KEY_STR];
       in.val_raw_len = c->doc_meta.col_len[C_VAL_RAW];
     }
+    // ---- host: the change metadata columns (a few thousand values) ----
     std::string err;
+    HistoryMeta meta;
+    int rc = history_metadata(in, meta, err);
+    if (rc == HISTORY_INVALID) return fail(c, AM355_E_INVALID, "%s", err.c_str());
+    if (rc) return fail(c, AM355_E_UNSUPPORTED, "%s", err.c_str());
+    lap("change metadata");
+    // ---- device, stage 1: ids -> slots, preds by slot, the changes' slot ranges (am355_hist.hip) ----
+    const uint32_t NC = (uint32_t)meta.chg.size(), NA = (uint32_t)c->actors.size(), W = meta.word_base[NA];
+    const size_t key_bytes = c->doc_meta.col_len[C_KEY_STR], val_bytes = c->doc_meta.col_len[C_VAL_RAW];
+    if (!c->d_hist.ensure(hist_bytes(N, P, NC, NA, W, key_bytes, val_bytes))) return fail(c, AM355_E_NOMEM, "device allocation failed (history)");
+    HistBufs hb;
+    hist_bind(hb, c->d_hist.p, N, P, NC, NA, W, key_bytes, val_bytes);
+    canary_arm();
+    const size_t AW = hb.AW, c1 = (size_t)NC + 1;
+    // pinned staging: [word_base | act_max | chg_actor | chg_prev_max | chg_max] up, [flags | chg_base | chg_nops] down, then
+    // [sorted_base | sorted_chg] up and [flags | col_len | col_off | abits | column bytes] down
+    size_t col_total_cap = 0;
+    for (int k = 0; k < HIST_NCOL; k++) col_total_cap += hb.col_cap[k] + 256;
+    const size_t up_words = 2 * ((size_t)NA + 1) + 5 * c1, down_words = 8 + 2 * c1 + HIST_NCOL + (size_t)HIST_NCOL * 2 * (c1) + c1 * AW;
+    if (!c->h_rows.ensure(4 * (up_words + down_words) + col_total_cap + 4096)) return fail(c, AM355_E_NOMEM, "host allocation failed (history)");
+    uint32_t* up = c->h_rows.as<uint32_t>();
+    uint32_t *u_word_base = up, *u_act_max = up + NA + 1, *u_actor = u_act_max + NA + 1, *u_prev = u_actor + c1, *u_max = u_prev + c1, *u_sbase = u_max + c1, *u_schg = u_sbase + c1;
+    uint32_t* down = up + up_words;
+    uint32_t *d_flags = down, *d_base = down + 8, *d_nops = d_base + c1, *d_col_len = d_nops + c1, *d_col_off = d_col_len + HIST_NCOL, *d_abits = d_col_off + (size_t)HIST_NCOL * 2 * c1;
+    uint8_t* d_cols = (uint8_t*)(down + down_words);
+    memcpy(u_word_base, meta.word_base.data(), 4 * ((size_t)NA + 1));
+    if (NA) memcpy(u_act_max, meta.act_max.data(), 4 * (size_t)NA);
+    for (uint32_t k = 0; k < NC; k++) {
+      const HistoryChange& ch = meta.chg[k];
+      u_actor[k] = ch.actor;
+      u_prev[k] = ch.prev_same_actor == NONE32 ? 0u : (uint32_t)meta.chg[ch.prev_same_actor].max_op;
+      u_max[k] = (uint32_t)ch.max_op;
+    }
+    HIPCHK(c, hipMemcpyAsync(hb.word_base, u_word_base, 4 * ((size_t)NA + 1), hipMemcpyHostToDevice, st));
+    if (NA) HIPCHK(c, hipMemcpyAsync(hb.act_max, u_act_max, 4 * (size_t)NA, hipMemcpyHostToDevice, st));
+    if (NC) {
+      HIPCHK(c, hipMemcpyAsync(hb.chg_actor, u_actor, 4 * (size_t)NC, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(hb.chg_prev_max, u_prev, 4 * (size_t)NC, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(hb.chg_max, u_max, 4 * (size_t)NC, hipMemcpyHostToDevice, st));
+    }
+    hist_stage1(c->cols, hb, st);
+    HIPCHK(c, hipMemcpyAsync(d_flags, hb.flags, 16, hipMemcpyDeviceToHost, st));
+    if (NC) {
+      HIPCHK(c, hipMemcpyAsync(d_base, hb.chg_base, 4 * (size_t)NC, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(d_nops, hb.chg_nops, 4 * (size_t)NC, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    lap("ids -> slots, preds (device)");
+    if (d_flags[0] & HF_INVALID) return fail(c, AM355_E_INVALID, "operation ids of the document contradict its change metadata");
+    const uint32_t M = d_flags[2], PT = d_flags[3];
+    // the changes that own slots, in slot order = (actor, seq) order; every slot must belong to one of them
+    uint32_t n_sorted = 0;
+    {
+      std::vector<uint32_t> order;
+      order.reserve(NC);
+      for (uint32_t k = 0; k < NC; k++) if (d_nops[k]) order.push_back(k);
+      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return d_base[x] < d_base[y]; });
+      uint64_t covered = 0;
+      for (uint32_t k : order) {
+        if (d_base[k] != covered) return fail(c, AM355_E_INVALID, "operation ids that no change of the document accounts for");
+        covered += d_nops[k];
+        u_sbase[n_sorted] = d_base[k];
+        u_schg[n_sorted++] = k;
+      }
+      if (covered != M) return fail(c, AM355_E_INVALID, "operation ids that no change of the document accounts for");
+    }
+    if (n_sorted) {
+      HIPCHK(c, hipMemcpyAsync(hb.sorted_base, u_sbase, 4 * (size_t)n_sorted, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(hb.sorted_chg, u_schg, 4 * (size_t)n_sorted, hipMemcpyHostToDevice, st));
+    }
+    // ---- device, stage 2: actor tables, the changes' op columns, the twelve column encodes segmented by change ----
+    hb.P = PT;   // (pred entries = succ entries the slots account for)
+    hist_stage2(c->cols, c->d_arena.as<uint8_t>(), c->raw.size(), hb, n_sorted, M, st);
+    HIPCHK(c, hipMemcpyAsync(d_flags, hb.flags, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(d_col_len, hb.col_len, 4 * HIST_NCOL, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(d_col_off, hb.col_off, 4 * (size_t)HIST_NCOL * 2 * c1, hipMemcpyDeviceToHost, st));
+    if (NC) HIPCHK(c, hipMemcpyAsync(d_abits, hb.abits, 4 * (size_t)NC * AW, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (d_flags[0] & HF_INVALID) return fail(c, AM355_E_INVALID, "the document's rows do not re-encode (an operation the reference throws on)");
+    if (d_flags[0] & HF_UNSUPPORTED) return fail(c, AM355_E_UNSUPPORTED, "a value or key the reference does not re-encode byte for byte: the JS path decides");
+    // (the value bytes of the rows must cover the valRaw column exactly: a longer column makes extra rows in the reference)
+    if (d_col_len[8] != in.val_raw_len) return fail(c, AM355_E_UNSUPPORTED, "value bytes do not cover the valRaw column: the JS path decides");
+    HistoryPieces pc;
+    pc.chg_nops = d_nops; pc.abits = d_abits; pc.aw = (uint32_t)AW; pc.col_off = d_col_off;
+    {
+      uint8_t* q = d_cols;
+      for (int k = 0; k < HIST_NCOL; k++) {
+        pc.col_bytes[k] = q;
+        if (d_col_len[k] > hb.col_cap[k]) return fail(c, AM355_E_DEVICE, "internal: encoded column larger than its bound");
+        if (d_col_len[k]) HIPCHK(c, hipMemcpyAsync(q, hb.col_out[k], d_col_len[k], hipMemcpyDeviceToHost, st));
+        q += ((size_t)d_col_len[k] + 255) & ~(size_t)255;
+      }
+      HIPCHK(c, hipStreamSynchronize(st));
+    }
+    lap("columns of all changes (device)");
     c->history = HistoryOutput{};
-    int rc = reconstruct_history(in, (flags & 1) != 0, [&](unsigned k, const std::function<void(unsigned)>& fn) { c->pool->run(k, fn); }, c->history, err);
-    lap("regroup + encode + hash");
+    rc = history_finish(in, meta, pc, (flags & 1) != 0, [&](unsigned k, const std::function<void(unsigned)>& fn) { c->pool->run(k, fn); }, c->history, err);
+    lap("headers + hash chain");
     if (rc == HISTORY_INVALID) return fail(c, AM355_E_INVALID, "%s", err.c_str());
     if (rc) return fail(c, AM355_E_UNSUPPORTED, "%s", err.c_str());
     c->history_ok = true;

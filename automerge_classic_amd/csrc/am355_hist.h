@@ -38,7 +38,7 @@ struct HistBufs {
   uint8_t* nullmask;               // [max(M, P) + 2]
   uint8_t* col_out[HIST_NCOL];     // encoded bytes of a column, all changes back to back
   size_t col_cap[HIST_NCOL];
-  uint32_t* col_off;               // [HIST_NCOL x (NC + 1)] byte offset of every change in every column
+  uint32_t* col_off;               // [HIST_NCOL][2 x (NC + 1)]: begin / end of change k in column q at [q][2k], [q][2k + 1]
   uint32_t* col_len;               // [HIST_NCOL] total bytes
   void* scan_ws;
 };

@@ -38,7 +38,7 @@ size_t hist_bytes(uint32_t N, uint32_t P, uint32_t NC, uint32_t NA, uint32_t W, 
   size_t b = al256(16) + al256(4 * ((size_t)NA + 1)) + al256(4 * (size_t)NA + 4) + 5 * al256(4 * C) + 4 * al256(4 * ((size_t)W + 2));
   b += 2 * al256(4 * M) + 3 * al256(4 * (M + 1)) + al256(4 * PP) + 2 * al256(4 * C) + al256(4 * C * AW);
   b += 12 * al256(4 * M) + al256(M) + 3 * al256(4 * PP) + 2 * al256(4 * (C + 1));
-  b += al256(enc_work_bytes((uint32_t)big)) + al256(4 * big) + al256(big) + al256(4 * HIST_NCOL * (C + 1)) + al256(4 * HIST_NCOL);
+  b += al256(enc_work_bytes((uint32_t)big)) + al256(4 * big) + al256(big) + al256(4 * HIST_NCOL * 2 * (C + 1)) + al256(4 * HIST_NCOL);
   for (int k = 0; k < HIST_NCOL; k++) b += al256(hist_col_cap(k, (uint32_t)M, (uint32_t)PP, key_bytes, val_bytes));
   b += al256(scan_workspace_bytes((uint32_t)std::max<size_t>(big, (size_t)W + 2)));
   return b + 4096;
@@ -75,7 +75,7 @@ void hist_bind(HistBufs& h, void* block, uint32_t N, uint32_t P, uint32_t NC, ui
   }
   h.deltas = (uint32_t*)take(4 * big);
   h.nullmask = (uint8_t*)take(big);
-  h.col_off = (uint32_t*)take(4 * HIST_NCOL * (C + 1));
+  h.col_off = (uint32_t*)take(4 * HIST_NCOL * 2 * (C + 1));
   h.col_len = (uint32_t*)take(4 * HIST_NCOL);
   for (int k = 0; k < HIST_NCOL; k++) {
     h.col_cap[k] = hist_col_cap(k, (uint32_t)M, (uint32_t)PP, key_bytes, val_bytes);

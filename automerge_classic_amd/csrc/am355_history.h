@@ -5,9 +5,12 @@
 // (deps by index -> hashes, each change re-encoded to learn its hash), :710-739 encodeChange, :370-444 encodeOps, :122-170 parseAllOpIds
 // (change-local actor table: author first, the others sorted).
 //
-// Division of work: the op columns of the document are decoded on the GPU (am355_bigcol.hip, the Backend.load path); this module
-// takes those rows on the host, regroups them into changes and re-encodes every change -- independent per change, on the engine's
-// host threads -- then chains the hashes in document order (a change's header holds the hashes of its dependencies).
+// Division of work: the op columns of the document are decoded on the GPU (am355_bigcol.hip, the Backend.load path) and stay there;
+// the device regroups the rows into changes -- ids to slots, preds from succ lists, the changes' slot ranges -- and encodes the twelve
+// op columns of ALL changes, segmented by change (am355_hist.hip + am355_encode.hip). The host reads the change metadata columns
+// (history_metadata: a few thousand values), writes the headers around the column pieces and chains the hashes in document order
+// (history_finish: a change's header holds the hashes of its dependencies; SHA-256 is one dependent block after the other, which a
+// host core with SHA extensions does two orders of magnitude faster than a lane of the device).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -19,14 +22,8 @@
 namespace am355 {
 
 struct HistoryInput {
-  // op rows of the document in canonical order (actor fields: rank in `actors`; NONE32 where absent), succ lists flattened
+  // the op rows of the document stay in device memory (n_rows of them, n_succ succ entries)
   uint32_t n_rows = 0, n_succ = 0;
-  const uint32_t *obj_actor = nullptr, *obj_ctr = nullptr, *key_actor = nullptr, *key_ctr = nullptr, *key_off = nullptr, *key_len = nullptr;
-  const uint32_t *action = nullptr, *val_tl = nullptr, *val_off = nullptr, *succ_first = nullptr, *succ_num = nullptr, *id_ctr = nullptr, *id_actor = nullptr;
-  const uint8_t* insert = nullptr;
-  const uint32_t *succ_actor = nullptr, *succ_ctr = nullptr;
-  const uint8_t* arena = nullptr;  // values and keys are byte ranges of it
-  size_t arena_len = 0;
   const std::vector<std::string>* actors = nullptr;  // raw actor ids by rank (lexicographic)
   // change metadata columns of the document, inflated: (column id, bytes); actor indexes in them are DOCUMENT actor indexes
   const std::vector<std::pair<uint32_t, std::vector<uint8_t>>>* change_columns = nullptr;
@@ -36,6 +33,31 @@ struct HistoryInput {
   size_t val_raw_len = 0;               // length of the valRaw column (the values of the rows must cover it exactly)
   const uint8_t* heads = nullptr;  // the document's heads, 32 bytes each, sorted
   uint32_t n_heads = 0;
+};
+
+// one change of the document, from the change metadata columns (+ n_ops / start_op once the device has counted its ids)
+struct HistoryChange {
+  uint32_t actor = 0;  // rank
+  uint64_t seq = 0, max_op = 0, start_op = 0;
+  int64_t time = 0;
+  std::string message, extra;
+  uint32_t dep_first = 0, dep_num = 0;
+  uint32_t op_base = 0, n_ops = 0;
+  uint32_t prev_same_actor = 0xffffffffu;
+};
+struct HistoryMeta {
+  std::vector<HistoryChange> chg;
+  std::vector<uint32_t> dep_index;              // dependencies by change index, flattened (HistoryChange.dep_first / dep_num)
+  std::vector<uint32_t> act_max, word_base;     // per actor: last maxOp | first 32-bit word of its stretch of the id bitmaps ([NA + 1])
+};
+constexpr int HISTORY_NCOL = 12;
+// what the device stages left, in host memory
+struct HistoryPieces {
+  const uint32_t* chg_nops = nullptr;           // [NC] ops of every change
+  const uint32_t* abits = nullptr;              // [NC x aw] actors a change mentions (bit = rank)
+  uint32_t aw = 0;
+  const uint32_t* col_off = nullptr;            // [HISTORY_NCOL][2 x (NC + 1)]: begin / end of change k in column q at [q][2k], [q][2k + 1]
+  const uint8_t* col_bytes[HISTORY_NCOL] = {};  // the encoded columns, all changes back to back
 };
 
 struct HistoryOutput {
@@ -49,7 +71,10 @@ enum { HISTORY_OK = 0, HISTORY_INVALID = 1, HISTORY_UNSUPPORTED = 2 };
 // par(k, fn): runs fn(0..k-1) on the caller's host threads and returns when all are done.
 using ParallelFor = std::function<void(unsigned, const std::function<void(unsigned)>&)>;
 
-// deflate: compress changes of >= 256 bytes as encodeChange does (columnar.js:798-811; zlib level 6 raw = pako's defaults).
-int reconstruct_history(const HistoryInput& in, bool deflate, const ParallelFor& par, HistoryOutput& out, std::string& err);
+// change metadata columns -> meta (and the layout of the id bitmaps the device builds)
+int history_metadata(const HistoryInput& in, HistoryMeta& meta, std::string& err);
+// headers + column pieces -> changes, hash chain, containers. deflate: compress changes of >= 256 bytes as encodeChange does
+// (columnar.js:798-811; zlib level 6 raw = pako's defaults).
+int history_finish(const HistoryInput& in, HistoryMeta& meta, const HistoryPieces& pc, bool deflate, const ParallelFor& par, HistoryOutput& out, std::string& err);
 
 }  // namespace am355
