@@ -3315,6 +3315,7 @@ static int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena,
       HIPCHK(c, hipMemcpyAsync(hb.sorted_chg, u_schg, 4 * (size_t)n_sorted, hipMemcpyHostToDevice, st));
     }
     // ---- device, stage 2: actor tables, the changes' op columns, the twelve column encodes segmented by change ----
+    c->pool->prewake(c->pool->size(), 4000);   // (the host threads assemble and hash right behind it: they poll instead of sleeping until then)
     hb.P = PT;   // (pred entries = succ entries the slots account for)
     hist_stage2(c->cols, c->d_arena.as<uint8_t>(), c->raw.size(), hb, n_sorted, M, st);
     HIPCHK(c, hipMemcpyAsync(d_flags, hb.flags, 16, hipMemcpyDeviceToHost, st));

@@ -104,6 +104,30 @@ struct RleReader {
     } else { uint64_t z; if (!r.uleb(z) || z == 0) return false; n += z; }
     return true;
   }
+  // numeric columns: the same as next() without the string (the dependency index column alone holds a value per dependency edge)
+  inline bool next_num(bool& is_null, int64_t& v) {
+    if (count == 0) {
+      if (r.off >= r.len) { is_null = true; return true; }   // a column that has run out yields nulls
+      int64_t n;
+      if (!r.sleb(n)) return false;
+      if (n > 1) { if (!raw_num(last)) return false; state = 1; count = n; }
+      else if (n == 1) return false;
+      else if (n < 0) { state = 2; count = -n; }
+      else { uint64_t z; if (!r.uleb(z) || z == 0) return false; state = 3; count = (int64_t)z; }
+    }
+    count--;
+    if (state == 2 && !raw_num(last)) return false;
+    is_null = state == 3;
+    v = last;
+    return true;
+  }
+  inline bool raw_num(int64_t& v) {
+    if (kind == 1) return r.sleb(v);
+    uint64_t u;
+    if (!r.uleb(u)) return false;
+    v = (int64_t)u;
+    return true;
+  }
   // a column that has run out yields nulls (encoding.js:639-642)
   bool next(bool& is_null, int64_t& v, std::string& s) {
     if (done()) { is_null = true; return true; }
@@ -236,18 +260,18 @@ int history_metadata(const HistoryInput& in, HistoryMeta& meta, std::string& err
       bool nul;
       int64_t v;
       std::string s;
-      if (!r_actor.next(nul, v, s)) return bad(HISTORY_INVALID, "malformed change metadata columns");
+      if (!r_actor.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul || v < 0 || (uint64_t)v >= in.doc_actor_rank->size()) return bad(HISTORY_INVALID, "bad actor index in change metadata");
       c.actor = (*in.doc_actor_rank)[(size_t)v];
-      if (!r_seq.next(nul, v, s)) return bad(HISTORY_INVALID, "malformed change metadata columns");
+      if (!r_seq.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul) return bad(HISTORY_INVALID, "change without seq");
       seq_abs += v; c.seq = (uint64_t)seq_abs;
-      if (!r_max.next(nul, v, s)) return bad(HISTORY_INVALID, "malformed change metadata columns");
+      if (!r_max.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul) return bad(HISTORY_INVALID, "change without maxOp");
       max_abs += v;
       if (max_abs < 0 || max_abs > 0x7fffffff) return bad(HISTORY_UNSUPPORTED, "maxOp beyond 2^31");
       c.max_op = (uint64_t)max_abs;
-      if (!r_time.next(nul, v, s)) return bad(HISTORY_INVALID, "malformed change metadata columns");
+      if (!r_time.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul) return bad(HISTORY_INVALID, "change without time");
       time_abs += v; c.time = time_abs;
       if (!r_msg.next(nul, v, s)) return bad(HISTORY_INVALID, "malformed change metadata columns");
@@ -255,19 +279,20 @@ int history_metadata(const HistoryInput& in, HistoryMeta& meta, std::string& err
         if (!valid_utf8((const uint8_t*)s.data(), s.size())) return bad(HISTORY_UNSUPPORTED, "message is not valid UTF-8");
         c.message = s;
       }
-      if (!r_dnum.next(nul, v, s)) return bad(HISTORY_INVALID, "malformed change metadata columns");
+      if (!r_dnum.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul || v < 0 || v > 0x7fffffff) return bad(HISTORY_INVALID, "bad dependency count");
       c.dep_first = (uint32_t)dep_index.size();
       c.dep_num = (uint32_t)v;
+      if (dep_index.capacity() < dep_index.size() + c.dep_num) dep_index.reserve(2 * (dep_index.size() + c.dep_num) + 1024);
       for (uint32_t d = 0; d < c.dep_num; d++) {
         bool dn;
         int64_t dv;
-        if (!r_didx.next(dn, dv, s) || dn) return bad(HISTORY_INVALID, "malformed dependency index column");
+        if (!r_didx.next_num(dn, dv) || dn) return bad(HISTORY_INVALID, "malformed dependency index column");
         didx_abs += dv;
         if (didx_abs < 0 || (uint64_t)didx_abs >= chg.size()) return bad(HISTORY_INVALID, "dependency index does not name an earlier change");
         dep_index.push_back((uint32_t)didx_abs);
       }
-      if (!r_xlen.next(nul, v, s)) return bad(HISTORY_INVALID, "malformed change metadata columns");
+      if (!r_xlen.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul || (v & 15) != 7) return bad(HISTORY_INVALID, "Bad datatype for extra bytes");
       size_t xl = (size_t)(v >> 4);
       if (xl > xtotal - xoff) return bad(HISTORY_INVALID, "extra bytes column too short");
@@ -457,19 +482,31 @@ int history_finish(const HistoryInput& in, HistoryMeta& meta, const HistoryPiece
       sha256_digest(base + 8, (size_t)(plain_off[k + 1] - plain_off[k] - 8), digest);   // over [chunk type][LEB length][body]
       memcpy(base + 4, digest, 4);
     };
-    std::vector<const uint8_t*> deps0;
-    for (uint32_t l = 0; l < n_levels; l++) {
-      const uint32_t lo = level_first[l], hi = level_first[l + 1], cnt = hi - lo;
-      if (cnt < 8) {
-        for (uint32_t i = lo; i < hi; i++) hash_change(by_level[i], deps0);
-      } else {
-        const unsigned tasks = std::min<uint32_t>(cnt, 32);
-        par(tasks, [&](unsigned t) {
-          std::vector<const uint8_t*> deps;
-          for (uint32_t i = lo + t; i < hi; i += tasks) hash_change(by_level[i], deps);
-        });
+    // ONE run of the pool for all levels: a task takes changes of the current level until none is left, waits for the ones others
+    // took, and goes on to the next level. (A task only ever waits for changes some RUNNING task holds, so the pool may execute the
+    // tasks on fewer threads than there are tasks. A run of the pool per level cost a wake-up per level: 5.5 ms for the 64 levels of
+    // the headline log against 0.4 ms of hashing.)
+    std::vector<uint32_t> taken((size_t)n_levels + 1, 0), finished((size_t)n_levels + 1, 0);
+    uint32_t widest = 0;
+    for (uint32_t l = 0; l < n_levels; l++) widest = std::max(widest, level_first[l + 1] - level_first[l]);
+    const unsigned tasks = std::max(1u, std::min<uint32_t>(widest, 32));
+    par(tasks, [&](unsigned) {
+      std::vector<const uint8_t*> deps;
+      for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t lo = level_first[l], cnt = level_first[l + 1] - lo;
+        for (;;) {
+          const uint32_t i = __atomic_fetch_add(&taken[l], 1u, __ATOMIC_RELAXED);
+          if (i >= cnt) break;
+          hash_change(by_level[lo + i], deps);
+          __atomic_fetch_add(&finished[l], 1u, __ATOMIC_RELEASE);
+        }
+        while (__atomic_load_n(&finished[l], __ATOMIC_ACQUIRE) < cnt) {
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
       }
-    }
+    });
   }
   {
     std::vector<const uint8_t*> heads;

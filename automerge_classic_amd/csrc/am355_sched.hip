@@ -69,9 +69,9 @@ struct SchedGroups {
 };
 
 // copy c has decided: it would be applied in pass v (SCHED_NEVER: never)
-__device__ __forceinline__ void sched_decide(const SchedGroups& g, uint32_t c, uint32_t F, uint32_t v) {
-  volatile uint32_t* left = g.left;
-  if (left[F] == 0) { g.G[F] = v; return; }  // no copies: A[F] == F from the start
+// (alone: the change has no copies -- known from LDS, so that the common case touches no global memory: F == c, A[c] == c from the start)
+__device__ __forceinline__ void sched_decide(const SchedGroups& g, uint32_t c, uint32_t F, uint32_t v, bool alone) {
+  if (alone) { g.G[c] = v; return; }
   if (v != SCHED_NEVER) atomicMin(&g.best[F], (unsigned long long)v << 32 | c);
   __threadfence();
   if (atomicSub(&g.left[F], 1u) == 1u) {  // the last copy to decide publishes the group
@@ -126,9 +126,12 @@ __global__ __launch_bounds__(SP_THREADS) void ks_pass(const ChangeMeta* __restri
   }
   __threadfence();
   __syncthreads();
+  constexpr uint32_t COPIES = 0x80000000u;   // in st_cnt: the change is one of several copies (its group is decided through global memory)
   for (uint32_t ci = t; ci < n; ci += SP_THREADS) {
     volatile uint32_t* left = g_left;
-    if ((self_idx[ci] >= n || self_idx[ci] == ci) && left[ci] != 0) g_left[ci] = left[ci] + 1;  // + the first copy itself
+    const bool first = self_idx[ci] >= n || self_idx[ci] == ci;
+    if (first && left[ci] != 0) g_left[ci] = left[ci] + 1;  // + the first copy itself
+    if (!first || left[ci] != 0) st_cnt[ci] |= COPIES;
   }
   __threadfence();
   __syncthreads();
@@ -136,10 +139,11 @@ __global__ __launch_bounds__(SP_THREADS) void ks_pass(const ChangeMeta* __restri
   // first sweep does not resolve all n copies -- one coalesced load each, but sixteen wavefronts' worth at a time -- only to find
   // nearly all of them blocked)
   for (uint32_t ci = t; ci < n; ci += SP_THREADS) {
-    const uint32_t cnt = st_cnt[ci];
+    const bool alone = !(st_cnt[ci] & COPIES);
+    const uint32_t cnt = st_cnt[ci] & ~COPIES;
     const uint32_t d0 = cnt ? dep_idx[st_first[ci]] : NONE32;
     if (cnt == 0 || d0 >= n) {
-      sched_decide(g, ci, self_idx[ci] < n ? self_idx[ci] : ci, cnt == 0 ? 0u : SCHED_NEVER);
+      sched_decide(g, ci, alone ? ci : (self_idx[ci] < n ? self_idx[ci] : ci), cnt == 0 ? 0u : SCHED_NEVER, alone);
       st_wait[ci] = NONE32;
     } else st_wait[ci] = d0;
   }
@@ -173,13 +177,14 @@ __global__ __launch_bounds__(SP_THREADS) void ks_pass(const ChangeMeta* __restri
         const uint32_t w = w0 + j * N_WAVES;
         ci_[j] = w < n_list ? st_list[w] : NONE32;
         first_[j] = ci_[j] != NONE32 ? st_first[ci_[j]] : 0u;
-        cnt_[j] = ci_[j] != NONE32 ? st_cnt[ci_[j]] : 0u;
+        cnt_[j] = ci_[j] != NONE32 ? st_cnt[ci_[j]] : 0u;   // (bit 31: COPIES)
       }
 #pragma unroll
-      for (uint32_t j = 0; j < RES; j++) d0_[j] = lane < cnt_[j] ? dep_idx[first_[j] + lane] : NONE32;
+      for (uint32_t j = 0; j < RES; j++) d0_[j] = lane < (cnt_[j] & ~COPIES) ? dep_idx[first_[j] + lane] : NONE32;
 #pragma unroll
       for (uint32_t j = 0; j < RES; j++) {
-        const uint32_t ci = ci_[j], first = first_[j], cnt = cnt_[j];
+        const uint32_t ci = ci_[j], first = first_[j], cnt = cnt_[j] & ~COPIES;
+        const bool alone = !(cnt_[j] & COPIES);
         if (ci == NONE32) continue;
         uint32_t mx = 0, waits = NONE32;
         bool never = false;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(SP_THREADS) void ks_pass(const ChangeMeta* __restri
         }
         if (lane == 0) {
           if (never || waits == NONE32) {
-            sched_decide(g, ci, self_idx[ci] < n ? self_idx[ci] : ci, never ? SCHED_NEVER : mx);
+            sched_decide(g, ci, alone ? ci : (self_idx[ci] < n ? self_idx[ci] : ci), never ? SCHED_NEVER : mx, alone);
             st_wait[ci] = NONE32;
           } else st_wait[ci] = waits;
         }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(SP_THREADS) void ks_pass(const ChangeMeta* __restri
     if (!any_progress || sweep + 1 >= max_sweeps) {
       if (any_progress) unfinished = 1;
       for (uint32_t ci = t; ci < n; ci += SP_THREADS)
-        if (st_wait[ci] != NONE32) sched_decide(g, ci, self_idx[ci] < n ? self_idx[ci] : ci, SCHED_NEVER);
+        if (st_wait[ci] != NONE32) sched_decide(g, ci, self_idx[ci] < n ? self_idx[ci] : ci, SCHED_NEVER, !(st_cnt[ci] & COPIES));
       break;
     }
   }
