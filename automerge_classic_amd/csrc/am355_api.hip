@@ -1762,7 +1762,9 @@ static int replay_document(am355_ctx* c) {
     canary_forget(c->d_ks.p, c->d_ks.cap);
     keystr_index_begin(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], c->d_ks.p, ks, d_words + W_TOTAL_ENTRIES, d_words + W_FAST_B,
                        c->stream2);
-    HIPCHK(c, hipMemcpyAsync(c->h_words.as<uint32_t>() + W_FAST_B, d_words + W_FAST_B, 4, hipMemcpyDeviceToHost, c->stream2));
+    // (the key stream needs no host decision any more: both halves are enqueued at once and run beside the token index)
+    keystr_index_finish(ks, false, &ks_start, &ks_off, &ks_len, d_words + W_FLAGS_B, c->stream2);
+    HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
     BigColInfo* hi = c->h_biginfo.as<BigColInfo>();
     bigcol_index_tokens(c->d_arena.as<uint8_t>(), d, w, st);
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
@@ -1770,13 +1772,7 @@ static int replay_document(am355_ctx* c) {
     bigcol_index_records(c->d_arena.as<uint8_t>(), d, w, hi->n_tokens, st);
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->ev[1], st));
-    // the key stream's one host decision (does the parse reach a literal longer than the first doubling rounds cover?) is
-    // taken while the main stream is busy with the token index
     lap("enqueued index");
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
-    lap("key stage 1 done");
-    keystr_index_finish(ks, c->h_words.as<uint32_t>()[W_FAST_B] != 0, &ks_start, &ks_off, &ks_len, d_words + W_FLAGS_B, c->stream2);
-    HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
     HIPCHK(c, hipStreamSynchronize(st));
     lap("token index done");
     if (hi->flags) { (void)hipStreamSynchronize(c->stream2); return error_for_flags(c, hi->flags, "malformed document columns"); }

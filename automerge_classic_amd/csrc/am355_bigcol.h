@@ -42,6 +42,8 @@ struct BigColVals {
   uint32_t *val_off, *succ_first;  // [N + 1] exclusive prefix sums of value lengths / succ counts
   uint32_t* tmp;               // [max(N, P) + 1]
   void* scan_ws;               // scan_workspace_bytes(max(N, P) + 1)
+  uint32_t* tile_rec;          // [BIG_NCOL x tile_stride] record that holds the first row of every stretch of 1024 rows (kb_tile_recs)
+  uint32_t tile_stride;
 };
 size_t bigcol_vals_bytes(uint32_t n_rows, uint32_t n_succ);
 void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_succ);
@@ -57,9 +59,9 @@ void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, cons
                      uint32_t val_raw_len, OpCols o, uint32_t* flags, hipStream_t st);
 
 // keyStr column -> run table (run_start has n_runs + 1 entries; run_len NONE32 = null run), fully parallel; scratch in `work`
-// (keystr_work_bytes(col_len) bytes). Two steps with one host decision in between (see am355_bigcol.hip): `begin` leaves one
-// word at *d_unresolved (zeroed by the caller) telling whether a literal longer than the first doubling rounds cover is on
-// the true parse; `finish` gets that word's value.
+// (keystr_work_bytes(col_len) bytes). `begin` (vnext / hnext of every position with the k-th successors of literal headers resolved
+// tile by tile in LDS, then the true headers) and `finish` (literal items, run table) are enqueued back to back: no host decision
+// in between (d_unresolved / unresolved are unused leftovers of the version that had one).
 struct KeyWork {
   uint32_t *vnext, *hnext, *kk, *ja, *jb, *mark_h, *mark_v, *item_ex, *rows;  // [L + 2]
   uint32_t *run_start, *run_off, *run_len, *run_kind;                        // [L + 2] (items <= bytes)
@@ -68,11 +70,9 @@ struct KeyWork {
 };
 struct KeyStage {
   KeyWork k;
-  uint32_t *j0, *j1;
   void* chain_ws;
   const uint8_t *col, *arena;
   uint32_t col_abs, L;
-  int rounds, done;
 };
 size_t keystr_work_bytes(uint32_t col_len);
 void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, KeyStage& s, uint32_t* n_runs, uint32_t* d_unresolved,

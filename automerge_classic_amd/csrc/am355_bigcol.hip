@@ -21,6 +21,7 @@ namespace am355 {
 static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); }
 constexpr uint64_t MAX_SAFE_BIG = 9007199254740991ull;
 
+constexpr uint32_t EXPAND_TILE = 1024;   // rows per entry of the coarse row -> record table (kb_tile_recs)
 static size_t al256(size_t b) { return carve_round(b); }
 size_t bigcol_work_bytes(uint32_t tok_bytes) {
   size_t cap = (size_t)tok_bytes + 2;
@@ -40,7 +41,8 @@ void bigcol_carve(BigColWork& w, void* base, uint32_t tok_bytes) {
 }
 size_t bigcol_vals_bytes(uint32_t n_rows, uint32_t n_succ) {
   size_t n = (size_t)n_rows + 1, p = (size_t)n_succ + 1;
-  return 12 * al256(4 * n) + 2 * al256(4 * p) + al256(n) + al256(4 * (n > p ? n : p)) + al256(scan_workspace_bytes((uint32_t)(n > p ? n : p)));
+  return 12 * al256(4 * n) + 2 * al256(4 * p) + al256(n) + al256(4 * (n > p ? n : p)) + al256(scan_workspace_bytes((uint32_t)(n > p ? n : p))) +
+         al256(4 * BIG_NCOL * ((n > p ? n : p) / EXPAND_TILE + 3));
 }
 void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_succ) {
   canary_scope("document column values (bigcol_carve_vals)");
@@ -53,6 +55,8 @@ void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_su
   v.key_ctr_null = (uint8_t*)take(n);
   v.tmp = (uint32_t*)take(4 * (n > pn ? n : pn));
   v.scan_ws = take(scan_workspace_bytes((uint32_t)(n > pn ? n : pn)));
+  v.tile_stride = (uint32_t)((n > pn ? n : pn) / EXPAND_TILE + 3);
+  v.tile_rec = (uint32_t*)take(4 * BIG_NCOL * (size_t)v.tile_stride);
 }
 
 // ---- tokens -------------------------------------------------------------------------------------------------
@@ -210,9 +214,30 @@ void bigcol_index_records(const uint8_t* arena, const BigColDesc& d, BigColWork&
 }
 
 // ---- rows ---------------------------------------------------------------------------------------------------
+// coarse table for kb_expand: the record that holds the first row of every stretch of EXPAND_TILE rows, per column (one binary
+// search over the column's records per stretch instead of one per row: a row then looks among the few records of its stretch)
+__global__ __launch_bounds__(BLOCK) void kb_tile_recs(BigColWork w, BigColVals v, uint32_t n_rows, uint32_t n_succ) {
+  const uint32_t tile = gtid();
+  const uint32_t c = blockIdx.y;
+  const uint32_t n = c >= BC_SUCC_ACTOR ? n_succ : n_rows;
+  const uint32_t tiles = n / EXPAND_TILE + 2;
+  if (tile >= tiles) return;
+  const uint32_t r0 = w.info->r0[c], r1 = w.info->r1[c];
+  const uint32_t base = w.rec_start[r0], avail = w.rec_start[r1] - base;
+  const uint64_t row = (uint64_t)tile * EXPAND_TILE;
+  uint32_t lo = r0, hi = r1;  // last record whose first row is <= row
+  if (row >= avail) lo = r1 > r0 ? r1 - 1 : r0;
+  else
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (w.rec_start[mid] - base <= row) lo = mid; else hi = mid;
+    }
+  v.tile_rec[(size_t)c * v.tile_stride + tile] = lo;
+}
+
 // one lane per row of one column. Delta columns: out = the delta (0 for null) and null_out = 1 for null.
 __global__ __launch_bounds__(BLOCK) void kb_expand(BigColWork w, uint32_t kind, uint32_t r0, uint32_t r1, uint32_t n_rows, uint32_t* __restrict__ out,
-                                                   uint8_t* __restrict__ null_out) {
+                                                   uint8_t* __restrict__ null_out, const uint32_t* __restrict__ tile_rec) {
   uint32_t row = gtid();
   if (row >= n_rows) return;
   uint32_t base = w.rec_start[r0];
@@ -220,12 +245,14 @@ __global__ __launch_bounds__(BLOCK) void kb_expand(BigColWork w, uint32_t kind, 
   uint32_t val = kind == BK_DELTA ? 0 : NONE32;
   bool nul = true;
   if (row < avail) {
-    uint32_t lo = r0, hi = r1;  // last record whose first row is <= row
+    // last record whose first row is <= row: between the records of the row's stretch and of the next one
+    uint32_t lo = tile_rec[row / EXPAND_TILE], hi = tile_rec[row / EXPAND_TILE + 1] + 1;
+    if (hi > r1) hi = r1;
     while (hi - lo > 1) {
       uint32_t mid = (lo + hi) >> 1;
       if (w.rec_start[mid] - base <= row) lo = mid; else hi = mid;
     }
-    uint32_t t = w.rec_tok[lo], off = row - (w.rec_start[lo] - base);
+  uint32_t t = w.rec_tok[lo], off = row - (w.rec_start[lo] - base);
     if (kind == BK_BOOL) { val = (lo - r0) & 1; nul = false; }
     else {
       int64_t cnt = 0;
@@ -275,10 +302,15 @@ __global__ __launch_bounds__(BLOCK) void kb_delta_abs(const uint32_t* __restrict
 }
 
 void bigcol_expand(const BigColDesc& d, const BigColWork& w, const BigColInfo& h, BigColVals& v, uint32_t n_rows, uint32_t n_succ_cap, hipStream_t st) {
+  {
+    const uint32_t big = n_rows > n_succ_cap ? n_rows : n_succ_cap;
+    AM355_LAUNCH_INDEPENDENT(kb_tile_recs, dim3((big / EXPAND_TILE + 2 + BLOCK - 1) / BLOCK, BIG_NCOL), dim3(BLOCK), st, w, v, n_rows, n_succ_cap);
+  }
   for (int c = 0; c < BIG_NCOL; c++) {
     uint32_t n = c >= BC_SUCC_ACTOR ? n_succ_cap : n_rows;
     if (!n) continue;
-    AM355_LAUNCH_INDEPENDENT(kb_expand, grid_for(n), dim3(BLOCK), st, w, d.kind[c], h.r0[c], h.r1[c], n, v.v[c], c == BC_KEY_CTR ? v.key_ctr_null : (uint8_t*)nullptr);
+    AM355_LAUNCH_INDEPENDENT(kb_expand, grid_for(n), dim3(BLOCK), st, w, d.kind[c], h.r0[c], h.r1[c], n, v.v[c], c == BC_KEY_CTR ? v.key_ctr_null : (uint8_t*)nullptr,
+                             (const uint32_t*)(v.tile_rec + (size_t)c * v.tile_stride));
   }
   // value offsets, succ list offsets
   AM355_LAUNCH_INDEPENDENT(kb_shift4, grid_for(n_rows + 1), dim3(BLOCK), st, (const uint32_t*)v.v[BC_VAL_LEN], n_rows, v.val_off);
@@ -405,45 +437,135 @@ __device__ __forceinline__ uint32_t key_string_end(const uint8_t* __restrict__ p
   return i + nb + (uint32_t)v;
 }
 
-__global__ __launch_bounds__(BLOCK) void kk_init(const uint8_t* __restrict__ col, uint32_t L, KeyWork k) {
-  uint32_t i = gtid();
-  if (i > L + 1) return;
-  k.mark_h[i] = (i == 0 && L > 0) ? 1u : 0u;
-  k.mark_v[i] = 0;
-  k.rows[i] = 0;
-  if (i >= L) { k.vnext[i] = NONE32; k.hnext[i] = NONE32; k.kk[i] = 0; k.ja[i] = NONE32; return; }
-  uint32_t vn = key_string_end(col, i, L, nullptr, nullptr);
-  k.vnext[i] = vn;
-  k.ja[i] = vn;
-  int64_t cnt;
-  uint32_t hb;
-  uint32_t hn = NONE32, kc = 0;
-  if (key_sleb(col, i, L, cnt, hb)) {
-    uint32_t q = i + hb;
-    if (cnt > 1) hn = key_string_end(col, q, L, nullptr, nullptr);
-    else if (cnt == 0) {
-      uint64_t n;
-      uint32_t nb;
-      if (key_uleb(col, q, L, n, nb) && n > 0) hn = q + nb;
-    } else if (cnt < 0 && (uint64_t)(-cnt) <= (uint64_t)L && q < L) {
-      hn = q;  // advanced k times by the doubling rounds
-      kc = (uint32_t)(-cnt);
+// ---- 1. vnext / hnext of every position, k-th successors included, tile by tile in LDS ------------------------------------------
+// One workgroup takes KEY_TILE consecutive positions. vnext chains only move forward, so inside the tile they are followed by pointer
+// doubling over 16-bit LOCAL indexes: after round r, P[i] = the 2^r-th successor of i, or EXIT once the chain has left the tile, in
+// which case H[i] = the number of hops that took and E[i] = the position (anywhere behind the tile) it left to. A literal header at i
+// with k strings walks the same tables -- it applies round r when bit r of k is set; jumps along one chain commute -- and either
+// stays inside the tile (hnext = where it stands after the last round) or leaves it, which happens exactly when k >= H[first
+// string]: then hnext / rem hold the CONTINUATION (E[first string], k - H[first string]) that kk_kth_cont finishes from the
+// per-position (hops to the tile's end, exit position) pairs every tile leaves in global memory.
+// (Before: twelve rounds over ALL positions in global memory, three 4-byte arrays read and two written per round and position --
+// 3.7 ms of the 34 MB key column of the config-5 document, plus a host decision in the middle for literals beyond 4096 strings.)
+constexpr uint32_t KEY_TILE = 4096;
+constexpr uint32_t KEY_TILE_THREADS = 1024;
+constexpr uint32_t KEY_PER = KEY_TILE / KEY_TILE_THREADS;
+constexpr uint32_t KEY_EXIT = 0xffffu;
+
+__global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __restrict__ col, uint32_t L, KeyWork k, uint32_t tile) {
+  __shared__ uint16_t P[2][KEY_TILE], H[2][KEY_TILE];
+  __shared__ uint32_t E[2][KEY_TILE];
+  const uint32_t base = blockIdx.x * tile, t = threadIdx.x;
+  const uint32_t end = base + tile;   // (positions >= L + 2 do not exist; L and L + 1 are the two end markers)
+  uint32_t kc_[KEY_PER], cur_[KEY_PER], hn_[KEY_PER], s0_[KEY_PER];
+  // ---- parse every position in both roles ----
+#pragma unroll
+  for (uint32_t j = 0; j < KEY_PER; j++) {
+    const uint32_t l = t + j * KEY_TILE_THREADS, i = base + l;
+    kc_[j] = 0; cur_[j] = KEY_EXIT; hn_[j] = NONE32; s0_[j] = NONE32;
+    if (l >= tile) continue;
+    uint32_t vn = NONE32;
+    if (i < L) {
+      vn = key_string_end(col, i, L, nullptr, nullptr);
+      int64_t cnt;
+      uint32_t hb;
+      if (key_sleb(col, i, L, cnt, hb)) {
+        const uint32_t q = i + hb;
+        if (cnt > 1) hn_[j] = key_string_end(col, q, L, nullptr, nullptr);
+        else if (cnt == 0) {
+          uint64_t n;
+          uint32_t nb;
+          if (key_uleb(col, q, L, n, nb) && n > 0) hn_[j] = q + nb;
+        } else if (cnt < 0 && (uint64_t)(-cnt) <= (uint64_t)L && q < L) {
+          kc_[j] = (uint32_t)(-cnt);
+          s0_[j] = q;   // the first string: advanced kc times below
+        }
+      }
     }
+    if (i <= L + 1) {
+      k.vnext[i] = vn;
+      k.mark_h[i] = (i == 0 && L > 0) ? 1u : 0u;
+      k.mark_v[i] = 0;
+      k.rows[i] = 0;
+      k.kk[i] = kc_[j];
+    }
+    // local successor: inside the tile, or EXIT to vn (NONE32: a dead end -- malformed, or beyond the column)
+    const bool inside = vn != NONE32 && vn < end && vn < L;
+    P[0][l] = inside ? (uint16_t)(vn - base) : (uint16_t)KEY_EXIT;
+    H[0][l] = 1;
+    E[0][l] = vn;
   }
-  k.hnext[i] = hn;
-  k.kk[i] = kc;
+  __syncthreads();
+  // a literal whose first string lies behind the tile, or which holds more strings than the tile positions, leaves the tile anyway
+#pragma unroll
+  for (uint32_t j = 0; j < KEY_PER; j++)
+    if (kc_[j] && s0_[j] < end && kc_[j] < tile) cur_[j] = s0_[j] - base;
+  int pp = 0;
+  for (uint32_t r = 0; (1u << r) < tile * 2 && r < 13; r++) {
+    // the header walks first (they read table r), then the table doubles
+#pragma unroll
+    for (uint32_t j = 0; j < KEY_PER; j++)
+      if (cur_[j] != KEY_EXIT && (kc_[j] >> r & 1u)) cur_[j] = P[pp][cur_[j]];
+#pragma unroll
+    for (uint32_t j = 0; j < KEY_PER; j++) {
+      const uint32_t l = t + j * KEY_TILE_THREADS;
+      if (l >= tile) continue;
+      uint16_t p = P[pp][l], h = H[pp][l];
+      uint32_t e = E[pp][l];
+      if (p != KEY_EXIT) {
+        const uint16_t p2 = P[pp][p];
+        h = (uint16_t)(h + H[pp][p]);
+        if (p2 == KEY_EXIT) e = E[pp][p];
+        p = p2;
+      }
+      P[pp ^ 1][l] = p; H[pp ^ 1][l] = h; E[pp ^ 1][l] = e;
+    }
+    __syncthreads();
+    pp ^= 1;
+  }
+  // ---- results: (hops to the tile's end, exit position) of every position; hnext, or the continuation of a literal that left ----
+#pragma unroll
+  for (uint32_t j = 0; j < KEY_PER; j++) {
+    const uint32_t l = t + j * KEY_TILE_THREADS, i = base + l;
+    if (l >= tile || i > L + 1) continue;
+    k.item_ex[i] = H[pp][l];   // (free until the item flags are built)
+    k.ja[i] = E[pp][l];        // (kk_item_init writes its own jumps there afterwards)
+    uint32_t hn = hn_[j], rem = 0;
+    if (kc_[j]) {
+      if (cur_[j] != KEY_EXIT) hn = base + cur_[j];   // all kc hops inside the tile
+      else if (s0_[j] >= end) { hn = s0_[j]; rem = kc_[j]; }   // the first string lies behind the tile: everything is left to do
+      else {
+        const uint32_t sl = s0_[j] - base, hops = H[pp][sl];
+        // kc >= hops (else the walk had stayed inside): leave the tile with the rest
+        hn = E[pp][sl];
+        rem = kc_[j] >= hops ? kc_[j] - hops : 0u;
+      }
+    }
+    k.hnext[i] = hn;
+    k.jb[i] = rem;
+  }
 }
 
-// round r of the k-th-successor computation; jump tables double each round
-__global__ __launch_bounds__(BLOCK) void kk_kth_round(uint32_t L, int r, KeyWork k, const uint32_t* __restrict__ jin, uint32_t* __restrict__ jout) {
-  uint32_t i = gtid();
+// literals that left their tile: tile by tile along (hops to the end, exit position), then the last hops one by one
+__global__ __launch_bounds__(BLOCK) void kk_kth_cont(uint32_t L, KeyWork k) {
+  const uint32_t i = gtid();
   if (i > L) return;
-  if ((k.kk[i] >> r) & 1) {
-    uint32_t x = k.hnext[i];
-    k.hnext[i] = x == NONE32 ? NONE32 : jin[x];
+  uint32_t rem = k.jb[i];
+  if (!rem) return;
+  uint32_t pos = k.hnext[i];
+  while (rem) {
+    if (pos == NONE32 || pos >= L) { pos = NONE32; break; }   // (L is the regular end of the parse; nothing follows it)
+    const uint32_t hops = k.item_ex[pos];
+    if (rem >= hops) { rem -= hops; pos = k.ja[pos]; }
+    else {
+      for (; rem; rem--) {
+        pos = k.vnext[pos];
+        if (pos == NONE32) break;
+      }
+      break;
+    }
   }
-  uint32_t j = jin[i];
-  jout[i] = j == NONE32 ? NONE32 : jin[j];
+  k.hnext[i] = pos;
 }
 
 // literal items: start marks on the first string of every true literal; jumps follow vnext but stop at a true header
@@ -534,26 +656,6 @@ size_t keystr_work_bytes(uint32_t col_len) {
   return 13 * al256(4 * cap) + al256(scan_workspace_bytes((uint32_t)cap)) + al256(chain_work_bytes((uint32_t)cap)) + 256;
 }
 
-// literal headers whose string count needs doubling rounds beyond `r0` are not resolved yet: the header walk stops at them
-__global__ __launch_bounds__(BLOCK) void kk_effective(uint32_t L, int r0, KeyWork k, uint32_t* __restrict__ heff) {
-  uint32_t i = gtid();
-  if (i > L + 1) return;
-  heff[i] = i < L && (k.kk[i] >> r0) == 0 ? k.hnext[i] : NONE32;
-}
-__global__ __launch_bounds__(BLOCK) void kk_check_unresolved(uint32_t L, int r0, KeyWork k, uint32_t* __restrict__ unresolved) {
-  uint32_t i = gtid();
-  if (i < L && k.mark_h[i] && (k.kk[i] >> r0) != 0) *unresolved = 1;
-}
-__global__ __launch_bounds__(BLOCK) void kk_reset_marks(uint32_t L, uint32_t* __restrict__ mark) {
-  uint32_t i = gtid();
-  if (i <= L + 1) mark[i] = (i == 0 && L > 0) ? 1u : 0u;
-}
-
-// Literals of a few thousand strings are the rule, so the k-th-successor doubling first runs KEY_ROUNDS_FIRST rounds only
-// (enough for k < 2^12) and the true headers are walked with longer literals treated as dead ends. Only if the walk actually
-// reaches such a header (one device word, read by the host) do the remaining rounds run and the walk repeat.
-constexpr int KEY_ROUNDS_FIRST = 12;
-
 void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, KeyStage& s, uint32_t* n_runs, uint32_t* d_unresolved,
                         hipStream_t st) {
   uint32_t L = col_len, cap = L + 2;
@@ -571,39 +673,18 @@ void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len
   s.arena = arena;
   s.col_abs = col_abs;
   s.L = L;
-  s.rounds = 1;
-  while (s.rounds < 32 && (L >> s.rounds)) s.rounds++;
-  int first = KEY_ROUNDS_FIRST;
-  if (const char* e = getenv("AM355_KEY_ROUNDS")) first = atoi(e) > 0 ? atoi(e) : first;  // (tests lower it to reach the second stage)
-  s.done = s.rounds < first ? s.rounds : first;
-  AM355_LAUNCH_INDEPENDENT(kk_init, grid_for(cap), dim3(BLOCK), st, s.col, L, k);
-  s.j0 = k.ja;
-  s.j1 = k.jb;
-  for (int r = 0; r < s.done; r++) {  // 1. k-th successors, first rounds
-    AM355_LAUNCH_INDEPENDENT(kk_kth_round, grid_for(L + 1), dim3(BLOCK), st, L, r, k, (const uint32_t*)s.j0, s.j1);
-    uint32_t* t = s.j0; s.j0 = s.j1; s.j1 = t;
-  }
-  if (s.done < s.rounds) {
-    uint32_t* heff = k.item_ex;  // (free until the item flags are built)
-    AM355_LAUNCH_INDEPENDENT(kk_effective, grid_for(cap), dim3(BLOCK), st, L, s.done, k, heff);
-    chain_mark(heff, L, k.mark_h, s.chain_ws, st);  // 2. true headers (as far as they are resolved)
-    AM355_LAUNCH_INDEPENDENT(kk_check_unresolved, grid_for(L), dim3(BLOCK), st, L, s.done, k, d_unresolved);
-  } else {
-    chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);
-  }
+  (void)d_unresolved;
+  uint32_t tile = KEY_TILE;
+  if (const char* e = getenv("AM355_KEY_TILE")) { int v = atoi(e); if (v >= 16 && (uint32_t)v <= KEY_TILE) tile = (uint32_t)v; }  // (tests: small tiles, so that small documents cross them)
+  hipLaunchKernelGGL(kk_tile, dim3((cap + tile - 1) / tile), dim3(KEY_TILE_THREADS), 0, st, s.col, L, k, tile);
+  AM355_LAUNCH_INDEPENDENT(kk_kth_cont, grid_for(L + 1), dim3(BLOCK), st, L, k);
+  chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);   // 2. true headers
 }
 
 void keystr_index_finish(KeyStage& s, bool unresolved, uint32_t** run_start, uint32_t** run_off, uint32_t** run_len, uint32_t* flags, hipStream_t st) {
   KeyWork& k = s.k;
   uint32_t L = s.L, cap = L + 2;
-  if (unresolved) {
-    for (int r = s.done; r < s.rounds; r++) {  // the remaining rounds, then the walk again
-      AM355_LAUNCH_INDEPENDENT(kk_kth_round, grid_for(L + 1), dim3(BLOCK), st, L, r, k, (const uint32_t*)s.j0, s.j1);
-      uint32_t* t = s.j0; s.j0 = s.j1; s.j1 = t;
-    }
-    AM355_LAUNCH_INDEPENDENT(kk_reset_marks, grid_for(cap), dim3(BLOCK), st, L, k.mark_h);
-    chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);
-  }
+  (void)unresolved;
   *run_start = k.run_start; *run_off = k.run_off; *run_len = k.run_len;
   AM355_LAUNCH_INDEPENDENT(kk_item_init, grid_for(cap), dim3(BLOCK), st, s.col, L, k, flags);
   chain_mark(k.ja, L, k.mark_v, s.chain_ws, st);     // 3. literal items

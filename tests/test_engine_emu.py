@@ -529,10 +529,11 @@ def test_mutated_change_headers_never_disagree_with_the_oracle(eng):
     assert equal > 10 and refused > 20, (equal, refused)
 
 
-@pytest.mark.parametrize("first_rounds", ["1", "3"])
-def test_key_column_second_stage(eng, first_rounds, monkeypatch):
-    """The key-string index resolves literals longer than its first doubling rounds cover in a second stage: force it."""
-    monkeypatch.setenv("AM355_KEY_ROUNDS", first_rounds)
+@pytest.mark.parametrize("tile", ["16", "64", "1024"])
+def test_key_column_literals_across_tiles(eng, tile, monkeypatch):
+    """The key-string index follows the strings of a literal inside LDS tiles and finishes the literals that leave their tile from the
+    tiles' (hops, exit) pairs: with tiles of a few bytes every literal of these documents crosses tiles, many of them several."""
+    monkeypatch.setenv("AM355_KEY_TILE", tile)
     for name in ("synthetic_doc_medium", "frontend_mixed_6actors", "campaign_mixed_1008"):
         fx = golden_util.load_fixture(name)
         eng.load_document(fx["doc_bytes"])
