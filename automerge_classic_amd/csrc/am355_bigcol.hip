@@ -447,61 +447,69 @@ __device__ __forceinline__ uint32_t key_string_end(const uint8_t* __restrict__ p
 // per-position (hops to the tile's end, exit position) pairs every tile leaves in global memory.
 // (Before: twelve rounds over ALL positions in global memory, three 4-byte arrays read and two written per round and position --
 // 3.7 ms of the 34 MB key column of the config-5 document, plus a host decision in the middle for literals beyond 4096 strings.)
-constexpr uint32_t KEY_TILE = 4096;
+// A workgroup OWNS `tile` positions and follows chains through a WINDOW of `win` = tile + halo positions: the strings of the garbage
+// "literals" that most byte positions are when read as headers (a letter is a count of a few dozen) span a few hundred bytes, so with
+// a halo of a thousand positions only real, long literals leave the window and need the walker -- with the window equal to the tile
+// every twentieth position did, and the walker (dependent loads, a lane at a time) took 2.2 ms of the config-5 key column.
+constexpr uint32_t KEY_WIN = 4096;            // table entries (LDS: 16 bytes each)
+constexpr uint32_t KEY_TILE = 3072;           // positions a workgroup owns by default; the rest of the window is halo
 constexpr uint32_t KEY_TILE_THREADS = 1024;
-constexpr uint32_t KEY_PER = KEY_TILE / KEY_TILE_THREADS;
+constexpr uint32_t KEY_PER = KEY_WIN / KEY_TILE_THREADS;
 constexpr uint32_t KEY_EXIT = 0xffffu;
 
-__global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __restrict__ col, uint32_t L, KeyWork k, uint32_t tile) {
-  __shared__ uint16_t P[2][KEY_TILE], H[2][KEY_TILE];
-  __shared__ uint32_t E[2][KEY_TILE];
+__global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __restrict__ col, uint32_t L, KeyWork k, uint32_t tile, uint32_t win,
+                                                            uint32_t* __restrict__ pend, uint32_t* __restrict__ n_pend) {
+  __shared__ uint16_t P[2][KEY_WIN], H[2][KEY_WIN];
+  __shared__ uint32_t E[2][KEY_WIN];
   const uint32_t base = blockIdx.x * tile, t = threadIdx.x;
-  const uint32_t end = base + tile;   // (positions >= L + 2 do not exist; L and L + 1 are the two end markers)
+  const uint32_t end = base + win;   // (positions >= L + 2 do not exist; L and L + 1 are the two end markers)
   uint32_t kc_[KEY_PER], cur_[KEY_PER], hn_[KEY_PER], s0_[KEY_PER];
-  // ---- parse every position in both roles ----
+  // ---- parse: every position of the window as a string, the owned ones as a header too ----
 #pragma unroll
   for (uint32_t j = 0; j < KEY_PER; j++) {
     const uint32_t l = t + j * KEY_TILE_THREADS, i = base + l;
     kc_[j] = 0; cur_[j] = KEY_EXIT; hn_[j] = NONE32; s0_[j] = NONE32;
-    if (l >= tile) continue;
+    if (l >= win) continue;
     uint32_t vn = NONE32;
-    if (i < L) {
-      vn = key_string_end(col, i, L, nullptr, nullptr);
-      int64_t cnt;
-      uint32_t hb;
-      if (key_sleb(col, i, L, cnt, hb)) {
-        const uint32_t q = i + hb;
-        if (cnt > 1) hn_[j] = key_string_end(col, q, L, nullptr, nullptr);
-        else if (cnt == 0) {
-          uint64_t n;
-          uint32_t nb;
-          if (key_uleb(col, q, L, n, nb) && n > 0) hn_[j] = q + nb;
-        } else if (cnt < 0 && (uint64_t)(-cnt) <= (uint64_t)L && q < L) {
-          kc_[j] = (uint32_t)(-cnt);
-          s0_[j] = q;   // the first string: advanced kc times below
+    if (i < L) vn = key_string_end(col, i, L, nullptr, nullptr);
+    if (l < tile) {
+      if (i < L) {
+        int64_t cnt;
+        uint32_t hb;
+        if (key_sleb(col, i, L, cnt, hb)) {
+          const uint32_t q = i + hb;
+          if (cnt > 1) hn_[j] = key_string_end(col, q, L, nullptr, nullptr);
+          else if (cnt == 0) {
+            uint64_t n;
+            uint32_t nb;
+            if (key_uleb(col, q, L, n, nb) && n > 0) hn_[j] = q + nb;
+          } else if (cnt < 0 && (uint64_t)(-cnt) <= (uint64_t)L && q < L) {
+            kc_[j] = (uint32_t)(-cnt);
+            s0_[j] = q;   // the first string: advanced kc times below
+          }
         }
       }
+      if (i <= L + 1) {
+        k.vnext[i] = vn;
+        k.mark_h[i] = (i == 0 && L > 0) ? 1u : 0u;
+        k.mark_v[i] = 0;
+        k.rows[i] = 0;
+        k.kk[i] = kc_[j];
+      }
     }
-    if (i <= L + 1) {
-      k.vnext[i] = vn;
-      k.mark_h[i] = (i == 0 && L > 0) ? 1u : 0u;
-      k.mark_v[i] = 0;
-      k.rows[i] = 0;
-      k.kk[i] = kc_[j];
-    }
-    // local successor: inside the tile, or EXIT to vn (NONE32: a dead end -- malformed, or beyond the column)
+    // local successor: inside the window, or EXIT to vn (NONE32: a dead end -- malformed, or beyond the column)
     const bool inside = vn != NONE32 && vn < end && vn < L;
     P[0][l] = inside ? (uint16_t)(vn - base) : (uint16_t)KEY_EXIT;
     H[0][l] = 1;
     E[0][l] = vn;
   }
   __syncthreads();
-  // a literal whose first string lies behind the tile, or which holds more strings than the tile positions, leaves the tile anyway
+  // a literal whose first string lies behind the window, or which holds more strings than the window positions, leaves it anyway
 #pragma unroll
   for (uint32_t j = 0; j < KEY_PER; j++)
-    if (kc_[j] && s0_[j] < end && kc_[j] < tile) cur_[j] = s0_[j] - base;
+    if (kc_[j] && s0_[j] < end && kc_[j] < win) cur_[j] = s0_[j] - base;
   int pp = 0;
-  for (uint32_t r = 0; (1u << r) < tile * 2 && r < 13; r++) {
+  for (uint32_t r = 0; (1u << r) < win * 2 && r < 13; r++) {
     // the header walks first (they read table r), then the table doubles
 #pragma unroll
     for (uint32_t j = 0; j < KEY_PER; j++)
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __res
 #pragma unroll
     for (uint32_t j = 0; j < KEY_PER; j++) {
       const uint32_t l = t + j * KEY_TILE_THREADS;
-      if (l >= tile) continue;
+      if (l >= win) continue;
       uint16_t p = P[pp][l], h = H[pp][l];
       uint32_t e = E[pp][l];
       if (p != KEY_EXIT) {
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __res
     __syncthreads();
     pp ^= 1;
   }
-  // ---- results: (hops to the tile's end, exit position) of every position; hnext, or the continuation of a literal that left ----
+  // ---- results for the owned positions: (hops to the window's end, exit position); hnext, or the continuation of a literal that left ----
 #pragma unroll
   for (uint32_t j = 0; j < KEY_PER; j++) {
     const uint32_t l = t + j * KEY_TILE_THREADS, i = base + l;
@@ -532,40 +540,41 @@ __global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __res
     k.ja[i] = E[pp][l];        // (kk_item_init writes its own jumps there afterwards)
     uint32_t hn = hn_[j], rem = 0;
     if (kc_[j]) {
-      if (cur_[j] != KEY_EXIT) hn = base + cur_[j];   // all kc hops inside the tile
-      else if (s0_[j] >= end) { hn = s0_[j]; rem = kc_[j]; }   // the first string lies behind the tile: everything is left to do
+      if (cur_[j] != KEY_EXIT) hn = base + cur_[j];   // all kc hops inside the window
+      else if (s0_[j] >= end) { hn = s0_[j]; rem = kc_[j]; }   // the first string lies behind the window: everything is left to do
       else {
         const uint32_t sl = s0_[j] - base, hops = H[pp][sl];
-        // kc >= hops (else the walk had stayed inside): leave the tile with the rest
+        // kc >= hops (else the walk had stayed inside): leave the window with the rest
         hn = E[pp][sl];
         rem = kc_[j] >= hops ? kc_[j] - hops : 0u;
       }
     }
     k.hnext[i] = hn;
     k.jb[i] = rem;
+    if (rem) pend[atomicAdd(n_pend, 1u)] = i;
   }
 }
 
-// literals that left their tile: tile by tile along (hops to the end, exit position), then the last hops one by one
-__global__ __launch_bounds__(BLOCK) void kk_kth_cont(uint32_t L, KeyWork k) {
-  const uint32_t i = gtid();
-  if (i > L) return;
-  uint32_t rem = k.jb[i];
-  if (!rem) return;
-  uint32_t pos = k.hnext[i];
-  while (rem) {
-    if (pos == NONE32 || pos >= L) { pos = NONE32; break; }   // (L is the regular end of the parse; nothing follows it)
-    const uint32_t hops = k.item_ex[pos];
-    if (rem >= hops) { rem -= hops; pos = k.ja[pos]; }
-    else {
-      for (; rem; rem--) {
-        pos = k.vnext[pos];
-        if (pos == NONE32) break;
+// literals that left their window: window by window along (hops to the end, exit position), then the last hops one by one
+__global__ __launch_bounds__(BLOCK) void kk_kth_cont(uint32_t L, KeyWork k, const uint32_t* __restrict__ pend, const uint32_t* __restrict__ n_pend) {
+  const uint32_t total = *n_pend;
+  for (uint32_t w = gtid(); w < total; w += gridDim.x * BLOCK) {
+    const uint32_t i = pend[w];
+    uint32_t rem = k.jb[i], pos = k.hnext[i];
+    while (rem) {
+      if (pos == NONE32 || pos >= L) { pos = NONE32; break; }   // (L is the regular end of the parse; nothing follows it)
+      const uint32_t hops = k.item_ex[pos];
+      if (rem >= hops) { rem -= hops; pos = k.ja[pos]; }
+      else {
+        for (; rem; rem--) {
+          pos = k.vnext[pos];
+          if (pos == NONE32) break;
+        }
+        break;
       }
-      break;
     }
+    k.hnext[i] = pos;
   }
-  k.hnext[i] = pos;
 }
 
 // literal items: start marks on the first string of every true literal; jumps follow vnext but stop at a true header
@@ -673,11 +682,13 @@ void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len
   s.arena = arena;
   s.col_abs = col_abs;
   s.L = L;
-  (void)d_unresolved;
+  // (d_unresolved, a device word the caller cleared, counts the literals that leave their window; their positions go to run_start,
+  // which is free until the run table is built)
   uint32_t tile = KEY_TILE;
   if (const char* e = getenv("AM355_KEY_TILE")) { int v = atoi(e); if (v >= 16 && (uint32_t)v <= KEY_TILE) tile = (uint32_t)v; }  // (tests: small tiles, so that small documents cross them)
-  hipLaunchKernelGGL(kk_tile, dim3((cap + tile - 1) / tile), dim3(KEY_TILE_THREADS), 0, st, s.col, L, k, tile);
-  AM355_LAUNCH_INDEPENDENT(kk_kth_cont, grid_for(L + 1), dim3(BLOCK), st, L, k);
+  const uint32_t win = tile + tile / 3 <= KEY_WIN ? tile + tile / 3 : KEY_WIN;
+  hipLaunchKernelGGL(kk_tile, dim3((cap + tile - 1) / tile), dim3(KEY_TILE_THREADS), 0, st, s.col, L, k, tile, win, k.run_start, d_unresolved);
+  AM355_LAUNCH_INDEPENDENT(kk_kth_cont, dim3(512), dim3(BLOCK), st, L, k, (const uint32_t*)k.run_start, (const uint32_t*)d_unresolved);
   chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);   // 2. true headers
 }
 
