@@ -1602,7 +1602,7 @@ static int run_device(am355_ctx* c, const std::vector<uint32_t>* slot_rank) {
   merge_prepare(c->mb, c->stream3);
   HIPCHK(c, hipEventRecord(c->ev[2], st));  // brackets the decode launch only
   launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, (uint32_t)np - n_small - n_large, d_amap,
-                        d_rank, c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3);
+                        d_rank, c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3, c->shard_rank, c->shard_world);
   HIPCHK(c, hipEventRecord(c->ev[3], st));
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -1656,7 +1656,7 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[2], st));
   launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n,
                         tot.n_small, tot.n_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
-                        &c->d_counts.as<Counts>()->flags, st, c->stream3);
+                        &c->d_counts.as<Counts>()->flags, st, c->stream3, c->shard_rank, c->shard_world);
   lap("decode launched");
   if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
   if (tot.n_small && (tot.n_large || tot.n_serial)) {

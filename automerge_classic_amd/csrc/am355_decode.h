@@ -37,12 +37,15 @@ void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct
                  ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st);
 void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, const ChangePlan* plans_serial, uint32_t n_changes,
                            uint32_t n_small, uint32_t n_large, uint32_t n_serial, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags,
-                           hipStream_t st, hipStream_t aux);
+                           hipStream_t st, hipStream_t aux, uint32_t shard_rank = 0, uint32_t shard_world = 1);
 // slot_rank == nullptr: `amap` already holds global actor ranks. plans = [n_small | n_large wave-decodable | n_serial others]
 // (ChangeBrief.flags_fits bit 30: small wave class, bit 31: any wave class). `aux`: a stream the caller forked from `st` and joins
 // afterwards (the second decoder class runs there)
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_small, uint32_t n_large, uint32_t n_serial,
-                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux);
+                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux, uint32_t shard_rank = 0,
+                           uint32_t shard_world = 1);
+// (shard_world > 1, objectId sharding: the wave decoder stops behind the object columns for a change that holds no row of an object
+// this rank owns -- what k_resolve reads of foreign rows is decoded by then)
 // documents: count rows / succ entries into meta->n_ops / n_preds, then decode all op columns of the one pseudo-change
 void launch_doc_count(const uint8_t* arena, ChangeMeta* meta, hipStream_t st);
 void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const ChangePlan* plan, const uint32_t* actor_rank, OpCols cols,

@@ -1241,6 +1241,7 @@ enum Task { T_OBJ, T_KEY, T_KEYSTR, T_INSERT, T_ACTION, T_VALUE, T_PREDNUM, T_PR
 struct ActorXlate {
   const uint32_t* amap;
   const uint32_t* slot_rank;
+  uint32_t shard_rank = 0, shard_world = 1;   // objectId sharding (am355_set_shard): which objects' rows this rank merges
 };
 __device__ __forceinline__ uint32_t xlate_actor(const ActorXlate& x, const ChangePlan& pl, int64_t local, uint32_t& err) {
   if (local < 0 || (uint64_t)local >= pl.n_actors) { err |= F_BAD_ROW; return 0; }
@@ -1830,6 +1831,18 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     if (!nul && (uint64_t)v >= NONE32) err |= F_OVERFLOW;
     o.obj_ctr[base + i] = nul ? 0 : (uint32_t)v;
   }
+  // ---- objectId sharding: a change none of whose rows belongs to an object of this rank is decoded as far as the merge
+  //      stage looks at foreign rows -- action, id, insert flag, object (k_resolve marks them K_FOREIGN from those and goes on; make
+  //      rows still enter the object table) -- and no further: keys, values and pred lists of such a change are its owners' business,
+  //      as is finding fault with them (a rank that rejects the batch makes every rank raise) ----
+  if (x.shard_world > 1) {
+    bool mine = false;
+    for (uint32_t i = lane; i < n; i += WAVE) mine = mine || shard_owner(o.obj_actor[base + i], o.obj_ctr[base + i], x.shard_world) == x.shard_rank;
+    if (!__ballot(mine)) {
+      if (err) atomicOr(flags, err);
+      return;
+    }
+  }
   // ---- key: element id (actor, delta-coded counter) ----
   load_col(C_KEY_ACTOR);
   err |= L.err;
@@ -2039,18 +2052,19 @@ void launch_keystr_expand(const uint32_t* run_start, const uint32_t* run_off, co
 // columns run to megabytes, far beyond the wave decoder's LDS staging; a parallel big-column decoder is the next step).
 void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const ChangePlan* plan, const uint32_t* actor_rank, OpCols cols,
                             uint32_t* flags, hipStream_t st) {
-  ActorXlate x{actor_rank, nullptr};
+  ActorXlate x{actor_rank, nullptr, 0, 1};
   AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3(1, T_NUM_DOC), dim3(WAVE), st, arena, meta, plan, 1u, x, cols, flags, 0);
 }
 
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_small, uint32_t n_large, uint32_t n_serial,
-                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux) {
+                           const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux, uint32_t shard_rank,
+                           uint32_t shard_world) {
   // plans = [small wave class | large wave class | lane-serial]: the first two go to the wave-per-change run-level decoder
   // (two LDS footprints, see WaveLdsT), the rest (a column too long for LDS staging) to the lane-serial decoder.
   // Every launch is bound by the latency of one change, not by throughput, so the classes run side by side: the large
   // class on the auxiliary stream, which the caller has forked from `st` and joins afterwards. With few changes the LDS
   // footprint does not limit residency: one launch.
-  ActorXlate x{amap, slot_rank};
+  ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   if (n_large && n_small + n_large <= 1024) { n_large += n_small; n_small = 0; }
   hipStream_t s2 = (n_small && aux) ? aux : st;
   if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags);
@@ -2063,8 +2077,8 @@ void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const 
 // the same three launches from the device-built plans (k_plan): small class at the front of `plans`, large class at its back
 void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, const ChangePlan* plans_serial, uint32_t n_changes,
                            uint32_t n_small, uint32_t n_large, uint32_t n_serial, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags,
-                           hipStream_t st, hipStream_t aux) {
-  ActorXlate x{amap, slot_rank};
+                           hipStream_t st, hipStream_t aux, uint32_t shard_rank, uint32_t shard_world) {
+  ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   hipStream_t s2 = (n_small && aux) ? aux : st;
   if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags);
   if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags);

@@ -99,4 +99,10 @@ struct OpCols {
   uint32_t *pred_actor, *pred_ctr;    // flattened pred lists
 };
 
+// Owner of an object's rows: _root on rank 0, every other object by its id (ordering and pred / succ resolution
+// never cross objects, new.js:1141-1145, 1173-1176; the one cross-object link, make row -> child object, is the object index).
+__host__ __device__ __forceinline__ uint32_t shard_owner(uint32_t obj_actor, uint32_t obj_ctr, uint32_t world) {
+  return obj_actor == NONE32 ? 0u : (obj_ctr + obj_actor) % world;
+}
+
 }  // namespace am355

@@ -1128,6 +1128,10 @@ __global__ __launch_bounds__(BLOCK) void k_doc_emit(MergeBufs b, uint32_t* __res
   bool vis = b.succ_cnt[g] == 0;
   bool valued = a == 1 || (a & 1) == 0;
   edit_flag[g] = 0;
+  // objectId sharding of a document (am355_set_shard before am355_load_document): every rank decodes and checks all
+  // rows -- a document's columns are run-length streams that cannot be entered in the middle -- but emits the records of the objects
+  // it owns only; the object table (make rows) is the same on every rank, so the fragments stitch by object index
+  if (b.shard_world > 1 && shard_owner(o.obj_actor[g], o.obj_ctr[g], b.shard_world) != b.shard_rank) return;
   if (kind == K_MAP) {
     if (vis && valued) { trig_flag[g] = 1; trig_src[g] = g; }
     else if (a == 1 && (o.val_tl[g] & 15) == 8 && b.succ_cnt[g] != 0 && b.inc_cnt[g] == b.succ_cnt[g]) {

@@ -1,7 +1,8 @@
 """objectId sharding of ONE document over the GPUs of a node (include/am355.h "objectId sharding").
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests). Every rank
-stages and decodes the whole batch of changes (rows keep their global indexes), merges only the objects it owns
+stages the whole batch of changes (rows keep their global indexes; a change none of whose rows it owns is decoded only as far as the
+object columns) or the whole saved document (its columns are run-length streams: decoded everywhere), merges only the objects it owns
 (am355_set_shard) and writes its part of the patch IR -- the map records / edit records / values of its objects -- as one
 contiguous fragment. The fragments are the only data exchanged: an all_gather of uint8 tensors (device tensors with RCCL: the
 fragment goes from HBM to HBM over xGMI), then every rank (or rank 0 only) stitches them by object index
@@ -70,16 +71,17 @@ class ShardedReplay:
         return True
 
 
-def bench_sharded(eng, log, dist, device, steps, warmup, barrier):
-    """K timed sharded replays of `log` (host buffers in -> stitched patch IR on rank 0's host). Returns seconds (this rank)."""
+def bench_sharded(eng, stage, dist, device, steps, warmup, barrier):
+    """K timed sharded replays of what `stage()` stages on this rank's engine -- am355_load_changes of a change log, or
+    am355_load_document of a saved document -- (host buffers in -> stitched patch IR on rank 0's host). Returns seconds (this rank)."""
     import time
     sr = ShardedReplay(eng, dist, device)
     for _ in range(warmup):
-        sr.step(lambda: eng.load_changes(log))
+        sr.step(stage)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        sr.step(lambda: eng.load_changes(log))
+        sr.step(stage)
     barrier()
     dt = time.perf_counter() - t0
     info = dict(sr.last)

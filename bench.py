@@ -332,34 +332,45 @@ def apply_changes_section(eng, log, sync, reps=7):
             "batches": rows, "sync_bloom_filter": {"hashes": n, "filter_bytes": int(bits.size), "ms": bloom_ms}}
 
 
-def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier, scale=1.0, sync=None):
-    """ONE document (c4_text_multi: 64 Text objects) sharded by objectId over the ranks: T_replay-style region (host buffers on
-    every rank -> stitched patch IR on rank 0's host), max over ranks; beside it the same log unsharded on rank 0 alone."""
+def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier, scale=1.0, sync=None, name="c4_text_multi"):
+    """ONE document sharded by objectId over the ranks: T_replay-style region (host buffers on every rank -> stitched
+    patch IR on rank 0's host), max over ranks; beside it the same input unsharded on rank 0 alone.
+    c4_text_multi: a change log of 64 Text objects -- every rank stages the batch, decodes the changes that touch its objects in
+    full and the others as far as the object columns, merges its objects. c5_doc_mixed: Backend.load of a saved document -- a
+    document's columns are run-length streams, every rank decodes and checks all rows and emits the records of its objects."""
     import hashlib
     import torch
-    from automerge_classic_amd import shard
-    name = "c4_text_multi"
-    log = make_log(name, scale, BASE_SEED[name])  # (the same log on every rank)
+    from automerge_classic_amd import loggen, shard
+    is_doc = WORKLOADS[name][0] == "doc"
+    if is_doc:
+        doc_bytes, n_ops = loggen.document_config(scale)
+        stage = lambda: eng.load_document(doc_bytes)
+        what = f"{name} x{scale}: Backend.load of a {len(doc_bytes)}-byte saved document, {n_ops} op rows"
+    else:
+        log = make_log(name, scale, BASE_SEED[name])  # (the same log on every rank)
+        stage = lambda: eng.load_changes(log)
+        n_ops = int(log.n_ops)
+        what = f"{name} x{scale}: {n_ops} ops, {log.n_changes} changes, 64 Text objects"
     if sync is None:
         sync = torch.cuda.synchronize
     # parity first, outside the timed region: stitched patch == unsharded patch
     eng.set_shard(0, 1)
-    eng.load_changes(log)
+    stage()
     eng.replay()
     want = hashlib.sha256(eng.patch_json().encode()).hexdigest() if rank == 0 else None
     sr = shard.ShardedReplay(eng, dist, device)
-    have = sr.step(lambda: eng.load_changes(log))
+    have = sr.step(stage)
     same = (hashlib.sha256(eng.patch_json().encode()).hexdigest() == want) if have else True
     eng.set_shard(0, 1)
-    dt, info = shard.bench_sharded(eng, log, dist, device, steps, warmup, barrier)
+    dt, info = shard.bench_sharded(eng, stage, dist, device, steps, warmup, barrier)
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t[0])
-    # the same log on one GPU (rank 0; the other ranks wait at the barrier)
+    # the same input on one GPU (rank 0; the other ranks wait at the barrier)
     t_single = 0.0
     if rank == 0:
         def one():
-            eng.load_changes(log)
+            stage()
             eng.replay()
             eng.fetch_ir()
         for _ in range(warmup):
@@ -368,10 +379,8 @@ def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier, 
     barrier()
     if rank != 0:
         return None
-    n_ops = int(log.n_ops)
-    return {"workload": f"{name} x{scale}: {n_ops} ops, {log.n_changes} changes, 64 Text objects, ONE document over {world} GPUs (objectId sharding: owner = "
-                        "(object counter + actor rank) mod N, _root on rank 0; every rank decodes the batch, merges its objects, all_gather of the "
-                        "patch-IR fragments over RCCL, stitch on rank 0)",
+    return {"workload": what + f", ONE document over {world} GPUs (objectId sharding: owner = (object counter + actor rank) mod N, _root on rank 0; "
+                        "all_gather of the patch-IR fragments over RCCL, stitch on rank 0)",
             "scaling": "strong", "n_gpus": world, "steps": steps, "ops_per_s": n_ops * steps / dt, "ms_per_step": dt / steps * 1e3,
             "single_gpu_ops_per_s": n_ops * steps / t_single, "single_gpu_ms_per_step": t_single / steps * 1e3,
             "speedup_vs_single_gpu": t_single / dt, "fragment_bytes": info.get("fragment_bytes"),
@@ -433,9 +442,11 @@ def main():
     t_dev = timed(eng.replay, args.steps, barrier)
     t_dev, _ = dist_util.aggregate(t_dev, 0.0, dist, torch.device("cuda", local_rank))
     phases = measure_phases(w, args.steps, lambda: torch.cuda.synchronize())  # (its own context, HIP events between the phases: not timed)
-    sharded = None
+    sharded = sharded_c5 = None
     if world > 1 and not args.no_shard:
         sharded = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), max(5, min(args.steps // 2, 30)), 3, barrier)
+        # BASELINE config 5 (the other 8-GPU configuration): one saved document over the N ranks
+        sharded_c5 = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), 3, 1, barrier, name="c5_doc_mixed")
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -478,6 +489,8 @@ def main():
     }
     if sharded is not None:
         out["sharded"] = sharded
+    if sharded_c5 is not None:
+        out["sharded_c5"] = sharded_c5
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
         if w.is_doc:
             out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops))

@@ -647,3 +647,45 @@ def test_call_sequence_and_argument_errors():
         assert emu_patch(e, fx["log"]) == fx["expected"]
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_objectid_shards_of_changes_and_documents_stitch_to_the_unsharded_patch(world):
+    """objectId sharding under the emulation, `world` contexts on one machine: every rank merges (change logs) or emits
+    (saved documents) the objects it owns, the fragments stitch by object index to the unsharded patch. For change logs a change none
+    of whose rows this rank owns is decoded only as far as k_resolve looks at foreign rows (am355_decode.hip)."""
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    single = engine.Engine(0, EMU_LIB)
+    ranks = [engine.Engine(0, EMU_LIB) for _ in range(world)]
+    try:
+        logs = [loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=3, ins_per_change=25, del_per_change=6, n_objects=7, seed=41),
+                golden_util.load_fixture("campaign_mixed_1004")["log"], golden_util.load_fixture("frontend_mixed_6actors")["log"]]
+        docs = [golden_util.load_fixture(n)["doc_bytes"] for n in ("campaign_mixed_1008", "frontend_mixed_6actors", "synthetic_doc_medium")]
+        docs.append(loggen.generate_document(n_actors=5, n_texts=6, text_len=200, n_maps=4, keys_per_map=60, n_submaps=3, n_lists=4, list_len=80, deflate=True, seed=0xD0C9)[0])
+
+        def stitched(stage):
+            frags, offsets = [], [0]
+            for r, e in enumerate(ranks):
+                e.set_shard(r, world)
+                stage(e)
+                e.replay()
+                buf = np.zeros(e.fragment_size(), dtype=np.uint8)
+                assert e.export_fragment(buf.ctypes.data, buf.size, False) == buf.size
+                frags.append(buf)
+                offsets.append(offsets[-1] + buf.size)
+            ranks[0].import_fragments(np.concatenate(frags), np.array(offsets, dtype=np.uint64))
+            return ranks[0].patch_json(), [f.size for f in frags]
+
+        for log in logs:
+            single.load_changes(log); single.replay()
+            got, _ = stitched(lambda e: e.load_changes(log))
+            assert got == single.patch_json() == oracle_lib.OracleDoc(log).patch_json()
+        for doc in docs:
+            single.load_document(doc); single.replay()
+            got, sizes = stitched(lambda e: e.load_document(doc))
+            assert got == single.patch_json() == oracle_lib.OracleDoc.load_document(doc).patch_json()
+        assert max(sizes) < 0.9 * sum(sizes)   # (the generated document: no rank holds nearly all records)
+    finally:
+        single.close()
+        for e in ranks:
+            e.close()

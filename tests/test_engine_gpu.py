@@ -435,6 +435,25 @@ def test_objectid_shards_stitch_to_the_unsharded_patch(eng, world):
                 # every rank holds a real share of the work: no fragment carries (nearly) all edit records
                 sizes = [f.size for f in frags]
                 assert max(sizes) < 0.6 * sum(sizes)
+        # saved documents (Backend.load; BASELINE config 5 is the other 8-GPU configuration): every rank decodes and checks all rows
+        # and emits the records of the objects it owns
+        docs = [golden_util.load_fixture("campaign_mixed_1008")["doc_bytes"], loggen.document_config(0.05)[0]]
+        for doc in docs:
+            eng.load_document(doc)
+            eng.replay()
+            want = eng.patch_json()
+            frags, offsets = [], [0]
+            for r, e in enumerate(ranks):
+                e.set_shard(r, world)
+                e.load_document(doc)
+                e.replay()
+                buf = np.zeros(e.fragment_size(), dtype=np.uint8)
+                assert e.export_fragment(buf.ctypes.data, buf.size, False) == buf.size
+                frags.append(buf)
+                offsets.append(offsets[-1] + buf.size)
+            ranks[0].import_fragments(np.concatenate(frags), np.array(offsets, dtype=np.uint64))
+            assert hashlib.sha256(ranks[0].patch_json().encode()).hexdigest() == hashlib.sha256(want.encode()).hexdigest()
+            assert want == oracle_lib.OracleDoc.load_document(doc).patch_json()
     finally:
         for e in ranks:
             e.close()

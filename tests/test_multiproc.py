@@ -77,6 +77,15 @@ for log in cases:
     assert want == oracle_lib.OracleDoc(log).patch_json()
     if rank == 0:
         sys.stdout.write("case ok %d ops, fragments %s\\n" % (single.stats().n_ops, sr.last["fragment_bytes"]))
+# saved documents (Backend.load, BASELINE config 5 shape): every rank decodes the rows, emits the records of its objects
+docs = [golden_util.load_fixture(n)["doc_bytes"] for n in ("campaign_mixed_1008", "synthetic_doc_medium")]
+docs.append(loggen.generate_document(n_actors=5, n_texts=6, text_len=200, n_maps=4, keys_per_map=60, n_submaps=3, n_lists=4, list_len=80, deflate=True, seed=0xD0C9)[0])
+for doc in docs:
+    single.load_document(doc); single.replay(); want = single.patch_json()
+    assert sr.step(lambda: eng.load_document(doc))
+    assert eng.patch_json() == want == oracle_lib.OracleDoc.load_document(doc).patch_json(), rank
+    if rank == 0:
+        sys.stdout.write("doc ok %d rows, fragments %s\\n" % (single.stats().n_ops, sr.last["fragment_bytes"]))
 # a batch one rank rejects is rejected on every rank (no rank is left waiting in a collective)
 bad = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=3, n_rounds=2, ins_per_change=10, del_per_change=2, n_objects=2, seed=44)
 arena = bad.arena.copy(); arena[int(bad.offsets[1]) + 20] ^= 0x55
@@ -94,6 +103,12 @@ if rank == 0:
     sys.stdout.write("bench section ok\\n")
 else:
     assert r is None
+r5 = bench.sharded_measurement(eng, rank, world, dist, torch.device("cpu"), 1, 1, dist.barrier, scale=0.002, sync=lambda: None, name="c5_doc_mixed")
+if rank == 0:
+    assert r5["parity"].startswith("stitched patch == unsharded patch") and r5["n_gpus"] == 2 and len(r5["fragment_bytes"]) == 2 and "Backend.load" in r5["workload"], r5
+    sys.stdout.write("bench section c5 ok\\n")
+else:
+    assert r5 is None
 dist.barrier()
 dist.destroy_process_group()
 sys.stdout.write("rank%dok\\n" % rank); sys.stdout.flush()
@@ -111,3 +126,4 @@ def test_two_rank_objectid_sharding_over_gloo(tmp_path):
                           "--master-port", "29534", str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "rank0ok" in out.stdout and "rank1ok" in out.stdout and out.stdout.count("case ok") >= 3 and "bench section ok" in out.stdout
+    assert out.stdout.count("doc ok") == 3 and "bench section c5 ok" in out.stdout
