@@ -688,7 +688,10 @@ void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len
   if (const char* e = getenv("AM355_KEY_TILE")) { int v = atoi(e); if (v >= 16 && (uint32_t)v <= KEY_TILE) tile = (uint32_t)v; }  // (tests: small tiles, so that small documents cross them)
   const uint32_t win = tile + tile / 3 <= KEY_WIN ? tile + tile / 3 : KEY_WIN;
   hipLaunchKernelGGL(kk_tile, dim3((cap + tile - 1) / tile), dim3(KEY_TILE_THREADS), 0, st, s.col, L, k, tile, win, k.run_start, d_unresolved);
-  AM355_LAUNCH_INDEPENDENT(kk_kth_cont, dim3(512), dim3(BLOCK), st, L, k, (const uint32_t*)k.run_start, (const uint32_t*)d_unresolved);
+  // (a lane per pending literal, all lanes of a wavefront busy: the walk is a chain of dependent loads, and what hides it is the number
+  // of wavefronts in flight -- 512 workgroups striding over the list took 3.3 ms for the config-5 column, a lane per POSITION with one
+  // lane in twenty-five busy 2.2 ms; the grid covers a literal for every eighth position and strides beyond that)
+  AM355_LAUNCH_INDEPENDENT(kk_kth_cont, dim3((cap / 8 + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), st, L, k, (const uint32_t*)k.run_start, (const uint32_t*)d_unresolved);
   chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);   // 2. true headers
 }
 

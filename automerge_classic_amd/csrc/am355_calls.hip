@@ -1,0 +1,371 @@
+// Calls on a replayed state (include/am355.h): patch IR to the host, Backend.applyChanges (delta stage orchestration), dependency graph,
+// Bloom filters of the sync protocol. See am355_ctx.h.
+#include "am355_ctx.h"
+
+int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out, bool with_edits) {
+  if (!c) return AM355_E_ARG;
+  if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");
+  (void)hipSetDevice(c->device);
+  if (!c->ir_fetched) {
+    hipStream_t st = c->stream;
+    uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NR = c->counts.n_erecs, NV = c->counts.n_edits;
+    size_t bytes = carve_size(NO, sizeof(am355_ir_object)) + carve_size(NM, sizeof(am355_ir_map)) + carve_size((size_t)NR + 1, sizeof(am355_ir_edit)) + 4096;
+    if (!c->h_ir.ensure(bytes)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+    uint8_t* p = c->h_ir.as<uint8_t>();
+    am355_patch_ir& h = c->hir;
+    auto pull = [&](const void* dev, size_t count, size_t elem) -> const void* {
+      void* dst = p;
+      p += carve_size(count, elem);
+      if (count) (void)hipMemcpyAsync(dst, dev, count * elem, hipMemcpyDeviceToHost, st);
+      return dst;
+    };
+    h.n_objects = NO; h.n_map = NM; h.n_edits = NR; h.n_values = NV;
+    h.objects = (const am355_ir_object*)pull(c->ir.obj, NO, sizeof(am355_ir_object));
+    h.map = (const am355_ir_map*)pull(c->ir.map, NM, sizeof(am355_ir_map));
+    h.edits = with_edits ? (const am355_ir_edit*)pull(c->ir.edit, (size_t)NR + 1, sizeof(am355_ir_edit)) : nullptr;
+    // (a ~0.1 ms copy: polled, not slept on -- a blocking wait adds an interrupt wake-up of tens of microseconds to a call of 140)
+    {
+      hipError_t q;
+      while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
+      if (q != hipSuccess) HIPCHK(c, q);
+    }
+    h.max_op = c->max_op;
+    h.n_actors = (uint32_t)c->actors.size();
+    c->actor_off.assign(1, 0);
+    c->actor_bytes.clear();
+    for (auto& a : c->actors) {
+      c->actor_bytes.insert(c->actor_bytes.end(), a.begin(), a.end());
+      c->actor_off.push_back((uint32_t)c->actor_bytes.size());
+    }
+    h.actor_off = c->actor_off.data();
+    h.actor_bytes = c->actor_bytes.data();
+    h.n_clock = (uint32_t)c->clock_actor.size();
+    h.clock_actor = c->clock_actor.data();
+    h.clock_seq = c->clock_seq.data();
+    h.n_heads = (uint32_t)(c->heads.size() / 32);
+    h.heads = c->heads.data();
+    h.pending = c->n_pending;
+    h.arena = c->raw.data();
+    h.arena_len = c->raw.size();
+    c->ir_fetched = with_edits;
+  }
+  if (out) *out = c->hir;
+  return AM355_OK;
+}
+
+int patch_json_impl(am355_ctx* c, const char** json, size_t* len) {
+  if (!c) return AM355_E_ARG;
+  int rc = fetch_ir_impl(c, nullptr);
+  if (rc) return rc;
+  std::string err;
+  c->json.clear();
+  if (!am355::render_patch_json(c->hir, c->json, err)) return fail(c, AM355_E_UNSUPPORTED, "%s", err.c_str());
+  if (json) *json = c->json.c_str();
+  if (len) *len = c->json.size();
+  return AM355_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Backend.applyChanges with its incremental patch (include/am355.h am355_apply_changes)
+// ---------------------------------------------------------------------------------------------------------
+
+// the device stage of am355_apply_changes over the replayed state of the context: rows >= T0 are the batch
+static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool check_only) {
+  hipStream_t st = c->stream;
+  const uint32_t N = (uint32_t)c->n_ops, NN = N - T0;
+  const uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NL = c->counts.n_list_ins;
+  if (c->pass_first_row.size() > 4096) return fail(c, AM355_E_UNSUPPORTED, "more scheduling passes than the incremental patch stage handles");
+  if (!c->d_delta.ensure(delta_bytes(N, NN, NM, NO, NL)) || !c->d_pass.ensure(4 * (c->pass_first_row.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
+  DeltaBufs& d = c->delta;
+  delta_bind(d, c->d_delta.p, N, NN, NM, NO, NL);
+  canary_arm();
+  d.T0 = T0; d.n_new = NN; d.n_obj = NO; d.n_map = NM; d.n_list = NL;
+  d.bits_new = (uint32_t)bits_for64(NN ? NN - 1 : 0);
+  std::vector<uint32_t> pass_rows;
+  for (uint32_t r : c->pass_first_row) if (r > T0) pass_rows.push_back(r);
+  d.n_pass = (uint32_t)pass_rows.size();
+  d.pass_rows = c->d_pass.as<uint32_t>();
+  // every row at which an op stream began: those of the earlier calls, this call's first row, its later passes
+  std::vector<uint32_t> breaks;
+  for (uint32_t r : c->stream_breaks) if (r < T0) breaks.push_back(r);
+  if (T0) breaks.push_back(T0);
+  breaks.insert(breaks.end(), pass_rows.begin(), pass_rows.end());
+  if (!c->d_breaks.ensure(4 * (breaks.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
+  d.n_breaks = (uint32_t)breaks.size();
+  d.breaks = c->d_breaks.as<uint32_t>();
+  d.breaks_exact = c->breaks_exact ? 1u : 0u;
+  if (!breaks.empty()) HIPCHK(c, hipMemcpyAsync(c->d_breaks.p, breaks.data(), 4 * breaks.size(), hipMemcpyHostToDevice, st));
+  if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));  // (pageable sources)
+  auto grow = [](void* user, size_t records) -> am355_ir_edit* {
+    am355_ctx* cx = (am355_ctx*)user;
+    return cx->d_delta_edit.ensure(sizeof(am355_ir_edit) * records) ? cx->d_delta_edit.as<am355_ir_edit>() : nullptr;
+  };
+  delta_run(c->mb, c->ir, d, hc, st, check_only, grow, c);
+  HIPCHK(c, hipGetLastError());
+  return AM355_OK;
+}
+
+int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) {
+  if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
+  (void)hipSetDevice(c->device);
+  c->apply_ready = false;
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "apply_changes: %-26s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
+  if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_apply_changes on a sharded context");
+  const bool have_state = c->staged;
+  if (have_state && c->is_document) return fail(c, AM355_E_UNSUPPORTED, "the state was made by am355_load_document: applyChanges onto it is served by the JS path");
+  if (have_state && !c->replayed) return fail(c, AM355_E_STATE, "the context holds no replayed state (the last replay failed?)");
+  for (uint32_t i = 0; i < n; i++)
+    if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
+  if (have_state && !c->state_checked) {
+    // The state came from ONE am355_load_changes + am355_replay (Backend.loadChanges: one call of the reference). The patches of later
+    // calls lean on objectMeta.children of the reference being the visible values of every property that holds a visible child
+    // object (am355_apply.cpp) -- true unless the merge loop of that one call skipped values of such a property: checked now, with
+    // every row of the state taken as the batch.
+    DeltaCounts pre{};
+    int prc = run_delta_stage(c, 0, &pre, true);
+    if (prc) return prc;
+    if (pre.hazard) c->children_hazard = true;  // (from here on no property is taken to list its visible values without asking)
+    c->state_checked = true;
+  }
+  // ---- the queue of the call: changes applied so far (application order) | the batch | changes still queued (new.js:1822) ----
+  const uint32_t n_old_applied = have_state ? (uint32_t)c->applied_change.size() : 0;
+  const uint64_t old_ops = have_state ? c->n_ops : 0;
+  // When every staged change was applied, in the order it is staged, and nothing is queued -- the usual case -- the staged bytes are
+  // already that queue's front, in the pinned arena and in HBM: only the batch is gathered and copied behind them.
+  bool append = have_state && c->pending_change.empty() && n_old_applied == c->n_changes && !getenv("AM355_APPLY_RESTAGE");
+  for (uint32_t i = 0; append && i < n_old_applied; i++) append = c->applied_change[i] == i;
+  int rc;
+  if (append) {
+    lap("queue = staged changes + batch");
+    rc = load_changes_impl(c, arena, offsets, n, true);
+  } else {
+    std::vector<uint8_t> comb;
+    std::vector<uint64_t> off;
+    size_t bytes = (size_t)(offsets[n] - offsets[0]);
+    if (have_state) bytes += c->raw.size();
+    comb.reserve(bytes + 64);
+    off.reserve((size_t)n_old_applied + n + c->pending_change.size() + 1);
+    off.push_back(0);
+    auto put_old = [&](uint32_t ci) {
+      const uint8_t* p = c->raw.data() + c->raw_off[ci];
+      comb.insert(comb.end(), p, p + (c->raw_off[ci + 1] - c->raw_off[ci]));
+      off.push_back(comb.size());
+    };
+    if (have_state) for (uint32_t ci : c->applied_change) put_old(ci);
+    for (uint32_t i = 0; i < n; i++) {
+      comb.insert(comb.end(), arena + offsets[i], arena + offsets[i + 1]);
+      off.push_back(comb.size());
+    }
+    if (have_state) for (uint32_t ci : c->pending_change) put_old(ci);
+    lap("queue assembled");
+    rc = load_changes_impl(c, comb.data(), off.data(), (uint32_t)off.size() - 1);
+  }
+  if (rc) { c->staged = false; return rc; }
+  lap("staged");
+  if (!have_state) { c->stream_breaks.clear(); c->breaks_exact = true; c->children_hazard = false; c->no_history = false; }
+  c->in_apply = true;
+  rc = replay_impl(c);
+  c->in_apply = false;
+  if (rc) { c->staged = false; return rc; }
+  lap("replayed");
+  // the earlier changes must have been applied again, first and in their order: rows [0, old_ops) are the state before the call
+  bool prefix_ok = c->applied_change.size() >= n_old_applied && c->n_ops >= old_ops;
+  for (uint32_t i = 0; prefix_ok && i < n_old_applied; i++) prefix_ok = c->applied_change[i] == i;
+  if (prefix_ok && n_old_applied < c->applied_change.size()) prefix_ok = c->applied_op_base[n_old_applied] == old_ops;
+  if (!prefix_ok) { c->staged = false; return fail(c, AM355_E_DEVICE, "internal: the earlier changes were not re-applied first"); }
+
+  // ---- delta stage on the device ----
+  hipStream_t st = c->stream;
+  const uint32_t NO = c->counts.n_objects;
+  DeltaBufs& d = c->delta;
+  DeltaCounts hc{};
+  // A call refused from here on leaves the context WITHOUT a state (include/am355.h): the replay above merged the batch, and a later
+  // call must not get patches relative to a state that silently holds a batch whose call boundary nobody recorded.
+  auto drop_state = [&](int code) { c->staged = c->replayed = c->ir_fetched = false; return code; };
+  rc = run_delta_stage(c, (uint32_t)old_ops, &hc, false);
+  if (rc) return drop_state(rc);
+  lap("delta stage");
+  c->state_checked = true;  // (a call the engine served: checked; a refused call leaves the state to the JS path)
+  if (hc.flags) {
+    c->state_checked = false;
+    drop_state(0);
+    if ((hc.flags & AM355_F_UNSUPPORTED) && hc.reason != NONE32) {
+      c->flags |= hc.flags;
+      return fail(c, AM355_E_UNSUPPORTED, "incremental patch not served: %s (JS path)", delta_reason_text(hc.reason));
+    }
+    return error_for_flags(c, hc.flags, "incremental patch not served");
+  }
+
+  // ---- tables to the host, setupPatches, assembly ----
+  rc = fetch_ir_impl(c, nullptr, false);
+  if (rc) return drop_state(rc);
+  lap("document tables on the host");
+  const uint32_t n_dmap = hc.n_kept + hc.n_place, n_dedits = hc.n_erecs;
+  size_t b_link = carve_size(NO, sizeof(ObjLink)), b_map = carve_size(n_dmap, sizeof(am355_ir_map)), b_edit = carve_size((size_t)n_dedits + 1, sizeof(am355_ir_edit));
+  if (!c->h_delta.ensure(b_link + b_map + b_edit + 256)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+  uint8_t* hp = c->h_delta.as<uint8_t>();
+  ObjLink* h_link = (ObjLink*)hp;
+  am355_ir_map* h_map = (am355_ir_map*)(hp + b_link);
+  am355_ir_edit* h_edit = (am355_ir_edit*)(hp + b_link + b_map);
+  HIPCHK(c, hipMemcpyAsync(h_link, d.link, sizeof(ObjLink) * (size_t)NO, hipMemcpyDeviceToHost, st));
+  if (n_dmap) HIPCHK(c, hipMemcpyAsync(h_map, d.map, sizeof(am355_ir_map) * (size_t)n_dmap, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(h_edit, d.edit, sizeof(am355_ir_edit) * ((size_t)n_dedits + 1), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  std::string err;
+  std::unordered_map<uint32_t, KeyHistory> known;
+  std::vector<uint32_t> need;
+  const bool ask_always = c->children_hazard;
+  if (hc.hazard) c->children_hazard = true;  // (this call skipped values of a property with a child object: later calls ask)
+  for (int round = 0;; round++) {
+    rc = assemble_apply_patch(c->hir, h_link, h_map, n_dmap, h_edit, n_dedits, known, ask_always, need, c->apply, err);
+    if (rc == AM355_E_UNSUPPORTED && need.empty() && !c->hir.edits && err == "edit records needed") {
+      // a touched object hangs in a list: setupPatches needs the whole-document edit records of that list
+      int frc = fetch_ir_impl(c, nullptr, true);
+      if (frc) return drop_state(frc);
+      lap("document edit records on the host");
+      continue;
+    }
+    if (rc != AM355_E_UNSUPPORTED || need.empty() || round == 16 || need.size() > 256 || c->no_history) break;
+    // the walk met objects that are no longer visible: what the reference's objectMeta lists for their property follows from the
+    // history of the rows on it (am355_delta.hip, delta_key_history)
+    std::vector<KeyHistory> st_of(need.size());
+    if (delta_key_history(c->mb, c->ir, d, need.data(), (uint32_t)need.size(), st_of.data(), st) != 0) return drop_state(0), fail(c, AM355_E_DEVICE, "key history: %s", hipGetErrorString(hipGetLastError()));
+    for (size_t i = 0; i < need.size(); i++) known[need[i]] = st_of[i];
+    lap("property histories");
+  }
+  if (rc) { if (rc == AM355_E_UNSUPPORTED) c->flags |= AM355_F_UNSUPPORTED; drop_state(0); return fail(c, rc, "%s", err.c_str()); }
+  // the op streams of this call (this engine re-applies the earlier changes in front of them: their rows keep their numbers)
+  if (old_ops) c->stream_breaks.push_back((uint32_t)old_ops);
+  for (uint32_t r : c->pass_first_row) if (r > old_ops) c->stream_breaks.push_back(r);
+  c->apply_ready = true;
+  c->apply_json.clear();
+  lap("patch assembled");
+  return AM355_OK;
+}
+
+extern "C" int am355_reset(am355_ctx* c) {
+  if (!c) return AM355_E_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->staging_in_flight) { c->staging_in_flight = false; (void)hipStreamSynchronize(c->stream); }
+  c->staged = c->replayed = c->ir_fetched = c->apply_ready = false;
+  c->state_checked = true;
+  c->stream_breaks.clear();
+  c->breaks_exact = true;
+  c->children_hazard = false;
+  c->no_history = false;
+  c->is_document = false;
+  c->flags = 0;
+  c->n_changes = 0;
+  c->applied_change.clear();
+  c->pending_change.clear();
+  return AM355_OK;
+}
+
+extern "C" int am355_forget_call_history(am355_ctx* c, int from_document) {
+  if (!c) return AM355_E_ARG;
+  c->breaks_exact = false;
+  if (from_document) c->no_history = true;
+  return AM355_OK;
+}
+
+extern "C" int am355_get_pending(const am355_ctx* c, uint32_t* out, uint32_t* n_pending) {
+  if (!c || !n_pending) return AM355_E_ARG;
+  if (!c->replayed || c->is_document) return AM355_E_STATE;
+  *n_pending = (uint32_t)c->pending_change.size();
+  if (out && !c->pending_change.empty()) memcpy(out, c->pending_change.data(), 4 * c->pending_change.size());
+  return AM355_OK;
+}
+
+int apply_patch_json_impl(am355_ctx* c, const char** json, size_t* len) {
+  if (!c) return AM355_E_ARG;
+  if (!c->apply_ready) return fail(c, AM355_E_STATE, "am355_apply_changes must succeed first");
+  if (c->apply_json.empty()) {
+    std::string err;
+    if (!am355::render_patch_json(c->apply.ir, c->apply_json, err)) { c->apply_json.clear(); return fail(c, AM355_E_UNSUPPORTED, "%s", err.c_str()); }
+  }
+  if (json) *json = c->apply_json.c_str();
+  if (len) *len = c->apply_json.size();
+  return AM355_OK;
+}
+
+extern "C" int am355_fetch_apply_ir(am355_ctx* c, am355_patch_ir* out) {
+  if (!c) return AM355_E_ARG;
+  if (!c->apply_ready) return fail(c, AM355_E_STATE, "am355_apply_changes must succeed first");
+  if (out) *out = c->apply.ir;
+  return AM355_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// sync protocol, bulk side (include/am355.h)
+// ---------------------------------------------------------------------------------------------------------
+int get_dep_graph_impl(am355_ctx* c, const uint32_t** dep_first, const uint32_t** dep_index, uint32_t* n_changes) {
+  if (!c) return AM355_E_ARG;
+  if (!c->replayed || c->is_document) return fail(c, AM355_E_STATE, "a replayed state of changes is needed");
+  (void)hipSetDevice(c->device);
+  if (!c->dep_graph_ready) {
+    const uint32_t n = c->n_changes;
+    const size_t dep_words = c->raw.size() / 32 + 2;
+    // the device resolved every dependency hash to the index of the change that carries it (k_deps_resolve), addressed by the
+    // dependency's place in the arena; the change headers say where those places are
+    if (!c->h_dep_idx.ensure(4 * dep_words) || !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u))) return fail(c, AM355_E_NOMEM, "host allocation failed");
+    HIPCHK(c, hipMemcpyAsync(c->h_metas.p, c->d_metas.p, sizeof(ChangeMeta) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_dep_idx.p, c->d_dep_idx.p, 4 * dep_words, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const ChangeMeta* metas = c->h_metas.as<ChangeMeta>();
+    const uint32_t* di = c->h_dep_idx.as<uint32_t>();
+    c->dep_first.assign((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; i++) c->dep_first[i + 1] = c->dep_first[i] + metas[i].n_deps;
+    c->dep_index.resize(c->dep_first[n]);
+    for (uint32_t i = 0; i < n; i++) {
+      const size_t first = (size_t)((metas[i].base + metas[i].deps_off) >> 5);
+      for (uint32_t k = 0; k < metas[i].n_deps; k++) c->dep_index[c->dep_first[i] + k] = di[first + k];
+    }
+    c->dep_graph_ready = true;
+  }
+  if (dep_first) *dep_first = c->dep_first.data();
+  if (dep_index) *dep_index = c->dep_index.data();
+  if (n_changes) *n_changes = c->n_changes;
+  return AM355_OK;
+}
+
+int sync_bloom_impl(am355_ctx* c, const uint32_t* idx, uint32_t n, uint32_t num_entries, uint32_t bits_per_entry, uint32_t num_probes, const uint8_t* probe_bits,
+                           size_t probe_bytes, uint8_t* out, size_t out_cap, bool build) {
+  if (!c || (n && !idx) || !out) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
+  if (!c->replayed || c->is_document || !c->d_hashes.p) return fail(c, AM355_E_STATE, "a replayed state of changes is needed");
+  (void)hipSetDevice(c->device);
+  for (uint32_t k = 0; k < n; k++)
+    if (idx[k] >= c->n_changes) return fail(c, AM355_E_ARG, "change index %u out of range", idx[k]);
+  hipStream_t st = c->stream;
+  const uint64_t n_bits64 = build ? 8 * (((uint64_t)n * 10 + 7) / 8) : 8 * (uint64_t)probe_bytes;
+  if (n_bits64 > 0xfffffff0ull) return fail(c, AM355_E_UNSUPPORTED, "Bloom filter beyond 2^32 bits");
+  const uint32_t n_bits = (uint32_t)n_bits64;
+  const size_t filter_bytes = n_bits / 8;
+  if (build && out_cap < filter_bytes) return fail(c, AM355_E_ARG, "filter needs %zu bytes", filter_bytes);
+  if (!build && (uint64_t)probe_bytes < ((uint64_t)num_entries * bits_per_entry + 7) / 8) return fail(c, AM355_E_ARG, "filter shorter than its header says");
+  size_t o_bits = ((4 * (size_t)n + 255) & ~(size_t)255), o_flags = o_bits + ((filter_bytes + 8 + 255) & ~(size_t)255);
+  if (!c->d_sync.ensure(o_flags + n + 256)) return fail(c, AM355_E_NOMEM, "device allocation failed");
+  uint8_t* d = c->d_sync.as<uint8_t>();
+  if (n) HIPCHK(c, hipMemcpyAsync(d, idx, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+  if (build) {
+    launch_bloom_build(c->d_hashes.as<uint8_t>(), (const uint32_t*)d, n, (uint32_t*)(d + o_bits), n_bits, 7, st);
+    if (filter_bytes) HIPCHK(c, hipMemcpyAsync(out, d + o_bits, filter_bytes, hipMemcpyDeviceToHost, st));
+  } else {
+    if (filter_bytes) HIPCHK(c, hipMemcpyAsync(d + o_bits, probe_bits, filter_bytes, hipMemcpyHostToDevice, st));
+    // (an empty filter -- numEntries 0 -- contains nothing: sync.js:120)
+    launch_bloom_probe(c->d_hashes.as<uint8_t>(), (const uint32_t*)d, n, d + o_bits, num_entries ? n_bits : 0, num_probes, d + o_flags, st);
+    if (n) HIPCHK(c, hipMemcpyAsync(out, d + o_flags, n, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(c, hipStreamSynchronize(st));
+  return AM355_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// diagnostics
+// ---------------------------------------------------------------------------------------------------------
