@@ -22,7 +22,7 @@
 //                 key's last op went on to a greater key of the same object (new.js:1125-1129), the document ops of the key with
 //                 a greater id than that last op are never looked at (new.js:1140-1149 keeps the stale `changeOp`), and their
 //                 values are missing from the patch.
-//   object links  am355_api.hip (host): setupPatches over the object table, from ObjLink.
+//   object links  am355_calls.hip / am355_apply.cpp (host): setupPatches over the object table, from ObjLink.
 //
 // Served subset (anything else raises F_UNSUPPORTED and the call is served by the JS path): list elements hold plain values -- inserted,
 // deleted and assigned to (`list[i] = v`: kd_events; the edit rewriting of appendUpdate and the index lag inside one merge call are

@@ -15,7 +15,7 @@
 // visited once plus one LDS read per waiting change and sweep. Then: stable radix sort of the changes by pass (am355_prims.hip) =
 // application order; ks_plan_sums / ks_plan_apply = the decode plans in that order (what k_actor_check / k_plan_apply build for the
 // in-order path); ks_checks = heads and the actor rule (new.js:1442-1449), one wavefront per applied change.
-// What is left to the host is what the in-order path leaves to it as well (plan_ordered in am355_api.hip, beside the decode kernels):
+// What is left to the host is what the in-order path leaves to it as well (plan_fast with an order, am355_replay.hip, beside the decode kernels):
 // sequence numbers, clock, per-actor span tables -- O(changes) over 32-byte digests.
 #include "am355_sched.h"
 #include "am355_prims.h"
