@@ -555,25 +555,57 @@ __global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __res
   }
 }
 
-// literals that left their window: window by window along (hops to the end, exit position), then the last hops one by one
-__global__ __launch_bounds__(BLOCK) void kk_kth_cont(uint32_t L, KeyWork k, const uint32_t* __restrict__ pend, const uint32_t* __restrict__ n_pend) {
+// literals that left their window: window by window along (hops to the end, exit position), then the last hops -- fewer than the
+// window's -- one by one: up to KEY_CONT_SMALL of them right here (the garbage "literals", a few dozen strings), more than that
+// (real literals: hundreds of strings in their last window) by kk_kth_big from a copy of the window in LDS
+constexpr uint32_t KEY_CONT_SMALL = 48;
+__global__ __launch_bounds__(BLOCK) void kk_kth_cont(uint32_t L, KeyWork k, const uint32_t* __restrict__ pend, const uint32_t* __restrict__ n_pend,
+                                                     uint32_t* __restrict__ big, uint32_t* __restrict__ n_big, uint32_t small) {
   const uint32_t total = *n_pend;
   for (uint32_t w = gtid(); w < total; w += gridDim.x * BLOCK) {
     const uint32_t i = pend[w];
     uint32_t rem = k.jb[i], pos = k.hnext[i];
     while (rem) {
-      if (pos == NONE32 || pos >= L) { pos = NONE32; break; }   // (L is the regular end of the parse; nothing follows it)
+      if (pos == NONE32 || pos >= L) { pos = NONE32; rem = 0; break; }   // (L is the regular end of the parse; nothing follows it)
       const uint32_t hops = k.item_ex[pos];
       if (rem >= hops) { rem -= hops; pos = k.ja[pos]; }
-      else {
+      else if (rem <= small) {
         for (; rem; rem--) {
           pos = k.vnext[pos];
           if (pos == NONE32) break;
         }
-        break;
-      }
+        rem = 0;
+      } else break;   // a long last stretch: a chain of dependent loads from global memory would hold this kernel up (3.3 ms for the config-5 column)
     }
     k.hnext[i] = pos;
+    k.jb[i] = rem;
+    if (rem) big[atomicAdd(n_big, 1u)] = i;
+  }
+}
+
+// one wavefront per literal with a long last stretch: the rest of its window comes to LDS in one round of loads, lane 0 walks there
+__global__ __launch_bounds__(WAVE) void kk_kth_big(const uint8_t* __restrict__ col, uint32_t L, KeyWork k, uint32_t tile, uint32_t win,
+                                                   const uint32_t* __restrict__ big, const uint32_t* __restrict__ n_big) {
+  __shared__ uint8_t bytes[KEY_WIN + 64];
+  const uint32_t total = *n_big, lane = threadIdx.x;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const uint32_t i = big[w];
+    uint32_t pos = k.hnext[i], rem = k.jb[i];
+    // the next `rem` strings start inside the window of pos (rem < its hops to the window's end); a length prefix may reach 10 bytes past it
+    const uint32_t wend0 = (pos / tile) * tile + win + 16, wend = wend0 < L ? wend0 : L;
+    __syncthreads();
+    for (uint32_t q = lane; pos + q < wend; q += WAVE) bytes[q] = col[pos + q];
+    __syncthreads();
+    if (lane == 0) {
+      const uint8_t* lp = bytes - pos;   // (indexed by column position)
+      uint32_t p = pos;
+      for (; rem; rem--) {
+        p = key_string_end(lp, p, wend, nullptr, nullptr);
+        if (p == NONE32) break;   // (cannot happen: the stretch stays inside the window by construction; kept as a dead end)
+      }
+      k.hnext[i] = p;
+      k.jb[i] = 0;
+    }
   }
 }
 
@@ -682,16 +714,20 @@ void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len
   s.arena = arena;
   s.col_abs = col_abs;
   s.L = L;
-  // (d_unresolved, a device word the caller cleared, counts the literals that leave their window; their positions go to run_start,
-  // which is free until the run table is built)
+  // (d_unresolved[0], [1]: two device words the caller cleared, count the literals that leave their window and those of them with a
+  // long last stretch; their positions go to run_start / run_off, which are free until the run table is built)
   uint32_t tile = KEY_TILE;
   if (const char* e = getenv("AM355_KEY_TILE")) { int v = atoi(e); if (v >= 16 && (uint32_t)v <= KEY_TILE) tile = (uint32_t)v; }  // (tests: small tiles, so that small documents cross them)
   const uint32_t win = tile + tile / 3 <= KEY_WIN ? tile + tile / 3 : KEY_WIN;
+  uint32_t cont_small = KEY_CONT_SMALL;
+  if (const char* e = getenv("AM355_KEY_CONT_SMALL")) cont_small = (uint32_t)atoi(e);   // (tests: 0 sends every last stretch through kk_kth_big)
   hipLaunchKernelGGL(kk_tile, dim3((cap + tile - 1) / tile), dim3(KEY_TILE_THREADS), 0, st, s.col, L, k, tile, win, k.run_start, d_unresolved);
   // (a lane per pending literal, all lanes of a wavefront busy: the walk is a chain of dependent loads, and what hides it is the number
   // of wavefronts in flight -- 512 workgroups striding over the list took 3.3 ms for the config-5 column, a lane per POSITION with one
   // lane in twenty-five busy 2.2 ms; the grid covers a literal for every eighth position and strides beyond that)
-  AM355_LAUNCH_INDEPENDENT(kk_kth_cont, dim3((cap / 8 + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), st, L, k, (const uint32_t*)k.run_start, (const uint32_t*)d_unresolved);
+  AM355_LAUNCH_INDEPENDENT(kk_kth_cont, dim3((cap / 8 + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), st, L, k, (const uint32_t*)k.run_start, (const uint32_t*)d_unresolved, k.run_off,
+                           d_unresolved + 1, cont_small);
+  hipLaunchKernelGGL(kk_kth_big, dim3(2048), dim3(WAVE), 0, st, s.col, L, k, tile, win, (const uint32_t*)k.run_off, (const uint32_t*)(d_unresolved + 1));
   chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);   // 2. true headers
 }
 

@@ -534,6 +534,8 @@ def test_key_column_literals_across_tiles(eng, tile, monkeypatch):
     """The key-string index follows the strings of a literal inside LDS tiles and finishes the literals that leave their tile from the
     tiles' (hops, exit) pairs: with tiles of a few bytes every literal of these documents crosses tiles, many of them several."""
     monkeypatch.setenv("AM355_KEY_TILE", tile)
+    if tile == "64":
+        monkeypatch.setenv("AM355_KEY_CONT_SMALL", "0")   # every last stretch through the LDS walker (kk_kth_big)
     for name in ("synthetic_doc_medium", "frontend_mixed_6actors", "campaign_mixed_1008"):
         fx = golden_util.load_fixture(name)
         eng.load_document(fx["doc_bytes"])
