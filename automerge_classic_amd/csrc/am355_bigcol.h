@@ -61,7 +61,8 @@ void bigcol_assemble(const BigColVals& v, uint32_t n_rows, uint32_t n_succ, cons
 // keyStr column -> run table (run_start has n_runs + 1 entries; run_len NONE32 = null run), fully parallel; scratch in `work`
 // (keystr_work_bytes(col_len) bytes). `begin` (vnext / hnext of every position with the k-th successors of literal headers resolved
 // tile by tile in LDS, then the true headers) and `finish` (literal items, run table) are enqueued back to back: no host decision
-// in between (d_unresolved / unresolved are unused leftovers of the version that had one).
+// in between. d_unresolved: four device words the caller cleared ([0], [1] pending counts; flags[3] of `finish` = 1 when the TRUE parse
+// reached a literal the walker had cut off after KeyStage.max_jumps windows: the caller repeats the load with max_jumps = 0).
 struct KeyWork {
   uint32_t *vnext, *hnext, *kk, *ja, *jb, *mark_h, *mark_v, *item_ex, *rows;  // [L + 2]
   uint32_t *run_start, *run_off, *run_len, *run_kind;                        // [L + 2] (items <= bytes)
@@ -73,6 +74,7 @@ struct KeyStage {
   void* chain_ws;
   const uint8_t *col, *arena;
   uint32_t col_abs, L;
+  uint32_t max_jumps = 64;   // windows the continuation walker follows a literal through (0: no bound); set before keystr_index_begin
 };
 size_t keystr_work_bytes(uint32_t col_len);
 void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len, void* work, KeyStage& s, uint32_t* n_runs, uint32_t* d_unresolved,

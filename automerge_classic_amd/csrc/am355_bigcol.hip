@@ -14,6 +14,7 @@
 // All of it is streaming integer work over HBM-resident arrays (prefix sums, gathers); no MFMA.
 #include "am355_bigcol.h"
 #include "am355_prims.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace am355 {
@@ -560,15 +561,23 @@ __global__ __launch_bounds__(KEY_TILE_THREADS) void kk_tile(const uint8_t* __res
 // (real literals: hundreds of strings in their last window) by kk_kth_big from a copy of the window in LDS
 constexpr uint32_t KEY_CONT_SMALL = 48;
 __global__ __launch_bounds__(BLOCK) void kk_kth_cont(uint32_t L, KeyWork k, const uint32_t* __restrict__ pend, const uint32_t* __restrict__ n_pend,
-                                                     uint32_t* __restrict__ big, uint32_t* __restrict__ n_big, uint32_t small) {
+                                                     uint32_t* __restrict__ big, uint32_t* __restrict__ n_big, uint32_t small, uint32_t max_jumps) {
   const uint32_t total = *n_pend;
   for (uint32_t w = gtid(); w < total; w += gridDim.x * BLOCK) {
     const uint32_t i = pend[w];
-    uint32_t rem = k.jb[i], pos = k.hnext[i];
+    uint32_t rem = k.jb[i], pos = k.hnext[i], jumps = 0;
+    bool cut = false;
     while (rem) {
       if (pos == NONE32 || pos >= L) { pos = NONE32; rem = 0; break; }   // (L is the regular end of the parse; nothing follows it)
       const uint32_t hops = k.item_ex[pos];
-      if (rem >= hops) { rem -= hops; pos = k.ja[pos]; }
+      if (rem >= hops) {
+        // Garbage "literals" of millions of strings exist (any bytes that read as a long negative count) and would walk window by
+        // window to the end of the column -- two dependent loads per window, 3.3 ms for a lane of the config-5 column, and the kernel
+        // waits for its slowest lane. The walk is cut after max_jumps windows: the header becomes a dead end with its rest kept in jb.
+        // Should the TRUE parse reach such a header (kk_item_init sees it), the load is repeated without the bound (am355_replay.hip).
+        if (max_jumps && ++jumps > max_jumps) { cut = true; break; }
+        rem -= hops; pos = k.ja[pos];
+      }
       else if (rem <= small) {
         for (; rem; rem--) {
           pos = k.vnext[pos];
@@ -577,9 +586,9 @@ __global__ __launch_bounds__(BLOCK) void kk_kth_cont(uint32_t L, KeyWork k, cons
         rem = 0;
       } else break;   // a long last stretch: a chain of dependent loads from global memory would hold this kernel up (3.3 ms for the config-5 column)
     }
-    k.hnext[i] = pos;
+    k.hnext[i] = cut ? NONE32 : pos;
     k.jb[i] = rem;
-    if (rem) big[atomicAdd(n_big, 1u)] = i;
+    if (rem && !cut) big[atomicAdd(n_big, 1u)] = i;
   }
 }
 
@@ -616,7 +625,8 @@ __global__ __launch_bounds__(BLOCK) void kk_item_init(const uint8_t* __restrict_
   uint32_t vn = k.vnext[i];
   k.ja[i] = (vn < L && !k.mark_h[vn]) ? vn : NONE32;
   if (k.mark_h[i]) {
-    if (k.hnext[i] == NONE32 || k.hnext[i] > L) atomicOr(flags, (uint32_t)F_BAD_LEB);  // header that is not a well-formed record, or runs off the column
+    if (k.jb[i]) { flags[3] = 1; }  // a true literal the walker cut off (kk_kth_cont): the caller repeats the load without the bound
+    else if (k.hnext[i] == NONE32 || k.hnext[i] > L) atomicOr(flags, (uint32_t)F_BAD_LEB);  // header that is not a well-formed record, or runs off the column
     if (k.kk[i]) {
       int64_t cnt;
       uint32_t hb;
@@ -721,13 +731,20 @@ void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len
   const uint32_t win = tile + tile / 3 <= KEY_WIN ? tile + tile / 3 : KEY_WIN;
   uint32_t cont_small = KEY_CONT_SMALL;
   if (const char* e = getenv("AM355_KEY_CONT_SMALL")) cont_small = (uint32_t)atoi(e);   // (tests: 0 sends every last stretch through kk_kth_big)
+  if (s.max_jumps) { if (const char* e = getenv("AM355_KEY_JUMPS")) s.max_jumps = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : s.max_jumps; }  // (tests: 1 cuts every long literal)
   hipLaunchKernelGGL(kk_tile, dim3((cap + tile - 1) / tile), dim3(KEY_TILE_THREADS), 0, st, s.col, L, k, tile, win, k.run_start, d_unresolved);
   // (a lane per pending literal, all lanes of a wavefront busy: the walk is a chain of dependent loads, and what hides it is the number
   // of wavefronts in flight -- 512 workgroups striding over the list took 3.3 ms for the config-5 column, a lane per POSITION with one
   // lane in twenty-five busy 2.2 ms; the grid covers a literal for every eighth position and strides beyond that)
   AM355_LAUNCH_INDEPENDENT(kk_kth_cont, dim3((cap / 8 + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), st, L, k, (const uint32_t*)k.run_start, (const uint32_t*)d_unresolved, k.run_off,
-                           d_unresolved + 1, cont_small);
+                           d_unresolved + 1, cont_small, s.max_jumps);
   hipLaunchKernelGGL(kk_kth_big, dim3(2048), dim3(WAVE), 0, st, s.col, L, k, tile, win, (const uint32_t*)k.run_off, (const uint32_t*)(d_unresolved + 1));
+  if (getenv("AM355_TRACE")) {  // (diagnostic: how many literals left their window / had a long last stretch)
+    uint32_t w[2] = {0, 0};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(w, d_unresolved, 8, hipMemcpyDeviceToHost);
+    fprintf(stderr, "keystr: %u positions, tile %u window %u: %u literals left their window, %u with a long last stretch\n", L, tile, win, w[0], w[1]);
+  }
   chain_mark(k.hnext, L, k.mark_h, s.chain_ws, st);   // 2. true headers
 }
 

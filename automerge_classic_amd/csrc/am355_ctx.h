@@ -332,6 +332,7 @@ struct am355_ctx {
   std::vector<uint32_t> pass_first_row;   // first op row of every scheduling pass after the first (general scheduler)
   DevBuf d_delta, d_pass, d_delta_edit, d_sched, d_hist;
   HostBuf h_sched;
+  bool key_unbounded = false;      // replay_document: second attempt, the key stream's walker follows literals without a bound
   bool device_scheduled = false;   // the last general-path replay was scheduled by the device (am355_sched.hip)
   HostBuf h_delta;
   DeltaBufs delta{};

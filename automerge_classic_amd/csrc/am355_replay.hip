@@ -725,6 +725,7 @@ static int replay_document(am355_ctx* c) {
     HIPCHK(c, hipEventRecord(c->ev_b0, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_b0, 0));
     KeyStage ks;
+    ks.max_jumps = c->key_unbounded ? 0u : 64u;
     canary_forget(c->d_ks.p, c->d_ks.cap);
     keystr_index_begin(c->d_arena.as<uint8_t>(), m.col_off[C_KEY_STR], m.col_len[C_KEY_STR], c->d_ks.p, ks, d_words + W_TOTAL_ENTRIES, d_words + W_FAST_B,
                        c->stream2);
@@ -770,7 +771,7 @@ static int replay_document(am355_ctx* c) {
     bigcol_assemble(v, N, (uint32_t)c->n_preds, c->d_amap.as<uint32_t>(), NA, m.col_off[C_VAL_RAW], m.col_len[C_VAL_RAW], c->cols, flags, st);
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_b1, 0));
     launch_keystr_expand(ks_start, ks_off, ks_len, d_words + W_TOTAL_ENTRIES, N, c->cols.key_off, c->cols.key_len, st);
-    HIPCHK(c, hipMemcpyAsync(c->h_words.as<uint32_t>() + W_FLAGS_B, d_words + W_FLAGS_B, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_words.as<uint32_t>() + W_FLAGS_B, d_words + W_FLAGS_B, 16, hipMemcpyDeviceToHost, st));  // (+ the key stream's "cut off" word)
   }
   HIPCHK(c, hipEventRecord(c->ev[3], st));
   // maxOp = max over op ids and succ counters (new.js:1627-1630)
@@ -784,6 +785,14 @@ static int replay_document(am355_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[5], st));
   HIPCHK(c, hipStreamSynchronize(st));
   lap("patch done");
+  if (!c->doc_serial && c->h_words.as<uint32_t>()[W_FLAGS_B + 3] && !c->key_unbounded) {
+    // the true parse of the key column reached a literal longer than the continuation walker follows (64 windows: tens of thousands of
+    // strings): once more, without the bound (the walker then also follows every garbage "literal" to the end of the column)
+    c->key_unbounded = true;
+    int rc2 = replay_document(c);
+    c->key_unbounded = false;
+    return rc2;
+  }
   if (!c->doc_serial && c->h_words.as<uint32_t>()[W_FLAGS_B]) return error_for_flags(c, c->h_words.as<uint32_t>()[W_FLAGS_B], "malformed key column");
   if (hc->flags) return error_for_flags(c, hc->flags, "document rejected");
   c->max_op = c->h_words.as<uint32_t>()[0];
