@@ -739,7 +739,7 @@ void keystr_index_begin(const uint8_t* arena, uint32_t col_abs, uint32_t col_len
   AM355_LAUNCH_INDEPENDENT(kk_kth_cont, dim3((cap / 8 + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), st, L, k, (const uint32_t*)k.run_start, (const uint32_t*)d_unresolved, k.run_off,
                            d_unresolved + 1, cont_small, s.max_jumps);
   hipLaunchKernelGGL(kk_kth_big, dim3(2048), dim3(WAVE), 0, st, s.col, L, k, tile, win, (const uint32_t*)k.run_off, (const uint32_t*)(d_unresolved + 1));
-  if (getenv("AM355_TRACE")) {  // (diagnostic: how many literals left their window / had a long last stretch)
+  if (getenv("AM355_KEY_DIAG")) {  // (diagnostic: how many literals left their window / had a long last stretch)
     uint32_t w[2] = {0, 0};
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(w, d_unresolved, 8, hipMemcpyDeviceToHost);

@@ -95,6 +95,7 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   d.n_breaks = (uint32_t)breaks.size();
   d.breaks = c->d_breaks.as<uint32_t>();
   d.breaks_exact = c->breaks_exact ? 1u : 0u;
+  d.T_doc = c->no_history && c->doc_rows_known ? (uint32_t)c->doc_rows : 0u;
   if (!breaks.empty()) HIPCHK(c, hipMemcpyAsync(c->d_breaks.p, breaks.data(), 4 * breaks.size(), hipMemcpyHostToDevice, st));
   if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipStreamSynchronize(st));  // (pageable sources)
@@ -117,8 +118,47 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
     if (trace) fprintf(stderr, "apply_changes: %-26s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   };
   if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_apply_changes on a sharded context");
+  if (c->staged && c->is_document) {
+    // Backend.applyChanges onto a loaded document. The reference rebuilds the document's changes first (computeHashGraph,
+    // new.js:1887-1912, called from applyChanges :1809): the batch is scheduled against THEIR hashes. So does the engine
+    // (am355_doc_changes: the device regroups rows into changes and encodes them, am355_hist.hip), then replays the rebuilt changes as
+    // the state the batch goes onto. What differs from a state that calls built is the reference's objectMeta: it came from one pass
+    // over the document's rows (new.js:1604-1635), which the delta stage is told by the number of rows the document had (T_doc).
+    if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must be called after am355_load_document");
+    const uint8_t *ha = nullptr, *hh = nullptr;
+    const uint64_t* ho = nullptr;
+    uint32_t hn = 0;
+    const bool head_index_known = !c->doc_tail.empty() || c->heads.size() <= 32;  // (heads.length === headsIndexes.length, or one head: new.js:1719-1729)
+    int hrc = doc_changes_impl(c, 0, &ha, &ho, &hn, &hh);
+    if (hrc) return hrc;
+    if (hn == 0) {  // (an empty document: Backend.init())
+      int rrc = am355_reset(c);
+      if (rrc) return rrc;
+    } else {
+    std::vector<uint8_t> hist(ha + ho[0], ha + ho[hn]);
+    std::vector<uint64_t> hoff(hn + 1);
+    for (uint32_t i = 0; i <= hn; i++) hoff[i] = ho[i] - ho[0];
+    lap("document history rebuilt");
+    hrc = load_changes_impl(c, hist.data(), hoff.data(), hn, false);
+    if (!hrc) hrc = replay_impl(c);
+    if (hrc) { c->staged = false; return hrc; }
+    bool in_order = c->pending_change.empty() && c->applied_change.size() == hn;
+    for (uint32_t i = 0; in_order && i < hn; i++) in_order = c->applied_change[i] == i;
+    if (!in_order) { c->staged = c->replayed = false; return fail(c, AM355_E_DEVICE, "internal: the rebuilt changes of the document did not apply in document order"); }
+    c->stream_breaks.clear();
+    c->breaks_exact = true;
+    c->children_hazard = false;
+    c->state_checked = true;  // (no merge call built this state: nothing was skipped)
+    c->no_history = true;
+    c->doc_rows = c->n_ops;
+    c->doc_rows_known = true;
+    c->graph_mode = c->doc_graph_known ? 0 : 1;  // (the reference has the document's heads only, until a round of its retry loop applies nothing or a query rebuilds the graph)
+    c->doc_n_changes = hn;
+    c->doc_head_index_known = head_index_known;
+    lap("document history replayed");
+    }
+  }
   const bool have_state = c->staged;
-  if (have_state && c->is_document) return fail(c, AM355_E_UNSUPPORTED, "the state was made by am355_load_document: applyChanges onto it is served by the JS path");
   if (have_state && !c->replayed) return fail(c, AM355_E_STATE, "the context holds no replayed state (the last replay failed?)");
   for (uint32_t i = 0; i < n; i++)
     if (offsets[i] > offsets[i + 1]) return fail(c, AM355_E_ARG, "change offsets must be ascending (offsets[%u] > offsets[%u])", i, i + 1);
@@ -168,10 +208,12 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
   }
   if (rc) { c->staged = false; return rc; }
   lap("staged");
-  if (!have_state) { c->stream_breaks.clear(); c->breaks_exact = true; c->children_hazard = false; c->no_history = false; }
+  if (!have_state) { c->stream_breaks.clear(); c->breaks_exact = true; c->children_hazard = false; c->no_history = false; c->doc_rows_known = false; c->graph_mode = 0; }
   c->in_apply = true;
+  c->sched_prefix = n_old_applied;
   rc = replay_impl(c);
   c->in_apply = false;
+  if (!rc && c->graph_mode == 1 && c->sched_graph_after) c->graph_mode = 0;  // (this call made the reference rebuild the hash graph)
   if (rc) { c->staged = false; return rc; }
   lap("replayed");
   // the earlier changes must have been applied again, first and in their order: rows [0, old_ops) are the state before the call
@@ -231,7 +273,7 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
       lap("document edit records on the host");
       continue;
     }
-    if (rc != AM355_E_UNSUPPORTED || need.empty() || round == 16 || need.size() > 256 || c->no_history) break;
+    if (rc != AM355_E_UNSUPPORTED || need.empty() || round == 16 || need.size() > 256 || (c->no_history && !c->doc_rows_known)) break;
     // the walk met objects that are no longer visible: what the reference's objectMeta lists for their property follows from the
     // history of the rows on it (am355_delta.hip, delta_key_history)
     std::vector<KeyHistory> st_of(need.size());
@@ -259,6 +301,8 @@ extern "C" int am355_reset(am355_ctx* c) {
   c->breaks_exact = true;
   c->children_hazard = false;
   c->no_history = false;
+  c->doc_rows_known = false;
+  c->graph_mode = 0;
   c->is_document = false;
   c->flags = 0;
   c->n_changes = 0;
@@ -270,7 +314,35 @@ extern "C" int am355_reset(am355_ctx* c) {
 extern "C" int am355_forget_call_history(am355_ctx* c, int from_document) {
   if (!c) return AM355_E_ARG;
   c->breaks_exact = false;
-  if (from_document) c->no_history = true;
+  if (from_document) {
+    // the first `from_document` staged changes are the document's: its rows are the ops of those changes, when they were applied first
+    // and in their order (the rebuilt history is a causal order: they are, unless the host staged something else)
+    c->no_history = true;
+    c->doc_rows_known = false;
+    c->graph_mode = 2;  // (whether a later call made the reference rebuild the hash graph is not known here: both are tried)
+    c->doc_n_changes = (uint32_t)from_document;
+    c->doc_head_index_known = true;
+    const uint32_t nd = (uint32_t)from_document;
+    bool ok = c->replayed && !c->is_document && nd <= c->applied_change.size();
+    for (uint32_t i = 0; ok && i < nd; i++) ok = c->applied_change[i] == i;
+    if (ok) {
+      c->doc_rows = nd < c->applied_change.size() ? c->applied_op_base[nd] : c->n_ops;
+      c->doc_rows_known = true;
+    }
+  }
+  return AM355_OK;
+}
+
+extern "C" int am355_hash_graph_known(am355_ctx* c, int set, int* known) {
+  if (!c) return AM355_E_ARG;
+  if (!c->staged) return fail(c, AM355_E_STATE, "the context holds no state");
+  if (c->is_document) {
+    if (set >= 0) c->doc_graph_known = set != 0;
+    if (known) *known = c->doc_graph_known ? 1 : 0;
+    return AM355_OK;
+  }
+  if (set >= 0 && c->graph_mode != 0) c->graph_mode = set ? 0 : 1;  // (a lineage without a document has no such state)
+  if (known) *known = c->graph_mode == 0 ? 1 : 0;
   return AM355_OK;
 }
 

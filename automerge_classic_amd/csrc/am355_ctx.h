@@ -346,6 +346,15 @@ struct am355_ctx {
   // that holds a child object (then objectMeta.children of the reference differs from the visible values: delta_key_history)
   std::vector<uint32_t> stream_breaks;
   bool breaks_exact = true, children_hazard = false, in_apply = false;
+  // Lineage that began with Backend.load: the reference schedules against the hashes it KNOWS -- the document's heads and what later
+  // calls applied -- until a round applies nothing; then it rebuilds the document's hash graph (new.js:1822-1841, computeHashGraph
+  // :1887-1912) and, in that call, forgets the hashes of the changes the call had applied so far. graph_mode: 0 = the graph is known
+  // (every other lineage), 1 = not rebuilt yet, 2 = the host replayed retained changes and does not know which (both are tried).
+  uint32_t graph_mode = 0, doc_n_changes = 0, sched_prefix = 0;
+  bool doc_head_index_known = true, sched_graph_after = true;
+  bool doc_graph_known = false;  // document context: the host served a query that makes the reference rebuild the hash graph
+  uint64_t doc_rows = 0;    // rows [0, doc_rows) of the state are the rebuilt history of a loaded document (valid while no_history)
+  bool doc_rows_known = false;
   bool no_history = false;  // the staged changes are the rebuilt history of a LOADED document: the reference's objectMeta came from one pass over the document
   DevBuf d_breaks;
   bool state_checked = false;  // the state was built by am355_apply_changes calls (each checked for what later patches depend on) or is empty

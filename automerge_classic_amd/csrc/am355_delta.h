@@ -64,6 +64,7 @@ struct DeltaBufs {
   const uint32_t* pass_rows;  // [n_pass] first row of each such pass
   uint32_t n_breaks;          // rows at which an op stream began: a call of applyChanges or a scheduling pass of one (all calls so far)
   const uint32_t* breaks;     // [n_breaks] ascending
+  uint32_t T_doc;             // rows [0, T_doc) are the rebuilt history of a document the lineage began with (Backend.load); 0: none
   uint32_t breaks_exact;      // 0: where EARLIER calls ended is not known (the staged changes were replayed in one go)
   DeltaCounts* counts;
   ObjLink* link;          // [NO]

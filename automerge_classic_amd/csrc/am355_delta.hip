@@ -979,8 +979,28 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
   bool unknown = false;
   uint32_t listed[(KH_ROWS_MAX + 31) / 32] = {};  // children[key]: bit q = the row by_id[q] is listed
   auto none_listed = [&]() { uint32_t any = 0; for (uint32_t w = 0; w < (KH_ROWS_MAX + 31) / 32; w++) any |= listed[w]; return any == 0; };
+  if (d.T_doc) {
+    // The lineage began with Backend.load: objectMeta came from ONE pass over the document's rows in id order, every row judged by
+    // the successors it had in the document (documentPatch, new.js:1604-1635 -> updatePatchProperty :893-931). A make row first puts
+    // itself into children[key] (:894-897) -- overwritten or not --, which makes the list non-empty for the refresh that follows.
+    uint32_t seen[(KH_ROWS_MAX + 31) / 32] = {};
+    bool has_child = false;
+    for (uint32_t q = 0; q < c; q++) {
+      const uint32_t i = by_id[q], r = rows[i];
+      if (r >= d.T_doc || b.kind[r] == K_DEL) continue;  // (a deletion is no row of a document)
+      const uint32_t a = o.action[r];
+      const bool is_make = (a & 1u) == 0;
+      if (death[i] >= d.T_doc) {
+        if (is_make) has_child = true;
+        if (a == 1 || is_make) seen[q >> 5] |= 1u << (q & 31);
+      }
+      if (is_make || has_child || !none_listed())
+        for (uint32_t w = 0; w < (KH_ROWS_MAX + 31) / 32; w++) listed[w] = seen[w];
+    }
+  }
   for (uint32_t j = 0; j < c && !unknown; j++) {
     const uint32_t g = rows[j];
+    if (g < d.T_doc) continue;  // (no call visited this row: it came with the document)
     const bool is_del = b.kind[g] == K_DEL;
     if (!map_prop && o.insert[g] && j > 0) { unknown = true; break; }
     // two ops of one actor on the property in a row share a merge call unless the second overwrites the first (new.js:1114-1121)

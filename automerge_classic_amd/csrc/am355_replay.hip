@@ -160,7 +160,85 @@ static int schedule(am355_ctx* c, const uint32_t* dev_amap, const uint32_t* dev_
     std::vector<uint32_t> dep_first(n), dep_count(n);
     for (uint32_t ci = 0; ci < n; ci++) { const ChangeMeta& m = metas[ci]; dep_first[ci] = (uint32_t)((m.base + m.deps_off) >> 5); dep_count[ci] = m.n_deps; }
     auto dep_of = [&](uint32_t ci, uint32_t k) { return dep_idx[dep_first[ci] + k]; };
-    for (uint32_t root = 0; root < n; root++) {
+    const bool lineage = c->in_apply && c->graph_mode != 0 && c->sched_prefix <= n;
+    if (lineage) {
+      // ---- a lineage that began with Backend.load: the retry loop itself, round by round (see am355_ctx.h graph_mode) ----
+      const uint32_t na0 = c->sched_prefix, nd = std::min(c->doc_n_changes, na0);
+      auto author_of = [&](uint32_t ci) { return rank[local_ids[local_off[ci]]]; };
+      auto group_of = [&](uint32_t ci) { return self[ci] < n ? self[ci] : ci; };
+      std::vector<uint8_t> doc_has_dependent(nd, 0);
+      for (uint32_t j = 0; j < nd; j++)
+        for (uint32_t k = 0; k < dep_count[j]; k++) { uint32_t dd = dep_of(j, k); if (dd < nd) doc_has_dependent[dd] = 1; }
+      struct Outcome { std::vector<uint32_t> pass, gpass, gpos; bool graph_after = true; uint32_t flags = 0; };
+      auto simulate = [&](bool graph_known, Outcome& o) {
+        o.pass.assign(n, NEVER); o.gpass.assign(n, NEVER); o.gpos.assign(n, 0); o.flags = 0;
+        std::vector<uint8_t> vis_dep(n, 0), vis_dup(n, 0), in_round(n, 0);  // by group: satisfies a dependency / makes a copy a duplicate
+        std::vector<uint64_t> clk(na, 0);
+        for (uint32_t i = 0; i < na0; i++) { clk[author_of(i)] = metas[i].seq; o.pass[i] = 0; o.gpass[group_of(i)] = 0; o.gpos[group_of(i)] = i; }
+        auto all_prior = [&]() {
+          std::fill(vis_dep.begin(), vis_dep.end(), 0); std::fill(vis_dup.begin(), vis_dup.end(), 0);
+          for (uint32_t i = 0; i < na0; i++) vis_dep[group_of(i)] = vis_dup[group_of(i)] = 1;
+        };
+        if (graph_known) all_prior();
+        else {
+          for (uint32_t i = nd; i < na0; i++) vis_dep[group_of(i)] = vis_dup[group_of(i)] = 1;
+          for (uint32_t i = 0; i < nd; i++)
+            if (!doc_has_dependent[i]) { vis_dup[i] = 1; vis_dep[i] = c->doc_head_index_known ? 1 : 0; }  // (a head without index: -1, new.js:1727-1729, 1563)
+        }
+        std::vector<uint32_t> queue, app, enq;
+        for (uint32_t ci = na0; ci < n; ci++) queue.push_back(ci);
+        bool graph = graph_known;
+        uint32_t round_pass = 0;
+        while (!queue.empty()) {
+          app.clear(); enq.clear();
+          std::vector<uint64_t> clk2 = clk;
+          bool aborted = false;
+          for (uint32_t ci : queue) {
+            const uint32_t F = group_of(ci);
+            if (vis_dup[F] || in_round[F]) continue;  // (new.js:1566)
+            bool ready = true;
+            for (uint32_t k = 0; k < dep_count[ci] && ready; k++) { const uint32_t dd = dep_of(ci, k); ready = dd < n && (vis_dep[dd] || in_round[dd]); }
+            const uint32_t a = author_of(ci);
+            const uint64_t expected = clk2[a] + 1;
+            if (!ready) enq.push_back(ci);
+            else if (metas[ci].seq < expected) {
+              if (graph) { o.flags |= AM355_F_BAD_SEQ; return; }  // "Reuse of sequence number"
+              aborted = true;  // (new.js:1581: nothing of this round is applied, the whole queue waits for the hash graph)
+              break;
+            } else if (metas[ci].seq > expected) { o.flags |= AM355_F_BAD_SEQ; return; }
+            else { clk2[a] = metas[ci].seq; in_round[F] = 1; app.push_back(ci); }
+          }
+          for (uint32_t ci : app) in_round[group_of(ci)] = 0;
+          if (aborted) { app.clear(); enq = queue; }
+          if (!app.empty()) {
+            for (uint32_t ci : app) { const uint32_t F = group_of(ci); o.pass[ci] = round_pass; o.gpass[F] = round_pass; o.gpos[F] = ci; vis_dep[F] = vis_dup[F] = 1; }
+            clk = clk2;
+            round_pass++;
+          }
+          queue = enq;
+          if (queue.empty()) break;
+          if (app.empty()) {
+            if (graph) break;
+            graph = true;  // computeHashGraph: the index is rebuilt from the document as it was BEFORE this call -- what the call applied so far is not in it
+            all_prior();
+          }
+        }
+        o.graph_after = graph;
+      };
+      Outcome a, b;
+      simulate(c->graph_mode != 1, a);
+      if (c->graph_mode == 2) {
+        simulate(false, b);
+        if (a.flags != b.flags || a.pass != b.pass || a.gpass != b.gpass) {
+          c->flags |= AM355_F_UNSUPPORTED;
+          return fail(c, AM355_E_UNSUPPORTED, "the schedule depends on whether the reference had rebuilt the loaded document's hash graph, which the replayed state does not tell (JS path)");
+        }
+      }
+      if (a.flags) sched_flags |= a.flags;
+      pass = a.pass; gpass = a.gpass; gpos = a.gpos;
+      c->sched_graph_after = a.graph_after;
+    }
+    for (uint32_t root = 0; root < n && !lineage; root++) {
       if ((self[root] < n ? self[root] : root) != root || gpass[root] != UNSET) continue;
       stack.push_back(root);
       while (!stack.empty()) {
@@ -722,6 +800,7 @@ static int replay_document(am355_ctx* c) {
     uint32_t* d_words = c->d_words.as<uint32_t>();
     HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, st));
     HIPCHK(c, hipMemcpyAsync(c->d_amap.p, c->doc_actor_rank.data(), 4 * (size_t)NA, hipMemcpyHostToDevice, st));
+    lap("actor ranks enqueued");
     HIPCHK(c, hipEventRecord(c->ev_b0, st));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_b0, 0));
     KeyStage ks;
@@ -732,9 +811,11 @@ static int replay_document(am355_ctx* c) {
     // (the key stream needs no host decision any more: both halves are enqueued at once and run beside the token index)
     keystr_index_finish(ks, false, &ks_start, &ks_off, &ks_len, d_words + W_FLAGS_B, c->stream2);
     HIPCHK(c, hipEventRecord(c->ev_b1, c->stream2));
+    lap("key stream enqueued");
     BigColInfo* hi = c->h_biginfo.as<BigColInfo>();
     bigcol_index_tokens(c->d_arena.as<uint8_t>(), d, w, st);
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
+    lap("token ends enqueued");
     HIPCHK(c, hipStreamSynchronize(st));  // number count: everything after runs over numbers, not bytes
     bigcol_index_records(c->d_arena.as<uint8_t>(), d, w, hi->n_tokens, st);
     HIPCHK(c, hipMemcpyAsync(hi, w.info, sizeof(BigColInfo), hipMemcpyDeviceToHost, st));
@@ -965,6 +1046,8 @@ int replay_impl(am355_ctx* c) {
   if (tot.flags_a) { (void)hipStreamSynchronize(sa); (void)hipStreamSynchronize(sb); return error_for_flags(c, tot.flags_a, "malformed change"); }
   c->has_unknown_cols = tot.reserved[0] != 0;
   bool fast = tot.fast_a == 0;
+  const bool lineage_schedule = c->in_apply && c->graph_mode != 0;  // (a lineage that began with Backend.load: the host's round-by-round scheduler, see schedule())
+  if (lineage_schedule) fast = false;
   if (tot.n_distinct > distinct_capacity()) fast = false;  // thousands of actors: the general path interns them on the host
   const bool planned = !tot.fallback && !getenv("AM355_HOST_PLAN");
   std::vector<uint32_t> slot_rank;
@@ -1024,7 +1107,7 @@ int replay_impl(am355_ctx* c) {
     // the device's actor tables, when its list of distinct ids holds them all (else the host interns)
     const bool dev_actors = tot.n_distinct <= distinct_capacity() && !(tot.fast_a & FF_CAPACITY) && tot.total_entries <= c->amap_cap;
     bool served = false;
-    const bool host_schedule = getenv("AM355_HOST_SCHEDULE") != nullptr;  // (A/B and tests: the host's scheduler for every batch)
+    const bool host_schedule = getenv("AM355_HOST_SCHEDULE") != nullptr || lineage_schedule;  // (A/B and tests: the host's scheduler for every batch)
     if (dev_actors && planned && !host_schedule && n > 0) {
       // The scheduler runs on the device (am355_sched.hip): pass numbers by relaxation over the dependency indexes stream B resolved,
       // application order by a stable sort, the decode plans in that order. The host reads the totals from the pinned words, launches
@@ -1145,6 +1228,8 @@ int replay_impl(am355_ctx* c) {
     c->breaks_exact = true;
     c->children_hazard = false;
     c->no_history = false;
+    c->doc_rows_known = false;
+    c->graph_mode = 0;
   }
   return AM355_OK;
 }

@@ -294,6 +294,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   if (!c || !doc) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }
+  c->doc_graph_known = false;
   c->staged = c->replayed = c->ir_fetched = false;
   c->history_ok = false;
   c->is_document = true;

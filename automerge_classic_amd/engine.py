@@ -95,10 +95,11 @@ def _bind(path):
     L.am355_sync_bloom_probe.argtypes = [vp, vp, u32, u32, u32, u32, vp, ctypes.c_size_t, vp]
     L.am355_get_pending.argtypes = [vp, vp, ctypes.POINTER(u32)]
     L.am355_forget_call_history.argtypes = [vp, ctypes.c_int]
+    L.am355_hash_graph_known.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.am355_set_phase_events.argtypes = [vp, ctypes.c_int]
     for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
-              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_forget_call_history", "am355_set_phase_events", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
+              "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_forget_call_history", "am355_hash_graph_known", "am355_set_phase_events", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
         getattr(L, f).restype = ctypes.c_int
     return L
 
@@ -178,9 +179,17 @@ class Engine:
         self._check(self._L.am355_reset(self._h))
         self._n_changes = 0
 
-    def forget_call_history(self, from_document=False):
-        """The staged changes were replayed in one go, not by the Backend.applyChanges calls that built the state (include/am355.h)."""
-        self._check(self._L.am355_forget_call_history(self._h, 1 if from_document else 0))
+    def forget_call_history(self, doc_changes=0):
+        """The staged changes were replayed in one go, not by the Backend.applyChanges calls that built the state; doc_changes: how
+        many of the leading ones are the rebuilt history of a loaded document (include/am355.h)."""
+        self._check(self._L.am355_forget_call_history(self._h, int(doc_changes)))
+
+    def hash_graph_known(self, set_to=None):
+        """Lineage that began with a loaded document: has the reference rebuilt the document's hash graph (include/am355.h)?
+        set_to True / False tells the engine; returns the state afterwards."""
+        known = ctypes.c_int(0)
+        self._check(self._L.am355_hash_graph_known(self._h, -1 if set_to is None else (1 if set_to else 0), ctypes.byref(known)))
+        return bool(known.value)
 
     def pending(self):
         """Indexes (into the engine's list of changes) of the changes still queued for a missing dependency."""

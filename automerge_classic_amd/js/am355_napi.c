@@ -231,18 +231,35 @@ static napi_value js_applied_order(napi_env env, napi_callback_info info) {
   return ta;
 }
 
-/* forgetCallHistory(ctx, fromDocument): am355_forget_call_history (the staged changes were replayed in one go, not by the calls that built the state) */
+/* forgetCallHistory(ctx, docChanges): am355_forget_call_history (the staged changes were replayed in one go, not by the calls that built the state) */
 static napi_value js_forget_call_history(napi_env env, napi_callback_info info) {
   size_t argc = 2;
   napi_value argv[2];
   NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   am355_ctx *ctx = get_ctx(env, argv[0]);
   if (!ctx) return NULL;
-  bool from_document = false;
-  if (argc > 1) NAPI_CALL(env, napi_get_value_bool(env, argv[1], &from_document));
-  int rc = am355_forget_call_history(ctx, from_document ? 1 : 0);
+  uint32_t doc_changes = 0;  /* how many of the leading staged changes are the rebuilt history of a loaded document (0: none) */
+  if (argc > 1) NAPI_CALL(env, napi_get_value_uint32(env, argv[1], &doc_changes));
+  int rc = am355_forget_call_history(ctx, (int)doc_changes);
   if (rc) return throw_engine(env, ctx, rc);
   return NULL;
+}
+
+/* hashGraphKnown(ctx, set) -> boolean: am355_hash_graph_known (set: 1 / 0 / -1 = only ask) */
+static napi_value js_hash_graph_known(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  int32_t set = -1;
+  if (argc > 1) NAPI_CALL(env, napi_get_value_int32(env, argv[1], &set));
+  int known = 1;
+  int rc = am355_hash_graph_known(ctx, (int)set, &known);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value out;
+  NAPI_CALL(env, napi_get_boolean(env, known != 0, &out));
+  return out;
 }
 
 /* pendingOrder(ctx) -> Uint32Array: am355_get_pending (the changes still queued, as indexes into the engine's list of changes) */
@@ -510,6 +527,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"applyChanges", NULL, js_apply_changes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"pendingOrder", NULL, js_pending_order, NULL, NULL, NULL, napi_enumerable, NULL},
       {"forgetCallHistory", NULL, js_forget_call_history, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"hashGraphKnown", NULL, js_hash_graph_known, NULL, NULL, NULL, napi_enumerable, NULL},
       {"reset", NULL, js_reset, NULL, NULL, NULL, napi_enumerable, NULL},
       {"depGraph", NULL, js_dep_graph, NULL, NULL, NULL, napi_enumerable, NULL},
       {"bloomBuild", NULL, js_bloom_build, NULL, NULL, NULL, napi_enumerable, NULL},

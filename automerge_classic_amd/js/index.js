@@ -122,13 +122,13 @@ function hydrate(backend) {
   const g = backend.state
   if (!g.js) {
     counters.hydrations++
-    if (g.doc) g.js = ref().load(g.doc)
+    if (g.doc) { g.js = ref().load(g.doc); if (g.graphKnown && !g.js.state.haveHashGraph) g.js.state.computeHashGraph() }
     else if (HYDRATE_FROM_DOC && !JS_ONLY) {
       // hydrate the JS BackendDoc from the engine's save() bytes: Backend.load of a document is several times cheaper in JS than
       // replaying every change (opt-in: MI355X_HYDRATE=doc; the default replays the retained changes, exact by construction)
       let bytes = null
       try {
-        if (!contextOf(g.generation)) { gpuReplay(g.changes); g.generation = generation }
+        if (!contextOf(g.generation)) replayForReading(g)
         bytes = addon.save(ctx, 0)
       } catch (e) {
         if (e.am355Code !== AM355_E_INVALID && e.am355Code !== AM355_E_UNSUPPORTED) throw e
@@ -136,7 +136,9 @@ function hydrate(backend) {
       g.js = bytes ? ref().load(bytes) : ref().loadChanges(ref().init(), g.changes)
     } else if (g.batches) {
       let handle = g.baseDoc ? ref().load(g.baseDoc) : ref().init()
-      for (const batch of g.batches) handle = ref().loadChanges(handle, batch)
+      for (const batch of g.batches) {
+        if (batch === GRAPH_QUERY) { if (!handle.state.haveHashGraph) handle.state.computeHashGraph() } else handle = ref().loadChanges(handle, batch)
+      }
       g.js = handle
     } else g.js = ref().loadChanges(ref().init(), g.changes)
   }
@@ -169,13 +171,28 @@ function gpuReplay(changes) {
 }
 
 // The retained changes of `g` replayed into a fresh context, in one go. When that is not how the state came to be -- several calls
-// built it, or it was loaded from a document -- the engine is told: the few patches of later applyChanges calls that depend on where
-// the reference's calls ended, or on an objectMeta made from a document, are then refused instead of guessed (am355_forget_call_history)
+// built it, or its lineage began with a loaded document -- the engine is told (am355_forget_call_history: how many of the leading changes
+// are the document's): the few patches of later applyChanges calls that depend on where the reference's calls ended, or on whether it
+// had rebuilt the document's hash graph by then, are refused instead of guessed
 function replayRetained(g) {
   gpuReplay(g.changes)
   g.generation = generation
   g.fromChanges = true
-  if (g.calls > 1 || g.fromDocument || g.doc) addon.forgetCallHistory(ctx, !!(g.fromDocument || g.doc))
+  if (g.calls > 1 || g.fromDocument || g.doc) addon.forgetCallHistory(ctx, g.doc ? g.changes.length : (g.docChanges || 0))
+  if (g.fromDocument || g.doc) addon.hashGraphKnown(ctx, g.graphKnown ? 1 : 0)
+}
+
+// A lineage that began with a loaded document can hold queued changes whose dependencies ARE in the document: the call in which the
+// reference rebuilt its hash graph forgot the hashes of what it had applied before (new.js:1837-1840), and what depended on those waits
+// for the next call. A replay of all retained changes would apply them too early: such a state is replayed from its APPLIED changes
+// only, and the next applyChanges hands the queue over behind its batch (the reference's queue is batch ++ queue, new.js:1822).
+const heldBack = g => !!(g.fromDocument && g.pendingIdx && g.pendingIdx.length > 0)
+const appliedOnly = g => Array.from(g.applied, i => g.changes[i])
+function replayForReading(g) {   // whole-document patch / save of a state whose context has moved on
+  if (heldBack(g)) return gpuReplay(appliedOnly(g))   // (the context then holds nobody's list: g.generation stays as it is)
+  const patch = gpuReplay(g.changes)
+  g.generation = generation
+  return patch
 }
 
 function init() {
@@ -214,7 +231,7 @@ function getPatch(backend) {
       // a state made by applyChanges: the whole-document patch is built when somebody asks for it (the engine context that
       // replayed the state still holds its record tables, else the retained changes are replayed)
       if (contextOf(g.generation)) g.patch = gpuPatch()
-      else { g.patch = gpuReplay(g.changes); g.generation = generation }
+      else g.patch = replayForReading(g)
     }
     return g.patch
   }
@@ -255,7 +272,7 @@ function save(backend) {
   if (!JS_ONLY && g instanceof GpuState) {
     if (g.doc) return g.doc   // unchanged loaded document: the bytes it was loaded from (new.js:2034)
     try {
-      if (!contextOf(g.generation)) { counters.saveReplays++; gpuReplay(g.changes); g.generation = generation }
+      if (!contextOf(g.generation)) { counters.saveReplays++; replayForReading(g) }
       const bytes = addon.save(ctx, 0)
       counters.gpuSave++
       return bytes
@@ -273,7 +290,20 @@ function gpuHistory(backend, withQueue) {
   const g = backend.state
   if (JS_ONLY || !(g instanceof GpuState) || g.js) return null
   if (g.doc && !g.changes && !g.noHistory) loadedHistory(g)
+  if (heldBack(g)) return null   // (its context list is not g.changes: the reference path, on the handle hydrate() makes call by call)
   return g.changes && g.applied && (g.pending === 0 || withQueue) ? g : null
+}
+// A BackendDoc made by load() rebuilds its hash graph IN PLACE when it is asked for changes, a change by hash, missing dependencies or
+// a clone (new.js:1774, 1922, 1980, 2000, 2015) -- and schedules later applyChanges calls differently from then on (new.js:1826-1840).
+// The wrapper serves those queries without a BackendDoc: it remembers that the reference would have the graph (am355_hash_graph_known).
+const GRAPH_QUERY = Object.freeze([])   // (in GpuState.batches: here the reference rebuilt the hash graph because it was asked, see hydrate())
+function noteGraphQuery(backend) {
+  const g = backend && backend.state
+  if (g instanceof GpuState && (g.doc || g.fromDocument) && !g.graphKnown) {
+    g.graphKnown = true
+    if (g.batches) g.batches = g.batches.concat([GRAPH_QUERY])
+    if (g.js && !g.js.state.haveHashGraph) g.js.state.computeHashGraph()
+  }
 }
 // History of a LOADED document (new.js:1887-1912 computeHashGraph, columnar.js:876-981): the engine rebuilds the binary changes
 // and their hashes from the rows it decoded (am355_doc_changes) -- once, on the first history query, as the reference defers it.
@@ -308,12 +338,14 @@ function hashIndex(g) {
 }
 function getAllChanges(backend) {   // new.js:1924-1927: BackendDoc.changes in application order (queued changes are not among them)
   isFrozenCheck(backend)
+  noteGraphQuery(backend)
   const g = gpuHistory(backend, true)
   if (g) return Array.from(g.applied, i => g.changes[i])
   return ref().getAllChanges(hydrate(backend))
 }
 function getChanges(backend, haveDeps) {   // backend.js:152-157, new.js:1921-1976
   isFrozenCheck(backend)
+  noteGraphQuery(backend)
   if (!Array.isArray(haveDeps)) throw new TypeError('Pass an array of hashes to Backend.getChanges()')
   const g = gpuHistory(backend, true)
   if (g) return changesSince(g, haveDeps).map(i => g.changes[i])
@@ -321,12 +353,14 @@ function getChanges(backend, haveDeps) {   // backend.js:152-157, new.js:1921-19
 }
 function getChangeByHash(backend, hash) {   // new.js:1999-2002 (applied changes only: queued ones have no index)
   isFrozenCheck(backend)
+  noteGraphQuery(backend)
   const g = gpuHistory(backend, true)
   if (g) { const i = hashIndex(g).get(hash); return i === undefined ? undefined : g.changes[i] }
   return ref().getChangeByHash(hydrate(backend), hash)
 }
 function getMissingDeps(backend, heads = []) {   // new.js:2014-2028
   isFrozenCheck(backend)
+  noteGraphQuery(backend)
   const g = gpuHistory(backend, true)
   if (g && g.pendingIdx) return missingDeps(g, heads)
   return ref().getMissingDeps(hydrate(backend), heads)
@@ -344,16 +378,36 @@ function gpuApplyChanges(backend, changes) {
     if (!g.changes) return null
   }
   if (g && !g.changes) return null
-  let entry
-  if (g) {
-    if ((g.doc && !g.fromChanges) || !(entry = contextOf(g.generation))) { replayRetained(g); entry = contextOf(generation) }
+  let entry, handed = null   // handed: queued changes that are not in the context (see heldBack), given behind the batch
+  if (g && g.doc) {
+    // an unchanged loaded document: the engine applies the batch onto the DOCUMENT in its context (am355_apply_changes rebuilds the
+    // hash graph as the reference's first applyChanges after load does, and knows that objectMeta came from the document's rows)
+    if (g.fromChanges || !(entry = contextOf(g.generation))) {
+      entry = acquireContext()
+      addon.loadDocument(ctx, g.doc)
+      addon.replay(ctx)
+      g.generation = generation
+      g.fromChanges = false
+    }
+  } else if (g) {
+    if (!(entry = contextOf(g.generation))) {
+      if (heldBack(g)) {
+        gpuReplay(appliedOnly(g))
+        addon.forgetCallHistory(ctx, g.docChanges || 0)
+        addon.hashGraphKnown(ctx, g.graphKnown ? 1 : 0)
+        handed = Array.from(g.pendingIdx, i => g.changes[i])
+      } else replayRetained(g)
+      entry = contextOf(generation)
+    }
     if (!g.applied || !g.pendingIdx) { g.applied = addon.appliedOrder(ctx); g.pendingIdx = addon.pendingOrder(ctx) }
   } else {
     entry = acquireContext()
     addon.reset(ctx)
   }
+  const docLineage = !!(g && (g.doc || g.fromDocument))
+  if (docLineage && g.graphKnown) addon.hashGraphKnown(ctx, 1)
   try {
-    addon.applyChanges(ctx, changes)
+    addon.applyChanges(ctx, handed ? changes.concat(handed) : changes)
   } catch (e) {
     entry.generation = 0   // (whatever the context holds now is nobody's state)
     throw e
@@ -370,8 +424,10 @@ function gpuApplyChanges(backend, changes) {
   state.pending = patch.pendingChanges
   state.calls = g ? g.calls + 1 : 1
   state.fromDocument = !!(g && (g.fromDocument || g.doc))
+  state.graphKnown = docLineage ? addon.hashGraphKnown(ctx, -1) : undefined   // (has this call made the reference rebuild the document's hash graph?)
+  state.docChanges = g ? (g.doc ? g.changes.length : (g.docChanges || 0)) : 0   // the leading changes that are a loaded document's
   state.baseDoc = g ? (g.baseDoc || g.doc || null) : null
-  state.batches = (g && g.batches ? g.batches : []).concat([changes.slice()])
+  state.batches = (g && g.batches ? g.batches : (g && g.doc && g.graphKnown ? [GRAPH_QUERY] : [])).concat([changes.slice()])
   counters.gpuApplyChanges++
   return [{ state, heads: patch.deps }, patch]
 }
@@ -619,10 +675,10 @@ const delegate1 = name => (backend, ...args) => ref()[name](toJs(backend), ...ar
 
 module.exports = {
   init, load, loadChanges, getPatch, getHeads, free, save, getAllChanges, getChanges, getChangeByHash, getMissingDeps,
-  clone: backend => ref().clone(hydrate(backend)),
+  clone: backend => { noteGraphQuery(backend); return ref().clone(hydrate(backend)) },
   applyChanges,
   applyLocalChange: delegate1('applyLocalChange'),
-  getChangesAdded: (b1, b2) => ref().getChangesAdded(hydrate(b1), hydrate(b2)),
+  getChangesAdded: (b1, b2) => { noteGraphQuery(b1); return ref().getChangesAdded(hydrate(b1), hydrate(b2)) },
   // sync protocol: the reference's own backend/sync.js bound to this module (boundSync above)
   generateSyncMessage: (...a) => syncModule().generateSyncMessage(...a),
   receiveSyncMessage: (...a) => syncModule().receiveSyncMessage(...a),
@@ -633,5 +689,6 @@ module.exports = {
   initSyncState: (...a) => syncModule().initSyncState(...a),
   // engine statistics of the last GPU replay (not part of the reference surface)
   _engineStats: () => (addon ? addon.stats(ctx) : null),
-  _counters: counters
+  _counters: counters,
+  _hydrate: hydrate   // (tests: the reference handle of an engine state, made the way the state came to be)
 }

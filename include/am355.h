@@ -227,8 +227,11 @@ int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
  * AM355_E_INVALID: the reference throws on this batch.  AM355_E_UNSUPPORTED: legal, but outside the subset served here -- the error
  * text names the reason (DR_* in csrc/am355_delta.h): two ops of one merge call on one list element, a list element that holds an
  * `inc` / `link` op or more than 32 value rows, a deletion whose place in the merge loop's work list is ambiguous, a property history
- * the device cannot replay (too long, or dependent on call boundaries the host did not keep), a sharded context, a state made by
- * am355_load_document.  Assignments to list elements, conflicting ones included (several values per element: one edit record per
+ * the device cannot replay (too long, or dependent on call boundaries the host did not keep), a sharded context.  A context made by
+ * am355_load_document + am355_replay IS served: Backend.applyChanges(Backend.load(doc), changes) -- the engine rebuilds the document's
+ * changes (am355_doc_changes: what computeHashGraph does in the reference), replays them as the state the batch goes onto, schedules
+ * the batch as a BackendDoc without hash graph does (am355_hash_graph_known) and takes objectMeta from the document's rows; documents
+ * am355_doc_changes refuses are refused here with its reason.  Assignments to list elements, conflicting ones included (several values per element: one edit record per
  * visible value), are served.  The host serves a refused call on the JS path.  After either error the context no longer holds a
  * state (every refusal path drops it: load again).
  */
@@ -240,10 +243,22 @@ int am355_reset(am355_ctx *ctx);
  * context of a state has moved on). Where those calls ended is then not known to the engine -- the reference's merge calls never
  * cross a call (new.js:1052-1290 runs per applyChanges), and what its objectMeta.children lists depends on them (new.js:916-931,
  * 1125-1149) --: am355_apply_changes then refuses the few patches that depend on it instead of assuming one call.
- * from_document != 0: the staged changes are the REBUILT history of a document that the reference loaded (Backend.load): its objectMeta
- * came from one pass over the document's rows (new.js:1695-1750), not from that history; patches that need what objectMeta lists for a
- * property whose child object is no longer visible are refused. Holds until am355_reset / the next am355_load_changes. */
+ * from_document = n > 0: the first n staged changes are the REBUILT history of a document that the reference loaded (Backend.load):
+ * its objectMeta came from one pass over the document's rows (new.js:1604-1635, 1695-1750), not from that history -- the delta stage
+ * replays that pass for the properties it must know (am355_delta.hip kh_simulate) --, and whether the reference has rebuilt the
+ * document's hash graph by now is unknown unless am355_hash_graph_known says: a batch whose schedule depends on it is refused.
+ * Holds until am355_reset / the next am355_load_changes. */
 int am355_forget_call_history(am355_ctx *ctx, int from_document);
+/* A BackendDoc made by Backend.load knows the hashes of the document's heads only; it rebuilds the hashes of all the document's changes
+ * (computeHashGraph, new.js:1887-1912) when an applyChanges call gets stuck on a missing dependency (new.js:1833-1840) or when
+ * getChanges / getChangeByHash / getMissingDeps / getChangesAdded / clone / applyLocalChange ask (new.js:1774, 1922, 1980, 2000, 2015,
+ * backend.js:38). Until then applyChanges schedules against what it knows, and the call that rebuilds the graph forgets the hashes
+ * of the changes it had applied so far -- both show in the patch (`pendingChanges`, `clock`, `deps`) and in the state. am355_apply_changes
+ * reproduces that for a context made by am355_load_document (and for the calls that follow); the host, which serves those queries
+ * from am355_doc_changes, says here that the reference would have the graph by now.
+ * set: 1 = the graph has been rebuilt, 0 = not yet (after am355_forget_call_history(ctx, n)), -1 = only ask. *known (may be NULL):
+ * the state after the call -- 1 for every lineage that did not begin with a document. */
+int am355_hash_graph_known(am355_ctx *ctx, int set, int *known);
 
 /* Input indexes of the changes still queued for a missing dependency (BackendDoc.queue, new.js:1866), in queue order. The engine's
  * own list of changes after am355_apply_changes is: the changes applied before the call in application order, the batch, the

@@ -6,7 +6,10 @@
 //   NODE_PATH=oracle/js_shims/node_modules [REF_BLOCK_SIZE=100000000] node oracle/js/apply_campaign.js out.jsonl SPEC...
 //   SPEC = seed:actors:steps:depth (mixed document) | t:seed:actors:rounds:burst (text) | m:seed:actors:steps:depth (see servedScenario)
 //        | l:seed:actors:steps:p2 (see listScenario) | c:seed:actors:elements:keys (see conflictScenario: its own call plan);
-//   every other SPEC yields 3 sessions
+//   every other SPEC yields 3 sessions.  With LOADED=1 in the environment every session is cut in two: the first calls build a
+//   document that is saved and loaded again (Backend.load: objectMeta from the document's rows, hash graph rebuilt on the first
+//   applyChanges), the recorded calls are those made onto the loaded document ({..., doc: base64 of the saved document}); every
+//   session a second time with the hash graph rebuilt by a query before the first call (name "...+g", graph: true).
 const fs = require('fs')
 const { splitmix, frontendScenario, textScenario, Backend } = require('./make_golden.js')
 const out = process.argv[2]
@@ -172,7 +175,9 @@ for (const spec of process.argv.slice(3)) {
   }
   const changes = f[0] === 't' ? textScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'm' ? servedScenario(+f[1], +f[2], +f[3], +f[4]) : f[0] === 'l' ? listScenario(+f[1], +f[2], +f[3], +f[4]) : frontendScenario(+f[0], +f[1], +f[2], +f[3])
   const rnd = splitmix(0xABCD + (f[0] === 't' || f[0] === 'm' || f[0] === 'l' ? +f[1] : +f[0]))
-  for (let variant = 0; variant < 3; variant++) {
+  // (LOADED: every session twice -- as loaded, and with the hash graph rebuilt by a query before the first call, "+g")
+  for (let run = 0; run < (process.env.LOADED ? 6 : 3); run++) {
+    const variant = run % 3, graphFirst = run >= 3
     let order = changes.slice()
     if (variant === 2) {
       // local shuffles: a change may arrive before its dependencies and wait in the queue
@@ -191,6 +196,18 @@ for (const spec of process.argv.slice(3)) {
     }
     let backend = Backend.init()
     const patches = []
+    let doc = null
+    if (process.env.LOADED) {
+      // cut: after a third / the big first call / two thirds of the calls (changes queued at that moment are lost with the save, as
+      // they are for any user of Backend.save)
+      const cut = Math.max(1, variant === 0 ? Math.floor(calls.length / 3) : variant === 1 ? 1 : Math.floor(2 * calls.length / 3))
+      try {
+        for (const batch of calls.splice(0, cut)) backend = Backend.applyChanges(backend, batch)[0]
+        doc = Backend.save(backend)
+        backend = Backend.load(doc)
+        if (graphFirst) Backend.getAllChanges(backend)   // (BackendDoc.getChanges rebuilds the hash graph in place, new.js:1922)
+      } catch (e) { continue }
+    }
     for (const batch of calls) {
       try {
         const [b2, patch] = Backend.applyChanges(backend, batch)
@@ -201,7 +218,10 @@ for (const spec of process.argv.slice(3)) {
         break
       }
     }
-    lines.push(JSON.stringify({ name: `${spec}#${variant}`, calls: calls.slice(0, patches.length).map(c => c.map(b64)), patches }))
+    const rec = { name: `${spec}#${variant}${graphFirst ? '+g' : ''}`, calls: calls.slice(0, patches.length).map(c => c.map(b64)), patches }
+    if (doc) rec.doc = b64(doc)
+    if (graphFirst) rec.graph = true
+    lines.push(JSON.stringify(rec))
   }
   console.error(`${spec}: ${changes.length} changes`)
 }

@@ -39,11 +39,11 @@ def _same(got, want, local=False):
     return list(g) == list(w) and all(dict(g[k]) == dict(w[k]) if k == "clock" else g[k] == w[k] for k in g)
 
 
-# The applyChanges calls of the reference's own suites (sessions that start from an empty document, chains of <= 40 calls): exactly
+# The applyChanges calls of the reference's own suites (sessions that start from an empty document or from a loaded one, chains of <= 40 calls): exactly
 # which ones the engine serves, refuses (JS path) and rejects like the reference -- by vector id, as the whole-document twin does
 # (tests/test_ref_suite_vectors.py). Refused: 15, 28, 507, 508 = hand-made batches with two ops on one list element in one merge call
 # (DR_SAME_ELEM_CALL); 501, 619 = batches the replay itself leaves to the JS path (counters / value-less rows inside lists).
-SUITE_EQUAL, SUITE_REFUSED, SUITE_REJECTED = 888, [15, 28, 501, 507, 508, 619], 4
+SUITE_EQUAL, SUITE_REFUSED, SUITE_REJECTED = 891, [15, 28, 501, 507, 508, 619], 4
 
 
 def run_vector_chains(make_engine, max_chain, max_chains=None):
@@ -54,13 +54,16 @@ def run_vector_chains(make_engine, max_chain, max_chains=None):
     equal = rejected = 0
     done = 0
     for chain in chains(vectors):
-        if "doc" in vectors[chain[0]] or len(chain) > max_chain:
+        if len(chain) > max_chain:
             continue
         if max_chains is not None and done >= max_chains:
             break
         done += 1
         eng = make_engine()
         try:
+            if "doc" in vectors[chain[0]]:  # the session starts from Backend.load(doc): the batch goes onto the loaded document
+                eng.load_document(pool[vectors[chain[0]]["doc"]])
+                eng.replay()
             for j in chain:
                 v = vectors[j]
                 try:
@@ -103,6 +106,11 @@ def run_campaign(make_engine, names=None, fixture="apply_campaign.json.gz"):
         eng = make_engine()
         given = []
         try:
+            if "doc" in s:  # the session goes onto a LOADED document (Backend.load(doc), then applyChanges)
+                eng.load_document(base64.b64decode(s["doc"]))
+                eng.replay()
+                if s.get("graph"):  # the reference had been asked for the document's changes before the first call (new.js:1922)
+                    assert eng.hash_graph_known(True)
             for ci, (call, want) in enumerate(zip(s["calls"], s["patches"])):
                 batch = [pool[k] for k in call]
                 given += batch
@@ -302,6 +310,60 @@ def test_state_replayed_in_one_go_is_served_or_refused_emulated(emu_lib):
     assert equal >= 30
 
 
+def test_loaded_lineage_replayed_in_one_go_emulated(emu_lib):
+    """A state whose lineage began with Backend.load, replayed into a fresh context from its retained changes (the JS host does that
+    when the context has moved on): the rebuilt changes of the document + what the calls since applied + what is queued, in one go,
+    with am355_forget_call_history(ctx, number of document changes). Told whether the reference has rebuilt the hash graph by then
+    (am355_hash_graph_known, which the host reads after every call) the engine goes on exactly like the context that made the calls;
+    not told, it serves a call only when both answers give the same schedule -- never a different patch."""
+    sessions, pool = load_campaign("apply_campaign_loaded.json.gz")
+    told_equal = untold_equal = untold_refused = 0
+    for name in ("m:51:3:120:2#2", "m:52:4:160:3#1", "m:55:2:100:3#1", "l:57:4:120:10#0", "m:56:6:140:2#2+g", "61:3:70:2#1"):
+        s = next(x for x in sessions if x["name"] == name)
+        doc = base64.b64decode(s["doc"])
+        for tell in (True, False):
+            eng = engine.Engine(0, emu_lib)
+            try:
+                eng.load_document(doc)
+                eng.replay()
+                if s.get("graph"):
+                    eng.hash_graph_known(True)
+                arena, offs, _ = eng.doc_changes(deflate=False)
+                history = [bytes(arena[int(offs[i]):int(offs[i + 1])]) for i in range(len(offs) - 1)]
+                listed, n_applied = list(history), len(history)  # the engine's list of changes, as the JS host keeps it: applied ++ queued
+                for ci, (call, want) in enumerate(zip(s["calls"], s["patches"])):
+                    batch = [pool[k] for k in call]
+                    if ci % 3 == 1:  # the context "moved on"
+                        known = eng.hash_graph_known()
+                        eng.close()
+                        eng = engine.Engine(0, emu_lib)
+                        # (the APPLIED changes only: a change queued because the reference forgot a hash while it rebuilt the graph must
+                        # not be applied before the next call -- it is handed over behind that call's batch, new.js:1822)
+                        eng.load_changes(ChangeLog.from_changes(listed[:n_applied]))
+                        eng.replay()
+                        eng.forget_call_history(len(history))
+                        if tell:
+                            assert eng.hash_graph_known(known) == known
+                        batch = batch + listed[n_applied:]
+                        listed = listed[:n_applied]
+                    try:
+                        eng.apply_changes(ChangeLog.from_changes(batch))
+                        got = eng.apply_patch_json()
+                    except engine.UnsupportedChanges:
+                        assert not tell, f"{name} call {ci}: refused although the host told what it knows"
+                        untold_refused += 1
+                        break
+                    assert not isinstance(want, dict) and same_patch(got, want), f"{name} call {ci} (told: {tell}):\n{got}\n{want}"
+                    told_equal += tell
+                    untold_equal += not tell
+                    applied, pending = eng.applied(), eng.pending()
+                    full = listed[:n_applied] + batch + listed[n_applied:]  # (the engine's list: applied before ++ batch ++ queued before)
+                    listed, n_applied = [full[i] for i in applied] + [full[i] for i in pending], len(applied)
+            finally:
+                eng.close()
+    assert told_equal >= 60 and untold_equal >= 20, (told_equal, untold_equal, untold_refused)
+
+
 def test_list_assignment_sessions_emulated(emu_lib):
     """Lists whose elements are assigned to (`list[i] = v`), concurrently, against deletions, inside one merge call with the
     reference's index lag (oracle/js/apply_campaign.js listScenario): a slice of tests/golden/apply_campaign_lists.json.gz."""
@@ -319,9 +381,27 @@ def test_wide_conflict_sessions_emulated(emu_lib):
     assert equal == 35 and refused == 0
 
 
+def test_sessions_onto_loaded_documents_emulated(emu_lib):
+    """Backend.applyChanges onto Backend.load(doc) (tests/golden/apply_campaign_loaded.json.gz, oracle/make_apply_campaign.py LOADED_SPECS:
+    the first calls of a campaign session are saved and loaded again by the live reference, the recorded calls go onto the loaded
+    document). The engine rebuilds the document's changes on the device, schedules the batch the way the reference does while it has
+    not rebuilt the hash graph (the document's heads are all it knows; a round that applies nothing makes it rebuild the graph and
+    forget what the call applied so far, new.js:1822-1841 -- visible as `pendingChanges` in these patches) and takes objectMeta from
+    one pass over the document's rows. Every session also with the graph rebuilt by a query before the first call ("+g":
+    am355_hash_graph_known). All 48 sessions / 684 calls: every call served, every patch the live reference's."""
+    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), fixture="apply_campaign_loaded.json.gz")
+    assert equal == 684 and refused == 0
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # GPU
 # ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_sessions_onto_loaded_documents_gpu():
+    equal, refused = run_campaign(lambda: engine.Engine(0), fixture="apply_campaign_loaded.json.gz")
+    assert equal == 684 and refused == 0
+
+
 @pytest.mark.gpu
 def test_wide_conflict_sessions_gpu():
     equal, refused = run_campaign(lambda: engine.Engine(0), fixture="apply_campaign_conflicts.json.gz")
