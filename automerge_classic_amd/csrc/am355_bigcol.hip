@@ -61,12 +61,6 @@ void bigcol_carve_vals(BigColVals& v, void* base, uint32_t n_rows, uint32_t n_su
 }
 
 // ---- tokens -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void kb_term_flags(const uint8_t* __restrict__ arena, uint32_t n, uint32_t* __restrict__ flags) {
-  uint32_t i = gtid();
-  if (i < n) flags[i] = (arena[i] & 0x80) ? 0u : 1u;
-  else if (i == n) flags[n] = 0;
-}
-
 __global__ __launch_bounds__(BLOCK) void kb_token_ends(const uint8_t* __restrict__ arena, uint32_t n, const uint32_t* __restrict__ term_ex,
                                                        uint32_t* __restrict__ tok_end) {
   uint32_t i = gtid();
@@ -196,8 +190,7 @@ __global__ __launch_bounds__(WAVE) void kb_col_rows(BigColWork w) {
 void bigcol_index_tokens(const uint8_t* arena, const BigColDesc& d, BigColWork& w, hipStream_t st) {
   uint32_t L = d.tok_bytes;
   (void)hipMemsetAsync(w.info, 0, sizeof(BigColInfo), st);
-  AM355_LAUNCH_INDEPENDENT(kb_term_flags, grid_for(L + 1), dim3(BLOCK), st, arena, L, w.term_ex);
-  exclusive_scan_u32(w.term_ex, w.term_ex, L + 1, &w.info->n_tokens, w.scan_ws, st);
+  exclusive_scan_terminators(arena, L, w.term_ex, &w.info->n_tokens, w.scan_ws, st);  // (index of every number = terminators in front of it)
   AM355_LAUNCH_INDEPENDENT(kb_col_ranges, dim3(1), dim3(WAVE), st, d, (const uint32_t*)w.term_ex, w.info);
   AM355_LAUNCH_INDEPENDENT(kb_token_ends, grid_for(L), dim3(BLOCK), st, arena, L, (const uint32_t*)w.term_ex, w.tok_end);
 }

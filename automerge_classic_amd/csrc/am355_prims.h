@@ -8,6 +8,8 @@ namespace am355 {
 size_t scan_workspace_bytes(uint32_t n);
 // out[i] = sum(in[0..i)); in == out allowed. *d_total (device, optional) receives the grand total.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total, void* ws, hipStream_t st);
+// out[i] = number of bytes in [0, i) with bit 7 clear (LEB128 terminators), i = 0 .. L: the scan of a flag array that is never stored
+void exclusive_scan_terminators(const uint8_t* bytes, uint32_t L, uint32_t* out, uint32_t* d_total, void* ws, hipStream_t st);
 // two scans over the same range in one pass (same workspace size); in == out allowed, totals optional
 void exclusive_scan2_u32(const uint32_t* in_a, uint32_t* out_a, uint32_t* d_total_a, const uint32_t* in_b, uint32_t* out_b, uint32_t* d_total_b, uint32_t n,
                          void* ws, hipStream_t st);

@@ -237,6 +237,61 @@ void exclusive_scan2_u32(const uint32_t* in_a, uint32_t* out_a, uint32_t* d_tota
                      (uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
+// ---- exclusive scan of the LEB128 terminator predicate of a byte string ----
+// element i (i < L) = 1 if byte i has bit 7 clear (it ends a number), element L = 0; out has L + 1 entries. The flags are never
+// stored: the two passes read the bytes themselves (1 byte per element instead of a 4-byte flag written once and read twice).
+__device__ __forceinline__ void term_load(const uint8_t* __restrict__ bytes, uint32_t L, uint32_t base, uint32_t (&v)[SCAN_ITEMS]) {
+  static_assert(SCAN_ITEMS == 8, "a thread's stretch is one 8-byte load");
+  if ((((uintptr_t)(bytes + base)) & 7) == 0 && base + SCAN_ITEMS <= L) {
+    const unsigned long long x = *(const unsigned long long*)(bytes + base);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) v[j] = (uint32_t)((x >> (8 * j + 7)) & 1ull) ^ 1u;
+  } else {
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) { uint32_t i = base + j; v[j] = i < L ? ((bytes[i] >> 7) ^ 1u) : 0u; }
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_scan_term_sums(const uint8_t* __restrict__ bytes, uint32_t L, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t s[BLOCK / WAVE];
+  uint32_t v[SCAN_ITEMS];
+  term_load(bytes, L, blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS, v);
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) sum += v[j];
+  uint32_t total = block_sum_u32(sum, s);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+// (tile_sums: exclusive prefixes, by k_scan_sums)
+__global__ __launch_bounds__(BLOCK) void k_scan_term_apply(const uint8_t* __restrict__ bytes, uint32_t L, uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t s[BLOCK / WAVE];
+  const uint32_t n = L + 1;
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  term_load(bytes, L, base, v);
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) sum += v[j];
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan_u32(sum, s, &total) + tile_sums[blockIdx.x];
+  uint32_t o[SCAN_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) { o[j] = ex; ex += v[j]; }
+  if ((((uintptr_t)(out + base)) & 15) == 0 && base + SCAN_ITEMS <= n) {
+    *(uint4*)(out + base) = uint4{o[0], o[1], o[2], o[3]};
+    *(uint4*)(out + base + 4) = uint4{o[4], o[5], o[6], o[7]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] = o[j];
+  }
+}
+void exclusive_scan_terminators(const uint8_t* bytes, uint32_t L, uint32_t* out, uint32_t* d_total, void* ws, hipStream_t st) {
+  const uint32_t n = L + 1, n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t* sums = (uint32_t*)ws;
+  hipLaunchKernelGGL(k_scan_term_sums, dim3(n_tiles), dim3(BLOCK), 0, st, bytes, L, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, st, sums, n_tiles, d_total);
+  hipLaunchKernelGGL(k_scan_term_apply, dim3(n_tiles), dim3(BLOCK), 0, st, bytes, L, out, (const uint32_t*)sums);
+}
+
 size_t scan_workspace_bytes(uint32_t n) { return 2 * sizeof(uint32_t) * ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 2); }  // (room for a dual scan)
 
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total, void* ws, hipStream_t st) {
@@ -429,15 +484,20 @@ constexpr uint32_t CH_TILE = 4096;
 constexpr uint32_t CH_PER = CH_TILE / BLOCK;
 constexpr int CH_ROUNDS = 12;  // 2^12 = CH_TILE
 
+// flagw / cstartw: one BIT per position (entry node / entry node reached from a start of an earlier tile); the caller zeroes them
 __global__ __launch_bounds__(BLOCK) void kc_tile_exits(const uint32_t* __restrict__ next, uint32_t n, const uint32_t* __restrict__ mark,
-                                                       uint32_t* __restrict__ exit1, uint32_t* __restrict__ flag, uint32_t* __restrict__ cstart) {
+                                                       uint32_t* __restrict__ exit1, uint32_t* __restrict__ flagw, uint32_t* __restrict__ cstartw) {
   __shared__ uint32_t cur[CH_TILE];
   uint32_t base = blockIdx.x * CH_TILE, t = threadIdx.x;
   uint32_t end = base + CH_TILE < n ? base + CH_TILE : n;
   for (uint32_t k = 0; k < CH_PER; k++) {
     uint32_t l = t + k * BLOCK, g = base + l;
     uint32_t c = g < n ? next[g] : NONE32;
-    cur[l] = (c >= n || c <= g) ? NONE32 : c;  // a chain that does not move forward ends (callers guarantee next > i)
+    c = (c >= n || c <= g) ? NONE32 : c;  // a chain that does not move forward ends (callers guarantee next > i)
+    cur[l] = c;
+    // the distinct exit targets of the tile are the successors of the LAST in-tile node of every chain: one atomic per chain that
+    // leaves the tile, not one store per position
+    if (c != NONE32 && c >= end) atomicOr(&flagw[c >> 5], 1u << (c & 31));
   }
   __syncthreads();
   // in place: every value is always some node further along the same chain, so stale reads only slow the doubling down
@@ -454,22 +514,35 @@ __global__ __launch_bounds__(BLOCK) void kc_tile_exits(const uint32_t* __restric
     if (g >= n) continue;
     uint32_t c = cur[l];
     exit1[g] = c;
-    if (c < n) {
-      flag[c] = 1;
-      if (mark[g]) cstart[c] = 1;
-    }
+    if (c < n && mark[g]) atomicOr(&cstartw[c >> 5], 1u << (c & 31));
   }
 }
 
-__global__ __launch_bounds__(BLOCK) void kc_compact(uint32_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ ex, const uint32_t* __restrict__ exit1,
-                                                    const uint32_t* __restrict__ cstart, uint32_t* __restrict__ cpos, uint32_t* __restrict__ cnext,
-                                                    uint32_t* __restrict__ cmark) {
-  uint32_t i = gtid();
-  if (i >= n || !flag[i]) return;
-  uint32_t id = ex[i], e = exit1[i];
-  cpos[id] = i;
-  cnext[id] = e < n ? ex[e] : NONE32;
-  cmark[id] = cstart[i];
+// entry nodes per 32 positions (their ranks follow from the exclusive scan of these counts)
+__global__ __launch_bounds__(BLOCK) void kc_word_counts(const uint32_t* __restrict__ flagw, uint32_t n_words, uint32_t* __restrict__ cnt) {
+  uint32_t w = gtid();
+  if (w < n_words) cnt[w] = (uint32_t)__popc(flagw[w]);
+}
+
+// one thread per word of the entry bitmap: node id = rank of the bit; its successor = rank of its exit target
+__global__ __launch_bounds__(BLOCK) void kc_compact(uint32_t n, uint32_t n_words, const uint32_t* __restrict__ flagw, const uint32_t* __restrict__ wrank,
+                                                    const uint32_t* __restrict__ exit1, const uint32_t* __restrict__ cstartw, uint32_t* __restrict__ cpos,
+                                                    uint32_t* __restrict__ cnext, uint32_t* __restrict__ cmark) {
+  uint32_t w = gtid();
+  if (w >= n_words) return;
+  uint32_t bits = flagw[w];
+  if (!bits) return;
+  const uint32_t starts = cstartw[w];
+  uint32_t id = wrank[w];
+  while (bits) {
+    const uint32_t b = (uint32_t)__ffs((int)bits) - 1;
+    bits &= bits - 1;
+    const uint32_t i = 32 * w + b, e = exit1[i];
+    cpos[id] = i;
+    cnext[id] = e < n ? wrank[e >> 5] + (uint32_t)__popc(flagw[e >> 5] & ((1u << (e & 31)) - 1u)) : NONE32;
+    cmark[id] = (starts >> b) & 1u;
+    id++;
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void kc_round(const uint32_t* __restrict__ n_nodes, const uint32_t* __restrict__ jin, uint32_t* __restrict__ jout,
@@ -543,15 +616,18 @@ void chain_mark(const uint32_t* next, uint32_t n, uint32_t* mark, void* work, hi
   if (!n) return;
   size_t cap = ((size_t)n + 2 + 63) & ~(size_t)63;
   uint32_t* p = (uint32_t*)work;
-  uint32_t *exit1 = p, *flag = p + cap, *cstart = p + 2 * cap, *ex = p + 3 * cap, *cpos = p + 4 * cap, *ca = p + 5 * cap, *cb = p + 6 * cap, *cmark = p + 7 * cap;
+  // (flagw | cstartw: bitmaps over the positions, in the first array; wcnt / wrank: per bitmap word)
+  const uint32_t n_words = (uint32_t)((cap + 31) / 32);
+  uint32_t *exit1 = p + cap, *flagw = p, *cstartw = p + n_words, *wrank = p + 2 * cap, *cpos = p + 4 * cap, *ca = p + 5 * cap, *cb = p + 6 * cap, *cmark = p + 7 * cap;
   uint32_t* n_nodes = p + 8 * cap;
   void* scan_ws = (void*)(n_nodes + 64);
   uint32_t tiles = (n + CH_TILE - 1) / CH_TILE;
-  (void)hipMemsetAsync(flag, 0, 2 * 4 * cap, st);  // flag and cstart
-  hipLaunchKernelGGL(kc_tile_exits, dim3(tiles), dim3(BLOCK), 0, st, next, n, (const uint32_t*)mark, exit1, flag, cstart);
-  exclusive_scan_u32(flag, ex, n + 1, n_nodes, scan_ws, st);
-  AM355_LAUNCH_INDEPENDENT(kc_compact, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, n, (const uint32_t*)flag, (const uint32_t*)ex, (const uint32_t*)exit1,
-                           (const uint32_t*)cstart, cpos, ca, cmark);
+  (void)hipMemsetAsync(flagw, 0, 2 * 4 * (size_t)n_words, st);
+  hipLaunchKernelGGL(kc_tile_exits, dim3(tiles), dim3(BLOCK), 0, st, next, n, (const uint32_t*)mark, exit1, flagw, cstartw);
+  AM355_LAUNCH_INDEPENDENT(kc_word_counts, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), st, (const uint32_t*)flagw, n_words, wrank);
+  exclusive_scan_u32(wrank, wrank, n_words, n_nodes, scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kc_compact, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), st, n, n_words, (const uint32_t*)flagw, (const uint32_t*)wrank,
+                           (const uint32_t*)exit1, (const uint32_t*)cstartw, cpos, ca, cmark);
   // a compact chain visits every tile at most once
   int rounds = 1;
   while (rounds < 32 && ((tiles + 1) >> rounds)) rounds++;

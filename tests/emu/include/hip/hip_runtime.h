@@ -210,6 +210,7 @@ inline unsigned __lane_id() { return emu::in_coop ? emu::cur_lane : (threadIdx.x
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
 inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 

@@ -19,7 +19,7 @@ def main():
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     q = f"select s.display_name, d.start, d.end, {('d.' + qcol) if qcol else '0'} from {disp} d join {sym} s on d.kernel_id=s.id order by d.start"
     rows = list(cur.execute(q))
-    anchor = sys.argv[3] if len(sys.argv) > 3 else "k_parse_changes"   # (document loads: kb_term_flags)
+    anchor = sys.argv[3] if len(sys.argv) > 3 else "k_parse_changes"   # (document loads: k_scan_term_sums)
     marks = [i for i, r in enumerate(rows) if anchor in r[0]]
     a = marks[which]
     b = marks[which + 1] if which + 1 < 0 or which + 1 < len(marks) and which >= 0 else len(rows)
