@@ -13,7 +13,7 @@ const addon = require(path.join(__dirname, 'am355_napi.node'))
 const { materialize } = require('./materialize.js')
 
 const file = process.argv[2] || path.join(__dirname, '..', '..', 'tests', 'golden', 'ref_apply_vectors.json.gz')
-const maxChain = parseInt(process.argv[3] || '40'), maxSessions = parseInt(process.argv[4] || '1000000')
+const maxChain = parseInt(process.argv[3] || '1000000'), maxSessions = parseInt(process.argv[4] || '1000000')
 const d = JSON.parse(zlib.gunzipSync(fs.readFileSync(file)).toString('utf8'))
 const pool = d.pool.map(x => new Uint8Array(Buffer.from(x, 'base64')))
 const V = d.vectors || []
@@ -39,6 +39,11 @@ if (d.sessions) {
     if (sessions >= maxSessions) break
     sessions++
     addon.reset(ctx)
+    if (s.doc) {   // a session onto a LOADED document (apply_campaign_loaded.json.gz): Backend.load, then the calls onto it
+      addon.loadDocument(ctx, new Uint8Array(Buffer.from(s.doc, 'base64')))
+      addon.replay(ctx)
+      if (s.graph) addon.hashGraphKnown(ctx, 1)   // (the reference had been asked for the document's changes first)
+    }
     for (let ci = 0; ci < s.calls.length && ci < s.patches.length; ci++) {
       const id = s.name + '/' + ci
       checked.add(id)
@@ -65,9 +70,10 @@ for (let leaf = 0; leaf < V.length && sessions < maxSessions; leaf++) {
   if (hasChild.has(leaf)) continue
   const chain = []
   for (let j = leaf; j !== -1; j = V[j].parent) chain.unshift(j)
-  if (V[chain[0]].doc !== undefined || chain.length > maxChain) continue
+  if (chain.length > maxChain) continue
   sessions++
   addon.reset(ctx)
+  if (V[chain[0]].doc !== undefined) { addon.loadDocument(ctx, pool[V[chain[0]].doc]); addon.replay(ctx) }   // applyChanges onto Backend.load(doc)
   for (const j of chain) {
     const v = V[j]
     let patch

@@ -527,18 +527,23 @@ def main():
         if save_info is not None:
             # the history of the saved headline document after Backend.load (binary changes + hashes rebuilt:
             # op columns decoded on the GPU, regroup / re-encode / hash chain on the host threads); not part of `value`
-            eng.load_document(saved)
-            eng.replay()
-            t0 = time.perf_counter()
-            _, h_off, _ = eng.doc_changes(deflate=False)
-            ms_plain = (time.perf_counter() - t0) * 1e3
-            eng.load_document(saved)
-            eng.replay()
-            t0 = time.perf_counter()
-            eng.doc_changes(deflate=True)
-            ms_deflate = (time.perf_counter() - t0) * 1e3
+            # (best of 5 after one untimed call, like every other timing of this line: the first call allocates the stage's buffers)
+            def history_ms(deflate):
+                best, off = None, None
+                for i in range(6):
+                    eng.load_document(saved)
+                    eng.replay()
+                    t0 = time.perf_counter()
+                    _, off, _ = eng.doc_changes(deflate=deflate)
+                    dt = (time.perf_counter() - t0) * 1e3
+                    if i:
+                        best = dt if best is None else min(best, dt)
+                return best, off
+            ms_plain, h_off = history_ms(False)
+            ms_deflate, _ = history_ms(True)
             out["history_after_load"] = {"n_changes": int(len(h_off) - 1), "change_bytes": int(h_off[-1]), "ms": ms_plain, "ms_with_deflate": ms_deflate,
-                                         "ops_per_s": st.n_ops / (ms_plain * 1e-3)}
+                                         "ops_per_s": st.n_ops / (ms_plain * 1e-3),
+                                         "timed_region": "am355_doc_changes of the loaded document: binary changes + hashes in host memory (best of 5 after one untimed call)"}
         if not w.is_doc:
             out["apply_changes"] = apply_changes_section(eng, w.log, barrier)
     print(json.dumps(out))

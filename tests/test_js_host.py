@@ -149,6 +149,12 @@ def test_js_host_materialises_incremental_patches_emulated():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["failed"] == 0 and res["refused"] == 0 and res["equal"] >= 60
+    # sessions onto loaded documents: Backend.load, then the calls (ten sessions; the GPU suite runs all 48)
+    out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js"), os.path.join(ROOT, "tests", "golden", "apply_campaign_loaded.json.gz"), "0", "10"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["refused"] == 0 and res["equal"] >= 80
 
 
 @pytest.mark.gpu
@@ -160,7 +166,12 @@ def test_js_host_reproduces_the_incremental_patches_of_the_reference_suites_on_g
     out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res["failed"] == 0 and res["equal"] >= 800 and res["rejected"] >= 3
+    assert res["failed"] == 0 and res["equal"] == 1572 and res["refused"] == 6 and res["rejected"] == 4   # all 1582 captured calls
+    out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js"), os.path.join(ROOT, "tests", "golden", "apply_campaign_loaded.json.gz")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["failed"] == 0 and res["refused"] == 0 and res["equal"] == 684   # sessions onto loaded documents
     out = subprocess.run([NODE, os.path.join(JS, "test_apply_vectors.js"), os.path.join(ROOT, "tests", "golden", "apply_campaign_lists.json.gz")],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
