@@ -37,6 +37,7 @@ struct Reader {
   const uint8_t* p = nullptr;
   size_t len = 0, off = 0;
   bool uleb(uint64_t& out) {
+    if (off < len && !(p[off] & 0x80)) { out = p[off++]; return true; }   // (one-byte numbers: nearly all of a metadata column)
     uint64_t v = 0;
     int shift = 0;
     while (off < len && shift < 64) {
@@ -48,6 +49,7 @@ struct Reader {
     return false;
   }
   bool sleb(int64_t& out) {
+    if (off < len && !(p[off] & 0x80)) { const uint8_t b = p[off++]; out = (b & 0x40) ? (int64_t)b - 128 : (int64_t)b; return true; }
     uint64_t v = 0;
     int shift = 0;
     while (off < len && shift < 64) {
@@ -250,8 +252,9 @@ int history_metadata(const HistoryInput& in, HistoryMeta& meta, std::string& err
       if (k < 0) { if (!c.second.empty()) return bad(HISTORY_UNSUPPORTED, "document has change columns this engine does not model"); continue; }
       col[k] = &c.second;
     }
-    RleReader r_actor(col[0], 0), r_seq(col[1], 1), r_max(col[2], 1), r_time(col[3], 1), r_msg(col[4], 2), r_dnum(col[5], 0), r_didx(col[6], 1), r_xlen(col[7], 0);
-    int64_t seq_abs = 0, max_abs = 0, time_abs = 0, didx_abs = 0;
+    RleReader r_actor(col[0], 0), r_seq(col[1], 1), r_max(col[2], 1), r_time(col[3], 1), r_msg(col[4], 2), r_dnum(col[5], 0), r_xlen(col[7], 0);
+    int64_t seq_abs = 0, max_abs = 0, time_abs = 0;
+    uint64_t n_deps = 0;
     size_t xoff = 0;
     const size_t xtotal = col[8] ? col[8]->size() : 0;
     std::vector<uint32_t> last_of(NA, NONE);
@@ -281,17 +284,12 @@ int history_metadata(const HistoryInput& in, HistoryMeta& meta, std::string& err
       }
       if (!r_dnum.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul || v < 0 || v > 0x7fffffff) return bad(HISTORY_INVALID, "bad dependency count");
-      c.dep_first = (uint32_t)dep_index.size();
+      // (the dependency INDEXES -- one value per edge of the hash graph, 63 per change in a log of 64 synced actors: the one long
+      // column of the metadata -- are decoded by history_dependencies, which the caller runs beside the device stages)
+      if (n_deps + (uint64_t)v > 0x7fffffffull) return bad(HISTORY_UNSUPPORTED, "too many dependency edges");
+      c.dep_first = (uint32_t)n_deps;
       c.dep_num = (uint32_t)v;
-      if (dep_index.capacity() < dep_index.size() + c.dep_num) dep_index.reserve(2 * (dep_index.size() + c.dep_num) + 1024);
-      for (uint32_t d = 0; d < c.dep_num; d++) {
-        bool dn;
-        int64_t dv;
-        if (!r_didx.next_num(dn, dv) || dn) return bad(HISTORY_INVALID, "malformed dependency index column");
-        didx_abs += dv;
-        if (didx_abs < 0 || (uint64_t)didx_abs >= chg.size()) return bad(HISTORY_INVALID, "dependency index does not name an earlier change");
-        dep_index.push_back((uint32_t)didx_abs);
-      }
+      n_deps += (uint64_t)v;
       if (!r_xlen.next_num(nul, v)) return bad(HISTORY_INVALID, "malformed change metadata columns");
       if (nul || (v & 15) != 7) return bad(HISTORY_INVALID, "Bad datatype for extra bytes");
       size_t xl = (size_t)(v >> 4);
@@ -307,7 +305,7 @@ int history_metadata(const HistoryInput& in, HistoryMeta& meta, std::string& err
       chg.push_back(std::move(c));
       if (chg.size() > 0x7ffffff0u) return bad(HISTORY_UNSUPPORTED, "too many changes");
     }
-    if (!r_didx.done()) return bad(HISTORY_INVALID, "dependency index column has trailing values");
+    meta.n_deps = (uint32_t)n_deps;
     lap("change metadata");
     // ---- 2. (device, am355_hist.hip) slots: one bit per (actor, counter) up to the actor's last maxOp, in 32-bit words ----
     meta.act_max.assign(NA, 0);
@@ -349,6 +347,32 @@ inline uint8_t* w_sleb(uint8_t* p, int64_t v) {
 }
 inline uint8_t* w_bytes(uint8_t* p, const void* src, size_t n) { if (n) memcpy(p, src, n); return p + n; }
 }  // namespace
+
+// The dependency index column (depsIndex, delta-coded: columnar.js:945-981 reads it change by change): meta.dep_index[c.dep_first ..
+// + c.dep_num) of every change. One sequential decode of one value per dependency edge -- independent of everything the device stages
+// need, so doc_changes_impl runs it on a thread of its own beside them.
+int history_dependencies(const HistoryInput& in, HistoryMeta& meta, std::string& err) {
+  auto bad = [&](int rc, const char* msg) { err = msg; return rc; };
+  const std::vector<uint8_t>* col = nullptr;
+  for (auto& c : *in.change_columns) if (c.first == 0x43) col = &c.second;
+  RleReader r(col, 1);
+  meta.dep_index.resize(meta.n_deps);
+  uint32_t* out = meta.dep_index.data();
+  int64_t abs = 0;
+  for (size_t k = 0; k < meta.chg.size(); k++) {
+    const ChangeRec& c = meta.chg[k];
+    for (uint32_t d = 0; d < c.dep_num; d++) {
+      bool nul;
+      int64_t dv;
+      if (!r.next_num(nul, dv) || nul) return bad(HISTORY_INVALID, "malformed dependency index column");
+      abs += dv;
+      if (abs < 0 || (uint64_t)abs >= k) return bad(HISTORY_INVALID, "dependency index does not name an earlier change");
+      out[c.dep_first + d] = (uint32_t)abs;
+    }
+  }
+  if (!r.done()) return bad(HISTORY_INVALID, "dependency index column has trailing values");
+  return HISTORY_OK;
+}
 
 int history_finish(const HistoryInput& in, HistoryMeta& meta, const HistoryPieces& pc, bool deflate, const ParallelFor& par, HistoryOutput& out, std::string& err) {
   auto bad = [&](int rc, const char* msg) { err = msg; return rc; };

@@ -48,6 +48,7 @@ struct HistoryChange {
 struct HistoryMeta {
   std::vector<HistoryChange> chg;
   std::vector<uint32_t> dep_index;              // dependencies by change index, flattened (HistoryChange.dep_first / dep_num)
+  uint32_t n_deps = 0;                          // entries of dep_index (known after history_metadata; filled by history_dependencies)
   std::vector<uint32_t> act_max, word_base;     // per actor: last maxOp | first 32-bit word of its stretch of the id bitmaps ([NA + 1])
 };
 constexpr int HISTORY_NCOL = 12;
@@ -73,6 +74,8 @@ using ParallelFor = std::function<void(unsigned, const std::function<void(unsign
 
 // change metadata columns -> meta (and the layout of the id bitmaps the device builds)
 int history_metadata(const HistoryInput& in, HistoryMeta& meta, std::string& err);
+// the dependency indexes of every change (meta.dep_index): needs only what history_metadata left; may run on another thread beside the device stages
+int history_dependencies(const HistoryInput& in, HistoryMeta& meta, std::string& err);
 // headers + column pieces -> changes, hash chain, containers. deflate: compress changes of >= 256 bytes as encodeChange does
 // (columnar.js:798-811; zlib level 6 raw = pako's defaults).
 int history_finish(const HistoryInput& in, HistoryMeta& meta, const HistoryPieces& pc, bool deflate, const ParallelFor& par, HistoryOutput& out, std::string& err);

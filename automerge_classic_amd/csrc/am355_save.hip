@@ -495,6 +495,13 @@ int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const 
     if (rc == HISTORY_INVALID) return fail(c, AM355_E_INVALID, "%s", err.c_str());
     if (rc) return fail(c, AM355_E_UNSUPPORTED, "%s", err.c_str());
     lap("change metadata");
+    // the dependency indexes (one value per edge of the hash graph: a quarter of a million for the headline log, 1.3 ms of one host
+    // thread) are needed only by the hash chain at the end: decoded on a thread of their own while the device stages run
+    struct DepTask {
+      std::thread t; int rc = 0; std::string err;
+      ~DepTask() { if (t.joinable()) t.join(); }
+    } deps;
+    deps.t = std::thread([&in, &meta, &deps]() { deps.rc = history_dependencies(in, meta, deps.err); });
     // ---- device, stage 1: ids -> slots, preds by slot, the changes' slot ranges (am355_hist.hip) ----
     const uint32_t NC = (uint32_t)meta.chg.size(), NA = (uint32_t)c->actors.size(), W = meta.word_base[NA];
     const size_t key_bytes = c->doc_meta.col_len[C_KEY_STR], val_bytes = c->doc_meta.col_len[C_VAL_RAW];
@@ -586,6 +593,10 @@ int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const 
     }
     lap("columns of all changes (device)");
     c->history = HistoryOutput{};
+    deps.t.join();
+    if (deps.rc == HISTORY_INVALID) return fail(c, AM355_E_INVALID, "%s", deps.err.c_str());
+    if (deps.rc) return fail(c, AM355_E_UNSUPPORTED, "%s", deps.err.c_str());
+    lap("dependency indexes joined");
     rc = history_finish(in, meta, pc, (flags & 1) != 0, [&](unsigned k, const std::function<void(unsigned)>& fn) { c->pool->run(k, fn); }, c->history, err);
     lap("headers + hash chain");
     if (rc == HISTORY_INVALID) return fail(c, AM355_E_INVALID, "%s", err.c_str());
