@@ -325,12 +325,10 @@ constexpr int SORT_TILE = (BLOCK / WAVE) * SORT_WAVE_SPAN;  // 2048 elements per
 constexpr int RADIX = 256;
 constexpr uint32_t SORT_FUSED_TILES = 64;
 
-// (table_zero, optional: a second table cleared on the way -- the one the first scatter pass accumulates the next digit's counts in)
 __global__ __launch_bounds__(BLOCK) void k_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
-                                                      uint32_t* __restrict__ table, uint32_t n_tiles, uint32_t* __restrict__ table_zero) {
+                                                      uint32_t* __restrict__ table, uint32_t n_tiles) {
   __shared__ uint32_t hist[RADIX];
   hist[threadIdx.x] = 0;
-  if (table_zero) table_zero[threadIdx.x * n_tiles + blockIdx.x] = 0;
   __syncthreads();
   uint32_t base = blockIdx.x * SORT_TILE;
   for (int j = 0; j < SORT_TILE / BLOCK; j++) {
@@ -343,19 +341,14 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(const uint64_t* __restrict_
 
 // RAW_TABLE: `table` holds the histograms as k_sort_hist left them (no scan launch in between): thread t = digit t adds up its row -- the
 // digit's count over all tiles, and over the tiles in front of this one -- and one workgroup scan over the rows gives the digit's base.
-// For sorts of up to SORT_FUSED_TILES tiles (131 k elements): a pass is ONE launch -- the histogram of the NEXT digit is taken while
-// this pass scatters (every element adds one to table_next[next digit][tile it lands in], which an earlier pass cleared through
-// table_zero): three tables rotate. (Round 3: two launches per pass, histogram + scatter; 11 passes order the map emissions of
-// c3_map_lww.)
+// For sorts of up to SORT_FUSED_TILES tiles (131 k elements): a pass is two launches instead of three.
 template <bool RAW_TABLE>
 __global__ __launch_bounds__(BLOCK) void k_sort_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
-                                                         int shift, const uint32_t* __restrict__ table, uint32_t n_tiles,
-                                                         uint32_t* __restrict__ table_next, uint32_t* __restrict__ table_zero) {
+                                                         int shift, const uint32_t* __restrict__ table, uint32_t n_tiles) {
   __shared__ uint32_t wave_cnt[BLOCK / WAVE][RADIX];
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t t = threadIdx.x, w = t / WAVE, lane = t % WAVE;
-  if (table_zero) table_zero[t * n_tiles + blockIdx.x] = 0;
   for (int k = 0; k < BLOCK / WAVE; k++) wave_cnt[k][t] = 0;
   __syncthreads();
 
@@ -411,7 +404,6 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(const uint64_t* __restri
       uint32_t pos = wave_cnt[w][d] + rank[j];
       keys_out[pos] = key[j];
       vals_out[pos] = val[j];
-      if (table_next) atomicAdd(&table_next[((uint32_t)(key[j] >> (shift + 8)) & 0xff) * n_tiles + pos / SORT_TILE], 1u);
     }
   }
 }
@@ -437,8 +429,8 @@ void max_u32(const uint32_t* v, uint32_t n, uint32_t* d_out, hipStream_t st) {
 
 size_t sort_workspace_bytes(uint32_t n) {
   uint32_t n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
-  size_t table = ((size_t)RADIX * n_tiles + 63) & ~(size_t)63;
-  return 3 * sizeof(uint32_t) * table + scan_workspace_bytes((uint32_t)table) + 256;  // (three rotating tables: see k_sort_scatter)
+  size_t table = (size_t)RADIX * n_tiles;
+  return sizeof(uint32_t) * table + scan_workspace_bytes((uint32_t)table) + 256;
 }
 
 // Sorts ascending by bits [begin_bit, end_bit) of the key. Buffers ping-pong; returns 0 if the result is in
@@ -452,29 +444,20 @@ int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint3
   if (n == 0) return 0;
   uint32_t n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
   uint32_t* table = (uint32_t*)ws;
-  size_t table_n = (size_t)RADIX * n_tiles, table_stride = (table_n + 63) & ~(size_t)63;
-  void* scan_ws = (void*)(table + 3 * table_stride);
-  const bool fused = n_tiles <= SORT_FUSED_TILES;
-  const int passes = (end_bit - begin_bit + 7) / 8;
-  int cur = 0, pass = 0;
-  for (int shift = begin_bit; shift < end_bit; shift += 8, pass++) {
+  size_t table_n = (size_t)RADIX * n_tiles;
+  void* scan_ws = (void*)(table + ((table_n + 63) & ~(size_t)63));
+  int cur = 0;
+  for (int shift = begin_bit; shift < end_bit; shift += 8) {
     uint64_t* ki = cur ? keys_b : keys_a;
     uint32_t* vi = cur ? vals_b : vals_a;
     uint64_t* ko = cur ? keys_a : keys_b;
     uint32_t* vo = cur ? vals_a : vals_b;
-    if (fused) {
-      // tables rotate: this pass reads T[pass % 3], counts the next digit into T[(pass + 1) % 3] and clears T[(pass + 2) % 3] for the pass after
-      uint32_t *t_cur = table + (size_t)(pass % 3) * table_stride, *t_next = pass + 1 < passes ? table + (size_t)((pass + 1) % 3) * table_stride : nullptr;
-      uint32_t* t_zero = pass + 2 < passes ? table + (size_t)((pass + 2) % 3) * table_stride : nullptr;
-      if (pass == 0) {
-        if (!first_hist_done) hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(BLOCK), 0, st, ki, n, shift, t_cur, n_tiles, t_next);
-        else if (t_next) (void)hipMemsetAsync(t_next, 0, sizeof(uint32_t) * table_n, st);
-      }
-      hipLaunchKernelGGL(k_sort_scatter<true>, dim3(n_tiles), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, (const uint32_t*)t_cur, n_tiles, t_next, t_zero);
+    if (!(first_hist_done && shift == begin_bit)) hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(BLOCK), 0, st, ki, n, shift, table, n_tiles);
+    if (n_tiles <= SORT_FUSED_TILES) {
+      hipLaunchKernelGGL(k_sort_scatter<true>, dim3(n_tiles), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, table, n_tiles);
     } else {
-      if (!(first_hist_done && shift == begin_bit)) hipLaunchKernelGGL(k_sort_hist, dim3(n_tiles), dim3(BLOCK), 0, st, ki, n, shift, table, n_tiles, (uint32_t*)nullptr);
       exclusive_scan_u32(table, table, (uint32_t)table_n, nullptr, scan_ws, st);
-      hipLaunchKernelGGL(k_sort_scatter<false>, dim3(n_tiles), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, (const uint32_t*)table, n_tiles, (uint32_t*)nullptr, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(k_sort_scatter<false>, dim3(n_tiles), dim3(BLOCK), 0, st, ki, vi, ko, vo, n, shift, table, n_tiles);
     }
     cur ^= 1;
   }
