@@ -953,7 +953,7 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
   const uint32_t c = counts[t];
   state[2 * t] = KH_UNKNOWN;
   state[2 * t + 1] = 0;
-  if (c > KH_ROWS_MAX) return;
+  if (c > KH_ROWS_MAX) { state[2 * t + 1] = 1; return; }  // (state[2t + 1] of an unknown answer: why -- diagnostics only)
   const bool map_prop = o.key_len[ir.obj[targets[t]].make_row] != NONE32;
   uint32_t rows[KH_ROWS_MAX], death[KH_ROWS_MAX], by_id[KH_ROWS_MAX];
   for (uint32_t i = 0; i < c; i++) {  // ascending row number = time
@@ -998,27 +998,44 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
         for (uint32_t w = 0; w < (KH_ROWS_MAX + 31) / 32; w++) listed[w] = seen[w];
     }
   }
+  // (an op stream ends with the scheduling pass, and with the call of applyChanges)
+  auto stream_begins_at = [&](uint32_t row) {
+    uint32_t lo = 0, hi = d.n_breaks;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.breaks[mid] < row) lo = mid + 1; else hi = mid; }
+    return lo < d.n_breaks && d.breaks[lo] == row;
+  };
+  uint32_t call_first = 0;  // rows[call_first .. j]: the ops of the merge call row j belongs to
   for (uint32_t j = 0; j < c && !unknown; j++) {
     const uint32_t g = rows[j];
-    if (g < d.T_doc) continue;  // (no call visited this row: it came with the document)
+    if (g < d.T_doc) { call_first = j + 1; continue; }  // (no call visited this row: it came with the document)
     const bool is_del = b.kind[g] == K_DEL;
-    if (!map_prop && o.insert[g] && j > 0) { unknown = true; break; }
-    // two ops of one actor on the property in a row share a merge call unless the second overwrites the first (new.js:1114-1121)
+    if (!map_prop && o.insert[g] && j > 0) { unknown = true; state[2 * t + 1] = 2; break; }
+    // Ops of one actor on the property that follow each other in the op stream share ONE merge call -- one visit, with all of them
+    // in place -- unless the next one overwrites an op the call already holds (new.js:1092-1117 "Collect several updates to the same
+    // key / list element": e.g. two increments of one counter in a change). A deletion among them is not modelled.
     if (j + 1 < c && rows[j + 1] == g + 1 && o.id_actor[g + 1] == o.id_actor[g]) {
       bool overwrites = false;
-      for (uint32_t k = 0; k < o.pred_num[g + 1]; k++)
-        overwrites = overwrites || (o.pred_ctr[o.pred_first[g + 1] + k] == o.id_ctr[g] && o.pred_actor[o.pred_first[g + 1] + k] == o.id_actor[g]);
-      if (!overwrites || is_del) { unknown = true; break; }
+      for (uint32_t q2 = call_first; q2 <= j; q2++)
+        for (uint32_t k = 0; k < o.pred_num[g + 1]; k++)
+          overwrites = overwrites || (o.pred_ctr[o.pred_first[g + 1] + k] == o.id_ctr[rows[q2]] && o.pred_actor[o.pred_first[g + 1] + k] == o.id_actor[rows[q2]]);
+      if (is_del) { unknown = true; state[2 * t + 1] = 3; break; }
+      if (!overwrites) {
+        // (where the op streams of EARLIER calls began is not known when the staged changes were replayed in one go)
+        if (!d.breaks_exact && g + 1 < d.T0) { unknown = true; state[2 * t + 1] = 4; break; }
+        if (!stream_begins_at(g + 1)) {
+          if (b.kind[g + 1] == K_DEL) { unknown = true; state[2 * t + 1] = 3; break; }
+          continue;  // visited together with the next op
+        }
+      }
     }
+    const uint32_t call_row0 = rows[call_first];  // the call's ops are the rows call_row0 .. g (consecutive, all on this property)
+    call_first = j + 1;
     // a call that goes on to a greater key of the object leaves the rows above a threshold unvisited (see kd_slots)
     bool cont = false;
     unsigned long long thr = pack_id(o.id_ctr[g], o.id_actor[g]);
     if (map_prop && g + 1 < b.n_ops) {
       uint32_t nx = g + 1;
-      // (an op stream ends with the scheduling pass, and with the call of applyChanges)
-      uint32_t lo = 0, hi = d.n_breaks;
-      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.breaks[mid] < nx) lo = mid + 1; else hi = mid; }
-      const bool new_pass = lo < d.n_breaks && d.breaks[lo] == nx;
+      const bool new_pass = stream_begins_at(nx);
       uint8_t kn = b.kind[nx];
       cont = !new_pass && (kn == K_MAP || kn == K_DEL) && o.key_len[nx] != NONE32 && !o.insert[nx] && o.id_actor[nx] == o.id_actor[g] && same_obj(b, nx, g) &&
              key_less_utf16(b, g, nx);
@@ -1035,10 +1052,10 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
     for (uint32_t q = 0; q < c; q++) {
       const uint32_t i = by_id[q], r = rows[i];
       if (r > g || b.kind[r] == K_DEL) continue;  // not there yet / a deletion leaves no row
-      if (cont && r != g && pack_id(o.id_ctr[r], o.id_actor[r]) > thr) {
+      if (cont && !(r >= call_row0 && r <= g) && pack_id(o.id_ctr[r], o.id_actor[r]) > thr) {
         // (when the staged changes were replayed in one go, whether an EARLIER call went on to the next row is not known -- a call of
         // applyChanges or a scheduling pass may have ended between them --: it only matters when a row it would have skipped is visible)
-        if (!d.breaks_exact && g + 1 < d.T0 && death[i] > g) unknown = true;
+        if (!d.breaks_exact && g + 1 < d.T0 && death[i] > g) { unknown = true; state[2 * t + 1] = 4; }
         continue;
       }
       if (r == g || death[i] > g) {
@@ -1054,7 +1071,7 @@ __global__ __launch_bounds__(WAVE) void kh_simulate(MergeBufs b, PatchIR ir, Del
   uint32_t nl = 0;
   for (uint32_t q = 0; q < c; q++)
     if (listed[q >> 5] >> (q & 31) & 1u) {
-      if (nl == KH_VALUES_MAX) return;  // (KH_UNKNOWN)
+      if (nl == KH_VALUES_MAX) { state[2 * t + 1] = 5; return; }  // (KH_UNKNOWN)
       uint32_t r = rows[by_id[q]];
       values[(size_t)t * 2 * KH_VALUES_MAX + 2 * nl] = o.id_ctr[r];
       values[(size_t)t * 2 * KH_VALUES_MAX + 2 * nl + 1] = o.id_actor[r];
@@ -1082,6 +1099,7 @@ int delta_key_history(MergeBufs& b, PatchIR& ir, DeltaBufs& d, const uint32_t* o
   (void)hipFree(dev);
   if (e != hipSuccess) return -1;
   for (uint32_t i = 0; i < n; i++) {
+    if (h[2 * (size_t)i] == KH_UNKNOWN && getenv("AM355_TRACE")) fprintf(stderr, "key history of object %u: unknown (reason %u)\n", objects[i], h[2 * (size_t)i + 1]);
     out[i].state = (uint8_t)h[2 * (size_t)i];
     out[i].n = h[2 * (size_t)i + 1];
     for (uint32_t k = 0; k < out[i].n && k < KH_VALUES_MAX; k++) {
