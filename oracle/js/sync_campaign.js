@@ -2,7 +2,7 @@
 // histories run generateSyncMessage / receiveSyncMessage until they agree -- once with the unmodified reference backend on both
 // sides, once with mi355x-backend (the engine, or its emulation preloaded) on one side and once on both. Every message must be
 // byte-identical and every patch equal (the key order of `clock` aside) in all three runs.
-//   NODE_PATH=oracle/js_shims/node_modules AUTOMERGE_BACKEND_PATH=/root/reference/backend node oracle/js/sync_campaign.js [scenarios]
+//   NODE_PATH=oracle/js_shims/node_modules AUTOMERGE_BACKEND_PATH=/root/reference/backend [SYNC_LOADED=1] node oracle/js/sync_campaign.js [scenarios]
 'use strict'
 const path = require('path')
 const { splitmix, Automerge } = require('./make_golden.js')
@@ -36,8 +36,13 @@ function scenario(seed) {
   return [Automerge.getAllChanges(a), Automerge.getAllChanges(b)]
 }
 
+// SYNC_LOADED=1: both peers start from a SAVED document (Backend.load): the protocol's getChanges / getMissingDeps make the reference
+// rebuild the document's hash graph, and the changes of the first message are applied onto the loaded document
+const docOf = changes => Ref.save(Ref.loadChanges(Ref.init(), changes))
 function syncRun(BackA, BackB, changesA, changesB) {
-  let bA = BackA.loadChanges(BackA.init(), changesA), bB = BackB.loadChanges(BackB.init(), changesB)
+  let bA, bB
+  if (process.env.SYNC_LOADED) { bA = BackA.load(docOf(changesA)); bB = BackB.load(docOf(changesB)) }
+  else { bA = BackA.loadChanges(BackA.init(), changesA); bB = BackB.loadChanges(BackB.init(), changesB) }
   let sA = BackA.initSyncState(), sB = BackB.initSyncState()
   const log = []
   for (let round = 0; round < 30; round++) {

@@ -103,6 +103,13 @@ def test_sync_protocol_over_the_engine_against_the_live_reference_emulated():
     assert out.returncode == 0 and "DISAGREE 0" in out.stdout and "18 runs identical" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
     served = json.loads(out.stdout.split("served by: ")[1].splitlines()[0])
     assert served["gpuApplyChanges"] >= 12 and served["fallbackToJs"] == 0 and served["hydrations"] == 0
+    # both peers start from SAVED documents (Backend.load): the protocol's queries rebuild the hash graph (am355_doc_changes, told to the
+    # engine by am355_hash_graph_known) and the first message's changes are applied onto the loaded document -- all on the engine
+    env["SYNC_LOADED"] = "1"
+    out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "sync_campaign.js"), "4"], capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0 and "DISAGREE 0" in out.stdout and "12 runs identical" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    served = json.loads(out.stdout.split("served by: ")[1].splitlines()[0])
+    assert served["gpuLoad"] >= 8 and served["gpuApplyChanges"] >= 8 and served["fallbackToJs"] == 0 and served["hydrations"] == 0
 
 
 @pytest.mark.skipif(NODE is None or not os.path.isdir("/root/reference"), reason="needs node and the reference tree (build container only)")
