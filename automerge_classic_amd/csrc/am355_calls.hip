@@ -129,7 +129,8 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
     const uint64_t* ho = nullptr;
     uint32_t hn = 0;
     const bool head_index_known = !c->doc_tail.empty() || c->heads.size() <= 32;  // (heads.length === headsIndexes.length, or one head: new.js:1719-1729)
-    int hrc = doc_changes_impl(c, 0, &ha, &ho, &hn, &hh);
+    // (the form the host last asked for, if it did: the history is kept per context and DEFLATEd changes stage like any others)
+    int hrc = doc_changes_impl(c, c->history_ok ? c->history_flags : 0, &ha, &ho, &hn, &hh);
     if (hrc) return hrc;
     if (hn == 0) {  // (an empty document: Backend.init())
       int rrc = am355_reset(c);
