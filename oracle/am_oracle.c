@@ -744,6 +744,13 @@ struct amo_doc {
   /* ---- session documents (amo_init / amo_apply_changes): what a BackendDoc keeps between calls ---- */
   int session, loaded, meta_built;
   tab_t known;            /* changeIndexByHash: hashes of the applied changes */
+  /* a document made by amo_load_document: haveHashGraph (new.js:1697), the hashes of the document's changes as the reference's
+   * computeHashGraph would rebuild them (given by the test: amo_set_document_history), the changes applied by the calls since */
+  int have_graph;
+  const uint8_t *doc_hashes;
+  uint32_t n_doc_hashes;
+  const uint8_t **since;
+  uint32_t n_since, cap_since;
   struct qchange *queue;  /* this.queue: changes waiting for a dependency */
   uint32_t n_queue;
   uint32_t actors_read;   /* actors whose first change has been read (getActorTable, new.js:1434-1451) */

@@ -54,6 +54,12 @@ void amo_free(amo_doc *doc);
  * amo_patch_json(doc) afterwards gives Backend.getPatch of the same state.
  */
 amo_doc *amo_init(void);
+/* A BackendDoc made by Backend.load knows the hashes of the document's heads only and rebuilds the hash graph when a scheduling
+ * round applies nothing (new.js:1833-1840, computeHashGraph :1887-1912) -- into a fresh index that lacks what the running call has
+ * applied so far. This restatement does not rebuild changes from a document: the test gives the hashes the reference's
+ * getAllChanges(load(doc)) has (32 bytes each, document order; kept by pointer). Without them a call that would need the graph fails
+ * with "unsupported:". rebuilt != 0: the reference has rebuilt the graph already (it was asked for changes: new.js:1922). */
+void amo_set_document_history(amo_doc *doc, const uint8_t *hashes, uint32_t n, int rebuilt);
 const char *amo_apply_changes(amo_doc *doc, const uint8_t *arena, const uint64_t *offsets, uint32_t n_changes, int is_local,
                               size_t *len, char *err, size_t errcap);
 

@@ -77,6 +77,7 @@ static void session_free(amo_doc *d) {
   free(d->root.sorted);
   tab_free(&d->known);
   free(d->queue);
+  free(d->since);
   free(d->apply_json.p);
 }
 
@@ -84,6 +85,7 @@ amo_doc *amo_init(void) {
   amo_doc *d = (amo_doc *)calloc(1, sizeof *d);
   d->hashes = (uint8_t *)calloc(1, 32);
   d->session = 1;
+  d->have_graph = 1;
   d->meta_built = 1;
   d->root.has_meta = 1;
   d->heads = (uint8_t *)pool_alloc(&d->pool, 32);
@@ -970,18 +972,37 @@ static void release_patches(ictx_t *x) {
   free(x->touched);
 }
 
+/* computeHashGraph (new.js:1887-1912): changeIndexByHash becomes the index of the document as saved BEFORE the running call -- the
+ * document's own changes and what earlier calls applied; the hashes of the changes the running call has applied so far are not in it */
+static void rebuild_hash_graph(amo_doc *d) {
+  tab_free(&d->known);
+  memset(&d->known, 0, sizeof d->known);
+  for (uint32_t i = 0; i < d->n_doc_hashes; i++) hset_add(&d->pool, &d->known, d->doc_hashes + 32 * (size_t)i);
+  for (uint32_t i = 0; i < d->n_since; i++) hset_add(&d->pool, &d->known, d->since[i]);
+  d->have_graph = 1;
+}
+
+static void enter_session(amo_doc *d) {
+  if (d->session) return;
+  /* a document made by amo_load_document enters session mode: the heads are the only change hashes it knows (new.js:1711-1730) */
+  d->session = 1;
+  d->loaded = 1;
+  d->actors_read = d->n_actors;
+  for (uint32_t i = 0; i < d->n_heads; i++) hset_add(&d->pool, &d->known, d->heads + 32 * i);
+}
+
+void amo_set_document_history(amo_doc *d, const uint8_t *hashes, uint32_t n, int rebuilt) {
+  enter_session(d);
+  d->doc_hashes = hashes;
+  d->n_doc_hashes = n;
+  if (rebuilt && !d->have_graph) rebuild_hash_graph(d);
+}
+
 const char *amo_apply_changes(amo_doc *d, const uint8_t *arena, const uint64_t *offsets, uint32_t n, int is_local, size_t *len,
                               char *errbuf, size_t errcap) {
   err_t e = {{0}, 0};
   int rc = 0;
-  if (!d->session) {
-    /* a document made by amo_load_document enters session mode: the heads are the only change hashes it knows
-     * (the reference would rebuild the hash graph, new.js:1836-1840) */
-    d->session = 1;
-    d->loaded = 1;
-    d->actors_read = d->n_actors;
-    for (uint32_t i = 0; i < d->n_heads; i++) hset_add(&d->pool, &d->known, d->heads + 32 * i);
-  }
+  enter_session(d);
   if (!d->meta_built) build_meta(d);
   d->json_done = 0;
   d->json.len = 0;
@@ -1024,21 +1045,37 @@ const char *amo_apply_changes(amo_doc *d, const uint8_t *arena, const uint64_t *
   uint64_t cap_cops = 0;
   int any_applied = 0;
 
+  const uint8_t **call_applied = (const uint8_t **)calloc(qn ? qn : 1, sizeof(uint8_t *));  /* hashes this call has applied (all rounds) */
+  uint32_t n_call_applied = 0;
   while (!rc && qn > 0) {
     uint32_t na = 0, nq = 0;
+    /* a round commits its clock / heads / actor table only when it is not abandoned (new.js:1551-1552 works on copies, :1581) */
+    const uint32_t snap_actors = d->n_actors, snap_clock_n = d->n_clock, snap_heads = n_heads, snap_call = n_call_applied;
+    uint64_t *snap_clock = (uint64_t *)malloc(8 * (size_t)(d->n_actors ? d->n_actors : 1));
+    memcpy(snap_clock, d->clock, 8 * (size_t)d->n_actors);
+    const uint8_t **snap_head_ptrs = (const uint8_t **)malloc(sizeof(uint8_t *) * (size_t)(n_heads ? n_heads : 1));
+    memcpy(snap_head_ptrs, heads, sizeof(uint8_t *) * (size_t)n_heads);
+    tab_t round_known;  /* changeHashes of this round (new.js:1551): committed to changeIndexByHash after the round (:1828-1830) */
+    memset(&round_known, 0, sizeof round_known);
+    int abandoned = 0;
     for (uint32_t qi = 0; qi < qn && !rc; qi++) {
       change_t *c = &queue[qi];
-      if (hset_has(&d->known, c->hash)) continue;
+      if (hset_has(&d->known, c->hash) || hset_has(&round_known, c->hash)) continue;
       int ai = doc_actor_index(d, c->actors[0]);
       uint64_t expected = (ai >= 0 ? d->clock[ai] : 0) + 1;
       int ready = 1;
-      for (uint32_t k = 0; k < c->n_deps; k++) if (!hset_has(&d->known, c->deps + 32 * k)) ready = 0;
+      for (uint32_t k = 0; k < c->n_deps; k++) if (!hset_has(&d->known, c->deps + 32 * k) && !hset_has(&round_known, c->deps + 32 * k)) ready = 0;
       if (!ready) { next_q[nq++] = *c; continue; }
       char hex[80];
       size_t hl = 0;
       for (size_t k = 0; k < c->actors[0].len && hl + 2 < sizeof hex; k++) hl += snprintf(hex + hl, sizeof hex - hl, "%02x", c->actors[0].p[k]);
       hex[hl] = 0;
-      if (c->seq < expected && d->loaded) { rc = fail(&e, "unsupported: a change of a loaded document given again (hash graph not rebuilt, new.js:1836-1840)"); break; }
+      if (c->seq < expected && !d->have_graph) {
+        /* a change the document may hold already, whose hash is not known yet: nothing of this round is applied, the whole queue
+         * waits for the hash graph (new.js:1578-1582) */
+        abandoned = 1;
+        break;
+      }
       if (c->seq < expected) { rc = fail(&e, "Reuse of sequence number %llu for actor %s", (unsigned long long)c->seq, hex); break; }
       if (c->seq > expected) { rc = fail(&e, "Skipped sequence number %llu for actor %s", (unsigned long long)expected, hex); break; }
       if (ai < 0) {
@@ -1061,7 +1098,8 @@ const char *amo_apply_changes(amo_doc *d, const uint8_t *arena, const uint64_t *
       d->clock[ai] = c->seq;
       uint8_t *hcopy = (uint8_t *)pool_alloc(&d->pool, 32);  /* the decoded change lives only as long as this call */
       memcpy(hcopy, c->hash, 32);
-      hset_add(&d->pool, &d->known, hcopy);
+      hset_add(&d->pool, &round_known, hcopy);
+      call_applied[n_call_applied++] = hcopy;
       for (uint32_t k = 0; k < c->n_deps; k++) {
         int h = head_find(heads, n_heads, c->deps + 32 * k);
         if (h >= 0) heads[h] = NULL;
@@ -1069,6 +1107,22 @@ const char *amo_apply_changes(amo_doc *d, const uint8_t *arena, const uint64_t *
       if (head_find(heads, n_heads, c->hash) < 0) heads[n_heads++] = hcopy;
       applied[na++] = c;
     }
+    if (abandoned) {
+      d->n_actors = snap_actors;
+      d->n_clock = snap_clock_n;
+      memcpy(d->clock, snap_clock, 8 * (size_t)snap_actors);
+      memcpy(heads, snap_head_ptrs, sizeof(uint8_t *) * (size_t)snap_heads);
+      n_heads = snap_heads;
+      n_call_applied = snap_call;
+      na = 0;
+      memcpy(next_q, queue, sizeof(change_t) * qn);
+      nq = qn;
+    } else {
+      for (uint32_t k = snap_call; k < n_call_applied; k++) hset_add(&d->pool, &d->known, call_applied[k]);
+    }
+    free(snap_clock);
+    free(snap_head_ptrs);
+    tab_free(&round_known);
     if (rc) break;
     if (na > 0) {
       any_applied = 1;
@@ -1121,9 +1175,24 @@ const char *amo_apply_changes(amo_doc *d, const uint8_t *arena, const uint64_t *
     }
     memcpy(queue, next_q, sizeof(change_t) * nq);
     qn = nq;
-    if (na == 0) break;
+    if (na == 0) {
+      /* a round that applies nothing ends the call -- unless the hash graph has not been rebuilt yet (new.js:1833-1840) */
+      if (d->have_graph || qn == 0 || !d->doc_hashes) break;
+      rebuild_hash_graph(d);
+    }
   }
-  if (!rc && d->loaded && qn > 0) rc = fail(&e, "unsupported: a change waits for a dependency the loaded document may hold (hash graph not rebuilt)");
+  if (!rc && d->loaded && !d->have_graph && qn > 0) rc = fail(&e, "unsupported: a change waits for a dependency the loaded document may hold (hash graph not rebuilt)");
+  /* the changes of this call enter changeIndexByHash whatever happened to it in between (new.js:1846-1850) */
+  if (!rc) {
+    for (uint32_t k = 0; k < n_call_applied; k++) {
+      if (!hset_has(&d->known, call_applied[k])) hset_add(&d->pool, &d->known, call_applied[k]);
+      if (d->loaded) {
+        if (d->n_since == d->cap_since) { d->cap_since = d->cap_since ? 2 * d->cap_since : 64; d->since = (const uint8_t **)realloc(d->since, sizeof(uint8_t *) * d->cap_since); }
+        d->since[d->n_since++] = call_applied[k];
+      }
+    }
+  }
+  free(call_applied);
   if (!rc) rc = setup_patches(&x);
 
   if (!rc) {

@@ -14,6 +14,7 @@ const fs = require('fs')
 const { splitmix, frontendScenario, textScenario, Backend } = require('./make_golden.js')
 const out = process.argv[2]
 const Automerge = require('./make_golden.js').Automerge
+const refColumnar = require(require('path').join(require('./ref_loader').REF, 'backend', 'columnar'))
 
 // "m:" scenarios: what the engine's incremental-patch stage serves (automerge_classic_amd/csrc/am355_delta.hip) -- nested maps and
 // tables with conflicting assignments, deletions and counters, lists and texts that grow and shrink by insertion and deletion
@@ -220,6 +221,9 @@ for (const spec of process.argv.slice(3)) {
     }
     const rec = { name: `${spec}#${variant}${graphFirst ? '+g' : ''}`, calls: calls.slice(0, patches.length).map(c => c.map(b64)), patches }
     if (doc) rec.doc = b64(doc)
+    // (the hashes of the document's changes as the reference rebuilds them, computeHashGraph new.js:1887-1912: the oracle does not
+    // restate that reconstruction and takes them from here, tests/oracle_lib.py OracleSession(doc, doc_hashes))
+    if (doc) rec.doc_hashes = Buffer.concat(Backend.getAllChanges(Backend.load(doc)).map(c => Buffer.from(refColumnar.decodeChangeMeta(c, true).hash, 'hex'))).toString('base64')
     if (graphFirst) rec.graph = true
     lines.push(JSON.stringify(rec))
   }

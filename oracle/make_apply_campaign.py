@@ -3,7 +3,7 @@
 real frontend (oracle/js/apply_campaign.js), every call with the patch the unmodified reference returned -- the incremental
 patches of SURVEY.md 8f-2 on documents larger and more concurrent than the reference's own test suites hold.
 -> tests/golden/apply_campaign.json.gz: {"pool": [base64 change...], "sessions": [{"name", "calls": [[pool index...]...],
-"patches": [JSON text | {"error": message}], "doc": base64 saved document the session starts from (loaded sessions only)}]}
+"patches": [JSON text | {"error": message}], "doc": base64 saved document the session starts from, "doc_hashes": base64 of the 32-byte hashes of its changes (loaded sessions only)}]}
 
   python oracle/make_apply_campaign.py
 """
@@ -48,7 +48,7 @@ def main(specs=SPECS, name="apply_campaign.json.gz", loaded=False):
                     idx.append(pool[c])
                 calls.append(idx)
             sessions.append({"name": d["name"], "calls": calls, "patches": d["patches"]})
-            for k in ("doc", "graph"):
+            for k in ("doc", "graph", "doc_hashes"):
                 if k in d:
                     sessions[-1][k] = d[k]
     blob = json.dumps({"made_by": "oracle/make_apply_campaign.py: oracle/js/apply_campaign.js " + " ".join(specs) + " on the unmodified reference",

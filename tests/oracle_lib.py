@@ -31,6 +31,8 @@ def lib():
         L.amo_patch_json.restype = ctypes.c_void_p
         L.amo_patch_json.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.c_size_t]
         L.amo_free.argtypes = [ctypes.c_void_p]
+        L.amo_set_document_history.restype = None
+        L.amo_set_document_history.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
         L.amo_init.restype = ctypes.c_void_p
         L.amo_init.argtypes = []
         L.amo_apply_changes.restype = ctypes.c_void_p
@@ -144,7 +146,10 @@ class OracleSession:
     """A BackendDoc advanced call by call: Backend.init() (or Backend.load(doc)) followed by Backend.applyChanges calls, each
     returning the incremental patch of that call as the oracle restates it (am_oracle_apply.c)."""
 
-    def __init__(self, doc_bytes: bytes = None):
+    def __init__(self, doc_bytes: bytes = None, doc_hashes: bytes = None, graph_rebuilt: bool = False):
+        """doc_hashes: the hashes of the document's changes as the reference rebuilds them (32 bytes each, document order): lets the
+        session follow the reference when it rebuilds its hash graph (am_oracle.h amo_set_document_history); graph_rebuilt: the
+        reference had been asked for the document's changes before the first call."""
         L = lib()
         self._keep = []
         if doc_bytes is None:
@@ -155,6 +160,10 @@ class OracleSession:
             self._h = L.amo_load_document(buf.ctypes.data, buf.size, err, 512)
             if not self._h:
                 raise OracleError(err.value.decode())
+            if doc_hashes is not None:
+                hb = np.frombuffer(doc_hashes, dtype=np.uint8).copy()
+                self._keep.append(hb)
+                L.amo_set_document_history(self._h, hb.ctypes.data if hb.size else None, hb.size // 32, 1 if graph_rebuilt else 0)
 
     def apply(self, changes, local=False) -> str:
         """changes: list of bytes. Returns JSON.stringify(patch); raises OracleError (the session is then dead)."""

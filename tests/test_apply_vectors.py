@@ -108,3 +108,34 @@ def test_whole_document_patch_after_a_session_equals_the_bulk_replay():
         if done >= 300:
             break
     assert done >= 200
+
+
+def test_oracle_follows_the_reference_onto_loaded_documents():
+    """Backend.load + applyChanges sessions recorded from the live reference (tests/golden/apply_campaign_loaded.json.gz: 48 sessions,
+    every one also with the hash graph rebuilt by a query before the first call). A BackendDoc made by load schedules against the
+    document's heads until a round applies nothing, then rebuilds the hash graph into an index that lacks what the running call has
+    applied so far (new.js:1822-1841, 1887-1912): the oracle restates that loop; the hashes of the document's changes, which it does
+    not rebuild itself, come from the fixture (`doc_hashes`, the reference's getAllChanges(load(doc))). Every patch must be the
+    reference's -- `pendingChanges`, `clock` and `deps` of the calls around the rebuild included."""
+    with open(os.path.join(HERE, "golden", "apply_campaign_loaded.json.gz"), "rb") as f:
+        d = json.loads(gzip.decompress(f.read()))
+    pool = [base64.b64decode(x) for x in d["pool"]]
+    equal = 0
+    for s in d["sessions"]:
+        session = oracle_lib.OracleSession(base64.b64decode(s["doc"]), base64.b64decode(s["doc_hashes"]), bool(s.get("graph")))
+        for ci, (call, want) in enumerate(zip(s["calls"], s["patches"])):
+            try:
+                got = session.apply([pool[k] for k in call])
+            except oracle_lib.OracleError as e:
+                assert isinstance(want, dict), f"{s['name']} call {ci}: the oracle rejects what the reference accepts: {e}"
+                break
+            assert not isinstance(want, dict), f"{s['name']} call {ci}: the oracle accepts what the reference rejects"
+            assert same_patch(got, want), f"{s['name']} call {ci}:\n{got}\n{want}"
+            equal += 1
+    assert equal == 681
+    # without the hashes the oracle says so instead of guessing
+    s = next(x for x in d["sessions"] if x["name"] == "m:52:4:160:3#1")
+    session = oracle_lib.OracleSession(base64.b64decode(s["doc"]))
+    with pytest.raises(oracle_lib.OracleError, match="unsupported"):
+        for call in s["calls"]:
+            session.apply([pool[k] for k in call])
