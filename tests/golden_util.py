@@ -15,7 +15,7 @@ def _all_names():
 
 def fixture_names():
     """Fixtures holding binary changes and the reference's loadChanges + getPatch result."""
-    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n not in ("save_generated", "doc_history", "bloom_filters")]
+    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n not in ("save_generated", "doc_history", "bloom_filters", "ref_apply_vector_doc_hashes")]
 
 
 def save_digest_cases():

@@ -15,10 +15,10 @@ import oracle_lib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-# the one vector the oracle does not decide: a change that a LOADED document already holds is given again, which the reference
-# recognises after rebuilding the document's hash graph (new.js:1836-1840, test.js:1291-1302) -- the oracle knows a loaded
-# document's heads only
-ORACLE_LEAVES_OUT = {475}
+# (Vector 475 gives a LOADED document a change it already holds, which the reference recognises after rebuilding the document's hash
+# graph, new.js:1836-1840, test.js:1291-1302: decided by the oracle since round 4, with the hashes of the document's changes from
+# tests/golden/ref_apply_vector_doc_hashes.json -- the oracle restates the scheduling, not the reconstruction of changes.)
+ORACLE_LEAVES_OUT = set()
 
 
 def _ordered(text):
@@ -55,9 +55,11 @@ def test_oracle_reproduces_every_applychanges_call_of_the_reference_suites():
     vectors, pool = load_vectors()
     checked, refused = set(), set()
     n_patches = n_errors = 0
+    with open(os.path.join(HERE, "golden", "ref_apply_vector_doc_hashes.json")) as f:
+        doc_hashes = {int(k): base64.b64decode(v) for k, v in json.load(f)["doc_hashes"].items()}
     for chain in chains(vectors):
         first = vectors[chain[0]]
-        session = oracle_lib.OracleSession(pool[first["doc"]] if "doc" in first else None)
+        session = oracle_lib.OracleSession(pool[first["doc"]], doc_hashes[first["doc"]]) if "doc" in first else oracle_lib.OracleSession()
         for j in chain:
             v = vectors[j]
             batch = [pool[k] for k in v["changes"]]
