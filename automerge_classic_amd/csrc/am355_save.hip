@@ -501,7 +501,11 @@ int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const 
       std::thread t; int rc = 0; std::string err;
       ~DepTask() { if (t.joinable()) t.join(); }
     } deps;
-    deps.t = std::thread([&in, &meta, &deps]() { deps.rc = history_dependencies(in, meta, deps.err); });
+    deps.t = std::thread([&in, &meta, &deps]() {
+      // (an exception must not leave this thread: the C ABI reports it like any other failure of the call)
+      try { deps.rc = history_dependencies(in, meta, deps.err); }
+      catch (const std::exception& e) { deps.rc = HISTORY_UNSUPPORTED; deps.err = std::string("history: ") + e.what(); }
+    });
     // ---- device, stage 1: ids -> slots, preds by slot, the changes' slot ranges (am355_hist.hip) ----
     const uint32_t NC = (uint32_t)meta.chg.size(), NA = (uint32_t)c->actors.size(), W = meta.word_base[NA];
     const size_t key_bytes = c->doc_meta.col_len[C_KEY_STR], val_bytes = c->doc_meta.col_len[C_VAL_RAW];
