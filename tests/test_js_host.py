@@ -145,7 +145,7 @@ def test_loaded_lineages_survive_a_context_that_moved_on_emulated():
 def test_states_after_calls_onto_loaded_documents_save_like_the_reference_emulated():
     """Backend.load + applyChanges sessions through the wrapper and the reference side by side: Backend.save and Backend.getAllChanges of
     the two states byte-identical after every fourth call (oracle/js/loaded_state_check.js)."""
-    env = _emu_env(NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"), AUTOMERGE_BACKEND_PATH="/root/reference/backend")
+    env = _emu_env(NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"), AUTOMERGE_BACKEND_PATH="/root/reference/backend", EVERY_SESSION="2")
     out = subprocess.run([NODE, os.path.join(ROOT, "oracle", "js", "loaded_state_check.js")], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0 and "diff 0; getAllChanges" in out.stdout and out.stdout.strip().split("getAllChanges same ")[1].split()[2] == "0", out.stdout[-2000:] + out.stderr[-2000:]
 
