@@ -173,6 +173,7 @@ extern "C" int am355_get_rows(am355_ctx* c, uint32_t* obj_actor, uint32_t* obj_c
                               uint32_t* key_len, uint32_t* action, uint32_t* val_tl, uint32_t* val_off, uint32_t* pred_num, uint32_t* id_ctr,
                               uint32_t* id_actor, uint8_t* insert, uint32_t* succ_cnt) {
   if (!c || !c->replayed) return AM355_E_STATE;
+  if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_get_rows on a sharded context (foreign rows are decoded as far as their object columns only)");
   (void)hipSetDevice(c->device);
   size_t N = c->n_ops;
   hipStream_t st = c->stream;

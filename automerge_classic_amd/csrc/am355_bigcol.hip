@@ -266,10 +266,28 @@ __global__ __launch_bounds__(BLOCK) void kb_expand(BigColWork w, uint32_t kind, 
           if (uv >= NONE32) { atomicOr(&w.info->flags, (uint32_t)F_OVERFLOW); uv = 0; }
           val = (uint32_t)uv;
         }
-        // a literal never repeats its predecessor, a repetition never continues the previous value (encoding.js:870-887)
-        if (cnt < 0 ? off > 0 : false) {
-          uint32_t pt = vt - 1;
-          if (w.tok_lo[pt] == vlo && w.tok_hi[pt] == vhi && (w.tok_meta[pt] & 0xff) == (vmeta & 0xff)) atomicOr(&w.info->flags, (uint32_t)F_BAD_RLE);
+        // a literal never repeats its predecessor (encoding.js:826), and the first value of a record never continues the last
+        // value of the record in front of it -- a repetition after a repetition or a literal (encoding.js:866-868), a literal
+        // after a repetition (lastValue survives into the literal, :826); a null run in between resets it
+        uint32_t pt = NONE32;
+        if (off > 0) { if (cnt < 0) pt = vt - 1; }
+        else if (lo > r0) {
+          uint32_t tp = w.rec_tok[lo - 1];
+          int64_t pcnt = 0;
+          big_tok_sint(w.tok_lo[tp], w.tok_hi[tp], w.tok_meta[tp], pcnt);
+          if (pcnt > 1) pt = tp + 1;
+          else if (pcnt < 0) pt = t - 1;
+        }
+        if (pt != NONE32) {  // (equal NUMBERS: an over-long encoding of the same value is the same value to readRawValue)
+          bool same;
+          if (kind == BK_DELTA) {
+            int64_t a = 0, b = 1;
+            same = big_tok_sint(w.tok_lo[pt], w.tok_hi[pt], w.tok_meta[pt], a) && big_tok_sint(vlo, vhi, vmeta, b) && a == b;
+          } else {
+            uint64_t a = 0, b = 1;
+            same = big_tok_uint(w.tok_lo[pt], w.tok_hi[pt], w.tok_meta[pt], a) && big_tok_uint(vlo, vhi, vmeta, b) && a == b;
+          }
+          if (same) atomicOr(&w.info->flags, (uint32_t)F_BAD_RLE);
         }
       }
     }

@@ -11,6 +11,7 @@
 #include "am355_prims.h"
 #include "am355_render.h"
 #include "am355_host.h"
+#include "am355_pinflate.h"
 #include "am355_history.h"
 #include "am355_delta.h"
 #include "am355_apply.h"
@@ -291,6 +292,7 @@ struct am355_ctx {
   HistoryOutput history;                                   // result of am355_doc_changes
   bool history_ok = false; uint32_t history_flags = 0;
   std::vector<std::vector<uint8_t>> inflate_scratch;       // am355_load_document: inflated columns, longest first (capacity kept between loads)
+  std::vector<std::unique_ptr<PInflateJob>> pinflate_jobs;  // am355_load_document: chunked decode of the long DEFLATE streams (symbol buffers kept between loads)
   std::vector<uint32_t> doc_col_rows;                      // loaded document: values per op column (BigCol order), parallel decode only
   std::vector<std::pair<uint32_t, std::vector<uint8_t>>> doc_chg_cols;  // loaded document: change-metadata columns, inflated
   std::vector<uint8_t> doc_tail;                           // loaded document: headsIndexes + extraBytes

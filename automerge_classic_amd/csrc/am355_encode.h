@@ -19,13 +19,14 @@ inline size_t enc_numbers_bound(uint32_t n) { return 10 * (size_t)n + 16; }
 // `seg` (every encoder; null = the column is one segment): seg[i] = index of the first value of the segment of value i. The columns
 // of ALL changes of a document are encoded in one go for the history reconstruction (am355_hist.hip): a segment is one change,
 // runs / literal stretches / null runs / delta chains end where a segment ends, and an all-null segment is empty.
+// `cap`: bytes `out` holds -- a run that would end beyond it is not written (*d_len still reports the full size: the caller compares).
 void enc_rle_numbers(const uint32_t* vals, const uint8_t* nullmask, uint32_t n, bool is_signed, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st,
-                     const uint32_t* seg = nullptr);
+                     const uint32_t* seg = nullptr, uint32_t cap = 0xffffffffu);
 // successive differences of the non-null values (encoding.js:932-948); deltas / nullmask feed enc_rle_numbers(is_signed)
 void enc_delta_prepare(const uint32_t* vals, uint32_t n, uint32_t* deltas, uint8_t* nullmask, EncWork& w, hipStream_t st, const uint32_t* seg = nullptr);
 // RLE of nullable UTF-8 strings given as arena ranges (len NONE32 = null)
 void enc_rle_strings(const uint8_t* arena, const uint32_t* off, const uint32_t* len, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st,
-                     const uint32_t* seg = nullptr);
+                     const uint32_t* seg = nullptr, uint32_t cap = 0xffffffffu);
 // alternating run lengths, the first run counts `false` (encoding.js:1061-1135)
 void enc_boolean(const uint8_t* vals, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st, const uint32_t* seg = nullptr);
 // concatenation of the value bytes (val_tl >> 4 bytes at val_off) of every row

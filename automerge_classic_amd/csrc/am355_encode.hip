@@ -160,11 +160,13 @@ __global__ __launch_bounds__(BLOCK) void ke_run_sizes(Src s, uint32_t n, const u
 template <class Src>
 __global__ __launch_bounds__(BLOCK) void ke_run_write(Src s, uint32_t n, const uint32_t* __restrict__ run_ex, const uint32_t* __restrict__ run_first,
                                                       const uint32_t* __restrict__ grp_flag, const uint32_t* __restrict__ grp_ex,
-                                                      const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ off_ex, uint8_t* __restrict__ out) {
+                                                      const uint32_t* __restrict__ grp_first, const uint32_t* __restrict__ off_ex, uint8_t* __restrict__ out,
+                                                      uint32_t cap) {
   uint32_t r = gtid();
   if (r >= n) return;
   uint32_t R = run_ex[n];
   if (r >= R) return;
+  if (off_ex[r + 1] > cap) return;  // never past the caller's carve-out: the caller sees the total (d_len) and sizes again or refuses
   uint32_t a = run_first[r], len = run_first[r + 1] - a;
   uint8_t* p = out + off_ex[r];
   if (s.is_null(a)) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void ke_run_write(Src s, uint32_t n, const u
 }
 
 template <class Src>
-static void enc_rle(Src s, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st) {
+static void enc_rle(Src s, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st, uint32_t cap) {
   if (!n) { (void)hipMemsetAsync(d_len, 0, 4, st); return; }
   AM355_LAUNCH_INDEPENDENT(ke_run_flags<Src>, grid_for(n + 1), dim3(BLOCK), st, s, n, w.flag);
   exclusive_scan_u32(w.flag, w.run_ex, n + 1, nullptr, w.scan_ws, st);
@@ -195,16 +197,16 @@ static void enc_rle(Src s, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len
                            (const uint32_t*)w.grp_flag, (const uint32_t*)w.grp_ex, (const uint32_t*)w.grp_first, w.size);
   exclusive_scan_u32(w.size, w.off_ex, n + 1, d_len, w.scan_ws, st);
   AM355_LAUNCH_INDEPENDENT(ke_run_write<Src>, grid_for(n), dim3(BLOCK), st, s, n, (const uint32_t*)w.run_ex, (const uint32_t*)w.run_first,
-                           (const uint32_t*)w.grp_flag, (const uint32_t*)w.grp_ex, (const uint32_t*)w.grp_first, (const uint32_t*)w.off_ex, out);
+                           (const uint32_t*)w.grp_flag, (const uint32_t*)w.grp_ex, (const uint32_t*)w.grp_first, (const uint32_t*)w.off_ex, out, cap);
 }
 
 void enc_rle_numbers(const uint32_t* vals, const uint8_t* nullmask, uint32_t n, bool is_signed, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st,
-                     const uint32_t* seg) {
-  enc_rle(NumSrc{vals, nullmask, is_signed, seg}, n, w, out, d_len, st);
+                     const uint32_t* seg, uint32_t cap) {
+  enc_rle(NumSrc{vals, nullmask, is_signed, seg}, n, w, out, d_len, st, cap);
 }
 void enc_rle_strings(const uint8_t* arena, const uint32_t* off, const uint32_t* len, uint32_t n, EncWork& w, uint8_t* out, uint32_t* d_len, hipStream_t st,
-                     const uint32_t* seg) {
-  enc_rle(StrSrc{arena, off, len, seg}, n, w, out, d_len, st);
+                     const uint32_t* seg, uint32_t cap) {
+  enc_rle(StrSrc{arena, off, len, seg}, n, w, out, d_len, st, cap);
 }
 
 // byte offset at which every segment's bytes begin in the output of the LAST run-length encode done with `w` (seg_base[k] = index of

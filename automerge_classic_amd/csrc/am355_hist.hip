@@ -28,7 +28,10 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + BLOCK - 1) / BLOCK); 
 static size_t al256(size_t b) { return carve_round(b); }
 
 static size_t hist_col_cap(int k, uint32_t M, uint32_t P, size_t key_bytes, size_t val_bytes) {
-  if (k == 4) return enc_numbers_bound(M) + key_bytes + 16;   // keyStr: headers + length prefixes + the key bytes
+  // keyStr: headers + length prefixes + the key bytes. `key_bytes` is the caller's estimate -- the document's own key column holds a
+  // repeated key once, the changes hold it once per change, so the rebuilt columns can be far longer than it; the encoder never
+  // writes past this bound and reports the size it needs, with which the caller binds again (am355_doc_changes)
+  if (k == 4) return enc_numbers_bound(M) + key_bytes + 16;
   if (k == 8) return val_bytes + 16;                          // valRaw
   return enc_numbers_bound(k >= 10 ? P : M);
 }
@@ -406,7 +409,7 @@ void hist_stage2(const OpCols& rows, const uint8_t* arena, size_t arena_len, His
   enc_rle_numbers(h.v_key_actor, nullptr, M, false, h.enc, h.col_out[2], h.col_len + 2, st, h.seg); ranges(2, false, false, M);
   enc_delta_prepare(h.v_key_ctr, M, h.deltas, h.nullmask, h.enc, st, h.seg);
   enc_rle_numbers(h.deltas, h.nullmask, M, true, h.enc, h.col_out[3], h.col_len + 3, st, h.seg); ranges(3, false, false, M);
-  enc_rle_strings(arena, h.v_key_off, h.v_key_len, M, h.enc, h.col_out[4], h.col_len + 4, st, h.seg); ranges(4, false, false, M);
+  enc_rle_strings(arena, h.v_key_off, h.v_key_len, M, h.enc, h.col_out[4], h.col_len + 4, st, h.seg, (uint32_t)std::min<size_t>(h.col_cap[4], 0xffffffffu)); ranges(4, false, false, M);
   enc_boolean(h.v_insert, M, h.enc, h.col_out[5], h.col_len + 5, st, h.seg); ranges(5, false, false, M);
   enc_rle_numbers(h.v_action, nullptr, M, false, h.enc, h.col_out[6], h.col_len + 6, st, h.seg); ranges(6, false, false, M);
   enc_rle_numbers(h.v_val_tl, nullptr, M, false, h.enc, h.col_out[7], h.col_len + 7, st, h.seg); ranges(7, false, false, M);

@@ -625,8 +625,9 @@ void chain_mark(const uint32_t* next, uint32_t n, uint32_t* mark, void* work, hi
   (void)hipMemsetAsync(flagw, 0, 2 * 4 * (size_t)n_words, st);
   hipLaunchKernelGGL(kc_tile_exits, dim3(tiles), dim3(BLOCK), 0, st, next, n, (const uint32_t*)mark, exit1, flagw, cstartw);
   AM355_LAUNCH_INDEPENDENT(kc_word_counts, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), st, (const uint32_t*)flagw, n_words, wrank);
-  exclusive_scan_u32(wrank, wrank, n_words, n_nodes, scan_ws, st);
-  AM355_LAUNCH_INDEPENDENT(kc_compact, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), st, n, n_words, (const uint32_t*)flagw, (const uint32_t*)wrank,
+  uint32_t* wrank_ex = p + 3 * cap;  // (its own array: the scan kernels take `in` and `out` as __restrict__)
+  exclusive_scan_u32(wrank, wrank_ex, n_words, n_nodes, scan_ws, st);
+  AM355_LAUNCH_INDEPENDENT(kc_compact, dim3((n_words + BLOCK - 1) / BLOCK), dim3(BLOCK), st, n, n_words, (const uint32_t*)flagw, (const uint32_t*)wrank_ex,
                            (const uint32_t*)exit1, (const uint32_t*)cstartw, cpos, ca, cmark);
   // a compact chain visits every tile at most once
   int rounds = 1;

@@ -163,6 +163,9 @@ int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, size_t* o
     *out_len = c->doc_bytes.size();
     return AM355_OK;
   }
+  // (a sharded replay decodes the rows of foreign objects only as far as their object columns: their key / value / pred fields are
+  // whatever an earlier replay left there)
+  if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_save on a sharded context");
   if (c->n_pending) return fail(c, AM355_E_UNSUPPORTED, "changes are queued: the document is saved by the JS path");
   if (!c->is_document && c->has_unknown_cols) return fail(c, AM355_E_UNSUPPORTED, "a change carries columns this engine does not model: the document is saved by the JS path");
   hipStream_t st = c->stream;
@@ -458,6 +461,7 @@ int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const 
   if (!c || !arena || !offsets || !n_changes || !hashes) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   if (!c->replayed || !c->is_document) return fail(c, AM355_E_STATE, "am355_load_document and am355_replay must be called first");
   (void)hipSetDevice(c->device);
+  if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_doc_changes on a sharded context");
   if (!(c->history_ok && c->history_flags == (flags & 1))) {
     if (c->doc_other_ops_cols) return fail(c, AM355_E_UNSUPPORTED, "document has op columns this engine does not model (child / link / unknown): history comes from the JS path");
     if (c->doc_col_rows.size() != BIG_NCOL) return fail(c, AM355_E_UNSUPPORTED, "history needs the parallel column decode (AM355_DOC_SERIAL is set)");
@@ -504,11 +508,17 @@ int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const 
     deps.t = std::thread([&in, &meta, &deps]() {
       // (an exception must not leave this thread: the C ABI reports it like any other failure of the call)
       try { deps.rc = history_dependencies(in, meta, deps.err); }
+      catch (const std::bad_alloc&) { deps.rc = -1; }   // (out of memory is not "unsupported": the JS host must not quietly retry on its own path)
       catch (const std::exception& e) { deps.rc = HISTORY_UNSUPPORTED; deps.err = std::string("history: ") + e.what(); }
     });
     // ---- device, stage 1: ids -> slots, preds by slot, the changes' slot ranges (am355_hist.hip) ----
     const uint32_t NC = (uint32_t)meta.chg.size(), NA = (uint32_t)c->actors.size(), W = meta.word_base[NA];
-    const size_t key_bytes = c->doc_meta.col_len[C_KEY_STR], val_bytes = c->doc_meta.col_len[C_VAL_RAW];
+    // (the keyStr output is sized from the document's key column first; a key that many changes write is held once there and once
+    // per change here: the encoder then stops at the bound and reports the size it needs, and the stages run again with it)
+    size_t key_bytes = c->doc_meta.col_len[C_KEY_STR];
+    const size_t val_bytes = c->doc_meta.col_len[C_VAL_RAW];
+    int bind_attempt = 0;
+  bind_again:
     if (!c->d_hist.ensure(hist_bytes(N, P, NC, NA, W, key_bytes, val_bytes))) return fail(c, AM355_E_NOMEM, "device allocation failed (history)");
     HistBufs hb;
     hist_bind(hb, c->d_hist.p, N, P, NC, NA, W, key_bytes, val_bytes);
@@ -579,6 +589,12 @@ int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const 
     HIPCHK(c, hipMemcpyAsync(d_col_off, hb.col_off, 4 * (size_t)HIST_NCOL * 2 * c1, hipMemcpyDeviceToHost, st));
     if (NC) HIPCHK(c, hipMemcpyAsync(d_abits, hb.abits, 4 * (size_t)NC * AW, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (d_col_len[4] > hb.col_cap[4] && bind_attempt == 0) {
+      bind_attempt = 1;
+      key_bytes = (size_t)d_col_len[4] + 64;
+      lap("key column beyond its bound: bound again");
+      goto bind_again;
+    }
     if (d_flags[0] & HF_INVALID) return fail(c, AM355_E_INVALID, "the document's rows do not re-encode (an operation the reference throws on)");
     if (d_flags[0] & HF_UNSUPPORTED) return fail(c, AM355_E_UNSUPPORTED, "a value or key the reference does not re-encode byte for byte: the JS path decides");
     // (the value bytes of the rows must cover the valRaw column exactly: a longer column makes extra rows in the reference)
@@ -598,6 +614,7 @@ int doc_changes_impl(am355_ctx* c, uint32_t flags, const uint8_t** arena, const 
     lap("columns of all changes (device)");
     c->history = HistoryOutput{};
     deps.t.join();
+    if (deps.rc == -1) return fail(c, AM355_E_NOMEM, "history: out of host memory");
     if (deps.rc == HISTORY_INVALID) return fail(c, AM355_E_INVALID, "%s", deps.err.c_str());
     if (deps.rc) return fail(c, AM355_E_UNSUPPORTED, "%s", deps.err.c_str());
     lap("dependency indexes joined");

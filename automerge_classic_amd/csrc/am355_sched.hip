@@ -18,6 +18,7 @@
 // What is left to the host is what the in-order path leaves to it as well (plan_fast with an order, am355_replay.hip, beside the decode kernels):
 // sequence numbers, clock, per-actor span tables -- O(changes) over 32-byte digests.
 #include "am355_sched.h"
+#include <algorithm>
 #include "am355_prims.h"
 
 namespace am355 {
@@ -432,7 +433,12 @@ void launch_sched_general(const ChangeMeta* metas, const ChangeBrief* briefs, ui
                           uint32_t seq, hipStream_t st) {
   // (read per call: the tests switch them inside one process)
   const char* e_sweeps = getenv("AM355_SCHED_SWEEPS");
-  const uint32_t max_sweeps = e_sweeps && atoi(e_sweeps) > 0 ? (uint32_t)atoi(e_sweeps) : (1u << 16);
+  // A sweep settles one dependency level and looks at all n changes, in ONE workgroup: a chain of 10^5 changes delivered in reverse
+  // order would hold that workgroup for n sweeps x n changes (~10 s). The sweeps are bounded by the work they may cost (n x sweeps
+  // <= 2^32 change visits, a few tens of milliseconds); beyond it SW_UNFINISHED hands the batch to the host's scheduler, which walks
+  // such a chain in O(n).
+  const uint32_t sweeps_by_work = (uint32_t)std::min<uint64_t>(1u << 16, std::max<uint64_t>(256, (1ull << 32) / std::max<uint32_t>(n, 1u)));
+  const uint32_t max_sweeps = e_sweeps && atoi(e_sweeps) > 0 ? (uint32_t)atoi(e_sweeps) : sweeps_by_work;
   const bool force_big = getenv("AM355_SCHED_BIG") != nullptr;  // (tests: the global-memory variant on small batches too)
   (void)hipMemsetAsync(s.words, 0, 4 * SW_NUM, st);
   (void)hipMemsetAsync(s.first_rank, 0xff, 4 * ((size_t)slot_mask + 1), st);

@@ -1,6 +1,7 @@
 // Staging of the C ABI (include/am355.h): am355_load_changes (gather into the pinned arena, inflate, H2D) and the host part of
 // am355_load_document (container, header, checksum, inflate of the columns, change metadata scan). See am355_ctx.h.
 #include "am355_ctx.h"
+#include "am355_pinflate.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // staging
@@ -340,7 +341,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   if (!read_uleb_host(h, hl, ho, nh) || nh > (hl - ho) / 32) return bad(AM355_F_BAD_LEB, "bad document header");
   c->heads.assign(h + ho, h + ho + nh * 32);
   ho += (size_t)nh * 32;
-  struct Col { uint64_t id, len; std::vector<uint8_t>* data = nullptr; const uint8_t* p = nullptr; size_t n = 0; };  // data: inflated bytes (a scratch vector of the context)
+  struct Col { uint64_t id, len; std::vector<uint8_t>* data = nullptr; const uint8_t* p = nullptr; size_t n = 0; PInflateJob* pj = nullptr; uint8_t last = 0; };  // data: inflated bytes (a scratch vector of the context); pj: inflated in parallel, bytes not resolved yet (p == nullptr)
   auto read_dir = [&](std::vector<Col>& cols) -> bool {
     uint64_t n;
     if (!read_uleb_host(h, hl, ho, n) || n > hl) return false;
@@ -357,7 +358,10 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   std::vector<Col> ccols, ocols;
   if (!read_dir(ccols) || !read_dir(ocols)) return bad(AM355_F_BAD_COLUMNS, "bad column directory");
   // column slices, then: checksum | copy of the document bytes (Backend.save of an unchanged document returns them, new.js:2034) |
-  // raw-DEFLATE of every compressed column (columnar.js:1062-1067), all on the host pool, longest columns first
+  // raw-DEFLATE of every compressed column (columnar.js:1062-1067), all on the host pool. A column is ONE DEFLATE stream: the
+  // 34 MB key column of the config-5 document took one thread 55 ms while sixty others had nothing to do, so long streams are
+  // decoded in chunks (am355_pinflate.h: block starts found by search, back-references beyond a chunk's start as markers that
+  // are resolved once the chunk in front is known) and their bytes land in the pinned arena directly.
   std::vector<Col*> all_cols;
   for (Col& col : ccols) all_cols.push_back(&col);
   for (Col& col : ocols) all_cols.push_back(&col);
@@ -368,7 +372,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     ho += (size_t)col->len;
   }
   {
-    std::vector<Col*> deflated;
+    std::vector<Col*> deflated, par;
     for (Col* col : all_cols)
       if (col->id & 8) deflated.push_back(col);
     std::sort(deflated.begin(), deflated.end(), [](const Col* x, const Col* y) { return x->len > y->len; });
@@ -377,31 +381,90 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     // 34 MB vector costs ~10 ms of page faults on the thread that is the critical path of this call)
     if (c->inflate_scratch.size() < deflated.size()) c->inflate_scratch.resize(deflated.size());
     for (size_t k = 0; k < deflated.size(); k++) deflated[k]->data = &c->inflate_scratch[k];
-    const unsigned n_tasks = (unsigned)deflated.size() + 2;
-    c->pool->run(n_tasks, [&](unsigned t) {
-      // (the two longest columns first, then the checksum, which takes about as long as a mid-sized column)
-      unsigned sum_slot = std::min<unsigned>(2, (unsigned)deflated.size()), copy_slot = sum_slot + 1;
-      if (t == sum_slot) { check_sum(); return; }
-      if (t == copy_slot) { c->doc_bytes.assign(doc, doc + len); return; }
-      size_t k = t < sum_slot ? t : t - 2;
-      Col* col = deflated[k];
-      irc[k] = inflate_raw(col->p, (size_t)col->len, *col->data, INFLATE_CAP);
+    // which streams are worth chunks (AM355_PINFLATE_MIN: compressed bytes, tests lower it; AM355_PINFLATE=0 switches the path off)
+    const char* pe = getenv("AM355_PINFLATE");
+    const char* pmin_env = getenv("AM355_PINFLATE_MIN");
+    const char* pchunk_env = getenv("AM355_PINFLATE_CHUNK");
+    const size_t par_min = pmin_env && atol(pmin_env) > 0 ? (size_t)atol(pmin_env) : (size_t)1 << 20;
+    const bool par_on = c->pool->size() >= 1 && !(pe && *pe == '0');
+    size_t par_bytes = 0;
+    for (Col* col : deflated)
+      if (par_on && col->len >= par_min) { par.push_back(col); par_bytes += (size_t)col->len; }
+    size_t chunk_bytes = std::min<size_t>((size_t)1 << 20, std::max<size_t>((size_t)128 << 10, par_bytes / (3 * ((size_t)c->pool->size() + 1))));
+    if (pchunk_env && atol(pchunk_env) > 0) chunk_bytes = (size_t)atol(pchunk_env);
+    while (c->pinflate_jobs.size() < par.size()) c->pinflate_jobs.emplace_back(new PInflateJob);
+    std::vector<std::atomic<unsigned>> chunks_left(par.size());
+    struct Task { int kind; unsigned a, b; };  // 0 search (stream a, chunk b) | 1 checksum | 2 copy | 3 decode (a, b) | 4 whole stream (deflated[a])
+    std::vector<Task> tasks;
+    for (size_t s = 0; s < par.size(); s++) {
+      PInflateJob* job = c->pinflate_jobs[s].get();
+      job->prepare(par[s]->p, (size_t)par[s]->len, INFLATE_CAP, chunk_bytes);
+      par[s]->pj = job;
+      chunks_left[s].store(job->n_chunks);
+      for (unsigned k = 1; k < job->n_chunks; k++) tasks.push_back(Task{0, (unsigned)s, k});
+    }
+    // (every search task in front of every decode task: a decode task spins for the searches of the chunks behind its own, and
+    // the pool hands tasks out in index order -- all of them have been taken by a thread when a decode task starts)
+    tasks.push_back(Task{1, 0, 0});
+    tasks.push_back(Task{2, 0, 0});
+    for (size_t s = 0; s < par.size(); s++)
+      for (unsigned k = 0; k < c->pinflate_jobs[s]->n_chunks; k++) tasks.push_back(Task{3, (unsigned)s, k});
+    for (size_t k = 0; k < deflated.size(); k++)
+      if (!deflated[k]->pj) tasks.push_back(Task{4, (unsigned)k, 0});
+    c->pool->run((unsigned)tasks.size(), [&](unsigned t) {
+      const Task& tk = tasks[t];
+      switch (tk.kind) {
+        case 0: c->pinflate_jobs[tk.a]->search(tk.b); break;
+        case 1: check_sum(); break;
+        case 2: c->doc_bytes.assign(doc, doc + len); break;
+        case 3: {
+          PInflateJob* job = c->pinflate_jobs[tk.a].get();
+          job->decode(tk.b);
+          if (chunks_left[tk.a].fetch_sub(1, std::memory_order_acq_rel) == 1) job->link();  // (the stream's last chunk to finish links it)
+          break;
+        }
+        default: irc[tk.a] = inflate_raw(deflated[tk.a]->p, (size_t)deflated[tk.a]->len, *deflated[tk.a]->data, INFLATE_CAP);
+      }
     });
     lap("inflate | checksum | copy");
+    // streams the chunked decode gave up on (no chain of block starts, output beyond the cap, damaged data): the ordinary
+    // single-stream inflate decides what they are
+    {
+      std::vector<size_t> again;
+      for (size_t k = 0; k < deflated.size(); k++)
+        if (deflated[k]->pj && !deflated[k]->pj->ok) { deflated[k]->pj = nullptr; again.push_back(k); }
+      if (!again.empty())
+        c->pool->run((unsigned)again.size(), [&](unsigned t) { size_t k = again[t]; irc[k] = inflate_raw(deflated[k]->p, (size_t)deflated[k]->len, *deflated[k]->data, INFLATE_CAP); });
+    }
     if (!sum_ok) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
     int rd = 0;
     for (Col* col : all_cols) {  // (errors in column order, as a sequential reader would meet them)
       if (!(col->id & 8)) continue;
       size_t k = (size_t)(std::find(deflated.begin(), deflated.end(), col) - deflated.begin());
       if (irc[k]) { rd = irc[k] == 1 ? 2 : irc[k] == 2 ? 3 : 4; break; }
-      col->p = col->data->data();
-      col->n = col->data->size();
+      if (col->pj) { col->p = nullptr; col->n = col->pj->out_len; col->last = col->pj->last_byte; }
+      else { col->p = col->data->data(); col->n = col->data->size(); col->last = col->n ? col->p[col->n - 1] : 0; }
       col->id ^= 8;
     }
     if (rd == 2) return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
     if (rd == 3) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "document column inflates beyond the 4 GiB limit"); }
     if (rd == 4) return fail(c, AM355_E_NOMEM, "inflate: out of memory");
   }
+  // bytes of a chunk-decoded column into a vector (columns that do not go to the arena: change metadata, unknown op columns)
+  auto resolve_to_vector = [&](Col& col) -> bool {
+    if (!col.pj) return true;
+    PInflateJob* job = col.pj;
+    col.data->resize(job->out_len);
+    std::vector<std::pair<unsigned, unsigned>> ps;
+    for (unsigned ci = 0; ci < job->chain.size(); ci++)
+      for (unsigned r = 0; r < job->n_pieces(ci); r++) ps.emplace_back(ci, r);
+    c->pool->run((unsigned)ps.size(), [&](unsigned t) { job->resolve(ps[t].first, ps[t].second, col.data->data()); });
+    col.pj = nullptr;
+    col.p = col.data->data();
+    return !job->resolve_failed.load();
+  };
+  for (Col& col : ccols)
+    if (!resolve_to_vector(col)) return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
   // (headsIndexes and extraBytes follow; neither influences the patch: kept for am355_save. The reference reads one index per
   // head when anything follows the columns, columnar.js:1032-1034)
   if (ho < hl) {
@@ -420,6 +483,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     bool k = false;
     for (uint64_t id : known) k = k || id == col.id;
     if (!k && col.n) c->doc_other_ops_cols = true;
+    if (!k) col.pj = nullptr;  // (its bytes are not looked at: the patch does not depend on them and am355_save refuses such documents)
   }
 
   // ---- change metadata: clock in first-appearance order, seq continuity (new.js:1645-1675) ----
@@ -467,9 +531,12 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   ChangeMeta& m = c->doc_meta;
   memset(&m, 0, sizeof m);
   m.n_entries = (uint32_t)na;
-  // (placement first -- offsets only --, the bytes follow in parallel pieces together with their H2D copies)
-  struct Piece { const uint8_t* src; size_t dst, n; };
+  // (placement first -- offsets only --, the bytes follow in parallel pieces; a column's H2D copy is enqueued by the thread that
+  // finishes its last piece)
+  struct Piece { const uint8_t* src; size_t dst, n; PInflateJob* pj; unsigned ci, r; uint32_t place; };
+  struct Placed { size_t off, n; PInflateJob* pj; };
   std::vector<Piece> pieces;
+  std::vector<Placed> placed;
   size_t arena_bytes = 0;
   uint8_t last_byte = 0;
   auto place = [&](int slot, uint64_t id) {
@@ -478,8 +545,15 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     m.col_off[slot] = (uint32_t)arena_bytes;
     m.col_len[slot] = col ? (uint32_t)col->n : 0;
     if (col && col->n) {
-      for (size_t o = 0; o < col->n; o += (size_t)4 << 20) pieces.push_back(Piece{col->p + o, arena_bytes + o, std::min<size_t>((size_t)4 << 20, col->n - o)});
-      last_byte = col->p[col->n - 1];
+      const uint32_t pl = (uint32_t)placed.size();
+      placed.push_back(Placed{arena_bytes, col->n, col->pj});
+      if (col->pj) {
+        for (unsigned ci = 0; ci < col->pj->chain.size(); ci++)
+          for (unsigned r = 0; r < col->pj->n_pieces(ci); r++) pieces.push_back(Piece{nullptr, arena_bytes, 0, col->pj, ci, r, pl});
+      } else {
+        for (size_t o = 0; o < col->n; o += (size_t)4 << 20) pieces.push_back(Piece{col->p + o, arena_bytes + o, std::min<size_t>((size_t)4 << 20, col->n - o), nullptr, 0, 0, pl});
+      }
+      last_byte = col->last;
       arena_bytes += col->n;
     }
   };
@@ -511,16 +585,28 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
       !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
   {
-    std::vector<hipError_t> h2d(pieces.size(), hipSuccess);
+    std::vector<hipError_t> h2d(placed.size(), hipSuccess);
+    std::vector<std::atomic<uint32_t>> left(placed.size());
+    for (auto& x : left) x.store(0);
+    for (const Piece& pc : pieces) left[pc.place].fetch_add(1);
     uint8_t* raw = c->raw.data();
     c->pool->run((unsigned)pieces.size(), [&](unsigned k) {
-      (void)hipSetDevice(c->device);
       const Piece& pc = pieces[k];
-      memcpy(raw + pc.dst, pc.src, pc.n);
-      h2d[k] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + pc.dst, raw + pc.dst, pc.n, hipMemcpyHostToDevice, c->stream);
+      if (pc.pj) pc.pj->resolve(pc.ci, pc.r, raw + pc.dst);
+      else memcpy(raw + pc.dst, pc.src, pc.n);
+      if (left[pc.place].fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        (void)hipSetDevice(c->device);
+        const Placed& pl = placed[pc.place];
+        h2d[pc.place] = hipMemcpyAsync(c->d_arena.as<uint8_t>() + pl.off, raw + pl.off, pl.n, hipMemcpyHostToDevice, c->stream);
+      }
     });
     for (hipError_t e : h2d)
       if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (document columns): %s", hipGetErrorString(e));
+    for (const Placed& pl : placed)
+      if (pl.pj && pl.pj->resolve_failed.load()) {  // a back-reference in front of the stream's first byte
+        (void)hipStreamSynchronize(c->stream);
+        return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
+      }
   }
   lap("gathered, H2D enqueued");
   HIPCHK(c, hipStreamSynchronize(c->stream));

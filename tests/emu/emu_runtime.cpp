@@ -171,3 +171,13 @@ void Runtime::run(dim3 g, dim3 b, const std::function<void()>& fn) {
 }
 
 }  // namespace emu
+
+// ---- test hook (tests/test_pinflate.py): the chunked DEFLATE decoder of am355_pinflate.cpp by itself ----
+#include "am355_pinflate.h"
+extern "C" long am355_emu_pinflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, size_t chunk_bytes, unsigned n_threads) {
+  std::vector<uint8_t> v;
+  if (am355::inflate_raw_parallel(in, in_len, v, out_cap, chunk_bytes, n_threads) != 0) return -1;
+  if (v.size() > out_cap) return -1;
+  if (!v.empty()) memcpy(out, v.data(), v.size());
+  return (long)v.size();
+}

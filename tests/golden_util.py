@@ -15,7 +15,7 @@ def _all_names():
 
 def fixture_names():
     """Fixtures holding binary changes and the reference's loadChanges + getPatch result."""
-    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n not in ("save_generated", "doc_history", "bloom_filters", "ref_apply_vector_doc_hashes")]
+    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n not in ("save_generated", "doc_history", "doc_history_longkey", "bloom_filters", "ref_apply_vector_doc_hashes")]
 
 
 def save_digest_cases():
@@ -29,6 +29,16 @@ def history_golden():
     the error it throws."""
     with open(os.path.join(GOLDEN_DIR, "doc_history.json")) as f:
         return json.load(f)
+
+
+def longkey_history_golden():
+    """Reference-made documents whose long map keys are overwritten by many changes (oracle/make_longkey_history_golden.py)."""
+    import base64
+    with open(os.path.join(GOLDEN_DIR, "doc_history_longkey.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases.values():
+        c["doc_bytes"] = base64.b64decode(c["doc"])
+    return cases
 
 
 def history_digests(arena, offsets, hashes):

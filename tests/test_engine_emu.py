@@ -407,6 +407,18 @@ def test_history_of_a_loaded_document_matches_the_reference(eng, name):
     # the patch is untouched by the history query
     assert eng.patch_json() == fx["expected_load"]
 
+@pytest.mark.parametrize("name", sorted(golden_util.longkey_history_golden()))
+def test_history_with_long_keys_that_many_changes_overwrite(eng, name):
+    """The rebuilt changes repeat a key the document's RLE column holds once: the device key column of the history is many times the
+    document's (its output was sized from the document's column). Reference-made document and digests."""
+    want = golden_util.longkey_history_golden()[name]
+    eng.load_document(want["doc_bytes"])
+    eng.replay()
+    assert json.loads(eng.patch_json()) == want["patch"]
+    arena, offsets, hashes = eng.doc_changes()
+    assert len(offsets) - 1 == want["n_changes"] and int(offsets[-1]) == want["bytes"] > 20 * len(want["doc_bytes"])
+    assert golden_util.history_digests(arena, offsets, hashes) == (want["changes_sha256"], want["hashes_sha256"])
+
 
 @pytest.mark.parametrize("case", golden_util.history_golden()["generated"], ids=lambda c: "%s-%s-%s" % (c["workload"], c["scale"], c["deflate"]))
 def test_history_after_save_and_load_of_generated_logs(eng, case):
@@ -684,6 +696,10 @@ def test_objectid_shards_of_changes_and_documents_stitch_to_the_unsharded_patch(
             single.load_changes(log); single.replay()
             got, _ = stitched(lambda e: e.load_changes(log))
             assert got == single.patch_json() == oracle_lib.OracleDoc(log).patch_json()
+        # foreign rows are decoded as far as their object columns: calls that read whole rows refuse a sharded context
+        for call in (ranks[-1].save, ranks[-1].rows):
+            with pytest.raises(engine.UnsupportedChanges):
+                call()
         for doc in docs:
             single.load_document(doc); single.replay()
             got, sizes = stitched(lambda e: e.load_document(doc))
