@@ -189,6 +189,7 @@ extern "C" int am355_get_rows(am355_ctx* c, uint32_t* obj_actor, uint32_t* obj_c
 
 extern "C" int am355_load_changes(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n) { return guarded(c, [&]() { return load_changes_impl(c, arena, offsets, n); }); }
 extern "C" int am355_load_document(am355_ctx* c, const uint8_t* doc, size_t len) { return guarded(c, [&]() { return load_document_impl(c, doc, len); }); }
+extern "C" int am355_backend_load(am355_ctx* c, const uint8_t* doc, size_t len) { return guarded(c, [&]() { return backend_load_impl(c, doc, len); }); }
 extern "C" int am355_replay(am355_ctx* c) { return guarded(c, [&]() { return replay_impl(c); }); }
 extern "C" int am355_fetch_ir(am355_ctx* c, am355_patch_ir* out) { return guarded(c, [&]() { return fetch_ir_impl(c, out); }); }
 extern "C" int am355_patch_json(am355_ctx* c, const char** json, size_t* len) { return guarded(c, [&]() { return patch_json_impl(c, json, len); }); }

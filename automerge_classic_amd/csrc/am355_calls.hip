@@ -2,27 +2,41 @@
 // Bloom filters of the sync protocol. See am355_ctx.h.
 #include "am355_ctx.h"
 
+// The three record tables, device -> pinned host memory, enqueued on the context's stream (no wait). am355_backend_load starts the
+// copy right behind the device stages, beside the tail of the checksum thread; am355_fetch_ir otherwise.
+int ir_copy_enqueue(am355_ctx* c, bool with_edits) {
+  hipStream_t st = c->stream;
+  uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NR = c->counts.n_erecs, NV = c->counts.n_edits;
+  size_t bytes = carve_size(NO, sizeof(am355_ir_object)) + carve_size(NM, sizeof(am355_ir_map)) + carve_size((size_t)NR + 1, sizeof(am355_ir_edit)) + 4096;
+  if (!c->h_ir.ensure(bytes)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+  uint8_t* p = c->h_ir.as<uint8_t>();
+  am355_patch_ir& h = c->hir;
+  auto pull = [&](const void* dev, size_t count, size_t elem) -> const void* {
+    void* dst = p;
+    p += carve_size(count, elem);
+    if (count) (void)hipMemcpyAsync(dst, dev, count * elem, hipMemcpyDeviceToHost, st);
+    return dst;
+  };
+  h.n_objects = NO; h.n_map = NM; h.n_edits = NR; h.n_values = NV;
+  h.objects = (const am355_ir_object*)pull(c->ir.obj, NO, sizeof(am355_ir_object));
+  h.map = (const am355_ir_map*)pull(c->ir.map, NM, sizeof(am355_ir_map));
+  h.edits = with_edits ? (const am355_ir_edit*)pull(c->ir.edit, (size_t)NR + 1, sizeof(am355_ir_edit)) : nullptr;
+  c->ir_copy_enqueued = with_edits ? 2 : 1;
+  return AM355_OK;
+}
+
 int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out, bool with_edits) {
   if (!c) return AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");
   (void)hipSetDevice(c->device);
   if (!c->ir_fetched) {
     hipStream_t st = c->stream;
-    uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NR = c->counts.n_erecs, NV = c->counts.n_edits;
-    size_t bytes = carve_size(NO, sizeof(am355_ir_object)) + carve_size(NM, sizeof(am355_ir_map)) + carve_size((size_t)NR + 1, sizeof(am355_ir_edit)) + 4096;
-    if (!c->h_ir.ensure(bytes)) return fail(c, AM355_E_NOMEM, "host allocation failed");
-    uint8_t* p = c->h_ir.as<uint8_t>();
     am355_patch_ir& h = c->hir;
-    auto pull = [&](const void* dev, size_t count, size_t elem) -> const void* {
-      void* dst = p;
-      p += carve_size(count, elem);
-      if (count) (void)hipMemcpyAsync(dst, dev, count * elem, hipMemcpyDeviceToHost, st);
-      return dst;
-    };
-    h.n_objects = NO; h.n_map = NM; h.n_edits = NR; h.n_values = NV;
-    h.objects = (const am355_ir_object*)pull(c->ir.obj, NO, sizeof(am355_ir_object));
-    h.map = (const am355_ir_map*)pull(c->ir.map, NM, sizeof(am355_ir_map));
-    h.edits = with_edits ? (const am355_ir_edit*)pull(c->ir.edit, (size_t)NR + 1, sizeof(am355_ir_edit)) : nullptr;
+    if (c->ir_copy_enqueued < (with_edits ? 2 : 1)) {
+      int erc = ir_copy_enqueue(c, with_edits);
+      if (erc) return erc;
+    }
+    c->ir_copy_enqueued = 0;
     // (a ~0.1 ms copy: polled, not slept on -- a blocking wait adds an interrupt wake-up of tens of microseconds to a call of 140)
     {
       hipError_t q;

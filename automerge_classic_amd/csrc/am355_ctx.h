@@ -252,6 +252,8 @@ struct am355_ctx {
   std::vector<uint64_t> raw_off;
   uint32_t n_changes = 0;
   bool staged = false, replayed = false, ir_fetched = false;
+  int ir_copy_enqueued = 0;          // the IR tables are on their way to h_ir (1: without the edit table, 2: all three); reset by every replay
+  bool prefetch_ir = false;          // am355_backend_load: the replay enqueues that copy itself
   bool has_unknown_cols = false;     // some change carries columns outside the modelled set (kept by the reference's save)
   bool staging_in_flight = false;    // am355_load_changes returned with its H2D copies still running on `stream`
   bool is_document = false;          // staged input is one saved document (am355_load_document) rather than changes
@@ -287,6 +289,23 @@ struct am355_ctx {
   // schedule
   std::vector<ChangePlan> plans;
   std::vector<uint32_t> applied_change, applied_op_base;  // applied changes in application order (plans get regrouped by decoder class)
+  // Chunk checksum of the staged document (columnar.js:699-705: one SHA-256 over the whole chunk, ~20 ms for 44 MB on a core with SHA
+  // extensions -- a dependent chain, the longest single item of Backend.load): a thread of its own hashes the context's COPY of the
+  // document piece by piece as the copy tasks of the staging job finish them. am355_load_document waits for the verdict before it
+  // returns; am355_backend_load lets the device stages of the load run beside it and asks at the end.
+  struct DocSum {
+    static constexpr size_t PIECE = (size_t)4 << 20;
+    std::thread t;
+    std::unique_ptr<std::atomic<uint8_t>[]> copied;  // per PIECE of doc_bytes: bytes are in place
+    size_t n_pieces = 0;
+    bool pending = false, ok = false;
+    bool wait() {  // the verdict (joins the thread)
+      if (t.joinable()) t.join();
+      pending = false;
+      return ok;
+    }
+    ~DocSum() { if (t.joinable()) t.join(); }
+  } doc_sum;
   std::vector<uint8_t> doc_bytes;                          // the loaded document as given (Backend.save of an unchanged document returns it)
   std::vector<uint8_t> saved;                              // result of am355_save
   HistoryOutput history;                                   // result of am355_doc_changes
@@ -434,7 +453,9 @@ static inline int error_for_flags(am355_ctx* c, uint32_t f, const char* what) {
 // staging (am355_stage.hip)
 bool read_uleb_host(const uint8_t* p, size_t len, size_t& off, uint64_t& out);
 int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n, bool keep_staged = false);
-int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len);
+int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_checksum = false);
+int backend_load_impl(am355_ctx* c, const uint8_t* doc, size_t len);
+int ir_copy_enqueue(am355_ctx* c, bool with_edits);
 // replay: host scheduler / plan, device buffers, orchestration of the device stages (am355_replay.hip)
 int setup_buffers(am355_ctx* c, uint32_t NA);
 int replay_impl(am355_ctx* c);

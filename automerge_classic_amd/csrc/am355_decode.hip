@@ -152,6 +152,14 @@ __device__ const uint32_t SHA_K[64] = {
     0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+// three-input xor: ONE v_bitop3_b32 (truth table 0x96) on gfx950 -- the compiler leaves two v_xor in the Sigma functions otherwise
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
 
 // One 64-byte block. Fully unrolled so that the 16-word message window lives in fixed registers (a rolled loop makes the
 // compiler index the register file dynamically, several times slower) and the a..h rotation is pure renaming.
@@ -621,23 +629,139 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_hash_changes: SHA-256 of every change (one lane per change) + checksum verification. Runs on its own stream:
-// nothing on the decode/merge critical path needs the hashes (they feed dependency resolution and the heads).
+// k_hash_changes: SHA-256 of every change + checksum verification (columnar.js:693-705). Runs on its own stream: nothing on
+// the decode/merge critical path needs the hashes (they feed dependency resolution and the heads).
+//
+// The blocks of one message are a dependent chain, and a lone wavefront issues one instruction every four cycles whatever
+// it is: the time of this kernel is (instructions per block on the chain) x (blocks of the longest change) x 4 cycles. Rounds
+// 1-3 ran everything in the one lane that owns the change: ~2000 instructions per block, 51 blocks, 236 us. But the message
+// SCHEDULE (W[16..63], 13 of the ~30 instructions of a round, plus the loads and byte swaps) does not depend on the chaining
+// value. A workgroup is now TWO wavefronts over the same 64 changes, on two SIMDs of one CU:
+//   producer  lane c loads block k+1 of change c (prefetched one step ahead), pads it if it is one of the last two, expands the
+//             schedule and leaves W[t] + K[t] for the 64 rounds in LDS (one 16-byte store per four rounds, [round/4][lane][4]:
+//             consecutive lanes on consecutive banks);
+//   consumer  lane c runs the 64 rounds of block k from LDS: Sigma1, Ch (one bit-select), Sigma0, Maj (bit-select + xor), adds.
+// One barrier per block; two LDS buffers of 16 KB. The chain per block is the consumer's ~1000 instructions.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_hash_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets, uint32_t n_changes,
-                                                        uint8_t* __restrict__ hashes, uint32_t* __restrict__ min_idx, uint32_t* __restrict__ flags) {
-  uint32_t c = gtid();
-  if (c >= n_changes) return;
-  const uint8_t* p = arena + offsets[c];
-  uint64_t len = offsets[c + 1] - offsets[c];
-  min_idx[c] = c;
-  uint8_t h[32];
-  for (int k = 0; k < 32; k++) h[k] = 0;
-  if (len >= 10 && len < 0xfffffff0ull) {
-    sha256_bytes(p + 8, (uint32_t)len - 8, h);
-    if (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7]) atomicOr(flags, (uint32_t)F_BAD_CHECKSUM);  // columnar.js:702-704
+constexpr int HASH_LANES = 64;  // changes per workgroup
+
+#define AM355_SHA_SCHED(i)                                                                                 \
+  {                                                                                                        \
+    uint32_t w15 = w[((i)-15) & 15], w2 = w[((i)-2) & 15];                                                 \
+    uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);                                          \
+    uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);                                           \
+    w[(i)&15] = w[(i)&15] + s0 + w[((i)-7) & 15] + s1;                                                     \
   }
-  for (int k = 0; k < 32; k++) hashes[32 * (size_t)c + k] = h[k];
+// (Ch = bit-select of f / g by e; Maj = bit-select of c / b by a ^ b: one v_bfi_b32 each)
+#define AM355_SHA_ROUND_WK(a, b, c, d, e, f, g, hh, wk)                                                    \
+  {                                                                                                        \
+    uint32_t t1 = hh + xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)) + (((f ^ g) & e) ^ g) + (wk);      \
+    uint32_t t2 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)) + (((a ^ b) & (c ^ b)) ^ b);          \
+    d += t1;                                                                                               \
+    hh = t1 + t2;                                                                                          \
+  }
+
+__global__ __launch_bounds__(2 * HASH_LANES) void k_hash_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets, uint32_t n_changes,
+                                                                  uint8_t* __restrict__ hashes, uint32_t* __restrict__ min_idx, uint32_t* __restrict__ flags) {
+  __shared__ V4 wk[2][16 * HASH_LANES];
+  __shared__ uint32_t s_steps;
+  const uint32_t lane = threadIdx.x & (HASH_LANES - 1);
+  const bool producer = threadIdx.x >= HASH_LANES;
+  const uint32_t c = blockIdx.x * HASH_LANES + lane;
+  if (threadIdx.x == 0) s_steps = 0;
+  const uint8_t* p = arena;
+  uint32_t mlen = 0, nblk = 0;  // message = the change without its first eight bytes (magic + checksum)
+  bool hashed = false;
+  if (c < n_changes) {
+    const uint64_t o = offsets[c], len = offsets[c + 1] - o;
+    if (len >= 10 && len < 0xfffffff0ull) {
+      hashed = true;
+      p = arena + o + 8;
+      mlen = (uint32_t)len - 8;
+      nblk = (mlen + 9 + 63) / 64;
+    }
+  }
+  __syncthreads();
+  if (nblk) atomicMax(&s_steps, nblk);
+  __syncthreads();
+  const uint32_t steps = s_steps;
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  U4 nxt[4] = {};
+  // (a block's 64 bytes are loaded whole when any of them belongs to the message: up to 63 bytes behind the change, inside the
+  // 64 bytes of slack every arena is allocated with)
+  if (producer && nblk && mlen)
+    for (int q = 0; q < 4; q++) nxt[q] = *(const U4*)(p + 16 * q);
+  for (uint32_t k = 0; k <= steps; k++) {
+    if (producer) {
+      if (k < nblk) {
+        uint32_t w[16];
+        for (int q = 0; q < 4; q++) {
+          w[4 * q] = __builtin_bswap32(nxt[q].x);
+          w[4 * q + 1] = __builtin_bswap32(nxt[q].y);
+          w[4 * q + 2] = __builtin_bswap32(nxt[q].z);
+          w[4 * q + 3] = __builtin_bswap32(nxt[q].w);
+        }
+        const uint32_t o = 64 * k;
+        if (k + 1 < nblk && o + 64 < mlen)  // the next block holds message bytes: requested before this block's schedule
+          for (int q = 0; q < 4; q++) nxt[q] = *(const U4*)(p + o + 64 + 16 * q);
+        if (o + 64 > mlen) {
+          // one of the last two blocks: message bytes, 0x80, zeros, and the bit length in the last eight bytes of the last one
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            const int rem = (int)mlen - (int)(o + 4 * j);  // message bytes from this word on
+            uint32_t v = 0;
+            if (rem >= 4) v = w[j];
+            else if (rem > 0) v = (w[j] & (0xffffffffu << (32 - 8 * rem))) | (0x80u << (24 - 8 * rem));
+            else if (rem == 0) v = 0x80000000u;
+            w[j] = v;
+          }
+          if (k + 1 == nblk) {
+            w[14] = mlen >> 29;
+            w[15] = mlen << 3;
+          }
+        }
+        V4* dst = wk[k & 1] + lane;
+#define AM355_SHA_PUT(r) dst[((r) >> 2) * HASH_LANES] = V4{w[(r)&15] + SHA_K[(r)], w[((r) + 1) & 15] + SHA_K[(r) + 1], w[((r) + 2) & 15] + SHA_K[(r) + 2], w[((r) + 3) & 15] + SHA_K[(r) + 3]};
+        AM355_SHA_PUT(0) AM355_SHA_PUT(4) AM355_SHA_PUT(8) AM355_SHA_PUT(12)
+#pragma unroll
+        for (int r = 16; r < 64; r += 4) {
+          AM355_SHA_SCHED(r) AM355_SHA_SCHED(r + 1) AM355_SHA_SCHED(r + 2) AM355_SHA_SCHED(r + 3)
+          AM355_SHA_PUT(r)
+        }
+#undef AM355_SHA_PUT
+      }
+    } else if (k >= 1 && k - 1 < nblk) {
+      const V4* src = wk[(k - 1) & 1] + lane;
+      uint32_t a = h[0], b = h[1], cc = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+      for (int r = 0; r < 64; r += 8) {
+        const V4 x = src[(r >> 2) * HASH_LANES], y = src[((r >> 2) + 1) * HASH_LANES];
+        AM355_SHA_ROUND_WK(a, b, cc, d, e, f, g, hh, x.x)
+        AM355_SHA_ROUND_WK(hh, a, b, cc, d, e, f, g, x.y)
+        AM355_SHA_ROUND_WK(g, hh, a, b, cc, d, e, f, x.z)
+        AM355_SHA_ROUND_WK(f, g, hh, a, b, cc, d, e, x.w)
+        AM355_SHA_ROUND_WK(e, f, g, hh, a, b, cc, d, y.x)
+        AM355_SHA_ROUND_WK(d, e, f, g, hh, a, b, cc, y.y)
+        AM355_SHA_ROUND_WK(cc, d, e, f, g, hh, a, b, y.z)
+        AM355_SHA_ROUND_WK(b, cc, d, e, f, g, hh, a, y.w)
+      }
+      h[0] += a; h[1] += b; h[2] += cc; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    __syncthreads();
+  }
+  if (producer || c >= n_changes) return;
+  min_idx[c] = c;
+  V4 lo = V4{0, 0, 0, 0}, hi = V4{0, 0, 0, 0};
+  if (hashed) {
+    lo = V4{__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3])};
+    hi = V4{__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7])};
+    const uint8_t* q = p - 4;  // the container's checksum field: the first four bytes of the hash (columnar.js:702-704)
+    const uint32_t sum = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
+    if (sum != lo.x) atomicOr(flags, (uint32_t)F_BAD_CHECKSUM);
+  }
+  V4* out = (V4*)(hashes + 32 * (size_t)c);
+  out[0] = lo;
+  out[1] = hi;
 }
 
 __device__ __forceinline__ bool equal32(const uint8_t* a, const uint8_t* b) {
@@ -1971,7 +2095,7 @@ void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
                          uint32_t tab_mask, uint32_t* flags, hipStream_t st) {
   if (!n) return;
-  AM355_LAUNCH_INDEPENDENT(k_hash_changes, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), st, arena, offsets, n, hashes, min_idx, flags);
+  hipLaunchKernelGGL(k_hash_changes, dim3((n + HASH_LANES - 1) / HASH_LANES), dim3(2 * HASH_LANES), 0, st, arena, offsets, n, hashes, min_idx, flags);
   AM355_LAUNCH_INDEPENDENT(k_hash_insert, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), st, (const uint8_t*)hashes, n, hash_tab, tab_mask, min_idx);
 }
 

@@ -100,18 +100,27 @@ void blocks(uint32_t h[8], const uint8_t* p, size_t nblocks) {
 
 }  // namespace
 
-void sha256_digest(const uint8_t* p, size_t len, uint8_t out[32]) {
-  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-  size_t full = len / 64;
-  blocks(h, p, full);
+void sha256_initial(uint32_t h[8]) {
+  static const uint32_t init[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  memcpy(h, init, sizeof init);
+}
+void sha256_blocks(uint32_t h[8], const uint8_t* p, size_t nblocks) { blocks(h, p, nblocks); }
+void sha256_finish(uint32_t h[8], const uint8_t* tail_bytes, size_t rem, uint64_t total_len, uint8_t out[32]) {
   uint8_t tail[128] = {0};
-  size_t rem = len - 64 * full, tl = rem < 56 ? 64 : 128;
-  if (rem) memcpy(tail, p + 64 * full, rem);
+  size_t tl = rem < 56 ? 64 : 128;
+  if (rem) memcpy(tail, tail_bytes, rem);
   tail[rem] = 0x80;
-  uint64_t bits = (uint64_t)len * 8;
+  uint64_t bits = total_len * 8;
   for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
   blocks(h, tail, tl / 64);
   for (int k = 0; k < 8; k++) { out[4 * k] = h[k] >> 24; out[4 * k + 1] = h[k] >> 16; out[4 * k + 2] = h[k] >> 8; out[4 * k + 3] = h[k]; }
+}
+void sha256_digest(const uint8_t* p, size_t len, uint8_t out[32]) {
+  uint32_t h[8];
+  sha256_initial(h);
+  size_t full = len / 64;
+  blocks(h, p, full);
+  sha256_finish(h, p + 64 * full, len - 64 * full, len, out);
 }
 
 // (one z_stream per host thread, re-armed with inflateReset: inflateInit2 allocates and clears ~40 KB of state, which for a batch of

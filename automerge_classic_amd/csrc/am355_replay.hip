@@ -749,7 +749,7 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
 
 // Backend.load(bytes) + getPatch: device decode of the document's op columns, then the whole-document patch of the
 // (already canonical) rows. new.js:1695-1750, 1604-1635.
-static int replay_document(am355_ctx* c) {
+static int replay_document_stages(am355_ctx* c) {
   auto t_begin = std::chrono::steady_clock::now();
   const bool trace = getenv("AM355_TRACE") != nullptr;
   auto lap = [&](const char* what) {
@@ -870,7 +870,7 @@ static int replay_document(am355_ctx* c) {
     // the true parse of the key column reached a literal longer than the continuation walker follows (64 windows: tens of thousands of
     // strings): once more, without the bound (the walker then also follows every garbage "literal" to the end of the column)
     c->key_unbounded = true;
-    int rc2 = replay_document(c);
+    int rc2 = replay_document_stages(c);
     c->key_unbounded = false;
     return rc2;
   }
@@ -895,11 +895,36 @@ static int replay_document(am355_ctx* c) {
   return AM355_OK;
 }
 
+// The device stages of a document, then the verdict of the checksum thread when am355_backend_load left it running beside them: the
+// reference verifies the checksum before anything else (columnar.js:699-705), so a mismatch outranks whatever the stages found.
+static int replay_document(am355_ctx* c) {
+  int rc = replay_document_stages(c);
+  if (rc == AM355_OK && c->prefetch_ir) (void)ir_copy_enqueue(c, true);  // (255 MB for the config-5 document: on its way while the checksum finishes)
+  if (c->doc_sum.pending && !c->doc_sum.wait()) {
+    c->replayed = false;
+    c->staged = false;
+    c->flags = AM355_F_BAD_CHECKSUM;
+    return fail(c, AM355_E_INVALID, "checksum does not match data");
+  }
+  return rc;
+}
+
+// Backend.load(bytes) in one call (backend.js:104-107): staging with the checksum verdict deferred, the device stages, the IR copy.
+int backend_load_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
+  int rc = load_document_impl(c, doc, len, true);
+  if (rc) return rc;
+  c->prefetch_ir = true;
+  rc = replay_impl(c);
+  c->prefetch_ir = false;
+  return rc;
+}
+
 int replay_impl(am355_ctx* c) {
   if (!c) return AM355_E_ARG;
   if (!c->staged) return fail(c, AM355_E_STATE, "am355_load_changes must be called first");
   (void)hipSetDevice(c->device);
   c->replayed = c->ir_fetched = false;
+  c->ir_copy_enqueued = 0;
   c->dep_graph_ready = false;
   c->flags = 0;
   if (c->is_document) return replay_document(c);

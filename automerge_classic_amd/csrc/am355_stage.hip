@@ -25,6 +25,7 @@ constexpr size_t INFLATE_CAP = 0xfff00000ull;  // one staged batch / document is
 int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n, bool keep_staged) {
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
+  (void)c->doc_sum.wait();
   const uint32_t k0 = keep_staged ? c->n_changes : 0;  // changes and bytes kept in front of the batch
   const size_t b0 = keep_staged ? c->raw.size() : 0;
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
@@ -291,9 +292,10 @@ struct HostRle {
 };
 }  // namespace
 
-int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
+int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_checksum) {
   if (!c || !doc) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
+  (void)c->doc_sum.wait();  // (the checksum thread of an earlier document reads doc_bytes)
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }
   c->doc_graph_known = false;
   c->staged = c->replayed = c->ir_fetched = false;
@@ -311,22 +313,64 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   uint64_t clen;
   if (!read_uleb_host(doc, len, off, clen) || clen != len - off) return bad0(AM355_F_BAD_CHUNK, "Encoded document has trailing data or is truncated");
   if (doc[8] != 0) return bad0(AM355_F_BAD_CHUNK, "Unexpected chunk type");
-  // The chunk checksum (one SHA-256 over the whole chunk: sequential by construction) runs on a pool thread beside the column
-  // inflates below. The reference verifies it before it reads the header (columnar.js:699-705), so a malformed header is only
-  // reported once the checksum is known to match.
-  bool sum_done = false, sum_ok = false;
-  auto check_sum = [&]() {
-    uint8_t digest[32];
-    sha256_digest(doc + 8, len - 8, digest);
-    sum_ok = memcmp(digest, doc + 4, 4) == 0;
-    sum_done = true;
+  // The chunk checksum (one SHA-256 over the whole chunk: a dependent chain, ~20 ms for 44 MB with the SHA extensions) runs on a
+  // thread of its own from the first moment on, over the context's copy of the document (Backend.save of an unchanged document
+  // returns these bytes, new.js:2034) as the copy tasks of the staging job below complete its pieces. The reference verifies it before
+  // it reads the header (columnar.js:699-705), so whatever this function finds wrong is only reported once the checksum is known to
+  // match; with `defer_checksum` a well-formed document is staged and returned without the verdict, which am355_replay then asks for.
+  c->doc_bytes.resize(len);
+  {
+    am355_ctx::DocSum& ds = c->doc_sum;
+    ds.n_pieces = (len + am355_ctx::DocSum::PIECE - 1) / am355_ctx::DocSum::PIECE;
+    ds.copied.reset(new std::atomic<uint8_t>[ds.n_pieces]);
+    for (size_t k = 0; k < ds.n_pieces; k++) ds.copied[k].store(0, std::memory_order_relaxed);
+    ds.ok = false;
+    ds.pending = true;
+    const uint8_t* bytes = c->doc_bytes.data();
+    const uint8_t want[4] = {doc[4], doc[5], doc[6], doc[7]};
+    ds.t = std::thread([&ds, bytes, len, want0 = want[0], want1 = want[1], want2 = want[2], want3 = want[3]]() {
+      uint32_t hs[8];
+      sha256_initial(hs);
+      size_t pos = 8;
+      for (size_t k = 0; k < ds.n_pieces; k++) {
+        while (!ds.copied[k].load(std::memory_order_acquire)) std::this_thread::yield();
+        const size_t end = std::min(len, (k + 1) * am355_ctx::DocSum::PIECE);
+        const size_t nb = end > pos ? (end - pos) / 64 : 0;
+        sha256_blocks(hs, bytes + pos, nb);
+        pos += nb * 64;
+      }
+      uint8_t digest[32];
+      sha256_finish(hs, bytes + pos, len - pos, len - 8, digest);
+      ds.ok = digest[0] == want0 && digest[1] == want1 && digest[2] == want2 && digest[3] == want3;
+    });
+  }
+  // (an early exit copies what the staging job has not: the thread waits for every piece)
+  auto copy_piece = [&](size_t k) {
+    const size_t b = k * am355_ctx::DocSum::PIECE, e = std::min(len, b + am355_ctx::DocSum::PIECE);
+    memcpy(c->doc_bytes.data() + b, doc + b, e - b);
+    c->doc_sum.copied[k].store(1, std::memory_order_release);
+  };
+  bool copy_done = false;
+  auto sum_verdict = [&]() {
+    if (!copy_done) {
+      for (size_t k = 0; k < c->doc_sum.n_pieces; k++)
+        if (!c->doc_sum.copied[k].load(std::memory_order_acquire)) copy_piece(k);
+      copy_done = true;
+    }
+    return c->doc_sum.wait();
   };
   auto bad = [&](uint32_t flag, const char* msg) {
-    if (!sum_done) check_sum();
-    if (!sum_ok) { flag = AM355_F_BAD_CHECKSUM; msg = "checksum does not match data"; }
+    if (!sum_verdict()) { flag = AM355_F_BAD_CHECKSUM; msg = "checksum does not match data"; }
     c->flags |= flag;
     return fail(c, AM355_E_INVALID, "%s", msg);
   };
+  // (failures that are not the document's fault -- memory, device -- still have to leave no thread behind)
+  struct SumGuard {
+    std::function<bool()>& verdict; bool armed = true;
+    ~SumGuard() { if (armed) (void)verdict(); }
+  };
+  std::function<bool()> sum_verdict_fn = sum_verdict;
+  SumGuard sum_guard{sum_verdict_fn};
   const uint8_t* h = doc + off;
   size_t hl = (size_t)clen, ho = 0;
   uint64_t na, nh;
@@ -394,8 +438,9 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     if (pchunk_env && atol(pchunk_env) > 0) chunk_bytes = (size_t)atol(pchunk_env);
     while (c->pinflate_jobs.size() < par.size()) c->pinflate_jobs.emplace_back(new PInflateJob);
     std::vector<std::atomic<unsigned>> chunks_left(par.size());
-    struct Task { int kind; unsigned a, b; };  // 0 search (stream a, chunk b) | 1 checksum | 2 copy | 3 decode (a, b) | 4 whole stream (deflated[a])
+    struct Task { int kind; unsigned a, b; };  // 0 search (stream a, chunk b) | 2 copy of piece a of the document | 3 decode (a, b) | 4 whole stream (deflated[a])
     std::vector<Task> tasks;
+    for (size_t k = 0; k < c->doc_sum.n_pieces; k++) tasks.push_back(Task{2, (unsigned)k, 0});  // (first: the checksum thread is waiting for them)
     for (size_t s = 0; s < par.size(); s++) {
       PInflateJob* job = c->pinflate_jobs[s].get();
       job->prepare(par[s]->p, (size_t)par[s]->len, INFLATE_CAP, chunk_bytes);
@@ -405,8 +450,6 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
     }
     // (every search task in front of every decode task: a decode task spins for the searches of the chunks behind its own, and
     // the pool hands tasks out in index order -- all of them have been taken by a thread when a decode task starts)
-    tasks.push_back(Task{1, 0, 0});
-    tasks.push_back(Task{2, 0, 0});
     for (size_t s = 0; s < par.size(); s++)
       for (unsigned k = 0; k < c->pinflate_jobs[s]->n_chunks; k++) tasks.push_back(Task{3, (unsigned)s, k});
     for (size_t k = 0; k < deflated.size(); k++)
@@ -415,8 +458,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
       const Task& tk = tasks[t];
       switch (tk.kind) {
         case 0: c->pinflate_jobs[tk.a]->search(tk.b); break;
-        case 1: check_sum(); break;
-        case 2: c->doc_bytes.assign(doc, doc + len); break;
+        case 2: copy_piece(tk.a); break;
         case 3: {
           PInflateJob* job = c->pinflate_jobs[tk.a].get();
           job->decode(tk.b);
@@ -426,7 +468,8 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
         default: irc[tk.a] = inflate_raw(deflated[tk.a]->p, (size_t)deflated[tk.a]->len, *deflated[tk.a]->data, INFLATE_CAP);
       }
     });
-    lap("inflate | checksum | copy");
+    copy_done = true;
+    lap("inflate | copy");
     // streams the chunked decode gave up on (no chain of block starts, output beyond the cap, damaged data): the ordinary
     // single-stream inflate decides what they are
     {
@@ -436,7 +479,6 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
       if (!again.empty())
         c->pool->run((unsigned)again.size(), [&](unsigned t) { size_t k = again[t]; irc[k] = inflate_raw(deflated[k]->p, (size_t)deflated[k]->len, *deflated[k]->data, INFLATE_CAP); });
     }
-    if (!sum_ok) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
     int rd = 0;
     for (Col* col : all_cols) {  // (errors in column order, as a sequential reader would meet them)
       if (!(col->id & 8)) continue;
@@ -504,6 +546,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
       if (an || a < 0 || (uint64_t)a >= na) return bad(AM355_F_BAD_ROW, "bad actor index in change metadata");
       if (!sn) seq_abs += dv;
       uint64_t seq = sn ? 0 : (uint64_t)seq_abs;
+      if (seq != 1 && seq != clock[a] + 1 && !sum_verdict()) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
       if (seq != 1 && seq != clock[a] + 1) { c->flags |= AM355_F_BAD_SEQ; return fail(c, AM355_E_INVALID, "Expected seq %llu, got %llu", (unsigned long long)clock[a] + 1, (unsigned long long)seq); }
       if (!seen[a]) { seen[a] = 1; c->clock_actor.push_back((uint32_t)a); }  // document actor index for now, ranks below
       clock[a] = seq;
@@ -611,6 +654,12 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   lap("gathered, H2D enqueued");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   lap("H2D done");
+  if (defer_checksum) sum_guard.armed = false;  // (am355_replay asks for the verdict: doc_sum.pending)
+  else {
+    sum_guard.armed = false;
+    if (!sum_verdict()) return bad(AM355_F_BAD_CHECKSUM, "checksum does not match data");
+    lap("checksum joined");
+  }
   c->staged = true;
   c->stats = am355_stats{};
   c->stats.n_changes = c->n_changes;

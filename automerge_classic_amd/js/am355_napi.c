@@ -10,6 +10,7 @@
  *   const ctx = am.create(0)                       // throws if no MI355X is usable (no CPU fallback)
  *   am.loadChanges(ctx, [Uint8Array, ...])         // stage + inflate + copy to HBM
  *   am.loadDocument(ctx, Uint8Array)               // stage one saved document (Backend.save bytes)
+ *   am.backendLoad(ctx, Uint8Array)                // Backend.load in one call: loadDocument + replay, checksum beside the device stages
  *   am.replay(ctx)                                 // the hot path (blocking, like every Backend call)
  *   am.patchJSON(ctx) -> string                    // JSON.stringify(getPatch) text, built from the device IR
  *   am.fetchIR(ctx) -> {objects, map, edits, values, arena, ...}   // the record tables; materialize.js builds the patch object
@@ -157,6 +158,25 @@ static napi_value js_load_document(napi_env env, napi_callback_info info) {
   napi_get_typedarray_info(env, argv[1], &t, &len, &data, &ab, &off);
   if (t != napi_uint8_array) { napi_throw_type_error(env, NULL, "document is not a Uint8Array"); return NULL; }
   int rc = am355_load_document(ctx, (const uint8_t *)data, len);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+static napi_value js_backend_load(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  bool is_ta = false;
+  napi_is_typedarray(env, argv[1], &is_ta);
+  if (!is_ta) { napi_throw_type_error(env, NULL, "document is not a Uint8Array"); return NULL; }
+  napi_typedarray_type t; size_t len; void *data; napi_value ab; size_t off;
+  napi_get_typedarray_info(env, argv[1], &t, &len, &data, &ab, &off);
+  if (t != napi_uint8_array) { napi_throw_type_error(env, NULL, "document is not a Uint8Array"); return NULL; }
+  int rc = am355_backend_load(ctx, (const uint8_t *)data, len);
   if (rc) return throw_engine(env, ctx, rc);
   napi_value u;
   napi_get_undefined(env, &u);
@@ -516,6 +536,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"destroy", NULL, js_destroy, NULL, NULL, NULL, napi_enumerable, NULL},
       {"loadChanges", NULL, js_load_changes, NULL, NULL, NULL, napi_enumerable, NULL},
       {"loadDocument", NULL, js_load_document, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"backendLoad", NULL, js_backend_load, NULL, NULL, NULL, napi_enumerable, NULL},
       {"replay", NULL, js_replay, NULL, NULL, NULL, napi_enumerable, NULL},
       {"patchJSON", NULL, js_patch_json, NULL, NULL, NULL, napi_enumerable, NULL},
       {"save", NULL, js_save, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -248,8 +248,7 @@ function load(data) {
   if (!JS_ONLY && data instanceof Uint8Array) {
     try {
       acquireContext()
-      addon.loadDocument(ctx, data)
-      addon.replay(ctx)
+      addon.backendLoad(ctx, data)
       const patch = gpuPatch()
       counters.gpuLoad++
       const state = new GpuState(null, patch, patch.deps, data)

@@ -73,6 +73,16 @@ int am355_load_changes(am355_ctx *ctx, const uint8_t *arena, const uint64_t *off
 int am355_load_document(am355_ctx *ctx, const uint8_t *doc, size_t len);
 
 /*
+ * Backend.load(bytes) in ONE call (backend/backend.js:104-107 -> new BackendDoc(buffer), new.js:1695-1750) = am355_load_document +
+ * am355_replay, with two things the two-call form cannot do: the chunk checksum (columnar.js:699-705, one SHA-256 over the whole
+ * document: a dependent chain of ~20 ms for a 44 MB document, longer than everything else of the load) runs on a thread of its own
+ * beside the inflate, the copies to HBM AND the device stages, and its verdict is asked for at the end (a mismatch outranks any other
+ * finding, as in the reference, which verifies it first); and the copy of the patch IR to host memory is enqueued behind the device
+ * stages right away, so that am355_fetch_ir / am355_patch_json find it under way. Same results, errors and flags as the two calls.
+ */
+int am355_backend_load(am355_ctx *ctx, const uint8_t *doc, size_t len);
+
+/*
  * The hot path, device-resident in and out: container parse + SHA-256 + column decode, causal scheduling
  * (host, between two device phases), op-set merge, RGA ordering, whole-document patch IR.  Equivalent to
  * Backend.loadChanges(Backend.init(), changes) + the work of Backend.getPatch().  Blocking.

@@ -71,3 +71,48 @@ def header_mutations(patch_fn, rounds=60):
             else:
                 refused += 1
     return equal, refused
+
+
+def _uleb(b, o):
+    v = s = 0
+    while True:
+        x = b[o]
+        o += 1
+        v |= (x & 0x7f) << s
+        s += 7
+        if not x & 0x80:
+            return v, o
+
+
+def _enc_uleb(v):
+    out = bytearray()
+    while True:
+        x = v & 0x7f
+        v >>= 7
+        out.append(x | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def with_message_and_actor(change, message, actor=None):
+    """The same (uncompressed) change with another commit message and, optionally, another author: chunk length and checksum
+    rewritten (columnar.js:635-652 header layout: deps, actor, seq, startOp, time, message, ...). Used to give changes every
+    length modulo the SHA-256 block size."""
+    import hashlib
+    assert change[8] == 1
+    _, body0 = _uleb(change, 9)
+    body = bytearray(change[body0:])
+    o = 0
+    ndeps, o = _uleb(body, o)
+    o += 32 * ndeps
+    alen, o = _uleb(body, o)
+    if actor is not None:
+        assert len(actor) == alen
+        body[o:o + alen] = actor
+    o += alen
+    for _ in range(3):  # seq, startOp, time (signed, but one LEB128 number either way)
+        _, o = _uleb(body, o)
+    mlen, o2 = _uleb(body, o)
+    body[o:o2 + mlen] = _enc_uleb(len(message)) + message
+    chunk = bytes([1]) + _enc_uleb(len(body)) + bytes(body)
+    return change[:4] + hashlib.sha256(chunk).digest()[:4] + chunk

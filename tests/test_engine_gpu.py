@@ -42,6 +42,8 @@ def test_document_load_matches_reference(eng, name):
     eng.load_document(fx["doc_bytes"])
     eng.replay()
     assert eng.patch_json() == fx["expected_load"]
+    eng.backend_load(fx["doc_bytes"])   # (Backend.load in one call: am355_backend_load)
+    assert eng.patch_json() == fx["expected_load"]
     assert oracle_lib.OracleDoc.load_document(fx["doc_bytes"]).patch_json() == fx["expected_load"]
 
 
@@ -517,3 +519,25 @@ def test_more_list_objects_than_the_fused_list_order_holds(eng):
     log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=4, ins_per_change=12, del_per_change=3, n_objects=1100, seed=77)
     assert gpu_patch(eng, log) == oracle_lib.OracleDoc(log).patch_json()
 
+
+def test_change_hashes_at_every_length_modulo_the_sha256_block(eng):
+    """columnar.js:693-705: hash = SHA-256 of the chunk, checksum = its first four bytes. The padding of the last one or two blocks
+    depends on the length modulo 64 (0x80 in the last data word, in a word of its own, in a block of its own; the bit length in the
+    same block or the next): 140 first changes of 140 actors whose commit messages differ in length by one byte each."""
+    import hashlib
+    base = loggen.generate(loggen.KIND_MAP_LWW, n_actors=1, n_rounds=1, n_keys=3, seed=9).change(0)
+    changes = [mutation_util.with_message_and_actor(base, bytes(97 + (i + j) % 26 for j in range(i)), hashlib.md5(b"actor%d" % i).digest()) for i in range(140)]
+    assert len({len(c) % 64 for c in changes}) == 64
+    log = loggen.ChangeLog.from_changes(changes, name="hash lengths")
+    eng.load_changes(log)
+    eng.replay()
+    assert eng.patch_json() == oracle_lib.OracleDoc(log).patch_json()
+    h = eng.hashes()
+    for i, c in enumerate(changes):
+        assert bytes(h[i]) == hashlib.sha256(c[8:]).digest(), i
+    # one flipped message byte in one change: the checksum no longer matches
+    bad = bytearray(changes[77])
+    bad[-20] ^= 1
+    with pytest.raises(engine.InvalidChanges):
+        eng.load_changes(loggen.ChangeLog.from_changes(changes[:77] + [bytes(bad)] + changes[78:], name="bad checksum"))
+        eng.replay()

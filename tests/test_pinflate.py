@@ -140,3 +140,46 @@ def test_document_columns_through_the_chunked_decode(chunk, monkeypatch):
         verdicts[g is not None] += 1
     assert verdicts[0] > 5
     eng.close()
+
+
+def test_backend_load_in_one_call_equals_the_two_calls(monkeypatch):
+    """am355_backend_load (checksum thread beside the device stages, verdict at the end) against am355_load_document + am355_replay:
+    same patch, same save bytes; a wrong checksum is reported by either form, and outranks damaged columns."""
+    import hashlib
+    monkeypatch.setenv("AM355_PINFLATE_MIN", "4096")
+    eng = engine.Engine(0, EMU_LIB)
+    doc, rows = loggen.generate_document(n_actors=5, n_texts=3, text_len=700, n_maps=2, keys_per_map=200, n_submaps=2, n_lists=2, list_len=250, deflate=True, seed=0xD0C8)
+    eng.load_document(doc)
+    eng.replay()
+    two = (eng.patch_json(), eng.save())
+    eng.backend_load(doc)
+    assert eng.stats().n_ops == rows
+    assert (eng.patch_json(), eng.save()) == two
+    assert two[0] == oracle_lib.OracleDoc.load_document(doc).patch_json()
+    bad = bytearray(doc)
+    bad[len(bad) - 100] ^= 4           # inside the last compressed column, checksum NOT repaired
+    for call in (eng.load_document, eng.backend_load):
+        with pytest.raises(engine.InvalidChanges) as e:
+            call(bytes(bad))
+        assert e.value.flags == (1 << 1)
+        with pytest.raises(engine.EngineError):
+            eng.patch_json()            # nothing is left to read after the failed load
+    bad[4:8] = hashlib.sha256(bytes(bad[8:])).digest()[:4]
+    for call in (eng.load_document, eng.backend_load):
+        try:
+            call(bytes(bad))
+            if call == eng.load_document:
+                eng.replay()
+            got = eng.patch_json()
+        except engine.InvalidChanges as e:
+            assert e.flags != (1 << 1)
+            got = None
+        try:
+            want = oracle_lib.OracleDoc.load_document(bytes(bad)).patch_json()
+        except oracle_lib.OracleError:
+            want = None
+        assert got == want or got is None
+    # the context is usable afterwards
+    eng.backend_load(doc)
+    assert eng.patch_json() == two[0]
+    eng.close()
