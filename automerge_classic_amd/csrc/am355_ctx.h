@@ -251,6 +251,11 @@ struct am355_ctx {
   std::unique_ptr<HostPool> pool;  // host worker threads (staging, inflate, checksum)
   std::vector<uint64_t> raw_off;
   uint32_t n_changes = 0;
+  // speculative decode launch (am355_internal.h decode_gate_open): op rows carved for a capacity before the totals are known
+  DevBuf d_plan_totals;              // PlanTotals, device copy (k_plan_apply)
+  bool spec_launched = false;        // this replay's decode kernels of the wave classes are enqueued behind the plan kernel
+  uint32_t spec_cap_ops = 0, spec_cap_preds = 0;   // what c->cols is carved for while spec_launched
+  uint32_t hint_ops = 0, hint_preds = 0;           // totals of the context's previous in-order replay
   bool staged = false, replayed = false, ir_fetched = false;
   int ir_copy_enqueued = 0;          // the IR tables are on their way to h_ir (1: without the edit table, 2: all three); reset by every replay
   bool prefetch_ir = false;          // am355_backend_load: the replay enqueues that copy itself

@@ -34,7 +34,11 @@ uint32_t distinct_capacity();
 // decode kernels need, so that they can start while the host is still validating sequence numbers and building the per-actor span
 // tables. The totals go to the host through `sig` (HostSignals.plan).
 void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, const uint32_t* slot_rank, uint32_t slot_mask, const unsigned long long* block_sums,
-                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st);
+                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st,
+                 PlanTotals* dev_totals = nullptr);
+void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_changes, const PlanTotals* totals, uint32_t cap_ops,
+                               uint32_t cap_preds, uint32_t cap_distinct, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st,
+                               hipStream_t aux, uint32_t shard_rank = 0, uint32_t shard_world = 1);
 void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, const ChangePlan* plans_serial, uint32_t n_changes,
                            uint32_t n_small, uint32_t n_large, uint32_t n_serial, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags,
                            hipStream_t st, hipStream_t aux, uint32_t shard_rank = 0, uint32_t shard_world = 1);

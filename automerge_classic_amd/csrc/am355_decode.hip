@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
 __global__ __launch_bounds__(BLOCK) void k_plan_apply(const ChangeBrief* __restrict__ briefs, uint32_t n, const uint32_t* __restrict__ slot_rank, uint32_t slot_mask,
                                                       const unsigned long long* __restrict__ block_sums, ChangePlan* __restrict__ plans,
                                                       ChangePlan* __restrict__ plans_serial, const uint32_t* __restrict__ words, const uint32_t* __restrict__ plan_words,
-                                                      const uint32_t* __restrict__ distinct, HostSignals* sig, uint32_t seq) {
+                                                      const uint32_t* __restrict__ distinct, HostSignals* sig, uint32_t seq, PlanTotals* __restrict__ dev_totals) {
   wave_priority_high();
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
   __shared__ unsigned long long s_base[6];
@@ -1194,6 +1194,7 @@ __global__ __launch_bounds__(BLOCK) void k_plan_apply(const ChangeBrief* __restr
     z.fallback = (plan_words[0] || ops >= 0x7ffffff0ull || preds >= 0xfffffff0ull || ent >= 0xfffffff0ull) ? 1u : 0u;
     z.flags_a = words[0] | plan_words[2]; z.fast_a = words[1]; z.total_entries = words[2]; z.n_distinct = distinct[0];
     z.reserved[0] = plan_words[3];  // some change carries columns this engine does not model (the reference's save keeps them)
+    if (dev_totals) *dev_totals = z;  // (for the decode kernels enqueued right behind this one: they start without the host in between)
     signal_host((uint32_t*)&sig->plan, (const uint32_t*)&z, sizeof(PlanTotals) / 4, &sig->plan_seq, seq);
   }
 }
@@ -1824,10 +1825,18 @@ uint32_t err = 0;
 template <class WL>
 __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                        const ChangePlan* __restrict__ plans, uint32_t n_plans, ActorXlate x, OpCols o,
-                                                       uint32_t* __restrict__ flags) {
+                                                       uint32_t* __restrict__ flags, DecodeGate gate) {
   __shared__ WL L;
   wave_priority_high();
   uint32_t pi = blockIdx.x, lane = threadIdx.x;
+  if (gate.totals) {
+    // launched behind k_plan_apply with one wavefront per CHANGE, before the host has seen the totals: the class size comes from
+    // the device copy, and the launch does nothing at all when the host is going to decide otherwise (same test as decode_gate_open)
+    const PlanTotals t = *gate.totals;
+    if (!decode_gate_open(t, gate.cap_ops, gate.cap_preds, gate.cap_distinct)) return;
+    n_plans = gate.large ? t.n_large : t.n_small;
+    if (gate.large) plans += gate.n_changes - t.n_large;
+  }
   if (pi >= n_plans) return;
   const ChangePlan pl = plans[pi];
   const ChangeMeta* m = &metas[pl.change];
@@ -2122,10 +2131,11 @@ size_t rank_ids_bytes() { return sizeof(RankId) * PLAN_RANK_MAX; }
 size_t plan_block_sums_bytes(uint32_t n) { return sizeof(unsigned long long) * PLAN_SUMS * ((size_t)(n + BLOCK - 1) / BLOCK + 1); }
 
 void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, const uint32_t* slot_rank, uint32_t slot_mask, const unsigned long long* block_sums,
-                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st) {
+                 ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st,
+                 PlanTotals* dev_totals) {
   uint32_t nb = (n + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(k_plan_apply, dim3(nb ? nb : 1), dim3(BLOCK), 0, st, briefs, n, slot_rank, slot_mask, block_sums, plans, plans_serial, words, plan_words,
-                     distinct, sig, seq);
+                     distinct, sig, seq, dev_totals);
 }
 
 uint32_t distinct_capacity() { return DISTINCT_CAP; }
@@ -2191,8 +2201,8 @@ void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const 
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   if (n_large && n_small + n_large <= 1024) { n_large += n_small; n_small = 0; }
   hipStream_t s2 = (n_small && aux) ? aux : st;
-  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags);
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags);
+  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans + n_small + n_large, n_serial,
                              x, cols, flags, 0);
@@ -2204,10 +2214,24 @@ void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const 
                            hipStream_t st, hipStream_t aux, uint32_t shard_rank, uint32_t shard_world) {
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   hipStream_t s2 = (n_small && aux) ? aux : st;
-  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags);
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags);
+  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans_serial, n_serial, x, cols, flags, 0);
+}
+
+// The two wavefront-per-change decoder classes enqueued BEFORE the totals are known (behind k_plan_apply, which leaves them in
+// `totals`): one wavefront per change each, the small class on `st`, the large class on `aux`; rows go to `cols`, carved for
+// cap_ops / cap_preds. Both launches do nothing unless decode_gate_open() holds, which the host evaluates on the same totals.
+void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_changes, const PlanTotals* totals, uint32_t cap_ops,
+                               uint32_t cap_preds, uint32_t cap_distinct, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st,
+                               hipStream_t aux, uint32_t shard_rank, uint32_t shard_world) {
+  if (!n_changes) return;
+  ActorXlate x{amap, slot_rank, shard_rank, shard_world};
+  hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_changes), dim3(WAVE), 0, st, arena, metas, plans, 0u, x, cols, flags,
+                     DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 0u});
+  hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
+                     DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 1u});
 }
 
 }  // namespace am355

@@ -65,6 +65,19 @@ struct PlanTotals {
   uint32_t reserved[4];
 };
 
+// The decode kernels of the in-order path are enqueued behind k_plan_apply BEFORE the host has read these totals (the host used to
+// sit between the two with a signal, its buffer carving and a launch: 50 us of idle device in a 400 us replay). They run over rows
+// carved for a CAPACITY (the previous replay's size or an estimate from the encoded bytes) and do nothing unless this test holds --
+// evaluated by every wavefront on the device copy of the totals and by the host on its own copy: in order, well-formed, planned on the
+// device, and inside the capacity. Otherwise the host carves for the real totals and launches as before.
+__host__ __device__ inline bool decode_gate_open(const PlanTotals& t, uint32_t cap_ops, uint32_t cap_preds, uint32_t cap_distinct) {
+  return !t.fallback && !t.flags_a && !t.fast_a && t.n_ops <= cap_ops && t.n_preds <= cap_preds && t.n_distinct <= cap_distinct;
+}
+struct DecodeGate {
+  const PlanTotals* totals = nullptr;   // null: an ordinary launch (grid = plans of the class)
+  uint32_t cap_ops = 0, cap_preds = 0, cap_distinct = 0, n_changes = 0, large = 0;
+};
+
 // Device -> host signalling without a copy and without a blocking wait: the LAST kernel of a phase writes its few result words
 // straight into pinned host memory (fine-grained, device-visible), fences at system scope and then publishes the sequence number
 // of the replay; the host spins on that word. A D2H copy + hipStreamSynchronize costs a copy dispatch (~15 us until it runs, ~5 us

@@ -340,24 +340,6 @@ int decode_body(BitIn& b, const Tables& T, SymOut* o, size_t max_syms) {
   }
 }
 
-// what follows a block must read as a block header again (search only): type 3 never, stored with matching length words,
-// dynamic with a valid header
-bool plausible_next_header(BitIn b /* copy */, size_t total_bits, Tables& scratch) {
-  if (b.bitpos() + 3 > total_bits) return false;
-  b.refill();
-  b.take(1);
-  uint32_t type = b.take(2);
-  if (type == 3) return false;
-  if (type == 1) return true;
-  if (type == 0) {
-    size_t byte = (b.bitpos() + 7) >> 3;
-    if (byte + 4 > b.len) return false;
-    uint32_t len = b.in[byte] | (b.in[byte + 1] << 8), nlen = b.in[byte + 2] | (b.in[byte + 3] << 8);
-    return len == (~nlen & 0xffffu) && byte + 4 + len <= b.len;
-  }
-  return read_dynamic(b, scratch) && b.bitpos() <= total_bits;
-}
-
 inline void cpu_pause() {
 #if defined(__x86_64__)
   __builtin_ia32_pause();
@@ -377,7 +359,7 @@ void PInflateJob::prepare(const uint8_t* in_, size_t in_len_, size_t cap_, size_
   last_byte = 0;
   chain.clear();
   resolve_failed.store(0);
-  if (chunk_bytes < 4096) chunk_bytes = 4096;
+  if (chunk_bytes < 512) chunk_bytes = 512;
   n_chunks = (unsigned)std::max<size_t>(1, in_len / chunk_bytes);
   while (chunks.size() < n_chunks) chunks.emplace_back(new PInflateChunk);
   for (unsigned k = 0; k < n_chunks; k++) {
@@ -397,7 +379,7 @@ void PInflateJob::search(unsigned k) {
   PInflateChunk& ch = *chunks[k];
   if (k == 0) return;  // the stream's first block starts at bit 0
   const size_t total_bits = in_len * 8;
-  std::unique_ptr<Tables> T(new Tables), scratch(new Tables);
+  std::unique_ptr<Tables> T(new Tables);
   uint64_t found = NOT_FOUND;
   for (size_t byte = ch.nominal_bit >> 3; byte * 8 < ch.limit_bit && found == NOT_FOUND; byte++) {
     uint64_t w = 0;
@@ -410,12 +392,25 @@ void PInflateJob::search(unsigned k) {
       if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;     // at most 286 literal/length and 30 distance codes
       size_t bit = byte * 8 + s;
       if (bit < ch.nominal_bit || bit >= ch.limit_bit) continue;
+      {
+        // the code-length code must be complete: 4 + HCLEN three-bit lengths from bit 17 on, Kraft sum exactly 1 -- from one more
+        // 64-bit load, before the bit reader is set up (one candidate in a hundred passes)
+        const size_t pos2 = bit + 17;
+        if ((pos2 >> 3) + 8 <= in_len) {
+          uint64_t q;
+          memcpy(&q, in + (pos2 >> 3), 8);
+          q >>= (pos2 & 7);
+          static const uint8_t kraft[8] = {0, 64, 32, 16, 8, 4, 2, 1};
+          uint32_t sum = 0;
+          for (unsigned n = (unsigned)((v >> 13) & 15) + 4; n; n--, q >>= 3) sum += kraft[q & 7];
+          if (sum != 128) continue;
+        }
+      }
       BitIn b(in, in_len);
       b.seek(bit + 3);
-      if (!read_dynamic(b, *T)) continue;
-      if (decode_body<true>(b, *T, nullptr, (size_t)1 << 22) != 0) continue;
-      if (b.bitpos() > total_bits) continue;
-      if (!plausible_next_header(b, total_bits, *scratch)) continue;
+      if (!read_dynamic(b, *T) || b.bitpos() > total_bits) continue;
+      // (no trial decode of the block: three complete prefix codes accept any bit string, so it would only tell at the block's
+      // end -- a third of a millisecond per chunk -- what the chain of chunks tells anyway: a start nobody lands on is skipped)
       found = bit;
       break;
     }
@@ -505,28 +500,19 @@ bool PInflateJob::link() {
     i = ch.next;
   }
   // windows: the last 32 KiB of (window of the chunk in front ++ its bytes); the marker prefix of the chunk in front stands
-  // for its own window, so this is the resolved tail of its prefixed symbol buffer
+  // for its own window, so this is the resolved tail of its prefixed symbol buffer. Kept as a table over SYMBOLS (0..255 the byte
+  // itself, 256 + w the window): resolving is one load per symbol, no branch on "is it a marker"
   for (size_t ci = 0; ci < chain.size(); ci++) {
     PInflateChunk& ch = *chunks[chain[ci]];
-    ch.window.resize(PINFLATE_WINDOW);
-    if (ci == 0) { memset(ch.window.data(), 0, PINFLATE_WINDOW); continue; }
+    ch.lut.resize(256 + PINFLATE_WINDOW);
+    uint8_t* lut = ch.lut.data();
+    for (int v = 0; v < 256; v++) lut[v] = (uint8_t)v;
+    uint8_t* w = lut + 256;
+    if (ci == 0) { memset(w, 0, PINFLATE_WINDOW); continue; }
     const PInflateChunk& prev = *chunks[chain[ci - 1]];
     const uint16_t* tail = prev.sym + prev.n_out;  // = prefix + n_out - WINDOW
-    const uint8_t* pw = prev.window.data();
-    uint8_t* w = ch.window.data();
-    uint32_t x = 0;
-#if defined(__x86_64__)
-    const __m128i hi = _mm_set1_epi16((short)0xff00);
-    for (; x + 16 <= PINFLATE_WINDOW; x += 16) {
-      __m128i a = _mm_loadu_si128((const __m128i*)(tail + x)), c = _mm_loadu_si128((const __m128i*)(tail + x + 8));
-      if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, c), hi), _mm_setzero_si128())) == 0xffff) {
-        _mm_storeu_si128((__m128i*)(w + x), _mm_packus_epi16(a, c));
-      } else {
-        for (uint32_t y = x; y < x + 16; y++) { uint16_t s = tail[y]; w[y] = s < 256 ? (uint8_t)s : pw[s - 256]; }
-      }
-    }
-#endif
-    for (; x < PINFLATE_WINDOW; x++) { uint16_t s = tail[x]; w[x] = s < 256 ? (uint8_t)s : pw[s - 256]; }
+    const uint8_t* pl = prev.lut.data();
+    for (uint32_t x = 0; x < PINFLATE_WINDOW; x++) w[x] = pl[tail[x]];
   }
   out_len = total;
   if (total) {
@@ -534,8 +520,7 @@ bool PInflateJob::link() {
     const PInflateChunk* lc = nullptr;
     for (size_t ci = chain.size(); ci-- > 0;)
       if (chunks[chain[ci]]->n_out) { lc = chunks[chain[ci]].get(); break; }
-    uint16_t s = lc->sym[PINFLATE_WINDOW + lc->n_out - 1];
-    last_byte = s < 256 ? (uint8_t)s : lc->window[s - 256];
+    last_byte = lc->lut[lc->sym[PINFLATE_WINDOW + lc->n_out - 1]];
   }
   ok = true;
   return true;
@@ -546,11 +531,11 @@ void PInflateJob::resolve(unsigned ci, unsigned r, uint8_t* dst) {
   const size_t b0 = (size_t)r * PIECE, b1 = std::min(ch.n_out, b0 + PIECE);
   const uint16_t* src = ch.sym + PINFLATE_WINDOW;
   uint8_t* d = dst + ch.out_off;
-  const uint8_t* w = ch.window.data();
+  const uint8_t* lut = ch.lut.data();
   // a marker that points in front of the stream's first byte is zlib's "invalid distance too far back" (every marker of the
-  // first chunk; in a later chunk only while less than a window of output lies in front of it)
-  const uint32_t min_w = ch.out_off >= PINFLATE_WINDOW ? 0 : (uint32_t)(PINFLATE_WINDOW - ch.out_off);
-  bool too_far = false;
+  // first chunk; in a later chunk only while less than a window of output lies in front of it): symbols in [256, too_far_end)
+  const uint32_t too_far_end = 256 + (ch.out_off >= PINFLATE_WINDOW ? 0 : (uint32_t)(PINFLATE_WINDOW - ch.out_off));
+  uint32_t too_far = 0;
   size_t x = b0;
 #if defined(__x86_64__)
   const __m128i hi = _mm_set1_epi16((short)0xff00);
@@ -560,17 +545,17 @@ void PInflateJob::resolve(unsigned ci, unsigned r, uint8_t* dst) {
       _mm_storeu_si128((__m128i*)(d + x), _mm_packus_epi16(a, c));
     } else {
       for (size_t y = x; y < x + 16; y++) {
-        uint16_t s = src[y];
-        if (s >= 256 && (uint32_t)(s - 256) < min_w) too_far = true;
-        d[y] = s < 256 ? (uint8_t)s : w[s - 256];
+        const uint32_t s = src[y];
+        too_far |= (uint32_t)(s - 256 < too_far_end - 256);
+        d[y] = lut[s];
       }
     }
   }
 #endif
   for (; x < b1; x++) {
-    uint16_t s = src[x];
-    if (s >= 256 && (uint32_t)(s - 256) < min_w) too_far = true;
-    d[x] = s < 256 ? (uint8_t)s : w[s - 256];
+    const uint32_t s = src[x];
+    too_far |= (uint32_t)(s - 256 < too_far_end - 256);
+    d[x] = lut[s];
   }
   if (too_far) resolve_failed.store(1, std::memory_order_relaxed);
 }

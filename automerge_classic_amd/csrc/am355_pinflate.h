@@ -4,8 +4,7 @@
 // A DEFLATE stream cannot be entered in the middle for two reasons: block boundaries are bit positions nobody recorded, and
 // a back-reference may reach 32 KiB behind its block. Both are worked around (the two-stage scheme of pugz / rapidgzip):
 //   search   -- per chunk of compressed bytes, the first bit position that reads as the header of a dynamic-Huffman block
-//               (complete pre-code, complete literal/length code with an end-of-block symbol, valid distance code) whose body
-//               decodes to an end-of-block symbol followed by another valid block header;
+//               (complete pre-code, complete literal/length code with an end-of-block symbol, valid distance code);
 //   decode   -- from that position into 16-BIT symbols: 0..255 = a byte, 256 + w = "byte w of the 32 KiB in front of this
 //               chunk", which is what a back-reference beyond the chunk's start copies (the unknown window is a prefix of
 //               markers in front of the chunk's output, so copies need no special case). A chunk stops at the block boundary
@@ -38,7 +37,7 @@ struct PInflateChunk {
   uint32_t next = 0;                      // chunk whose start this one reached; n_chunks = it decoded the final block
   int status = 0;                         // 0 not decoded, 1 ok, 2 failed
   size_t out_off = 0;                     // link: offset of the chunk's bytes in the stream's output
-  std::vector<uint8_t> window;            // link: the 32 KiB in front of the chunk
+  std::vector<uint8_t> lut;               // link: symbol -> byte: the identity for 0..255, then the 32 KiB in front of the chunk (one branch-free gather resolves a symbol)
   ~PInflateChunk() { free(sym); }
 };
 

@@ -495,6 +495,25 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank, const uint3
   return AM355_OK;
 }
 
+// The op rows (13 word columns + the insert byte) and the flattened pred lists, for N rows / P preds.
+static int carve_cols(am355_ctx* c, uint32_t N, uint32_t P) {
+  canary_scope("replay buffers (carve_cols: op rows, preds)");
+  size_t Nc = (size_t)N + 1;
+  size_t bytes = 13 * carve_size(Nc, 4) + carve_size(Nc, 1);
+  if (!c->d_cols.ensure(bytes) || !c->d_pred.ensure(2 * carve_size((size_t)P + 1, 4))) return fail(c, AM355_E_NOMEM, "device allocation failed (op rows)");
+  canary_forget(c->d_cols.p, c->d_cols.cap); canary_forget(c->d_pred.p, c->d_pred.cap);
+  uint8_t* p = c->d_cols.as<uint8_t>();
+  OpCols& o = c->cols;
+  o.obj_actor = carve<uint32_t>(p, Nc); o.obj_ctr = carve<uint32_t>(p, Nc); o.key_actor = carve<uint32_t>(p, Nc); o.key_ctr = carve<uint32_t>(p, Nc);
+  o.key_off = carve<uint32_t>(p, Nc); o.key_len = carve<uint32_t>(p, Nc); o.action = carve<uint32_t>(p, Nc); o.val_tl = carve<uint32_t>(p, Nc);
+  o.val_off = carve<uint32_t>(p, Nc); o.pred_first = carve<uint32_t>(p, Nc); o.pred_num = carve<uint32_t>(p, Nc); o.id_ctr = carve<uint32_t>(p, Nc);
+  o.id_actor = carve<uint32_t>(p, Nc); o.insert = carve<uint8_t>(p, Nc);
+  uint8_t* q = c->d_pred.as<uint8_t>();
+  o.pred_actor = carve<uint32_t>(q, (size_t)P + 1);
+  o.pred_ctr = carve<uint32_t>(q, (size_t)P + 1);
+  return AM355_OK;
+}
+
 // Device buffers for N op rows / P preds, decode, merge, patch IR. `slot_rank` != null: actor tables are the
 // device-interned slots (fast path); null: c->amap holds ranks (general path).
 // Device buffers for N op rows / P preds (op rows, merge scratch, sort scratch, patch IR), carved from a few arenas.
@@ -504,20 +523,13 @@ int setup_buffers(am355_ctx* c, uint32_t NA) {
   if (1 + bits_row + bits_ctr + bits_actor > 64) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "sort key wider than 64 bits"); }
   size_t Nc = (size_t)N + 1;
   canary_scope("replay buffers (setup_buffers: op rows, preds, merge scratch, sort scratch, patch IR)");
-  {
-    size_t bytes = 13 * carve_size(Nc, 4) + carve_size(Nc, 1);
-    if (!c->d_cols.ensure(bytes) || !c->d_pred.ensure(2 * carve_size((size_t)P + 1, 4))) return fail(c, AM355_E_NOMEM, "device allocation failed (op rows)");
-    canary_forget(c->d_cols.p, c->d_cols.cap); canary_forget(c->d_pred.p, c->d_pred.cap);
-    uint8_t* p = c->d_cols.as<uint8_t>();
-    OpCols& o = c->cols;
-    o.obj_actor = carve<uint32_t>(p, Nc); o.obj_ctr = carve<uint32_t>(p, Nc); o.key_actor = carve<uint32_t>(p, Nc); o.key_ctr = carve<uint32_t>(p, Nc);
-    o.key_off = carve<uint32_t>(p, Nc); o.key_len = carve<uint32_t>(p, Nc); o.action = carve<uint32_t>(p, Nc); o.val_tl = carve<uint32_t>(p, Nc);
-    o.val_off = carve<uint32_t>(p, Nc); o.pred_first = carve<uint32_t>(p, Nc); o.pred_num = carve<uint32_t>(p, Nc); o.id_ctr = carve<uint32_t>(p, Nc);
-    o.id_actor = carve<uint32_t>(p, Nc); o.insert = carve<uint8_t>(p, Nc);
-    uint8_t* q = c->d_pred.as<uint8_t>();
-    o.pred_actor = carve<uint32_t>(q, (size_t)P + 1);
-    o.pred_ctr = carve<uint32_t>(q, (size_t)P + 1);
+  // (rows the speculative decode launch of this replay is writing keep their place: they are carved for a capacity >= N, P)
+  if (!(c->spec_launched && N <= c->spec_cap_ops && P <= c->spec_cap_preds)) {
+    c->spec_launched = false;
+    int rcc = carve_cols(c, N, P);
+    if (rcc) return rcc;
   }
+  canary_scope("replay buffers (setup_buffers: merge scratch, sort scratch, patch IR)");
   {
     size_t cw = carry_words(N);
     size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc + 2, 4) + 4 * carve_size(2 * Nc + 2, 4) +
@@ -691,18 +703,47 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   lap("buffers carved");
   // the decode launch first (every HIP call before it is device idle time); the merge stage's fills follow on stream3 -- they depend
   // on nothing of this replay -- and stream3 only waits for the counter reset when a second decoder class runs there
-  if (!(c->counts_zeroed_at == c->d_counts.p && c->mb.counts_bytes <= c->counts_zeroed)) HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
-  c->counts_zeroed_at = nullptr;  // (one replay's worth: the merge kernels are about to write it)
-  if (tot.n_small && (tot.n_large || tot.n_serial)) {
-    HIPCHK(c, hipEventRecord(c->ev_fork, st));
-    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+  // (c->spec_launched survived setup_buffers: the rows are where the speculative launch writes them; its gate was open iff this holds)
+  const bool spec_done = c->spec_launched && decode_gate_open(tot, c->spec_cap_ops, c->spec_cap_preds, distinct_capacity()) &&
+                         c->counts_zeroed_at == c->d_counts.p && c->mb.counts_bytes <= c->counts_zeroed;
+  if (trace && c->spec_launched && !spec_done)
+    fprintf(stderr, "  planned: speculative decode not usable: ops %u / cap %u, preds %u / cap %u, distinct %u, fast_a %x flags_a %x fallback %u, counts %p/%p %zu/%zu\n", tot.n_ops,
+            c->spec_cap_ops, tot.n_preds, c->spec_cap_preds, tot.n_distinct, tot.fast_a, tot.flags_a, tot.fallback, c->counts_zeroed_at, c->d_counts.p, c->mb.counts_bytes, c->counts_zeroed);
+  if (c->spec_launched && !spec_done) {
+    // the launch did nothing, or wrote rows that have just been carved anew: wait for it, then decode as if it had not been there
+    c->spec_launched = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream3));
+    HIPCHK(c, hipStreamSynchronize(st));
+    int rc2 = setup_buffers(c, n_distinct);
+    if (rc2) return rc2;
   }
-  if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[2], st));
-  launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n,
-                        tot.n_small, tot.n_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
-                        &c->d_counts.as<Counts>()->flags, st, c->stream3, c->shard_rank, c->shard_world);
-  lap("decode launched");
-  if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
+  if (!spec_done && !(c->counts_zeroed_at == c->d_counts.p && c->mb.counts_bytes <= c->counts_zeroed)) HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
+  c->counts_zeroed_at = nullptr;  // (one replay's worth: the merge kernels are about to write it)
+  if (spec_done) {
+    c->hint_ops = std::max(c->hint_ops, tot.n_ops);
+    c->hint_preds = std::max(c->hint_preds, tot.n_preds);
+    // the two wave classes are running (small on `st`, large on stream3, which was ordered behind the plan kernel then); what is
+    // left for the host to launch is the lane-serial class, beside them on stream3
+    if (tot.n_serial)
+      launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n, 0, 0,
+                            tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols, &c->d_counts.as<Counts>()->flags, c->stream3, nullptr,
+                            c->shard_rank, c->shard_world);
+    lap("decode was launched behind the plan kernel");
+  } else {
+    c->hint_ops = tot.n_ops;
+    c->hint_preds = tot.n_preds;
+    if (tot.n_small && (tot.n_large || tot.n_serial)) {
+      HIPCHK(c, hipEventRecord(c->ev_fork, st));
+      HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+    }
+    if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n,
+                          tot.n_small, tot.n_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
+                          &c->d_counts.as<Counts>()->flags, st, c->stream3, c->shard_rank, c->shard_world);
+    lap("decode launched");
+    if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
+  }
+  c->spec_launched = false;  // (used up: a second merge run of this replay -- the general path after a late dependency -- decodes in its own order)
   if (tot.n_small && (tot.n_large || tot.n_serial)) {
     // (stream3 carries the second decoder class -- 0.27 ms for a batch of fat changes --: the fills, which depend on nothing, would
     // start behind it and k_resolve would wait for them; they go to the copy stream, which is idle now)
@@ -927,6 +968,7 @@ int replay_impl(am355_ctx* c) {
   c->ir_copy_enqueued = 0;
   c->dep_graph_ready = false;
   c->flags = 0;
+  c->spec_launched = false;
   if (c->is_document) return replay_document(c);
   auto t_begin = std::chrono::steady_clock::now();
   const bool trace = getenv("AM355_TRACE") != nullptr;
@@ -1025,6 +1067,10 @@ int replay_impl(am355_ctx* c) {
   static const bool enqueue_early = []() { const char* e = getenv("AM355_HASH_ENQUEUE"); return e && !strcmp(e, "early"); }();
   if (hash_after_parse && enqueue_early) { int rb = enqueue_stream_b(); if (rb) return rb; }
   exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_wa + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
+  // (AM355_SPEC_DECODE=0: the decode kernels wait for the host to read the totals, as in rounds 2-4)
+  static const bool spec_env = []() { const char* e = getenv("AM355_SPEC_DECODE"); return !(e && *e == '0'); }();
+  const bool spec_possible = spec_env && n && c->inline_fills && counts_too && hash_after_parse && !getenv("AM355_HOST_PLAN") && !(c->in_apply && c->graph_mode != 0) &&
+                             c->d_plan_totals.ensure(sizeof(PlanTotals));
   for (int attempt = 0;; attempt++) {
     if (attempt) {
       HIPCHK(c, hipMemsetAsync(c->d_slots.p, 0, 8 * (size_t)(c->slot_mask + 1), sa));
@@ -1038,14 +1084,33 @@ int replay_impl(am355_ctx* c) {
     // (its totals, and the stage-1 words the host decides on, reach the host through HostSignals: no copy, no blocking wait)
     c->sig_seq++;
     launch_plan(d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plan_sums.as<unsigned long long>(), c->d_plans.as<ChangePlan>(),
-                c->d_plans.as<ChangePlan>() + n1, d_wa, d_wa + 8, sig, c->sig_seq, sa);
+                c->d_plans.as<ChangePlan>() + n1, d_wa, d_wa + 8, sig, c->sig_seq, sa, spec_possible ? c->d_plan_totals.as<PlanTotals>() : nullptr);
     // the host's own half of the plan needs a 32-byte digest per change and the handful of distinct actor ids: they follow
     // -- on stream4, behind the plan kernel: in stream A the copy (and its dispatch gap) would sit in front of the decode kernels
     HIPCHK(c, hipEventRecord(c->ev_plan, sa));
     HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_plan, 0));
+    if (spec_possible && attempt == 0) {
+      // the decode kernels of the wave classes right behind the plan kernel, before the host knows the totals (decode_gate_open,
+      // am355_internal.h): rows carved for a capacity -- the context's previous in-order replay, or one row per four encoded bytes
+      const uint64_t est = c->raw.size() / 2 + 1024;
+      c->spec_cap_ops = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->hint_ops, est), 0x7ffffff0u);
+      c->spec_cap_preds = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->hint_preds, est), 0x7ffffff0u);
+      // (the merge stage's counter block, cleared by the parse kernel above, must not move when the real totals arrive)
+      if (trace) fprintf(stderr, "replay: speculative decode: cap %u ops / %u preds (counter block %zu of %zu bytes)\n", c->spec_cap_ops, c->spec_cap_preds, merge_counts_bytes(c->spec_cap_ops), cb);
+      if (merge_counts_bytes(c->spec_cap_ops) <= cb && carve_cols(c, c->spec_cap_ops, c->spec_cap_preds) == AM355_OK) {
+        canary_arm();
+        if (c->phase_events) { HIPCHK(c, hipEventRecord(c->ev[1], sa)); HIPCHK(c, hipEventRecord(c->ev[2], sa)); }
+        HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_plan, 0));
+        launch_decode_speculative(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n, c->d_plan_totals.as<PlanTotals>(), c->spec_cap_ops,
+                                  c->spec_cap_preds, distinct_capacity(), c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
+                                  &c->d_counts.as<Counts>()->flags, sa, c->stream3, c->shard_rank, c->shard_world);
+        if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], sa));
+        c->spec_launched = true;
+      }
+    }
     HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, c->stream4));
     HIPCHK(c, hipEventRecord(c->ev_s1, c->stream4));
-    if (c->phase_events || !hash_after_parse) HIPCHK(c, hipEventRecord(c->ev[1], sa));
+    if ((c->phase_events && !c->spec_launched) || !hash_after_parse) HIPCHK(c, hipEventRecord(c->ev[1], sa));
     if (attempt == 0 && !(hash_after_parse && enqueue_early)) { int rb = enqueue_stream_b(); if (rb) return rb; }
     lap("stage 1 enqueued");
     if (!wait_host_signal(&sig->plan_seq, c->sig_seq, sa)) {
@@ -1056,6 +1121,7 @@ int replay_impl(am355_ctx* c) {
     memcpy(&tot, (const void*)&sig->plan, sizeof tot);
     lap("stage 1 totals read");
     if (!(tot.fast_a & FF_CAPACITY) || attempt) break;
+    c->spec_launched = false;  // (the decode kernels behind the first plan saw its capacity flag and did nothing; the second plan gets an ordinary launch)
     // the staging buffer for actor tables was too small: grow to the measured total and redo the interning
     c->amap_cap = tot.total_entries + 1024;
     if (!c->d_amap_prov.ensure(4 * (size_t)c->amap_cap)) return fail(c, AM355_E_NOMEM, "device allocation failed (actor tables)");

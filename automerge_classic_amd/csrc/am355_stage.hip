@@ -429,7 +429,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
     const char* pe = getenv("AM355_PINFLATE");
     const char* pmin_env = getenv("AM355_PINFLATE_MIN");
     const char* pchunk_env = getenv("AM355_PINFLATE_CHUNK");
-    const size_t par_min = pmin_env && atol(pmin_env) > 0 ? (size_t)atol(pmin_env) : (size_t)1 << 20;
+    const size_t par_min = pmin_env && atol(pmin_env) > 0 ? (size_t)atol(pmin_env) : (size_t)256 << 10;
     const bool par_on = c->pool->size() >= 1 && !(pe && *pe == '0');
     size_t par_bytes = 0;
     for (Col* col : deflated)
@@ -450,12 +450,23 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
     }
     // (every search task in front of every decode task: a decode task spins for the searches of the chunks behind its own, and
     // the pool hands tasks out in index order -- all of them have been taken by a thread when a decode task starts)
-    for (size_t s = 0; s < par.size(); s++)
-      for (unsigned k = 0; k < c->pinflate_jobs[s]->n_chunks; k++) tasks.push_back(Task{3, (unsigned)s, k});
+    // (whole streams -- the shorter columns, longest first -- in front of the chunk decodes: a single long task must not be the last one drawn)
     for (size_t k = 0; k < deflated.size(); k++)
       if (!deflated[k]->pj) tasks.push_back(Task{4, (unsigned)k, 0});
+    for (size_t s = 0; s < par.size(); s++)
+      for (unsigned k = 0; k < c->pinflate_jobs[s]->n_chunks; k++) tasks.push_back(Task{3, (unsigned)s, k});
+    std::atomic<int64_t> kind_end_us[5];  // (trace: when the last task of each kind ended, microseconds from the start of the call)
+    for (auto& x : kind_end_us) x.store(0);
     c->pool->run((unsigned)tasks.size(), [&](unsigned t) {
       const Task& tk = tasks[t];
+      struct Stamp {
+        std::atomic<int64_t>* slot; std::chrono::steady_clock::time_point t0;
+        ~Stamp() {
+          if (!slot) return;
+          int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(), prev = slot->load();
+          while (prev < us && !slot->compare_exchange_weak(prev, us)) {}
+        }
+      } stamp{trace ? &kind_end_us[tk.kind] : nullptr, t_begin};
       switch (tk.kind) {
         case 0: c->pinflate_jobs[tk.a]->search(tk.b); break;
         case 2: copy_piece(tk.a); break;
@@ -470,6 +481,10 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
     });
     copy_done = true;
     lap("inflate | copy");
+    if (trace)
+      fprintf(stderr, "load_document:   %zu tasks on %u threads (%zu streams in chunks of %zu KiB): last search +%.3f, copy +%.3f, chunk decode +%.3f, whole stream +%.3f ms\n",
+              tasks.size(), c->pool->size() + 1, par.size(), chunk_bytes >> 10, kind_end_us[0].load() / 1e3, kind_end_us[2].load() / 1e3, kind_end_us[3].load() / 1e3,
+              kind_end_us[4].load() / 1e3);
     // streams the chunked decode gave up on (no chain of block starts, output beyond the cap, damaged data): the ordinary
     // single-stream inflate decides what they are
     {
@@ -633,6 +648,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
     for (auto& x : left) x.store(0);
     for (const Piece& pc : pieces) left[pc.place].fetch_add(1);
     uint8_t* raw = c->raw.data();
+    lap("arena ready");
     c->pool->run((unsigned)pieces.size(), [&](unsigned k) {
       const Piece& pc = pieces[k];
       if (pc.pj) pc.pj->resolve(pc.ci, pc.r, raw + pc.dst);

@@ -99,11 +99,11 @@ def test_damaged_streams_are_given_up_or_decode_like_zlib(pinflate):
     assert accepted > 20  # (a flipped bit inside a literal changes one byte of the output: legal DEFLATE)
 
 
-@pytest.mark.parametrize("chunk", [4096, 30000])
+@pytest.mark.parametrize("chunk", [700, 5000])
 def test_document_columns_through_the_chunked_decode(chunk, monkeypatch):
     """Backend.load (columnar.js:1062-1067) with every compressed column of the document in chunks: same patch as the oracle's,
     same as with the path switched off; a damaged column is reported as before."""
-    monkeypatch.setenv("AM355_PINFLATE_MIN", "4096")
+    monkeypatch.setenv("AM355_PINFLATE_MIN", "1500")
     monkeypatch.setenv("AM355_PINFLATE_CHUNK", str(chunk))
     eng = engine.Engine(0, EMU_LIB)
     doc, rows = loggen.generate_document(n_actors=6, n_texts=3, text_len=900, n_maps=3, keys_per_map=300, n_submaps=2, n_lists=2, list_len=300, deflate=True, seed=0xD0C7)
@@ -146,7 +146,8 @@ def test_backend_load_in_one_call_equals_the_two_calls(monkeypatch):
     """am355_backend_load (checksum thread beside the device stages, verdict at the end) against am355_load_document + am355_replay:
     same patch, same save bytes; a wrong checksum is reported by either form, and outranks damaged columns."""
     import hashlib
-    monkeypatch.setenv("AM355_PINFLATE_MIN", "4096")
+    monkeypatch.setenv("AM355_PINFLATE_MIN", "1500")
+    monkeypatch.setenv("AM355_PINFLATE_CHUNK", "900")
     eng = engine.Engine(0, EMU_LIB)
     doc, rows = loggen.generate_document(n_actors=5, n_texts=3, text_len=700, n_maps=2, keys_per_map=200, n_submaps=2, n_lists=2, list_len=250, deflate=True, seed=0xD0C8)
     eng.load_document(doc)
