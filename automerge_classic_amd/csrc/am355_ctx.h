@@ -222,6 +222,64 @@ class HostPool {
   bool stop_ = false;
 };
 
+// One helper thread with a one-slot mailbox: the replay hands it the enqueueing of the hash stream's commands (ten HIP calls,
+// ~40 us of host time) while the calling thread enqueues the critical stream -- the host's launch rate, not the device, sets the pace
+// of a 0.4 ms replay. Polls for a few milliseconds after a job (replays come in bursts), sleeps otherwise.
+class AsyncLane {
+ public:
+  AsyncLane() : t_([this]() { loop(); }) {}
+  ~AsyncLane() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    t_.join();
+  }
+  void post(std::function<void()> job) {
+    job_ = std::move(job);
+    state_.store(1, std::memory_order_release);
+    if (sleeping_.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> l(m_); cv_.notify_one(); }
+  }
+  bool busy() const { return state_.load(std::memory_order_acquire) != 0; }
+  void wait() {  // returns when the posted job has run (at once when nothing is posted)
+    while (state_.load(std::memory_order_acquire) != 0) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+ private:
+  void loop() {
+    uint64_t hot_until = 0;
+    for (;;) {
+      if (state_.load(std::memory_order_acquire) == 1) {
+        job_();
+        job_ = nullptr;
+        state_.store(0, std::memory_order_release);
+        hot_until = now_us() + 3000;
+        continue;
+      }
+      if (now_us() < hot_until) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        continue;
+      }
+      std::unique_lock<std::mutex> l(m_);
+      sleeping_.store(true, std::memory_order_release);
+      cv_.wait(l, [&]() { return stop_ || state_.load(std::memory_order_acquire) == 1; });
+      sleeping_.store(false, std::memory_order_release);
+      if (stop_) return;
+    }
+  }
+  static uint64_t now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  std::function<void()> job_;
+  std::atomic<int> state_{0};
+  std::atomic<bool> sleeping_{false};
+  std::mutex m_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+  std::thread t_;  // (last member: the thread starts with everything above constructed)
+};
+
 struct Hash32 {
   uint8_t b[32];
   bool operator==(const Hash32& o) const { return memcmp(b, o.b, 32) == 0; }
@@ -249,13 +307,15 @@ struct am355_ctx {
   // staged batch
   PinnedBytes raw;                 // uncompressed changes, host copy in pinned memory (the scheduler reads deps / actor ids here)
   std::unique_ptr<HostPool> pool;  // host worker threads (staging, inflate, checksum)
+  std::unique_ptr<AsyncLane> lane; // enqueues the hash stream's commands beside the calling thread (created on first use)
   std::vector<uint64_t> raw_off;
   uint32_t n_changes = 0;
   // speculative decode launch (am355_internal.h decode_gate_open): op rows carved for a capacity before the totals are known
   DevBuf d_plan_totals;              // PlanTotals, device copy (k_plan_apply)
   bool spec_launched = false;        // this replay's decode kernels of the wave classes are enqueued behind the plan kernel
+  bool spec_large_launched = false;  // ... the large class among them (only when the previous batch had such changes)
   uint32_t spec_cap_ops = 0, spec_cap_preds = 0;   // what c->cols is carved for while spec_launched
-  uint32_t hint_ops = 0, hint_preds = 0;           // totals of the context's previous in-order replay
+  uint32_t hint_ops = 0, hint_preds = 0, hint_large = 0;   // totals (and large-class changes) of the context's previous in-order replay
   bool staged = false, replayed = false, ir_fetched = false;
   int ir_copy_enqueued = 0;          // the IR tables are on their way to h_ir (1: without the edit table, 2: all three); reset by every replay
   bool prefetch_ir = false;          // am355_backend_load: the replay enqueues that copy itself

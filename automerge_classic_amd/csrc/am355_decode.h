@@ -25,7 +25,8 @@ void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const ui
 // rank_ids: rank_ids_bytes() bytes of device memory (the ids of the distinct actors as the ranking workgroup reads them; needs no clearing)
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
-                         void* rank_ids, ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st);
+                         void* rank_ids, ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st,
+                         ChangeBrief* host_briefs = nullptr);
 size_t rank_ids_bytes();
 size_t plan_block_sums_bytes(uint32_t n);
 uint32_t distinct_capacity();
@@ -35,7 +36,7 @@ uint32_t distinct_capacity();
 // tables. The totals go to the host through `sig` (HostSignals.plan).
 void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, const uint32_t* slot_rank, uint32_t slot_mask, const unsigned long long* block_sums,
                  ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st,
-                 PlanTotals* dev_totals = nullptr);
+                 PlanTotals* dev_totals = nullptr, uint32_t* host_s1 = nullptr);
 void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_changes, const PlanTotals* totals, uint32_t cap_ops,
                                uint32_t cap_preds, uint32_t cap_distinct, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st,
                                hipStream_t aux, uint32_t shard_rank = 0, uint32_t shard_world = 1);

@@ -1091,7 +1091,8 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
                                                        const uint32_t* __restrict__ amap_base, const uint32_t* __restrict__ amap, uint32_t amap_cap,
                                                        const uint32_t* __restrict__ first_idx, uint32_t* __restrict__ flags, uint32_t* __restrict__ fast_flags,
                                                        ChangeBrief* __restrict__ briefs, const uint32_t* __restrict__ distinct, const RankId* __restrict__ rank_ids,
-                                                       uint32_t* __restrict__ slot_rank, unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words) {
+                                                       uint32_t* __restrict__ slot_rank, unsigned long long* __restrict__ block_sums, uint32_t* __restrict__ plan_words,
+                                                       ChangeBrief* __restrict__ host_briefs) {
   wave_priority_high();
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
   if (blockIdx.x + 1 == gridDim.x) {  // the extra workgroup
@@ -1117,6 +1118,10 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
       if (m->pad & 1) br.flags_fits |= 0x20000000u;  // the change carries columns this engine does not model
     }
     briefs[c] = br;
+    // (the host's half of the plan reads the briefs: written into its pinned memory right here -- 32 bytes per change over the link --
+    // they are there when the NEXT kernel, k_plan_apply, signals; a D2H copy behind that kernel cost an event record in the main
+    // stream, a copy dispatch on another and a blocking wait on the host, which is the critical path between plan and k_resolve)
+    if (host_briefs) host_briefs[c] = br;
   }
   // ---- sums of this workgroup's changes for k_plan_apply (a malformed change counts nothing: the host rejects the batch on its flags) ----
   const bool valid = in_range && !(br.flags_fits & 0x1fffffffu);
@@ -1150,7 +1155,8 @@ __global__ __launch_bounds__(BLOCK) void k_actor_check(const uint8_t* __restrict
 __global__ __launch_bounds__(BLOCK) void k_plan_apply(const ChangeBrief* __restrict__ briefs, uint32_t n, const uint32_t* __restrict__ slot_rank, uint32_t slot_mask,
                                                       const unsigned long long* __restrict__ block_sums, ChangePlan* __restrict__ plans,
                                                       ChangePlan* __restrict__ plans_serial, const uint32_t* __restrict__ words, const uint32_t* __restrict__ plan_words,
-                                                      const uint32_t* __restrict__ distinct, HostSignals* sig, uint32_t seq, PlanTotals* __restrict__ dev_totals) {
+                                                      const uint32_t* __restrict__ distinct, HostSignals* sig, uint32_t seq, PlanTotals* __restrict__ dev_totals,
+                                                      uint32_t* __restrict__ host_s1) {
   wave_priority_high();
   __shared__ unsigned long long s_scan[BLOCK / WAVE][3];
   __shared__ unsigned long long s_base[6];
@@ -1184,6 +1190,20 @@ __global__ __launch_bounds__(BLOCK) void k_plan_apply(const ChangeBrief* __restr
     if (small) plans[(uint32_t)(s_base[3] + e2[0])] = pl;
     else if (large) plans[n - 1 - (uint32_t)(s_base[4] + e2[1])] = pl;
     else plans_serial[(uint32_t)(s_base[5] + e2[2])] = pl;
+  }
+  if (blockIdx.x + 1 == gridDim.x && host_s1) {
+    // the stage-1 words and the distinct actor ids (count, slots, (offset, length) records: what the host ranks the actors from) into
+    // the host's mirror of the block -- written by earlier kernels, so complete; in place before the signal below
+    const uint32_t nd = distinct[0] < DISTINCT_CAP ? distinct[0] : DISTINCT_CAP;
+    const uint32_t* src = words;  // (the block: 16 words | distinct[0 .. ] at word 16)
+    for (uint32_t i = threadIdx.x; i < 16; i += BLOCK) host_s1[i] = src[i];
+    uint32_t* hd = host_s1 + 16;
+    for (uint32_t i = threadIdx.x; i < 1 + nd; i += BLOCK) hd[i] = distinct[i];
+    const unsigned long long* ids = (const unsigned long long*)(distinct + 2 + DISTINCT_CAP);
+    unsigned long long* hids = (unsigned long long*)(hd + 2 + DISTINCT_CAP);
+    for (uint32_t i = threadIdx.x; i < nd; i += BLOCK) hids[i] = ids[i];
+    __threadfence_system();
+    __syncthreads();
   }
   if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {
     unsigned long long ops = s_base[0] + t1[0], preds = s_base[1] + t1[1], ent = s_base[2] + t1[2];
@@ -1822,6 +1842,9 @@ uint32_t err = 0;
   return err;
 }
 
+// column groups of k_decode_wave (see there)
+enum : uint32_t { DG_ROWS = 1 /* action, op ids, insert, object */, DG_KEY_ID = 2 /* key element id, value */, DG_KEY_STR = 4, DG_PRED = 8, DG_ALL = 15 };
+
 template <class WL>
 __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                        const ChangePlan* __restrict__ plans, uint32_t n_plans, ActorXlate x, OpCols o,
@@ -1829,6 +1852,12 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
   __shared__ WL L;
   wave_priority_high();
   uint32_t pi = blockIdx.x, lane = threadIdx.x;
+  // A batch of few, fat changes (256 changes of 6 KB in the map workload) leaves three quarters of the SIMDs idle with one wavefront
+  // per change, and a wavefront's time is the serial record walks of its twelve columns one after the other. The columns fall into
+  // groups that do not read each other's rows: with gridDim.y = 4 a change is decoded by four wavefronts (on four SIMDs, each staging
+  // the change's 6 KB for itself), one group each; gridDim.y = 1: all of them (the small class; sharded replays, whose early exit
+  // for foreign changes needs the object columns in the wavefront that decides).
+  const uint32_t groups = gridDim.y > 1 ? (1u << blockIdx.y) : (uint32_t)DG_ALL;
   if (gate.totals) {
     // launched behind k_plan_apply with one wavefront per CHANGE, before the host has seen the totals: the class size comes from
     // the device copy, and the launch does nothing at all when the host is going to decide otherwise (same test as decode_gate_open)
@@ -1868,6 +1897,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     else wv_load_column(L, p + col_off[k], col_len[k], lane);
   };
 
+  if (groups & DG_ROWS) {
   // ---- action (+ op ids: op i of a change is (startOp + i, author), new.js:708-709) ----
   load_col(C_ACTION);
   err |= L.err;
@@ -1964,6 +1994,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     if (!nul && (uint64_t)v >= NONE32) err |= F_OVERFLOW;
     o.obj_ctr[base + i] = nul ? 0 : (uint32_t)v;
   }
+  }  // DG_ROWS
   // ---- objectId sharding: a change none of whose rows belongs to an object of this rank is decoded as far as the merge
   //      stage looks at foreign rows -- action, id, insert flag, object (k_resolve marks them K_FOREIGN from those and goes on; make
   //      rows still enter the object table) -- and no further: keys, values and pred lists of such a change are its owners' business,
@@ -1976,6 +2007,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
       return;
     }
   }
+  if (groups & DG_KEY_ID) {
   // ---- key: element id (actor, delta-coded counter) ----
   load_col(C_KEY_ACTOR);
   err |= L.err;
@@ -2006,8 +2038,9 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
       }
     }
   }
+  }  // DG_KEY_ID (continued below: the value column)
   // ---- key: string ----
-  {
+  if (groups & DG_KEY_STR) {
     __syncthreads();
     // lane 0 compares neighbouring strings byte by byte: make sure it does so in LDS. If the whole column region did
     // not fit, the key column alone usually does (`region` is unused in that case: the other columns stage through `bytes`).
@@ -2022,6 +2055,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
     if (key_lds) err |= wv_key_column(L, (LdsBytes)(L.region + key_at), col_len[C_KEY_STR], col_abs, n, base, lane, o);
     else err |= wv_key_column(L, p + col_off[C_KEY_STR], col_len[C_KEY_STR], col_abs, n, base, lane, o);
   }
+  if (groups & DG_KEY_ID) {
   // ---- value: (len << 4 | tag) per row, offsets into valRaw are an exclusive prefix sum of the lengths ----
   load_col(C_VAL_LEN);
   err |= L.err;
@@ -2043,6 +2077,8 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
       }
     }
   }
+  }  // DG_KEY_ID
+  if (groups & DG_PRED) {
   // ---- preds: group cardinality, then the two value columns consumed predNum[i] entries per row ----
   uint32_t total_preds = 0;
   load_col(C_PRED_NUM);
@@ -2092,6 +2128,7 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
       }
     }
   }
+  }  // DG_PRED
   if (err) atomicOr(flags, err);
 }
 
@@ -2117,13 +2154,15 @@ void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const ui
 
 void launch_actor_intern(const uint8_t* arena, ChangeMeta* metas, uint32_t n, const uint32_t* amap_base, uint32_t* amap, uint32_t amap_cap,
                          unsigned long long* slots, uint32_t slot_mask, uint32_t* first_idx, uint32_t* flags, uint32_t* fast_flags, uint32_t* distinct,
-                         void* rank_ids, ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st) {
+                         void* rank_ids, ChangeBrief* briefs, uint32_t* slot_rank, unsigned long long* block_sums, uint32_t* plan_words, hipStream_t st,
+                         ChangeBrief* host_briefs) {
   if (n)
     hipLaunchKernelGGL(k_actor_intern, dim3(n), dim3(WAVE), 0, st, arena, metas, n, amap_base, amap, amap_cap, slots, slot_mask, first_idx, flags,
                        fast_flags, distinct, (RankId*)rank_ids);
   if (n) hipLaunchKernelGGL(k_actor_first, dim3(n), dim3(WAVE), 0, st, metas, n, amap_base, (const uint32_t*)amap, amap_cap, (const uint32_t*)first_idx, fast_flags);
   hipLaunchKernelGGL(k_actor_check, dim3((n + BLOCK - 1) / BLOCK + 1), dim3(BLOCK), 0, st, arena, metas, n, amap_base, (const uint32_t*)amap, amap_cap,
-                     (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, (const RankId*)rank_ids, slot_rank, block_sums, plan_words);
+                     (const uint32_t*)first_idx, flags, fast_flags, briefs, (const uint32_t*)distinct, (const RankId*)rank_ids, slot_rank, block_sums, plan_words,
+                     host_briefs);
 }
 
 size_t rank_ids_bytes() { return sizeof(RankId) * PLAN_RANK_MAX; }
@@ -2132,10 +2171,10 @@ size_t plan_block_sums_bytes(uint32_t n) { return sizeof(unsigned long long) * P
 
 void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct, const uint32_t* slot_rank, uint32_t slot_mask, const unsigned long long* block_sums,
                  ChangePlan* plans, ChangePlan* plans_serial, const uint32_t* words, const uint32_t* plan_words, HostSignals* sig, uint32_t seq, hipStream_t st,
-                 PlanTotals* dev_totals) {
+                 PlanTotals* dev_totals, uint32_t* host_s1) {
   uint32_t nb = (n + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(k_plan_apply, dim3(nb ? nb : 1), dim3(BLOCK), 0, st, briefs, n, slot_rank, slot_mask, block_sums, plans, plans_serial, words, plan_words,
-                     distinct, sig, seq, dev_totals);
+                     distinct, sig, seq, dev_totals, host_s1);
 }
 
 uint32_t distinct_capacity() { return DISTINCT_CAP; }
@@ -2202,7 +2241,7 @@ void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const 
   if (n_large && n_small + n_large <= 1024) { n_large += n_small; n_small = 0; }
   hipStream_t s2 = (n_small && aux) ? aux : st;
   if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, shard_world > 1 ? 1 : 4), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans + n_small + n_large, n_serial,
                              x, cols, flags, 0);
@@ -2215,7 +2254,7 @@ void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const 
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   hipStream_t s2 = (n_small && aux) ? aux : st;
   if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, shard_world > 1 ? 1 : 4), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans_serial, n_serial, x, cols, flags, 0);
 }
@@ -2230,8 +2269,11 @@ void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, co
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_changes), dim3(WAVE), 0, st, arena, metas, plans, 0u, x, cols, flags,
                      DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 0u});
-  hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
-                     DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 1u});
+  // (aux == null: the caller expects no change of the large class -- none in the context's previous batch -- and launches that class
+  // itself should there be one after all)
+  if (aux)
+    hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes, shard_world <= 1 ? 4 : 1), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
+                       DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 1u});
 }
 
 }  // namespace am355

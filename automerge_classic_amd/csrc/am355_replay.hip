@@ -719,15 +719,22 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   }
   if (!spec_done && !(c->counts_zeroed_at == c->d_counts.p && c->mb.counts_bytes <= c->counts_zeroed)) HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, c->mb.counts_bytes, st));
   c->counts_zeroed_at = nullptr;  // (one replay's worth: the merge kernels are about to write it)
+  c->hint_large = tot.n_large;
   if (spec_done) {
     c->hint_ops = std::max(c->hint_ops, tot.n_ops);
     c->hint_preds = std::max(c->hint_preds, tot.n_preds);
     // the two wave classes are running (small on `st`, large on stream3, which was ordered behind the plan kernel then); what is
     // left for the host to launch is the lane-serial class, beside them on stream3
-    if (tot.n_serial)
-      launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n, 0, 0,
-                            tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols, &c->d_counts.as<Counts>()->flags, c->stream3, nullptr,
-                            c->shard_rank, c->shard_world);
+    const uint32_t host_large = c->spec_large_launched ? 0u : tot.n_large;  // (no large-class change last time: that launch was left out)
+    if (tot.n_serial || host_large) {
+      if (!c->spec_large_launched) {  // stream3 has not been ordered behind the plan kernel yet
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+      }
+      launch_decode_planned(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), c->d_plans.as<ChangePlan>() + std::max(n, 1u), n, 0,
+                            host_large, tot.n_serial, c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols, &c->d_counts.as<Counts>()->flags,
+                            c->stream3, nullptr, c->shard_rank, c->shard_world);
+    }
     lap("decode was launched behind the plan kernel");
   } else {
     c->hint_ops = tot.n_ops;
@@ -757,7 +764,6 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   lap("fills enqueued");
   // ---- host half of the plan, beside the decode kernels (the digests were copied right behind k_plan) ----
-  HIPCHK(c, hipEventSynchronize(c->ev_s1));
   if (go) HIPCHK(c, hipEventSynchronize(go->ready));
   auto t0 = std::chrono::steady_clock::now();
   std::vector<uint32_t> slot_rank;
@@ -1065,7 +1071,25 @@ int replay_impl(am355_ctx* c) {
     return AM355_OK;
   };
   static const bool enqueue_early = []() { const char* e = getenv("AM355_HASH_ENQUEUE"); return e && !strcmp(e, "early"); }();
-  if (hash_after_parse && enqueue_early) { int rb = enqueue_stream_b(); if (rb) return rb; }
+  // AM355_HASH_ENQUEUE=main: by the calling thread, behind the stage-1 launches (rounds 2-4). Default: by the helper thread, beside them.
+#if defined(AM355_EMULATED)   // (the CPU test harness runs a launch to its end inside the call: its streams have no order a second thread could rely on)
+  static const bool enqueue_thread = false;
+#else
+  static const bool enqueue_thread = []() { const char* e = getenv("AM355_HASH_ENQUEUE"); return !e || !strcmp(e, "thread"); }();
+#endif
+  std::atomic<int> lane_rc{AM355_OK};
+  struct LaneJoin {   // (whatever way this function is left, the helper is not enqueueing into the context any more)
+    AsyncLane* l = nullptr;
+    ~LaneJoin() { if (l) l->wait(); }
+  } lane_join;
+  bool b_enqueued = false;
+  if (hash_after_parse && enqueue_early) { int rb = enqueue_stream_b(); if (rb) return rb; b_enqueued = true; }
+  else if (hash_after_parse && enqueue_thread && n >= 512) {
+    if (!c->lane) c->lane.reset(new AsyncLane);
+    c->lane->post([&]() { (void)hipSetDevice(c->device); lane_rc.store(enqueue_stream_b()); });
+    lane_join.l = c->lane.get();
+    b_enqueued = true;
+  }
   exclusive_scan_u32(c->d_entries.as<uint32_t>(), c->d_amap_base.as<uint32_t>(), n, d_wa + W_TOTAL_ENTRIES, c->d_scan1.p, sa);
   // (AM355_SPEC_DECODE=0: the decode kernels wait for the host to read the totals, as in rounds 2-4)
   static const bool spec_env = []() { const char* e = getenv("AM355_SPEC_DECODE"); return !(e && *e == '0'); }();
@@ -1079,16 +1103,18 @@ int replay_impl(am355_ctx* c) {
     }
     launch_actor_intern(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), n, c->d_amap_base.as<uint32_t>(), c->d_amap_prov.as<uint32_t>(), c->amap_cap,
                         c->d_slots.as<unsigned long long>(), c->slot_mask, c->d_first_idx.as<uint32_t>(), d_wa + W_FLAGS_A, d_wa + W_FAST_A,
-                        d_distinct, c->d_rank_ids.p, d_briefs, c->d_slot_rank.as<uint32_t>(), c->d_plan_sums.as<unsigned long long>(), d_wa + 8, sa);
+                        d_distinct, c->d_rank_ids.p, d_briefs, c->d_slot_rank.as<uint32_t>(), c->d_plan_sums.as<unsigned long long>(), d_wa + 8, sa, c->hp_briefs);
     // device half of the in-order plan (actor ranks, per-change bases, decoder classes): the decode kernels start from it
     // (its totals, and the stage-1 words the host decides on, reach the host through HostSignals: no copy, no blocking wait)
     c->sig_seq++;
     launch_plan(d_briefs, n, d_distinct, c->d_slot_rank.as<uint32_t>(), c->slot_mask, c->d_plan_sums.as<unsigned long long>(), c->d_plans.as<ChangePlan>(),
-                c->d_plans.as<ChangePlan>() + n1, d_wa, d_wa + 8, sig, c->sig_seq, sa, spec_possible ? c->d_plan_totals.as<PlanTotals>() : nullptr);
-    // the host's own half of the plan needs a 32-byte digest per change and the handful of distinct actor ids: they follow
-    // -- on stream4, behind the plan kernel: in stream A the copy (and its dispatch gap) would sit in front of the decode kernels
-    HIPCHK(c, hipEventRecord(c->ev_plan, sa));
-    HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_plan, 0));
+                c->d_plans.as<ChangePlan>() + n1, d_wa, d_wa + 8, sig, c->sig_seq, sa, spec_possible ? c->d_plan_totals.as<PlanTotals>() : nullptr,
+                c->h_s1.as<uint32_t>());
+    // the host's own half of the plan needs a 32-byte digest per change and the handful of distinct actor ids: k_actor_check and
+    // k_plan_apply write them into the host's pinned mirror themselves (rounds 2-4: an event record in this stream, a copy on
+    // stream4 and a blocking wait for it -- the wait was the longest item between the plan and k_resolve)
+    const bool want_large_spec = spec_possible && attempt == 0 && c->hint_large != 0;
+    if (want_large_spec) HIPCHK(c, hipEventRecord(c->ev_plan, sa));  // (the large class decodes on stream3, ordered behind the plan kernel)
     if (spec_possible && attempt == 0) {
       // the decode kernels of the wave classes right behind the plan kernel, before the host knows the totals (decode_gate_open,
       // am355_internal.h): rows carved for a capacity -- the context's previous in-order replay, or one row per four encoded bytes
@@ -1100,18 +1126,17 @@ int replay_impl(am355_ctx* c) {
       if (merge_counts_bytes(c->spec_cap_ops) <= cb && carve_cols(c, c->spec_cap_ops, c->spec_cap_preds) == AM355_OK) {
         canary_arm();
         if (c->phase_events) { HIPCHK(c, hipEventRecord(c->ev[1], sa)); HIPCHK(c, hipEventRecord(c->ev[2], sa)); }
-        HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_plan, 0));
+        if (want_large_spec) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_plan, 0));
         launch_decode_speculative(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n, c->d_plan_totals.as<PlanTotals>(), c->spec_cap_ops,
                                   c->spec_cap_preds, distinct_capacity(), c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
-                                  &c->d_counts.as<Counts>()->flags, sa, c->stream3, c->shard_rank, c->shard_world);
+                                  &c->d_counts.as<Counts>()->flags, sa, want_large_spec ? c->stream3 : nullptr, c->shard_rank, c->shard_world);
+        c->spec_large_launched = want_large_spec;
         if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], sa));
         c->spec_launched = true;
       }
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_s1.p, c->d_s1.p, s1_briefs + sizeof(ChangeBrief) * n, hipMemcpyDeviceToHost, c->stream4));
-    HIPCHK(c, hipEventRecord(c->ev_s1, c->stream4));
     if ((c->phase_events && !c->spec_launched) || !hash_after_parse) HIPCHK(c, hipEventRecord(c->ev[1], sa));
-    if (attempt == 0 && !(hash_after_parse && enqueue_early)) { int rb = enqueue_stream_b(); if (rb) return rb; }
+    if (attempt == 0 && !b_enqueued) { int rb = enqueue_stream_b(); if (rb) return rb; b_enqueued = true; }
     lap("stage 1 enqueued");
     if (!wait_host_signal(&sig->plan_seq, c->sig_seq, sa)) {
       (void)hipStreamSynchronize(sb);
@@ -1153,7 +1178,6 @@ int replay_impl(am355_ctx* c) {
     opt_flags = c->flags;
     opt_err = c->err;
   } else {
-    HIPCHK(c, hipEventSynchronize(c->ev_s1));  // the digests
     if (tot.fallback) {  // (k_plan stopped before it looked at the changes: their flags come from the digests)
       const ChangeBrief* br = c->hp_briefs;
       uint32_t dev_flags = 0;
@@ -1175,6 +1199,7 @@ int replay_impl(am355_ctx* c) {
     }
   }
   // ---- join stream B ----
+  if (lane_join.l) { lane_join.l->wait(); lane_join.l = nullptr; if (lane_rc.load()) return lane_rc.load(); }
   HIPCHK(c, hipEventSynchronize(c->ev_b1));
   lap("hash stream joined");
   if (h_words[W_FLAGS_B]) return error_for_flags(c, h_words[W_FLAGS_B], "checksum does not match data");
@@ -1277,7 +1302,6 @@ int replay_impl(am355_ctx* c) {
       }
       HIPCHK(c, hipStreamSynchronize(sa));
       if (dev_actors) c->h_amap_base.as<uint32_t>()[n] = tot.total_entries;
-      HIPCHK(c, hipEventSynchronize(c->ev_s1));  // (the distinct-actor list rides with the digests)
       auto t0 = std::chrono::steady_clock::now();
       rc = schedule(c, dev_actors ? c->h_amap.as<uint32_t>() : nullptr, dev_actors ? c->h_amap_base.as<uint32_t>() : nullptr);
       ms_host += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -119,6 +119,80 @@ def reference_js_baseline(name, scale_full, seed):
                       f"the unmodified reference's Backend.loadChanges + getPatch under node {ver}, 1 core of {os.cpu_count()} ({time.perf_counter() - t_all:.1f} s of CPU work)"}
 
 
+def live_kernel_table(timeout_s=170):
+    """Per-kernel table measured IN THIS RUN: a traced child of this very script -- `rocprofv3 --kernel-trace --stats`
+    for the durations, then one pass each with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` for the HBM bytes (counters in passes of their
+    own, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) -- summarised by tools/kernel_table.py. None when rocprofv3 is not on PATH
+    or the kernel-trace pass fails; the byte columns are simply absent when a counter pass fails. The committed table of the round is
+    the fallback and the line says which one it carries."""
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None or os.environ.get("AM355_BENCH_CHILD"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="am355_live_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", AM355_BENCH_CHILD="1")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--prewarm", "0.3", "--no-sublines", "--no-cpu-baseline"]
+    t0 = time.perf_counter()
+    try:
+        def find(sub, suffix):
+            for d, _, fs in os.walk(os.path.join(tmp, sub)):
+                for f in fs:
+                    if f.endswith(suffix):
+                        return os.path.join(d, f)
+            return None
+        with open(os.path.join(tmp, "line.json"), "w") as line:
+            r = subprocess.run([prof, "--kernel-trace", "--stats", "-d", os.path.join(tmp, "kt"), "-o", "run", "--"] + child, env=env, cwd="/tmp",
+                               stdout=line, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        db = find("kt", "_results.db")
+        if r.returncode != 0 or db is None:
+            return None
+        csvs = {}
+        for tag, counter in (("pf", "FETCH_SIZE"), ("pw", "WRITE_SIZE")):
+            try:
+                subprocess.run([prof, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, tag), "-o", tag, "--output-format", "csv", "--"] + child, env=env,
+                               cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+                csvs[tag] = find(tag, "counter_collection.csv")
+            except Exception:
+                csvs[tag] = None
+        with open(os.path.join(tmp, "line.json")) as f:   # (the child's own bench line is the last line of its stdout)
+            last = [l for l in f.read().splitlines() if l.startswith("{")][-1]
+        with open(os.path.join(tmp, "line1.json"), "w") as f:
+            f.write(last)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "kernel_table.py"), "--db", db, "--line", os.path.join(tmp, "line1.json"), "--replays", "13",
+               "--out", os.path.join(tmp, "table.json"), "--source",
+               "measured in this run: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-sublines --no-cpu-baseline"]
+        if csvs.get("pf") and csvs.get("pw"):
+            cmd += ["--fetch", csvs["pf"], "--write", csvs["pw"]]
+        if subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120).returncode != 0:
+            return None
+        with open(os.path.join(tmp, "table.json")) as f:
+            t = json.load(f)
+        t["seconds"] = round(time.perf_counter() - t0, 1)
+        t["t_device_ms_under_trace"] = json.loads(last).get("t_device_ms")
+        return t
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def reference_js_recorded(name):
+    """The reference JS backend's rate on this workload as recorded in the build container (tools/record_reference_js.py ->
+    profiles/r05_reference_js_baseline.json): the reference tree cannot travel to the GPU box, its dated measurement can."""
+    path = os.path.join(ROOT, "profiles", "r05_reference_js_baseline.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        w = rec["workloads"][name]
+    except Exception:
+        return None
+    return {"value": w["ops_per_s"], "unit": "ops/s", "cores": w["cores"], "kind": "reference", "sample": w["sample"], "recorded": rec["date"], "host": rec["host"],
+            "node": rec["node"], "file": "profiles/r05_reference_js_baseline.json",
+            "note": "NOT measured in this run: recorded with bench.reference_js_baseline in the build container, where node and the reference tree exist"}
+
+
 def js_end_to_end(log):
     """T_e2e: node -> N-API addon -> GPU -> record tables -> js/materialize.js = the patch OBJECT the frontend consumes,
     through automerge_classic_amd/js/bench_e2e.js on the same log. None when node or the addon is missing."""
@@ -285,16 +359,24 @@ def run_workload(w, steps, warmup, sync, want_rows=True):
     return {"t_replay_s": t_replay, "t_device_s": t_device, "stats": st, "phases": phases, "n_preds": n_preds}
 
 
-def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False, deflate=False):
+def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False, deflate=False, cpu_budget_s=0.0):
     w = Workload(eng, name, scale, seed, shuffled=shuffled, deflate=deflate)
     r = run_workload(w, steps, warmup, sync, want_rows=False)
     st = r["stats"]
     A = algorithmic_bytes(st)
     whole = st.n_ops * A["A"] / (r["t_device_s"] / steps) / 1e9
-    return {"workload": w.describe(st), "ops_per_s": st.n_ops * steps / r["t_replay_s"], "ms_per_step": r["t_replay_s"] / steps * 1e3,
-            "t_device_ops_per_s": st.n_ops * steps / r["t_device_s"], "t_device_ms": r["t_device_s"] / steps * 1e3, "fast_path": int(st.fast_path),
-            "phases_ms": r["phases"], "algorithmic_bytes_per_op": A,
-            "roofline_whole_path": {"achieved": whole, "unit": "GB/s", "frac": whole / 8000.0}}
+    whole_r40 = st.n_ops * (A["A"] - A["R_op_record"] + 40.0) / (r["t_device_s"] / steps) / 1e9   # (R = 40)
+    out = {"workload": w.describe(st), "ops_per_s": st.n_ops * steps / r["t_replay_s"], "ms_per_step": r["t_replay_s"] / steps * 1e3,
+           "t_device_ops_per_s": st.n_ops * steps / r["t_device_s"], "t_device_ms": r["t_device_s"] / steps * 1e3, "fast_path": int(st.fast_path),
+           "phases_ms": r["phases"], "algorithmic_bytes_per_op": A,
+           "roofline_whole_path": {"achieved": whole_r40, "unit": "GB/s", "frac": whole_r40 / 8000.0, "R53_rows_as_written": {"achieved": whole, "frac": whole / 8000.0}}}
+    if w.is_doc and cpu_budget_s:
+        # (Backend.load has a CPU leg of its own: the C port on this box on the same document, and the reference's recorded rate)
+        out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops), budget_s=cpu_budget_s)
+        rec = reference_js_recorded(name)
+        if rec is not None:
+            out["cpu_baseline"]["reference_js_recorded"] = rec
+    return out
 
 
 def apply_changes_section(eng, log, sync, reps=7):
@@ -401,6 +483,7 @@ def main():
     ap.add_argument("--prewarm", type=float, default=2.0, help="seconds of untimed steps before the warm-up steps (clocks, PCIe link, host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sublines", action="store_true")
+    ap.add_argument("--no-live-trace", action="store_true", help="do not run the rocprofv3-traced child that fills roofline.kernels (the committed table is embedded instead)")
     ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the objectId-sharded measurement that follows the replica measurement")
     args = ap.parse_args()
 
@@ -461,18 +544,27 @@ def main():
     n_preds = int(eng.rows()["pred_num"].sum())
     A = algorithmic_bytes(st)
     whole = st.n_ops * A["A"] / (t_device_ms * 1e-3) / 1e9  # (N_ops x A / T_device), GB/s
-    # SURVEY.md §8d prices the op record at R = 40 B (10 x u32); the rows this engine writes are 53 B (13 SoA fields + the insert flag):
-    # `achieved` / `frac` use the 53 B actually written, the survey's figure rides along
+    # SURVEY.md §8d prices the op record at R = 40 B (10 x u32); the rows this engine writes are 53 B (13 SoA fields + the insert flag)
     whole_r40 = st.n_ops * (A["A"] - A["R_op_record"] + 40.0) / (t_device_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": whole, "peak": 8000.0, "unit": "GB/s", "frac": whole / 8000.0, "traffic": None,
+    # (`achieved` / `frac`: SURVEY.md §8d's definition, R = 40 B; the 53 B this engine's rows take are in record_bytes beside it)
+    roofline = {"bound": "hbm", "achieved": whole_r40, "peak": 8000.0, "unit": "GB/s", "frac": whole_r40 / 8000.0, "traffic": None,
                 "record_bytes": {"R53_rows_as_written": {"achieved": whole, "frac": whole / 8000.0},
                                  "R40_survey_figure": {"achieved": whole_r40, "frac": whole_r40 / 8000.0}},
-                "kernel": "whole path (SURVEY.md §8d): N_ops x (E + R + P) / T_device", "algorithmic_bytes_per_launch": st.n_ops * A["A"],
+                "kernel": "whole path (SURVEY.md §8d): N_ops x (E + R + P) / T_device, R = 40", "algorithmic_bytes_per_launch": st.n_ops * (A["A"] - A["R_op_record"] + 40.0),
                 "launch_ms": t_device_ms, "n_preds": n_preds, "phases": phase_table(phases, st, n_preds)}
     import glob
     tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_table.json")))  # (the latest round's summary)
     table = tables[-1] if tables else os.path.join(ROOT, "profiles", "r02_kernel_table.json")
-    if os.path.exists(table) and args.workload == "c4_text_single" and args.scale == 1.0:
+    live = live_kernel_table() if (args.workload == "c4_text_single" and args.scale == 1.0 and world == 1 and not args.no_live_trace) else None
+    if live is not None:
+        roofline["kernels"] = live.get("kernels")
+        roofline["traffic"] = live.get("traffic_bytes_per_replay") or None
+        roofline["kernels_source"] = live.get("source")
+        roofline["kernels_live"] = True
+        roofline["kernels_trace_seconds"] = live.get("seconds")
+        roofline["t_device_ms_under_trace"] = live.get("t_device_ms_under_trace")
+    elif os.path.exists(table) and args.workload == "c4_text_single" and args.scale == 1.0:
+        roofline["kernels_live"] = False
         # rocprofv3 kernel-trace + PMC passes of this same command (committed summary; counters cannot be read in-process):
         # per kernel: calls per replay, average us, algorithmic bytes, PMC HBM bytes, fraction of the 8 TB/s peak
         with open(table) as f:
@@ -503,6 +595,9 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
         if w.is_doc:
             out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops))
+            rec = reference_js_recorded(args.workload)
+            if rec is not None:
+                out["cpu_baseline"]["reference_js_recorded"] = rec
         else:
             port = cpu_baseline(w.log)
             ref_js = reference_js_baseline(args.workload, args.scale, BASE_SEED[args.workload])
@@ -512,6 +607,9 @@ def main():
                 out["cpu_baseline"] = ref_js
             else:
                 port["leg"] = "C port of the reference's algorithm (oracle/): node or the reference tree is not on this box"
+                rec = reference_js_recorded(args.workload)
+                if rec is not None:
+                    port["reference_js_recorded"] = rec
                 out["cpu_baseline"] = port
     if world == 1 and not w.is_doc and not args.no_sublines:
         e2e = js_end_to_end(w.log)
@@ -531,7 +629,7 @@ def main():
         # a larger batch of the headline shape (4 x: 4.1 M ops, 54 MB of changes): the same kernels with more work per launch
         subs.append(subline(eng, "c4_text_single", 4.0, BASE_SEED["c4_text_single"], 8, 2, barrier))
         if args.workload != "c5_doc_mixed":
-            subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 3, 1, barrier))
+            subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 5, 2, barrier, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0))
         out["workloads"] = subs
         if save_info is not None:
             # the history of the saved headline document after Backend.load (binary changes + hashes rebuilt:

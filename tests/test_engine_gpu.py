@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import golden_util
+import mutation_util
 import oracle_lib
 from automerge_classic_amd import engine, loggen
 
