@@ -1614,6 +1614,142 @@ __device__ __forceinline__ bool wv_tok_sint(const WL& L, uint32_t t, int64_t& ou
   return (w >> 59) & 1;
 }
 
+#ifndef AM355_WV_SERIAL_TOKENS
+#define AM355_WV_SERIAL_TOKENS 40   // (built with 2 once per change to this file: every column of every fixture and mutation campaign through the wavefront walk)
+#endif
+constexpr uint32_t WV_SERIAL_TOKENS = AM355_WV_SERIAL_TOKENS;
+__device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t x, uint32_t lane);
+
+// what token t says when read as a record header: kind, rows, the header after it (T = none), the first error the serial walk would
+// find AT this record given the kind of the record in front (0 = no error)
+template <class WL>
+__device__ __forceinline__ void wv_header(const WL& L, uint32_t t, uint32_t T, uint32_t& kind, uint64_t& count, uint32_t& next, uint32_t& err_self, uint32_t& err_after_same) {
+  kind = 0; count = 0; next = T; err_self = 0; err_after_same = 0;
+  int64_t cnt;
+  if (!wv_tok_sint(L, t, cnt)) { err_self = F_BAD_LEB; return; }
+  if (cnt > 1) {
+    kind = RK_REP; count = (uint64_t)cnt;
+    if (t + 1 >= T) { err_self = F_BAD_LEB; return; }
+    next = t + 2;
+  } else if (cnt == 1) {
+    err_self = F_BAD_RLE;  // repetition count of 1
+  } else if (cnt < 0) {
+    kind = RK_LIT; count = (uint64_t)(-cnt);
+    err_after_same = F_BAD_RLE;  // successive literals (checked before the length of the literal)
+    if (count > (uint64_t)(T - t - 1)) { err_self = F_BAD_LEB; return; }
+    next = t + 1 + (uint32_t)count;
+  } else {
+    kind = RK_NUL;
+    err_after_same = F_BAD_RLE;  // successive null runs (checked before the run's own length)
+    uint64_t z;
+    if (t + 1 >= T || !wv_tok_uint(L, t + 1, z)) { err_self = F_BAD_LEB; return; }
+    if (z == 0) { err_self = F_BAD_RLE; return; }
+    count = z;
+    next = t + 2;
+  }
+  if (next > T) next = T;
+}
+
+// The record tables of the column whose T tokens are in L.tok, by the whole wavefront (see wv_load_column). Scratch: L.bytes (the
+// column's bytes are not needed once tokenised) holds one mark per token, L.aux (the key column's, unused here) the jump table.
+template <class WL>
+__device__ __forceinline__ void wv_records_parallel(WL& L, uint32_t T, uint32_t lane) {
+  uint16_t* jump = (uint16_t*)L.aux;   // [COLMAX] 16-bit entries in (COLMAX / 2 + 1) words
+  uint8_t* mark = L.bytes;
+  for (uint32_t t = lane; t < T; t += WAVE) {
+    uint32_t kind, nx, e1, e2; uint64_t cnt;
+    wv_header(L, t, T, kind, cnt, nx, e1, e2);
+    jump[t] = (uint16_t)(e1 ? T : nx);   // (a header in error ends the chain: the walk stops there)
+    mark[t] = t == 0 ? 1 : 0;
+  }
+  __syncthreads();
+  // orbit of token 0: after round k every one of the first 2^k headers is marked
+  for (uint32_t hop = 1; hop < T; hop <<= 1) {
+    uint16_t nj[WL::COLMAX / WAVE];   // (fixed trip count: the new jumps stay in registers)
+#pragma unroll
+    for (uint32_t k = 0; k < WL::COLMAX / WAVE; k++) {
+      const uint32_t t = lane + k * WAVE;
+      nj[k] = (uint16_t)T;
+      if (t < T) {
+        const uint32_t j = jump[t];
+        if (mark[t] && j < T) mark[j] = 1;
+        if (j < T) nj[k] = jump[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < WL::COLMAX / WAVE; k++) {
+      const uint32_t t = lane + k * WAVE;
+      if (t < T) jump[t] = nj[k];
+    }
+    __syncthreads();
+    if (jump[0] >= T) {   // the chain from token 0 has reached the end: one more marking pass with the final jumps is still due
+      for (uint32_t t = lane; t < T; t += WAVE) { const uint32_t j = jump[t]; if (mark[t] && j < T) mark[j] = 1; }
+      __syncthreads();
+      break;
+    }
+  }
+  // records in order: rank of every marked token, its kind / first value token / rows; first error in chain order
+  uint32_t base = 0, first_bad = NONE32, first_err = 0;
+  for (uint32_t chunk = 0; chunk < T; chunk += WAVE) {
+    const uint32_t t = chunk + lane;
+    const bool m = t < T && mark[t];
+    const unsigned long long mm = __ballot(m);
+    if (m) {
+      const uint32_t r = base + (uint32_t)__popcll(mm & ((1ull << lane) - 1));
+      uint32_t kind, nx, e1, e2; uint64_t cnt;
+      wv_header(L, t, T, kind, cnt, nx, e1, e2);
+      if (r < WL::RUNMAX) {
+        L.run_kind[r] = (uint8_t)kind;
+        L.run_tok[r] = t + 1;
+        L.run_start[r] = cnt > 0xfffffff0ull ? 0xfffffff1u : (uint32_t)cnt;   // rows of the record for now: scanned below
+      }
+    }
+    base += (uint32_t)__popcll(mm);
+  }
+  const uint32_t R = base < WL::RUNMAX ? base : WL::RUNMAX;
+  __syncthreads();
+  // errors: a record's own, or "same kind as the record in front" for literals and null runs -- the earliest record decides
+  for (uint32_t r = lane; r < R; r += WAVE) {
+    const uint32_t t = L.run_tok[r] - 1;
+    uint32_t kind, nx, e1, e2; uint64_t cnt;
+    wv_header(L, t, T, kind, cnt, nx, e1, e2);
+    uint32_t e = 0;
+    if (!kind && e1) e = e1;                                              // not a count at all / repetition count of 1
+    else if (e2 && r > 0 && L.run_kind[r - 1] == kind) e = e2;            // successive literals / null runs
+    else e = e1;
+    if (e && r < first_bad) { first_bad = r; first_err = e; }
+  }
+  for (int d = WAVE / 2; d; d >>= 1) {
+    const uint32_t ob = __shfl_xor(first_bad, d), oe = __shfl_xor(first_err, d);
+    if (ob < first_bad) { first_bad = ob; first_err = oe; }
+  }
+  // rows before every record: exclusive scan of the record lengths (the serial walk stops at the record in error: so does the scan)
+  const uint32_t R_ok = first_bad < R ? first_bad : R;
+  uint64_t carry = 0;
+  uint32_t overflow = 0;
+  for (uint32_t chunk = 0; chunk < R_ok; chunk += WAVE) {
+    const uint32_t r = chunk + lane;
+    const uint64_t c = r < R_ok ? (uint64_t)L.run_start[r] : 0;
+    const uint64_t incl = carry + (uint64_t)wave_incl_scan_i64((int64_t)c, lane);
+    if (r < R_ok) {
+      if (incl > 0xfffffff0ull) overflow = 1;
+      L.run_start[r] = (uint32_t)(incl - c);
+    }
+    carry = (uint64_t)__shfl((long long)incl, WAVE - 1);
+  }
+  const bool any_overflow = __ballot(overflow) != 0;
+  __syncthreads();
+  if (lane == 0) {
+    L.run_start[R_ok] = (uint32_t)carry;
+    L.n_runs = R_ok;
+    L.n_tokens = T;
+    L.total_rows = (uint32_t)carry;
+    L.err = first_bad < R ? first_err : any_overflow ? (uint32_t)F_OVERFLOW : 0u;
+  }
+  __syncthreads();
+}
+
 // Stage + tokenise + record-walk one RLE column (uint or int values). All lanes must call it.
 template <class WL, class P>
 __device__ __forceinline__ void wv_load_column(WL& L, P col, uint32_t len, uint32_t lane) {
@@ -1641,6 +1777,16 @@ __device__ __forceinline__ void wv_load_column(WL& L, P col, uint32_t len, uint3
     tok_base += (uint32_t)__popcll(mask);
   }
   __syncthreads();
+  // Record walk. A record header names the next one (count > 1: two tokens on; count < 0: behind its -count values; count 0: two
+  // on), so the headers are the orbit of token 0 under that map. Lane 0 walking it costs two or three dependent LDS reads per RECORD:
+  // for the columns of a fat map change -- three hundred short records each, twelve columns -- that walk was nearly all of the 0.23 ms
+  // such a change took. Columns of more than WV_SERIAL_TOKENS numbers are walked by the whole wavefront instead: every token computes
+  // where it would point as a header, the orbit of token 0 is marked by pointer doubling (log2 rounds over the tokens, jumps read
+  // before any is written), marked tokens are ranked by ballots and write their record. Same tables, same first error.
+  if (tok_base > WV_SERIAL_TOKENS && carry_start == len) {
+    wv_records_parallel(L, tok_base, lane);
+    return;
+  }
   if (lane == 0) {
     uint32_t e = carry_start != len ? (uint32_t)F_BAD_LEB : 0;  // buffer ended with incomplete number
     uint32_t t = 0, nr = 0, prev = 0;
@@ -2229,6 +2375,8 @@ void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const 
   AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3(1, T_NUM_DOC), dim3(WAVE), st, arena, meta, plan, 1u, x, cols, flags, 0);
 }
 
+static uint32_t decode_group_split(uint32_t n_waves, uint32_t shard_world) { return (shard_world <= 1 && n_waves <= 512) ? 4u : 1u; }
+
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_small, uint32_t n_large, uint32_t n_serial,
                            const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux, uint32_t shard_rank,
                            uint32_t shard_world) {
@@ -2240,8 +2388,8 @@ void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const 
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   if (n_large && n_small + n_large <= 1024) { n_large += n_small; n_small = 0; }
   hipStream_t s2 = (n_small && aux) ? aux : st;
-  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, shard_world > 1 ? 1 : 4), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags, DecodeGate{});
+  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small, decode_group_split(n_small, shard_world)), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, decode_group_split(n_large, shard_world)), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans + n_small + n_large, n_serial,
                              x, cols, flags, 0);
@@ -2253,12 +2401,15 @@ void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const 
                            hipStream_t st, hipStream_t aux, uint32_t shard_rank, uint32_t shard_world) {
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   hipStream_t s2 = (n_small && aux) ? aux : st;
-  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, shard_world > 1 ? 1 : 4), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags, DecodeGate{});
+  if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small, decode_group_split(n_small, shard_world)), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, decode_group_split(n_large, shard_world)), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans_serial, n_serial, x, cols, flags, 0);
 }
 
+// Four wavefronts per change (one per column group, k_decode_wave) when the launch would otherwise leave SIMDs idle: up to 512
+// changes -- 2048 wavefronts on 1024 SIMDs. A batch of thousands of changes fills the device with one wavefront per change, and four
+// would only stage every change four times. (Sharded replays keep one: the early exit for foreign changes needs the object columns.)
 // The two wavefront-per-change decoder classes enqueued BEFORE the totals are known (behind k_plan_apply, which leaves them in
 // `totals`): one wavefront per change each, the small class on `st`, the large class on `aux`; rows go to `cols`, carved for
 // cap_ops / cap_preds. Both launches do nothing unless decode_gate_open() holds, which the host evaluates on the same totals.
@@ -2267,12 +2418,12 @@ void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, co
                                hipStream_t aux, uint32_t shard_rank, uint32_t shard_world) {
   if (!n_changes) return;
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
-  hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_changes), dim3(WAVE), 0, st, arena, metas, plans, 0u, x, cols, flags,
+  hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_changes, decode_group_split(n_changes, shard_world)), dim3(WAVE), 0, st, arena, metas, plans, 0u, x, cols, flags,
                      DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 0u});
   // (aux == null: the caller expects no change of the large class -- none in the context's previous batch -- and launches that class
   // itself should there be one after all)
   if (aux)
-    hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes, shard_world <= 1 ? 4 : 1), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
+    hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes, decode_group_split(n_changes, shard_world)), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
                        DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 1u});
 }
 

@@ -462,15 +462,58 @@ def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier, 
         for _ in range(warmup):
             one()
         t_single = timed(one, steps, sync)
+    model = None
+    if rank == 0 and not is_doc:
+        # the critical-path model (sharding_model) from rank 0's own single-GPU phases, next to the measured figure
+        eng.set_shard(0, 1)
+        sub = subline(eng, name, scale, BASE_SEED[name], max(3, steps // 2), 2, sync)
+        m = sharding_model(sub, n_list=(1, world))
+        model = {"projected_speedup": m["projected"][-1]["projected_speedup"], "projected_ms_per_step": m["projected"][-1]["ms_per_step"],
+                 "measured_on_one_gpu_ms": m["measured_on_one_gpu_ms"], "assumptions": m["assumptions"]}
     barrier()
     if rank != 0:
         return None
-    return {"workload": what + f", ONE document over {world} GPUs (objectId sharding: owner = (object counter + actor rank) mod N, _root on rank 0; "
+    return {"model": model, "workload": what + f", ONE document over {world} GPUs (objectId sharding: owner = (object counter + actor rank) mod N, _root on rank 0; "
                         "all_gather of the patch-IR fragments over RCCL, stitch on rank 0)",
             "scaling": "strong", "n_gpus": world, "steps": steps, "ops_per_s": n_ops * steps / dt, "ms_per_step": dt / steps * 1e3,
             "single_gpu_ops_per_s": n_ops * steps / t_single, "single_gpu_ms_per_step": t_single / steps * 1e3,
             "speedup_vs_single_gpu": t_single / dt, "fragment_bytes": info.get("fragment_bytes"),
             "parity": "stitched patch == unsharded patch (sha256 of the patch text)" if same else "MISMATCH"}
+
+
+def sharding_model(sub, n_list=(1, 2, 4, 8)):
+    """Critical-path model of the objectId-sharded replay of ONE change log over N GPUs, from the phases
+    measured in THIS run on one GPU -- printed so that the first real multi-GPU run has something to be checked against (no 8-GPU node
+    has been available to the driver so far). What the design replicates on every rank and what it divides:
+      replicated  host staging + H2D of the whole batch (every rank has its own PCIe link), stage 1 (parse, actor tables, plan), the hash
+                  stream (overlapped), the object columns of foreign changes in the decoder, the IR of the whole document to rank 0's host;
+      divided     the full decode of the changes that touch the rank's objects, every merge / order / patch kernel (rows of own objects);
+      added       one all_gather of the patch-IR fragments over xGMI (ring: (N-1)/N of the IR per link at ~153 GB/s, + ~40 us launch).
+    A kernel does not get shorter than a launch of ~5 us: the ~20 kernels of the merge / order phases bound that part from below."""
+    ph = sub["phases_ms"]
+    t_dev, t_replay = sub["t_device_ms"], sub["ms_per_step"]
+    host_side = max(t_replay - t_dev, 0.0)          # staging + IR to host (what of them the replay does not hide)
+    parse, decode, merge_order, hash_stream = ph["ms_parse"], ph["ms_decode"], ph["ms_merge"] + ph["ms_order"], ph["ms_hash_stream"]
+    gaps = max(t_dev - parse - decode - merge_order, 0.0)
+    f_obj = 0.35                                     # decoder time up to the object columns (5 of 12 columns: action, ids, insert, object)
+    floor = 20 * 0.005                               # 20 launches of >= 5 us
+    ir_bytes = sub["algorithmic_bytes_per_op"]["P_patch_ir"] * sub["t_device_ops_per_s"] * t_dev * 1e-3
+    rows = []
+    for n in n_list:
+        dec = decode * (1.0 / n + f_obj * (1.0 - 1.0 / n))
+        mo = max(merge_order / n, min(floor, merge_order))
+        main_chain = parse + dec + mo + gaps
+        gather = 0.0 if n == 1 else 0.04 + ir_bytes * (n - 1) / n / 153e9 * 1e3
+        t = host_side + max(main_chain, hash_stream) + gather
+        rows.append({"n_gpus": n, "ms_per_step": t, "device_chain_ms": main_chain, "all_gather_ms": gather})
+    t1 = rows[0]["ms_per_step"]
+    for r in rows:
+        r["projected_speedup"] = t1 / r["ms_per_step"]
+    return {"workload": sub["workload"], "measured_on_one_gpu_ms": {"t_replay": t_replay, "t_device": t_dev, "parse": parse, "decode": decode, "merge_order": merge_order,
+                                                                   "hash_stream": hash_stream, "host_side": host_side},
+            "assumptions": {"decoder_fraction_for_foreign_changes": f_obj, "launch_floor_ms": floor, "xgmi_link_GB_per_s": 153, "all_gather_launch_ms": 0.04},
+            "projected": rows,
+            "note": "strong scaling of ONE document; the deployment shape (one document per GPU, `value` at N > 1) scales with N by construction"}
 
 
 def main():
@@ -631,6 +674,9 @@ def main():
         if args.workload != "c5_doc_mixed":
             subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 5, 2, barrier, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0))
         out["workloads"] = subs
+        multi = next((x for x in subs if x["workload"].startswith("c4_text_multi")), None)
+        if multi is not None:
+            out["sharding_model"] = sharding_model(multi)
         if save_info is not None:
             # the history of the saved headline document after Backend.load (binary changes + hashes rebuilt:
             # op columns decoded on the GPU, regroup / re-encode / hash chain on the host threads); not part of `value`
