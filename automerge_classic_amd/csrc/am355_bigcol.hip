@@ -229,9 +229,20 @@ __global__ __launch_bounds__(BLOCK) void kb_tile_recs(BigColWork w, BigColVals v
   v.tile_rec[(size_t)c * v.tile_stride + tile] = lo;
 }
 
-// one lane per row of one column. Delta columns: out = the delta (0 for null) and null_out = 1 for null.
-__global__ __launch_bounds__(BLOCK) void kb_expand(BigColWork w, uint32_t kind, uint32_t r0, uint32_t r1, uint32_t n_rows, uint32_t* __restrict__ out,
-                                                   uint8_t* __restrict__ null_out, const uint32_t* __restrict__ tile_rec) {
+// one lane per row of one column (blockIdx.y = the column: the twelve columns of a document in ONE launch -- they were twelve, each
+// with its own ramp and tail). Delta columns: out = the delta (0 for null) and null_out = 1 for null.
+struct ExpandCols {
+  uint32_t kind[BIG_NCOL], r0[BIG_NCOL], r1[BIG_NCOL], n[BIG_NCOL];
+  uint32_t* out[BIG_NCOL];
+  const uint32_t* tile_rec[BIG_NCOL];
+  uint8_t* key_ctr_null;
+};
+__global__ __launch_bounds__(BLOCK) void kb_expand(BigColWork w, ExpandCols cols) {
+  const uint32_t c = blockIdx.y;
+  const uint32_t kind = cols.kind[c], r0 = cols.r0[c], r1 = cols.r1[c], n_rows = cols.n[c];
+  uint32_t* __restrict__ out = cols.out[c];
+  uint8_t* __restrict__ null_out = c == BC_KEY_CTR ? cols.key_ctr_null : nullptr;
+  const uint32_t* __restrict__ tile_rec = cols.tile_rec[c];
   uint32_t row = gtid();
   if (row >= n_rows) return;
   uint32_t base = w.rec_start[r0];
@@ -318,11 +329,18 @@ void bigcol_expand(const BigColDesc& d, const BigColWork& w, const BigColInfo& h
     const uint32_t big = n_rows > n_succ_cap ? n_rows : n_succ_cap;
     AM355_LAUNCH_INDEPENDENT(kb_tile_recs, dim3((big / EXPAND_TILE + 2 + BLOCK - 1) / BLOCK, BIG_NCOL), dim3(BLOCK), st, w, v, n_rows, n_succ_cap);
   }
-  for (int c = 0; c < BIG_NCOL; c++) {
-    uint32_t n = c >= BC_SUCC_ACTOR ? n_succ_cap : n_rows;
-    if (!n) continue;
-    AM355_LAUNCH_INDEPENDENT(kb_expand, grid_for(n), dim3(BLOCK), st, w, d.kind[c], h.r0[c], h.r1[c], n, v.v[c], c == BC_KEY_CTR ? v.key_ctr_null : (uint8_t*)nullptr,
-                             (const uint32_t*)(v.tile_rec + (size_t)c * v.tile_stride));
+  {
+    ExpandCols ec{};
+    uint32_t n_max = 0;
+    for (int c = 0; c < BIG_NCOL; c++) {
+      ec.kind[c] = d.kind[c]; ec.r0[c] = h.r0[c]; ec.r1[c] = h.r1[c];
+      ec.n[c] = c >= BC_SUCC_ACTOR ? n_succ_cap : n_rows;
+      ec.out[c] = v.v[c];
+      ec.tile_rec[c] = v.tile_rec + (size_t)c * v.tile_stride;
+      n_max = ec.n[c] > n_max ? ec.n[c] : n_max;
+    }
+    ec.key_ctr_null = v.key_ctr_null;
+    if (n_max) AM355_LAUNCH_INDEPENDENT(kb_expand, dim3(grid_for(n_max).x, BIG_NCOL), dim3(BLOCK), st, w, ec);
   }
   // value offsets, succ list offsets
   AM355_LAUNCH_INDEPENDENT(kb_shift4, grid_for(n_rows + 1), dim3(BLOCK), st, (const uint32_t*)v.v[BC_VAL_LEN], n_rows, v.val_off);

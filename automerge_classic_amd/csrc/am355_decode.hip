@@ -1904,6 +1904,24 @@ uint32_t err = 0;
       while (nr < WL::RUNMAX && rows < n && !e && (lit_left > 0 || c.off < c.len)) {
         uint32_t kind, off = 0, len = 0;
         uint64_t count = 1;
+        // inside a literal, the common case -- a string shorter than 128 bytes that lies inside the column -- in a loop of its own: one
+        // dependent byte read and a dozen instructions per string (the general step below costs several times that, and a map change
+        // of three hundred literal keys spent most of its decode time in it)
+        while (lit_left > 0 && nr < WL::RUNMAX && rows < n) {
+          const uint32_t at = c.off;
+          if (at >= c.len) break;
+          const uint32_t b = c.byte_at(at);
+          if (b >= 0x80 || b > c.len - at - 1) break;
+          L.run_start[nr] = (uint32_t)(rows - rows_done);
+          L.run_kind[nr] = (uint8_t)RK_REP;
+          L.run_tok[nr] = col_abs + at + 1;
+          L.aux[nr] = b;
+          c.off = at + 1 + b;
+          nr++;
+          rows++;
+          lit_left--;
+        }
+        if (!(nr < WL::RUNMAX && rows < n && (lit_left > 0 || c.off < c.len))) break;
         if (lit_left > 0) {
           uint64_t l;
           if (!read_uleb(c, l)) { e = F_BAD_LEB; break; }

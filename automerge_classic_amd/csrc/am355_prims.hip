@@ -120,6 +120,91 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict
   }
 }
 
+// ---- single pass with decoupled look-back (the large regime: more than SCAN_TWO_LAUNCH_TILES tiles) ----
+// Three launches move 12 bytes per element (the sums kernel reads it, apply reads it again and writes); a document load runs
+// eighteen such scans over tens of millions of positions: 3 GB of its 17 GB. Here a tile is read ONCE: the workgroup publishes the sum
+// of its tile (one 64-bit word: state << 32 | value, state 1 = the tile's own sum, 2 = sum of everything up to and including it), its
+// first wavefront looks back over the tiles in front -- 64 words per step, one lane each -- adding sums until it meets a state-2 word,
+// publishes its own state-2 word and the tile is written. Tiles are handed out by a ticket, so every tile in front of a running one has
+// been started; words are exchanged with device-scope atomics (the XCDs have L2 caches of their own). 8 bytes per element, one launch
+// + one small memset of the words.
+constexpr unsigned long long LB_SUM = 1ull << 32, LB_PREFIX = 2ull << 32;
+
+__global__ __launch_bounds__(BLOCK) void k_scan_lookback(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, unsigned long long* __restrict__ state,
+                                                         uint32_t* __restrict__ ticket, uint32_t* __restrict__ grand_total) {
+  __shared__ uint32_t s[BLOCK / WAVE];
+  __shared__ uint32_t s_tile, s_before;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  static_assert(SCAN_ITEMS == 8, "a thread's stretch moves as two uint4");
+  const uint32_t base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  const bool wide = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) && base + SCAN_ITEMS <= n;
+  uint32_t v[SCAN_ITEMS];
+  if (wide) {
+    const uint4 a = *(const uint4*)(in + base), b4 = *(const uint4*)(in + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t i = base + j;
+      v[j] = i < n ? in[i] : 0;
+    }
+  }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) sum += v[j];
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan_u32(sum, s, &total);
+  if (threadIdx.x == 0) {
+    (void)atomicExch(&state[tile], (tile ? LB_SUM : LB_PREFIX) | total);
+    s_before = 0;
+  }
+  if (tile && threadIdx.x < WAVE) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t before = 0;
+    int look = (int)tile - 1;  // lane L inspects tile look - L
+    for (;;) {
+      const int idx = look - (int)lane;
+      const unsigned long long w = idx >= 0 ? atomicAdd(&state[idx], 0ull) : LB_PREFIX;  // (in front of tile 0: nothing, known)
+      const uint32_t st = (uint32_t)(w >> 32);
+      const unsigned long long pending = __ballot(st == 0), prefix = __ballot(st == 2);
+      const uint32_t first = prefix ? (uint32_t)__ffsll((long long)prefix) - 1 : WAVE;   // nearest tile whose word already sums everything in front of it
+      const unsigned long long needed = first >= WAVE - 1 ? ~0ull : ((2ull << first) - 1);
+      if (pending & needed) continue;  // a tile between here and there has not published yet: read again
+      uint32_t part = lane <= first ? (uint32_t)w : 0u;
+      for (int d = WAVE / 2; d; d >>= 1) part += __shfl_xor(part, d);
+      before += part;
+      if (prefix) break;
+      look -= WAVE;
+    }
+    if (lane == 0) {
+      s_before = before;
+      (void)atomicExch(&state[tile], LB_PREFIX | (before + total));
+    }
+  }
+  __syncthreads();
+  const uint32_t before = s_before;
+  if (grand_total && (size_t)(tile + 1) * SCAN_TILE >= n && threadIdx.x == 0) *grand_total = before + total;
+  ex += before;
+  uint32_t o[SCAN_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    o[j] = ex;
+    ex += v[j];
+  }
+  if (wide) {
+    *(uint4*)(out + base) = uint4{o[0], o[1], o[2], o[3]};
+    *(uint4*)(out + base + 4) = uint4{o[4], o[5], o[6], o[7]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+      uint32_t i = base + j;
+      if (i < n) out[i] = o[j];
+    }
+  }
+}
+
 // one workgroup, one launch: tiles in sequence with a running carry
 __global__ __launch_bounds__(BLOCK) void k_scan_single(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ grand_total) {
   wave_priority_high();
@@ -305,11 +390,21 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(BLOCK), 0, st, in, out, n, d_total);
     return;
   }
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(BLOCK), 0, st, in, sums, n);
   if (n_tiles <= SCAN_TWO_LAUNCH_TILES) {
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(BLOCK), 0, st, in, sums, n);
     hipLaunchKernelGGL(k_scan_apply<false>, dim3(n_tiles), dim3(BLOCK), 0, st, in, out, (const uint32_t*)sums, n, d_total);
     return;
   }
+  static const bool lookback = []() { const char* e = getenv("AM355_SCAN_LOOKBACK"); return !(e && *e == '0'); }();
+  if (lookback) {
+    // (the workspace holds 8 bytes per tile + 16: the tile words, then the ticket)
+    unsigned long long* state = (unsigned long long*)ws;
+    uint32_t* ticket = (uint32_t*)(state + n_tiles);
+    (void)hipMemsetAsync(ws, 0, sizeof(unsigned long long) * n_tiles + 8, st);
+    hipLaunchKernelGGL(k_scan_lookback, dim3(n_tiles), dim3(BLOCK), 0, st, in, out, n, state, ticket, d_total);
+    return;
+  }
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(BLOCK), 0, st, in, sums, n);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLOCK), 0, st, sums, n_tiles, d_total);
   hipLaunchKernelGGL(k_scan_apply<true>, dim3(n_tiles), dim3(BLOCK), 0, st, in, out, (const uint32_t*)sums, n, (uint32_t*)nullptr);
 }
