@@ -1174,6 +1174,9 @@ int replay_impl(am355_ctx* c) {
     float ms_plan = 0;
     opt_rc = run_device_planned(c, tot, tot.n_distinct, &ms_plan);  // optimistic: confirmed (or discarded) when stream B is joined
     ms_host += ms_plan;  // (host planning time; it runs beside the decode kernels)
+    // the record tables are final: their way to host memory (5 MB for the headline document, 0.1 ms) starts now, beside the join of
+    // the hash stream and the heads below, instead of with am355_fetch_ir (a merge run of the general path starts it over)
+    if (opt_rc == AM355_OK && !c->in_apply && c->shard_world <= 1) (void)ir_copy_enqueue(c, true);
     lap("run_device (device plan) done");
     opt_flags = c->flags;
     opt_err = c->err;
@@ -1220,6 +1223,7 @@ int replay_impl(am355_ctx* c) {
   } else {
     // ---- general path (any delivery order, duplicates, missing dependencies) ----
     c->flags = 0;
+    c->ir_copy_enqueued = 0;   // (tables of a discarded optimistic run may be on their way: what am355_fetch_ir hands out is enqueued behind the new ones)
     // the device's actor tables, when its list of distinct ids holds them all (else the host interns)
     const bool dev_actors = tot.n_distinct <= distinct_capacity() && !(tot.fast_a & FF_CAPACITY) && tot.total_entries <= c->amap_cap;
     bool served = false;

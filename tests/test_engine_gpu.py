@@ -510,9 +510,9 @@ def test_mutated_changes_and_headers_never_disagree_with_the_oracle(eng):
     or gives the oracle's patch -- the wave-parallel header parse of k_parse_changes and its fallback to the lane-serial parser included."""
     import mutation_util
     equal, refused = mutation_util.column_mutations(lambda log: gpu_patch(eng, log))
-    assert equal > 3 and refused > 20
+    assert (equal, refused) == mutation_util.COLUMN_CAMPAIGN, (equal, refused)   # (deterministic campaign: the exact split, not a lower bound)
     equal, refused = mutation_util.header_mutations(lambda log: gpu_patch(eng, log))
-    assert equal > 10 and refused > 20, (equal, refused)
+    assert (equal, refused) == mutation_util.HEADER_CAMPAIGN, (equal, refused)
 
 
 def test_more_list_objects_than_the_fused_list_order_holds(eng):
