@@ -495,9 +495,141 @@ __device__ __forceinline__ uint32_t wave_tokenize(P p, uint32_t off, uint32_t le
   return (uint32_t)__popcll(term);
 }
 
+// Rows of the action column / sum of the predNum column of a FAT change by the whole wavefront (k_parse_changes<true>). Two lanes
+// walking the two columns record by record (rle_count_sum) are two or three dependent LDS reads per record: 94 us for the map
+// workload's changes -- three hundred short records in predNum -- and the parse kernel is as long as its slowest wavefront. Here: the
+// column's numbers by ballots (as the decoder does), every number read as a record header names the next header, the true headers
+// are the orbit of the first number (pointer doubling), and a header's rows / sum come from prefix sums over the numbers. Accepts and
+// rejects exactly what rle_count_sum does; anything unusual -- a number of more than four bytes, a column that does not end on a
+// number, more than FAT_TOKENS numbers -- is left to rle_count_sum itself (`handled` false).
+constexpr uint32_t FAT_TOKENS = 1024;
+struct FatScratch {
+  uint32_t tok[FAT_TOKENS];    // 7-bit groups assembled (<= 28 bits) | byte count << 28
+  uint32_t pre[FAT_TOKENS + 1];  // exclusive prefix sums of the numbers read as unsigned values
+  uint16_t jump[FAT_TOKENS];
+  uint8_t mark[FAT_TOKENS];
+};
+__device__ __forceinline__ int32_t fat_signed(uint32_t w) {
+  const uint32_t nb = w >> 28, raw = w & 0x0fffffffu, bits = 7 * nb;
+  return (raw >> (bits - 1)) & 1 ? (int32_t)(raw | (~0u << bits)) : (int32_t)raw;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32x(uint32_t v) {
+  for (int d = WAVE / 2; d; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ bool wave_count_sum(LdsBytes col, uint32_t len, uint32_t lane, FatScratch& F, uint64_t& count, uint64_t& sum, bool& handled) {
+  handled = false;
+  count = sum = 0;
+  if (len == 0) { handled = true; return true; }
+  if (len > FAT_TOKENS) return true;
+  // numbers
+  uint32_t T = 0, carry_start = 0;
+  bool plain = true;
+  __syncthreads();
+  for (uint32_t chunk = 0; chunk < len; chunk += WAVE) {
+    const uint32_t pos = chunk + lane;
+    const bool in = pos < len;
+    const uint32_t b = in ? (uint32_t)col[pos] : 0x80u;
+    const bool term = in && !(b & 0x80);
+    const unsigned long long mask = __ballot(term);
+    if (term) {
+      const unsigned long long below = mask & ((1ull << lane) - 1);
+      const uint32_t start = below ? chunk + (63 - (uint32_t)__clzll(below)) + 1 : carry_start;
+      const uint32_t nb = pos - start + 1, idx = T + (uint32_t)__popcll(below);
+      if (nb > 4) plain = false;
+      else {
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < nb; k++) v |= ((uint32_t)col[start + k] & 0x7f) << (7 * k);
+        F.tok[idx] = v | nb << 28;
+      }
+    }
+    if (mask) carry_start = chunk + (63 - (uint32_t)__clzll(mask)) + 1;
+    T += (uint32_t)__popcll(mask);
+  }
+  if (__ballot(!plain) || carry_start != len) return true;  // (rle_count_sum decides)
+  __syncthreads();
+  // prefix sums of the numbers as unsigned values; what every number says as a header
+  uint64_t run = 0;   // (64 numbers of 28 bits: a chunk's sum stays below 2^34; the running total is kept in 64 bits)
+  for (uint32_t chunk = 0; chunk < T; chunk += WAVE) {
+    const uint32_t t = chunk + lane;
+    const uint64_t v = t < T ? (uint64_t)(F.tok[t] & 0x0fffffffu) : 0ull;
+    uint64_t incl = v;
+    for (int d = 1; d < WAVE; d <<= 1) { const uint64_t o = (uint64_t)__shfl_up((long long)incl, d); if ((int)lane >= d) incl += o; }
+    if (t < T) F.pre[t] = (uint32_t)(run + incl - v);
+    run += (uint64_t)__shfl((long long)incl, WAVE - 1);
+  }
+  if (run > 0xffffffffull) return true;  // (32-bit prefix sums would wrap: rle_count_sum decides -- it rejects sums beyond 2^32 - 16)
+  if (lane == 0) F.pre[T] = (uint32_t)run;
+  for (uint32_t t = lane; t < T; t += WAVE) {
+    const int32_t cnt = fat_signed(F.tok[t]);
+    uint32_t next = T;
+    if (cnt > 1) { if (t + 1 < T) next = t + 2; }
+    else if (cnt < 0) { if ((uint32_t)(-cnt) <= T - t - 1) next = t + 1 + (uint32_t)(-cnt); }
+    else if (cnt == 0) { if (t + 1 < T) next = t + 2; }
+    F.jump[t] = (uint16_t)(next > T ? T : next);
+    F.mark[t] = t == 0 ? 1 : 0;
+  }
+  __syncthreads();
+  for (uint32_t hop = 1; hop < T; hop <<= 1) {
+    uint16_t nj[FAT_TOKENS / WAVE];
+#pragma unroll
+    for (uint32_t k = 0; k < FAT_TOKENS / WAVE; k++) {
+      const uint32_t t = lane + k * WAVE;
+      nj[k] = (uint16_t)T;
+      if (t < T) {
+        const uint32_t j = F.jump[t];
+        if (F.mark[t] && j < T) F.mark[j] = 1;
+        if (j < T) nj[k] = F.jump[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < FAT_TOKENS / WAVE; k++) {
+      const uint32_t t = lane + k * WAVE;
+      if (t < T) F.jump[t] = nj[k];
+    }
+    __syncthreads();
+    if (F.jump[0] >= T) {
+      for (uint32_t t = lane; t < T; t += WAVE) { const uint32_t j = F.jump[t]; if (F.mark[t] && j < T) F.mark[j] = 1; }
+      __syncthreads();
+      break;
+    }
+  }
+  // rows and sum of the marked headers; a header rle_count_sum would stop at makes the column malformed
+  uint64_t rows = 0, total = 0;
+  bool bad = false;
+  for (uint32_t t = lane; t < T; t += WAVE) {
+    if (!F.mark[t]) continue;
+    const int32_t cnt = fat_signed(F.tok[t]);
+    if (cnt > 1) {
+      if (t + 1 >= T) bad = true;
+      else { rows += (uint64_t)cnt; total += (uint64_t)cnt * (F.tok[t + 1] & 0x0fffffffu); }
+    } else if (cnt == 1) bad = true;
+    else if (cnt < 0) {
+      const uint32_t k = (uint32_t)(-cnt);
+      if (k > T - t - 1) bad = true;
+      else { rows += k; total += F.pre[t + 1 + k] - F.pre[t + 1]; }
+    } else {
+      if (t + 1 >= T) bad = true;
+      else rows += F.tok[t + 1] & 0x0fffffffu;
+    }
+  }
+  handled = true;
+  if (__ballot(bad)) return false;
+  for (int d = WAVE / 2; d; d >>= 1) {
+    rows += (uint64_t)__shfl_xor((long long)rows, d);
+    total += (uint64_t)__shfl_xor((long long)total, d);
+  }
+  // (rle_count_sum gives up as soon as a running total passes 2^32 - 16; both totals only grow: the final ones decide the same)
+  if (rows > 0xfffffff0ull || total > 0xfffffff0ull) return false;
+  count = rows;
+  sum = total;
+  return true;
+}
+
 template <class P>
 __device__ __forceinline__ bool parse_change_wave(P p, uint64_t base64, uint64_t len64, ChangeMeta* out, uint32_t* n_entries_out, uint32_t lane,
-                                                  TokScratch& S) {
+                                                  TokScratch& S, FatScratch* F = nullptr) {
   if (len64 > 0xfffffff0ull || len64 < 10) return false;
   const uint32_t len = (uint32_t)len64;
   if (p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83 || p[8] != 1) return false;
@@ -570,12 +702,28 @@ __device__ __forceinline__ bool parse_change_wave(P p, uint64_t base64, uint64_t
   // rows = values of the action column, preds = sum of the predNum column: two lanes, one column each
   uint64_t cnt = 0, sum = 0;
   bool rle_ok = true;
-  if (lane < 2) {
+  bool by_wave[2] = {false, false};
+  uint64_t wave_cnt = 0, wave_sum = 0;
+  if (F) {
+    // fat changes (k_parse_changes<true>): a column of some length is counted by the whole wavefront
+    for (int which = 0; which < 2; which++) {
+      const int s = which == 0 ? C_ACTION : C_PRED_NUM;
+      if (S.col_len[s] < 96) continue;
+      uint64_t c0, s0;
+      bool handled;
+      const bool ok = wave_count_sum((LdsBytes)(p + S.col_off[s]), S.col_len[s], lane, *F, c0, s0, handled);
+      if (!handled) continue;
+      if (!ok) return false;
+      by_wave[which] = true;
+      if (which == 0) wave_cnt = c0; else wave_sum = s0;
+    }
+  }
+  if (lane < 2 && !by_wave[lane]) {
     int s = lane == 0 ? C_ACTION : C_PRED_NUM;
     rle_ok = rle_count_sum(p + S.col_off[s], S.col_len[s], cnt, sum);
   }
   if (__ballot(!rle_ok)) return false;
-  const uint64_t n_ops = __shfl(cnt, 0), n_preds = __shfl(sum, 1);
+  const uint64_t n_ops = by_wave[0] ? wave_cnt : __shfl(cnt, 0), n_preds = by_wave[1] ? wave_sum : __shfl(sum, 1);
   if (start_op + n_ops > 0xfffffff0ull) return false;
   if (lane < C_NUM) { out->col_off[lane] = S.col_off[lane]; out->col_len[lane] = S.col_len[lane]; }
   if (lane == 0) {
@@ -605,10 +753,18 @@ __device__ __forceinline__ bool parse_change_wave(P p, uint64_t base64, uint64_t
 // `fills`: word ranges the kernels behind this one expect cleared (flag words, the actor hash table, the merge stage's counter block).
 // They depend on nothing of the replay; as fills on a stream of their own they cost the main stream an event wait in front of the
 // next kernel -- here every workgroup clears a slice on its way in (a few hundred bytes each).
+// FAT (chosen by the host from the batch's bytes per change): 11 KB more of LDS per wavefront for wave_count_sum. A batch of thousands of
+// small changes keeps the lean form: every one of its wavefronts is resident at once with 9 KB each, and its columns are a few records.
+template <bool FAT>
 __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
                                                          uint32_t n_changes, ChangeMeta* __restrict__ metas, uint32_t* __restrict__ n_entries, ParseFills fills) {
   __shared__ alignas(16) uint8_t stage[PARSE_STAGE];
   __shared__ TokScratch scratch;
+  FatScratch* fat = nullptr;
+  if constexpr (FAT) {
+    __shared__ FatScratch fat_scratch;
+    fat = &fat_scratch;
+  }
   wave_priority_high();
   uint32_t c = blockIdx.x, lane = threadIdx.x;
   for (uint32_t r = 0; r < fills.n; r++) {
@@ -621,7 +777,7 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
   bool staged = total64 <= PARSE_STAGE;
   if (staged) stage_to_lds(stage, arena + base64, (uint32_t)total64, lane);
   __syncthreads();
-  if (staged && parse_change_wave((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c], lane, scratch)) return;
+  if (staged && parse_change_wave((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c], lane, scratch, fat)) return;
   if (lane != 0) return;
   // two instantiations so that the staged case reads LDS with ds_read instead of FLAT loads through a generic pointer
   if (staged) parse_change((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c]);
@@ -2297,9 +2453,10 @@ __global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict_
 }
 
 void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, const ParseFills& fills,
-                          hipStream_t st) {
+                          hipStream_t st, bool fat) {
   if (!n_changes && !fills.n) return;
-  hipLaunchKernelGGL(k_parse_changes, dim3(n_changes ? n_changes : 64), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries, fills);
+  if (fat) hipLaunchKernelGGL(k_parse_changes<true>, dim3(n_changes ? n_changes : 64), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries, fills);
+  else hipLaunchKernelGGL(k_parse_changes<false>, dim3(n_changes ? n_changes : 64), dim3(WAVE), 0, st, arena, offsets, n_changes, metas, n_entries, fills);
 }
 
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,

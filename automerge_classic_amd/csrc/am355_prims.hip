@@ -129,6 +129,22 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const uint32_t* __restrict
 // been started; words are exchanged with device-scope atomics (the XCDs have L2 caches of their own). 8 bytes per element, one launch
 // + one small memset of the words.
 constexpr unsigned long long LB_SUM = 1ull << 32, LB_PREFIX = 2ull << 32;
+// one tile word, device scope: a plain 64-bit load / store that bypasses the XCD-local caches (a read-modify-write "add 0" was measured
+// first: 64 lanes of every tile hammering the atomic units made the scan slower than its three-launch form)
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *(const volatile unsigned long long*)p;
+#endif
+}
+__device__ __forceinline__ void lb_store(unsigned long long* p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *(volatile unsigned long long*)p = v;
+#endif
+}
 
 __global__ __launch_bounds__(BLOCK) void k_scan_lookback(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, unsigned long long* __restrict__ state,
                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ grand_total) {
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_lookback(const uint32_t* __restr
   uint32_t total;
   uint32_t ex = block_exclusive_scan_u32(sum, s, &total);
   if (threadIdx.x == 0) {
-    (void)atomicExch(&state[tile], (tile ? LB_SUM : LB_PREFIX) | total);
+    lb_store(&state[tile], (tile ? LB_SUM : LB_PREFIX) | total);
     s_before = 0;
   }
   if (tile && threadIdx.x < WAVE) {
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_lookback(const uint32_t* __restr
     int look = (int)tile - 1;  // lane L inspects tile look - L
     for (;;) {
       const int idx = look - (int)lane;
-      const unsigned long long w = idx >= 0 ? atomicAdd(&state[idx], 0ull) : LB_PREFIX;  // (in front of tile 0: nothing, known)
+      const unsigned long long w = idx >= 0 ? lb_load(&state[idx]) : LB_PREFIX;  // (in front of tile 0: nothing, known)
       const uint32_t st = (uint32_t)(w >> 32);
       const unsigned long long pending = __ballot(st == 0), prefix = __ballot(st == 2);
       const uint32_t first = prefix ? (uint32_t)__ffsll((long long)prefix) - 1 : WAVE;   // nearest tile whose word already sums everything in front of it
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_lookback(const uint32_t* __restr
     }
     if (lane == 0) {
       s_before = before;
-      (void)atomicExch(&state[tile], LB_PREFIX | (before + total));
+      lb_store(&state[tile], LB_PREFIX | (before + total));
     }
   }
   __syncthreads();

@@ -1021,6 +1021,8 @@ int replay_impl(am355_ctx* c) {
   const size_t cb = merge_counts_bytes((uint32_t)std::min<size_t>(c->raw.size(), 0x7ffffff0u));
   c->counts_zeroed_at = nullptr;
   const bool counts_too = c->d_counts.ensure(cb);
+  // (more than 2 KB per change on average: the parse kernel with the wavefront-parallel row / pred counts, k_parse_changes<true>)
+  const bool fat_changes = n && c->raw.size() / n > 2048 && !getenv("AM355_PARSE_LEAN");
   if (c->inline_fills) {
     // (cleared by the parse kernel's workgroups on their way in: no second stream, no event wait in front of the next kernel)
     ParseFills f{};
@@ -1030,10 +1032,10 @@ int replay_impl(am355_ctx* c) {
     add(c->d_slots.p, 8 * (size_t)(c->slot_mask + 1), 0);
     add(c->d_first_idx.p, 4 * (size_t)(c->slot_mask + 1), 0xffffffffu);
     if (counts_too) add(c->d_counts.p, cb, 0);
-    launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), f, sa);
+    launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), f, sa, fat_changes);
     HIPCHK(c, hipEventRecord(c->ev_parse, sa));
   } else {
-    launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), ParseFills{}, sa);
+    launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>(), n, c->d_metas.as<ChangeMeta>(), c->d_entries.as<uint32_t>(), ParseFills{}, sa, fat_changes);
     HIPCHK(c, hipEventRecord(c->ev_parse, sa));
     HIPCHK(c, hipMemsetAsync(d_words, 0, 4 * W_NUM, c->stream3));
     HIPCHK(c, hipMemsetAsync(d_wa, 0, s1_distinct + 16, c->stream3));

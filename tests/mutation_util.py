@@ -42,10 +42,10 @@ def _check(patch_fn, changes, ci, ch, pos, what):
     return True
 
 
-def column_mutations(patch_fn, rounds=70):
+def column_mutations(patch_fn, rounds=70, changes=None, seed=11):
     """Damage in the op columns (the last 60 % of a change)."""
-    changes = _changes("frontend_mixed_3actors")
-    rng = random.Random(11)
+    changes = changes or _changes("frontend_mixed_3actors")
+    rng = random.Random(seed)
     equal = refused = 0
     for _ in range(rounds):
         ci = rng.randrange(len(changes))

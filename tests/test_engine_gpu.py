@@ -542,3 +542,22 @@ def test_change_hashes_at_every_length_modulo_the_sha256_block(eng):
     with pytest.raises(engine.InvalidChanges):
         eng.load_changes(loggen.ChangeLog.from_changes(changes[:77] + [bytes(bad)] + changes[78:], name="bad checksum"))
         eng.replay()
+
+
+def test_fat_changes_counted_by_the_wavefront(eng, monkeypatch):
+    """Changes of more than 2 KB on average go through k_parse_changes<true>: the rows of the action column and the sum of the predNum
+    column by the whole wavefront (orbit of the record headers by pointer doubling) instead of two lanes walking the records. Same
+    rows, same patch as the lean kernel and as the oracle; damaged columns (checksum repaired) are refused or give the oracle's patch."""
+    log = loggen.config("c3_map_lww", 0.07)
+    assert log.raw_bytes / log.n_changes > 2048
+    want = oracle_lib.OracleDoc(log).patch_json()
+    fat = gpu_patch(eng, log)
+    assert fat == want
+    monkeypatch.setenv("AM355_PARSE_LEAN", "1")
+    fat = gpu_patch(eng, log)
+    monkeypatch.delenv("AM355_PARSE_LEAN")
+    assert fat == want
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    changes = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    equal, refused = mutation_util.column_mutations(lambda l: gpu_patch(eng, l), rounds=60, changes=changes, seed=5)
+    assert equal + refused == 60 and refused > 10
