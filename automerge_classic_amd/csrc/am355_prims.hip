@@ -411,7 +411,11 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t*
     hipLaunchKernelGGL(k_scan_apply<false>, dim3(n_tiles), dim3(BLOCK), 0, st, in, out, (const uint32_t*)sums, n, d_total);
     return;
   }
-  static const bool lookback = []() { const char* e = getenv("AM355_SCAN_LOOKBACK"); return !(e && *e == '0'); }();
+  // (measured on the config-5 load, same box, profiles/r05_ab_scan_lookback.txt: 9.05 ms with the single pass against 8.05 ms with the
+  // three launches -- a tile waits for the words of the tiles in front of it, and the three streaming passes run at full bandwidth while
+  // the chain of words does not. Kept behind AM355_SCAN_LOOKBACK=1, not the default.)
+  const char* lb_env = getenv("AM355_SCAN_LOOKBACK");   // (read per call: the tests switch it inside one process)
+  const bool lookback = lb_env && *lb_env == '1';
   if (lookback) {
     // (the workspace holds 8 bytes per tile + 16: the tile words, then the ticket)
     unsigned long long* state = (unsigned long long*)ws;

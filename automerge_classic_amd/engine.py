@@ -70,7 +70,9 @@ def _bind(path):
     L.am355_flags.argtypes = [vp]
     L.am355_load_changes.argtypes = [vp, vp, u64p, u32]
     L.am355_load_document.argtypes = [vp, vp, ctypes.c_size_t]
-    L.am355_backend_load.argtypes = [vp, vp, ctypes.c_size_t]
+    if hasattr(L, "am355_backend_load"):   # (tools/ab_libs.sh loads libraries of earlier rounds, which end before this entry point; tests/test_abi.py holds the shipped library to the header)
+        L.am355_backend_load.argtypes = [vp, vp, ctypes.c_size_t]
+        L.am355_backend_load.restype = ctypes.c_int
     L.am355_replay.argtypes = [vp]
     L.am355_patch_json.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t)]
     L.am355_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
@@ -98,7 +100,7 @@ def _bind(path):
     L.am355_forget_call_history.argtypes = [vp, ctypes.c_int]
     L.am355_hash_graph_known.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.am355_set_phase_events.argtypes = [vp, ctypes.c_int]
-    for f in ("am355_load_changes", "am355_load_document", "am355_backend_load", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
+    for f in ("am355_load_changes", "am355_load_document", "am355_replay", "am355_patch_json", "am355_get_stats", "am355_get_hashes", "am355_test_sort",
               "am355_test_scan", "am355_get_rows", "am355_save", "am355_get_applied", "am355_fetch_ir", "am355_get_raw", "am355_set_shard", "am355_fragment_size", "am355_export_fragment",
               "am355_import_fragments", "am355_doc_changes", "am355_apply_changes", "am355_apply_patch_json", "am355_fetch_apply_ir", "am355_reset", "am355_get_pending", "am355_forget_call_history", "am355_hash_graph_known", "am355_set_phase_events", "am355_get_dep_graph", "am355_sync_bloom_build", "am355_sync_bloom_probe"):
         getattr(L, f).restype = ctypes.c_int

@@ -290,8 +290,13 @@ def test_device_primitives(eng):
     # three-launch scan (more than 1024 tiles: k_scan_sums between the tile sums and the apply kernel), aligned and unaligned length
     for n in (2_200_003, 2_300_000):
         vals = rng.integers(0, 3, n, dtype=np.uint32)
-        out, total = eng.test_scan(vals)
-        assert np.array_equal(out, np.concatenate(([0], np.cumsum(vals)[:-1])).astype(np.uint32)) and total == int(vals.sum())
+        for lookback in ("0", "1"):   # (1: the single-pass form with decoupled look-back, off by default -- measured slower)
+            os.environ["AM355_SCAN_LOOKBACK"] = lookback
+            try:
+                out, total = eng.test_scan(vals)
+            finally:
+                del os.environ["AM355_SCAN_LOOKBACK"]
+            assert np.array_equal(out, np.concatenate(([0], np.cumsum(vals)[:-1])).astype(np.uint32)) and total == int(vals.sum())
 
 
 @pytest.mark.parametrize("serial", [False, True])

@@ -65,11 +65,18 @@ def test_defect_fixture_both_delivery_orders(eng):
 
 def test_device_primitives(eng):
     rng = np.random.default_rng(7)
-    for n in (1, 63, 2048, 2049, 8192, 8193, 100_003, 1_500_000, 5_000_011):  # one launch / two launches / three launches of the scan
+    for n in (1, 63, 2048, 2049, 8192, 8193, 100_003, 1_500_000, 5_000_011, 41_000_003):  # one launch / two launches / three launches of the scan
         vals = rng.integers(0, 9, n, dtype=np.uint32)
         out, total = eng.test_scan(vals)
         ref = np.concatenate(([0], np.cumsum(vals.astype(np.uint64))[:-1])).astype(np.uint32)
         assert np.array_equal(out, ref) and total == int(vals.sum())
+        if n > 2_200_000:   # (the single-pass form with decoupled look-back: off by default, kept correct)
+            os.environ["AM355_SCAN_LOOKBACK"] = "1"
+            try:
+                out, total = eng.test_scan(vals)
+            finally:
+                del os.environ["AM355_SCAN_LOOKBACK"]
+            assert np.array_equal(out, ref) and total == int(vals.sum())
         keys = rng.integers(0, 1 << 40, n, dtype=np.uint64)
         k, v = eng.test_sort(keys, np.arange(n, dtype=np.uint32), 40)
         order = np.argsort(keys, kind="stable")
