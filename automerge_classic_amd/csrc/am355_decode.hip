@@ -1774,6 +1774,7 @@ __device__ __forceinline__ bool wv_tok_sint(const WL& L, uint32_t t, int64_t& ou
 #define AM355_WV_SERIAL_TOKENS 40   // (built with 2 once per change to this file: every column of every fixture and mutation campaign through the wavefront walk)
 #endif
 constexpr uint32_t WV_SERIAL_TOKENS = AM355_WV_SERIAL_TOKENS;
+constexpr uint32_t WV_SERIAL_RECORDS = 12;
 __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t x, uint32_t lane);
 
 // what token t says when read as a record header: kind, rows, the header after it (T = none), the first error the serial walk would
@@ -1939,15 +1940,16 @@ __device__ __forceinline__ void wv_load_column(WL& L, P col, uint32_t len, uint3
   // such a change took. Columns of more than WV_SERIAL_TOKENS numbers are walked by the whole wavefront instead: every token computes
   // where it would point as a header, the orbit of token 0 is marked by pointer doubling (log2 rounds over the tokens, jumps read
   // before any is written), marked tokens are ranked by ballots and write their record. Same tables, same first error.
-  if (tok_base > WV_SERIAL_TOKENS && carry_start == len) {
-    wv_records_parallel(L, tok_base, lane);
-    return;
-  }
+  // (a long column of FEW records -- a run of three hundred consecutive counters is one record of two numbers -- is walked by lane 0
+  // faster than the doubling rounds take: lane 0 starts, and hands over when the column turns out to have more than WV_SERIAL_RECORDS)
+  const bool may_hand_over = tok_base > WV_SERIAL_TOKENS && carry_start == len;
   if (lane == 0) {
     uint32_t e = carry_start != len ? (uint32_t)F_BAD_LEB : 0;  // buffer ended with incomplete number
     uint32_t t = 0, nr = 0, prev = 0;
     uint64_t rows = 0;
+    L.n_runs = 0;
     while (t < tok_base && !e) {
+      if (may_hand_over && nr >= WV_SERIAL_RECORDS) { L.n_runs = NONE32; break; }
       int64_t cnt;
       if (!wv_tok_sint(L, t, cnt)) { e = F_BAD_LEB; break; }
       uint32_t kind, first = t + 1;
@@ -1977,13 +1979,16 @@ __device__ __forceinline__ void wv_load_column(WL& L, P col, uint32_t len, uint3
       if (rows > 0xfffffff0ull) { e = F_OVERFLOW; break; }
       prev = kind;
     }
-    L.run_start[nr] = (uint32_t)rows;
-    L.n_runs = nr;
-    L.n_tokens = tok_base;
-    L.total_rows = (uint32_t)rows;
-    L.err = e;
+    if (L.n_runs != NONE32) {
+      L.run_start[nr] = (uint32_t)rows;
+      L.n_runs = nr;
+      L.n_tokens = tok_base;
+      L.total_rows = (uint32_t)rows;
+      L.err = e;
+    }
   }
   __syncthreads();
+  if (L.n_runs == NONE32) wv_records_parallel(L, tok_base, lane);   // (uniform: every lane reads the same LDS word)
 }
 
 // value of row i of the loaded column: returns the token index holding it, or NONE32 for null. *prev receives the token of

@@ -1176,9 +1176,9 @@ int replay_impl(am355_ctx* c) {
     float ms_plan = 0;
     opt_rc = run_device_planned(c, tot, tot.n_distinct, &ms_plan);  // optimistic: confirmed (or discarded) when stream B is joined
     ms_host += ms_plan;  // (host planning time; it runs beside the decode kernels)
-    // the record tables are final: their way to host memory (5 MB for the headline document, 0.1 ms) starts now, beside the join of
-    // the hash stream and the heads below, instead of with am355_fetch_ir (a merge run of the general path starts it over)
-    if (opt_rc == AM355_OK && !c->in_apply && c->shard_world <= 1) (void)ir_copy_enqueue(c, true);
+    // (measured and taken out again, profiles/r05_ab_libs.txt: starting the copy of the record tables to the host right here, beside the
+    // join of the hash stream, instead of in am355_fetch_ir -- no gain for the host-to-host time within the spread of the runs, and a
+    // caller that replays without fetching pays 0.1 ms for 5 MB it did not ask for)
     lap("run_device (device plan) done");
     opt_flags = c->flags;
     opt_err = c->err;
