@@ -2170,8 +2170,10 @@ uint32_t err = 0;
 // column groups of k_decode_wave (see there)
 enum : uint32_t { DG_ROWS = 1 /* action, op ids, insert, object */, DG_KEY_ID = 2 /* key element id, value */, DG_KEY_STR = 4, DG_PRED = 8, DG_ALL = 15 };
 
+// (the small class is held to 80 registers = six wavefronts per SIMD: the gate and the wavefront record walk had taken it to 83 = five,
+// and the headline decode from 60 to 66 us)
 template <class WL>
-__global__ __launch_bounds__(WAVE) void k_decode_wave(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
+__global__ __launch_bounds__(WAVE) AM355_WAVES_PER_EU(WL::COLMAX <= 256 ? 6 : 1) void k_decode_wave(const uint8_t* __restrict__ arena, const ChangeMeta* __restrict__ metas,
                                                        const ChangePlan* __restrict__ plans, uint32_t n_plans, ActorXlate x, OpCols o,
                                                        uint32_t* __restrict__ flags, DecodeGate gate) {
   __shared__ WL L;

@@ -10,6 +10,13 @@
 #define AM355_LAUNCH_INDEPENDENT(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #endif
 
+// occupancy floor of a kernel (wavefronts per SIMD the register allocation must allow): a device-compiler attribute
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AM355_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#else
+#define AM355_WAVES_PER_EU(n)
+#endif
+
 namespace am355 {
 
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;

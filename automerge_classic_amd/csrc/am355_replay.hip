@@ -751,17 +751,19 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
     if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], st));
   }
   c->spec_launched = false;  // (used up: a second merge run of this replay -- the general path after a late dependency -- decodes in its own order)
-  if (tot.n_small && (tot.n_large || tot.n_serial)) {
-    // (stream3 carries the second decoder class -- 0.27 ms for a batch of fat changes --: the fills, which depend on nothing, would
-    // start behind it and k_resolve would wait for them; they go to the copy stream, which is idle now)
-    merge_prepare(c->mb, c->stream4);
-    HIPCHK(c, hipEventRecord(c->ev_fills, c->stream4));
-    HIPCHK(c, hipStreamWaitEvent(st, c->ev_fills, 0));
-  } else {
-    merge_prepare(c->mb, c->stream3);
+  // The merge stage's fills and, behind them on the SAME stream, the host-built span tables (below): one stream that is busy from here
+  // on, one event for k_resolve to wait for. (Rounds 2-4 sent the tables over stream4 alone, which the copy of the digests had used a
+  // moment earlier; with the digests written into host memory by the kernels that copy was the stream's first command, and k_resolve
+  // waited 60 us for it in most replays -- same-box A/B, profiles/r05_ab_libs.txt.)
+  const bool second_class = tot.n_small && (tot.n_large || tot.n_serial);
+  // (stream3 carries the second decoder class -- 0.1-0.27 ms for a batch of fat changes --: the fills, which depend on nothing, would
+  // start behind it and k_resolve would wait for them; they go to stream4 then)
+  hipStream_t fill_stream = second_class ? c->stream4 : c->stream3;
+  merge_prepare(c->mb, fill_stream);
+  if (second_class) {
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   }
-  HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
-  HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   lap("fills enqueued");
   // ---- host half of the plan, beside the decode kernels (the digests were copied right behind k_plan) ----
   if (go) HIPCHK(c, hipEventSynchronize(go->ready));
@@ -778,10 +780,9 @@ static int run_device_planned(am355_ctx* c, const PlanTotals& tot, uint32_t n_di
     size_t b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size();
     if (b_spans) memcpy(h, c->spans.data(), b_spans);
     memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
-    // on stream4, beside the decode kernels: in the main stream the copy would start when the decode kernels end (and on
-    // stream3 when the merge fills end) and k_resolve would wait for it
-    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_tab + b_tab, hipMemcpyHostToDevice, c->stream4));
-    HIPCHK(c, hipEventRecord(c->ev_tables, c->stream4));
+    // behind the fills, beside the decode kernels (in the main stream the copy would start when the decode kernels end)
+    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_tab + b_tab, hipMemcpyHostToDevice, fill_stream));
+    HIPCHK(c, hipEventRecord(c->ev_tables, fill_stream));
     HIPCHK(c, hipStreamWaitEvent(st, c->ev_tables, 0));
   }
   lap("tables enqueued");
