@@ -423,105 +423,6 @@ __global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_
   map_finish_one(b, ir, i, perm[i], i > 0 ? perm[i - 1] : NONE32, i + 1 < n ? perm[i + 1] : NONE32);
 }
 
-// ---- up to MAP_SORT_ONE_MAX emissions: every pass of every field in ONE launch of one workgroup ----
-// The tiled radix sort costs two launches per 8-bit pass (histogram, scatter); the keys of a map are long -- trigger id, key length, the
-// key's bytes -- and the map workload's 17 k emissions went through eleven passes = 22 launches of 5-9 us each for data that fits the L2
-// cache several times over: 150 of its 520 us. Here sixteen wavefronts of one workgroup run all the passes: a wavefront owns a
-// contiguous stretch of the items (so that (wavefront, iteration, lane) order is item order and the pass is stable), counts its digits
-// with eight ballots per 64 items into its own row of LDS counters, the 16 x 256 counters are scanned digit-major / wavefront-minor by
-// the workgroup, and the wavefront scatters its stretch to the other buffer (global memory: the pairs stay in the CU's L1 / L2).
-constexpr uint32_t MAP_SORT_ONE_MAX = 32768, MAP_SORT_ONE_THREADS = 1024, MAP_SORT_ONE_FIELDS = 12;
-struct MapSortFields {
-  uint32_t n_fields;
-  int32_t mode[MAP_SORT_ONE_FIELDS];
-  uint32_t chunk[MAP_SORT_ONE_FIELDS];
-  int32_t begin_bit[MAP_SORT_ONE_FIELDS], end_bit[MAP_SORT_ONE_FIELDS];
-};
-__global__ __launch_bounds__(MAP_SORT_ONE_THREADS) void k_map_sort_one(MergeBufs b, uint32_t n, MapSortFields f, uint64_t* __restrict__ key_a, uint32_t* __restrict__ val_a,
-                                                                       uint64_t* __restrict__ key_b, uint32_t* __restrict__ val_b, uint32_t* __restrict__ perm_out) {
-  wave_priority_high();
-  constexpr uint32_t NW = MAP_SORT_ONE_THREADS / WAVE;
-  __shared__ uint32_t cnt[NW][256];
-  __shared__ uint32_t s_wave[NW];
-  const uint32_t t = threadIdx.x, lane = t & (WAVE - 1), w = t / WAVE;
-  const uint32_t stretch = ((n + NW - 1) / NW + WAVE - 1) / WAVE * WAVE;   // items per wavefront, a multiple of 64
-  const uint32_t lo = w * stretch < n ? w * stretch : n, hi = lo + stretch < n ? lo + stretch : n;
-  uint64_t* kin = key_a; uint64_t* kout = key_b;
-  uint32_t* vin = val_a; uint32_t* vout = val_b;
-  for (uint32_t i = t; i < n; i += MAP_SORT_ONE_THREADS) vin[i] = i;
-  __threadfence();
-  __syncthreads();
-  for (uint32_t fi = 0; fi < f.n_fields; fi++) {
-    for (uint32_t i = t; i < n; i += MAP_SORT_ONE_THREADS) kin[i] = map_key_of(b, vin[i], f.mode[fi], f.chunk[fi], nullptr);
-    __threadfence();
-    __syncthreads();
-    for (int shift = f.begin_bit[fi]; shift < f.end_bit[fi]; shift += 8) {
-      for (uint32_t k = lane; k < 256; k += WAVE) cnt[w][k] = 0;
-      __syncthreads();
-      // count: the lowest lane of every group of equal digits adds the group's size to the wavefront's counter
-      for (uint32_t i0 = lo; i0 < hi; i0 += WAVE) {
-        const uint32_t i = i0 + lane;
-        const bool in = i < hi;
-        const uint32_t d = in ? (uint32_t)(kin[i] >> shift) & 0xffu : 0u;
-        unsigned long long m = __ballot(in);
-#pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
-          const unsigned long long bal = __ballot(in && ((d >> bit) & 1));
-          m &= ((d >> bit) & 1) ? bal : ~bal;
-        }
-        if (in && (m & ((1ull << lane) - 1)) == 0) cnt[w][d] += (uint32_t)__popcll(m);
-      }
-      __syncthreads();
-      // exclusive scan of the counters in (digit, wavefront) order: thread t owns four consecutive entries
-      {
-        uint32_t c4[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t e = 4 * t + k; c4[k] = cnt[e % NW][e / NW]; sum += c4[k]; }
-        uint32_t incl = wave_incl_scan_u32(sum, lane);
-        if (lane == WAVE - 1) s_wave[w] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-        for (uint32_t k = 0; k < w; k++) before += s_wave[k];
-        uint32_t ex = before + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t e = 4 * t + k; cnt[e % NW][e / NW] = ex; ex += c4[k]; }
-      }
-      __syncthreads();
-      // scatter, in the order of the count
-      for (uint32_t i0 = lo; i0 < hi; i0 += WAVE) {
-        const uint32_t i = i0 + lane;
-        const bool in = i < hi;
-        const uint64_t key = in ? kin[i] : 0ull;
-        const uint32_t val = in ? vin[i] : 0u;
-        const uint32_t d = (uint32_t)(key >> shift) & 0xffu;
-        unsigned long long m = __ballot(in);
-#pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
-          const unsigned long long bal = __ballot(in && ((d >> bit) & 1));
-          m &= ((d >> bit) & 1) ? bal : ~bal;
-        }
-        const unsigned long long below = m & ((1ull << lane) - 1);
-        // (the lowest lane of a group of equal digits reads the group's offset, hands it round and moves it on)
-        const uint32_t leader = m ? (uint32_t)__ffsll((long long)m) - 1 : lane;
-        uint32_t base = in && lane == leader ? cnt[w][d] : 0u;
-        base = __shfl(base, (int)leader);
-        if (in) {
-          const uint32_t dst = base + (uint32_t)__popcll(below);
-          kout[dst] = key;
-          vout[dst] = val;
-        }
-        if (in && lane == leader) cnt[w][d] = base + (uint32_t)__popcll(m);
-      }
-      __threadfence();
-      __syncthreads();
-      uint64_t* tk = kin; kin = kout; kout = tk;
-      uint32_t* tv = vin; vin = vout; vout = tv;
-    }
-  }
-  if (vin != perm_out)
-    for (uint32_t i = t; i < n; i += MAP_SORT_ONE_THREADS) perm_out[i] = vin[i];
-}
-
 // up to BLOCK emissions (a text document's root map: one): ranks by comparison and the records, one workgroup, one launch
 __device__ __forceinline__ void map_small_finish(const MergeBufs& b, uint32_t n, const PatchIR& ir) {
   __shared__ uint32_t s_perm[BLOCK];
@@ -1373,36 +1274,17 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
                   : radix_sort_pairs(b.key_a, perm_a, b.key_b, perm_b, ne, begin_bit, bits, b.sort_ws, st, fused);
     cur ^= res;
   };
-  // (AM355_MAP_SORT_FORCE=one: every map, however small, through k_map_sort_one -- the tests send the reference-made fixtures with
-  // their nested maps through it that way)
-  const char* force = getenv("AM355_MAP_SORT_FORCE");
-  const bool force_one = force && !strcmp(force, "one");
-  if (ne <= BLOCK && !force_one) {
+  // (measured in round 5 and not adopted: all passes of all key fields in ONE launch of one workgroup, 8-16 wavefronts each owning a
+  // contiguous stretch of the pairs -- 400 us for the map workload's 17 k emissions against 150 us for the 22 tiled launches: a
+  // wavefront's 64-item steps each wait a memory round trip, and keeping a lane's 24-48 pairs in registers spilled; profiles/r05_c3_*)
+  if (ne <= BLOCK) {
     if (ride_with_list_order) *ride_with_list_order = ne;  // (an extra workgroup of k_list_order_objs: merge_run)
     else hipLaunchKernelGGL(k_map_small_finish, dim3(1), dim3(BLOCK), 0, st, b, ne, ir);
     return;
   }
-  if (ne <= MAP_SORT_SMALL && !force_one) {
+  if (ne <= MAP_SORT_SMALL) {
     AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(ne), dim3(BLOCK), st, b, ne, (const uint32_t*)nullptr, perm_b);  // (one emission: rank 0)
     cur = 1;
-  } else if (ne <= MAP_SORT_ONE_MAX && 3 + (hc->max_key_len + 7) / 8 <= MAP_SORT_ONE_FIELDS && !getenv("AM355_MAP_SORT_TILED")) {
-    MapSortFields f{};
-    auto add = [&](int mode, uint32_t chunk, int bits, int begin_bit = 0) {
-      if (bits <= begin_bit) return;
-      f.mode[f.n_fields] = mode; f.chunk[f.n_fields] = chunk; f.begin_bit[f.n_fields] = begin_bit; f.end_bit[f.n_fields] = bits; f.n_fields++;
-    };
-    add(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
-    add(MK_LEN, 0, bits_for(hc->max_key_len));
-    uint32_t chunks = (hc->max_key_len + 7) / 8;
-    for (uint32_t c = chunks; c-- > 0;) {
-      uint32_t used = hc->max_key_len - 8 * c < 8 ? hc->max_key_len - 8 * c : 8;
-      add(MK_CHUNK, c, 64, 64 - 8 * (int)used);
-    }
-    if (hc->n_objects) add(MK_OBJECT, 0, bits_for(hc->n_objects));
-    // (the result goes to perm_b whatever the number of passes: the pair buffers are the workgroup's own ping-pong)
-    hipLaunchKernelGGL(k_map_sort_one, dim3(1), dim3(MAP_SORT_ONE_THREADS), 0, st, b, ne, f, b.key_a, perm_a, b.key_b, perm_b, perm_b);
-    AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)perm_b, ne, ir);
-    return;
   } else {
     AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
     pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);

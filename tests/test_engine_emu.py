@@ -757,19 +757,3 @@ def test_fat_changes_counted_by_the_wavefront(eng, monkeypatch):
     changes = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
     equal, refused = mutation_util.column_mutations(lambda l: emu_patch(eng, l), rounds=60, changes=changes, seed=5)
     assert equal + refused == 60 and refused > 10
-
-
-def test_maps_through_the_single_launch_sort(eng, monkeypatch):
-    """k_map_sort_one (maps of 513 .. 32768 visible values: all radix passes of all key fields in one launch of one workgroup) against the
-    tiled sort and the oracle on the map workload; and, forced for maps of every size (AM355_MAP_SORT_FORCE=one), on the reference-made
-    fixtures -- nested maps, conflicts, the object field of the key."""
-    log = loggen.config("c3_map_lww", 0.1)
-    want = oracle_lib.OracleDoc(log).patch_json()
-    assert emu_patch(eng, log) == want
-    monkeypatch.setenv("AM355_MAP_SORT_TILED", "1")
-    assert emu_patch(eng, log) == want
-    monkeypatch.delenv("AM355_MAP_SORT_TILED")
-    monkeypatch.setenv("AM355_MAP_SORT_FORCE", "one")
-    for name in golden_util.fixture_names():
-        fx = golden_util.load_fixture(name)
-        assert emu_patch(eng, fx["log"]) == fx["expected"], name

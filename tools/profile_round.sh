@@ -7,7 +7,7 @@ TAG=${1:-round}
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-B="python bench.py --steps 10 --warmup 3 --no-sublines --no-cpu-baseline"
+B="python bench.py --steps 10 --warmup 3 --no-sublines --no-cpu-baseline --no-live-trace"
 timeout -k 5 400 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 # (every profiler pass under a hard limit: a pass that stalls must not eat the GPU budget; if the first one stalls, the passes are
 # repeated with AM355_STAGE_SYNC=1 = am355_load_changes waits for its copies, and the note is written next to the results)

@@ -5,7 +5,7 @@ TAG=${1:-w}; W=${2:-c3_map_lww}; ANCHOR=${3:-k_parse_changes}
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-B="python bench.py --workload $W --steps 20 --warmup 5 --prewarm 0.2 --no-sublines --no-cpu-baseline"
+B="python bench.py --workload $W --steps 20 --warmup 5 --prewarm 0.2 --no-sublines --no-cpu-baseline --no-live-trace"
 timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run -- $B > $OUT/${W}_bench_under_trace.json 2> $OUT/${W}_kt.err
 python tools/rocpd_summary.py $OUT/kt/run_results.db 8 > $OUT/${W}_kernel_stats.txt 2>&1
 python tools/rocpd_timeline.py $OUT/kt/run_results.db -2 $ANCHOR > $OUT/${W}_timeline.txt 2>&1
