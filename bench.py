@@ -47,7 +47,9 @@ SHAPE = {"c2_text_typing": "one Text object, 1 actor", "c3_map_lww": "root map o
 BASE_SEED = {"c2_text_typing": 0x5EED0002, "c3_map_lww": 0x5EED0003, "c4_text_single": 0x5EED0004, "c4_text_multi": 0x5EED0004, "c5_doc_mixed": 0x5EED0005}
 PARITY = ("bit-exact getPatch vs the CPU oracle at this size and vs reference goldens (pytest -m gpu); NOTE the STOCK reference is "
           "delivery-order dependent on this workload (600-op block-boundary defect, tests/golden/defect_block_boundary.json): "
-          "the answer reproduced is the block-size-patched reference's = the documented RGA rule (DESIGN.md §6)")
+          "the answer reproduced is the block-size-patched reference's = the documented RGA rule (DESIGN.md §6). At THIS size the oracle is the "
+          "only checker: it is pinned to the block-size-patched reference on this workload's shape up to 43 k ops in-tree "
+          "(tests/golden/save_generated.json, defect_block_boundary.json) -- an O(n^2) patched reference does not go further in minutes")
 
 
 def make_log(name, scale, seed, deflate=False):
