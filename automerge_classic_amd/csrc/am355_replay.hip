@@ -1022,8 +1022,9 @@ int replay_impl(am355_ctx* c) {
   const size_t cb = merge_counts_bytes((uint32_t)std::min<size_t>(c->raw.size(), 0x7ffffff0u));
   c->counts_zeroed_at = nullptr;
   const bool counts_too = c->d_counts.ensure(cb);
-  // (more than 2 KB per change on average: the parse kernel with the wavefront-parallel row / pred counts, k_parse_changes<true>)
-  const bool fat_changes = n && c->raw.size() / n > 2048 && !getenv("AM355_PARSE_LEAN");
+  // (more than 4 KB per change on average: the parse kernel with the wavefront-parallel row / pred counts, k_parse_changes<true>; the
+  // headline log's 3.2 KB changes keep the lean kernel -- 20 us against 36 with the bigger LDS footprint, profiles/r05_kernel_table_fat_parse.txt)
+  const bool fat_changes = n && c->raw.size() / n > 4096 && !getenv("AM355_PARSE_LEAN");
   if (c->inline_fills) {
     // (cleared by the parse kernel's workgroups on their way in: no second stream, no event wait in front of the next kernel)
     ParseFills f{};

@@ -552,11 +552,11 @@ def test_change_hashes_at_every_length_modulo_the_sha256_block(eng):
 
 
 def test_fat_changes_counted_by_the_wavefront(eng, monkeypatch):
-    """Changes of more than 2 KB on average go through k_parse_changes<true>: the rows of the action column and the sum of the predNum
+    """Changes of more than 4 KB on average go through k_parse_changes<true>: the rows of the action column and the sum of the predNum
     column by the whole wavefront (orbit of the record headers by pointer doubling) instead of two lanes walking the records. Same
     rows, same patch as the lean kernel and as the oracle; damaged columns (checksum repaired) are refused or give the oracle's patch."""
-    log = loggen.config("c3_map_lww", 0.07)
-    assert log.raw_bytes / log.n_changes > 2048
+    log = loggen.config("c3_map_lww", 0.3)
+    assert log.raw_bytes / log.n_changes > 4096
     want = oracle_lib.OracleDoc(log).patch_json()
     fat = gpu_patch(eng, log)
     assert fat == want
