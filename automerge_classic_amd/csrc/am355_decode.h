@@ -39,7 +39,7 @@ void launch_plan(const ChangeBrief* briefs, uint32_t n, const uint32_t* distinct
                  PlanTotals* dev_totals = nullptr, uint32_t* host_s1 = nullptr);
 void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_changes, const PlanTotals* totals, uint32_t cap_ops,
                                uint32_t cap_preds, uint32_t cap_distinct, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st,
-                               hipStream_t aux, uint32_t shard_rank = 0, uint32_t shard_world = 1);
+                               hipStream_t aux, bool with_large, uint32_t shard_rank = 0, uint32_t shard_world = 1);
 void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, const ChangePlan* plans_serial, uint32_t n_changes,
                            uint32_t n_small, uint32_t n_large, uint32_t n_serial, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags,
                            hipStream_t st, hipStream_t aux, uint32_t shard_rank = 0, uint32_t shard_world = 1);

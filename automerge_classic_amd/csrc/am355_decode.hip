@@ -2597,14 +2597,14 @@ void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const 
 // cap_ops / cap_preds. Both launches do nothing unless decode_gate_open() holds, which the host evaluates on the same totals.
 void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_changes, const PlanTotals* totals, uint32_t cap_ops,
                                uint32_t cap_preds, uint32_t cap_distinct, const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st,
-                               hipStream_t aux, uint32_t shard_rank, uint32_t shard_world) {
+                               hipStream_t aux, bool with_large, uint32_t shard_rank, uint32_t shard_world) {
   if (!n_changes) return;
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_changes, decode_group_split(n_changes, shard_world)), dim3(WAVE), 0, st, arena, metas, plans, 0u, x, cols, flags,
                      DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 0u});
-  // (aux == null: the caller expects no change of the large class -- none in the context's previous batch -- and launches that class
+  // (!with_large: the caller expects no change of the large class -- none in the context's previous batch -- and launches that class
   // itself should there be one after all)
-  if (aux)
+  if (with_large)
     hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes, decode_group_split(n_changes, shard_world)), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
                        DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 1u});
 }

@@ -1133,7 +1133,7 @@ int replay_impl(am355_ctx* c) {
         if (want_large_spec) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_plan, 0));
         launch_decode_speculative(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), c->d_plans.as<ChangePlan>(), n, c->d_plan_totals.as<PlanTotals>(), c->spec_cap_ops,
                                   c->spec_cap_preds, distinct_capacity(), c->d_amap_prov.as<uint32_t>(), c->d_slot_rank.as<uint32_t>(), c->cols,
-                                  &c->d_counts.as<Counts>()->flags, sa, want_large_spec ? c->stream3 : nullptr, c->shard_rank, c->shard_world);
+                                  &c->d_counts.as<Counts>()->flags, sa, c->stream3, want_large_spec, c->shard_rank, c->shard_world);
         c->spec_large_launched = want_large_spec;
         if (c->phase_events) HIPCHK(c, hipEventRecord(c->ev[3], sa));
         c->spec_launched = true;
