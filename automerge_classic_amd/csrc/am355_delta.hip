@@ -203,6 +203,12 @@ __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
   const OpCols& o = b.ops;
   uint32_t err = 0;
   if (kind == K_FOREIGN) err |= refuse(d, DR_FOREIGN_ROW);
+  // a new list row that is neither a value, a child object nor a deletion (an increment, a link): the reference's counter states and
+  // `remove` rule in an incremental patch are not restated here (the whole-document patch serves them, k_quirk_rows)
+  if (kind == K_LIST_INS || kind == K_LIST_INS_VIS || kind == K_LIST_UPD) {
+    const uint32_t a = o.action[g];
+    if (!(a == 1 || ((a & 1u) == 0 && a < 7))) err |= refuse(d, DR_ELEM_NOT_PLAIN);
+  }
   if (kind != K_NONE && kind != K_FOREIGN) {
     if (kind == K_MAP || (kind == K_DEL && o.key_len[g] != NONE32)) {
       uint32_t s = key_slot(b, d, g, true);

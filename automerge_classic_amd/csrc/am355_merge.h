@@ -21,7 +21,9 @@ struct Counts {
   uint32_t euler_done;   // the single-workgroup LDS list ranking handled the tour
   uint32_t n_erecs;      // edit records (a multi-insert run counts once)
   uint32_t n_head_children;  // insert rows whose reference element is _head (all list objects)
-  uint32_t reserved[4];
+  uint32_t n_quirk;      // list rows that need the reference's counter / `remove` rules (new.js:937-965, 1010-1033): counters completed by
+                         // increments, visible rows without a value. 0 = the ordinary edits (merge_run then skips k_quirk_rows)
+  uint32_t reserved[3];
 };
 
 // Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.

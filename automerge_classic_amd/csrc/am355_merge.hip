@@ -119,7 +119,6 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
     } else {
       kind = a == 3 ? K_DEL : K_LIST_UPD;
     }
-    if (a == 5) err |= F_UNSUPPORTED;  // counters inside lists (reference quirk)
   }
   if (a == 3 && o.pred_num[g] == 0) err |= F_UNSUPPORTED;
 
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   } else if (live) {
     bool valued = (a == 1) || (a & 1) == 0;
     want_ins = kind == K_LIST_INS;
-    if (vis && !valued) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);  // value-less visible row: reference 'remove' quirk
+    bool quirk = false;
     if (vis && valued) {
       if (kind == K_LIST_INS) b.kind[g] = K_LIST_INS_VIS;
       else {
@@ -239,7 +238,22 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
           want_upd = true;
         }
       }
+    } else if (vis) {
+      // a visible row without a value (an increment, a link): it takes part in the element's edits by the reference's `remove` rule
+      // (new.js:1026-1033) -- k_quirk_rows / k_list_edits
+      quirk = true;
+    } else if (a == 1 && (o.val_tl[g] & 15) == 8 && b.inc_cnt[g] == b.succ_cnt[g]) {
+      // a counter whose successors are all increments (new.js:937-965): one value of its element, listed where the LAST increment
+      // stands among the element's rows -- it travels with the update rows, keyed by that increment's id (k_upd_keys), also when the
+      // counter is the element's own insert row
+      el = kind == K_LIST_INS ? g : b.ref_row[g];
+      if (el != NONE32) {
+        atomicAdd(&b.val_cnt[el], 1u);
+        want_upd = true;
+      }
+      quirk = true;
     }
+    if (quirk) atomicAdd(&b.counts->n_quirk, 1u);
   }
   uint32_t slot = block_append(&b.counts->n_map_emit, want_map, s_app);
   if (want_map) {
@@ -870,7 +884,25 @@ __global__ __launch_bounds__(BLOCK) void k_list_order_objs(MergeBufs b, PatchIR 
 }
 
 // per list position: visibility and edit counts, scanned by k_list_scan through the carried sums published here
-__global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n) {
+// Lists that hold counters or visible rows without a value (Counts.n_quirk != 0; new.js:937-965, 1010-1018, 1026-1033). Per element the
+// reference's state machine comes down to: the VALUES of the element in row order -- visible `set` / make rows, and every counter
+// whose successors are all increments at the place of its last increment --; when a visible row without a value (an increment that
+// does not complete its counter, a link) stands in front of the first value the element is first reported as `remove` and its
+// values then all become `update` edits, and with no value at all the `remove` edit stays. vl_min[element row] = the smallest id
+// (ctr << 32 | actor) among its visible rows without a value (all ones: none). An increment that completes its counter counts as
+// such a row too: its id is the counter's place among the values, so it is never in FRONT of the first value.
+__global__ __launch_bounds__(BLOCK) void k_quirk_rows(MergeBufs b, unsigned long long* __restrict__ vl_min) {
+  uint32_t g = gtid();
+  if (g >= b.n_ops) return;
+  const uint8_t kind = b.kind[g];
+  if (kind != K_LIST_INS && kind != K_LIST_UPD) return;  // (K_LIST_INS_VIS: valued)
+  const uint32_t a = b.ops.action[g];
+  if (a == 1 || (a & 1) == 0 || b.succ_cnt[g] != 0) return;
+  const uint32_t el = kind == K_LIST_INS ? g : b.ref_row[g];
+  if (el != NONE32) atomicMin(&vl_min[el], pack_id(b.ops.id_ctr[g], b.ops.id_actor[g]));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n, const unsigned long long* __restrict__ vl_min) {
   wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t p = gtid();
@@ -878,7 +910,10 @@ __global__ __launch_bounds__(BLOCK) void k_list_counts(MergeBufs b, uint32_t n) 
   if (p < n) {
     uint32_t v = b.order[p];
     if (v == NONE32) atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM);
-    else c = b.val_cnt[v] + (b.kind[v] == K_LIST_INS_VIS ? 1u : 0u);
+    else {
+      c = b.val_cnt[v] + (b.kind[v] == K_LIST_INS_VIS ? 1u : 0u);
+      if (vl_min && c == 0 && vl_min[v] != ~0ull) c = 1;  // the `remove` edit of an element that shows rows but no value
+    }
     b.list_vis[p] = c ? 1 : 0;
     b.list_cnt[p] = c;
   }
@@ -900,14 +935,21 @@ __global__ __launch_bounds__(BLOCK) void k_upd_keys(MergeBufs b, uint64_t* __res
   uint32_t i = gtid();
   if (i >= n) return;
   uint32_t g = b.upd_row[i];
-  keys[i] = (uint64_t)b.ref_row[g] << (b.bits_ctr + b.bits_actor) | (uint64_t)b.ops.id_ctr[g] << b.bits_actor | b.ops.id_actor[g];
+  uint32_t el = b.ref_row[g], ctr = b.ops.id_ctr[g], actor = b.ops.id_actor[g];
+  if (b.succ_cnt[g] != 0) {  // a counter completed by increments (k_emit): placed by its last increment; may be the element's insert row
+    const unsigned long long t = b.last_inc[g];
+    ctr = (uint32_t)(t >> 32);
+    actor = (uint32_t)t;
+    if (b.kind[g] == K_LIST_INS) el = g;
+  }
+  keys[i] = (uint64_t)el << (b.bits_ctr + b.bits_actor) | (uint64_t)ctr << b.bits_actor | actor;
   vals[i] = g;
 }
 
 // one lane per list position: write the element's edits (insert first, then updates in ascending op id)
 __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, const uint32_t* __restrict__ vis_ex, const uint32_t* __restrict__ cnt_ex,
                                                       const uint64_t* __restrict__ upd_keys, const uint32_t* __restrict__ upd_vals, uint32_t n_upd,
-                                                      PatchIR ir) {
+                                                      PatchIR ir, const unsigned long long* __restrict__ vl_min) {
   wave_priority_high();
   uint32_t p = gtid();
   if (p >= n) return;
@@ -915,11 +957,17 @@ __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, c
   if (v == NONE32) return;
   const bool own = b.kind[v] == K_LIST_INS_VIS;  // the insert's own value is visible
   uint32_t c = b.val_cnt[v] + (own ? 1u : 0u);
-  if (!c) return;
+  const unsigned long long vl = vl_min ? vl_min[v] : ~0ull;  // first visible row without a value (k_quirk_rows)
+  if (!c && vl == ~0ull) return;
   uint32_t oi = obj_index_of(b, b.obj_row[v]);
   uint32_t index = vis_ex[p] - vis_ex[b.obj_first_pos[oi]];
   uint32_t e = cnt_ex[p], k = 0;
+  if (!c) {  // rows, but no value: the `remove` edit stays (new.js:1026-1033)
+    ir.e_row[e] = v; ir.e_elem[e] = v; ir.e_index[e] = index; ir.e_flags[e] = 8u;
+    return;
+  }
   uint32_t a = b.ops.action[v];
+  // (the insert row has the smallest id of its element: a row without a value is never in front of it)
   if (own) {
     ir.e_row[e] = v; ir.e_elem[e] = v; ir.e_index[e] = index; ir.e_flags[e] = ((a & 1) == 0 ? 4u : 0u);
     k = 1;
@@ -931,12 +979,25 @@ __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, c
       uint32_t mid = (lo + hi) >> 1;
       if ((upd_keys[mid] >> sh) < v) lo = mid + 1; else hi = mid;
     }
+    // a row without a value in front of the first value: the element was reported as `remove` first, every value is an `update` then
+    // (new.js:1010-1018; appendUpdate finds nothing of this element to take away: its index is its own)
+    bool removed_first = false;
+    if (!own && vl != ~0ull && lo < n_upd && (upd_keys[lo] >> sh) == v) {
+      const uint64_t first_id = upd_keys[lo] & ((1ull << sh) - 1);
+      removed_first = ((uint64_t)(vl >> 32) << b.bits_actor | (uint32_t)vl) < first_id;
+    }
+    bool shown = own || vl != ~0ull;  // some row of the element has no successor (the reference's elemVisible, new.js:1626)
     for (; k < c && lo < n_upd && (upd_keys[lo] >> sh) == v; k++, lo++) {
       uint32_t u = upd_vals[lo];
+      const bool counter = b.succ_cnt[u] != 0;  // (k_emit: the only rows with successors that are listed)
+      shown = shown || !counter;
       ir.e_row[e + k] = u; ir.e_elem[e + k] = v; ir.e_index[e + k] = index;
-      ir.e_flags[e + k] = (k ? 1u : 0u) | ((b.ops.action[u] & 1) == 0 ? 4u : 0u);
+      ir.e_flags[e + k] = ((k || removed_first) ? 1u : 0u) | ((b.ops.action[u] & 1) == 0 ? 4u : 0u) | (counter ? 32u : 0u);
     }
     if (k != c) atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM);
+    // a counter whose increments have all been deleted: the reference lists its total but does not count the element as visible -- the
+    // next element is then reported at the same index and the two interfere (appendUpdate, new.js:803-815): left to the JS path
+    if (!shown) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);
   }
 }
 
@@ -951,20 +1012,21 @@ __global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
   uint32_t head = 0;
   if (e < n) {
     const OpCols& o = b.ops;
-    uint32_t r = ir.e_row[e], el = ir.e_elem[e], f = ir.e_flags[e] & 5u;
+    uint32_t r = ir.e_row[e], el = ir.e_elem[e], f = ir.e_flags[e] & 0x2du;  // update | child | remove | counter total
     uint32_t oi = obj_index_of(b, b.obj_row[el]);
     uint32_t prev_oi = NONE32, next_oi = NONE32;
     if (e > 0) {
       uint32_t pr = ir.e_row[e - 1], pel = ir.e_elem[e - 1], pf = ir.e_flags[e - 1];
       prev_oi = obj_index_of(b, b.obj_row[pel]);
-      bool simple = !(f & 5) && r == el, psimple = !(pf & 5) && pr == pel;
+      bool simple = !(f & 0xdu) && r == el, psimple = !(pf & 0xdu) && pr == pel;
       if (simple && psimple && prev_oi == oi && o.id_actor[r] == o.id_actor[pr] && o.id_ctr[r] == o.id_ctr[pr] + 1 &&
           value_class(o.val_tl[r]) == value_class(o.val_tl[pr]) && ir.e_index[e] == ir.e_index[e - 1] + 1) {
         f |= 2u;
         // a record holds values with one type/length word, back to back in the arena (consecutive ops of a change: consecutive
-        // bytes of its valRaw column); anything else starts a new record of the same multi-insert
+        // bytes of its valRaw column); anything else -- a counter's total is not in the arena at all -- starts a new record of
+        // the same multi-insert
         uint32_t tl = o.val_tl[r], ptl = o.val_tl[pr];
-        if (tl != ptl || o.val_off[r] != o.val_off[pr] + (ptl >> 4)) f |= 0x400u;
+        if (tl != ptl || o.val_off[r] != o.val_off[pr] + (ptl >> 4) || ((f | pf) & 32u)) f |= 0x400u;
       }
     }
     if (e + 1 < n) next_oi = obj_index_of(b, b.obj_row[ir.e_elem[e + 1]]);
@@ -995,8 +1057,17 @@ __global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
   if (e >= n) return;
   const OpCols& o = b.ops;
   uint32_t r = ir.e_row[e], el = ir.e_elem[e];
-  if (head) ir.edit[k] = am355_ir_edit{f & 7u, ir.e_index[e], o.id_ctr[r], o.id_actor[r], o.id_ctr[el], o.id_actor[el], e, o.val_tl[r],
-                                       (f & 4u) ? b.obj_index[r] : o.val_off[r], 0};
+  if (head) {
+    uint32_t val = (f & 4u) ? b.obj_index[r] : o.val_off[r], val_hi = 0;
+    if (f & 32u) {  // the total of a counter (new.js:944, 958): its `set` value + the increments k_resolve summed up
+      long long base = 0;
+      if (!int_value(b, r, base)) atomicOr(&b.counts->flags, (uint32_t)F_BAD_LEB);
+      const unsigned long long total = (unsigned long long)(base + (long long)b.inc_sum[r]);
+      val = (uint32_t)total;
+      val_hi = (uint32_t)(total >> 32);
+    }
+    ir.edit[k] = am355_ir_edit{f & 0x2fu, ir.e_index[e], o.id_ctr[r], o.id_actor[r], o.id_ctr[el], o.id_actor[el], e, o.val_tl[r], val, val_hi};
+  }
   if (f & 0x300u) {
     uint32_t oi = obj_index_of(b, b.obj_row[el]);
     if (f & 0x100u) ir.obj[oi].edit_begin = k;         // (the first edit of an object is always a head)
@@ -1032,7 +1103,6 @@ __global__ __launch_bounds__(BLOCK) void k_doc_prepare(MergeBufs b, unsigned lon
   else if (has_str) { kind = K_MAP; if (ins) err |= F_UNSUPPORTED; }
   else kind = ins ? K_LIST_INS : K_LIST_UPD;
   if (a == 3) err |= F_UNSUPPORTED;  // a `del` row only exists in documents written from the empty-pred corner case
-  if (kind != K_MAP && a == 5) err |= F_UNSUPPORTED;  // counters inside lists (reference quirk)
   b.kind[g] = kind;
   b.succ_cnt[g] = o.pred_num[g];
   b.scan_b[g] = kind == K_LIST_INS ? 1u : 0u;
@@ -1059,6 +1129,23 @@ __device__ __forceinline__ uint32_t doc_find_make(const unsigned long long* __re
     if (k == 0) return NONE32;
     if (k == key) return tab_row[i];
     i = (i + 1) & mask;
+  }
+  return NONE32;
+}
+
+// The counter an increment ON A LIST ELEMENT feeds (document rows: the rows of an element follow its insert row `el`, ascending by
+// id): the latest preceding `set` of a counter that lists the increment among its successors (counterStates[succOp] = counterState,
+// later assignment wins: new.js:944-950). NONE32: none -- "increment operation for unknown counter".
+__device__ __forceinline__ uint32_t doc_list_counter_of(const MergeBufs& b, uint32_t g, uint32_t el) {
+  const OpCols& o = b.ops;
+  if (el == NONE32 || el >= g) return NONE32;
+  const uint32_t my_a = o.id_actor[g], my_c = o.id_ctr[g];
+  for (uint32_t r = g; r-- > el;) {
+    if (o.action[r] == 1 && (o.val_tl[r] & 15) == 8) {
+      const uint32_t f = o.pred_first[r], n = o.pred_num[r];
+      for (uint32_t k = 0; k < n; k++)
+        if (o.pred_actor[f + k] == my_a && o.pred_ctr[f + k] == my_c) return r;
+    }
   }
   return NONE32;
 }
@@ -1133,12 +1220,27 @@ __global__ __launch_bounds__(BLOCK) void k_doc_resolve(MergeBufs b, const unsign
       atomicAdd(&b.inc_sum[owner], (unsigned long long)v);
       atomicMax(&b.last_inc[owner], (unsigned long long)g);  // row order within a key is op-id order
     }
+  } else if (kind != K_NONE && kind != K_MAP && o.action[g] == 5 && !(err & F_BAD_ELEM)) {
+    // an increment on a list element (new.js:952-965)
+    const uint32_t owner = doc_list_counter_of(b, g, ref);
+    long long v;
+    if (owner == NONE32) err |= F_BAD_COUNTER;
+    else if (!int_value(b, g, v)) err |= F_UNSUPPORTED;
+    else {
+      atomicAdd(&b.inc_cnt[owner], 1u);
+      atomicAdd(&b.inc_sum[owner], (unsigned long long)v);
+      atomicMax(&b.last_inc[owner], (unsigned long long)g);
+    }
   }
   if (err) atomicOr(&b.counts->flags, err);
 }
 
 // per row: which rows trigger a map emission / produce a list edit; value counts per list element
-__global__ __launch_bounds__(BLOCK) void k_doc_emit(MergeBufs b, uint32_t* __restrict__ trig_flag, uint32_t* __restrict__ trig_src, uint32_t* __restrict__ edit_flag) {
+// (lists: a value-less visible row -- an increment that does not complete its counter, a link -- and a counter completed by increments
+// follow the reference's `remove` rule, see k_quirk_rows. vl_first[insert row] = the first visible row without a value of the element;
+// the row of the LAST increment of a completed counter is the place of the counter's value among the element's edits, and carries it.)
+__global__ __launch_bounds__(BLOCK) void k_doc_emit(MergeBufs b, uint32_t* __restrict__ trig_flag, uint32_t* __restrict__ trig_src, uint32_t* __restrict__ edit_flag,
+                                                    uint32_t* __restrict__ vl_first) {
   uint32_t g = gtid();
   if (g >= b.n_ops) return;
   const OpCols& o = b.ops;
@@ -1159,23 +1261,43 @@ __global__ __launch_bounds__(BLOCK) void k_doc_emit(MergeBufs b, uint32_t* __res
       trig_src[t] = g;
     }
   } else if (kind == K_LIST_INS || kind == K_LIST_UPD) {
-    if (vis && !valued) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);  // reference 'remove' quirk
-    if (vis && valued) {
-      uint32_t el = kind == K_LIST_INS ? g : b.ref_row[g];
-      if (el != NONE32) { edit_flag[g] = 1; atomicAdd(&b.val_cnt[el], 1u); }
+    const uint32_t el = kind == K_LIST_INS ? g : b.ref_row[g];
+    if (el == NONE32) return;
+    if (vis && valued) { edit_flag[g] = 1; atomicAdd(&b.val_cnt[el], 1u); }
+    if (vis && !valued) atomicMin(&vl_first[el], g);
+    if (a == 5) {
+      const uint32_t owner = doc_list_counter_of(b, g, el);
+      if (owner != NONE32 && b.inc_cnt[owner] == b.succ_cnt[owner] && (uint32_t)b.last_inc[owner] == g) {
+        edit_flag[g] = 1;
+        atomicAdd(&b.val_cnt[el], 1u);
+        // a counter whose increments have all been deleted is listed by the reference without the element counting as visible; the
+        // next element then has the same index and the two interfere (appendUpdate, new.js:803-815): left to the JS path
+        bool shown = false;
+        for (uint32_t r = el; r < b.n_ops && !shown && (r == el || (b.kind[r] == K_LIST_UPD && b.ref_row[r] == el)); r++) shown = b.succ_cnt[r] == 0;
+        if (!shown) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_doc_visflag(MergeBufs b, uint32_t* __restrict__ flag) {
+// per insert row: does the element show in the list (a value, or -- the reference's `remove` rule -- any visible row); an element that
+// shows rows but no value gets its `remove` edit at the first of them
+__global__ __launch_bounds__(BLOCK) void k_doc_visflag(MergeBufs b, uint32_t* __restrict__ flag, const uint32_t* __restrict__ vl_first, uint32_t* __restrict__ edit_flag) {
   uint32_t g = gtid();
-  if (g < b.n_ops) flag[g] = (b.kind[g] == K_LIST_INS && b.val_cnt[g] > 0) ? 1u : 0u;
+  if (g >= b.n_ops) return;
+  bool vis = false;
+  if (b.kind[g] == K_LIST_INS) {
+    if (b.val_cnt[g] > 0) vis = true;
+    else if (vl_first[g] != NONE32) { vis = true; edit_flag[vl_first[g]] = 1; }
+  }
+  flag[g] = vis ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_doc_scatter(MergeBufs b, const uint32_t* __restrict__ trig_flag, const uint32_t* __restrict__ trig_src,
                                                        const uint32_t* __restrict__ em_pos, const uint32_t* __restrict__ edit_flag,
                                                        const uint32_t* __restrict__ ed_pos, const uint32_t* __restrict__ idx_ex,
-                                                       const uint32_t* __restrict__ obj_first, uint32_t* __restrict__ perm, PatchIR ir) {
+                                                       const uint32_t* __restrict__ obj_first, uint32_t* __restrict__ perm, PatchIR ir,
+                                                       const uint32_t* __restrict__ vl_first) {
   uint32_t g = gtid();
   if (g >= b.n_ops) return;
   if (trig_flag[g]) {
@@ -1187,10 +1309,19 @@ __global__ __launch_bounds__(BLOCK) void k_doc_scatter(MergeBufs b, const uint32
     uint32_t e = ed_pos[g];
     uint32_t el = b.kind[g] == K_LIST_INS ? g : b.ref_row[g];
     uint32_t first_row = obj_first[obj_index_of(b, b.obj_row[g])];
-    ir.e_row[e] = g;
+    const uint32_t a = b.ops.action[g];
+    uint32_t src = g, f;
+    if (b.val_cnt[el] == 0) f = 8u;  // rows, but no value: the `remove` edit (k_doc_visflag)
+    else {
+      // an increment stands for the counter it completes (k_doc_emit); a visible row without a value in front of the element's
+      // first value makes every value an `update` (new.js:1010-1018)
+      if (a == 5) src = doc_list_counter_of(b, g, el);
+      f = ((ed_pos[g] != ed_pos[el] || vl_first[el] < g) ? 1u : 0u) | ((a & 1) == 0 ? 4u : 0u) | (a == 5 ? 32u : 0u);
+    }
+    ir.e_row[e] = src;
     ir.e_elem[e] = el;
     ir.e_index[e] = idx_ex[el] - idx_ex[first_row];
-    ir.e_flags[e] = (ed_pos[g] != ed_pos[el] ? 1u : 0u) | ((b.ops.action[g] & 1) == 0 ? 4u : 0u);
+    ir.e_flags[e] = f;
   }
 }
 
@@ -1397,7 +1528,15 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
     // visibility / edit-count prefix sums over document order
     uint32_t* vis_ex = b.scan_a;
     uint32_t* cnt_ex = b.scan_b;
-    hipLaunchKernelGGL(k_list_counts, grid_for(ni), dim3(BLOCK), 0, st, b, ni);
+    // counters / rows without a value inside lists (rare): the first such row of every element, in whichever half of the Euler
+    // scratch the ranked tour is not in (both are free once the elements have their positions)
+    unsigned long long* vl_min = nullptr;
+    if (hc->n_quirk) {
+      vl_min = el == b.euler_a ? b.euler_b : b.euler_a;
+      (void)hipMemsetAsync(vl_min, 0xff, sizeof(unsigned long long) * (size_t)N, st);
+      AM355_LAUNCH_INDEPENDENT(k_quirk_rows, grid_for(N), dim3(BLOCK), st, b, vl_min);
+    }
+    hipLaunchKernelGGL(k_list_counts, grid_for(ni), dim3(BLOCK), 0, st, b, ni, (const unsigned long long*)vl_min);
     hipLaunchKernelGGL(k_list_scan, grid_for(ni), dim3(BLOCK), 0, st, b, ni, vis_ex, cnt_ex);
     const uint64_t* uk = b.key_a;
     const uint32_t* uv = b.val_a;
@@ -1407,7 +1546,8 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
       uk = r2 ? b.key_b : b.key_a;
       uv = r2 ? b.val_b : b.val_a;
     }
-    AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis_ex, (const uint32_t*)cnt_ex, uk, uv, nu, ir);
+    AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis_ex, (const uint32_t*)cnt_ex, uk, uv, nu, ir,
+                             (const unsigned long long*)vl_min);
     hipLaunchKernelGGL(k_edit_runs, grid_for(N), dim3(BLOCK), 0, st, b, ir);
     hipLaunchKernelGGL(k_edit_pack, grid_for(N), dim3(BLOCK), 0, st, b, ir);
   } else {
@@ -1437,6 +1577,8 @@ void doc_patch(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
   uint32_t* edit_flag = b.next_sib;
   uint32_t* idx_ex = (uint32_t*)b.euler_b;      // [N+1]
   uint32_t* perm = b.val_a;
+  uint32_t* vl_first = b.list_vis;              // [N] per insert row: first visible row of the element without a value (k_doc_emit)
+  (void)hipMemsetAsync(vl_first, 0xff, sizeof(uint32_t) * (size_t)N, st);
   (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, st);
   (void)hipMemsetAsync(tab_key, 0, sizeof(unsigned long long) * ((size_t)mask + 1), st);
   (void)hipMemsetAsync(obj_first, 0xff, sizeof(uint32_t) * ((size_t)N + 1), st);
@@ -1449,14 +1591,14 @@ void doc_patch(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
     AM355_LAUNCH_INDEPENDENT(k_ins_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_b, (const uint32_t*)b.scan_a);
     AM355_LAUNCH_INDEPENDENT(k_doc_resolve, grid_for(N), dim3(BLOCK), st, b, (const unsigned long long*)tab_key, (const uint32_t*)tab_row, mask,
                              (const uint32_t*)b.scan_a, obj_first);
-    AM355_LAUNCH_INDEPENDENT(k_doc_emit, grid_for(N), dim3(BLOCK), st, b, trig_flag, trig_src, edit_flag);
+    AM355_LAUNCH_INDEPENDENT(k_doc_emit, grid_for(N), dim3(BLOCK), st, b, trig_flag, trig_src, edit_flag, vl_first);
     exclusive_scan_u32(trig_flag, b.scan_a, N, &b.counts->n_map_emit, b.scan_ws, st);
+    AM355_LAUNCH_INDEPENDENT(k_doc_visflag, grid_for(N), dim3(BLOCK), st, b, b.ins_row, (const uint32_t*)vl_first, edit_flag);  // (may add `remove` edits)
     exclusive_scan_u32(edit_flag, b.scan_b, N, &b.counts->n_edits, b.scan_ws, st);
-    AM355_LAUNCH_INDEPENDENT(k_doc_visflag, grid_for(N), dim3(BLOCK), st, b, b.ins_row);
     exclusive_scan_u32(b.ins_row, idx_ex, N, nullptr, b.scan_ws, st);
     AM355_LAUNCH_INDEPENDENT(k_doc_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)trig_flag, (const uint32_t*)trig_src,
                              (const uint32_t*)b.scan_a, (const uint32_t*)edit_flag, (const uint32_t*)b.scan_b, (const uint32_t*)idx_ex,
-                             (const uint32_t*)obj_first, perm, ir);
+                             (const uint32_t*)obj_first, perm, ir, (const uint32_t*)vl_first);
   } else {
     (void)hipMemsetAsync(ir.obj, 0, sizeof(am355_ir_object), st);
     (void)hipMemsetAsync(ir.edit, 0, sizeof(am355_ir_edit), st);

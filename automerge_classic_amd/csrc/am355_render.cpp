@@ -204,6 +204,17 @@ struct R {
     }
   }
 
+  // value of a single-value edit record
+  bool edit_value(const am355_ir_edit& ed) {
+    if (ed.flags & AM355_EDIT_COUNTER) {  // {type:'value', datatype:'counter', value} (new.js:963)
+      char t[80];
+      snprintf(t, sizeof t, "{\"type\":\"value\",\"datatype\":\"counter\",\"value\":%lld}", (long long)((uint64_t)ed.pad << 32 | ed.val_off));
+      out += t;
+      return true;
+    }
+    return value(ed.val_tl, ed.val_off, (ed.flags & AM355_EDIT_CHILD) != 0);
+  }
+
   bool value(uint32_t tl, uint32_t off, bool child) {
     if (child) return object(off);
     out += "{\"type\":\"value\",\"value\":";
@@ -254,6 +265,12 @@ struct R {
 
   // one record's values (all with the type/length word val_tl, back to back in the arena), comma separated
   bool record_values(const am355_ir_edit& ed, uint32_t count) {
+    if (ed.flags & AM355_EDIT_COUNTER) {  // one value per record: the total of a counter inside a list
+      char t[32];
+      snprintf(t, sizeof t, "%lld", (long long)((uint64_t)ed.pad << 32 | ed.val_off));
+      out += t;
+      return count == 1 || fail("internal: counter record with several values");
+    }
     uint32_t len = ed.val_tl >> 4;
     for (uint32_t k = 0; k < count; k++) {
       if (k) out.push_back(',');
@@ -292,7 +309,7 @@ struct R {
         out += t;
         if (!op_id(ed.id_ctr, ed.id_actor)) return false;
         out += ",\"value\":";
-        if (!value(ed.val_tl, ed.val_off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
+        if (!edit_value(ed)) return false;
         out.push_back('}');
       } else {
         snprintf(t, sizeof t, "{\"action\":\"insert\",\"index\":%u,\"elemId\":", ed.index);
@@ -301,7 +318,7 @@ struct R {
         out += ",\"opId\":";
         if (!op_id(ed.id_ctr, ed.id_actor)) return false;
         out += ",\"value\":";
-        if (!value(ed.val_tl, ed.val_off, (ed.flags & AM355_EDIT_CHILD) != 0)) return false;
+        if (!edit_value(ed)) return false;
         out.push_back('}');
       }
       i = j;

@@ -11,7 +11,7 @@
 'use strict'
 
 const OBJ_WORDS = 8, MAP_WORDS = 10, EDIT_WORDS = 10
-const MAP_COUNTER = 1, MAP_CHILD = 2, MAP_EMPTY = 4, EDIT_UPDATE = 1, EDIT_CONT = 2, EDIT_CHILD = 4, EDIT_REMOVE = 8, EDIT_MULTI = 16
+const MAP_COUNTER = 1, MAP_CHILD = 2, MAP_EMPTY = 4, EDIT_UPDATE = 1, EDIT_CONT = 2, EDIT_CHILD = 4, EDIT_REMOVE = 8, EDIT_MULTI = 16, EDIT_COUNTER = 32
 const TYPE_NAME = { 0: 'map', 2: 'list', 4: 'text', 6: 'table' }
 const HEX = []
 for (let i = 0; i < 256; i++) HEX.push((i < 16 ? '0' : '') + i.toString(16))
@@ -163,19 +163,22 @@ class Materializer {
             const rw = r * EDIT_WORDS, rtl = e[rw + 7], len = rtl >>> 4
             let roff = e[rw + 8]
             const rcount = e[rw + EDIT_WORDS + 6] - e[rw + 6]
-            if ((rtl & 15) === 6) for (let i = 0; i < rcount; i++, roff += len) values.push(this.str(roff, len))
+            if (e[rw] & EDIT_COUNTER) values.push((e[rw + 9] | 0) * 4294967296 + roff)   // the total of a counter inside a list: one value per record
+            else if ((rtl & 15) === 6) for (let i = 0; i < rcount; i++, roff += len) values.push(this.str(roff, len))
             else for (let i = 0; i < rcount; i++, roff += len) values.push(this.decode(rtl, roff).value)
           }
         }
         const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
-        if ((tl & 15) !== 6) { const head = this.decode(tl, off); if (head.datatype) edit.datatype = head.datatype }   // only truthy datatypes (new.js:762)
+        if (flags & EDIT_COUNTER) edit.datatype = 'counter'
+        else if ((tl & 15) !== 6) { const head = this.decode(tl, off); if (head.datatype) edit.datatype = head.datatype }   // only truthy datatypes (new.js:762)
         edit.values = values
         out.push(edit)
-      } else if (flags & EDIT_UPDATE) {
-        out.push({ action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) })
       } else {
-        out.push({ action: 'insert', index, elemId: this.opId(e[w + 4], e[w + 5]), opId: this.opId(e[w + 2], e[w + 3]),
-                   value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) })
+        // (a counter inside a list: its total, new.js:963 -- low word in the value-offset field, high word behind it)
+        const value = (flags & EDIT_COUNTER) ? { type: 'value', datatype: 'counter', value: (e[w + 9] | 0) * 4294967296 + off }
+          : this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0)
+        if (flags & EDIT_UPDATE) out.push({ action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value })
+        else out.push({ action: 'insert', index, elemId: this.opId(e[w + 4], e[w + 5]), opId: this.opId(e[w + 2], e[w + 3]), value })
       }
       k = j
     }

@@ -187,9 +187,12 @@ typedef struct {
   int64_t counter;                /* AM355_MAP_COUNTER: the counter's total (new.js:937-967) */
 } am355_ir_map;
 enum { AM355_EDIT_UPDATE = 1u, AM355_EDIT_CONT = 2u, AM355_EDIT_CHILD = 4u,
-       AM355_EDIT_REMOVE = 8u, /* incremental patches only: `remove` edit of count = next record's first - first elements (new.js:775-777, 1029) */
-       AM355_EDIT_MULTI = 16u  /* incremental patches only: a `multi-insert` edit even with one value left (appendUpdate took the last
-                                  value of a two-value multi-insert away, new.js:812-814; the reference keeps the edit's action) */ };
+       AM355_EDIT_REMOVE = 8u, /* `remove` edit of count = next record's first - first elements (new.js:775-777, 1029): incremental patches, and
+                                  whole-document patches of lists that hold a visible row without a value (an increment of a deleted counter) */
+       AM355_EDIT_MULTI = 16u, /* incremental patches only: a `multi-insert` edit even with one value left (appendUpdate took the last
+                                  value of a two-value multi-insert away, new.js:812-814; the reference keeps the edit's action) */
+       AM355_EDIT_COUNTER = 32u /* the value is the total of a counter inside a list (new.js:937-965): one value per record,
+                                  (int64_t)((uint64_t)pad << 32 | val_off); val_tl keeps the type/length word of the counter's `set` */ };
 typedef struct {
   uint32_t flags;                 /* AM355_EDIT_UPDATE: `update` edit (else insert / multi-insert); AM355_EDIT_CHILD: the value is an object;
                                      AM355_EDIT_CONT: more values of the previous record's multi-insert */
@@ -199,7 +202,7 @@ typedef struct {
   uint32_t first;                 /* ordinal of the record's first value among all list values; count = next record's first - first */
   uint32_t val_tl;                /* type/length word of every value of the record */
   uint32_t val_off;               /* arena offset of the first value (value i at val_off + i * (val_tl >> 4)); AM355_EDIT_CHILD: object index */
-  uint32_t pad;
+  uint32_t pad;                   /* AM355_EDIT_COUNTER: high word of the total */
 } am355_ir_edit;
 
 typedef struct {

@@ -1820,7 +1820,8 @@ static int json_pobj(pctx_t *c, sbuf_t *b, pobj_t *p) {
           json_opid(b, c->d, e->elem);
           /* `if (nextEdit.value.datatype) lastEdit.datatype = ...` -- truthy datatypes only (new.js:762) */
           pval_t second = e->vals[e->nvals > 1 ? 1 : 0];
-          if (has_datatype(&second) && (second.tag_len & 15) != 0) {
+          /* (a counter total -- kind 1 -- has no type/length word of its own: its datatype is 'counter') */
+          if (has_datatype(&second) && (second.kind == 1 || (second.tag_len & 15) != 0)) {
             sb_puts(b, ",\"datatype\":");
             json_datatype(b, second.kind == 1 ? 8 : (int)(second.tag_len & 15));
           }

@@ -393,9 +393,28 @@ def test_sessions_onto_loaded_documents_emulated(emu_lib):
     assert equal >= 300 and refused == 0
 
 
+QUIRK_EQUAL, QUIRK_REFUSED = 165, 32
+
+
+def test_sessions_with_counters_inside_lists_emulated(emu_lib):
+    """Lists that hold counters and rows without a value (tests/golden/apply_campaign_quirks.json.gz, oracle/js/make_list_quirk_golden.js:
+    24 sessions from empty documents, 18 onto documents the reference saved and loaded with such lists in them; patches of the live
+    reference). The whole-document patch serves these lists since round 5; the INCREMENTAL patch of a call that increments a counter
+    inside a list, or assigns to an element that holds one, stays with the JS path (the session ends there) -- everything else is
+    served, the calls onto the loaded documents included, and no served call differs."""
+    equal, refused = run_campaign(lambda: engine.Engine(0, emu_lib), fixture="apply_campaign_quirks.json.gz")
+    assert (equal, refused) == (QUIRK_EQUAL, QUIRK_REFUSED)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # GPU
 # ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_sessions_with_counters_inside_lists_gpu():
+    equal, refused = run_campaign(lambda: engine.Engine(0), fixture="apply_campaign_quirks.json.gz")
+    assert (equal, refused) == (QUIRK_EQUAL, QUIRK_REFUSED)
+
+
 @pytest.mark.gpu
 def test_sessions_onto_loaded_documents_gpu():
     equal, refused = run_campaign(lambda: engine.Engine(0), fixture="apply_campaign_loaded.json.gz")

@@ -42,6 +42,13 @@ def test_golden_reference_patches(eng, name):
     assert eng.stats().fast_path == (2 if general else 1)   # (2: the general path, scheduled on the device)
 
 
+def test_counters_and_valueless_rows_inside_lists(eng):
+    """new.js:937-965, 1010-1018, 1026-1033 in whole-document patches (refused through round 4): patch, save, load, history of every case
+    of tests/golden/list_quirks.json equal the unmodified reference's; exactly one case is left to the JS path."""
+    served, refused = golden_util.check_list_quirk_cases(eng, engine)
+    assert set(refused) == golden_util.LIST_QUIRK_REFUSED and served >= 47
+
+
 def test_defect_fixture_both_delivery_orders(eng):
     """Inputs on which the stock reference diverges with delivery order: the engine gives the block-size-patched
     reference's document for both orders."""

@@ -26,7 +26,7 @@ EMU_DIR = os.path.join(HERE, "emu")
 
 # vector ids (position in the file) the engine must not serve, and why
 REJECTED_BY_REFERENCE = {14: "BAD_PRED", 16: "BAD_PRED", 25: "BAD_ELEM", 33: "BAD_ELEM"}   # the reference throws on these batches too
-LEFT_TO_JS_PATH = {56: "UNSUPPORTED", 911: "UNSUPPORTED"}   # legal, outside the GPU-served subset (counter / value-less row in a list)
+LEFT_TO_JS_PATH = {}   # (rounds 1-4: 56 and 911 -- a counter inside a list; served since round 5)
 SAVE_LEFT_TO_JS_PATH = {82}                                 # replay served, save() refused: a change carries columns the engine does not model
 
 
@@ -124,7 +124,7 @@ def test_engine_emulation_on_a_sample_of_reference_suite_vectors():
     """Every fifth vector (plus all documents, all rejects and every vector the engine is expected to refuse) through the CPU
     emulation of the kernels; the GPU suite runs them all."""
     subprocess.check_call(["make", "-s", "-C", EMU_DIR])
-    special = set(REJECTED_BY_REFERENCE) | set(LEFT_TO_JS_PATH) | SAVE_LEFT_TO_JS_PATH
+    special = set(REJECTED_BY_REFERENCE) | set(LEFT_TO_JS_PATH) | SAVE_LEFT_TO_JS_PATH | {56, 911}   # (56, 911: a counter inside a list)
     sample = [(i, v, b) for i, (v, b) in enumerate(_vectors()) if i % 5 == 0 or v["kind"] != "changes" or i in special]
     eng = engine.Engine(0, os.path.join(EMU_DIR, "libam355_emu.so"))
     try:
@@ -143,6 +143,6 @@ def test_engine_on_every_reference_suite_vector():
         equal, refused, save_refused, loaded = _run_engine(eng, vs)
     finally:
         eng.close()
-    # exactly: the 4 batches the reference rejects, the 2 legal inputs left to the JS path; one save() left to the JS path
+    # exactly: the 4 batches the reference rejects, no legal input left to the JS path; one save() left to the JS path
     _check_refusals(range(len(vs)), refused, save_refused)
-    assert len(equal) == len(vs) - 6 and loaded >= 1400
+    assert len(equal) == len(vs) - 4 and loaded >= 1400
