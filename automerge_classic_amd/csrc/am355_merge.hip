@@ -1154,38 +1154,17 @@ __device__ __forceinline__ uint32_t doc_list_counter_of(const MergeBufs& b, uint
 __global__ __launch_bounds__(BLOCK) void k_doc_resolve(MergeBufs b, const unsigned long long* __restrict__ tab_key, const uint32_t* __restrict__ tab_row,
                                                        uint32_t mask, const uint32_t* __restrict__ ins_ex, uint32_t* __restrict__ obj_first) {
   uint32_t g = gtid();
-  const bool in_range = g < b.n_ops;
+  if (g >= b.n_ops) return;
   const OpCols& o = b.ops;
   uint32_t err = 0;
+  uint8_t kind = b.kind[g];
   uint32_t orow = NONE32;
   bool list_obj = false;
-  {
-    // the rows of one object are contiguous: nearly every row of a wavefront names the same object, so one lane probes the id -> row
-    // table for the wave (a random 16-byte read per ROW was most of this kernel's traffic) and only rows naming another object probe
-    // for themselves
-    const uint32_t oa_ = in_range ? o.obj_actor[g] : NONE32, oc_ = in_range ? o.obj_ctr[g] : 0;
-    const bool has_obj = oa_ != NONE32;
-    const unsigned long long m = __ballot(has_obj);
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint32_t leader = m ? (uint32_t)__ffsll((long long)m) - 1 : 0;
-    const uint32_t la = __shfl(oa_, (int)leader), lc = __shfl(oc_, (int)leader);
-    uint32_t lrow = (m && lane == leader) ? doc_find_make(tab_key, tab_row, mask, pack_id(oc_, oa_)) : NONE32;
-    uint32_t lact = (m && lane == leader && lrow != NONE32) ? o.action[lrow] : 0u;
-    lrow = __shfl(lrow, (int)leader);
-    lact = __shfl(lact, (int)leader);
-    if (has_obj) {
-      uint32_t oact = lact;
-      if (oa_ == la && oc_ == lc) orow = lrow;
-      else {
-        orow = doc_find_make(tab_key, tab_row, mask, pack_id(oc_, oa_));
-        oact = orow != NONE32 ? o.action[orow] : 0u;
-      }
-      if (orow == NONE32) err |= F_UNKNOWN_OBJECT;
-      else list_obj = oact == 2 || oact == 4;
-    }
+  if (o.obj_actor[g] != NONE32) {
+    orow = doc_find_make(tab_key, tab_row, mask, pack_id(o.obj_ctr[g], o.obj_actor[g]));
+    if (orow == NONE32) err |= F_UNKNOWN_OBJECT;
+    else { uint32_t oa = o.action[orow]; list_obj = oa == 2 || oa == 4; }
   }
-  if (!in_range) return;
-  uint8_t kind = b.kind[g];
   if (kind == K_MAP && list_obj) err |= F_UNSUPPORTED;
   if ((kind == K_LIST_INS || kind == K_LIST_UPD) && !list_obj) err |= F_UNSUPPORTED;
   b.obj_row[g] = orow;
@@ -1610,8 +1589,8 @@ void doc_patch(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
     AM355_LAUNCH_INDEPENDENT(k_object_table, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_a, ir);
     exclusive_scan_u32(b.scan_b, b.scan_a, N, &b.counts->n_list_ins, b.scan_ws, st);
     AM355_LAUNCH_INDEPENDENT(k_ins_scatter, grid_for(N), dim3(BLOCK), st, b, (const uint32_t*)b.scan_b, (const uint32_t*)b.scan_a);
-    hipLaunchKernelGGL(k_doc_resolve, grid_for(N), dim3(BLOCK), 0, st, b, (const unsigned long long*)tab_key, (const uint32_t*)tab_row, mask,
-                       (const uint32_t*)b.scan_a, obj_first);  // (wave-level lookup of the object: ballots and shuffles)
+    AM355_LAUNCH_INDEPENDENT(k_doc_resolve, grid_for(N), dim3(BLOCK), st, b, (const unsigned long long*)tab_key, (const uint32_t*)tab_row, mask,
+                             (const uint32_t*)b.scan_a, obj_first);
     AM355_LAUNCH_INDEPENDENT(k_doc_emit, grid_for(N), dim3(BLOCK), st, b, trig_flag, trig_src, edit_flag, vl_first);
     exclusive_scan_u32(trig_flag, b.scan_a, N, &b.counts->n_map_emit, b.scan_ws, st);
     AM355_LAUNCH_INDEPENDENT(k_doc_visflag, grid_for(N), dim3(BLOCK), st, b, b.ins_row, (const uint32_t*)vl_first, edit_flag);  // (may add `remove` edits)
