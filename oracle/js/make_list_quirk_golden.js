@@ -268,7 +268,9 @@ function main() {
           try { const [s2, patch] = Backend.applyChanges(state, batch); state = s2; patches.push(JSON.stringify(patch)) } catch (e) { patches.push({ error: String(e.message) }); break }
           i += k
         }
-        sessions.push({ name: `qdoc:${seed}:${rep}`, doc: b64(doc), calls, patches })
+        // (doc_hashes: the hashes of the document's changes as the reference rebuilds them -- tests/oracle_lib.py OracleSession takes them from here)
+        const docHashes = Buffer.concat(Backend.getAllChanges(Backend.load(doc)).map(c => Buffer.from(columnar.decodeChangeMeta(c, true).hash, 'hex'))).toString('base64')
+        sessions.push({ name: `qdoc:${seed}:${rep}`, doc: b64(doc), doc_hashes: docHashes, calls, patches })
       }
     fs.writeFileSync(process.argv[3], zlib.gzipSync(JSON.stringify({ made_by: 'oracle/js/make_list_quirk_golden.js (unmodified reference, node ' + process.version + ')', pool, sessions })))
     console.error(`${sessions.length} sessions, ${sessions.reduce((x, y) => x + y.calls.length, 0)} calls`)

@@ -112,6 +112,23 @@ def test_whole_document_patch_after_a_session_equals_the_bulk_replay():
     assert done >= 200
 
 
+def test_oracle_follows_the_reference_through_sessions_with_counters_inside_lists():
+    """tests/golden/apply_campaign_quirks.json.gz (oracle/js/make_list_quirk_golden.js): applyChanges sessions of the live reference on lists
+    that hold counters, increments and deleted counters -- from empty documents and onto documents saved and loaded with such lists."""
+    with open(os.path.join(HERE, "golden", "apply_campaign_quirks.json.gz"), "rb") as f:
+        d = json.loads(gzip.decompress(f.read()))
+    pool = [base64.b64decode(x) for x in d["pool"]]
+    equal = 0
+    for s in d["sessions"]:
+        session = oracle_lib.OracleSession(base64.b64decode(s["doc"]), base64.b64decode(s["doc_hashes"])) if "doc" in s else oracle_lib.OracleSession()
+        for ci, (call, want) in enumerate(zip(s["calls"], s["patches"])):
+            assert not isinstance(want, dict), f"{s['name']} call {ci}: the reference rejects this batch"
+            got = session.apply([pool[k] for k in call])
+            assert same_patch(got, want), f"{s['name']} call {ci}:\n{got}\n{want}"
+            equal += 1
+    assert equal == sum(len(s["calls"]) for s in d["sessions"]) >= 450
+
+
 def test_oracle_follows_the_reference_onto_loaded_documents():
     """Backend.load + applyChanges sessions recorded from the live reference (tests/golden/apply_campaign_loaded.json.gz: 48 sessions,
     every one also with the hash graph rebuilt by a query before the first call). A BackendDoc made by load schedules against the

@@ -206,7 +206,7 @@ def test_js_host_reproduces_all_reference_suite_vectors_on_gpu():
     out = subprocess.run([NODE, os.path.join(JS, "test_vectors.js")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res["failed"] == 0 and res["vectors"] >= 1499 and res["equal"] >= 1490 and res["rejected"] == [14, 16, 25, 33] and res["unsupported"] == [56, 911]
+    assert res["failed"] == 0 and res["vectors"] >= 1499 and res["equal"] >= 1490 and res["rejected"] == [14, 16, 25, 33] and res["unsupported"] == []   # (56, 911 -- a counter inside a list -- are served since round 5)
 
 
 @pytest.mark.skipif(NODE is None, reason="node not installed")
