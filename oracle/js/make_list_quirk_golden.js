@@ -214,7 +214,7 @@ function main() {
   const cases = []
   const hc = handCases()
   for (const k of Object.keys(hc)) cases.push(record('hand_' + k, hc[k]))
-  const specs = [
+  let specs = [
     [11, 2, 6, { opsPerChange: 3, pInsert: 0.35, pInc: 0.35, pSet: 0.15, pCounter: 0.7, pDelInc: 0 }],
     [12, 3, 8, { opsPerChange: 4, pInsert: 0.3, pInc: 0.4, pSet: 0.15, pCounter: 0.6, pDelInc: 0 }],
     [13, 3, 10, { opsPerChange: 5, pInsert: 0.45, pInc: 0.25, pSet: 0.1, pCounter: 0.4, pDelInc: 0 }],
@@ -222,8 +222,17 @@ function main() {
     [15, 2, 12, { opsPerChange: 6, pInsert: 0.5, pInc: 0.3, pSet: 0.1, pCounter: 0.3, pDelInc: 0, text: true }],
     [16, 5, 6, { opsPerChange: 3, pInsert: 0.25, pInc: 0.45, pSet: 0.15, pCounter: 0.8, pDelInc: 0.2 }]
   ]
-  for (let rep = 0; rep < 6; rep++)
-    for (const [seed, a, r, o] of specs) cases.push(record(`gen_${seed}_${rep}`, scenario(seed * 1000 + rep, a, r, o)))
+  if (process.env.QUIRK_WILD) {   // (campaigns only: deletions that name increments, many assignments over counters, long sessions)
+    specs.length = 0
+    specs.push([21, 3, 10, { opsPerChange: 4, pInsert: 0.2, pInc: 0.3, pSet: 0.25, pCounter: 0.7, pDelInc: 0.7 }],
+      [22, 6, 8, { opsPerChange: 6, pInsert: 0.25, pInc: 0.35, pSet: 0.2, pCounter: 0.9, pDelInc: 0.5 }],
+      [23, 2, 30, { opsPerChange: 8, pInsert: 0.3, pInc: 0.4, pSet: 0.1, pCounter: 0.5, pDelInc: 0.2 }],
+      [24, 4, 12, { opsPerChange: 5, pInsert: 0.15, pInc: 0.5, pSet: 0.3, pCounter: 0.6, pDelInc: 0.4, text: true }])
+  }
+  // (QUIRK_SEED_BASE / QUIRK_REPS: a differential campaign with other seeds -- not the committed fixture)
+  const seedBase = parseInt(process.env.QUIRK_SEED_BASE || '0'), reps = parseInt(process.env.QUIRK_REPS || '6')
+  for (let rep = 0; rep < reps; rep++)
+    for (const [seed, a, r, o] of specs) cases.push(record(`gen_${seed}_${rep}`, scenario(seedBase + seed * 1000 + rep, a, r, o)))
   // the same generated logs as sessions of Backend.applyChanges calls (a few changes per call): the patches of the live reference, in the
   // format of tests/golden/apply_campaign*.json.gz -- what the engine's incremental path must equal or refuse (counters inside lists in an
   // INCREMENTAL patch are left to the JS path; everything else of such a session is served)
@@ -231,10 +240,10 @@ function main() {
     const zlib = require('zlib')
     const pool = [], sessions = []
     const rnd = splitmix(99)
-    for (let rep = 0; rep < 4; rep++)
+    for (let rep = 0; rep < (process.env.QUIRK_REPS ? reps : 4); rep++)
       for (const [seed, a, r, o] of specs) {
         const o2 = Object.assign({}, o, { pInc: o.pInc * (rep % 2 ? 0.3 : 1), pCounter: o.pCounter * (rep % 2 ? 0.5 : 1) })
-        const bin = scenario(seed * 7000 + rep, a, r + 4, o2).map(encodeChange)
+        const bin = scenario(seedBase + seed * 7000 + rep, a, r + 4, o2).map(encodeChange)
         const calls = [], patches = []
         let state = Backend.init(), i = 0
         while (i < bin.length) {
@@ -248,14 +257,14 @@ function main() {
       }
     // sessions onto LOADED documents that hold counters / rows without a value in their lists: the first rounds (with increments) are
     // saved and loaded by the reference, the later rounds (plain values on other elements) arrive in calls
-    for (let rep = 0; rep < 3; rep++)
+    for (let rep = 0; rep < (process.env.QUIRK_REPS ? reps : 3); rep++)
       for (const [seed, a, r, o] of specs) {
         const o2 = Object.assign({}, o, { quirkRounds: r })
-        const all = scenario(seed * 9000 + rep, a, r + 6, o2)
+        const all = scenario(seedBase + seed * 9000 + rep, a, r + 6, o2)
         let nDoc = 0
         { // changes of the first r rounds: everything before the first change whose deps name a change of round r
           const o3 = Object.assign({}, o, { quirkRounds: r })
-          nDoc = scenario(seed * 9000 + rep, a, r, o3).length
+          nDoc = scenario(seedBase + seed * 9000 + rep, a, r, o3).length
         }
         const bin = all.map(encodeChange)
         const doc = Backend.save(Backend.loadChanges(Backend.init(), bin.slice(0, nDoc)))
