@@ -142,6 +142,9 @@ int assemble_apply_patch(const am355_patch_ir& whole, const ObjLink* link, const
                 const am355_ir_edit& ed = whole.edits[r];
                 if (ed.elem_ctr != L.elem_ctr || ed.elem_actor != L.elem_actor || (ed.flags & AM355_EDIT_CONT)) break;
                 if (r > hit->second && !(ed.flags & AM355_EDIT_UPDATE)) break;
+                // (an element that holds a counter completed by increments, or shows rows without a value: what objectMeta.children
+                // lists for it -- the counter's `set` value, not its total, new.js:919-926 -- is not restated)
+                if (ed.flags & (AM355_EDIT_COUNTER | AM355_EDIT_REMOVE)) return refuse_history();
                 am355_ir_edit u = ed;
                 u.flags = AM355_EDIT_UPDATE | (ed.flags & AM355_EDIT_CHILD);
                 any_child = any_child || (ed.flags & AM355_EDIT_CHILD);

@@ -71,6 +71,8 @@ struct DeltaBufs {
   // rows: first_del / new_succ per VALUE row (first row of the batch that overwrites or deletes it, how many do); upd_*: the
   // assignment rows (K_LIST_UPD) of every list element, grouped by element
   uint32_t *first_del, *new_succ, *upd_n, *pos_of;    // [N + 1]
+  uint32_t *first_kill;                               // [N + 1] first row of the batch that names the row as pred and is NOT an increment of the
+                                                      // counter the row sets (an increment does not take a counter away: new.js:937-965)
   uint32_t *upd_off, *upd_cur, *upd_rows;             // [N + 2]
   // per new row that deletes from or assigns to a list element: what the patch shows for it (EV_*), was the element visible before
   // it, how many values it shows afterwards

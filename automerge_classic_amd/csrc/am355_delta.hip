@@ -58,7 +58,7 @@ static uint32_t key_table_cap(uint32_t n_new) {
 size_t delta_bytes(uint32_t N, uint32_t NN, uint32_t NM, uint32_t NO, uint32_t NL) {
   size_t cap = key_table_cap(NN);
   size_t b = al256(sizeof(DeltaCounts)) + al256(sizeof(ObjLink) * ((size_t)NO + 1));
-  b += 4 * al256(4 * ((size_t)N + 1)) + 3 * al256(4 * ((size_t)N + 2));
+  b += 5 * al256(4 * ((size_t)N + 1)) + 3 * al256(4 * ((size_t)N + 2));
   b += 5 * al256(4 * ((size_t)NL + 2));
   b += 3 * al256(4 * ((size_t)NN + 1));
   b += 10 * al256(4 * ((size_t)NN + 2)) + 4 * al256(4 * ((size_t)NN + 3)) + 6 * al256(4 * ((size_t)NN + 2)) + al256(sizeof(am355_ir_edit) * ((size_t)NN + 2));
@@ -85,9 +85,13 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   d.key_mask = (uint32_t)cap - 1;
   d.counts = dcarve<DeltaCounts>(p, 1);
   d.link = dcarve<ObjLink>(p, (size_t)NO + 1);
-  d.first_del = dcarve<uint32_t>(p, (size_t)N + 1); d.new_succ = dcarve<uint32_t>(p, (size_t)N + 1);
-  d.upd_n = dcarve<uint32_t>(p, (size_t)N + 1); d.pos_of = dcarve<uint32_t>(p, (size_t)N + 1);
-  d.upd_off = dcarve<uint32_t>(p, (size_t)N + 2); d.upd_cur = dcarve<uint32_t>(p, (size_t)N + 2); d.upd_rows = dcarve<uint32_t>(p, (size_t)N + 2);
+  // (first_del | first_kill are filled with ones, new_succ | upd_n | upd_cur cleared: neighbours, one fill each -- delta_run)
+  d.first_del = dcarve<uint32_t>(p, (size_t)N + 1); d.first_kill = dcarve<uint32_t>(p, (size_t)N + 1);
+  d.new_succ = dcarve<uint32_t>(p, (size_t)N + 1); d.upd_n = dcarve<uint32_t>(p, (size_t)N + 1); d.upd_cur = dcarve<uint32_t>(p, (size_t)N + 2);
+  d.pos_of = dcarve<uint32_t>(p, (size_t)N + 1);
+  d.upd_off = dcarve<uint32_t>(p, (size_t)N + 2); d.upd_rows = dcarve<uint32_t>(p, (size_t)N + 2);
+  canary_allow(d.first_del, (size_t)((uint8_t*)(d.first_kill + N + 1) - (uint8_t*)d.first_del));
+  canary_allow(d.new_succ, (size_t)((uint8_t*)(d.upd_cur + N + 2) - (uint8_t*)d.new_succ));
   d.ev_kind = dcarve<uint32_t>(p, (size_t)NN + 1); d.ev_before = dcarve<uint32_t>(p, (size_t)NN + 1); d.ev_nafter = dcarve<uint32_t>(p, (size_t)NN + 1);
   d.v0 = dcarve<uint32_t>(p, (size_t)NL + 2); d.icnt = dcarve<uint32_t>(p, (size_t)NL + 2);
   d.v0_ex = dcarve<uint32_t>(p, (size_t)NL + 2); d.item_ex = dcarve<uint32_t>(p, (size_t)NL + 2); d.icur = dcarve<uint32_t>(p, (size_t)NL + 2);
@@ -191,6 +195,22 @@ __global__ __launch_bounds__(BLOCK) void kd_touch(MergeBufs b, DeltaBufs d) {
   }
 }
 
+// The counter an increment feeds: among its preds the counter `set` with the greatest id (counterStates[succOp] = counterState, the
+// later assignment wins: new.js:944-950; k_resolve counts the increment for that row in inc_cnt / inc_sum). NONE32: none.
+__device__ __forceinline__ uint32_t inc_counter_of(const MergeBufs& b, uint32_t g) {
+  const OpCols& o = b.ops;
+  uint32_t fed = NONE32;
+  unsigned long long best = 0;
+  for (uint32_t k = 0; k < o.pred_num[g]; k++) {
+    const uint32_t pa = o.pred_actor[o.pred_first[g] + k], pc = o.pred_ctr[o.pred_first[g] + k];
+    const uint32_t r = row_of(b, pa, pc);
+    if (r == NONE32 || r >= g || o.action[r] != 1 || (o.val_tl[r] & 15) != 8) continue;
+    const unsigned long long id = pack_id(pc, pa);
+    if (fed == NONE32 || id > best) { fed = r; best = id; }
+  }
+  return fed;
+}
+
 __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
   uint32_t g = gtid();
   if (g >= b.n_ops) return;
@@ -203,11 +223,11 @@ __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
   const OpCols& o = b.ops;
   uint32_t err = 0;
   if (kind == K_FOREIGN) err |= refuse(d, DR_FOREIGN_ROW);
-  // a new list row that is neither a value, a child object nor a deletion (an increment, a link): the reference's counter states and
-  // `remove` rule in an incremental patch are not restated here (the whole-document patch serves them, k_quirk_rows)
+  // a new list row that is neither a value, a child object, a deletion nor an increment of a counter (a link, an unknown action): not
+  // restated here (the whole-document patch serves them, k_quirk_rows)
   if (kind == K_LIST_INS || kind == K_LIST_INS_VIS || kind == K_LIST_UPD) {
     const uint32_t a = o.action[g];
-    if (!(a == 1 || ((a & 1u) == 0 && a < 7))) err |= refuse(d, DR_ELEM_NOT_PLAIN);
+    if (!(a == 1 || ((a & 1u) == 0 && a < 7) || (a == 5 && kind == K_LIST_UPD))) err |= refuse(d, DR_ELEM_NOT_PLAIN);  // (increments: kd_events)
   }
   if (kind != K_NONE && kind != K_FOREIGN) {
     if (kind == K_MAP || (kind == K_DEL && o.key_len[g] != NONE32)) {
@@ -215,13 +235,17 @@ __global__ __launch_bounds__(BLOCK) void kd_rows(MergeBufs b, DeltaBufs d) {
       if (s == NONE32) err |= refuse(d, DR_KEY_TABLE);
       else { atomicMin(&d.slot_first[s], g); atomicMax(&d.slot_last[s], g); }
     } else if (kind == K_DEL || kind == K_LIST_UPD) {
-      // every value row this op overwrites or deletes: how many rows of the batch do so, and which is the first
+      // every value row this op overwrites or deletes: how many rows of the batch do so, and which is the first. An increment does
+      // not take the counter it feeds away (first_kill: the first successor that does); first_del / new_succ count every successor,
+      // as the reference's succNum does
       if (b.ref_row[g] == NONE32) err |= F_BAD_ELEM;
+      const uint32_t fed = o.action[g] == 5 ? inc_counter_of(b, g) : NONE32;
       for (uint32_t k = 0; k < o.pred_num[g]; k++) {
         uint32_t r = row_of(b, o.pred_actor[o.pred_first[g] + k], o.pred_ctr[o.pred_first[g] + k]);
         if (r == NONE32 || r >= g) { err |= F_BAD_ELEM; continue; }
         atomicAdd(&d.new_succ[r], 1u);
         atomicMin(&d.first_del[r], g);
+        if (r != fed) atomicMin(&d.first_kill[r], g);
       }
     }
   }
@@ -255,6 +279,76 @@ __device__ __forceinline__ void elem_state(const MergeBufs& b, const DeltaBufs& 
     uint32_t dies = d.first_del[r];
     if (r < g && dies >= g) before++;
     if (dies > g) after++;
+  }
+}
+
+// ---- elements that hold counters (new.js:937-965) ----------------------------------------------------------------------------
+// A counter `set` stays a value of its element while every successor it has is an increment that feeds it; it then shows its
+// total, and stands among the element's values where its LAST increment stands (the reference lists it when it visits that row).
+// Times are row numbers: "at tau" = rows < tau, as they stand when row tau is about to be applied.
+constexpr uint32_t QUIRK_ROWS_MAX = 64;  // rows of an element with increments this stage walks (quadratic: more are refused)
+
+__device__ __forceinline__ bool is_value_action(uint32_t a) { return a == 1 || ((a & 1u) == 0 && a < 7); }
+__device__ __forceinline__ uint32_t elem_row(const DeltaBufs& d, uint32_t e, uint32_t q) { return q == 0 ? e : d.upd_rows[d.upd_off[e] + q - 1]; }
+
+// does the element hold an increment (at any time)?  (its rows: the insert row and the K_LIST_UPD rows, kd_upd_scatter)
+__device__ __forceinline__ bool elem_has_inc(const MergeBufs& b, const DeltaBufs& d, uint32_t e) {
+  const uint32_t nu = d.upd_n[e];
+  for (uint32_t q = 0; q <= nu; q++)
+    if (b.ops.action[elem_row(d, e, q)] == 5) return true;
+  return false;
+}
+
+// value row r of element e at tau: still a value?  *key: where it stands among the element's values (op id; a counter: the id of its
+// last increment before tau), *total: a counter's total at tau (valid when *is_total)
+__device__ bool quirk_value_at(const MergeBufs& b, const DeltaBufs& d, uint32_t e, uint32_t r, uint32_t tau, unsigned long long* key, long long* total,
+                               bool* is_total) {
+  const OpCols& o = b.ops;
+  if (r >= tau || !is_value_action(o.action[r])) return false;
+  if (key) *key = pack_id(o.id_ctr[r], o.id_actor[r]);
+  if (is_total) *is_total = false;
+  if (o.action[r] != 1 || (o.val_tl[r] & 15) != 8 || b.succ_cnt[r] == 0) return alive_at_T0(b, d, r) && d.first_del[r] >= tau;
+  // a counter with successors: the increments that feed it, old and new (the element's rows hold them all)
+  const uint32_t nu = d.upd_n[e];
+  uint32_t new_incs = 0, incs_before = 0;
+  long long sum = 0;
+  unsigned long long last = 0;
+  for (uint32_t q = 1; q <= nu; q++) {
+    const uint32_t r2 = elem_row(d, e, q);
+    if (o.action[r2] != 5 || inc_counter_of(b, r2) != r) continue;
+    if (r2 >= d.T0) new_incs++;
+    if (r2 < tau) {
+      incs_before++;
+      long long v = 0;
+      (void)int_value(b, r2, v);
+      sum += v;
+      const unsigned long long id = pack_id(o.id_ctr[r2], o.id_actor[r2]);
+      last = id > last ? id : last;
+    }
+  }
+  // successors before the batch that are not its increments: all of them, less the increments, less what the batch adds
+  const uint32_t old_other = (b.succ_cnt[r] - d.new_succ[r]) - (b.inc_cnt[r] - new_incs);
+  if (old_other != 0 || d.first_kill[r] < tau) return false;
+  if (incs_before) {
+    if (key && last > *key) *key = last;
+    if (total) { long long base = 0; (void)int_value(b, r, base); *total = base + sum; }
+    if (is_total) *is_total = true;
+  }
+  return true;
+}
+
+// values the element shows at tau, whether any of its rows is without successor at tau (what the reference counts as a visible
+// element, new.js:1626 / seekToOp), whether it holds a row this stage does not model (a link, an unknown action)
+__device__ void quirk_elem_state(const MergeBufs& b, const DeltaBufs& d, uint32_t e, uint32_t tau, uint32_t& n_vals, bool& raw_vis, bool& weird) {
+  n_vals = 0; raw_vis = false; weird = false;
+  const uint32_t nu = d.upd_n[e];
+  for (uint32_t q = 0; q <= nu; q++) {
+    const uint32_t r = elem_row(d, e, q);
+    const uint32_t a = b.ops.action[r];
+    if (a != 5 && !is_value_action(a)) weird = true;
+    if (r >= tau) continue;
+    if (alive_at_T0(b, d, r) && d.first_del[r] >= tau) raw_vis = true;
+    if (quirk_value_at(b, d, e, r, tau, nullptr, nullptr, nullptr)) n_vals++;
   }
 }
 
@@ -309,16 +403,25 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
     const OpCols& o = b.ops;
     uint32_t e = b.ref_row[g];
     const uint32_t nu = d.upd_n[e];
-    if (nu > ELEM_ROWS_MAX) err |= refuse(d, DR_ELEM_ROWS);
+    const bool quirk = nu <= ELEM_ROWS_MAX && elem_has_inc(b, d, e);  // the element holds increments: counter rules (quirk_elem_state)
+    if (nu > ELEM_ROWS_MAX || (quirk && nu + 1 > QUIRK_ROWS_MAX)) err |= refuse(d, DR_ELEM_ROWS);
     else {
-      elem_state(b, d, e, g, before, after);
+      if (quirk) {
+        // Served when the two notions of "the element is visible" agree before and after the op -- the reference counts an element as
+        // visible when any of its rows has no successor (list indexes), and reports insert / remove / update by the values it lists;
+        // they part when a deleted counter still has increments, or when every increment of a counter has been deleted (a `remove`
+        // edit for an element that stays, a value of an element that does not count: left to the JS path)
+        bool raw_b, raw_a, weird_b, weird_a;
+        quirk_elem_state(b, d, e, g, before, raw_b, weird_b);
+        quirk_elem_state(b, d, e, g + 1, after, raw_a, weird_a);
+        if (weird_b || weird_a || raw_b != (before != 0) || raw_a != (after != 0)) err |= refuse(d, DR_ELEM_NOT_PLAIN);
+      } else elem_state(b, d, e, g, before, after);
       ev = before ? (after ? EV_UPDATE : EV_REMOVE) : (after ? EV_INSERT : EV_NONE);
-      if (nu > 0) {  // (the element holds assignment rows, old or new)
-        // values are `set` rows and make rows (child objects); anything else (inc, link, unknown actions) is not restated
-        auto is_value = [&](uint32_t r) { uint32_t a = o.action[r]; return a == 1 || ((a & 1u) == 0 && a < 7); };
-        bool plain = is_value(e);
-        for (uint32_t k = 0; k < nu; k++) plain = plain && is_value(d.upd_rows[d.upd_off[e] + k]);
-        if (!plain) err |= refuse(d, DR_ELEM_NOT_PLAIN);  // child objects / counters among the values: objectMeta bookkeeping, counter states
+      if (nu > 0 && !quirk) {  // (the element holds assignment rows, old or new)
+        // values are `set` rows and make rows (child objects); anything else (link, unknown actions) is not restated
+        bool plain = is_value_action(o.action[e]);
+        for (uint32_t k = 0; k < nu; k++) plain = plain && is_value_action(o.action[d.upd_rows[d.upd_off[e] + k]]);
+        if (!plain) err |= refuse(d, DR_ELEM_NOT_PLAIN);
       }
       // ---- does the op continue the merge call of the previous op of the stream? ----
       bool first_of_pass = g == d.T0;
@@ -332,8 +435,14 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
             overwrites = overwrites || (o.pred_ctr[o.pred_first[g] + k] == o.id_ctr[g - 1] && o.pred_actor[o.pred_first[g] + k] == o.id_actor[g - 1]);
           if (!overwrites) err |= refuse(d, DR_SAME_ELEM_CALL);
         } else if (d.upd_n[a] <= ELEM_ROWS_MAX) {
-          uint32_t a_before, a_after;
-          elem_state(b, d, a, g - 1, a_before, a_after);
+          uint32_t a_before = 0, a_after = 0;
+          if (elem_has_inc(b, d, a)) {
+            // (an element with increments: its values after row g - 1; the thread of that row has checked that they say the same as
+            // the reference's own count of visible elements)
+            bool raw_vis, weird;
+            if (d.upd_n[a] + 1 > QUIRK_ROWS_MAX) err |= refuse(d, DR_ELEM_ROWS);
+            else quirk_elem_state(b, d, a, g, a_after, raw_vis, weird);
+          } else elem_state(b, d, a, g - 1, a_before, a_after);
           const bool ins_row_visible = e < g && alive_at_T0(b, d, e) && d.first_del[e] >= g;  // the insert row held a visible value
           if (a_after > 0 && ins_row_visible) {
             // was e the element right behind a when the op was applied? (elements inserted later may stand between them now)
@@ -631,7 +740,31 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, 
       // the element's visible values after row g, ascending by op id
       const uint32_t nu = d.upd_n[e], base = d.upd_off[e];
       unsigned long long last = 0;
-      for (uint32_t j = 0; j < recs; j++) {
+      const bool quirk = elem_has_inc(b, d, e);
+      for (uint32_t j = 0; quirk && j < recs; j++) {
+        // (an element with increments: a counter stands where its last increment stands and shows its total, quirk_value_at)
+        unsigned long long best = ~0ull;
+        uint32_t best_r = NONE32;
+        long long best_total = 0;
+        bool best_is_total = false;
+        for (uint32_t q = 0; q <= nu; q++) {
+          const uint32_t r = elem_row(d, e, q);
+          unsigned long long key = 0;
+          long long total = 0;
+          bool is_total = false;
+          if (!quirk_value_at(b, d, e, r, v.g + 1, &key, &total, &is_total)) continue;
+          if (key > last && key < best) { best = key; best_r = r; best_total = total; best_is_total = is_total; }
+        }
+        if (best_r == NONE32) { atomicOr(&d.counts->flags, refuse(d, DR_INTERNAL)); break; }
+        last = best;
+        uint32_t rf = (j == 0 && (f & 0x1000u)) ? 0u : (uint32_t)AM355_EDIT_UPDATE;
+        const bool child = (o.action[best_r] & 1u) == 0;
+        if (child) rf |= AM355_EDIT_CHILD;
+        uint32_t val = child ? b.obj_index[best_r] : o.val_off[best_r], val_hi = 0;
+        if (best_is_total) { rf |= AM355_EDIT_COUNTER; val = (uint32_t)(unsigned long long)best_total; val_hi = (uint32_t)((unsigned long long)best_total >> 32); }
+        d.edit[k + j] = am355_ir_edit{rf, v.idx, o.id_ctr[best_r], o.id_actor[best_r], o.id_ctr[e], o.id_actor[e], first + j, o.val_tl[best_r], val, val_hi};
+      }
+      for (uint32_t j = 0; !quirk && j < recs; j++) {
         unsigned long long best = ~0ull;
         uint32_t best_r = NONE32;
         for (uint32_t q = 0; q <= nu; q++) {
@@ -815,10 +948,8 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   };
   (void)hipMemsetAsync(d.counts, 0, sizeof(DeltaCounts), st);
   (void)hipMemsetAsync(&d.counts->reason, 0xff, 4, st);
-  (void)hipMemsetAsync(d.first_del, 0xff, 4 * ((size_t)N + 1), st);
-  (void)hipMemsetAsync(d.new_succ, 0, 4 * ((size_t)N + 1), st);
-  (void)hipMemsetAsync(d.upd_n, 0, 4 * ((size_t)N + 1), st);
-  (void)hipMemsetAsync(d.upd_cur, 0, 4 * ((size_t)N + 1), st);
+  (void)hipMemsetAsync(d.first_del, 0xff, (size_t)((uint8_t*)(d.first_kill + N + 1) - (uint8_t*)d.first_del), st);   // first_del | first_kill
+  (void)hipMemsetAsync(d.new_succ, 0, (size_t)((uint8_t*)(d.upd_cur + N + 2) - (uint8_t*)d.new_succ), st);           // new_succ | upd_n | upd_cur
   (void)hipMemsetAsync(d.icur, 0, 4 * ((size_t)d.n_list + 2), st);
   (void)hipMemsetAsync(d.slot_rep, 0, 4 * ((size_t)cap + 1), st);
   (void)hipMemsetAsync(d.slot_first, 0xff, 4 * ((size_t)cap + 1), st);

@@ -66,4 +66,24 @@ __device__ __forceinline__ uint32_t value_class(uint32_t tl) {
   return 16 + tag;
 }
 
+// sLEB / uLEB value of an integer-typed op value (tags 3 uint, 4 int, 8 counter, 9 timestamp); columnar.js:300-329
+__device__ __forceinline__ bool int_value(const MergeBufs& b, uint32_t row, long long& out) {
+  uint32_t tl = b.ops.val_tl[row], tag = tl & 15, len = tl >> 4;
+  if (!(tag == 3 || tag == 4 || tag == 8 || tag == 9) || len == 0 || len > 10) return false;
+  const uint8_t* p = b.arena + b.ops.val_off[row];
+  unsigned long long v = 0;
+  int shift = 0;
+  for (uint32_t k = 0; k < len; k++) {
+    uint32_t byte = p[k];
+    v |= (unsigned long long)(byte & 0x7f) << shift;
+    shift += 7;
+    if (!(byte & 0x80)) {
+      if (tag != 3 && (byte & 0x40) && shift < 64) v |= ~0ull << shift;
+      out = (long long)v;
+      return true;
+    }
+  }
+  return false;
+}
+
 }  // namespace am355
