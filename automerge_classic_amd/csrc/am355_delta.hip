@@ -106,9 +106,12 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   d.e_val = dcarve<uint32_t>(p, (size_t)NN + 2); d.e_val_ex = dcarve<uint32_t>(p, (size_t)NN + 2);
   d.edit = dcarve<am355_ir_edit>(p, (size_t)NN + 2);
   d.edit_cap = NN + 2;
-  d.slot_rep = dcarve<uint32_t>(p, cap + 1); d.slot_first = dcarve<uint32_t>(p, cap + 1); d.slot_last = dcarve<uint32_t>(p, cap + 1);
-  d.slot_cont = dcarve<uint32_t>(p, cap + 1); d.slot_cnt = dcarve<uint32_t>(p, cap + 1); d.slot_child = dcarve<uint32_t>(p, cap + 1);
-  d.slot_drop = dcarve<uint32_t>(p, cap + 1); d.place = dcarve<uint32_t>(p, cap + 1); d.place_ex = dcarve<uint32_t>(p, cap + 1);
+  // (slot_rep | slot_last | slot_cnt | slot_child | slot_drop are cleared by one fill: neighbours)
+  d.slot_rep = dcarve<uint32_t>(p, cap + 1); d.slot_last = dcarve<uint32_t>(p, cap + 1); d.slot_cnt = dcarve<uint32_t>(p, cap + 1);
+  d.slot_child = dcarve<uint32_t>(p, cap + 1); d.slot_drop = dcarve<uint32_t>(p, cap + 1);
+  canary_allow(d.slot_rep, (size_t)((uint8_t*)(d.slot_drop + cap + 1) - (uint8_t*)d.slot_rep));
+  d.slot_first = dcarve<uint32_t>(p, cap + 1); d.slot_cont = dcarve<uint32_t>(p, cap + 1);
+  d.place = dcarve<uint32_t>(p, cap + 1); d.place_ex = dcarve<uint32_t>(p, cap + 1);
   d.slot_L = dcarve<unsigned long long>(p, cap);
   d.keep = dcarve<uint32_t>(p, (size_t)NM + 1); d.keep_ex = dcarve<uint32_t>(p, (size_t)NM + 1); d.rec_slot = dcarve<uint32_t>(p, (size_t)NM + 1);
   for (int k = 0; k < 2; k++) { d.pair_key[k] = dcarve<uint64_t>(p, (size_t)NM + cap + 1); d.pair_val[k] = dcarve<uint32_t>(p, (size_t)NM + cap + 1); }
@@ -951,12 +954,8 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   (void)hipMemsetAsync(d.first_del, 0xff, (size_t)((uint8_t*)(d.first_kill + N + 1) - (uint8_t*)d.first_del), st);   // first_del | first_kill
   (void)hipMemsetAsync(d.new_succ, 0, (size_t)((uint8_t*)(d.upd_cur + N + 2) - (uint8_t*)d.new_succ), st);           // new_succ | upd_n | upd_cur
   (void)hipMemsetAsync(d.icur, 0, 4 * ((size_t)d.n_list + 2), st);
-  (void)hipMemsetAsync(d.slot_rep, 0, 4 * ((size_t)cap + 1), st);
+  (void)hipMemsetAsync(d.slot_rep, 0, (size_t)((uint8_t*)(d.slot_drop + cap + 1) - (uint8_t*)d.slot_rep), st);  // slot_rep | slot_last | slot_cnt | slot_child | slot_drop
   (void)hipMemsetAsync(d.slot_first, 0xff, 4 * ((size_t)cap + 1), st);
-  (void)hipMemsetAsync(d.slot_last, 0, 4 * ((size_t)cap + 1), st);
-  (void)hipMemsetAsync(d.slot_cnt, 0, 4 * ((size_t)cap + 1), st);
-  (void)hipMemsetAsync(d.slot_child, 0, 4 * ((size_t)cap + 1), st);
-  (void)hipMemsetAsync(d.slot_drop, 0, 4 * ((size_t)cap + 1), st);
   AM355_LAUNCH_INDEPENDENT(kd_objects, dgrid(d.n_obj), dim3(BLOCK), st, b, ir, d);
   step("objects");
   if (N) AM355_LAUNCH_INDEPENDENT(kd_rows, dgrid(N), dim3(BLOCK), st, b, d);
