@@ -981,7 +981,8 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   step("positions");
   if (d.n_new) AM355_LAUNCH_INDEPENDENT(kd_events, dgrid(d.n_new), dim3(BLOCK), st, b, d);
   step("events");
-  exclusive_scan2_u32(d.v0, d.v0_ex, nullptr, d.icnt, d.item_ex, nullptr, d.n_list + 1, d.scan_ws, st);
+  // (the totals the host sizes the second half from -- items, kept map records, placeholders -- are written by the scans themselves)
+  exclusive_scan2_u32(d.v0, d.v0_ex, nullptr, d.icnt, d.item_ex, &d.counts->n_items, d.n_list + 1, d.scan_ws, st);
   step("scan positions");
   if (d.n_new && d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items, dgrid(d.n_new), dim3(BLOCK), st, b, d);
   if (d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items_sort, dgrid(d.n_list), dim3(BLOCK), st, d);
@@ -993,12 +994,9 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   step("map records");
   AM355_LAUNCH_INDEPENDENT(kd_placeholders, dgrid(cap + 1), dim3(BLOCK), st, d);
   step("placeholders");
-  exclusive_scan_u32(d.keep, d.keep_ex, d.n_map + 1, nullptr, d.scan_ws, st);
-  exclusive_scan_u32(d.place, d.place_ex, cap + 1, nullptr, d.scan_ws, st);
+  exclusive_scan_u32(d.keep, d.keep_ex, d.n_map + 1, &d.counts->n_kept, d.scan_ws, st);
+  exclusive_scan_u32(d.place, d.place_ex, cap + 1, &d.counts->n_place, d.scan_ws, st);
   step("scans");
-  (void)hipMemcpyAsync(&d.counts->n_items, d.item_ex + d.n_list, 4, hipMemcpyDeviceToDevice, st);
-  (void)hipMemcpyAsync(&d.counts->n_kept, d.keep_ex + d.n_map, 4, hipMemcpyDeviceToDevice, st);
-  (void)hipMemcpyAsync(&d.counts->n_place, d.place_ex + cap, 4, hipMemcpyDeviceToDevice, st);
   (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
   if (hc->flags || check_only) return;
