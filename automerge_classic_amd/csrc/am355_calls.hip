@@ -110,9 +110,19 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   d.breaks = c->d_breaks.as<uint32_t>();
   d.breaks_exact = c->breaks_exact ? 1u : 0u;
   d.T_doc = c->no_history && c->doc_rows_known ? (uint32_t)c->doc_rows : 0u;
-  if (!breaks.empty()) HIPCHK(c, hipMemcpyAsync(c->d_breaks.p, breaks.data(), 4 * breaks.size(), hipMemcpyHostToDevice, st));
-  if (d.n_pass) HIPCHK(c, hipMemcpyAsync(c->d_pass.p, pass_rows.data(), 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipStreamSynchronize(st));  // (pageable sources)
+  // (from pinned memory: no bounce through the driver and no wait -- the tables are read by kernels enqueued behind these copies, and
+  // the pinned words are only rewritten by the next stage, which starts after this one has drained the stream)
+  if (!c->h_delta_tabs.ensure(4 * (breaks.size() + pass_rows.size() + 2))) return fail(c, AM355_E_NOMEM, "host allocation failed (delta)");
+  uint32_t* h_breaks = c->h_delta_tabs.as<uint32_t>();
+  uint32_t* h_pass = h_breaks + breaks.size();
+  if (!breaks.empty()) {
+    memcpy(h_breaks, breaks.data(), 4 * breaks.size());
+    HIPCHK(c, hipMemcpyAsync(c->d_breaks.p, h_breaks, 4 * breaks.size(), hipMemcpyHostToDevice, st));
+  }
+  if (d.n_pass) {
+    memcpy(h_pass, pass_rows.data(), 4 * pass_rows.size());
+    HIPCHK(c, hipMemcpyAsync(c->d_pass.p, h_pass, 4 * pass_rows.size(), hipMemcpyHostToDevice, st));
+  }
   auto grow = [](void* user, size_t records) -> am355_ir_edit* {
     am355_ctx* cx = (am355_ctx*)user;
     return cx->d_delta_edit.ensure(sizeof(am355_ir_edit) * records) ? cx->d_delta_edit.as<am355_ir_edit>() : nullptr;

@@ -443,6 +443,7 @@ struct am355_ctx {
   bool doc_rows_known = false;
   bool no_history = false;  // the staged changes are the rebuilt history of a LOADED document: the reference's objectMeta came from one pass over the document
   DevBuf d_breaks;
+  HostBuf h_delta_tabs;  // pinned: stream breaks | pass rows of a delta stage on their way to the device (run_delta_stage)
   bool state_checked = false;  // the state was built by am355_apply_changes calls (each checked for what later patches depend on) or is empty
   std::string apply_json;
 
