@@ -397,6 +397,34 @@ __device__ __forceinline__ bool list_elem_op(const MergeBufs& b, uint32_t g) {
 // others not is refused.
 constexpr uint32_t GAP_WALK_MAX = 4096;  // later insertions between two elements this stage walks over to decide whether they were neighbours
 
+// Several ops of one change on ONE list element share a merge call -- and one visit of the element, one edit -- unless a later one
+// overwrites an earlier one of them (new.js:1092-1118): `del x; set x` arrives as one `update`, not as remove + insert. Such a RUN of
+// consecutive rows reports through its last row, with the element's state before its first row and after its last.
+constexpr uint32_t RUN_ROWS_MAX = 64;  // rows of one run this stage walks (more: refused)
+
+__device__ __forceinline__ bool first_row_of_pass(const DeltaBufs& d, uint32_t g) {
+  bool first = g == d.T0;
+  for (uint32_t k = 0; k < d.n_pass; k++) first = first || d.pass_rows[k] == g;
+  return first;
+}
+// row x could continue the merge call of row x - 1 on the same element (same stream, actor, object, element)
+__device__ __forceinline__ bool same_elem_follows(const MergeBufs& b, const DeltaBufs& d, uint32_t x) {
+  if (x <= d.T0 || x >= b.n_ops || first_row_of_pass(d, x)) return false;
+  if (!list_elem_op(b, x) || !list_elem_op(b, x - 1)) return false;
+  const OpCols& o = b.ops;
+  return o.id_actor[x - 1] == o.id_actor[x] && same_obj(b, x - 1, x) && b.ref_row[x] != NONE32 && b.ref_row[x] == b.ref_row[x - 1];
+}
+// does row x name one of the rows [s, x) as pred?
+__device__ __forceinline__ bool overwrites_one_of(const MergeBufs& b, uint32_t x, uint32_t s) {
+  const OpCols& o = b.ops;
+  for (uint32_t k = 0; k < o.pred_num[x]; k++) {
+    const uint32_t pc = o.pred_ctr[o.pred_first[x] + k], pa = o.pred_actor[o.pred_first[x] + k];
+    for (uint32_t r = s; r < x; r++)
+      if (o.id_ctr[r] == pc && o.id_actor[r] == pa) return true;
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
   uint32_t t = gtid();
   if (t >= d.n_new) return;
@@ -407,18 +435,31 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
     uint32_t e = b.ref_row[g];
     const uint32_t nu = d.upd_n[e];
     const bool quirk = nu <= ELEM_ROWS_MAX && elem_has_inc(b, d, e);  // the element holds increments: counter rules (quirk_elem_state)
+    // ---- the run of the merge call this row belongs to: [g0, g] so far; does row g + 1 go on with it? ----
+    uint32_t chain = g, steps = 0;
+    while (same_elem_follows(b, d, chain) && steps <= RUN_ROWS_MAX) { chain--; steps++; }
+    uint32_t g0 = chain;
+    for (uint32_t x = chain + 1; x <= g; x++)
+      if (overwrites_one_of(b, x, g0)) g0 = x;  // (a row that overwrites one of the call's rows starts a call of its own, new.js:1094-1101)
+    const bool goes_on = same_elem_follows(b, d, g + 1) && !overwrites_one_of(b, g + 1, g0);
+    if (steps > RUN_ROWS_MAX) err |= refuse(d, DR_SAME_ELEM_CALL);
     if (nu > ELEM_ROWS_MAX || (quirk && nu + 1 > QUIRK_ROWS_MAX)) err |= refuse(d, DR_ELEM_ROWS);
-    else {
+    else if (!goes_on) {
       if (quirk) {
         // Served when the two notions of "the element is visible" agree before and after the op -- the reference counts an element as
         // visible when any of its rows has no successor (list indexes), and reports insert / remove / update by the values it lists;
         // they part when a deleted counter still has increments, or when every increment of a counter has been deleted (a `remove`
         // edit for an element that stays, a value of an element that does not count: left to the JS path)
         bool raw_b, raw_a, weird_b, weird_a;
-        quirk_elem_state(b, d, e, g, before, raw_b, weird_b);
+        quirk_elem_state(b, d, e, g0, before, raw_b, weird_b);
         quirk_elem_state(b, d, e, g + 1, after, raw_a, weird_a);
         if (weird_b || weird_a || raw_b != (before != 0) || raw_a != (after != 0)) err |= refuse(d, DR_ELEM_NOT_PLAIN);
-      } else elem_state(b, d, e, g, before, after);
+      } else {
+        uint32_t unused;
+        elem_state(b, d, e, g, unused, after);
+        if (g0 == g) before = unused;
+        else elem_state(b, d, e, g0, before, unused);
+      }
       ev = before ? (after ? EV_UPDATE : EV_REMOVE) : (after ? EV_INSERT : EV_NONE);
       if (nu > 0 && !quirk) {  // (the element holds assignment rows, old or new)
         // values are `set` rows and make rows (child objects); anything else (link, unknown actions) is not restated
@@ -426,33 +467,27 @@ __global__ __launch_bounds__(BLOCK) void kd_events(MergeBufs b, DeltaBufs d) {
         for (uint32_t k = 0; k < nu; k++) plain = plain && is_value_action(o.action[d.upd_rows[d.upd_off[e] + k]]);
         if (!plain) err |= refuse(d, DR_ELEM_NOT_PLAIN);
       }
-      // ---- does the op continue the merge call of the previous op of the stream? ----
-      bool first_of_pass = g == d.T0;
-      for (uint32_t k = 0; k < d.n_pass; k++) first_of_pass = first_of_pass || d.pass_rows[k] == g;
-      if (!first_of_pass && list_elem_op(b, g - 1) && o.id_actor[g - 1] == o.id_actor[g] && same_obj(b, g - 1, g) && b.ref_row[g - 1] != NONE32) {
-        uint32_t a = b.ref_row[g - 1];
+      // ---- does the call continue the merge call of the previous op of the stream (on another element)? ----
+      if (!first_row_of_pass(d, g0) && list_elem_op(b, g0 - 1) && o.id_actor[g0 - 1] == o.id_actor[g0] && same_obj(b, g0 - 1, g0) && b.ref_row[g0 - 1] != NONE32) {
+        uint32_t a = b.ref_row[g0 - 1];
         if (a == e) {
-          // several ops on one element share a call unless the later one overwrites the earlier (new.js:1118-1121): not restated
-          bool overwrites = false;
-          for (uint32_t k = 0; k < o.pred_num[g]; k++)
-            overwrites = overwrites || (o.pred_ctr[o.pred_first[g] + k] == o.id_ctr[g - 1] && o.pred_actor[o.pred_first[g] + k] == o.id_actor[g - 1]);
-          if (!overwrites) err |= refuse(d, DR_SAME_ELEM_CALL);
+          // (the same element: row g0 overwrites a row of the call in front -- a call of its own, no index lag)
         } else if (d.upd_n[a] <= ELEM_ROWS_MAX) {
           uint32_t a_before = 0, a_after = 0;
           if (elem_has_inc(b, d, a)) {
-            // (an element with increments: its values after row g - 1; the thread of that row has checked that they say the same as
+            // (an element with increments: its values after row g0 - 1; the thread of that row has checked that they say the same as
             // the reference's own count of visible elements)
             bool raw_vis, weird;
             if (d.upd_n[a] + 1 > QUIRK_ROWS_MAX) err |= refuse(d, DR_ELEM_ROWS);
-            else quirk_elem_state(b, d, a, g, a_after, raw_vis, weird);
-          } else elem_state(b, d, a, g - 1, a_before, a_after);
-          const bool ins_row_visible = e < g && alive_at_T0(b, d, e) && d.first_del[e] >= g;  // the insert row held a visible value
+            else quirk_elem_state(b, d, a, g0, a_after, raw_vis, weird);
+          } else elem_state(b, d, a, g0 - 1, a_before, a_after);
+          const bool ins_row_visible = e < g0 && alive_at_T0(b, d, e) && d.first_del[e] >= g0;  // the insert row held a visible value
           if (a_after > 0 && ins_row_visible) {
             // was e the element right behind a when the op was applied? (elements inserted later may stand between them now)
             uint32_t pa = d.pos_of[a], pe = d.pos_of[e];
             bool neighbours = pe > pa;
             if (neighbours && pe - pa - 1 > GAP_WALK_MAX) { neighbours = false; err |= refuse(d, DR_GAP_WALK); }
-            for (uint32_t q = pa + 1; neighbours && q < pe; q++) neighbours = b.order[q] > g;
+            for (uint32_t q = pa + 1; neighbours && q < pe; q++) neighbours = b.order[q] > g0;
             if (neighbours) {
               if (ev == EV_REMOVE) lag = 1;
               else if (d.first_del[e] > g) err |= refuse(d, DR_LAGGING_UPDATE);  // the insert row's value stays: its update edit alone would lag

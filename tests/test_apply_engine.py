@@ -41,12 +41,12 @@ def _same(got, want, local=False):
 
 # The applyChanges calls of the reference's own suites (sessions that start from an empty document or from a loaded one): exactly
 # which ones the engine serves, refuses (JS path) and rejects like the reference -- by vector id, as the whole-document twin does
-# (tests/test_ref_suite_vectors.py). Refused: 15, 28, 507, 508 = hand-made batches with two ops on one list element in one merge call
-# (DR_SAME_ELEM_CALL). (501, 619 -- an increment of a counter inside a list -- were refused through round 4 and are served since round 5:
-# the whole-document patch of such lists, k_quirk_rows, and the counter rules of the delta stage, quirk_elem_state.)
-# All 1582 captured calls are accounted for: 1574 served and equal, 4 refused, 4 rejected (GPU: every chain, the 600-call one included;
-# emulation: chains of <= 50 calls, 974 served).
-SUITE_EQUAL, SUITE_EQUAL_SHORT, SUITE_REFUSED, SUITE_REJECTED = 1574, 974, [15, 28, 507, 508], 4
+# (tests/test_ref_suite_vectors.py). Refused: none any more. (Through round 4: 15, 28, 507, 508 = two ops on one list element in one
+# merge call -- now one event per run of a call, kd_events --, and 501, 619 = an increment of a counter inside a list -- now the
+# whole-document patch of such lists, k_quirk_rows, and the counter rules of the delta stage, quirk_elem_state.)
+# All 1582 captured calls are accounted for: 1578 served and equal, none refused, 4 rejected (GPU: every chain, the 600-call one
+# included; emulation: chains of <= 50 calls, 978 served).
+SUITE_EQUAL, SUITE_EQUAL_SHORT, SUITE_REFUSED, SUITE_REJECTED = 1578, 978, [], 4
 
 
 def run_vector_chains(make_engine, max_chain, max_chains=None):
@@ -253,15 +253,32 @@ def test_apply_after_load_changes_and_queue_emulated(emu_lib):
 
 
 def test_unserved_batch_is_refused_emulated(emu_lib):
-    """A batch outside the served subset (vector 15 of the reference's suites: two assignments to one list element in one change) ends
-    in a refusal that names the reason, not in a patch."""
-    vectors, pool = load_vectors()
+    """A batch outside the served subset ends in a refusal that names the reason, not in a patch: an increment of a counter inside a
+    list that another actor has deleted meanwhile (the reference then goes on counting the element as visible while its patch says
+    `remove`: DESIGN.md 5, tests/golden/list_quirks.json hand_counter_deleted_and_incremented). (Through round 4 this test used vector
+    15 of the reference's suites -- two assignments to one list element in one change --, which is served since round 5.)"""
+    import golden_util
+    blobs = next(c[1] for c in golden_util.list_quirk_cases() if c[0] == "hand_counter_deleted_and_incremented")
     eng = engine.Engine(0, emu_lib)
     try:
-        with pytest.raises(engine.UnsupportedChanges, match="two ops on one list element"):
-            eng.apply_changes(ChangeLog.from_changes([pool[k] for k in vectors[15]["changes"]]))
+        eng.apply_changes(ChangeLog.from_changes(blobs[:2]))   # the list with its counter; the deletion
+        with pytest.raises(engine.UnsupportedChanges, match="neither a value nor"):
+            eng.apply_changes(ChangeLog.from_changes(blobs[2:]))   # the concurrent increment
     finally:
         eng.close()
+
+
+def test_several_ops_of_one_merge_call_on_one_list_element_emulated(emu_lib):
+    """Vectors 15, 28, 507, 508 of the reference's suites (two assignments to one list element in one change: one merge call, one visit of
+    the element, new.js:1092-1118) -- refused through round 4, served since the runs of a call report as one event (kd_events)."""
+    vectors, pool = load_vectors()
+    for j in (15, 28):   # (sessions of one call; 507 / 508 are later calls of sessions: test_reference_suite_calls_emulated)
+        eng = engine.Engine(0, emu_lib)
+        try:
+            eng.apply_changes(ChangeLog.from_changes([pool[k] for k in vectors[j]["changes"]]))
+            assert _same(eng.apply_patch_json(), vectors[j]["patch"], vectors[j]["local"])
+        finally:
+            eng.close()
 
 
 def test_edits_inside_objects_that_are_no_longer_visible_emulated(emu_lib):
@@ -394,7 +411,7 @@ def test_sessions_onto_loaded_documents_emulated(emu_lib):
     assert equal >= 300 and refused == 0
 
 
-QUIRK_EQUAL, QUIRK_REFUSED = 222, 30
+QUIRK_EQUAL, QUIRK_REFUSED = 316, 19
 
 
 def test_sessions_with_counters_inside_lists_emulated(emu_lib):
