@@ -1116,11 +1116,16 @@ __device__ __forceinline__ uint32_t doc_find_make(const unsigned long long* __re
 // The counter an increment ON A LIST ELEMENT feeds (document rows: the rows of an element follow its insert row `el`, ascending by
 // id): the latest preceding `set` of a counter that lists the increment among its successors (counterStates[succOp] = counterState,
 // later assignment wins: new.js:944-950). NONE32: none -- "increment operation for unknown counter".
+// (the walk is bounded: a property with more than DOC_COUNTER_WALK rows between an increment and its counter -- a counter incremented
+// a hundred thousand times -- would cost its rows a quadratic number of steps inside one launch; such documents get F_UNSUPPORTED from
+// k_doc_resolve and go to the JS path)
+constexpr uint32_t DOC_COUNTER_WALK = 1u << 16;
 __device__ __forceinline__ uint32_t doc_list_counter_of(const MergeBufs& b, uint32_t g, uint32_t el) {
   const OpCols& o = b.ops;
   if (el == NONE32 || el >= g) return NONE32;
   const uint32_t my_a = o.id_actor[g], my_c = o.id_ctr[g];
-  for (uint32_t r = g; r-- > el;) {
+  const uint32_t stop = g - el > DOC_COUNTER_WALK ? g - DOC_COUNTER_WALK : el;
+  for (uint32_t r = g; r-- > stop;) {
     if (o.action[r] == 1 && (o.val_tl[r] & 15) == 8) {
       const uint32_t f = o.pred_first[r], n = o.pred_num[r];
       for (uint32_t k = 0; k < n; k++)
@@ -1185,6 +1190,7 @@ __global__ __launch_bounds__(BLOCK) void k_doc_resolve(MergeBufs b, const unsign
     uint32_t my_a = o.id_actor[g], my_c = o.id_ctr[g];
     uint32_t owner = NONE32;
     for (uint32_t r = g; r-- > 0 && owner == NONE32;) {
+      if (g - r > DOC_COUNTER_WALK) { err |= F_UNSUPPORTED; break; }  // (bounded walk, see doc_list_counter_of)
       if (!same_obj(b, r, g) || !same_key(b, r, g)) break;
       if (o.action[r] == 1 && (o.val_tl[r] & 15) == 8) {
         uint32_t f = o.pred_first[r], n = o.pred_num[r];
@@ -1193,7 +1199,7 @@ __global__ __launch_bounds__(BLOCK) void k_doc_resolve(MergeBufs b, const unsign
       }
     }
     long long v;
-    if (owner == NONE32) err |= F_BAD_COUNTER;  // increment operation for unknown counter (new.js:954-956)
+    if (owner == NONE32) { if (!(err & F_UNSUPPORTED)) err |= F_BAD_COUNTER; }  // increment operation for unknown counter (new.js:954-956); (not when the walk was cut)
     else if (!int_value(b, g, v)) err |= F_UNSUPPORTED;
     else {
       atomicAdd(&b.inc_cnt[owner], 1u);
@@ -1204,7 +1210,8 @@ __global__ __launch_bounds__(BLOCK) void k_doc_resolve(MergeBufs b, const unsign
     // an increment on a list element (new.js:952-965)
     const uint32_t owner = doc_list_counter_of(b, g, ref);
     long long v;
-    if (owner == NONE32) err |= F_BAD_COUNTER;
+    if (owner == NONE32 && ref != NONE32 && g - ref > DOC_COUNTER_WALK) err |= F_UNSUPPORTED;  // (the walk was cut short)
+    else if (owner == NONE32) err |= F_BAD_COUNTER;
     else if (!int_value(b, g, v)) err |= F_UNSUPPORTED;
     else {
       atomicAdd(&b.inc_cnt[owner], 1u);
