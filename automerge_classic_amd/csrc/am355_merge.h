@@ -23,7 +23,8 @@ struct Counts {
   uint32_t n_head_children;  // insert rows whose reference element is _head (all list objects)
   uint32_t n_quirk;      // list rows that need the reference's counter / `remove` rules (new.js:937-965, 1010-1033): counters completed by
                          // increments, visible rows without a value. 0 = the ordinary edits (merge_run then skips k_quirk_rows)
-  uint32_t reserved[3];
+  uint32_t n_list_inc;   // increments on list elements seen by k_resolve: only then does k_emit look for counters among the invisible `set` rows of lists
+  uint32_t reserved[2];
 };
 
 // Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
       atomicAdd(&b.inc_cnt[counter_row], 1u);
       atomicAdd(&b.inc_sum[counter_row], (unsigned long long)v);
       atomicMax(&b.last_inc[counter_row], my_id);
+      if (!has_str) atomicAdd(&b.counts->n_list_inc, 1u);  // (rare: tells k_emit that lists may hold counters completed by increments)
     }
   }
   b.obj_row[g] = orow;
@@ -193,6 +194,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   bool is_make = live && (a & 1) == 0;  // (a foreign make row too: the object table is the same on every rank)
   if (kind == K_FOREIGN) live = false;
   bool vis = live && b.succ_cnt[g] == 0;
+  // (one word for the whole kernel: without increments on list elements -- every ordinary document -- the invisible `set` rows of lists
+  // cost no second look; k_resolve has completed)
+  const bool any_list_inc = b.counts->n_list_inc != 0;
   bool want_map = false, want_ins = false, want_upd = false;
   unsigned long long trig = 0;
   uint32_t el = NONE32;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
       // a visible row without a value (an increment, a link): it takes part in the element's edits by the reference's `remove` rule
       // (new.js:1026-1033) -- k_quirk_rows / k_list_edits
       quirk = true;
-    } else if (a == 1 && (o.val_tl[g] & 15) == 8 && b.inc_cnt[g] == b.succ_cnt[g]) {
+    } else if (any_list_inc && a == 1 && (o.val_tl[g] & 15) == 8 && b.inc_cnt[g] == b.succ_cnt[g]) {
       // a counter whose successors are all increments (new.js:937-965): one value of its element, listed where the LAST increment
       // stands among the element's rows -- it travels with the update rows, keyed by that increment's id (k_upd_keys), also when the
       // counter is the element's own insert row
@@ -911,6 +915,30 @@ __global__ __launch_bounds__(BLOCK) void k_list_scan(MergeBufs b, uint32_t n, ui
   if (p + 1 == n) b.counts->n_edits = ce + c;
 }
 
+// The same two steps without the per-position arrays (list_vis / list_cnt written and read again, vis_ex / cnt_ex written and read again:
+// 32 bytes per element of a text document): k_list_counts_pub only publishes the workgroup sums, k_list_scan_edits rebuilds a position's
+// count, takes its two prefixes from the carried sums and writes the element's edits right away. An edit's index is then the number of
+// visible elements in front of it over ALL lists (the lists are chained); the first position of every object leaves that number at
+// its object's first element in vis_base[object], which k_edit_pack subtracts.
+__device__ __forceinline__ uint32_t list_pos_count(const MergeBufs& b, uint32_t v, const unsigned long long* __restrict__ vl_min) {
+  uint32_t c = b.val_cnt[v] + (b.kind[v] == K_LIST_INS_VIS ? 1u : 0u);
+  if (vl_min && c == 0 && vl_min[v] != ~0ull) c = 1;  // the `remove` edit of an element that shows rows but no value
+  return c;
+}
+__global__ __launch_bounds__(BLOCK) void k_list_counts_pub(MergeBufs b, uint32_t n, const unsigned long long* __restrict__ vl_min) {
+  wave_priority_high();
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  uint32_t p = gtid();
+  uint32_t c = 0;
+  if (p < n) {
+    uint32_t v = b.order[p];
+    if (v == NONE32) atomicOr(&b.counts->flags, (uint32_t)F_BAD_ELEM);
+    else c = list_pos_count(b, v, vl_min);
+  }
+  carry_publish(b.cs_vis, c ? 1u : 0u, s_red);
+  carry_publish(b.cs_cnt, c, s_red);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_upd_keys(MergeBufs b, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n) {
   uint32_t i = gtid();
   if (i >= n) return;
@@ -926,22 +954,14 @@ __global__ __launch_bounds__(BLOCK) void k_upd_keys(MergeBufs b, uint64_t* __res
   vals[i] = g;
 }
 
-// one lane per list position: write the element's edits (insert first, then updates in ascending op id)
-__global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, const uint32_t* __restrict__ vis_ex, const uint32_t* __restrict__ cnt_ex,
-                                                      const uint64_t* __restrict__ upd_keys, const uint32_t* __restrict__ upd_vals, uint32_t n_upd,
-                                                      PatchIR ir, const unsigned long long* __restrict__ vl_min) {
-  wave_priority_high();
-  uint32_t p = gtid();
-  if (p >= n) return;
-  uint32_t v = b.order[p];
-  if (v == NONE32) return;
+// one element's edits (insert first, then updates in ascending op id) from entry e on; index: the element's list index
+__device__ __forceinline__ void list_edits_of(const MergeBufs& b, uint32_t v, uint32_t index, uint32_t e, const uint64_t* __restrict__ upd_keys,
+                                              const uint32_t* __restrict__ upd_vals, uint32_t n_upd, const PatchIR& ir, const unsigned long long* __restrict__ vl_min) {
   const bool own = b.kind[v] == K_LIST_INS_VIS;  // the insert's own value is visible
   uint32_t c = b.val_cnt[v] + (own ? 1u : 0u);
   const unsigned long long vl = vl_min ? vl_min[v] : ~0ull;  // first visible row without a value (k_quirk_rows)
   if (!c && vl == ~0ull) return;
-  uint32_t oi = obj_index_of(b, b.obj_row[v]);
-  uint32_t index = vis_ex[p] - vis_ex[b.obj_first_pos[oi]];
-  uint32_t e = cnt_ex[p], k = 0;
+  uint32_t k = 0;
   if (!c) {  // rows, but no value: the `remove` edit stays (new.js:1026-1033)
     ir.e_row[e] = v; ir.e_elem[e] = v; ir.e_index[e] = index; ir.e_flags[e] = 8u;
     return;
@@ -979,6 +999,36 @@ __global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, c
     // next element is then reported at the same index and the two interfere (appendUpdate, new.js:803-815): left to the JS path
     if (!shown) atomicOr(&b.counts->flags, (uint32_t)F_UNSUPPORTED);
   }
+}
+
+// one lane per list position
+__global__ __launch_bounds__(BLOCK) void k_list_edits(MergeBufs b, uint32_t n, const uint32_t* __restrict__ vis_ex, const uint32_t* __restrict__ cnt_ex,
+                                                      const uint64_t* __restrict__ upd_keys, const uint32_t* __restrict__ upd_vals, uint32_t n_upd,
+                                                      PatchIR ir, const unsigned long long* __restrict__ vl_min) {
+  wave_priority_high();
+  uint32_t p = gtid();
+  if (p >= n) return;
+  uint32_t v = b.order[p];
+  if (v == NONE32) return;
+  uint32_t oi = obj_index_of(b, b.obj_row[v]);
+  list_edits_of(b, v, vis_ex[p] - vis_ex[b.obj_first_pos[oi]], cnt_ex[p], upd_keys, upd_vals, n_upd, ir, vl_min);
+}
+
+// k_list_scan + k_list_edits in one pass over the positions (see k_list_counts_pub)
+__global__ __launch_bounds__(BLOCK) void k_list_scan_edits(MergeBufs b, uint32_t n, const uint64_t* __restrict__ upd_keys, const uint32_t* __restrict__ upd_vals,
+                                                           uint32_t n_upd, PatchIR ir, const unsigned long long* __restrict__ vl_min, uint32_t* __restrict__ vis_base) {
+  wave_priority_high();
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  uint32_t p = gtid();
+  uint32_t v = p < n ? b.order[p] : NONE32;
+  uint32_t c = v != NONE32 ? list_pos_count(b, v, vl_min) : 0u;
+  uint32_t ve = carry_prefix(b.cs_vis, c ? 1u : 0u, s_red);
+  uint32_t ce = carry_prefix(b.cs_cnt, c, s_red);
+  if (p + 1 == n) b.counts->n_edits = ce + c;
+  if (v == NONE32) return;
+  uint32_t oi = obj_index_of(b, b.obj_row[v]);
+  if (p == b.obj_first_pos[oi]) vis_base[oi] = ve;
+  list_edits_of(b, v, ve, ce, upd_keys, upd_vals, n_upd, ir, vl_min);
 }
 
 // multi-insert run detection (new.js:754-773), first / last edit of every list object; publishes the number of edit RECORDS
@@ -1020,7 +1070,9 @@ __global__ __launch_bounds__(BLOCK) void k_edit_runs(MergeBufs b, PatchIR ir) {
 
 // consumer of k_edit_runs' carried scan (same grid): one edit record per head (start of an edit, or of a new uniform stretch of a
 // multi-insert), the edit ranges of the list objects, the sentinel record and Counts.n_erecs
-__global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
+// (vis_base: the replay's e_index counts the visible elements of ALL lists in front -- k_list_scan_edits --, less the object's own base;
+// null: e_index is the list index already)
+__global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir, const uint32_t* __restrict__ vis_base) {
   wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t n = b.counts->n_edits;
@@ -1046,7 +1098,8 @@ __global__ __launch_bounds__(BLOCK) void k_edit_pack(MergeBufs b, PatchIR ir) {
       val = (uint32_t)total;
       val_hi = (uint32_t)(total >> 32);
     }
-    ir.edit[k] = am355_ir_edit{f & 0x2fu, ir.e_index[e], o.id_ctr[r], o.id_actor[r], o.id_ctr[el], o.id_actor[el], e, o.val_tl[r], val, val_hi};
+    const uint32_t index = ir.e_index[e] - (vis_base ? vis_base[obj_index_of(b, b.obj_row[el])] : 0u);
+    ir.edit[k] = am355_ir_edit{f & 0x2fu, index, o.id_ctr[r], o.id_actor[r], o.id_ctr[el], o.id_actor[el], e, o.val_tl[r], val, val_hi};
   }
   if (f & 0x300u) {
     uint32_t oi = obj_index_of(b, b.obj_row[el]);
@@ -1523,8 +1576,15 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
       (void)hipMemsetAsync(vl_min, 0xff, sizeof(unsigned long long) * (size_t)N, st);
       AM355_LAUNCH_INDEPENDENT(k_quirk_rows, grid_for(N), dim3(BLOCK), st, b, vl_min);
     }
-    hipLaunchKernelGGL(k_list_counts, grid_for(ni), dim3(BLOCK), 0, st, b, ni, (const unsigned long long*)vl_min);
-    hipLaunchKernelGGL(k_list_scan, grid_for(ni), dim3(BLOCK), 0, st, b, ni, vis_ex, cnt_ex);
+    // (AM355_LIST_UNFUSED=1: the three-kernel form of rounds 2-5 -- counts, scan, edits over per-position arrays -- for A/B runs and tests)
+    static const bool unfused = getenv("AM355_LIST_UNFUSED") != nullptr;
+    uint32_t* vis_base = unfused ? nullptr : b.list_vis;  // [objects] (the per-position array of the other form: free here)
+    if (unfused) {
+      hipLaunchKernelGGL(k_list_counts, grid_for(ni), dim3(BLOCK), 0, st, b, ni, (const unsigned long long*)vl_min);
+      hipLaunchKernelGGL(k_list_scan, grid_for(ni), dim3(BLOCK), 0, st, b, ni, vis_ex, cnt_ex);
+    } else {
+      hipLaunchKernelGGL(k_list_counts_pub, grid_for(ni), dim3(BLOCK), 0, st, b, ni, (const unsigned long long*)vl_min);
+    }
     const uint64_t* uk = b.key_a;
     const uint32_t* uv = b.val_a;
     if (nu) {
@@ -1533,10 +1593,13 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
       uk = r2 ? b.key_b : b.key_a;
       uv = r2 ? b.val_b : b.val_a;
     }
-    AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis_ex, (const uint32_t*)cnt_ex, uk, uv, nu, ir,
-                             (const unsigned long long*)vl_min);
+    if (unfused)
+      AM355_LAUNCH_INDEPENDENT(k_list_edits, grid_for(ni), dim3(BLOCK), st, b, ni, (const uint32_t*)vis_ex, (const uint32_t*)cnt_ex, uk, uv, nu, ir,
+                               (const unsigned long long*)vl_min);
+    else
+      hipLaunchKernelGGL(k_list_scan_edits, grid_for(ni), dim3(BLOCK), 0, st, b, ni, uk, uv, nu, ir, (const unsigned long long*)vl_min, vis_base);
     hipLaunchKernelGGL(k_edit_runs, grid_for(N), dim3(BLOCK), 0, st, b, ir);
-    hipLaunchKernelGGL(k_edit_pack, grid_for(N), dim3(BLOCK), 0, st, b, ir);
+    hipLaunchKernelGGL(k_edit_pack, grid_for(N), dim3(BLOCK), 0, st, b, ir, (const uint32_t*)vis_base);
   } else {
     (void)hipMemsetAsync(ir.edit, 0, sizeof(am355_ir_edit), st);
   }
@@ -1595,7 +1658,7 @@ void doc_patch(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
   if (hc->flags || !N) return;
   if (hc->n_map_emit) AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(hc->n_map_emit), dim3(BLOCK), st, b, (const uint32_t*)perm, hc->n_map_emit, ir);
   hipLaunchKernelGGL(k_edit_runs, grid_for(hc->n_edits ? hc->n_edits : 1), dim3(BLOCK), 0, st, b, ir);
-  hipLaunchKernelGGL(k_edit_pack, grid_for(hc->n_edits ? hc->n_edits : 1), dim3(BLOCK), 0, st, b, ir);
+  hipLaunchKernelGGL(k_edit_pack, grid_for(hc->n_edits ? hc->n_edits : 1), dim3(BLOCK), 0, st, b, ir, (const uint32_t*)nullptr);
   (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
 }
