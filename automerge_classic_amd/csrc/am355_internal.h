@@ -86,7 +86,7 @@ struct HostSignals {
   volatile uint32_t plan_seq;    uint32_t pad0[15];
   PlanTotals plan;
   volatile uint32_t counts_seq;  uint32_t pad1[15];
-  uint32_t counts[16];           // Counts after k_compact_rows
+  uint32_t counts[32];           // Counts after k_compact_rows, MapKeyStats behind it
   volatile uint32_t runs_seq;    uint32_t pad2[15];
   uint32_t runs[16];             // Counts after k_run_heads
   volatile uint32_t final_seq;   uint32_t pad3[15];

@@ -27,6 +27,17 @@ struct Counts {
   uint32_t reserved[2];
 };
 
+// What the keys of the map emissions have in common (k_emit; behind Counts in its device block, cleared with it, signalled with it):
+// bit i of or_b / or_inv_b word w = some key has / lacks that bit in byte 4 w + (3 - i / 8) ... -- stored as the big-endian words the
+// sort keys are made of (map_key_of): byte j of a key (zero beyond its length, UTF-16 order remap applied) sits in word j / 4 at bits
+// [24 - 8 (j % 4), 32 - 8 (j % 4)). A byte position is the same in every key iff (or & or_inv) is zero there: its radix pass is the
+// identity and is not run; likewise the pass over the key lengths when every key has the same length.
+struct MapKeyStats {
+  uint32_t or_len, or_inv_len;
+  uint32_t or_b[4], or_inv_b[4];   // the first 16 key bytes
+};
+constexpr uint32_t MAP_KEY_STATS_WORD = 16;  // word offset behind Counts (sizeof(Counts) / 4)
+
 // Device buffers of the merge stage. N = op rows, P = preds. Everything is uint32 unless noted.
 struct MergeBufs {
   // inputs

@@ -165,7 +165,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
 
 // Workgroup-aggregated append: ONE atomic per workgroup of four wavefronts (same-word device atomics serialise at ~12 ns each: a map
 // batch of 80 k rows, every row an emission, spent 15 of k_emit's 20 us in 1252 of them). Must be reached by every thread; the order of
-// the appended items among workgroups is arbitrary, as with wave_append. s: BLOCK / WAVE + 1 words of LDS.
+// the appended items among workgroups is arbitrary, as with wave_append. s: BLOCK / WAVE + 2 words of LDS.
 __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, uint32_t* s) {
   const unsigned long long m = __ballot(want);
   const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
@@ -176,6 +176,7 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, u
     uint32_t total = 0;
     for (uint32_t k = 0; k < BLOCK / WAVE; k++) { uint32_t c = s[k]; s[k] = total; total += c; }
     s[BLOCK / WAVE] = total ? atomicAdd(counter, total) : 0u;
+    s[BLOCK / WAVE + 1] = total;  // (how many the workgroup appended: read by the caller before its next use of s)
   }
   __syncthreads();
   return s[BLOCK / WAVE] + s[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
@@ -184,7 +185,7 @@ __device__ __forceinline__ uint32_t block_append(uint32_t* counter, bool want, u
 __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   wave_priority_high();
   __shared__ uint32_t s_red[BLOCK / WAVE];
-  __shared__ uint32_t s_app[BLOCK / WAVE + 1];
+  __shared__ uint32_t s_app[BLOCK / WAVE + 2];
   uint32_t g = gtid();
   const OpCols& o = b.ops;
   bool in_range = g < b.n_ops;
@@ -240,11 +241,39 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
     if (quirk) atomicAdd(&b.counts->n_quirk, 1u);
   }
   uint32_t slot = block_append(&b.counts->n_map_emit, want_map, s_app);
+  const uint32_t block_maps = s_app[BLOCK / WAVE + 1];  // map emissions of this workgroup (the same word for every thread)
   if (want_map) {
     b.em_row[slot] = g;
     b.em_trig[slot] = trig;
     // (monotone maximum: the plain read only filters; same-word device atomics cost ~12 ns each, serialised)
     if (o.key_len[g] > *(volatile uint32_t*)&b.counts->max_key_len) atomicMax(&b.counts->max_key_len, o.key_len[g]);
+  }
+  // what the keys of the emissions have in common (MapKeyStats): OR over the workgroup in LDS, ten atomics per workgroup that emits
+  if (block_maps) {
+    uint32_t w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (want_map) {
+      const uint32_t len = o.key_len[g];
+      const uint8_t* kp = b.arena + o.key_off[g];
+      w[0] = len; w[1] = ~len;
+      for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t x = j < len ? utf16_order_byte(kp[j]) : 0u;
+        w[2 + (j >> 2)] |= x << (24 - 8 * (j & 3));
+      }
+      for (uint32_t k = 0; k < 4; k++) w[6 + k] = ~w[2 + k];
+    }
+    __shared__ uint32_t s_or[10];
+    if (threadIdx.x < 10) s_or[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t k = 0; k < 10; k++) {
+      uint32_t x = w[k];
+      for (int d = WAVE / 2; d >= 1; d >>= 1) x |= __shfl_xor(x, d);
+      if ((threadIdx.x & (WAVE - 1)) == 0 && x) atomicOr(&s_or[k], x);
+    }
+    __syncthreads();
+    if (threadIdx.x < 10 && s_or[threadIdx.x]) {
+      uint32_t* dst = (uint32_t*)b.counts + MAP_KEY_STATS_WORD + threadIdx.x;
+      if ((*(volatile uint32_t*)dst | s_or[threadIdx.x]) != *(volatile uint32_t*)dst) atomicOr(dst, s_or[threadIdx.x]);
+    }
   }
   slot = block_append(&b.counts->n_list_upd, want_upd, s_app);
   if (want_upd) b.upd_row[slot] = g;
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(BLOCK) void k_compact_rows(MergeBufs b, PatchIR ir)
     b.counts->n_list_ins = pos + (want_ins ? 1u : 0u);
     b.counts->n_objects = idx - 1 + (is_make ? 1u : 0u);
     // (everything else in Counts up to here was written by k_resolve / k_emit, which have completed)
-    if (b.sig) signal_host(b.sig->counts, (const uint32_t*)b.counts, 16, &b.sig->counts_seq, b.sig_seq);
+    if (b.sig) signal_host(b.sig->counts, (const uint32_t*)b.counts, MAP_KEY_STATS_WORD + sizeof(MapKeyStats) / 4, &b.sig->counts_seq, b.sig_seq);
   }
 }
 
@@ -1394,8 +1423,17 @@ bool wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st)
 }
 
 // the counters of a phase: from the pinned words the phase's last kernel signalled, or -- no signal -- from the device after a drain
-static void read_phase_counts(MergeBufs& b, volatile uint32_t* seq_word, const uint32_t* words, Counts* dst, hipStream_t st) {
-  if (wait_host_signal(seq_word, b.sig_seq, st)) { memcpy(dst, (const void*)words, sizeof(Counts)); return; }
+// (key_stats: the MapKeyStats behind the counters, when the caller wants them -- the signal after k_compact_rows carries them)
+static void read_phase_counts(MergeBufs& b, volatile uint32_t* seq_word, const uint32_t* words, Counts* dst, hipStream_t st, MapKeyStats* key_stats = nullptr) {
+  if (wait_host_signal(seq_word, b.sig_seq, st)) {
+    memcpy(dst, (const void*)words, sizeof(Counts));
+    if (key_stats) memcpy(key_stats, (const void*)(words + MAP_KEY_STATS_WORD), sizeof(MapKeyStats));
+    return;
+  }
+  if (key_stats) {  // (no signal: every byte position is taken to vary)
+    key_stats->or_len = key_stats->or_inv_len = ~0u;
+    for (int k = 0; k < 4; k++) key_stats->or_b[k] = key_stats->or_inv_b[k] = ~0u;
+  }
   (void)hipMemcpyAsync(dst, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
   (void)hipStreamSynchronize(st);
 }
@@ -1426,7 +1464,8 @@ void merge_prepare(MergeBufs& b, hipStream_t aux) {
 }
 
 // map emissions: LSD over (trigger id | key length | key chunks last..first | object)
-static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hipStream_t st, uint32_t* ride_with_list_order = nullptr) {
+static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hipStream_t st, uint32_t* ride_with_list_order = nullptr,
+                                const MapKeyStats* ks = nullptr) {
   uint32_t ne = hc->n_map_emit;
   if (!ne) return;
   uint32_t* perm_a = b.val_a;
@@ -1459,12 +1498,30 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
   } else {
     AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
     pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
-    pass(MK_LEN, 0, bits_for(hc->max_key_len));
+    // (round 5, second session: a byte position -- or the length -- that is the same in every key is not sorted by: the pass would be
+    // the identity. k_emit leaves what the keys have in common behind the counters, MapKeyStats; keys like `k00017` lose two of
+    // their six byte passes and the length pass: three of the map workload's ten passes of two launches each)
+    static const bool all_passes = getenv("AM355_MAP_ALL_PASSES") != nullptr;  // (A/B and tests)
+    const bool have_stats = ks && !all_passes;
+    if (!have_stats || (ks->or_len & ks->or_inv_len)) pass(MK_LEN, 0, bits_for(hc->max_key_len));
     uint32_t chunks = (hc->max_key_len + 7) / 8;
     for (uint32_t c = chunks; c-- > 0;) {
       // bytes are packed first-byte-highest: positions past the longest key are zero in every key -- no pass over them
       uint32_t used = hc->max_key_len - 8 * c < 8 ? hc->max_key_len - 8 * c : 8;
-      pass(MK_CHUNK, c, 64, 64 - 8 * (int)used);
+      auto varies = [&](uint32_t j) {  // byte j of chunk c
+        const uint32_t pos = 8 * c + j;
+        if (!have_stats || pos >= 16) return true;
+        const uint32_t sh = 24 - 8 * (pos & 3);
+        return (((ks->or_b[pos >> 2] & ks->or_inv_b[pos >> 2]) >> sh) & 0xffu) != 0;
+      };
+      // least significant byte first; every maximal stretch of varying bytes is one call (bits of byte j: [64 - 8 (j + 1), 64 - 8 j))
+      for (int j = (int)used - 1; j >= 0;) {
+        if (!varies((uint32_t)j)) { j--; continue; }
+        int j_hi = j;
+        while (j - 1 >= 0 && varies((uint32_t)(j - 1))) j--;
+        pass(MK_CHUNK, c, 64 - 8 * j, 64 - 8 * (j_hi + 1));
+        j--;
+      }
     }
     // object index <= number of make rows (0 is _root); a document whose only map is _root needs no object pass at all
     if (hc->n_objects) pass(MK_OBJECT, 0, bits_for(hc->n_objects));
@@ -1511,13 +1568,14 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   hipLaunchKernelGGL(k_euler_rank_lds, dim3(1), dim3(EULER_LDS_THREADS), 0, st, b.counts, b.euler_a);
 
   lap("first half enqueued");
-  if (b.sig) read_phase_counts(b, &b.sig->counts_seq, b.sig->counts, hc, st);
+  MapKeyStats key_stats;
+  if (b.sig) read_phase_counts(b, &b.sig->counts_seq, b.sig->counts, hc, st, &key_stats);
   else (void)hipEventSynchronize(ev_counts);
   lap("counts read");
   if (hc->flags) { (void)hipStreamSynchronize(st); return; }
   const uint32_t ni = hc->n_list_ins, nu = hc->n_list_upd, n_obj = hc->n_objects + 1;
   uint32_t map_small = 0;  // a few map emissions: they ride with k_list_order_objs when that kernel is going to run
-  order_map_emissions(b, ir, hc, st, ni && n_obj <= OBJ_LDS_MAX ? &map_small : nullptr);
+  order_map_emissions(b, ir, hc, st, ni && n_obj <= OBJ_LDS_MAX ? &map_small : nullptr, b.sig ? &key_stats : nullptr);
 
   if (ni) {
     if (b.sig) read_phase_counts(b, &b.sig->runs_seq, b.sig->runs, hc_runs, st);
