@@ -255,11 +255,21 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
       const uint32_t len = o.key_len[g];
       const uint8_t* kp = b.arena + o.key_off[g];
       w[0] = len; w[1] = ~len;
-      for (uint32_t j = 0; j < 16; j++) {
-        const uint32_t x = j < len ? utf16_order_byte(kp[j]) : 0u;
-        w[2 + (j >> 2)] |= x << (24 - 8 * (j & 3));
+      // the first sixteen key bytes in two 8-byte loads (the arena has slack behind its last byte), bytes behind the key's end zeroed
+      unsigned long long lo, hi;
+      __builtin_memcpy(&lo, kp, 8);
+      __builtin_memcpy(&hi, kp + 8, 8);
+      if (len < 8) { lo &= len ? (~0ull >> (64 - 8 * len)) : 0ull; hi = 0; }
+      else if (len < 16) hi &= len > 8 ? (~0ull >> (64 - 8 * (len - 8))) : 0ull;
+      uint32_t q[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+      for (uint32_t k = 0; k < 4; k++) {
+        uint32_t x = __builtin_bswap32(q[k]);  // first byte highest, as map_key_of packs them
+        // (the UTF-16 order remap only touches lead bytes EE..F4: rare, byte by byte then)
+        if (((x >> 24) >= 0xee) || (((x >> 16) & 0xff) >= 0xee) || (((x >> 8) & 0xff) >= 0xee) || ((x & 0xff) >= 0xee))
+          x = utf16_order_byte(x >> 24) << 24 | utf16_order_byte((x >> 16) & 0xff) << 16 | utf16_order_byte((x >> 8) & 0xff) << 8 | utf16_order_byte(x & 0xff);
+        w[2 + k] = x;
+        w[6 + k] = ~x;
       }
-      for (uint32_t k = 0; k < 4; k++) w[6 + k] = ~w[2 + k];
     }
     __shared__ uint32_t s_or[10];
     if (threadIdx.x < 10) s_or[threadIdx.x] = 0;
