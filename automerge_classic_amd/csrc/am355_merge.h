@@ -24,7 +24,8 @@ struct Counts {
   uint32_t n_quirk;      // list rows that need the reference's counter / `remove` rules (new.js:937-965, 1010-1033): counters completed by
                          // increments, visible rows without a value. 0 = the ordinary edits (merge_run then skips k_quirk_rows)
   uint32_t n_list_inc;   // increments on list elements seen by k_resolve: only then does k_emit look for counters among the invisible `set` rows of lists
-  uint32_t reserved[2];
+  uint32_t map_group_big; // k_map_group_rank met more than MAP_GROUP_MAX values on one key: the host orders the emissions again, by radix passes over the trigger ids
+  uint32_t reserved[1];
 };
 
 // What the keys of the map emissions have in common (k_emit; behind Counts in its device block, cleared with it, signalled with it):

@@ -425,6 +425,34 @@ __global__ __launch_bounds__(BLOCK) void k_map_sort_small(MergeBufs b, uint32_t 
   perm[rank] = i;
 }
 
+// The values of one key in op id order WITHOUT radix passes over the trigger ids (three passes of two launches for 22-bit ids): the key
+// passes leave the emissions of one (object, key) next to each other in emission order; every emission ranks itself among them --
+// a handful: the conflicting values of a register -- and takes its place. More than MAP_GROUP_MAX values on one key (thousands of
+// actors assigning one key concurrently): Counts.map_group_big, and the host orders again with the trigger passes.
+constexpr uint32_t MAP_GROUP_MAX = 256;
+__global__ __launch_bounds__(BLOCK) void k_map_group_rank(MergeBufs b, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n) {
+  uint32_t i = gtid();
+  if (i >= n) return;
+  const uint32_t e = perm_in[i], g = b.em_row[e], orow = b.obj_row[g];
+  auto same = [&](uint32_t j) {
+    const uint32_t g2 = b.em_row[perm_in[j]];
+    return b.obj_row[g2] == orow && same_key(b, g2, g);
+  };
+  uint32_t s = i, t = i, steps = 0;
+  while (s > 0 && steps <= MAP_GROUP_MAX && same(s - 1)) { s--; steps++; }
+  while (t + 1 < n && steps <= MAP_GROUP_MAX && same(t + 1)) { t++; steps++; }
+  if (steps > MAP_GROUP_MAX) { b.counts->map_group_big = 1; return; }
+  const unsigned long long mine = b.em_trig[e];
+  uint32_t rank = 0;
+  for (uint32_t j = s; j <= t; j++) {
+    if (j == i) continue;
+    const uint32_t e2 = perm_in[j];
+    const unsigned long long other = b.em_trig[e2];
+    rank += (other < mine || (other == mine && e2 < e)) ? 1u : 0u;
+  }
+  perm_out[s + rank] = e;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* __restrict__ v, uint32_t n) {
   uint32_t i = gtid();
   if (i < n) v[i] = i;
@@ -1475,12 +1503,13 @@ void merge_prepare(MergeBufs& b, hipStream_t aux) {
 
 // map emissions: LSD over (trigger id | key length | key chunks last..first | object)
 static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hipStream_t st, uint32_t* ride_with_list_order = nullptr,
-                                const MapKeyStats* ks = nullptr) {
+                                const MapKeyStats* ks = nullptr, bool trigger_passes = false) {
   uint32_t ne = hc->n_map_emit;
   if (!ne) return;
   uint32_t* perm_a = b.val_a;
   uint32_t* perm_b = b.val_b;
   int cur = 0;
+  bool by_rank = false;
   auto pass = [&](int mode, uint32_t chunk, int bits, int begin_bit = 0) {
     uint32_t* pin = cur ? perm_b : perm_a;
     uint64_t* kin = cur ? b.key_b : b.key_a;
@@ -1507,7 +1536,11 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
     cur = 1;
   } else {
     AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
-    pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
+    // (AM355_MAP_TRIGGER_PASSES=1, or the second attempt after Counts.map_group_big: the values of a key ordered by radix passes over
+    // their trigger ids, as in rounds 1-5; else by k_map_group_rank behind the key passes)
+    static const bool trigger_env = getenv("AM355_MAP_TRIGGER_PASSES") != nullptr;
+    by_rank = !(trigger_passes || trigger_env);
+    if (!by_rank) pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);
     // (round 5, second session: a byte position -- or the length -- that is the same in every key is not sorted by: the pass would be
     // the identity. k_emit leaves what the keys have in common behind the counters, MapKeyStats; keys like `k00017` lose two of
     // their six byte passes and the length pass: three of the map workload's ten passes of two launches each)
@@ -1535,6 +1568,10 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
     }
     // object index <= number of make rows (0 is _root); a document whose only map is _root needs no object pass at all
     if (hc->n_objects) pass(MK_OBJECT, 0, bits_for(hc->n_objects));
+  }
+  if (by_rank) {
+    AM355_LAUNCH_INDEPENDENT(k_map_group_rank, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), cur ? perm_a : perm_b, ne);
+    cur ^= 1;
   }
   AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
 }
@@ -1677,6 +1714,15 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   } else {
     (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
+  }
+  if (hc->map_group_big) {
+    // some key holds more values than k_map_group_rank walks (hundreds of actors assigning one key concurrently): the emissions are
+    // ordered once more, the values of a key by radix passes over their trigger ids
+    if (trace) fprintf(stderr, "  merge_run: a key with more than %u values: map emissions ordered again with the trigger passes\n", MAP_GROUP_MAX);
+    (void)hipMemsetAsync(&b.counts->map_group_big, 0, sizeof(uint32_t), st);
+    order_map_emissions(b, ir, hc, st, nullptr, b.sig ? &key_stats : nullptr, true);
+    (void)hipStreamSynchronize(st);
+    hc->map_group_big = 0;
   }
   lap("done");
 }
