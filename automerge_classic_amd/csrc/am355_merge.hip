@@ -430,11 +430,16 @@ __global__ __launch_bounds__(BLOCK) void k_map_sort_small(MergeBufs b, uint32_t 
 // a handful: the conflicting values of a register -- and takes its place. More than MAP_GROUP_MAX values on one key (thousands of
 // actors assigning one key concurrently): Counts.map_group_big, and the host orders again with the trigger passes.
 constexpr uint32_t MAP_GROUP_MAX = 256;
-__global__ __launch_bounds__(BLOCK) void k_map_group_rank(MergeBufs b, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n) {
+// (first8: the sort keys of the last pass when that pass was over the keys' first eight bytes -- in sorted order, one coalesced load:
+// neighbours whose first eight bytes differ are told apart without a look at their rows; null: not available)
+__global__ __launch_bounds__(BLOCK) void k_map_group_rank(MergeBufs b, const uint32_t* __restrict__ perm_in, uint32_t* __restrict__ perm_out, uint32_t n,
+                                                          const uint64_t* __restrict__ first8) {
   uint32_t i = gtid();
   if (i >= n) return;
   const uint32_t e = perm_in[i], g = b.em_row[e], orow = b.obj_row[g];
+  const uint64_t my8 = first8 ? first8[i] : 0;
   auto same = [&](uint32_t j) {
+    if (first8 && first8[j] != my8) return false;
     const uint32_t g2 = b.em_row[perm_in[j]];
     return b.obj_row[g2] == orow && same_key(b, g2, g);
   };
@@ -1510,7 +1515,9 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
   uint32_t* perm_b = b.val_b;
   int cur = 0;
   bool by_rank = false;
+  bool last_is_chunk0 = false;  // the last pass run sorted by bytes of the keys' first chunk: the key buffer then holds every key's first eight bytes
   auto pass = [&](int mode, uint32_t chunk, int bits, int begin_bit = 0) {
+    last_is_chunk0 = mode == MK_CHUNK && chunk == 0;
     uint32_t* pin = cur ? perm_b : perm_a;
     uint64_t* kin = cur ? b.key_b : b.key_a;
     const bool fused = sort_is_fused(ne) && bits > begin_bit;
@@ -1570,7 +1577,8 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
     if (hc->n_objects) pass(MK_OBJECT, 0, bits_for(hc->n_objects));
   }
   if (by_rank) {
-    AM355_LAUNCH_INDEPENDENT(k_map_group_rank, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), cur ? perm_a : perm_b, ne);
+    AM355_LAUNCH_INDEPENDENT(k_map_group_rank, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), cur ? perm_a : perm_b, ne,
+                             last_is_chunk0 ? (const uint64_t*)(cur ? b.key_b : b.key_a) : (const uint64_t*)nullptr);
     cur ^= 1;
   }
   AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
