@@ -2557,7 +2557,15 @@ void launch_decode_document(const uint8_t* arena, const ChangeMeta* meta, const 
   AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3(1, T_NUM_DOC), dim3(WAVE), st, arena, meta, plan, 1u, x, cols, flags, 0);
 }
 
-static uint32_t decode_group_split(uint32_t n_waves, uint32_t shard_world) { return (shard_world <= 1 && n_waves <= 512) ? 4u : 1u; }
+// Four wavefronts per change (one per column group) while all of them are resident at once: the small class holds six wavefronts per
+// SIMD -- 6144 on the device, 1536 changes --, the large class (24 KB of LDS per wavefront) a quarter of that. Measured (round 5, second
+// session, profiles/r05_s2_ab_decode_split.txt): `c2_text_typing` (1001 changes) T_device 0.255 -> 0.237 ms with the split; the headline's
+// 4097 changes decode 9 us faster with it but the replay is not (0.383 -> 0.390: sixteen thousand wavefronts take the SIMDs from the
+// fills beside them): rounds 3-5 split up to 512 changes. (AM355_DECODE_SPLIT_MAX: the small class's bound, for A/B runs.)
+static uint32_t decode_group_split(uint32_t n_waves, uint32_t shard_world, bool large_class = false) {
+  static const uint32_t split_max = []() { const char* e = getenv("AM355_DECODE_SPLIT_MAX"); return e && atol(e) > 0 ? (uint32_t)atol(e) : 1536u; }();
+  return (shard_world <= 1 && n_waves <= (large_class ? 512u : split_max)) ? 4u : 1u;
+}
 
 void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const ChangePlan* plans, uint32_t n_small, uint32_t n_large, uint32_t n_serial,
                            const uint32_t* amap, const uint32_t* slot_rank, OpCols cols, uint32_t* flags, hipStream_t st, hipStream_t aux, uint32_t shard_rank,
@@ -2571,7 +2579,7 @@ void launch_decode_columns(const uint8_t* arena, const ChangeMeta* metas, const 
   if (n_large && n_small + n_large <= 1024) { n_large += n_small; n_small = 0; }
   hipStream_t s2 = (n_small && aux) ? aux : st;
   if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small, decode_group_split(n_small, shard_world)), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, decode_group_split(n_large, shard_world)), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, decode_group_split(n_large, shard_world, true)), dim3(WAVE), 0, s2, arena, metas, plans + n_small, n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans + n_small + n_large, n_serial,
                              x, cols, flags, 0);
@@ -2584,7 +2592,7 @@ void launch_decode_planned(const uint8_t* arena, const ChangeMeta* metas, const 
   ActorXlate x{amap, slot_rank, shard_rank, shard_world};
   hipStream_t s2 = (n_small && aux) ? aux : st;
   if (n_small) hipLaunchKernelGGL(k_decode_wave<WaveLdsSmall>, dim3(n_small, decode_group_split(n_small, shard_world)), dim3(WAVE), 0, st, arena, metas, plans, n_small, x, cols, flags, DecodeGate{});
-  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, decode_group_split(n_large, shard_world)), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags, DecodeGate{});
+  if (n_large) hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_large, decode_group_split(n_large, shard_world, true)), dim3(WAVE), 0, s2, arena, metas, plans + (n_changes - n_large), n_large, x, cols, flags, DecodeGate{});
   if (n_serial)
     AM355_LAUNCH_INDEPENDENT(k_decode_columns, dim3((n_serial + WAVE - 1) / WAVE, T_NUM), dim3(WAVE), s2, arena, metas, plans_serial, n_serial, x, cols, flags, 0);
 }
@@ -2605,7 +2613,7 @@ void launch_decode_speculative(const uint8_t* arena, const ChangeMeta* metas, co
   // (!with_large: the caller expects no change of the large class -- none in the context's previous batch -- and launches that class
   // itself should there be one after all)
   if (with_large)
-    hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes, decode_group_split(n_changes, shard_world)), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
+    hipLaunchKernelGGL(k_decode_wave<WaveLdsLarge>, dim3(n_changes, decode_group_split(n_changes, shard_world, true)), dim3(WAVE), 0, aux, arena, metas, plans, 0u, x, cols, flags,
                        DecodeGate{totals, cap_ops, cap_preds, cap_distinct, n_changes, 1u});
 }
 
