@@ -238,8 +238,9 @@ int am355_fetch_ir(am355_ctx *ctx, am355_patch_ir *out);
  * give that patch, and am355_patch_json / am355_fetch_ir / am355_save / am355_get_applied ... describe the new state as after
  * am355_replay.
  * AM355_E_INVALID: the reference throws on this batch.  AM355_E_UNSUPPORTED: legal, but outside the subset served here -- the error
- * text names the reason (DR_* in csrc/am355_delta.h): two ops of one merge call on one list element, a list element that holds an
- * `inc` / `link` op or more than 32 value rows, a deletion whose place in the merge loop's work list is ambiguous, a property history
+ * text names the reason (DR_* in csrc/am355_delta.h): a list element that holds a `link` op, or counter rows on which the reference's
+ * count of visible elements and the values it lists part, or more value rows than the stage walks, a deletion whose place in the
+ * merge loop's work list is ambiguous, a property history
  * the device cannot replay (too long, or dependent on call boundaries the host did not keep), a sharded context.  A context made by
  * am355_load_document + am355_replay IS served: Backend.applyChanges(Backend.load(doc), changes) -- the engine rebuilds the document's
  * changes (am355_doc_changes: what computeHashGraph does in the reference), replays them as the state the batch goes onto, schedules
