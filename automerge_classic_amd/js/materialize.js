@@ -173,12 +173,17 @@ class Materializer {
         else if ((tl & 15) !== 6) { const head = this.decode(tl, off); if (head.datatype) edit.datatype = head.datatype }   // only truthy datatypes (new.js:762)
         edit.values = values
         out.push(edit)
-      } else {
-        // (a counter inside a list: its total, new.js:963 -- low word in the value-offset field, high word behind it)
-        const value = (flags & EDIT_COUNTER) ? { type: 'value', datatype: 'counter', value: (e[w + 9] | 0) * 4294967296 + off }
-          : this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0)
+      } else if (flags & EDIT_COUNTER) {
+        // (a counter inside a list: its total, new.js:963 -- low word in the value-offset field, high word behind it; rare: kept out of
+        // the two ordinary branches below)
+        const value = { type: 'value', datatype: 'counter', value: (e[w + 9] | 0) * 4294967296 + off }
         if (flags & EDIT_UPDATE) out.push({ action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value })
         else out.push({ action: 'insert', index, elemId: this.opId(e[w + 4], e[w + 5]), opId: this.opId(e[w + 2], e[w + 3]), value })
+      } else if (flags & EDIT_UPDATE) {
+        out.push({ action: 'update', index, opId: this.opId(e[w + 2], e[w + 3]), value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) })
+      } else {
+        out.push({ action: 'insert', index, elemId: this.opId(e[w + 4], e[w + 5]), opId: this.opId(e[w + 2], e[w + 3]),
+                   value: this.valueDiff(tl, off, (flags & EDIT_CHILD) !== 0) })
       }
       k = j
     }
