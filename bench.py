@@ -4,14 +4,15 @@
 A "step" is one pass of the hot path over one batch of synthetic changes, timed as SURVEY.md §8(d) defines T_replay:
 from "array of binary changes in HOST memory" to "patch IR + envelope in HOST memory" -- host inflate + staging, H2D,
 container parse + SHA-256 + column decode -> causal schedule -> op-set merge -> RGA order -> whole-document patch IR, D2H.
-`value` = ops / T_replay.  The same line also carries
-  t_device_ops_per_s   the replay alone, inputs already resident in HBM and the IR left in HBM (what round 1 reported as `value`),
-  roofline             whole path: N_ops x A / T_device with A = E + R + P algorithmic bytes per op, plus a
-                       per-kernel table (live HIP-event brackets of the phases; rocprofv3 + PMC figures of the top kernels
-                       from the committed summary of this same command, profiles/rNN_kernel_table.json of the latest round),
-  cpu_baseline         the CPU oracle (plain-C port of the reference's algorithm) on the same workload, 1 thread,
-  workloads            sub-lines for c4_text_multi, c3_map_lww, c2_text_typing, the headline log in shuffled delivery order
-                       (general scheduler, fast_path 0) and c5_doc_mixed (Backend.load), N = 1 only.
+`value` = ops / T_replay.
+
+stdout carries ONE compact JSON line (< 6 KB, strict JSON: compact_line) -- the contract keys, `t_device_ms`, the whole-path `roofline`
+(N_ops x A / T_device with A = E + R + P algorithmic bytes per op) with its dominant kernel as measured by a
+rocprofv3-traced child of this run, `cpu_baseline`, and one short row per sub-workload. The whole record -- live per-kernel table with PMC
+bytes, phase brackets, every sub-workload in full (c4_text_multi, c3_map_lww, c2_text_typing, the headline log shuffled / DEFLATEd / x4,
+c5_doc_mixed = Backend.load), sharding model, save / history / applyChanges / JS end-to-end timings -- goes to --detail
+(gpurun_out/bench_detail.json) and to stderr. Before anything is timed the engine's getPatch text of the workload is compared with
+the CPU oracle's on the same bytes (sha256; N = 1): a mismatch ends the run without a line.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4_text_single] [--scale 1.0] [--no-sublines]
 
@@ -45,11 +46,10 @@ WORKLOADS = {
 SHAPE = {"c2_text_typing": "one Text object, 1 actor", "c3_map_lww": "root map of 10 k keys, multi-value conflicts",
          "c4_text_single": "one Text object", "c4_text_multi": "64 Text objects at root keys", "c5_doc_mixed": "256 Text + nested maps + lists"}
 BASE_SEED = {"c2_text_typing": 0x5EED0002, "c3_map_lww": 0x5EED0003, "c4_text_single": 0x5EED0004, "c4_text_multi": 0x5EED0004, "c5_doc_mixed": 0x5EED0005}
-PARITY = ("bit-exact getPatch vs the CPU oracle at this size and vs reference goldens (pytest -m gpu); NOTE the STOCK reference is "
-          "delivery-order dependent on this workload (600-op block-boundary defect, tests/golden/defect_block_boundary.json): "
-          "the answer reproduced is the block-size-patched reference's = the documented RGA rule (DESIGN.md §6). At THIS size the oracle is the "
-          "only checker: it is pinned to the block-size-patched reference on this workload's shape up to 43 k ops in-tree "
-          "(tests/golden/save_generated.json, defect_block_boundary.json) -- an O(n^2) patched reference does not go further in minutes")
+PARITY = ("sha256(getPatch text) == CPU oracle's on this log, checked in this run before timing; oracle == block-size-patched reference "
+          "on this shape at 124,801 ops (tests/golden/headline_pin.json)")
+assert len(PARITY) <= 200
+LINE_LIMIT = 6144   # bytes: the driver keeps ~8 KB of stdout tail; the ONE json line must fit whole
 
 
 def make_log(name, scale, seed, deflate=False):
@@ -61,6 +61,32 @@ def make_log(name, scale, seed, deflate=False):
         return loggen.generate(loggen.KIND_TEXT_TYPING, seed=seed, name=name, **kw)
     kw["n_rounds"] = max(1, int(kw["n_rounds"] * scale))
     return loggen.generate(loggen.KIND_MAP_LWW if kind == "map" else loggen.KIND_TEXT_CONCURRENT, seed=seed, name=name, **kw)
+
+
+def oracle_patch_sha256(log):
+    """The in-run parity gate's checker (parity before any timing counts): sha256 of the CPU oracle's getPatch text
+    for this very log. The oracle is test infrastructure; here it only checks, the engine's own patch is what is compared."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.lib()
+    doc = oracle_lib.OracleDoc(log)
+    try:
+        return hashlib.sha256(doc.patch_json().encode()).hexdigest()
+    finally:
+        doc.close()
+
+
+def oracle_document_patch_sha256(doc_bytes):
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.lib()
+    doc = oracle_lib.OracleDoc.load_document(doc_bytes)
+    try:
+        return hashlib.sha256(doc.patch_json().encode()).hexdigest()
+    finally:
+        doc.close()
 
 
 def cpu_baseline(log, budget_s=12.0):
@@ -80,9 +106,7 @@ def cpu_baseline(log, budget_s=12.0):
         reps += 1
     return {"value": log.n_ops / best, "unit": "ops/s", "cores": 1, "kind": "port",
             "sample": f"{log.name}: {log.n_ops} ops, {log.n_changes} changes, best of {reps} runs of oracle loadChanges+getPatch "
-                      f"({time.perf_counter() - t_all:.1f} s of CPU work)",
-            "reference_js_note": "the reference itself (JavaScript, node 12, 1 core) cannot run on the GPU box (no reference tree there); in the build "
-                                 "container it replays this workload at ~25-30 k ops/s (BASELINE.md §2, DESIGN.md §7)"}
+                      f"({time.perf_counter() - t_all:.1f} s of CPU work)"}
 
 
 def reference_js_baseline(name, scale_full, seed):
@@ -182,16 +206,19 @@ def live_kernel_table(timeout_s=170):
 
 def reference_js_recorded(name):
     """The reference JS backend's rate on this workload as recorded in the build container (tools/record_reference_js.py ->
-    profiles/r05_reference_js_baseline.json): the reference tree cannot travel to the GPU box, its dated measurement can."""
-    path = os.path.join(ROOT, "profiles", "r05_reference_js_baseline.json")
+    profiles/rNN_reference_js_baseline.json, the latest round's): the reference tree cannot travel to the GPU box, its dated
+    measurement can."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_reference_js_baseline.json")))
     try:
-        with open(path) as f:
+        with open(files[-1]) as f:
             rec = json.load(f)
         w = rec["workloads"][name]
     except Exception:
         return None
+    rel = os.path.relpath(files[-1], ROOT)
     return {"value": w["ops_per_s"], "unit": "ops/s", "cores": w["cores"], "kind": "reference", "sample": w["sample"], "recorded": rec["date"], "host": rec["host"],
-            "node": rec["node"], "file": "profiles/r05_reference_js_baseline.json",
+            "node": rec["node"], "file": rel,
             "note": "NOT measured in this run: recorded with bench.reference_js_baseline in the build container, where node and the reference tree exist"}
 
 
@@ -518,7 +545,7 @@ def sharding_model(sub, n_list=(1, 2, 4, 8)):
             "note": "strong scaling of ONE document; the deployment shape (one document per GPU, `value` at N > 1) scales with N by construction"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -530,27 +557,27 @@ def main():
     ap.add_argument("--no-sublines", action="store_true")
     ap.add_argument("--no-live-trace", action="store_true", help="do not run the rocprofv3-traced child that fills roofline.kernels (the committed table is embedded instead)")
     ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the objectId-sharded measurement that follows the replica measurement")
-    args = ap.parse_args()
+    ap.add_argument("--subline-scale", type=float, default=1.0, help="scale of the sub-workloads (tests run the line builder at a small one)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the full record goes (the stdout line is the compact one)")
+    return ap.parse_args(argv)
 
-    import torch
-    from automerge_classic_amd import dist_util, engine
-    rank, world, local_rank = dist_util.rank_world()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    eng = engine.Engine(local_rank)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+def run(args, eng, rank, world, dist, device, barrier, sync):
+    """Everything bench.py measures, as ONE record (rank 0; None on the other ranks). main() prints its compact form (compact_line) on
+    stdout and the whole of it to --detail and stderr."""
+    import hashlib
+    from automerge_classic_amd import dist_util
     w = Workload(eng, args.workload, args.scale, dist_util.rank_seed(BASE_SEED[args.workload], rank))
+    # ---- the in-run parity gate (BASELINE.md §3: before any timing counts): the engine's getPatch text of the workload about to be
+    # timed == the CPU oracle's on the same bytes (sha256 of the text). N = 1 only (the oracle leg runs on rank 0 at N = 1).
+    parity_in_run = "skipped (--no-cpu-baseline)" if args.no_cpu_baseline else "skipped (N > 1: the oracle leg runs at N = 1 only)" if world > 1 else None
+    if parity_in_run is None:
+        w.step_replay()
+        got = hashlib.sha256(eng.patch_json().encode()).hexdigest()
+        want = oracle_document_patch_sha256(w.doc_bytes) if w.is_doc else oracle_patch_sha256(w.log)
+        if got != want:
+            raise SystemExit(f"PARITY GATE FAILED: sha256(engine getPatch) {got} != sha256(oracle getPatch) {want} on {args.workload} x{args.scale}: no timing is reported")
+        parity_in_run = True
     # untimed: a fresh box needs a moment of load before it runs at its steady rate (on two of five boxes of the pool the first
     # ~0.2 s of steps -- the PCIe-heavy staging part -- ran 30 % slower than everything after); then the W warm-up steps of the contract
     t_pre, pre = time.perf_counter(), []
@@ -566,23 +593,21 @@ def main():
     # ---- the timed region of `value`: K steps of T_replay (host buffers in -> patch IR in host memory) ----
     elapsed = timed(w.step_replay, args.steps, barrier)
     st = eng.stats()
-    elapsed, total_ops = dist_util.aggregate(elapsed, float(st.n_ops) * args.steps, dist, torch.device("cuda", local_rank))
+    elapsed, total_ops = dist_util.aggregate(elapsed, float(st.n_ops) * args.steps, dist, device)
     # ---- T_device (not `value`): the replay alone, inputs resident in HBM ----
     w.stage()
     for _ in range(3):
         w.step_device()
     t_dev = timed(eng.replay, args.steps, barrier)
-    t_dev, _ = dist_util.aggregate(t_dev, 0.0, dist, torch.device("cuda", local_rank))
-    phases = measure_phases(w, args.steps, lambda: torch.cuda.synchronize())  # (its own context, HIP events between the phases: not timed)
+    t_dev, _ = dist_util.aggregate(t_dev, 0.0, dist, device)
+    phases = measure_phases(w, args.steps, sync)  # (its own context, HIP events between the phases: not timed)
     sharded = sharded_c5 = None
     if world > 1 and not args.no_shard:
-        sharded = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), max(5, min(args.steps // 2, 30)), 3, barrier)
+        sharded = sharded_measurement(eng, rank, world, dist, device, max(5, min(args.steps // 2, 30)), 3, barrier)
         # BASELINE config 5 (the other 8-GPU configuration): one saved document over the N ranks
-        sharded_c5 = sharded_measurement(eng, rank, world, dist, torch.device("cuda", local_rank), 3, 1, barrier, name="c5_doc_mixed")
+        sharded_c5 = sharded_measurement(eng, rank, world, dist, device, 3, 1, barrier, name="c5_doc_mixed")
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
     st = eng.stats()
     value = total_ops / elapsed
     t_device_ms = t_dev / args.steps * 1e3
@@ -600,7 +625,8 @@ def main():
     import glob
     tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_table.json")))  # (the latest round's summary)
     table = tables[-1] if tables else os.path.join(ROOT, "profiles", "r02_kernel_table.json")
-    live = live_kernel_table() if (args.workload == "c4_text_single" and args.scale == 1.0 and world == 1 and not args.no_live_trace) else None
+    headline = args.workload == "c4_text_single" and args.scale == 1.0
+    live = live_kernel_table() if (headline and world == 1 and not args.no_live_trace) else None
     if live is not None:
         roofline["kernels"] = live.get("kernels")
         roofline["traffic"] = live.get("traffic_bytes_per_replay") or None
@@ -608,7 +634,7 @@ def main():
         roofline["kernels_live"] = True
         roofline["kernels_trace_seconds"] = live.get("seconds")
         roofline["t_device_ms_under_trace"] = live.get("t_device_ms_under_trace")
-    elif os.path.exists(table) and args.workload == "c4_text_single" and args.scale == 1.0:
+    elif os.path.exists(table) and headline:
         roofline["kernels_live"] = False
         # rocprofv3 kernel-trace + PMC passes of this same command (committed summary; counters cannot be read in-process):
         # per kernel: calls per replay, average us, algorithmic bytes, PMC HBM bytes, fraction of the 8 TB/s peak
@@ -629,7 +655,8 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": w.describe(st) + "; one document per GPU",
                    "timed_region": "T_replay (SURVEY.md §8d): binary changes in host memory -> host inflate/staging -> H2D -> replay -> patch IR + envelope in host memory",
-                   "parity": PARITY, "fast_path": int(st.fast_path), "untimed_before_the_K_steps": f"{args.prewarm} s of steps + {args.warmup} warm-up steps"},
+                   "parity": PARITY, "parity_checked_in_run": parity_in_run, "fast_path": int(st.fast_path),
+                   "untimed_before_the_K_steps": f"{args.prewarm} s of steps + {args.warmup} warm-up steps"},
         "t_device_ops_per_s": st.n_ops / (t_device_ms * 1e-3), "t_device_ms": t_device_ms,
         "phases_ms": phases, "algorithmic_bytes_per_op": A, "n_list_elems": int(st.n_list_elems), "save": save_info, "roofline": roofline,
     }
@@ -651,7 +678,7 @@ def main():
                 ref_js["leg"] = "reference JS backend (AUTOMERGE_REF resolved)"
                 out["cpu_baseline"] = ref_js
             else:
-                port["leg"] = "C port of the reference's algorithm (oracle/): node or the reference tree is not on this box"
+                port["leg"] = "C port of the reference's algorithm (oracle/): the reference tree is not on this box; its recorded rate is beside it"
                 rec = reference_js_recorded(args.workload)
                 if rec is not None:
                     port["reference_js_recorded"] = rec
@@ -663,18 +690,19 @@ def main():
             if "t_e2e_ms" in e2e:
                 out["t_e2e_ms"] = e2e["t_e2e_ms"]
     if not args.no_sublines and world == 1:
+        ss = args.subline_scale
         subs, k, wu = [], max(5, min(args.steps // 3, 30)), 3
         for name in ("c4_text_multi", "c3_map_lww", "c2_text_typing"):
             if name != args.workload:
-                subs.append(subline(eng, name, 1.0, BASE_SEED[name], k, wu, barrier))
-        subs.append(subline(eng, "c4_text_single", 1.0, BASE_SEED["c4_text_single"], k, wu, barrier, shuffled=True))
+                subs.append(subline(eng, name, ss, BASE_SEED[name], k, wu, barrier))
+        subs.append(subline(eng, "c4_text_single", ss, BASE_SEED["c4_text_single"], k, wu, barrier, shuffled=True))
         # the same log with every change DEFLATEd as the reference's encodeChange does for changes >= 256 bytes (columnar.js:798-811):
         # T_replay then includes the host inflate (zlib, on the engine's host threads)
-        subs.append(subline(eng, "c4_text_single", 1.0, BASE_SEED["c4_text_single"], k, wu, barrier, deflate=True))
+        subs.append(subline(eng, "c4_text_single", ss, BASE_SEED["c4_text_single"], k, wu, barrier, deflate=True))
         # a larger batch of the headline shape (4 x: 4.1 M ops, 54 MB of changes): the same kernels with more work per launch
-        subs.append(subline(eng, "c4_text_single", 4.0, BASE_SEED["c4_text_single"], 8, 2, barrier))
+        subs.append(subline(eng, "c4_text_single", 4.0 * ss, BASE_SEED["c4_text_single"], min(8, k), 2, barrier))
         if args.workload != "c5_doc_mixed":
-            subs.append(subline(eng, "c5_doc_mixed", 1.0, BASE_SEED["c5_doc_mixed"], 5, 2, barrier, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0))
+            subs.append(subline(eng, "c5_doc_mixed", ss, BASE_SEED["c5_doc_mixed"], min(5, k), 2, barrier, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0))
         out["workloads"] = subs
         multi = next((x for x in subs if x["workload"].startswith("c4_text_multi")), None)
         if multi is not None:
@@ -701,7 +729,145 @@ def main():
                                          "timed_region": "am355_doc_changes of the loaded document: binary changes + hashes in host memory (best of 5 after one untimed call)"}
         if not w.is_doc:
             out["apply_changes"] = apply_changes_section(eng, w.log, barrier)
-    print(json.dumps(out))
+    return out
+
+
+def _r(x, digits=4):
+    """Numbers of the compact line: 4 significant digits are what a reader compares; NaN / inf never reach the line."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    if x == 0.0:
+        return 0.0
+    from math import floor, log10
+    return round(x, digits - 1 - int(floor(log10(abs(x)))))
+
+
+def compact_line(d):
+    """The ONE stdout line (<= LINE_LIMIT bytes): the contract keys, the whole-path roofline with the dominant kernel, the CPU baseline,
+    one short row per sub-workload. Everything else of run()'s record stays in --detail."""
+    cfg = d["config"]
+    line = {k: d[k] for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"] = _r(d["value"], 6)
+    line["ms_per_step"] = _r(d["ms_per_step"], 5)
+    line["config"] = {"workload": cfg["workload"][:300], "timed_region": cfg["timed_region"][:200], "parity": cfg["parity"][:200],
+                      "parity_checked_in_run": cfg["parity_checked_in_run"], "fast_path": cfg["fast_path"]}
+    line["t_device_ms"] = _r(d["t_device_ms"], 5)
+    line["algorithmic_bytes_per_op"] = {k: _r(v) for k, v in d["algorithmic_bytes_per_op"].items()}
+    rf = d["roofline"]
+    roof = {"bound": rf["bound"], "achieved": _r(rf["achieved"], 5), "peak": rf["peak"], "unit": rf["unit"], "frac": _r(rf["frac"], 4),
+            "traffic": rf.get("traffic"), "kernel": rf["kernel"], "launch_ms": _r(rf["launch_ms"], 5),
+            "algorithmic_bytes_per_launch": int(rf["algorithmic_bytes_per_launch"])}
+    ks = [k for k in (rf.get("kernels") or []) if k.get("avg_us")]
+    if ks:
+        dom = max(ks, key=lambda k: k.get("pct_of_kernel_time") or 0.0)
+        roof["dominant_kernel"] = {"name": str(dom.get("kernel"))[:60], "avg_us": _r(dom.get("avg_us")), "pct_of_kernel_time": _r(dom.get("pct_of_kernel_time")),
+                                   "algorithmic_bytes": dom.get("algorithmic_bytes"), "frac": _r(dom.get("frac_of_hbm_peak")),
+                                   "pmc_traffic_bytes": dom.get("pmc_traffic_bytes"), "live": bool(rf.get("kernels_live"))}
+        if rf.get("traffic"):
+            roof["traffic_over_algorithmic"] = _r(rf["traffic"] / max(rf["algorithmic_bytes_per_launch"], 1.0))
+    line["roofline"] = roof
+    cb = d.get("cpu_baseline")
+    if cb:
+        c = {k: (_r(cb[k], 5) if k == "value" else cb[k]) for k in ("value", "unit", "cores", "kind") if k in cb}
+        c["sample"] = str(cb.get("sample", ""))[:220]
+        if "port" in cb:
+            c["port"] = {"value": _r(cb["port"]["value"], 5), "cores": cb["port"]["cores"]}
+        rec = cb.get("reference_js_recorded")
+        if rec:
+            c["reference_js_recorded"] = {"value": _r(rec["value"], 5), "file": rec["file"], "recorded": rec.get("recorded"),
+                                          "why": "the reference tree cannot travel to the GPU box: its rate recorded in the build container by tools/record_reference_js.py"}
+        line["cpu_baseline"] = c
+    rows = []
+    for x in d.get("workloads") or []:
+        row = {"name": x["workload"].split(":")[0], "ops_per_s": _r(x["ops_per_s"], 5), "ms_per_step": _r(x["ms_per_step"], 5),
+               "t_device_ms": _r(x["t_device_ms"], 5), "frac": _r(x["roofline_whole_path"]["frac"], 4)}
+        rows.append(row)
+    if rows:
+        line["workloads"] = rows
+    if d.get("apply_changes"):
+        line["apply_changes_ms"] = [[b["batch_changes"], _r(b["ms"])] for b in d["apply_changes"]["batches"]]
+    for k in ("t_e2e_ms",):
+        if d.get(k) is not None:
+            line[k] = _r(d[k])
+    if d.get("save"):
+        line["save_ms"] = _r(d["save"]["ms"])
+    if d.get("history_after_load"):
+        line["history_after_load_ms"] = _r(d["history_after_load"]["ms"])
+    for k in ("sharded", "sharded_c5"):
+        if d.get(k):
+            x = d[k]
+            line[k] = {"n_gpus": x["n_gpus"], "scaling": x["scaling"], "ops_per_s": _r(x["ops_per_s"], 5), "ms_per_step": _r(x["ms_per_step"], 5),
+                       "single_gpu_ms_per_step": _r(x["single_gpu_ms_per_step"], 5), "speedup_vs_single_gpu": _r(x["speedup_vs_single_gpu"]),
+                       "parity": x["parity"][:80]}
+    if d.get("sharding_model"):
+        line["sharding_model_projected_speedup"] = {str(r["n_gpus"]): _r(r["projected_speedup"]) for r in d["sharding_model"]["projected"]}
+    line["detail"] = d.get("detail_file", "gpurun_out/bench_detail.json")
+    # the line must fit whole in the driver's record: drop the optional parts, last first, until it does
+    for k in ("sharding_model_projected_speedup", "history_after_load_ms", "save_ms", "apply_changes_ms", "sharded_c5", "workloads"):
+        if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT - 64:
+            break
+        line.pop(k, None)
+    return line
+
+
+def _finite(x):
+    """run()'s record with every NaN / inf replaced by None (strict JSON on both outputs)."""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, np.generic):
+        return _finite(x.item())
+    return x
+
+
+def emit(detail, path):
+    """stderr + --detail: the whole record. stdout: the compact line, the LAST thing printed."""
+    detail = _finite(detail)
+    detail["detail_file"] = os.path.relpath(path, ROOT) if path else None
+    text = json.dumps(detail, allow_nan=False)
+    if path:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:   # (a read-only checkout must not cost the line)
+            print(f"bench detail not written: {e}", file=sys.stderr)
+    print("bench detail: " + text, file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(detail), allow_nan=False)
+    assert len(line) < LINE_LIMIT, len(line)
+    print(line, flush=True)
+    return line
+
+
+def main():
+    args = parse_args()
+    import torch
+    from automerge_classic_amd import dist_util, engine
+    rank, world, local_rank = dist_util.rank_world()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    eng = engine.Engine(local_rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    detail = run(args, eng, rank, world, dist, torch.device("cuda", local_rank), barrier, torch.cuda.synchronize)
+    if detail is not None:
+        emit(detail, args.detail)
     if dist is not None:
         dist.destroy_process_group()
 

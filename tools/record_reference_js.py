@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Records the UNMODIFIED reference JS backend's rate on the bench workloads in the BUILD container (node + /root/reference exist here,
-not on the GPU box) into profiles/r05_reference_js_baseline.json -- dated, with the box and the node version. bench.py embeds the file
+not on the GPU box) into profiles/r06_reference_js_baseline.json -- dated, with the box and the node version. bench.py embeds the file
 as cpu_baseline.reference_js_recorded next to the live C-port leg it can run on the GPU box (VERDICT r4 missing #4: the reference tree
 cannot travel; a committed measurement made by the bench's own reference_js_baseline leg can).
 
@@ -72,7 +72,7 @@ def main():
     out["workloads"]["c5_doc_mixed"] = {"ops_per_s": rows / r["median_s"], "cores": 1,
                                         "sample": f"c5_doc_mixed x0.02: Backend.load + getPatch of a {len(doc)}-byte saved document, {rows} op rows, median of 3"}
     print("c5_doc_mixed", "%.0f rows/s" % (rows / r["median_s"]), flush=True)
-    path = os.path.join(ROOT, "profiles", "r05_reference_js_baseline.json")
+    path = os.path.join(ROOT, "profiles", "r06_reference_js_baseline.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)
