@@ -124,6 +124,36 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   canary_note(p, sort_workspace_bytes((uint32_t)((size_t)NM + cap + 1)));
 }
 
+// word ranges of the stage's device block and the value each is filled with (delta_run)
+struct DeltaFills {
+  uint32_t* p[8];
+  uint32_t n_words[8];
+  uint32_t value[8];
+  uint32_t n;
+};
+// The counter words (ranges 0 and 1 overlap: `reason` is set behind the clearing of the block that holds it) are written by thread 0
+// of workgroup 0 in range order; every other range is grid-strided, four words per thread where the alignment allows.
+__global__ __launch_bounds__(BLOCK) void kd_fills(DeltaFills f) {
+  const uint32_t tid = gtid(), stride = gridDim.x * BLOCK;
+  for (uint32_t k = 0; k < f.n; k++) {
+    uint32_t* p = f.p[k];
+    const uint32_t n = f.n_words[k], v = f.value[k];
+    if (n <= 64) {  // (small ranges may overlap: one thread, in order)
+      if (tid == 0) for (uint32_t i = 0; i < n; i++) p[i] = v;
+      continue;
+    }
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4u;  // words up to the first 16-byte boundary
+    const uint32_t n4 = (n - head) / 4;
+    uint4* q = (uint4*)(p + head);
+    uint4 vv;
+    vv.x = vv.y = vv.z = vv.w = v;
+    for (uint32_t i = tid; i < n4; i += stride) q[i] = vv;
+    if (tid < head) p[tid] = v;
+    const uint32_t tail = head + 4 * n4;
+    if (tid < n - tail) p[tail + tid] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // objects: parent link of every object (setupPatches walks them on the host, new.js:1461-1528)
 // ---------------------------------------------------------------------------------------------------------
@@ -984,13 +1014,22 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     hipError_t e = hipStreamSynchronize(st);
     fprintf(stderr, "delta_run: %-18s %s (N %u T0 %u new %u obj %u map %u list %u cap %u)\n", what, hipGetErrorString(e), N, d.T0, d.n_new, d.n_obj, d.n_map, d.n_list, cap);
   };
-  (void)hipMemsetAsync(d.counts, 0, sizeof(DeltaCounts), st);
-  (void)hipMemsetAsync(&d.counts->reason, 0xff, 4, st);
-  (void)hipMemsetAsync(d.first_del, 0xff, (size_t)((uint8_t*)(d.first_kill + N + 1) - (uint8_t*)d.first_del), st);   // first_del | first_kill
-  (void)hipMemsetAsync(d.new_succ, 0, (size_t)((uint8_t*)(d.upd_cur + N + 2) - (uint8_t*)d.new_succ), st);           // new_succ | upd_n | upd_cur
-  (void)hipMemsetAsync(d.icur, 0, 4 * ((size_t)d.n_list + 2), st);
-  (void)hipMemsetAsync(d.slot_rep, 0, (size_t)((uint8_t*)(d.slot_drop + cap + 1) - (uint8_t*)d.slot_rep), st);  // slot_rep | slot_last | slot_cnt | slot_child | slot_drop
-  (void)hipMemsetAsync(d.slot_first, 0xff, 4 * ((size_t)cap + 1), st);
+  {
+    // every fill of the stage in ONE launch (seven memsets in a row cost a launch gap each: ~35 us of a 0.2 ms stage)
+    DeltaFills f{};
+    auto add = [&](void* q, size_t bytes, uint32_t v) { f.p[f.n] = (uint32_t*)q; f.n_words[f.n] = (uint32_t)((bytes + 3) / 4); f.value[f.n] = v; f.n++; };
+    add(d.counts, sizeof(DeltaCounts), 0);
+    add(&d.counts->reason, 4, 0xffffffffu);   // (behind the range that clears it: the ranges are filled in order by the same threads' loop)
+    add(d.first_del, (size_t)((uint8_t*)(d.first_kill + N + 1) - (uint8_t*)d.first_del), 0xffffffffu);   // first_del | first_kill
+    add(d.new_succ, (size_t)((uint8_t*)(d.upd_cur + N + 2) - (uint8_t*)d.new_succ), 0);                  // new_succ | upd_n | upd_cur
+    add(d.icur, 4 * ((size_t)d.n_list + 2), 0);
+    add(d.slot_rep, (size_t)((uint8_t*)(d.slot_drop + cap + 1) - (uint8_t*)d.slot_rep), 0);  // slot_rep | slot_last | slot_cnt | slot_child | slot_drop
+    add(d.slot_first, 4 * ((size_t)cap + 1), 0xffffffffu);
+    size_t words = 0;
+    for (uint32_t k = 0; k < f.n; k++) words += f.n_words[k];
+    uint32_t grid = (uint32_t)std::min<size_t>((words / 4 + BLOCK - 1) / BLOCK + 1, 2048);
+    hipLaunchKernelGGL(kd_fills, dim3(grid), dim3(BLOCK), 0, st, f);
+  }
   AM355_LAUNCH_INDEPENDENT(kd_objects, dgrid(d.n_obj), dim3(BLOCK), st, b, ir, d);
   step("objects");
   if (N) AM355_LAUNCH_INDEPENDENT(kd_rows, dgrid(N), dim3(BLOCK), st, b, d);
@@ -1049,7 +1088,10 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   }
   int cur = 0;
   if (m) {
-    static const bool no_lds = getenv("AM355_DELTA_NO_LDS") != nullptr;  // (tests: the level-by-level version on small batches too)
+    const bool no_lds = getenv("AM355_DELTA_NO_LDS") != nullptr;  // (tests: the level-by-level version on small batches too)
+    // (Round 6 tried all levels in ONE 1024-thread workgroup over HBM for up to 32 k items, profiles/r06_apply_partition_wg.txt: 35 us per
+    // level against ~15 for the three launches -- one CU's memory pipeline is no match for 256, and the device-side cost of a dependent
+    // kernel boundary is only ~1.5-2 us, MI355X_MICROARCH.md "boundary". Taken out again.)
     if (m <= PART_LDS_MAX && !no_lds) {
       hipLaunchKernelGGL(kd_partition_lds, dim3(1), dim3(BLOCK), 0, st, d, m, d.bits_new);
       cur = (int)(d.bits_new & 1u);

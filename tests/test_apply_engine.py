@@ -212,6 +212,26 @@ def test_generated_logs_in_batches_match_the_oracle_emulated(emu_lib, kind, kw, 
         eng.close()
 
 
+def test_partition_variants_agree_emulated(emu_lib, monkeypatch):
+    """The dominance counts of the list edits by both versions of the partition levels -- all levels in LDS (<= 1024 items) and three
+    launches per level -- give the oracle's patches, on batches of a few hundred and of ~1200 items."""
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=8, n_rounds=4, ins_per_change=60, del_per_change=15, n_objects=2, seed=29)
+    texts = []
+    for env in ({}, {"AM355_DELTA_NO_LDS": "1"}):
+        monkeypatch.delenv("AM355_DELTA_NO_LDS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng, eng2 = engine.Engine(0, emu_lib), engine.Engine(0, emu_lib)
+        try:
+            check_against_oracle_session(eng, split_log(log, 2))
+            check_against_oracle_session(eng2, split_log(log, 16))
+            texts.append(eng.patch_json())
+        finally:
+            eng.close()
+            eng2.close()
+    assert texts[0] == texts[1]
+
+
 def test_batches_behind_the_staged_changes_or_restaged_emulated(emu_lib, monkeypatch):
     """A batch onto a state whose changes are all applied is staged behind them (only the batch is copied); AM355_APPLY_RESTAGE=1
     rebuilds the whole queue instead, as a call with queued changes does. Same patches either way, deflated batches included."""
