@@ -10,6 +10,13 @@
 #define AM355_LAUNCH_INDEPENDENT(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #endif
 
+// Commands two host threads enqueue into two streams are ordered by the events between the streams: the replay lets a helper thread
+// enqueue the hash stream's commands beside the calling thread (am355_replay.hip). (A runtime whose launches run to their end inside
+// the call has no such order and defines this 0 -- the CPU test harness in tests/emu/ does.)
+#ifndef AM355_STREAMS_ORDER_ACROSS_THREADS
+#define AM355_STREAMS_ORDER_ACROSS_THREADS 1
+#endif
+
 // occupancy floor of a kernel (wavefronts per SIMD the register allocation must allow): a device-compiler attribute
 #if defined(__HIP_DEVICE_COMPILE__)
 #define AM355_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))

@@ -446,7 +446,9 @@ __global__ __launch_bounds__(BLOCK) void k_map_group_rank(MergeBufs b, const uin
   uint32_t s = i, t = i, steps = 0;
   while (s > 0 && steps <= MAP_GROUP_MAX && same(s - 1)) { s--; steps++; }
   while (t + 1 < n && steps <= MAP_GROUP_MAX && same(t + 1)) { t++; steps++; }
-  if (steps > MAP_GROUP_MAX) { b.counts->map_group_big = 1; return; }
+  // (the host orders the emissions again when it reads the flag; until then k_map_finish runs over THIS buffer: a valid entry, not
+  // whatever the scratch held -- ADVICE r5)
+  if (steps > MAP_GROUP_MAX) { b.counts->map_group_big = 1; perm_out[i] = e; return; }
   const unsigned long long mine = b.em_trig[e];
   uint32_t rank = 0;
   for (uint32_t j = s; j <= t; j++) {

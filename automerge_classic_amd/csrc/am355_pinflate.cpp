@@ -247,17 +247,31 @@ struct SymOut {
   PInflateChunk* ch;
   uint16_t* out;    // next symbol
   uint16_t* limit;  // grow when out passes it (keeps room for one loop iteration: three literals + one match + copy overshoot)
+  size_t cap_syms = ~(size_t)0;               // the job's output cap: the chunk alone must not pass it ...
+  std::atomic<size_t>* job_made = nullptr;    // ... nor all chunks of the job together (symbols made so far, reported at every grow)
   static constexpr size_t SLACK = 280;
-  bool reserve(size_t cap_syms) {
-    if (cap_syms <= ch->sym_cap) return true;
-    uint16_t* q = (uint16_t*)realloc(ch->sym, cap_syms * sizeof(uint16_t));
+  bool reserve(size_t cap_syms_) {
+    if (cap_syms_ <= ch->sym_cap) return true;
+    uint16_t* q = (uint16_t*)realloc(ch->sym, cap_syms_ * sizeof(uint16_t));
     if (!q) return false;
     ch->sym = q;
-    ch->sym_cap = cap_syms;
+    ch->sym_cap = cap_syms_;
     return true;
   }
+  size_t reported = 0;   // symbols of this chunk already counted in *job_made
   bool grow() {
     size_t at = (size_t)(out - ch->sym);
+    // the cap is enforced INSIDE the decode (it used to be looked at at block boundaries only, and per chunk: one long block of a
+    // crafted column could ask for ~2 KB of symbols per input byte, N chunks for N x cap, before anybody compared -- ADVICE r5).
+    // Together the chunks may make half as many symbols again as the stream may have: a chunk that started from a false block
+    // header decodes noise until the data stops making sense, and that is no reason to give a sound stream up.
+    const size_t made = at > PINFLATE_WINDOW ? at - PINFLATE_WINDOW : 0;
+    if (made > cap_syms) return false;
+    if (job_made) {
+      const size_t add = made - reported;
+      reported = made;
+      if (job_made->fetch_add(add, std::memory_order_relaxed) + add > cap_syms + cap_syms / 2 + ((size_t)1 << 20)) return false;
+    }
     if (!reserve(ch->sym_cap + ch->sym_cap / 2 + 4096)) return false;
     out = ch->sym + at;
     limit = ch->sym + ch->sym_cap - SLACK;
@@ -359,6 +373,7 @@ void PInflateJob::prepare(const uint8_t* in_, size_t in_len_, size_t cap_, size_
   last_byte = 0;
   chain.clear();
   resolve_failed.store(0);
+  made_syms.store(0);
   if (chunk_bytes < 512) chunk_bytes = 512;
   n_chunks = (unsigned)std::max<size_t>(1, in_len / chunk_bytes);
   while (chunks.size() < n_chunks) chunks.emplace_back(new PInflateChunk);
@@ -426,6 +441,8 @@ void PInflateJob::decode(unsigned k) {
   ch.status = 2;
   const size_t total_bits = in_len * 8;
   SymOut o{&ch, nullptr, nullptr};
+  o.cap_syms = cap;
+  o.job_made = &made_syms;
   {
     size_t comp = (ch.limit_bit - ch.nominal_bit) / 8;
     if (!o.reserve(PINFLATE_WINDOW + comp * 4 + 4096)) return;
@@ -558,6 +575,33 @@ void PInflateJob::resolve(unsigned ci, unsigned r, uint8_t* dst) {
     d[x] = lut[s];
   }
   if (too_far) resolve_failed.store(1, std::memory_order_relaxed);
+}
+
+bool PInflateJob::has_too_far_marker() const {
+  for (size_t ci = 0; ci < chain.size(); ci++) {
+    const PInflateChunk& ch = *chunks[chain[ci]];
+    if (ch.out_off >= PINFLATE_WINDOW) break;   // (a window of output lies in front of this chunk and of every later one)
+    const uint32_t too_far_end = 256 + (uint32_t)(PINFLATE_WINDOW - ch.out_off);
+    const uint16_t* src = ch.sym + PINFLATE_WINDOW;
+    for (size_t x = 0; x < ch.n_out; x++)
+      if ((uint32_t)(src[x] - 256) < too_far_end - 256) return true;
+  }
+  return false;
+}
+
+void PInflateJob::trim(size_t keep_chunk_bytes, size_t keep_job_bytes) {
+  size_t kept = 0;
+  for (auto& ch : chunks) {
+    const size_t bytes = ch->sym_cap * sizeof(uint16_t);
+    if (bytes > keep_chunk_bytes || kept + bytes > keep_job_bytes) {
+      free(ch->sym);
+      ch->sym = nullptr;
+      ch->sym_cap = 0;
+    } else {
+      kept += bytes;
+    }
+    std::vector<uint8_t>().swap(ch->lut);
+  }
 }
 
 int inflate_raw_parallel(const uint8_t* in, size_t in_len, std::vector<uint8_t>& out, size_t cap, size_t chunk_bytes, unsigned n_threads) {

@@ -54,6 +54,9 @@ struct PInflateJob {
   uint8_t last_byte = 0;
   std::vector<unsigned> chain;
   std::atomic<int> resolve_failed{0};
+  // symbols all chunks of the job have made so far (each chunk reports when it grows its buffer): the cap bounds the JOB, not each
+  // chunk -- a stream of zeros lets every chunk of N grow towards `cap` on its own otherwise
+  std::atomic<size_t> made_syms{0};
 
   // chunk_bytes: compressed bytes per chunk
   void prepare(const uint8_t* in_, size_t in_len_, size_t cap_, size_t chunk_bytes);
@@ -63,6 +66,11 @@ struct PInflateJob {
   bool link();                // serial, after all decode tasks
   unsigned n_pieces(unsigned ci) const { return (unsigned)((chunks[chain[ci]]->n_out + PIECE - 1) / PIECE); }
   void resolve(unsigned ci, unsigned r, uint8_t* dst);  // piece r of chunk chain[ci] -> dst[out_off + ...]
+  // a column whose bytes nobody needs (an unknown op column): only the verdict zlib would give -- is some back-reference "too far back"?
+  bool has_too_far_marker() const;
+  // The symbol buffers are kept between jobs (a load of the same shape then faults no pages); trim frees every buffer above
+  // `keep_chunk_bytes` and whatever exceeds `keep_job_bytes` in total, so that one large or hostile column does not stay resident.
+  void trim(size_t keep_chunk_bytes, size_t keep_job_bytes);
 };
 
 // One-call form (tests, and streams inflated outside a larger pool job): runs the stages on `n_threads` std::threads.

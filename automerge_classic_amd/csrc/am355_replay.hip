@@ -1076,11 +1076,7 @@ int replay_impl(am355_ctx* c) {
   };
   static const bool enqueue_early = []() { const char* e = getenv("AM355_HASH_ENQUEUE"); return e && !strcmp(e, "early"); }();
   // AM355_HASH_ENQUEUE=main: by the calling thread, behind the stage-1 launches (rounds 2-4). Default: by the helper thread, beside them.
-#if defined(AM355_EMULATED)   // (the CPU test harness runs a launch to its end inside the call: its streams have no order a second thread could rely on)
-  static const bool enqueue_thread = false;
-#else
-  static const bool enqueue_thread = []() { const char* e = getenv("AM355_HASH_ENQUEUE"); return !e || !strcmp(e, "thread"); }();
-#endif
+  static const bool enqueue_thread = AM355_STREAMS_ORDER_ACROSS_THREADS && []() { const char* e = getenv("AM355_HASH_ENQUEUE"); return !e || !strcmp(e, "thread"); }();
   std::atomic<int> lane_rc{AM355_OK};
   struct LaneJoin {   // (whatever way this function is left, the helper is not enqueueing into the context any more)
     AsyncLane* l = nullptr;

@@ -540,7 +540,13 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
     bool k = false;
     for (uint64_t id : known) k = k || id == col.id;
     if (!k && col.n) c->doc_other_ops_cols = true;
-    if (!k) col.pj = nullptr;  // (its bytes are not looked at: the patch does not depend on them and am355_save refuses such documents)
+    if (!k && col.pj) {
+      // its bytes are not looked at (the patch does not depend on them and am355_save refuses such documents) -- but the reference
+      // inflates every column (columnar.js:1026-1030) and throws on a back-reference in front of the stream's first byte, which the
+      // chunked decode only notices when symbols are resolved: scan them for such a marker
+      if (col.pj->has_too_far_marker()) return bad(AM355_F_BAD_DEFLATE, "invalid or truncated deflate data in a document column");
+      col.pj = nullptr;
+    }
   }
 
   // ---- change metadata: clock in first-appearance order, seq continuity (new.js:1645-1675) ----
@@ -668,6 +674,9 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
       }
   }
   lap("gathered, H2D enqueued");
+  // (the symbol buffers of the chunked inflate -- 2 bytes per inflated byte -- are kept between loads for speed, up to 32 MB per chunk
+  // and 512 MB per stream; what a large or hostile column grew beyond that goes back to the process now, beside the H2D copies: ADVICE r5)
+  for (auto& job : c->pinflate_jobs) job->trim((size_t)32 << 20, (size_t)512 << 20);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   lap("H2D done");
   if (defer_checksum) sum_guard.armed = false;  // (am355_replay asks for the verdict: doc_sum.pending)

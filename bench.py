@@ -159,7 +159,11 @@ def live_kernel_table(timeout_s=170):
         return None
     tmp = tempfile.mkdtemp(prefix="am355_live_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", AM355_BENCH_CHILD="1")
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--prewarm", "0.3", "--no-sublines", "--no-cpu-baseline"]
+    # (the child's whole record goes to a file of its own: tools/kernel_table.py reads n_preds / n_list_elems from it, and the parent's
+    # --detail file must not be overwritten by a child's)
+    child_detail = os.path.join(tmp, "child_detail.json")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--prewarm", "0.3", "--no-sublines", "--no-cpu-baseline",
+             "--detail", child_detail]
     t0 = time.perf_counter()
     try:
         def find(sub, suffix):
@@ -182,11 +186,9 @@ def live_kernel_table(timeout_s=170):
                 csvs[tag] = find(tag, "counter_collection.csv")
             except Exception:
                 csvs[tag] = None
-        with open(os.path.join(tmp, "line.json")) as f:   # (the child's own bench line is the last line of its stdout)
-            last = [l for l in f.read().splitlines() if l.startswith("{")][-1]
-        with open(os.path.join(tmp, "line1.json"), "w") as f:
-            f.write(last)
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "kernel_table.py"), "--db", db, "--line", os.path.join(tmp, "line1.json"), "--replays", "13",
+        with open(child_detail) as f:   # (written by the kernel-trace pass; the counter passes rewrite it with the same workload)
+            child_rec = json.load(f)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "kernel_table.py"), "--db", db, "--line", child_detail, "--replays", "13",
                "--out", os.path.join(tmp, "table.json"), "--source",
                "measured in this run: rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 10 --warmup 3 --no-sublines --no-cpu-baseline"]
         if csvs.get("pf") and csvs.get("pw"):
@@ -196,7 +198,7 @@ def live_kernel_table(timeout_s=170):
         with open(os.path.join(tmp, "table.json")) as f:
             t = json.load(f)
         t["seconds"] = round(time.perf_counter() - t0, 1)
-        t["t_device_ms_under_trace"] = json.loads(last).get("t_device_ms")
+        t["t_device_ms_under_trace"] = child_rec.get("t_device_ms")
         return t
     except Exception:
         return None

@@ -21,6 +21,7 @@
 #include <vector>
 
 #define AM355_EMULATED 1
+#define AM355_STREAMS_ORDER_ACROSS_THREADS 0   // (a launch runs to its end inside the call: am355_device.h)
 #define __global__
 #define __device__
 #define __host__

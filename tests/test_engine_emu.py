@@ -83,6 +83,7 @@ def test_document_load_matches_reference(eng, name):
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=3, n_rounds=2, ins_per_change=40, del_per_change=700, n_objects=1)),  # columns > 1 KiB: lane-serial decoder
     (loggen.KIND_MAP_LWW, dict(n_actors=3, n_rounds=3, n_keys=1500)),  # 500 literal keys/values per change
     (loggen.KIND_MAP_LWW, dict(n_actors=700, n_rounds=1, n_keys=2)),   # ~350 concurrent values per key: beyond k_map_group_rank's walk, the trigger passes
+    (loggen.KIND_MAP_LWW, dict(n_actors=700, n_rounds=1, n_keys=1)),   # every emission on ONE key: no radix pass runs at all before the walk gives up (perm_out was left unwritten)
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=300, n_rounds=2, ins_per_change=2, del_per_change=1, n_objects=1)),  # 300 children of _head: radix fallback
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=16, n_rounds=3, ins_per_change=30, del_per_change=8, n_objects=5)),
     (loggen.KIND_TEXT_CONCURRENT, dict(n_actors=40, n_rounds=210, ins_per_change=1, del_per_change=0, n_objects=1)),  # 8400 typing runs: tour beyond the LDS list ranking

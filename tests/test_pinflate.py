@@ -78,6 +78,23 @@ def test_chunks_are_really_used_and_the_cap_holds(pinflate):
     assert pinflate(deflate_raw(data, 6, mem=9), len(data), 8192, 4) == data  # 32 K symbols per block
 
 
+def test_zip_bombs_are_given_up_within_the_cap(pinflate):
+    """the cap bounds the JOB's memory, inside the decode -- not each chunk at its block boundaries. 512 MB of zeros (0.5 MB
+    compressed, 64 chunks that used to grow to the cap each) and one giant run inside few blocks must be given up after about `cap`
+    symbols in total."""
+    import resource
+    cap = 8 << 20
+    bomb = deflate_raw(bytes(512 << 20), 9, mem=9)
+    assert len(bomb) < (1 << 20)
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert pinflate(bomb, cap, 8192, 4) is None
+    assert pinflate(bomb, cap, len(bomb), 1) is None          # one chunk: the single-stream shape
+    grown_mb = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) / 1024.0
+    assert grown_mb < 160, grown_mb     # (cap symbols = 16 MB, the chunks' first allocations, the caller's 8 MB buffer; the old code: > 1 GB)
+    small = deflate_raw(bytes(6 << 20), 9, mem=9)
+    assert pinflate(small, cap, 2048, 4) == bytes(6 << 20)     # under the cap: decoded as before
+
+
 def test_damaged_streams_are_given_up_or_decode_like_zlib(pinflate):
     data = sample("keys", 400000, 11)
     comp = deflate_raw(data)

@@ -7,16 +7,16 @@ TAG=${1:-round}
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-B="python bench.py --steps 10 --warmup 3 --no-sublines --no-cpu-baseline --no-live-trace"
-timeout -k 5 400 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+B="python bench.py --steps 10 --warmup 3 --no-sublines --no-cpu-baseline --no-live-trace --detail $OUT/bench_under_trace.json"
+timeout -k 5 400 python bench.py --detail $OUT/bench_detail.json > $OUT/bench_line.json 2> $OUT/bench.err
 # (every profiler pass under a hard limit: a pass that stalls must not eat the GPU budget; if the first one stalls, the passes are
 # repeated with AM355_STAGE_SYNC=1 = am355_load_changes waits for its copies, and the note is written next to the results)
-timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run -- $B > $OUT/bench_under_trace.json 2> $OUT/kt.err
+timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run -- $B > /dev/null 2> $OUT/kt.err
 if [ $? -ge 124 ]; then
   echo "kernel-trace pass stalled without AM355_STAGE_SYNC; profiler passes run with AM355_STAGE_SYNC=1" > $OUT/profiler_note.txt
   export AM355_STAGE_SYNC=1
   rm -rf $OUT/kt
-  timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run -- $B > $OUT/bench_under_trace.json 2> $OUT/kt.err || { echo "kernel-trace pass stalled again" >> $OUT/profiler_note.txt; exit 1; }
+  timeout -k 5 120 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run -- $B > /dev/null 2> $OUT/kt.err || { echo "kernel-trace pass stalled again" >> $OUT/profiler_note.txt; exit 1; }
 fi
 python tools/rocpd_summary.py $OUT/kt/run_results.db 26 > $OUT/kernel_stats.txt 2>&1
 python tools/rocpd_timeline.py $OUT/kt/run_results.db -2 > $OUT/timeline.txt 2>&1
