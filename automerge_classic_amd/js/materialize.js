@@ -141,7 +141,7 @@ class Materializer {
   }
 
   edits(begin, end) {
-    const e = this.edit, out = []
+    const e = this.edit, out = [], actors = this.actors
     for (let k = begin; k < end;) {
       const w = k * EDIT_WORDS, flags = e[w], index = e[w + 1]
       const first = e[w + 6], tl = e[w + 7], off = e[w + 8]
@@ -168,11 +168,13 @@ class Materializer {
             else for (let i = 0; i < rcount; i++, roff += len) values.push(this.decode(rtl, roff).value)
           }
         }
-        const edit = { action: 'multi-insert', index, elemId: this.opId(e[w + 4], e[w + 5]) }
-        if (flags & EDIT_COUNTER) edit.datatype = 'counter'
-        else if ((tl & 15) !== 6) { const head = this.decode(tl, off); if (head.datatype) edit.datatype = head.datatype }   // only truthy datatypes (new.js:762)
-        edit.values = values
-        out.push(edit)
+        // (every key at once, in the reference's order -- action, index, elemId, [datatype,] values -- : one hidden class per form, no
+        // transition and no out-of-object property store per edit)
+        let datatype
+        if (flags & EDIT_COUNTER) datatype = 'counter'
+        else if ((tl & 15) !== 6) { const head = this.decode(tl, off); if (head.datatype) datatype = head.datatype }   // only truthy datatypes (new.js:762)
+        const elemId = e[w + 4] + actors[e[w + 5]]
+        out.push(datatype === undefined ? { action: 'multi-insert', index, elemId, values } : { action: 'multi-insert', index, elemId, datatype, values })
       } else if (flags & EDIT_COUNTER) {
         // (a counter inside a list: its total, new.js:963 -- low word in the value-offset field, high word behind it; rare: kept out of
         // the two ordinary branches below)
