@@ -450,6 +450,11 @@ struct am355_ctx {
   // objectId sharding (am355_set_shard): this context merges the objects rank `shard_rank` of `shard_world` owns
   uint32_t shard_rank = 0, shard_world = 1;
   std::vector<uint8_t> stitched;  // am355_import_fragments: the combined record tables
+  // am355_shard_init: this context's RCCL communicator (one rank per GPU, one process per rank) and the collective's buffers
+  void* shard_comm = nullptr;       // ncclComm_t
+  DevBuf d_shard_send, d_shard_recv, d_shard_sizes;
+  HostBuf h_shard_sizes, h_shard_frags;
+  std::vector<uint64_t> shard_fragment_bytes;   // of the last am355_sharded_replay, per rank
 };
 
 static inline int fail(am355_ctx* c, int code, const char* fmt, ...) {

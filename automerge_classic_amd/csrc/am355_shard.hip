@@ -1,5 +1,6 @@
 // objectId sharding across GPUs (include/am355.h am355_set_shard / _export_fragment / _import_fragments). See am355_ctx.h.
 #include "am355_ctx.h"
+#include <dlfcn.h>
 
 // ---------------------------------------------------------------------------------------------------------
 // objectId sharding across GPUs. Every rank stages and decodes the whole batch (rows keep their global
@@ -123,3 +124,151 @@ int import_fragments_impl(am355_ctx* c, const uint8_t* frags, const uint64_t* of
   return AM355_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// The collective inside the library: RCCL over xGMI (include/am355.h am355_shard_init / am355_sharded_replay)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+// The five entry points of RCCL this path calls, as nccl.h declares them (this image ships librccl.so.1 without its header;
+// NCCL's C ABI: ncclUniqueId is 128 opaque bytes passed BY VALUE to ncclCommInitRank, ncclUint8 == 1, ncclSuccess == 0).
+struct RcclUniqueId { char internal[AM355_SHARD_ID_BYTES]; };
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+  int (*CommInitRank)(void** comm, int nranks, RcclUniqueId id, int rank) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t st) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+constexpr int RCCL_UINT8 = 1;
+
+RcclApi* rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    const char* env = getenv("AM355_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+      api.err = dlerror();
+      if (n == env) break;   // (an explicit name that does not load is an error, not a reason to try another library)
+    }
+    if (!api.lib) return;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { api.err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy"; api.lib = nullptr; }
+  });
+  return &api;
+}
+const char* rccl_error(int rc) {
+  RcclApi* a = rccl();
+  return a->GetErrorString ? a->GetErrorString(rc) : "RCCL error";
+}
+#define RCCLCHK(ctx, call)                                                                                  \
+  do {                                                                                                      \
+    int r_ = (call);                                                                                        \
+    if (r_ != 0) return fail(ctx, AM355_E_DEVICE, "%s: %s", #call, rccl_error(r_));                         \
+  } while (0)
+}  // namespace
+
+extern "C" int am355_shard_unique_id(uint8_t id[AM355_SHARD_ID_BYTES]) {
+  if (!id) return AM355_E_ARG;
+  RcclApi* a = rccl();
+  if (!a->lib) return AM355_E_DEVICE;
+  RcclUniqueId u{};
+  if (a->GetUniqueId(&u) != 0) return AM355_E_DEVICE;
+  memcpy(id, u.internal, AM355_SHARD_ID_BYTES);
+  return AM355_OK;
+}
+
+extern "C" int am355_shard_finalize(am355_ctx* c) {
+  if (!c) return AM355_E_ARG;
+  if (c->shard_comm) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)rccl()->CommDestroy(c->shard_comm);
+    c->shard_comm = nullptr;
+  }
+  c->shard_fragment_bytes.clear();
+  return am355_set_shard(c, 0, 1);
+}
+
+extern "C" int am355_shard_init(am355_ctx* c, const uint8_t id[AM355_SHARD_ID_BYTES], uint32_t rank, uint32_t world) {
+  if (!c || !id || world == 0 || rank >= world) return c ? fail(c, AM355_E_ARG, "bad shard (rank %u of %u)", rank, world) : AM355_E_ARG;
+  RcclApi* a = rccl();
+  if (!a->lib) return fail(c, AM355_E_DEVICE, "RCCL is not available: %s", a->err.c_str());
+  (void)hipSetDevice(c->device);
+  if (c->shard_comm) { int frc = am355_shard_finalize(c); if (frc) return frc; }
+  RcclUniqueId u{};
+  memcpy(u.internal, id, AM355_SHARD_ID_BYTES);
+  void* comm = nullptr;
+  RCCLCHK(c, a->CommInitRank(&comm, (int)world, u, (int)rank));
+  c->shard_comm = comm;
+  return am355_set_shard(c, rank, world);
+}
+
+extern "C" int am355_shard_fragment_bytes(am355_ctx* c, uint64_t* bytes, uint32_t capacity) {
+  if (!c || !bytes) return AM355_E_ARG;
+  if (c->shard_fragment_bytes.size() > capacity) return fail(c, AM355_E_ARG, "%zu ranks, room for %u", c->shard_fragment_bytes.size(), capacity);
+  for (size_t r = 0; r < c->shard_fragment_bytes.size(); r++) bytes[r] = c->shard_fragment_bytes[r];
+  return AM355_OK;
+}
+
+extern "C" int am355_sharded_replay(am355_ctx* c, int stitch_on_all_ranks) {
+  if (!c) return AM355_E_ARG;
+  if (!c->shard_comm) return fail(c, AM355_E_STATE, "am355_shard_init must succeed first");
+  return guarded(c, [&]() -> int {
+    (void)hipSetDevice(c->device);
+    RcclApi* a = rccl();
+    hipStream_t st = c->stream;
+    const uint32_t world = c->shard_world, rank = c->shard_rank;
+    // this rank's part; a failure is carried into the first collective, which every rank enters whatever happened to it
+    int own_rc = c->staged ? replay_impl(c) : fail(c, AM355_E_STATE, "am355_load_changes / am355_load_document must be called first");
+    const std::string own_err = c->err;
+    const uint32_t own_flags = c->flags;
+    size_t need = 0;
+    if (!own_rc) own_rc = am355_fragment_size(c, &need);
+    if (!c->d_shard_sizes.ensure(16 * ((size_t)world + 1)) || !c->h_shard_sizes.ensure(16 * ((size_t)world + 1))) return fail(c, AM355_E_NOMEM, "allocation failed (shard sizes)");
+    uint64_t* h_sizes = c->h_shard_sizes.as<uint64_t>();        // [0..1]: mine {failed, bytes}; [2 ..]: everybody's
+    uint64_t* d_sizes = c->d_shard_sizes.as<uint64_t>();
+    h_sizes[0] = own_rc ? 1 : 0;
+    h_sizes[1] = need;
+    HIPCHK(c, hipMemcpyAsync(d_sizes, h_sizes, 16, hipMemcpyHostToDevice, st));
+    RCCLCHK(c, a->AllGather(d_sizes, d_sizes + 2, 16, RCCL_UINT8, c->shard_comm, st));
+    HIPCHK(c, hipMemcpyAsync(h_sizes + 2, d_sizes + 2, 16 * (size_t)world, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->shard_fragment_bytes.assign(world, 0);
+    uint64_t cap = 0;
+    int first_failed = -1;
+    for (uint32_t r = 0; r < world; r++) {
+      if (h_sizes[2 + 2 * r] && first_failed < 0) first_failed = (int)r;
+      c->shard_fragment_bytes[r] = h_sizes[2 + 2 * r + 1];
+      cap = std::max<uint64_t>(cap, h_sizes[2 + 2 * r + 1]);
+    }
+    if (first_failed >= 0) {
+      c->replayed = false;
+      if (own_rc) { c->err = own_err; c->flags = own_flags; return own_rc; }
+      return fail(c, AM355_E_INVALID, "rank %d rejected the batch", first_failed);
+    }
+    // the data-path collective: every rank's fragment, HBM -> HBM over xGMI, at one stride
+    const size_t stride = frag_align((size_t)cap);
+    if (!c->d_shard_send.ensure(stride) || !c->d_shard_recv.ensure(stride * (size_t)world)) return fail(c, AM355_E_NOMEM, "device allocation failed (shard fragments)");
+    size_t wrote = 0;
+    int erc = am355_export_fragment(c, c->d_shard_send.p, stride, 1, &wrote);
+    if (erc) return erc;
+    RCCLCHK(c, a->AllGather(c->d_shard_send.p, c->d_shard_recv.p, stride, RCCL_UINT8, c->shard_comm, st));
+    if (rank != 0 && !stitch_on_all_ranks) { HIPCHK(c, hipStreamSynchronize(st)); return AM355_OK; }
+    if (!c->h_shard_frags.ensure(stride * (size_t)world)) return fail(c, AM355_E_NOMEM, "host allocation failed (shard fragments)");
+    HIPCHK(c, hipMemcpyAsync(c->h_shard_frags.p, c->d_shard_recv.p, stride * (size_t)world, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::vector<uint64_t> offsets((size_t)world + 1);
+    for (uint32_t r = 0; r <= world; r++) offsets[r] = (uint64_t)r * stride;   // (fragment r fills the front of its stride)
+    return import_fragments_impl(c, c->h_shard_frags.as<uint8_t>(), offsets.data(), world);
+  });
+}

@@ -87,6 +87,13 @@ def _bind(path):
     L.am355_fragment_size.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
     L.am355_export_fragment.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
     L.am355_import_fragments.argtypes = [vp, vp, vp, u32]
+    L.am355_shard_unique_id.argtypes = [vp]
+    L.am355_shard_init.argtypes = [vp, vp, u32, u32]
+    L.am355_sharded_replay.argtypes = [vp, ctypes.c_int]
+    L.am355_shard_fragment_bytes.argtypes = [vp, vp, u32]
+    L.am355_shard_finalize.argtypes = [vp]
+    for f in ("am355_shard_unique_id", "am355_shard_init", "am355_sharded_replay", "am355_shard_fragment_bytes", "am355_shard_finalize"):
+        getattr(L, f).restype = ctypes.c_int
     L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
     L.am355_doc_changes.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_void_p)]
     L.am355_apply_changes.argtypes = [vp, vp, u64p, u32]
@@ -295,6 +302,30 @@ class Engine:
         f = np.ascontiguousarray(frags, dtype=np.uint8)
         o = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._check(self._L.am355_import_fragments(self._h, f.ctypes.data, o.ctypes.data, o.size - 1))
+
+    # ---- the same with the collective inside the library: RCCL over xGMI (am355_shard_init / am355_sharded_replay) ----
+    def shard_unique_id(self):
+        """128 bytes from ncclGetUniqueId (rank 0 makes them, the host carries them to the other ranks' processes)."""
+        buf = (ctypes.c_uint8 * 128)()
+        if self._L.am355_shard_unique_id(buf) != AM355_OK:
+            raise EngineError(AM355_E_DEVICE, "RCCL is not available (librccl.so.1, or AM355_RCCL_LIB)")
+        return bytes(buf)
+
+    def shard_init(self, unique_id, rank, world):
+        assert len(unique_id) == 128
+        self._check(self._L.am355_shard_init(self._h, ctypes.c_char_p(bytes(unique_id)), rank, world))
+
+    def sharded_replay(self, stitch_on_all_ranks=False):
+        """am355_replay of the staged batch + ncclAllGather of the fragments + stitch (rank 0, or every rank)."""
+        self._check(self._L.am355_sharded_replay(self._h, 1 if stitch_on_all_ranks else 0))
+
+    def shard_fragment_bytes(self, world):
+        out = np.zeros(world, dtype=np.uint64)
+        self._check(self._L.am355_shard_fragment_bytes(self._h, out.ctypes.data, world))
+        return out
+
+    def shard_finalize(self):
+        self._check(self._L.am355_shard_finalize(self._h))
 
     def raw(self):
         """(arena, offsets) as staged: the uncompressed change containers back to back (copies)."""

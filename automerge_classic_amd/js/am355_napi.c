@@ -17,6 +17,7 @@
  *   am.stats(ctx) -> {nOps, nChanges, msTotal, ...};  am.hashes(ctx) -> Uint8Array(32 * n);  am.destroy(ctx)
  */
 #include <node_api.h>
+#include <stdbool.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -530,6 +531,101 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* ---- objectId sharding with the collective inside the library (am355_shard_init / am355_sharded_replay: RCCL over xGMI) ----
+ * shardUniqueId() -> Uint8Array(128)      rank 0's worker makes it; js/sharded.js hands it to the other workers (process.send)
+ * shardInit(ctx, id, rank, world)         ncclCommInitRank on the context's GPU
+ * shardedReplay(ctx, stitchOnAllRanks)    replay + ncclAllGather of the fragments + stitch; then patchJSON / fetchIR as usual
+ * shardFragmentBytes(ctx, world) -> [..]  bytes each rank contributed;  shardFinalize(ctx)                                         */
+static napi_value js_shard_unique_id(napi_env env, napi_callback_info info) {
+  (void)info;
+  void *data = NULL;
+  napi_value ab, ta;
+  NAPI_CALL(env, napi_create_arraybuffer(env, AM355_SHARD_ID_BYTES, &data, &ab));
+  if (am355_shard_unique_id((uint8_t *)data) != AM355_OK) {
+    napi_throw_error(env, NULL, "RCCL is not available (librccl.so.1, or AM355_RCCL_LIB)");
+    return NULL;
+  }
+  NAPI_CALL(env, napi_create_typedarray(env, napi_uint8_array, AM355_SHARD_ID_BYTES, ab, 0, &ta));
+  return ta;
+}
+
+static napi_value js_shard_init(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  napi_typedarray_type ty;
+  size_t len = 0, off = 0;
+  void *data = NULL;
+  napi_value ab;
+  uint32_t rank = 0, world = 0;
+  if (argc < 4 || napi_get_typedarray_info(env, argv[1], &ty, &len, &data, &ab, &off) != napi_ok || ty != napi_uint8_array || len != AM355_SHARD_ID_BYTES ||
+      napi_get_value_uint32(env, argv[2], &rank) != napi_ok || napi_get_value_uint32(env, argv[3], &world) != napi_ok) {
+    napi_throw_type_error(env, NULL, "shardInit(ctx, Uint8Array(128), rank, world)");
+    return NULL;
+  }
+  int rc = am355_shard_init(ctx, (const uint8_t *)data, rank, world);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+static napi_value js_sharded_replay(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  bool all = false;
+  if (argc > 1) (void)napi_get_value_bool(env, argv[1], &all);
+  int rc = am355_sharded_replay(ctx, all ? 1 : 0);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+static napi_value js_shard_fragment_bytes(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  uint32_t world = 0;
+  if (argc < 2 || napi_get_value_uint32(env, argv[1], &world) != napi_ok || world == 0 || world > 4096) {
+    napi_throw_type_error(env, NULL, "shardFragmentBytes(ctx, world)");
+    return NULL;
+  }
+  uint64_t *bytes = (uint64_t *)calloc(world, sizeof(uint64_t));
+  if (!bytes) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  int rc = am355_shard_fragment_bytes(ctx, bytes, world);
+  if (rc) { free(bytes); return throw_engine(env, ctx, rc); }
+  napi_value arr;
+  napi_create_array_with_length(env, world, &arr);
+  for (uint32_t r = 0; r < world; r++) {
+    napi_value n;
+    napi_create_double(env, (double)bytes[r], &n);
+    napi_set_element(env, arr, r, n);
+  }
+  free(bytes);
+  return arr;
+}
+
+static napi_value js_shard_finalize(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  am355_ctx *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return NULL;
+  int rc = am355_shard_finalize(ctx);
+  if (rc) return throw_engine(env, ctx, rc);
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"create", NULL, js_create, NULL, NULL, NULL, napi_enumerable, NULL},
@@ -554,6 +650,11 @@ static napi_value init(napi_env env, napi_value exports) {
       {"bloomBuild", NULL, js_bloom_build, NULL, NULL, NULL, napi_enumerable, NULL},
       {"bloomProbe", NULL, js_bloom_probe, NULL, NULL, NULL, napi_enumerable, NULL},
       {"fetchApplyIR", NULL, js_fetch_apply_ir, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"shardUniqueId", NULL, js_shard_unique_id, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"shardInit", NULL, js_shard_init, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"shardedReplay", NULL, js_sharded_replay, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"shardFragmentBytes", NULL, js_shard_fragment_bytes, NULL, NULL, NULL, napi_enumerable, NULL},
+      {"shardFinalize", NULL, js_shard_finalize, NULL, NULL, NULL, napi_enumerable, NULL},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -71,6 +71,39 @@ class ShardedReplay:
         return True
 
 
+class NativeShardedReplay:
+    """The same hot path with the collective INSIDE the library (am355_shard_init / am355_sharded_replay: ncclAllGather on the
+    context's stream, no torch tensor on the data path). `dist` only carries the 128-byte RCCL unique id from rank 0 to the other
+    ranks once -- what the JS host does with process.send between its per-GPU workers (js/sharded.js)."""
+
+    def __init__(self, eng, dist, stitch_on_all_ranks=False):
+        self.eng, self.rank, self.world = eng, dist.get_rank(), dist.get_world_size()
+        self.stitch_all = stitch_on_all_ranks
+        box = [eng.shard_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.shard_init(box[0], self.rank, self.world)
+        self.last = {}
+
+    def step(self, stage):
+        """stage(): stages the batch on this rank's engine. True on the ranks that hold the stitched patch afterwards. A staging
+        failure on this rank is carried into the library's first collective (am355_sharded_replay is entered on every rank)."""
+        err = None
+        try:
+            stage()
+        except Exception as e:
+            err = e
+            self.eng.reset()   # (nothing staged: am355_sharded_replay reports this rank as failed to the others)
+        try:
+            self.eng.sharded_replay(self.stitch_all)
+        except Exception as e:
+            raise err if err else e
+        self.last = {"fragment_bytes": [int(x) for x in self.eng.shard_fragment_bytes(self.world)]}
+        return self.rank == 0 or self.stitch_all
+
+    def close(self):
+        self.eng.shard_finalize()
+
+
 def bench_sharded(eng, stage, dist, device, steps, warmup, barrier):
     """K timed sharded replays of what `stage()` stages on this rank's engine -- am355_load_changes of a change log, or
     am355_load_document of a saved document -- (host buffers in -> stitched patch IR on rank 0's host). Returns seconds (this rank)."""

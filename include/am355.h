@@ -320,6 +320,31 @@ int am355_export_fragment(am355_ctx *ctx, void *dst, size_t capacity, int dst_is
 /* fragments of ranks 0..world-1 back to back in host memory, fragment r = frags[offsets[r] .. offsets[r+1]) */
 int am355_import_fragments(am355_ctx *ctx, const uint8_t *frags, const uint64_t *offsets, uint32_t world);
 
+/*
+ * The sharded replay with its collective INSIDE the library: RCCL over xGMI, one process per GPU (north_star: "Changes shard by
+ * objectId across the 8 GPUs of one node with an RCCL ... over xGMI").  The library opens librccl.so.1 when the first communicator
+ * is made (AM355_RCCL_LIB overrides the name; nothing of RCCL is loaded by a single-GPU user) and calls ncclGetUniqueId /
+ * ncclCommInitRank / ncclAllGather / ncclCommDestroy on the context's stream.
+ *   am355_shard_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId); the host carries it to the other ranks' processes
+ *                           (the JS host: process.send between the per-GPU workers, js/sharded.js).
+ *   am355_shard_init        ncclCommInitRank on the context's GPU; implies am355_set_shard(ctx, rank, world).
+ *   am355_sharded_replay    am355_replay of the staged batch (every rank stages the same batch) + one ncclAllGather of
+ *                           {failed, fragment bytes} + one ncclAllGather of the patch-IR fragments, HBM to HBM + the stitch
+ *                           (am355_import_fragments) on rank 0, or on every rank when stitch_on_all_ranks != 0.  A batch any rank
+ *                           rejects is rejected on every rank (no rank waits in a collective).  Afterwards am355_patch_json /
+ *                           am355_fetch_ir of a stitching rank return the patch of the WHOLE document.
+ *   am355_shard_fragment_bytes  bytes every rank contributed to the last sharded replay (diagnostics, world entries).
+ *   am355_shard_finalize    ncclCommDestroy; the context is unsharded again.
+ * What the reference has in this place: nothing (a BackendDoc is one single-threaded object, new.js:1695); the partition is legal
+ * because preds never cross objects (new.js:1141-1145, 1173-1176) and the one cross-object link is make op -> child (:894-897).
+ */
+#define AM355_SHARD_ID_BYTES 128
+int am355_shard_unique_id(uint8_t id[AM355_SHARD_ID_BYTES]);
+int am355_shard_init(am355_ctx *ctx, const uint8_t id[AM355_SHARD_ID_BYTES], uint32_t rank, uint32_t world);
+int am355_sharded_replay(am355_ctx *ctx, int stitch_on_all_ranks);
+int am355_shard_fragment_bytes(am355_ctx *ctx, uint64_t *bytes, uint32_t capacity);
+int am355_shard_finalize(am355_ctx *ctx);
+
 /* ---- diagnostics: device primitives exposed for kernel-level tests ---- */
 int am355_test_sort(am355_ctx *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, int key_bits);
 int am355_test_scan(am355_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total);

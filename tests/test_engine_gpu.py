@@ -519,6 +519,45 @@ def test_sharded_replay_through_rccl_world_1(tmp_path):
     assert out.returncode == 0 and "rccl-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+LIB_RCCL_WORKER = r'''
+import hashlib, os, sys
+sys.path.insert(0, ROOT)
+from automerge_classic_amd import engine, loggen   # (no torch in this process: the library opens librccl.so.1 itself)
+log = loggen.config("c4_text_multi", 0.1)
+doc = loggen.document_config(0.02)[0]
+e = engine.Engine(0)
+e.load_changes(log); e.replay(); want = e.patch_json()
+e.load_document(doc); e.replay(); want_doc = e.patch_json()
+e.shard_init(e.shard_unique_id(), 0, 1)            # ncclGetUniqueId + ncclCommInitRank
+e.load_changes(log); e.sharded_replay()            # replay + ncclAllGather (sizes) + ncclAllGather (fragment, HBM -> HBM) + stitch
+assert e.patch_json() == want
+assert int(e.shard_fragment_bytes(1)[0]) > 1000
+e.load_document(doc); e.sharded_replay(True)
+assert e.patch_json() == want_doc
+bad = loggen.ChangeLog(log.arena.copy(), log.offsets, log.n_ops); bad.arena[int(bad.offsets[1]) + 20] ^= 0x55
+e.load_changes(bad)
+try:
+    e.sharded_replay(); raise SystemExit("corrupt batch accepted")
+except engine.EngineError:
+    pass
+e.shard_finalize()                                  # ncclCommDestroy: the context is unsharded again
+e.load_changes(log); e.replay(); assert e.patch_json() == want
+print("lib-rccl-ok", hashlib.sha256(want.encode()).hexdigest())
+'''
+
+
+def test_sharded_replay_with_the_collective_inside_the_library_world_1(tmp_path):
+    """am355_shard_init / am355_sharded_replay (include/am355.h): the library itself calls RCCL (librccl.so.1, opened on first use) on
+    the context's stream -- communicator of one rank on the one GPU of the test box; world 2 runs between processes of the emulation
+    over a stand-in for librccl (tests/test_multiproc.py, tests/test_js_host.py)."""
+    import subprocess
+    import sys
+    script = tmp_path / "lib_rccl_worker.py"
+    script.write_text(f"ROOT = {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}\n" + LIB_RCCL_WORKER)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "lib-rccl-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_mutated_changes_and_headers_never_disagree_with_the_oracle(eng):
     """tests/mutation_util.py on the GPU: single-byte damage in the op columns and in the header of a change (checksum repaired) is refused
     or gives the oracle's patch -- the wave-parallel header parse of k_parse_changes and its fallback to the lane-serial parser included."""

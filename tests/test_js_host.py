@@ -219,3 +219,24 @@ def test_js_backend_fails_loudly_without_gpu():
         g.build_js_addon()
     out = subprocess.run([NODE, "-e", f"require({os.path.join(JS, 'index.js')!r})"], capture_output=True, text=True)
     assert out.returncode != 0 and "no CPU fallback" in out.stderr
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_js_sharded_pool_over_worker_processes_emulated(gpus, tmp_path):
+    """js/sharded.js: one worker process per GPU, the collective inside the library (here the emulated engine and a stand-in for
+    librccl between the processes): every golden change log and saved document through `gpus` ranks == the reference's patches; a
+    batch one rank rejects is rejected as a whole and the pool goes on."""
+    env = _emu_env(AM355_RCCL_LIB=os.path.join(ROOT, "tests", "emu", "libfake_rccl.so"), AM355_SHARD_ALL_ON_DEVICE0="1", TMPDIR=str(tmp_path))
+    out = subprocess.run([NODE, os.path.join(JS, "test_sharded.js"), os.path.join(ROOT, "tests", "golden"), str(gpus)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "sharded fixtures reproduced" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    info = json.loads(out.stdout.strip().splitlines()[-2])
+    assert info["sharded_fixtures"] >= 15 and info["sharded_documents"] >= 15 and len(info["fragmentBytes"]) == gpus
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_sharded_pool_on_gpu_world_1():
+    """The same through the real addon, the MI355X and librccl.so.1 (a communicator of one rank: the test box has one GPU)."""
+    out = subprocess.run([NODE, os.path.join(JS, "test_sharded.js"), os.path.join(ROOT, "tests", "golden"), "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sharded fixtures reproduced" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

