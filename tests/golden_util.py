@@ -15,7 +15,7 @@ def _all_names():
 
 def fixture_names():
     """Fixtures holding binary changes and the reference's loadChanges + getPatch result."""
-    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n not in ("save_generated", "doc_history", "doc_history_longkey", "bloom_filters", "ref_apply_vector_doc_hashes", "list_quirks")]
+    return [n for n in _all_names() if not n.startswith("synthetic_doc_") and n not in ("save_generated", "doc_history", "doc_history_longkey", "bloom_filters", "ref_apply_vector_doc_hashes", "list_quirks", "headline_pin")]
 
 
 def save_digest_cases():
@@ -142,3 +142,21 @@ def defect_fixture():
     changes = [base64.b64decode(c) for c in fx["changes"]]
     fx["log_reversed"] = ChangeLog.from_changes([changes[i] for i in fx["order_reversed"]], name="defect_block_boundary+reversed")
     return fx
+
+
+def headline_pin_cases():
+    """tests/golden/headline_pin.json (oracle/make_headline_pin.py): digests of the BLOCK-SIZE-PATCHED reference's getPatch / save on the
+    headline shape at 124,801 ops (c4_text_single x0.125), in the generator's delivery order and in bench.py's shuffled one.
+    Yields (case, log): the logs are regenerated here (loggen.config is deterministic), only digests are committed."""
+    import json
+    import os
+    import numpy as np
+    from automerge_classic_amd import loggen
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "headline_pin.json")) as f:
+        pin = json.load(f)
+    base = loggen.config(pin["workload"], pin["scale"], False)
+    perm = np.random.default_rng(int(pin["seed"], 16) & 0xFFFF).permutation(base.n_changes)
+    logs = {"in_order": base, "shuffled": base.reordered(perm)}
+    for case in pin["cases"]:
+        assert case["n_ops"] == base.n_ops and case["n_changes"] == base.n_changes
+        yield case, logs[case["order"]]

@@ -49,6 +49,18 @@ def test_counters_and_valueless_rows_inside_lists(eng):
     assert set(refused) == golden_util.LIST_QUIRK_REFUSED and served >= 47
 
 
+def test_headline_shape_at_125k_ops_equals_the_patched_reference(eng):
+    """getPatch text and Backend.save bytes of the (emulated) engine == the block-size-patched reference's digests on c4_text_single
+    x0.125, in both delivery orders (tests/golden/headline_pin.json; in-order fast path and general scheduler)."""
+    import hashlib
+    for case, log in golden_util.headline_pin_cases():
+        text = emu_patch(eng, log)
+        assert hashlib.sha256(text.encode()).hexdigest() == case["patch_sha256"], case["order"]
+        assert eng.stats().fast_path == (1 if case["order"] == "in_order" else 2)
+        doc = eng.save()
+        assert len(doc) == case["save_len"] and hashlib.sha256(doc).hexdigest() == case["save_sha256"], case["order"]
+
+
 def test_defect_fixture_both_delivery_orders(eng):
     """Inputs on which the stock reference diverges with delivery order: the engine gives the block-size-patched
     reference's document for both orders."""

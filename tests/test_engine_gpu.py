@@ -519,6 +519,18 @@ def test_sharded_replay_through_rccl_world_1(tmp_path):
     assert out.returncode == 0 and "rccl-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_headline_shape_at_125k_ops_equals_the_patched_reference(eng):
+    """The engine on the GPU == the block-size-patched reference at 124,801 ops of the headline shape (tests/golden/headline_pin.json,
+    oracle/make_headline_pin.py): getPatch text and Backend.save bytes, generator order (in-order fast path) and bench.py's shuffled
+    order (device scheduler). The same digests pin the oracle (tests/test_oracle_golden.py), which checks the 1 M-op size."""
+    for case, log in golden_util.headline_pin_cases():
+        text = gpu_patch(eng, log)
+        assert hashlib.sha256(text.encode()).hexdigest() == case["patch_sha256"], case["order"]
+        assert eng.stats().fast_path == (1 if case["order"] == "in_order" else 2)
+        doc = eng.save()
+        assert len(doc) == case["save_len"] and hashlib.sha256(doc).hexdigest() == case["save_sha256"], case["order"]
+
+
 LIB_RCCL_WORKER = r'''
 import hashlib, os, sys
 sys.path.insert(0, ROOT)

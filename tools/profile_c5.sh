@@ -5,7 +5,7 @@ TAG=${1:-c5}
 OUT=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-B="python bench.py --workload c5_doc_mixed --steps 6 --warmup 2 --prewarm 0.2 --no-sublines --no-cpu-baseline --no-live-trace"
+B="python bench.py --workload c5_doc_mixed --steps 6 --warmup 2 --prewarm 0.2 --no-sublines --no-cpu-baseline --no-live-trace --detail $OUT/c5_bench_detail.json"
 timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run -- $B > $OUT/c5_bench_under_trace.json 2> $OUT/c5_kt.err
 python tools/rocpd_summary.py $OUT/kt/run_results.db 8 > $OUT/c5_kernel_stats.txt 2>&1
 python tools/rocpd_timeline.py $OUT/kt/run_results.db -2 k_scan_term_sums > $OUT/c5_timeline.txt 2>&1
