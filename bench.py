@@ -397,7 +397,7 @@ def subline(eng, name, scale, seed, steps, warmup, sync, shuffled=False, deflate
     A = algorithmic_bytes(st)
     whole = st.n_ops * A["A"] / (r["t_device_s"] / steps) / 1e9
     whole_r40 = st.n_ops * (A["A"] - A["R_op_record"] + 40.0) / (r["t_device_s"] / steps) / 1e9   # (R = 40)
-    out = {"workload": w.describe(st), "ops_per_s": st.n_ops * steps / r["t_replay_s"], "ms_per_step": r["t_replay_s"] / steps * 1e3,
+    out = {"workload": w.describe(st), "n_changes": int(st.n_changes), "ops_per_s": st.n_ops * steps / r["t_replay_s"], "ms_per_step": r["t_replay_s"] / steps * 1e3,
            "t_device_ops_per_s": st.n_ops * steps / r["t_device_s"], "t_device_ms": r["t_device_s"] / steps * 1e3, "fast_path": int(st.fast_path),
            "phases_ms": r["phases"], "algorithmic_bytes_per_op": A,
            "roofline_whole_path": {"achieved": whole_r40, "unit": "GB/s", "frac": whole_r40 / 8000.0, "R53_rows_as_written": {"achieved": whole, "frac": whole / 8000.0}}}
@@ -530,20 +530,31 @@ def sharding_model(sub, n_list=(1, 2, 4, 8)):
     floor = 20 * 0.005                               # 20 launches of >= 5 us
     ir_bytes = sub["algorithmic_bytes_per_op"]["P_patch_ir"] * sub["t_device_ops_per_s"] * t_dev * 1e-3
     rows = []
+    n_changes = int(sub.get("n_changes") or 4097)
     for n in n_list:
         dec = decode * (1.0 / n + f_obj * (1.0 - 1.0 / n))
         mo = max(merge_order / n, min(floor, merge_order))
         main_chain = parse + dec + mo + gaps
         gather = 0.0 if n == 1 else 0.04 + ir_bytes * (n - 1) / n / 153e9 * 1e3
         t = host_side + max(main_chain, hash_stream) + gather
-        rows.append({"n_gpus": n, "ms_per_step": t, "device_chain_ms": main_chain, "all_gather_ms": gather})
+        # SURVEY.md §8e(i) on top (VERDICT r5 next #6b, modelled, not built): parse + SHA-256 sharded by change index, one ncclAllGather of the
+        # ChangeMetas (176 B per change) in the main chain and one of the digests (32 B) in the hash stream, ~25 us of latency each
+        ag1 = 0.0 if n == 1 else 0.025 + 176.0 * n_changes * (n - 1) / n / 153e9 * 1e3
+        ag2 = 0.0 if n == 1 else 0.025 + 32.0 * n_changes * (n - 1) / n / 153e9 * 1e3
+        chain_b = parse / n + ag1 + dec + mo + gaps
+        t_b = host_side + max(chain_b, hash_stream / n + ag2) + gather
+        rows.append({"n_gpus": n, "ms_per_step": t, "device_chain_ms": main_chain, "all_gather_ms": gather,
+                     "with_stage1_sharded": {"ms_per_step": t_b, "device_chain_ms": chain_b, "parse_ms": parse / n, "metas_all_gather_ms": ag1}})
     t1 = rows[0]["ms_per_step"]
     for r in rows:
         r["projected_speedup"] = t1 / r["ms_per_step"]
+        r["with_stage1_sharded"]["projected_speedup"] = t1 / r["with_stage1_sharded"]["ms_per_step"]
     return {"workload": sub["workload"], "measured_on_one_gpu_ms": {"t_replay": t_replay, "t_device": t_dev, "parse": parse, "decode": decode, "merge_order": merge_order,
                                                                    "hash_stream": hash_stream, "host_side": host_side},
             "assumptions": {"decoder_fraction_for_foreign_changes": f_obj, "launch_floor_ms": floor, "xgmi_link_GB_per_s": 153, "all_gather_launch_ms": 0.04},
             "projected": rows,
+            "stage1_sharding": "modelled, not built: parse / N + an all-gather of the ChangeMetas costs what it saves when a change parses in ~5 ns (21 us for 4097 changes) "
+                               "and an all-gather starts at ~25 us; it pays for batches of few fat changes (c3_map_lww: parse 95 us, hash stream 380 us)",
             "note": "strong scaling of ONE document; the deployment shape (one document per GPU, `value` at N > 1) scales with N by construction"}
 
 
@@ -805,7 +816,7 @@ def compact_line(d):
                        "single_gpu_ms_per_step": _r(x["single_gpu_ms_per_step"], 5), "speedup_vs_single_gpu": _r(x["speedup_vs_single_gpu"]),
                        "parity": x["parity"][:80]}
     if d.get("sharding_model"):
-        line["sharding_model_projected_speedup"] = {str(r["n_gpus"]): _r(r["projected_speedup"]) for r in d["sharding_model"]["projected"]}
+        line["sharding_model_projected_speedup"] = {str(r["n_gpus"]): [_r(r["projected_speedup"]), _r(r["with_stage1_sharded"]["projected_speedup"])] for r in d["sharding_model"]["projected"]}
     line["detail"] = d.get("detail_file", "gpurun_out/bench_detail.json")
     # the line must fit whole in the driver's record: drop the optional parts, last first, until it does
     for k in ("sharding_model_projected_speedup", "history_after_load_ms", "save_ms", "apply_changes_ms", "sharded_c5", "workloads"):
