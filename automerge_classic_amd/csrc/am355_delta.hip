@@ -670,6 +670,85 @@ __global__ __launch_bounds__(BLOCK) void kd_partition_lds(DeltaBufs d, uint32_t 
   }
 }
 
+// The same for up to PART_BIG_MAX items -- the list edits of a few dozen changes -- in ONE workgroup of 1024 threads with 158 KB of the
+// CU's 160 KB of LDS: the level-by-level version spends three dependent launches (~15-24 us) on each of 13-15 levels there. Every
+// thread owns up to eleven consecutive items; ONE copy of the items lives in LDS (a level reads its items into registers, computes
+// where they go from the packed prefixes, and writes them back after a barrier), the count so far as 16 bits (|acc| <= items < 2^15),
+// the element not at all (it follows from the item's row: put_item). (A single workgroup working on HBM instead of LDS was measured
+// slower than the launches: profiles/r06_apply_partition_wg.txt.)
+constexpr uint32_t PART_BIG_THREADS = 1024, PART_BIG_PER = 11, PART_BIG_MAX = PART_BIG_THREADS * PART_BIG_PER;
+__global__ __launch_bounds__(PART_BIG_THREADS) void kd_partition_lds_big(MergeBufs b, DeltaBufs d, uint32_t m, uint32_t bits) {
+  __shared__ uint32_t s_tk[PART_BIG_MAX], s_lh[PART_BIG_MAX], s_pre[PART_BIG_MAX + 1];   // lo | hi << 16; zeros in front | weight of them << 16
+  __shared__ uint16_t s_acc[PART_BIG_MAX];
+  __shared__ uint32_t s_z[PART_BIG_THREADS / WAVE], s_w[PART_BIG_THREADS / WAVE];
+  const uint32_t t = threadIdx.x, lane = t & (WAVE - 1), wv = t / WAVE;
+  for (uint32_t i = t; i < m; i += PART_BIG_THREADS) { s_tk[i] = d.tk[0][i]; s_lh[i] = d.lo[0][i] | d.hi[0][i] << 16; s_acc[i] = 0; }
+  const uint32_t per = (m + PART_BIG_THREADS - 1) / PART_BIG_THREADS;   // <= PART_BIG_PER
+  const uint32_t b0 = t * per < m ? t * per : m, cnt = (b0 + per < m ? b0 + per : m) - b0;
+  __syncthreads();
+  for (int bit = (int)bits - 1; bit >= 0; bit--) {
+    uint32_t tk[PART_BIG_PER], lh[PART_BIG_PER], acc[PART_BIG_PER], to[PART_BIG_PER];
+    uint32_t zs = 0, ws = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PART_BIG_PER; k++)
+      if (k < cnt) {
+        tk[k] = s_tk[b0 + k]; lh[k] = s_lh[b0 + k]; acc[k] = s_acc[b0 + k];
+        if (!(((tk[k] >> 2) >> bit) & 1u)) { zs++; ws += item_weight(tk[k]); }
+      }
+    // exclusive prefixes of the zero flags and of their weights over all items (both fit 16 bits: at most PART_BIG_MAX items, weights +-1)
+    uint32_t zi = wave_incl_scan_u32(zs, lane), wi = wave_incl_scan_u32(ws, lane);
+    if (lane == WAVE - 1) { s_z[wv] = zi; s_w[wv] = wi; }
+    __syncthreads();
+    uint32_t zb = zi - zs, wb = wi - ws, zt = 0, wt = 0;
+    for (uint32_t k = 0; k < PART_BIG_THREADS / WAVE; k++) {
+      uint32_t x = s_z[k], y = s_w[k];
+      zb += k < wv ? x : 0; wb += k < wv ? y : 0;
+      zt += x; wt += y;
+    }
+    const uint32_t zb0 = zb, wb0 = wb;
+#pragma unroll
+    for (uint32_t k = 0; k < PART_BIG_PER; k++)
+      if (k < cnt) {
+        s_pre[b0 + k] = (zb & 0xffffu) | wb << 16;
+        if (!(((tk[k] >> 2) >> bit) & 1u)) { zb++; wb += item_weight(tk[k]); }
+      }
+    if (t == 0) s_pre[m] = (zt & 0xffffu) | wt << 16;
+    __syncthreads();
+    // the stable partition of every group by the bit (kd_partition), destinations computed from the prefixes at the group's bounds
+    zb = zb0; wb = wb0;
+#pragma unroll
+    for (uint32_t k = 0; k < PART_BIG_PER; k++)
+      if (k < cnt) {
+        const uint32_t i = b0 + k, lo = lh[k] & 0xffffu, hi = lh[k] >> 16;
+        const uint32_t pl = s_pre[lo], ph = s_pre[hi];
+        const uint32_t zl = pl & 0xffffu, nz = ((ph & 0xffffu) - zl) & 0xffffu;
+        if (((tk[k] >> 2) >> bit) & 1u) {
+          acc[k] += (wb - (pl >> 16)) & 0xffffu;   // (mod 2^16: the count is kept as 16 bits)
+          to[k] = lo + nz + ((i - lo) - ((zb - zl) & 0xffffu));
+          lh[k] = (lo + nz) | hi << 16;
+        } else {
+          to[k] = lo + ((zb - zl) & 0xffffu);
+          lh[k] = lo | (lo + nz) << 16;
+          zb++; wb += item_weight(tk[k]);
+        }
+      }
+    __syncthreads();   // every thread has its items and its prefixes in registers: the single copy may be overwritten
+#pragma unroll
+    for (uint32_t k = 0; k < PART_BIG_PER; k++)
+      if (k < cnt) { s_tk[to[k]] = tk[k]; s_lh[to[k]] = lh[k]; s_acc[to[k]] = (uint16_t)acc[k]; }
+    __syncthreads();
+  }
+  const int out = (int)(bits & 1u);  // (where the level-by-level version leaves them)
+  for (uint32_t i = t; i < m; i += PART_BIG_THREADS) {
+    const uint32_t tk = s_tk[i], g = d.T0 + (tk >> 2);
+    const uint8_t kind = b.kind[g];
+    d.tk[out][i] = tk;
+    d.elem[out][i] = ((tk & 3u) == 0u && (kind == K_LIST_INS || kind == K_LIST_INS_VIS)) ? g : b.ref_row[g];   // (put_item: a new element's own insert row, or the element a row deletes / assigns to)
+    d.acc[out][i] = (uint32_t)(int32_t)(int16_t)s_acc[i];
+    d.lo[out][i] = s_lh[i] & 0xffffu; d.hi[out][i] = s_lh[i] >> 16;
+  }
+}
+
 // items are now in (object, time) order: index of each edit
 __global__ __launch_bounds__(BLOCK) void kd_edit_index(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
   uint32_t i = gtid();
@@ -1092,8 +1171,12 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     // (Round 6 tried all levels in ONE 1024-thread workgroup over HBM for up to 32 k items, profiles/r06_apply_partition_wg.txt: 35 us per
     // level against ~15 for the three launches -- one CU's memory pipeline is no match for 256, and the device-side cost of a dependent
     // kernel boundary is only ~1.5-2 us, MI355X_MICROARCH.md "boundary". Taken out again.)
+    const bool no_big = getenv("AM355_DELTA_NO_BIG_LDS") != nullptr;   // (tests, A/B: the level-by-level version for 1 k - 11 k items)
     if (m <= PART_LDS_MAX && !no_lds) {
       hipLaunchKernelGGL(kd_partition_lds, dim3(1), dim3(BLOCK), 0, st, d, m, d.bits_new);
+      cur = (int)(d.bits_new & 1u);
+    } else if (m <= PART_BIG_MAX && !no_lds && !no_big && d.bits_new) {
+      hipLaunchKernelGGL(kd_partition_lds_big, dim3(1), dim3(PART_BIG_THREADS), 0, st, b, d, m, d.bits_new);
       cur = (int)(d.bits_new & 1u);
     } else {
       if (d.bits_new) AM355_LAUNCH_INDEPENDENT(kd_bit_flags, dgrid(m + 1), dim3(BLOCK), st, d, cur, m, d.bits_new - 1);

@@ -213,23 +213,27 @@ def test_generated_logs_in_batches_match_the_oracle_emulated(emu_lib, kind, kw, 
 
 
 def test_partition_variants_agree_emulated(emu_lib, monkeypatch):
-    """The dominance counts of the list edits by both versions of the partition levels -- all levels in LDS (<= 1024 items) and three
-    launches per level -- give the oracle's patches, on batches of a few hundred and of ~1200 items."""
+    """The dominance counts of the list edits by the three versions of the partition levels -- all levels in LDS in a workgroup of 256
+    (<= 1024 items), all levels in LDS in a workgroup of 1024 with the items held once (<= 11264 items, kd_partition_lds_big), three
+    launches per level -- give the oracle's patches, on batches of a few hundred, ~1200 and ~4800 items (two list objects, deletions)."""
     log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=8, n_rounds=4, ins_per_change=60, del_per_change=15, n_objects=2, seed=29)
+    big = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=16, n_rounds=4, ins_per_change=120, del_per_change=30, n_objects=2, seed=31)
     texts = []
-    for env in ({}, {"AM355_DELTA_NO_LDS": "1"}):
-        monkeypatch.delenv("AM355_DELTA_NO_LDS", raising=False)
+    for env in ({}, {"AM355_DELTA_NO_BIG_LDS": "1"}, {"AM355_DELTA_NO_LDS": "1"}):
+        for k in ("AM355_DELTA_NO_BIG_LDS", "AM355_DELTA_NO_LDS"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        eng, eng2 = engine.Engine(0, emu_lib), engine.Engine(0, emu_lib)
+        engs = [engine.Engine(0, emu_lib) for _ in range(3)]
         try:
-            check_against_oracle_session(eng, split_log(log, 2))
-            check_against_oracle_session(eng2, split_log(log, 16))
-            texts.append(eng.patch_json())
+            check_against_oracle_session(engs[0], split_log(log, 2))
+            check_against_oracle_session(engs[1], split_log(log, 16))
+            check_against_oracle_session(engs[2], split_log(big, 2))
+            texts.append((engs[0].patch_json(), engs[2].patch_json()))
         finally:
-            eng.close()
-            eng2.close()
-    assert texts[0] == texts[1]
+            for e in engs:
+                e.close()
+    assert texts[0] == texts[1] == texts[2]
 
 
 def test_batches_behind_the_staged_changes_or_restaged_emulated(emu_lib, monkeypatch):
