@@ -117,6 +117,13 @@ extern "C" int am355_get_hashes(const am355_ctx* c, uint8_t* out) {
   return AM355_OK;
 }
 
+extern "C" int am355_resident_counters(const am355_ctx* c, uint64_t out[2]) {
+  if (!c || !out) return AM355_E_ARG;
+  out[0] = c->n_resident_calls;
+  out[1] = c->n_resident_fallbacks;
+  return AM355_OK;
+}
+
 extern "C" int am355_get_raw(const am355_ctx* c, const uint8_t** arena, const uint64_t** offsets, uint32_t* n) {
   if (!c || !c->staged) return AM355_E_STATE;
   if (arena) *arena = c->raw.data();

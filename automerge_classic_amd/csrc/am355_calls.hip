@@ -200,7 +200,7 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
   }
   // ---- the queue of the call: changes applied so far (application order) | the batch | changes still queued (new.js:1822) ----
   const uint32_t n_old_applied = have_state ? (uint32_t)c->applied_change.size() : 0;
-  const uint64_t old_ops = have_state ? c->n_ops : 0;
+  const uint64_t old_ops = have_state ? c->n_ops : 0, old_preds = have_state ? c->n_preds : 0;
   // When every staged change was applied, in the order it is staged, and nothing is queued -- the usual case -- the staged bytes are
   // already that queue's front, in the pinned arena and in HBM: only the batch is gathered and copied behind them.
   bool append = have_state && c->pending_change.empty() && n_old_applied == c->n_changes && !getenv("AM355_APPLY_RESTAGE");
@@ -236,6 +236,15 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
   if (!have_state) { c->stream_breaks.clear(); c->breaks_exact = true; c->children_hazard = false; c->no_history = false; c->doc_rows_known = false; c->graph_mode = 0; }
   c->in_apply = true;
   c->sched_prefix = n_old_applied;
+  // the state the context holds stays where it is and the batch is merged into it (am355_replay.hip replay_resident) when the staged
+  // changes are exactly the applied ones; AM355_NO_RESIDENT=1: the full replay for every call (rounds 3-5; A/B and tests)
+  // (measured, profiles/r06_apply_resident.txt: the batch's host-side schedule -- 1.5 us per change -- overtakes what the skipped device
+  // stages cost at about sixteen changes; larger batches take the full replay, whose stage 1 runs on the device. AM355_RESIDENT_MAX)
+  static const uint32_t resident_max = []() { const char* e = getenv("AM355_RESIDENT_MAX"); return e && atol(e) > 0 ? (uint32_t)atol(e) : 12u; }();
+  c->keep.want = append && n > 0 && n <= resident_max && !getenv("AM355_NO_RESIDENT");
+  c->keep.n_changes = n_old_applied;
+  c->keep.n_ops = old_ops;
+  c->keep.n_preds = old_preds;
   rc = replay_impl(c);
   c->in_apply = false;
   if (!rc && c->graph_mode == 1 && c->sched_graph_after) c->graph_mode = 0;  // (this call made the reference rebuild the hash graph)
@@ -321,6 +330,7 @@ extern "C" int am355_reset(am355_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->staging_in_flight) { c->staging_in_flight = false; (void)hipStreamSynchronize(c->stream); }
   c->staged = c->replayed = c->ir_fetched = c->apply_ready = false;
+  c->resident_valid = false;
   c->state_checked = true;
   c->stream_breaks.clear();
   c->breaks_exact = true;
@@ -408,7 +418,7 @@ int get_dep_graph_impl(am355_ctx* c, const uint32_t** dep_first, const uint32_t*
   (void)hipSetDevice(c->device);
   if (!c->dep_graph_ready) {
     const uint32_t n = c->n_changes;
-    const size_t dep_words = c->raw.size() / 32 + 2;
+    const size_t dep_words = std::min(c->raw.size() / 32 + 2, c->d_dep_idx.cap / 4);   // (resident calls grow the arena without touching this table)
     // the device resolved every dependency hash to the index of the change that carries it (k_deps_resolve), addressed by the
     // dependency's place in the arena; the change headers say where those places are
     if (!c->h_dep_idx.ensure(4 * dep_words) || !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n, 1u))) return fail(c, AM355_E_NOMEM, "host allocation failed");
@@ -420,9 +430,16 @@ int get_dep_graph_impl(am355_ctx* c, const uint32_t** dep_first, const uint32_t*
     c->dep_first.assign((size_t)n + 1, 0);
     for (uint32_t i = 0; i < n; i++) c->dep_first[i + 1] = c->dep_first[i] + metas[i].n_deps;
     c->dep_index.resize(c->dep_first[n]);
-    for (uint32_t i = 0; i < n; i++) {
+    // (changes appended by resident calls, replay_resident: their dependencies were resolved on the host)
+    const uint32_t nr = std::min(n, c->res_dep_base);
+    for (uint32_t i = 0; i < nr; i++) {
       const size_t first = (size_t)((metas[i].base + metas[i].deps_off) >> 5);
       for (uint32_t k = 0; k < metas[i].n_deps; k++) c->dep_index[c->dep_first[i] + k] = di[first + k];
+    }
+    for (uint32_t i = nr; i < n; i++) {
+      const uint32_t j = i - c->res_dep_base;
+      if (j + 1 >= c->res_dep_first.size() || c->res_dep_first[j + 1] - c->res_dep_first[j] != metas[i].n_deps) return fail(c, AM355_E_DEVICE, "internal: dependency record of an appended change is missing");
+      for (uint32_t k = 0; k < metas[i].n_deps; k++) c->dep_index[c->dep_first[i] + k] = c->res_dep_index[c->res_dep_first[j] + k];
     }
     c->dep_graph_ready = true;
   }

@@ -44,8 +44,10 @@ namespace am355_host {   // (host-side helpers of the C ABI's translation units)
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  uint32_t lost = 0;   // times the CONTENT was given up (ensure that had to grow, release): what a kept state checks (am355_replay.hip resident_mark)
   bool ensure(size_t bytes) {
     if (bytes <= cap) return true;
+    lost++;
     canary_forget(p, cap);
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -69,6 +71,7 @@ struct DevBuf {
     return true;
   }
   void release() {
+    lost++;
     canary_forget(p, cap);
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -80,8 +83,22 @@ struct DevBuf {
 struct HostBuf {
   void* p = nullptr;
   size_t cap = 0;
+  uint32_t lost = 0;   // as DevBuf::lost
+  // grows like ensure() but carries the first `keep` bytes over
+  bool ensure_keep(size_t bytes, size_t keep) {
+    if (bytes <= cap) return true;
+    size_t want = bytes + bytes / 2 + 256;
+    void* q = nullptr;
+    if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return false;
+    if (p && keep) memcpy(q, p, keep);
+    if (p) (void)hipHostFree(p);
+    p = q;
+    cap = want;
+    return true;
+  }
   bool ensure(size_t bytes) {
     if (bytes <= cap) return true;
+    lost++;
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
@@ -446,6 +463,29 @@ struct am355_ctx {
   HostBuf h_delta_tabs;  // pinned: stream breaks | pass rows of a delta stage on their way to the device (run_delta_stage)
   bool state_checked = false;  // the state was built by am355_apply_changes calls (each checked for what later patches depend on) or is empty
   std::string apply_json;
+
+  // Resident state (am355_apply_changes onto a state this context holds; am355_replay.hip replay_resident): when the last replay left
+  // the op rows, their per-row results and the per-change tables of exactly the applied changes in HBM -- in staged order, nothing
+  // queued -- the next call parses, hashes, decodes and resolves the BATCH alone and appends. In apply mode the row arrays are carved
+  // for a capacity (cols_cap_*) so that they stay where they are while the document grows.
+  struct Keep { bool want = false; uint32_t n_changes = 0; uint64_t n_ops = 0, n_preds = 0; } keep;   // apply_changes_impl -> replay_impl
+  uint32_t cols_cap_ops = 0, cols_cap_preds = 0;   // what c->cols / c->mb's per-row arrays are carved for (>= n_ops, n_preds)
+  bool resident_valid = false;
+  struct ResidentMark { uint32_t lost[8] = {}; uint32_t n_changes = 0; uint64_t n_ops = 0, n_preds = 0; } res_mark;
+  uint32_t seed_list_inc = 0;                      // Counts.n_list_inc after the last replay
+  std::vector<uint32_t> hash_index;                // open addressing over h_hashes: change index + 1 (0 empty); rebuilt when hash_index_n != applied changes
+  uint32_t hash_index_n = 0;
+  // actor ids -> ranks for the host's schedule of a batch: the document's table inverted, and per author the "other actors" table of its
+  // last change with the ranks it gave (changes of one author nearly always carry the same table: one memcmp instead of 64 lookups);
+  // both describe c->actors and are dropped with it (a full replay ranks the actors anew)
+  std::unordered_map<std::string, uint32_t> res_rank_of;
+  struct ActorMemo { std::vector<uint8_t> bytes; std::vector<uint32_t> ranks; };
+  std::vector<ActorMemo> res_actor_memo;
+  HostBuf h_res_metas;                             // pinned: the batch's ChangeMetas on their way to the host
+  uint32_t res_dep_base = 0;                       // changes >= this were applied by resident calls: their dependency indexes live in ...
+  std::vector<uint32_t> res_dep_first, res_dep_index;   // ... CSR over (change - res_dep_base)
+  uint64_t n_resident_calls = 0, n_resident_fallbacks = 0;
+  std::string resident_why;                        // why the last attempt fell back (diagnostics, AM355_TRACE)
 
   // objectId sharding (am355_set_shard): this context merges the objects rank `shard_rank` of `shard_world` owns
   uint32_t shard_rank = 0, shard_world = 1;

@@ -12,6 +12,9 @@ struct ParseFills {
 };
 void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, const ParseFills& fills,
                           hipStream_t st, bool fat = false);
+// decoder class of a parsed change for a host-built plan (what k_actor_check writes into ChangeBrief.flags_fits): 2 small wave class,
+// 1 large wave class, 0 lane-serial
+int change_wave_class(const ChangeMeta& m);
 void launch_hash_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n, uint8_t* hashes, uint32_t* min_idx, uint32_t* hash_tab,
                          uint32_t tab_mask, uint32_t* flags, hipStream_t st);
 void launch_deps_resolve(const uint8_t* arena, const ChangeMeta* metas, const uint8_t* hashes, uint32_t n, const uint32_t* hash_tab, uint32_t tab_mask,

@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(WAVE) void k_actor_intern(const uint8_t* __restrict
 
 // every actor a change mentions must already be in the document when the change is read (new.js:1442-1449):
 // with in-order application that means its first change has an index <= this one
-__device__ __forceinline__ int wave_class_of(const ChangeMeta& m);
+__host__ __device__ __forceinline__ int wave_class_of(const ChangeMeta& m);
 
 // Device half of the in-order plan, part 1 (with k_plan_apply below): while it writes the digests, every workgroup also publishes the
 // sums of its 256 changes (ops, preds, actor entries, plans per decoder class), and one EXTRA workgroup (blockIdx == gridDim - 1)
@@ -1733,7 +1733,7 @@ using WaveLdsLarge = WaveLdsT<1024, 4096, 1024>;  // ~24 KB: 6 waves per CU
 enum { RK_REP = 1, RK_LIT = 2, RK_NUL = 3 };
 
 // 2: small wave class, 1: large wave class, 0: lane-serial decoder
-__device__ __forceinline__ int wave_class_of(const ChangeMeta& m) {
+__host__ __device__ __forceinline__ int wave_class_of(const ChangeMeta& m) {
   const int tokenised[] = {C_OBJ_ACTOR, C_OBJ_CTR, C_KEY_ACTOR, C_KEY_CTR, C_INSERT, C_ACTION, C_VAL_LEN, C_PRED_NUM, C_PRED_ACTOR, C_PRED_CTR};
   uint32_t longest = 0;
   for (int k = 0; k < 10; k++) longest = m.col_len[tokenised[k]] > longest ? m.col_len[tokenised[k]] : longest;
@@ -2458,6 +2458,8 @@ __global__ __launch_bounds__(WAVE) AM355_WAVES_PER_EU(WL::COLMAX <= 256 ? 6 : 1)
   }  // DG_PRED
   if (err) atomicOr(flags, err);
 }
+
+int change_wave_class(const ChangeMeta& m) { return wave_class_of(m); }
 
 void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, const ParseFills& fills,
                           hipStream_t st, bool fat) {

@@ -124,36 +124,6 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t N, uint32_t NN, uint32_t NM,
   canary_note(p, sort_workspace_bytes((uint32_t)((size_t)NM + cap + 1)));
 }
 
-// word ranges of the stage's device block and the value each is filled with (delta_run)
-struct DeltaFills {
-  uint32_t* p[8];
-  uint32_t n_words[8];
-  uint32_t value[8];
-  uint32_t n;
-};
-// The counter words (ranges 0 and 1 overlap: `reason` is set behind the clearing of the block that holds it) are written by thread 0
-// of workgroup 0 in range order; every other range is grid-strided, four words per thread where the alignment allows.
-__global__ __launch_bounds__(BLOCK) void kd_fills(DeltaFills f) {
-  const uint32_t tid = gtid(), stride = gridDim.x * BLOCK;
-  for (uint32_t k = 0; k < f.n; k++) {
-    uint32_t* p = f.p[k];
-    const uint32_t n = f.n_words[k], v = f.value[k];
-    if (n <= 64) {  // (small ranges may overlap: one thread, in order)
-      if (tid == 0) for (uint32_t i = 0; i < n; i++) p[i] = v;
-      continue;
-    }
-    const uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4u;  // words up to the first 16-byte boundary
-    const uint32_t n4 = (n - head) / 4;
-    uint4* q = (uint4*)(p + head);
-    uint4 vv;
-    vv.x = vv.y = vv.z = vv.w = v;
-    for (uint32_t i = tid; i < n4; i += stride) q[i] = vv;
-    if (tid < head) p[tid] = v;
-    const uint32_t tail = head + 4 * n4;
-    if (tid < n - tail) p[tail + tid] = v;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // objects: parent link of every object (setupPatches walks them on the host, new.js:1461-1528)
 // ---------------------------------------------------------------------------------------------------------
@@ -1095,19 +1065,15 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   };
   {
     // every fill of the stage in ONE launch (seven memsets in a row cost a launch gap each: ~35 us of a 0.2 ms stage)
-    DeltaFills f{};
-    auto add = [&](void* q, size_t bytes, uint32_t v) { f.p[f.n] = (uint32_t*)q; f.n_words[f.n] = (uint32_t)((bytes + 3) / 4); f.value[f.n] = v; f.n++; };
-    add(d.counts, sizeof(DeltaCounts), 0);
-    add(&d.counts->reason, 4, 0xffffffffu);   // (behind the range that clears it: the ranges are filled in order by the same threads' loop)
-    add(d.first_del, (size_t)((uint8_t*)(d.first_kill + N + 1) - (uint8_t*)d.first_del), 0xffffffffu);   // first_del | first_kill
-    add(d.new_succ, (size_t)((uint8_t*)(d.upd_cur + N + 2) - (uint8_t*)d.new_succ), 0);                  // new_succ | upd_n | upd_cur
-    add(d.icur, 4 * ((size_t)d.n_list + 2), 0);
-    add(d.slot_rep, (size_t)((uint8_t*)(d.slot_drop + cap + 1) - (uint8_t*)d.slot_rep), 0);  // slot_rep | slot_last | slot_cnt | slot_child | slot_drop
-    add(d.slot_first, 4 * ((size_t)cap + 1), 0xffffffffu);
-    size_t words = 0;
-    for (uint32_t k = 0; k < f.n; k++) words += f.n_words[k];
-    uint32_t grid = (uint32_t)std::min<size_t>((words / 4 + BLOCK - 1) / BLOCK + 1, 2048);
-    hipLaunchKernelGGL(kd_fills, dim3(grid), dim3(BLOCK), 0, st, f);
+    FillRanges f;
+    f.add(d.counts, sizeof(DeltaCounts), 0);
+    f.add(&d.counts->reason, 4, 0xffffffffu);   // (behind the range that clears it: small ranges are written in order by one thread)
+    f.add(d.first_del, (size_t)((uint8_t*)(d.first_kill + N + 1) - (uint8_t*)d.first_del), 0xffffffffu);   // first_del | first_kill
+    f.add(d.new_succ, (size_t)((uint8_t*)(d.upd_cur + N + 2) - (uint8_t*)d.new_succ), 0);                  // new_succ | upd_n | upd_cur
+    f.add(d.icur, 4 * ((size_t)d.n_list + 2), 0);
+    f.add(d.slot_rep, (size_t)((uint8_t*)(d.slot_drop + cap + 1) - (uint8_t*)d.slot_rep), 0);  // slot_rep | slot_last | slot_cnt | slot_child | slot_drop
+    f.add(d.slot_first, 4 * ((size_t)cap + 1), 0xffffffffu);
+    launch_fill_ranges(f, st);
   }
   AM355_LAUNCH_INDEPENDENT(kd_objects, dgrid(d.n_obj), dim3(BLOCK), st, b, ir, d);
   step("objects");

@@ -46,6 +46,12 @@ struct MergeBufs {
   OpCols ops;
   uint32_t n_ops, n_preds, n_actors;
   uint32_t shard_rank, shard_world;  // objectId sharding: this rank merges the objects it owns (shard_owner); world 1 = everything
+  // Resident state (am355_apply_changes onto a state the context holds, am355_replay.hip replay_resident): rows [0, first_row) were
+  // decoded and resolved by an earlier replay and are where they were -- with their obj_row / ref_row / kind and with the successor /
+  // increment accumulators the rows so far left in them; k_resolve then runs over the rows >= first_row only. seed_list_inc: what
+  // Counts.n_list_inc held after that earlier replay (the counter block is cleared per replay). row_stride: words between the per-row
+  // arrays of this block (capacity + 1; 0 = n_ops + 1): the fills go by n_ops, not by the stride.
+  uint32_t first_row, seed_list_inc, row_stride;
   const uint32_t* actor_tab_off;  // [n_actors + 1] into spans
   const ActorSpan* spans;
   uint32_t bits_ctr, bits_actor;  // key widths: bits(max op counter), bits(n_actors)

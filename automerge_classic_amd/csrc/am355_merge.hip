@@ -19,6 +19,7 @@
 #include "am355_prims.h"
 #include "am355_rows.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -32,8 +33,9 @@ namespace am355 {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_resolve(MergeBufs b) {
   wave_priority_high();
-  uint32_t g = gtid();
+  uint32_t g = b.first_row + gtid();   // (first_row > 0: the rows in front were resolved by an earlier replay and kept, see MergeBufs)
   const bool in_range = g < b.n_ops;
+  if (b.seed_list_inc && gtid() == 0) atomicAdd(&b.counts->n_list_inc, b.seed_list_inc);
   const OpCols& o = b.ops;
   uint32_t err = 0;
   uint32_t a = in_range ? o.action[g] : 1;
@@ -190,6 +192,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
   const OpCols& o = b.ops;
   bool in_range = g < b.n_ops;
   uint8_t kind = in_range ? b.kind[g] : (uint8_t)K_NONE;
+  // (a kept row of an earlier replay may carry that replay's verdict "its own value is visible": judged again below)
+  const bool was_vis = kind == K_LIST_INS_VIS;
+  if (was_vis) kind = K_LIST_INS;
   uint32_t a = in_range ? o.action[g] : 1;
   bool live = kind != K_NONE && kind != K_DEL;
   bool is_make = live && (a & 1) == 0;  // (a foreign make row too: the object table is the same on every rank)
@@ -214,8 +219,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit(MergeBufs b) {
     bool valued = (a == 1) || (a & 1) == 0;
     want_ins = kind == K_LIST_INS;
     bool quirk = false;
+    if (kind == K_LIST_INS && was_vis != (vis && valued)) b.kind[g] = (vis && valued) ? K_LIST_INS_VIS : K_LIST_INS;
     if (vis && valued) {
-      if (kind == K_LIST_INS) b.kind[g] = K_LIST_INS_VIS;
+      if (kind == K_LIST_INS) {}
       else {
         el = b.ref_row[g];
         if (el != NONE32) {
@@ -1503,9 +1509,27 @@ void merge_bind_counts(MergeBufs& b, void* block) {
 
 void merge_prepare(MergeBufs& b, hipStream_t aux) {
   uint32_t N = b.n_ops;
-  (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, aux);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
-  if (!N) return;
-  (void)hipMemsetAsync(b.fill_base, 0xff, b.fill_bytes, aux);  // order, first_child, child_head
+  if (b.row_stride == 0 && b.first_row == 0) {
+    (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, aux);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
+    if (!N) return;
+    (void)hipMemsetAsync(b.fill_base, 0xff, b.fill_bytes, aux);  // order, first_child, child_head
+    return;
+  }
+  // arrays carved for a capacity (am355_apply_changes: the rows stay where they are from call to call) are filled by their rows, in
+  // one launch; the accumulators of kept rows [0, first_row) keep what the earlier rows left in them
+  const size_t F = b.first_row, M = (size_t)N + 1 - F;
+  FillRanges f;
+  f.add(b.succ_cnt + F, 4 * M, 0);
+  f.add(b.inc_cnt + F, 4 * M, 0);
+  f.add(b.inc_sum + F, 8 * M, 0);
+  f.add(b.last_inc + F, 8 * M, 0);
+  f.add(b.val_cnt, 4 * ((size_t)N + 1), 0);   // (recounted by k_emit over all rows)
+  if (N) {
+    f.add(b.order, 4 * ((size_t)N + 2), 0xffffffffu);
+    f.add(b.first_child, 4 * (2 * (size_t)N + 3), 0xffffffffu);
+    f.add(b.child_head, 4 * (2 * (size_t)N + 2), 0xffffffffu);
+  }
+  launch_fill_ranges(f, aux);
 }
 
 // map emissions: LSD over (trigger id | key length | key chunks last..first | object)
@@ -1606,7 +1630,7 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   uint32_t* heads = b.run_heads;  // [runs + 1]
   uint32_t* row_run = b.row_run;  // [N]
   // ---- per-row resolution, visibility, compaction (b.counts already holds the decode kernels' validity flags) ----
-  hipLaunchKernelGGL(k_resolve, grid_for(N), dim3(BLOCK), 0, st, b);
+  hipLaunchKernelGGL(k_resolve, grid_for(std::max(N - b.first_row, 1u)), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_compact_rows, grid_for(N), dim3(BLOCK), 0, st, b, ir);
   if (!b.sig) (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);

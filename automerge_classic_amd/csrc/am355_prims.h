@@ -5,6 +5,16 @@
 #include <stddef.h>
 
 namespace am355 {
+// Several word ranges filled with a value each in ONE launch (a memset per range costs a launch gap each). Ranges of <= 64 words
+// are written by one thread in the order given (they may overlap: a later range wins); longer ones must not overlap.
+struct FillRanges {
+  uint32_t* p[8];
+  uint32_t n_words[8];
+  uint32_t value[8];
+  uint32_t n = 0;
+  void add(void* q, size_t bytes, uint32_t v) { p[n] = (uint32_t*)q; n_words[n] = (uint32_t)((bytes + 3) / 4); value[n] = v; n++; }
+};
+void launch_fill_ranges(const FillRanges& f, hipStream_t st);
 size_t scan_workspace_bytes(uint32_t n);
 // out[i] = sum(in[0..i)); in == out allowed. *d_total (device, optional) receives the grand total.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total, void* ws, hipStream_t st);

@@ -3,6 +3,7 @@
 // ranking, LDS histograms. These are HBM-bound integer kernels (no MFMA): each sort pass reads and writes
 // every pair once (12 B in, 12 B out) plus one histogram read of the keys.
 #include "am355_prims.h"
+#include <algorithm>
 #include "am355_scan.h"
 #include "am355_canary.h"
 #include <mutex>
@@ -910,6 +911,38 @@ bool canary_check(char* msg, size_t msg_len) {
     e.armed = false;  // (filled again by the next canary_arm: one report per overrun)
   } else snprintf(msg, msg_len, "AM355_CANARY: the check itself failed (%s)", hipGetErrorString(hipGetLastError()));
   return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fills: several word ranges in one launch (am355_prims.h FillRanges)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_fill_ranges(FillRanges f) {
+  const uint32_t tid = gtid(), stride = gridDim.x * BLOCK;
+  for (uint32_t k = 0; k < f.n; k++) {
+    uint32_t* p = f.p[k];
+    const uint32_t n = f.n_words[k], v = f.value[k];
+    if (n <= 64) {  // (small ranges may overlap: one thread, in order)
+      if (tid == 0) for (uint32_t i = 0; i < n; i++) p[i] = v;
+      continue;
+    }
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4u;  // words up to the first 16-byte boundary
+    const uint32_t n4 = (n - head) / 4;
+    uint4* q = (uint4*)(p + head);
+    uint4 vv;
+    vv.x = vv.y = vv.z = vv.w = v;
+    for (uint32_t i = tid; i < n4; i += stride) q[i] = vv;
+    if (tid < head) p[tid] = v;
+    const uint32_t tail = head + 4 * n4;
+    if (tid < n - tail) p[tail + tid] = v;
+  }
+}
+
+void launch_fill_ranges(const FillRanges& f, hipStream_t st) {
+  if (!f.n) return;
+  size_t words = 0;
+  for (uint32_t k = 0; k < f.n; k++) words += f.n_words[k];
+  uint32_t grid = (uint32_t)std::min<size_t>((words / 4 + BLOCK - 1) / BLOCK + 1, 2048);
+  hipLaunchKernelGGL(k_fill_ranges, dim3(grid), dim3(BLOCK), 0, st, f);
 }
 
 }  // namespace am355

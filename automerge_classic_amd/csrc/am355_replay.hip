@@ -498,6 +498,14 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank, const uint3
 // The op rows (13 word columns + the insert byte) and the flattened pred lists, for N rows / P preds.
 static int carve_cols(am355_ctx* c, uint32_t N, uint32_t P) {
   canary_scope("replay buffers (carve_cols: op rows, preds)");
+  if (c->in_apply) {
+    // am355_apply_changes: room for the document to grow without the rows moving (replay_resident appends to them)
+    N = (uint32_t)std::min<uint64_t>((uint64_t)N + N / 4 + 65536, 0x7ffffff0u);
+    P = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 4 + 65536, 0xfffffff0u);
+  }
+  c->cols_cap_ops = N;
+  c->cols_cap_preds = P;
+  c->resident_valid = false;   // (the rows are about to be written anew, maybe somewhere else)
   size_t Nc = (size_t)N + 1;
   size_t bytes = 13 * carve_size(Nc, 4) + carve_size(Nc, 1);
   if (!c->d_cols.ensure(bytes) || !c->d_pred.ensure(2 * carve_size((size_t)P + 1, 4))) return fail(c, AM355_E_NOMEM, "device allocation failed (op rows)");
@@ -522,6 +530,7 @@ int setup_buffers(am355_ctx* c, uint32_t NA) {
   int bits_ctr = bits_for64(c->max_op), bits_actor = bits_for64(NA ? NA - 1 : 0), bits_row = bits_for64(N);
   if (1 + bits_row + bits_ctr + bits_actor > 64) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "sort key wider than 64 bits"); }
   size_t Nc = (size_t)N + 1;
+  c->resident_valid = false;
   canary_scope("replay buffers (setup_buffers: op rows, preds, merge scratch, sort scratch, patch IR)");
   // (rows the speculative decode launch of this replay is writing keep their place: they are carved for a capacity >= N, P)
   if (!(c->spec_launched && N <= c->spec_cap_ops && P <= c->spec_cap_preds)) {
@@ -530,8 +539,12 @@ int setup_buffers(am355_ctx* c, uint32_t NA) {
     if (rcc) return rcc;
   }
   canary_scope("replay buffers (setup_buffers: merge scratch, sort scratch, patch IR)");
+  // am355_apply_changes: the per-row arrays of the merge stage are carved with the stride of the op rows' capacity, so that the kept
+  // rows' results stay where they are from call to call (replay_resident); their fills go by N (merge_prepare)
+  const bool by_cap = c->in_apply && c->cols_cap_ops >= N;
+  if (by_cap) Nc = (size_t)c->cols_cap_ops + 1;
   {
-    size_t cw = carry_words(N);
+    size_t cw = carry_words((uint32_t)(Nc - 1));
     size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc + 2, 4) + 4 * carve_size(2 * Nc + 2, 4) +
                    3 * carve_size(Nc + 1, 4) + scan_workspace_bytes((uint32_t)(2 * Nc + 2)) + 256 +
                    6 * carve_size(Nc + 3, 4) + 6 * carve_size(cw, 4) + carve_size(2048, 4);
@@ -551,6 +564,7 @@ int setup_buffers(am355_ctx* c, uint32_t NA) {
     b.actor_tab_off = c->p_tab_off;
     b.spans = c->p_spans;
     b.bits_ctr = (uint32_t)bits_ctr; b.bits_actor = (uint32_t)bits_actor;
+    b.first_row = 0; b.seed_list_inc = 0; b.row_stride = by_cap ? (uint32_t)Nc : 0u;
     b.zero_base = p;
     b.succ_cnt = carve<uint32_t>(p, Nc); b.inc_cnt = carve<uint32_t>(p, Nc); b.val_cnt = carve<uint32_t>(p, Nc);
     b.inc_sum = carve<unsigned long long>(p, Nc); b.last_inc = carve<unsigned long long>(p, Nc);
@@ -967,6 +981,329 @@ int backend_load_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Resident state: Backend.applyChanges onto the state the context holds (new.js:1797-1879 with mergeDocChangeOps :1052-1290 merging
+// the batch INTO the stored op set). When the last replay left the op rows, their per-row results and the per-change tables of
+// exactly the applied changes in HBM (am355_ctx.h resident_valid), only the BATCH is parsed (k_parse_changes over its changes),
+// hashed (host: SHA extensions, ~2 us per 3 KB change against ~130 us of chain latency on the device), scheduled (host: the
+// in-order case of new.js:1550-1597 -- every dependency applied, next sequence number, known actors; anything else falls back to
+// the full replay, which has the general scheduler), decoded (the batch's plans) and resolved (k_resolve over the new rows, onto
+// the kept accumulators). The whole-document order / patch tables are then rebuilt by the kernels of merge_run as in a full replay
+// (they are what the delta stage reads); what a call no longer pays is stage 1, the decode and the resolution of the old rows.
+// Returns AM355_OK, an error, or RESIDENT_FALLBACK: nothing of the state was touched, replay_impl goes on with the full replay.
+// ---------------------------------------------------------------------------------------------------------
+enum { RESIDENT_FALLBACK = 1 };
+
+static void resident_mark(am355_ctx* c) {
+  am355_ctx::ResidentMark& m = c->res_mark;
+  const uint32_t lost[8] = {c->d_cols.lost, c->d_pred.lost, c->d_merge.lost, c->d_metas.lost, c->d_hashes.lost, c->d_ir.lost, c->d_sort.lost, c->h_hashes.lost};
+  for (int k = 0; k < 8; k++) m.lost[k] = lost[k];
+  m.n_changes = c->n_changes; m.n_ops = c->n_ops; m.n_preds = c->n_preds;
+}
+
+// none of the buffers the kept state lives in has given its content up since the mark (growing WITH the content -- ensure_keep -- is fine)
+static bool resident_mark_holds(const am355_ctx* c) {
+  const am355_ctx::ResidentMark& m = c->res_mark;
+  const uint32_t lost[8] = {c->d_cols.lost, c->d_pred.lost, c->d_merge.lost, c->d_metas.lost, c->d_hashes.lost, c->d_ir.lost, c->d_sort.lost, c->h_hashes.lost};
+  for (int k = 0; k < 8; k++)
+    if (m.lost[k] != lost[k]) return false;
+  return c->d_cols.p && c->d_merge.p && c->d_metas.p && c->d_hashes.p && c->h_hashes.p;
+}
+
+// hash -> change index over c->h_hashes (open addressing, change index + 1; keyed by eight bytes of the hash, verified by full comparison)
+static inline size_t hash_slot(const uint8_t* h, size_t mask) { uint64_t v; memcpy(&v, h, 8); return (size_t)((v * 0x9e3779b97f4a7c15ull) >> 20) & mask; }
+static void hash_index_add(am355_ctx* c, uint32_t ci) {
+  const uint8_t* hs = c->h_hashes.as<uint8_t>();
+  const size_t mask = c->hash_index.size() - 1;
+  size_t i = hash_slot(hs + 32 * (size_t)ci, mask);
+  while (c->hash_index[i]) i = (i + 1) & mask;
+  c->hash_index[i] = ci + 1;
+}
+static uint32_t hash_index_find(const am355_ctx* c, const uint8_t* h) {
+  const uint8_t* hs = (const uint8_t*)c->h_hashes.p;
+  const size_t mask = c->hash_index.size() - 1;
+  for (size_t i = hash_slot(h, mask); c->hash_index[i]; i = (i + 1) & mask)
+    if (memcmp(hs + 32 * (size_t)(c->hash_index[i] - 1), h, 32) == 0) return c->hash_index[i] - 1;
+  return NONE32;
+}
+
+static int replay_resident(am355_ctx* c) {
+  const bool trace = getenv("AM355_TRACE") != nullptr;
+  auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (trace) fprintf(stderr, "resident: %-30s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
+  auto fallback = [&](const char* why) {
+    c->resident_why = why;
+    c->n_resident_fallbacks++;
+    if (trace) fprintf(stderr, "resident: full replay instead (%s)\n", why);
+    return (int)RESIDENT_FALLBACK;
+  };
+  // (once changes of the batch have entered the hash index it no longer describes the applied changes: dropped, rebuilt by the next attempt)
+  auto fallback_dirty = [&](const char* why) { c->hash_index_n = 0; c->hash_index.clear(); return fallback(why); };
+  const uint32_t K = c->keep.n_changes, n = c->n_changes;
+  const uint64_t old_ops = c->keep.n_ops, old_preds = c->keep.n_preds;
+  if (n <= K) return fallback("empty batch");
+  const uint32_t nb = n - K;
+  if (!c->resident_valid || !resident_mark_holds(c) || c->res_mark.n_changes != K || c->res_mark.n_ops != old_ops || c->res_mark.n_preds != old_preds)
+    return fallback("the context's arrays are not the kept state");
+  if (c->shard_world != 1 || c->phase_events || c->graph_mode != 0 || !c->mb.sig) return fallback("mode");
+  if (c->d_metas.cap < sizeof(ChangeMeta) * (size_t)n) return fallback("per-change tables full");   // (am355_load_changes grows it with its content)
+  if (!c->d_hashes.ensure_keep(32 * (size_t)n, 32 * (size_t)K) || !c->h_hashes.ensure_keep(32 * (size_t)n, 32 * (size_t)K) || !c->d_entries.ensure_keep(4 * (size_t)n, 0))
+    return fail(c, AM355_E_NOMEM, "allocation failed (per-change tables)");
+  if (!c->h_res_metas.ensure(sizeof(ChangeMeta) * (size_t)nb)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+  hipStream_t st = c->stream;
+  const uint8_t* raw = c->raw.data();
+
+  // ---- device: header / column directory / row counts of the batch's changes; host meanwhile: their hashes ----
+  const bool fat = c->raw.size() - (size_t)c->raw_off[K] > 4096 * (size_t)nb;
+  launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>() + K, nb, c->d_metas.as<ChangeMeta>() + K, c->d_entries.as<uint32_t>() + K, ParseFills{}, st, fat);
+  HIPCHK(c, hipMemcpyAsync(c->h_res_metas.p, c->d_metas.as<ChangeMeta>() + K, sizeof(ChangeMeta) * (size_t)nb, hipMemcpyDeviceToHost, st));
+  uint8_t* hs = c->h_hashes.as<uint8_t>();
+  std::atomic<int> bad_sum{0};
+  auto hash_one = [&](uint32_t i) {
+    const uint64_t off = c->raw_off[K + i], len = c->raw_off[K + i + 1] - off;
+    if (len < 9) { bad_sum.store(1); return; }
+    sha256_digest(raw + off + 8, (size_t)len - 8, hs + 32 * (size_t)(K + i));     // columnar.js:693-705: over the chunk without magic + checksum
+    if (memcmp(hs + 32 * (size_t)(K + i), raw + off + 4, 4) != 0) bad_sum.store(1);
+  };
+  if (nb >= 32 && c->pool->size() >= 2) {
+    const unsigned parts = std::min<unsigned>(c->pool->size() + 1, 16u);
+    c->pool->run(parts, [&](unsigned t) { for (uint32_t i = t; i < nb; i += parts) hash_one(i); });
+  } else {
+    for (uint32_t i = 0; i < nb; i++) hash_one(i);
+  }
+  if (bad_sum.load()) { (void)hipStreamSynchronize(st); return fallback("checksum"); }
+  lap("batch hashed (host)");
+  // the hash index of the applied changes (rebuilt when it does not describe exactly them: after a full replay, a reset, a fallback)
+  if (c->hash_index_n != K || c->hash_index.empty() || c->hash_index.size() < 4 * (size_t)n) {
+    size_t cap = 64;
+    while (cap < 4 * (size_t)n + 64) cap <<= 1;
+    c->hash_index.assign(cap, 0);
+    for (uint32_t i = 0; i < K; i++) hash_index_add(c, i);
+    c->hash_index_n = K;
+  }
+  {
+    hipError_t q;
+    while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
+    if (q != hipSuccess) HIPCHK(c, q);
+  }
+  lap("batch parsed (device)");
+  const ChangeMeta* metas = c->h_res_metas.as<ChangeMeta>();
+
+  // ---- host: the in-order schedule of the batch, on copies (committed only when every change passes) ----
+  const uint32_t NA = (uint32_t)c->actors.size();
+  if (c->res_rank_of.size() != NA) {
+    c->res_rank_of.clear();
+    c->res_rank_of.reserve(2 * NA + 8);
+    for (uint32_t r = 0; r < NA; r++) c->res_rank_of.emplace(c->actors[r], r);
+    c->res_actor_memo.assign(NA, am355_ctx::ActorMemo{});
+  }
+  const std::unordered_map<std::string, uint32_t>& rank_of = c->res_rank_of;
+  std::vector<uint64_t> clock(NA, 0);
+  for (size_t k = 0; k < c->clock_actor.size(); k++) clock[c->clock_actor[k]] = c->clock_seq[k];
+  std::vector<uint32_t> new_clock_actors;
+  // heads as a mark per change index: the document's heads now, minus what the batch depends on, plus the batch
+  std::vector<uint8_t> is_head(n, 0);
+  for (size_t k = 0; k + 32 <= c->heads.size(); k += 32) {
+    const uint32_t hi = hash_index_find(c, &c->heads[k]);
+    if (hi == NONE32) return fallback("a head that is not an applied change");
+    is_head[hi] = 1;
+  }
+  const uint8_t* prev_deps = nullptr;   // the dependency block of the change in front (a round of synced peers shares it): resolved once
+  uint32_t prev_n_deps = 0, prev_first = 0;
+  std::vector<ChangePlan> plans;
+  std::vector<uint32_t> amap, dep_first(1, 0), dep_index, op_base(nb);
+  std::vector<std::vector<ActorSpan>> add_spans(NA);
+  uint64_t ops = old_ops, preds = old_preds, max_op = c->max_op;
+  for (uint32_t i = 0; i < nb; i++) {
+    const ChangeMeta& m = metas[i];
+    const uint32_t ci = K + i;
+    if (m.flags || (m.pad & 1)) return fallback_dirty("a change the parser flags");
+    const uint8_t* p = raw + m.base;
+    if (hash_index_find(c, hs + 32 * (size_t)ci) != NONE32) return fallback_dirty("duplicate change");
+    // dependencies: all applied already (a change of this batch in front of this one counts)
+    const uint8_t* deps = p + m.deps_off;
+    if (prev_deps && prev_n_deps == m.n_deps && m.n_deps && memcmp(prev_deps, deps, 32 * (size_t)m.n_deps) == 0) {
+      for (uint32_t k = 0; k < m.n_deps; k++) dep_index.push_back(dep_index[prev_first + k]);   // (their head marks are already down)
+    } else {
+      for (uint32_t k = 0; k < m.n_deps; k++) {
+        const uint32_t di = hash_index_find(c, deps + 32 * (size_t)k);
+        if (di == NONE32) return fallback_dirty("dependency not applied yet");
+        dep_index.push_back(di);
+        is_head[di] = 0;
+      }
+    }
+    prev_deps = deps; prev_n_deps = m.n_deps; prev_first = dep_first.back();
+    dep_first.push_back((uint32_t)dep_index.size());
+    is_head[ci] = 1;
+    hash_index_add(c, ci);   // (undone by dropping the index on every fallback below)
+    // actor table: author + the others, all known to the document (a new actor changes the ranks of the kept rows: full replay)
+    auto it = rank_of.find(std::string((const char*)p + m.actor_off, m.actor_len));
+    if (it == rank_of.end()) return fallback_dirty("new actor");
+    const uint32_t author = it->second;
+    ChangePlan pl{ci, (uint32_t)ops, (uint32_t)preds, (uint32_t)amap.size(), author, 1 + m.n_other};
+    if (pl.n_actors != m.n_entries) return fallback_dirty("actor table");
+    amap.push_back(author);
+    {
+      // the table of the other actors: the same bytes as in the author's last change -> the same ranks
+      am355_ctx::ActorMemo& memo = c->res_actor_memo[author];
+      size_t off = m.others_off, end = off;
+      for (uint32_t k = 0; k < m.n_other; k++) {
+        uint64_t l;
+        if (!read_uleb_host(p, m.len, end, l) || l > m.len - end) return fallback_dirty("actor table");
+        end += (size_t)l;
+      }
+      const size_t tlen = end - off;
+      if (memo.ranks.size() == m.n_other && memo.bytes.size() == tlen && (tlen == 0 || memcmp(memo.bytes.data(), p + off, tlen) == 0)) {
+        amap.insert(amap.end(), memo.ranks.begin(), memo.ranks.end());
+      } else {
+        std::vector<uint32_t> ranks;
+        ranks.reserve(m.n_other);
+        size_t o = off;
+        for (uint32_t k = 0; k < m.n_other; k++) {
+          uint64_t l;
+          (void)read_uleb_host(p, m.len, o, l);
+          auto jt = rank_of.find(std::string((const char*)p + o, (size_t)l));
+          if (jt == rank_of.end()) return fallback_dirty("new actor");
+          ranks.push_back(jt->second);
+          o += (size_t)l;
+        }
+        amap.insert(amap.end(), ranks.begin(), ranks.end());
+        memo.bytes.assign(p + off, p + end);
+        memo.ranks.swap(ranks);
+      }
+    }
+    if (m.seq != clock[author] + 1) return fallback_dirty("sequence number");
+    if (clock[author] == 0) new_clock_actors.push_back(author);
+    clock[author] = m.seq;
+    op_base[i] = (uint32_t)ops;
+    if (m.n_ops) {
+      // the change's op ids lie behind every id of its author so far (ascending, disjoint spans: what plan_fast verifies)
+      const uint32_t a0 = c->actor_tab_off[author], a1 = c->actor_tab_off[author + 1];
+      uint64_t last_end = a1 > a0 ? (uint64_t)c->spans[a1 - 1].start_op + c->spans[a1 - 1].n_ops : 0;
+      if (!add_spans[author].empty()) last_end = (uint64_t)add_spans[author].back().start_op + add_spans[author].back().n_ops;
+      if (m.start_op < last_end || m.start_op + m.n_ops > 0xfffffff0ull) return fallback_dirty("op id range");
+      add_spans[author].push_back(ActorSpan{(uint32_t)m.start_op, m.n_ops, (uint32_t)ops});
+      max_op = std::max<uint64_t>(max_op, m.start_op + m.n_ops - 1);
+      plans.push_back(pl);
+    }
+    ops += m.n_ops;
+    preds += m.n_preds;
+    if (ops >= 0x7ffffff0ull || preds >= 0xfffffff0ull) return fallback_dirty("size");
+  }
+  const uint32_t N = (uint32_t)ops, P = (uint32_t)preds;
+  if (N > c->cols_cap_ops || P > c->cols_cap_preds) return fallback_dirty("row capacity");
+  const int bits_ctr = bits_for64(max_op), bits_actor = bits_for64(NA ? NA - 1 : 0), bits_row = bits_for64(N);
+  if (1 + bits_row + bits_ctr + bits_actor > 64) return fallback_dirty("sort key width");
+  lap("batch scheduled (host)");
+
+  // ---- commit the host state ----
+  c->hash_index_n = n;
+  for (uint32_t a : new_clock_actors) c->clock_actor.push_back(a);
+  c->clock_seq.clear();
+  for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
+  {
+    std::vector<const uint8_t*> hv;
+    for (uint32_t i = 0; i < n; i++)
+      if (is_head[i]) hv.push_back(hs + 32 * (size_t)i);
+    std::sort(hv.begin(), hv.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
+    std::vector<uint8_t> heads_new(hv.size() * 32);
+    for (size_t k = 0; k < hv.size(); k++) memcpy(&heads_new[32 * k], hv[k], 32);
+    c->heads.swap(heads_new);
+  }
+  {
+    std::vector<ActorSpan> spans;
+    std::vector<uint32_t> tab(NA + 1, 0);
+    spans.reserve(c->spans.size() + plans.size());
+    for (uint32_t a = 0; a < NA; a++) {
+      tab[a] = (uint32_t)spans.size();
+      spans.insert(spans.end(), c->spans.begin() + c->actor_tab_off[a], c->spans.begin() + c->actor_tab_off[a + 1]);
+      spans.insert(spans.end(), add_spans[a].begin(), add_spans[a].end());
+    }
+    tab[NA] = (uint32_t)spans.size();
+    c->spans.swap(spans);
+    c->actor_tab_off.swap(tab);
+  }
+  for (uint32_t i = 0; i < nb; i++) { c->applied_change.push_back(K + i); c->applied_op_base.push_back(op_base[i]); }
+  if (c->res_dep_first.empty()) c->res_dep_first.assign(1, 0);
+  for (uint32_t i = 0; i < nb; i++) {
+    c->res_dep_index.insert(c->res_dep_index.end(), dep_index.begin() + dep_first[i], dep_index.begin() + dep_first[i + 1]);
+    c->res_dep_first.push_back((uint32_t)c->res_dep_index.size());
+  }
+  c->n_applied = n; c->n_pending = 0;
+  c->pending_change.clear();
+  c->pass_first_row.clear();
+  c->n_ops = N; c->n_preds = P; c->max_op = max_op;
+  c->has_unknown_cols = false;
+  c->plans = plans;
+  c->amap = amap;
+
+  // ---- device: tables, the batch's rows, their resolution, then the whole-document order / patch tables ----
+  const size_t np = plans.size();
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_plans = sizeof(ChangePlan) * np, b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size(), b_amap = 4 * amap.size();
+  const size_t o_spans = al(b_plans + 16), o_tab = o_spans + al(b_spans + 16), o_x = o_tab + al(b_tab + 16), tables_bytes = o_x + al(b_amap + 16);
+  if (!c->d_tables.ensure(tables_bytes) || !c->h_stage.ensure(tables_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed");
+  uint8_t* d_tables = c->d_tables.as<uint8_t>();
+  c->p_spans = (ActorSpan*)(d_tables + o_spans);
+  c->p_tab_off = (uint32_t*)(d_tables + o_tab);
+  c->sig_seq++;
+  uint32_t n_small = 0, n_large = 0;
+  {
+    std::vector<ChangePlan> large, serial;
+    size_t w = 0;
+    for (size_t i = 0; i < np; i++) {
+      const int wc = change_wave_class(metas[c->plans[i].change - K]);
+      if (wc == 2) c->plans[w++] = c->plans[i];
+      else if (wc == 1) large.push_back(c->plans[i]);
+      else serial.push_back(c->plans[i]);
+    }
+    n_small = (uint32_t)w;
+    n_large = (uint32_t)large.size();
+    for (auto& pl : large) c->plans[w++] = pl;
+    for (auto& pl : serial) c->plans[w++] = pl;
+  }
+  {
+    uint8_t* h = c->h_stage.as<uint8_t>();
+    if (b_plans) memcpy(h, c->plans.data(), b_plans);
+    if (b_spans) memcpy(h + o_spans, c->spans.data(), b_spans);
+    memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
+    if (b_amap) memcpy(h + o_x, amap.data(), b_amap);
+    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_x + b_amap, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_hashes.as<uint8_t>() + 32 * (size_t)K, hs + 32 * (size_t)K, 32 * (size_t)nb, hipMemcpyHostToDevice, st));
+  MergeBufs& b = c->mb;
+  b.arena = c->d_arena.as<uint8_t>();
+  b.ops = c->cols;
+  b.n_ops = N; b.n_preds = P; b.n_actors = NA;
+  b.sig = c->h_sig.as<HostSignals>(); b.sig_seq = c->sig_seq;
+  b.actor_tab_off = c->p_tab_off; b.spans = c->p_spans;
+  b.bits_ctr = (uint32_t)bits_ctr; b.bits_actor = (uint32_t)bits_actor;
+  b.first_row = (uint32_t)old_ops; b.seed_list_inc = c->seed_list_inc; b.row_stride = c->cols_cap_ops + 1;
+  if (!c->d_counts.ensure(merge_counts_bytes(N))) return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
+  merge_bind_counts(b, c->d_counts.p);
+  c->resident_valid = false;   // (from here on the kept arrays change: a failure leaves no state behind)
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, b.counts_bytes, st));
+  merge_prepare(b, st);   // (one fill launch; in this stream: the decode of a small batch is too short to hide a second stream's join)
+  HIPCHK(c, hipEventRecord(c->ev_fork, st));
+  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, (uint32_t)np - n_small - n_large,
+                        (const uint32_t*)(d_tables + o_x), nullptr, c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3, 0, 1);
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+  HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+  lap("decode enqueued");
+  Counts* hc = c->h_counts.as<Counts>();
+  merge_run(b, c->ir, hc, st, nullptr, c->ev_runs);
+  HIPCHK(c, hipEventRecord(c->ev[5], st));
+  lap("merge_run done");
+  if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
+  c->counts = *hc;
+  c->counts.n_objects += 1;  // + _root
+  c->n_resident_calls++;
+  return AM355_OK;
+}
+
 int replay_impl(am355_ctx* c) {
   if (!c) return AM355_E_ARG;
   if (!c->staged) return fail(c, AM355_E_STATE, "am355_load_changes must be called first");
@@ -978,6 +1315,32 @@ int replay_impl(am355_ctx* c) {
   c->spec_launched = false;
   if (c->is_document) return replay_document(c);
   auto t_begin = std::chrono::steady_clock::now();
+  if (c->in_apply && c->keep.want) {
+    // Backend.applyChanges onto the state this context holds: the batch alone (replay_resident), unless it needs the general path
+    c->keep.want = false;
+    const int rr = replay_resident(c);
+    if (rr != RESIDENT_FALLBACK) {
+      if (rr != AM355_OK) return rr;
+      am355_stats& s = c->stats;
+      s.n_changes = c->n_changes; s.n_applied = c->n_applied; s.n_pending = 0; s.n_actors = (uint32_t)c->actors.size(); s.n_objects = c->counts.n_objects;
+      s.n_heads = (uint32_t)(c->heads.size() / 32); s.n_ops = c->n_ops; s.max_op = c->max_op; s.raw_bytes = c->raw.size();
+      s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
+      s.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
+                   ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit);
+      while (hipEventQuery(c->ev[5]) == hipErrorNotReady) {}
+      s.ms_parse = s.ms_decode = s.ms_merge = s.ms_order = s.ms_hash_stream = s.ms_host_schedule = 0;
+      s.fast_path = 1;
+      s.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+      c->used_fast_path = true;
+      c->device_scheduled = false;
+      c->replayed = true;
+      c->seed_list_inc = c->counts.n_list_inc;
+      resident_mark(c);
+      c->resident_valid = true;
+      return AM355_OK;
+    }
+  }
+  c->keep.want = false;
   const bool trace = getenv("AM355_TRACE") != nullptr;
   auto lap = [&](const char* what) {
     if (trace) fprintf(stderr, "replay: %-28s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
@@ -1342,6 +1705,16 @@ int replay_impl(am355_ctx* c) {
   s.fast_path = fast ? 1 : (c->device_scheduled ? 2 : 0);
   s.ms_total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
   c->replayed = true;
+  // what a later am355_apply_changes may keep (replay_resident): every staged change applied, in staged order, rows carved for a capacity
+  c->seed_list_inc = c->counts.n_list_inc;
+  c->res_dep_base = n;
+  c->res_dep_first.clear();
+  c->res_dep_index.clear();
+  c->hash_index_n = 0;
+  c->res_rank_of.clear();
+  c->res_actor_memo.clear();
+  c->resident_valid = fast && c->in_apply && c->shard_world == 1 && c->mb.row_stride != 0 && !c->has_unknown_cols;
+  if (c->resident_valid) resident_mark(c);
   if (!c->in_apply) {  // (one call of Backend.loadChanges: its scheduling passes are the op streams)
     c->stream_breaks = c->pass_first_row;
     c->breaks_exact = true;

@@ -30,6 +30,7 @@ int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offset
   const size_t b0 = keep_staged ? c->raw.size() : 0;
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
   c->staged = c->replayed = c->ir_fetched = false;
+  if (!keep_staged) c->resident_valid = false;
   c->apply_ready = false;
   c->state_checked = false;
   c->is_document = false;
@@ -124,7 +125,8 @@ int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offset
   c->raw_off[n_all] = b0 + total;
   c->n_changes = n_all;
   if (!(keep_staged ? c->d_arena.ensure_keep(b0 + total + 64, b0) : c->d_arena.ensure(total + 64)) || !c->d_offsets.ensure(sizeof(uint64_t) * ((size_t)n_all + 1)) ||
-      !c->d_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n_all, 1u)) || !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n_all, 1u)) ||
+      !(keep_staged ? c->d_metas.ensure_keep(sizeof(ChangeMeta) * (size_t)std::max(n_all, 1u), sizeof(ChangeMeta) * (size_t)k0)
+                    : c->d_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n_all, 1u))) || !c->h_metas.ensure(sizeof(ChangeMeta) * (size_t)std::max(n_all, 1u)) ||
       !c->d_counts.ensure(sizeof(Counts)) || !c->h_counts.ensure(2 * sizeof(Counts)) || !c->h_offsets.ensure(sizeof(uint64_t) * ((size_t)n_all + 1)))
     return fail(c, AM355_E_NOMEM, "device allocation failed");
   // (from here on `raw`, `d_raw` and `roff` address the batch's part: byte b0 of the arena, entry k0 of the offsets)
@@ -296,6 +298,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
   if (!c || !doc) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
   (void)c->doc_sum.wait();  // (the checksum thread of an earlier document reads doc_bytes)
+  c->resident_valid = false;
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }
   c->doc_graph_known = false;
   c->staged = c->replayed = c->ir_fetched = false;

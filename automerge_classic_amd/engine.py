@@ -94,6 +94,8 @@ def _bind(path):
     L.am355_shard_finalize.argtypes = [vp]
     for f in ("am355_shard_unique_id", "am355_shard_init", "am355_sharded_replay", "am355_shard_fragment_bytes", "am355_shard_finalize"):
         getattr(L, f).restype = ctypes.c_int
+    L.am355_resident_counters.argtypes = [vp, vp]
+    L.am355_resident_counters.restype = ctypes.c_int
     L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
     L.am355_doc_changes.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_void_p)]
     L.am355_apply_changes.argtypes = [vp, vp, u64p, u32]
@@ -326,6 +328,12 @@ class Engine:
 
     def shard_finalize(self):
         self._check(self._L.am355_shard_finalize(self._h))
+
+    def resident_counters(self):
+        """(calls of apply_changes that merged the batch alone into the resident state, calls that asked for it and took the full replay)."""
+        out = (ctypes.c_uint64 * 2)()
+        self._check(self._L.am355_resident_counters(self._h, out))
+        return int(out[0]), int(out[1])
 
     def raw(self):
         """(arena, offsets) as staged: the uncompressed change containers back to back (copies)."""

@@ -236,6 +236,63 @@ def test_partition_variants_agree_emulated(emu_lib, monkeypatch):
     assert texts[0] == texts[1] == texts[2]
 
 
+def _one_by_one(log, head):
+    """`head` changes as the first batch, then every following change as a batch of its own."""
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    changes = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    return [changes[:head]] + [[c] for c in changes[head:]]
+
+
+def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
+    """Backend.applyChanges change by change onto the state the context holds (am355_replay.hip replay_resident: only the batch is
+    parsed, hashed, scheduled, decoded and resolved): every incremental patch and the final getPatch equal the oracle session's, the
+    resident path really served the calls, and a batch it cannot take -- a new actor, a dependency that is not applied yet -- goes
+    through the full replay with the same result. Text with deletions, two list objects, and a map with conflicts."""
+    cases = [
+        (loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=5, n_rounds=6, ins_per_change=14, del_per_change=5, n_objects=2, seed=61), 5),
+        (loggen.generate(loggen.KIND_MAP_LWW, n_actors=4, n_rounds=5, n_keys=40, seed=62), 4),
+        (loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=400, ops_per_change=10, seed=63), 3),
+    ]
+    for log, head in cases:
+        batches = _one_by_one(log, head)
+        eng = engine.Engine(0, emu_lib)
+        try:
+            check_against_oracle_session(eng, batches)
+            served, fell_back = eng.resident_counters()
+            assert served >= len(batches) - 3 and fell_back <= 1, (served, fell_back, len(batches))
+        finally:
+            eng.close()
+    # the same calls with the resident path switched off give the same document
+    log, head = cases[0]
+    monkeypatch.setenv("AM355_NO_RESIDENT", "1")
+    eng = engine.Engine(0, emu_lib)
+    try:
+        check_against_oracle_session(eng, _one_by_one(log, head))
+        assert eng.resident_counters() == (0, 0)
+    finally:
+        eng.close()
+    monkeypatch.delenv("AM355_NO_RESIDENT")
+    # new actors arrive one by one (the ranks of the kept rows change: full replay each time), then steady state again
+    late = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=3, ins_per_change=9, del_per_change=3, n_objects=1, seed=64)
+    eng = engine.Engine(0, emu_lib)
+    try:
+        check_against_oracle_session(eng, _one_by_one(late, 1))
+        served, fell_back = eng.resident_counters()
+        assert fell_back >= 4 and served >= 8, (served, fell_back)
+    finally:
+        eng.close()
+    # a change delivered before its dependency: queued by the full path, applied by a later call; the calls after that are resident again
+    arena, offs = bytes(late.arena), [int(x) for x in late.offsets]
+    ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    batches = [ch[:8], [ch[9]], [ch[8]], [ch[10]], [ch[11]]] + [[c] for c in ch[12:]]
+    eng = engine.Engine(0, emu_lib)
+    try:
+        check_against_oracle_session(eng, batches)
+        assert eng.resident_counters()[0] >= len(ch) - 14
+    finally:
+        eng.close()
+
+
 def test_batches_behind_the_staged_changes_or_restaged_emulated(emu_lib, monkeypatch):
     """A batch onto a state whose changes are all applied is staged behind them (only the batch is copied); AM355_APPLY_RESTAGE=1
     rebuilds the whole queue instead, as a call with queued changes does. Same patches either way, deflated batches included."""
@@ -497,6 +554,36 @@ def test_bench_workloads_in_batches_match_the_oracle_gpu(name, scale, n_batches)
     eng = engine.Engine(0)
     try:
         check_against_oracle_session(eng, split_log(log, n_batches))
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_resident_state_200_small_batches_gpu():
+    """200 small batches (1-3 changes) onto a 100 k-op Text document of 64 actors, interleaved with getPatch calls:
+    every incremental patch AND the whole-document patch after every 25th batch equal the oracle session's; the resident path served
+    them (am355_replay.hip replay_resident)."""
+    log = loggen.config("c4_text_single", 0.125)
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    head = len(ch) - 400
+    batches, k, size = [ch[:head]], head, 1
+    while len(batches) < 201:
+        batches.append(ch[k:k + size])
+        k += size
+        size = size % 3 + 1
+    eng = engine.Engine(0)
+    session = oracle_lib.OracleSession()
+    try:
+        for i, batch in enumerate(batches):
+            want = session.apply(batch)
+            eng.apply_changes(ChangeLog.from_changes(batch))
+            assert same_patch(eng.apply_patch_json(), want), f"batch {i}"
+            if i % 25 == 0:
+                assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"getPatch after batch {i}"
+        assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"]
+        served, fell_back = eng.resident_counters()
+        assert served >= 195 and fell_back <= 2, (served, fell_back)
     finally:
         eng.close()
 
