@@ -496,9 +496,10 @@ static int plan_fast(am355_ctx* c, std::vector<uint32_t>& slot_rank, const uint3
 }
 
 // The op rows (13 word columns + the insert byte) and the flattened pred lists, for N rows / P preds.
-static int carve_cols(am355_ctx* c, uint32_t N, uint32_t P) {
+static int carve_cols(am355_ctx* c, uint32_t N, uint32_t P, bool estimate = false) {
   canary_scope("replay buffers (carve_cols: op rows, preds)");
-  if (c->in_apply) {
+  static const bool no_cap = getenv("AM355_NO_ROW_CAP") != nullptr;   // (A/B: rows carved exactly, as in rounds 1-5; no resident state then)
+  if (c->in_apply && !no_cap && !estimate) {   // (estimate: N, P are the speculative launch's upper estimate already, several times the rows)
     // am355_apply_changes: room for the document to grow without the rows moving (replay_resident appends to them)
     N = (uint32_t)std::min<uint64_t>((uint64_t)N + N / 4 + 65536, 0x7ffffff0u);
     P = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 4 + 65536, 0xfffffff0u);
@@ -541,8 +542,10 @@ int setup_buffers(am355_ctx* c, uint32_t NA) {
   canary_scope("replay buffers (setup_buffers: merge scratch, sort scratch, patch IR)");
   // am355_apply_changes: the per-row arrays of the merge stage are carved with the stride of the op rows' capacity, so that the kept
   // rows' results stay where they are from call to call (replay_resident); their fills go by N (merge_prepare)
-  const bool by_cap = c->in_apply && c->cols_cap_ops >= N;
-  if (by_cap) Nc = (size_t)c->cols_cap_ops + 1;
+  static const bool no_cap = getenv("AM355_NO_ROW_CAP") != nullptr;
+  const bool by_cap = c->in_apply && c->cols_cap_ops >= N && !no_cap;
+  // (the op rows of a speculative launch are carved for several times N; the merge arrays take a quarter more than N: ~1.3 x the exact size)
+  if (by_cap) Nc = std::min<size_t>(c->cols_cap_ops, (size_t)N + N / 4 + 65536) + 1;
   {
     size_t cw = carry_words((uint32_t)(Nc - 1));
     size_t bytes = 10 * carve_size(Nc, 4) + 3 * carve_size(Nc, 8) + carve_size(Nc, 1) + carve_size(2 * Nc + 2, 4) + 4 * carve_size(2 * Nc + 2, 4) +
@@ -564,7 +567,8 @@ int setup_buffers(am355_ctx* c, uint32_t NA) {
     b.actor_tab_off = c->p_tab_off;
     b.spans = c->p_spans;
     b.bits_ctr = (uint32_t)bits_ctr; b.bits_actor = (uint32_t)bits_actor;
-    b.first_row = 0; b.seed_list_inc = 0; b.row_stride = by_cap ? (uint32_t)Nc : 0u;
+    static const bool fill_kernel = getenv("AM355_FILL_KERNEL") != nullptr;   // (A/B: the fused fill launch with exactly carved rows too)
+    b.first_row = 0; b.seed_list_inc = 0; b.row_stride = (by_cap || fill_kernel) ? (uint32_t)Nc : 0u;
     b.zero_base = p;
     b.succ_cnt = carve<uint32_t>(p, Nc); b.inc_cnt = carve<uint32_t>(p, Nc); b.val_cnt = carve<uint32_t>(p, Nc);
     b.inc_sum = carve<unsigned long long>(p, Nc); b.last_inc = carve<unsigned long long>(p, Nc);
@@ -1193,7 +1197,7 @@ static int replay_resident(am355_ctx* c) {
     if (ops >= 0x7ffffff0ull || preds >= 0xfffffff0ull) return fallback_dirty("size");
   }
   const uint32_t N = (uint32_t)ops, P = (uint32_t)preds;
-  if (N > c->cols_cap_ops || P > c->cols_cap_preds) return fallback_dirty("row capacity");
+  if (N > c->cols_cap_ops || P > c->cols_cap_preds || (size_t)N + 1 > c->mb.row_stride) return fallback_dirty("row capacity");
   const int bits_ctr = bits_for64(max_op), bits_actor = bits_for64(NA ? NA - 1 : 0), bits_row = bits_for64(N);
   if (1 + bits_row + bits_ctr + bits_actor > 64) return fallback_dirty("sort key width");
   lap("batch scheduled (host)");
@@ -1280,7 +1284,7 @@ static int replay_resident(am355_ctx* c) {
   b.sig = c->h_sig.as<HostSignals>(); b.sig_seq = c->sig_seq;
   b.actor_tab_off = c->p_tab_off; b.spans = c->p_spans;
   b.bits_ctr = (uint32_t)bits_ctr; b.bits_actor = (uint32_t)bits_actor;
-  b.first_row = (uint32_t)old_ops; b.seed_list_inc = c->seed_list_inc; b.row_stride = c->cols_cap_ops + 1;
+  b.first_row = (uint32_t)old_ops; b.seed_list_inc = c->seed_list_inc;   // (b.row_stride: as the last full replay carved the arrays)
   if (!c->d_counts.ensure(merge_counts_bytes(N))) return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
   merge_bind_counts(b, c->d_counts.p);
   c->resident_valid = false;   // (from here on the kept arrays change: a failure leaves no state behind)
@@ -1486,7 +1490,7 @@ int replay_impl(am355_ctx* c) {
       c->spec_cap_preds = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->hint_preds, est), 0x7ffffff0u);
       // (the merge stage's counter block, cleared by the parse kernel above, must not move when the real totals arrive)
       if (trace) fprintf(stderr, "replay: speculative decode: cap %u ops / %u preds (counter block %zu of %zu bytes)\n", c->spec_cap_ops, c->spec_cap_preds, merge_counts_bytes(c->spec_cap_ops), cb);
-      if (merge_counts_bytes(c->spec_cap_ops) <= cb && carve_cols(c, c->spec_cap_ops, c->spec_cap_preds) == AM355_OK) {
+      if (merge_counts_bytes(c->spec_cap_ops) <= cb && carve_cols(c, c->spec_cap_ops, c->spec_cap_preds, true) == AM355_OK) {
         canary_arm();
         if (c->phase_events) { HIPCHK(c, hipEventRecord(c->ev[1], sa)); HIPCHK(c, hipEventRecord(c->ev[2], sa)); }
         if (want_large_spec) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_plan, 0));

@@ -94,8 +94,9 @@ def _bind(path):
     L.am355_shard_finalize.argtypes = [vp]
     for f in ("am355_shard_unique_id", "am355_shard_init", "am355_sharded_replay", "am355_shard_fragment_bytes", "am355_shard_finalize"):
         getattr(L, f).restype = ctypes.c_int
-    L.am355_resident_counters.argtypes = [vp, vp]
-    L.am355_resident_counters.restype = ctypes.c_int
+    if hasattr(L, "am355_resident_counters"):   # (tools/ab_apply.sh loads libraries of earlier commits; tests/test_abi.py holds the shipped one to the header)
+        L.am355_resident_counters.argtypes = [vp, vp]
+        L.am355_resident_counters.restype = ctypes.c_int
     L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
     L.am355_doc_changes.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_void_p)]
     L.am355_apply_changes.argtypes = [vp, vp, u64p, u32]
