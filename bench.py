@@ -109,7 +109,7 @@ def cpu_baseline(log, budget_s=12.0):
                       f"({time.perf_counter() - t_all:.1f} s of CPU work)"}
 
 
-def reference_js_baseline(name, scale_full, seed):
+def reference_js_baseline(name, scale_full, seed, timeout_s=240):
     """The UNMODIFIED reference JS backend (north_star: "next to the reference JS backend timed on the box's own host cores in the same
     run"): `Backend.loadChanges(Backend.init(), changes)` + `Backend.getPatch` under node, 1 core, on a BOUNDED sample of the same
     workload (the reference replays ~25-30 k ops/s: the full 1 M-op log would take ~40 s per run) -- oracle/js/ref_patch.js --time.
@@ -132,7 +132,7 @@ def reference_js_baseline(name, scale_full, seed):
             path = os.path.join(tmp, "log.bin")
             log.save(path)
             out = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "ref_patch.js"), path, "--time", "3", "--out", os.path.join(tmp, "patch.json")],
-                                 env=env, capture_output=True, text=True, timeout=240)
+                                 env=env, capture_output=True, text=True, timeout=timeout_s)
         line = [l for l in out.stderr.splitlines() if l.startswith("reference median of")]
         if out.returncode != 0 or not line:
             return None
@@ -420,7 +420,7 @@ def apply_changes_section(eng, log, sync, reps=7):
     changes = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
     n = len(changes)
     rows = []
-    for k in (n, max(1, n // 10), max(1, n // 100)):
+    for k in sorted({n, max(1, n // 10), max(1, n // 100), 1}, reverse=True):   # (the last one: a single change, the resident path of am355_apply_changes)
         base = ChangeLog.from_changes(changes[:n - k]) if n > k else None
         batch = ChangeLog.from_changes(changes[n - k:])
         best, ops_before = None, 0

@@ -57,7 +57,7 @@ def main():
     for name in ("c4_text_single", "c4_text_multi", "c3_map_lww", "c2_text_typing"):
         t0 = time.time()
         # (the reference replays the map workload at ~1.5 k ops/s: a fifth of it is 16 k ops, ~10 s per run)
-        r = bench.reference_js_baseline(name, 0.2 if name == "c3_map_lww" else 1.0, bench.BASE_SEED[name])
+        r = bench.reference_js_baseline(name, 0.2 if name == "c3_map_lww" else 1.0, bench.BASE_SEED[name], timeout_s=1200)
         if r is None:
             raise SystemExit(f"{name}: node or the reference tree is missing, or the run exceeded its limit")
         out["workloads"][name] = {"ops_per_s": r["value"], "cores": 1, "sample": r["sample"]}
