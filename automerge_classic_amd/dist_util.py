@@ -1,4 +1,4 @@
-"""Multi-GPU helpers for bench.py: one process per GPU, replicas only (DESIGN.md §8).
+"""Multi-GPU helpers for bench.py: one process per GPU, replicas only (DESIGN.md §9).
 
 The headline document is a single Text object, which objectId sharding cannot split, so under torch.distributed
 every rank replays its own document of the same shape; there is no data-path collective. The only communication

@@ -1,6 +1,6 @@
 // End-to-end timing through the JS host (node -> N-API addon -> GPU): SURVEY.md §8d "T_replay" (change Uint8Arrays in host
 // memory -> patch IR in host memory) and "T_e2e" (through the materialised JS patch object, materialize.js). For comparison
-// the older route through JSON text (engine renders JSON, JSON.parse builds the object) is timed too. Reported in DESIGN.md §7.
+// the older route through JSON text (engine renders JSON, JSON.parse builds the object) is timed too. Reported in DESIGN.md §8.
 //
 //   python -c "from automerge_classic_amd import loggen; loggen.config('c4_text_single', 1.0, False).save('/tmp/c4.bin')"
 //   node automerge_classic_amd/js/bench_e2e.js /tmp/c4.bin [reps]

@@ -513,7 +513,7 @@ def sharded_measurement(eng, rank, world, dist, device, steps, warmup, barrier, 
 
 
 def sharding_model(sub, n_list=(1, 2, 4, 8)):
-    """Critical-path model of the objectId-sharded replay of ONE change log over N GPUs (SURVEY.md §8e; DESIGN.md §8), from the phases
+    """Critical-path model of the objectId-sharded replay of ONE change log over N GPUs (SURVEY.md §8e; DESIGN.md §9), from the phases
     measured in THIS run on one GPU -- printed so that the first real multi-GPU run has something to be checked against (no 8-GPU node
     has been available to the driver so far). What the design replicates on every rank and what it divides:
       replicated  host staging + H2D of the whole batch (every rank has its own PCIe link), stage 1 (parse, actor tables, plan), the hash

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE. Demonstrates, in-tree, the stock reference's block-boundary defect (DESIGN.md §6) and pins the
+"""TEST INFRASTRUCTURE. Demonstrates, in-tree, the stock reference's block-boundary defect (DESIGN.md §7) and pins the
 engine/oracle answer on inputs where it fires.
 
 The stock reference (backend/new.js, MAX_BLOCK_SIZE = 600) mis-places a concurrent list insertion when the skip scan over

@@ -72,7 +72,7 @@ def same_patch(got_text, want_text):
     return all(dict(got[k]) == dict(want[k]) if k == "clock" else got[k] == want[k] for k in got)
 
 
-# the one case left to the JS path (a counter whose increments have all been deleted: DESIGN.md §5); `link` ops are columns the
+# the one case left to the JS path (a counter whose increments have all been deleted: DESIGN.md §6); `link` ops are columns the
 # engine's save() / history do not model (patches are served)
 LIST_QUIRK_REFUSED = {"hand_increment_deleted"}
 LIST_QUIRK_NO_SAVE = {"hand_link_on_element", "hand_link_inserted"}

@@ -62,7 +62,7 @@ def test_headline_shape_at_125k_ops_equals_the_patched_reference(eng):
 
 
 def test_defect_fixture_both_delivery_orders(eng):
-    """Inputs on which the stock reference diverges with delivery order (DESIGN.md §6): the engine gives the block-size-patched
+    """Inputs on which the stock reference diverges with delivery order (DESIGN.md §7): the engine gives the block-size-patched
     reference's document for both orders."""
     fx = golden_util.defect_fixture()
     assert emu_patch(eng, fx["log"]) == fx["patch_bigblock"] != fx["patch"]
@@ -311,7 +311,7 @@ def test_device_primitives(eng):
     # three-launch scan (more than 1024 tiles: k_scan_sums between the tile sums and the apply kernel), aligned and unaligned length
     for n in (2_200_003, 2_300_000):
         vals = rng.integers(0, 3, n, dtype=np.uint32)
-        for lookback in ("0", "1"):   # (1: the single-pass form with decoupled look-back, off by default -- measured slower, DESIGN.md §7 round 5)
+        for lookback in ("0", "1"):   # (1: the single-pass form with decoupled look-back, off by default -- measured slower, DESIGN.md §8 round 5)
             os.environ["AM355_SCAN_LOOKBACK"] = lookback
             try:
                 out, total = eng.test_scan(vals)

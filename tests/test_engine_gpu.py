@@ -57,7 +57,7 @@ def test_counters_and_valueless_rows_inside_lists(eng):
 
 def test_defect_fixture_both_delivery_orders(eng):
     """Inputs on which the STOCK reference's block-boundary defect fires (its two patches for the two delivery orders differ
-    from each other; DESIGN.md §6): the engine gives the block-size-patched reference's document for both orders, also on the
+    from each other; DESIGN.md §7): the engine gives the block-size-patched reference's document for both orders, also on the
     12,801-op slice of the headline workload (reference digests committed by oracle/make_defect_fixture.py)."""
     fx = golden_util.defect_fixture()
     assert json.loads(fx["patch"])["diffs"] != json.loads(fx["patch_reversed"])["diffs"]

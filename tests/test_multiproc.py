@@ -1,4 +1,4 @@
-"""N>1 path of bench.py on CPU: world_size 2 over gloo. Replicas only (DESIGN.md §8): each rank replays its own
+"""N>1 path of bench.py on CPU: world_size 2 over gloo. Replicas only (DESIGN.md §9): each rank replays its own
 document (here through the CPU emulation build of the kernels) and the ranks only exchange the timing contract."""
 import os
 import subprocess

@@ -26,7 +26,7 @@ EMU_DIR = os.path.join(HERE, "emu")
 
 # vector ids (position in the file) the engine must not serve, and why
 REJECTED_BY_REFERENCE = {14: "BAD_PRED", 16: "BAD_PRED", 25: "BAD_ELEM", 33: "BAD_ELEM"}   # the reference throws on these batches too
-LEFT_TO_JS_PATH = {}   # (rounds 1-4: 56 and 911 -- a counter inside a list; served since round 5, DESIGN.md §5)
+LEFT_TO_JS_PATH = {}   # (rounds 1-4: 56 and 911 -- a counter inside a list; served since round 5, DESIGN.md §6)
 SAVE_LEFT_TO_JS_PATH = {82}                                 # replay served, save() refused: a change carries columns the engine does not model
 
 
@@ -83,7 +83,7 @@ def _run_engine(eng, vectors):
             eng.replay()
             got = eng.patch_json()
         except engine.EngineError as e:
-            refused[i] = (type(e).__name__, e.flag_names)   # reference rejects it too, or legal input left to the JS path (DESIGN.md §5)
+            refused[i] = (type(e).__name__, e.flag_names)   # reference rejects it too, or legal input left to the JS path (DESIGN.md §6)
             continue
         assert v["kind"] != "reject", f"vector {i}: the engine accepted a batch the reference rejects ({v['error']})"
         assert _same_patch(got, v["patch"]), f"vector {i} ({v['kind']}, {len(blobs)} blobs): patch differs from the reference"
