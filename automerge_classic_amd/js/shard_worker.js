@@ -38,25 +38,36 @@ process.on('message', msg => {
       addon.shardInit(ctx, new Uint8Array(Buffer.from(msg.id, 'hex')), rank, world)
       process.send({ type: 'ready' })
     } else if (msg.type === 'replay') {
+      // (msg.reps > 1, bench_sharded.js: the engine part -- stage, sharded replay, record tables to the host -- repeated on the batch
+      // read once; the times of the last repetition are reported)
+      const input = msg.kind === 'document' ? new Uint8Array(fs.readFileSync(msg.file)) : readChanges(msg.file)
+      const reps = msg.reps > 1 ? msg.reps : 1
+      let error = null, patch, ir, times = null
       const t0 = process.hrtime.bigint()
-      let staged = true
-      try {
-        if (msg.kind === 'document') addon.loadDocument(ctx, new Uint8Array(fs.readFileSync(msg.file)))
-        else addon.loadChanges(ctx, readChanges(msg.file))
-      } catch (e) {
-        staged = false   // (the collective is entered all the same: the library tells the other ranks that this one failed)
-        addon.reset(ctx)
+      for (let r = 0; r < reps && !error; r++) {
+        const a = process.hrtime.bigint()
+        let staged = true
+        try {
+          if (msg.kind === 'document') addon.loadDocument(ctx, input)
+          else addon.loadChanges(ctx, input)
+        } catch (e) {
+          staged = false   // (the collective is entered all the same: the library tells the other ranks that this one failed)
+          addon.reset(ctx)
+        }
+        const b = process.hrtime.bigint()
+        try {
+          addon.shardedReplay(ctx, false)
+          const c = process.hrtime.bigint()
+          if (!staged) error = 'staging failed'
+          else if (rank === 0) ir = addon.fetchIR(ctx)
+          times = { stage: Number(b - a) / 1e6, replay: Number(c - b) / 1e6, fetch: Number(process.hrtime.bigint() - c) / 1e6 }
+        } catch (e) {
+          error = String(e.message || e)
+        }
       }
-      let error = null, patch
-      try {
-        addon.shardedReplay(ctx, false)
-        if (!staged) error = 'staging failed'
-        else if (rank === 0) patch = JSON.stringify(materialize(addon.fetchIR(ctx)))
-      } catch (e) {
-        error = String(e.message || e)
-      }
+      if (!error && rank === 0) patch = JSON.stringify(materialize(ir))
       const ms = Number(process.hrtime.bigint() - t0) / 1e6
-      process.send({ type: 'done', rank, error, patch, ms, fragmentBytes: rank === 0 && !error ? addon.shardFragmentBytes(ctx, world) : undefined })
+      process.send({ type: 'done', rank, error, patch, ms, times, fragmentBytes: rank === 0 && !error ? addon.shardFragmentBytes(ctx, world) : undefined })
     } else if (msg.type === 'close') {
       try { addon.shardFinalize(ctx) } catch (e) { /* the communicator goes with the process */ }
       addon.destroy(ctx)

@@ -54,13 +54,13 @@ class Pool {
     })))
   }
 
-  async _replay(kind, write) {
+  async _replay(kind, write, reps) {
     if (this.busy) throw new Error('one sharded replay at a time per pool')
     this.busy = true
     const file = path.join(this.dir, `batch${this.seq++}.bin`)
     try {
       write(file)
-      const done = await this._round({ type: 'replay', file, kind }, 'done')
+      const done = await this._round({ type: 'replay', file, kind, reps }, 'done')
       const failed = done.filter(d => d.error)
       if (failed.length) {
         const e = new RangeError(`sharded replay rejected: ${failed.map(d => `rank ${d.rank}: ${d.error}`).join('; ')}`)
@@ -68,7 +68,7 @@ class Pool {
         throw e
       }
       const r0 = done.find(d => d.rank === 0)
-      this.last = { ms: done.map(d => d.ms), fragmentBytes: r0.fragmentBytes }
+      this.last = { ms: done.map(d => d.ms), times: done.map(d => d.times), fragmentBytes: r0.fragmentBytes }
       return JSON.parse(r0.patch)
     } finally {
       this.busy = false
@@ -76,8 +76,8 @@ class Pool {
     }
   }
 
-  getPatchOfChanges(changes) { return this._replay('changes', file => writeLog(file, changes)) }
-  getPatchOfDocument(bytes) { return this._replay('document', file => fs.writeFileSync(file, bytes)) }
+  getPatchOfChanges(changes, reps) { return this._replay('changes', file => writeLog(file, changes), reps) }
+  getPatchOfDocument(bytes, reps) { return this._replay('document', file => fs.writeFileSync(file, bytes), reps) }
 
   async close() {
     for (const w of this.workers) { try { w.send({ type: 'close' }) } catch (e) { /* gone */ } }

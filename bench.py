@@ -248,6 +248,59 @@ def js_end_to_end(log):
             "timed_region": "change Uint8Arrays in node -> addon.loadChanges -> addon.replay -> addon.fetchIR -> materialize.js (the JS patch object); median of 7"}
 
 
+def sharded_js(name, scale, gpus, want_sha=None, reps=5, timeout_s=150):
+    """ONE document over `gpus` GPUs from the JS host (north_star: host code stays JavaScript): node -> js/sharded.js -> one worker
+    process per GPU -> am355_shard_init / am355_sharded_replay (RCCL inside libam355.so: ncclAllGather of the patch-IR fragments) ->
+    stitched record tables on rank 0 -> materialize.js. js/bench_sharded.js reports the engine part of a step (max over the workers
+    of stage + sharded replay, + rank 0's fetch) and the sha256 of the patch text; with gpus > 1 the same batch also runs through a
+    pool of ONE worker, for the ratio. In processes of its own under a hard limit: whatever happens there cannot cost the bench line.
+    None when node or the addon is missing."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    js = os.path.join(ROOT, "automerge_classic_amd", "js")
+    if node is None or not os.path.exists(os.path.join(js, "am355_napi.node")):
+        return None
+    log = make_log(name, scale, BASE_SEED[name])
+
+    def one(path, g):
+        p = subprocess.Popen([node, os.path.join(js, "bench_sharded.js"), path, str(g), str(reps)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)   # (the pool's workers are in the group: none is left holding a GPU)
+            p.communicate()
+            return {"error": f"no answer within {timeout_s} s"}
+        if p.returncode != 0:
+            return {"error": (err or out)[-300:]}
+        return json.loads(out.strip().splitlines()[-1])
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "log.bin")
+            log.save(path)
+            r = one(path, gpus)
+            r1 = one(path, 1) if gpus > 1 and "error" not in r else None
+    except Exception as e:   # (an extra: it must not cost the bench line)
+        return {"error": str(e)[:300]}
+    if "error" in r:
+        return {"n_gpus": gpus, "error": r["error"]}
+    out = {"workload": f"{name} x{scale}: {log.n_ops} ops, {log.n_changes} changes, ONE document over {gpus} GPU(s) by objectId; node -> js/sharded.js -> worker process per GPU -> am355_sharded_replay (RCCL in the library)",
+           "n_gpus": gpus, "engine_ms_per_step": r["engine_ms_per_step"], "ops_per_s": r["ops_per_s"], "per_rank_ms": r["per_rank_ms"], "fragment_bytes": r.get("fragment_bytes"),
+           "timed_region": f"per worker: am355_load_changes + am355_sharded_replay, max over the workers, + rank 0's am355_fetch_ir; last of {reps} repetitions"}
+    same = []
+    if want_sha is not None:
+        same.append(r["patch_sha256"] == want_sha)
+    if r1 is not None and "error" not in r1:
+        out["single_worker_ms_per_step"] = r1["engine_ms_per_step"]
+        out["speedup_vs_single_worker"] = r1["engine_ms_per_step"] / r["engine_ms_per_step"]
+        same.append(r["patch_sha256"] == r1["patch_sha256"])
+    out["parity"] = ("patch text sha256 == the unsharded engine's" if all(same) else "MISMATCH") if same else "not compared"
+    return out
+
+
 def cpu_baseline_document(doc_bytes, n_rows, budget_s=12.0):
     """The CPU oracle's Backend.load + getPatch on the same saved document (1 thread)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -677,6 +730,15 @@ def run(args, eng, rank, world, dist, device, barrier, sync):
         out["sharded"] = sharded
     if sharded_c5 is not None:
         out["sharded_c5"] = sharded_c5
+    if world > 1 and not args.no_shard:
+        # (rank 0 only; the other ranks have left run() and idle in main() until rank 0 is through: their GPUs are free for the workers)
+        eng.set_shard(0, 1)
+        mlog = make_log("c4_text_multi", 1.0, BASE_SEED["c4_text_multi"])
+        eng.load_changes(mlog)
+        eng.replay()
+        sj = sharded_js("c4_text_multi", 1.0, world, want_sha=hashlib.sha256(eng.patch_json().encode()).hexdigest())
+        if sj is not None:
+            out["sharded_js"] = sj
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
         if w.is_doc:
             out["cpu_baseline"] = cpu_baseline_document(w.doc_bytes, int(st.n_ops))
@@ -742,6 +804,14 @@ def run(args, eng, rank, world, dist, device, barrier, sync):
                                          "timed_region": "am355_doc_changes of the loaded document: binary changes + hashes in host memory (best of 5 after one untimed call)"}
         if not w.is_doc:
             out["apply_changes"] = apply_changes_section(eng, w.log, barrier)
+        # the sharded path as the JS host reaches it, on this box's one GPU: a communicator of one rank through the real librccl
+        eng.set_shard(0, 1)
+        mlog = make_log("c4_text_multi", args.subline_scale, BASE_SEED["c4_text_multi"])
+        eng.load_changes(mlog)
+        eng.replay()
+        sj = sharded_js("c4_text_multi", args.subline_scale, 1, want_sha=hashlib.sha256(eng.patch_json().encode()).hexdigest())
+        if sj is not None:
+            out["sharded_js"] = sj
     return out
 
 
@@ -815,11 +885,16 @@ def compact_line(d):
             line[k] = {"n_gpus": x["n_gpus"], "scaling": x["scaling"], "ops_per_s": _r(x["ops_per_s"], 5), "ms_per_step": _r(x["ms_per_step"], 5),
                        "single_gpu_ms_per_step": _r(x["single_gpu_ms_per_step"], 5), "speedup_vs_single_gpu": _r(x["speedup_vs_single_gpu"]),
                        "parity": x["parity"][:80]}
+    if d.get("sharded_js"):
+        x = d["sharded_js"]
+        line["sharded_js"] = {k: (_r(x[k]) if isinstance(x[k], float) else x[k]) for k in ("n_gpus", "engine_ms_per_step", "single_worker_ms_per_step", "speedup_vs_single_worker", "parity", "error") if k in x}
+        if "error" in line["sharded_js"]:
+            line["sharded_js"]["error"] = str(line["sharded_js"]["error"])[:120]
     if d.get("sharding_model"):
         line["sharding_model_projected_speedup"] = {str(r["n_gpus"]): [_r(r["projected_speedup"]), _r(r["with_stage1_sharded"]["projected_speedup"])] for r in d["sharding_model"]["projected"]}
     line["detail"] = d.get("detail_file", "gpurun_out/bench_detail.json")
     # the line must fit whole in the driver's record: drop the optional parts, last first, until it does
-    for k in ("sharding_model_projected_speedup", "history_after_load_ms", "save_ms", "apply_changes_ms", "sharded_c5", "workloads"):
+    for k in ("sharding_model_projected_speedup", "history_after_load_ms", "save_ms", "apply_changes_ms", "sharded_js", "sharded_c5", "workloads"):
         if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT - 64:
             break
         line.pop(k, None)
