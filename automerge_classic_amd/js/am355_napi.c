@@ -13,7 +13,8 @@
  *   am.backendLoad(ctx, Uint8Array)                // Backend.load in one call: loadDocument + replay, checksum beside the device stages
  *   am.replay(ctx)                                 // the hot path (blocking, like every Backend call)
  *   am.patchJSON(ctx) -> string                    // JSON.stringify(getPatch) text, built from the device IR
- *   am.fetchIR(ctx) -> {objects, map, edits, values, arena, ...}   // the record tables; materialize.js builds the patch object
+ *   am.fetchIR(ctx[, reuse]) -> {objects, map, edits, arena, ...}  // the record tables; materialize.js builds the patch object.
+ *                                                  // reuse = true: into the context's own ArrayBuffers (valid until its next fetchIR)
  *   am.stats(ctx) -> {nOps, nChanges, msTotal, ...};  am.hashes(ctx) -> Uint8Array(32 * n);  am.destroy(ctx)
  */
 #include <node_api.h>
@@ -33,14 +34,36 @@
   } while (0)
 
 /* the external wraps a small box so that an explicit destroy() and the finalizer cannot both release the context */
-typedef struct { am355_ctx *ctx; } ctx_box;
+/* It also keeps what the binding reuses from call to call on a context: the gather buffer of loadChanges / applyChanges (a fresh
+ * 13 MB malloc per call cost more in page faults than the copy itself) and, for fetchIR(ctx, true), the JS ArrayBuffers the record
+ * tables are copied into. */
+enum { IR_OBJECTS = 0, IR_MAP, IR_EDITS, IR_ARENA, IR_SLOTS };
+typedef struct {
+  am355_ctx *ctx;
+  uint8_t *gather; size_t gather_cap;
+  uint64_t *offsets; size_t offsets_cap;
+  napi_ref ir_ref[IR_SLOTS]; size_t ir_cap[IR_SLOTS];
+} ctx_box;
 
 static void finalize_ctx(napi_env env, void *data, void *hint) {
-  (void)env; (void)hint;
+  (void)hint;
   ctx_box *box = (ctx_box *)data;
   if (!box) return;
   if (box->ctx) am355_destroy(box->ctx);
+  for (int k = 0; k < IR_SLOTS; k++)
+    if (box->ir_ref[k]) napi_delete_reference(env, box->ir_ref[k]);
+  free(box->gather);
+  free(box->offsets);
   free(box);
+}
+
+static ctx_box *get_box(napi_env env, napi_value v) {
+  void *p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((ctx_box *)p)->ctx) {
+    napi_throw_type_error(env, NULL, "expected a live am355 context");
+    return NULL;
+  }
+  return (ctx_box *)p;
 }
 
 static am355_ctx *get_ctx(napi_env env, napi_value v) {
@@ -76,7 +99,7 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
     napi_throw_error(env, NULL, "am355_create failed: no usable MI355X / HIP device (the engine has no CPU fallback)");
     return NULL;
   }
-  ctx_box *box = (ctx_box *)malloc(sizeof(ctx_box));
+  ctx_box *box = (ctx_box *)calloc(1, sizeof(ctx_box));
   if (!box) { am355_destroy(ctx); napi_throw_error(env, NULL, "out of memory"); return NULL; }
   box->ctx = ctx;
   napi_value ext;
@@ -105,39 +128,44 @@ static napi_value stage_changes(napi_env env, napi_callback_info info, int apply
   size_t argc = 2;
   napi_value argv[2];
   NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  am355_ctx *ctx = get_ctx(env, argv[0]);
-  if (!ctx) return NULL;
+  ctx_box *box = get_box(env, argv[0]);
+  if (!box) return NULL;
+  am355_ctx *ctx = box->ctx;
   bool is_array = false;
   napi_is_array(env, argv[1], &is_array);
   if (!is_array) { napi_throw_type_error(env, NULL, "applyChanges takes an array of Uint8Arrays"); return NULL; }
   uint32_t n = 0;
   napi_get_array_length(env, argv[1], &n);
-  uint64_t *offsets = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+  if (box->offsets_cap < (size_t)n + 1) {
+    size_t cap = ((size_t)n + 1) * 2;
+    uint64_t *q = (uint64_t *)realloc(box->offsets, sizeof(uint64_t) * cap);
+    if (!q) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    box->offsets = q; box->offsets_cap = cap;
+  }
+  uint64_t *offsets = box->offsets;
+  /* ONE pass over the array: every change is copied behind the one in front as its typed-array info arrives (two N-API calls per
+   * change; the first version made five and went over the array twice) */
   size_t total = 0;
   offsets[0] = 0;
   for (uint32_t i = 0; i < n; i++) {
     napi_value el;
-    napi_get_element(env, argv[1], i, &el);
-    bool is_ta = false;
-    napi_is_typedarray(env, el, &is_ta);
-    if (!is_ta) { free(offsets); napi_throw_type_error(env, NULL, "change is not a Uint8Array"); return NULL; }
     napi_typedarray_type t; size_t len; void *data; napi_value ab; size_t off;
-    napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off);
-    if (t != napi_uint8_array) { free(offsets); napi_throw_type_error(env, NULL, "change is not a Uint8Array"); return NULL; }
+    if (napi_get_element(env, argv[1], i, &el) != napi_ok || napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off) != napi_ok || t != napi_uint8_array) {
+      napi_throw_type_error(env, NULL, "change is not a Uint8Array");
+      return NULL;
+    }
+    if (total + len > box->gather_cap) {
+      size_t cap = (total + len) * 2 + 4096;
+      uint8_t *q = (uint8_t *)realloc(box->gather, cap);
+      if (!q) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+      box->gather = q; box->gather_cap = cap;
+    }
+    if (len) memcpy(box->gather + total, data, len);
     total += len;
     offsets[i + 1] = total;
   }
-  uint8_t *arena = (uint8_t *)malloc(total ? total : 1);
-  for (uint32_t i = 0; i < n; i++) {
-    napi_value el;
-    napi_get_element(env, argv[1], i, &el);
-    napi_typedarray_type t; size_t len; void *data; napi_value ab; size_t off;
-    napi_get_typedarray_info(env, el, &t, &len, &data, &ab, &off);
-    if (len) memcpy(arena + offsets[i], data, len);
-  }
-  int rc = apply ? am355_apply_changes(ctx, arena, offsets, n) : am355_load_changes(ctx, arena, offsets, n);
-  free(arena);
-  free(offsets);
+  static const uint8_t none = 0;
+  int rc = apply ? am355_apply_changes(ctx, total ? box->gather : &none, offsets, n) : am355_load_changes(ctx, total ? box->gather : &none, offsets, n);
   if (rc) return throw_engine(env, ctx, rc);
   napi_value u;
   napi_get_undefined(env, &u);
@@ -434,27 +462,56 @@ static napi_value copy_to_arraybuffer(napi_env env, const void *src, size_t len)
 /* fetchIR(ctx) -> {objects, map, edits, arena: ArrayBuffer, nObjects, nMap, nEdits, nValues, maxOp, pending,
  *                  actorOff: ArrayBuffer(u32), actorBytes: ArrayBuffer, clockActor: ArrayBuffer(u32), clockSeq: ArrayBuffer(f64), heads: ArrayBuffer}
  * am355_fetch_ir: the record tables of include/am355.h as the device wrote them; materialize.js builds the patch object. */
+/* the table in a JS ArrayBuffer: a fresh one, or -- fetchIR(ctx, true) -- the context's own buffer for that table, grown when needed
+ * (its content then changes with the next fetchIR on the context: for callers that materialise the patch at once, as index.js does) */
+static napi_value ir_table(napi_env env, ctx_box *box, int slot, bool reuse, const void *src, size_t len) {
+  if (!reuse) return copy_to_arraybuffer(env, src, len);
+  napi_value ab = NULL;
+  void *data = NULL;
+  size_t have = 0;
+  if (box->ir_ref[slot] && box->ir_cap[slot] >= len && napi_get_reference_value(env, box->ir_ref[slot], &ab) == napi_ok && ab &&
+      napi_get_arraybuffer_info(env, ab, &data, &have) == napi_ok && have >= len) {
+    if (len && src) memcpy(data, src, len);
+    return ab;
+  }
+  if (box->ir_ref[slot]) { napi_delete_reference(env, box->ir_ref[slot]); box->ir_ref[slot] = NULL; box->ir_cap[slot] = 0; }
+  size_t cap = (len + len / 4 + 4096 + 7) & ~(size_t)7;   /* (a multiple of 8: the JS side lays Uint32Array / Float64Array views over the whole buffer) */
+  if (napi_create_arraybuffer(env, cap, &data, &ab) != napi_ok) return NULL;
+  if (len && src) memcpy(data, src, len);
+  if (napi_create_reference(env, ab, 1, &box->ir_ref[slot]) == napi_ok) box->ir_cap[slot] = cap;
+  return ab;
+}
+
 static napi_value fetch_ir_common(napi_env env, napi_callback_info info, int apply) {
-  size_t argc = 1;
-  napi_value argv[1];
+  size_t argc = 2;
+  napi_value argv[2];
   NAPI_CALL(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  am355_ctx *ctx = get_ctx(env, argv[0]);
-  if (!ctx) return NULL;
+  ctx_box *box = get_box(env, argv[0]);
+  if (!box) return NULL;
+  am355_ctx *ctx = box->ctx;
+  bool reuse = false;
+  if (argc > 1) (void)napi_get_value_bool(env, argv[1], &reuse);
   am355_patch_ir ir;
   int rc = apply ? am355_fetch_apply_ir(ctx, &ir) : am355_fetch_ir(ctx, &ir);
   if (rc) return throw_engine(env, ctx, rc);
   napi_value o;
   NAPI_CALL(env, napi_create_object(env, &o));
+#define PUT_TAB(name, slot, ptr, bytes)                                                 \
+  do {                                                                                  \
+    napi_value ab_ = ir_table(env, box, (slot), reuse, (ptr), (bytes));                 \
+    if (!ab_) { napi_throw_error(env, NULL, "out of memory (patch IR)"); return NULL; } \
+    napi_set_named_property(env, o, name, ab_);                                         \
+  } while (0)
 #define PUT_AB(name, ptr, bytes)                                                        \
   do {                                                                                  \
     napi_value ab_ = copy_to_arraybuffer(env, (ptr), (bytes));                          \
     if (!ab_) { napi_throw_error(env, NULL, "out of memory (patch IR)"); return NULL; } \
     napi_set_named_property(env, o, name, ab_);                                         \
   } while (0)
-  PUT_AB("objects", ir.objects, (size_t)ir.n_objects * sizeof(am355_ir_object));
-  PUT_AB("map", ir.map, (size_t)ir.n_map * sizeof(am355_ir_map));
-  PUT_AB("edits", ir.edits, ((size_t)ir.n_edits + 1) * sizeof(am355_ir_edit));
-  PUT_AB("arena", ir.arena, (size_t)ir.arena_len);
+  PUT_TAB("objects", IR_OBJECTS, ir.objects, (size_t)ir.n_objects * sizeof(am355_ir_object));
+  PUT_TAB("map", IR_MAP, ir.map, (size_t)ir.n_map * sizeof(am355_ir_map));
+  PUT_TAB("edits", IR_EDITS, ir.edits, ((size_t)ir.n_edits + 1) * sizeof(am355_ir_edit));
+  PUT_TAB("arena", IR_ARENA, ir.arena, (size_t)ir.arena_len);
   PUT_AB("actorOff", ir.actor_off, ((size_t)ir.n_actors + 1) * sizeof(uint32_t));
   PUT_AB("actorBytes", ir.actor_bytes, ir.n_actors ? (size_t)ir.actor_off[ir.n_actors] : 0);
   PUT_AB("clockActor", ir.clock_actor, (size_t)ir.n_clock * sizeof(uint32_t));
@@ -467,6 +524,7 @@ static napi_value fetch_ir_common(napi_env env, napi_callback_info info, int app
     napi_set_named_property(env, o, "clockSeq", ab);
   }
 #undef PUT_AB
+#undef PUT_TAB
   set_num(env, o, "nObjects", ir.n_objects); set_num(env, o, "nMap", ir.n_map); set_num(env, o, "nEdits", ir.n_edits);
   set_num(env, o, "nValues", ir.n_values); set_num(env, o, "nActors", ir.n_actors); set_num(env, o, "maxOp", (double)ir.max_op);
   set_num(env, o, "pending", ir.pending);

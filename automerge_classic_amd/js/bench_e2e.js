@@ -32,7 +32,7 @@ for (let r = 0; r < reps + 2; r++) {
   const t1 = ms()
   addon.replay(ctx)                 // the hot path
   const t2 = ms()
-  const ir = addon.fetchIR(ctx)     // patch IR (record tables) -> host -> JS-owned ArrayBuffers
+  const ir = addon.fetchIR(ctx, true)   // patch IR (record tables) -> host -> the context's own JS ArrayBuffers (as index.js asks for them)
   const t2a = ms()
   const patchIR = materialize(ir)   // the object the frontend consumes
   const t2b = ms()

@@ -160,7 +160,7 @@ function toJs(backend) {
 // the patch object of the last replay: built from the record tables the device wrote (materialize.js) -- real JS values, no
 // JSON text in between
 function gpuPatch() {
-  return PATCH_VIA_JSON ? JSON.parse(addon.patchJSON(ctx)) : materialize(addon.fetchIR(ctx))
+  return PATCH_VIA_JSON ? JSON.parse(addon.patchJSON(ctx)) : materialize(addon.fetchIR(ctx, true))
 }
 
 function gpuReplay(changes) {
@@ -411,7 +411,7 @@ function gpuApplyChanges(backend, changes) {
     entry.generation = 0   // (whatever the context holds now is nobody's state)
     throw e
   }
-  const patch = materialize(addon.fetchApplyIR(ctx))
+  const patch = materialize(addon.fetchApplyIR(ctx, true))
   // the engine's list of changes: those applied so far in application order, the batch, those that were queued
   const list = g ? Array.from(g.applied, i => g.changes[i]).concat(changes, Array.from(g.pendingIdx, i => g.changes[i])) : changes.slice()
   const state = new GpuState(list, null, patch.deps)

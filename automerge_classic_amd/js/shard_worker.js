@@ -59,7 +59,7 @@ process.on('message', msg => {
           addon.shardedReplay(ctx, false)
           const c = process.hrtime.bigint()
           if (!staged) error = 'staging failed'
-          else if (rank === 0) ir = addon.fetchIR(ctx)
+          else if (rank === 0) ir = addon.fetchIR(ctx, true)
           times = { stage: Number(b - a) / 1e6, replay: Number(c - b) / 1e6, fetch: Number(process.hrtime.bigint() - c) / 1e6 }
         } catch (e) {
           error = String(e.message || e)
