@@ -117,10 +117,11 @@ extern "C" int am355_get_hashes(const am355_ctx* c, uint8_t* out) {
   return AM355_OK;
 }
 
-extern "C" int am355_resident_counters(const am355_ctx* c, uint64_t out[2]) {
+extern "C" int am355_resident_counters(const am355_ctx* c, uint64_t out[3]) {
   if (!c || !out) return AM355_E_ARG;
   out[0] = c->n_resident_calls;
   out[1] = c->n_resident_fallbacks;
+  out[2] = c->n_resorder_calls;
   return AM355_OK;
 }
 

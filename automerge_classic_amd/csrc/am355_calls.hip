@@ -29,6 +29,10 @@ int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out, bool with_edits) {
   if (!c) return AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");
   (void)hipSetDevice(c->device);
+  if (with_edits && c->ir_stale) {   // (the object and map tables of a state are current after an in-place list merge; its edit tables are not)
+    int frc = ensure_ir_fresh(c);
+    if (frc) return frc;
+  }
   if (!c->ir_fetched) {
     hipStream_t st = c->stream;
     am355_patch_ir& h = c->hir;

@@ -14,6 +14,7 @@
 #include "am355_pinflate.h"
 #include "am355_history.h"
 #include "am355_delta.h"
+#include "am355_resorder.h"
 #include "am355_apply.h"
 #include "am355_sync.h"
 #include "am355_sched.h"
@@ -481,6 +482,14 @@ struct am355_ctx {
   std::unordered_map<std::string, uint32_t> res_rank_of;
   struct ActorMemo { std::vector<uint8_t> bytes; std::vector<uint32_t> ranks; };
   std::vector<ActorMemo> res_actor_memo;
+  // resident list ORDER (am355_resorder.hip): the new elements of a small list-only batch are merged into the stored order; the
+  // whole-document edit tables (ir.edit ...) are then stale until somebody asks for them (ensure_ir_fresh)
+  DevBuf d_pos, d_order_alt, d_resorder;           // pos_of[row] | the other order buffer | the stage's scratch
+  uint32_t* order_alt_ptr = nullptr;               // whichever of the two order arrays c->mb.order does NOT point to (null: not set up since the last carve)
+  HostBuf h_resorder;                              // pinned: its verdict words + the merge counters' flag word
+  bool pos_valid = false;                          // d_pos describes c->mb.order
+  bool ir_stale = false;                           // rows / order are current, the whole-document patch tables are not
+  uint64_t n_resorder_calls = 0;
   HostBuf h_res_metas;                             // pinned: the batch's ChangeMetas on their way to the host
   uint32_t res_dep_base = 0;                       // changes >= this were applied by resident calls: their dependency indexes live in ...
   std::vector<uint32_t> res_dep_first, res_dep_index;   // ... CSR over (change - res_dep_base)
@@ -570,6 +579,7 @@ int ir_copy_enqueue(am355_ctx* c, bool with_edits);
 // replay: host scheduler / plan, device buffers, orchestration of the device stages (am355_replay.hip)
 int setup_buffers(am355_ctx* c, uint32_t NA);
 int replay_impl(am355_ctx* c);
+int ensure_ir_fresh(am355_ctx* c);   // rebuilds the whole-document patch tables when a resident call left them stale (ir_stale)
 // the calls on a replayed state: patch IR to the host, Backend.applyChanges, dependency graph, Bloom filters (am355_calls.hip)
 int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out, bool with_edits = true);
 int patch_json_impl(am355_ctx* c, const char** json, size_t* len);

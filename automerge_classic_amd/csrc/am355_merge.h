@@ -121,12 +121,18 @@ bool wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st)
 
 // Zero-fills the merge stage needs (succ / counter accumulators, child lists, list order): independent of the decode kernels,
 // so the caller issues them on a second stream beside the decode and joins before merge_run.
-void merge_prepare(MergeBufs& b, hipStream_t aux);
+// (what: the accumulators of the rows k_resolve is about to run over | what the kernels of merge_run from k_emit on fill and count in:
+// replay_resident clears the first before its k_resolve and the second only when it does not merge the list order in place)
+enum { MERGE_FILL_ROWS = 1, MERGE_FILL_TABLES = 2 };
+void merge_prepare(MergeBufs& b, hipStream_t aux, int what = MERGE_FILL_ROWS | MERGE_FILL_TABLES);
 // resolve -> emit -> compaction -> object table, map emission order, RGA order (sibling ordering, typing runs, list ranking),
 // edits. `b.counts` (cleared by the caller BEFORE the decode kernels, whose validity flags it already holds) is read back
 // twice without draining the stream (ev_counts, ev_runs: the host sizes the later launches while the device works through
 // the earlier ones) and once at the end (synchronises st). Returns the counters in *h_counts.
-void merge_run(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs);
+void merge_run(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs, bool resolved = false);
+// k_resolve alone over the rows >= b.first_row (replay_resident: the list order of a small batch is then updated in place,
+// am355_resorder.hip, or merge_run(..., resolved = true) goes on from k_emit)
+void merge_resolve(MergeBufs& b, hipStream_t st);
 
 // Document load: whole-document patch of rows already in canonical order (pred_* arrays = succ lists). `b.counts` must be
 // cleared by the caller before the decode kernels run.

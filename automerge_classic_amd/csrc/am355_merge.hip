@@ -1507,7 +1507,7 @@ void merge_bind_counts(MergeBufs& b, void* block) {
   b.cs_erec.group_sum = g + 5 * groups;
 }
 
-void merge_prepare(MergeBufs& b, hipStream_t aux) {
+void merge_prepare(MergeBufs& b, hipStream_t aux, int what) {
   uint32_t N = b.n_ops;
   if (b.row_stride == 0 && b.first_row == 0) {
     (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, aux);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
@@ -1519,15 +1519,19 @@ void merge_prepare(MergeBufs& b, hipStream_t aux) {
   // one launch; the accumulators of kept rows [0, first_row) keep what the earlier rows left in them
   const size_t F = b.first_row, M = (size_t)N + 1 - F;
   FillRanges f;
-  f.add(b.succ_cnt + F, 4 * M, 0);
-  f.add(b.inc_cnt + F, 4 * M, 0);
-  f.add(b.inc_sum + F, 8 * M, 0);
-  f.add(b.last_inc + F, 8 * M, 0);
-  f.add(b.val_cnt, 4 * ((size_t)N + 1), 0);   // (recounted by k_emit over all rows)
-  if (N) {
-    f.add(b.order, 4 * ((size_t)N + 2), 0xffffffffu);
-    f.add(b.first_child, 4 * (2 * (size_t)N + 3), 0xffffffffu);
-    f.add(b.child_head, 4 * (2 * (size_t)N + 2), 0xffffffffu);
+  if (what & MERGE_FILL_ROWS) {
+    f.add(b.succ_cnt + F, 4 * M, 0);
+    f.add(b.inc_cnt + F, 4 * M, 0);
+    f.add(b.inc_sum + F, 8 * M, 0);
+    f.add(b.last_inc + F, 8 * M, 0);
+  }
+  if (what & MERGE_FILL_TABLES) {
+    f.add(b.val_cnt, 4 * ((size_t)N + 1), 0);   // (recounted by k_emit over all rows)
+    if (N) {
+      f.add(b.order, 4 * ((size_t)N + 2), 0xffffffffu);
+      f.add(b.first_child, 4 * (2 * (size_t)N + 4), 0xffffffffu);
+      f.add(b.child_head, 4 * (2 * (size_t)N + 3), 0xffffffffu);
+    }
   }
   launch_fill_ranges(f, aux);
 }
@@ -1610,7 +1614,11 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
   AM355_LAUNCH_INDEPENDENT(k_map_finish, grid_for(ne), dim3(BLOCK), st, b, (const uint32_t*)(cur ? perm_b : perm_a), ne, ir);
 }
 
-void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs) {
+void merge_resolve(MergeBufs& b, hipStream_t st) {
+  if (b.n_ops) hipLaunchKernelGGL(k_resolve, grid_for(std::max(b.n_ops - b.first_row, 1u)), dim3(BLOCK), 0, st, b);
+}
+
+void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs, bool resolved) {
   const uint32_t N = b.n_ops;
   const bool trace = getenv("AM355_TRACE") != nullptr;
   auto t_begin = std::chrono::steady_clock::now();
@@ -1630,7 +1638,7 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
   uint32_t* heads = b.run_heads;  // [runs + 1]
   uint32_t* row_run = b.row_run;  // [N]
   // ---- per-row resolution, visibility, compaction (b.counts already holds the decode kernels' validity flags) ----
-  hipLaunchKernelGGL(k_resolve, grid_for(std::max(N - b.first_row, 1u)), dim3(BLOCK), 0, st, b);
+  if (!resolved) hipLaunchKernelGGL(k_resolve, grid_for(std::max(N - b.first_row, 1u)), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
   hipLaunchKernelGGL(k_compact_rows, grid_for(N), dim3(BLOCK), 0, st, b, ir);
   if (!b.sig) (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);

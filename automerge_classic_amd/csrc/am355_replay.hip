@@ -532,6 +532,9 @@ int setup_buffers(am355_ctx* c, uint32_t NA) {
   if (1 + bits_row + bits_ctr + bits_actor > 64) { c->flags |= AM355_F_OVERFLOW; return fail(c, AM355_E_UNSUPPORTED, "sort key wider than 64 bits"); }
   size_t Nc = (size_t)N + 1;
   c->resident_valid = false;
+  c->order_alt_ptr = nullptr;
+  c->pos_valid = false;
+  c->ir_stale = false;
   canary_scope("replay buffers (setup_buffers: op rows, preds, merge scratch, sort scratch, patch IR)");
   // (rows the speculative decode launch of this replay is writing keep their place: they are carved for a capacity >= N, P)
   if (!(c->spec_launched && N <= c->spec_cap_ops && P <= c->spec_cap_preds)) {
@@ -1289,7 +1292,7 @@ static int replay_resident(am355_ctx* c) {
   merge_bind_counts(b, c->d_counts.p);
   c->resident_valid = false;   // (from here on the kept arrays change: a failure leaves no state behind)
   HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, b.counts_bytes, st));
-  merge_prepare(b, st);   // (one fill launch; in this stream: the decode of a small batch is too short to hide a second stream's join)
+  merge_prepare(b, st, MERGE_FILL_ROWS);   // (the new rows' accumulators; in this stream: the decode of a small batch is too short to hide a second stream's join)
   HIPCHK(c, hipEventRecord(c->ev_fork, st));
   HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
   launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, (uint32_t)np - n_small - n_large,
@@ -1298,13 +1301,112 @@ static int replay_resident(am355_ctx* c) {
   HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
   lap("decode enqueued");
   Counts* hc = c->h_counts.as<Counts>();
-  merge_run(b, c->ir, hc, st, nullptr, c->ev_runs);
+  merge_resolve(b, st);
+  // ---- list order: a batch of plain list edits is merged into the STORED order (am355_resorder.hip); anything else -- map rows, new
+  //      objects, a new element with two new children -- orders every list anew with the kernels of merge_run ----
+  static const bool no_resorder = getenv("AM355_NO_RESORDER") != nullptr;
+  const uint32_t NN = N - (uint32_t)old_ops, NL_old = c->counts.n_list_ins, NO = c->counts.n_objects;
+  bool merged_in_place = false;
+  if (!no_resorder && NN && NN <= RESORDER_ROWS_MAX && NL_old && c->mb.row_stride) {
+    const size_t cap_rows = c->mb.row_stride;
+    // (the order lives in one of two arrays of row_stride + 2 words -- the one carved with the merge arrays and c->d_order_alt --, and
+    // every in-place merge writes the other one; a new carve, setup_buffers, starts over)
+    if (!c->order_alt_ptr) {
+      if (!c->d_order_alt.ensure(4 * (cap_rows + 2))) return fail(c, AM355_E_NOMEM, "device allocation failed (resident list order)");
+      c->order_alt_ptr = c->d_order_alt.as<uint32_t>();
+    }
+    if (!c->d_pos.ensure_keep(4 * cap_rows, c->pos_valid ? 4 * (size_t)old_ops : 0) || !c->d_resorder.ensure(resorder_bytes(NN, NO)) || !c->h_resorder.ensure(64))
+      return fail(c, AM355_E_NOMEM, "device allocation failed (resident list order)");
+    ResOrderBufs ro{};
+    resorder_bind(ro, c->d_resorder.p, NN, NO);
+    ro.T0 = (uint32_t)old_ops; ro.n_new = NN; ro.n_list = NL_old; ro.n_obj = NO;
+    ro.pos_of = c->d_pos.as<uint32_t>();
+    ro.order_new = c->order_alt_ptr;
+    if (!c->pos_valid) resorder_positions(b, NL_old, ro.pos_of, st);
+    HIPCHK(c, hipMemsetAsync(ro.obj_add, 0, 4 * ((size_t)NO + 2) + 256 + 64, st));   // obj_add | words (neighbours in the block)
+    resorder_run(b, ro, st);
+    uint32_t* hw = c->h_resorder.as<uint32_t>();
+    HIPCHK(c, hipMemcpyAsync(hw, ro.words, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hw + 8, &b.counts->flags, 4, hipMemcpyDeviceToHost, st));
+    {
+      hipError_t q;
+      while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
+      if (q != hipSuccess) HIPCHK(c, q);
+    }
+    if (hw[8]) return error_for_flags(c, hw[8], "op set rejected");
+    if (hw[0] == 0) {
+      // the order after the batch is in the other buffer: it is the state's order from here on
+      uint32_t* old_order = b.order;
+      b.order = ro.order_new;
+      c->order_alt_ptr = old_order;   // (the previous order array is what the next in-place merge writes)
+      c->counts.n_list_ins = NL_old + hw[1];
+      c->pos_valid = true;
+      c->ir_stale = true;
+      c->ir_fetched = false;
+      c->ir_copy_enqueued = 0;
+      c->n_resorder_calls++;
+      merged_in_place = true;
+      lap("list order merged in place");
+    } else {
+      c->pos_valid = false;
+      lap("list order: not a batch for the in-place merge");
+    }
+  }
+  if (!merged_in_place) {
+    merge_prepare(b, st, MERGE_FILL_TABLES);
+    merge_run(b, c->ir, hc, st, nullptr, c->ev_runs, true);
+    lap("merge_run done");
+    if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
+    c->counts = *hc;
+    c->counts.n_objects += 1;  // + _root
+    c->pos_valid = false;
+    c->ir_stale = false;
+  }
   HIPCHK(c, hipEventRecord(c->ev[5], st));
-  lap("merge_run done");
-  if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
-  c->counts = *hc;
-  c->counts.n_objects += 1;  // + _root
   c->n_resident_calls++;
+  return AM355_OK;
+}
+
+// The whole-document patch tables of a state whose last calls merged their list edits in place (replay_resident: c->ir_stale): the
+// kernels of merge_run from k_emit on, over the rows as they stand. AM355_RESORDER_VERIFY=1: the order they compute must be the one
+// the in-place merges left (tests).
+int ensure_ir_fresh(am355_ctx* c) {
+  if (!c || !c->ir_stale) return AM355_OK;
+  (void)hipSetDevice(c->device);
+  hipStream_t st = c->stream;
+  MergeBufs& b = c->mb;
+  const uint32_t N = b.n_ops;
+  std::vector<uint32_t> kept;
+  const bool verify = getenv("AM355_RESORDER_VERIFY") != nullptr;
+  if (verify) {
+    kept.resize(c->counts.n_list_ins);
+    HIPCHK(c, hipMemcpy(kept.data(), b.order, 4 * kept.size(), hipMemcpyDeviceToHost));
+  }
+  c->sig_seq++;
+  b.sig_seq = c->sig_seq;
+  b.first_row = N;                      // (nothing to resolve: every row has been)
+  b.seed_list_inc = c->seed_list_inc;
+  if (!c->d_counts.ensure(merge_counts_bytes(N))) return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
+  merge_bind_counts(b, c->d_counts.p);
+  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, b.counts_bytes, st));
+  merge_prepare(b, st);
+  Counts* hc = c->h_counts.as<Counts>();
+  merge_run(b, c->ir, hc, st, nullptr, c->ev_runs);
+  if (hc->flags) { c->staged = c->replayed = false; return error_for_flags(c, hc->flags, "op set rejected"); }
+  c->counts = *hc;
+  c->counts.n_objects += 1;
+  c->ir_stale = false;
+  c->ir_fetched = false;
+  c->ir_copy_enqueued = 0;
+  c->pos_valid = false;
+  c->stats.n_edits = c->counts.n_edits;
+  c->stats.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
+                      ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit);
+  if (verify) {
+    std::vector<uint32_t> now(c->counts.n_list_ins);
+    HIPCHK(c, hipMemcpy(now.data(), b.order, 4 * now.size(), hipMemcpyDeviceToHost));
+    if (now != kept) return fail(c, AM355_E_DEVICE, "internal: the list order merged in place differs from the order computed from scratch");
+  }
   return AM355_OK;
 }
 

@@ -1,0 +1,242 @@
+// Resident list order: Backend.applyChanges onto a state the context holds, small batches (am355_replay.hip replay_resident).
+//
+// Reference: a new list element is placed by seekToOp / seekWithinBlock (backend/new.js:227-317, 50-192): from the op behind its
+// reference element (or the head of the list) skip every following element with a GREATER opId and insert in front of the first
+// one with a smaller opId (the RGA rule, :144-163). A child's id is greater than its parent's, so the skipped stretch is exactly the
+// subtrees of the greater siblings. For a batch merged into an EXISTING order that gives, per new element x:
+//   * reference element old (or the head): gap(x) = the first OLD position q behind it with id(order[q]) < id(x) (the end of the
+//     object when there is none) -- one forward scan over the stored order, 64 positions per step;
+//   * two such elements with the same gap stand in DESCENDING id order (the greater one is skipped by the smaller one's scan), each
+//     followed by the new elements that hang below it;
+//   * reference element new: x follows it directly when it is its only new child (a typing run: the shape of nearly every batch).
+//     A new element with two new children is left to the full ordering (flag), as is everything that is not a plain list edit.
+// The order after the batch is then a MERGE: an old element at position p moves up by the number of new elements with gap <= p, the
+// k-th new element (by gap, root id descending, depth in its run) lands at gap + k.
+#include "am355_resorder.h"
+#include "am355_rows.h"
+#include "am355_canary.h"
+
+namespace am355 {
+
+static size_t al256(size_t b) { return carve_round(b); }
+
+size_t resorder_bytes(uint32_t n_new, uint32_t n_obj) {
+  return 3 * al256(4 * ((size_t)n_new + 1)) + al256(4 * ((size_t)n_obj + 2)) + al256(64) + 256;
+}
+
+void resorder_bind(ResOrderBufs& r, void* block, uint32_t n_new, uint32_t n_obj) {
+  uint8_t* p = (uint8_t*)block;
+  auto take = [&](size_t bytes) { void* q = p; p += al256(bytes); return q; };
+  r.gap = (uint32_t*)take(4 * ((size_t)n_new + 1));
+  r.srt_gap = (uint32_t*)take(4 * ((size_t)n_new + 1));
+  r.srt_row = (uint32_t*)take(4 * ((size_t)n_new + 1));
+  r.obj_add = (uint32_t*)take(4 * ((size_t)n_obj + 2));
+  r.words = (uint32_t*)take(64);
+}
+
+__global__ __launch_bounds__(BLOCK) void kr_positions(MergeBufs b, uint32_t n_list, uint32_t* __restrict__ pos_of) {
+  uint32_t p = gtid();
+  if (p < n_list) pos_of[b.order[p]] = p;
+}
+
+void resorder_positions(const MergeBufs& b, uint32_t n_list, uint32_t* pos_of, hipStream_t st) {
+  if (n_list) AM355_LAUNCH_INDEPENDENT(kr_positions, dim3((n_list + BLOCK - 1) / BLOCK), dim3(BLOCK), st, b, n_list, pos_of);
+}
+
+// one wavefront per new row: is the row one this path serves; the gap of a new element whose reference element is old
+constexpr uint32_t GAP_STEPS_MAX = 4096;   // 64 positions each: a scan past 262 k greater elements is left to the full ordering
+__global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
+  const uint32_t t = blockIdx.x, lane = threadIdx.x;
+  if (t >= r.n_new) return;
+  const uint32_t g = r.T0 + t;
+  const OpCols& o = b.ops;
+  const uint8_t kind = b.kind[g];
+  const uint32_t a = o.action[g];
+  uint32_t gap = NONE32;
+  bool refuse = false;
+  const bool list_del = kind == K_DEL && o.key_len[g] == NONE32;
+  if (!(kind == K_LIST_INS || kind == K_LIST_UPD || list_del)) refuse = true;   // map rows, foreign rows, rows k_resolve left without a kind
+  else if (kind != K_DEL && a != 1) refuse = true;                               // child objects (the object table grows), increments, links
+  else if (kind == K_LIST_INS) {
+    const uint32_t parent = b.ref_row[g];
+    const bool head = o.key_ctr[g] == 0;
+    const uint32_t make_row = b.obj_row[g];
+    if (!head && parent == NONE32) refuse = true;
+    else if (make_row != NONE32 && make_row >= r.T0) refuse = true;   // (an object this batch makes: it has no index in the object table yet -- its make row refuses the batch anyway)
+    else if (head || parent < r.T0) {
+      const uint32_t oi = obj_index_of(b, make_row);
+      const uint32_t first = b.obj_first_pos[oi], end = first + b.obj_n[oi];
+      uint32_t q = head ? first : r.pos_of[parent] + 1;
+      const unsigned long long my_id = pack_id(o.id_ctr[g], o.id_actor[g]);
+      gap = end;
+      if (q < first || q > end) refuse = true;   // (the stored positions do not describe this object: never expected)
+      for (uint32_t step = 0; !refuse && q < end; step++, q += WAVE) {
+        if (step >= GAP_STEPS_MAX) { refuse = true; break; }
+        bool smaller = false;
+        if (q + lane < end) {
+          const uint32_t e = b.order[q + lane];
+          smaller = pack_id(o.id_ctr[e], o.id_actor[e]) < my_id;
+        }
+        const unsigned long long m = __ballot(smaller);
+        if (m) { gap = q + (uint32_t)__ffsll(m) - 1; break; }
+      }
+    }
+  }
+  if (lane == 0) {
+    r.gap[t] = gap;
+    if (refuse) r.words[0] = 1;
+  }
+}
+
+// one workgroup: the new elements in their final order
+constexpr uint32_t RO_THREADS = 1024;
+__global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs r) {
+  __shared__ uint32_t s_par[RESORDER_ROWS_MAX];      // reference element of a new element, as an index into the batch; NONE32: a root; NONE32 - 1: not an element
+  __shared__ uint32_t s_root[2][RESORDER_ROWS_MAX], s_depth[2][RESORDER_ROWS_MAX];
+  __shared__ uint32_t s_nchild[RESORDER_ROWS_MAX];
+  __shared__ uint32_t s_roots[RESORDER_ROOTS_MAX], s_rank_of_root[RESORDER_ROOTS_MAX], s_size[RESORDER_ROOTS_MAX], s_base[RESORDER_ROOTS_MAX + 1];
+  __shared__ unsigned long long s_rid[RESORDER_ROOTS_MAX];
+  __shared__ uint32_t s_rgap[RESORDER_ROOTS_MAX];
+  __shared__ uint32_t s_n_roots, s_bad, s_n_ins;
+  const uint32_t t0 = threadIdx.x, n = r.n_new;
+  const OpCols& o = b.ops;
+  constexpr uint32_t NOT_ELEM = NONE32 - 1;
+  if (t0 == 0) { s_n_roots = 0; s_bad = 0; s_n_ins = 0; }
+  for (uint32_t t = t0; t < n; t += RO_THREADS) s_nchild[t] = 0;
+  __syncthreads();
+  if (r.words[0] || n > RESORDER_ROWS_MAX) { if (t0 == 0) r.words[0] = 1; return; }
+  // ---- parents within the batch, roots ----
+  for (uint32_t t = t0; t < n; t += RO_THREADS) {
+    const uint32_t g = r.T0 + t;
+    uint32_t par = NOT_ELEM;
+    if (b.kind[g] == K_LIST_INS) {
+      const uint32_t p = b.ref_row[g];
+      if (o.key_ctr[g] != 0 && p != NONE32 && p >= r.T0) {
+        par = p - r.T0;
+        if (atomicAdd(&s_nchild[par], 1u) != 0) s_bad = 1;   // a second new child of a new element: not a run
+      } else {
+        par = NONE32;
+        const uint32_t k = atomicAdd(&s_n_roots, 1u);
+        if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
+      }
+      atomicAdd(&s_n_ins, 1u);
+    }
+    s_par[t] = par;
+    s_root[0][t] = par == NONE32 || par == NOT_ELEM ? t : par;
+    s_depth[0][t] = par == NONE32 || par == NOT_ELEM ? 0u : 1u;
+  }
+  __syncthreads();
+  if (s_bad) { if (t0 == 0) r.words[0] = 1; return; }
+  // ---- root and depth of every new element: pointer jumping over the runs ----
+  int cur = 0;
+  for (uint32_t span = 1; span < n; span <<= 1) {
+    for (uint32_t t = t0; t < n; t += RO_THREADS) {
+      const uint32_t up = s_root[cur][t];
+      s_root[cur ^ 1][t] = s_root[cur][up];
+      s_depth[cur ^ 1][t] = s_depth[cur][t] + (up != t ? s_depth[cur][up] : 0u);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- roots by (gap, id descending): rank by counting (a batch of a few changes has a few roots) ----
+  const uint32_t R = s_n_roots;
+  for (uint32_t k = t0; k < R; k += RO_THREADS) {
+    const uint32_t t = s_roots[k], g = r.T0 + t;
+    s_rgap[k] = r.gap[t];
+    s_rid[k] = pack_id(o.id_ctr[g], o.id_actor[g]);
+    s_size[k] = 0;
+  }
+  __syncthreads();
+  for (uint32_t k = t0; k < R; k += RO_THREADS) {
+    const uint32_t gap_k = s_rgap[k];
+    const unsigned long long id_k = s_rid[k];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < R; j++) rank += (s_rgap[j] < gap_k || (s_rgap[j] == gap_k && s_rid[j] > id_k)) ? 1u : 0u;   // (ids are unique: j == k counts nothing)
+    s_rank_of_root[k] = rank;
+  }
+  __syncthreads();
+  // root index of a batch row -> its slot k in s_roots: through s_nchild (free now)
+  for (uint32_t k = t0; k < R; k += RO_THREADS) s_nchild[s_roots[k]] = k;
+  __syncthreads();
+  for (uint32_t t = t0; t < n; t += RO_THREADS)
+    if (s_par[t] != NOT_ELEM) atomicAdd(&s_size[s_rank_of_root[s_nchild[s_root[cur][t]]]], 1u);   // sizes in RANK order
+  __syncthreads();
+  if (t0 == 0) {
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < R; k++) { s_base[k] = acc; acc += s_size[k]; }
+    s_base[R] = acc;
+    r.words[1] = acc;
+  }
+  __syncthreads();
+  for (uint32_t t = t0; t < n; t += RO_THREADS) {
+    if (s_par[t] == NOT_ELEM) continue;
+    const uint32_t root_t = s_root[cur][t], k = s_nchild[root_t];
+    const uint32_t at = s_base[s_rank_of_root[k]] + s_depth[cur][t];
+    r.srt_gap[at] = r.gap[root_t];
+    r.srt_row[at] = r.T0 + t;
+    atomicAdd(&r.obj_add[obj_index_of(b, b.obj_row[r.T0 + t])], 1u);
+  }
+}
+
+// the merged order: old elements move up by the new elements in front of them, the k-th new element lands at gap + k
+__global__ __launch_bounds__(BLOCK) void kr_shift(MergeBufs b, ResOrderBufs r) {
+  if (r.words[0]) return;
+  const uint32_t i = gtid(), K = r.words[1];
+  if (i < r.n_list) {
+    uint32_t lo = 0, hi = K;   // new elements with gap <= i
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (r.srt_gap[mid] <= i) lo = mid + 1; else hi = mid; }
+    const uint32_t e = b.order[i];
+    r.order_new[i + lo] = e;
+    r.pos_of[e] = i + lo;
+  }
+  if (i < K) {
+    const uint32_t at = r.srt_gap[i] + i, row = r.srt_row[i];
+    r.order_new[at] = row;
+    r.pos_of[row] = at;
+  }
+}
+
+// per object: its new elements; first positions move up by the new elements of the objects in front (one workgroup; objects are few)
+__global__ __launch_bounds__(BLOCK) void kr_objects(MergeBufs b, ResOrderBufs r) {
+  if (r.words[0]) return;
+  __shared__ uint32_t s_red[BLOCK / WAVE];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base <= r.n_obj; base += BLOCK) {
+    const uint32_t oi = base + threadIdx.x;
+    const uint32_t add = oi <= r.n_obj ? r.obj_add[oi] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan_u32(add, s_red, &total);
+    if (oi <= r.n_obj) {
+      b.obj_first_pos[oi] += carry + ex;
+      b.obj_n[oi] += add;
+    }
+    carry += total;
+  }
+}
+
+// the verdict "its own value is visible" (k_emit) of the batch's elements and of the elements its rows overwrite or delete
+__global__ __launch_bounds__(BLOCK) void kr_kinds(MergeBufs b, ResOrderBufs r) {
+  if (r.words[0]) return;
+  const uint32_t t = gtid();
+  if (t >= r.n_new) return;
+  const uint32_t g = r.T0 + t;
+  const OpCols& o = b.ops;
+  const uint8_t kind = b.kind[g];
+  if (kind == K_LIST_INS) { if (b.succ_cnt[g] == 0) b.kind[g] = K_LIST_INS_VIS; return; }   // (valued: kr_gaps admitted `set` rows only)
+  for (uint32_t k = 0; k < o.pred_num[g]; k++) {
+    const uint32_t pr = row_of(b, o.pred_actor[o.pred_first[g] + k], o.pred_ctr[o.pred_first[g] + k]);
+    if (pr != NONE32 && b.kind[pr] == K_LIST_INS_VIS) b.kind[pr] = K_LIST_INS;   // (it has a successor now: this row)
+  }
+}
+
+void resorder_run(MergeBufs& b, ResOrderBufs& r, hipStream_t st) {
+  if (!r.n_new) return;
+  hipLaunchKernelGGL(kr_gaps, dim3(r.n_new), dim3(WAVE), 0, st, b, r);
+  hipLaunchKernelGGL(kr_order, dim3(1), dim3(RO_THREADS), 0, st, b, r);
+  const uint32_t most = r.n_list > r.n_new ? r.n_list : r.n_new;
+  hipLaunchKernelGGL(kr_shift, dim3((most + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, b, r);
+  hipLaunchKernelGGL(kr_objects, dim3(1), dim3(BLOCK), 0, st, b, r);
+  AM355_LAUNCH_INDEPENDENT(kr_kinds, dim3((r.n_new + BLOCK - 1) / BLOCK), dim3(BLOCK), st, b, r);
+}
+
+}  // namespace am355

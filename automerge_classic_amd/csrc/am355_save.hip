@@ -167,6 +167,7 @@ int save_impl(am355_ctx* c, uint32_t flags, const uint8_t** out_bytes, size_t* o
   // whatever an earlier replay left there)
   if (c->shard_world > 1) return fail(c, AM355_E_UNSUPPORTED, "am355_save on a sharded context");
   if (c->n_pending) return fail(c, AM355_E_UNSUPPORTED, "changes are queued: the document is saved by the JS path");
+  { int frc = ensure_ir_fresh(c); if (frc) return frc; }   // (the save's row order reads the whole-document tables: rebuilt if in-place list merges left them stale)
   if (!c->is_document && c->has_unknown_cols) return fail(c, AM355_E_UNSUPPORTED, "a change carries columns this engine does not model: the document is saved by the JS path");
   hipStream_t st = c->stream;
   const bool trace = getenv("AM355_TRACE") != nullptr;

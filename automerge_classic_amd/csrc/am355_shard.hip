@@ -39,6 +39,7 @@ extern "C" int am355_set_shard(am355_ctx* c, uint32_t rank, uint32_t world) {
 extern "C" int am355_fragment_size(am355_ctx* c, size_t* bytes) {
   if (!c || !bytes) return AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");
+  { int frc = ensure_ir_fresh(c); if (frc) return frc; }
   *bytes = (size_t)fragment_layout(c->shard_world, c->shard_rank, c->counts).total;
   return AM355_OK;
 }
@@ -47,6 +48,7 @@ extern "C" int am355_export_fragment(am355_ctx* c, void* dst, size_t cap, int ds
   if (!c || !dst || !len) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   if (!c->replayed) return fail(c, AM355_E_STATE, "am355_replay must succeed first");
   (void)hipSetDevice(c->device);
+  { int frc = ensure_ir_fresh(c); if (frc) return frc; }
   FragmentHeader h = fragment_layout(c->shard_world, c->shard_rank, c->counts);
   if (h.total > cap) return fail(c, AM355_E_ARG, "fragment needs %llu bytes, buffer has %llu", (unsigned long long)h.total, (unsigned long long)cap);
   hipStream_t st = c->stream;

@@ -331,10 +331,11 @@ class Engine:
         self._check(self._L.am355_shard_finalize(self._h))
 
     def resident_counters(self):
-        """(calls of apply_changes that merged the batch alone into the resident state, calls that asked for it and took the full replay)."""
-        out = (ctypes.c_uint64 * 2)()
+        """(calls of apply_changes that merged the batch alone into the resident state, calls that asked for it and took the full replay,
+        calls of the first kind that also merged their new list elements into the stored order in place)."""
+        out = (ctypes.c_uint64 * 3)()
         self._check(self._L.am355_resident_counters(self._h, out))
-        return int(out[0]), int(out[1])
+        return int(out[0]), int(out[1]), int(out[2])
 
     def raw(self):
         """(arena, offsets) as staged: the uncompressed change containers back to back (copies)."""

@@ -345,9 +345,10 @@ int am355_sharded_replay(am355_ctx *ctx, int stitch_on_all_ranks);
 int am355_shard_fragment_bytes(am355_ctx *ctx, uint64_t *bytes, uint32_t capacity);
 int am355_shard_finalize(am355_ctx *ctx);
 
-/* diagnostics: how many am355_apply_changes calls on this context merged the batch alone into the resident state (out[0]) and how
- * many took the full replay although they asked for it (out[1]: new actor, dependency not applied yet, duplicate, capacity ...) */
-int am355_resident_counters(const am355_ctx *ctx, uint64_t out[2]);
+/* diagnostics: how many am355_apply_changes calls on this context merged the batch alone into the resident state (out[0]), how
+ * many took the full replay although they asked for it (out[1]: new actor, dependency not applied yet, duplicate, capacity ...), and
+ * how many of the first kind also merged their new list elements into the stored document order in place (out[2]) */
+int am355_resident_counters(const am355_ctx *ctx, uint64_t out[3]);
 
 /* ---- diagnostics: device primitives exposed for kernel-level tests ---- */
 int am355_test_sort(am355_ctx *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, int key_bits);

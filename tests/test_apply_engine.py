@@ -258,7 +258,7 @@ def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
         eng = engine.Engine(0, emu_lib)
         try:
             check_against_oracle_session(eng, batches)
-            served, fell_back = eng.resident_counters()
+            served, fell_back, in_place = eng.resident_counters()
             assert served >= len(batches) - 3 and fell_back <= 1, (served, fell_back, len(batches))
         finally:
             eng.close()
@@ -268,7 +268,7 @@ def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
     eng = engine.Engine(0, emu_lib)
     try:
         check_against_oracle_session(eng, _one_by_one(log, head))
-        assert eng.resident_counters() == (0, 0)
+        assert eng.resident_counters() == (0, 0, 0)
     finally:
         eng.close()
     monkeypatch.delenv("AM355_NO_RESIDENT")
@@ -277,7 +277,7 @@ def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
     eng = engine.Engine(0, emu_lib)
     try:
         check_against_oracle_session(eng, _one_by_one(late, 1))
-        served, fell_back = eng.resident_counters()
+        served, fell_back, _ = eng.resident_counters()
         assert fell_back >= 4 and served >= 8, (served, fell_back)
     finally:
         eng.close()
@@ -291,6 +291,50 @@ def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
         assert eng.resident_counters()[0] >= len(ch) - 14
     finally:
         eng.close()
+
+
+def test_resident_list_order_merged_in_place_emulated(emu_lib, monkeypatch):
+    """am355_resorder.hip: the new elements of a small list-only batch are ranked against the STORED order (forward scan for the first
+    smaller id behind the reference element, roots of one gap by descending id, typing runs behind their roots). Change by change on
+    concurrent text edits -- insertions at the same spots by several actors, deletions, two objects --; after every third call the
+    whole-document patch is asked for, which rebuilds the tables from scratch and (AM355_RESORDER_VERIFY) compares the order computed
+    from scratch with the one the in-place merges left; every incremental patch and every getPatch equal the oracle session's."""
+    monkeypatch.setenv("AM355_RESORDER_VERIFY", "1")
+    logs = [
+        loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=5, ins_per_change=9, del_per_change=3, n_objects=2, seed=71),
+        loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=8, ins_per_change=3, del_per_change=1, n_objects=1, seed=72),   # short runs: many roots per object
+        loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=300, ops_per_change=7, seed=73),
+    ]
+    for log in logs:
+        arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+        ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+        head = max(2, len(ch) // 4)
+        batches = [ch[:head]]
+        k, size = head, 1
+        while k < len(ch):
+            batches.append(ch[k:k + size])
+            k += size
+            size = size % 3 + 1
+        eng = engine.Engine(0, emu_lib)
+        session = oracle_lib.OracleSession()
+        try:
+            for i, batch in enumerate(batches):
+                want = session.apply(batch)
+                eng.apply_changes(ChangeLog.from_changes(batch))
+                assert same_patch(eng.apply_patch_json(), want), f"batch {i}"
+                if i % 3 == 2:
+                    assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"getPatch after batch {i}"
+            assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"]
+            doc = eng.save()
+            eng2 = engine.Engine(0, emu_lib)
+            eng2.load_changes(log)
+            eng2.replay()
+            assert bytes(doc) == bytes(eng2.save())    # Backend.save of the state the in-place merges built == of the bulk replay
+            eng2.close()
+            served, fell_back, in_place = eng.resident_counters()
+            assert in_place >= (len(batches) - 1) // 2, (served, fell_back, in_place, len(batches))
+        finally:
+            eng.close()
 
 
 def test_batches_behind_the_staged_changes_or_restaged_emulated(emu_lib, monkeypatch):
@@ -582,8 +626,8 @@ def test_resident_state_200_small_batches_gpu():
             if i % 25 == 0:
                 assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"getPatch after batch {i}"
         assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"]
-        served, fell_back = eng.resident_counters()
-        assert served >= 195 and fell_back <= 2, (served, fell_back)
+        served, fell_back, in_place = eng.resident_counters()
+        assert served >= 195 and fell_back <= 2 and in_place >= 150, (served, fell_back, in_place)
     finally:
         eng.close()
 
