@@ -89,7 +89,40 @@ int patch_json_impl(am355_ctx* c, const char** json, size_t* len) {
 // ---------------------------------------------------------------------------------------------------------
 
 // the device stage of am355_apply_changes over the replayed state of the context: rows >= T0 are the batch
-static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool check_only) {
+// (tail: the host copies of the stage's tables, enqueued by the stage itself in front of its last wait -- apply_tail_enqueue below)
+struct ApplyTail {
+  am355_ctx* c = nullptr;
+  uint32_t n_obj = 0, n_dmap = 0;
+  size_t edit_records = 0;       // records of d.edit on their way (>= n_erecs + 1 when the stage ends well)
+  ObjLink* h_link = nullptr;
+  am355_ir_map* h_map = nullptr;
+  am355_ir_edit* h_edit = nullptr;
+  bool enqueued = false;
+};
+static void apply_tail_enqueue(am355_ctx* c, ApplyTail* t, const DeltaCounts* mid, size_t rec_bound) {
+  // a bounded guess of the edit table is cheap for the small batches this is for: larger ones copy the exact size after the last wait
+  if (!t) return;
+  t->enqueued = false;   // (a second call of one stage: what the first put on its way is not what the stage ends with)
+  if (rec_bound * sizeof(am355_ir_edit) > ((size_t)256 << 10)) return;
+  hipStream_t st = c->stream;
+  DeltaBufs& d = c->delta;
+  const uint32_t NO = t->n_obj, n_dmap = mid->n_kept + mid->n_place;
+  const size_t n_rec = std::min<size_t>(rec_bound, d.edit_cap);
+  const size_t b_link = carve_size(NO, sizeof(ObjLink)), b_map = carve_size(n_dmap, sizeof(am355_ir_map)), b_edit = carve_size(n_rec, sizeof(am355_ir_edit));
+  if (!c->h_delta.ensure(b_link + b_map + b_edit + 256)) return;
+  uint8_t* hp = c->h_delta.as<uint8_t>();
+  t->h_link = (ObjLink*)hp;
+  t->h_map = (am355_ir_map*)(hp + b_link);
+  t->h_edit = (am355_ir_edit*)(hp + b_link + b_map);
+  if (hipMemcpyAsync(t->h_link, d.link, sizeof(ObjLink) * (size_t)NO, hipMemcpyDeviceToHost, st) != hipSuccess) return;
+  if (n_dmap && hipMemcpyAsync(t->h_map, d.map, sizeof(am355_ir_map) * (size_t)n_dmap, hipMemcpyDeviceToHost, st) != hipSuccess) return;
+  if (hipMemcpyAsync(t->h_edit, d.edit, sizeof(am355_ir_edit) * n_rec, hipMemcpyDeviceToHost, st) != hipSuccess) return;
+  t->n_dmap = n_dmap;
+  t->edit_records = n_rec;
+  t->enqueued = true;
+}
+
+static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool check_only, ApplyTail* tail = nullptr) {
   hipStream_t st = c->stream;
   const uint32_t N = (uint32_t)c->n_ops, NN = N - T0;
   const uint32_t NO = c->counts.n_objects, NM = c->counts.n_map_emit, NL = c->counts.n_list_ins;
@@ -131,7 +164,16 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
     am355_ctx* cx = (am355_ctx*)user;
     return cx->d_delta_edit.ensure(sizeof(am355_ir_edit) * records) ? cx->d_delta_edit.as<am355_ir_edit>() : nullptr;
   };
-  delta_run(c->mb, c->ir, d, hc, st, check_only, grow, c);
+  d.sig = c->h_sig.as<HostSignals>();
+  d.sig_seq = ++c->sig_seq;
+  d.list_only = T0 && c->batch_list_only && !check_only ? 1u : 0u;
+  c->apply_tail = tail;
+  auto before_end = [](void* user, const DeltaCounts* mid, size_t rec_bound) {
+    am355_ctx* cx = (am355_ctx*)user;
+    apply_tail_enqueue(cx, (ApplyTail*)cx->apply_tail, mid, rec_bound);
+  };
+  delta_run(c->mb, c->ir, d, hc, st, check_only, grow, c, tail ? (DeltaBeforeEnd)before_end : nullptr);
+  c->apply_tail = nullptr;
   HIPCHK(c, hipGetLastError());
   return AM355_OK;
 }
@@ -268,7 +310,13 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
   // A call refused from here on leaves the context WITHOUT a state (include/am355.h): the replay above merged the batch, and a later
   // call must not get patches relative to a state that silently holds a batch whose call boundary nobody recorded.
   auto drop_state = [&](int code) { c->staged = c->replayed = c->ir_fetched = false; return code; };
-  rc = run_delta_stage(c, (uint32_t)old_ops, &hc, false);
+  // (the whole-document object / map tables setupPatches reads are final since the replay: their copy goes in front of the stage and is
+  // covered by the stage's first wait; the stage's own tables follow behind its last kernel -- ApplyTail)
+  if (!c->ir_fetched && c->ir_copy_enqueued < 1) { int erc = ir_copy_enqueue(c, false); if (erc) return drop_state(erc); }
+  ApplyTail tail;
+  tail.c = c;
+  tail.n_obj = NO;
+  rc = run_delta_stage(c, (uint32_t)old_ops, &hc, false, &tail);
   if (rc) return drop_state(rc);
   lap("delta stage");
   c->state_checked = true;  // (a call the engine served: checked; a refused call leaves the state to the JS path)
@@ -287,16 +335,23 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
   if (rc) return drop_state(rc);
   lap("document tables on the host");
   const uint32_t n_dmap = hc.n_kept + hc.n_place, n_dedits = hc.n_erecs;
-  size_t b_link = carve_size(NO, sizeof(ObjLink)), b_map = carve_size(n_dmap, sizeof(am355_ir_map)), b_edit = carve_size((size_t)n_dedits + 1, sizeof(am355_ir_edit));
-  if (!c->h_delta.ensure(b_link + b_map + b_edit + 256)) return fail(c, AM355_E_NOMEM, "host allocation failed");
-  uint8_t* hp = c->h_delta.as<uint8_t>();
-  ObjLink* h_link = (ObjLink*)hp;
-  am355_ir_map* h_map = (am355_ir_map*)(hp + b_link);
-  am355_ir_edit* h_edit = (am355_ir_edit*)(hp + b_link + b_map);
-  HIPCHK(c, hipMemcpyAsync(h_link, d.link, sizeof(ObjLink) * (size_t)NO, hipMemcpyDeviceToHost, st));
-  if (n_dmap) HIPCHK(c, hipMemcpyAsync(h_map, d.map, sizeof(am355_ir_map) * (size_t)n_dmap, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(h_edit, d.edit, sizeof(am355_ir_edit) * ((size_t)n_dedits + 1), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
+  ObjLink* h_link;
+  am355_ir_map* h_map;
+  am355_ir_edit* h_edit;
+  if (tail.enqueued && tail.n_dmap == n_dmap && (size_t)n_dedits + 1 <= tail.edit_records) {
+    h_link = tail.h_link; h_map = tail.h_map; h_edit = tail.h_edit;   // (on the host since the stage's last wait)
+  } else {
+    size_t b_link = carve_size(NO, sizeof(ObjLink)), b_map = carve_size(n_dmap, sizeof(am355_ir_map)), b_edit = carve_size((size_t)n_dedits + 1, sizeof(am355_ir_edit));
+    if (!c->h_delta.ensure(b_link + b_map + b_edit + 256)) return fail(c, AM355_E_NOMEM, "host allocation failed");
+    uint8_t* hp = c->h_delta.as<uint8_t>();
+    h_link = (ObjLink*)hp;
+    h_map = (am355_ir_map*)(hp + b_link);
+    h_edit = (am355_ir_edit*)(hp + b_link + b_map);
+    HIPCHK(c, hipMemcpyAsync(h_link, d.link, sizeof(ObjLink) * (size_t)NO, hipMemcpyDeviceToHost, st));
+    if (n_dmap) HIPCHK(c, hipMemcpyAsync(h_map, d.map, sizeof(am355_ir_map) * (size_t)n_dmap, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_edit, d.edit, sizeof(am355_ir_edit) * ((size_t)n_dedits + 1), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
   std::string err;
   std::unordered_map<uint32_t, KeyHistory> known;
   std::vector<uint32_t> need;

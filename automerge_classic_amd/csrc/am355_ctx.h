@@ -50,10 +50,13 @@ struct DevBuf {
     if (bytes <= cap) return true;
     lost++;
     canary_forget(p, cap);
+    // (a buffer that grows AGAIN belongs to a document that is growing call by call -- Backend.applyChanges in a loop --: half as much
+    // again, so that a reallocation, ~1 ms of hipFree + hipMalloc, comes once in dozens of calls instead of once in a few)
+    const size_t slack = cap ? bytes / 2 : bytes / 8;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 8 + 256 + (canary_on() ? (128u << 10) : 0u);
+    size_t want = bytes + slack + 256 + (canary_on() ? (128u << 10) : 0u);
     if (hipMalloc(&p, want) != hipSuccess) return false;
     cap = want;
     return true;
@@ -343,6 +346,7 @@ struct am355_ctx {
   ChangeMeta doc_meta{};             // column layout of the staged document inside `raw`
   std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
   DevBuf d_arena, d_offsets, d_metas;
+  bool offsets_on_device = false;      // d_offsets holds raw_off of every staged change (a batch staged behind a kept state defers the copy)
   HostBuf h_metas, h_offsets, h_sig;   // h_sig: HostSignals (device -> host result words without a copy)
   uint32_t sig_seq = 0;
   hipEvent_t ev_s1 = nullptr;          // the per-change digests (briefs) have arrived on the host
@@ -440,6 +444,8 @@ struct am355_ctx {
   bool device_scheduled = false;   // the last general-path replay was scheduled by the device (am355_sched.hip)
   HostBuf h_delta;
   DeltaBufs delta{};
+  bool batch_list_only = false;      // the last replay merged a batch of plain list edits in place (replay_resident): no map row among the new rows
+  void* apply_tail = nullptr;        // (am355_calls.hip ApplyTail of the delta stage that is running)
   ApplyPatch apply;
   bool apply_ready = false;
   std::vector<uint32_t> dep_first, dep_index;   // am355_get_dep_graph
@@ -573,6 +579,7 @@ static inline int error_for_flags(am355_ctx* c, uint32_t f, const char* what) {
 // staging (am355_stage.hip)
 bool read_uleb_host(const uint8_t* p, size_t len, size_t& off, uint64_t& out);
 int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n, bool keep_staged = false);
+int upload_offsets(am355_ctx* c);   // the staged changes' offsets table to HBM, if it is not there (am355_stage.hip)
 int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_checksum = false);
 int backend_load_impl(am355_ctx* c, const uint8_t* doc, size_t len);
 int ir_copy_enqueue(am355_ctx* c, bool with_edits);

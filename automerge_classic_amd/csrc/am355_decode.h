@@ -10,6 +10,8 @@ struct ParseFills {
   uint32_t value[5];
   uint32_t n;
 };
+// the same records computed by the host from the bytes it holds (parse_change compiled for the host; small batches)
+void parse_changes_host(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries);
 void launch_parse_changes(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries, const ParseFills& fills,
                           hipStream_t st, bool fat = false);
 // decoder class of a parsed change for a host-built plan (what k_actor_check writes into ChangeBrief.flags_fits): 2 small wave class,

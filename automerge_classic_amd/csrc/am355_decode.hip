@@ -28,7 +28,7 @@ namespace am355 {
 struct __attribute__((packed)) U8B {
   uint64_t v;
 };
-__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) { return ((const U8B*)p)->v; }
+__host__ __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) { return ((const U8B*)p)->v; }
 #ifdef AM355_LDS_IS_DISTINCT
 __device__ __forceinline__ uint64_t load_u64_unaligned(LdsBytes p) { return ((const __attribute__((address_space(3))) U8B*)p)->v; }
 #endif
@@ -40,10 +40,10 @@ struct CurT {
   uint32_t off, len;
   uint64_t win;
   uint32_t win_off;  // window holds bytes [win_off, win_off + 8); WIN_EMPTY makes every offset miss
-  __device__ __forceinline__ CurT() {}
+  __host__ __device__ __forceinline__ CurT() {}
   static constexpr uint32_t WIN_EMPTY = 0xffffff00u;  // o - WIN_EMPTY = o + 256 >= 8 for every valid offset
-  __device__ __forceinline__ CurT(P p_, uint32_t off_, uint32_t len_) : p(p_), off(off_), len(len_), win(0), win_off(WIN_EMPTY) {}
-  __device__ __forceinline__ uint32_t byte_at(uint32_t o) {
+  __host__ __device__ __forceinline__ CurT(P p_, uint32_t off_, uint32_t len_) : p(p_), off(off_), len(len_), win(0), win_off(WIN_EMPTY) {}
+  __host__ __device__ __forceinline__ uint32_t byte_at(uint32_t o) {
     uint32_t d = o - win_off;
     if (d >= 8) {
       // refill; near the end of the buffer fall back to byte loads so nothing beyond `len` is touched
@@ -94,7 +94,7 @@ constexpr uint64_t MAX_SAFE = 9007199254740991ull;  // 2^53 - 1
 
 // encoding.js:389-396 + 410-436: at most 10 bytes / 64 bits, result must fit in 53 bits
 template <class C>
-__device__ __forceinline__ bool read_uleb(C& c, uint64_t& out) {
+__host__ __device__ __forceinline__ bool read_uleb(C& c, uint64_t& out) {
   uint64_t v = 0;
   int shift = 0;
   while (c.off < c.len) {
@@ -113,7 +113,7 @@ __device__ __forceinline__ bool read_uleb(C& c, uint64_t& out) {
 
 // encoding.js:398-408 + 438-488
 template <class C>
-__device__ __forceinline__ bool read_sleb(C& c, int64_t& out) {
+__host__ __device__ __forceinline__ bool read_sleb(C& c, int64_t& out) {
   uint64_t v = 0;
   int shift = 0;
   while (c.off < c.len) {
@@ -133,7 +133,7 @@ __device__ __forceinline__ bool read_sleb(C& c, int64_t& out) {
 }
 
 template <class C>
-__device__ __forceinline__ bool skip_bytes(C& c, uint64_t n) {
+__host__ __device__ __forceinline__ bool skip_bytes(C& c, uint64_t n) {
   if (n > (uint64_t)(c.len - c.off)) return false;
   c.off += (uint32_t)n;
   return true;
@@ -252,7 +252,7 @@ __device__ void sha256_bytes(const uint8_t* p, uint32_t len, uint8_t out[32]) {
 // k_parse_changes: one lane per change.  Container header, checksum, change header, column directory, row and
 // pred counts (run-level scan of the action / predNum columns).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int col_slot(uint64_t id) {
+__host__ __device__ __forceinline__ int col_slot(uint64_t id) {
   switch (id) {
     case 0x01: return C_OBJ_ACTOR;
     case 0x02: return C_OBJ_CTR;
@@ -276,7 +276,7 @@ __device__ __forceinline__ int col_slot(uint64_t id) {
 // ~100 instructions per byte, and this walk is one lane's: for a change of 313 ops with pred lists it was 80 us of k_parse_changes,
 // measured with the kernel's clock. Literal runs of one-byte values are summed eight bytes at a time.)
 template <class P>
-__device__ __forceinline__ bool rle_count_sum(P p, uint32_t len, uint64_t& count, uint64_t& sum) {
+__host__ __device__ __forceinline__ bool rle_count_sum(P p, uint32_t len, uint64_t& count, uint64_t& sum) {
   uint32_t off = 0;
   count = 0;
   sum = 0;
@@ -345,7 +345,7 @@ constexpr uint32_t PARSE_STAGE = 8192;
 
 // header + column directory of one change, read through `p` (LDS when the change was staged, else global memory)
 template <class P>
-__device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len64, ChangeMeta* out, uint32_t* n_entries_out) {
+__host__ __device__ __forceinline__ void parse_change(P p, uint64_t base64, uint64_t len64, ChangeMeta* out, uint32_t* n_entries_out) {
   bool stored = false;
   uint32_t unknown_cols = 0;
   ChangeMeta m;
@@ -782,6 +782,16 @@ __global__ __launch_bounds__(WAVE) void k_parse_changes(const uint8_t* __restric
   // two instantiations so that the staged case reads LDS with ds_read instead of FLAT loads through a generic pointer
   if (staged) parse_change((LdsBytes)stage, base64, total64, &metas[c], &n_entries[c]);
   else parse_change(arena + base64, base64, total64, &metas[c], &n_entries[c]);
+}
+
+// The same records for a handful of changes whose bytes the host has at hand (am355_replay.hip replay_resident: the batch of a
+// Backend.applyChanges onto a kept state): parse_change() above, compiled for the host -- a kernel launch, a copy back and the wait for
+// both cost ~25 us, the walk of a change's header a microsecond. The device never sees a different parser: this IS parse_change.
+void parse_changes_host(const uint8_t* arena, const uint64_t* offsets, uint32_t n_changes, ChangeMeta* metas, uint32_t* n_entries) {
+  for (uint32_t i = 0; i < n_changes; i++) {
+    const uint64_t base = offsets[i], len = offsets[i + 1] - offsets[i];
+    parse_change<const uint8_t*>(arena + base, base, len, &metas[i], &n_entries[i]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

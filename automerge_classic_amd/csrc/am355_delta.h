@@ -33,7 +33,7 @@ struct DeltaCounts {
   uint32_t hazard;     // a key that holds a visible child object lost values to the merge loop's skipping rule (see kd_placeholders)
   uint32_t reason;     // DR_*: why the call is refused (the smallest code raised), NONE32: not refused by this stage
   uint32_t rec_extra;  // edit records beyond one per item: an update / re-insert item writes one record per visible value (kd_events)
-  uint32_t pad;
+  uint32_t deferred;   // kd_edit_small left the second half of the stage to the host (more items / records than one workgroup takes, map records)
 };
 enum : uint32_t {
   DR_FOREIGN_ROW = 1,     // a row of an object another shard owns
@@ -97,6 +97,10 @@ struct DeltaBufs {
   am355_ir_map* map;                                  // [NM + cap + 1]
   void* scan_ws;
   void* sort_ws;
+  // counters to the host through pinned words instead of a copy + a blocking wait (am355_internal.h HostSignals; nullptr: copies)
+  HostSignals* sig;
+  uint32_t sig_seq;
+  uint32_t list_only;   // the caller knows that no new row is a map row (am355_resorder.hip served the batch): the stage's map kernels are not launched
 };
 
 enum : uint32_t { EV_NONE = 0, EV_INSERT = 1, EV_REMOVE = 2, EV_UPDATE = 3 };
@@ -111,8 +115,12 @@ void delta_bind(DeltaBufs& d, void* block, uint32_t n_ops, uint32_t n_new, uint3
 // grow_edit(records): device memory for that many edit records (the caller owns it), nullptr = out of memory. An item of a conflicted
 // list element writes one record per visible value, so the records can outnumber the new rows the block was carved for.
 typedef am355_ir_edit* (*DeltaGrowEdit)(void* user, size_t records);
+// before_end(mid, rec_bound): called when every kernel of the stage is enqueued and nothing has been waited for since the first half:
+// *mid holds the first half's counters (n_kept, n_place: final), rec_bound >= n_erecs + 1. The caller may enqueue the copies of the
+// tables it wants (d.link, d.map, at most rec_bound records of d.edit) on `st`: the stage's last wait then covers them too.
+typedef void (*DeltaBeforeEnd)(void* user, const DeltaCounts* mid, size_t rec_bound);
 void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only = false, DeltaGrowEdit grow_edit = nullptr,
-               void* grow_user = nullptr);
+               void* grow_user = nullptr, DeltaBeforeEnd before_end = nullptr);
 
 // What the reference's objectMeta holds in `children[key]` for the property (map key or list element) that holds -- or held -- each
 // of the given objects: the visible values, or nothing (KH_DEAD). It is refreshed only while it is non-empty or a child object is

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(BLOCK) void kd_partition(DeltaBufs d, int src, uint
 // All levels in one workgroup with the items in LDS: a batch of a few changes has a few hundred items and would otherwise spend two
 // launches per level of a dozen levels on them.
 constexpr uint32_t PART_LDS_MAX = 1024;  // items (4 per thread)
-__global__ __launch_bounds__(BLOCK) void kd_partition_lds(DeltaBufs d, uint32_t m, uint32_t bits) {
+__device__ __forceinline__ void partition_lds_block(const DeltaBufs& d, uint32_t m, uint32_t bits) {
   __shared__ uint32_t s_tk[2][PART_LDS_MAX], s_el[2][PART_LDS_MAX], s_acc[2][PART_LDS_MAX], s_lh[2][PART_LDS_MAX];  // lo | hi << 16
   __shared__ uint32_t s_zf[PART_LDS_MAX + 1], s_zw[PART_LDS_MAX + 1], s_scan[BLOCK / WAVE];
   const uint32_t t = threadIdx.x;
@@ -639,6 +639,7 @@ __global__ __launch_bounds__(BLOCK) void kd_partition_lds(DeltaBufs d, uint32_t 
     d.lo[out][i] = s_lh[cur][i] & 0xffffu; d.hi[out][i] = s_lh[cur][i] >> 16;
   }
 }
+__global__ __launch_bounds__(BLOCK) void kd_partition_lds(DeltaBufs d, uint32_t m, uint32_t bits) { partition_lds_block(d, m, bits); }
 
 // The same for up to PART_BIG_MAX items -- the list edits of a few dozen changes -- in ONE workgroup of 1024 threads with 158 KB of the
 // CU's 160 KB of LDS: the level-by-level version spends three dependent launches (~15-24 us) on each of 13-15 levels there. Every
@@ -720,9 +721,7 @@ __global__ __launch_bounds__(PART_BIG_THREADS) void kd_partition_lds_big(MergeBu
 }
 
 // items are now in (object, time) order: index of each edit
-__global__ __launch_bounds__(BLOCK) void kd_edit_index(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
-  uint32_t i = gtid();
-  if (i >= m) return;
+__device__ __forceinline__ void edit_index_item(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t i) {
   uint32_t tk = d.tk[src][i], e = d.elem[src][i];
   uint32_t t = tk >> 2, g = d.T0 + t;
   uint32_t oi = obj_index_of(b, b.obj_row[e]);
@@ -732,6 +731,10 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_index(MergeBufs b, DeltaBufs d,
   // its visibility before the batch to its visibility just before this item
   if (g != e) idx -= (d.ev_before[t] & 1u) - d.v0[p] + (d.ev_before[t] >> 1);  // (bit 1: the reference's index lag, kd_events)
   d.e_index[i] = idx;
+}
+__global__ __launch_bounds__(BLOCK) void kd_edit_index(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
+  uint32_t i = gtid();
+  if (i < m) edit_index_item(b, d, src, i);
 }
 
 // ---- the edits array (new.js:747-869), item by item -------------------------------------------------------------------------
@@ -772,9 +775,7 @@ __device__ __forceinline__ uint32_t continues_multi_insert(const MergeBufs& b, c
 
 constexpr uint32_t POP_WALK_MAX = 1u << 16;  // update items at one index in a row the LAST of them walks back over (more: refused)
 
-__global__ __launch_bounds__(BLOCK) void kd_edit_runs(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
-  uint32_t i = gtid();
-  if (i > m) return;
+__device__ __forceinline__ void edit_runs_item(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t m, uint32_t i) {   // i <= m
   if (i == m) { d.e_head[i] = 0; d.e_val[i] = 0; return; }
   const OpCols& o = b.ops;
   ItemView v = item_view(b, d, src, i);
@@ -833,10 +834,12 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_runs(MergeBufs b, DeltaBufs d, 
   d.e_head[i] = recs;
   d.e_val[i] = vals;
 }
-
-__global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
+__global__ __launch_bounds__(BLOCK) void kd_edit_runs(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
   uint32_t i = gtid();
-  if (i > m) return;
+  if (i <= m) edit_runs_item(b, d, src, m, i);
+}
+
+__device__ __forceinline__ void edit_pack_item(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t m, uint32_t i) {   // i <= m
   if (i == m) {
     uint32_t n = d.e_head_ex[m];
     d.edit[n] = am355_ir_edit{0, 0, 0, 0, 0, 0, d.e_val_ex[m], 0, 0, 0};
@@ -902,6 +905,52 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, 
   }
   if (f & 0x100u) d.link[v.oi].edit_begin = k;
   if (f & 0x200u) d.link[v.oi].edit_end = d.e_head_ex[i + 1];
+}
+__global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
+  uint32_t i = gtid();
+  if (i <= m) edit_pack_item(b, d, src, m, i);
+}
+
+// The whole second half of the stage for a batch of a change or two, in ONE workgroup: the partition levels in LDS, the index of every
+// edit, the runs, their two prefix sums and the records -- six launches and, in front of them, the host's wait for the item count
+// (which sizes their grids) otherwise: ~45 us of a call that takes 0.3 ms, most of it the host's launch rate. The item count is read
+// HERE; what this workgroup does not handle -- more than PART_LDS_MAX items, map records to order, more edit records than the table holds
+// -- is left alone and reported through DeltaCounts.deferred: the host then runs the second half as it does for larger batches.
+__global__ __launch_bounds__(BLOCK) void kd_edit_small(MergeBufs b, DeltaBufs d) {
+  __shared__ uint32_t s_scan[BLOCK / WAVE];
+  const DeltaCounts c = *d.counts;
+  if (c.flags) return;   // (refused by the first half: nothing to build)
+  const uint32_t m = c.n_items;
+  if (m > PART_LDS_MAX || c.n_kept + c.n_place != 0 || (uint64_t)m + c.rec_extra + 2 > d.edit_cap) {
+    if (threadIdx.x == 0) d.counts->deferred = 1;
+    return;
+  }
+  const uint32_t t = threadIdx.x;
+  int src = 0;
+  if (m) {
+    partition_lds_block(d, m, d.bits_new);
+    src = (int)(d.bits_new & 1u);
+    __syncthreads();
+    for (uint32_t i = t; i < m; i += BLOCK) edit_index_item(b, d, src, i);
+    __syncthreads();
+  }
+  for (uint32_t i = t; i <= m; i += BLOCK) edit_runs_item(b, d, src, m, i);
+  __syncthreads();
+  {
+    // e_head_ex / e_val_ex over the m + 1 entries: a thread takes `per` consecutive ones
+    const uint32_t n = m + 1, per = (n + BLOCK - 1) / BLOCK, i0 = t * per < n ? t * per : n, i1 = i0 + per < n ? i0 + per : n;
+    uint32_t hs = 0, vs = 0;
+    for (uint32_t i = i0; i < i1; i++) { hs += d.e_head[i]; vs += d.e_val[i]; }
+    uint32_t tot;
+    uint32_t hb = block_exclusive_scan_u32(hs, s_scan, &tot), vb = block_exclusive_scan_u32(vs, s_scan, &tot);
+    for (uint32_t i = i0; i < i1; i++) {
+      const uint32_t h = d.e_head[i], v = d.e_val[i];
+      d.e_head_ex[i] = hb; d.e_val_ex[i] = vb;
+      hb += h; vb += v;
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = t; i <= m; i += BLOCK) edit_pack_item(b, d, src, m, i);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1051,7 +1100,18 @@ static int dbits_for(uint64_t max_value) {
   return b;
 }
 
-void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only, DeltaGrowEdit grow_edit, void* grow_user) {
+void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStream_t st, bool check_only, DeltaGrowEdit grow_edit, void* grow_user,
+               DeltaBeforeEnd before_end) {
+  // the counters of a half: through the pinned words a one-thread launch behind it signals (no copy dispatch, no interrupt wake-up: ~30 us
+  // of a 0.15 ms stage), or -- no signal block, or no signal -- by a copy after a drain
+  auto read_counts = [&](volatile uint32_t* seq_word, uint32_t* words) {
+    if (d.sig) {
+      launch_signal_words((const uint32_t*)d.counts, (uint32_t)(sizeof(DeltaCounts) / 4), nullptr, 0, words, seq_word, d.sig_seq, st);
+      if (wait_host_signal(seq_word, d.sig_seq, st)) { *hc = *(const DeltaCounts*)words; return; }
+    }
+    (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+  };
   const uint32_t N = b.n_ops, cap = d.key_mask + 1;
   static const bool debug = getenv("AM355_DELTA_DEBUG") != nullptr;  // (diagnostic: drain the stream after every step and say which)
   auto step = [&](const char* what) {
@@ -1106,18 +1166,36 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   if (d.n_new && d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items, dgrid(d.n_new), dim3(BLOCK), st, b, d);
   if (d.n_list) AM355_LAUNCH_INDEPENDENT(kd_items_sort, dgrid(d.n_list), dim3(BLOCK), st, d);
   step("items");
-  // ---- maps: touched keys, kept records, placeholders ----
-  AM355_LAUNCH_INDEPENDENT(kd_slots, dgrid(cap), dim3(BLOCK), st, b, d);
-  step("slots");
-  AM355_LAUNCH_INDEPENDENT(kd_map_records, dgrid(d.n_map + 1), dim3(BLOCK), st, b, ir, d);
-  step("map records");
-  AM355_LAUNCH_INDEPENDENT(kd_placeholders, dgrid(cap + 1), dim3(BLOCK), st, d);
-  step("placeholders");
-  exclusive_scan_u32(d.keep, d.keep_ex, d.n_map + 1, &d.counts->n_kept, d.scan_ws, st);
-  exclusive_scan_u32(d.place, d.place_ex, cap + 1, &d.counts->n_place, d.scan_ws, st);
-  step("scans");
-  (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
+  // ---- maps: touched keys, kept records, placeholders (a batch without map rows touches no key: n_kept = n_place = 0 as filled) ----
+  const bool all_kernels = getenv("AM355_DELTA_ALL_KERNELS") != nullptr;   // (tests, A/B: read per call)
+  if (!d.list_only || all_kernels) {
+    AM355_LAUNCH_INDEPENDENT(kd_slots, dgrid(cap), dim3(BLOCK), st, b, d);
+    step("slots");
+    AM355_LAUNCH_INDEPENDENT(kd_map_records, dgrid(d.n_map + 1), dim3(BLOCK), st, b, ir, d);
+    step("map records");
+    AM355_LAUNCH_INDEPENDENT(kd_placeholders, dgrid(cap + 1), dim3(BLOCK), st, d);
+    step("placeholders");
+    exclusive_scan_u32(d.keep, d.keep_ex, d.n_map + 1, &d.counts->n_kept, d.scan_ws, st);
+    exclusive_scan_u32(d.place, d.place_ex, cap + 1, &d.counts->n_place, d.scan_ws, st);
+    step("scans");
+  }
+  // ---- a small batch: the second half in one workgroup, behind the first without a word from the host in between (kd_edit_small) ----
+  const bool no_small = getenv("AM355_DELTA_NO_SMALL") != nullptr;   // (tests, A/B: read per call)
+  // (for batches the caller knows to be plain list edits: a batch with map rows has records to order, which this workgroup leaves to the
+  //  host -- an attempt that ends so costs a round trip more than it could have saved)
+  if (d.sig && d.list_only && !check_only && !no_small && d.n_new <= PART_LDS_MAX && getenv("AM355_DELTA_NO_LDS") == nullptr) {
+    hipLaunchKernelGGL(kd_edit_small, dim3(1), dim3(BLOCK), 0, st, b, d);
+    step("edit small");
+    if (before_end) {
+      DeltaCounts none{};   // (no map records in what kd_edit_small serves)
+      before_end(grow_user, &none, d.edit_cap);
+    }
+    read_counts(&d.sig->delta_mid_seq, d.sig->delta_mid);   // (the slot of the first half: when the work was left to the host, that is what this is)
+    if (hc->flags || !hc->deferred) return;
+    hc->deferred = 0;   // (not served there: the counters are the first half's, the tables untouched -- on as for a larger batch)
+  } else {
+    read_counts(d.sig ? &d.sig->delta_mid_seq : nullptr, d.sig ? d.sig->delta_mid : nullptr);
+  }
   if (hc->flags || check_only) return;
 
   // ---- list edits: dominance counts by binary partitions on the time bits, most significant first ----
@@ -1170,8 +1248,11 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     AM355_LAUNCH_INDEPENDENT(kd_map_out, dgrid(nm), dim3(BLOCK), st, b, ir, d, (const uint64_t*)d.pair_key[res], (const uint32_t*)d.pair_val[res], nm);
     step("map out");
   }
-  (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
+  if (before_end) {
+    const DeltaCounts mid = *hc;
+    before_end(grow_user, &mid, rec_bound);
+  }
+  read_counts(d.sig ? &d.sig->delta_end_seq : nullptr, d.sig ? d.sig->delta_end : nullptr);
   hc->n_items = m;
 }
 

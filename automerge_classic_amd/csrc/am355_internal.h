@@ -91,6 +91,13 @@ struct HostSignals {
   uint32_t runs[16];             // Counts after k_run_heads
   volatile uint32_t final_seq;   uint32_t pad3[15];
   uint32_t final_counts[16];     // Counts after k_edit_pack
+  // Backend.applyChanges (signalled by a one-thread launch behind the phase, am355_prims.h launch_signal_words)
+  volatile uint32_t resorder_seq;  uint32_t pad4[15];
+  uint32_t resorder[16];         // ResOrderBufs.words [8] | Counts.flags after the in-place list order merge
+  volatile uint32_t delta_mid_seq; uint32_t pad5[15];
+  uint32_t delta_mid[16];        // DeltaCounts after the first half of the delta stage
+  volatile uint32_t delta_end_seq; uint32_t pad6[15];
+  uint32_t delta_end[16];        // DeltaCounts after the stage (behind the copies of its tables, when the caller enqueued them)
 };
 
 // Per-actor lookup table entry for opId -> row resolution: the applied changes of one actor, ascending start_op

@@ -15,6 +15,10 @@ struct FillRanges {
   void add(void* q, size_t bytes, uint32_t v) { p[n] = (uint32_t*)q; n_words[n] = (uint32_t)((bytes + 3) / 4); value[n] = v; n++; }
 };
 void launch_fill_ranges(const FillRanges& f, hipStream_t st);
+// Result words of a phase into pinned host memory, then the sequence number (signal_host, am355_device.h), as a one-thread launch of its
+// own behind the phase: for phases that end in a library scan or in one of several kernels. Two source ranges, a then b (n_b may be 0).
+void launch_signal_words(const uint32_t* src_a, uint32_t n_a, const uint32_t* src_b, uint32_t n_b, uint32_t* host_words, volatile uint32_t* host_seq, uint32_t seq,
+                         hipStream_t st);
 size_t scan_workspace_bytes(uint32_t n);
 // out[i] = sum(in[0..i)); in == out allowed. *d_total (device, optional) receives the grand total.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* d_total, void* ws, hipStream_t st);

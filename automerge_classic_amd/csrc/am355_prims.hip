@@ -937,6 +937,20 @@ __global__ __launch_bounds__(BLOCK) void k_fill_ranges(FillRanges f) {
   }
 }
 
+__global__ __launch_bounds__(WAVE) void k_signal_words(const uint32_t* __restrict__ src_a, uint32_t n_a, const uint32_t* __restrict__ src_b, uint32_t n_b,
+                                                      uint32_t* host_words, volatile uint32_t* host_seq, uint32_t seq) {
+  if (gtid() != 0) return;
+  for (uint32_t k = 0; k < n_a; k++) host_words[k] = src_a[k];
+  for (uint32_t k = 0; k < n_b; k++) host_words[n_a + k] = src_b[k];
+  __threadfence_system();
+  *host_seq = seq;
+}
+
+void launch_signal_words(const uint32_t* src_a, uint32_t n_a, const uint32_t* src_b, uint32_t n_b, uint32_t* host_words, volatile uint32_t* host_seq, uint32_t seq,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_signal_words, dim3(1), dim3(WAVE), 0, st, src_a, n_a, src_b, n_b, host_words, host_seq, seq);
+}
+
 void launch_fill_ranges(const FillRanges& f, hipStream_t st) {
   if (!f.n) return;
   size_t words = 0;

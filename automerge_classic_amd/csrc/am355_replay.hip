@@ -991,12 +991,14 @@ int backend_load_impl(am355_ctx* c, const uint8_t* doc, size_t len) {
 // ---------------------------------------------------------------------------------------------------------
 // Resident state: Backend.applyChanges onto the state the context holds (new.js:1797-1879 with mergeDocChangeOps :1052-1290 merging
 // the batch INTO the stored op set). When the last replay left the op rows, their per-row results and the per-change tables of
-// exactly the applied changes in HBM (am355_ctx.h resident_valid), only the BATCH is parsed (k_parse_changes over its changes),
+// exactly the applied changes in HBM (am355_ctx.h resident_valid), only the BATCH is parsed (host: the device's parser compiled for
+// the host, am355_decode.hip parse_changes_host -- a launch, a copy back and the wait for them cost ~25 us, the walk a microsecond),
 // hashed (host: SHA extensions, ~2 us per 3 KB change against ~130 us of chain latency on the device), scheduled (host: the
 // in-order case of new.js:1550-1597 -- every dependency applied, next sequence number, known actors; anything else falls back to
 // the full replay, which has the general scheduler), decoded (the batch's plans) and resolved (k_resolve over the new rows, onto
-// the kept accumulators). The whole-document order / patch tables are then rebuilt by the kernels of merge_run as in a full replay
-// (they are what the delta stage reads); what a call no longer pays is stage 1, the decode and the resolution of the old rows.
+// the kept accumulators). A batch of plain list edits is then merged into the stored order (am355_resorder.hip); for any other the
+// whole-document order / patch tables are rebuilt by the kernels of merge_run as in a full replay. What a call no longer pays is
+// stage 1, the decode and the resolution of the old rows -- and, for list edits, the ordering of the old elements.
 // Returns AM355_OK, an error, or RESIDENT_FALLBACK: nothing of the state was touched, replay_impl goes on with the full replay.
 // ---------------------------------------------------------------------------------------------------------
 enum { RESIDENT_FALLBACK = 1 };
@@ -1056,16 +1058,19 @@ static int replay_resident(am355_ctx* c) {
     return fallback("the context's arrays are not the kept state");
   if (c->shard_world != 1 || c->phase_events || c->graph_mode != 0 || !c->mb.sig) return fallback("mode");
   if (c->d_metas.cap < sizeof(ChangeMeta) * (size_t)n) return fallback("per-change tables full");   // (am355_load_changes grows it with its content)
-  if (!c->d_hashes.ensure_keep(32 * (size_t)n, 32 * (size_t)K) || !c->h_hashes.ensure_keep(32 * (size_t)n, 32 * (size_t)K) || !c->d_entries.ensure_keep(4 * (size_t)n, 0))
+  if (!c->d_hashes.ensure_keep(32 * (size_t)n, 32 * (size_t)K) || !c->h_hashes.ensure_keep(32 * (size_t)n, 32 * (size_t)K))
     return fail(c, AM355_E_NOMEM, "allocation failed (per-change tables)");
   if (!c->h_res_metas.ensure(sizeof(ChangeMeta) * (size_t)nb)) return fail(c, AM355_E_NOMEM, "host allocation failed");
   hipStream_t st = c->stream;
   const uint8_t* raw = c->raw.data();
 
-  // ---- device: header / column directory / row counts of the batch's changes; host meanwhile: their hashes ----
-  const bool fat = c->raw.size() - (size_t)c->raw_off[K] > 4096 * (size_t)nb;
-  launch_parse_changes(c->d_arena.as<uint8_t>(), c->d_offsets.as<uint64_t>() + K, nb, c->d_metas.as<ChangeMeta>() + K, c->d_entries.as<uint32_t>() + K, ParseFills{}, st, fat);
-  HIPCHK(c, hipMemcpyAsync(c->h_res_metas.p, c->d_metas.as<ChangeMeta>() + K, sizeof(ChangeMeta) * (size_t)nb, hipMemcpyDeviceToHost, st));
+  // ---- host: header / column directory / row counts of the batch's changes (the device's own parser, am355_decode.hip parse_change,
+  //      compiled for the host: no launch, no copy back, no wait), and their hashes ----
+  {
+    std::vector<uint32_t> ne(nb);
+    parse_changes_host(raw, c->raw_off.data() + K, nb, c->h_res_metas.as<ChangeMeta>(), ne.data());
+    HIPCHK(c, hipMemcpyAsync(c->d_metas.as<ChangeMeta>() + K, c->h_res_metas.p, sizeof(ChangeMeta) * (size_t)nb, hipMemcpyHostToDevice, st));
+  }
   uint8_t* hs = c->h_hashes.as<uint8_t>();
   std::atomic<int> bad_sum{0};
   auto hash_one = [&](uint32_t i) {
@@ -1081,7 +1086,7 @@ static int replay_resident(am355_ctx* c) {
     for (uint32_t i = 0; i < nb; i++) hash_one(i);
   }
   if (bad_sum.load()) { (void)hipStreamSynchronize(st); return fallback("checksum"); }
-  lap("batch hashed (host)");
+  lap("batch parsed and hashed (host)");
   // the hash index of the applied changes (rebuilt when it does not describe exactly them: after a full replay, a reset, a fallback)
   if (c->hash_index_n != K || c->hash_index.empty() || c->hash_index.size() < 4 * (size_t)n) {
     size_t cap = 64;
@@ -1090,12 +1095,6 @@ static int replay_resident(am355_ctx* c) {
     for (uint32_t i = 0; i < K; i++) hash_index_add(c, i);
     c->hash_index_n = K;
   }
-  {
-    hipError_t q;
-    while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
-    if (q != hipSuccess) HIPCHK(c, q);
-  }
-  lap("batch parsed (device)");
   const ChangeMeta* metas = c->h_res_metas.as<ChangeMeta>();
 
   // ---- host: the in-order schedule of the batch, on copies (committed only when every change passes) ----
@@ -1325,13 +1324,14 @@ static int replay_resident(am355_ctx* c) {
     if (!c->pos_valid) resorder_positions(b, NL_old, ro.pos_of, st);
     HIPCHK(c, hipMemsetAsync(ro.obj_add, 0, 4 * ((size_t)NO + 2) + 256 + 64, st));   // obj_add | words (neighbours in the block)
     resorder_run(b, ro, st);
+    // its verdict and the flags of the resolution: signalled into pinned words by a launch behind it (two copy dispatches and their wait otherwise)
     uint32_t* hw = c->h_resorder.as<uint32_t>();
-    HIPCHK(c, hipMemcpyAsync(hw, ro.words, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hw + 8, &b.counts->flags, 4, hipMemcpyDeviceToHost, st));
-    {
-      hipError_t q;
-      while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
-      if (q != hipSuccess) HIPCHK(c, q);
+    launch_signal_words(ro.words, 8, &b.counts->flags, 1, b.sig->resorder, &b.sig->resorder_seq, b.sig_seq, st);
+    if (wait_host_signal(&b.sig->resorder_seq, b.sig_seq, st)) memcpy(hw, (const void*)b.sig->resorder, 36);
+    else {
+      HIPCHK(c, hipMemcpyAsync(hw, ro.words, 32, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(hw + 8, &b.counts->flags, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));
     }
     if (hw[8]) return error_for_flags(c, hw[8], "op set rejected");
     if (hw[0] == 0) {
@@ -1345,6 +1345,7 @@ static int replay_resident(am355_ctx* c) {
       c->ir_fetched = false;
       c->ir_copy_enqueued = 0;
       c->n_resorder_calls++;
+      c->batch_list_only = true;
       merged_in_place = true;
       lap("list order merged in place");
     } else {
@@ -1419,6 +1420,7 @@ int replay_impl(am355_ctx* c) {
   c->dep_graph_ready = false;
   c->flags = 0;
   c->spec_launched = false;
+  c->batch_list_only = false;
   if (c->is_document) return replay_document(c);
   auto t_begin = std::chrono::steady_clock::now();
   if (c->in_apply && c->keep.want) {
@@ -1447,6 +1449,7 @@ int replay_impl(am355_ctx* c) {
     }
   }
   c->keep.want = false;
+  { int orc = upload_offsets(c); if (orc) return orc; }
   const bool trace = getenv("AM355_TRACE") != nullptr;
   auto lap = [&](const char* what) {
     if (trace) fprintf(stderr, "replay: %-28s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());

@@ -22,6 +22,16 @@ constexpr size_t INFLATE_CAP = 0xfff00000ull;  // one staged batch / document is
 
 // keep_staged: the changes staged so far stay where they are -- in the pinned arena and in HBM -- and the batch goes behind them
 // (am355_apply_changes onto a state whose changes were all applied in the order they are staged: only the batch crosses the link)
+int upload_offsets(am355_ctx* c) {
+  if (c->offsets_on_device) return AM355_OK;
+  const size_t bytes = sizeof(uint64_t) * ((size_t)c->n_changes + 1);
+  if (!c->d_offsets.ensure(bytes) || !c->h_offsets.ensure(bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed");
+  memcpy(c->h_offsets.p, c->raw_off.data(), bytes);  // (pinned mirror: the copy below must not bounce through the driver)
+  HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->h_offsets.p, bytes, hipMemcpyHostToDevice, c->stream));
+  c->offsets_on_device = true;
+  return AM355_OK;
+}
+
 int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n, bool keep_staged) {
   if (!c || (!arena && n) || !offsets) return c ? fail(c, AM355_E_ARG, "null argument") : AM355_E_ARG;
   (void)hipSetDevice(c->device);
@@ -212,6 +222,20 @@ int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offset
     for (auto& x : left) x.store(0);
     for (unsigned k = 0; k < n_slices; k++) left[group_of[k]].fetch_add(1);
     h2d.assign(n_groups, hipSuccess);
+    if (n_slices == 1) {
+      // a small batch (Backend.applyChanges with a change or two): copied and enqueued by the calling thread -- handing one of the two
+      // tasks to a pool thread means waiting ~50 us for a sleeping thread to wake up and copy a kilobyte
+      Slice& sl = slices[0];
+      if (sl.any_deflated) {
+        if (sl.out_bytes) memcpy(raw, sl.tmp.data(), sl.out_bytes);
+        size_t o = b0;
+        for (uint32_t i = 0; i < n; i++) { roff[i] = o; o += sl.tmp_len[i]; }
+      } else {
+        if (sl.out_bytes) memcpy(raw, arena + offsets[0], sl.out_bytes);
+        for (uint32_t i = 0; i < n; i++) roff[i] = b0 + (offsets[i] - offsets[0]);
+      }
+      if (total) h2d[0] = hipMemcpyAsync(d_raw, raw, total, hipMemcpyHostToDevice, c->stream);
+    } else
     c->pool->run(n_slices + 1, [&](unsigned task) {
       if (task == 0) {
         (void)hipSetDevice(c->device);
@@ -241,8 +265,10 @@ int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offset
   lap("gathered, H2D enqueued");
   for (hipError_t e : h2d)
     if (e != hipSuccess) return fail(c, AM355_E_DEVICE, "hipMemcpyAsync (arena): %s", hipGetErrorString(e));
-  memcpy(c->h_offsets.p, c->raw_off.data(), sizeof(uint64_t) * ((size_t)n_all + 1));  // (pinned mirror: the copy below must not bounce through the driver)
-  HIPCHK(c, hipMemcpyAsync(c->d_offsets.p, c->h_offsets.p, sizeof(uint64_t) * ((size_t)n_all + 1), hipMemcpyHostToDevice, c->stream));
+  // the offsets table is what the device's own parse / hash kernels walk: a batch that goes behind a kept state may never need it
+  // (am355_replay.hip replay_resident reads the headers on the host) -- upload_offsets() when a full replay does
+  c->offsets_on_device = false;
+  if (!keep_staged) { int orc = upload_offsets(c); if (orc) return orc; }
   // No wait here: am355_replay enqueues behind these copies on the same stream, so its host-side set-up runs beside the tail of
   // the DMA instead of after a wake-up. The pinned arena is only rewritten by the next load, which waits first.
   c->staging_in_flight = true;

@@ -219,8 +219,10 @@ def test_partition_variants_agree_emulated(emu_lib, monkeypatch):
     log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=8, n_rounds=4, ins_per_change=60, del_per_change=15, n_objects=2, seed=29)
     big = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=16, n_rounds=4, ins_per_change=120, del_per_change=30, n_objects=2, seed=31)
     texts = []
-    for env in ({}, {"AM355_DELTA_NO_BIG_LDS": "1"}, {"AM355_DELTA_NO_LDS": "1"}):
-        for k in ("AM355_DELTA_NO_BIG_LDS", "AM355_DELTA_NO_LDS"):
+    # (+ the second half of the stage by one workgroup without a host round trip, kd_edit_small, against the launches it stands for, and
+    #  the stage with its map kernels launched for batches the in-place list merge knows to be free of map rows)
+    for env in ({}, {"AM355_DELTA_NO_BIG_LDS": "1"}, {"AM355_DELTA_NO_LDS": "1"}, {"AM355_DELTA_NO_SMALL": "1", "AM355_DELTA_ALL_KERNELS": "1"}):
+        for k in ("AM355_DELTA_NO_BIG_LDS", "AM355_DELTA_NO_LDS", "AM355_DELTA_NO_SMALL", "AM355_DELTA_ALL_KERNELS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -233,7 +235,7 @@ def test_partition_variants_agree_emulated(emu_lib, monkeypatch):
         finally:
             for e in engs:
                 e.close()
-    assert texts[0] == texts[1] == texts[2]
+    assert texts[0] == texts[1] == texts[2] == texts[3]
 
 
 def _one_by_one(log, head):
