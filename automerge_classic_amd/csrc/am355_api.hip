@@ -84,7 +84,7 @@ extern "C" void am355_destroy(am355_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->shard_comm) (void)am355_shard_finalize(c);   // (ncclCommDestroy)
   c->d_shard_send.release(); c->d_shard_recv.release(); c->d_shard_sizes.release(); c->h_shard_sizes.release(); c->h_shard_frags.release();
-  c->d_delta.release(); c->d_delta_edit.release(); c->d_sched.release(); c->h_sched.release(); c->d_hist.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta_tabs.release(); c->h_delta.release(); c->d_sync.release();
+  c->d_delta.release(); c->d_delta_edit.release(); c->d_sched.release(); c->h_sched.release(); c->d_hist.release(); c->d_pass.release(); c->d_breaks.release(); c->h_delta_tabs.release(); c->h_breaks_ahead.release(); c->h_delta.release(); c->d_sync.release();
   for (DevBuf* b : {&c->d_arena, &c->d_offsets, &c->d_metas, &c->d_plans, &c->d_amap, &c->d_tables, &c->d_cols, &c->d_pred,
                     &c->d_merge, &c->d_sort, &c->d_ir, &c->d_counts, &c->d_big, &c->d_bigvals, &c->d_ks, &c->d_save, &c->d_enc, &c->d_encout})
     b->release();

@@ -47,6 +47,7 @@ int fetch_ir_impl(am355_ctx* c, am355_patch_ir* out, bool with_edits) {
       while ((q = hipStreamQuery(st)) == hipErrorNotReady) {}
       if (q != hipSuccess) HIPCHK(c, q);
     }
+    c->h_tables_current = true;
     h.max_op = c->max_op;
     h.n_actors = (uint32_t)c->actors.size();
     c->actor_off.assign(1, 0);
@@ -142,7 +143,8 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   for (uint32_t r : c->stream_breaks) if (r < T0) breaks.push_back(r);
   if (T0) breaks.push_back(T0);
   breaks.insert(breaks.end(), pass_rows.begin(), pass_rows.end());
-  if (!c->d_breaks.ensure(4 * (breaks.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
+  const bool breaks_there = c->breaks_dev_ptr && c->breaks_dev_ptr == c->d_breaks.p && c->breaks_dev == breaks;   // (am355_apply_changes sent them ahead)
+  if (!breaks_there && !c->d_breaks.ensure(4 * (breaks.size() + 1))) return fail(c, AM355_E_NOMEM, "device allocation failed (delta)");
   d.n_breaks = (uint32_t)breaks.size();
   d.breaks = c->d_breaks.as<uint32_t>();
   d.breaks_exact = c->breaks_exact ? 1u : 0u;
@@ -152,9 +154,10 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   if (!c->h_delta_tabs.ensure(4 * (breaks.size() + pass_rows.size() + 2))) return fail(c, AM355_E_NOMEM, "host allocation failed (delta)");
   uint32_t* h_breaks = c->h_delta_tabs.as<uint32_t>();
   uint32_t* h_pass = h_breaks + breaks.size();
-  if (!breaks.empty()) {
+  if (!breaks.empty() && !breaks_there) {
     memcpy(h_breaks, breaks.data(), 4 * breaks.size());
     HIPCHK(c, hipMemcpyAsync(c->d_breaks.p, h_breaks, 4 * breaks.size(), hipMemcpyHostToDevice, st));
+    c->breaks_dev_ptr = nullptr;   // (what the device holds is this call's: nothing sent ahead)
   }
   if (d.n_pass) {
     memcpy(h_pass, pass_rows.data(), 4 * pass_rows.size());
@@ -167,6 +170,16 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   d.sig = c->h_sig.as<HostSignals>();
   d.sig_seq = ++c->sig_seq;
   d.list_only = T0 && c->batch_list_only && !check_only ? 1u : 0u;
+  d.host_link = nullptr;
+  d.host_edit = nullptr;
+  if (tail && d.list_only && NN <= 1024 && NO <= 4096 && !getenv("AM355_DELTA_COPY_TABLES")) {
+    // a batch kd_edit_small may serve: it writes the two small tables the assembly reads straight into pinned memory
+    const size_t b_link = carve_size(NO, sizeof(ObjLink)), b_edit = carve_size((size_t)d.edit_cap + 1, sizeof(am355_ir_edit));
+    if (c->h_delta.ensure(b_link + b_edit + 256)) {
+      d.host_link = (ObjLink*)c->h_delta.as<uint8_t>();
+      d.host_edit = (am355_ir_edit*)(c->h_delta.as<uint8_t>() + b_link);
+    }
+  }
   c->apply_tail = tail;
   auto before_end = [](void* user, const DeltaCounts* mid, size_t rec_bound) {
     am355_ctx* cx = (am355_ctx*)user;
@@ -174,6 +187,11 @@ static int run_delta_stage(am355_ctx* c, uint32_t T0, DeltaCounts* hc, bool chec
   };
   delta_run(c->mb, c->ir, d, hc, st, check_only, grow, c, tail ? (DeltaBeforeEnd)before_end : nullptr);
   c->apply_tail = nullptr;
+  if (tail && d.host_edit && !hc->flags) {   // (kd_edit_small handed the tables over itself)
+    tail->h_link = d.host_link; tail->h_map = nullptr; tail->h_edit = d.host_edit;
+    tail->n_dmap = 0; tail->edit_records = (size_t)hc->n_erecs + 1;
+    tail->enqueued = true;
+  }
   HIPCHK(c, hipGetLastError());
   return AM355_OK;
 }
@@ -291,6 +309,18 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
   c->keep.n_changes = n_old_applied;
   c->keep.n_ops = old_ops;
   c->keep.n_preds = old_preds;
+  c->breaks_dev_ptr = nullptr;
+  if (c->keep.want && old_ops) {
+    // the rows at which the op streams so far began, as the delta stage of this call will want them when the batch applies in one
+    // pass: queued with the replay's own small uploads (one launch for all of them), recognised by run_delta_stage
+    std::vector<uint32_t> br;
+    for (uint32_t r : c->stream_breaks) if (r < old_ops) br.push_back(r);
+    br.push_back((uint32_t)old_ops);
+    if (c->d_breaks.ensure(4 * (br.size() + 1)) && c->h_breaks_ahead.ensure(4 * br.size())) {
+      memcpy(c->h_breaks_ahead.p, br.data(), 4 * br.size());
+      if (queue_upload(c, c->d_breaks.p, c->h_breaks_ahead.p, 4 * br.size()) == AM355_OK) { c->breaks_dev.swap(br); c->breaks_dev_ptr = c->d_breaks.p; }
+    }
+  }
   rc = replay_impl(c);
   c->in_apply = false;
   if (!rc && c->graph_mode == 1 && c->sched_graph_after) c->graph_mode = 0;  // (this call made the reference rebuild the hash graph)

@@ -346,6 +346,12 @@ struct am355_ctx {
   ChangeMeta doc_meta{};             // column layout of the staged document inside `raw`
   std::vector<uint32_t> doc_actor_rank;  // document actor index -> lexicographic rank
   DevBuf d_arena, d_offsets, d_metas;
+  // small host -> device copies put off until the next launch on `stream`, where they go out as ONE kernel (am355_prims.h CopyRanges;
+  // sources: pinned memory that stays as it is until that kernel has run). flush_uploads() before anything that reads the destinations.
+  CopyRanges pending_up;
+  std::vector<uint32_t> breaks_dev;   // the delta stage's `breaks` table as am355_apply_changes queued it ahead of the replay (breaks_dev_ptr: in which allocation)
+  void* breaks_dev_ptr = nullptr;
+  HostBuf h_breaks_ahead;
   bool offsets_on_device = false;      // d_offsets holds raw_off of every staged change (a batch staged behind a kept state defers the copy)
   HostBuf h_metas, h_offsets, h_sig;   // h_sig: HostSignals (device -> host result words without a copy)
   uint32_t sig_seq = 0;
@@ -444,6 +450,7 @@ struct am355_ctx {
   bool device_scheduled = false;   // the last general-path replay was scheduled by the device (am355_sched.hip)
   HostBuf h_delta;
   DeltaBufs delta{};
+  bool h_tables_current = false, h_tables_were_current = false;   // the object and map tables in h_ir (c->hir) are the device's (set by a completed fetch, dropped by every replay that rebuilds them)
   bool batch_list_only = false;      // the last replay merged a batch of plain list edits in place (replay_resident): no map row among the new rows
   void* apply_tail = nullptr;        // (am355_calls.hip ApplyTail of the delta stage that is running)
   ApplyPatch apply;
@@ -519,6 +526,7 @@ static inline int fail(am355_ctx* c, int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   c->err = buf;
+  c->pending_up.n = 0;   // (uploads a failed call queued and never launched must not go out later, into buffers that may have moved)
   return code;
 }
 
@@ -579,6 +587,9 @@ static inline int error_for_flags(am355_ctx* c, uint32_t f, const char* what) {
 // staging (am355_stage.hip)
 bool read_uleb_host(const uint8_t* p, size_t len, size_t& off, uint64_t& out);
 int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offsets, uint32_t n, bool keep_staged = false);
+// dst (HBM) <- src (pinned) on c->stream: queued when small and room is left, else copied at once (after what is queued)
+int queue_upload(am355_ctx* c, void* dst, const void* src, size_t bytes);
+int flush_uploads(am355_ctx* c);
 int upload_offsets(am355_ctx* c);   // the staged changes' offsets table to HBM, if it is not there (am355_stage.hip)
 int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_checksum = false);
 int backend_load_impl(am355_ctx* c, const uint8_t* doc, size_t len);

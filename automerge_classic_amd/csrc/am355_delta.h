@@ -100,6 +100,10 @@ struct DeltaBufs {
   // counters to the host through pinned words instead of a copy + a blocking wait (am355_internal.h HostSignals; nullptr: copies)
   HostSignals* sig;
   uint32_t sig_seq;
+  // kd_edit_small leaves the tables the host wants -- d.link [n_obj], d.edit [n_erecs + 1] -- in pinned host memory itself and signals
+  // behind them (nullptr: the caller copies): two copy dispatches and a signalling launch less
+  ObjLink* host_link;
+  am355_ir_edit* host_edit;
   uint32_t list_only;   // the caller knows that no new row is a map row (am355_resorder.hip served the batch): the stage's map kernels are not launched
 };
 

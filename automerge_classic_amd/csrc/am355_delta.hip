@@ -916,7 +916,27 @@ __global__ __launch_bounds__(BLOCK) void kd_edit_pack(MergeBufs b, DeltaBufs d, 
 // (which sizes their grids) otherwise: ~45 us of a call that takes 0.3 ms, most of it the host's launch rate. The item count is read
 // HERE; what this workgroup does not handle -- more than PART_LDS_MAX items, map records to order, more edit records than the table holds
 // -- is left alone and reported through DeltaCounts.deferred: the host then runs the second half as it does for larger batches.
+// With d.host_edit set it also hands the result over: the object links and the edit records go to pinned host memory from here and the
+// counters are signalled behind them (HostSignals.delta_mid) -- in every case, also when there is nothing to hand over.
+__device__ __forceinline__ void edit_small_block(const MergeBufs& b, const DeltaBufs& d);
 __global__ __launch_bounds__(BLOCK) void kd_edit_small(MergeBufs b, DeltaBufs d) {
+  edit_small_block(b, d);
+  if (!d.host_edit) return;
+  __syncthreads();
+  const DeltaCounts c = *d.counts;
+  if (!c.flags && !c.deferred) {
+    const uint32_t* src = (const uint32_t*)d.link;
+    uint32_t* dst = (uint32_t*)d.host_link;
+    for (uint32_t w = threadIdx.x; w < d.n_obj * (uint32_t)(sizeof(ObjLink) / 4); w += BLOCK) dst[w] = src[w];
+    src = (const uint32_t*)d.edit;
+    dst = (uint32_t*)d.host_edit;
+    for (uint32_t w = threadIdx.x; w < (c.n_erecs + 1) * (uint32_t)(sizeof(am355_ir_edit) / 4); w += BLOCK) dst[w] = src[w];
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) signal_host(d.sig->delta_mid, (const uint32_t*)d.counts, (uint32_t)(sizeof(DeltaCounts) / 4), &d.sig->delta_mid_seq, d.sig_seq);
+}
+__device__ __forceinline__ void edit_small_block(const MergeBufs& b, const DeltaBufs& d) {
   __shared__ uint32_t s_scan[BLOCK / WAVE];
   const DeltaCounts c = *d.counts;
   if (c.flags) return;   // (refused by the first half: nothing to build)
@@ -1186,14 +1206,22 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
   if (d.sig && d.list_only && !check_only && !no_small && d.n_new <= PART_LDS_MAX && getenv("AM355_DELTA_NO_LDS") == nullptr) {
     hipLaunchKernelGGL(kd_edit_small, dim3(1), dim3(BLOCK), 0, st, b, d);
     step("edit small");
-    if (before_end) {
-      DeltaCounts none{};   // (no map records in what kd_edit_small serves)
-      before_end(grow_user, &none, d.edit_cap);
+    if (d.host_edit) {
+      // (the kernel hands the tables over and signals itself)
+      if (wait_host_signal(&d.sig->delta_mid_seq, d.sig_seq, st)) *hc = *(const DeltaCounts*)d.sig->delta_mid;
+      else { (void)hipMemcpyAsync(hc, d.counts, sizeof(DeltaCounts), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st); d.host_edit = nullptr; }
+    } else {
+      if (before_end) {
+        DeltaCounts none{};   // (no map records in what kd_edit_small serves)
+        before_end(grow_user, &none, d.edit_cap);
+      }
+      read_counts(&d.sig->delta_mid_seq, d.sig->delta_mid);   // (the slot of the first half: when the work was left to the host, that is what this is)
     }
-    read_counts(&d.sig->delta_mid_seq, d.sig->delta_mid);   // (the slot of the first half: when the work was left to the host, that is what this is)
     if (hc->flags || !hc->deferred) return;
+    d.host_edit = nullptr;
     hc->deferred = 0;   // (not served there: the counters are the first half's, the tables untouched -- on as for a larger batch)
   } else {
+    d.host_edit = nullptr;   // (only kd_edit_small hands tables over)
     read_counts(d.sig ? &d.sig->delta_mid_seq : nullptr, d.sig ? d.sig->delta_mid : nullptr);
   }
   if (hc->flags || check_only) return;

@@ -2,6 +2,7 @@
 #pragma once
 #include "am355_internal.h"
 #include "am355_scan.h"
+#include "am355_prims.h"
 #include "../../include/am355.h"
 #include <stddef.h>
 
@@ -124,7 +125,7 @@ bool wait_host_signal(volatile uint32_t* seq_word, uint32_t seq, hipStream_t st)
 // (what: the accumulators of the rows k_resolve is about to run over | what the kernels of merge_run from k_emit on fill and count in:
 // replay_resident clears the first before its k_resolve and the second only when it does not merge the list order in place)
 enum { MERGE_FILL_ROWS = 1, MERGE_FILL_TABLES = 2 };
-void merge_prepare(MergeBufs& b, hipStream_t aux, int what = MERGE_FILL_ROWS | MERGE_FILL_TABLES);
+void merge_prepare(MergeBufs& b, hipStream_t aux, int what = MERGE_FILL_ROWS | MERGE_FILL_TABLES, const FillRanges* extra = nullptr);   // extra: clears of the caller's, in the same launch
 // resolve -> emit -> compaction -> object table, map emission order, RGA order (sibling ordering, typing runs, list ranking),
 // edits. `b.counts` (cleared by the caller BEFORE the decode kernels, whose validity flags it already holds) is read back
 // twice without draining the stream (ev_counts, ev_runs: the host sizes the later launches while the device works through

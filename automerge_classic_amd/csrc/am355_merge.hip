@@ -1507,10 +1507,11 @@ void merge_bind_counts(MergeBufs& b, void* block) {
   b.cs_erec.group_sum = g + 5 * groups;
 }
 
-void merge_prepare(MergeBufs& b, hipStream_t aux, int what) {
+void merge_prepare(MergeBufs& b, hipStream_t aux, int what, const FillRanges* extra) {
   uint32_t N = b.n_ops;
   if (b.row_stride == 0 && b.first_row == 0) {
     (void)hipMemsetAsync(b.zero_base, 0, b.zero_bytes, aux);  // succ_cnt, inc_cnt, val_cnt, inc_sum, last_inc
+    if (extra) launch_fill_ranges(*extra, aux);
     if (!N) return;
     (void)hipMemsetAsync(b.fill_base, 0xff, b.fill_bytes, aux);  // order, first_child, child_head
     return;
@@ -1533,6 +1534,8 @@ void merge_prepare(MergeBufs& b, hipStream_t aux, int what) {
       f.add(b.child_head, 4 * (2 * (size_t)N + 3), 0xffffffffu);
     }
   }
+  if (extra)   // (the caller's own clears ride in the same launch)
+    for (uint32_t k = 0; k < extra->n && f.n < 8; k++) { f.p[f.n] = extra->p[k]; f.n_words[f.n] = extra->n_words[k]; f.value[f.n] = extra->value[k]; f.n++; }
   launch_fill_ranges(f, aux);
 }
 

@@ -15,6 +15,16 @@ struct FillRanges {
   void add(void* q, size_t bytes, uint32_t v) { p[n] = (uint32_t*)q; n_words[n] = (uint32_t)((bytes + 3) / 4); value[n] = v; n++; }
 };
 void launch_fill_ranges(const FillRanges& f, hipStream_t st);
+// Small host -> device copies as ONE launch: the kernel reads the (pinned, device-visible) sources over the link itself. A copy command
+// costs the host ~5-8 us whatever its size; a call of Backend.applyChanges with a one-change batch has five of a few hundred bytes each.
+struct CopyRanges {
+  void* dst[8];
+  const void* src[8];
+  uint32_t bytes[8];
+  uint32_t n = 0;
+  void add(void* d, const void* s, size_t b) { dst[n] = d; src[n] = s; bytes[n] = (uint32_t)b; n++; }
+};
+void launch_copy_ranges(const CopyRanges& r, hipStream_t st);
 // Result words of a phase into pinned host memory, then the sequence number (signal_host, am355_device.h), as a one-thread launch of its
 // own behind the phase: for phases that end in a library scan or in one of several kernels. Two source ranges, a then b (n_b may be 0).
 void launch_signal_words(const uint32_t* src_a, uint32_t n_a, const uint32_t* src_b, uint32_t n_b, uint32_t* host_words, volatile uint32_t* host_seq, uint32_t seq,

@@ -937,6 +937,37 @@ __global__ __launch_bounds__(BLOCK) void k_fill_ranges(FillRanges f) {
   }
 }
 
+__global__ __launch_bounds__(BLOCK) void k_copy_ranges(CopyRanges r) {
+  const uint32_t tid = gtid(), stride = gridDim.x * BLOCK;
+  for (uint32_t k = 0; k < r.n; k++) {
+    uint8_t* d = (uint8_t*)r.dst[k];
+    const uint8_t* s = (const uint8_t*)r.src[k];
+    const uint32_t n = r.bytes[k];
+    if ((((uintptr_t)d ^ (uintptr_t)s) & 15u) == 0) {
+      // the same misalignment on both sides: bytes up to the first 16-byte boundary, 16-byte words, the last bytes
+      uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);
+      if (head > n) head = n;
+      const uint32_t n16 = (n - head) / 16;
+      const uint4* s4 = (const uint4*)(s + head);
+      uint4* d4 = (uint4*)(d + head);
+      for (uint32_t i = tid; i < n16; i += stride) d4[i] = s4[i];
+      if (tid < head) d[tid] = s[tid];
+      const uint32_t tail = head + 16 * n16;
+      if (tid < n - tail) d[tail + tid] = s[tail + tid];
+    } else {
+      for (uint32_t i = tid; i < n; i += stride) d[i] = s[i];
+    }
+  }
+}
+
+void launch_copy_ranges(const CopyRanges& r, hipStream_t st) {
+  if (!r.n) return;
+  size_t most = 0;
+  for (uint32_t k = 0; k < r.n; k++) most = std::max<size_t>(most, r.bytes[k]);
+  const uint32_t grid = (uint32_t)std::min<size_t>((most / 16 + BLOCK - 1) / BLOCK + 1, 256);
+  hipLaunchKernelGGL(k_copy_ranges, dim3(grid), dim3(BLOCK), 0, st, r);
+}
+
 __global__ __launch_bounds__(WAVE) void k_signal_words(const uint32_t* __restrict__ src_a, uint32_t n_a, const uint32_t* __restrict__ src_b, uint32_t n_b,
                                                       uint32_t* host_words, volatile uint32_t* host_seq, uint32_t seq) {
   if (gtid() != 0) return;

@@ -1069,7 +1069,7 @@ static int replay_resident(am355_ctx* c) {
   {
     std::vector<uint32_t> ne(nb);
     parse_changes_host(raw, c->raw_off.data() + K, nb, c->h_res_metas.as<ChangeMeta>(), ne.data());
-    HIPCHK(c, hipMemcpyAsync(c->d_metas.as<ChangeMeta>() + K, c->h_res_metas.p, sizeof(ChangeMeta) * (size_t)nb, hipMemcpyHostToDevice, st));
+    { int qrc = queue_upload(c, c->d_metas.as<ChangeMeta>() + K, c->h_res_metas.p, sizeof(ChangeMeta) * (size_t)nb); if (qrc) return qrc; }
   }
   uint8_t* hs = c->h_hashes.as<uint8_t>();
   std::atomic<int> bad_sum{0};
@@ -1276,9 +1276,9 @@ static int replay_resident(am355_ctx* c) {
     if (b_spans) memcpy(h + o_spans, c->spans.data(), b_spans);
     memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
     if (b_amap) memcpy(h + o_x, amap.data(), b_amap);
-    HIPCHK(c, hipMemcpyAsync(d_tables, h, o_x + b_amap, hipMemcpyHostToDevice, st));
+    { int qrc = queue_upload(c, d_tables, h, o_x + b_amap); if (qrc) return qrc; }
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_hashes.as<uint8_t>() + 32 * (size_t)K, hs + 32 * (size_t)K, 32 * (size_t)nb, hipMemcpyHostToDevice, st));
+  { int qrc = queue_upload(c, c->d_hashes.as<uint8_t>() + 32 * (size_t)K, hs + 32 * (size_t)K, 32 * (size_t)nb); if (qrc) return qrc; }
   MergeBufs& b = c->mb;
   b.arena = c->d_arena.as<uint8_t>();
   b.ops = c->cols;
@@ -1289,24 +1289,14 @@ static int replay_resident(am355_ctx* c) {
   b.first_row = (uint32_t)old_ops; b.seed_list_inc = c->seed_list_inc;   // (b.row_stride: as the last full replay carved the arrays)
   if (!c->d_counts.ensure(merge_counts_bytes(N))) return fail(c, AM355_E_NOMEM, "device allocation failed (merge)");
   merge_bind_counts(b, c->d_counts.p);
-  c->resident_valid = false;   // (from here on the kept arrays change: a failure leaves no state behind)
-  HIPCHK(c, hipMemsetAsync(c->d_counts.p, 0, b.counts_bytes, st));
-  merge_prepare(b, st, MERGE_FILL_ROWS);   // (the new rows' accumulators; in this stream: the decode of a small batch is too short to hide a second stream's join)
-  HIPCHK(c, hipEventRecord(c->ev_fork, st));
-  HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, (uint32_t)np - n_small - n_large,
-                        (const uint32_t*)(d_tables + o_x), nullptr, c->cols, &c->d_counts.as<Counts>()->flags, st, c->stream3, 0, 1);
-  HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
-  HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-  lap("decode enqueued");
-  Counts* hc = c->h_counts.as<Counts>();
-  merge_resolve(b, st);
   // ---- list order: a batch of plain list edits is merged into the STORED order (am355_resorder.hip); anything else -- map rows, new
-  //      objects, a new element with two new children -- orders every list anew with the kernels of merge_run ----
+  //      objects, a new element with two new children -- orders every list anew with the kernels of merge_run. Its buffers are bound here:
+  //      their clears ride with the fill of the new rows' accumulators ----
   static const bool no_resorder = getenv("AM355_NO_RESORDER") != nullptr;
   const uint32_t NN = N - (uint32_t)old_ops, NL_old = c->counts.n_list_ins, NO = c->counts.n_objects;
-  bool merged_in_place = false;
-  if (!no_resorder && NN && NN <= RESORDER_ROWS_MAX && NL_old && c->mb.row_stride) {
+  const bool try_resorder = !no_resorder && NN && NN <= RESORDER_ROWS_MAX && NL_old && c->mb.row_stride;
+  ResOrderBufs ro{};
+  if (try_resorder) {
     const size_t cap_rows = c->mb.row_stride;
     // (the order lives in one of two arrays of row_stride + 2 words -- the one carved with the merge arrays and c->d_order_alt --, and
     // every in-place merge writes the other one; a new carve, setup_buffers, starts over)
@@ -1316,19 +1306,47 @@ static int replay_resident(am355_ctx* c) {
     }
     if (!c->d_pos.ensure_keep(4 * cap_rows, c->pos_valid ? 4 * (size_t)old_ops : 0) || !c->d_resorder.ensure(resorder_bytes(NN, NO)) || !c->h_resorder.ensure(64))
       return fail(c, AM355_E_NOMEM, "device allocation failed (resident list order)");
-    ResOrderBufs ro{};
     resorder_bind(ro, c->d_resorder.p, NN, NO);
     ro.T0 = (uint32_t)old_ops; ro.n_new = NN; ro.n_list = NL_old; ro.n_obj = NO;
     ro.pos_of = c->d_pos.as<uint32_t>();
     ro.order_new = c->order_alt_ptr;
+    ro.sig = b.sig; ro.sig_seq = b.sig_seq;
+  }
+  c->resident_valid = false;   // (from here on the kept arrays change: a failure leaves no state behind)
+  { int frc = flush_uploads(c); if (frc) return frc; }   // (the batch's bytes, its records, the tables, its hashes, the delta stage's breaks: one launch)
+  {
+    FillRanges extra;
+    extra.add(c->d_counts.p, b.counts_bytes, 0);
+    if (try_resorder) extra.add(ro.obj_add, 4 * ((size_t)NO + 2) + 256 + 64, 0);   // obj_add | words (neighbours in the block)
+    merge_prepare(b, st, MERGE_FILL_ROWS, &extra);   // (the new rows' accumulators; in this stream: the decode of a small batch is too short to hide a second stream's join)
+  }
+  // (launch_decode_columns puts a class on the second stream only when the small class and the lane-serial one are both there and no
+  // large one: a handful of changes otherwise decode in ONE launch on `st`, and the fork / join would be four runtime calls for nothing)
+  const uint32_t n_serial = (uint32_t)np - n_small - n_large;
+  const bool second_stream = n_small && n_serial && !(n_large && n_small + n_large <= 1024);
+  if (second_stream) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+  }
+  launch_decode_columns(c->d_arena.as<uint8_t>(), c->d_metas.as<ChangeMeta>(), (const ChangePlan*)d_tables, n_small, n_large, n_serial,
+                        (const uint32_t*)(d_tables + o_x), nullptr, c->cols, &c->d_counts.as<Counts>()->flags, st, second_stream ? c->stream3 : nullptr, 0, 1);
+  if (second_stream) {
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+    HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+  }
+  lap("decode enqueued");
+  Counts* hc = c->h_counts.as<Counts>();
+  merge_resolve(b, st);
+  bool merged_in_place = false;
+  if (try_resorder) {
     if (!c->pos_valid) resorder_positions(b, NL_old, ro.pos_of, st);
-    HIPCHK(c, hipMemsetAsync(ro.obj_add, 0, 4 * ((size_t)NO + 2) + 256 + 64, st));   // obj_add | words (neighbours in the block)
     resorder_run(b, ro, st);
     // its verdict and the flags of the resolution: signalled into pinned words by a launch behind it (two copy dispatches and their wait otherwise)
     uint32_t* hw = c->h_resorder.as<uint32_t>();
-    launch_signal_words(ro.words, 8, &b.counts->flags, 1, b.sig->resorder, &b.sig->resorder_seq, b.sig_seq, st);
-    if (wait_host_signal(&b.sig->resorder_seq, b.sig_seq, st)) memcpy(hw, (const void*)b.sig->resorder, 36);
-    else {
+    if (wait_host_signal(&b.sig->resorder_seq, b.sig_seq, st)) {
+      memcpy(hw, (const void*)b.sig->resorder, 36);
+      c->staging_in_flight = false;   // (the kernel that signalled ran behind everything that read the pinned arena)
+    } else {
       HIPCHK(c, hipMemcpyAsync(hw, ro.words, 32, hipMemcpyDeviceToHost, st));
       HIPCHK(c, hipMemcpyAsync(hw + 8, &b.counts->flags, 4, hipMemcpyDeviceToHost, st));
       HIPCHK(c, hipStreamSynchronize(st));
@@ -1343,7 +1361,11 @@ static int replay_resident(am355_ctx* c) {
       c->pos_valid = true;
       c->ir_stale = true;
       c->ir_fetched = false;
-      c->ir_copy_enqueued = 0;
+      // the object and map tables are what they were (the batch has list rows only and makes no object): a host copy of them that was
+      // current before the call still is, and no copy is enqueued for the call's patch; the edit table it may have come with is not
+      c->h_tables_current = c->h_tables_were_current;
+      c->ir_copy_enqueued = c->h_tables_current ? 1 : 0;
+      c->hir.edits = nullptr;
       c->n_resorder_calls++;
       c->batch_list_only = true;
       merged_in_place = true;
@@ -1363,7 +1385,6 @@ static int replay_resident(am355_ctx* c) {
     c->pos_valid = false;
     c->ir_stale = false;
   }
-  HIPCHK(c, hipEventRecord(c->ev[5], st));
   c->n_resident_calls++;
   return AM355_OK;
 }
@@ -1399,6 +1420,7 @@ int ensure_ir_fresh(am355_ctx* c) {
   c->ir_stale = false;
   c->ir_fetched = false;
   c->ir_copy_enqueued = 0;
+  c->h_tables_current = false;
   c->pos_valid = false;
   c->stats.n_edits = c->counts.n_edits;
   c->stats.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
@@ -1421,6 +1443,8 @@ int replay_impl(am355_ctx* c) {
   c->flags = 0;
   c->spec_launched = false;
   c->batch_list_only = false;
+  c->h_tables_were_current = c->h_tables_current;   // (of the state before this replay: replay_resident may find them unchanged)
+  c->h_tables_current = false;
   if (c->is_document) return replay_document(c);
   auto t_begin = std::chrono::steady_clock::now();
   if (c->in_apply && c->keep.want) {
@@ -1435,7 +1459,7 @@ int replay_impl(am355_ctx* c) {
       s.n_map_values = c->counts.n_map_emit; s.n_list_elems = c->counts.n_list_ins; s.n_edits = c->counts.n_edits;
       s.ir_bytes = (uint64_t)c->counts.n_objects * sizeof(am355_ir_object) + (uint64_t)c->counts.n_map_emit * sizeof(am355_ir_map) +
                    ((uint64_t)c->counts.n_erecs + 1) * sizeof(am355_ir_edit);
-      while (hipEventQuery(c->ev[5]) == hipErrorNotReady) {}
+      // (no wait here: what the call goes on with -- the delta stage, a fetch -- is enqueued behind the batch on the same stream)
       s.ms_parse = s.ms_decode = s.ms_merge = s.ms_order = s.ms_hash_stream = s.ms_host_schedule = 0;
       s.fast_path = 1;
       s.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1449,7 +1473,7 @@ int replay_impl(am355_ctx* c) {
     }
   }
   c->keep.want = false;
-  { int orc = upload_offsets(c); if (orc) return orc; }
+  { int orc = flush_uploads(c); if (!orc) orc = upload_offsets(c); if (orc) return orc; }
   const bool trace = getenv("AM355_TRACE") != nullptr;
   auto lap = [&](const char* what) {
     if (trace) fprintf(stderr, "replay: %-28s +%8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());

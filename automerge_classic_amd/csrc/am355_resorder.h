@@ -19,6 +19,8 @@ struct ResOrderBufs {
   uint32_t* srt_row;         // [n_new] ... and row
   uint32_t* obj_add;         // [n_obj + 1] new elements per object (cleared by the caller)
   uint32_t* words;           // [8] (cleared by the caller): [0] != 0: not served here (the caller orders all lists anew), [1] new elements
+  HostSignals* sig;          // the words + Counts.flags for the host through pinned memory (HostSignals.resorder), nullptr: the caller copies them
+  uint32_t sig_seq;
 };
 
 size_t resorder_bytes(uint32_t n_new, uint32_t n_obj);
@@ -29,7 +31,7 @@ void resorder_positions(const MergeBufs& b, uint32_t n_list, uint32_t* pos_of, h
 // Ranks the batch's new list elements against the stored order (k_resolve of the batch has run): r.words[0] tells whether the batch is
 // one this path serves -- list rows only (inserts, deletions, assignments of plain values), no new object, at most one new child per
 // new element (typing runs), <= RESORDER_ROWS_MAX rows, <= RESORDER_ROOTS_MAX roots --; if so r.order_new / r.pos_of / b.obj_n /
-// b.obj_first_pos / b.kind describe the state after the batch. The caller reads r.words back (8 words) before it relies on them.
+// b.obj_first_pos / b.kind describe the state after the batch. The caller reads r.words back (8 words; r.sig: signalled) before it relies on them.
 void resorder_run(MergeBufs& b, ResOrderBufs& r, hipStream_t st);
 
 }  // namespace am355

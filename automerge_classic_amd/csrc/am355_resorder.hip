@@ -178,10 +178,14 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   }
 }
 
+// ---- what follows from kr_order's result, in ONE launch (three launches and a signalling one before: the host's launch rate, ~4 us per
+// launch, is what a call of 0.3 ms is made of). Workgroups [0, shift_blocks) write the merged order, workgroup shift_blocks the object
+// table, the rest the visibility verdicts; none reads what another writes. The verdict words the host waits for are final since
+// kr_order: the first thread sends them on its way in (r.sig), so the host enqueues the next stage while this one runs. ----
+
 // the merged order: old elements move up by the new elements in front of them, the k-th new element lands at gap + k
-__global__ __launch_bounds__(BLOCK) void kr_shift(MergeBufs b, ResOrderBufs r) {
-  if (r.words[0]) return;
-  const uint32_t i = gtid(), K = r.words[1];
+__device__ __forceinline__ void shift_item(const MergeBufs& b, const ResOrderBufs& r, uint32_t i) {
+  const uint32_t K = r.words[1];
   if (i < r.n_list) {
     uint32_t lo = 0, hi = K;   // new elements with gap <= i
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (r.srt_gap[mid] <= i) lo = mid + 1; else hi = mid; }
@@ -197,8 +201,7 @@ __global__ __launch_bounds__(BLOCK) void kr_shift(MergeBufs b, ResOrderBufs r) {
 }
 
 // per object: its new elements; first positions move up by the new elements of the objects in front (one workgroup; objects are few)
-__global__ __launch_bounds__(BLOCK) void kr_objects(MergeBufs b, ResOrderBufs r) {
-  if (r.words[0]) return;
+__device__ __forceinline__ void objects_block(const MergeBufs& b, const ResOrderBufs& r) {
   __shared__ uint32_t s_red[BLOCK / WAVE];
   uint32_t carry = 0;
   for (uint32_t base = 0; base <= r.n_obj; base += BLOCK) {
@@ -215,9 +218,7 @@ __global__ __launch_bounds__(BLOCK) void kr_objects(MergeBufs b, ResOrderBufs r)
 }
 
 // the verdict "its own value is visible" (k_emit) of the batch's elements and of the elements its rows overwrite or delete
-__global__ __launch_bounds__(BLOCK) void kr_kinds(MergeBufs b, ResOrderBufs r) {
-  if (r.words[0]) return;
-  const uint32_t t = gtid();
+__device__ __forceinline__ void kinds_item(const MergeBufs& b, const ResOrderBufs& r, uint32_t t) {
   if (t >= r.n_new) return;
   const uint32_t g = r.T0 + t;
   const OpCols& o = b.ops;
@@ -229,14 +230,26 @@ __global__ __launch_bounds__(BLOCK) void kr_kinds(MergeBufs b, ResOrderBufs r) {
   }
 }
 
+__global__ __launch_bounds__(BLOCK) void kr_apply(MergeBufs b, ResOrderBufs r, uint32_t shift_blocks) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && r.sig) {
+    uint32_t v[9];
+    for (int k = 0; k < 8; k++) v[k] = r.words[k];
+    v[8] = b.counts->flags;
+    signal_host(r.sig->resorder, v, 9, &r.sig->resorder_seq, r.sig_seq);
+  }
+  if (r.words[0]) return;
+  if (blockIdx.x < shift_blocks) shift_item(b, r, gtid());
+  else if (blockIdx.x == shift_blocks) objects_block(b, r);
+  else kinds_item(b, r, (blockIdx.x - shift_blocks - 1) * BLOCK + threadIdx.x);
+}
+
 void resorder_run(MergeBufs& b, ResOrderBufs& r, hipStream_t st) {
   if (!r.n_new) return;
   hipLaunchKernelGGL(kr_gaps, dim3(r.n_new), dim3(WAVE), 0, st, b, r);
   hipLaunchKernelGGL(kr_order, dim3(1), dim3(RO_THREADS), 0, st, b, r);
   const uint32_t most = r.n_list > r.n_new ? r.n_list : r.n_new;
-  hipLaunchKernelGGL(kr_shift, dim3((most + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, b, r);
-  hipLaunchKernelGGL(kr_objects, dim3(1), dim3(BLOCK), 0, st, b, r);
-  AM355_LAUNCH_INDEPENDENT(kr_kinds, dim3((r.n_new + BLOCK - 1) / BLOCK), dim3(BLOCK), st, b, r);
+  const uint32_t shift_blocks = (most + BLOCK - 1) / BLOCK, kind_blocks = (r.n_new + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL(kr_apply, dim3(shift_blocks + 1 + kind_blocks), dim3(BLOCK), 0, st, b, r, shift_blocks);
 }
 
 }  // namespace am355

@@ -32,6 +32,7 @@ extern "C" int am355_set_shard(am355_ctx* c, uint32_t rank, uint32_t world) {
   c->shard_rank = rank;
   c->shard_world = world;
   c->replayed = c->ir_fetched = false;
+  c->h_tables_current = false;
   c->resident_valid = false;
   return AM355_OK;
 }

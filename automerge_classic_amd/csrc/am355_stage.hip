@@ -22,6 +22,28 @@ constexpr size_t INFLATE_CAP = 0xfff00000ull;  // one staged batch / document is
 
 // keep_staged: the changes staged so far stay where they are -- in the pinned arena and in HBM -- and the batch goes behind them
 // (am355_apply_changes onto a state whose changes were all applied in the order they are staged: only the batch crosses the link)
+int flush_uploads(am355_ctx* c) {
+  if (!c->pending_up.n) return AM355_OK;
+  launch_copy_ranges(c->pending_up, c->stream);
+  c->pending_up.n = 0;
+  HIPCHK(c, hipGetLastError());
+  return AM355_OK;
+}
+
+int queue_upload(am355_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return AM355_OK;
+  static const bool off = getenv("AM355_NO_UPLOAD_QUEUE") != nullptr;   // (A/B: one copy command per upload, as before)
+  if (off || bytes > ((size_t)256 << 10)) {
+    int rc = flush_uploads(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return AM355_OK;
+  }
+  if (c->pending_up.n == 8) { int rc = flush_uploads(c); if (rc) return rc; }
+  c->pending_up.add(dst, src, bytes);
+  return AM355_OK;
+}
+
 int upload_offsets(am355_ctx* c) {
   if (c->offsets_on_device) return AM355_OK;
   const size_t bytes = sizeof(uint64_t) * ((size_t)c->n_changes + 1);
@@ -38,6 +60,7 @@ int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offset
   (void)c->doc_sum.wait();
   const uint32_t k0 = keep_staged ? c->n_changes : 0;  // changes and bytes kept in front of the batch
   const size_t b0 = keep_staged ? c->raw.size() : 0;
+  { int frc = flush_uploads(c); if (frc) return frc; }   // (none expected: a call that queued uploads launched them)
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
   c->staged = c->replayed = c->ir_fetched = false;
   if (!keep_staged) c->resident_valid = false;
@@ -234,7 +257,11 @@ int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offset
         if (sl.out_bytes) memcpy(raw, arena + offsets[0], sl.out_bytes);
         for (uint32_t i = 0; i < n; i++) roff[i] = b0 + (offsets[i] - offsets[0]);
       }
-      if (total) h2d[0] = hipMemcpyAsync(d_raw, raw, total, hipMemcpyHostToDevice, c->stream);
+      if (total) {
+        // (behind a kept state the bytes wait for the replay's first launch -- its tables ride in the same copy kernel)
+        if (keep_staged) { int qrc = queue_upload(c, d_raw, raw, total); if (qrc) return qrc; }
+        else h2d[0] = hipMemcpyAsync(d_raw, raw, total, hipMemcpyHostToDevice, c->stream);
+      }
     } else
     c->pool->run(n_slices + 1, [&](unsigned task) {
       if (task == 0) {
