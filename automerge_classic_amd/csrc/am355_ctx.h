@@ -492,7 +492,8 @@ struct am355_ctx {
   // actor ids -> ranks for the host's schedule of a batch: the document's table inverted, and per author the "other actors" table of its
   // last change with the ranks it gave (changes of one author nearly always carry the same table: one memcmp instead of 64 lookups);
   // both describe c->actors and are dropped with it (a full replay ranks the actors anew)
-  std::unordered_map<std::string, uint32_t> res_rank_of;
+  std::vector<uint32_t> res_rank_of;   // actor id -> rank: open addressing over c->actors (rank + 1; keyed by the id's first bytes), built for res_rank_n actors
+  uint32_t res_rank_n = 0;
   struct ActorMemo { std::vector<uint8_t> bytes; std::vector<uint32_t> ranks; };
   std::vector<ActorMemo> res_actor_memo;
   // resident list ORDER (am355_resorder.hip): the new elements of a small list-only batch are merged into the stored order; the

@@ -1099,13 +1099,32 @@ static int replay_resident(am355_ctx* c) {
 
   // ---- host: the in-order schedule of the batch, on copies (committed only when every change passes) ----
   const uint32_t NA = (uint32_t)c->actors.size();
-  if (c->res_rank_of.size() != NA) {
-    c->res_rank_of.clear();
-    c->res_rank_of.reserve(2 * NA + 8);
-    for (uint32_t r = 0; r < NA; r++) c->res_rank_of.emplace(c->actors[r], r);
+  // actor id -> rank without building a std::string per lookup (a change names dozens of other actors: their table is a lookup each)
+  auto actor_slot = [](const uint8_t* a, size_t len, size_t mask) {
+    uint64_t v = 0;
+    memcpy(&v, a, len < 8 ? len : 8);
+    return (size_t)(((v ^ len) * 0x9e3779b97f4a7c15ull) >> 24) & mask;
+  };
+  if (c->res_rank_n != NA || c->res_rank_of.empty()) {
+    size_t cap = 64;
+    while (cap < 4 * (size_t)NA + 16) cap <<= 1;
+    c->res_rank_of.assign(cap, 0);
+    for (uint32_t r = 0; r < NA; r++) {
+      size_t i = actor_slot((const uint8_t*)c->actors[r].data(), c->actors[r].size(), cap - 1);
+      while (c->res_rank_of[i]) i = (i + 1) & (cap - 1);
+      c->res_rank_of[i] = r + 1;
+    }
+    c->res_rank_n = NA;
     c->res_actor_memo.assign(NA, am355_ctx::ActorMemo{});
   }
-  const std::unordered_map<std::string, uint32_t>& rank_of = c->res_rank_of;
+  auto rank_of = [&](const uint8_t* a, size_t len) -> uint32_t {
+    const size_t mask = c->res_rank_of.size() - 1;
+    for (size_t i = actor_slot(a, len, mask); c->res_rank_of[i]; i = (i + 1) & mask) {
+      const std::string& s = c->actors[c->res_rank_of[i] - 1];
+      if (s.size() == len && memcmp(s.data(), a, len) == 0) return c->res_rank_of[i] - 1;
+    }
+    return NONE32;
+  };
   std::vector<uint64_t> clock(NA, 0);
   for (size_t k = 0; k < c->clock_actor.size(); k++) clock[c->clock_actor[k]] = c->clock_seq[k];
   std::vector<uint32_t> new_clock_actors;
@@ -1116,10 +1135,13 @@ static int replay_resident(am355_ctx* c) {
     if (hi == NONE32) return fallback("a head that is not an applied change");
     is_head[hi] = 1;
   }
+  const uint8_t* prev_author_bytes = nullptr;
+  uint32_t prev_author_len = 0, prev_author = 0;
   const uint8_t* prev_deps = nullptr;   // the dependency block of the change in front (a round of synced peers shares it): resolved once
   uint32_t prev_n_deps = 0, prev_first = 0;
   std::vector<ChangePlan> plans;
   std::vector<uint32_t> amap, dep_first(1, 0), dep_index, op_base(nb);
+  plans.reserve(nb); dep_first.reserve(nb + 1); dep_index.reserve(2 * (size_t)nb); amap.reserve(4 * (size_t)nb);
   std::vector<std::vector<ActorSpan>> add_spans(NA);
   uint64_t ops = old_ops, preds = old_preds, max_op = c->max_op;
   for (uint32_t i = 0; i < nb; i++) {
@@ -1145,9 +1167,14 @@ static int replay_resident(am355_ctx* c) {
     is_head[ci] = 1;
     hash_index_add(c, ci);   // (undone by dropping the index on every fallback below)
     // actor table: author + the others, all known to the document (a new actor changes the ranks of the kept rows: full replay)
-    auto it = rank_of.find(std::string((const char*)p + m.actor_off, m.actor_len));
-    if (it == rank_of.end()) return fallback_dirty("new actor");
-    const uint32_t author = it->second;
+    // (a run of changes by one author -- a peer's backlog, a typing session -- looks its rank up once)
+    uint32_t author;
+    if (prev_author_bytes && prev_author_len == m.actor_len && memcmp(prev_author_bytes, p + m.actor_off, m.actor_len) == 0) author = prev_author;
+    else {
+      author = rank_of(p + m.actor_off, m.actor_len);
+      if (author == NONE32) return fallback_dirty("new actor");
+      prev_author_bytes = p + m.actor_off; prev_author_len = m.actor_len; prev_author = author;
+    }
     ChangePlan pl{ci, (uint32_t)ops, (uint32_t)preds, (uint32_t)amap.size(), author, 1 + m.n_other};
     if (pl.n_actors != m.n_entries) return fallback_dirty("actor table");
     amap.push_back(author);
@@ -1156,6 +1183,8 @@ static int replay_resident(am355_ctx* c) {
       am355_ctx::ActorMemo& memo = c->res_actor_memo[author];
       size_t off = m.others_off, end = off;
       for (uint32_t k = 0; k < m.n_other; k++) {
+        // (actor ids are 16 bytes in practice: a one-byte length, no general LEB128 walk)
+        if (end < m.len && p[end] < 0x80 && (size_t)p[end] < m.len - end) { end += 1 + (size_t)p[end]; continue; }
         uint64_t l;
         if (!read_uleb_host(p, m.len, end, l) || l > m.len - end) return fallback_dirty("actor table");
         end += (size_t)l;
@@ -1170,9 +1199,9 @@ static int replay_resident(am355_ctx* c) {
         for (uint32_t k = 0; k < m.n_other; k++) {
           uint64_t l;
           (void)read_uleb_host(p, m.len, o, l);
-          auto jt = rank_of.find(std::string((const char*)p + o, (size_t)l));
-          if (jt == rank_of.end()) return fallback_dirty("new actor");
-          ranks.push_back(jt->second);
+          const uint32_t rk = l <= m.len - o ? rank_of(p + o, (size_t)l) : NONE32;
+          if (rk == NONE32) return fallback_dirty("new actor");
+          ranks.push_back(rk);
           o += (size_t)l;
         }
         amap.insert(amap.end(), ranks.begin(), ranks.end());
@@ -1294,7 +1323,7 @@ static int replay_resident(am355_ctx* c) {
   //      their clears ride with the fill of the new rows' accumulators ----
   static const bool no_resorder = getenv("AM355_NO_RESORDER") != nullptr;
   const uint32_t NN = N - (uint32_t)old_ops, NL_old = c->counts.n_list_ins, NO = c->counts.n_objects;
-  const bool try_resorder = !no_resorder && NN && NN <= RESORDER_ROWS_MAX && NL_old && c->mb.row_stride;
+  const bool try_resorder = !no_resorder && NN && NN <= resorder_chunk_rows() * RESORDER_CHUNKS_MAX && NL_old && c->mb.row_stride;
   ResOrderBufs ro{};
   if (try_resorder) {
     const size_t cap_rows = c->mb.row_stride;
@@ -1340,7 +1369,8 @@ static int replay_resident(am355_ctx* c) {
   bool merged_in_place = false;
   if (try_resorder) {
     if (!c->pos_valid) resorder_positions(b, NL_old, ro.pos_of, st);
-    resorder_run(b, ro, st);
+    bool final_in_new = true;
+    resorder_run(b, ro, st, &final_in_new);
     // its verdict and the flags of the resolution: signalled into pinned words by a launch behind it (two copy dispatches and their wait otherwise)
     uint32_t* hw = c->h_resorder.as<uint32_t>();
     if (wait_host_signal(&b.sig->resorder_seq, b.sig_seq, st)) {
@@ -1353,11 +1383,13 @@ static int replay_resident(am355_ctx* c) {
     }
     if (hw[8]) return error_for_flags(c, hw[8], "op set rejected");
     if (hw[0] == 0) {
-      // the order after the batch is in the other buffer: it is the state's order from here on
-      uint32_t* old_order = b.order;
-      b.order = ro.order_new;
-      c->order_alt_ptr = old_order;   // (the previous order array is what the next in-place merge writes)
-      c->counts.n_list_ins = NL_old + hw[1];
+      // the order after the batch is the state's order from here on: in the other buffer after an odd number of chunks
+      if (final_in_new) {
+        uint32_t* old_order = b.order;
+        b.order = ro.order_new;
+        c->order_alt_ptr = old_order;   // (the previous order array is what the next in-place merge writes)
+      }
+      c->counts.n_list_ins = hw[2] + hw[1];
       c->pos_valid = true;
       c->ir_stale = true;
       c->ir_fetched = false;
@@ -1845,6 +1877,7 @@ int replay_impl(am355_ctx* c) {
   c->res_dep_index.clear();
   c->hash_index_n = 0;
   c->res_rank_of.clear();
+  c->res_rank_n = 0;
   c->res_actor_memo.clear();
   c->resident_valid = fast && c->in_apply && c->shard_world == 1 && c->mb.row_stride != 0 && !c->has_unknown_cols;
   if (c->resident_valid) resident_mark(c);

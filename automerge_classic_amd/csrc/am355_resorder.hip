@@ -90,6 +90,7 @@ __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
 
 // one workgroup: the new elements in their final order
 constexpr uint32_t RO_THREADS = 1024;
+static_assert(RESORDER_ROOTS_MAX <= RO_THREADS, "kr_order scans the root sizes one root per thread");
 __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs r) {
   __shared__ uint32_t s_par[RESORDER_ROWS_MAX];      // reference element of a new element, as an index into the batch; NONE32: a root; NONE32 - 1: not an element
   __shared__ uint32_t s_root[2][RESORDER_ROWS_MAX], s_depth[2][RESORDER_ROWS_MAX];
@@ -97,11 +98,15 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   __shared__ uint32_t s_roots[RESORDER_ROOTS_MAX], s_rank_of_root[RESORDER_ROOTS_MAX], s_size[RESORDER_ROOTS_MAX], s_base[RESORDER_ROOTS_MAX + 1];
   __shared__ unsigned long long s_rid[RESORDER_ROOTS_MAX];
   __shared__ uint32_t s_rgap[RESORDER_ROOTS_MAX];
-  __shared__ uint32_t s_n_roots, s_bad, s_n_ins;
+  __shared__ uint32_t s_n_roots, s_bad, s_wave_tot[RO_THREADS / WAVE];
   const uint32_t t0 = threadIdx.x, n = r.n_new;
   const OpCols& o = b.ops;
   constexpr uint32_t NOT_ELEM = NONE32 - 1;
-  if (t0 == 0) { s_n_roots = 0; s_bad = 0; s_n_ins = 0; }
+  if (t0 == 0) {
+    s_n_roots = 0; s_bad = 0;
+    if (r.chunk) { r.words[2] += r.words[1]; r.words[1] = 0; }   // (the elements of the chunk in front are part of the order now)
+    else r.words[2] = r.n_list;
+  }
   for (uint32_t t = t0; t < n; t += RO_THREADS) s_nchild[t] = 0;
   __syncthreads();
   if (r.words[0] || n > RESORDER_ROWS_MAX) { if (t0 == 0) r.words[0] = 1; return; }
@@ -119,7 +124,6 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
         const uint32_t k = atomicAdd(&s_n_roots, 1u);
         if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
       }
-      atomicAdd(&s_n_ins, 1u);
     }
     s_par[t] = par;
     s_root[0][t] = par == NONE32 || par == NOT_ELEM ? t : par;
@@ -161,11 +165,18 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   for (uint32_t t = t0; t < n; t += RO_THREADS)
     if (s_par[t] != NOT_ELEM) atomicAdd(&s_size[s_rank_of_root[s_nchild[s_root[cur][t]]]], 1u);   // sizes in RANK order
   __syncthreads();
-  if (t0 == 0) {
-    uint32_t acc = 0;
-    for (uint32_t k = 0; k < R; k++) { s_base[k] = acc; acc += s_size[k]; }
-    s_base[R] = acc;
-    r.words[1] = acc;
+  {
+    // s_base = exclusive prefix of the sizes (R <= RESORDER_ROOTS_MAX = RO_THREADS: one root per thread; a single thread walking a
+    // thousand dependent LDS reads was 30 us of this kernel)
+    const uint32_t lane = t0 & (WAVE - 1), wv = t0 / WAVE;
+    const uint32_t v = t0 < R ? s_size[t0] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == WAVE - 1) s_wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t k = 0; k < RO_THREADS / WAVE; k++) { const uint32_t x = s_wave_tot[k]; before += k < wv ? x : 0u; all += x; }
+    if (t0 < R) s_base[t0] = before + incl - v;
+    if (t0 == 0) { s_base[R] = all; r.words[1] = all; }
   }
   __syncthreads();
   for (uint32_t t = t0; t < n; t += RO_THREADS) {
@@ -174,7 +185,20 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
     const uint32_t at = s_base[s_rank_of_root[k]] + s_depth[cur][t];
     r.srt_gap[at] = r.gap[root_t];
     r.srt_row[at] = r.T0 + t;
-    atomicAdd(&r.obj_add[obj_index_of(b, b.obj_row[r.T0 + t])], 1u);
+  }
+  // new elements per object: a batch names few objects -- usually ONE --, and device-scope atomics on one word execute one after another
+  // (~12 ns each: 49 us for a chunk of 4096 rows). The lanes of a wavefront that name the object of its first element share one.
+  for (uint32_t base = 0; base < n; base += RO_THREADS) {
+    const uint32_t t = base + t0;
+    const bool elem = t < n && s_par[t] != NOT_ELEM;
+    const uint32_t oi = elem ? obj_index_of(b, b.obj_row[r.T0 + t]) : NONE32;
+    const unsigned long long m = __ballot(elem);
+    if (!m) continue;
+    const uint32_t lane = t0 & (WAVE - 1), leader = (uint32_t)__ffsll(m) - 1;
+    const uint32_t loi = __shfl(oi, (int)leader);
+    const unsigned long long same = __ballot(elem && oi == loi);
+    if (lane == leader) atomicAdd(&r.obj_add[loi], (uint32_t)__popcll(same));
+    else if (elem && oi != loi) atomicAdd(&r.obj_add[oi], 1u);
   }
 }
 
@@ -185,8 +209,8 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
 
 // the merged order: old elements move up by the new elements in front of them, the k-th new element lands at gap + k
 __device__ __forceinline__ void shift_item(const MergeBufs& b, const ResOrderBufs& r, uint32_t i) {
-  const uint32_t K = r.words[1];
-  if (i < r.n_list) {
+  const uint32_t K = r.words[1], n_list = r.words[2];
+  if (i < n_list) {
     uint32_t lo = 0, hi = K;   // new elements with gap <= i
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (r.srt_gap[mid] <= i) lo = mid + 1; else hi = mid; }
     const uint32_t e = b.order[i];
@@ -207,6 +231,7 @@ __device__ __forceinline__ void objects_block(const MergeBufs& b, const ResOrder
   for (uint32_t base = 0; base <= r.n_obj; base += BLOCK) {
     const uint32_t oi = base + threadIdx.x;
     const uint32_t add = oi <= r.n_obj ? r.obj_add[oi] : 0u;
+    if (oi <= r.n_obj && add) r.obj_add[oi] = 0;   // (the next chunk counts anew)
     uint32_t total;
     const uint32_t ex = block_exclusive_scan_u32(add, s_red, &total);
     if (oi <= r.n_obj) {
@@ -243,13 +268,38 @@ __global__ __launch_bounds__(BLOCK) void kr_apply(MergeBufs b, ResOrderBufs r, u
   else kinds_item(b, r, (blockIdx.x - shift_blocks - 1) * BLOCK + threadIdx.x);
 }
 
-void resorder_run(MergeBufs& b, ResOrderBufs& r, hipStream_t st) {
+uint32_t resorder_chunk_rows() {
+  const char* e = getenv("AM355_RESORDER_CHUNK");
+  const long v = e ? atol(e) : 0;
+  return v > 0 && v < (long)RESORDER_ROWS_MAX ? (uint32_t)v : RESORDER_ROWS_MAX;
+}
+
+void resorder_run(MergeBufs& b, ResOrderBufs& r, hipStream_t st, bool* final_in_new) {
+  if (final_in_new) *final_in_new = false;
   if (!r.n_new) return;
-  hipLaunchKernelGGL(kr_gaps, dim3(r.n_new), dim3(WAVE), 0, st, b, r);
-  hipLaunchKernelGGL(kr_order, dim3(1), dim3(RO_THREADS), 0, st, b, r);
-  const uint32_t most = r.n_list > r.n_new ? r.n_list : r.n_new;
-  const uint32_t shift_blocks = (most + BLOCK - 1) / BLOCK, kind_blocks = (r.n_new + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL(kr_apply, dim3(shift_blocks + 1 + kind_blocks), dim3(BLOCK), 0, st, b, r, shift_blocks);
+  const uint32_t rows = resorder_chunk_rows();
+  const uint32_t T0 = r.T0, n_all = r.n_new, chunks = (n_all + rows - 1) / rows;
+  HostSignals* sig = r.sig;
+  uint32_t* src = b.order;
+  uint32_t* dst = r.order_new;
+  MergeBufs bb = b;
+  ResOrderBufs rr = r;
+  for (uint32_t c = 0; c < chunks; c++) {
+    rr.chunk = c;
+    rr.T0 = T0 + c * rows;
+    rr.n_new = std::min(rows, n_all - c * rows);
+    rr.sig = c + 1 == chunks ? sig : nullptr;   // (the last chunk's kr_apply tells the host)
+    bb.order = src;
+    rr.order_new = dst;
+    hipLaunchKernelGGL(kr_gaps, dim3(rr.n_new), dim3(WAVE), 0, st, bb, rr);
+    hipLaunchKernelGGL(kr_order, dim3(1), dim3(RO_THREADS), 0, st, bb, rr);
+    const uint32_t n_list_most = r.n_list + c * rows;   // (what the running count can have reached)
+    const uint32_t most = n_list_most > rr.n_new ? n_list_most : rr.n_new;
+    const uint32_t shift_blocks = (most + BLOCK - 1) / BLOCK, kind_blocks = (rr.n_new + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(kr_apply, dim3(shift_blocks + 1 + kind_blocks), dim3(BLOCK), 0, st, bb, rr, shift_blocks);
+    std::swap(src, dst);
+  }
+  if (final_in_new) *final_in_new = (chunks & 1u) != 0;
 }
 
 }  // namespace am355

@@ -295,13 +295,18 @@ def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
         eng.close()
 
 
-def test_resident_list_order_merged_in_place_emulated(emu_lib, monkeypatch):
-    """am355_resorder.hip: the new elements of a small list-only batch are ranked against the STORED order (forward scan for the first
+@pytest.mark.parametrize("chunk", [0, 5])
+def test_resident_list_order_merged_in_place_emulated(emu_lib, monkeypatch, chunk):
+    """(chunk = 5: AM355_RESORDER_CHUNK -- a batch is merged five rows at a time, each chunk against the order the chunks in front left,
+    the order ping-ponging between its two arrays: what a batch of more than 4096 rows goes through.)
+    am355_resorder.hip: the new elements of a small list-only batch are ranked against the STORED order (forward scan for the first
     smaller id behind the reference element, roots of one gap by descending id, typing runs behind their roots). Change by change on
     concurrent text edits -- insertions at the same spots by several actors, deletions, two objects --; after every third call the
     whole-document patch is asked for, which rebuilds the tables from scratch and (AM355_RESORDER_VERIFY) compares the order computed
     from scratch with the one the in-place merges left; every incremental patch and every getPatch equal the oracle session's."""
     monkeypatch.setenv("AM355_RESORDER_VERIFY", "1")
+    if chunk:
+        monkeypatch.setenv("AM355_RESORDER_CHUNK", str(chunk))
     logs = [
         loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=6, n_rounds=5, ins_per_change=9, del_per_change=3, n_objects=2, seed=71),
         loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=8, ins_per_change=3, del_per_change=1, n_objects=1, seed=72),   # short runs: many roots per object

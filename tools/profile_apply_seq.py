@@ -14,7 +14,7 @@ log = loggen.config(name, scale)
 arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
 changes = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
 k = per * calls
-eng = engine.Engine(0)
+eng = engine.Engine(0, os.environ["AM355_TOOL_LIB"]) if os.environ.get("AM355_TOOL_LIB") else engine.Engine(0)   # (AM355_TOOL_LIB: the CPU emulation of tests/emu, for host-side timings)
 eng.apply_changes(ChangeLog.from_changes(changes[:len(changes) - k]))
 times = []
 for j in range(calls):
