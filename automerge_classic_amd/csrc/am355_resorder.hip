@@ -48,6 +48,8 @@ constexpr uint32_t GAP_STEPS_MAX = 4096;   // 64 positions each: a scan past 262
 __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
   const uint32_t t = blockIdx.x, lane = threadIdx.x;
   if (t >= r.n_new) return;
+  // (a chunk behind one that was refused: the order it would scan was never written)
+  if (r.chunk && r.words[0]) return;
   const uint32_t g = r.T0 + t;
   const OpCols& o = b.ops;
   const uint8_t kind = b.kind[g];
