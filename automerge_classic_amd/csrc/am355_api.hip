@@ -117,6 +117,29 @@ extern "C" int am355_get_hashes(const am355_ctx* c, uint8_t* out) {
   return AM355_OK;
 }
 
+extern "C" int am355_arena_epoch(const am355_ctx* c, uint64_t* epoch) {
+  if (!c || !epoch) return AM355_E_ARG;
+  *epoch = c->arena_epoch;
+  return AM355_OK;
+}
+
+extern "C" int am355_get_hashes_range(const am355_ctx* c, uint32_t first, uint32_t count, uint8_t* out) {
+  if (!c || (!out && count)) return AM355_E_ARG;
+  if (!c->replayed || !c->h_hashes.p || c->is_document) return AM355_E_STATE;
+  if (first > c->n_changes || count > c->n_changes - first) return AM355_E_ARG;
+  if (count) memcpy(out, (const uint8_t*)c->h_hashes.p + 32 * (size_t)first, 32 * (size_t)count);
+  return AM355_OK;
+}
+
+extern "C" int am355_applied_in_input_order(const am355_ctx* c, int* yes) {
+  if (!c || !yes) return AM355_E_ARG;
+  if (!c->replayed || c->is_document) return AM355_E_STATE;
+  bool ok = c->pending_change.empty() && c->n_pending == 0 && c->applied_change.size() == c->n_changes;
+  for (uint32_t i = 0; ok && i < c->n_changes; i++) ok = c->applied_change[i] == i;
+  *yes = ok ? 1 : 0;
+  return AM355_OK;
+}
+
 extern "C" int am355_resident_counters(const am355_ctx* c, uint64_t out[3]) {
   if (!c || !out) return AM355_E_ARG;
   out[0] = c->n_resident_calls;

@@ -421,6 +421,7 @@ extern "C" int am355_reset(am355_ctx* c) {
   if (c->staging_in_flight) { c->staging_in_flight = false; (void)hipStreamSynchronize(c->stream); }
   c->staged = c->replayed = c->ir_fetched = c->apply_ready = false;
   c->resident_valid = false;
+  c->arena_epoch++;
   c->state_checked = true;
   c->stream_breaks.clear();
   c->breaks_exact = true;

@@ -348,6 +348,7 @@ struct am355_ctx {
   DevBuf d_arena, d_offsets, d_metas;
   // small host -> device copies put off until the next launch on `stream`, where they go out as ONE kernel (am355_prims.h CopyRanges;
   // sources: pinned memory that stays as it is until that kernel has run). flush_uploads() before anything that reads the destinations.
+  uint64_t arena_epoch = 1;           // am355_arena_epoch: bumped whenever `raw` is rewritten rather than appended to
   CopyRanges pending_up;
   std::vector<uint32_t> breaks_dev;   // the delta stage's `breaks` table as am355_apply_changes queued it ahead of the replay (breaks_dev_ptr: in which allocation)
   void* breaks_dev_ptr = nullptr;

@@ -63,7 +63,7 @@ int load_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offset
   { int frc = flush_uploads(c); if (frc) return frc; }   // (none expected: a call that queued uploads launched them)
   if (c->staging_in_flight) { c->staging_in_flight = false; HIPCHK(c, hipStreamSynchronize(c->stream)); }  // (copies of the previous batch still read the pinned arena)
   c->staged = c->replayed = c->ir_fetched = false;
-  if (!keep_staged) c->resident_valid = false;
+  if (!keep_staged) { c->resident_valid = false; c->arena_epoch++; }
   c->apply_ready = false;
   c->state_checked = false;
   c->is_document = false;
@@ -647,6 +647,7 @@ int load_document_impl(am355_ctx* c, const uint8_t* doc, size_t len, bool defer_
   }
   // ---- op columns -> one arena; layout recorded like a change's column directory ----
   c->raw.clear();
+  c->arena_epoch++;
   c->raw_off.assign(1, 0);
   ChangeMeta& m = c->doc_meta;
   memset(&m, 0, sizeof m);

@@ -62,6 +62,8 @@ class GpuState {
     this.pending = 0
     this.byHash = null       // lazily: hex hash -> input index, applied changes only
     this.pendingIdx = null   // input indexes of the changes still queued (loadChanges / applyChanges states)
+    this.inOrder = false     // every change applied in the order of `changes`, none queued: applied = 0 .. n - 1 (gpuApplyChanges)
+    this.hashStore = null    // the growing buffer `hashes` is a view of, shared along a line of applyChanges calls
     this.calls = 1           // backend calls that built the state (1: one loadChanges / applyChanges onto an empty document)
     this.fromDocument = false // the lineage began with load(bytes): the reference's objectMeta came from the document, not from changes
     // How the reference would have come to this state, call by call: the document the lineage began with (or null) and the batch of
@@ -370,7 +372,39 @@ function getMissingDeps(backend, heads = []) {   // new.js:2014-2028
 // earlier changes and the batch together and derives the incremental patch on the device (am355_apply_changes). What the engine
 // refuses (an assignment to a list element, an edit inside an object the document no longer reaches ...) or rejects is served by
 // the reference path, which returns the reference's patch or throws its exception.
+// 0 .. n - 1 as a view of one shared array (application order of a state whose changes all applied in the order they were given)
+const EMPTY_U32 = new Uint32Array(0)
+let IDENTITY = new Uint32Array(0)
+function identity(n) {
+  if (n > IDENTITY.length) {
+    IDENTITY = new Uint32Array(Math.max(2 * n, 1024))
+    for (let i = 0; i < IDENTITY.length; i++) IDENTITY[i] = i
+  }
+  return IDENTITY.subarray(0, n)
+}
+// The hashes of the n changes of `state` (all applied in input order). States along one line of calls share a growing store: the
+// state at its tip appends the batch's hashes (fetched alone), a state that is not the tip -- a fork -- starts a store of its own.
+function hashesExtended(g, state, n) {
+  const have = g && g.inOrder && g.hashes && g.hashStore && g.hashStore.used === g.hashes.length && g.hashes.length <= 32 * n ? g.hashes.length / 32 : -1
+  let store = have >= 0 ? g.hashStore : null
+  if (store && 32 * n <= store.buf.length) {
+    if (n > have) store.buf.set(addon.hashes(ctx, have), 32 * have)
+  } else {
+    const all = addon.hashes(ctx)
+    store = { buf: new Uint8Array(Math.max(64 * n, 4096)), used: 0 }
+    store.buf.set(all, 0)
+  }
+  store.used = 32 * n
+  state.hashStore = store
+  return store.buf.subarray(0, 32 * n)
+}
+
+// (AM355_JS_PROFILE=1: where a served applyChanges call spends its time -- before the engine call, in it, fetch + materialise, the new state)
+const PROFILE = !!process.env.AM355_JS_PROFILE
+const now = () => Number(process.hrtime.bigint()) / 1e6
+const profile = { calls: 0, before_ms: 0, engine_ms: 0, patch_ms: 0, state_ms: 0 }
 function gpuApplyChanges(backend, changes) {
+  const tpIn = PROFILE ? now() : 0
   const g = backend.state instanceof GpuState ? backend.state : null
   if (g && g.doc && !g.changes) {
     loadedHistory(g)   // a loaded document: its changes, rebuilt by the engine (am355_doc_changes)
@@ -405,21 +439,35 @@ function gpuApplyChanges(backend, changes) {
   }
   const docLineage = !!(g && (g.doc || g.fromDocument))
   if (docLineage && g.graphKnown) addon.hashGraphKnown(ctx, 1)
+  const tp0 = PROFILE ? now() : 0
   try {
     addon.applyChanges(ctx, handed ? changes.concat(handed) : changes)
   } catch (e) {
     entry.generation = 0   // (whatever the context holds now is nobody's state)
     throw e
   }
+  const tp1 = PROFILE ? now() : 0
   const patch = materialize(addon.fetchApplyIR(ctx, true))
+  const tp2 = PROFILE ? now() : 0
   // the engine's list of changes: those applied so far in application order, the batch, those that were queued
-  const list = g ? Array.from(g.applied, i => g.changes[i]).concat(changes, Array.from(g.pendingIdx, i => g.changes[i])) : changes.slice()
+  const list = !g ? changes.slice() : g.inOrder ? g.changes.concat(changes)
+    : Array.from(g.applied, i => g.changes[i]).concat(changes, Array.from(g.pendingIdx, i => g.changes[i]))
   const state = new GpuState(list, null, patch.deps)
   entry.generation = ++generation
   state.generation = generation
-  state.applied = addon.appliedOrder(ctx)
-  state.pendingIdx = addon.pendingOrder(ctx)
-  state.hashes = addon.hashes(ctx)
+  // The usual call -- everything applied in the order it was given, nothing queued -- needs none of the per-change tables copied out of
+  // the context: the application order is 0 .. n - 1, the queue is empty, and the hashes of the earlier changes are the previous
+  // state's (a call on a 4 k-change document spent 0.27 ms on these copies, more than the engine on the batch).
+  state.inOrder = !handed && addon.appliedInInputOrder(ctx)
+  if (state.inOrder) {
+    state.applied = identity(list.length)
+    state.pendingIdx = EMPTY_U32
+    state.hashes = hashesExtended(g, state, list.length)
+  } else {
+    state.applied = addon.appliedOrder(ctx)
+    state.pendingIdx = addon.pendingOrder(ctx)
+    state.hashes = addon.hashes(ctx)
+  }
   state.pending = patch.pendingChanges
   state.calls = g ? g.calls + 1 : 1
   state.fromDocument = !!(g && (g.fromDocument || g.doc))
@@ -428,6 +476,7 @@ function gpuApplyChanges(backend, changes) {
   state.baseDoc = g ? (g.baseDoc || g.doc || null) : null
   state.batches = (g && g.batches ? g.batches : (g && g.doc && g.graphKnown ? [GRAPH_QUERY] : [])).concat([changes.slice()])
   counters.gpuApplyChanges++
+  if (PROFILE) { const tp3 = now(); profile.calls++; profile.before_ms += tp0 - tpIn; profile.engine_ms += tp1 - tp0; profile.patch_ms += tp2 - tp1; profile.state_ms += tp3 - tp2 }
   return [{ state, heads: patch.deps }, patch]
 }
 
@@ -689,5 +738,6 @@ module.exports = {
   // engine statistics of the last GPU replay (not part of the reference surface)
   _engineStats: () => (addon ? addon.stats(ctx) : null),
   _counters: counters,
+  _applyProfile: profile,
   _hydrate: hydrate   // (tests: the reference handle of an engine state, made the way the state came to be)
 }

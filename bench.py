@@ -248,6 +248,37 @@ def js_end_to_end(log):
             "timed_region": "change Uint8Arrays in node -> addon.loadChanges -> addon.replay -> addon.fetchIR -> materialize.js (the JS patch object); median of 7"}
 
 
+def js_apply_latency(log, calls=60):
+    """Backend.applyChanges through the JS host (index.js -> addon -> am355_apply_changes -> fetchApplyIR -> materialize.js -> the new
+    backend state), one change per call onto the document the rest of the log made: js/bench_apply.js, median of the calls after the
+    first. None when node or the addon is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    js = os.path.join(ROOT, "automerge_classic_amd", "js")
+    if node is None or not os.path.exists(os.path.join(js, "am355_napi.node")):
+        return None
+    env = dict(os.environ, AM355_JS_PROFILE="1", NODE_PATH=os.path.join(ROOT, "oracle", "js_shims", "node_modules"))   # (index.js requires pako's shim at load)
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "log.bin")
+            log.save(path)
+            out = subprocess.run([node, os.path.join(js, "bench_apply.js"), path, "1", str(calls)], capture_output=True, text=True, timeout=180, env=env)
+        if out.returncode != 0:
+            return {"error": (out.stderr or out.stdout)[-300:]}
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": str(e)[:300]}
+    pr, n = d.get("profile") or {}, max(1, (d.get("profile") or {}).get("calls", 1))
+    return {"ms_per_call": d["median_ms"], "first_call_ms": d["first_call_ms"], "calls": d["calls"], "served_by_engine": d["counters"]["gpuApplyChanges"] - 1,
+            "fallback_to_js": d["counters"]["fallbackToJs"],
+            "ms": {"engine": pr.get("engine_ms", 0) / n, "fetch_and_materialize": pr.get("patch_ms", 0) / n, "new_state": pr.get("state_ms", 0) / n},
+            "reference_js_recorded_ms_per_call": 21.5,
+            "timed_region": "Backend.applyChanges(state, [one change]) in node, change Uint8Array in -> [new state, patch object] out; the reference's own Backend "
+                            "on the same calls: 21.5 ms median in the build container (profiles/r06_js_apply_latency.txt)"}
+
+
 def sharded_js(name, scale, gpus, want_sha=None, reps=5, timeout_s=150):
     """ONE document over `gpus` GPUs from the JS host (north_star: host code stays JavaScript): node -> js/sharded.js -> one worker
     process per GPU -> am355_shard_init / am355_sharded_replay (RCCL inside libam355.so: ncclAllGather of the patch-IR fragments) ->
@@ -775,6 +806,9 @@ def run(args, eng, rank, world, dist, device, barrier, sync):
             out["js_end_to_end"] = e2e
             if "t_e2e_ms" in e2e:
                 out["t_e2e_ms"] = e2e["t_e2e_ms"]
+        ja = js_apply_latency(w.log)
+        if ja is not None:
+            out["js_apply_changes"] = ja
     if not args.no_sublines and world == 1:
         ss = args.subline_scale
         subs, k, wu = [], max(5, min(args.steps // 3, 30)), 3
@@ -881,6 +915,8 @@ def compact_line(d):
         rows.append(row)
     if rows:
         line["workloads"] = rows
+    if d.get("js_apply_changes") and "ms_per_call" in d["js_apply_changes"]:
+        line["js_apply_changes_ms_per_call"] = _r(d["js_apply_changes"]["ms_per_call"])
     if d.get("apply_changes"):
         line["apply_changes_ms"] = [[b["batch_changes"], _r(b["ms"])] for b in d["apply_changes"]["batches"]]
     for k in ("t_e2e_ms",):
@@ -905,7 +941,7 @@ def compact_line(d):
         line["sharding_model_projected_speedup"] = {str(r["n_gpus"]): [_r(r["projected_speedup"]), _r(r["with_stage1_sharded"]["projected_speedup"])] for r in d["sharding_model"]["projected"]}
     line["detail"] = d.get("detail_file", "gpurun_out/bench_detail.json")
     # the line must fit whole in the driver's record: drop the optional parts, last first, until it does
-    for k in ("sharding_model_projected_speedup", "history_after_load_ms", "save_ms", "apply_changes_ms", "sharded_js", "sharded_c5", "workloads"):
+    for k in ("sharding_model_projected_speedup", "history_after_load_ms", "save_ms", "js_apply_changes_ms_per_call", "apply_changes_ms", "sharded_js", "sharded_c5", "workloads"):
         if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT - 64:
             break
         line.pop(k, None)

@@ -350,6 +350,18 @@ int am355_shard_finalize(am355_ctx *ctx);
  * how many of the first kind also merged their new list elements into the stored document order in place (out[2]) */
 int am355_resident_counters(const am355_ctx *ctx, uint64_t out[3]);
 
+/* For bindings that mirror per-state tables of the context in their own memory (the N-API addon: BackendDoc.changes, their hashes and
+ * the raw arena, backend/new.js:1847, 1855-1879) and must not copy all of them for every one-change Backend.applyChanges:
+ *  - am355_arena_epoch: a counter that changes whenever bytes the context handed out as am355_patch_ir.arena may no longer be what
+ *    they were (a new am355_load_changes / am355_load_document / am355_reset); while it stays the same the arena has only GROWN at its
+ *    end (am355_apply_changes stages a batch behind the kept changes), so a mirror copies [its length, arena_len) only;
+ *  - am355_get_hashes_range: change hashes [first, first + count) in input order, 32 bytes each;
+ *  - am355_applied_in_input_order: *yes = 1 when every staged change is applied, in the order it was staged, and none is queued (the
+ *    applied order is then 0 .. n_changes - 1 and the pending list empty: no need to fetch either). */
+int am355_arena_epoch(const am355_ctx *ctx, uint64_t *epoch);
+int am355_get_hashes_range(const am355_ctx *ctx, uint32_t first, uint32_t count, uint8_t *out);
+int am355_applied_in_input_order(const am355_ctx *ctx, int *yes);
+
 /* ---- diagnostics: device primitives exposed for kernel-level tests ---- */
 int am355_test_sort(am355_ctx *ctx, uint64_t *keys, uint32_t *vals, uint32_t n, int key_bits);
 int am355_test_scan(am355_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total);

@@ -32,14 +32,15 @@ def record(tmp_path_factory):
     eng = engine.Engine(0, EMU_LIB)
     path = str(tmp_path_factory.mktemp("bench") / "bench_detail.json")
     args = bench.parse_args(["--steps", "2", "--warmup", "1", "--prewarm", "0", "--scale", "0.02", "--subline-scale", "0.004", "--no-live-trace", "--detail", path])
-    saved = bench.js_end_to_end, bench.reference_js_baseline, bench.sharded_js
+    saved = bench.js_end_to_end, bench.reference_js_baseline, bench.sharded_js, bench.js_apply_latency
+    bench.js_apply_latency = lambda log, calls=60: {"ms_per_call": 0.3, "first_call_ms": 1.5, "calls": 60, "ms": {}, "timed_region": "stub"}
     bench.sharded_js = lambda *a, **k: {"workload": "stub", "n_gpus": 1, "engine_ms_per_step": 1.0, "ops_per_s": 1.0e9, "per_rank_ms": [], "parity": "patch text sha256 == the unsharded engine's"}
     bench.js_end_to_end = lambda log: {"t_e2e_ms": 12.5, "t_e2e_ops_per_s": 8.0e7, "t_replay_ms_through_node": 1.0, "ms": {}, "timed_region": "stub"}
     bench.reference_js_baseline = lambda *a, **k: None   # (the GPU box's situation: no reference tree -> the C port leg + the recorded figure)
     try:
         detail = bench.run(args, eng, 0, 1, None, None, lambda: None, lambda: None)
     finally:
-        bench.js_end_to_end, bench.reference_js_baseline, bench.sharded_js = saved
+        bench.js_end_to_end, bench.reference_js_baseline, bench.sharded_js, bench.js_apply_latency = saved
         eng.close()
     return detail, path
 
@@ -64,6 +65,7 @@ def test_line_is_one_strict_json_line_under_6k(record, capsys):
         full = strict(f.read())
     assert "phases_ms" in full and "sharding_model" in full and len(full["workloads"]) == len(d["workloads"])
     assert d["sharded_js"]["n_gpus"] == 1 and "parity" in d["sharded_js"]
+    assert d["js_apply_changes_ms_per_call"] == 0.3
 
 
 def test_worst_case_record_still_fits(record):

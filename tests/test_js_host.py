@@ -174,6 +174,41 @@ def test_js_host_materialises_incremental_patches_emulated():
     assert res["failed"] == 0 and res["refused"] == 0 and res["equal"] >= 80
 
 
+def _apply_tables_logs(tmp_path):
+    from automerge_classic_amd import loggen
+    logs = [loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=300, ops_per_change=7, seed=73),
+            loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=5, n_rounds=5, ins_per_change=9, del_per_change=3, n_objects=2, seed=74),
+            loggen.generate(loggen.KIND_MAP_LWW, n_actors=4, n_rounds=5, n_keys=30, seed=75)]
+    paths = []
+    for i, log in enumerate(logs):
+        paths.append(str(tmp_path / ("log%d.bin" % i)))
+        log.save(paths[-1])
+    return paths
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_host_keeps_its_per_state_tables_across_applychanges_calls_emulated(tmp_path):
+    """States made by Backend.applyChanges call after call (index.js: application order as a view of 0 .. n - 1, hashes appended to a
+    shared store, the binding's arena mirror extended by the batch's bytes only -- am355_arena_epoch / am355_get_hashes_range /
+    am355_applied_in_input_order): getAllChanges / getChangeByHash agree with the change bytes, every patch equals the one a state built
+    in one go gets for the same call. Typing, concurrent text with deletions, a map with conflicts."""
+    env = _emu_env()
+    for path in _apply_tables_logs(tmp_path):
+        out = subprocess.run([NODE, os.path.join(JS, "test_apply_tables.js"), path], capture_output=True, text=True, env=env, timeout=900)
+        assert out.returncode == 0 and '"ok":true' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_host_keeps_its_per_state_tables_across_applychanges_calls_on_gpu(tmp_path):
+    if not os.path.exists(os.path.join(JS, "am355_napi.node")):
+        import __graft_entry__ as g
+        g.build_js_addon()
+    for path in _apply_tables_logs(tmp_path):
+        out = subprocess.run([NODE, os.path.join(JS, "test_apply_tables.js"), path], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and '"ok":true' in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(NODE is None, reason="node not installed")
 def test_js_host_reproduces_the_incremental_patches_of_the_reference_suites_on_gpu():
