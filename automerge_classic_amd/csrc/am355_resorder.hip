@@ -7,7 +7,8 @@
 //   * reference element old (or the head): gap(x) = the first OLD position q behind it with id(order[q]) < id(x) (the end of the
 //     object when there is none) -- one forward scan over the stored order, 64 positions per step;
 //   * two such elements with the same gap stand in DESCENDING id order (the greater one is skipped by the smaller one's scan), each
-//     followed by the new elements that hang below it;
+//     followed by the new elements that hang below it (elements of two OBJECTS can share a gap -- the end of one object is the first
+//     position of the next: the object in front first);
 //   * reference element new: x follows it directly when it is its only new child (a typing run: the shape of nearly every batch).
 //     A new element with two new children is left to the full ordering (flag), as is everything that is not a plain list edit.
 // The order after the batch is then a MERGE: an old element at position p moves up by the number of new elements with gap <= p, the
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   __shared__ uint32_t s_nchild[RESORDER_ROWS_MAX];
   __shared__ uint32_t s_roots[RESORDER_ROOTS_MAX], s_rank_of_root[RESORDER_ROOTS_MAX], s_size[RESORDER_ROOTS_MAX], s_base[RESORDER_ROOTS_MAX + 1];
   __shared__ unsigned long long s_rid[RESORDER_ROOTS_MAX];
-  __shared__ uint32_t s_rgap[RESORDER_ROOTS_MAX];
+  __shared__ uint32_t s_rgap[RESORDER_ROOTS_MAX], s_roi[RESORDER_ROOTS_MAX];
   __shared__ uint32_t s_n_roots, s_bad, s_wave_tot[RO_THREADS / WAVE];
   const uint32_t t0 = threadIdx.x, n = r.n_new;
   const OpCols& o = b.ops;
@@ -149,15 +150,19 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   for (uint32_t k = t0; k < R; k += RO_THREADS) {
     const uint32_t t = s_roots[k], g = r.T0 + t;
     s_rgap[k] = r.gap[t];
+    s_roi[k] = obj_index_of(b, b.obj_row[g]);
     s_rid[k] = pack_id(o.id_ctr[g], o.id_actor[g]);
     s_size[k] = 0;
   }
   __syncthreads();
   for (uint32_t k = t0; k < R; k += RO_THREADS) {
-    const uint32_t gap_k = s_rgap[k];
+    const uint32_t gap_k = s_rgap[k], oi_k = s_roi[k];
     const unsigned long long id_k = s_rid[k];
     uint32_t rank = 0;
-    for (uint32_t j = 0; j < R; j++) rank += (s_rgap[j] < gap_k || (s_rgap[j] == gap_k && s_rid[j] > id_k)) ? 1u : 0u;   // (ids are unique: j == k counts nothing)
+    // (one gap can belong to two objects: the end of one is the first position of the next -- the object in front first; objects lie
+    //  in the order of their indexes, kr_apply's object table counts on the same)
+    for (uint32_t j = 0; j < R; j++)
+      rank += (s_rgap[j] < gap_k || (s_rgap[j] == gap_k && (s_roi[j] < oi_k || (s_roi[j] == oi_k && s_rid[j] > id_k)))) ? 1u : 0u;   // (ids are unique: j == k counts nothing)
     s_rank_of_root[k] = rank;
   }
   __syncthreads();

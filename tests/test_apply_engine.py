@@ -344,6 +344,32 @@ def test_resident_list_order_merged_in_place_emulated(emu_lib, monkeypatch, chun
             eng.close()
 
 
+def test_resident_new_elements_of_two_objects_sharing_a_gap_emulated(emu_lib, monkeypatch):
+    """The end of one list object is the first position of the next: a batch that appends to the first and inserts at the head of the
+    second has new elements with the SAME gap in two objects -- the object in front first, whatever the ids (found by
+    tools/soak_resident.py, seed 2118: kr_order ranked them by id alone and the merged order interleaved the objects)."""
+    monkeypatch.setenv("AM355_RESORDER_VERIFY", "1")
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=5, n_rounds=6, ins_per_change=1, del_per_change=2, n_objects=2, seed=2118)
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    batches, k = [], 0
+    for size in (1, 1, 1, 2, 3, 8, 13, 2):
+        batches.append(ch[k:k + size])
+        k += size
+    assert k >= len(ch)
+    eng = engine.Engine(0, emu_lib)
+    session = oracle_lib.OracleSession()
+    try:
+        for i, batch in enumerate(b for b in batches if b):
+            want = session.apply(batch)
+            eng.apply_changes(ChangeLog.from_changes(batch))
+            assert same_patch(eng.apply_patch_json(), want), f"batch {i}"
+            assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"getPatch after batch {i}"
+        assert eng.resident_counters()[2] >= 2
+    finally:
+        eng.close()
+
+
 def test_batches_behind_the_staged_changes_or_restaged_emulated(emu_lib, monkeypatch):
     """A batch onto a state whose changes are all applied is staged behind them (only the batch is copied); AM355_APPLY_RESTAGE=1
     rebuilds the whole queue instead, as a call with queued changes does. Same patches either way, deflated batches included."""

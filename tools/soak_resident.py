@@ -1,0 +1,75 @@
+"""Randomised sessions of am355_apply_changes onto a kept state against the oracle session, on the GPU (or, with AM355_TOOL_LIB, on the
+CPU emulation): text typed by one author, concurrent text with deletions over one or more objects, maps with conflicts; batches of
+random sizes (1 .. 40 changes), the in-place list merge in random chunk sizes, AM355_RESORDER_VERIFY on. Every incremental patch, the
+whole-document patch every few calls and at the end, and Backend.save against a bulk replay are compared.
+  python tools/soak_resident.py <first seed> <sessions>"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["AM355_RESORDER_VERIFY"] = "1"
+from automerge_classic_amd import engine, loggen  # noqa: E402
+from automerge_classic_amd.loggen import ChangeLog  # noqa: E402
+import oracle_lib  # noqa: E402
+from test_apply_engine import _ordered  # noqa: E402
+from test_apply_vectors import same_patch  # noqa: E402
+
+LIB = os.environ.get("AM355_TOOL_LIB")
+first, count = int(sys.argv[1]), int(sys.argv[2])
+totals = {"sessions": 0, "calls": 0, "served": 0, "fell_back": 0, "in_place": 0, "refused": 0}
+for seed in range(first, first + count):
+    rnd = random.Random(seed)
+    kind = rnd.choice(["typing", "concurrent", "concurrent", "concurrent_small", "map"])
+    if kind == "typing":
+        log = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=rnd.randint(200, 3000), ops_per_change=rnd.randint(1, 60), seed=seed)
+    elif kind == "concurrent":
+        log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=rnd.randint(2, 12), n_rounds=rnd.randint(3, 8), ins_per_change=rnd.randint(5, 120),
+                              del_per_change=rnd.randint(0, 30), n_objects=rnd.randint(1, 3), seed=seed)
+    elif kind == "concurrent_small":
+        log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=rnd.randint(2, 6), n_rounds=rnd.randint(4, 12), ins_per_change=rnd.randint(1, 4),
+                              del_per_change=rnd.randint(0, 2), n_objects=rnd.randint(1, 2), seed=seed)
+    else:
+        log = loggen.generate(loggen.KIND_MAP_LWW, n_actors=rnd.randint(2, 6), n_rounds=rnd.randint(3, 8), n_keys=rnd.randint(5, 60), seed=seed)
+    os.environ.pop("AM355_RESORDER_CHUNK", None)
+    if rnd.random() < 0.4:
+        os.environ["AM355_RESORDER_CHUNK"] = str(rnd.choice([3, 7, 50, 400]))
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    k = max(1, rnd.randint(1, max(1, len(ch) // 2)))
+    batches = [ch[:k]]
+    while k < len(ch):
+        size = rnd.choice([1, 1, 1, 2, 3, 5, 8, 13, 40])
+        batches.append(ch[k:k + size])
+        k += size
+    eng = engine.Engine(0, LIB) if LIB else engine.Engine(0)
+    session = oracle_lib.OracleSession()
+    try:
+        for i, batch in enumerate(batches):
+            want = session.apply(batch)
+            try:
+                eng.apply_changes(ChangeLog.from_changes(batch))
+            except engine.UnsupportedChanges:
+                totals["refused"] += 1
+                break
+            got = eng.apply_patch_json()
+            assert same_patch(got, want), f"seed {seed} ({kind}) batch {i}:\n{got[:2000]}\n{want[:2000]}"
+            totals["calls"] += 1
+            if rnd.random() < 0.15:
+                assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"seed {seed} ({kind}) getPatch after batch {i}"
+        else:
+            assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"seed {seed} ({kind}) final getPatch"
+            doc = bytes(eng.save())
+            bulk = engine.Engine(0, LIB) if LIB else engine.Engine(0)
+            bulk.load_changes(log)
+            bulk.replay()
+            assert doc == bytes(bulk.save()), f"seed {seed} ({kind}) save differs from the bulk replay's"
+            bulk.close()
+        s, f, p = eng.resident_counters()
+        totals["served"] += s; totals["fell_back"] += f; totals["in_place"] += p
+        totals["sessions"] += 1
+    finally:
+        eng.close()
+print("soak_resident seeds %d..%d:" % (first, first + count - 1), totals)
