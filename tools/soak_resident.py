@@ -73,3 +73,44 @@ for seed in range(first, first + count):
     finally:
         eng.close()
 print("soak_resident seeds %d..%d:" % (first, first + count - 1), totals)
+
+# ---- the committed applyChanges campaigns (nested maps, tables, lists with assigned elements, counters in lists, wide conflicts), their
+#      changes given in the recorded order but in batches of OTHER sizes than the recorded calls: engine == oracle session per batch ----
+if len(sys.argv) > 3 and sys.argv[3] == "campaigns":
+    from test_apply_engine import load_campaign  # noqa: E402
+    ct = {"sessions": 0, "calls": 0, "served": 0, "in_place": 0, "refused": 0, "oracle_rejects": 0}
+    for fixture in ("apply_campaign.json.gz", "apply_campaign_lists.json.gz", "apply_campaign_quirks.json.gz"):
+        sessions, pool = load_campaign(fixture)
+        for si, s in enumerate(sessions):
+            if "doc" in s:
+                continue
+            for variant in range(2):
+                rnd = random.Random(first * 1000003 + si * 7 + variant)
+                ch = [pool[k] for call in s["calls"] for k in call]
+                batches, k = [], 0
+                while k < len(ch):
+                    size = rnd.choice([1, 1, 2, 3, 5])
+                    batches.append(ch[k:k + size])
+                    k += size
+                eng = engine.Engine(0, LIB) if LIB else engine.Engine(0)
+                session = oracle_lib.OracleSession()
+                try:
+                    for i, batch in enumerate(batches):
+                        try:
+                            want = session.apply(batch)
+                        except oracle_lib.OracleError:
+                            ct["oracle_rejects"] += 1
+                            break
+                        try:
+                            eng.apply_changes(ChangeLog.from_changes(batch))
+                        except engine.UnsupportedChanges:
+                            ct["refused"] += 1
+                            break
+                        got = eng.apply_patch_json()
+                        assert same_patch(got, want), f"{fixture} session {s['name']} variant {variant} batch {i}:\n{got[:2000]}\n{want[:2000]}"
+                        ct["calls"] += 1
+                    a, _, c = eng.resident_counters()
+                    ct["served"] += a; ct["in_place"] += c; ct["sessions"] += 1
+                finally:
+                    eng.close()
+    print("soak_resident campaigns re-split:", ct)
