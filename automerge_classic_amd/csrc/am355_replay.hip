@@ -1323,7 +1323,8 @@ static int replay_resident(am355_ctx* c) {
   //      their clears ride with the fill of the new rows' accumulators ----
   static const bool no_resorder = getenv("AM355_NO_RESORDER") != nullptr;
   const uint32_t NN = N - (uint32_t)old_ops, NL_old = c->counts.n_list_ins, NO = c->counts.n_objects;
-  const bool try_resorder = !no_resorder && NN && NN <= resorder_chunk_rows() * RESORDER_CHUNKS_MAX && NL_old && c->mb.row_stride;
+  const bool try_resorder = !no_resorder && NN && NN <= resorder_chunk_rows() * (resorder_chunk_rows() < RESORDER_ROWS_MAX ? 64u : RESORDER_CHUNKS_MAX) &&   // (tests' small chunks: many of them)
+                             NL_old && c->mb.row_stride;
   ResOrderBufs ro{};
   if (try_resorder) {
     const size_t cap_rows = c->mb.row_stride;

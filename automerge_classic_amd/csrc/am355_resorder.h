@@ -5,8 +5,8 @@
 
 namespace am355 {
 
-constexpr uint32_t RESORDER_ROWS_MAX = 4096;    // new rows the single ordering workgroup holds in LDS: one CHUNK of a batch
-constexpr uint32_t RESORDER_CHUNKS_MAX = 8;     // a larger batch is merged chunk by chunk, each against the order the chunks in front left (resorder_run)
+constexpr uint32_t RESORDER_ROWS_MAX = 12288;   // new rows the single ordering workgroup holds in LDS: one CHUNK of a batch
+constexpr uint32_t RESORDER_CHUNKS_MAX = 3;     // a larger batch is merged chunk by chunk, each against the order the chunks in front left (resorder_run)
 constexpr uint32_t RESORDER_ROOTS_MAX = 1024;   // new elements whose reference element is old (or a list head)
 
 struct ResOrderBufs {

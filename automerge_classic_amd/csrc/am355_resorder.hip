@@ -94,56 +94,72 @@ __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
 // one workgroup: the new elements in their final order
 constexpr uint32_t RO_THREADS = 1024;
 static_assert(RESORDER_ROOTS_MAX <= RO_THREADS, "kr_order scans the root sizes one root per thread");
+// (LDS: 12288 rows x four 16-bit words + the roots' tables = 130 KB of the CU's 160: a batch of 40 changes of 250 ops is ONE chunk.
+//  Round 6 first held 32-bit words and two copies of root / depth for 4096 rows; a 10 k-row batch then took three chunks, each with its
+//  own pass over the whole stored order.)
+constexpr uint32_t RO_PER = (RESORDER_ROWS_MAX + RO_THREADS - 1) / RO_THREADS;   // rows per thread
 __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs r) {
-  __shared__ uint32_t s_par[RESORDER_ROWS_MAX];      // reference element of a new element, as an index into the batch; NONE32: a root; NONE32 - 1: not an element
-  __shared__ uint32_t s_root[2][RESORDER_ROWS_MAX], s_depth[2][RESORDER_ROWS_MAX];
-  __shared__ uint32_t s_nchild[RESORDER_ROWS_MAX];
+  constexpr uint16_t NOT_ELEM = 0xfffe, ROOT = 0xffff;
+  static_assert(RESORDER_ROWS_MAX < NOT_ELEM, "batch indexes are 16-bit words here");
+  __shared__ uint16_t s_par[RESORDER_ROWS_MAX];      // reference element of a new element, as an index into the batch; ROOT: a root; NOT_ELEM: not an element
+  __shared__ uint16_t s_root[RESORDER_ROWS_MAX], s_depth[RESORDER_ROWS_MAX];
+  __shared__ uint16_t s_slot[RESORDER_ROWS_MAX];     // of a root row: its slot in s_roots
+  __shared__ uint32_t s_has_child[(RESORDER_ROWS_MAX + 31) / 32];   // bit per batch row: a new element refers to it
   __shared__ uint32_t s_roots[RESORDER_ROOTS_MAX], s_rank_of_root[RESORDER_ROOTS_MAX], s_size[RESORDER_ROOTS_MAX], s_base[RESORDER_ROOTS_MAX + 1];
   __shared__ unsigned long long s_rid[RESORDER_ROOTS_MAX];
   __shared__ uint32_t s_rgap[RESORDER_ROOTS_MAX], s_roi[RESORDER_ROOTS_MAX];
   __shared__ uint32_t s_n_roots, s_bad, s_wave_tot[RO_THREADS / WAVE];
   const uint32_t t0 = threadIdx.x, n = r.n_new;
   const OpCols& o = b.ops;
-  constexpr uint32_t NOT_ELEM = NONE32 - 1;
   if (t0 == 0) {
     s_n_roots = 0; s_bad = 0;
     if (r.chunk) { r.words[2] += r.words[1]; r.words[1] = 0; }   // (the elements of the chunk in front are part of the order now)
     else r.words[2] = r.n_list;
   }
-  for (uint32_t t = t0; t < n; t += RO_THREADS) s_nchild[t] = 0;
+  for (uint32_t w = t0; w < (RESORDER_ROWS_MAX + 31) / 32; w += RO_THREADS) s_has_child[w] = 0;
   __syncthreads();
   if (r.words[0] || n > RESORDER_ROWS_MAX) { if (t0 == 0) r.words[0] = 1; return; }
   // ---- parents within the batch, roots ----
   for (uint32_t t = t0; t < n; t += RO_THREADS) {
     const uint32_t g = r.T0 + t;
-    uint32_t par = NOT_ELEM;
+    uint16_t par = NOT_ELEM;
     if (b.kind[g] == K_LIST_INS) {
       const uint32_t p = b.ref_row[g];
       if (o.key_ctr[g] != 0 && p != NONE32 && p >= r.T0) {
-        par = p - r.T0;
-        if (atomicAdd(&s_nchild[par], 1u) != 0) s_bad = 1;   // a second new child of a new element: not a run
+        par = (uint16_t)(p - r.T0);
+        const uint32_t bit = 1u << (par & 31u);
+        if (atomicOr(&s_has_child[par >> 5], bit) & bit) s_bad = 1;   // a second new child of a new element: not a run
       } else {
-        par = NONE32;
+        par = ROOT;
         const uint32_t k = atomicAdd(&s_n_roots, 1u);
         if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
       }
     }
     s_par[t] = par;
-    s_root[0][t] = par == NONE32 || par == NOT_ELEM ? t : par;
-    s_depth[0][t] = par == NONE32 || par == NOT_ELEM ? 0u : 1u;
+    s_root[t] = par == ROOT || par == NOT_ELEM ? (uint16_t)t : par;
+    s_depth[t] = par == ROOT || par == NOT_ELEM ? 0 : 1;
   }
   __syncthreads();
   if (s_bad) { if (t0 == 0) r.words[0] = 1; return; }
-  // ---- root and depth of every new element: pointer jumping over the runs ----
-  int cur = 0;
+  // ---- root and depth of every new element: pointer jumping over the runs, in place (a step reads into registers, then writes) ----
   for (uint32_t span = 1; span < n; span <<= 1) {
-    for (uint32_t t = t0; t < n; t += RO_THREADS) {
-      const uint32_t up = s_root[cur][t];
-      s_root[cur ^ 1][t] = s_root[cur][up];
-      s_depth[cur ^ 1][t] = s_depth[cur][t] + (up != t ? s_depth[cur][up] : 0u);
+    uint16_t nr[RO_PER], nd[RO_PER];
+#pragma unroll
+    for (uint32_t j = 0; j < RO_PER; j++) {
+      const uint32_t t = t0 + j * RO_THREADS;
+      if (t < n) {
+        const uint16_t up = s_root[t];
+        nr[j] = s_root[up];
+        nd[j] = (uint16_t)(s_depth[t] + (up != t ? s_depth[up] : 0));
+      }
     }
     __syncthreads();
-    cur ^= 1;
+#pragma unroll
+    for (uint32_t j = 0; j < RO_PER; j++) {
+      const uint32_t t = t0 + j * RO_THREADS;
+      if (t < n) { s_root[t] = nr[j]; s_depth[t] = nd[j]; }
+    }
+    __syncthreads();
   }
   // ---- roots by (gap, id descending): rank by counting (a batch of a few changes has a few roots) ----
   const uint32_t R = s_n_roots;
@@ -166,11 +182,11 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
     s_rank_of_root[k] = rank;
   }
   __syncthreads();
-  // root index of a batch row -> its slot k in s_roots: through s_nchild (free now)
-  for (uint32_t k = t0; k < R; k += RO_THREADS) s_nchild[s_roots[k]] = k;
+  // root index of a batch row -> its slot k in s_roots
+  for (uint32_t k = t0; k < R; k += RO_THREADS) s_slot[s_roots[k]] = (uint16_t)k;
   __syncthreads();
   for (uint32_t t = t0; t < n; t += RO_THREADS)
-    if (s_par[t] != NOT_ELEM) atomicAdd(&s_size[s_rank_of_root[s_nchild[s_root[cur][t]]]], 1u);   // sizes in RANK order
+    if (s_par[t] != NOT_ELEM) atomicAdd(&s_size[s_rank_of_root[s_slot[s_root[t]]]], 1u);   // sizes in RANK order
   __syncthreads();
   {
     // s_base = exclusive prefix of the sizes (R <= RESORDER_ROOTS_MAX = RO_THREADS: one root per thread; a single thread walking a
@@ -188,8 +204,8 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   __syncthreads();
   for (uint32_t t = t0; t < n; t += RO_THREADS) {
     if (s_par[t] == NOT_ELEM) continue;
-    const uint32_t root_t = s_root[cur][t], k = s_nchild[root_t];
-    const uint32_t at = s_base[s_rank_of_root[k]] + s_depth[cur][t];
+    const uint32_t root_t = s_root[t], k = s_slot[root_t];
+    const uint32_t at = s_base[s_rank_of_root[k]] + s_depth[t];
     r.srt_gap[at] = r.gap[root_t];
     r.srt_row[at] = r.T0 + t;
   }

@@ -26,6 +26,7 @@ let empty
 try { empty = Backend.init() } catch (e) { empty = { state: { changes: [], queue: [] }, heads: [] } }
 let [state] = Backend.applyChanges(empty, changes.slice(0, first))
 const tBase = ms() - t0
+const baseProfile = Backend._applyProfile ? Object.assign({}, Backend._applyProfile) : undefined
 if (Backend._applyProfile) for (const k of Object.keys(Backend._applyProfile)) Backend._applyProfile[k] = 0   // (the calls below only)
 const times = []
 let edits = 0
@@ -41,5 +42,5 @@ for (let j = 0; j < calls; j++) {
 const later = times.slice(1).sort((a, b) => a - b)
 console.log(JSON.stringify({
   n_changes: n, changes_per_call: per, calls, base_ms: tBase, first_call_ms: times[0], median_ms: later[Math.floor(later.length / 2)], min_ms: later[0],
-  patch_text_bytes_per_call: Math.round(edits / calls), counters: Backend._counters, profile: Backend._applyProfile
+  patch_text_bytes_per_call: Math.round(edits / calls), counters: Backend._counters, profile: Backend._applyProfile, base_profile: baseProfile
 }))
