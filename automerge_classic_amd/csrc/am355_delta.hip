@@ -613,6 +613,7 @@ __device__ __forceinline__ void partition_lds_block(const DeltaBufs& d, uint32_t
       if (i <= m) { s_zf[i] = zb; s_zw[i] = wb; }
       zb += z[k]; wb += w[k];
     }
+    if (t == 0) { s_zf[m] = zt; s_zw[m] = wt; }   // (m == PART_LDS_MAX: no thread's four items reach index m)
     __syncthreads();
     for (uint32_t k = 0; k < 4; k++) {
       uint32_t i = 4 * t + k;
@@ -720,21 +721,107 @@ __global__ __launch_bounds__(PART_BIG_THREADS) void kd_partition_lds_big(MergeBu
   }
 }
 
+// The same counts TILE BY TILE over the whole device (round 6, second half): for 1 k - 64 k items. What an item needs -- the weights of
+// the earlier items in front of it, and how many items of its list come before it in (time, position) order -- is a two-dimensional
+// dominance count, and it splits over pairs of 256-item tiles: every tile sorts its items by time once (kd_dom_tiles, which also does
+// the pairs inside the tile), and a (tile J, tile I) workgroup answers for the 256 items of I with ONE binary search each into J's sorted
+// times (kd_dom_cross: prefix weights at the found place for J in front of I, the bare count for J behind). 40 changes of 250 ops:
+// 40 x 40 workgroups of ~2 us side by side instead of 14 dependent levels in one workgroup (94 us -> ~10). A tile that holds the border
+// of two lists is compared item by item. kd_dom_scatter then moves every item to its place in (list, time) order and leaves the index
+// of its edit there (kd_edit_index's work: one launch less).
+constexpr uint32_t DOM_TILE = BLOCK;
+constexpr uint32_t DOM_ITEMS_MAX = DOM_TILE * 256;
+__global__ __launch_bounds__(BLOCK) void kd_dom_tiles(DeltaBufs d, uint32_t m) {
+  __shared__ uint32_t s_tk[DOM_TILE], s_lo[DOM_TILE], s_srt_t[DOM_TILE], s_srt_w[DOM_TILE], s_scan[BLOCK / WAVE];
+  const uint32_t t = threadIdx.x, i0 = blockIdx.x * DOM_TILE, i = i0 + t, cnt = m - i0 < DOM_TILE ? m - i0 : DOM_TILE;
+  uint32_t tk = NONE32, lo = NONE32;
+  if (t < cnt) { tk = d.tk[0][i]; lo = d.lo[0][i]; }
+  s_tk[t] = tk; s_lo[t] = lo;
+  __syncthreads();
+  uint32_t acc = 0, rank_list = 0, rank_tile = 0;
+  if (t < cnt) {
+    const uint32_t ti = tk >> 2;
+    for (uint32_t j = 0; j < cnt; j++) {
+      const uint32_t tkj = s_tk[j], tj = tkj >> 2;
+      const bool less = tj < ti, before = less || (tj == ti && j < t), same = s_lo[j] == lo;
+      rank_tile += before ? 1u : 0u;
+      rank_list += before && same ? 1u : 0u;
+      if (less && same && j < t) acc += item_weight(tkj);
+    }
+    s_srt_t[rank_tile] = ti; s_srt_w[rank_tile] = item_weight(tk);
+  }
+  __syncthreads();
+  const uint32_t w = t < cnt ? s_srt_w[t] : 0u;
+  uint32_t tot;
+  const uint32_t ex = block_exclusive_scan_u32(w, s_scan, &tot);
+  if (t < cnt) { d.zf[i] = s_srt_t[t]; d.zw[i] = ex + w; d.acc[0][i] = acc; d.lo[1][i] = rank_list; }   // (zf | zw: the tile's times ascending, the weights up to and with each)
+}
+__global__ __launch_bounds__(BLOCK) void kd_dom_cross(DeltaBufs d, uint32_t m) {
+  const uint32_t J = blockIdx.x, I = blockIdx.y;
+  if (J == I) return;
+  const uint32_t i0 = I * DOM_TILE, j0 = J * DOM_TILE, icnt = m - i0 < DOM_TILE ? m - i0 : DOM_TILE, jcnt = m - j0 < DOM_TILE ? m - j0 : DOM_TILE;
+  if (j0 + jcnt <= d.lo[0][i0] || j0 >= d.hi[0][i0 + icnt - 1]) return;   // (the lists of tile I's items: from its first item's to its last item's)
+  __shared__ uint32_t s_t[DOM_TILE], s_w[DOM_TILE], s_tk[DOM_TILE], s_lo[DOM_TILE];
+  const uint32_t t = threadIdx.x;
+  const bool whole = d.lo[0][j0] == d.lo[0][j0 + jcnt - 1];   // tile J lies inside one list
+  if (t < jcnt) {
+    if (whole) { s_t[t] = d.zf[j0 + t]; s_w[t] = d.zw[j0 + t]; }
+    else { s_tk[t] = d.tk[0][j0 + t]; s_lo[t] = d.lo[0][j0 + t]; }
+  }
+  __syncthreads();
+  if (t >= icnt) return;
+  const uint32_t i = i0 + t, lo = d.lo[0][i];
+  if (j0 + jcnt <= lo || j0 >= d.hi[0][i]) return;
+  const uint32_t ti = d.tk[0][i] >> 2;
+  const bool front = J < I;
+  uint32_t acc = 0, rank = 0;
+  if (whole) {
+    uint32_t a = 0, n = jcnt;   // items of J earlier than ti
+    while (n) {
+      const uint32_t h = n >> 1;
+      if (s_t[a + h] < ti) { a += h + 1; n -= h + 1; } else n = h;
+    }
+    rank = a;
+    if (front) {
+      acc = a ? s_w[a - 1] : 0u;
+      while (rank < jcnt && s_t[rank] == ti) rank++;   // (items of the same row in front of it come first)
+    }
+  } else {
+    for (uint32_t j = 0; j < jcnt; j++) {
+      if (s_lo[j] != lo) continue;
+      const uint32_t tkj = s_tk[j], tj = tkj >> 2;
+      if (tj < ti) { rank++; if (front) acc += item_weight(tkj); }
+      else if (front && tj == ti) rank++;
+    }
+  }
+  if (acc) atomicAdd(&d.acc[0][i], acc);
+  if (rank) atomicAdd(&d.lo[1][i], rank);
+}
+
 // items are now in (object, time) order: index of each edit
-__device__ __forceinline__ void edit_index_item(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t i) {
-  uint32_t tk = d.tk[src][i], e = d.elem[src][i];
+__device__ __forceinline__ uint32_t edit_index_of(const MergeBufs& b, const DeltaBufs& d, uint32_t tk, uint32_t e, uint32_t acc) {
   uint32_t t = tk >> 2, g = d.T0 + t;
   uint32_t oi = obj_index_of(b, b.obj_row[e]);
   uint32_t p = d.pos_of[e];
-  uint32_t idx = d.v0_ex[p] - d.v0_ex[b.obj_first_pos[oi]] + d.acc[src][i];
+  uint32_t idx = d.v0_ex[p] - d.v0_ex[b.obj_first_pos[oi]] + acc;
   // the earlier items of its own element sit at the same position and are not "in front": together they moved the element from
   // its visibility before the batch to its visibility just before this item
   if (g != e) idx -= (d.ev_before[t] & 1u) - d.v0[p] + (d.ev_before[t] >> 1);  // (bit 1: the reference's index lag, kd_events)
-  d.e_index[i] = idx;
+  return idx;
+}
+__device__ __forceinline__ void edit_index_item(const MergeBufs& b, const DeltaBufs& d, int src, uint32_t i) {
+  d.e_index[i] = edit_index_of(b, d, d.tk[src][i], d.elem[src][i], d.acc[src][i]);
 }
 __global__ __launch_bounds__(BLOCK) void kd_edit_index(MergeBufs b, DeltaBufs d, int src, uint32_t m) {
   uint32_t i = gtid();
   if (i < m) edit_index_item(b, d, src, i);
+}
+__global__ __launch_bounds__(BLOCK) void kd_dom_scatter(MergeBufs b, DeltaBufs d, uint32_t m) {
+  uint32_t i = gtid();
+  if (i >= m) return;
+  const uint32_t to = d.lo[0][i] + d.lo[1][i], tk = d.tk[0][i], e = d.elem[0][i], acc = d.acc[0][i];
+  d.tk[1][to] = tk; d.elem[1][to] = e; d.acc[1][to] = acc;
+  d.e_index[to] = edit_index_of(b, d, tk, e, acc);
 }
 
 // ---- the edits array (new.js:747-869), item by item -------------------------------------------------------------------------
@@ -1244,9 +1331,18 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
     // level against ~15 for the three launches -- one CU's memory pipeline is no match for 256, and the device-side cost of a dependent
     // kernel boundary is only ~1.5-2 us, MI355X_MICROARCH.md "boundary". Taken out again.)
     const bool no_big = getenv("AM355_DELTA_NO_BIG_LDS") != nullptr;   // (tests, A/B: the level-by-level version for 1 k - 11 k items)
+    const bool no_tiles = getenv("AM355_DELTA_NO_TILES") != nullptr;   // (tests, A/B: the versions below for 1 k - 64 k items)
+    bool indexed = false;
     if (m <= PART_LDS_MAX && !no_lds) {
       hipLaunchKernelGGL(kd_partition_lds, dim3(1), dim3(BLOCK), 0, st, d, m, d.bits_new);
       cur = (int)(d.bits_new & 1u);
+    } else if (m <= DOM_ITEMS_MAX && !no_lds && !no_tiles) {
+      const uint32_t nt = (m + DOM_TILE - 1) / DOM_TILE;
+      hipLaunchKernelGGL(kd_dom_tiles, dim3(nt), dim3(BLOCK), 0, st, d, m);
+      hipLaunchKernelGGL(kd_dom_cross, dim3(nt, nt), dim3(BLOCK), 0, st, d, m);
+      AM355_LAUNCH_INDEPENDENT(kd_dom_scatter, dgrid(m), dim3(BLOCK), st, b, d, m);
+      cur = 1;
+      indexed = true;
     } else if (m <= PART_BIG_MAX && !no_lds && !no_big && d.bits_new) {
       hipLaunchKernelGGL(kd_partition_lds_big, dim3(1), dim3(PART_BIG_THREADS), 0, st, b, d, m, d.bits_new);
       cur = (int)(d.bits_new & 1u);
@@ -1258,7 +1354,7 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
         cur ^= 1;
       }
     }
-    AM355_LAUNCH_INDEPENDENT(kd_edit_index, dgrid(m), dim3(BLOCK), st, b, d, cur, m);
+    if (!indexed) AM355_LAUNCH_INDEPENDENT(kd_edit_index, dgrid(m), dim3(BLOCK), st, b, d, cur, m);
   }
   step("edit index");
   AM355_LAUNCH_INDEPENDENT(kd_edit_runs, dgrid(m + 1), dim3(BLOCK), st, b, d, cur, m);

@@ -17,6 +17,7 @@ struct ResOrderBufs {
   uint32_t* pos_of;          // [row capacity] position of every element row in b.order (kept between calls)
   uint32_t* order_new;       // [row capacity + 2] the order after the call (the caller swaps it with b.order)
   uint32_t* gap;             // [n_new] a new element whose reference element is old / a head: the old position it goes in front of
+  uint16_t* par;             // [n_new] the reference element of a new element as an index into the batch (kr_gaps -> kr_order)
   uint32_t* srt_gap;         // [n_new] the new elements in their final order: gap ...
   uint32_t* srt_row;         // [n_new] ... and row
   uint32_t* obj_add;         // [n_obj + 1] new elements per object (cleared by the caller)

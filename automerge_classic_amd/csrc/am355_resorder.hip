@@ -20,9 +20,10 @@
 namespace am355 {
 
 static size_t al256(size_t b) { return carve_round(b); }
+constexpr uint16_t RO_NOT_ELEM = 0xfffe, RO_ROOT = 0xffff;   // r.par: not a new list element; a new element whose reference element is old (or a list head)
 
 size_t resorder_bytes(uint32_t n_new, uint32_t n_obj) {
-  return 3 * al256(4 * ((size_t)n_new + 1)) + al256(4 * ((size_t)n_obj + 2)) + al256(64) + 256;
+  return 3 * al256(4 * ((size_t)n_new + 1)) + al256(2 * ((size_t)n_new + 1)) + al256(4 * ((size_t)n_obj + 2)) + al256(64) + 256;
 }
 
 void resorder_bind(ResOrderBufs& r, void* block, uint32_t n_new, uint32_t n_obj) {
@@ -31,6 +32,7 @@ void resorder_bind(ResOrderBufs& r, void* block, uint32_t n_new, uint32_t n_obj)
   r.gap = (uint32_t*)take(4 * ((size_t)n_new + 1));
   r.srt_gap = (uint32_t*)take(4 * ((size_t)n_new + 1));
   r.srt_row = (uint32_t*)take(4 * ((size_t)n_new + 1));
+  r.par = (uint16_t*)take(2 * ((size_t)n_new + 1));
   r.obj_add = (uint32_t*)take(4 * ((size_t)n_obj + 2));
   r.words = (uint32_t*)take(64);
 }
@@ -87,6 +89,13 @@ __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
   }
   if (lane == 0) {
     r.gap[t] = gap;
+    // (kr_order: the reference element as an index into the batch)
+    uint16_t par = RO_NOT_ELEM;
+    if (kind == K_LIST_INS) {
+      const uint32_t parent = b.ref_row[g];
+      par = (o.key_ctr[g] != 0 && parent != NONE32 && parent >= r.T0) ? (uint16_t)(parent - r.T0) : RO_ROOT;
+    }
+    r.par[t] = par;
     if (refuse) r.words[0] = 1;
   }
 }
@@ -94,72 +103,72 @@ __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
 // one workgroup: the new elements in their final order
 constexpr uint32_t RO_THREADS = 1024;
 static_assert(RESORDER_ROOTS_MAX <= RO_THREADS, "kr_order scans the root sizes one root per thread");
-// (LDS: 12288 rows x four 16-bit words + the roots' tables = 130 KB of the CU's 160: a batch of 40 changes of 250 ops is ONE chunk.
-//  Round 6 first held 32-bit words and two copies of root / depth for 4096 rows; a 10 k-row batch then took three chunks, each with its
-//  own pass over the whole stored order.)
 constexpr uint32_t RO_PER = (RESORDER_ROWS_MAX + RO_THREADS - 1) / RO_THREADS;   // rows per thread
+// (LDS: 12288 rows x (parent 2 B + root | depth 4 B + slot 2 B) + the roots' tables = 130 KB of the CU's 160: a batch of 40 changes of 250
+//  ops is ONE chunk. Round 6 first held two copies of root / depth as 32-bit words for 4096 rows; a 10 k-row batch then took three
+//  chunks, each with its own pass over the whole stored order.
+//  What one workgroup must do is the pointer jumping; everything per ROW that needs device memory is done by kr_gaps' wavefronts (the
+//  parent of every row as a 16-bit word, r.par) and everything else is per RUN: its length is its last element's depth + 1, which
+//  sizes the root's stretch and counts the object's new elements -- no atomics per row, no gathers from device memory per row.)
 __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs r) {
-  constexpr uint16_t NOT_ELEM = 0xfffe, ROOT = 0xffff;
-  static_assert(RESORDER_ROWS_MAX < NOT_ELEM, "batch indexes are 16-bit words here");
-  __shared__ uint16_t s_par[RESORDER_ROWS_MAX];      // reference element of a new element, as an index into the batch; ROOT: a root; NOT_ELEM: not an element
-  __shared__ uint16_t s_root[RESORDER_ROWS_MAX], s_depth[RESORDER_ROWS_MAX];
+  static_assert(RESORDER_ROWS_MAX < RO_NOT_ELEM, "batch indexes are 16-bit words here");
+  __shared__ uint16_t s_par[RESORDER_ROWS_MAX];      // reference element of a new element, as an index into the batch; RO_ROOT: a root; RO_NOT_ELEM: not an element
+  __shared__ uint32_t s_rd[RESORDER_ROWS_MAX];       // root so far | depth below it << 16
   __shared__ uint16_t s_slot[RESORDER_ROWS_MAX];     // of a root row: its slot in s_roots
   __shared__ uint32_t s_has_child[(RESORDER_ROWS_MAX + 31) / 32];   // bit per batch row: a new element refers to it
   __shared__ uint32_t s_roots[RESORDER_ROOTS_MAX], s_rank_of_root[RESORDER_ROOTS_MAX], s_size[RESORDER_ROOTS_MAX], s_base[RESORDER_ROOTS_MAX + 1];
   __shared__ unsigned long long s_rid[RESORDER_ROOTS_MAX];
   __shared__ uint32_t s_rgap[RESORDER_ROOTS_MAX], s_roi[RESORDER_ROOTS_MAX];
-  __shared__ uint32_t s_n_roots, s_bad, s_wave_tot[RO_THREADS / WAVE];
+  __shared__ uint32_t s_n_roots, s_bad, s_moved[2], s_wave_tot[RO_THREADS / WAVE];
   const uint32_t t0 = threadIdx.x, n = r.n_new;
   const OpCols& o = b.ops;
   if (t0 == 0) {
-    s_n_roots = 0; s_bad = 0;
+    s_n_roots = 0; s_bad = 0; s_moved[0] = 0;
     if (r.chunk) { r.words[2] += r.words[1]; r.words[1] = 0; }   // (the elements of the chunk in front are part of the order now)
     else r.words[2] = r.n_list;
   }
   for (uint32_t w = t0; w < (RESORDER_ROWS_MAX + 31) / 32; w += RO_THREADS) s_has_child[w] = 0;
   __syncthreads();
   if (r.words[0] || n > RESORDER_ROWS_MAX) { if (t0 == 0) r.words[0] = 1; return; }
-  // ---- parents within the batch, roots ----
+  // ---- parents within the batch (kr_gaps), roots ----
   for (uint32_t t = t0; t < n; t += RO_THREADS) {
-    const uint32_t g = r.T0 + t;
-    uint16_t par = NOT_ELEM;
-    if (b.kind[g] == K_LIST_INS) {
-      const uint32_t p = b.ref_row[g];
-      if (o.key_ctr[g] != 0 && p != NONE32 && p >= r.T0) {
-        par = (uint16_t)(p - r.T0);
-        const uint32_t bit = 1u << (par & 31u);
-        if (atomicOr(&s_has_child[par >> 5], bit) & bit) s_bad = 1;   // a second new child of a new element: not a run
-      } else {
-        par = ROOT;
-        const uint32_t k = atomicAdd(&s_n_roots, 1u);
-        if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
-      }
+    const uint16_t par = r.par[t];
+    if (par < RO_NOT_ELEM) {
+      const uint32_t bit = 1u << (par & 31u);
+      if (par >= n || (atomicOr(&s_has_child[par >> 5], bit) & bit)) s_bad = 1;   // a second new child of a new element: not a run
+    } else if (par == RO_ROOT) {
+      const uint32_t k = atomicAdd(&s_n_roots, 1u);
+      if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
     }
     s_par[t] = par;
-    s_root[t] = par == ROOT || par == NOT_ELEM ? (uint16_t)t : par;
-    s_depth[t] = par == ROOT || par == NOT_ELEM ? 0 : 1;
+    s_rd[t] = par < RO_NOT_ELEM && par < n ? (uint32_t)par | 1u << 16 : t;
   }
   __syncthreads();
   if (s_bad) { if (t0 == 0) r.words[0] = 1; return; }
-  // ---- root and depth of every new element: pointer jumping over the runs, in place (a step reads into registers, then writes) ----
-  for (uint32_t span = 1; span < n; span <<= 1) {
-    uint16_t nr[RO_PER], nd[RO_PER];
+  // ---- root and depth of every new element: pointer jumping over the runs, in place (a step reads into registers, then writes); it ends
+  //      with the first step that moves nothing -- log2 of the LONGEST run steps, not of the batch ----
+  for (uint32_t span = 1, round = 0; span < n; span <<= 1, round++) {
+    uint32_t nw[RO_PER];
+    bool moved = false;
 #pragma unroll
     for (uint32_t j = 0; j < RO_PER; j++) {
       const uint32_t t = t0 + j * RO_THREADS;
       if (t < n) {
-        const uint16_t up = s_root[t];
-        nr[j] = s_root[up];
-        nd[j] = (uint16_t)(s_depth[t] + (up != t ? s_depth[up] : 0));
+        const uint32_t rd = s_rd[t], up = rd & 0xffffu, ru = s_rd[up];
+        nw[j] = (ru & 0xffffu) | ((rd >> 16) + (up != t ? ru >> 16 : 0u)) << 16;
+        moved |= (ru & 0xffffu) != up;
       }
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < RO_PER; j++) {
       const uint32_t t = t0 + j * RO_THREADS;
-      if (t < n) { s_root[t] = nr[j]; s_depth[t] = nd[j]; }
+      if (t < n) s_rd[t] = nw[j];
     }
+    if (moved) s_moved[round & 1u] = 1;
+    if (t0 == 0) s_moved[(round & 1u) ^ 1u] = 0;   // (the next step's word: every thread has read it a barrier ago)
     __syncthreads();
+    if (!s_moved[round & 1u]) break;
   }
   // ---- roots by (gap, id descending): rank by counting (a batch of a few changes has a few roots) ----
   const uint32_t R = s_n_roots;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
     s_rgap[k] = r.gap[t];
     s_roi[k] = obj_index_of(b, b.obj_row[g]);
     s_rid[k] = pack_id(o.id_ctr[g], o.id_actor[g]);
-    s_size[k] = 0;
+    s_slot[t] = (uint16_t)k;   // root index of a batch row -> its slot k in s_roots
   }
   __syncthreads();
   for (uint32_t k = t0; k < R; k += RO_THREADS) {
@@ -182,11 +191,12 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
     s_rank_of_root[k] = rank;
   }
   __syncthreads();
-  // root index of a batch row -> its slot k in s_roots
-  for (uint32_t k = t0; k < R; k += RO_THREADS) s_slot[s_roots[k]] = (uint16_t)k;
-  __syncthreads();
+  // the length of a run: the depth of its last element (the one no new element refers to) + 1; sizes in RANK order
   for (uint32_t t = t0; t < n; t += RO_THREADS)
-    if (s_par[t] != NOT_ELEM) atomicAdd(&s_size[s_rank_of_root[s_slot[s_root[t]]]], 1u);   // sizes in RANK order
+    if (s_par[t] != RO_NOT_ELEM && !(s_has_child[t >> 5] >> (t & 31u) & 1u)) {
+      const uint32_t rd = s_rd[t];
+      s_size[s_rank_of_root[s_slot[rd & 0xffffu]]] = (rd >> 16) + 1u;
+    }
   __syncthreads();
   {
     // s_base = exclusive prefix of the sizes (R <= RESORDER_ROOTS_MAX = RO_THREADS: one root per thread; a single thread walking a
@@ -203,25 +213,27 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   }
   __syncthreads();
   for (uint32_t t = t0; t < n; t += RO_THREADS) {
-    if (s_par[t] == NOT_ELEM) continue;
-    const uint32_t root_t = s_root[t], k = s_slot[root_t];
-    const uint32_t at = s_base[s_rank_of_root[k]] + s_depth[t];
-    r.srt_gap[at] = r.gap[root_t];
+    if (s_par[t] == RO_NOT_ELEM) continue;
+    const uint32_t rd = s_rd[t], k = s_slot[rd & 0xffffu];
+    const uint32_t at = s_base[s_rank_of_root[k]] + (rd >> 16);
+    r.srt_gap[at] = s_rgap[k];
     r.srt_row[at] = r.T0 + t;
   }
-  // new elements per object: a batch names few objects -- usually ONE --, and device-scope atomics on one word execute one after another
-  // (~12 ns each: 49 us for a chunk of 4096 rows). The lanes of a wavefront that name the object of its first element share one.
-  for (uint32_t base = 0; base < n; base += RO_THREADS) {
-    const uint32_t t = base + t0;
-    const bool elem = t < n && s_par[t] != NOT_ELEM;
-    const uint32_t oi = elem ? obj_index_of(b, b.obj_row[r.T0 + t]) : NONE32;
-    const unsigned long long m = __ballot(elem);
-    if (!m) continue;
-    const uint32_t lane = t0 & (WAVE - 1), leader = (uint32_t)__ffsll(m) - 1;
-    const uint32_t loi = __shfl(oi, (int)leader);
-    const unsigned long long same = __ballot(elem && oi == loi);
-    if (lane == leader) atomicAdd(&r.obj_add[loi], (uint32_t)__popcll(same));
-    else if (elem && oi != loi) atomicAdd(&r.obj_add[oi], 1u);
+  // new elements per object, run by run: a batch names few objects -- usually ONE --, and device-scope atomics on one word execute one
+  // after another (~12 ns each). The lanes of a wavefront (a root each) whose runs lie in one object share one.
+  {
+    const uint32_t lane = t0 & (WAVE - 1);
+    const bool mine = t0 < R;
+    const uint32_t oi = mine ? s_roi[t0] : NONE32, sz = mine ? s_size[s_rank_of_root[t0]] : 0u;
+    unsigned long long left = __ballot(mine);
+    while (left) {
+      const uint32_t leader = (uint32_t)__ffsll(left) - 1;
+      const uint32_t loi = __shfl(oi, (int)leader);
+      const bool same = mine && oi == loi;
+      const uint32_t sum = __shfl(wave_incl_scan_u32(same ? sz : 0u, lane), WAVE - 1);
+      if (lane == leader) atomicAdd(&r.obj_add[loi], sum);
+      left &= ~__ballot(same);
+    }
   }
 }
 

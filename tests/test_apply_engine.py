@@ -213,16 +213,18 @@ def test_generated_logs_in_batches_match_the_oracle_emulated(emu_lib, kind, kw, 
 
 
 def test_partition_variants_agree_emulated(emu_lib, monkeypatch):
-    """The dominance counts of the list edits by the three versions of the partition levels -- all levels in LDS in a workgroup of 256
-    (<= 1024 items), all levels in LDS in a workgroup of 1024 with the items held once (<= 11264 items, kd_partition_lds_big), three
-    launches per level -- give the oracle's patches, on batches of a few hundred, ~1200 and ~4800 items (two list objects, deletions)."""
+    """The dominance counts of the list edits by their four versions -- all partition levels in LDS in a workgroup of 256 (<= 1024 items),
+    pairs of 256-item tiles over the whole device (kd_dom_tiles / kd_dom_cross, <= 65536 items), all levels in LDS in a workgroup of 1024
+    with the items held once (<= 11264 items, kd_partition_lds_big), three launches per level -- give the oracle's patches, on batches of a
+    few hundred, ~1200 and ~4800 items (two list objects, deletions)."""
     log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=8, n_rounds=4, ins_per_change=60, del_per_change=15, n_objects=2, seed=29)
     big = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=16, n_rounds=4, ins_per_change=120, del_per_change=30, n_objects=2, seed=31)
     texts = []
     # (+ the second half of the stage by one workgroup without a host round trip, kd_edit_small, against the launches it stands for, and
     #  the stage with its map kernels launched for batches the in-place list merge knows to be free of map rows)
-    for env in ({}, {"AM355_DELTA_NO_BIG_LDS": "1"}, {"AM355_DELTA_NO_LDS": "1"}, {"AM355_DELTA_NO_SMALL": "1", "AM355_DELTA_ALL_KERNELS": "1"}):
-        for k in ("AM355_DELTA_NO_BIG_LDS", "AM355_DELTA_NO_LDS", "AM355_DELTA_NO_SMALL", "AM355_DELTA_ALL_KERNELS"):
+    for env in ({}, {"AM355_DELTA_NO_TILES": "1"}, {"AM355_DELTA_NO_TILES": "1", "AM355_DELTA_NO_BIG_LDS": "1"}, {"AM355_DELTA_NO_LDS": "1"},
+                {"AM355_DELTA_NO_SMALL": "1", "AM355_DELTA_ALL_KERNELS": "1"}):
+        for k in ("AM355_DELTA_NO_TILES", "AM355_DELTA_NO_BIG_LDS", "AM355_DELTA_NO_LDS", "AM355_DELTA_NO_SMALL", "AM355_DELTA_ALL_KERNELS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -235,7 +237,21 @@ def test_partition_variants_agree_emulated(emu_lib, monkeypatch):
         finally:
             for e in engs:
                 e.close()
-    assert texts[0] == texts[1] == texts[2] == texts[3]
+    assert texts[0] == texts[1] == texts[2] == texts[3] == texts[4]
+
+
+def test_batch_of_exactly_1024_edit_items_emulated(emu_lib):
+    """A batch whose list edits are EXACTLY the 1024 items the single-workgroup partition holds (partition_lds_block, four items per thread
+    of 256): the prefix entry behind the last item was nobody's to write, and the group's zero count came from stale LDS
+    (tools/soak_resident.py, seed 7019: every edit of the batch at one index, in position order)."""
+    log = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=1229, ops_per_change=41, seed=7019)
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    eng = engine.Engine(0, emu_lib)
+    try:
+        check_against_oracle_session(eng, [ch[:6], ch[6:31]])
+    finally:
+        eng.close()
 
 
 def _one_by_one(log, head):
