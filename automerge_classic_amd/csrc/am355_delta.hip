@@ -731,30 +731,45 @@ __global__ __launch_bounds__(PART_BIG_THREADS) void kd_partition_lds_big(MergeBu
 // of its edit there (kd_edit_index's work: one launch less).
 constexpr uint32_t DOM_TILE = BLOCK;
 constexpr uint32_t DOM_ITEMS_MAX = DOM_TILE * 256;
-__global__ __launch_bounds__(BLOCK) void kd_dom_tiles(DeltaBufs d, uint32_t m) {
-  __shared__ uint32_t s_tk[DOM_TILE], s_lo[DOM_TILE], s_srt_t[DOM_TILE], s_srt_w[DOM_TILE], s_scan[BLOCK / WAVE];
-  const uint32_t t = threadIdx.x, i0 = blockIdx.x * DOM_TILE, i = i0 + t, cnt = m - i0 < DOM_TILE ? m - i0 : DOM_TILE;
+constexpr uint32_t DOM_SPLIT = 4;   // threads per item in kd_dom_tiles: each takes a quarter of the tile's items (256 dependent steps of one thread were 17 us)
+__global__ __launch_bounds__(DOM_TILE * DOM_SPLIT) void kd_dom_tiles(DeltaBufs d, uint32_t m) {
+  __shared__ uint32_t s_tk[DOM_TILE], s_lo[DOM_TILE], s_srt_t[DOM_TILE], s_srt_w[DOM_TILE], s_scan[DOM_TILE / WAVE];
+  __shared__ uint32_t s_acc[DOM_TILE], s_rank_list[DOM_TILE], s_rank_tile[DOM_TILE];
+  const uint32_t t = threadIdx.x % DOM_TILE, part = threadIdx.x / DOM_TILE, i0 = blockIdx.x * DOM_TILE, i = i0 + t, cnt = m - i0 < DOM_TILE ? m - i0 : DOM_TILE;
   uint32_t tk = NONE32, lo = NONE32;
   if (t < cnt) { tk = d.tk[0][i]; lo = d.lo[0][i]; }
-  s_tk[t] = tk; s_lo[t] = lo;
+  if (part == 0) { s_tk[t] = tk; s_lo[t] = lo; s_acc[t] = 0; s_rank_list[t] = 0; s_rank_tile[t] = 0; }
   __syncthreads();
-  uint32_t acc = 0, rank_list = 0, rank_tile = 0;
   if (t < cnt) {
-    const uint32_t ti = tk >> 2;
-    for (uint32_t j = 0; j < cnt; j++) {
+    uint32_t acc = 0, rank_list = 0, rank_tile = 0;
+    const uint32_t ti = tk >> 2, per = DOM_TILE / DOM_SPLIT, j1 = (part + 1) * per < cnt ? (part + 1) * per : cnt;
+    for (uint32_t j = part * per; j < j1; j++) {
       const uint32_t tkj = s_tk[j], tj = tkj >> 2;
       const bool less = tj < ti, before = less || (tj == ti && j < t), same = s_lo[j] == lo;
       rank_tile += before ? 1u : 0u;
       rank_list += before && same ? 1u : 0u;
       if (less && same && j < t) acc += item_weight(tkj);
     }
-    s_srt_t[rank_tile] = ti; s_srt_w[rank_tile] = item_weight(tk);
+    if (acc) atomicAdd(&s_acc[t], acc);
+    if (rank_list) atomicAdd(&s_rank_list[t], rank_list);
+    if (rank_tile) atomicAdd(&s_rank_tile[t], rank_tile);
   }
   __syncthreads();
-  const uint32_t w = t < cnt ? s_srt_w[t] : 0u;
-  uint32_t tot;
-  const uint32_t ex = block_exclusive_scan_u32(w, s_scan, &tot);
-  if (t < cnt) { d.zf[i] = s_srt_t[t]; d.zw[i] = ex + w; d.acc[0][i] = acc; d.lo[1][i] = rank_list; }   // (zf | zw: the tile's times ascending, the weights up to and with each)
+  if (part == 0 && t < cnt) { s_srt_t[s_rank_tile[t]] = tk >> 2; s_srt_w[s_rank_tile[t]] = item_weight(tk); }
+  __syncthreads();
+  // the weights up to and with each item in time order (the first DOM_TILE threads: a wavefront scan each, then the wavefronts in front)
+  const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const uint32_t w = part == 0 && t < cnt ? s_srt_w[t] : 0u;
+  uint32_t incl = 0;
+  if (part == 0) {   // (whole wavefronts: DOM_TILE is a multiple of WAVE)
+    incl = wave_incl_scan_u32(w, lane);
+    if (lane == WAVE - 1) s_scan[wv] = incl;
+  }
+  __syncthreads();
+  if (part == 0 && t < cnt) {
+    for (uint32_t k = 0; k < wv; k++) incl += s_scan[k];
+    d.zf[i] = s_srt_t[t]; d.zw[i] = incl; d.acc[0][i] = s_acc[t]; d.lo[1][i] = s_rank_list[t];   // (zf | zw: the tile's times ascending, the weights up to and with each)
+  }
 }
 __global__ __launch_bounds__(BLOCK) void kd_dom_cross(DeltaBufs d, uint32_t m) {
   const uint32_t J = blockIdx.x, I = blockIdx.y;
@@ -1338,7 +1353,7 @@ void delta_run(MergeBufs& b, PatchIR& ir, DeltaBufs& d, DeltaCounts* hc, hipStre
       cur = (int)(d.bits_new & 1u);
     } else if (m <= DOM_ITEMS_MAX && !no_lds && !no_tiles) {
       const uint32_t nt = (m + DOM_TILE - 1) / DOM_TILE;
-      hipLaunchKernelGGL(kd_dom_tiles, dim3(nt), dim3(BLOCK), 0, st, d, m);
+      hipLaunchKernelGGL(kd_dom_tiles, dim3(nt), dim3(DOM_TILE * DOM_SPLIT), 0, st, d, m);
       hipLaunchKernelGGL(kd_dom_cross, dim3(nt, nt), dim3(BLOCK), 0, st, d, m);
       AM355_LAUNCH_INDEPENDENT(kd_dom_scatter, dgrid(m), dim3(BLOCK), st, b, d, m);
       cur = 1;

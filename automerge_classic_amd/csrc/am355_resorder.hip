@@ -104,18 +104,18 @@ __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
 constexpr uint32_t RO_THREADS = 1024;
 static_assert(RESORDER_ROOTS_MAX <= RO_THREADS, "kr_order scans the root sizes one root per thread");
 constexpr uint32_t RO_PER = (RESORDER_ROWS_MAX + RO_THREADS - 1) / RO_THREADS;   // rows per thread
-// (LDS: 12288 rows x (parent 2 B + root | depth 4 B + slot 2 B) + the roots' tables = 130 KB of the CU's 160: a batch of 40 changes of 250
+// (LDS: 12288 rows x (root | depth 4 B + new child 2 B + slot 2 B) + the roots' tables = 130 KB of the CU's 160: a batch of 40 changes of 250
 //  ops is ONE chunk. Round 6 first held two copies of root / depth as 32-bit words for 4096 rows; a 10 k-row batch then took three
 //  chunks, each with its own pass over the whole stored order.
 //  What one workgroup must do is the pointer jumping; everything per ROW that needs device memory is done by kr_gaps' wavefronts (the
 //  parent of every row as a 16-bit word, r.par) and everything else is per RUN: its length is its last element's depth + 1, which
 //  sizes the root's stretch and counts the object's new elements -- no atomics per row, no gathers from device memory per row.)
 __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs r) {
-  static_assert(RESORDER_ROWS_MAX < RO_NOT_ELEM, "batch indexes are 16-bit words here");
-  __shared__ uint16_t s_par[RESORDER_ROWS_MAX];      // reference element of a new element, as an index into the batch; RO_ROOT: a root; RO_NOT_ELEM: not an element
-  __shared__ uint32_t s_rd[RESORDER_ROWS_MAX];       // root so far | depth below it << 16
+  static_assert(RESORDER_ROWS_MAX < RO_NOT_ELEM && RESORDER_ROWS_MAX < 0x8000, "batch indexes are 16-bit words here, depths 15 bits");
+  constexpr uint32_t NOT_ELEM_BIT = 1u << 31;
+  __shared__ uint32_t s_rd[RESORDER_ROWS_MAX];       // root so far | depth below it << 16 | NOT_ELEM_BIT: not a new list element
+  __shared__ uint16_t s_kid[RESORDER_ROWS_MAX];      // the new element that refers to this one (0xffff: none)
   __shared__ uint16_t s_slot[RESORDER_ROWS_MAX];     // of a root row: its slot in s_roots
-  __shared__ uint32_t s_has_child[(RESORDER_ROWS_MAX + 31) / 32];   // bit per batch row: a new element refers to it
   __shared__ uint32_t s_roots[RESORDER_ROOTS_MAX], s_rank_of_root[RESORDER_ROOTS_MAX], s_size[RESORDER_ROOTS_MAX], s_base[RESORDER_ROOTS_MAX + 1];
   __shared__ unsigned long long s_rid[RESORDER_ROOTS_MAX];
   __shared__ uint32_t s_rgap[RESORDER_ROOTS_MAX], s_roi[RESORDER_ROOTS_MAX];
@@ -127,21 +127,35 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
     if (r.chunk) { r.words[2] += r.words[1]; r.words[1] = 0; }   // (the elements of the chunk in front are part of the order now)
     else r.words[2] = r.n_list;
   }
-  for (uint32_t w = t0; w < (RESORDER_ROWS_MAX + 31) / 32; w += RO_THREADS) s_has_child[w] = 0;
+  for (uint32_t t = t0; t < n; t += RO_THREADS) s_kid[t] = 0xffff;
   __syncthreads();
   if (r.words[0] || n > RESORDER_ROWS_MAX) { if (t0 == 0) r.words[0] = 1; return; }
-  // ---- parents within the batch (kr_gaps), roots ----
-  for (uint32_t t = t0; t < n; t += RO_THREADS) {
-    const uint16_t par = r.par[t];
-    if (par < RO_NOT_ELEM) {
-      const uint32_t bit = 1u << (par & 31u);
-      if (par >= n || (atomicOr(&s_has_child[par >> 5], bit) & bit)) s_bad = 1;   // a second new child of a new element: not a run
-    } else if (par == RO_ROOT) {
+  // ---- parents within the batch (kr_gaps), roots. A new element with two new children is not a run: both write their index at the
+  //      parent and one of them does not find it there (plain stores -- atomics on a bit per row were 32 lanes on one word) ----
+  uint16_t par[RO_PER];
+#pragma unroll
+  for (uint32_t j = 0; j < RO_PER; j++) {
+    const uint32_t t = t0 + j * RO_THREADS;
+    par[j] = t < n ? r.par[t] : RO_NOT_ELEM;
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < RO_PER; j++) {
+    const uint32_t t = t0 + j * RO_THREADS;
+    if (t >= n) continue;
+    const uint16_t p = par[j];
+    if (p < RO_NOT_ELEM) {
+      if (p >= n) s_bad = 1; else s_kid[p] = (uint16_t)t;
+    } else if (p == RO_ROOT) {
       const uint32_t k = atomicAdd(&s_n_roots, 1u);
       if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
     }
-    s_par[t] = par;
-    s_rd[t] = par < RO_NOT_ELEM && par < n ? (uint32_t)par | 1u << 16 : t;
+    s_rd[t] = p < RO_NOT_ELEM && p < n ? (uint32_t)p | 1u << 16 : p == RO_ROOT ? t : t | NOT_ELEM_BIT;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < RO_PER; j++) {
+    const uint32_t t = t0 + j * RO_THREADS;
+    if (t < n && par[j] < RO_NOT_ELEM && par[j] < n && s_kid[par[j]] != t) s_bad = 1;
   }
   __syncthreads();
   if (s_bad) { if (t0 == 0) r.words[0] = 1; return; }
@@ -192,11 +206,10 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   }
   __syncthreads();
   // the length of a run: the depth of its last element (the one no new element refers to) + 1; sizes in RANK order
-  for (uint32_t t = t0; t < n; t += RO_THREADS)
-    if (s_par[t] != RO_NOT_ELEM && !(s_has_child[t >> 5] >> (t & 31u) & 1u)) {
-      const uint32_t rd = s_rd[t];
-      s_size[s_rank_of_root[s_slot[rd & 0xffffu]]] = (rd >> 16) + 1u;
-    }
+  for (uint32_t t = t0; t < n; t += RO_THREADS) {
+    const uint32_t rd = s_rd[t];
+    if (!(rd & NOT_ELEM_BIT) && s_kid[t] == 0xffff) s_size[s_rank_of_root[s_slot[rd & 0xffffu]]] = (rd >> 16) + 1u;
+  }
   __syncthreads();
   {
     // s_base = exclusive prefix of the sizes (R <= RESORDER_ROOTS_MAX = RO_THREADS: one root per thread; a single thread walking a
@@ -213,8 +226,8 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   }
   __syncthreads();
   for (uint32_t t = t0; t < n; t += RO_THREADS) {
-    if (s_par[t] == RO_NOT_ELEM) continue;
     const uint32_t rd = s_rd[t], k = s_slot[rd & 0xffffu];
+    if (rd & NOT_ELEM_BIT) continue;
     const uint32_t at = s_base[s_rank_of_root[k]] + (rd >> 16);
     r.srt_gap[at] = s_rgap[k];
     r.srt_row[at] = r.T0 + t;
