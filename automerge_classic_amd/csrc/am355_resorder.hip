@@ -138,18 +138,34 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
     const uint32_t t = t0 + j * RO_THREADS;
     par[j] = t < n ? r.par[t] : RO_NOT_ELEM;
   }
+  // (a typing run is a stretch of consecutive rows, each the child of the row in front: inside a wavefront -- 64 consecutive rows -- such a
+  //  stretch is contracted at once, every row pointing at the reference element of the stretch's first row; the jumping below then takes
+  //  log2 of the wavefronts a run spans, not of its length)
+  const uint32_t lane = t0 & (WAVE - 1);
 #pragma unroll
   for (uint32_t j = 0; j < RO_PER; j++) {
     const uint32_t t = t0 + j * RO_THREADS;
-    if (t >= n) continue;
+    const bool active = t < n;
     const uint16_t p = par[j];
-    if (p < RO_NOT_ELEM) {
-      if (p >= n) s_bad = 1; else s_kid[p] = (uint16_t)t;
-    } else if (p == RO_ROOT) {
-      const uint32_t k = atomicAdd(&s_n_roots, 1u);
-      if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
+    if (active) {
+      if (p < RO_NOT_ELEM) {
+        if (p >= n) s_bad = 1; else s_kid[p] = (uint16_t)t;
+      } else if (p == RO_ROOT) {
+        const uint32_t k = atomicAdd(&s_n_roots, 1u);
+        if (k < RESORDER_ROOTS_MAX) s_roots[k] = t; else s_bad = 1;
+      }
     }
-    s_rd[t] = p < RO_NOT_ELEM && p < n ? (uint32_t)p | 1u << 16 : p == RO_ROOT ? t : t | NOT_ELEM_BIT;
+    const bool follows = active && lane > 0 && (uint32_t)p + 1u == t;
+    const unsigned long long heads = __ballot(!follows);
+    const uint32_t hl = 63u - (uint32_t)__clzll(heads & (~0ull >> (63u - lane))), dl = lane - hl;   // (lane 0 is a head)
+    const uint32_t hp = (uint32_t)__shfl((int)p, (int)hl);   // the reference element of the stretch's first row
+    if (active) {
+      uint32_t rd;
+      if (p >= RO_NOT_ELEM || p >= n) rd = p == RO_ROOT ? t : t | NOT_ELEM_BIT;
+      else if (hp < RO_NOT_ELEM) rd = hp | (dl + 1u) << 16;
+      else { rd = (t - dl) | dl << 16; if (hp != RO_ROOT) s_bad = 1; }   // (the stretch hangs below a root of this wavefront)
+      s_rd[t] = rd;
+    }
   }
   __syncthreads();
 #pragma unroll
