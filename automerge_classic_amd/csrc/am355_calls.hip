@@ -302,10 +302,11 @@ int apply_changes_impl(am355_ctx* c, const uint8_t* arena, const uint64_t* offse
   c->sched_prefix = n_old_applied;
   // the state the context holds stays where it is and the batch is merged into it (am355_replay.hip replay_resident) when the staged
   // changes are exactly the applied ones; AM355_NO_RESIDENT=1: the full replay for every call (rounds 3-5; A/B and tests)
-  // (measured, profiles/r06_apply_resident.txt: the batch's host-side work -- headers, SHA-256, schedule: ~2 us per change -- and the
-  // chunk-by-chunk list merge overtake what the skipped device stages cost at about a hundred changes of 250 ops; larger batches take
-  // the full replay, whose stage 1 runs on the device. AM355_RESIDENT_MAX)
-  static const uint32_t resident_max = []() { const char* e = getenv("AM355_RESIDENT_MAX"); return e && atol(e) > 0 ? (uint32_t)atol(e) : 96u; }();
+  // (measured, profiles/r06_s3_apply_seq_big.txt: the batch's host-side work -- headers, SHA-256, schedule: ~2 us per change -- and the
+  // chunk-by-chunk list merge meet what the skipped device stages cost at about 150 changes of 250 ops -- 100 changes 0.55 against
+  // 0.67 ms, 144 changes 0.65 against 0.68-0.75, 200 changes the same --; larger batches take the full replay, whose stage 1 runs on
+  // the device. AM355_RESIDENT_MAX)
+  static const uint32_t resident_max = []() { const char* e = getenv("AM355_RESIDENT_MAX"); return e && atol(e) > 0 ? (uint32_t)atol(e) : 144u; }();
   c->keep.want = append && n > 0 && n <= resident_max && !getenv("AM355_NO_RESIDENT");
   c->keep.n_changes = n_old_applied;
   c->keep.n_ops = old_ops;

@@ -1079,14 +1079,17 @@ static int replay_resident(am355_ctx* c) {
     sha256_digest(raw + off + 8, (size_t)len - 8, hs + 32 * (size_t)(K + i));     // columnar.js:693-705: over the chunk without magic + checksum
     if (memcmp(hs + 32 * (size_t)(K + i), raw + off + 4, 4) != 0) bad_sum.store(1);
   };
-  if (nb >= 32 && c->pool->size() >= 2) {
-    const unsigned parts = std::min<unsigned>(c->pool->size() + 1, 16u);
-    c->pool->run(parts, [&](unsigned t) { for (uint32_t i = t; i < nb; i += parts) hash_one(i); });
-  } else {
-    for (uint32_t i = 0; i < nb; i++) hash_one(i);
-  }
-  if (bad_sum.load()) { (void)hipStreamSynchronize(st); return fallback("checksum"); }
-  lap("batch parsed and hashed (host)");
+  // (run BEHIND the enqueue of the batch's device work, see below: ~1 us per change of the calling thread's time that the device spends decoding)
+  auto hash_batch = [&]() {
+    if (nb >= 32 && c->pool->size() >= 2) {
+      const unsigned parts = std::min<unsigned>(c->pool->size() + 1, 16u);
+      c->pool->run(parts, [&](unsigned t) { for (uint32_t i = t; i < nb; i += parts) hash_one(i); });
+    } else {
+      for (uint32_t i = 0; i < nb; i++) hash_one(i);
+    }
+    return bad_sum.load() == 0;
+  };
+  lap("batch parsed (host)");
   // the hash index of the applied changes (rebuilt when it does not describe exactly them: after a full replay, a reset, a fallback)
   if (c->hash_index_n != K || c->hash_index.empty() || c->hash_index.size() < 4 * (size_t)n) {
     size_t cap = 64;
@@ -1137,8 +1140,6 @@ static int replay_resident(am355_ctx* c) {
   }
   const uint8_t* prev_author_bytes = nullptr;
   uint32_t prev_author_len = 0, prev_author = 0;
-  const uint8_t* prev_deps = nullptr;   // the dependency block of the change in front (a round of synced peers shares it): resolved once
-  uint32_t prev_n_deps = 0, prev_first = 0;
   std::vector<ChangePlan> plans;
   std::vector<uint32_t> amap, dep_first(1, 0), dep_index, op_base(nb);
   plans.reserve(nb); dep_first.reserve(nb + 1); dep_index.reserve(2 * (size_t)nb); amap.reserve(4 * (size_t)nb);
@@ -1149,23 +1150,6 @@ static int replay_resident(am355_ctx* c) {
     const uint32_t ci = K + i;
     if (m.flags || (m.pad & 1)) return fallback_dirty("a change the parser flags");
     const uint8_t* p = raw + m.base;
-    if (hash_index_find(c, hs + 32 * (size_t)ci) != NONE32) return fallback_dirty("duplicate change");
-    // dependencies: all applied already (a change of this batch in front of this one counts)
-    const uint8_t* deps = p + m.deps_off;
-    if (prev_deps && prev_n_deps == m.n_deps && m.n_deps && memcmp(prev_deps, deps, 32 * (size_t)m.n_deps) == 0) {
-      for (uint32_t k = 0; k < m.n_deps; k++) dep_index.push_back(dep_index[prev_first + k]);   // (their head marks are already down)
-    } else {
-      for (uint32_t k = 0; k < m.n_deps; k++) {
-        const uint32_t di = hash_index_find(c, deps + 32 * (size_t)k);
-        if (di == NONE32) return fallback_dirty("dependency not applied yet");
-        dep_index.push_back(di);
-        is_head[di] = 0;
-      }
-    }
-    prev_deps = deps; prev_n_deps = m.n_deps; prev_first = dep_first.back();
-    dep_first.push_back((uint32_t)dep_index.size());
-    is_head[ci] = 1;
-    hash_index_add(c, ci);   // (undone by dropping the index on every fallback below)
     // actor table: author + the others, all known to the document (a new actor changes the ranks of the kept rows: full replay)
     // (a run of changes by one author -- a peer's backlog, a typing session -- looks its rank up once)
     uint32_t author;
@@ -1233,51 +1217,85 @@ static int replay_resident(am355_ctx* c) {
   if (1 + bits_row + bits_ctr + bits_actor > 64) return fallback_dirty("sort key width");
   lap("batch scheduled (host)");
 
-  // ---- commit the host state ----
-  c->hash_index_n = n;
-  for (uint32_t a : new_clock_actors) c->clock_actor.push_back(a);
-  c->clock_seq.clear();
-  for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
-  {
-    std::vector<const uint8_t*> hv;
-    for (uint32_t i = 0; i < n; i++)
-      if (is_head[i]) hv.push_back(hs + 32 * (size_t)i);
-    std::sort(hv.begin(), hv.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
-    std::vector<uint8_t> heads_new(hv.size() * 32);
-    for (size_t k = 0; k < hv.size(); k++) memcpy(&heads_new[32 * k], hv[k], 32);
-    c->heads.swap(heads_new);
-  }
-  {
-    std::vector<ActorSpan> spans;
-    std::vector<uint32_t> tab(NA + 1, 0);
-    spans.reserve(c->spans.size() + plans.size());
-    for (uint32_t a = 0; a < NA; a++) {
-      tab[a] = (uint32_t)spans.size();
-      spans.insert(spans.end(), c->spans.begin() + c->actor_tab_off[a], c->spans.begin() + c->actor_tab_off[a + 1]);
-      spans.insert(spans.end(), add_spans[a].begin(), add_spans[a].end());
+  // ---- the batch's hashes, and what depends on them: not a duplicate, every dependency an applied change (a change of this batch in
+  //      front counts), the heads. Run BEHIND the enqueue of the batch's device work (decode, resolution, list order): SHA-256 of a
+  //      3 KB change is ~1.5 us of the calling thread -- 40 changes 60 us with the lookups -- which the device spends on the batch anyway.
+  //      A batch that fails here has changed the kept arrays: the full replay that follows starts from the staged bytes, as it does
+  //      after any failure. Returns the reason, nullptr when the batch passes. ----
+  auto hashes_and_dependencies = [&]() -> const char* {
+    if (!hash_batch()) return "checksum";
+    const uint8_t* prev_deps = nullptr;   // the dependency block of the change in front (a round of synced peers shares it): resolved once
+    uint32_t prev_n_deps = 0, prev_first = 0;
+    for (uint32_t i = 0; i < nb; i++) {
+      const ChangeMeta& m = metas[i];
+      const uint32_t ci = K + i;
+      const uint8_t* p = raw + m.base;
+      if (hash_index_find(c, hs + 32 * (size_t)ci) != NONE32) return "duplicate change";
+      const uint8_t* deps = p + m.deps_off;
+      if (prev_deps && prev_n_deps == m.n_deps && m.n_deps && memcmp(prev_deps, deps, 32 * (size_t)m.n_deps) == 0) {
+        for (uint32_t k = 0; k < m.n_deps; k++) dep_index.push_back(dep_index[prev_first + k]);   // (their head marks are already down)
+      } else {
+        for (uint32_t k = 0; k < m.n_deps; k++) {
+          const uint32_t di = hash_index_find(c, deps + 32 * (size_t)k);
+          if (di == NONE32) return "dependency not applied yet";
+          dep_index.push_back(di);
+          is_head[di] = 0;
+        }
+      }
+      prev_deps = deps; prev_n_deps = m.n_deps; prev_first = dep_first.back();
+      dep_first.push_back((uint32_t)dep_index.size());
+      is_head[ci] = 1;
+      hash_index_add(c, ci);   // (undone by dropping the index when a later change fails)
     }
-    tab[NA] = (uint32_t)spans.size();
-    c->spans.swap(spans);
-    c->actor_tab_off.swap(tab);
+    return nullptr;
+  };
+  // the per-actor op-id spans with the batch's (what the device tables hold from this call on; the context's copy follows with the commit)
+  std::vector<ActorSpan> spans_new;
+  std::vector<uint32_t> tab_new(NA + 1, 0);
+  spans_new.reserve(c->spans.size() + plans.size());
+  for (uint32_t a = 0; a < NA; a++) {
+    tab_new[a] = (uint32_t)spans_new.size();
+    spans_new.insert(spans_new.end(), c->spans.begin() + c->actor_tab_off[a], c->spans.begin() + c->actor_tab_off[a + 1]);
+    spans_new.insert(spans_new.end(), add_spans[a].begin(), add_spans[a].end());
   }
-  for (uint32_t i = 0; i < nb; i++) { c->applied_change.push_back(K + i); c->applied_op_base.push_back(op_base[i]); }
-  if (c->res_dep_first.empty()) c->res_dep_first.assign(1, 0);
-  for (uint32_t i = 0; i < nb; i++) {
-    c->res_dep_index.insert(c->res_dep_index.end(), dep_index.begin() + dep_first[i], dep_index.begin() + dep_first[i + 1]);
-    c->res_dep_first.push_back((uint32_t)c->res_dep_index.size());
-  }
-  c->n_applied = n; c->n_pending = 0;
-  c->pending_change.clear();
-  c->pass_first_row.clear();
-  c->n_ops = N; c->n_preds = P; c->max_op = max_op;
-  c->has_unknown_cols = false;
-  c->plans = plans;
-  c->amap = amap;
+  tab_new[NA] = (uint32_t)spans_new.size();
+  std::vector<ChangePlan> plans_dev = plans;   // (in the decoder's class order below)
+  // ---- commit the host state (once the batch has passed every check) ----
+  auto commit_host_state = [&]() {
+    c->hash_index_n = n;
+    for (uint32_t a : new_clock_actors) c->clock_actor.push_back(a);
+    c->clock_seq.clear();
+    for (uint32_t a : c->clock_actor) c->clock_seq.push_back(clock[a]);
+    {
+      std::vector<const uint8_t*> hv;
+      for (uint32_t i = 0; i < n; i++)
+        if (is_head[i]) hv.push_back(hs + 32 * (size_t)i);
+      std::sort(hv.begin(), hv.end(), [](const uint8_t* x, const uint8_t* y) { return memcmp(x, y, 32) < 0; });
+      std::vector<uint8_t> heads_new(hv.size() * 32);
+      for (size_t k = 0; k < hv.size(); k++) memcpy(&heads_new[32 * k], hv[k], 32);
+      c->heads.swap(heads_new);
+    }
+    c->spans.swap(spans_new);
+    c->actor_tab_off.swap(tab_new);
+    for (uint32_t i = 0; i < nb; i++) { c->applied_change.push_back(K + i); c->applied_op_base.push_back(op_base[i]); }
+    if (c->res_dep_first.empty()) c->res_dep_first.assign(1, 0);
+    for (uint32_t i = 0; i < nb; i++) {
+      c->res_dep_index.insert(c->res_dep_index.end(), dep_index.begin() + dep_first[i], dep_index.begin() + dep_first[i + 1]);
+      c->res_dep_first.push_back((uint32_t)c->res_dep_index.size());
+    }
+    c->n_applied = n; c->n_pending = 0;
+    c->pending_change.clear();
+    c->pass_first_row.clear();
+    c->n_ops = N; c->n_preds = P; c->max_op = max_op;
+    c->has_unknown_cols = false;
+    c->plans.swap(plans_dev);
+    c->amap = amap;
+  };
 
   // ---- device: tables, the batch's rows, their resolution, then the whole-document order / patch tables ----
   const size_t np = plans.size();
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  const size_t b_plans = sizeof(ChangePlan) * np, b_spans = sizeof(ActorSpan) * c->spans.size(), b_tab = 4 * c->actor_tab_off.size(), b_amap = 4 * amap.size();
+  const size_t b_plans = sizeof(ChangePlan) * np, b_spans = sizeof(ActorSpan) * spans_new.size(), b_tab = 4 * tab_new.size(), b_amap = 4 * amap.size();
   const size_t o_spans = al(b_plans + 16), o_tab = o_spans + al(b_spans + 16), o_x = o_tab + al(b_tab + 16), tables_bytes = o_x + al(b_amap + 16);
   if (!c->d_tables.ensure(tables_bytes) || !c->h_stage.ensure(tables_bytes)) return fail(c, AM355_E_NOMEM, "device allocation failed");
   uint8_t* d_tables = c->d_tables.as<uint8_t>();
@@ -1289,25 +1307,24 @@ static int replay_resident(am355_ctx* c) {
     std::vector<ChangePlan> large, serial;
     size_t w = 0;
     for (size_t i = 0; i < np; i++) {
-      const int wc = change_wave_class(metas[c->plans[i].change - K]);
-      if (wc == 2) c->plans[w++] = c->plans[i];
-      else if (wc == 1) large.push_back(c->plans[i]);
-      else serial.push_back(c->plans[i]);
+      const int wc = change_wave_class(metas[plans_dev[i].change - K]);
+      if (wc == 2) plans_dev[w++] = plans_dev[i];
+      else if (wc == 1) large.push_back(plans_dev[i]);
+      else serial.push_back(plans_dev[i]);
     }
     n_small = (uint32_t)w;
     n_large = (uint32_t)large.size();
-    for (auto& pl : large) c->plans[w++] = pl;
-    for (auto& pl : serial) c->plans[w++] = pl;
+    for (auto& pl : large) plans_dev[w++] = pl;
+    for (auto& pl : serial) plans_dev[w++] = pl;
   }
   {
     uint8_t* h = c->h_stage.as<uint8_t>();
-    if (b_plans) memcpy(h, c->plans.data(), b_plans);
-    if (b_spans) memcpy(h + o_spans, c->spans.data(), b_spans);
-    memcpy(h + o_tab, c->actor_tab_off.data(), b_tab);
+    if (b_plans) memcpy(h, plans_dev.data(), b_plans);
+    if (b_spans) memcpy(h + o_spans, spans_new.data(), b_spans);
+    memcpy(h + o_tab, tab_new.data(), b_tab);
     if (b_amap) memcpy(h + o_x, amap.data(), b_amap);
     { int qrc = queue_upload(c, d_tables, h, o_x + b_amap); if (qrc) return qrc; }
   }
-  { int qrc = queue_upload(c, c->d_hashes.as<uint8_t>() + 32 * (size_t)K, hs + 32 * (size_t)K, 32 * (size_t)nb); if (qrc) return qrc; }
   MergeBufs& b = c->mb;
   b.arena = c->d_arena.as<uint8_t>();
   b.ops = c->cols;
@@ -1343,7 +1360,7 @@ static int replay_resident(am355_ctx* c) {
     ro.sig = b.sig; ro.sig_seq = b.sig_seq;
   }
   c->resident_valid = false;   // (from here on the kept arrays change: a failure leaves no state behind)
-  { int frc = flush_uploads(c); if (frc) return frc; }   // (the batch's bytes, its records, the tables, its hashes, the delta stage's breaks: one launch)
+  { int frc = flush_uploads(c); if (frc) return frc; }   // (the batch's bytes, its records, the tables, the delta stage's breaks: one launch; its hashes follow)
   {
     FillRanges extra;
     extra.add(c->d_counts.p, b.counts_bytes, 0);
@@ -1367,11 +1384,23 @@ static int replay_resident(am355_ctx* c) {
   lap("decode enqueued");
   Counts* hc = c->h_counts.as<Counts>();
   merge_resolve(b, st);
-  bool merged_in_place = false;
+  bool merged_in_place = false, final_in_new = true;
   if (try_resorder) {
     if (!c->pos_valid) resorder_positions(b, NL_old, ro.pos_of, st);
-    bool final_in_new = true;
     resorder_run(b, ro, st, &final_in_new);
+  }
+  lap("resolution / list order enqueued");
+  // ---- host, while the device works on the batch: hashes, duplicates, dependencies; then the commit ----
+  if (const char* why = hashes_and_dependencies()) {
+    (void)hipStreamSynchronize(st);   // (the copy kernel reads the pinned arena; the kernels behind it signal into this call's words)
+    c->staging_in_flight = false;
+    c->pos_valid = false;
+    return fallback_dirty(why);
+  }
+  commit_host_state();
+  { int qrc = queue_upload(c, c->d_hashes.as<uint8_t>() + 32 * (size_t)K, hs + 32 * (size_t)K, 32 * (size_t)nb); if (!qrc) qrc = flush_uploads(c); if (qrc) return qrc; }
+  lap("batch hashed, dependencies checked, committed (host)");
+  if (try_resorder) {
     // its verdict and the flags of the resolution: signalled into pinned words by a launch behind it (two copy dispatches and their wait otherwise)
     uint32_t* hw = c->h_resorder.as<uint32_t>();
     if (wait_host_signal(&b.sig->resorder_seq, b.sig_seq, st)) {

@@ -311,6 +311,60 @@ def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
         eng.close()
 
 
+def test_resident_batches_that_fail_behind_the_device_work_emulated(emu_lib, monkeypatch):
+    """The batch's hashes, the duplicate check and the dependency check run on the host BEHIND the enqueue of its decode / resolution /
+    list merge (replay_resident, hashes_and_dependencies): a batch that fails there has already changed the kept arrays, and the full
+    replay that follows must start from the staged bytes. Text merged in place: a batch that repeats an applied change among new ones,
+    a batch whose second change depends on a change not delivered yet, a batch that holds one change twice -- each followed by calls
+    the resident path serves again; every incremental patch and the final document equal the oracle session's. And a change whose
+    checksum is wrong is rejected like the reference rejects it (the context then starts over, as after any rejected call)."""
+    monkeypatch.setenv("AM355_RESORDER_VERIFY", "1")
+    log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=4, n_rounds=8, ins_per_change=12, del_per_change=3, n_objects=1, seed=71)
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    assert len(ch) >= 30
+    batches = [ch[:10], [ch[10]], [ch[11]],
+               [ch[3], ch[12], ch[13]],          # an applied change again, then two new ones
+               [ch[14]],
+               [ch[15], ch[17]],                 # (same actor's next change first: 17 depends on 16) -> queued by the full path
+               [ch[16]],
+               [ch[18]], [ch[19]],
+               [ch[20], ch[20], ch[21]],         # one change twice in a batch
+               [ch[22]], [ch[23]]] + [[c] for c in ch[24:]]
+    eng = engine.Engine(0, emu_lib)
+    try:
+        check_against_oracle_session(eng, batches)
+        served, fell_back, in_place = eng.resident_counters()
+        assert fell_back >= 3 and served >= len(batches) - 8 and in_place >= 5, (served, fell_back, in_place, len(batches))
+    finally:
+        eng.close()
+    # a wrong checksum in the middle of a batch
+    bad = bytearray(ch[12]); bad[5] ^= 0x40
+    eng = engine.Engine(0, emu_lib)
+    session = oracle_lib.OracleSession()
+    try:
+        for batch in (ch[:10], [ch[10]], [ch[11]]):
+            want = session.apply(batch)
+            eng.apply_changes(ChangeLog.from_changes(batch))
+            assert same_patch(eng.apply_patch_json(), want)
+        with pytest.raises(Exception):
+            eng.apply_changes(ChangeLog.from_changes([bytes(bad), ch[13]]))
+        # (a rejected call leaves the context without a state, whichever path rejected it -- include/am355.h: the caller delivers the
+        #  document's changes again, as js/index.js does)
+        fresh = oracle_lib.OracleSession()
+        want = fresh.apply(ch[:14])
+        eng.apply_changes(ChangeLog.from_changes(ch[:14]))
+        assert same_patch(eng.apply_patch_json(), want)
+        for batch in ([ch[14]], [ch[15]]):
+            want = fresh.apply(batch)
+            eng.apply_changes(ChangeLog.from_changes(batch))
+            assert same_patch(eng.apply_patch_json(), want)
+        assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(fresh.patch_json()))["diffs"]
+        assert eng.resident_counters()[0] >= 4
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("chunk", [0, 5])
 def test_resident_list_order_merged_in_place_emulated(emu_lib, monkeypatch, chunk):
     """(chunk = 5: AM355_RESORDER_CHUNK -- a batch is merged five rows at a time, each chunk against the order the chunks in front left,
