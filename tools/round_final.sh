@@ -12,7 +12,7 @@ bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_round.log 2>&1
 timeout 300 python tools/time_apply.py > gpurun_out/$TAG/apply_changes_timings.jsonl 2> gpurun_out/$TAG/apply_changes_timings.err
 # applyChanges call after call onto a kept state (resident path): ms per call for several batch sizes, and the stream commands of one call
 {
-  for spec in "c4_text_single 1 40" "c4_text_single 4 20" "c4_text_single 16 8" "c4_text_single 40 8" "c4_text_single 100 8" "c2_text_typing 1 40" "c4_text_multi 2 40" "c3_map_lww 1 40"; do
+  for spec in "c4_text_single 1 40" "c4_text_single 4 20" "c4_text_single 16 8" "c4_text_single 40 8" "c4_text_single 64 8" "c4_text_single 96 6" "c4_text_single 144 5" "c4_text_single 200 5" "c2_text_typing 1 40" "c4_text_multi 2 40" "c3_map_lww 1 40"; do
     set -- $spec
     echo "== $1: $2 change(s) per call"; timeout 200 python tools/profile_apply_seq.py $1 1.0 $2 $3
     echo "   full replay per call:"; AM355_NO_RESIDENT=1 timeout 200 python tools/profile_apply_seq.py $1 1.0 $2 $3
@@ -20,7 +20,10 @@ timeout 300 python tools/time_apply.py > gpurun_out/$TAG/apply_changes_timings.j
 } > gpurun_out/$TAG/apply_seq_timings.txt 2>&1
 ( export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/prof_apply_seq -o run -- python tools/profile_apply_seq.py c4_text_single 1.0 1 40 > gpurun_out/$TAG/prof_apply_seq.log 2>&1
   python tools/rocpd_timeline.py $(find gpurun_out/$TAG/prof_apply_seq -name "*.db" | head -1) -3 k_decode > gpurun_out/$TAG/apply_seq_timeline.txt 2>&1
-  rm -rf gpurun_out/$TAG/prof_apply_seq )
+  rm -rf gpurun_out/$TAG/prof_apply_seq
+  timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/prof_apply40 -o run -- python tools/profile_apply_seq.py c4_text_single 1.0 40 8 > gpurun_out/$TAG/prof_apply40.log 2>&1
+  python tools/rocpd_timeline.py $(find gpurun_out/$TAG/prof_apply40 -name "*.db" | head -1) -3 k_decode > gpurun_out/$TAG/apply40_timeline.txt 2>&1
+  rm -rf gpurun_out/$TAG/prof_apply40 )
 timeout 200 python tools/time_history.py > gpurun_out/$TAG/history_trace.txt 2>&1
 ls gpurun_out/$TAG
 cat gpurun_out/$TAG/bench_line.json; echo
