@@ -1354,6 +1354,7 @@ static int replay_resident(am355_ctx* c) {
     if (!c->d_pos.ensure_keep(4 * cap_rows, c->pos_valid ? 4 * (size_t)old_ops : 0) || !c->d_resorder.ensure(resorder_bytes(NN, NO)) || !c->h_resorder.ensure(64))
       return fail(c, AM355_E_NOMEM, "device allocation failed (resident list order)");
     resorder_bind(ro, c->d_resorder.p, NN, NO);
+    canary_arm();   // (AM355_CANARY=1 only)
     ro.T0 = (uint32_t)old_ops; ro.n_new = NN; ro.n_list = NL_old; ro.n_obj = NO;
     ro.pos_of = c->d_pos.as<uint32_t>();
     ro.order_new = c->order_alt_ptr;
@@ -1364,7 +1365,7 @@ static int replay_resident(am355_ctx* c) {
   {
     FillRanges extra;
     extra.add(c->d_counts.p, b.counts_bytes, 0);
-    if (try_resorder) extra.add(ro.obj_add, 4 * ((size_t)NO + 2) + 256 + 64, 0);   // obj_add | words (neighbours in the block)
+    if (try_resorder) extra.add(ro.obj_add, (size_t)((uint8_t*)(ro.words + 8) - (uint8_t*)ro.obj_add), 0);   // obj_add | words (neighbours in the block, resorder_bind)
     merge_prepare(b, st, MERGE_FILL_ROWS, &extra);   // (the new rows' accumulators; in this stream: the decode of a small batch is too short to hide a second stream's join)
   }
   // (launch_decode_columns puts a class on the second stream only when the small class and the lane-serial one are both there and no

@@ -27,14 +27,17 @@ size_t resorder_bytes(uint32_t n_new, uint32_t n_obj) {
 }
 
 void resorder_bind(ResOrderBufs& r, void* block, uint32_t n_new, uint32_t n_obj) {
+  canary_scope("resident list order (resorder_bind)");
+  canary_forget(block, resorder_bytes(n_new, n_obj));
   uint8_t* p = (uint8_t*)block;
-  auto take = [&](size_t bytes) { void* q = p; p += al256(bytes); return q; };
+  auto take = [&](size_t bytes) { void* q = p; canary_note(p, bytes); p += al256(bytes); return q; };
   r.gap = (uint32_t*)take(4 * ((size_t)n_new + 1));
   r.srt_gap = (uint32_t*)take(4 * ((size_t)n_new + 1));
   r.srt_row = (uint32_t*)take(4 * ((size_t)n_new + 1));
   r.par = (uint16_t*)take(2 * ((size_t)n_new + 1));
   r.obj_add = (uint32_t*)take(4 * ((size_t)n_obj + 2));
   r.words = (uint32_t*)take(64);
+  canary_allow(r.obj_add, (size_t)((uint8_t*)(r.words + 8) - (uint8_t*)r.obj_add));   // (cleared by one fill, replay_resident)
 }
 
 __global__ __launch_bounds__(BLOCK) void kr_positions(MergeBufs b, uint32_t n_list, uint32_t* __restrict__ pos_of) {
