@@ -148,6 +148,12 @@ extern "C" int am355_resident_counters(const am355_ctx* c, uint64_t out[3]) {
   return AM355_OK;
 }
 
+extern "C" int am355_resident_maps_only_calls(const am355_ctx* c, uint64_t* out) {
+  if (!c || !out) return AM355_E_ARG;
+  *out = c->n_maps_only_calls;
+  return AM355_OK;
+}
+
 extern "C" int am355_get_raw(const am355_ctx* c, const uint8_t** arena, const uint64_t** offsets, uint32_t* n) {
   if (!c || !c->staged) return AM355_E_STATE;
   if (arena) *arena = c->raw.data();

@@ -131,6 +131,8 @@ void merge_prepare(MergeBufs& b, hipStream_t aux, int what = MERGE_FILL_ROWS | M
 // twice without draining the stream (ev_counts, ev_runs: the host sizes the later launches while the device works through
 // the earlier ones) and once at the end (synchronises st). Returns the counters in *h_counts.
 void merge_run(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st, hipEvent_t ev_counts, hipEvent_t ev_runs, bool resolved = false);
+// the map half alone (rows resolved; a batch of plain map rows onto a kept state): see am355_merge.hip
+void merge_run_maps(MergeBufs& b, PatchIR& ir, Counts* h_counts, hipStream_t st);
 // k_resolve alone over the rows >= b.first_row (replay_resident: the list order of a small batch is then updated in place,
 // am355_resorder.hip, or merge_run(..., resolved = true) goes on from k_emit)
 void merge_resolve(MergeBufs& b, hipStream_t st);

@@ -423,11 +423,48 @@ __device__ __forceinline__ bool map_emission_less(const MergeBufs& b, uint32_t e
   if (ta != tb) return ta < tb;
   return ea < eb;
 }
+// What a comparison of two emissions looks at, staged once per emission (LDS): object, key length, the key's first sixteen bytes as two
+// big-endian words in UTF-16 order (zero behind the key's end), trigger id. A rank by comparison with every other emission then reads
+// LDS: from the rows, every one of a thread's n comparisons was a chain of dependent loads (64 emissions: 137 us in one workgroup).
+struct MapStaged {
+  uint32_t oi, len;
+  unsigned long long k0, k1, trig;
+};
+__device__ __forceinline__ MapStaged map_stage(const MergeBufs& b, uint32_t e, const uint32_t* __restrict__ obj_rank) {
+  const uint32_t g = b.em_row[e];
+  MapStaged m;
+  m.oi = obj_index_of(b, b.obj_row[g]);
+  if (obj_rank) m.oi = obj_rank[m.oi];
+  m.len = b.ops.key_len[g];
+  const uint8_t* p = b.arena + b.ops.key_off[g];
+  m.k0 = m.k1 = 0;
+  for (uint32_t j = 0; j < 16; j++) {
+    const unsigned long long x = j < m.len ? utf16_order_byte(p[j]) : 0u;
+    if (j < 8) m.k0 = m.k0 << 8 | x; else m.k1 = m.k1 << 8 | x;
+  }
+  m.trig = b.em_trig[e];
+  return m;
+}
+// a < b in (object, key bytes in UTF-16 order -- a prefix sorts first --, trigger id, emission) order; ea / eb: their emission indexes
+__device__ __forceinline__ bool map_staged_less(const MergeBufs& b, const MapStaged& x, uint32_t ea, const MapStaged& y, uint32_t eb, const uint32_t* __restrict__ obj_rank) {
+  if (x.oi != y.oi) return x.oi < y.oi;
+  // (differing prefixes decide: where they first differ either both keys have a byte, or the shorter one is padded with zero and sorts first)
+  if (x.k0 != y.k0) return x.k0 < y.k0;
+  if (x.k1 != y.k1) return x.k1 < y.k1;
+  if (x.len > 16 || y.len > 16) return map_emission_less(b, ea, eb, obj_rank);   // (the bytes behind the sixteenth: from the rows)
+  if (x.len != y.len) return x.len < y.len;   // (equal prefixes, both short: the longer one ends in zero bytes)
+  if (x.trig != y.trig) return x.trig < y.trig;
+  return ea < eb;
+}
 __global__ __launch_bounds__(BLOCK) void k_map_sort_small(MergeBufs b, uint32_t n, const uint32_t* __restrict__ obj_rank, uint32_t* __restrict__ perm) {
+  __shared__ MapStaged s_m[MAP_SORT_SMALL];   // (every workgroup stages all n <= MAP_SORT_SMALL emissions: two per thread)
+  for (uint32_t j = threadIdx.x; j < n && j < MAP_SORT_SMALL; j += BLOCK) s_m[j] = map_stage(b, j, obj_rank);
+  __syncthreads();
   uint32_t i = gtid();
   if (i >= n) return;
+  const MapStaged mine = s_m[i];
   uint32_t rank = 0;
-  for (uint32_t j = 0; j < n; j++) rank += map_emission_less(b, j, i, obj_rank) ? 1u : 0u;
+  for (uint32_t j = 0; j < n; j++) rank += map_staged_less(b, s_m[j], j, mine, i, obj_rank) ? 1u : 0u;
   perm[rank] = i;
 }
 
@@ -504,10 +541,14 @@ __global__ __launch_bounds__(BLOCK) void k_map_finish(MergeBufs b, const uint32_
 // up to BLOCK emissions (a text document's root map: one): ranks by comparison and the records, one workgroup, one launch
 __device__ __forceinline__ void map_small_finish(const MergeBufs& b, uint32_t n, const PatchIR& ir) {
   __shared__ uint32_t s_perm[BLOCK];
+  __shared__ MapStaged s_m[BLOCK];
   uint32_t i = threadIdx.x;
+  if (i < n) s_m[i] = map_stage(b, i, nullptr);
+  __syncthreads();
   if (i < n) {
+    const MapStaged mine = s_m[i];
     uint32_t rank = 0;
-    for (uint32_t j = 0; j < n; j++) rank += map_emission_less(b, j, i, nullptr) ? 1u : 0u;
+    for (uint32_t j = 0; j < n; j++) rank += map_staged_less(b, s_m[j], j, mine, i, nullptr) ? 1u : 0u;
     s_perm[rank] = i;
   }
   __syncthreads();
@@ -1572,7 +1613,7 @@ static void order_map_emissions(MergeBufs& b, PatchIR& ir, const Counts* hc, hip
     return;
   }
   if (ne <= MAP_SORT_SMALL) {
-    AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(ne), dim3(BLOCK), st, b, ne, (const uint32_t*)nullptr, perm_b);  // (one emission: rank 0)
+    hipLaunchKernelGGL(k_map_sort_small, grid_for(ne), dim3(BLOCK), 0, st, b, ne, (const uint32_t*)nullptr, perm_b);  // (one emission: rank 0)
     cur = 1;
   } else {
     AM355_LAUNCH_INDEPENDENT(k_iota, grid_for(ne), dim3(BLOCK), st, perm_a, ne);
@@ -1770,6 +1811,30 @@ void merge_run(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st, hipEvent_t
     hc->map_group_big = 0;
   }
   lap("done");
+}
+
+// The map half of merge_run alone, for a batch the caller knows to hold plain map rows only (replay_resident: `set` / `del` on string
+// keys, no object made, no increment): visibility verdicts and map emissions of all rows (k_emit), the object table with its map ranges
+// (k_compact_rows, k_map_finish), the map records in patch order. No list kernel runs: the stored list order, positions and per-object
+// element counts stay what they are -- a batch without list rows cannot change them --, the whole-document EDIT tables are stale
+// afterwards (the caller marks them so: ensure_ir_fresh). Counts of the list side in *hc are k_emit's / k_compact_rows' recount.
+void merge_run_maps(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
+  const uint32_t N = b.n_ops;
+  hipLaunchKernelGGL(k_emit, grid_for(N), dim3(BLOCK), 0, st, b);
+  hipLaunchKernelGGL(k_compact_rows, grid_for(N), dim3(BLOCK), 0, st, b, ir);
+  MapKeyStats key_stats;
+  if (b.sig) read_phase_counts(b, &b.sig->counts_seq, b.sig->counts, hc, st, &key_stats);
+  else { (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st); }
+  if (hc->flags) { (void)hipStreamSynchronize(st); return; }
+  order_map_emissions(b, ir, hc, st, nullptr, b.sig ? &key_stats : nullptr);
+  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+  (void)hipStreamSynchronize(st);
+  if (hc->map_group_big) {
+    (void)hipMemsetAsync(&b.counts->map_group_big, 0, sizeof(uint32_t), st);
+    order_map_emissions(b, ir, hc, st, nullptr, b.sig ? &key_stats : nullptr, true);
+    (void)hipStreamSynchronize(st);
+    hc->map_group_big = 0;
+  }
 }
 
 // Whole-document patch of canonical rows (document load). Synchronises the stream twice (counts).
@@ -2025,7 +2090,7 @@ void save_phase2(MergeBufs& b, PatchIR& ir, SaveBufs& s, const uint32_t* words, 
       cur ^= res;
     };
     if (nm > 1 && nm <= MAP_SORT_SMALL) {
-      AM355_LAUNCH_INDEPENDENT(k_map_sort_small, grid_for(nm), dim3(BLOCK), st, b, nm, (const uint32_t*)s.obj_rank, perm_b);
+      hipLaunchKernelGGL(k_map_sort_small, grid_for(nm), dim3(BLOCK), 0, st, b, nm, (const uint32_t*)s.obj_rank, perm_b);
       cur = 1;
     } else if (nm > 1) {
       pass(MK_TRIGGER, 0, b.bits_ctr + b.bits_actor);

@@ -1385,7 +1385,7 @@ static int replay_resident(am355_ctx* c) {
   lap("decode enqueued");
   Counts* hc = c->h_counts.as<Counts>();
   merge_resolve(b, st);
-  bool merged_in_place = false, final_in_new = true;
+  bool merged_in_place = false, maps_only = false, final_in_new = true;
   if (try_resorder) {
     if (!c->pos_valid) resorder_positions(b, NL_old, ro.pos_of, st);
     resorder_run(b, ro, st, &final_in_new);
@@ -1433,12 +1433,25 @@ static int replay_resident(am355_ctx* c) {
       c->batch_list_only = true;
       merged_in_place = true;
       lap("list order merged in place");
+    } else if (hw[3] == 0 && !getenv("AM355_NO_MAPS_ONLY")) {
+      // a batch of plain map rows (`set` / `del` on string keys): no list changes -- the stored order, positions and element counts stay,
+      // the map half of the merge runs alone (visibility, object table, map records in patch order); the whole-document edit tables are
+      // stale from here on, as after an in-place list merge
+      merge_run_maps(b, c->ir, hc, st);
+      lap("map half of the merge done");
+      if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
+      c->counts.n_map_emit = hc->n_map_emit;
+      c->counts.max_key_len = hc->max_key_len;
+      c->ir_stale = true;
+      c->ir_fetched = false;
+      c->n_maps_only_calls++;
+      maps_only = true;
     } else {
       c->pos_valid = false;
       lap("list order: not a batch for the in-place merge");
     }
   }
-  if (!merged_in_place) {
+  if (!merged_in_place && !maps_only) {
     merge_prepare(b, st, MERGE_FILL_TABLES);
     merge_run(b, c->ir, hc, st, nullptr, c->ev_runs, true);
     lap("merge_run done");

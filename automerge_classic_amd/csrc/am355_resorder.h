@@ -22,7 +22,8 @@ struct ResOrderBufs {
   uint32_t* srt_row;         // [n_new] ... and row
   uint32_t* obj_add;         // [n_obj + 1] new elements per object (cleared by the caller)
   uint32_t* words;           // [8] (cleared by the caller): [0] != 0: not served here (the caller orders all lists anew), [1] new
-                             // elements of the last chunk, [2] elements in front of them: the order holds [1] + [2] after the call
+                             // elements of the last chunk, [2] elements in front of them: the order holds [1] + [2] after the call;
+                             // [3] != 0: some row of the batch is not a plain map row (kr_gaps)
   HostSignals* sig;          // the words + Counts.flags for the host through pinned memory (HostSignals.resorder), nullptr: the caller copies them
   uint32_t sig_seq;
 };

@@ -54,12 +54,15 @@ constexpr uint32_t GAP_STEPS_MAX = 4096;   // 64 positions each: a scan past 262
 __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
   const uint32_t t = blockIdx.x, lane = threadIdx.x;
   if (t >= r.n_new) return;
-  // (a chunk behind one that was refused: the order it would scan was never written)
-  if (r.chunk && r.words[0]) return;
   const uint32_t g = r.T0 + t;
   const OpCols& o = b.ops;
   const uint8_t kind = b.kind[g];
   const uint32_t a = o.action[g];
+  // words[3]: some row of the batch is not a plain map row (`set` of a value / `del` on a string key). A batch of such rows only leaves
+  // every list as it is: the caller then runs the map half of the merge alone (merge_run_maps). Every chunk's rows are looked at.
+  if (lane == 0 && !((kind == K_MAP && a == 1) || (kind == K_DEL && o.key_len[g] != NONE32))) r.words[3] = 1;
+  // (a chunk behind one that was refused: the order it would scan was never written)
+  if (r.chunk && r.words[0]) return;
   uint32_t gap = NONE32;
   bool refuse = false;
   const bool list_del = kind == K_DEL && o.key_len[g] == NONE32;

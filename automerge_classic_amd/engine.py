@@ -97,6 +97,9 @@ def _bind(path):
     if hasattr(L, "am355_resident_counters"):   # (tools/ab_apply.sh loads libraries of earlier commits; tests/test_abi.py holds the shipped one to the header)
         L.am355_resident_counters.argtypes = [vp, vp]
         L.am355_resident_counters.restype = ctypes.c_int
+    if hasattr(L, "am355_resident_maps_only_calls"):
+        L.am355_resident_maps_only_calls.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.am355_resident_maps_only_calls.restype = ctypes.c_int
     L.am355_get_raw.argtypes = [vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32)]
     L.am355_doc_changes.argtypes = [vp, u32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_void_p)]
     L.am355_apply_changes.argtypes = [vp, vp, u64p, u32]
@@ -336,6 +339,12 @@ class Engine:
         out = (ctypes.c_uint64 * 3)()
         self._check(self._L.am355_resident_counters(self._h, out))
         return int(out[0]), int(out[1]), int(out[2])
+
+    def resident_maps_only_calls(self):
+        """Calls of apply_changes onto the resident state whose batch held plain map rows only (the map half of the merge ran alone)."""
+        out = ctypes.c_uint64()
+        self._check(self._L.am355_resident_maps_only_calls(self._h, ctypes.byref(out)))
+        return int(out.value)
 
     def raw(self):
         """(arena, offsets) as staged: the uncompressed change containers back to back (copies)."""

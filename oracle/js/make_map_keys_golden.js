@@ -4,6 +4,9 @@
 // whole-document patch (UTF-16 code unit order of the keys, then op id; new.js:84, 1035-1039) through every pass the engine's map
 // sort may skip or keep (MapKeyStats). Patches of the UNMODIFIED reference, in the format of make_golden.js.
 //   NODE_PATH=oracle/js_shims/node_modules node oracle/js/make_map_keys_golden.js tests/golden/map_keys_mixed.json
+// With a third argument s: every s-th key only -- s = 2 (~440 keys: the engine ranks 257 .. 512 map records by comparison in LDS,
+// k_map_sort_small) and s = 5 (~180 keys: one workgroup ranks and finishes up to 256, map_small_finish); round 6:
+//   ... make_map_keys_golden.js tests/golden/map_keys_mid.json 2 ;  ... tests/golden/map_keys_small.json 5
 const fs = require('fs')
 const { loadBackend } = require('./ref_loader')
 const { Backend, columnar } = loadBackend()
@@ -20,7 +23,8 @@ for (let i = 0; i < 60; i++) keys.push(['é', '日本', '😀', '￮', 'ß', 'Ω
 for (let i = 0; i < 100; i++) keys.push('same-len-' + String.fromCharCode(97 + (i % 26)) + String.fromCharCode(97 + Math.floor(i / 26)) + '-tail')
 for (let i = 0; i < 120; i++) keys.push(String.fromCharCode(33 + (i % 90)))               // one byte (with repeats -> conflicts by assignment below)
 for (let i = 0; i < 60; i++) keys.push('0123456789abcdef' + 'z'.repeat(i % 5) + i)      // equal in the first sixteen bytes
-const uniq = Array.from(new Set(keys))
+const stride = parseInt(process.argv[3] || '1')
+const uniq = Array.from(new Set(keys)).filter((k, i) => i % stride === 0)
 
 const A = '0a0a0a0a', B = 'b1b1b1b1'
 const ops1 = [{ action: 'makeMap', obj: '_root', key: 'nested', pred: [] }]
@@ -36,7 +40,7 @@ const c3 = { actor: A, seq: 2, startOp: 2 + uniq.length, time: 0, deps: [hashOf(
 const changes = [c1, c2, c3].map(encodeChange)
 const state = Backend.loadChanges(Backend.init(), changes)
 const doc = Backend.save(state)
-const fx = { name: 'map_keys_mixed', note: 'hand-built: ' + uniq.length + ' map keys of many shapes, two actors, conflicts (oracle/js/make_map_keys_golden.js)',
+const fx = { name: require('path').basename(process.argv[2], '.json'), note: 'hand-built: ' + uniq.length + ' map keys of many shapes, two actors, conflicts (oracle/js/make_map_keys_golden.js)',
   changes: changes.map(b64), patch: JSON.stringify(Backend.getPatch(state)), doc: b64(doc), load_patch: JSON.stringify(Backend.getPatch(Backend.load(doc))),
   stock_equals_bigblock: true }
 fs.writeFileSync(process.argv[2], JSON.stringify(fx))

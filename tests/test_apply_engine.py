@@ -311,6 +311,74 @@ def test_resident_state_small_batches_emulated(emu_lib, monkeypatch):
         eng.close()
 
 
+def _changes_of(log):
+    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
+    return [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+
+
+def mixed_document_batches(seed, text_kw, map_kw, held_text):
+    """A document that holds a Text AND root-map keys: the changes of a concurrent-text log and of a map log (two sets of actors, two
+    histories side by side -- neither depends on the other). The first batch holds the text log but its last `held_text` changes and the
+    first round of the map log (every actor known from then on); then map changes, text changes and pairs of both take turns."""
+    text = _changes_of(loggen.generate(loggen.KIND_TEXT_CONCURRENT, seed=seed, **text_kw))
+    maps = _changes_of(loggen.generate(loggen.KIND_MAP_LWW, seed=seed + 1, **map_kw))
+    na = map_kw["n_actors"]
+    batches = [text[:len(text) - held_text] + maps[:na]]
+    t, m = len(text) - held_text, na
+    k = 0
+    while t < len(text) or m < len(maps):
+        turn = k % 4
+        if turn in (0, 1) and m < len(maps):
+            n = 1 if turn == 0 else min(3, len(maps) - m)
+            batches.append(maps[m:m + n]); m += n                       # map rows only
+        elif turn == 2 and t < len(text):
+            batches.append([text[t]]); t += 1                           # list rows only
+        elif t < len(text) and m < len(maps):
+            batches.append([text[t], maps[m]]); t += 1; m += 1          # both: the full merge
+        elif m < len(maps):
+            batches.append([maps[m]]); m += 1
+        else:
+            batches.append([text[t]]); t += 1
+        k += 1
+    return batches
+
+
+def test_resident_map_batches_leave_the_lists_alone_emulated(emu_lib, monkeypatch):
+    """A batch of plain map rows onto a kept state (replay_resident, merge_run_maps): the map half of the merge alone -- no list kernel
+    runs, the stored order stays --, in turn with list-only batches merged in place and mixed batches that take the whole merge. Every
+    incremental patch, getPatch in between and at the end (which rebuilds the stale edit tables and, AM355_RESORDER_VERIFY, compares the
+    order) equal the oracle session's; and the same calls with the path switched off."""
+    monkeypatch.setenv("AM355_RESORDER_VERIFY", "1")
+    batches = mixed_document_batches(81, dict(n_actors=4, n_rounds=6, ins_per_change=15, del_per_change=4, n_objects=2),
+                                     dict(n_actors=3, n_rounds=12, n_keys=25), held_text=12)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("AM355_NO_MAPS_ONLY", "1")
+        eng = engine.Engine(0, emu_lib)
+        session = oracle_lib.OracleSession()
+        try:
+            for i, batch in enumerate(batches):
+                want = session.apply(batch)
+                eng.apply_changes(ChangeLog.from_changes(batch))
+                assert same_patch(eng.apply_patch_json(), want), f"batch {i}"
+                if i % 7 == 3:
+                    assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"getPatch after batch {i}"
+            assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"]
+            served, fell_back, in_place = eng.resident_counters()
+            maps_only = eng.resident_maps_only_calls()
+            if off:
+                assert maps_only == 0
+            else:
+                assert maps_only >= 10 and in_place >= 5 and served >= len(batches) - 3, (served, fell_back, in_place, maps_only, len(batches))
+            doc = bytes(eng.save())
+            back = oracle_lib.OracleSession(doc)
+            assert dict(_ordered(back.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"]
+            back.close()
+        finally:
+            eng.close()
+            session.close()
+
+
 def test_resident_batches_that_fail_behind_the_device_work_emulated(emu_lib, monkeypatch):
     """The batch's hashes, the duplicate check and the dependency check run on the host BEHIND the enqueue of its decode / resolution /
     list merge (replay_resident, hashes_and_dependencies): a batch that fails there has already changed the kept arrays, and the full
@@ -703,6 +771,31 @@ def test_bench_workloads_in_batches_match_the_oracle_gpu(name, scale, n_batches)
         check_against_oracle_session(eng, split_log(log, n_batches))
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_resident_map_batches_leave_the_lists_alone_gpu(monkeypatch):
+    """test_resident_map_batches_leave_the_lists_alone_emulated's calls on the GPU, on a larger document (a 60 k-op text, 2 objects, and
+    150 map changes): map-only batches run the map half of the merge alone, list-only batches merge in place, mixed ones take the whole
+    merge; every incremental patch and the whole-document patch every 25 calls equal the oracle session's."""
+    monkeypatch.setenv("AM355_RESORDER_VERIFY", "1")
+    batches = mixed_document_batches(83, dict(n_actors=8, n_rounds=10, ins_per_change=600, del_per_change=150, n_objects=2),
+                                     dict(n_actors=6, n_rounds=25, n_keys=300), held_text=30)
+    eng = engine.Engine(0)
+    session = oracle_lib.OracleSession()
+    try:
+        for i, batch in enumerate(batches):
+            want = session.apply(batch)
+            eng.apply_changes(ChangeLog.from_changes(batch))
+            assert same_patch(eng.apply_patch_json(), want), f"batch {i}"
+            if i % 25 == 24:
+                assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"getPatch after batch {i}"
+        assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"]
+        served, fell_back, in_place = eng.resident_counters()
+        assert eng.resident_maps_only_calls() >= 40 and in_place >= 10 and fell_back <= 2, (served, fell_back, in_place, eng.resident_maps_only_calls(), len(batches))
+    finally:
+        eng.close()
+        session.close()
 
 
 @pytest.mark.gpu

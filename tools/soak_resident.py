@@ -19,10 +19,10 @@ from test_apply_vectors import same_patch  # noqa: E402
 
 LIB = os.environ.get("AM355_TOOL_LIB")
 first, count = int(sys.argv[1]), int(sys.argv[2])
-totals = {"sessions": 0, "calls": 0, "served": 0, "fell_back": 0, "in_place": 0, "refused": 0}
+totals = {"sessions": 0, "calls": 0, "served": 0, "fell_back": 0, "in_place": 0, "maps_only": 0, "refused": 0}
 for seed in range(first, first + count):
     rnd = random.Random(seed)
-    kind = rnd.choice(["typing", "concurrent", "concurrent", "concurrent_small", "map"])
+    kind = rnd.choice(["typing", "concurrent", "concurrent", "concurrent_small", "map", "mixed", "mixed"])
     if kind == "typing":
         log = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=rnd.randint(200, 3000), ops_per_change=rnd.randint(1, 60), seed=seed)
     elif kind == "concurrent":
@@ -31,13 +31,33 @@ for seed in range(first, first + count):
     elif kind == "concurrent_small":
         log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=rnd.randint(2, 6), n_rounds=rnd.randint(4, 12), ins_per_change=rnd.randint(1, 4),
                               del_per_change=rnd.randint(0, 2), n_objects=rnd.randint(1, 2), seed=seed)
+    elif kind == "mixed":
+        # a Text (or several) AND root-map keys in one document: two logs side by side, their changes interleaved at random (each log's own
+        # order kept) -- batches of map rows only (the map half of the merge alone), of list rows only (in place), of both (the whole merge)
+        log = None
+        la = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=rnd.randint(2, 6), n_rounds=rnd.randint(3, 7), ins_per_change=rnd.randint(3, 60),
+                             del_per_change=rnd.randint(0, 10), n_objects=rnd.randint(1, 2), seed=seed)
+        lb = loggen.generate(loggen.KIND_MAP_LWW, n_actors=rnd.randint(2, 4), n_rounds=rnd.randint(4, 12), n_keys=rnd.randint(5, 40), seed=seed + 500000)
     else:
         log = loggen.generate(loggen.KIND_MAP_LWW, n_actors=rnd.randint(2, 6), n_rounds=rnd.randint(3, 8), n_keys=rnd.randint(5, 60), seed=seed)
     os.environ.pop("AM355_RESORDER_CHUNK", None)
     if rnd.random() < 0.4:
         os.environ["AM355_RESORDER_CHUNK"] = str(rnd.choice([3, 7, 50, 400]))
-    arena, offs = bytes(log.arena), [int(x) for x in log.offsets]
-    ch = [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    def changes_of(lg):
+        arena, offs = bytes(lg.arena), [int(x) for x in lg.offsets]
+        return [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    if kind == "mixed":
+        ca, cb = changes_of(la), changes_of(lb)
+        ch, ia, ib = [], 0, 0
+        run_a = True
+        while ia < len(ca) or ib < len(cb):   # stretches of one log, then of the other
+            take = rnd.randint(1, 6)
+            if run_a and ia < len(ca): ch += ca[ia:ia + take]; ia += take
+            elif ib < len(cb): ch += cb[ib:ib + take]; ib += take
+            else: ch += ca[ia:ia + take]; ia += take
+            run_a = not run_a
+    else:
+        ch = changes_of(log)
     k = max(1, rnd.randint(1, max(1, len(ch) // 2)))
     batches = [ch[:k]]
     while k < len(ch):
@@ -75,7 +95,7 @@ for seed in range(first, first + count):
         else:
             assert dict(_ordered(eng.patch_json()))["diffs"] == dict(_ordered(session.patch_json()))["diffs"], f"seed {seed} ({kind}) final getPatch"
             doc = bytes(eng.save())
-            if not perturbed:   # (a document holds its changes in application order: the generator's order only when delivered in it)
+            if not perturbed and log is not None:   # (a document holds its changes in application order: the generator's order only when delivered in it)
                 bulk = engine.Engine(0, LIB) if LIB else engine.Engine(0)
                 bulk.load_changes(log)
                 bulk.replay()
@@ -87,6 +107,7 @@ for seed in range(first, first + count):
                 back.close()
         s, f, p = eng.resident_counters()
         totals["served"] += s; totals["fell_back"] += f; totals["in_place"] += p
+        totals["maps_only"] += eng.resident_maps_only_calls()
         totals["sessions"] += 1
     finally:
         eng.close()
