@@ -1445,6 +1445,7 @@ static int replay_resident(am355_ctx* c) {
       c->ir_stale = true;
       c->ir_fetched = false;
       c->n_maps_only_calls++;
+      c->pos_valid = true;   // (the positions this call read or rebuilt: the order did not change)
       maps_only = true;
     } else {
       c->pos_valid = false;

@@ -24,6 +24,13 @@ timeout 300 python tools/time_apply.py > gpurun_out/$TAG/apply_changes_timings.j
   timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/prof_apply40 -o run -- python tools/profile_apply_seq.py c4_text_single 1.0 40 8 > gpurun_out/$TAG/prof_apply40.log 2>&1
   python tools/rocpd_timeline.py $(find gpurun_out/$TAG/prof_apply40 -name "*.db" | head -1) -3 k_decode > gpurun_out/$TAG/apply40_timeline.txt 2>&1
   rm -rf gpurun_out/$TAG/prof_apply40 )
+{
+echo "== 1 map change (8 keys) per call onto the 1 M-op text + map document (tools/profile_apply_mixed.py)"; timeout 200 python tools/profile_apply_mixed.py 1.0 1 40
+echo "   the whole merge per call (AM355_NO_MAPS_ONLY=1):"; AM355_NO_MAPS_ONLY=1 timeout 200 python tools/profile_apply_mixed.py 1.0 1 40
+echo "   full replay per call (AM355_NO_RESIDENT=1):"; AM355_NO_RESIDENT=1 timeout 200 python tools/profile_apply_mixed.py 1.0 1 40
+echo "== 8 map changes per call"; timeout 200 python tools/profile_apply_mixed.py 1.0 8 20
+echo "   the whole merge per call (AM355_NO_MAPS_ONLY=1):"; AM355_NO_MAPS_ONLY=1 timeout 200 python tools/profile_apply_mixed.py 1.0 8 20
+} > gpurun_out/$TAG/apply_mixed_timings.txt 2>&1
 timeout 200 python tools/time_history.py > gpurun_out/$TAG/history_trace.txt 2>&1
 ls gpurun_out/$TAG
 cat gpurun_out/$TAG/bench_line.json; echo
