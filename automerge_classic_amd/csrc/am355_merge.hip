@@ -1827,8 +1827,14 @@ void merge_run_maps(MergeBufs& b, PatchIR& ir, Counts* hc, hipStream_t st) {
   else { (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st); }
   if (hc->flags) { (void)hipStreamSynchronize(st); return; }
   order_map_emissions(b, ir, hc, st, nullptr, b.sig ? &key_stats : nullptr);
-  (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
+  // (the counters behind the map order through the pinned words: a copy + blocking wait is an interrupt wake-up of 20-30 us)
+  if (b.sig) {
+    launch_signal_words((const uint32_t*)b.counts, (uint32_t)(sizeof(Counts) / 4), nullptr, 0, b.sig->final_counts, &b.sig->final_seq, b.sig_seq, st);
+    read_phase_counts(b, &b.sig->final_seq, b.sig->final_counts, hc, st);
+  } else {
+    (void)hipMemcpyAsync(hc, b.counts, sizeof(Counts), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+  }
   if (hc->map_group_big) {
     (void)hipMemsetAsync(&b.counts->map_group_big, 0, sizeof(uint32_t), st);
     order_map_emissions(b, ir, hc, st, nullptr, b.sig ? &key_stats : nullptr, true);
