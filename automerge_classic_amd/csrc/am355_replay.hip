@@ -1359,6 +1359,7 @@ static int replay_resident(am355_ctx* c) {
     ro.pos_of = c->d_pos.as<uint32_t>();
     ro.order_new = c->order_alt_ptr;
     ro.sig = b.sig; ro.sig_seq = b.sig_seq;
+    ro.allow_maps = getenv("AM355_NO_MAPS_ONLY") ? 0u : 1u;   // (tests, A/B: read per call)
   }
   c->resident_valid = false;   // (from here on the kept arrays change: a failure leaves no state behind)
   { int frc = flush_uploads(c); if (frc) return frc; }   // (the batch's bytes, its records, the tables, the delta stage's breaks: one launch; its hashes follow)
@@ -1433,6 +1434,19 @@ static int replay_resident(am355_ctx* c) {
       c->batch_list_only = true;
       merged_in_place = true;
       lap("list order merged in place");
+      if (hw[4]) {
+        // plain map rows beside the list edits (text typed and a key assigned in one change): the map half of the merge behind the
+        // in-place list merge -- the map records and the object table's map ranges change, the delta stage runs its map kernels
+        merge_run_maps(b, c->ir, hc, st);
+        lap("map half of the merge done");
+        if (hc->flags) return error_for_flags(c, hc->flags, "op set rejected");
+        c->counts.n_map_emit = hc->n_map_emit;
+        c->counts.max_key_len = hc->max_key_len;
+        c->h_tables_current = false;
+        c->ir_copy_enqueued = 0;
+        c->batch_list_only = false;
+        c->n_maps_only_calls++;
+      }
     } else if (hw[3] == 0 && !getenv("AM355_NO_MAPS_ONLY")) {
       // a batch of plain map rows (`set` / `del` on string keys): no list changes -- the stored order, positions and element counts stay,
       // the map half of the merge runs alone (visibility, object table, map records in patch order); the whole-document edit tables are

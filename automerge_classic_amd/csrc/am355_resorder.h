@@ -13,6 +13,7 @@ struct ResOrderBufs {
   uint32_t T0, n_new;        // the batch's rows: [T0, T0 + n_new) (resorder_run: of the chunk it is launching)
   uint32_t n_list;           // elements in b.order before the call (the kernels read the running count, words[2])
   uint32_t chunk;            // 0 .. chunks - 1 (resorder_run)
+  uint32_t allow_maps;       // plain map rows among the batch's rows do not refuse it (the caller runs the map half of the merge behind the list merge)
   uint32_t n_obj;            // objects including _root (obj_n / obj_first_pos hold n_obj + 1 entries)
   uint32_t* pos_of;          // [row capacity] position of every element row in b.order (kept between calls)
   uint32_t* order_new;       // [row capacity + 2] the order after the call (the caller swaps it with b.order)
@@ -23,7 +24,7 @@ struct ResOrderBufs {
   uint32_t* obj_add;         // [n_obj + 1] new elements per object (cleared by the caller)
   uint32_t* words;           // [8] (cleared by the caller): [0] != 0: not served here (the caller orders all lists anew), [1] new
                              // elements of the last chunk, [2] elements in front of them: the order holds [1] + [2] after the call;
-                             // [3] != 0: some row of the batch is not a plain map row (kr_gaps)
+                             // [3] != 0: some row of the batch is not a plain map row, [4] != 0: some row is one (kr_gaps)
   HostSignals* sig;          // the words + Counts.flags for the host through pinned memory (HostSignals.resorder), nullptr: the caller copies them
   uint32_t sig_seq;
 };

@@ -60,13 +60,17 @@ __global__ __launch_bounds__(WAVE) void kr_gaps(MergeBufs b, ResOrderBufs r) {
   const uint32_t a = o.action[g];
   // words[3]: some row of the batch is not a plain map row (`set` of a value / `del` on a string key). A batch of such rows only leaves
   // every list as it is: the caller then runs the map half of the merge alone (merge_run_maps). Every chunk's rows are looked at.
-  if (lane == 0 && !((kind == K_MAP && a == 1) || (kind == K_DEL && o.key_len[g] != NONE32))) r.words[3] = 1;
+  // words[4]: some row IS a plain map row: it takes no part in the list order (a row like a deletion here), and the caller runs the map
+  // half of the merge behind the in-place list merge.
+  const bool plain_map = (kind == K_MAP && a == 1) || (kind == K_DEL && o.key_len[g] != NONE32);
+  if (lane == 0) r.words[plain_map ? 4 : 3] = 1;
   // (a chunk behind one that was refused: the order it would scan was never written)
   if (r.chunk && r.words[0]) return;
   uint32_t gap = NONE32;
   bool refuse = false;
   const bool list_del = kind == K_DEL && o.key_len[g] == NONE32;
-  if (!(kind == K_LIST_INS || kind == K_LIST_UPD || list_del)) refuse = true;   // map rows, foreign rows, rows k_resolve left without a kind
+  if (plain_map && r.allow_maps) {}
+  else if (!(kind == K_LIST_INS || kind == K_LIST_UPD || list_del)) refuse = true;   // other map rows (objects made, increments), foreign rows, rows k_resolve left without a kind
   else if (kind != K_DEL && a != 1) refuse = true;                               // child objects (the object table grows), increments, links
   else if (kind == K_LIST_INS) {
     const uint32_t parent = b.ref_row[g];
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(RO_THREADS) void kr_order(MergeBufs b, ResOrderBufs
   }
   for (uint32_t t = t0; t < n; t += RO_THREADS) s_kid[t] = 0xffff;
   __syncthreads();
-  if (r.words[0] || n > RESORDER_ROWS_MAX) { if (t0 == 0) r.words[0] = 1; return; }
+  // (no row so far that is not a plain map row: nothing to merge -- left to the caller's map path, which runs no list kernel at all)
+  if (r.words[0] || n > RESORDER_ROWS_MAX || r.words[3] == 0) { if (t0 == 0) r.words[0] = 1; return; }
   // ---- parents within the batch (kr_gaps), roots. A new element with two new children is not a run: both write their index at the
   //      parent and one of them does not find it there (plain stores -- atomics on a bit per row were 32 lanes on one word) ----
   uint16_t par[RO_PER];

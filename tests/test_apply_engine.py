@@ -345,7 +345,8 @@ def mixed_document_batches(seed, text_kw, map_kw, held_text):
 
 def test_resident_map_batches_leave_the_lists_alone_emulated(emu_lib, monkeypatch):
     """A batch of plain map rows onto a kept state (replay_resident, merge_run_maps): the map half of the merge alone -- no list kernel
-    runs, the stored order stays --, in turn with list-only batches merged in place and mixed batches that take the whole merge. Every
+    runs, the stored order stays --, in turn with list-only batches merged in place and batches of both (list rows merged in place, then
+    the map half; with the path switched off: the whole merge). Every
     incremental patch, getPatch in between and at the end (which rebuilds the stale edit tables and, AM355_RESORDER_VERIFY, compares the
     order) equal the oracle session's; and the same calls with the path switched off."""
     monkeypatch.setenv("AM355_RESORDER_VERIFY", "1")

@@ -1,6 +1,7 @@
 """Map changes onto a document that also holds a large Text (am355_apply_changes onto a kept state): the headline text log + a map log side by
 side (two sets of actors); the base holds the whole text log and the map log's first round, then `calls` calls of `per` map changes each.
-  python tools/profile_apply_mixed.py [text scale = 1.0] [per = 1] [calls = 40]      AM355_NO_MAPS_ONLY=1: the whole merge per call"""
+  python tools/profile_apply_mixed.py [text scale = 1.0] [per = 1] [calls = 40] [both]     AM355_NO_MAPS_ONLY=1: the whole merge per call
+  both: every call also holds one change of the text log (held back from the base): list rows and map rows in one batch"""
 import os
 import sys
 import time
@@ -23,10 +24,12 @@ NA = 8
 text = changes_of(loggen.config("c4_text_single", scale))
 maps = changes_of(loggen.generate(loggen.KIND_MAP_LWW, n_actors=NA, n_rounds=2 + (per * calls + NA - 1) // NA, n_keys=64, seed=4242))
 eng = engine.Engine(0, os.environ["AM355_TOOL_LIB"]) if os.environ.get("AM355_TOOL_LIB") else engine.Engine(0)
-eng.apply_changes(ChangeLog.from_changes(text + maps[:NA]))
+both = len(sys.argv) > 4 and sys.argv[4] == "both"
+held = calls if both else 0
+eng.apply_changes(ChangeLog.from_changes(text[:len(text) - held] + maps[:NA]))
 times = []
 for j in range(calls):
-    b = ChangeLog.from_changes(maps[NA + j * per:NA + (j + 1) * per])
+    b = ChangeLog.from_changes(([text[len(text) - held + j]] if both else []) + maps[NA + j * per:NA + (j + 1) * per])
     t0 = time.perf_counter()
     eng.apply_changes(b)
     times.append((time.perf_counter() - t0) * 1e3)

@@ -28,6 +28,9 @@ timeout 300 python tools/time_apply.py > gpurun_out/$TAG/apply_changes_timings.j
 echo "== 1 map change (8 keys) per call onto the 1 M-op text + map document (tools/profile_apply_mixed.py)"; timeout 200 python tools/profile_apply_mixed.py 1.0 1 40
 echo "   the whole merge per call (AM355_NO_MAPS_ONLY=1):"; AM355_NO_MAPS_ONLY=1 timeout 200 python tools/profile_apply_mixed.py 1.0 1 40
 echo "   full replay per call (AM355_NO_RESIDENT=1):"; AM355_NO_RESIDENT=1 timeout 200 python tools/profile_apply_mixed.py 1.0 1 40
+echo "== 1 text change (250 ops) + 1 map change per call: list rows merged in place, then the map half"; timeout 200 python tools/profile_apply_mixed.py 1.0 1 40 both
+echo "   the whole merge per call (AM355_NO_MAPS_ONLY=1):"; AM355_NO_MAPS_ONLY=1 timeout 200 python tools/profile_apply_mixed.py 1.0 1 40 both
+echo "   full replay per call (AM355_NO_RESIDENT=1):"; AM355_NO_RESIDENT=1 timeout 200 python tools/profile_apply_mixed.py 1.0 1 40 both
 echo "== 8 map changes per call"; timeout 200 python tools/profile_apply_mixed.py 1.0 8 20
 echo "   the whole merge per call (AM355_NO_MAPS_ONLY=1):"; AM355_NO_MAPS_ONLY=1 timeout 200 python tools/profile_apply_mixed.py 1.0 8 20
 } > gpurun_out/$TAG/apply_mixed_timings.txt 2>&1
