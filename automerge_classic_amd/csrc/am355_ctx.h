@@ -505,7 +505,7 @@ struct am355_ctx {
   bool pos_valid = false;                          // d_pos describes c->mb.order
   bool ir_stale = false;                           // rows / order are current, the whole-document patch tables are not
   uint64_t n_resorder_calls = 0;
-  uint64_t n_maps_only_calls = 0;   // resident calls whose batch held plain map rows only: merge_run_maps, no list kernel
+  uint64_t n_maps_only_calls = 0;   // resident calls that ran merge_run_maps: plain map rows only, or beside list edits merged in place
   HostBuf h_res_metas;                             // pinned: the batch's ChangeMetas on their way to the host
   uint32_t res_dep_base = 0;                       // changes >= this were applied by resident calls: their dependency indexes live in ...
   std::vector<uint32_t> res_dep_first, res_dep_index;   // ... CSR over (change - res_dep_base)

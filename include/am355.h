@@ -349,8 +349,8 @@ int am355_shard_finalize(am355_ctx *ctx);
  * many took the full replay although they asked for it (out[1]: new actor, dependency not applied yet, duplicate, capacity ...), and
  * how many of the first kind also merged their new list elements into the stored document order in place (out[2]) */
 int am355_resident_counters(const am355_ctx *ctx, uint64_t out[3]);
-/* ... and how many of the first kind were batches of plain map rows (`set` / `del` on string keys), for which the map half of the merge
- * ran alone and every list stayed as it was (*out) */
+/* ... and for how many of the first kind the map half of the merge ran on its own: batches of plain map rows only (`set` / `del` on
+ * string keys: every list stayed as it was) and batches of such rows beside list edits (the list rows merged in place first) (*out) */
 int am355_resident_maps_only_calls(const am355_ctx *ctx, uint64_t *out);
 
 /* For bindings that mirror per-state tables of the context in their own memory (the N-API addon: BackendDoc.changes, their hashes and
