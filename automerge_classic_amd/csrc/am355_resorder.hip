@@ -11,6 +11,9 @@
 //     position of the next: the object in front first);
 //   * reference element new: x follows it directly when it is its only new child (a typing run: the shape of nearly every batch).
 //     A new element with two new children is left to the full ordering (flag), as is everything that is not a plain list edit.
+// Plain map rows among the batch's rows (`set` / `del` on string keys) take no part in any of this: they stand like deletions here, and
+// the caller runs the map half of the merge behind the list merge (words[3] / words[4]; a batch of map rows only is left to that half
+// alone, replay_resident / merge_run_maps).
 // The order after the batch is then a MERGE: an old element at position p moves up by the number of new elements with gap <= p, the
 // k-th new element (by gap, root id descending, depth in its run) lands at gap + k.
 #include "am355_resorder.h"
