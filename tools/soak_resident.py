@@ -19,11 +19,17 @@ from test_apply_vectors import same_patch  # noqa: E402
 
 LIB = os.environ.get("AM355_TOOL_LIB")
 first, count = int(sys.argv[1]), int(sys.argv[2])
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"   # long concurrent-text logs delivered in batches of up to 144 changes: several chunks of the in-place merge, tens of thousands of edit items
 totals = {"sessions": 0, "calls": 0, "served": 0, "fell_back": 0, "in_place": 0, "maps_only": 0, "refused": 0}
 for seed in range(first, first + count):
     rnd = random.Random(seed)
     kind = rnd.choice(["typing", "concurrent", "concurrent", "concurrent_small", "map", "mixed", "mixed"])
-    if kind == "typing":
+    if BIG:
+        kind = "big"
+    if kind == "big":
+        log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=rnd.randint(8, 24), n_rounds=rnd.randint(6, 14), ins_per_change=rnd.randint(40, 320),
+                              del_per_change=rnd.randint(0, 60), n_objects=rnd.randint(1, 3), seed=seed)
+    elif kind == "typing":
         log = loggen.generate(loggen.KIND_TEXT_TYPING, n_ops=rnd.randint(200, 3000), ops_per_change=rnd.randint(1, 60), seed=seed)
     elif kind == "concurrent":
         log = loggen.generate(loggen.KIND_TEXT_CONCURRENT, n_actors=rnd.randint(2, 12), n_rounds=rnd.randint(3, 8), ins_per_change=rnd.randint(5, 120),
@@ -42,7 +48,7 @@ for seed in range(first, first + count):
         log = loggen.generate(loggen.KIND_MAP_LWW, n_actors=rnd.randint(2, 6), n_rounds=rnd.randint(3, 8), n_keys=rnd.randint(5, 60), seed=seed)
     os.environ.pop("AM355_RESORDER_CHUNK", None)
     if rnd.random() < 0.4:
-        os.environ["AM355_RESORDER_CHUNK"] = str(rnd.choice([3, 7, 50, 400]))
+        os.environ["AM355_RESORDER_CHUNK"] = str(rnd.choice([3, 7, 50, 400]) if not BIG else rnd.choice([700, 2000, 5000]))
     def changes_of(lg):
         arena, offs = bytes(lg.arena), [int(x) for x in lg.offsets]
         return [arena[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
@@ -61,7 +67,7 @@ for seed in range(first, first + count):
     k = max(1, rnd.randint(1, max(1, len(ch) // 2)))
     batches = [ch[:k]]
     while k < len(ch):
-        size = rnd.choice([1, 1, 1, 2, 3, 5, 8, 13, 40])
+        size = rnd.choice([1, 1, 1, 2, 3, 5, 8, 13, 40]) if not BIG else rnd.choice([1, 7, 25, 40, 64, 96, 120, 144])
         batches.append(ch[k:k + size])
         k += size
     # deliveries the resident path must hand to the full replay AFTER it has enqueued the batch's device work (the hash-dependent checks run
